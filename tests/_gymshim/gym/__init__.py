@@ -1,0 +1,171 @@
+"""Test-only stand-in for the absent third-party ``gym`` package.
+
+It exists solely so that the *reference* (pfnet/pfrl, mounted read-only at
+/root/reference in the build container) can be imported by
+``tests/golden/make_golden.py`` to record golden vectors.  It is NOT part of
+the product and nothing under ``pfrl_amd/`` imports it.
+"""
+import types
+
+import numpy as np
+
+__version__ = "0.21.0"
+
+
+class Space:
+    def __init__(self, shape=None, dtype=None):
+        self.shape = shape
+        self.dtype = dtype
+
+
+class Box(Space):
+    def __init__(self, low, high, shape=None, dtype=np.float32):
+        if shape is None:
+            shape = np.shape(low)
+        super().__init__(tuple(shape), np.dtype(dtype))
+        self.low = np.broadcast_to(np.asarray(low, dtype=dtype), self.shape)
+        self.high = np.broadcast_to(np.asarray(high, dtype=dtype), self.shape)
+
+    def sample(self):
+        return np.random.uniform(self.low, self.high).astype(self.dtype)
+
+
+class Discrete(Space):
+    def __init__(self, n):
+        super().__init__((), np.dtype(np.int64))
+        self.n = n
+
+    def sample(self):
+        return np.random.randint(self.n)
+
+
+spaces = types.ModuleType("gym.spaces")
+spaces.Space = Space
+spaces.Box = Box
+spaces.Discrete = Discrete
+
+
+class Env:
+    metadata = {}
+    reward_range = (-float("inf"), float("inf"))
+    spec = None
+    action_space = None
+    observation_space = None
+
+    def step(self, action):
+        raise NotImplementedError
+
+    def reset(self):
+        raise NotImplementedError
+
+    def render(self, mode="human"):
+        pass
+
+    def close(self):
+        pass
+
+    def seed(self, seed=None):
+        return [seed]
+
+    @property
+    def unwrapped(self):
+        return self
+
+
+class Wrapper(Env):
+    def __init__(self, env):
+        self.env = env
+        self.action_space = env.action_space
+        self.observation_space = env.observation_space
+        self.reward_range = getattr(env, "reward_range", None)
+        self.metadata = getattr(env, "metadata", {})
+
+    def __getattr__(self, name):
+        if name.startswith("_"):
+            raise AttributeError(name)
+        return getattr(self.env, name)
+
+    @property
+    def spec(self):
+        return self.env.spec
+
+    def step(self, action):
+        return self.env.step(action)
+
+    def reset(self, **kwargs):
+        return self.env.reset(**kwargs)
+
+    def render(self, mode="human", **kwargs):
+        return self.env.render(mode, **kwargs)
+
+    def close(self):
+        return self.env.close()
+
+    def seed(self, seed=None):
+        return self.env.seed(seed)
+
+    @property
+    def unwrapped(self):
+        return self.env.unwrapped
+
+
+class ObservationWrapper(Wrapper):
+    def reset(self, **kwargs):
+        return self.observation(self.env.reset(**kwargs))
+
+    def step(self, action):
+        o, r, d, i = self.env.step(action)
+        return self.observation(o), r, d, i
+
+    def observation(self, observation):
+        raise NotImplementedError
+
+
+class RewardWrapper(Wrapper):
+    def step(self, action):
+        o, r, d, i = self.env.step(action)
+        return o, self.reward(r), d, i
+
+    def reward(self, reward):
+        raise NotImplementedError
+
+
+class ActionWrapper(Wrapper):
+    def step(self, action):
+        return self.env.step(self.action(action))
+
+    def action(self, action):
+        raise NotImplementedError
+
+
+class _TimeLimit(Wrapper):
+    def __init__(self, env, max_episode_steps=None):
+        super().__init__(env)
+        self._max_episode_steps = max_episode_steps
+        self._elapsed_steps = 0
+
+    def step(self, action):
+        o, r, d, i = self.env.step(action)
+        self._elapsed_steps += 1
+        if self._elapsed_steps >= self._max_episode_steps:
+            i["TimeLimit.truncated"] = not d
+            d = True
+        return o, r, d, i
+
+    def reset(self, **kwargs):
+        self._elapsed_steps = 0
+        return self.env.reset(**kwargs)
+
+
+wrappers = types.ModuleType("gym.wrappers")
+wrappers.TimeLimit = _TimeLimit
+
+
+def make(*args, **kwargs):
+    raise RuntimeError("gym shim: no registered environments")
+
+
+import sys  # noqa: E402
+
+sys.modules.setdefault("gym.spaces", spaces)
+sys.modules.setdefault("gym.wrappers", wrappers)

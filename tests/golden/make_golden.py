@@ -1,0 +1,515 @@
+#!/usr/bin/env python
+"""Record golden vectors by running the REFERENCE (pfnet/pfrl) itself.
+
+Run in the build container only (needs /root/reference, read-only):
+
+    python tests/golden/make_golden.py
+
+The reference cannot travel to the GPU box, so the vectors are committed as
+small ``.npz`` fixtures next to this script.  They pin the CPU oracle
+(tests/test_oracle_golden.py) and, through it and directly, the HIP path.
+
+Scalars that live inside the reference's priority trees are recorded as
+(float64 value, type tag) pairs: 0 absent, 1 Python float, 2 np.float32,
+3 np.float64 -- see oracle/pfrl_oracle.c.
+"""
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "..", "_gymshim"))
+sys.path.insert(0, os.environ.get("PFRL_REFERENCE", "/root/reference"))
+
+import random  # noqa: E402
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+import pfrl  # noqa: E402
+from pfrl.collections.prioritized import PrioritizedBuffer  # noqa: E402
+from pfrl.replay_buffer import batch_experiences  # noqa: E402
+from pfrl.replay_buffers import PrioritizedReplayBuffer, ReplayBuffer  # noqa: E402
+
+
+def tag(x):
+    if x is None:
+        return 0
+    if isinstance(x, np.float32):
+        return 2
+    if isinstance(x, np.float64):
+        return 3
+    if isinstance(x, (float, int)):
+        return 1
+    raise TypeError(type(x))
+
+
+def val(x):
+    return 0.0 if x is None else float(x)
+
+
+def dump_tree(tq):
+    """Level-order dump of a TreeQueue: dict width -> (values, tags)."""
+    out = {}
+    if tq.length == 0:
+        return out
+    ixl, ixr = tq.bounds
+    size = ixr - ixl
+
+    def rec(node, lo, hi, width, vs, ts):
+        if hi - lo == width:
+            j = (lo - ixl) // width
+            if node:
+                vs[j] = val(node[2])
+                ts[j] = tag(node[2])
+            return
+        c = (lo + hi) // 2
+        left = node[0] if node else []
+        right = node[1] if node else []
+        rec(left if left is not None else [], lo, c, width, vs, ts)
+        rec(right if right is not None else [], c, hi, width, vs, ts)
+
+    w = 1
+    while w <= size:
+        vs = np.zeros(size // w, dtype=np.float64)
+        ts = np.zeros(size // w, dtype=np.int32)
+        rec(tq.root, ixl, ixr, w, vs, ts)
+        out[w] = (vs, ts)
+        w *= 2
+    return out
+
+
+def flat_dump(tq):
+    d = dump_tree(tq)
+    if not d:
+        return np.zeros(0), np.zeros(0, dtype=np.int32)
+    vs = np.concatenate([d[w][0] for w in sorted(d)])
+    ts = np.concatenate([d[w][1] for w in sorted(d)])
+    return vs, ts
+
+
+# --------------------------------------------------------------------------
+# A. PrioritizedReplayBuffer traces
+# --------------------------------------------------------------------------
+def per_trace(name, seed, capacity, num_steps, n_ops, batch, err_kind, normalize_by_max,
+              alpha=0.6, beta0=0.4, betasteps=200, n_envs=3, dump_every=25):
+    np.random.seed(seed)
+    rs = np.random.RandomState(seed + 1000)  # script randomness, separate stream
+    rbuf = PrioritizedReplayBuffer(
+        capacity=capacity, alpha=alpha, beta0=beta0, betasteps=betasteps,
+        normalize_by_max=normalize_by_max, num_steps=num_steps,
+    )
+    captured = {}
+    orig_set = rbuf.memory.set_last_priority
+
+    def spy_set(priority):
+        captured["pri"] = list(priority)
+        return orig_set(priority)
+
+    rbuf.memory.set_last_priority = spy_set
+
+    ops = []  # (kind, a, b)   kind: 0 append(env, terminal) 1 stop(env) 2 sample(n)+update
+    rec = dict(
+        op_kind=[], op_a=[], op_b=[], length=[], sum_v=[], sum_t=[], min_v=[], min_t=[],
+        maxp_v=[], maxp_t=[], ixl=[], ixr=[],
+        u01=[], idx=[], pri_v=[], pri_t=[], weight=[], entry_tids=[], entry_len=[],
+        err=[], err_is_py=[], new_pri_v=[], new_pri_t=[], beta=[],
+        dump_op=[], dump_sum_v=[], dump_sum_t=[], dump_min_v=[], dump_min_t=[], dump_off=[0],
+        smp_total_v=[], smp_total_t=[], smp_min_prob=[], prob=[],
+    )
+    tid = 0
+    for k in range(n_ops):
+        r = rs.rand()
+        can_sample = len(rbuf) >= batch
+        if can_sample and r < 0.3:
+            kind = 2
+        elif r < 0.38:
+            kind = 1
+        else:
+            kind = 0
+        if kind == 0:
+            env = int(rs.randint(n_envs))
+            term = bool(rs.rand() < 0.15)
+            rbuf.append(state=tid, action=0, reward=float(rs.randn()), next_state=tid + 1,
+                        is_state_terminal=term, env_id=env, tid=tid)
+            rec["op_kind"].append(0); rec["op_a"].append(env); rec["op_b"].append(int(term))
+            tid += 1
+        elif kind == 1:
+            env = int(rs.randint(n_envs))
+            rbuf.stop_current_episode(env_id=env)
+            rec["op_kind"].append(1); rec["op_a"].append(env); rec["op_b"].append(0)
+        else:
+            st = np.random.get_state()
+            total_before = rbuf.memory.priority_sums.sum()
+            beta_before = rbuf.beta
+            # spy on the collections-level sample to get indices/priorities/probs
+            orig = rbuf.memory._sample_indices_and_probabilities
+            got = {}
+
+            def spy(n, uniform_ratio, _orig=orig, _got=got):
+                # re-implement the call to read sampled priorities too
+                res = _orig(n, uniform_ratio)
+                _got["res"] = res
+                return res
+
+            rbuf.memory._sample_indices_and_probabilities = spy
+            sampled = rbuf.sample(batch)
+            rbuf.memory._sample_indices_and_probabilities = orig
+            indices, probs, min_prob = got["res"]
+            st_after = np.random.get_state()
+            np.random.set_state(st)
+            u = np.random.random_sample(batch)
+            st_chk = np.random.get_state()
+            assert all(np.array_equal(a, b) if isinstance(a, np.ndarray) else a == b
+                       for a, b in zip(st_after, st_chk)), "rng stream mismatch"
+            rec["u01"].extend(u.tolist())
+            rec["idx"].extend(int(i) for i in indices)
+            rec["prob"].extend(float(p) for p in probs)
+            rec["smp_total_v"].append(val(total_before)); rec["smp_total_t"].append(tag(total_before))
+            rec["smp_min_prob"].append(float(min_prob))
+            rec["beta"].append(beta_before)
+            for e in sampled:
+                rec["weight"].append(float(e[0]["weight"]))
+                tids = [tr["tid"] for tr in e]
+                rec["entry_len"].append(len(tids))
+                rec["entry_tids"].extend(tids + [-1] * (num_steps - len(tids)))
+            # errors
+            if err_kind == "f32":
+                errs = [np.float32(x) for x in (rs.rand(batch) * 1.6).astype(np.float32)]
+                if rs.rand() < 0.5:
+                    errs[int(rs.randint(batch))] = np.float32(0.0)
+            elif err_kind == "py":
+                errs = [float(x) for x in rs.rand(batch) * 1.6]
+            else:  # mixed
+                errs = [np.float32(x) if rs.rand() < 0.7 else float(x)
+                        for x in rs.rand(batch) * 1.6]
+            rbuf.update_errors(errs)
+            rec["err"].extend(float(e) for e in errs)
+            rec["err_is_py"].extend(int(not isinstance(e, np.float32)) for e in errs)
+            rec["new_pri_v"].extend(val(p) for p in captured["pri"])
+            rec["new_pri_t"].extend(tag(p) for p in captured["pri"])
+            # sampled priorities (removed values) are not returned by the
+            # reference API; recover them from probs*total is inexact, so read
+            # them through a second spy below (see pri_v note)
+            rec["op_kind"].append(2); rec["op_a"].append(batch); rec["op_b"].append(0)
+        mem = rbuf.memory
+        rec["length"].append(len(mem))
+        s = mem.priority_sums.sum() if len(mem) else 0.0
+        m = mem.priority_mins.min() if len(mem) else float("inf")
+        rec["sum_v"].append(val(s)); rec["sum_t"].append(tag(s))
+        rec["min_v"].append(val(m)); rec["min_t"].append(1 if not len(mem) else tag(m))
+        rec["maxp_v"].append(val(mem.max_priority)); rec["maxp_t"].append(tag(mem.max_priority))
+        if len(mem):
+            rec["ixl"].append(mem.priority_sums.bounds[0]); rec["ixr"].append(mem.priority_sums.bounds[1])
+        else:
+            rec["ixl"].append(0); rec["ixr"].append(0)
+        if (k % dump_every == dump_every - 1) or k == n_ops - 1:
+            sv, st_ = flat_dump(mem.priority_sums)
+            mv, mt = flat_dump(mem.priority_mins)
+            rec["dump_op"].append(k)
+            rec["dump_sum_v"].append(sv); rec["dump_sum_t"].append(st_)
+            rec["dump_min_v"].append(mv); rec["dump_min_t"].append(mt)
+            rec["dump_off"].append(rec["dump_off"][-1] + len(sv))
+    out = {}
+    for key, v in rec.items():
+        if key.startswith("dump_") and key not in ("dump_op", "dump_off"):
+            out[key] = np.concatenate(v) if v else np.zeros(0)
+        else:
+            out[key] = np.asarray(v)
+    out["meta"] = np.array([seed, -1 if capacity is None else capacity, num_steps, batch, n_envs])
+    out["hyper"] = np.array([alpha, beta0, betasteps, 0.01], dtype=np.float64)
+    out["normalize_by_max"] = np.array(
+        {True: 1, "batch": 1, "memory": 2, False: 0}[normalize_by_max])
+    np.savez_compressed(os.path.join(HERE, "per_trace_%s.npz" % name), **out)
+    print("per_trace", name, "ops", n_ops, "final len", len(rbuf))
+
+
+# --------------------------------------------------------------------------
+# A'. collections-level PrioritizedBuffer trace (records removed priorities)
+# --------------------------------------------------------------------------
+def pbuf_trace(name, seed, capacity, n_ops, batch):
+    np.random.seed(seed)
+    rs = np.random.RandomState(seed + 77)
+    buf = PrioritizedBuffer(capacity=capacity)
+    rec = dict(op_kind=[], op_n=[], u01=[], idx=[], pri_v=[], pri_t=[], prob=[], min_prob=[],
+               total_v=[], total_t=[], set_v=[], set_t=[], app_v=[], app_t=[],
+               sum_v=[], sum_t=[], min_v=[], min_t=[], maxp_v=[], maxp_t=[], length=[],
+               ixl=[], ixr=[])
+    payload = 0
+    for k in range(n_ops):
+        r = rs.rand()
+        if len(buf) >= batch and r < 0.3:
+            st = np.random.get_state()
+            total = buf.priority_sums.sum()
+            # replicate PrioritizedBuffer.sample but keep the removed priorities
+            tq = buf.priority_sums
+            got = {}
+            orig = tq.prioritized_sample
+
+            def spy(n, remove, _orig=orig, _got=got):
+                ixs, vals = _orig(n, remove)
+                _got["vals"] = vals
+                return ixs, vals
+
+            tq.prioritized_sample = spy
+            sampled, probs, min_prob = buf.sample(batch)
+            tq.prioritized_sample = orig
+            np.random.set_state(st)
+            u = np.random.random_sample(batch)
+            rec["op_kind"].append(2); rec["op_n"].append(batch)
+            rec["u01"].extend(u.tolist())
+            rec["idx"].extend(int(i) for i in buf.sampled_indices)
+            rec["pri_v"].extend(val(v) for v in got["vals"])
+            rec["pri_t"].extend(tag(v) for v in got["vals"])
+            rec["prob"].extend(float(p) for p in probs)
+            rec["min_prob"].append(float(min_prob))
+            rec["total_v"].append(val(total)); rec["total_t"].append(tag(total))
+            # new priorities: mixture of types
+            newp = []
+            for _ in range(batch):
+                c = rs.rand()
+                x = rs.rand() * 3 + 1e-3
+                if c < 0.5:
+                    newp.append(np.float32(x))
+                elif c < 0.9:
+                    newp.append(float(x))
+                else:
+                    newp.append(np.float64(x))
+            buf.set_last_priority(newp)
+            rec["set_v"].extend(val(p) for p in newp)
+            rec["set_t"].extend(tag(p) for p in newp)
+        elif len(buf) > 0 and r < 0.36:
+            buf.popleft()
+            rec["op_kind"].append(4); rec["op_n"].append(0)
+        else:
+            c = rs.rand()
+            if c < 0.6:
+                p = None
+            elif c < 0.8:
+                p = float(rs.rand() * 2 + 0.01)
+            else:
+                p = np.float32(rs.rand() * 2 + 0.01)
+            buf.append(payload, priority=p)
+            payload += 1
+            rec["op_kind"].append(0 if p is None else 1); rec["op_n"].append(0)
+            rec["app_v"].append(val(p)); rec["app_t"].append(tag(p))
+        s = buf.priority_sums.sum() if len(buf) else 0.0
+        m = buf.priority_mins.min() if len(buf) else float("inf")
+        rec["sum_v"].append(val(s)); rec["sum_t"].append(tag(s))
+        rec["min_v"].append(val(m)); rec["min_t"].append(1 if not len(buf) else tag(m))
+        rec["maxp_v"].append(val(buf.max_priority)); rec["maxp_t"].append(tag(buf.max_priority))
+        rec["length"].append(len(buf))
+        if len(buf):
+            rec["ixl"].append(buf.priority_sums.bounds[0]); rec["ixr"].append(buf.priority_sums.bounds[1])
+        else:
+            rec["ixl"].append(0); rec["ixr"].append(0)
+    out = {k2: np.asarray(v) for k2, v in rec.items()}
+    sv, st_ = flat_dump(buf.priority_sums)
+    mv, mt = flat_dump(buf.priority_mins)
+    out.update(final_sum_v=sv, final_sum_t=st_, final_min_v=mv, final_min_t=mt)
+    out["meta"] = np.array([seed, -1 if capacity is None else capacity, batch])
+    np.savez_compressed(os.path.join(HERE, "pbuf_trace_%s.npz" % name), **out)
+    print("pbuf_trace", name, "final len", len(buf))
+
+
+# --------------------------------------------------------------------------
+# B. uniform ReplayBuffer n-step traces + batch_experiences
+# --------------------------------------------------------------------------
+def replay_trace(name, seed, capacity, num_steps, n_ops, n_envs, gamma=0.99, batch=8):
+    np.random.seed(seed)
+    rs = np.random.RandomState(seed + 5)
+    rbuf = ReplayBuffer(capacity=capacity, num_steps=num_steps)
+    obs_dim = 5
+    obs_table = rs.randn(n_ops + 2, obs_dim).astype(np.float32)
+    rec = dict(op_kind=[], op_a=[], op_b=[], reward=[], action=[], length=[])
+    samples = dict(at_op=[], indices=[], entry_tids=[], entry_len=[], reward=[], terminal=[],
+                   discount=[], action=[], state_tid=[], next_state_tid=[])
+    tid = 0
+    for k in range(n_ops):
+        r = rs.rand()
+        if r < 0.1:
+            env = int(rs.randint(n_envs))
+            rbuf.stop_current_episode(env_id=env)
+            rec["op_kind"].append(1); rec["op_a"].append(env); rec["op_b"].append(0)
+        else:
+            env = int(rs.randint(n_envs))
+            term = bool(rs.rand() < 0.12)
+            rew = float(rs.randn())
+            act = int(rs.randint(4))
+            rbuf.append(state=obs_table[tid], action=act, reward=rew, next_state=obs_table[tid + 1],
+                        is_state_terminal=term, env_id=env, tid=tid)
+            rec["op_kind"].append(0); rec["op_a"].append(env); rec["op_b"].append(int(term))
+            rec["reward"].append(rew); rec["action"].append(act)
+            tid += 1
+        rec["length"].append(len(rbuf))
+        if len(rbuf) >= batch and rs.rand() < 0.2:
+            st = np.random.get_state()
+            exps = rbuf.sample(batch)
+            np.random.set_state(st)
+            idx = pfrl.utils.random.sample_n_k(len(rbuf), batch)
+            samples["at_op"].append(k)
+            samples["indices"].extend(int(i) for i in idx)
+            be = batch_experiences(exps, torch.device("cpu"), lambda x: x, gamma)
+            for e in exps:
+                tids = [tr["tid"] for tr in e]
+                samples["entry_len"].append(len(tids))
+                samples["entry_tids"].extend(tids + [-1] * (num_steps - len(tids)))
+                samples["state_tid"].append(e[0]["tid"])
+                samples["next_state_tid"].append(e[-1]["tid"] + 1)
+            samples["reward"].extend(be["reward"].numpy().tolist())
+            samples["terminal"].extend(be["is_state_terminal"].numpy().tolist())
+            samples["discount"].extend(be["discount"].numpy().tolist())
+            samples["action"].extend(be["action"].numpy().tolist())
+            # the batched states must be the rows of obs_table
+            assert np.array_equal(be["state"].numpy(), obs_table[[e[0]["tid"] for e in exps]])
+            assert np.array_equal(be["next_state"].numpy(),
+                                  obs_table[[e[-1]["tid"] + 1 for e in exps]])
+    final_entries = [[tr["tid"] for tr in e] for e in rbuf.memory]
+    out = {k2: np.asarray(v) for k2, v in rec.items()}
+    for k2, v in samples.items():
+        dt = np.float32 if k2 in ("reward", "terminal", "discount") else None
+        out["s_" + k2] = np.asarray(v, dtype=dt)
+    out["final_len"] = np.array([len(e) for e in final_entries])
+    out["final_tids"] = np.array(
+        [e + [-1] * (num_steps - len(e)) for e in final_entries]).reshape(-1, num_steps)
+    out["meta"] = np.array([seed, -1 if capacity is None else capacity, num_steps, n_envs, batch])
+    out["gamma"] = np.array(gamma)
+    np.savez_compressed(os.path.join(HERE, "replay_trace_%s.npz" % name), **out)
+    print("replay_trace", name, "final len", len(rbuf), "samples", len(samples["at_op"]))
+
+
+# --------------------------------------------------------------------------
+# C. batch_states with the Atari phi
+# --------------------------------------------------------------------------
+def batch_states_golden():
+    from pfrl.utils.batch_states import batch_states
+    from pfrl.wrappers.atari_wrappers import LazyFrames
+
+    def phi(x):  # examples/atari/train_dqn_batch_ale.py:229-231
+        return np.asarray(x, dtype=np.float32) / 255
+
+    lut = phi(np.arange(256, dtype=np.uint8))
+    rs = np.random.RandomState(3)
+    frames = rs.randint(0, 256, size=(7, 1, 12, 10)).astype(np.uint8)
+    refs = np.array([[0, 0, 0, 0], [0, 0, 0, 1], [0, 1, 2, 3], [3, 4, 5, 6], [6, 6, 6, 6]],
+                    dtype=np.int32)
+    obs = [LazyFrames([frames[j] for j in r], stack_axis=0) for r in refs]
+    out = batch_states(obs, torch.device("cpu"), phi).numpy()
+    np.savez_compressed(os.path.join(HERE, "batch_states_atari.npz"), lut=lut, frames=frames,
+                        refs=refs, out=out)
+    print("batch_states", out.shape, out.dtype)
+
+
+# --------------------------------------------------------------------------
+# D. GAE (ppo.py:36-47), both reward dtypes
+# --------------------------------------------------------------------------
+def gae_golden():
+    from pfrl.agents.ppo import _add_advantage_and_value_target_to_episode
+
+    rs = np.random.RandomState(11)
+    rec = dict(off=[0], reward=[], v=[], nv=[], nonterm=[], adv=[], vt=[], adv_t=[], vt_t=[],
+               mode=[], gamma=[], lambd=[])
+    for case in range(24):
+        T = int(rs.randint(1, 140))
+        mode = case % 2
+        gamma = [0.99, 1.0, 0.8, 0.0][case % 4]
+        lambd = [0.95, 1.0, 0.0][case % 3]
+        v = rs.randn(T).astype(np.float32)
+        nv = rs.randn(T).astype(np.float32)
+        rew = rs.choice([-1.0, 0.0, 1.0], size=T) if case % 3 else rs.randn(T)
+        ep = []
+        for i in range(T):
+            done = (i == T - 1) and (case % 5 != 0)
+            ep.append(dict(
+                reward=(np.float64(rew[i]) if mode else float(rew[i])),
+                nonterminal=0.0 if done else 1.0, v_pred=v[i], next_v_pred=nv[i]))
+        _add_advantage_and_value_target_to_episode(ep, gamma, lambd)
+        rec["off"].append(rec["off"][-1] + T)
+        rec["reward"].extend(float(t["reward"]) for t in ep)
+        rec["v"].extend(v.tolist()); rec["nv"].extend(nv.tolist())
+        rec["nonterm"].extend(t["nonterminal"] for t in ep)
+        rec["adv"].extend(float(t["adv"]) for t in ep)
+        rec["vt"].extend(float(t["v_teacher"]) for t in ep)
+        rec["adv_t"].extend(tag(t["adv"]) for t in ep)
+        rec["vt_t"].extend(tag(t["v_teacher"]) for t in ep)
+        rec["mode"].append(mode); rec["gamma"].append(gamma); rec["lambd"].append(lambd)
+    out = {k: np.asarray(v) for k, v in rec.items()}
+    out["v"] = out["v"].astype(np.float32); out["nv"] = out["nv"].astype(np.float32)
+    np.savez_compressed(os.path.join(HERE, "gae.npz"), **out)
+    print("gae cases", len(rec["mode"]))
+
+
+# --------------------------------------------------------------------------
+# E. A2C._compute_returns (a2c.py:150-167)
+# --------------------------------------------------------------------------
+def a2c_golden():
+    from pfrl.agents import A2C
+
+    rs = np.random.RandomState(5)
+    out = {}
+    for ci, (T, N, use_gae, gamma, tau) in enumerate(
+        [(5, 3, True, 0.99, 0.95), (5, 3, False, 0.99, 0.95), (16, 8, True, 0.9, 1.0),
+         (16, 8, False, 1.0, 0.5)]):
+        model = torch.nn.Linear(2, 2)
+        agent = A2C(model, torch.optim.SGD(model.parameters(), lr=0.1), gamma=gamma,
+                    num_processes=N, update_steps=T, use_gae=use_gae, tau=tau)
+        agent.device = torch.device("cpu")
+        agent._flush_storage((N, 2), torch.zeros(N, 1))
+        agent.rewards = torch.tensor(rs.randn(T, N).astype(np.float32))
+        agent.value_preds = torch.tensor(rs.randn(T + 1, N).astype(np.float32))
+        agent.masks = torch.tensor((rs.rand(T, N) > 0.2).astype(np.float32))
+        nvs = torch.tensor(rs.randn(N).astype(np.float32))
+        vp_in = agent.value_preds.numpy().copy()
+        agent._compute_returns(nvs)
+        out["c%d_meta" % ci] = np.array([T, N, int(use_gae)])
+        out["c%d_hyper" % ci] = np.array([gamma, tau])
+        out["c%d_rewards" % ci] = agent.rewards.numpy()
+        out["c%d_masks" % ci] = agent.masks.numpy()
+        out["c%d_value_preds" % ci] = vp_in
+        out["c%d_next_value" % ci] = nvs.numpy()
+        out["c%d_returns" % ci] = agent.returns.numpy()
+    np.savez_compressed(os.path.join(HERE, "a2c_returns.npz"), **out)
+    print("a2c cases 4")
+
+
+# --------------------------------------------------------------------------
+# F. sample_n_k (utils/random.py) -- pins RNG stream use of our restatement
+# --------------------------------------------------------------------------
+def sample_n_k_golden():
+    from pfrl.utils.random import sample_n_k
+
+    rec = dict(n=[], k=[], seed=[], off=[0], idx=[])
+    for seed, (n, k) in enumerate([(10, 3), (10, 4), (100, 32), (50000, 32), (1000000, 32),
+                                   (33, 32), (5, 5), (7, 0), (97, 32), (96, 32), (40, 13)]):
+        np.random.seed(seed)
+        idx = sample_n_k(n, k)
+        tail = np.random.random_sample()  # pins how much of the stream was consumed
+        rec["n"].append(n); rec["k"].append(k); rec["seed"].append(seed)
+        rec["idx"].extend(int(i) for i in idx)
+        rec["off"].append(rec["off"][-1] + k)
+        rec.setdefault("tail", []).append(tail)
+    np.savez_compressed(os.path.join(HERE, "sample_n_k.npz"),
+                        **{k: np.asarray(v) for k, v in rec.items()})
+    print("sample_n_k cases", len(rec["n"]))
+
+
+if __name__ == "__main__":
+    random.seed(0)
+    torch.manual_seed(0)
+    pbuf_trace("cap5", 0, 5, 400, 2)
+    pbuf_trace("cap1", 1, 1, 120, 1)
+    pbuf_trace("cap10", 2, 10, 500, 4)
+    pbuf_trace("cap64", 3, 64, 1500, 16)
+    pbuf_trace("cap1000", 4, 1000, 3000, 32)
+    pbuf_trace("unbounded", 5, None, 700, 8)
+    per_trace("f32_cap100_n1", 10, 100, 1, 600, 8, "f32", True)
+    per_trace("f32_cap50_n3", 11, 50, 3, 600, 8, "f32", "memory", alpha=0.5)
+    per_trace("py_cap20_n1", 12, 20, 1, 300, 4, "py", False)
+    per_trace("mixed_cap300_n3", 13, 300, 3, 1500, 32, "mixed", "memory", alpha=0.5, n_envs=8)
+    replay_trace("cap30_n1", 20, 30, 1, 400, 3)
+    replay_trace("cap30_n3", 21, 30, 3, 500, 4)
+    replay_trace("unbounded_n5", 22, None, 5, 300, 2)
+    replay_trace("cap200_n3_env16", 23, 200, 3, 1200, 16, batch=32)
+    batch_states_golden()
+    gae_golden()
+    a2c_golden()
+    sample_n_k_golden()
