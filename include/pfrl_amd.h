@@ -1,0 +1,235 @@
+/*
+ * pfrl_amd.h -- C ABI of the MI355X (gfx950) replay / rollout data path.
+ *
+ * This is the drop-in boundary of the hot path.  The
+ * reference (pfnet/pfrl) is pure Python and has no FFI of its own; the entry
+ * points below are what a ctypes binding for its L2 data path would bind, one
+ * per reference function that moved to the device.  Every pointer is a plain
+ * device pointer (HBM) unless the name says `host_`; sizes are element counts;
+ * `stream` is a hipStream_t passed as void*.  No torch types cross this
+ * boundary.  All functions return 0 on success or a hipError_t / negative
+ * pfrl error code; pfrl_amd_last_error() gives a message.  Not re-entrant per
+ * object: one owner thread per GPU, as the reference's batched path
+ * (pfrl/agents/dqn.py:509-549 is single-threaded).
+ *
+ * Typed scalars.  The reference as executed with NumPy 2 keeps a mixture of
+ * Python floats, np.float32 and np.float64 inside its priority trees
+ * (SURVEY.md section 7.1).  A tree node here is (double value, uint8 tag):
+ */
+#ifndef PFRL_AMD_H
+#define PFRL_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PFRL_TAG_ABSENT 0 /* empty list node */
+#define PFRL_TAG_PY 1     /* Python float (weak f64) */
+#define PFRL_TAG_F32 2    /* np.float32 */
+#define PFRL_TAG_F64 3    /* np.float64 */
+
+#define PFRL_MAX_LEVELS 40
+#define PFRL_MAX_NSTEP 16
+#define PFRL_MAX_STACK 8
+
+#define PFRL_ERR_ARG (-2)
+
+int pfrl_amd_version(void);
+const char *pfrl_amd_last_error(void);
+
+/* ------------------------------------------------------------------------
+ * Observation store: a ring of fixed-size frames in HBM.  An observation is a
+ * stack of k frame slots (k = 4 for the Atari frame stack, k = 1 for flat
+ * vector observations).  Replaces VectorFrameStack/LazyFrames storage
+ * (pfrl/wrappers/vector_frame_stack.py:54-105, atari_wrappers.py:251-272).
+ * ------------------------------------------------------------------------ */
+
+/* frames[slots[i]] <- src[i]  (i < n); frame_bytes must be a multiple of 4.
+ * New frames of one env step, already on the device. */
+int pfrl_frames_scatter(void *frames, int64_t frame_bytes, const void *src, const int32_t *slots,
+                        int64_t n, void *stream);
+
+/* Synthetic Atari-shaped env: fills frames[slots[i]]
+ * with iid U{0..255} bytes from a counter-based generator keyed by
+ * (seed, env_id0 + i, step). */
+int pfrl_frames_synth_u8(void *frames, int64_t frame_bytes, const int32_t *slots, int64_t n,
+                         uint64_t seed, int64_t env_id0, int64_t step, void *stream);
+
+/* batch_states(states, device, phi) with phi(x) = asarray(x, float32) / divisor
+ * (pfrl/utils/batch_states.py:18-36; examples/atari/train_dqn_batch_ale.py:
+ * 229-231).  out[m][j][:] = float(frames[refs[m*k+j]][:]) / divisor, IEEE
+ * division, bit-exact.  divisor == 1 is the cast-only phi.
+ * n_refs = M*k; out is f32 [n_refs][frame_bytes]. */
+int pfrl_batch_states_u8(const void *frames, int64_t frame_bytes, const int32_t *refs,
+                         int64_t n_refs, float divisor, float *out, void *stream);
+
+/* batch_states with the identity phi on float32 observations
+ * (examples/gym/train_dqn_gym.py, mujoco examples): plain gather. */
+int pfrl_batch_states_f32(const void *frames, int64_t frame_bytes, const int32_t *refs,
+                          int64_t n_refs, float *out, void *stream);
+
+/* ------------------------------------------------------------------------
+ * Transition table + n-step entries (pfrl/replay_buffers/replay_buffer.py:
+ * 24-76; pfrl/collections/random_access_queue.py).  Structure-of-arrays in
+ * HBM, all rings indexed by slot:
+ *   t_state_ref, t_next_ref : int32 [R][k]   frame slots of s_t and s_{t+1}
+ *   t_action                : int64 [R]  (discrete)  or  float [R][act_dim]
+ *   t_reward                : double[R]      (Python float rewards)
+ *   t_terminal              : uint8 [R]
+ *   e_tids                  : int32 [E][n]   transition slots of an n-step
+ *                                            entry, -1 padded
+ *   e_len                   : int32 [E]
+ * ------------------------------------------------------------------------ */
+typedef struct {
+    int32_t *t_state_ref;
+    int32_t *t_next_ref;
+    void *t_action;
+    double *t_reward;
+    uint8_t *t_terminal;
+    int32_t *e_tids;
+    int32_t *e_len;
+    int32_t k;        /* frames per observation */
+    int32_t n;        /* num_steps */
+    int32_t act_dim;  /* 0: int64 discrete actions, >0: float[act_dim] */
+    int32_t reserved;
+} pfrl_table_t;
+
+/* ReplayBuffer.append for a batch of transitions already on the device
+ * (pfrl/agents/dqn.py:527-544): row i of the staging arrays goes to
+ * transition slot t_slots[i]. */
+int pfrl_table_append(const pfrl_table_t *tab, int64_t n_rows, const int32_t *t_slots,
+                      const int32_t *state_ref, const int32_t *next_ref, const void *action,
+                      const double *reward, const uint8_t *terminal, void *stream);
+
+/* Emitted n-step windows (replay_buffer.py:53-62,64-76): entry slot
+ * e_slots[i] <- (tids[i][0..n), len[i]). */
+int pfrl_entries_append(const pfrl_table_t *tab, int64_t n_rows, const int32_t *e_slots,
+                        const int32_t *tids, const int32_t *lens, void *stream);
+
+/* batch_experiences (pfrl/replay_buffer.py:157-212) for B sampled entry slots:
+ *   state      f32 [B][k][frame_bytes] = phi(e[0].state)
+ *   next_state f32 [B][k][frame_bytes] = phi(e[-1].next_state)
+ *   action     = e[0].action
+ *   reward     = float32(sum_i gamma_pow[i] * r_i)   (f64 accumulate, :183-190)
+ *   terminal   = any(is_state_terminal)              (:194-201)
+ *   discount   = float32(gamma_pow[len])             (:202-206)
+ * gamma_pow: host array of n+1 doubles (gamma**i computed by the caller's own
+ * pow, passed by value).  frame_is_f32 != 0 selects the identity phi on f32
+ * frames.  One launch does the scalar collapse and both gathers. */
+int pfrl_batch_experiences(const pfrl_table_t *tab, const void *frames, int64_t frame_bytes,
+                           int frame_is_f32, float divisor, const int32_t *entry_slots, int64_t B,
+                           const double *host_gamma_pow, float *out_state, float *out_next_state,
+                           void *out_action, float *out_reward, float *out_terminal,
+                           float *out_discount, void *stream);
+
+/* ------------------------------------------------------------------------
+ * Prioritized buffer: the sliding sum/min trees of
+ * pfrl/collections/prioritized.py:135-323 as per-level rings of tagged nodes.
+ *   level l (0 = leaves) has M_l = max(smax >> l, 1) slots starting at
+ *   level_off[l]; node of absolute leaf coordinate x at level l is
+ *   ((x - origin[l]) >> l) & (M_l - 1).
+ * The host mirrors the integer bookkeeping of TreeQueue (length, bounds,
+ * re-rooting, :207-242) and passes it in this descriptor by value.
+ * ------------------------------------------------------------------------ */
+typedef struct {
+    double *sum_val;
+    uint8_t *sum_tag;
+    double *min_val;
+    uint8_t *min_tag;
+    double *maxp_val;   /* device scalar: PrioritizedBuffer.max_priority */
+    uint8_t *maxp_tag;
+    int64_t level_off[PFRL_MAX_LEVELS];
+    int64_t origin[PFRL_MAX_LEVELS];
+    int64_t base;       /* absolute coordinate of the frame start (bounds[0]) */
+    int64_t head;       /* absolute coordinate of logical index 0 */
+    int64_t length;
+    int32_t log2_size;  /* frame size = 1 << log2_size */
+    int32_t log2_smax;
+} pfrl_tree_t;
+
+/* PrioritizedBuffer.append / popleft for a batch (prioritized.py:39-54):
+ * leaves x[i] are written in both trees and every ancestor is re-reduced.
+ * tag[i] == PFRL_TAG_ABSENT deletes the leaf (popleft);
+ * use_maxp[i] != 0 writes the current max_priority (append with
+ * priority=None).  x must be unique within one call. n <= 1024. */
+int pfrl_tree_write(const pfrl_tree_t *tree, int64_t n, const int64_t *x, const double *val,
+                    const uint8_t *tag, const uint8_t *use_maxp, void *stream);
+
+/* SumTreeQueue.prioritized_sample(n, remove=True) + the probability / weight
+ * math of PrioritizedBuffer._sample_indices_and_probabilities (:56-84) and
+ * PriorityWeightError.weights_from_probabilities
+ * (pfrl/replay_buffers/prioritized.py:57-66).
+ *   u01[i]          : the doubles np.random.uniform would consume
+ *   out_x[i]        : absolute leaf coordinate (logical index = x - head)
+ *   out_pri / _tag  : removed priorities (bit-exact)
+ *   out_prob        : f64 probabilities
+ *   out_weight      : f32 importance weights
+ *   normalize: 0 False, 1 "batch", 2 "memory";  beta: current beta
+ *   out_total/_tag, out_min_prob: root sum before sampling, min/total
+ *   out_slot (optional)         : int32 x % slot_mod -- the replay buffer's
+ *                                 entry-ring slot of each sampled item
+ * B <= 1024. */
+int pfrl_tree_sample(const pfrl_tree_t *tree, int64_t B, const double *u01, int64_t *out_x,
+                     double *out_pri, uint8_t *out_pri_tag, double *out_prob, float *out_weight,
+                     double *out_total, uint8_t *out_total_tag, double *out_min_prob,
+                     int normalize, double beta, int64_t slot_mod, int32_t *out_slot,
+                     void *stream);
+
+/* PrioritizedReplayBuffer.update_errors (pfrl/replay_buffers/prioritized.py:
+ * 47-55,125-126) + PrioritizedBuffer.set_last_priority (:107-116) for
+ * np.float32 errors resident on the device (|y-t| of DQN, dqn.py:447-454):
+ * p = (clip(err, error_min, error_max) + eps) ** alpha with NEP-50 typing;
+ * clipped values use the host-supplied constants (Python-float results of
+ * (error_min + eps) ** alpha and (error_max + eps) ** alpha).
+ * x must be unique unless dedupe != 0 (last occurrence wins). */
+int pfrl_tree_update_errors_f32(const pfrl_tree_t *tree, int64_t B, const int64_t *x,
+                                const float *err, int has_min, float error_min, double pri_at_min,
+                                int has_max, float error_max, double pri_at_max, double eps,
+                                double alpha, int dedupe, void *stream);
+
+/* set_last_priority with explicit typed priorities (host-computed, e.g. from
+ * Python-float errors): val/tag are device arrays. */
+int pfrl_tree_set_priorities(const pfrl_tree_t *tree, int64_t B, const int64_t *x,
+                             const double *val, const uint8_t *tag, int dedupe, void *stream);
+
+/* ------------------------------------------------------------------------
+ * On-policy rollouts (pfrl/agents/ppo.py, a2c.py).  Layout [T][N], env minor.
+ * ------------------------------------------------------------------------ */
+
+/* _add_advantage_and_value_target_to_episode (ppo.py:36-47) for every episode
+ * fragment of a T x N rollout.  cut[t][e] != 0 marks the last transition of a
+ * fragment (done, reset or rollout end): the scan restarts with adv = 0.
+ * mode 0: Python-float rewards (all f32 arithmetic); mode 1: np.float64
+ * rewards (f64 accumulate).  adv / v_teacher are written as f32. */
+int pfrl_gae_scan(int64_t T, int64_t N, const double *reward, const float *v_pred,
+                  const float *next_v_pred, const uint8_t *nonterminal, const uint8_t *cut,
+                  double gamma, double lambd, int mode, float *adv, float *v_teacher,
+                  void *stream);
+
+/* A2C._compute_returns (a2c.py:150-167); value_preds/returns are [T+1][N]
+ * with row T already holding next_value as the reference sets it. */
+int pfrl_a2c_returns(int64_t T, int64_t N, const float *rewards, const float *masks,
+                     const float *value_preds, float *returns, double gamma, double tau,
+                     int use_gae, void *stream);
+
+/* torch.std_mean(all_advs, unbiased=False) (ppo.py:476-478): out[0] = mean,
+ * out[1] = std, f32, accumulated in f64 with wavefront shuffle reductions. */
+int pfrl_adv_stats(const float *adv, int64_t n, float *out_mean_std, void *partial_ws,
+                   void *stream);
+
+/* PPO minibatch assembly (ppo.py:483-511): for dataset positions idx[i]
+ *   out_adv   = (adv[idx] - mean) / (std + 1e-8)   if standardize
+ *   out_logp  = log_prob[idx], out_v = v_pred[idx], out_vt = v_teacher[idx],
+ *   out_action= action[idx] (int64),  out_refs[i][:] = state_refs[idx][:]. */
+int pfrl_ppo_minibatch(int64_t M, const int64_t *idx, const float *adv, const float *mean_std,
+                       int standardize, const float *log_prob, const float *v_pred,
+                       const float *v_teacher, const int64_t *action, const int32_t *state_refs,
+                       int32_t k, float *out_adv, float *out_logp, float *out_v, float *out_vt,
+                       int64_t *out_action, int32_t *out_refs, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PFRL_AMD_H */

@@ -68,7 +68,7 @@ def lib():
         L.orc_batch_states_u8.argtypes = [c.c_long, c.c_int, c.c_long, P, P, c.c_float, P]
         L.orc_batch_states_f32.argtypes = [c.c_long, c.c_int, c.c_long, P, P, P]
         L.orc_gae_fragment.argtypes = [c.c_long, P, P, P, P, c.c_double, c.c_double, c.c_int, P, P]
-        L.orc_a2c_returns.argtypes = [c.c_long, c.c_long, P, P, P, P, c.c_float, c.c_float, c.c_int]
+        L.orc_a2c_returns.argtypes = [c.c_long, c.c_long, P, P, P, P, c.c_double, c.c_double, c.c_int]
         L.orc_priority_from_errors_f32.argtypes = [
             c.c_long, P, c.c_int, c.c_double, c.c_int, c.c_double, c.c_double, c.c_double, P, P,
         ]

@@ -690,8 +690,10 @@ void orc_gae_fragment(long T, const double *reward, const float *v_pred, const f
  * rewards/masks [T][N], value_preds/returns [T+1][N]; value_preds[T] must
  * already hold next_value (use_gae) / returns[T] must hold next_value. */
 void orc_a2c_returns(long T, long N, const float *rewards, const float *masks, float *value_preds,
-                     float *returns, float gamma, float tau, int use_gae) {
+                     float *returns, double gamma_d, double tau_d, int use_gae) {
     long i, e;
+    const float gamma = (float)gamma_d;
+    const float gt = (float)(gamma_d * tau_d);
     if (use_gae) {
         for (e = 0; e < N; e++) {
             volatile float gae = 0.0f;
@@ -700,8 +702,7 @@ void orc_a2c_returns(long T, long N, const float *rewards, const float *masks, f
                 volatile float b = a * masks[i * N + e];
                 volatile float c = rewards[i * N + e] + b;
                 volatile float delta = c - value_preds[i * N + e];
-                volatile float g1 = gamma * tau;
-                volatile float g2 = g1 * masks[i * N + e];
+                volatile float g2 = gt * masks[i * N + e];
                 volatile float g3 = g2 * gae;
                 gae = delta + g3;
                 returns[i * N + e] = gae + value_preds[i * N + e];

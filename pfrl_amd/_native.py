@@ -1,0 +1,154 @@
+"""ctypes binding of the C ABI declared in include/pfrl_amd.h.
+
+The shared library is built in-tree by :func:`build` (hipcc, gfx950) as
+``pfrl_amd/lib/libpfrl_amd.so``.  There is no CPU fallback: any attempt to use
+a device-resident buffer without the library raises ``RuntimeError``.
+"""
+import ctypes
+import os
+import shutil
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_DIR = os.path.join(_HERE, "lib")
+LIB_PATH = os.path.join(LIB_DIR, "libpfrl_amd.so")
+SOURCES = ["frames.hip", "replay.hip", "sumtree.hip", "rollout.hip"]
+HIPCC_FLAGS = [
+    "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
+    # the parity contract is one correctly rounded IEEE op per source op
+    "-ffp-contract=off", "-fno-fast-math",
+]
+
+MAX_LEVELS = 40
+MAX_NSTEP = 16
+MAX_STACK = 8
+
+
+def _hipcc():
+    for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found; cannot build pfrl_amd HIP kernels")
+
+
+def build(force=False, verbose=False):
+    """Compile every HIP source for gfx950 and link libpfrl_amd.so (in-tree)."""
+    os.makedirs(LIB_DIR, exist_ok=True)
+    srcs = [os.path.join(CSRC, s) for s in SOURCES]
+    deps = srcs + [os.path.join(CSRC, "common.h"),
+                   os.path.join(_HERE, "..", "include", "pfrl_amd.h")]
+    if not force and os.path.exists(LIB_PATH):
+        if all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
+            return LIB_PATH
+    hipcc = _hipcc()
+    objs = []
+    for s in srcs:
+        o = os.path.join(LIB_DIR, os.path.basename(s).replace(".hip", ".o"))
+        cmd = [hipcc] + HIPCC_FLAGS + ["-c", s, "-o", o]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+        objs.append(o)
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB_PATH]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+class TableDesc(ctypes.Structure):
+    """pfrl_table_t"""
+
+    _fields_ = [
+        ("t_state_ref", ctypes.c_void_p),
+        ("t_next_ref", ctypes.c_void_p),
+        ("t_action", ctypes.c_void_p),
+        ("t_reward", ctypes.c_void_p),
+        ("t_terminal", ctypes.c_void_p),
+        ("e_tids", ctypes.c_void_p),
+        ("e_len", ctypes.c_void_p),
+        ("k", ctypes.c_int32),
+        ("n", ctypes.c_int32),
+        ("act_dim", ctypes.c_int32),
+        ("reserved", ctypes.c_int32),
+    ]
+
+
+class TreeDesc(ctypes.Structure):
+    """pfrl_tree_t"""
+
+    _fields_ = [
+        ("sum_val", ctypes.c_void_p),
+        ("sum_tag", ctypes.c_void_p),
+        ("min_val", ctypes.c_void_p),
+        ("min_tag", ctypes.c_void_p),
+        ("maxp_val", ctypes.c_void_p),
+        ("maxp_tag", ctypes.c_void_p),
+        ("level_off", ctypes.c_int64 * MAX_LEVELS),
+        ("origin", ctypes.c_int64 * MAX_LEVELS),
+        ("base", ctypes.c_int64),
+        ("head", ctypes.c_int64),
+        ("length", ctypes.c_int64),
+        ("log2_size", ctypes.c_int32),
+        ("log2_smax", ctypes.c_int32),
+    ]
+
+
+EXPORTS = {
+    # name: (restype, argtypes)
+    "pfrl_amd_version": (ctypes.c_int, []),
+    "pfrl_amd_last_error": (ctypes.c_char_p, []),
+    "pfrl_frames_scatter": (ctypes.c_int, "pqppqp"),
+    "pfrl_frames_synth_u8": (ctypes.c_int, "pqpqQqqp"),
+    "pfrl_batch_states_u8": (ctypes.c_int, "pqpqfpp"),
+    "pfrl_batch_states_f32": (ctypes.c_int, "pqpqpp"),
+    "pfrl_table_append": (ctypes.c_int, "Tqppppppp"),
+    "pfrl_entries_append": (ctypes.c_int, "Tqpppp"),
+    "pfrl_batch_experiences": (ctypes.c_int, "Tpqifpqpppppppp"),
+    "pfrl_tree_write": (ctypes.c_int, "Rqppppp"),
+    "pfrl_tree_sample": (ctypes.c_int, "Rqpppppppppidqpp"),
+    "pfrl_tree_update_errors_f32": (ctypes.c_int, "Rqppifdifdddip"),
+    "pfrl_tree_set_priorities": (ctypes.c_int, "Rqpppip"),
+    "pfrl_gae_scan": (ctypes.c_int, "qqpppppddippp"),
+    "pfrl_a2c_returns": (ctypes.c_int, "qqppppddip"),
+    "pfrl_adv_stats": (ctypes.c_int, "pqppp"),
+    "pfrl_ppo_minibatch": (ctypes.c_int, "qpppipppppippppppp"),
+}
+
+_CODES = {
+    "p": ctypes.c_void_p, "q": ctypes.c_int64, "Q": ctypes.c_uint64, "i": ctypes.c_int,
+    "f": ctypes.c_float, "d": ctypes.c_double,
+    "T": ctypes.POINTER(TableDesc), "R": ctypes.POINTER(TreeDesc),
+}
+
+_lib = None
+
+
+def lib():
+    """Load libpfrl_amd.so; raise loudly if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "pfrl_amd: %s is missing.  The device replay path has no CPU fallback; "
+            "run `python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc)." % LIB_PATH
+        )
+    L = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in EXPORTS.items():
+        fn = getattr(L, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = [_CODES[c] for c in args] if isinstance(args, str) else args
+    _lib = L
+    return L
+
+
+def available():
+    return os.path.exists(LIB_PATH)
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib().pfrl_amd_last_error().decode()
+        raise RuntimeError("pfrl_amd %s failed (code %d): %s" % (what, rc, msg))

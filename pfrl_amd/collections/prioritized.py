@@ -1,0 +1,241 @@
+"""Device-resident PrioritizedBuffer.
+
+Mirrors ``pfrl.collections.prioritized.PrioritizedBuffer``
+(/root/reference/pfrl/collections/prioritized.py:21-123): same constructor,
+``append / popleft / sample / set_last_priority / __len__`` and the same
+assertion behaviour, but the sum/min trees live in HBM as tagged nodes and are
+driven by the kernels in pfrl_amd/csrc/sumtree.hip.  The host keeps only the
+integer bookkeeping (TreeFrame) and the Python payload deque.
+"""
+import collections
+
+import numpy as np
+import torch
+
+from pfrl_amd import ops
+from pfrl_amd._native import MAX_LEVELS, TreeDesc
+from pfrl_amd.collections.tree_frame import TreeFrame, smax_log2_for_capacity
+from pfrl_amd.staging import StagingRing
+
+TAG_ABSENT, TAG_PY, TAG_F32, TAG_F64 = 0, 1, 2, 3
+
+
+def type_tag(x):
+    """NEP-50 tag of a scalar priority."""
+    if isinstance(x, np.float32):
+        return TAG_F32
+    if isinstance(x, np.float64):
+        return TAG_F64
+    if isinstance(x, (float, int)):
+        return TAG_PY
+    if isinstance(x, np.floating):
+        return TAG_F64
+    raise TypeError("unsupported priority type %r" % type(x))
+
+
+class PrioritizedBuffer:
+    def __init__(self, capacity=None, wait_priority_after_sampling=True,
+                 initial_max_priority=1.0, device=None, max_size=None):
+        if device is None:
+            device = torch.device("cuda", torch.cuda.current_device())
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("pfrl_amd PrioritizedBuffer is device-resident (needs a GPU)")
+        self.capacity = capacity
+        self.wait_priority_after_sampling = wait_priority_after_sampling
+        if not wait_priority_after_sampling:
+            raise NotImplementedError("remove=False sampling is not used by any replay buffer")
+        self.flag_wait_priority = False
+        self.data = collections.deque()
+        self.frame = TreeFrame()
+        bound = capacity if capacity is not None else (max_size or (1 << 20))
+        self._bound = bound
+        self.log2_smax = smax_log2_for_capacity(bound)
+        smax = 1 << self.log2_smax
+        self._level_off = [0] * MAX_LEVELS
+        off = 0
+        for l in range(MAX_LEVELS):
+            self._level_off[l] = off
+            off += max(smax >> l, 1) if l <= self.log2_smax else 0
+        n_nodes = off
+        dev = self.device
+        self.sum_val = torch.zeros(n_nodes, dtype=torch.float64, device=dev)
+        self.sum_tag = torch.zeros(n_nodes, dtype=torch.uint8, device=dev)
+        self.min_val = torch.zeros(n_nodes, dtype=torch.float64, device=dev)
+        self.min_tag = torch.zeros(n_nodes, dtype=torch.uint8, device=dev)
+        self._maxp_val = torch.full((1,), float(initial_max_priority), dtype=torch.float64,
+                                    device=dev)
+        self._maxp_tag = torch.full((1,), type_tag(initial_max_priority), dtype=torch.uint8,
+                                    device=dev)
+        self._stage = StagingRing(dev, slot_bytes=1 << 16, n_slots=64)
+        self._pend_x, self._pend_v, self._pend_t, self._pend_m = [], [], [], []
+        self._sampled_x = None  # device int64 tensor of the last sample
+        self._n_sampled = 0
+        self._desc = TreeDesc()
+        d = self._desc
+        d.sum_val, d.sum_tag = self.sum_val.data_ptr(), self.sum_tag.data_ptr()
+        d.min_val, d.min_tag = self.min_val.data_ptr(), self.min_tag.data_ptr()
+        d.maxp_val, d.maxp_tag = self._maxp_val.data_ptr(), self._maxp_tag.data_ptr()
+        for l in range(MAX_LEVELS):
+            d.level_off[l] = self._level_off[l]
+        d.log2_smax = self.log2_smax
+
+    # -- descriptor ---------------------------------------------------------
+    def _sync_desc(self):
+        d, f = self._desc, self.frame
+        d.base, d.head, d.length, d.log2_size = f.base, f.head, f.length, f.log2_size
+        for l in range(1, f.log2_size + 1):
+            d.origin[l] = f.origin[l]
+        return d
+
+    def __len__(self):
+        return len(self.data)
+
+    # -- pending leaf writes ------------------------------------------------
+    def _record(self, x, val, tag, use_maxp):
+        self._pend_x.append(x)
+        self._pend_v.append(val)
+        self._pend_t.append(tag)
+        self._pend_m.append(use_maxp)
+
+    def flush(self):
+        """Launch the recorded leaf writes under the frame they belong to."""
+        n = len(self._pend_x)
+        if n == 0:
+            return
+        desc = self._sync_desc()
+        for lo in range(0, n, 1024):
+            hi = min(n, lo + 1024)
+            x, v, t, m = self._stage.upload([
+                np.asarray(self._pend_x[lo:hi], dtype=np.int64),
+                np.asarray(self._pend_v[lo:hi], dtype=np.float64),
+                np.asarray(self._pend_t[lo:hi], dtype=np.uint8),
+                np.asarray(self._pend_m[lo:hi], dtype=np.uint8),
+            ])
+            ops.tree_write(desc, x, v, t, m)
+        self._pend_x, self._pend_v, self._pend_t, self._pend_m = [], [], [], []
+
+    # -- reference API ------------------------------------------------------
+    def append(self, value, priority=None):
+        """prioritized.py:39-48"""
+        if self.capacity is not None and len(self) == self.capacity:
+            self.popleft()
+        if self.frame.length >= self._bound and self.capacity is None:
+            raise RuntimeError("unbounded PrioritizedBuffer exceeded max_size=%d" % self._bound)
+        if self.frame.will_change_on_append():
+            self.flush()
+        x = self.frame.append()
+        if priority is None:
+            self._record(x, 0.0, TAG_PY, 1)
+        else:
+            self._record(x, float(priority), type_tag(priority), 0)
+        self.data.append(value)
+
+    def popleft(self):
+        """prioritized.py:50-54"""
+        assert len(self) > 0
+        x = self.frame.popleft_coord()
+        self._record(x, 0.0, TAG_ABSENT, 0)
+        if self.frame.will_change_on_popleft():
+            self.flush()
+        self.frame.popleft()
+        return self.data.popleft()
+
+    def sample_device(self, n, u01=None, normalize=1, beta=0.0, slot_mod=0):
+        """Device-side ``sample``: returns a dict of device tensors (x, pri,
+        pri_tag, prob, weight, total, total_tag, min_prob[, slot]).  ``u01``
+        defaults to the draws np.random.uniform would consume (same stream)."""
+        assert not self.wait_priority_after_sampling or not self.flag_wait_priority
+        assert len(self) >= n
+        self.flush()
+        if u01 is None:
+            u01 = np.random.random_sample(n)
+        (u_dev,) = self._stage.upload([np.asarray(u01, dtype=np.float64)])
+        dev = self.device
+        out = dict(
+            x=torch.empty(n, dtype=torch.int64, device=dev),
+            pri=torch.empty(n, dtype=torch.float64, device=dev),
+            pri_tag=torch.empty(n, dtype=torch.uint8, device=dev),
+            prob=torch.empty(n, dtype=torch.float64, device=dev),
+            weight=torch.empty(n, dtype=torch.float32, device=dev),
+            total=torch.empty(1, dtype=torch.float64, device=dev),
+            total_tag=torch.empty(1, dtype=torch.uint8, device=dev),
+            min_prob=torch.empty(1, dtype=torch.float64, device=dev),
+        )
+        if slot_mod:
+            out["slot"] = torch.empty(n, dtype=torch.int32, device=dev)
+        ops.tree_sample(self._sync_desc(), u_dev, out, normalize, beta, slot_mod)
+        self._sampled_x = out["x"]
+        self._n_sampled = n
+        self.flag_wait_priority = True
+        return out
+
+    def sample(self, n, uniform_ratio=0):
+        """prioritized.py:86-105 (host-visible results; one D2H sync)."""
+        if uniform_ratio != 0:
+            raise NotImplementedError("uniform_ratio > 0 is not used by the replay buffers")
+        out = self.sample_device(n)
+        x = out["x"].cpu().numpy()
+        idx = x - self.frame.head
+        self.sampled_indices = [int(i) for i in idx]
+        sampled = [self.data[i] for i in self.sampled_indices]
+        probs = out["prob"].cpu().numpy().tolist()
+        return sampled, probs, float(out["min_prob"].item())
+
+    def set_last_priority(self, priority):
+        """prioritized.py:107-116 with host-side typed priorities."""
+        assert not self.wait_priority_after_sampling or self.flag_wait_priority
+        assert all([p > 0.0 for p in priority])
+        assert self._n_sampled == len(priority)
+        v, t = self._stage.upload([
+            np.asarray([float(p) for p in priority], dtype=np.float64),
+            np.asarray([type_tag(p) for p in priority], dtype=np.uint8),
+        ])
+        ops.tree_set_priorities(self._sync_desc(), self._sampled_x, v, t, dedupe=True)
+        self.flag_wait_priority = False
+        self.sampled_indices = []
+        self._n_sampled = 0
+
+    def update_errors_device(self, err, error_min, pri_at_min, error_max, pri_at_max, eps, alpha):
+        """set_last_priority for f32 errors already on the device (DQN path)."""
+        assert not self.wait_priority_after_sampling or self.flag_wait_priority
+        assert self._n_sampled == err.numel()
+        ops.tree_update_errors_f32(self._sync_desc(), self._sampled_x, err, error_min, pri_at_min,
+                                   error_max, pri_at_max, eps, alpha, dedupe=True)
+        self.flag_wait_priority = False
+        self.sampled_indices = []
+        self._n_sampled = 0
+
+    # -- inspection (tests / statistics) ------------------------------------
+    @property
+    def max_priority(self):
+        v = float(self._maxp_val.item())
+        t = int(self._maxp_tag.item())
+        return np.float32(v) if t == TAG_F32 else (np.float64(v) if t == TAG_F64 else v)
+
+    def root_stats(self):
+        """((sum, tag), (min, tag), (max_priority, tag)) read back from HBM."""
+        self.flush()
+        f = self.frame
+        if f.length == 0:
+            return None
+        q = (f.base - f.origin[f.log2_size]) >> f.log2_size
+        M = max((1 << self.log2_smax) >> f.log2_size, 1)
+        i = self._level_off[f.log2_size] + (q & (M - 1))
+        return ((float(self.sum_val[i].item()), int(self.sum_tag[i].item())),
+                (float(self.min_val[i].item()), int(self.min_tag[i].item())),
+                (float(self._maxp_val.item()), int(self._maxp_tag.item())))
+
+    def dump_level(self, which, l):
+        """Nodes of level ``l`` (0 = leaves) in frame order: (values, tags)."""
+        self.flush()
+        f = self.frame
+        n = f.size >> l
+        M = max((1 << self.log2_smax) >> l, 1)
+        q0 = (f.base - f.origin[l]) >> l
+        idx = (torch.arange(n, device=self.device) + q0) & (M - 1)
+        idx = idx + self._level_off[l]
+        val = (self.min_val if which else self.sum_val)[idx].cpu().numpy()
+        tag = (self.min_tag if which else self.sum_tag)[idx].cpu().numpy()
+        val = np.where(tag == 0, 0.0, val)
+        return val, tag.astype(np.int32)

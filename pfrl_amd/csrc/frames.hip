@@ -1,0 +1,181 @@
+// Observation store kernels: frame ring writes and the gather-by-index
+// u8 -> f32 minibatch assembly that replaces batch_states(phi(...)).
+//
+// Roofline: HBM.  Per gathered frame the kernel reads frame_bytes and writes
+// 4*frame_bytes (u8 path); nothing is reused on chip except frames shared by
+// consecutive stacks (served by L2/MALL).  Work decomposition: one 256-thread
+// workgroup per output frame; each lane loads dwords strided by the workgroup
+// (256 B per wave instruction) and stores one float4 per dword, so every store
+// instruction of a wave covers 1 KiB of contiguous HBM.
+#include "common.h"
+
+static char g_err[512] = "";
+extern "C" void pfrl_set_error(const char *msg) { snprintf(g_err, sizeof(g_err), "%s", msg); }
+extern "C" const char *pfrl_amd_last_error(void) { return g_err; }
+extern "C" int pfrl_amd_version(void) { return 100; }
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kUnroll = 8;
+
+__device__ __forceinline__ float4 cvt_div(uint32_t w, float d) {
+    float4 o;
+    o.x = __fdiv_rn((float)(w & 0xffu), d);
+    o.y = __fdiv_rn((float)((w >> 8) & 0xffu), d);
+    o.z = __fdiv_rn((float)((w >> 16) & 0xffu), d);
+    o.w = __fdiv_rn((float)(w >> 24), d);
+    return o;
+}
+
+__device__ __forceinline__ float4 cvt_only(uint32_t w) {
+    float4 o;
+    o.x = (float)(w & 0xffu);
+    o.y = (float)((w >> 8) & 0xffu);
+    o.z = (float)((w >> 16) & 0xffu);
+    o.w = (float)(w >> 24);
+    return o;
+}
+
+// One workgroup converts one frame of `nd` dwords.
+template <bool DIV>
+__device__ __forceinline__ void convert_frame(const uint32_t *__restrict__ src,
+                                              float4 *__restrict__ dst, int nd, float d) {
+    const int tid = threadIdx.x;
+    for (int base = 0; base < nd; base += kThreads * kUnroll) {
+        uint32_t w[kUnroll];
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) {
+            int i = base + u * kThreads + tid;
+            w[u] = (i < nd) ? src[i] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) {
+            int i = base + u * kThreads + tid;
+            if (i < nd) dst[i] = DIV ? cvt_div(w[u], d) : cvt_only(w[u]);
+        }
+    }
+}
+
+template <bool DIV>
+__global__ __launch_bounds__(kThreads) void k_batch_states_u8(const uint8_t *__restrict__ frames,
+                                                              int64_t frame_bytes,
+                                                              const int32_t *__restrict__ refs,
+                                                              float d, float *__restrict__ out) {
+    const int64_t f = blockIdx.x;
+    const int64_t slot = refs[f];
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(frames + slot * frame_bytes);
+    float4 *dst = reinterpret_cast<float4 *>(out + f * frame_bytes);
+    convert_frame<DIV>(src, dst, (int)(frame_bytes >> 2), d);
+}
+
+// f32 frames: plain gather, 16 B per lane when the frame size allows.
+template <typename VecT>
+__global__ __launch_bounds__(kThreads) void k_batch_states_f32(const uint8_t *__restrict__ frames,
+                                                               int64_t frame_bytes,
+                                                               const int32_t *__restrict__ refs,
+                                                               int64_t n_refs,
+                                                               uint8_t *__restrict__ out) {
+    const uint32_t nv = (uint32_t)(frame_bytes / sizeof(VecT));
+    const int64_t total = n_refs * (int64_t)nv;
+    for (int64_t g = (int64_t)blockIdx.x * kThreads + threadIdx.x; g < total;
+         g += (int64_t)gridDim.x * kThreads) {
+        const int64_t f = g / nv;
+        const uint32_t i = (uint32_t)(g - f * nv);
+        const VecT *src = reinterpret_cast<const VecT *>(frames + (int64_t)refs[f] * frame_bytes);
+        reinterpret_cast<VecT *>(out + f * frame_bytes)[i] = src[i];
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void k_frames_scatter(uint8_t *__restrict__ frames,
+                                                             int64_t frame_bytes,
+                                                             const uint8_t *__restrict__ src,
+                                                             const int32_t *__restrict__ slots) {
+    const int64_t f = blockIdx.x;
+    const uint32_t *s = reinterpret_cast<const uint32_t *>(src + f * frame_bytes);
+    uint32_t *d = reinterpret_cast<uint32_t *>(frames + (int64_t)slots[f] * frame_bytes);
+    const int nd = (int)(frame_bytes >> 2);
+    for (int i = threadIdx.x; i < nd; i += kThreads) d[i] = s[i];
+}
+
+__device__ __forceinline__ uint64_t mix64(uint64_t z) {
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+    return z ^ (z >> 31);
+}
+
+__global__ __launch_bounds__(kThreads) void k_frames_synth(uint8_t *__restrict__ frames,
+                                                           int64_t frame_bytes,
+                                                           const int32_t *__restrict__ slots,
+                                                           uint64_t seed, int64_t env_id0,
+                                                           int64_t step) {
+    const int64_t f = blockIdx.x;
+    uint2 *d = reinterpret_cast<uint2 *>(frames + (int64_t)slots[f] * frame_bytes);
+    const int nq = (int)(frame_bytes >> 3);
+    const uint64_t key = mix64(seed ^ mix64((uint64_t)(env_id0 + f) * 0x9e3779b97f4a7c15ull +
+                                            (uint64_t)step));
+    for (int i = threadIdx.x; i < nq; i += kThreads) {
+        uint64_t r = mix64(key + (uint64_t)i * 0xd1342543de82ef95ull);
+        d[i] = make_uint2((uint32_t)r, (uint32_t)(r >> 32));
+    }
+    // tail (frame_bytes % 8 == 4)
+    if ((frame_bytes & 7) && threadIdx.x == 0) {
+        uint64_t r = mix64(key + (uint64_t)nq * 0xd1342543de82ef95ull);
+        reinterpret_cast<uint32_t *>(d)[2 * nq] = (uint32_t)r;
+    }
+}
+
+}  // namespace
+
+extern "C" int pfrl_frames_scatter(void *frames, int64_t frame_bytes, const void *src,
+                                   const int32_t *slots, int64_t n, void *stream) {
+    PFRL_CHECK_ARG(frame_bytes > 0 && (frame_bytes & 3) == 0, "frame_bytes must be a multiple of 4");
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(k_frames_scatter, dim3((unsigned)n), dim3(kThreads), 0, (hipStream_t)stream,
+                       (uint8_t *)frames, frame_bytes, (const uint8_t *)src, slots);
+    PFRL_LAUNCH_CHECK();
+}
+
+extern "C" int pfrl_frames_synth_u8(void *frames, int64_t frame_bytes, const int32_t *slots,
+                                    int64_t n, uint64_t seed, int64_t env_id0, int64_t step,
+                                    void *stream) {
+    PFRL_CHECK_ARG(frame_bytes > 0 && (frame_bytes & 3) == 0, "frame_bytes must be a multiple of 4");
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(k_frames_synth, dim3((unsigned)n), dim3(kThreads), 0, (hipStream_t)stream,
+                       (uint8_t *)frames, frame_bytes, slots, seed, env_id0, step);
+    PFRL_LAUNCH_CHECK();
+}
+
+extern "C" int pfrl_batch_states_u8(const void *frames, int64_t frame_bytes, const int32_t *refs,
+                                    int64_t n_refs, float divisor, float *out, void *stream) {
+    PFRL_CHECK_ARG(frame_bytes > 0 && (frame_bytes & 3) == 0, "frame_bytes must be a multiple of 4");
+    if (n_refs <= 0) return 0;
+    if (divisor == 1.0f)
+        hipLaunchKernelGGL(k_batch_states_u8<false>, dim3((unsigned)n_refs), dim3(kThreads), 0,
+                           (hipStream_t)stream, (const uint8_t *)frames, frame_bytes, refs, divisor,
+                           out);
+    else
+        hipLaunchKernelGGL(k_batch_states_u8<true>, dim3((unsigned)n_refs), dim3(kThreads), 0,
+                           (hipStream_t)stream, (const uint8_t *)frames, frame_bytes, refs, divisor,
+                           out);
+    PFRL_LAUNCH_CHECK();
+}
+
+extern "C" int pfrl_batch_states_f32(const void *frames, int64_t frame_bytes, const int32_t *refs,
+                                     int64_t n_refs, float *out, void *stream) {
+    PFRL_CHECK_ARG(frame_bytes > 0 && (frame_bytes & 3) == 0, "frame_bytes must be a multiple of 4");
+    if (n_refs <= 0) return 0;
+    const bool v16 = (frame_bytes & 15) == 0;
+    const int64_t items = n_refs * (frame_bytes / (v16 ? 16 : 4));
+    int64_t blocks = (items + kThreads - 1) / kThreads;
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    if (v16)
+        hipLaunchKernelGGL(k_batch_states_f32<uint4>, dim3((unsigned)blocks), dim3(kThreads), 0,
+                           (hipStream_t)stream, (const uint8_t *)frames, frame_bytes, refs, n_refs,
+                           (uint8_t *)out);
+    else
+        hipLaunchKernelGGL(k_batch_states_f32<uint32_t>, dim3((unsigned)blocks), dim3(kThreads), 0,
+                           (hipStream_t)stream, (const uint8_t *)frames, frame_bytes, refs, n_refs,
+                           (uint8_t *)out);
+    PFRL_LAUNCH_CHECK();
+}

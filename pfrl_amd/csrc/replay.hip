@@ -1,0 +1,230 @@
+// Transition table / n-step entry kernels and the fused batch_experiences
+// (pfrl/replay_buffer.py:157-212): one launch resolves the sampled entries,
+// collapses the n-step scalars and gathers state + next_state stacks into
+// fp32 minibatches.
+//
+// Roofline: HBM.  Algorithmic bytes per sampled entry =
+//   2 * k * frame_bytes read + 2 * k * 4 * frame_bytes written (u8 frames)
+// plus < 0.1 % metadata.
+#include "common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kUnroll = 8;
+
+struct GammaPow {
+    double g[PFRL_MAX_NSTEP + 1];
+};
+
+template <typename ActT>
+__global__ __launch_bounds__(kThreads) void k_table_append(pfrl_table_t tab, int64_t n_rows,
+                                                           const int32_t *__restrict__ t_slots,
+                                                           const int32_t *__restrict__ state_ref,
+                                                           const int32_t *__restrict__ next_ref,
+                                                           const ActT *__restrict__ action,
+                                                           const double *__restrict__ reward,
+                                                           const uint8_t *__restrict__ terminal) {
+    const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (i >= n_rows) return;
+    const int64_t s = t_slots[i];
+    for (int j = 0; j < tab.k; ++j) {
+        tab.t_state_ref[s * tab.k + j] = state_ref[i * tab.k + j];
+        tab.t_next_ref[s * tab.k + j] = next_ref[i * tab.k + j];
+    }
+    const int ad = tab.act_dim > 0 ? tab.act_dim : 1;
+    ActT *dst = reinterpret_cast<ActT *>(tab.t_action);
+    for (int j = 0; j < ad; ++j) dst[s * ad + j] = action[i * ad + j];
+    tab.t_reward[s] = reward[i];
+    tab.t_terminal[s] = terminal[i];
+}
+
+__global__ __launch_bounds__(kThreads) void k_entries_append(pfrl_table_t tab, int64_t n_rows,
+                                                             const int32_t *__restrict__ e_slots,
+                                                             const int32_t *__restrict__ tids,
+                                                             const int32_t *__restrict__ lens) {
+    const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (i >= n_rows) return;
+    const int64_t s = e_slots[i];
+    for (int j = 0; j < tab.n; ++j) tab.e_tids[s * tab.n + j] = tids[i * tab.n + j];
+    tab.e_len[s] = lens[i];
+}
+
+__device__ __forceinline__ float4 cvt_div(uint32_t w, float d) {
+    float4 o;
+    o.x = __fdiv_rn((float)(w & 0xffu), d);
+    o.y = __fdiv_rn((float)((w >> 8) & 0xffu), d);
+    o.z = __fdiv_rn((float)((w >> 16) & 0xffu), d);
+    o.w = __fdiv_rn((float)(w >> 24), d);
+    return o;
+}
+
+__device__ __forceinline__ float4 cvt_only(uint32_t w) {
+    float4 o;
+    o.x = (float)(w & 0xffu);
+    o.y = (float)((w >> 8) & 0xffu);
+    o.z = (float)((w >> 16) & 0xffu);
+    o.w = (float)(w >> 24);
+    return o;
+}
+
+// MODE 0: u8 / divisor, 1: u8 cast only, 2: f32 copy
+template <int MODE>
+__device__ __forceinline__ void move_frame(const uint8_t *__restrict__ src8,
+                                           uint8_t *__restrict__ dst8, int64_t frame_bytes,
+                                           float d) {
+    const int tid = threadIdx.x;
+    if (MODE == 2) {
+        if ((frame_bytes & 15) == 0) {
+            const uint4 *s = reinterpret_cast<const uint4 *>(src8);
+            uint4 *o = reinterpret_cast<uint4 *>(dst8);
+            const int nv = (int)(frame_bytes >> 4);
+            for (int i = tid; i < nv; i += kThreads) o[i] = s[i];
+        } else {
+            const uint32_t *s = reinterpret_cast<const uint32_t *>(src8);
+            uint32_t *o = reinterpret_cast<uint32_t *>(dst8);
+            const int nv = (int)(frame_bytes >> 2);
+            for (int i = tid; i < nv; i += kThreads) o[i] = s[i];
+        }
+        return;
+    }
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(src8);
+    float4 *dst = reinterpret_cast<float4 *>(dst8);
+    const int nd = (int)(frame_bytes >> 2);
+    for (int base = 0; base < nd; base += kThreads * kUnroll) {
+        uint32_t w[kUnroll];
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) {
+            int i = base + u * kThreads + tid;
+            w[u] = (i < nd) ? src[i] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) {
+            int i = base + u * kThreads + tid;
+            if (i < nd) dst[i] = (MODE == 0) ? cvt_div(w[u], d) : cvt_only(w[u]);
+        }
+    }
+}
+
+// grid.x = 2*B*k frame blocks followed by ceil(B/256) scalar blocks.
+template <int MODE, typename ActT>
+__global__ __launch_bounds__(kThreads) void k_batch_experiences(
+    pfrl_table_t tab, const uint8_t *__restrict__ frames, int64_t frame_bytes, float divisor,
+    const int32_t *__restrict__ entry_slots, int64_t B, GammaPow gp, uint8_t *__restrict__ out_state,
+    uint8_t *__restrict__ out_next, ActT *__restrict__ out_action, float *__restrict__ out_reward,
+    float *__restrict__ out_terminal, float *__restrict__ out_discount) {
+    const int64_t nf = B * tab.k;
+    const int64_t f = blockIdx.x;
+    const int64_t out_frame_bytes = (MODE == 2) ? frame_bytes : 4 * frame_bytes;
+    if (f < 2 * nf) {
+        const bool is_next = f >= nf;
+        const int64_t ff = is_next ? f - nf : f;
+        const int64_t b = ff / tab.k;
+        const int j = (int)(ff - b * tab.k);
+        const int64_t e = entry_slots[b];
+        int64_t slot;
+        if (!is_next) {
+            const int64_t t0 = tab.e_tids[e * tab.n];
+            slot = tab.t_state_ref[t0 * tab.k + j];
+        } else {
+            const int len = tab.e_len[e];
+            const int64_t tl = tab.e_tids[e * tab.n + len - 1];
+            slot = tab.t_next_ref[tl * tab.k + j];
+        }
+        uint8_t *dst = (is_next ? out_next : out_state) + ff * out_frame_bytes;
+        move_frame<MODE>(frames + slot * frame_bytes, dst, frame_bytes, divisor);
+        return;
+    }
+    // scalar collapse
+    const int64_t b = (f - 2 * nf) * kThreads + threadIdx.x;
+    if (b >= B) return;
+    const int64_t e = entry_slots[b];
+    const int len = tab.e_len[e];
+    double acc = 0.0;
+    bool any = false;
+    for (int i = 0; i < len; ++i) {
+        const int64_t t = tab.e_tids[e * tab.n + i];
+        acc = __dadd_rn(acc, __dmul_rn(gp.g[i], tab.t_reward[t]));
+        any |= tab.t_terminal[t] != 0;
+    }
+    out_reward[b] = (float)acc;
+    out_terminal[b] = any ? 1.0f : 0.0f;
+    out_discount[b] = (float)gp.g[len];
+    const int64_t t0 = tab.e_tids[e * tab.n];
+    const int ad = tab.act_dim > 0 ? tab.act_dim : 1;
+    const ActT *src = reinterpret_cast<const ActT *>(tab.t_action);
+    for (int i = 0; i < ad; ++i) out_action[b * ad + i] = src[t0 * ad + i];
+}
+
+}  // namespace
+
+extern "C" int pfrl_table_append(const pfrl_table_t *tab, int64_t n_rows, const int32_t *t_slots,
+                                 const int32_t *state_ref, const int32_t *next_ref,
+                                 const void *action, const double *reward, const uint8_t *terminal,
+                                 void *stream) {
+    PFRL_CHECK_ARG(tab && tab->k >= 1 && tab->k <= PFRL_MAX_STACK, "bad table.k");
+    if (n_rows <= 0) return 0;
+    const unsigned blocks = (unsigned)((n_rows + kThreads - 1) / kThreads);
+    if (tab->act_dim > 0)
+        hipLaunchKernelGGL(k_table_append<float>, dim3(blocks), dim3(kThreads), 0,
+                           (hipStream_t)stream, *tab, n_rows, t_slots, state_ref, next_ref,
+                           (const float *)action, reward, terminal);
+    else
+        hipLaunchKernelGGL(k_table_append<int64_t>, dim3(blocks), dim3(kThreads), 0,
+                           (hipStream_t)stream, *tab, n_rows, t_slots, state_ref, next_ref,
+                           (const int64_t *)action, reward, terminal);
+    PFRL_LAUNCH_CHECK();
+}
+
+extern "C" int pfrl_entries_append(const pfrl_table_t *tab, int64_t n_rows, const int32_t *e_slots,
+                                   const int32_t *tids, const int32_t *lens, void *stream) {
+    PFRL_CHECK_ARG(tab && tab->n >= 1 && tab->n <= PFRL_MAX_NSTEP, "bad table.n");
+    if (n_rows <= 0) return 0;
+    const unsigned blocks = (unsigned)((n_rows + kThreads - 1) / kThreads);
+    hipLaunchKernelGGL(k_entries_append, dim3(blocks), dim3(kThreads), 0, (hipStream_t)stream, *tab,
+                       n_rows, e_slots, tids, lens);
+    PFRL_LAUNCH_CHECK();
+}
+
+template <int MODE>
+static void launch_be(const pfrl_table_t *tab, const void *frames, int64_t frame_bytes,
+                      float divisor, const int32_t *entry_slots, int64_t B, const GammaPow &gp,
+                      float *out_state, float *out_next_state, void *out_action, float *out_reward,
+                      float *out_terminal, float *out_discount, hipStream_t stream) {
+    const unsigned blocks = (unsigned)(2 * B * tab->k + (B + kThreads - 1) / kThreads);
+    if (tab->act_dim > 0)
+        hipLaunchKernelGGL((k_batch_experiences<MODE, float>), dim3(blocks), dim3(kThreads), 0,
+                           stream, *tab, (const uint8_t *)frames, frame_bytes, divisor, entry_slots,
+                           B, gp, (uint8_t *)out_state, (uint8_t *)out_next_state,
+                           (float *)out_action, out_reward, out_terminal, out_discount);
+    else
+        hipLaunchKernelGGL((k_batch_experiences<MODE, int64_t>), dim3(blocks), dim3(kThreads), 0,
+                           stream, *tab, (const uint8_t *)frames, frame_bytes, divisor, entry_slots,
+                           B, gp, (uint8_t *)out_state, (uint8_t *)out_next_state,
+                           (int64_t *)out_action, out_reward, out_terminal, out_discount);
+}
+
+extern "C" int pfrl_batch_experiences(const pfrl_table_t *tab, const void *frames,
+                                      int64_t frame_bytes, int frame_is_f32, float divisor,
+                                      const int32_t *entry_slots, int64_t B,
+                                      const double *host_gamma_pow, float *out_state,
+                                      float *out_next_state, void *out_action, float *out_reward,
+                                      float *out_terminal, float *out_discount, void *stream) {
+    PFRL_CHECK_ARG(tab && tab->k >= 1 && tab->k <= PFRL_MAX_STACK, "bad table.k");
+    PFRL_CHECK_ARG(tab->n >= 1 && tab->n <= PFRL_MAX_NSTEP, "bad table.n");
+    PFRL_CHECK_ARG(frame_bytes > 0 && (frame_bytes & 3) == 0, "frame_bytes must be a multiple of 4");
+    if (B <= 0) return 0;
+    GammaPow gp;
+    for (int i = 0; i <= tab->n; ++i) gp.g[i] = host_gamma_pow[i];
+    hipStream_t s = (hipStream_t)stream;
+    if (frame_is_f32)
+        launch_be<2>(tab, frames, frame_bytes, divisor, entry_slots, B, gp, out_state,
+                     out_next_state, out_action, out_reward, out_terminal, out_discount, s);
+    else if (divisor == 1.0f)
+        launch_be<1>(tab, frames, frame_bytes, divisor, entry_slots, B, gp, out_state,
+                     out_next_state, out_action, out_reward, out_terminal, out_discount, s);
+    else
+        launch_be<0>(tab, frames, frame_bytes, divisor, entry_slots, B, gp, out_state,
+                     out_next_state, out_action, out_reward, out_terminal, out_discount, s);
+    PFRL_LAUNCH_CHECK();
+}

@@ -1,0 +1,227 @@
+// On-policy rollout kernels: GAE / return reverse scans, advantage statistics
+// with wavefront (64-lane) shuffle reductions, PPO minibatch assembly.
+// Layout [T][N] with the env index minor, so the 64 lanes of a wave read 64
+// consecutive envs of one time step (coalesced) and each lane owns one env's
+// sequential scan (pfrl/agents/ppo.py:36-47 is inherently sequential in t).
+#include "common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+
+template <int MODE>
+__global__ __launch_bounds__(kThreads) void k_gae_scan(int64_t T, int64_t N,
+                                                       const double *__restrict__ reward,
+                                                       const float *__restrict__ v_pred,
+                                                       const float *__restrict__ next_v_pred,
+                                                       const uint8_t *__restrict__ nonterminal,
+                                                       const uint8_t *__restrict__ cut, double gamma,
+                                                       double lambd, float *__restrict__ adv_out,
+                                                       float *__restrict__ vt_out) {
+    const int64_t e = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (e >= N) return;
+    const double gl = __dmul_rn(gamma, lambd);
+    if (MODE == 0) {
+        const float glf = (float)gl;
+        float adv = 0.0f;
+        for (int64_t t = T - 1; t >= 0; --t) {
+            const int64_t i = t * N + e;
+            if (cut[i]) adv = 0.0f;
+            const double gn = nonterminal[i] ? gamma : __dmul_rn(gamma, 0.0);
+            const float prod = __fmul_rn((float)gn, next_v_pred[i]);
+            const float s1 = __fadd_rn((float)reward[i], prod);
+            const float td = __fsub_rn(s1, v_pred[i]);
+            const float ga = __fmul_rn(glf, adv);
+            adv = __fadd_rn(td, ga);
+            adv_out[i] = adv;
+            vt_out[i] = __fadd_rn(adv, v_pred[i]);
+        }
+    } else {
+        double adv = 0.0;
+        for (int64_t t = T - 1; t >= 0; --t) {
+            const int64_t i = t * N + e;
+            if (cut[i]) adv = 0.0;
+            const double gn = nonterminal[i] ? gamma : __dmul_rn(gamma, 0.0);
+            const float prod = __fmul_rn((float)gn, next_v_pred[i]);
+            const double s1 = __dadd_rn(reward[i], (double)prod);
+            const double td = __dsub_rn(s1, (double)v_pred[i]);
+            const double ga = __dmul_rn(gl, adv);
+            adv = __dadd_rn(td, ga);
+            adv_out[i] = (float)adv;
+            vt_out[i] = (float)__dadd_rn(adv, (double)v_pred[i]);
+        }
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void k_a2c_returns(int64_t T, int64_t N,
+                                                          const float *__restrict__ rewards,
+                                                          const float *__restrict__ masks,
+                                                          const float *__restrict__ value_preds,
+                                                          float *__restrict__ returns, double gamma_d,
+                                                          double tau_d, int use_gae) {
+    const int64_t e = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (e >= N) return;
+    // Python floats meet f32 tensors: each scalar is rounded to f32 once.
+    const float gamma = (float)gamma_d;
+    if (use_gae) {
+        // a2c.py:151-161 ; gae starts as Python int 0; gamma*tau is an f64 product
+        float gae = 0.0f;
+        const float gt = (float)__dmul_rn(gamma_d, tau_d);
+        for (int64_t t = T - 1; t >= 0; --t) {
+            const int64_t i = t * N + e;
+            const float a = __fmul_rn(gamma, value_preds[i + N]);
+            const float b = __fmul_rn(a, masks[i]);
+            const float c = __fadd_rn(rewards[i], b);
+            const float delta = __fsub_rn(c, value_preds[i]);
+            const float g2 = __fmul_rn(gt, masks[i]);
+            const float g3 = __fmul_rn(g2, gae);
+            gae = __fadd_rn(delta, g3);
+            returns[i] = __fadd_rn(gae, value_preds[i]);
+        }
+    } else {
+        // a2c.py:162-167
+        float nxt = returns[T * N + e];
+        for (int64_t t = T - 1; t >= 0; --t) {
+            const int64_t i = t * N + e;
+            const float a = __fmul_rn(gamma, nxt);
+            const float b = __fmul_rn(a, masks[i]);
+            nxt = __fadd_rn(rewards[i], b);
+            returns[i] = nxt;
+        }
+    }
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+// Stage 1: per-block partial (sum, sum of squares) in f64.
+__global__ __launch_bounds__(kThreads) void k_adv_partial(const float *__restrict__ adv, int64_t n,
+                                                          double *__restrict__ partial) {
+    __shared__ double s1[kThreads / 64], s2[kThreads / 64];
+    double a = 0.0, b = 0.0;
+    const int64_t stride = (int64_t)gridDim.x * kThreads;
+    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += stride) {
+        const double x = (double)adv[i];
+        a += x;
+        b += x * x;
+    }
+    a = wave_sum(a);
+    b = wave_sum(b);
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+        s1[w] = a;
+        s2[w] = b;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double x = 0.0, y = 0.0;
+        for (int k = 0; k < kThreads / 64; ++k) {
+            x += s1[k];
+            y += s2[k];
+        }
+        partial[2 * blockIdx.x] = x;
+        partial[2 * blockIdx.x + 1] = y;
+    }
+}
+
+// Stage 2: one wave folds the partials; std with unbiased=False.
+__global__ __launch_bounds__(64) void k_adv_final(const double *__restrict__ partial, int nblocks,
+                                                  int64_t n, float *__restrict__ out) {
+    double a = 0.0, b = 0.0;
+    for (int i = threadIdx.x; i < nblocks; i += 64) {
+        a += partial[2 * i];
+        b += partial[2 * i + 1];
+    }
+    a = wave_sum(a);
+    b = wave_sum(b);
+    if (threadIdx.x == 0) {
+        const double mean = a / (double)n;
+        double var = b / (double)n - mean * mean;
+        if (var < 0.0) var = 0.0;
+        out[0] = (float)mean;
+        out[1] = (float)sqrt(var);
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void k_ppo_minibatch(
+    int64_t M, const int64_t *__restrict__ idx, const float *__restrict__ adv,
+    const float *__restrict__ mean_std, int standardize, const float *__restrict__ log_prob,
+    const float *__restrict__ v_pred, const float *__restrict__ v_teacher,
+    const int64_t *__restrict__ action, const int32_t *__restrict__ state_refs, int32_t k,
+    float *__restrict__ out_adv, float *__restrict__ out_logp, float *__restrict__ out_v,
+    float *__restrict__ out_vt, int64_t *__restrict__ out_action, int32_t *__restrict__ out_refs) {
+    const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (i >= M) return;
+    const int64_t p = idx[i];
+    float a = adv[p];
+    if (standardize) {
+        // ppo.py:494-495  (advs - mean_advs) / (std_advs + 1e-8)
+        const float den = __fadd_rn(mean_std[1], 1e-8f);
+        a = __fdiv_rn(__fsub_rn(a, mean_std[0]), den);
+    }
+    out_adv[i] = a;
+    out_logp[i] = log_prob[p];
+    out_v[i] = v_pred[p];
+    out_vt[i] = v_teacher[p];
+    out_action[i] = action[p];
+    for (int j = 0; j < k; ++j) out_refs[i * k + j] = state_refs[p * k + j];
+}
+
+}  // namespace
+
+extern "C" int pfrl_gae_scan(int64_t T, int64_t N, const double *reward, const float *v_pred,
+                             const float *next_v_pred, const uint8_t *nonterminal,
+                             const uint8_t *cut, double gamma, double lambd, int mode, float *adv,
+                             float *v_teacher, void *stream) {
+    PFRL_CHECK_ARG(T >= 0 && N >= 0, "pfrl_gae_scan: bad shape");
+    if (T == 0 || N == 0) return 0;
+    const unsigned blocks = (unsigned)((N + kThreads - 1) / kThreads);
+    if (mode == 0)
+        hipLaunchKernelGGL(k_gae_scan<0>, dim3(blocks), dim3(kThreads), 0, (hipStream_t)stream, T,
+                           N, reward, v_pred, next_v_pred, nonterminal, cut, gamma, lambd, adv,
+                           v_teacher);
+    else
+        hipLaunchKernelGGL(k_gae_scan<1>, dim3(blocks), dim3(kThreads), 0, (hipStream_t)stream, T,
+                           N, reward, v_pred, next_v_pred, nonterminal, cut, gamma, lambd, adv,
+                           v_teacher);
+    PFRL_LAUNCH_CHECK();
+}
+
+extern "C" int pfrl_a2c_returns(int64_t T, int64_t N, const float *rewards, const float *masks,
+                                const float *value_preds, float *returns, double gamma, double tau,
+                                int use_gae, void *stream) {
+    PFRL_CHECK_ARG(T >= 0 && N >= 0, "pfrl_a2c_returns: bad shape");
+    if (T == 0 || N == 0) return 0;
+    const unsigned blocks = (unsigned)((N + kThreads - 1) / kThreads);
+    hipLaunchKernelGGL(k_a2c_returns, dim3(blocks), dim3(kThreads), 0, (hipStream_t)stream, T, N,
+                       rewards, masks, value_preds, returns, gamma, tau, use_gae);
+    PFRL_LAUNCH_CHECK();
+}
+
+extern "C" int pfrl_adv_stats(const float *adv, int64_t n, float *out_mean_std, void *partial_ws,
+                              void *stream) {
+    PFRL_CHECK_ARG(n > 0 && partial_ws, "pfrl_adv_stats: need n > 0 and a workspace of 2*1024 f64");
+    int blocks = (int)((n + kThreads * 8 - 1) / (kThreads * 8));
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(k_adv_partial, dim3(blocks), dim3(kThreads), 0, (hipStream_t)stream, adv, n,
+                       (double *)partial_ws);
+    hipLaunchKernelGGL(k_adv_final, dim3(1), dim3(64), 0, (hipStream_t)stream,
+                       (const double *)partial_ws, blocks, n, out_mean_std);
+    PFRL_LAUNCH_CHECK();
+}
+
+extern "C" int pfrl_ppo_minibatch(int64_t M, const int64_t *idx, const float *adv,
+                                  const float *mean_std, int standardize, const float *log_prob,
+                                  const float *v_pred, const float *v_teacher,
+                                  const int64_t *action, const int32_t *state_refs, int32_t k,
+                                  float *out_adv, float *out_logp, float *out_v, float *out_vt,
+                                  int64_t *out_action, int32_t *out_refs, void *stream) {
+    if (M <= 0) return 0;
+    const unsigned blocks = (unsigned)((M + kThreads - 1) / kThreads);
+    hipLaunchKernelGGL(k_ppo_minibatch, dim3(blocks), dim3(kThreads), 0, (hipStream_t)stream, M,
+                       idx, adv, mean_std, standardize, log_prob, v_pred, v_teacher, action,
+                       state_refs, k, out_adv, out_logp, out_v, out_vt, out_action, out_refs);
+    PFRL_LAUNCH_CHECK();
+}

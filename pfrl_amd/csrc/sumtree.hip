@@ -1,0 +1,342 @@
+// Prioritized-replay sum/min trees (pfrl/collections/prioritized.py:135-323)
+// as per-level rings of NEP-50 tagged nodes in HBM.
+//
+// Every node value is a pure function of its two children
+//   sum: ((0 + left) + right) over the children present   (prioritized.py:140-151)
+//   min: left unless right < left
+// so a batch of leaf writes followed by a bottom-up re-reduction of the touched
+// paths yields exactly the state the reference reaches with its sequential
+// _write calls.  Structure changes (frame doubling / halving / re-rooting,
+// prioritized.py:207-242) are integer bookkeeping done by the host and handed
+// over in the pfrl_tree_t descriptor; the host starts a new launch whenever
+// the frame changes, so all leaves of one launch share one frame.
+//
+// These kernels are latency-bound (B sequential 20-level descents), not
+// bandwidth-bound: ~27 KB of tree traffic per DQN update.
+#include "common.h"
+
+namespace {
+
+constexpr int kMaxBatch = 1024;
+
+__device__ __forceinline__ int64_t node_idx(const pfrl_tree_t &T, int l, int64_t x) {
+    const int sh = T.log2_smax - l;
+    const int64_t M = sh > 0 ? ((int64_t)1 << sh) : 1;
+    const int64_t q = (x - T.origin[l]) >> l;
+    return T.level_off[l] + (q & (M - 1));
+}
+
+__device__ __forceinline__ TV reduce_sum(TV l, TV r) {
+    const bool lp = l.t != PFRL_TAG_ABSENT, rp = r.t != PFRL_TAG_ABSENT;
+    if (lp && rp) return tv_add(l, r);
+    if (lp) return l;
+    if (rp) return r;
+    return mk_tv(0.0, PFRL_TAG_ABSENT);
+}
+
+__device__ __forceinline__ TV reduce_min(TV l, TV r) {
+    const bool lp = l.t != PFRL_TAG_ABSENT, rp = r.t != PFRL_TAG_ABSENT;
+    if (lp && rp) return tv_lt(r, l) ? r : l;
+    if (lp) return l;
+    if (rp) return r;
+    return mk_tv(0.0, PFRL_TAG_ABSENT);
+}
+
+// Re-reduce the ancestors of leaf x (levels 1..log2_size) in both trees.
+// Must be called by every thread of the (single) workgroup.
+__device__ void repair_paths(const pfrl_tree_t &T, bool active, int64_t x) {
+    const int L = T.log2_size;
+    if (active && (x < T.base || x >= T.base + ((int64_t)1 << L))) active = false;
+    for (int l = 1; l <= L; ++l) {
+        __threadfence_block();
+        __syncthreads();
+        if (active) {
+            const int64_t half = (int64_t)1 << (l - 1);
+            const int64_t xl = x - ((x - T.origin[l]) & (((int64_t)1 << l) - 1));
+            const int64_t il = node_idx(T, l - 1, xl);
+            const int64_t ir = node_idx(T, l - 1, xl + half);
+            const int64_t ip = node_idx(T, l, x);
+            TV a = mk_tv(T.sum_val[il], T.sum_tag[il]);
+            TV b = mk_tv(T.sum_val[ir], T.sum_tag[ir]);
+            TV s = reduce_sum(a, b);
+            T.sum_val[ip] = s.v;
+            T.sum_tag[ip] = (uint8_t)s.t;
+            a = mk_tv(T.min_val[il], T.min_tag[il]);
+            b = mk_tv(T.min_val[ir], T.min_tag[ir]);
+            TV m = reduce_min(a, b);
+            T.min_val[ip] = m.v;
+            T.min_tag[ip] = (uint8_t)m.t;
+        }
+    }
+}
+
+__global__ __launch_bounds__(kMaxBatch) void k_tree_write(pfrl_tree_t T, int64_t n,
+                                                          const int64_t *__restrict__ x,
+                                                          const double *__restrict__ val,
+                                                          const uint8_t *__restrict__ tag,
+                                                          const uint8_t *__restrict__ use_maxp) {
+    const int i = threadIdx.x;
+    const bool active = i < n;
+    int64_t xi = 0;
+    if (active) {
+        xi = x[i];
+        TV p;
+        if (use_maxp && use_maxp[i])
+            p = mk_tv(*T.maxp_val, *T.maxp_tag);
+        else
+            p = mk_tv(val[i], tag[i]);
+        const int64_t il = node_idx(T, 0, xi);
+        T.sum_val[il] = p.v;
+        T.sum_tag[il] = (uint8_t)p.t;
+        T.min_val[il] = p.v;
+        T.min_tag[il] = (uint8_t)p.t;
+    }
+    repair_paths(T, active, xi);
+}
+
+// Shared tail of set_last_priority: typed max_priority scan, last-occurrence
+// de-duplication, leaf writes into both trees, path repair.
+__device__ void set_priorities_tail(const pfrl_tree_t &T, int64_t B, const int64_t *x, TV p,
+                                    int dedupe, double *s_v, uint8_t *s_t, int64_t *s_x) {
+    const int i = threadIdx.x;
+    const bool in = i < B;
+    int64_t xi = 0;
+    if (in) {
+        xi = x[i];
+        s_v[i] = p.v;
+        s_t[i] = (uint8_t)p.t;
+        s_x[i] = xi;
+    }
+    __syncthreads();
+    if (i == 0) {
+        // prioritized.py:114  self.max_priority = max(self.max_priority, p)
+        TV m = mk_tv(*T.maxp_val, *T.maxp_tag);
+        for (int j = 0; j < B; ++j) {
+            TV pj = mk_tv(s_v[j], s_t[j]);
+            if (tv_lt(m, pj)) m = pj;
+        }
+        *T.maxp_val = m.v;
+        *T.maxp_tag = (uint8_t)m.t;
+    }
+    bool active = in;
+    if (in && dedupe) {
+        for (int j = i + 1; j < B; ++j)
+            if (s_x[j] == xi) {
+                active = false;
+                break;
+            }
+    }
+    if (active) {
+        const int64_t il = node_idx(T, 0, xi);
+        T.sum_val[il] = p.v;
+        T.sum_tag[il] = (uint8_t)p.t;
+        T.min_val[il] = p.v;
+        T.min_tag[il] = (uint8_t)p.t;
+    }
+    repair_paths(T, active, xi);
+}
+
+__global__ __launch_bounds__(kMaxBatch) void k_tree_set_priorities(pfrl_tree_t T, int64_t B,
+                                                                   const int64_t *__restrict__ x,
+                                                                   const double *__restrict__ val,
+                                                                   const uint8_t *__restrict__ tag,
+                                                                   int dedupe) {
+    __shared__ double s_v[kMaxBatch];
+    __shared__ uint8_t s_t[kMaxBatch];
+    __shared__ int64_t s_x[kMaxBatch];
+    const int i = threadIdx.x;
+    TV p = mk_tv(0.0, PFRL_TAG_PY);
+    if (i < B) p = mk_tv(val[i], tag[i]);
+    set_priorities_tail(T, B, x, p, dedupe, s_v, s_t, s_x);
+}
+
+struct ErrCfg {
+    int has_min, has_max;
+    float error_min, error_max;
+    double pri_at_min, pri_at_max, eps, alpha;
+};
+
+__global__ __launch_bounds__(kMaxBatch) void k_tree_update_errors(pfrl_tree_t T, int64_t B,
+                                                                  const int64_t *__restrict__ x,
+                                                                  const float *__restrict__ err,
+                                                                  ErrCfg c, int dedupe) {
+    __shared__ double s_v[kMaxBatch];
+    __shared__ uint8_t s_t[kMaxBatch];
+    __shared__ int64_t s_x[kMaxBatch];
+    const int i = threadIdx.x;
+    TV p = mk_tv(0.0, PFRL_TAG_PY);
+    if (i < B) {
+        // pfrl/replay_buffers/prioritized.py:47-55 with np.float32 errors
+        const float e = err[i];
+        if (c.has_min && !(e > c.error_min)) {
+            p = mk_tv(c.pri_at_min, PFRL_TAG_PY);
+        } else if (c.has_max && !(e < c.error_max)) {
+            p = mk_tv(c.pri_at_max, PFRL_TAG_PY);
+        } else {
+            const float s = __fadd_rn(e, (float)c.eps);
+            // np.float32 ** float -> powf(s, (float)alpha); evaluated here as the
+            // correctly rounded result (glibc powf differs by 1 ulp in ~0.05 % of
+            // inputs -- see DESIGN.md "priority transform").
+            p = mk_tv((double)(float)pow((double)s, (double)(float)c.alpha), PFRL_TAG_F32);
+        }
+    }
+    set_priorities_tail(T, B, x, p, dedupe, s_v, s_t, s_x);
+}
+
+// One wave; lane 0 performs the B sequentially dependent draws
+// (prioritized.py:294-312), the wave then evaluates probabilities / weights.
+__global__ __launch_bounds__(64) void k_tree_sample(pfrl_tree_t T, int64_t B,
+                                                    const double *__restrict__ u01,
+                                                    int64_t *__restrict__ out_x,
+                                                    double *__restrict__ out_pri,
+                                                    uint8_t *__restrict__ out_pri_tag,
+                                                    double *__restrict__ out_prob,
+                                                    float *__restrict__ out_weight,
+                                                    double *__restrict__ out_total,
+                                                    uint8_t *__restrict__ out_total_tag,
+                                                    double *__restrict__ out_min_prob,
+                                                    int normalize, double beta, int64_t slot_mod,
+                                                    int32_t *__restrict__ out_slot) {
+    __shared__ double sib_v[PFRL_MAX_LEVELS];
+    __shared__ uint8_t sib_t[PFRL_MAX_LEVELS];
+    __shared__ uint8_t went_right[PFRL_MAX_LEVELS];
+    __shared__ double s_total_v, s_min_v;
+    __shared__ int s_total_t, s_min_t;
+    const int L = T.log2_size;
+    if (threadIdx.x == 0) {
+        const int64_t iroot = node_idx(T, L, T.base);
+        TV total = mk_tv(T.sum_val[iroot], T.sum_tag[iroot]);
+        TV minv = mk_tv(T.min_val[iroot], T.min_tag[iroot]);
+        s_total_v = total.v;
+        s_total_t = total.t;
+        s_min_v = minv.v;
+        s_min_t = minv.t;
+        for (int64_t i = 0; i < B; ++i) {
+            TV root = mk_tv(T.sum_val[iroot], T.sum_tag[iroot]);
+            // np.random.uniform(0.0, root) = 0.0 + (root - 0.0) * u
+            TV pos = mk_tv(__dadd_rn(0.0, __dmul_rn(root.v, u01[i])), PFRL_TAG_PY);
+            int64_t x = T.base;
+            for (int l = L; l >= 1; --l) {
+                const int64_t half = (int64_t)1 << (l - 1);
+                const int64_t il = node_idx(T, l - 1, x);
+                const int64_t ir = node_idx(T, l - 1, x + half);
+                TV lc = mk_tv(T.sum_val[il], T.sum_tag[il]);
+                TV rc = mk_tv(T.sum_val[ir], T.sum_tag[ir]);
+                TV left = lc.t != PFRL_TAG_ABSENT ? lc : mk_tv(0.0, PFRL_TAG_PY);
+                if (tv_lt(pos, left)) {
+                    sib_v[l] = rc.v;
+                    sib_t[l] = (uint8_t)rc.t;
+                    went_right[l] = 0;
+                } else {
+                    pos = tv_sub(pos, left);
+                    x += half;
+                    sib_v[l] = lc.v;
+                    sib_t[l] = (uint8_t)lc.t;
+                    went_right[l] = 1;
+                }
+            }
+            const int64_t ileaf = node_idx(T, 0, x);
+            out_x[i] = x;
+            out_pri[i] = T.sum_val[ileaf];
+            out_pri_tag[i] = T.sum_tag[ileaf];
+            // _write(ix, 0.0): zero the leaf, re-reduce the path (sum tree only)
+            T.sum_val[ileaf] = 0.0;
+            T.sum_tag[ileaf] = PFRL_TAG_PY;
+            TV cur = mk_tv(0.0, PFRL_TAG_PY);
+            for (int l = 1; l <= L; ++l) {
+                TV sib = mk_tv(sib_v[l], sib_t[l]);
+                cur = went_right[l] ? reduce_sum(sib, cur) : reduce_sum(cur, sib);
+                const int64_t ip = node_idx(T, l, x);
+                T.sum_val[ip] = cur.v;
+                T.sum_tag[ip] = (uint8_t)cur.t;
+            }
+            __threadfence_block();
+        }
+        *out_total = s_total_v;
+        *out_total_tag = (uint8_t)s_total_t;
+    }
+    __syncthreads();
+    // probabilities (prioritized.py:80-83 with uniform_ratio = 0)
+    const TV total = mk_tv(s_total_v, s_total_t);
+    double local_min = __builtin_huge_val();
+    for (int64_t i = threadIdx.x; i < B; i += 64) {
+        TV pr = tv_add(mk_tv(0.0, PFRL_TAG_PY), tv_div(mk_tv(out_pri[i], out_pri_tag[i]), total));
+        out_prob[i] = pr.v;
+        local_min = fmin(local_min, pr.v);
+    }
+    for (int off = 32; off > 0; off >>= 1) local_min = fmin(local_min, __shfl_xor(local_min, off));
+    double min_prob = tv_div(mk_tv(s_min_v, s_min_t), total).v;
+    if (threadIdx.x == 0) *out_min_prob = min_prob;
+    // weights (pfrl/replay_buffers/prioritized.py:57-66)
+    if (normalize == 1) min_prob = local_min;
+    for (int64_t i = threadIdx.x; i < B; i += 64) {
+        const double p = out_prob[i];
+        double w;
+        if (normalize)
+            w = pow(p / min_prob, -beta);
+        else
+            w = pow((double)T.length * p, -beta);
+        out_weight[i] = (float)w;
+        if (out_slot) out_slot[i] = (int32_t)(out_x[i] % slot_mod);
+    }
+}
+
+}  // namespace
+
+extern "C" int pfrl_tree_write(const pfrl_tree_t *tree, int64_t n, const int64_t *x,
+                               const double *val, const uint8_t *tag, const uint8_t *use_maxp,
+                               void *stream) {
+    PFRL_CHECK_ARG(tree && n <= kMaxBatch, "pfrl_tree_write: n must be <= 1024");
+    if (n <= 0) return 0;
+    int threads = (int)((n + 63) / 64 * 64);
+    hipLaunchKernelGGL(k_tree_write, dim3(1), dim3(threads), 0, (hipStream_t)stream, *tree, n, x,
+                       val, tag, use_maxp);
+    PFRL_LAUNCH_CHECK();
+}
+
+extern "C" int pfrl_tree_sample(const pfrl_tree_t *tree, int64_t B, const double *u01,
+                                int64_t *out_x, double *out_pri, uint8_t *out_pri_tag,
+                                double *out_prob, float *out_weight, double *out_total,
+                                uint8_t *out_total_tag, double *out_min_prob, int normalize,
+                                double beta, int64_t slot_mod, int32_t *out_slot, void *stream) {
+    PFRL_CHECK_ARG(tree && B >= 0, "pfrl_tree_sample: bad args");
+    PFRL_CHECK_ARG(tree->length >= B, "pfrl_tree_sample: fewer items than requested");
+    if (B == 0) return 0;
+    hipLaunchKernelGGL(k_tree_sample, dim3(1), dim3(64), 0, (hipStream_t)stream, *tree, B, u01,
+                       out_x, out_pri, out_pri_tag, out_prob, out_weight, out_total, out_total_tag,
+                       out_min_prob, normalize, beta, slot_mod > 0 ? slot_mod : 1, out_slot);
+    PFRL_LAUNCH_CHECK();
+}
+
+extern "C" int pfrl_tree_update_errors_f32(const pfrl_tree_t *tree, int64_t B, const int64_t *x,
+                                           const float *err, int has_min, float error_min,
+                                           double pri_at_min, int has_max, float error_max,
+                                           double pri_at_max, double eps, double alpha, int dedupe,
+                                           void *stream) {
+    PFRL_CHECK_ARG(tree && B <= kMaxBatch, "pfrl_tree_update_errors_f32: B must be <= 1024");
+    if (B <= 0) return 0;
+    ErrCfg c;
+    c.has_min = has_min;
+    c.has_max = has_max;
+    c.error_min = error_min;
+    c.error_max = error_max;
+    c.pri_at_min = pri_at_min;
+    c.pri_at_max = pri_at_max;
+    c.eps = eps;
+    c.alpha = alpha;
+    int threads = (int)((B + 63) / 64 * 64);
+    hipLaunchKernelGGL(k_tree_update_errors, dim3(1), dim3(threads), 0, (hipStream_t)stream, *tree,
+                       B, x, err, c, dedupe);
+    PFRL_LAUNCH_CHECK();
+}
+
+extern "C" int pfrl_tree_set_priorities(const pfrl_tree_t *tree, int64_t B, const int64_t *x,
+                                        const double *val, const uint8_t *tag, int dedupe,
+                                        void *stream) {
+    PFRL_CHECK_ARG(tree && B <= kMaxBatch, "pfrl_tree_set_priorities: B must be <= 1024");
+    if (B <= 0) return 0;
+    int threads = (int)((B + 63) / 64 * 64);
+    hipLaunchKernelGGL(k_tree_set_priorities, dim3(1), dim3(threads), 0, (hipStream_t)stream, *tree,
+                       B, x, val, tag, dedupe);
+    PFRL_LAUNCH_CHECK();
+}

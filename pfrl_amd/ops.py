@@ -1,0 +1,184 @@
+"""Thin torch-tensor front-end of the C ABI (include/pfrl_amd.h).
+
+Tensors only supply device pointers and the current HIP stream; every
+computation happens in the hand-written gfx950 kernels of pfrl_amd/csrc.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from pfrl_amd import _native
+from pfrl_amd._native import TableDesc, TreeDesc, check
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    if t is None:
+        return None
+    assert t.is_cuda and t.is_contiguous(), "device-contiguous tensor required"
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def frame_bytes_of(frames):
+    return frames[0].numel() * frames.element_size()
+
+
+def frames_scatter(frames, src, slots):
+    """frames[slots[i]] <- src[i]."""
+    n = slots.numel()
+    check(_native.lib().pfrl_frames_scatter(_ptr(frames), frame_bytes_of(frames), _ptr(src),
+                                            _ptr(slots), n, _stream()), "frames_scatter")
+
+
+def frames_synth_u8(frames, slots, seed, env_id0, step):
+    check(_native.lib().pfrl_frames_synth_u8(_ptr(frames), frame_bytes_of(frames), _ptr(slots),
+                                             slots.numel(), seed, env_id0, step, _stream()),
+          "frames_synth_u8")
+
+
+def batch_states(frames, refs, divisor=255.0, out=None):
+    """refs: int32 [M, k] -> f32 [M, k, *frame_shape]."""
+    M, k = refs.shape
+    fshape = tuple(frames.shape[1:])
+    if out is None:
+        out = torch.empty((M, k) + fshape, dtype=torch.float32, device=frames.device)
+    fb = frame_bytes_of(frames)
+    if frames.dtype == torch.uint8:
+        check(_native.lib().pfrl_batch_states_u8(_ptr(frames), fb, _ptr(refs), M * k,
+                                                 float(divisor), _ptr(out), _stream()),
+              "batch_states_u8")
+    elif frames.dtype == torch.float32:
+        check(_native.lib().pfrl_batch_states_f32(_ptr(frames), fb, _ptr(refs), M * k, _ptr(out),
+                                                  _stream()), "batch_states_f32")
+    else:
+        raise TypeError("frame store dtype must be uint8 or float32, got %s" % frames.dtype)
+    return out
+
+
+def make_table_desc(t_state_ref, t_next_ref, t_action, t_reward, t_terminal, e_tids, e_len, k, n,
+                    act_dim):
+    d = TableDesc()
+    d.t_state_ref = t_state_ref.data_ptr()
+    d.t_next_ref = t_next_ref.data_ptr()
+    d.t_action = t_action.data_ptr()
+    d.t_reward = t_reward.data_ptr()
+    d.t_terminal = t_terminal.data_ptr()
+    d.e_tids = e_tids.data_ptr()
+    d.e_len = e_len.data_ptr()
+    d.k, d.n, d.act_dim, d.reserved = k, n, act_dim, 0
+    return d
+
+
+def table_append(desc, t_slots, state_ref, next_ref, action, reward, terminal):
+    check(_native.lib().pfrl_table_append(ctypes.byref(desc), t_slots.numel(), _ptr(t_slots),
+                                          _ptr(state_ref), _ptr(next_ref), _ptr(action),
+                                          _ptr(reward), _ptr(terminal), _stream()), "table_append")
+
+
+def entries_append(desc, e_slots, tids, lens):
+    check(_native.lib().pfrl_entries_append(ctypes.byref(desc), e_slots.numel(), _ptr(e_slots),
+                                            _ptr(tids), _ptr(lens), _stream()), "entries_append")
+
+
+def batch_experiences(desc, frames, divisor, entry_slots, gamma_pow, out):
+    """Fused n-step collapse + state/next_state gathers.  ``out`` is a dict of
+    preallocated tensors: state, next_state, action, reward, is_state_terminal,
+    discount."""
+    B = entry_slots.numel()
+    gp = (ctypes.c_double * len(gamma_pow))(*gamma_pow)
+    check(_native.lib().pfrl_batch_experiences(
+        ctypes.byref(desc), _ptr(frames), frame_bytes_of(frames),
+        int(frames.dtype == torch.float32), float(divisor), _ptr(entry_slots), B,
+        ctypes.cast(gp, ctypes.c_void_p), _ptr(out["state"]), _ptr(out["next_state"]),
+        _ptr(out["action"]), _ptr(out["reward"]), _ptr(out["is_state_terminal"]),
+        _ptr(out["discount"]), _stream()), "batch_experiences")
+    return out
+
+
+def tree_write(desc, x, val, tag, use_maxp):
+    check(_native.lib().pfrl_tree_write(ctypes.byref(desc), x.numel(), _ptr(x), _ptr(val),
+                                        _ptr(tag), _ptr(use_maxp), _stream()), "tree_write")
+
+
+def tree_sample(desc, u01, out, normalize, beta, slot_mod=0):
+    B = u01.numel()
+    check(_native.lib().pfrl_tree_sample(
+        ctypes.byref(desc), B, _ptr(u01), _ptr(out["x"]), _ptr(out["pri"]), _ptr(out["pri_tag"]),
+        _ptr(out["prob"]), _ptr(out["weight"]), _ptr(out["total"]), _ptr(out["total_tag"]),
+        _ptr(out["min_prob"]), int(normalize), float(beta), int(slot_mod), _ptr(out.get("slot")),
+        _stream()), "tree_sample")
+    return out
+
+
+def tree_update_errors_f32(desc, x, err, error_min, pri_at_min, error_max, pri_at_max, eps, alpha,
+                           dedupe=True):
+    check(_native.lib().pfrl_tree_update_errors_f32(
+        ctypes.byref(desc), x.numel(), _ptr(x), _ptr(err),
+        int(error_min is not None), float(error_min or 0.0), float(pri_at_min or 0.0),
+        int(error_max is not None), float(error_max or 0.0), float(pri_at_max or 0.0),
+        float(eps), float(alpha), int(dedupe), _stream()), "tree_update_errors_f32")
+
+
+def tree_set_priorities(desc, x, val, tag, dedupe=True):
+    check(_native.lib().pfrl_tree_set_priorities(ctypes.byref(desc), x.numel(), _ptr(x), _ptr(val),
+                                                 _ptr(tag), int(dedupe), _stream()),
+          "tree_set_priorities")
+
+
+def gae_scan(reward, v_pred, next_v_pred, nonterminal, cut, gamma, lambd, mode=0):
+    """All inputs [T, N] on the device; reward float64, v f32, flags uint8."""
+    T, N = reward.shape
+    adv = torch.empty((T, N), dtype=torch.float32, device=reward.device)
+    vt = torch.empty_like(adv)
+    check(_native.lib().pfrl_gae_scan(T, N, _ptr(reward), _ptr(v_pred), _ptr(next_v_pred),
+                                      _ptr(nonterminal), _ptr(cut), float(gamma), float(lambd),
+                                      int(mode), _ptr(adv), _ptr(vt), _stream()), "gae_scan")
+    return adv, vt
+
+
+def a2c_returns(rewards, masks, value_preds, returns, gamma, tau, use_gae):
+    T, N = rewards.shape
+    check(_native.lib().pfrl_a2c_returns(T, N, _ptr(rewards), _ptr(masks), _ptr(value_preds),
+                                         _ptr(returns), float(gamma), float(tau), int(use_gae),
+                                         _stream()), "a2c_returns")
+    return returns
+
+
+_ws_cache = {}
+
+
+def adv_stats(adv):
+    """-> f32 tensor [2] = (mean, std(unbiased=False)), left on the device."""
+    key = adv.device
+    ws = _ws_cache.get(key)
+    if ws is None:
+        ws = _ws_cache[key] = torch.empty(2 * 1024, dtype=torch.float64, device=adv.device)
+    out = torch.empty(2, dtype=torch.float32, device=adv.device)
+    check(_native.lib().pfrl_adv_stats(_ptr(adv), adv.numel(), _ptr(out), _ptr(ws), _stream()),
+          "adv_stats")
+    return out
+
+
+def ppo_minibatch(idx, adv, mean_std, standardize, log_prob, v_pred, v_teacher, action,
+                  state_refs):
+    M = idx.numel()
+    k = state_refs.shape[1]
+    dev = adv.device
+    out = dict(
+        adv=torch.empty(M, dtype=torch.float32, device=dev),
+        log_prob=torch.empty(M, dtype=torch.float32, device=dev),
+        v_pred=torch.empty(M, dtype=torch.float32, device=dev),
+        v_teacher=torch.empty(M, dtype=torch.float32, device=dev),
+        action=torch.empty(M, dtype=torch.int64, device=dev),
+        refs=torch.empty((M, k), dtype=torch.int32, device=dev),
+    )
+    check(_native.lib().pfrl_ppo_minibatch(
+        M, _ptr(idx), _ptr(adv), _ptr(mean_std), int(standardize), _ptr(log_prob), _ptr(v_pred),
+        _ptr(v_teacher), _ptr(action), _ptr(state_refs), k, _ptr(out["adv"]),
+        _ptr(out["log_prob"]), _ptr(out["v_pred"]), _ptr(out["v_teacher"]), _ptr(out["action"]),
+        _ptr(out["refs"]), _stream()), "ppo_minibatch")
+    return out

@@ -1,0 +1,460 @@
+"""Parity of the hand-written gfx950 kernels (through the C ABI) against the
+CPU oracle and the golden vectors recorded from the reference.
+
+Bit-exact for every integer / index / tree quantity and for the f32 scans;
+the only tolerance-based checks are transcendental (pow) and statistics, with
+the tolerance written next to the assertion.
+"""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    from pfrl_amd import _native
+
+    _native.lib()  # fail loudly if the HIP library is missing
+    return torch.device("cuda:0")
+
+
+def _ops():
+    from pfrl_amd import ops
+
+    return ops
+
+
+# ---------------------------------------------------------------------------
+# observation store
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("shape,M,k", [((84, 84), 32, 4), ((84, 84), 256, 4), ((12, 10), 5, 4),
+                                       ((1, 84, 84), 7, 4), ((4,), 3, 1), ((33, 4), 2, 3)])
+@pytest.mark.parametrize("divisor", [255.0, 1.0])
+def test_batch_states_u8_bit_exact(dev, shape, M, k, divisor):
+    rs = np.random.RandomState(0)
+    F = 3 * M + 5
+    frames = rs.randint(0, 256, size=(F,) + shape).astype(np.uint8)
+    refs = rs.randint(0, F, size=(M, k)).astype(np.int32)
+    want = oracle.batch_states_u8(frames.reshape(F, -1), refs, divisor).reshape((M, k) + shape)
+    got = _ops().batch_states(torch.from_numpy(frames).to(dev), torch.from_numpy(refs).to(dev),
+                              divisor)
+    np.testing.assert_array_equal(got.cpu().numpy(), want)
+
+
+def test_batch_states_u8_golden_lut(dev):
+    g = np.load(os.path.join(GOLDEN, "batch_states_atari.npz"))
+    frames = np.arange(256, dtype=np.uint8).reshape(64, 4)
+    refs = np.arange(64, dtype=np.int32).reshape(64, 1)
+    got = _ops().batch_states(torch.from_numpy(frames).to(dev), torch.from_numpy(refs).to(dev),
+                              255.0)
+    np.testing.assert_array_equal(got.cpu().numpy().ravel(), g["lut"])
+    # padded copy of the golden stack layout case (frame of 120 B -> dword multiple)
+    fr = torch.from_numpy(g["frames"]).to(dev)
+    got = _ops().batch_states(fr, torch.from_numpy(g["refs"]).to(dev), 255.0)
+    np.testing.assert_array_equal(got.cpu().numpy().reshape(g["out"].shape), g["out"])
+
+
+@pytest.mark.parametrize("fe", [376, 4, 17, 1024])
+def test_batch_states_f32(dev, fe):
+    rs = np.random.RandomState(1)
+    frames = rs.randn(100, fe).astype(np.float32)
+    refs = rs.randint(0, 100, size=(64, 1)).astype(np.int32)
+    got = _ops().batch_states(torch.from_numpy(frames).to(dev), torch.from_numpy(refs).to(dev))
+    np.testing.assert_array_equal(got.cpu().numpy(), oracle.batch_states_f32(frames, refs)
+                                  .reshape(64, 1, fe))
+
+
+def test_frames_scatter_and_synth(dev):
+    ops = _ops()
+    frames = torch.zeros((50, 84, 84), dtype=torch.uint8, device=dev)
+    src = torch.randint(0, 256, (8, 84, 84), dtype=torch.uint8, device=dev)
+    slots = torch.tensor([3, 7, 49, 0, 11, 12, 13, 20], dtype=torch.int32, device=dev)
+    ops.frames_scatter(frames, src, slots)
+    assert torch.equal(frames[slots.long()], src)
+    assert int(frames.sum()) == int(src.sum())
+    a = torch.zeros((16, 84, 84), dtype=torch.uint8, device=dev)
+    b = torch.zeros((16, 84, 84), dtype=torch.uint8, device=dev)
+    sl = torch.arange(16, dtype=torch.int32, device=dev)
+    ops.frames_synth_u8(a, sl, 7, 0, 5)
+    ops.frames_synth_u8(b, sl, 7, 0, 5)
+    assert torch.equal(a, b)  # counter based: same key -> same frame
+    ops.frames_synth_u8(b, sl, 7, 0, 6)
+    assert not torch.equal(a, b)
+    m = a.float().mean().item()
+    assert 120 < m < 135  # iid U{0..255}
+    assert len(torch.unique(a)) == 256
+
+
+# ---------------------------------------------------------------------------
+# fused batch_experiences
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("n,k,B,u8", [(1, 4, 32, True), (3, 4, 32, True), (5, 1, 17, False),
+                                      (3, 2, 300, True)])
+def test_batch_experiences_fused(dev, n, k, B, u8):
+    ops = _ops()
+    rs = np.random.RandomState(n * 10 + k)
+    R, E, F = 500, 200, 700
+    fshape = (84, 84) if u8 else (24,)
+    frames = (rs.randint(0, 256, size=(F,) + fshape).astype(np.uint8) if u8
+              else rs.randn(F, *fshape).astype(np.float32))
+    t_state = rs.randint(0, F, size=(R, k)).astype(np.int32)
+    t_next = rs.randint(0, F, size=(R, k)).astype(np.int32)
+    t_action = rs.randint(0, 6, size=R).astype(np.int64)
+    t_reward = rs.randn(R)
+    t_term = (rs.rand(R) < 0.2).astype(np.uint8)
+    e_len = rs.randint(1, n + 1, size=E).astype(np.int32)
+    e_tids = -np.ones((E, n), dtype=np.int32)
+    for e in range(E):
+        e_tids[e, :e_len[e]] = rs.randint(0, R, size=e_len[e])
+    gamma = 0.99
+    gp = [gamma ** i for i in range(n + 1)]
+    T = lambda a: torch.from_numpy(a).to(dev)
+    # go through the append kernels so they are covered too
+    d_state = torch.zeros((R, k), dtype=torch.int32, device=dev)
+    d_next = torch.zeros((R, k), dtype=torch.int32, device=dev)
+    d_act = torch.zeros(R, dtype=torch.int64, device=dev)
+    d_rew = torch.zeros(R, dtype=torch.float64, device=dev)
+    d_term = torch.zeros(R, dtype=torch.uint8, device=dev)
+    d_tids = torch.zeros((E, n), dtype=torch.int32, device=dev)
+    d_len = torch.zeros(E, dtype=torch.int32, device=dev)
+    desc = ops.make_table_desc(d_state, d_next, d_act, d_rew, d_term, d_tids, d_len, k, n, 0)
+    perm = rs.permutation(R).astype(np.int32)
+    ops.table_append(desc, T(perm), T(t_state[perm]), T(t_next[perm]), T(t_action[perm]),
+                     T(t_reward[perm]), T(t_term[perm]))
+    eperm = rs.permutation(E).astype(np.int32)
+    ops.entries_append(desc, T(eperm), T(e_tids[eperm]), T(e_len[eperm]))
+    assert torch.equal(d_state.cpu(), torch.from_numpy(t_state))
+    assert torch.equal(d_tids.cpu(), torch.from_numpy(e_tids))
+    slots = rs.randint(0, E, size=B).astype(np.int32)
+    out = dict(
+        state=torch.empty((B, k) + fshape, dtype=torch.float32, device=dev),
+        next_state=torch.empty((B, k) + fshape, dtype=torch.float32, device=dev),
+        action=torch.empty(B, dtype=torch.int64, device=dev),
+        reward=torch.empty(B, dtype=torch.float32, device=dev),
+        is_state_terminal=torch.empty(B, dtype=torch.float32, device=dev),
+        discount=torch.empty(B, dtype=torch.float32, device=dev),
+    )
+    ops.batch_experiences(desc, T(frames), 255.0, T(slots), gp, out)
+    entries = [list(e_tids[s, :e_len[s]]) for s in slots]
+    want = oracle.batch_experiences_scalars(entries, t_reward, t_term, gamma, n)
+    np.testing.assert_array_equal(out["reward"].cpu().numpy(), want["reward"])
+    np.testing.assert_array_equal(out["is_state_terminal"].cpu().numpy(),
+                                  want["is_state_terminal"])
+    np.testing.assert_array_equal(out["discount"].cpu().numpy(), want["discount"])
+    np.testing.assert_array_equal(out["action"].cpu().numpy(), t_action[want["first"]])
+    srefs = t_state[want["first"]]
+    nrefs = t_next[want["last"]]
+    flat = frames.reshape(F, -1)
+    if u8:
+        ws = oracle.batch_states_u8(flat, srefs, 255.0)
+        wn = oracle.batch_states_u8(flat, nrefs, 255.0)
+    else:
+        ws = oracle.batch_states_f32(flat, srefs)
+        wn = oracle.batch_states_f32(flat, nrefs)
+    np.testing.assert_array_equal(out["state"].cpu().numpy().reshape(ws.shape), ws)
+    np.testing.assert_array_equal(out["next_state"].cpu().numpy().reshape(wn.shape), wn)
+
+
+# ---------------------------------------------------------------------------
+# prioritized buffer (sum / min trees)
+# ---------------------------------------------------------------------------
+def _np_scalar(v, t):
+    return np.float32(v) if t == 2 else (np.float64(v) if t == 3 else float(v))
+
+
+def _check_tree_dump(buf, which, v, t):
+    f = buf.frame
+    off = 0
+    for l in range(f.log2_size + 1):
+        n = f.size >> l
+        gv, gt = buf.dump_level(which, l)
+        np.testing.assert_array_equal(gt, t[off:off + n], err_msg="tags level %d" % l)
+        np.testing.assert_array_equal(gv, v[off:off + n], err_msg="values level %d" % l)
+        off += n
+    assert off == len(v)
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "pbuf_trace_*.npz"))),
+                         ids=os.path.basename)
+def test_prioritized_buffer_golden_trace(dev, path):
+    """Sampled indices, removed priorities, root sum/min, max_priority and the
+    frame bounds equal the reference's after every operation; full node dump
+    (values + type tags) equal at the end."""
+    from pfrl_amd.collections.prioritized import PrioritizedBuffer
+
+    g = np.load(path)
+    cap = int(g["meta"][1])
+    buf = PrioritizedBuffer(None if cap < 0 else cap, device=dev, max_size=4096)
+    iu = ia = iset = ismp = 0
+    payload = 0
+    check_every = 1 if len(g["op_kind"]) <= 600 else 7
+    for k, (kind, n) in enumerate(zip(g["op_kind"], g["op_n"])):
+        if kind in (0, 1):
+            v, t = g["app_v"][ia], int(g["app_t"][ia])
+            ia += 1
+            buf.append(payload, None if t == 0 else _np_scalar(v, t))
+            payload += 1
+        elif kind == 4:
+            buf.popleft()
+        else:
+            out = buf.sample_device(int(n), u01=g["u01"][iu:iu + n], normalize=2, beta=0.5)
+            x = out["x"].cpu().numpy()
+            np.testing.assert_array_equal(x - buf.frame.head, g["idx"][iu:iu + n])
+            np.testing.assert_array_equal(out["pri"].cpu().numpy(), g["pri_v"][iu:iu + n])
+            np.testing.assert_array_equal(out["pri_tag"].cpu().numpy(), g["pri_t"][iu:iu + n])
+            np.testing.assert_allclose(out["prob"].cpu().numpy(), g["prob"][iu:iu + n], rtol=1e-6)
+            assert float(out["total"].item()) == g["total_v"][ismp]
+            assert int(out["total_tag"].item()) == g["total_t"][ismp]
+            np.testing.assert_allclose(float(out["min_prob"].item()), g["min_prob"][ismp],
+                                       rtol=1e-6)
+            newp = [_np_scalar(v, t) for v, t in zip(g["set_v"][iset:iset + n],
+                                                     g["set_t"][iset:iset + n])]
+            buf.set_last_priority(newp)
+            iu += n
+            iset += n
+            ismp += 1
+        assert len(buf) == g["length"][k]
+        if len(buf):
+            assert buf.frame.bounds == (g["ixl"][k], g["ixr"][k]), k
+        if k % check_every == 0 or kind == 2:
+            st = buf.root_stats()
+            if st is not None:
+                assert st[0] == (g["sum_v"][k], g["sum_t"][k]), k
+                assert st[1] == (g["min_v"][k], g["min_t"][k]), k
+                assert st[2] == (g["maxp_v"][k], g["maxp_t"][k]), k
+    _check_tree_dump(buf, 0, g["final_sum_v"], g["final_sum_t"])
+    _check_tree_dump(buf, 1, g["final_min_v"], g["final_min_t"])
+
+
+@pytest.mark.parametrize("cap,n_ops,batch", [(3000, 9000, 32), (257, 4000, 64)])
+def test_prioritized_buffer_vs_oracle_random(dev, cap, n_ops, batch):
+    """Larger seeded differential run against the C oracle (which is pinned to
+    the reference by tests/test_oracle_golden.py)."""
+    from pfrl_amd.collections.prioritized import PrioritizedBuffer
+
+    rs = np.random.RandomState(cap)
+    buf = PrioritizedBuffer(cap, device=dev)
+    orc = oracle.OraclePrioritizedBuffer(cap)
+    for k in range(n_ops):
+        r = rs.rand()
+        if len(orc) >= batch and r < 0.05:
+            u = rs.random_sample(batch)
+            want = orc.sample(u)
+            out = buf.sample_device(batch, u01=u, normalize=1, beta=0.4)
+            np.testing.assert_array_equal(out["x"].cpu().numpy() - buf.frame.head, want["indices"])
+            np.testing.assert_array_equal(out["pri"].cpu().numpy(), want["priorities"])
+            np.testing.assert_array_equal(out["pri_tag"].cpu().numpy(), want["priority_tags"])
+            w_ref = (want["probabilities"] / want["probabilities"].min()) ** -0.4
+            # float tolerance: weights are pow() results, 1e-5 relative (north star)
+            np.testing.assert_allclose(out["weight"].cpu().numpy(), w_ref, rtol=1e-5)
+            vals = rs.rand(batch) * 2 + 1e-3
+            tags = rs.choice([1, 2, 2, 2, 3], size=batch)
+            vals = np.where(tags == 2, vals.astype(np.float32).astype(np.float64), vals)
+            orc.set_last_priority(vals, tags)
+            buf.set_last_priority([_np_scalar(v, t) for v, t in zip(vals, tags)])
+        else:
+            orc.append(k)
+            buf.append(k)
+        if k % 500 == 0 or k == n_ops - 1:
+            st, so = buf.root_stats(), orc.stats()
+            assert st[0] == so["sum"] and st[1] == so["min"] and st[2] == so["max_priority"], k
+            assert buf.frame.bounds == so["bounds"]
+    for l in range(buf.frame.log2_size + 1):
+        for which in (0, 1):
+            gv, gt = buf.dump_level(which, l)
+            ov, ot = orc.dump_level(which, 1 << l)
+            np.testing.assert_array_equal(gt, ot)
+            np.testing.assert_array_equal(gv, ov)
+
+
+def test_update_errors_f32_priority_transform(dev):
+    """(clip(err) + eps) ** alpha on the device.  Type tags and the clipped
+    (Python-float) branches are exact; the np.float32 ** float branch is the
+    correctly rounded power, which may differ from this host's libm powf by one
+    ulp in a small fraction of inputs -- asserted here."""
+    from pfrl_amd.collections.prioritized import PrioritizedBuffer
+
+    rs = np.random.RandomState(3)
+    n = 1024
+    buf = PrioritizedBuffer(n, device=dev)
+    for i in range(n):
+        buf.append(i)
+    u = rs.random_sample(n)
+    out = buf.sample_device(n, u01=u)
+    err = (rs.rand(n) * 1.5).astype(np.float32)
+    err[:8] = [0.0, 1.0, 1.5, 0.99999994, 1e-8, 0.5, 2.0, 1.0000001]
+    eps, alpha = 0.01, 0.6
+    buf.update_errors_device(torch.from_numpy(err).to(dev), 0, (0 + eps) ** alpha, 1,
+                             (1 + eps) ** alpha, eps, alpha)
+    x = out["x"].cpu().numpy() - buf.frame.head
+    lv, lt = buf.dump_level(0, 0)
+    wv, wt = oracle.priority_from_errors_f32(err, 0, 1, eps, alpha)
+    got_v, got_t = lv[x], lt[x]
+    np.testing.assert_array_equal(got_t, wt)
+    py = wt == 1
+    np.testing.assert_array_equal(got_v[py], wv[py])
+    f32 = ~py
+    a, b = got_v[f32].astype(np.float32), wv[f32].astype(np.float32)
+    ulp = np.abs(a.view(np.int32).astype(np.int64) - b.view(np.int32).astype(np.int64))
+    assert ulp.max() <= 1
+    assert (ulp != 0).mean() < 0.01
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "per_trace_*.npz"))),
+                         ids=os.path.basename)
+def test_prioritized_golden_weights_and_tree(dev, path):
+    """Wrapper-level golden traces: with the reference's priorities injected,
+    indices / tree are bit-exact and weights are within 1e-5."""
+    from pfrl_amd.collections.prioritized import PrioritizedBuffer
+
+    g = np.load(path)
+    seed, cap, n_steps, batch, n_envs = (int(v) for v in g["meta"])
+    alpha, beta0, betasteps, eps = (float(v) for v in g["hyper"])
+    norm = int(g["normalize_by_max"])
+    buf = PrioritizedBuffer(None if cap < 0 else cap, device=dev, max_size=4096)
+    ns = oracle.OracleNStep(n_steps, max_envs=n_envs)  # host window logic is tested elsewhere
+    tid = iu = ismp = idump = 0
+    beta = beta0
+    for k, (kind, a, b) in enumerate(zip(g["op_kind"], g["op_a"], g["op_b"])):
+        emitted = []
+        if kind == 0:
+            emitted = ns.append(a, tid, b)
+            tid += 1
+        elif kind == 1:
+            emitted = ns.stop(a)
+        else:
+            out = buf.sample_device(batch, u01=g["u01"][iu:iu + batch], normalize=norm, beta=beta)
+            np.testing.assert_array_equal(out["x"].cpu().numpy() - buf.frame.head,
+                                          g["idx"][iu:iu + batch])
+            # tolerance: pow() of f64 probabilities, rounded to f32
+            np.testing.assert_allclose(out["weight"].cpu().numpy(), g["weight"][iu:iu + batch],
+                                       rtol=1e-5)
+            beta = min(1.0, beta + (1.0 - beta0) / betasteps)
+            buf.set_last_priority([_np_scalar(v, t) for v, t in
+                                   zip(g["new_pri_v"][iu:iu + batch], g["new_pri_t"][iu:iu + batch])])
+            iu += batch
+            ismp += 1
+        for e in emitted:
+            buf.append(tuple(e))
+        assert len(buf) == g["length"][k]
+        if idump < len(g["dump_op"]) and g["dump_op"][idump] == k:
+            lo, hi = g["dump_off"][idump], g["dump_off"][idump + 1]
+            if hi > lo:
+                _check_tree_dump(buf, 0, g["dump_sum_v"][lo:hi], g["dump_sum_t"][lo:hi])
+                _check_tree_dump(buf, 1, g["dump_min_v"][lo:hi], g["dump_min_t"][lo:hi])
+            idump += 1
+
+
+# ---------------------------------------------------------------------------
+# rollout kernels
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("T,N", [(128, 512), (5, 3), (1, 70), (37, 257)])
+def test_gae_scan_bit_exact(dev, mode, T, N):
+    rs = np.random.RandomState(T * 7 + N + mode)
+    gamma, lambd = 0.99, 0.95
+    reward = rs.choice([-1.0, 0.0, 1.0], size=(T, N)) if N % 2 else rs.randn(T, N)
+    v = rs.randn(T, N).astype(np.float32)
+    nv = rs.randn(T, N).astype(np.float32)
+    done = rs.rand(T, N) < 0.05
+    reset = rs.rand(T, N) < 0.03
+    cut = done | reset
+    cut[T - 1] = True
+    want_adv = np.zeros((T, N))
+    want_vt = np.zeros((T, N))
+    for e in range(N):
+        t0 = 0
+        for t in range(T):
+            if cut[t, e]:
+                sl = slice(t0, t + 1)
+                a, b = oracle.gae_fragment(reward[sl, e], v[sl, e], nv[sl, e],
+                                           (~done[sl, e]).astype(np.float64), gamma, lambd, mode)
+                want_adv[sl, e], want_vt[sl, e] = a, b
+                t0 = t + 1
+    T_ = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    adv, vt = _ops().gae_scan(T_(reward.astype(np.float64)), T_(v), T_(nv),
+                              T_((~done).astype(np.uint8)), T_(cut.astype(np.uint8)), gamma, lambd,
+                              mode)
+    np.testing.assert_array_equal(adv.cpu().numpy(), want_adv.astype(np.float32))
+    np.testing.assert_array_equal(vt.cpu().numpy(), want_vt.astype(np.float32))
+
+
+def test_gae_scan_golden(dev):
+    g = np.load(os.path.join(GOLDEN, "gae.npz"))
+    for c in range(len(g["mode"])):
+        lo, hi = g["off"][c], g["off"][c + 1]
+        T = hi - lo
+        T_ = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev).reshape(T, 1)
+        cut = np.zeros(T, dtype=np.uint8)
+        cut[-1] = 1
+        adv, vt = _ops().gae_scan(T_(g["reward"][lo:hi].astype(np.float64)), T_(g["v"][lo:hi]),
+                                  T_(g["nv"][lo:hi]), T_((g["nonterm"][lo:hi] != 0).astype(np.uint8)),
+                                  T_(cut), float(g["gamma"][c]), float(g["lambd"][c]),
+                                  int(g["mode"][c]))
+        np.testing.assert_array_equal(adv.cpu().numpy().ravel(), g["adv"][lo:hi].astype(np.float32))
+        np.testing.assert_array_equal(vt.cpu().numpy().ravel(), g["vt"][lo:hi].astype(np.float32))
+
+
+def test_a2c_returns_golden(dev):
+    g = np.load(os.path.join(GOLDEN, "a2c_returns.npz"))
+    for c in range(4):
+        T, N, use_gae = (int(x) for x in g["c%d_meta" % c])
+        gamma, tau = (float(x) for x in g["c%d_hyper" % c])
+        vp = g["c%d_value_preds" % c].copy()
+        ret = np.zeros((T + 1, N), dtype=np.float32)
+        if use_gae:
+            vp[T] = g["c%d_next_value" % c]
+        else:
+            ret[T] = g["c%d_next_value" % c]
+        T_ = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+        d_ret = T_(ret)
+        _ops().a2c_returns(T_(g["c%d_rewards" % c]), T_(g["c%d_masks" % c]), T_(vp), d_ret, gamma,
+                           tau, use_gae)
+        want = g["c%d_returns" % c]
+        np.testing.assert_array_equal(d_ret.cpu().numpy()[:T], want[:T])
+
+
+@pytest.mark.parametrize("n", [1, 63, 65536, 1000003])
+def test_adv_stats(dev, n):
+    rs = np.random.RandomState(n % 1000)
+    adv = (rs.randn(n) * 3 + 0.7).astype(np.float32)
+    out = _ops().adv_stats(torch.from_numpy(adv).to(dev)).cpu().numpy()
+    m, s = oracle.adv_stats(adv)
+    # tolerance: torch.std_mean itself is only reproducible to f32 rounding
+    assert abs(out[0] - m) <= 1e-6 * max(1.0, abs(m))
+    assert abs(out[1] - s) <= 1e-6 * max(1.0, abs(s))
+    ref_std, ref_mean = torch.std_mean(torch.from_numpy(adv), unbiased=False)
+    assert abs(out[0] - ref_mean.item()) <= 1e-5 and abs(out[1] - ref_std.item()) <= 1e-5
+
+
+def test_ppo_minibatch(dev):
+    rs = np.random.RandomState(4)
+    D, M, k = 4096, 1000, 4
+    adv = rs.randn(D).astype(np.float32)
+    lp = rs.randn(D).astype(np.float32)
+    v = rs.randn(D).astype(np.float32)
+    vt = rs.randn(D).astype(np.float32)
+    act = rs.randint(0, 6, size=D).astype(np.int64)
+    refs = rs.randint(0, 9999, size=(D, k)).astype(np.int32)
+    idx = rs.randint(0, D, size=M).astype(np.int64)
+    T_ = lambda a: torch.from_numpy(a).to(dev)
+    ms = _ops().adv_stats(T_(adv))
+    out = _ops().ppo_minibatch(T_(idx), T_(adv), ms, True, T_(lp), T_(v), T_(vt), T_(act),
+                               T_(refs))
+    ms_h = ms.cpu().numpy()
+    want = (adv[idx] - ms_h[0]) / (ms_h[1] + np.float32(1e-8))
+    np.testing.assert_array_equal(out["adv"].cpu().numpy(), want.astype(np.float32))
+    np.testing.assert_array_equal(out["log_prob"].cpu().numpy(), lp[idx])
+    np.testing.assert_array_equal(out["v_teacher"].cpu().numpy(), vt[idx])
+    np.testing.assert_array_equal(out["action"].cpu().numpy(), act[idx])
+    np.testing.assert_array_equal(out["refs"].cpu().numpy(), refs[idx])

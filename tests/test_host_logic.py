@@ -1,0 +1,60 @@
+"""CPU tests of the host-side integer bookkeeping (no kernels involved) and of
+the C-ABI library's exported symbols."""
+import glob
+import os
+import re
+
+import numpy as np
+import pytest
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "pbuf_trace_*.npz"))),
+                         ids=os.path.basename)
+def test_tree_frame_matches_reference_bounds(path):
+    """TreeFrame reproduces TreeQueue.bounds / length after every operation
+    (pfrl/collections/prioritized.py:207-242)."""
+    from pfrl_amd.collections.tree_frame import TreeFrame, smax_log2_for_capacity
+
+    g = np.load(path)
+    cap = int(g["meta"][1])
+    f = TreeFrame()
+    max_log2 = 0
+    for k, kind in enumerate(g["op_kind"]):
+        if kind in (0, 1):
+            if cap >= 0 and f.length == cap:
+                f.popleft()
+            f.append()
+        elif kind == 4:
+            f.popleft()
+        assert f.length == g["length"][k]
+        if f.length:
+            assert f.bounds == (g["ixl"][k], g["ixr"][k]), k
+            assert f.base <= f.head < f.base + f.size
+            assert f.head + f.length <= f.base + f.size
+            max_log2 = max(max_log2, f.log2_size)
+            # every live level is aligned to the frame start
+            for l in range(1, f.log2_size + 1):
+                assert (f.base - f.origin[l]) % (1 << l) == 0
+    if cap >= 0:
+        assert max_log2 <= smax_log2_for_capacity(cap)
+
+
+def test_c_abi_exports_every_declared_symbol():
+    """The shared library loads without a GPU and exports every function that
+    include/pfrl_amd.h declares (no compute calls here)."""
+    from pfrl_amd import _native
+
+    if not _native.available():
+        _native.build()
+    lib = _native.lib()
+    header = open(os.path.join(ROOT, "include", "pfrl_amd.h")).read()
+    declared = set(re.findall(r"\b(pfrl_[a-z0-9_]+)\s*\(", header))
+    declared = {d for d in declared if not d.endswith("_t")}
+    assert declared, "no declarations parsed"
+    for name in sorted(declared):
+        assert hasattr(lib, name), "library does not export %s" % name
+    assert set(_native.EXPORTS) == declared
+    assert lib.pfrl_amd_version() >= 100
