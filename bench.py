@@ -1,0 +1,284 @@
+#!/usr/bin/env python
+"""Headline benchmark: env-steps/s of the batched DQN hot path on MI355X.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one batch of synthetic input: 256
+Atari-shaped envs step once (84x84 uint8 frames generated on the device into
+the HBM frame ring) -> batch_act (gather u8->f32, Q forward, eps-greedy) ->
+batch_observe (256 appends, 64 updates at the reference schedule: sample 32,
+fused batch_experiences gather, Huber loss, backward, centered RMSprop) ->
+env.reset(not_end).  BASELINE.json config[1]: DQN, Nature CNN,
+ReplayBuffer(10**6) prefilled to capacity, B=32, update_interval=4,
+batch_accumulator='sum', fp32 network.  Nothing is skipped inside the timed
+region.  N GPUs = N ranks with 256 envs each (weak scaling), per-GPU-local
+replay, one flat RCCL all-reduce of the gradient per update.
+
+Prints ONE JSON line on rank 0 (see DESIGN.md section "Measurement").
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def parse_args():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=20)
+    p.add_argument("--warmup", type=int, default=5)
+    p.add_argument("--num-envs", type=int, default=256)
+    p.add_argument("--capacity", type=int, default=10 ** 6)
+    p.add_argument("--minibatch", type=int, default=32)
+    p.add_argument("--update-interval", type=int, default=4)
+    p.add_argument("--seed", type=int, default=0)
+    p.add_argument("--prefill", type=int, default=None,
+                   help="transitions to prefill (default: capacity, i.e. full buffer)")
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--cpu-baseline-seconds", type=float, default=12.0)
+    p.add_argument("--profile-every", type=int, default=4,
+                   help="bracket every n-th batch_experiences launch with HIP events")
+    return p.parse_args()
+
+
+def build_agent(args, device, rank):
+    import pfrl_amd as pfrl
+    from pfrl_amd import agents, explorers, replay_buffers
+    from pfrl_amd.device_store import DeviceFrameStore
+    from pfrl_amd.envs import SyntheticAtariVectorEnv
+    from pfrl_amd.initializers import init_chainer_default
+    from pfrl_amd.q_functions import DiscreteActionValueHead
+
+    N = args.num_envs
+    n_actions = 6
+    pfrl.utils.set_random_seed(args.seed * 64 + rank)
+    # examples/atari/train_dqn_batch_ale.py:35-41 (arch "nature")
+    q_func = torch.nn.Sequential(
+        pfrl.nn.LargeAtariCNN(),
+        init_chainer_default(torch.nn.Linear(512, n_actions)),
+        DiscreteActionValueHead(),
+    )
+    # ... :199-206
+    opt = torch.optim.RMSprop(q_func.parameters(), lr=2.5e-4, alpha=0.95, momentum=0.0, eps=1e-2,
+                              centered=True)
+    frame_slots = args.capacity + N * 16 + 8192
+    store = DeviceFrameStore(frame_slots, (84, 84), torch.uint8, device, stack=4)
+    env = SyntheticAtariVectorEnv(N, store=store, seed=args.seed, env_id0=rank * N,
+                                  n_actions=n_actions)
+    rbuf = replay_buffers.ReplayBuffer(args.capacity, num_steps=1)
+    explorer = explorers.LinearDecayEpsilonGreedy(
+        1.0, 0.01, 10 ** 6, lambda: np.random.randint(n_actions))
+
+    def phi(x):  # :229-231
+        return np.asarray(x, dtype=np.float32) / 255
+
+    agent = agents.DQN(
+        q_func, opt, rbuf, gpu=device.index, gamma=0.99, explorer=explorer,
+        replay_start_size=5 * 10 ** 4, target_update_interval=3 * 10 ** 4, clip_delta=True,
+        update_interval=args.update_interval, minibatch_size=args.minibatch,
+        batch_accumulator="sum", phi=phi)
+    agent.grad_reducer.broadcast_parameters(agent.model)
+    agent.sync_target_network()
+    return agent, env, rbuf
+
+
+def one_step(agent, env, obss, num_envs):
+    actions = agent.batch_act(obss)
+    obss, rs, dones, infos = env.step(actions)
+    resets = np.zeros(num_envs, dtype=bool)
+    agent.batch_observe(obss, rs, dones, resets)
+    not_end = np.logical_not(dones)
+    return env.reset(not_end)
+
+
+def prefill(agent, env, obss, num_envs, target):
+    """Fill the replay buffer through the normal act/observe path with updates
+    disabled (the timed region then runs at full-buffer steady state)."""
+    saved = agent.replay_updater.replay_start_size
+    agent.replay_updater.replay_start_size = 1 << 62
+    while len(agent.replay_buffer) < target:
+        obss = one_step(agent, env, obss, num_envs)
+    agent.replay_updater.replay_start_size = saved
+    return obss
+
+
+def cpu_baseline(args, seconds):
+    """The same workload through the CPU oracle (oracle/pfrl_oracle.c = plain C
+    restatement of the reference's data path) plus the same network in torch
+    CPU, on this box's host cores, for a bounded sample.  kind = "port"."""
+    import oracle
+    import pfrl_amd as pfrl
+    from pfrl_amd.agents.dqn import compute_value_loss
+    from pfrl_amd.initializers import init_chainer_default
+    from pfrl_amd.q_functions import DiscreteActionValueHead
+    from pfrl_amd.utils.random import sample_n_k
+
+    N, B = args.num_envs, args.minibatch
+    cores = torch.get_num_threads()
+    rs = np.random.RandomState(0)
+    F = 20000
+    frames = rs.randint(0, 256, size=(F, 84 * 84)).astype(np.uint8)
+    cap = 100000  # host memory bound, stated in the sample description
+    t_state = rs.randint(0, F, size=(cap, 4)).astype(np.int32)
+    t_next = rs.randint(0, F, size=(cap, 4)).astype(np.int32)
+    rewards = rs.choice([-1.0, 0.0, 1.0], size=cap)
+    terms = (rs.rand(cap) < 0.002).astype(np.uint8)
+    actions = rs.randint(0, 6, size=cap)
+    torch.manual_seed(0)
+    q = torch.nn.Sequential(pfrl.nn.LargeAtariCNN(),
+                            init_chainer_default(torch.nn.Linear(512, 6)),
+                            DiscreteActionValueHead())
+    tq = torch.nn.Sequential(pfrl.nn.LargeAtariCNN(), torch.nn.Linear(512, 6),
+                             DiscreteActionValueHead())
+    tq.load_state_dict(q.state_dict())
+    opt = torch.optim.RMSprop(q.parameters(), lr=2.5e-4, alpha=0.95, eps=1e-2, centered=True)
+    n_updates_per_step = N // args.update_interval
+    t0 = time.perf_counter()
+    steps = 0
+    data_s = 0.0
+    while True:
+        d0 = time.perf_counter()
+        refs = rs.randint(0, F, size=(N, 4)).astype(np.int32)
+        x = oracle.batch_states_u8(frames, refs, 255.0).reshape(N, 4, 84, 84)
+        data_s += time.perf_counter() - d0
+        with torch.no_grad():
+            q(torch.from_numpy(x)).greedy_actions.numpy()
+        for _ in range(n_updates_per_step):
+            d0 = time.perf_counter()
+            idx = sample_n_k(cap, B)
+            ents = [[int(i)] for i in idx]
+            sc = oracle.batch_experiences_scalars(ents, rewards, terms, 0.99, 1)
+            s = oracle.batch_states_u8(frames, t_state[idx], 255.0).reshape(B, 4, 84, 84)
+            ns = oracle.batch_states_u8(frames, t_next[idx], 255.0).reshape(B, 4, 84, 84)
+            data_s += time.perf_counter() - d0
+            qout = q(torch.from_numpy(s))
+            y = qout.evaluate_actions(torch.from_numpy(actions[idx]))
+            with torch.no_grad():
+                nq = tq(torch.from_numpy(ns)).max
+                t = (torch.from_numpy(sc["reward"]) + torch.from_numpy(sc["discount"])
+                     * (1.0 - torch.from_numpy(sc["is_state_terminal"])) * nq)
+            loss = compute_value_loss(y, t, True, "sum")
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+        steps += 1
+        el = time.perf_counter() - t0
+        if el >= seconds:
+            break
+    return {
+        "value": round(steps * N / el, 2), "unit": "env-steps/s", "cores": cores, "kind": "port",
+        "data_path_only_value": round(steps * N / max(data_s, 1e-9), 2),
+        "sample": "%d batched steps of %d envs (%d updates of B=%d) in %.1f s; oracle C data path "
+                  "(single thread) + torch-CPU Nature CNN (%d threads); replay capacity 1e5 on the "
+                  "host" % (steps, N, steps * n_updates_per_step, B, el, cores),
+    }
+
+
+def main():
+    args = parse_args()
+    from pfrl_amd import _native, ops
+    from pfrl_amd.distributed import init_process_group_from_env
+
+    rank, world, local = init_process_group_from_env()
+    assert torch.cuda.is_available(), "bench.py needs the MI355X"
+    if world != args.gpus:
+        assert world == 1 and args.gpus == 1, "--gpus must equal WORLD_SIZE (use torchrun for N>1)"
+    device = torch.device("cuda", local)
+    torch.cuda.set_device(device)
+    _native.lib()
+
+    agent, env, rbuf = build_agent(args, device, rank)
+    N = args.num_envs
+    obss = env.reset()
+    target = args.prefill if args.prefill is not None else args.capacity
+    target = max(min(target, args.capacity), 5 * 10 ** 4)
+    t_fill = time.perf_counter()
+    obss = prefill(agent, env, obss, N, target)
+    torch.cuda.synchronize()
+    t_fill = time.perf_counter() - t_fill
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+
+    for _ in range(args.warmup):
+        obss = one_step(agent, env, obss, N)
+    optim_before = agent.optim_t
+    ops.PROFILE_EVERY = args.profile_every
+    ops.PROFILE_EVENTS = []
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        obss = one_step(agent, env, obss, N)
+    barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    ops.PROFILE_EVERY = 0
+    n_updates = agent.optim_t - optim_before
+
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    # dominant HIP kernel: the fused batch_experiences gather
+    evs = ops.PROFILE_EVENTS
+    k_ms = [a.elapsed_time(b) for a, b in evs]
+    B, k, fb = args.minibatch, 4, 84 * 84
+    alg_bytes = B * 2 * k * (fb + 4 * fb)
+    roofline = None
+    if k_ms:
+        avg_s = float(np.mean(k_ms)) * 1e-3
+        achieved = alg_bytes / avg_s / 1e9
+        roofline = {
+            "bound": "hbm", "kernel": "k_batch_experiences<0,long>",
+            "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+            "bytes_per_launch": alg_bytes, "avg_launch_us": round(avg_s * 1e6, 2),
+            "launches_timed": len(k_ms),
+        }
+
+    if rank == 0:
+        total_env_steps = world * N * args.steps
+        value = total_env_steps / elapsed
+        out = {
+            "metric": "env-steps/sec whole node (DQN 256 envs per GPU)",
+            "value": round(value, 1), "unit": "env-steps/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {
+                "workload": "BASELINE.json configs[1]: DQN Nature-CNN, %d synthetic Atari-shaped "
+                            "envs/GPU (84x84x4 u8), ReplayBuffer(%d) on device prefilled to %d, "
+                            "B=%d, update_interval=%d (replay ratio %.1f sampled transitions per "
+                            "env-step), RMSprop centered, batch_accumulator=sum"
+                            % (N, args.capacity, len(rbuf), args.minibatch, args.update_interval,
+                               args.minibatch / args.update_interval),
+                "global_envs": world * N, "updates_in_timed_region": n_updates,
+                "parallelism": "env-sharded dp%d, per-GPU-local replay" % world,
+                "prefill_s": round(t_fill, 1),
+            },
+            "roofline": roofline,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(args, args.cpu_baseline_seconds)
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

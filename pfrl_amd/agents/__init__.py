@@ -1,0 +1,2 @@
+from pfrl_amd.agents.dqn import DQN  # NOQA
+from pfrl_amd.agents.double_dqn import DoubleDQN  # NOQA

@@ -1,0 +1,15 @@
+"""Double DQN target (reference pfrl/agents/double_dqn.py:12-40): the online
+network picks argmax_a Q(s', a), the target network evaluates it."""
+from pfrl_amd.agents import dqn
+from pfrl_amd.utils.contexts import evaluating
+
+
+class DoubleDQN(dqn.DQN):
+    def _compute_target_values(self, exp_batch):
+        batch_next_state = exp_batch["next_state"]
+        with evaluating(self.model):
+            next_qout = self.model(batch_next_state)
+        target_next_qout = self.target_model(batch_next_state)
+        next_q_max = target_next_qout.evaluate_actions(next_qout.greedy_actions)
+        return (exp_batch["reward"]
+                + exp_batch["discount"] * (1.0 - exp_batch["is_state_terminal"]) * next_q_max)

@@ -1,0 +1,314 @@
+"""Deep Q-Network on the device-resident replay path.
+
+Mirrors ``pfrl.agents.dqn.DQN`` (/root/reference/pfrl/agents/dqn.py): same
+constructor (:181-206), ``batch_act`` (:490-507), ``batch_observe`` with the
+per-env append -> update interleaving (:509-549), ``update`` (:316-365), the
+Huber / MSE losses (:44-104), target synchronisation (:307-314), statistics
+(:812-819) and snapshots (:794-810).  Differences are in *where* data lives,
+not in what is computed:
+
+* minibatches come from ``batch_experiences`` = one fused HIP launch over the
+  HBM replay store (no per-update H2D of fp32 stacks);
+* TD errors for prioritized replay are handed to ``update_errors`` as a device
+  tensor (the reference does ``.cpu().numpy()``, dqn.py:449-454);
+* ``q_record`` / ``loss_record`` keep device tensors and are reduced only when
+  ``get_statistics()`` is called (the reference blocks on a D2H copy per update,
+  dqn.py:358,445);
+* with ``torch.distributed`` initialised, gradients are all-reduced (RCCL over
+  xGMI) before the optimizer step -- env-sharded data parallelism.
+"""
+import collections
+import copy
+import os
+from logging import getLogger
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from pfrl_amd import agent
+from pfrl_amd.replay_buffer import DeviceExperienceBatch, ReplayUpdater, batch_experiences
+from pfrl_amd.utils.batch_states import batch_states
+from pfrl_amd.utils.clip_l2_grad_norm import clip_l2_grad_norm_
+from pfrl_amd.utils.contexts import evaluating
+from pfrl_amd.utils.copy_param import synchronize_parameters
+
+
+def _mean_or_nan(xs):
+    return float(np.mean(xs)) if len(xs) else np.nan
+
+
+def compute_value_loss(y, t, clip_delta=True, batch_accumulator="mean"):
+    """Huber(delta=1) or half-MSE value loss, 'mean' or 'sum' over the batch
+    (reference :44-68)."""
+    assert batch_accumulator in ("mean", "sum")
+    y = y.reshape(-1, 1)
+    t = t.reshape(-1, 1)
+    if clip_delta:
+        return F.smooth_l1_loss(y, t, reduction=batch_accumulator)
+    return F.mse_loss(y, t, reduction=batch_accumulator) / 2
+
+
+def compute_weighted_value_loss(y, t, weights, clip_delta=True, batch_accumulator="mean"):
+    """Importance-weighted variant (reference :71-104)."""
+    assert batch_accumulator in ("mean", "sum")
+    y = y.reshape(-1, 1)
+    t = t.reshape(-1, 1)
+    if clip_delta:
+        losses = F.smooth_l1_loss(y, t, reduction="none")
+    else:
+        losses = F.mse_loss(y, t, reduction="none") / 2
+    losses = losses.reshape(-1)
+    loss_sum = torch.sum(losses * weights.to(losses.device))
+    if batch_accumulator == "mean":
+        return loss_sum / y.shape[0]
+    return loss_sum
+
+
+def make_target_model_as_copy(model):
+    target_model = copy.deepcopy(model)
+    target_model.eval()
+    return target_model
+
+
+class _DeviceRecord:
+    """Bounded record of the most recent ``maxlen`` scalars kept as device
+    tensors; reduced on demand."""
+
+    def __init__(self, maxlen):
+        self.maxlen = maxlen
+        self._chunks = collections.deque()
+        self._count = 0
+
+    def extend(self, t):
+        t = t.detach().reshape(-1)
+        self._chunks.append(t)
+        self._count += t.numel()
+        while self._count - self._chunks[0].numel() >= self.maxlen:
+            self._count -= self._chunks.popleft().numel()
+
+    def values(self):
+        if not self._chunks:
+            return np.zeros(0, dtype=np.float32)
+        allv = torch.cat([c.float() for c in self._chunks]).cpu().numpy()
+        return allv[-self.maxlen:]
+
+    def __len__(self):
+        return min(self._count, self.maxlen)
+
+
+class DQN(agent.AttributeSavingMixin, agent.BatchAgent):
+    """Deep Q-Network algorithm (see module docstring for the argument list;
+    it is the reference's)."""
+
+    saved_attributes = ("model", "target_model", "optimizer")
+
+    def __init__(self, q_function, optimizer, replay_buffer, gamma, explorer, gpu=None,
+                 replay_start_size=50000, minibatch_size=32, update_interval=1,
+                 target_update_interval=10000, clip_delta=True, phi=lambda x: x,
+                 target_update_method="hard", soft_update_tau=1e-2, n_times_update=1,
+                 batch_accumulator="mean", episodic_update_len=None, logger=getLogger(__name__),
+                 batch_states=batch_states, recurrent=False, max_grad_norm=None):
+        self.model = q_function
+        if gpu is not None and gpu >= 0:
+            assert torch.cuda.is_available()
+            self.device = torch.device("cuda:{}".format(gpu))
+            self.model.to(self.device)
+        else:
+            self.device = torch.device("cpu")
+        if recurrent:
+            raise NotImplementedError("recurrent DQN is outside the batched hot path")
+        self.replay_buffer = replay_buffer
+        if hasattr(replay_buffer, "bind"):
+            replay_buffer.bind(self.device, phi)
+        self.optimizer = optimizer
+        self.gamma = gamma
+        self.explorer = explorer
+        self.gpu = gpu
+        self.target_update_interval = target_update_interval
+        self.clip_delta = clip_delta
+        self.phi = phi
+        self.target_update_method = target_update_method
+        self.soft_update_tau = soft_update_tau
+        self.batch_accumulator = batch_accumulator
+        assert batch_accumulator in ("mean", "sum")
+        self.logger = logger
+        self.batch_states = batch_states
+        self.recurrent = False
+        self.replay_updater = ReplayUpdater(
+            replay_buffer=replay_buffer, update_func=self.update, batchsize=minibatch_size,
+            episodic_update=False, episodic_update_len=episodic_update_len,
+            n_times_update=n_times_update, replay_start_size=replay_start_size,
+            update_interval=update_interval)
+        self.minibatch_size = minibatch_size
+        self.episodic_update_len = episodic_update_len
+        self.replay_start_size = replay_start_size
+        self.update_interval = update_interval
+        self.max_grad_norm = max_grad_norm
+        assert target_update_interval % update_interval == 0, \
+            "target_update_interval should be a multiple of update_interval"
+        self.t = 0
+        self.optim_t = 0
+        self._cumulative_steps = 0
+        self.target_model = make_target_model_as_copy(self.model)
+        self.q_record = _DeviceRecord(1000)
+        self.loss_record = _DeviceRecord(100)
+        self.batch_last_obs = []
+        self.batch_last_action = []
+        if (self.replay_buffer.capacity is not None
+                and self.replay_buffer.capacity < self.replay_updater.replay_start_size):
+            raise ValueError("Replay start size cannot exceed replay buffer capacity.")
+        # data-parallel gradient averaging (no-op for a single process)
+        from pfrl_amd.distributed import GradientAllReducer
+
+        self.grad_reducer = GradientAllReducer(self.model)
+
+    @property
+    def cumulative_steps(self):
+        return self._cumulative_steps
+
+    def sync_target_network(self):
+        synchronize_parameters(src=self.model, dst=self.target_model,
+                               method=self.target_update_method, tau=self.soft_update_tau)
+
+    # -- learning -------------------------------------------------------------
+    def update(self, experiences, errors_out=None):
+        """One minibatch update (reference :316-365)."""
+        if isinstance(experiences, DeviceExperienceBatch):
+            has_weight = experiences.has_weight
+        else:
+            has_weight = "weight" in experiences[0][0]
+        exp_batch = batch_experiences(experiences, device=self.device, phi=self.phi,
+                                      gamma=self.gamma, batch_states=self.batch_states)
+        if has_weight and "weights" not in exp_batch:
+            exp_batch["weights"] = torch.tensor([e[0]["weight"] for e in experiences],
+                                                device=self.device, dtype=torch.float32)
+        want_errors = has_weight or errors_out is not None
+        loss, delta = self._compute_loss(exp_batch, want_errors=want_errors)
+        if errors_out is not None:
+            del errors_out[:]
+            errors_out.extend(delta.cpu().numpy())
+        if has_weight:
+            self.replay_buffer.update_errors(delta if errors_out is None else errors_out)
+        self.loss_record.extend(loss)
+        self.optimizer.zero_grad()
+        loss.backward()
+        self.grad_reducer.all_reduce()
+        if self.max_grad_norm is not None:
+            clip_l2_grad_norm_(self.model.parameters(), self.max_grad_norm)
+        self.optimizer.step()
+        self.optim_t += 1
+
+    def _compute_target_values(self, exp_batch):
+        target_next_qout = self.target_model(exp_batch["next_state"])
+        next_q_max = target_next_qout.max
+        return (exp_batch["reward"]
+                + exp_batch["discount"] * (1.0 - exp_batch["is_state_terminal"]) * next_q_max)
+
+    def _compute_y_and_t(self, exp_batch):
+        batch_size = exp_batch["reward"].shape[0]
+        qout = self.model(exp_batch["state"])
+        batch_q = torch.reshape(qout.evaluate_actions(exp_batch["action"]), (batch_size, 1))
+        with torch.no_grad():
+            batch_q_target = torch.reshape(self._compute_target_values(exp_batch), (batch_size, 1))
+        return batch_q, batch_q_target
+
+    def _compute_loss(self, exp_batch, errors_out=None, want_errors=False):
+        """Returns (loss, |y - t| per sample or None).  ``errors_out`` keeps the
+        reference's list-filling form for callers that use it directly."""
+        y, t = self._compute_y_and_t(exp_batch)
+        self.q_record.extend(y)
+        delta = None
+        if errors_out is not None or want_errors:
+            delta = torch.abs(y.detach() - t)
+            if delta.ndim == 2:
+                delta = torch.sum(delta, dim=1)
+            if errors_out is not None:
+                del errors_out[:]
+                errors_out.extend(delta.cpu().numpy())
+        if "weights" in exp_batch:
+            loss = compute_weighted_value_loss(y, t, exp_batch["weights"],
+                                               clip_delta=self.clip_delta,
+                                               batch_accumulator=self.batch_accumulator)
+        else:
+            loss = compute_value_loss(y, t, clip_delta=self.clip_delta,
+                                      batch_accumulator=self.batch_accumulator)
+        return loss, delta
+
+    # -- acting ---------------------------------------------------------------
+    def _evaluate_model(self, batch_obs):
+        batch_xs = self.batch_states(batch_obs, self.device, self.phi)
+        return self.model(batch_xs)
+
+    def batch_act(self, batch_obs):
+        with torch.no_grad(), evaluating(self.model):
+            batch_av = self._evaluate_model(batch_obs)
+            batch_argmax = batch_av.greedy_actions.detach().cpu().numpy()
+        if self.training:
+            select = self.explorer.select_action
+            batch_action = [
+                select(self.t, lambda i=i: batch_argmax[i], action_value=None)
+                for i in range(len(batch_obs))
+            ]
+            self.batch_last_obs = list(batch_obs)
+            self.batch_last_action = list(batch_action)
+        else:
+            batch_action = batch_argmax
+        return batch_action
+
+    def _batch_observe_train(self, batch_obs, batch_reward, batch_done, batch_reset):
+        rbuf = self.replay_buffer
+        updater = self.replay_updater
+        for i in range(len(batch_obs)):
+            self.t += 1
+            self._cumulative_steps += 1
+            if self.t % self.target_update_interval == 0:
+                self.sync_target_network()
+            if self.batch_last_obs[i] is not None:
+                assert self.batch_last_action[i] is not None
+                rbuf.append(state=self.batch_last_obs[i], action=self.batch_last_action[i],
+                            reward=batch_reward[i], next_state=batch_obs[i], next_action=None,
+                            is_state_terminal=batch_done[i], env_id=i)
+                if batch_reset[i] or batch_done[i]:
+                    self.batch_last_obs[i] = None
+                    self.batch_last_action[i] = None
+                    rbuf.stop_current_episode(env_id=i)
+            updater.update_if_necessary(self.t)
+
+    def _batch_observe_eval(self, batch_obs, batch_reward, batch_done, batch_reset):
+        pass
+
+    def batch_observe(self, batch_obs, batch_reward, batch_done, batch_reset):
+        if self.training:
+            return self._batch_observe_train(batch_obs, batch_reward, batch_done, batch_reset)
+        return self._batch_observe_eval(batch_obs, batch_reward, batch_done, batch_reset)
+
+    def _can_start_replay(self):
+        return len(self.replay_buffer) >= self.replay_start_size
+
+    def stop_episode(self):
+        pass
+
+    # -- persistence / statistics ----------------------------------------------
+    def save_snapshot(self, dirname):
+        self.save(dirname)
+        torch.save(self.t, os.path.join(dirname, "t.pt"))
+        torch.save(self.optim_t, os.path.join(dirname, "optim_t.pt"))
+        torch.save(self._cumulative_steps, os.path.join(dirname, "_cumulative_steps.pt"))
+        self.replay_buffer.save(os.path.join(dirname, "replay_buffer.pkl"))
+
+    def load_snapshot(self, dirname):
+        self.load(dirname)
+        self.t = torch.load(os.path.join(dirname, "t.pt"))
+        self.optim_t = torch.load(os.path.join(dirname, "optim_t.pt"))
+        self._cumulative_steps = torch.load(os.path.join(dirname, "_cumulative_steps.pt"))
+        self.replay_buffer.load(os.path.join(dirname, "replay_buffer.pkl"))
+
+    def get_statistics(self):
+        return [
+            ("average_q", _mean_or_nan(self.q_record.values())),
+            ("average_loss", _mean_or_nan(self.loss_record.values())),
+            ("cumulative_steps", self.cumulative_steps),
+            ("n_updates", self.optim_t),
+            ("rlen", len(self.replay_buffer)),
+        ]

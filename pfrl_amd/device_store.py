@@ -1,0 +1,161 @@
+"""Device-resident observation storage.
+
+The reference keeps observations as Python objects: ``VectorFrameStack`` hands
+out ``LazyFrames`` that share the last k-1 frame arrays by identity
+(/root/reference/pfrl/wrappers/vector_frame_stack.py:93-105,
+atari_wrappers.py:251-272) and every consumer re-materialises them with
+``np.concatenate``.  Here a frame is written ONCE into a ring in HBM and an
+observation is just k slot numbers (int32); consecutive observations share
+slots instead of array identities.
+"""
+import numpy as np
+import torch
+
+from pfrl_amd import ops
+
+
+class DeviceFrameStore:
+    """Ring of ``n_slots`` frames of ``frame_shape`` / ``dtype`` in HBM."""
+
+    def __init__(self, n_slots, frame_shape, dtype=torch.uint8, device=None, stack=4):
+        if device is None:
+            device = torch.device("cuda", torch.cuda.current_device())
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("DeviceFrameStore lives in HBM; got device %s" % device)
+        assert dtype in (torch.uint8, torch.float32)
+        self.n_slots = int(n_slots)
+        self.frame_shape = tuple(int(s) for s in frame_shape)
+        self.dtype = dtype
+        self.stack = int(stack)
+        nbytes = int(np.prod(self.frame_shape)) * (1 if dtype == torch.uint8 else 4)
+        if nbytes % 4:
+            raise ValueError("frame size must be a multiple of 4 bytes, got %d" % nbytes)
+        self.frame_bytes = nbytes
+        self.frames = torch.zeros((self.n_slots,) + self.frame_shape, dtype=dtype,
+                                  device=self.device)
+        self.next_seq = 0  # frames written so far; slot = seq % n_slots
+
+    def alloc(self, n):
+        """Reserve ``n`` consecutive ring positions -> (seqs int64, slots int32)."""
+        seqs = np.arange(self.next_seq, self.next_seq + n, dtype=np.int64)
+        self.next_seq += n
+        return seqs, (seqs % self.n_slots).astype(np.int32)
+
+    def oldest_live_seq(self):
+        return self.next_seq - self.n_slots
+
+    def write(self, src, slots_dev):
+        """frames[slots] <- src (device tensor [n, *frame_shape])."""
+        ops.frames_scatter(self.frames, src.contiguous(), slots_dev)
+
+    def gather(self, refs_dev, divisor=255.0, out=None):
+        return ops.batch_states(self.frames, refs_dev, divisor, out=out)
+
+
+class DeviceObs:
+    """One observation = k frame slots of a DeviceFrameStore."""
+
+    __slots__ = ("store", "refs", "min_seq")
+
+    def __init__(self, store, refs, min_seq):
+        self.store = store
+        self.refs = refs        # numpy int32 [k]
+        self.min_seq = min_seq  # oldest frame sequence number in the stack
+
+    def to_numpy(self):
+        """Materialise on the host (API compatibility / debugging; one D2H)."""
+        idx = torch.from_numpy(self.refs.astype(np.int64)).to(self.store.device)
+        x = self.store.frames[idx].cpu().numpy()
+        if x.shape[0] == 1:
+            return x[0]
+        # LazyFrames concatenates on axis 0 (atari_wrappers.py:262-266)
+        if x.ndim >= 3 and x.shape[1] == 1:
+            return np.concatenate(list(x), axis=0)
+        return x
+
+    def __array__(self, dtype=None, copy=None):
+        out = self.to_numpy()
+        return out.astype(dtype) if dtype is not None else out
+
+
+class DeviceObsBatch:
+    """A batch of observations living in a DeviceFrameStore; what a device
+    VectorEnv returns from reset()/step().  Behaves as a sequence of
+    DeviceObs so drivers written for lists of observations keep working."""
+
+    __slots__ = ("store", "refs", "min_seq", "_refs_dev")
+
+    def __init__(self, store, refs, min_seq, refs_dev=None):
+        self.store = store
+        self.refs = refs          # numpy int32 [N, k]
+        self.min_seq = min_seq    # numpy int64 [N]
+        self._refs_dev = refs_dev
+
+    def __len__(self):
+        return self.refs.shape[0]
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return DeviceObsBatch(self.store, self.refs[i], self.min_seq[i])
+        return DeviceObs(self.store, self.refs[i], self.min_seq[i])
+
+    def __iter__(self):
+        for i in range(len(self)):
+            yield DeviceObs(self.store, self.refs[i], self.min_seq[i])
+
+    def refs_device(self, staging=None):
+        if self._refs_dev is None:
+            if staging is not None:
+                (self._refs_dev,) = staging.upload([self.refs])
+            else:
+                self._refs_dev = torch.from_numpy(np.ascontiguousarray(self.refs)).to(
+                    self.store.device)
+        return self._refs_dev
+
+
+# ---------------------------------------------------------------------------
+# phi recognition
+# ---------------------------------------------------------------------------
+class ScaleU8:
+    """Explicit marker for the Atari feature extractor
+    ``phi(x) = np.asarray(x, dtype=np.float32) / divisor``
+    (examples/atari/train_dqn_batch_ale.py:229-231).  Callable on host data."""
+
+    def __init__(self, divisor=255.0):
+        self.divisor = float(divisor)
+
+    def __call__(self, x):
+        return np.asarray(x, dtype=np.float32) / np.float32(self.divisor)
+
+
+def recognise_phi(phi, sample_obs):
+    """Classify ``phi`` by evaluating it on a real observation.
+
+    Returns the divisor d such that phi(x) == float32(x) / d elementwise with
+    the same shape (d == 1.0 covers cast-only and identity), or None if phi is
+    something else.  Arbitrary Python callables cannot run on the device; the
+    three forms used by the reference's example scripts can."""
+    if isinstance(phi, ScaleU8):
+        return phi.divisor
+    x = np.asarray(sample_obs)
+    try:
+        y = np.asarray(phi(sample_obs))
+    except Exception:
+        return None
+    if y.shape != x.shape or y.dtype != np.float32:
+        return None
+    xf = x.astype(np.float32)
+    if np.array_equal(y, xf):
+        # identity / cast-only; make sure it is not a coincidence of an all-zero frame
+        if np.any(xf != 0) or x.dtype == np.float32:
+            return 1.0
+    nz = xf != 0
+    if not np.any(nz):
+        return None
+    ratio = xf[nz] / y[nz]
+    d = float(np.median(ratio))
+    for cand in (d, round(d)):
+        if cand > 0 and np.array_equal(y, xf / np.float32(cand)):
+            return float(cand)
+    return None

@@ -1,0 +1,98 @@
+"""Batched training driver.
+
+Same contract as ``pfrl.experiments.train_agent_batch``
+(/root/reference/pfrl/experiments/train_agent_batch.py:10-154): the loop is
+``batch_act -> env.step -> batch_observe -> env.reset(not_end)``; ``resets`` is
+``episode_len == max_episode_len`` or the env's ``needs_reset`` info flag
+(:74-80); every env step advances ``t`` by one and fires the step hooks
+(:98-104); the agent is saved on exceptions (``_except``) and at the end
+(``_finish``).  Observations are passed through untouched, so a device
+VectorEnv's ``DeviceObsBatch`` reaches the agent without a host copy.
+"""
+import logging
+import os
+from collections import deque
+
+import numpy as np
+
+
+def save_agent(agent, t, outdir, logger, suffix=""):
+    dirname = os.path.join(outdir, "{}{}".format(t, suffix))
+    agent.save(dirname)
+    logger.info("Saved the agent to %s", dirname)
+
+
+def train_agent_batch(agent, env, steps, outdir, checkpoint_freq=None, log_interval=None,
+                      max_episode_len=None, step_offset=0, evaluator=None, successful_score=None,
+                      step_hooks=(), return_window_size=100, logger=None):
+    logger = logger or logging.getLogger(__name__)
+    recent_returns = deque(maxlen=return_window_size)
+    num_envs = env.num_envs
+    episode_r = np.zeros(num_envs, dtype=np.float64)
+    episode_idx = np.zeros(num_envs, dtype="i")
+    episode_len = np.zeros(num_envs, dtype="i")
+
+    obss = env.reset()
+    t = step_offset
+    if hasattr(agent, "t"):
+        agent.t = step_offset
+
+    eval_stats_history = []
+    try:
+        while True:
+            actions = agent.batch_act(obss)
+            obss, rs, dones, infos = env.step(actions)
+            episode_r += rs
+            episode_len += 1
+
+            if max_episode_len is None:
+                resets = np.zeros(num_envs, dtype=bool)
+            else:
+                resets = episode_len == max_episode_len
+            resets = np.logical_or(resets, [info.get("needs_reset", False) for info in infos])
+            agent.batch_observe(obss, rs, dones, resets)
+
+            end = np.logical_or(resets, dones)
+            not_end = np.logical_not(end)
+            episode_idx += end
+            recent_returns.extend(episode_r[end])
+
+            for _ in range(num_envs):
+                t += 1
+                if checkpoint_freq and t % checkpoint_freq == 0:
+                    save_agent(agent, t, outdir, logger, suffix="_checkpoint")
+                for hook in step_hooks:
+                    hook(env, agent, t)
+
+            if log_interval is not None and t >= log_interval and t % log_interval < num_envs:
+                logger.info("outdir:%s step:%s episode:%s last_R: %s average_R:%s", outdir, t,
+                            np.sum(episode_idx),
+                            recent_returns[-1] if recent_returns else np.nan,
+                            np.mean(recent_returns) if recent_returns else np.nan)
+                logger.info("statistics: %s", agent.get_statistics())
+            if evaluator:
+                eval_score = evaluator.evaluate_if_necessary(t=t, episodes=np.sum(episode_idx))
+                if eval_score is not None:
+                    eval_stats = dict(agent.get_statistics())
+                    eval_stats["eval_score"] = eval_score
+                    eval_stats_history.append(eval_stats)
+                    if successful_score is not None and evaluator.max_score >= successful_score:
+                        break
+
+            if t >= steps:
+                break
+
+            episode_r[end] = 0
+            episode_len[end] = 0
+            obss = env.reset(not_end)
+
+    except (Exception, KeyboardInterrupt):
+        save_agent(agent, t, outdir, logger, suffix="_except")
+        env.close()
+        if evaluator:
+            evaluator.env.close()
+        raise
+    else:
+        save_agent(agent, t, outdir, logger, suffix="_finish")
+
+    return eval_stats_history

@@ -1,0 +1,55 @@
+"""Nature-DQN convolutional trunks (reference pfrl/nn/atari_cnn.py:17-80).
+These are the MFMA part of the workload and stay stock PyTorch-ROCm
+(MIOpen conv + hipBLASLt GEMM)."""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from pfrl_amd.initializers import init_chainer_default
+
+
+def constant_bias_initializer(bias=0.0):
+    @torch.no_grad()
+    def init_bias(m):
+        if isinstance(m, (nn.Linear, nn.Conv2d)):
+            m.bias.fill_(bias)
+
+    return init_bias
+
+
+class _AtariCNN(nn.Module):
+    def __init__(self, convs, flat, n_output_channels, activation, bias):
+        super().__init__()
+        self.activation = activation
+        self.n_output_channels = n_output_channels
+        self.layers = nn.ModuleList(convs)
+        self.output = nn.Linear(flat, n_output_channels)
+        self.apply(init_chainer_default)
+        self.apply(constant_bias_initializer(bias=bias))
+
+    def forward(self, state):
+        h = state
+        for layer in self.layers:
+            h = self.activation(layer(h))
+        return self.activation(self.output(h.view(h.size(0), -1)))
+
+
+class LargeAtariCNN(_AtariCNN):
+    """Nature 2015: conv 32x8x8/4, 64x4x4/2, 64x3x3/1, fc 3136 -> 512."""
+
+    def __init__(self, n_input_channels=4, n_output_channels=512, activation=F.relu, bias=0.1):
+        self.n_input_channels = n_input_channels
+        super().__init__([nn.Conv2d(n_input_channels, 32, 8, stride=4),
+                          nn.Conv2d(32, 64, 4, stride=2),
+                          nn.Conv2d(64, 64, 3, stride=1)], 3136, n_output_channels, activation,
+                         bias)
+
+
+class SmallAtariCNN(_AtariCNN):
+    """NIPS-workshop 2013: conv 16x8x8/4, 32x4x4/2, fc 2592 -> 256."""
+
+    def __init__(self, n_input_channels=4, n_output_channels=256, activation=F.relu, bias=0.1):
+        self.n_input_channels = n_input_channels
+        super().__init__([nn.Conv2d(n_input_channels, 16, 8, stride=4),
+                          nn.Conv2d(16, 32, 4, stride=2)], 2592, n_output_channels, activation,
+                         bias)

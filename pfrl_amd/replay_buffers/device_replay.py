@@ -1,0 +1,396 @@
+"""HBM-resident payload of the replay buffers.
+
+Layout (all rings, slot = sequence number % ring size):
+
+  frames      DeviceFrameStore     u8 / f32 [F][frame]      one write per frame
+  transitions SoA                  state_ref/next_ref int32 [R][k], action
+                                   int64 [R] | f32 [R][A], reward f64 [R],
+                                   terminal u8 [R]
+  entries     n-step windows       e_tids int32 [E][n] (-1 padded), e_len [E]
+
+The host keeps a mirror of the small integer / scalar columns (a few tens of
+bytes per transition) for bookkeeping, liveness checks, API-compatible views
+and checkpoints; observation bytes exist only in HBM.
+"""
+import collections
+
+import numpy as np
+import torch
+
+from pfrl_amd import ops
+from pfrl_amd.device_store import DeviceFrameStore, DeviceObs, recognise_phi
+from pfrl_amd.staging import StagingRing
+
+_STAGE_ROWS = 4096
+
+
+class _LazyFramesLike:
+    """Duck type of pfrl.wrappers.atari_wrappers.LazyFrames: ``_frames`` list."""
+
+
+def _frames_of(obs):
+    fr = getattr(obs, "_frames", None)
+    if isinstance(fr, (list, tuple)) and len(fr) > 0:
+        return fr
+    return None
+
+
+class DeviceReplayStore:
+    def __init__(self, device, capacity, num_steps, max_size=None, slack=None, frame_slots=None):
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("DeviceReplayStore needs a CUDA/HIP device")
+        from pfrl_amd import _native
+
+        _native.lib()  # fail loudly when the HIP library is missing
+        self.capacity = capacity
+        self.n = int(num_steps)
+        bound = capacity if capacity is not None else (max_size or (1 << 20))
+        self.bound = int(bound)
+        slack = int(slack) if slack is not None else max(65536, 64 * self.n)
+        self.slack = slack
+        self.E = self.bound + slack
+        self.R = self.bound + slack
+        self.frame_slots = frame_slots
+        self.frames = None            # DeviceFrameStore
+        self._own_frames = False
+        self.k = None
+        self.act_dim = None
+        self.desc = None
+        self.n_trans = 0              # transitions appended so far (tid counter)
+        self.n_entries = 0            # entries appended so far (seq counter)
+        self._stage = StagingRing(self.device, slot_bytes=1 << 19, n_slots=32)
+        self._frame_stage = None
+        self._pend_rows = 0
+        self._pend_entries = 0
+        self._phi = None
+        self._divisor = None
+        self._phi_at_ingest = False
+        # host ingestion caches (identity de-duplication)
+        self._obs_cache = collections.OrderedDict()
+        self._frame_cache = collections.OrderedDict()
+        self._pend_frames = []
+        self._pend_frame_slots = []
+        # host mirrors, allocated with the tables
+        self.h_state_ref = self.h_next_ref = self.h_action = None
+        self.h_reward = self.h_terminal = self.h_min_fseq = None
+        self.h_e_tids = self.h_e_len = self.h_e_min_fseq = self.h_extra = None
+
+    # -- configuration --------------------------------------------------------
+    def set_phi(self, phi):
+        if phi is not self._phi:
+            self._phi = phi
+            self._divisor = None
+
+    def _alloc_tables(self, k, action):
+        dev = self.device
+        self.k = int(k)
+        a = np.asarray(action)
+        if a.dtype.kind in "iub" and a.ndim == 0:
+            self.act_dim = 0
+            self.t_action = torch.zeros(self.R, dtype=torch.int64, device=dev)
+            self.h_action = np.zeros(self.R, dtype=np.int64)
+            self._s_action = np.zeros(_STAGE_ROWS, dtype=np.int64)
+        else:
+            self.act_dim = int(a.size)
+            self.t_action = torch.zeros((self.R, self.act_dim), dtype=torch.float32, device=dev)
+            self.h_action = np.zeros((self.R, self.act_dim), dtype=np.float32)
+            self._s_action = np.zeros((_STAGE_ROWS, self.act_dim), dtype=np.float32)
+        self.t_state_ref = torch.zeros((self.R, self.k), dtype=torch.int32, device=dev)
+        self.t_next_ref = torch.zeros((self.R, self.k), dtype=torch.int32, device=dev)
+        self.t_reward = torch.zeros(self.R, dtype=torch.float64, device=dev)
+        self.t_terminal = torch.zeros(self.R, dtype=torch.uint8, device=dev)
+        self.e_tids = torch.full((self.E, self.n), -1, dtype=torch.int32, device=dev)
+        self.e_len = torch.zeros(self.E, dtype=torch.int32, device=dev)
+        self.desc = ops.make_table_desc(self.t_state_ref, self.t_next_ref, self.t_action,
+                                        self.t_reward, self.t_terminal, self.e_tids, self.e_len,
+                                        self.k, self.n, self.act_dim)
+        self.h_state_ref = np.zeros((self.R, self.k), dtype=np.int32)
+        self.h_next_ref = np.zeros((self.R, self.k), dtype=np.int32)
+        self.h_reward = np.zeros(self.R, dtype=np.float64)
+        self.h_terminal = np.zeros(self.R, dtype=np.uint8)
+        self.h_min_fseq = np.zeros(self.R, dtype=np.int64)
+        self.h_e_tids = -np.ones((self.E, self.n), dtype=np.int64)   # absolute tids
+        self.h_e_len = np.zeros(self.E, dtype=np.int32)
+        self.h_e_min_fseq = np.zeros(self.E, dtype=np.int64)
+        self.h_extra = {}
+        # staging
+        self._s_slot = np.zeros(_STAGE_ROWS, dtype=np.int32)
+        self._s_state = np.zeros((_STAGE_ROWS, self.k), dtype=np.int32)
+        self._s_next = np.zeros((_STAGE_ROWS, self.k), dtype=np.int32)
+        self._s_reward = np.zeros(_STAGE_ROWS, dtype=np.float64)
+        self._s_term = np.zeros(_STAGE_ROWS, dtype=np.uint8)
+        self._s_eslot = np.zeros(_STAGE_ROWS, dtype=np.int32)
+        self._s_etids = -np.ones((_STAGE_ROWS, self.n), dtype=np.int32)
+        self._s_elen = np.zeros(_STAGE_ROWS, dtype=np.int32)
+
+    # -- observation ingestion ------------------------------------------------
+    def _adopt_store(self, store):
+        if self.frames is None:
+            self.frames = store
+        elif self.frames is not store:
+            raise ValueError("all observations of one replay buffer must share a frame store")
+
+    def _make_own_store(self, frame, k):
+        frame = np.asarray(frame)
+        dtype = torch.uint8 if frame.dtype == np.uint8 else torch.float32
+        slots = self.frame_slots or (self.R + self.R // 8 + 4096)
+        self.frames = DeviceFrameStore(slots, frame.shape, dtype, self.device, stack=k)
+        self._own_frames = True
+        fb = self.frames.frame_bytes
+        rows = max(1, min(4096, (8 << 20) // fb))
+        self._frame_stage = StagingRing(self.device, slot_bytes=rows * fb + 64 + rows * 4 + 64,
+                                        n_slots=4)
+        self._frame_stage_rows = rows
+
+    def _ingest_frame(self, frame):
+        """Host frame -> (seq, slot); identical array objects are stored once."""
+        key = id(frame)
+        hit = self._frame_cache.get(key)
+        if hit is not None and hit[0] is frame:
+            return hit[1], hit[2]
+        arr = np.asarray(frame)
+        if self.frames.dtype == torch.float32 and arr.dtype != np.float32:
+            arr = arr.astype(np.float32)
+        seqs, slots = self.frames.alloc(1)
+        self._pend_frames.append(np.ascontiguousarray(arr).reshape(self.frames.frame_shape))
+        self._pend_frame_slots.append(int(slots[0]))
+        self._frame_cache[key] = (frame, int(seqs[0]), int(slots[0]))
+        if len(self._frame_cache) > 4096:
+            self._frame_cache.popitem(last=False)
+        if len(self._pend_frames) >= self._frame_stage_rows:
+            self._flush_frames()
+        return int(seqs[0]), int(slots[0])
+
+    def ingest(self, obs):
+        """Any observation -> (refs int32[k], min_seq)."""
+        if isinstance(obs, DeviceObs):
+            self._adopt_store(obs.store)
+            return obs.refs, obs.min_seq
+        key = id(obs)
+        hit = self._obs_cache.get(key)
+        if hit is not None and hit[0] is obs:
+            return hit[1], hit[2]
+        if isinstance(obs, tuple):
+            raise TypeError("tuple observations are not supported by the device replay store")
+        frs = _frames_of(obs)
+        if frs is not None:
+            # LazyFrames-like: frames are shared between consecutive observations
+            if self.frames is None:
+                self._make_own_store(frs[0], len(frs))
+            pairs = [self._ingest_frame(f) for f in frs]
+        else:
+            if self._phi_at_ingest or self._needs_phi_at_ingest(obs):
+                # arbitrary (pure) phi: evaluate it once, store phi(obs) as f32
+                self._phi_at_ingest = True
+                arr = np.asarray(self._phi(obs), dtype=np.float32)
+            else:
+                arr = np.asarray(obs)
+                if arr.dtype not in (np.uint8, np.float32):
+                    arr = arr.astype(np.float32)
+            if self.frames is None:
+                if arr.nbytes % 4:
+                    raise ValueError("observation size must be a multiple of 4 bytes")
+                self._make_own_store(arr, 1)
+            pairs = [self._ingest_frame(arr)]
+        refs = np.array([p[1] for p in pairs], dtype=np.int32)
+        min_seq = min(p[0] for p in pairs)
+        self._obs_cache[key] = (obs, refs, min_seq)
+        if len(self._obs_cache) > 4096:
+            self._obs_cache.popitem(last=False)
+        return refs, min_seq
+
+    def _needs_phi_at_ingest(self, obs):
+        """Arbitrary phi: apply it once on the host when the observation enters
+        the buffer and store phi(obs) as f32 (phi must be a pure function)."""
+        if self._phi is None or self._divisor is not None:
+            return False
+        d = recognise_phi(self._phi, obs)
+        if d is not None:
+            self._divisor = d
+            return False
+        return True
+
+    def _flush_frames(self):
+        n = len(self._pend_frames)
+        if n == 0:
+            return
+        block = np.stack(self._pend_frames)
+        slots = np.asarray(self._pend_frame_slots, dtype=np.int32)
+        src, sl = self._frame_stage.upload([block, slots])
+        self.frames.write(src.view(self.frames.dtype).view((n,) + self.frames.frame_shape), sl)
+        self._pend_frames, self._pend_frame_slots = [], []
+
+    # -- transitions / entries ------------------------------------------------
+    def add_transition(self, state, action, reward, next_state, terminal, extra=None):
+        s_refs, s_seq = self.ingest(state)
+        if next_state is None:
+            n_refs, n_seq = s_refs, s_seq
+        else:
+            n_refs, n_seq = self.ingest(next_state)
+        if self.desc is None:
+            self._alloc_tables(len(s_refs), action)
+        if self._pend_rows == _STAGE_ROWS:
+            self.flush()
+        tid = self.n_trans
+        slot = tid % self.R
+        i = self._pend_rows
+        self._s_slot[i] = slot
+        self._s_state[i] = s_refs
+        self._s_next[i] = n_refs
+        self._s_action[i] = action
+        self._s_reward[i] = reward
+        self._s_term[i] = terminal
+        self._pend_rows = i + 1
+        self.h_state_ref[slot] = s_refs
+        self.h_next_ref[slot] = n_refs
+        self.h_action[slot] = action
+        self.h_reward[slot] = reward
+        self.h_terminal[slot] = terminal
+        self.h_min_fseq[slot] = s_seq if s_seq < n_seq else n_seq
+        if extra:
+            for key, val in extra.items():
+                self.h_extra.setdefault(key, {})[tid] = val
+        self.n_trans = tid + 1
+        return tid
+
+    def add_entry(self, tids):
+        """An emitted n-step window (list of absolute tids) -> entry seq."""
+        first = tids[0]
+        if self.n_trans - first > self.slack:
+            raise RuntimeError(
+                "replay transition ring too small: an n-step window spans %d transitions; "
+                "increase `slack`" % (self.n_trans - first))
+        if self._pend_entries == _STAGE_ROWS:
+            self.flush()
+        seq = self.n_entries
+        slot = seq % self.E
+        i = self._pend_entries
+        ln = len(tids)
+        self._s_eslot[i] = slot
+        row = self._s_etids[i]
+        row[:] = -1
+        hrow = self.h_e_tids[slot]
+        hrow[:] = -1
+        mf = None
+        for j, t in enumerate(tids):
+            ts = t % self.R
+            row[j] = ts
+            hrow[j] = t
+            f = self.h_min_fseq[ts]
+            mf = f if mf is None or f < mf else mf
+        self._s_elen[i] = ln
+        self.h_e_len[slot] = ln
+        self.h_e_min_fseq[slot] = mf
+        self._pend_entries = i + 1
+        self.n_entries = seq + 1
+        return seq
+
+    def flush(self):
+        """Ship staged frames, transition rows and entries to HBM (async)."""
+        if self._pend_frames:
+            self._flush_frames()
+        r = self._pend_rows
+        if r:
+            up = self._stage.upload([self._s_slot[:r], self._s_state[:r], self._s_next[:r],
+                                     self._s_action[:r], self._s_reward[:r], self._s_term[:r]])
+            ops.table_append(self.desc, *up)
+            self._pend_rows = 0
+        e = self._pend_entries
+        if e:
+            up = self._stage.upload([self._s_eslot[:e], self._s_etids[:e], self._s_elen[:e]])
+            ops.entries_append(self.desc, *up)
+            self._pend_entries = 0
+
+    # -- sampling -------------------------------------------------------------
+    def slots_for(self, seqs):
+        """Entry seqs (numpy int64) -> device int32 slots, with liveness check."""
+        slots = (seqs % self.E).astype(np.int32)
+        if self.frames is not None:
+            oldest = self.h_e_min_fseq[slots].min() if len(slots) else 0
+            if oldest < self.frames.oldest_live_seq():
+                raise RuntimeError(
+                    "frame ring too small: a sampled transition references frame %d but the "
+                    "ring (n_slots=%d) has already wrapped past it; allocate the "
+                    "DeviceFrameStore with at least capacity + num_envs * (stack + num_steps + 2)"
+                    " slots" % (oldest, self.frames.n_slots))
+        (slots_dev,) = self._stage.upload([slots])
+        return slots_dev
+
+    def divisor_for(self, phi):
+        if self._phi_at_ingest:
+            return 1.0
+        if phi is not self._phi or self._divisor is None:
+            self._phi = phi
+            if self.frames.dtype == torch.float32:
+                sample = self.frames.frames[:1].cpu().numpy()[0]
+            else:
+                sample = self.frames.frames[: self.k].cpu().numpy()
+                if sample.shape[0] == 1:
+                    sample = sample[0]
+                elif sample.ndim >= 3 and sample.shape[1] == 1:
+                    sample = np.concatenate(list(sample), axis=0)
+                if not np.any(sample):
+                    sample = sample.copy()
+                    sample.reshape(-1)[: 256] = np.arange(min(256, sample.size), dtype=np.uint8)
+            d = recognise_phi(phi, sample)
+            if d is None:
+                raise TypeError(
+                    "pfrl_amd: phi is not a cast/scale feature extractor and the observations "
+                    "are already device-resident; use phi(x) = float32(x) / c")
+            self._divisor = d
+        return self._divisor
+
+    def fetch(self, batch, phi, gamma):
+        """The fused batch_experiences launch for a DeviceExperienceBatch."""
+        self.flush()
+        B = len(batch)
+        dev = self.device
+        fshape = self.frames.frame_shape
+        k = self.k
+        if k == 1:
+            oshape = (B,) + fshape
+        elif len(fshape) >= 2 and fshape[0] == 1:
+            oshape = (B, k) + fshape[1:]        # LazyFrames: concatenate on axis 0
+        else:
+            oshape = (B, k) + fshape
+        out = dict(
+            state=torch.empty(oshape, dtype=torch.float32, device=dev),
+            next_state=torch.empty(oshape, dtype=torch.float32, device=dev),
+            action=(torch.empty(B, dtype=torch.int64, device=dev) if self.act_dim == 0 else
+                    torch.empty((B, self.act_dim), dtype=torch.float32, device=dev)),
+            reward=torch.empty(B, dtype=torch.float32, device=dev),
+            is_state_terminal=torch.empty(B, dtype=torch.float32, device=dev),
+            discount=torch.empty(B, dtype=torch.float32, device=dev),
+        )
+        gp = [gamma ** i for i in range(self.n + 1)]
+        ops.batch_experiences(self.desc, self.frames.frames, self.divisor_for(phi),
+                              batch.slots_dev, gp, out)
+        if batch.weights_dev is not None:
+            out["weights"] = batch.weights_dev
+        return out
+
+    # -- API-compatible host views ---------------------------------------------
+    def transition_view(self, tid, weight=None):
+        slot = tid % self.R
+        store = self.frames
+        d = dict(
+            state=DeviceObs(store, self.h_state_ref[slot].copy(), int(self.h_min_fseq[slot])),
+            action=(int(self.h_action[slot]) if self.act_dim == 0 else self.h_action[slot].copy()),
+            reward=float(self.h_reward[slot]),
+            next_state=DeviceObs(store, self.h_next_ref[slot].copy(), int(self.h_min_fseq[slot])),
+            next_action=None,
+            is_state_terminal=bool(self.h_terminal[slot]),
+        )
+        for key, table in self.h_extra.items():
+            if tid in table:
+                d[key] = table[tid]
+        if weight is not None:
+            d["weight"] = weight
+        return d
+
+    def entry_view(self, seq, weight=None):
+        slot = seq % self.E
+        ln = int(self.h_e_len[slot])
+        tids = [int(t) for t in self.h_e_tids[slot][:ln]]
+        return [self.transition_view(t, weight if j == 0 else None) for j, t in enumerate(tids)]

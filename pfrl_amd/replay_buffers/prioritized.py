@@ -1,0 +1,182 @@
+"""Proportional prioritized replay (https://arxiv.org/abs/1511.05952, 3.3).
+
+Mirrors ``pfrl.replay_buffers.prioritized``
+(/root/reference/pfrl/replay_buffers/prioritized.py): ``PriorityWeightError``
+(:9-66) and ``PrioritizedReplayBuffer`` (:69-126) with the same constructor
+signature and defaults.  The sum / min trees, the B sequentially dependent
+draws, the importance weights and the priority update all run on the device
+(pfrl_amd/csrc/sumtree.hip); per ``sample`` the host contributes only the B
+uniform draws taken from the global NumPy stream (so seeds mean the same thing
+as in the reference) and per ``update_errors`` nothing at all when the TD
+errors are already a device tensor.
+"""
+import collections
+
+import numpy as np
+import torch
+
+from pfrl_amd.replay_buffer import DeviceExperienceBatch
+from pfrl_amd.replay_buffers.replay_buffer import ReplayBuffer
+
+_NORMALIZE_CODE = {False: 0, "batch": 1, "memory": 2}
+
+
+class PriorityWeightError(object):
+    """alpha / beta / eps arithmetic of proportional prioritisation."""
+
+    def __init__(self, alpha, beta0, betasteps, eps, normalize_by_max, error_min, error_max):
+        assert 0.0 <= alpha
+        assert 0.0 <= beta0 <= 1.0
+        self.alpha = alpha
+        self.beta = beta0
+        self.beta_add = 0 if betasteps is None else (1.0 - beta0) / betasteps
+        self.eps = eps
+        if normalize_by_max is True:
+            normalize_by_max = "batch"
+        assert normalize_by_max in [False, "batch", "memory"]
+        self.normalize_by_max = normalize_by_max
+        self.error_min = error_min
+        self.error_max = error_max
+
+    def _clip(self, error):
+        if self.error_min is not None:
+            error = max(self.error_min, error)
+        if self.error_max is not None:
+            error = min(self.error_max, error)
+        return error
+
+    def priority_from_errors(self, errors):
+        """(clip(d) + eps) ** alpha for host scalars (reference :47-55); the
+        scalar types (Python float / np.float32) are preserved exactly as NumPy
+        would, because they end up inside the priority trees."""
+        return [(self._clip(d) + self.eps) ** self.alpha for d in errors]
+
+    def weights_from_probabilities(self, probabilities, min_probability):
+        """Host version of the importance weights (reference :57-66)."""
+        if self.normalize_by_max == "batch":
+            min_probability = np.min(probabilities)
+        if self.normalize_by_max:
+            weights = [(p / min_probability) ** -self.beta for p in probabilities]
+        else:
+            weights = [(len(self.memory) * p) ** -self.beta for p in probabilities]
+        self.beta = min(1.0, self.beta + self.beta_add)
+        return weights
+
+
+class _LazySeqs:
+    """Entry sequence numbers of a prioritized sample, fetched from the device
+    only if somebody asks for host views."""
+
+    def __init__(self, x_dev, n):
+        self._x = x_dev
+        self._n = n
+        self._host = None
+
+    def __len__(self):
+        return self._n
+
+    def __getitem__(self, i):
+        if self._host is None:
+            self._host = self._x.cpu().numpy()
+        return self._host[i]
+
+
+class _DevicePrioritizedQueue:
+    """PrioritizedBuffer over the entry ring: tree coordinate x == entry seq."""
+
+    def __init__(self, store, capacity, max_size):
+        from pfrl_amd.collections.prioritized import PrioritizedBuffer
+
+        self.store = store
+        self.capacity = capacity
+        self.tree = PrioritizedBuffer(capacity=capacity, device=store.device, max_size=max_size)
+        self._appends = 0
+
+    def __len__(self):
+        return len(self.tree)
+
+    @property
+    def head(self):
+        return self.tree.frame.head
+
+    def append_entry(self, tids):
+        seq = self.store.add_entry(tids)
+        self.tree.append(seq)
+        assert self.tree.frame.next_x == self.store.n_entries
+        self._appends += 1
+        if (self._appends & 63) == 0 and self.store.frames is not None:
+            oldest = self.store.h_e_min_fseq[self.head % self.store.E]
+            if oldest < self.store.frames.oldest_live_seq():
+                raise RuntimeError("frame ring too small for this replay capacity "
+                                   "(n_slots=%d)" % self.store.frames.n_slots)
+
+    def __getitem__(self, i):
+        n = len(self)
+        if i < 0:
+            i += n
+        if not 0 <= i < n:
+            raise IndexError("replay index out of range")
+        return self.store.entry_view(self.head + i)
+
+    def __iter__(self):
+        for i in range(len(self)):
+            yield self[i]
+
+    @property
+    def max_priority(self):
+        return self.tree.max_priority
+
+
+class PrioritizedReplayBuffer(ReplayBuffer, PriorityWeightError):
+    """Stochastic prioritisation, proportional variant."""
+
+    def __init__(self, capacity=None, alpha=0.6, beta0=0.4, betasteps=2e5, eps=0.01,
+                 normalize_by_max=True, error_min=0, error_max=1, num_steps=1, device=None,
+                 max_size=None, slack=None, frame_slots=None, priority_pow="device"):
+        PriorityWeightError.__init__(self, alpha, beta0, betasteps, eps, normalize_by_max,
+                                     error_min=error_min, error_max=error_max)
+        assert priority_pow in ("device", "host_libm")
+        self.priority_pow = priority_pow
+        ReplayBuffer.__init__(self, capacity=capacity, num_steps=num_steps, device=None,
+                              max_size=max_size, slack=slack, frame_slots=frame_slots)
+        if device is not None:
+            self.bind(device)
+
+    def _make_memory_host(self):
+        raise RuntimeError(
+            "pfrl_amd.PrioritizedReplayBuffer keeps its sum/min trees in HBM and needs a GPU "
+            "(construct with device='cuda:0' or use an agent with gpu>=0)")
+
+    def _make_memory_device(self):
+        return _DevicePrioritizedQueue(self.store, self.capacity, self._device_opts["max_size"])
+
+    def sample(self, n):
+        self._ensure_bound()
+        assert len(self.memory) >= n
+        tree = self.memory.tree
+        out = tree.sample_device(n, normalize=_NORMALIZE_CODE[self.normalize_by_max],
+                                 beta=self.beta, slot_mod=self.store.E)
+        self.beta = min(1.0, self.beta + self.beta_add)
+        self._last_sample = out
+        return DeviceExperienceBatch(self.store, out["slot"], _LazySeqs(out["x"], n),
+                                     weights_dev=out["weight"])
+
+    def update_errors(self, errors):
+        """TD errors of the last sampled batch -> new priorities.
+
+        ``errors`` may be a float32 device tensor (no host round trip), or a
+        sequence of host scalars as in the reference."""
+        tree = self.memory.tree
+        if isinstance(errors, torch.Tensor):
+            if self.priority_pow == "device" and errors.is_cuda:
+                err = errors.detach().reshape(-1).to(torch.float32).contiguous()
+                at_min = None if self.error_min is None else \
+                    (self._clip(self.error_min) + self.eps) ** self.alpha
+                at_max = None if self.error_max is None else \
+                    (self._clip(self.error_max) + self.eps) ** self.alpha
+                tree.update_errors_device(err, self.error_min, at_min, self.error_max, at_max,
+                                          self.eps, self.alpha)
+                return
+            # strict mode: evaluate the power with this host's libm, as NumPy does
+            errors = list(errors.detach().cpu().numpy().reshape(-1))
+        tree.set_last_priority(self.priority_from_errors(errors))

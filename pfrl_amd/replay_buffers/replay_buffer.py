@@ -1,0 +1,205 @@
+"""Experience replay buffer with n-step windows.
+
+Mirrors ``pfrl.replay_buffers.ReplayBuffer``
+(/root/reference/pfrl/replay_buffers/replay_buffer.py:9-94): constructor
+``(capacity=None, num_steps=1)``, ``append`` with per-``env_id`` n-step
+windows (:33-62), ``stop_current_episode`` (:64-76), ``sample`` (:78-80),
+``__len__``, ``save`` / ``load`` and the same assertions.
+
+Storage back-ends
+  * device (``device='cuda:N'`` or bound by an agent created with ``gpu>=0``):
+    observation bytes, transition columns and n-step entries live in HBM
+    (:class:`DeviceReplayStore`); ``sample`` returns a
+    :class:`DeviceExperienceBatch` that ``batch_experiences`` turns into fp32
+    minibatches with one fused HIP launch.  There is no CPU fallback on this
+    path: a missing HIP library raises.
+  * host (no device, or an agent created with ``gpu=None/-1``): the plumbing
+    path of config 1 -- Python lists of transition dicts, as in the reference.
+"""
+import collections
+import pickle
+
+import numpy as np
+import torch
+
+from pfrl_amd import replay_buffer
+from pfrl_amd.collections.random_access_queue import RandomAccessQueue
+from pfrl_amd.replay_buffer import DeviceExperienceBatch
+from pfrl_amd.utils.random import sample_n_k
+
+
+class _DeviceQueue:
+    """FIFO view over the entry ring: logical index i <-> entry seq head + i
+    (the role RandomAccessQueue plays in the reference)."""
+
+    def __init__(self, store, maxlen):
+        self.store = store
+        self.maxlen = maxlen
+        self.head = 0  # seq of logical index 0
+
+    def __len__(self):
+        return self.store.n_entries - self.head
+
+    def append_entry(self, tids):
+        self.store.add_entry(tids)
+        if self.maxlen is not None and len(self) > self.maxlen:
+            self.head += 1
+        elif self.maxlen is None and len(self) > self.store.bound:
+            raise RuntimeError(
+                "unbounded ReplayBuffer exceeded its device allocation (max_size=%d)"
+                % self.store.bound)
+
+    def __getitem__(self, i):
+        n = len(self)
+        if i < 0:
+            i += n
+        if not 0 <= i < n:
+            raise IndexError("replay index out of range")
+        return self.store.entry_view(self.head + i)
+
+    def __iter__(self):
+        for i in range(len(self)):
+            yield self[i]
+
+    def sample(self, k):
+        idx = sample_n_k(len(self), k)
+        seqs = self.head + np.asarray(idx, dtype=np.int64)
+        return DeviceExperienceBatch(self.store, self.store.slots_for(seqs), seqs)
+
+
+class ReplayBuffer(replay_buffer.AbstractReplayBuffer):
+    """Experience Replay Buffer (uniform sampling, optional N-step)."""
+
+    capacity = None
+
+    def __init__(self, capacity=None, num_steps=1, device=None, max_size=None, slack=None,
+                 frame_slots=None):
+        self.capacity = capacity
+        assert num_steps > 0
+        self.num_steps = num_steps
+        self._device_opts = dict(max_size=max_size, slack=slack, frame_slots=frame_slots)
+        self.device = None
+        self.store = None
+        self.memory = None
+        self.last_n_transitions = collections.defaultdict(
+            lambda: collections.deque([], maxlen=num_steps))
+        if device is not None:
+            self.bind(device)
+
+    # -- back-end selection -----------------------------------------------------
+    def _make_memory_host(self):
+        return RandomAccessQueue(maxlen=self.capacity)
+
+    def _make_memory_device(self):
+        return _DeviceQueue(self.store, self.capacity)
+
+    def bind(self, device, phi=None):
+        """Choose the storage back-end.  Called by agents with their device."""
+        device = torch.device(device)
+        if self.memory is not None:
+            if self.device != device:
+                raise RuntimeError("replay buffer already bound to %s" % self.device)
+            if self.store is not None and phi is not None:
+                self.store.set_phi(phi)
+            return self
+        self.device = device
+        if device.type == "cuda":
+            from pfrl_amd.replay_buffers.device_replay import DeviceReplayStore
+
+            self.store = DeviceReplayStore(device, self.capacity, self.num_steps,
+                                           **self._device_opts)
+            if phi is not None:
+                self.store.set_phi(phi)
+            self.memory = self._make_memory_device()
+        else:
+            self.memory = self._make_memory_host()
+        return self
+
+    def _ensure_bound(self):
+        if self.memory is None:
+            self.bind(torch.device("cpu"))
+
+    @property
+    def is_device(self):
+        return self.store is not None
+
+    # -- reference API ------------------------------------------------------------
+    def _emit(self, window):
+        if self.store is not None:
+            self.memory.append_entry(list(window))
+        else:
+            self.memory.append(list(window))
+
+    def append(self, state, action, reward, next_state=None, next_action=None,
+               is_state_terminal=False, env_id=0, **kwargs):
+        self._ensure_bound()
+        window = self.last_n_transitions[env_id]
+        if self.store is not None:
+            if next_action is not None:
+                kwargs = dict(kwargs, next_action=next_action)
+            item = self.store.add_transition(state, action, reward, next_state, is_state_terminal,
+                                             kwargs or None)
+        else:
+            item = dict(state=state, action=action, reward=reward, next_state=next_state,
+                        next_action=next_action, is_state_terminal=is_state_terminal, **kwargs)
+        window.append(item)
+        if is_state_terminal:
+            # flush every suffix of the window (reference :55-59)
+            while window:
+                self._emit(window)
+                del window[0]
+        elif len(window) == self.num_steps:
+            self._emit(window)
+
+    def stop_current_episode(self, env_id=0):
+        self._ensure_bound()
+        window = self.last_n_transitions[env_id]
+        # a full window has already been emitted by append (reference :66-72)
+        if 0 < len(window) < self.num_steps:
+            self._emit(window)
+        if 0 < len(window) <= self.num_steps:
+            del window[0]
+        while window:
+            self._emit(window)
+            del window[0]
+
+    def sample(self, num_experiences):
+        self._ensure_bound()
+        assert len(self.memory) >= num_experiences
+        return self.memory.sample(num_experiences)
+
+    def __len__(self):
+        return 0 if self.memory is None else len(self.memory)
+
+    def save(self, filename):
+        self._ensure_bound()
+        with open(filename, "wb") as f:
+            if self.store is None:
+                pickle.dump(self.memory, f)
+            else:
+                pickle.dump(self._materialise_host(), f)
+
+    def _materialise_host(self):
+        """Device contents as the reference's pickled queue of dict lists
+        (observations read back from HBM)."""
+        q = RandomAccessQueue(maxlen=self.capacity)
+        for entry in self.memory:
+            q.append([dict(t, state=np.asarray(t["state"]), next_state=np.asarray(t["next_state"]))
+                      for t in entry])
+        return q
+
+    def load(self, filename):
+        with open(filename, "rb") as f:
+            loaded = pickle.load(f)
+        if isinstance(loaded, collections.deque):
+            loaded = RandomAccessQueue(loaded, maxlen=loaded.maxlen)
+        if self.store is None:
+            self._ensure_bound()
+            if self.store is None:
+                self.memory = loaded
+                return
+        for entry in loaded:
+            tids = [self.store.add_transition(t["state"], t["action"], t["reward"],
+                                              t["next_state"], t["is_state_terminal"])
+                    for t in entry]
+            self.memory.append_entry(tids)

@@ -1,0 +1,73 @@
+"""``batch_states(states, device, phi)`` -- injection point #1 of every agent.
+
+Mirrors ``pfrl.utils.batch_states.batch_states``
+(/root/reference/pfrl/utils/batch_states.py:18-36).  Three input forms:
+
+* observations that already live in HBM (``DeviceObsBatch`` or a list of
+  ``DeviceObs`` from a device VectorEnv): one gather-by-index kernel
+  (pfrl_batch_states_u8 / _f32) produces the fp32 minibatch -- no host work;
+* host observations with a CUDA target and a recognised ``phi`` (cast / scale):
+  the raw bytes are uploaded once and converted by the same kernel;
+* anything else (CPU target, tuple observations, arbitrary ``phi``): phi is
+  applied per observation on the host and the result collated, as in the
+  reference.
+"""
+import numpy as np
+import torch
+
+from pfrl_amd.device_store import DeviceObs, DeviceObsBatch, recognise_phi
+
+_phi_cache = {}
+
+
+def _divisor_for(phi, sample_obs_fn):
+    key = id(phi)
+    hit = _phi_cache.get(key)
+    if hit is not None and hit[0] is phi:
+        return hit[1]
+    d = recognise_phi(phi, sample_obs_fn())
+    _phi_cache[key] = (phi, d)
+    return d
+
+
+def _collate(features, device):
+    first = features[0]
+    if isinstance(first, tuple):
+        return tuple(_collate([f[i] for f in features], device) for i in range(len(first)))
+    if isinstance(first, torch.Tensor):
+        return torch.stack(list(features)).to(device)
+    arr = np.stack([np.asarray(f) for f in features])
+    return torch.from_numpy(arr).to(device)
+
+
+def batch_states(states, device, phi):
+    """Make a batch of observations for the model."""
+    device = torch.device(device) if not isinstance(device, torch.device) else device
+    if isinstance(states, DeviceObsBatch):
+        store, refs_dev = states.store, states.refs_device()
+        d = _divisor_for(phi, lambda: states[0].to_numpy())
+        if d is None:
+            raise TypeError(
+                "pfrl_amd: phi is not a cast/scale feature extractor; device-resident "
+                "observations need phi(x) == float32(x) / c (see pfrl_amd.device_store.ScaleU8)")
+        return store.gather(refs_dev, d)
+    if len(states) > 0 and isinstance(states[0], DeviceObs):
+        store = states[0].store
+        refs = np.stack([s.refs for s in states])
+        batch = DeviceObsBatch(store, refs, np.array([s.min_seq for s in states]))
+        return batch_states(batch, device, phi)
+
+    if device.type == "cuda" and len(states) > 0 and not isinstance(states[0], tuple):
+        x0 = np.asarray(states[0])
+        if x0.dtype in (np.uint8, np.float32) and x0.nbytes % 4 == 0 and x0.size > 0:
+            d = _divisor_for(phi, lambda: states[0])
+            if d is not None:
+                from pfrl_amd import ops
+
+                raw = np.stack([np.asarray(s) for s in states])
+                frames = torch.from_numpy(raw).to(device)
+                refs = torch.arange(len(states), dtype=torch.int32, device=device).view(-1, 1)
+                out = ops.batch_states(frames, refs, d)
+                return out.view((len(states),) + x0.shape)
+    features = [phi(s) for s in states]
+    return _collate(features, device)

@@ -1,0 +1,34 @@
+"""Target-network synchronisation (reference pfrl/utils/copy_param.py:4-41).
+
+Hard sync is ``load_state_dict``; soft sync is theta' <- (1-tau) theta' + tau
+theta over parameters, with BatchNorm running statistics hard-copied."""
+import torch
+
+
+def copy_param(target_link, source_link):
+    target_link.load_state_dict(source_link.state_dict())
+
+
+def soft_copy_param(target_link, source_link, tau):
+    tgt = target_link.state_dict()
+    for name, src in source_link.state_dict().items():
+        dst = tgt[name]
+        if dst.dtype in (torch.int32, torch.int64):
+            dst.copy_(src)  # e.g. BatchNorm.num_batches_tracked
+        else:
+            dst.mul_(1 - tau)
+            dst.add_(tau * src)
+
+
+def copy_grad(target_link, source_link):
+    for tp, sp in zip(target_link.parameters(), source_link.parameters()):
+        tp.grad = None if sp.grad is None else sp.grad.clone()
+
+
+def synchronize_parameters(src, dst, method, tau=None):
+    if method == "hard":
+        copy_param(dst, src)
+    elif method == "soft":
+        soft_copy_param(dst, src, tau)
+    else:
+        raise ValueError("unknown target update method %r" % (method,))

@@ -492,6 +492,75 @@ def sample_n_k_golden():
     print("sample_n_k cases", len(rec["n"]))
 
 
+# --------------------------------------------------------------------------
+# G. agent-level trace: reference DQN / DoubleDQN+PER driven by the reference's
+#    train_agent_batch on a deterministic synthetic vector env.
+# --------------------------------------------------------------------------
+def make_q_function(n_in, n_actions, head):
+    torch.manual_seed(1234)
+    return torch.nn.Sequential(
+        torch.nn.Flatten(), torch.nn.Linear(n_in, 32), torch.nn.ReLU(),
+        torch.nn.Linear(32, n_actions), head)
+
+
+def agent_trace(name, prioritized, num_steps, double, steps=640, N=4):
+    sys.path.insert(0, os.path.join(HERE, "..", ".."))
+    from pfrl_amd.envs.synthetic import HostSyntheticAtariVectorEnv  # env only (numpy)
+
+    import tempfile
+
+    from pfrl import agents, explorers, experiments, replay_buffers
+    from pfrl.q_functions import DiscreteActionValueHead
+
+    pfrl.utils.set_random_seed(0)
+    env = HostSyntheticAtariVectorEnv(N, seed=3, frame_shape=(12, 12), p_done=0.04)
+
+    def phi(x):
+        return np.asarray(x, dtype=np.float32) / 255
+
+    q = make_q_function(4 * 144, 6, DiscreteActionValueHead())
+    opt = torch.optim.RMSprop(q.parameters(), lr=2.5e-4, alpha=0.95, eps=1e-2)
+    if prioritized:
+        rbuf = replay_buffers.PrioritizedReplayBuffer(
+            200, alpha=0.5, beta0=0.4, betasteps=100, num_steps=num_steps,
+            normalize_by_max="memory")
+    else:
+        rbuf = replay_buffers.ReplayBuffer(200, num_steps=num_steps)
+    ex = explorers.LinearDecayEpsilonGreedy(1.0, 0.1, 400, lambda: np.random.randint(6))
+    cls = agents.DoubleDQN if double else agents.DQN
+    ag = cls(q, opt, rbuf, 0.99, ex, gpu=-1, replay_start_size=40, minibatch_size=8,
+             update_interval=4, target_update_interval=60, phi=phi, batch_accumulator="sum")
+    actions, losses, sampled = [], [], []
+    orig_act = ag.batch_act
+
+    def spy_act(obs):
+        a = orig_act(obs)
+        actions.append([int(x) for x in a])
+        return a
+
+    ag.batch_act = spy_act
+    orig_update = ag.update
+
+    def spy_update(exps, errors_out=None):
+        sampled.append([[float(np.asarray(t["reward"])) for t in e] for e in exps])
+        orig_update(exps, errors_out)
+        losses.append(ag.loss_record[-1])
+
+    ag.replay_updater.update_func = spy_update
+    experiments.train_agent_batch(ag, env, steps, tempfile.mkdtemp())
+    flat_rewards = [sum(r for e in s for r in e) for s in sampled]
+    out = dict(actions=np.asarray(actions), losses=np.asarray(losses),
+               sampled_reward_sum=np.asarray(flat_rewards),
+               sampled_len=np.asarray([[len(e) for e in s] for s in sampled]),
+               final_params=np.concatenate([p.detach().numpy().ravel() for p in q.parameters()]),
+               stats=np.asarray([float(v) for _, v in ag.get_statistics()]))
+    if prioritized:
+        out["final_tree_sum"] = np.asarray(float(rbuf.memory.priority_sums.sum()))
+        out["final_max_priority"] = np.asarray(float(rbuf.memory.max_priority))
+    np.savez_compressed(os.path.join(HERE, "agent_trace_%s.npz" % name), **out)
+    print("agent_trace", name, "updates", len(losses), "final loss", losses[-1])
+
+
 if __name__ == "__main__":
     random.seed(0)
     torch.manual_seed(0)
@@ -513,3 +582,5 @@ if __name__ == "__main__":
     gae_golden()
     a2c_golden()
     sample_n_k_golden()
+    agent_trace("dqn_uniform_n1", False, 1, False)
+    agent_trace("ddqn_per_n3", True, 3, True)
