@@ -108,7 +108,8 @@ class DQN(agent.AttributeSavingMixin, agent.BatchAgent):
                  target_update_interval=10000, clip_delta=True, phi=lambda x: x,
                  target_update_method="hard", soft_update_tau=1e-2, n_times_update=1,
                  batch_accumulator="mean", episodic_update_len=None, logger=getLogger(__name__),
-                 batch_states=batch_states, recurrent=False, max_grad_norm=None):
+                 batch_states=batch_states, recurrent=False, max_grad_norm=None,
+                 use_graphs=None, step_fused_gather=None):
         self.model = q_function
         if gpu is not None and gpu >= 0:
             assert torch.cuda.is_available()
@@ -162,6 +163,14 @@ class DQN(agent.AttributeSavingMixin, agent.BatchAgent):
         from pfrl_amd.distributed import GradientAllReducer
 
         self.grad_reducer = GradientAllReducer(self.model)
+        # HIP-graph replay of the update and one fused gather per env step are
+        # device-path optimisations; both compute exactly what eager mode does.
+        on_gpu = self.device.type == "cuda"
+        self.use_graphs = on_gpu if use_graphs is None else bool(use_graphs and on_gpu)
+        self.step_fused_gather = on_gpu if step_fused_gather is None else \
+            bool(step_fused_gather and on_gpu)
+        self._graphed = None
+        self._last_y = None
 
     @property
     def cumulative_steps(self):
@@ -183,21 +192,55 @@ class DQN(agent.AttributeSavingMixin, agent.BatchAgent):
         if has_weight and "weights" not in exp_batch:
             exp_batch["weights"] = torch.tensor([e[0]["weight"] for e in experiences],
                                                 device=self.device, dtype=torch.float32)
+        self._update_from_batch(exp_batch, has_weight, errors_out)
+
+    def _update_from_batch(self, exp_batch, has_weight=False, errors_out=None):
         want_errors = has_weight or errors_out is not None
-        loss, delta = self._compute_loss(exp_batch, want_errors=want_errors)
+        if self.use_graphs:
+            loss, delta = self._graphed_step(exp_batch, want_errors)
+        else:
+            loss, delta = self._compute_loss(exp_batch, want_errors=want_errors)
         if errors_out is not None:
             del errors_out[:]
             errors_out.extend(delta.cpu().numpy())
         if has_weight:
             self.replay_buffer.update_errors(delta if errors_out is None else errors_out)
-        self.loss_record.extend(loss)
-        self.optimizer.zero_grad()
-        loss.backward()
-        self.grad_reducer.all_reduce()
-        if self.max_grad_norm is not None:
-            clip_l2_grad_norm_(self.model.parameters(), self.max_grad_norm)
-        self.optimizer.step()
+        if not self.use_graphs:
+            self.loss_record.extend(loss)
+            self.optimizer.zero_grad()
+            loss.backward()
+            self.grad_reducer.all_reduce()
+            if self.max_grad_norm is not None:
+                clip_l2_grad_norm_(self.model.parameters(), self.max_grad_norm)
+            self.optimizer.step()
         self.optim_t += 1
+
+    def _graphed_step(self, exp_batch, want_errors):
+        """loss -> backward -> step replayed from a captured HIP graph."""
+        if self._graphed is None:
+            from pfrl_amd.agents.graphed_update import GraphedUpdate
+
+            self._graphed = GraphedUpdate(self)
+        try:
+            loss, delta, y = self._graphed.run(exp_batch, want_errors)
+        except Exception as e:  # capture not possible -> stay eager on the GPU
+            if self._graphed.graphs:
+                raise
+            self.logger.warning("HIP-graph capture of the update failed (%s); running eagerly", e)
+            self.use_graphs = False
+            loss, delta = self._compute_loss(exp_batch, want_errors=want_errors)
+            self.loss_record.extend(loss)
+            self.optimizer.zero_grad()
+            loss.backward()
+            self.grad_reducer.all_reduce()
+            if self.max_grad_norm is not None:
+                clip_l2_grad_norm_(self.model.parameters(), self.max_grad_norm)
+            self.optimizer.step()
+            return loss, delta
+        # graph outputs are static buffers: copy what the records keep
+        self.loss_record.extend(loss.clone())
+        self.q_record.extend(y.clone())
+        return loss, delta
 
     def _compute_target_values(self, exp_batch):
         target_next_qout = self.target_model(exp_batch["next_state"])
@@ -213,11 +256,13 @@ class DQN(agent.AttributeSavingMixin, agent.BatchAgent):
             batch_q_target = torch.reshape(self._compute_target_values(exp_batch), (batch_size, 1))
         return batch_q, batch_q_target
 
-    def _compute_loss(self, exp_batch, errors_out=None, want_errors=False):
+    def _compute_loss(self, exp_batch, errors_out=None, want_errors=False, record=True):
         """Returns (loss, |y - t| per sample or None).  ``errors_out`` keeps the
         reference's list-filling form for callers that use it directly."""
         y, t = self._compute_y_and_t(exp_batch)
-        self.q_record.extend(y)
+        self._last_y = y.detach()
+        if record:
+            self.q_record.extend(y)
         delta = None
         if errors_out is not None or want_errors:
             delta = torch.abs(y.detach() - t)
@@ -256,24 +301,62 @@ class DQN(agent.AttributeSavingMixin, agent.BatchAgent):
             batch_action = batch_argmax
         return batch_action
 
+    def _append_transition(self, i, batch_obs, batch_reward, batch_done, batch_reset):
+        rbuf = self.replay_buffer
+        if self.batch_last_obs[i] is not None:
+            assert self.batch_last_action[i] is not None
+            rbuf.append(state=self.batch_last_obs[i], action=self.batch_last_action[i],
+                        reward=batch_reward[i], next_state=batch_obs[i], next_action=None,
+                        is_state_terminal=batch_done[i], env_id=i)
+            if batch_reset[i] or batch_done[i]:
+                self.batch_last_obs[i] = None
+                self.batch_last_action[i] = None
+                rbuf.stop_current_episode(env_id=i)
+
     def _batch_observe_train(self, batch_obs, batch_reward, batch_done, batch_reset):
         rbuf = self.replay_buffer
+        if self.step_fused_gather and getattr(rbuf, "supports_lookahead", False):
+            return self._batch_observe_train_fused(batch_obs, batch_reward, batch_done,
+                                                   batch_reset)
         updater = self.replay_updater
         for i in range(len(batch_obs)):
             self.t += 1
             self._cumulative_steps += 1
             if self.t % self.target_update_interval == 0:
                 self.sync_target_network()
-            if self.batch_last_obs[i] is not None:
-                assert self.batch_last_action[i] is not None
-                rbuf.append(state=self.batch_last_obs[i], action=self.batch_last_action[i],
-                            reward=batch_reward[i], next_state=batch_obs[i], next_action=None,
-                            is_state_terminal=batch_done[i], env_id=i)
-                if batch_reset[i] or batch_done[i]:
-                    self.batch_last_obs[i] = None
-                    self.batch_last_action[i] = None
-                    rbuf.stop_current_episode(env_id=i)
+            self._append_transition(i, batch_obs, batch_reward, batch_done, batch_reset)
             updater.update_if_necessary(self.t)
+
+    def _batch_observe_train_fused(self, batch_obs, batch_reward, batch_done, batch_reset):
+        """Same schedule as the loop above (reference :516-549), reorganised
+        for the device: pass 1 appends all N transitions and draws the index
+        sets of every update this step is going to make (uniform replay: they
+        depend only on len(buffer) and the NumPy stream, in the same order);
+        ONE fused launch gathers all minibatches; pass 2 walks the envs again
+        and runs target syncs and updates at exactly their original positions.
+        The entry ring keeps `slack` spare slots, so rows appended "early" never
+        overwrite entries still visible to an earlier update of this step."""
+        rbuf = self.replay_buffer
+        up = self.replay_updater
+        n_env = len(batch_obs)
+        t0 = self.t
+        plan_env, plan_seqs = [], []
+        for i in range(n_env):
+            self._append_transition(i, batch_obs, batch_reward, batch_done, batch_reset)
+            if len(rbuf) >= up.replay_start_size and (t0 + i + 1) % up.update_interval == 0:
+                for _ in range(up.n_times_update):
+                    plan_env.append(i)
+                    plan_seqs.append(rbuf.lookahead_sample(up.batchsize))
+        big = rbuf.fetch_many(plan_seqs, self.phi, self.gamma) if plan_seqs else None
+        p = 0
+        for i in range(n_env):
+            self.t += 1
+            self._cumulative_steps += 1
+            if self.t % self.target_update_interval == 0:
+                self.sync_target_network()
+            while p < len(plan_env) and plan_env[p] == i:
+                self._update_from_batch({k: v[p] for k, v in big.items()})
+                p += 1
 
     def _batch_observe_eval(self, batch_obs, batch_reward, batch_done, batch_reset):
         pass

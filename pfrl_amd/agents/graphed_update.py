@@ -1,0 +1,167 @@
+"""HIP-graph capture of one optimizer update.
+
+The DQN update at minibatch 32 is ~150 tiny kernels (MIOpen convs, GEMMs,
+elementwise, foreach optimizer): eager dispatch costs ~1.7 ms of host time for
+~0.6 ms of device time.  Capturing loss -> backward -> (clip) -> optimizer.step
+once and replaying it removes the dispatcher from the loop (hipGraphLaunch,
+~15 us).  Capture is keyed by the *addresses* of the minibatch tensors: the
+replay store writes minibatches into persistent HBM buffers, so the same key
+recurs every step.
+
+Numerics are unchanged: the graph replays exactly the kernels eager mode
+launches.  The warm-up iterations PyTorch needs before capture run on a
+snapshot that is restored afterwards, so no extra optimizer step leaks into
+training.
+"""
+import copy
+import logging
+
+import torch
+
+from pfrl_amd import distributed
+
+
+def _optimizer_tensors(optimizer):
+    out = []
+    for st in optimizer.state.values():
+        for k, v in st.items():
+            if isinstance(v, torch.Tensor):
+                out.append((st, k, v))
+    return out
+
+
+def _make_capturable(optimizer, device):
+    """Switch a stock torch optimizer to its graph-capturable code path."""
+    ok = True
+    for group in optimizer.param_groups:
+        if "capturable" in group:
+            group["capturable"] = True
+        elif "foreach" in group or "fused" in group:
+            # optimizers without a step counter dependency (SGD) capture as is
+            pass
+        else:
+            ok = False
+    for st in optimizer.state.values():
+        step = st.get("step")
+        if isinstance(step, torch.Tensor) and step.device != device:
+            st["step"] = step.to(device)
+    return ok
+
+
+class GraphedUpdate:
+    """Caches one captured graph per minibatch-buffer address set."""
+
+    def __init__(self, agent, max_graphs=256):
+        self.agent = agent
+        self.graphs = {}
+        self.pool = None
+        self.enabled = True
+        self.max_graphs = max_graphs
+        self.logger = logging.getLogger(__name__)
+        self._capturable_done = False
+        self.split_for_allreduce = distributed.world_size() > 1
+
+    def _key(self, exp_batch):
+        return tuple(sorted((k, v.data_ptr(), tuple(v.shape)) for k, v in exp_batch.items()
+                            if isinstance(v, torch.Tensor)))
+
+    # the work that gets captured ------------------------------------------------
+    def _forward_backward(self, exp_batch, want_errors):
+        ag = self.agent
+        loss, delta = ag._compute_loss(exp_batch, want_errors=want_errors, record=False)
+        loss.backward()
+        return loss, delta
+
+    def _step(self):
+        ag = self.agent
+        if ag.max_grad_norm is not None:
+            torch.nn.utils.clip_grad_norm_(ag.model.parameters(), float(ag.max_grad_norm))
+        ag.optimizer.step()
+
+    def _snapshot(self):
+        ag = self.agent
+        params = [p.detach().clone() for p in ag.model.parameters()]
+        bufs = [b.detach().clone() for b in ag.model.buffers()]
+        had_state = len(ag.optimizer.state) > 0
+        opt = [(st, k, v.detach().clone()) for st, k, v in _optimizer_tensors(ag.optimizer)]
+        rng = torch.cuda.get_rng_state(ag.device)
+        return params, bufs, had_state, opt, rng
+
+    def _restore(self, snap):
+        ag = self.agent
+        params, bufs, had_state, opt, rng = snap
+        with torch.no_grad():
+            for p, s in zip(ag.model.parameters(), params):
+                p.copy_(s)
+            for b, s in zip(ag.model.buffers(), bufs):
+                b.copy_(s)
+            if had_state:
+                for st, k, v in opt:
+                    st[k].copy_(v)
+            else:
+                # state was created by the warm-up: reset it to its initial value
+                for st, k, v in _optimizer_tensors(ag.optimizer):
+                    v.zero_()
+        torch.cuda.set_rng_state(rng, ag.device)
+
+    def _capture(self, exp_batch, want_errors):
+        ag = self.agent
+        dev = ag.device
+        if not self._capturable_done:
+            if not _make_capturable(ag.optimizer, dev):
+                raise RuntimeError("optimizer %s has no capturable mode" % type(ag.optimizer))
+            self._capturable_done = True
+        snap = self._snapshot()
+        cur = torch.cuda.current_stream(dev)
+        side = torch.cuda.Stream(dev)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                ag.optimizer.zero_grad(set_to_none=True)
+                self._forward_backward(exp_batch, want_errors)
+                ag.grad_reducer.all_reduce()
+                self._step()
+        cur.wait_stream(side)
+        _make_capturable(ag.optimizer, dev)  # state created by the warm-up
+        entry = {}
+        ag.optimizer.zero_grad(set_to_none=True)
+        g1 = torch.cuda.CUDAGraph()
+        kw = {} if self.pool is None else {"pool": self.pool}
+        if not self.split_for_allreduce:
+            with torch.cuda.graph(g1, **kw):
+                loss, delta = self._forward_backward(exp_batch, want_errors)
+                self._step()
+            if self.pool is None:
+                self.pool = g1.pool()
+            entry["graphs"] = (g1,)
+        else:
+            # data parallel: graph(fwd+bwd) -> eager RCCL all-reduce -> graph(step)
+            with torch.cuda.graph(g1, **kw):
+                loss, delta = self._forward_backward(exp_batch, want_errors)
+            if self.pool is None:
+                self.pool = g1.pool()
+            g2 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g2, pool=self.pool):
+                self._step()
+            entry["graphs"] = (g1, g2)
+        entry["loss"] = loss
+        entry["delta"] = delta
+        entry["y"] = ag._last_y
+        self._restore(snap)
+        return entry
+
+    def run(self, exp_batch, want_errors):
+        """Returns (loss, delta, y) tensors owned by the graph (static)."""
+        key = (self._key(exp_batch), bool(want_errors))
+        entry = self.graphs.get(key)
+        if entry is None:
+            if len(self.graphs) >= self.max_graphs:
+                raise RuntimeError("too many distinct minibatch buffers for graph capture")
+            entry = self._capture(exp_batch, want_errors)
+            self.graphs[key] = entry
+        gs = entry["graphs"]
+        gs[0].replay()
+        if len(gs) == 2:
+            self.agent.grad_reducer.all_reduce()
+            gs[1].replay()
+        return entry["loss"], entry["delta"], entry["y"]

@@ -70,6 +70,7 @@ class PrioritizedBuffer:
         self._stage = StagingRing(dev, slot_bytes=1 << 16, n_slots=64)
         self._pend_x, self._pend_v, self._pend_t, self._pend_m = [], [], [], []
         self._sampled_x = None  # device int64 tensor of the last sample
+        self._sample_out = {}
         self._n_sampled = 0
         self._desc = TreeDesc()
         d = self._desc
@@ -151,19 +152,23 @@ class PrioritizedBuffer:
         if u01 is None:
             u01 = np.random.random_sample(n)
         (u_dev,) = self._stage.upload([np.asarray(u01, dtype=np.float64)])
-        dev = self.device
-        out = dict(
-            x=torch.empty(n, dtype=torch.int64, device=dev),
-            pri=torch.empty(n, dtype=torch.float64, device=dev),
-            pri_tag=torch.empty(n, dtype=torch.uint8, device=dev),
-            prob=torch.empty(n, dtype=torch.float64, device=dev),
-            weight=torch.empty(n, dtype=torch.float32, device=dev),
-            total=torch.empty(1, dtype=torch.float64, device=dev),
-            total_tag=torch.empty(1, dtype=torch.uint8, device=dev),
-            min_prob=torch.empty(1, dtype=torch.float64, device=dev),
-        )
-        if slot_mod:
-            out["slot"] = torch.empty(n, dtype=torch.int32, device=dev)
+        out = self._sample_out.get(n)
+        if out is None:
+            dev = self.device
+            out = self._sample_out[n] = dict(
+                x=torch.empty(n, dtype=torch.int64, device=dev),
+                pri=torch.empty(n, dtype=torch.float64, device=dev),
+                pri_tag=torch.empty(n, dtype=torch.uint8, device=dev),
+                prob=torch.empty(n, dtype=torch.float64, device=dev),
+                weight=torch.empty(n, dtype=torch.float32, device=dev),
+                total=torch.empty(1, dtype=torch.float64, device=dev),
+                total_tag=torch.empty(1, dtype=torch.uint8, device=dev),
+                min_prob=torch.empty(1, dtype=torch.float64, device=dev),
+                slot=torch.empty(n, dtype=torch.int32, device=dev),
+            )
+        out = dict(out)  # persistent buffers (stable addresses for graph replay)
+        if not slot_mod:
+            del out["slot"]
         ops.tree_sample(self._sync_desc(), u_dev, out, normalize, beta, slot_mod)
         self._sampled_x = out["x"]
         self._n_sampled = n

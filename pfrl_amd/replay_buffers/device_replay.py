@@ -71,6 +71,7 @@ class DeviceReplayStore:
         self._frame_cache = collections.OrderedDict()
         self._pend_frames = []
         self._pend_frame_slots = []
+        self._out_cache = {}
         # host mirrors, allocated with the tables
         self.h_state_ref = self.h_next_ref = self.h_action = None
         self.h_reward = self.h_terminal = self.h_min_fseq = None
@@ -341,10 +342,13 @@ class DeviceReplayStore:
             self._divisor = d
         return self._divisor
 
-    def fetch(self, batch, phi, gamma):
-        """The fused batch_experiences launch for a DeviceExperienceBatch."""
-        self.flush()
-        B = len(batch)
+    def _out_buffers(self, B, tag):
+        """Persistent fp32 minibatch buffers (stable addresses let the update
+        be replayed from a captured HIP graph)."""
+        key = (tag, B)
+        out = self._out_cache.get(key)
+        if out is not None:
+            return out
         dev = self.device
         fshape = self.frames.frame_shape
         k = self.k
@@ -363,12 +367,33 @@ class DeviceReplayStore:
             is_state_terminal=torch.empty(B, dtype=torch.float32, device=dev),
             discount=torch.empty(B, dtype=torch.float32, device=dev),
         )
+        self._out_cache[key] = out
+        return out
+
+    def fetch(self, batch, phi, gamma):
+        """The fused batch_experiences launch for a DeviceExperienceBatch."""
+        self.flush()
+        B = len(batch)
+        out = dict(self._out_buffers(B, "single"))
         gp = [gamma ** i for i in range(self.n + 1)]
         ops.batch_experiences(self.desc, self.frames.frames, self.divisor_for(phi),
                               batch.slots_dev, gp, out)
         if batch.weights_dev is not None:
             out["weights"] = batch.weights_dev
         return out
+
+    def fetch_many(self, seq_sets, phi, gamma):
+        """All minibatches of one env step in ONE launch (U * B entries)."""
+        self.flush()
+        U = len(seq_sets)
+        B = len(seq_sets[0])
+        seqs = np.concatenate(seq_sets)
+        slots_dev = self.slots_for(seqs)
+        flat = self._out_buffers(U * B, "many")
+        gp = [gamma ** i for i in range(self.n + 1)]
+        ops.batch_experiences(self.desc, self.frames.frames, self.divisor_for(phi), slots_dev, gp,
+                              flat)
+        return {k: v.view((U, B) + tuple(v.shape[1:])) for k, v in flat.items()}
 
     # -- API-compatible host views ---------------------------------------------
     def transition_view(self, tid, weight=None):

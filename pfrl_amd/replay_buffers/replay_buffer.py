@@ -171,6 +171,23 @@ class ReplayBuffer(replay_buffer.AbstractReplayBuffer):
     def __len__(self):
         return 0 if self.memory is None else len(self.memory)
 
+    # -- step-fused sampling (device, uniform) ----------------------------------
+    @property
+    def supports_lookahead(self):
+        return self.store is not None and type(self.memory) is _DeviceQueue
+
+    def lookahead_sample(self, k):
+        """Draw the indices ``sample(k)`` would draw NOW (same NumPy stream use)
+        and return the entry sequence numbers, without touching the device."""
+        assert len(self.memory) >= k
+        idx = sample_n_k(len(self.memory), k)
+        return self.memory.head + np.asarray(idx, dtype=np.int64)
+
+    def fetch_many(self, seq_sets, phi, gamma):
+        """One fused batch_experiences launch for several planned minibatches;
+        returns a dict of tensors with a leading "update" dimension."""
+        return self.store.fetch_many(seq_sets, phi, gamma)
+
     def save(self, filename):
         self._ensure_bound()
         with open(filename, "wb") as f:
