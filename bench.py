@@ -48,7 +48,7 @@ def parse_args():
                    help="transitions to prefill (default: capacity, i.e. full buffer)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-baseline-seconds", type=float, default=12.0)
-    p.add_argument("--profile-every", type=int, default=4,
+    p.add_argument("--profile-every", type=int, default=1,
                    help="bracket every n-th batch_experiences launch with HIP events")
     return p.parse_args()
 
@@ -236,19 +236,22 @@ def main():
 
     # dominant HIP kernel: the fused batch_experiences gather
     evs = ops.PROFILE_EVENTS
-    k_ms = [a.elapsed_time(b) for a, b in evs]
-    B, k, fb = args.minibatch, 4, 84 * 84
-    alg_bytes = B * 2 * k * (fb + 4 * fb)
+    k, fb = 4, 84 * 84
     roofline = None
-    if k_ms:
-        avg_s = float(np.mean(k_ms)) * 1e-3
-        achieved = alg_bytes / avg_s / 1e9
+    if evs:
+        # algorithmic bytes per sampled entry: state + next_state,
+        # each k frames read as u8 and written as f32
+        per_entry = 2 * k * (fb + 4 * fb)
+        tot_bytes = sum(per_entry * b for _, _, b in evs)
+        tot_s = sum(a.elapsed_time(b_) for a, b_, _ in evs) * 1e-3
+        achieved = tot_bytes / tot_s / 1e9
         roofline = {
             "bound": "hbm", "kernel": "k_batch_experiences<0,long>",
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-            "bytes_per_launch": alg_bytes, "avg_launch_us": round(avg_s * 1e6, 2),
-            "launches_timed": len(k_ms),
+            "bytes_per_launch": int(tot_bytes / len(evs)),
+            "entries_per_launch": int(np.mean([b for _, _, b in evs])),
+            "avg_launch_us": round(tot_s / len(evs) * 1e6, 2), "launches_timed": len(evs),
         }
 
     if rank == 0:

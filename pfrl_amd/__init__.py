@@ -16,6 +16,7 @@ from pfrl_amd import explorer  # NOQA
 from pfrl_amd import explorers  # NOQA
 from pfrl_amd import initializers  # NOQA
 from pfrl_amd import nn  # NOQA
+from pfrl_amd import policies  # NOQA
 from pfrl_amd import q_functions  # NOQA
 from pfrl_amd import replay_buffer  # NOQA
 from pfrl_amd import replay_buffers  # NOQA

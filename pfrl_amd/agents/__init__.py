@@ -1,2 +1,3 @@
 from pfrl_amd.agents.dqn import DQN  # NOQA
 from pfrl_amd.agents.double_dqn import DoubleDQN  # NOQA
+from pfrl_amd.agents.ppo import PPO  # NOQA

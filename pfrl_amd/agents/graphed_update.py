@@ -112,6 +112,10 @@ class GraphedUpdate:
                 raise RuntimeError("optimizer %s has no capturable mode" % type(ag.optimizer))
             self._capturable_done = True
         snap = self._snapshot()
+        try:
+            torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
+        except AttributeError:
+            pass
         cur = torch.cuda.current_stream(dev)
         side = torch.cuda.Stream(dev)
         side.wait_stream(cur)

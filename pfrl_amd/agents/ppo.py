@@ -1,0 +1,397 @@
+"""Proximal Policy Optimization on the device rollout path.
+
+Mirrors ``pfrl.agents.ppo.PPO`` (/root/reference/pfrl/agents/ppo.py) for the
+non-recurrent case: constructor (:320-346), ``batch_act`` / ``batch_observe``
+(:706-807), dataset construction (:110-142, :228-244), GAE (:36-47),
+advantage standardisation (:476-478, :494-495), minibatch order (:247-257),
+loss (:634-671), statistics (:809-817).
+
+Where the reference keeps a Python list of transition dicts and re-collates
+observations for every pass, this implementation keeps a T x N rollout on the
+device:
+
+  observations   frame slots in a DeviceFrameStore (one write per frame)
+  value pass     gather kernel -> model, in chunks sized for HBM
+  GAE            pfrl_gae_scan: one lane per env, reverse scan over T, restart
+                 at every fragment end (done / reset / rollout end)
+  adv statistics pfrl_adv_stats (f64 accumulate, wavefront shuffle reduce)
+  minibatches    pfrl_ppo_minibatch gathers advantages (standardised), old
+                 log-probs / values, targets, actions and observation refs for
+                 the dataset positions drawn on the host with Python's
+                 ``random`` exactly as the reference does
+
+so the only per-update host work is the permutation draw.
+"""
+import itertools
+import random
+from logging import getLogger
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from pfrl_amd import agent, ops
+from pfrl_amd.agents.dqn import _DeviceRecord, _mean_or_nan
+from pfrl_amd.device_store import DeviceObsBatch
+from pfrl_amd.utils.batch_states import batch_states
+from pfrl_amd.utils.contexts import evaluating
+from pfrl_amd.utils.mode_of_distribution import mode_of_distribution
+
+
+def _elementwise_clip(x, x_min, x_max):
+    return torch.min(torch.max(x, x_min), x_max)
+
+
+def _yield_minibatch_positions(n, minibatch_size, num_epochs):
+    """Dataset positions of successive minibatches.  Same consumption of the
+    ``random`` stream as reference :247-257 (random.sample over the dataset)."""
+    buf = []
+    done = 0
+    while done < n * num_epochs:
+        while len(buf) < minibatch_size:
+            buf = random.sample(range(n), k=n) + buf
+        yield buf[-minibatch_size:]
+        done += minibatch_size
+        buf = buf[:-minibatch_size]
+
+
+class _Rollout:
+    """T x N on-device rollout (env index minor)."""
+
+    def __init__(self, device, n_envs, k, t_cap, act_shape, act_dtype):
+        self.device = device
+        self.N, self.k, self.cap = n_envs, k, t_cap
+        self.T = 0
+        self.h_state = np.zeros((t_cap, n_envs, k), dtype=np.int32)
+        self.h_next = np.zeros((t_cap, n_envs, k), dtype=np.int32)
+        self.h_reward = np.zeros((t_cap, n_envs), dtype=np.float64)
+        self.h_nonterm = np.zeros((t_cap, n_envs), dtype=np.uint8)
+        self.h_cut = np.zeros((t_cap, n_envs), dtype=np.uint8)
+        self.h_action = np.zeros((t_cap, n_envs) + tuple(act_shape), dtype=act_dtype)
+        self.closed = []          # (env, t_start, t_end) in completion order
+        self.open_start = np.zeros(n_envs, dtype=np.int64)
+
+    def add_step(self, s_refs, n_refs, action, reward, done, reset):
+        t = self.T
+        assert t < self.cap, "rollout longer than allocated"
+        self.h_state[t] = s_refs
+        self.h_next[t] = n_refs
+        self.h_action[t] = action
+        self.h_reward[t] = reward
+        self.h_nonterm[t] = ~done
+        end = done | reset
+        self.h_cut[t] = end
+        for e in np.flatnonzero(end):   # reference :786-789, env order
+            self.closed.append((int(e), int(self.open_start[e]), t))
+            self.open_start[e] = t + 1
+        self.T = t + 1
+
+    def size(self):
+        return self.T * self.N
+
+    def dataset_order(self):
+        """Flat (t * N + e) index of every dataset position, in the reference's
+        order: completed episodes first (completion order), then the unfinished
+        fragments in env order (reference :450-458)."""
+        parts = []
+        T, N = self.T, self.N
+        for e, a, b in self.closed:
+            parts.append(np.arange(a, b + 1, dtype=np.int64) * N + e)
+        for e in range(N):
+            a = int(self.open_start[e])
+            if a < T:
+                parts.append(np.arange(a, T, dtype=np.int64) * N + e)
+        return np.concatenate(parts) if parts else np.zeros(0, dtype=np.int64)
+
+    def reset(self):
+        self.T = 0
+        self.closed = []
+        self.open_start[:] = 0
+
+
+class PPO(agent.AttributeSavingMixin, agent.BatchAgent):
+    """Proximal Policy Optimization (arguments as in the reference)."""
+
+    saved_attributes = ("model", "optimizer", "obs_normalizer")
+
+    def __init__(self, model, optimizer, obs_normalizer=None, gpu=None, gamma=0.99, lambd=0.95,
+                 phi=lambda x: x, value_func_coef=1.0, entropy_coef=0.01, update_interval=2048,
+                 minibatch_size=64, epochs=10, clip_eps=0.2, clip_eps_vf=None,
+                 standardize_advantages=True, batch_states=batch_states, recurrent=False,
+                 max_recurrent_sequence_len=None, act_deterministically=False, max_grad_norm=None,
+                 value_stats_window=1000, entropy_stats_window=1000, value_loss_stats_window=100,
+                 policy_loss_stats_window=100, value_pass_chunk=8192):
+        self.model = model
+        self.optimizer = optimizer
+        self.obs_normalizer = obs_normalizer
+        if recurrent:
+            raise NotImplementedError("recurrent PPO is outside the batched hot path")
+        if obs_normalizer is not None:
+            raise NotImplementedError("obs_normalizer (MuJoCo PPO) is not on the Atari hot path")
+        if gpu is None or gpu < 0:
+            raise RuntimeError("pfrl_amd.PPO keeps its rollout in HBM and needs gpu >= 0")
+        assert torch.cuda.is_available()
+        self.device = torch.device("cuda:{}".format(gpu))
+        self.model.to(self.device)
+        from pfrl_amd import _native
+
+        _native.lib()
+        self.gamma = gamma
+        self.lambd = lambd
+        self.phi = phi
+        self.value_func_coef = value_func_coef
+        self.entropy_coef = entropy_coef
+        self.update_interval = update_interval
+        self.minibatch_size = minibatch_size
+        self.epochs = epochs
+        self.clip_eps = clip_eps
+        self.clip_eps_vf = clip_eps_vf
+        self.standardize_advantages = standardize_advantages
+        self.batch_states = batch_states
+        self.recurrent = False
+        self.act_deterministically = act_deterministically
+        self.max_grad_norm = max_grad_norm
+        self.value_pass_chunk = value_pass_chunk
+        self.logger = getLogger(__name__)
+
+        self.rollout = None
+        self.ingest = None         # DeviceReplayStore used for host-observation ingestion
+        self.frames = None
+        self.batch_last_state = None
+        self.batch_last_action = None
+        self._last_refs = None
+
+        self.value_record = _DeviceRecord(value_stats_window)
+        self.entropy_record = _DeviceRecord(entropy_stats_window)
+        self.value_loss_record = _DeviceRecord(value_loss_stats_window)
+        self.policy_loss_record = _DeviceRecord(policy_loss_stats_window)
+        self.explained_variance = np.nan
+        self.n_updates = 0
+        self._reward_mode = None
+        from pfrl_amd.distributed import GradientAllReducer
+
+        self.grad_reducer = GradientAllReducer(self.model)
+        from pfrl_amd.staging import StagingRing
+
+        self._stage = StagingRing(self.device, slot_bytes=max(1 << 22, 96 * int(update_interval)),
+                                  n_slots=8)
+
+    # -- observations ------------------------------------------------------------
+    def _refs_of(self, batch_obs):
+        """Frame slots [N, k] of a batch of observations (device or host)."""
+        if isinstance(batch_obs, DeviceObsBatch):
+            if self.frames is None:
+                self.frames = batch_obs.store
+            return batch_obs.refs, batch_obs
+        if self.ingest is None:
+            from pfrl_amd.replay_buffers.device_replay import DeviceReplayStore
+
+            self.ingest = DeviceReplayStore(
+                self.device, capacity=self.update_interval + 4 * len(batch_obs) + 64, num_steps=1)
+            self.ingest.set_phi(self.phi)
+        pairs = [self.ingest.ingest(o) for o in batch_obs]
+        self.ingest.flush()
+        self.frames = self.ingest.frames
+        refs = np.stack([p[0] for p in pairs]).astype(np.int32)
+        batch = DeviceObsBatch(self.frames, refs, np.array([p[1] for p in pairs]))
+        return refs, batch
+
+    def _divisor(self):
+        if self.ingest is not None:
+            return self.ingest.divisor_for(self.phi)
+        from pfrl_amd.utils.batch_states import _divisor_for
+
+        d = _divisor_for(self.phi, lambda: self._sample_obs.to_numpy())
+        if d is None:
+            raise TypeError("pfrl_amd.PPO: phi must be a cast/scale feature extractor")
+        return d
+
+    def _gather(self, refs_dev):
+        x = self.frames.gather(refs_dev, self._divisor())
+        fs = self.frames.frame_shape
+        if refs_dev.shape[1] == 1:
+            return x.view((x.shape[0],) + fs)
+        if len(fs) >= 2 and fs[0] == 1:
+            return x.view((x.shape[0], refs_dev.shape[1]) + fs[1:])
+        return x
+
+    # -- acting --------------------------------------------------------------------
+    def _sample_action(self, action_distrib):
+        return action_distrib.sample()
+
+    def _batch_act_train(self, batch_obs):
+        assert self.training
+        refs, dev_batch = self._refs_of(batch_obs)
+        self._sample_obs = dev_batch[0]
+        (refs_dev,) = self._stage.upload([refs])
+        b_state = self._gather(refs_dev)
+        with torch.no_grad(), evaluating(self.model):
+            action_distrib, batch_value = self.model(b_state)
+            action_dev = self._sample_action(action_distrib)
+            self.entropy_record.extend(action_distrib.entropy())
+            self.value_record.extend(batch_value)
+        batch_action = action_dev.cpu().numpy()
+        self._last_refs = refs.copy()
+        self.batch_last_state = list(range(len(batch_obs)))
+        self.batch_last_action = list(batch_action)
+        return batch_action
+
+    def _batch_act_eval(self, batch_obs):
+        assert not self.training
+        refs, dev_batch = self._refs_of(batch_obs)
+        self._sample_obs = dev_batch[0]
+        (refs_dev,) = self._stage.upload([refs])
+        b_state = self._gather(refs_dev)
+        with torch.no_grad(), evaluating(self.model):
+            action_distrib, _ = self.model(b_state)
+            if self.act_deterministically:
+                action = mode_of_distribution(action_distrib).cpu().numpy()
+            else:
+                action = action_distrib.sample().cpu().numpy()
+        return action
+
+    def batch_act(self, batch_obs):
+        if self.training:
+            return self._batch_act_train(batch_obs)
+        return self._batch_act_eval(batch_obs)
+
+    # -- observing -------------------------------------------------------------------
+    def _batch_observe_train(self, batch_obs, batch_reward, batch_done, batch_reset):
+        assert self.training
+        n_env = len(batch_obs)
+        next_refs, _ = self._refs_of(batch_obs)
+        actions = np.asarray(self.batch_last_action)
+        if self.rollout is None:
+            t_cap = -(-self.update_interval // n_env) + 2
+            self.rollout = _Rollout(self.device, n_env, next_refs.shape[1], t_cap,
+                                    actions.shape[1:], actions.dtype)
+        if self._reward_mode is None:
+            r0 = batch_reward[0]
+            # NEP 50: np.float64 rewards promote the GAE arithmetic to f64,
+            # Python floats / np.float32 keep it in f32
+            self._reward_mode = 1 if isinstance(r0, np.float64) else 0
+        done = np.asarray(batch_done, dtype=bool)
+        reset = np.asarray(batch_reset, dtype=bool)
+        self.rollout.add_step(self._last_refs, next_refs, actions,
+                              np.asarray(batch_reward, dtype=np.float64), done, reset)
+        self.batch_last_state = [None] * n_env
+        self.batch_last_action = [None] * n_env
+        self._update_if_dataset_is_ready()
+
+    def batch_observe(self, batch_obs, batch_reward, batch_done, batch_reset):
+        if self.training:
+            self._batch_observe_train(batch_obs, batch_reward, batch_done, batch_reset)
+
+    # -- learning --------------------------------------------------------------------
+    def _update_if_dataset_is_ready(self):
+        if self.rollout.size() >= self.update_interval:
+            self._update()
+            self.rollout.reset()
+
+    def _value_pass(self, refs_dev, actions_dev):
+        """log pi(a|s) and V(s) for every rollout position (reference :110-142),
+        chunked so that the fp32 observation batch stays a few hundred MB."""
+        M = refs_dev.shape[0]
+        log_probs = torch.empty(M, dtype=torch.float32, device=self.device)
+        values = torch.empty(M, dtype=torch.float32, device=self.device)
+        with torch.no_grad(), evaluating(self.model):
+            for lo in range(0, M, self.value_pass_chunk):
+                hi = min(M, lo + self.value_pass_chunk)
+                distribs, vs = self.model(self._gather(refs_dev[lo:hi]))
+                values[lo:hi] = vs.reshape(-1)
+                if actions_dev is not None:
+                    log_probs[lo:hi] = distribs.log_prob(actions_dev[lo:hi])
+        return log_probs, values
+
+    def _update(self):
+        ro = self.rollout
+        T, N, k = ro.T, ro.N, ro.k
+        dev = self.device
+        order = ro.dataset_order()
+        n = len(order)
+        assert n == T * N
+        # ship the rollout columns (one transfer)
+        up = self._stage.upload([
+            ro.h_state[:T].reshape(T * N, k), ro.h_next[:T].reshape(T * N, k),
+            ro.h_action[:T].reshape((T * N,) + ro.h_action.shape[2:]),
+            ro.h_reward[:T].reshape(-1), ro.h_nonterm[:T].reshape(-1),
+            self._cut_with_rollout_end(ro, T).reshape(-1), order])
+        s_refs, n_refs, actions, reward, nonterm, cut, order_dev = up
+        log_probs, v_pred = self._value_pass(s_refs, actions)
+        _, next_v = self._value_pass(n_refs, None)
+        adv, v_teacher = ops.gae_scan(reward.view(T, N), v_pred.view(T, N), next_v.view(T, N),
+                                      nonterm.view(T, N), cut.view(T, N), self.gamma, self.lambd,
+                                      self._reward_mode)
+        adv = adv.view(-1)
+        v_teacher = v_teacher.view(-1)
+        mean_std = ops.adv_stats(adv) if self.standardize_advantages else \
+            torch.zeros(2, dtype=torch.float32, device=dev)
+        actions_i64 = actions if actions.dtype == torch.int64 else None
+        self._last_dataset = dict(order=order, adv=adv, v_teacher=v_teacher, v_pred=v_pred,
+                                  log_prob=log_probs, mean_std=mean_std)
+
+        for pos in _yield_minibatch_positions(n, self.minibatch_size, self.epochs):
+            flat = order[np.asarray(pos, dtype=np.int64)]
+            (idx,) = self._stage.upload([flat])
+            if actions_i64 is not None:
+                mb = ops.ppo_minibatch(idx, adv, mean_std, self.standardize_advantages, log_probs,
+                                       v_pred, v_teacher, actions_i64, s_refs)
+                mb_actions = mb["action"]
+            else:
+                dummy = torch.zeros(1, dtype=torch.int64, device=dev).expand(n).contiguous()
+                mb = ops.ppo_minibatch(idx, adv, mean_std, self.standardize_advantages, log_probs,
+                                       v_pred, v_teacher, dummy, s_refs)
+                mb_actions = actions[idx]
+            states = self._gather(mb["refs"])
+            distribs, vs_pred = self.model(states)
+            self.model.zero_grad()
+            loss = self._lossfun(
+                distribs.entropy(), vs_pred, distribs.log_prob(mb_actions),
+                vs_pred_old=mb["v_pred"][..., None], log_probs_old=mb["log_prob"],
+                advs=mb["adv"], vs_teacher=mb["v_teacher"][..., None])
+            loss.backward()
+            self.grad_reducer.all_reduce()
+            if self.max_grad_norm is not None:
+                torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.max_grad_norm)
+            self.optimizer.step()
+            self.n_updates += 1
+        # explained variance (reference :181-193), one small reduction
+        with torch.no_grad():
+            vart = torch.var(v_teacher, unbiased=False)
+            ev = 1 - torch.var(v_teacher - v_pred, unbiased=False) / vart
+            self.explained_variance = float("nan") if float(vart) == 0 else float(ev)
+
+    @staticmethod
+    def _cut_with_rollout_end(ro, T):
+        cut = ro.h_cut[:T].copy()
+        cut[T - 1] = 1   # unfinished fragments end with the rollout (reference :450-458)
+        return cut
+
+    def _lossfun(self, entropy, vs_pred, log_probs, vs_pred_old, log_probs_old, advs, vs_teacher):
+        prob_ratio = torch.exp(log_probs - log_probs_old)
+        loss_policy = -torch.mean(torch.min(
+            prob_ratio * advs,
+            torch.clamp(prob_ratio, 1 - self.clip_eps, 1 + self.clip_eps) * advs))
+        if self.clip_eps_vf is None:
+            loss_value_func = F.mse_loss(vs_pred, vs_teacher)
+        else:
+            clipped_vs_pred = _elementwise_clip(vs_pred, vs_pred_old - self.clip_eps_vf,
+                                                vs_pred_old + self.clip_eps_vf)
+            loss_value_func = torch.mean(torch.max(
+                F.mse_loss(vs_pred, vs_teacher, reduction="none"),
+                F.mse_loss(clipped_vs_pred, vs_teacher, reduction="none")))
+        loss_entropy = -torch.mean(entropy)
+        self.value_loss_record.extend(loss_value_func)
+        self.policy_loss_record.extend(loss_policy)
+        return (loss_policy + self.value_func_coef * loss_value_func
+                + self.entropy_coef * loss_entropy)
+
+    def get_statistics(self):
+        return [
+            ("average_value", _mean_or_nan(self.value_record.values())),
+            ("average_entropy", _mean_or_nan(self.entropy_record.values())),
+            ("average_value_loss", _mean_or_nan(self.value_loss_record.values())),
+            ("average_policy_loss", _mean_or_nan(self.policy_loss_record.values())),
+            ("n_updates", self.n_updates),
+            ("explained_variance", self.explained_variance),
+        ]

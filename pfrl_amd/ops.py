@@ -112,7 +112,7 @@ def batch_experiences(desc, frames, divisor, entry_slots, gamma_pow, out):
         _ptr(out["discount"]), _stream()), "batch_experiences")
     if ev is not None:
         ev[1].record()
-        PROFILE_EVENTS.append(ev)
+        PROFILE_EVENTS.append((ev[0], ev[1], B))
     return out
 
 

@@ -561,6 +561,80 @@ def agent_trace(name, prioritized, num_steps, double, steps=640, N=4):
     print("agent_trace", name, "updates", len(losses), "final loss", losses[-1])
 
 
+# --------------------------------------------------------------------------
+# H. PPO trace: reference PPO on the synthetic vector env.  Actions are
+#    recorded so that a run on another device (whose torch RNG differs) can
+#    replay them; everything downstream (value pass, GAE, advantage
+#    standardisation, minibatch order from `random`, losses) is then
+#    comparable.
+# --------------------------------------------------------------------------
+def make_ppo_model(n_in, n_actions, SoftmaxCategoricalHead, Branched):
+    torch.manual_seed(4321)
+    return torch.nn.Sequential(
+        torch.nn.Flatten(), torch.nn.Linear(n_in, 32), torch.nn.ReLU(),
+        Branched(torch.nn.Sequential(torch.nn.Linear(32, n_actions), SoftmaxCategoricalHead()),
+                 torch.nn.Linear(32, 1)))
+
+
+def ppo_trace(name="ppo", steps=280, N=4):
+    sys.path.insert(0, os.path.join(HERE, "..", ".."))
+    import tempfile
+
+    from pfrl import agents, experiments
+    from pfrl.policies import SoftmaxCategoricalHead
+
+    from pfrl_amd.envs.synthetic import HostSyntheticAtariVectorEnv
+
+    pfrl.utils.set_random_seed(0)
+    env = HostSyntheticAtariVectorEnv(N, seed=5, frame_shape=(12, 12), p_done=0.06)
+
+    def phi(x):
+        return np.asarray(x, dtype=np.float32) / 255
+
+    model = make_ppo_model(4 * 144, 6, SoftmaxCategoricalHead, pfrl.nn.Branched)
+    opt = torch.optim.Adam(model.parameters(), lr=2.5e-4, eps=1e-5)
+    ag = agents.PPO(model, opt, gpu=-1, gamma=0.99, lambd=0.95, phi=phi, update_interval=64,
+                    minibatch_size=16, epochs=2, clip_eps=0.1, clip_eps_vf=None,
+                    standardize_advantages=True, max_grad_norm=0.5)
+    actions, losses, datasets = [], [], []
+    orig_act = ag.batch_act
+
+    def spy_act(obs):
+        a = orig_act(obs)
+        actions.append([int(x) for x in a])
+        return a
+
+    ag.batch_act = spy_act
+    orig_loss = ag._lossfun
+
+    def spy_loss(*a, **kw):
+        out = orig_loss(*a, **kw)
+        losses.append([float(out), ag.value_loss_record[-1], ag.policy_loss_record[-1]])
+        return out
+
+    ag._lossfun = spy_loss
+    orig_update = ag._update
+
+    def spy_update(dataset):
+        datasets.append(np.asarray([[float(b["adv"]), float(b["v_teacher"]), float(b["v_pred"]),
+                                     float(b["log_prob"]), float(b["reward"]),
+                                     float(b["nonterminal"])] for b in dataset]))
+        return orig_update(dataset)
+
+    ag._update = spy_update
+    experiments.train_agent_batch(ag, env, steps, tempfile.mkdtemp())
+    out = dict(actions=np.asarray(actions), losses=np.asarray(losses),
+               final_params=np.concatenate([p.detach().numpy().ravel()
+                                            for p in model.parameters()]),
+               n_updates=np.asarray(ag.n_updates),
+               explained_variance=np.asarray(ag.explained_variance))
+    for i, d in enumerate(datasets):
+        out["dataset%d" % i] = d
+    out["n_datasets"] = np.asarray(len(datasets))
+    np.savez_compressed(os.path.join(HERE, "agent_trace_%s.npz" % name), **out)
+    print("ppo_trace updates", ag.n_updates, "datasets", len(datasets))
+
+
 if __name__ == "__main__":
     random.seed(0)
     torch.manual_seed(0)
@@ -584,3 +658,4 @@ if __name__ == "__main__":
     sample_n_k_golden()
     agent_trace("dqn_uniform_n1", False, 1, False)
     agent_trace("ddqn_per_n3", True, 3, True)
+    ppo_trace()

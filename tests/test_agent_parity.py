@@ -47,15 +47,38 @@ def _run(name, prioritized, num_steps, double, gpu, priority_pow="device", steps
         return a
 
     ag.batch_act = spy_act
-    orig_update = ag.update
 
-    def spy_update(exps, errors_out=None):
+    # record every sampled minibatch (as reward sums / window lengths) and the
+    # loss of every update, whichever path the agent takes (per-update sample()
+    # or the step-fused lookahead)
+    def note_sample(exps):
         sampled_sum.append(sum(float(t["reward"]) for e in exps for t in e))
         sampled_len.append([len(e) for e in exps])
-        orig_update(exps, errors_out)
+
+    orig_sample = rbuf.sample
+
+    def spy_sample(n):
+        exps = orig_sample(n)
+        note_sample(exps)
+        return exps
+
+    rbuf.sample = spy_sample
+    if hasattr(rbuf, "lookahead_sample"):
+        orig_look = rbuf.lookahead_sample
+
+        def spy_look(k):
+            seqs = orig_look(k)
+            note_sample([rbuf.store.entry_view(int(q)) for q in seqs])
+            return seqs
+
+        rbuf.lookahead_sample = spy_look
+    orig_core = ag._update_from_batch
+
+    def spy_core(*a, **kw):
+        orig_core(*a, **kw)
         losses.append(float(ag.loss_record.values()[-1]))
 
-    ag.replay_updater.update_func = spy_update
+    ag._update_from_batch = spy_core
     pfrl.experiments.train_agent_batch(ag, env, steps, tempfile.mkdtemp())
     params = np.concatenate([p.detach().cpu().numpy().ravel() for p in q.parameters()])
     return dict(actions=np.asarray(actions), losses=np.asarray(losses),
@@ -107,3 +130,76 @@ def test_double_dqn_prioritized_n3_device_matches_reference(priority_pow):
         # fp32 tolerance with the CPU reference run
         np.testing.assert_allclose(st[0][0], float(g["final_tree_sum"]), rtol=1e-4)
     np.testing.assert_allclose(st[2][0], float(g["final_max_priority"]), rtol=1e-4)
+
+
+@pytest.mark.gpu
+def test_ppo_device_rollout_matches_reference():
+    """PPO on the device rollout path vs the reference trace.  The sampled
+    actions are replayed (CPU and GPU torch RNG streams differ by construction);
+    value pass, GAE kernel, advantage statistics, minibatch order (``random``
+    stream), losses and the trained parameters must then agree."""
+    import pfrl_amd as pfrl
+    from pfrl_amd import agents
+    from pfrl_amd.envs.synthetic import HostSyntheticAtariVectorEnv
+    from pfrl_amd.nn import Branched
+    from pfrl_amd.policies import SoftmaxCategoricalHead
+
+    g = np.load(os.path.join(GOLDEN, "agent_trace_ppo.npz"))
+    N = 4
+    pfrl.utils.set_random_seed(0)
+    env = HostSyntheticAtariVectorEnv(N, seed=5, frame_shape=(12, 12), p_done=0.06)
+
+    def phi(x):
+        return np.asarray(x, dtype=np.float32) / 255
+
+    torch.manual_seed(4321)
+    model = torch.nn.Sequential(
+        torch.nn.Flatten(), torch.nn.Linear(4 * 144, 32), torch.nn.ReLU(),
+        Branched(torch.nn.Sequential(torch.nn.Linear(32, 6), SoftmaxCategoricalHead()),
+                 torch.nn.Linear(32, 1)))
+    opt = torch.optim.Adam(model.parameters(), lr=2.5e-4, eps=1e-5)
+    ag = agents.PPO(model, opt, gpu=0, gamma=0.99, lambd=0.95, phi=phi, update_interval=64,
+                    minibatch_size=16, epochs=2, clip_eps=0.1, clip_eps_vf=None,
+                    standardize_advantages=True, max_grad_norm=0.5)
+    step = [0]
+
+    def replay_action(distrib):
+        a = torch.as_tensor(g["actions"][step[0]], device=ag.device)
+        step[0] += 1
+        return a
+
+    ag._sample_action = replay_action
+    losses, datasets = [], []
+    orig_loss = ag._lossfun
+
+    def spy_loss(*a, **kw):
+        out = orig_loss(*a, **kw)
+        losses.append([float(out), float(ag.value_loss_record.values()[-1]),
+                       float(ag.policy_loss_record.values()[-1])])
+        return out
+
+    ag._lossfun = spy_loss
+    orig_update = ag._update
+
+    def spy_update():
+        orig_update()
+        d = ag._last_dataset
+        o = torch.from_numpy(d["order"]).to(ag.device)
+        datasets.append(np.stack([d["adv"][o].cpu().numpy(), d["v_teacher"][o].cpu().numpy(),
+                                  d["v_pred"][o].cpu().numpy(), d["log_prob"][o].cpu().numpy()],
+                                 axis=1))
+
+    ag._update = spy_update
+    pfrl.experiments.train_agent_batch(ag, env, 280, tempfile.mkdtemp())
+    assert ag.n_updates == int(g["n_updates"])
+    assert len(datasets) == int(g["n_datasets"])
+    # first dataset: identical weights on both sides -> fp32 tolerance 1e-5
+    np.testing.assert_allclose(datasets[0], g["dataset0"][:, :4], rtol=1e-5, atol=1e-5)
+    for i in range(1, len(datasets)):
+        np.testing.assert_allclose(datasets[i], g["dataset%d" % i][:, :4], rtol=1e-3, atol=1e-4)
+    got = np.asarray(losses)
+    np.testing.assert_allclose(got[:8], g["losses"][:8], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(got, g["losses"], rtol=1e-3, atol=1e-4)
+    params = np.concatenate([p.detach().cpu().numpy().ravel() for p in model.parameters()])
+    np.testing.assert_allclose(params, g["final_params"], rtol=1e-3, atol=1e-5)
+    np.testing.assert_allclose(ag.explained_variance, float(g["explained_variance"]), atol=1e-3)
