@@ -592,7 +592,10 @@ def ppo_trace(name="ppo", steps=280, N=4):
         return np.asarray(x, dtype=np.float32) / 255
 
     model = make_ppo_model(4 * 144, 6, SoftmaxCategoricalHead, pfrl.nn.Branched)
-    opt = torch.optim.Adam(model.parameters(), lr=2.5e-4, eps=1e-5)
+    # plain SGD: Adam's normalised step amplifies CPU-vs-GPU fp32 rounding of
+    # near-zero gradients to O(lr) parameter differences, which would hide the
+    # data path under optimiser noise
+    opt = torch.optim.SGD(model.parameters(), lr=1e-2)
     ag = agents.PPO(model, opt, gpu=-1, gamma=0.99, lambd=0.95, phi=phi, update_interval=64,
                     minibatch_size=16, epochs=2, clip_eps=0.1, clip_eps_vf=None,
                     standardize_advantages=True, max_grad_norm=0.5)

@@ -157,7 +157,7 @@ def test_ppo_device_rollout_matches_reference():
         torch.nn.Flatten(), torch.nn.Linear(4 * 144, 32), torch.nn.ReLU(),
         Branched(torch.nn.Sequential(torch.nn.Linear(32, 6), SoftmaxCategoricalHead()),
                  torch.nn.Linear(32, 1)))
-    opt = torch.optim.Adam(model.parameters(), lr=2.5e-4, eps=1e-5)
+    opt = torch.optim.SGD(model.parameters(), lr=1e-2)
     ag = agents.PPO(model, opt, gpu=0, gamma=0.99, lambd=0.95, phi=phi, update_interval=64,
                     minibatch_size=16, epochs=2, clip_eps=0.1, clip_eps_vf=None,
                     standardize_advantages=True, max_grad_norm=0.5)
@@ -174,7 +174,7 @@ def test_ppo_device_rollout_matches_reference():
 
     def spy_loss(*a, **kw):
         out = orig_loss(*a, **kw)
-        losses.append([float(out), float(ag.value_loss_record.values()[-1]),
+        losses.append([float(out.detach()), float(ag.value_loss_record.values()[-1]),
                        float(ag.policy_loss_record.values()[-1])])
         return out
 
@@ -195,11 +195,12 @@ def test_ppo_device_rollout_matches_reference():
     assert len(datasets) == int(g["n_datasets"])
     # first dataset: identical weights on both sides -> fp32 tolerance 1e-5
     np.testing.assert_allclose(datasets[0], g["dataset0"][:, :4], rtol=1e-5, atol=1e-5)
+    # later datasets come from weights trained on the other device: 1e-4
     for i in range(1, len(datasets)):
-        np.testing.assert_allclose(datasets[i], g["dataset%d" % i][:, :4], rtol=1e-3, atol=1e-4)
+        np.testing.assert_allclose(datasets[i], g["dataset%d" % i][:, :4], rtol=1e-4, atol=1e-4)
     got = np.asarray(losses)
     np.testing.assert_allclose(got[:8], g["losses"][:8], rtol=1e-5, atol=1e-5)
-    np.testing.assert_allclose(got, g["losses"], rtol=1e-3, atol=1e-4)
+    np.testing.assert_allclose(got, g["losses"], rtol=1e-4, atol=1e-4)
     params = np.concatenate([p.detach().cpu().numpy().ravel() for p in model.parameters()])
-    np.testing.assert_allclose(params, g["final_params"], rtol=1e-3, atol=1e-5)
+    np.testing.assert_allclose(params, g["final_params"], rtol=1e-4, atol=1e-5)
     np.testing.assert_allclose(ag.explained_variance, float(g["explained_variance"]), atol=1e-3)
