@@ -316,7 +316,9 @@ class PPO(agent.AttributeSavingMixin, agent.BatchAgent):
             ro.h_action[:T].reshape((T * N,) + ro.h_action.shape[2:]),
             ro.h_reward[:T].reshape(-1), ro.h_nonterm[:T].reshape(-1),
             self._cut_with_rollout_end(ro, T).reshape(-1), order])
-        s_refs, n_refs, actions, reward, nonterm, cut, order_dev = up
+        # staging views are recycled when the ring wraps (the minibatch loop below
+        # uploads through the same ring): keep private device copies
+        s_refs, n_refs, actions, reward, nonterm, cut, order_dev = [t.clone() for t in up]
         log_probs, v_pred = self._value_pass(s_refs, actions)
         _, next_v = self._value_pass(n_refs, None)
         adv, v_teacher = ops.gae_scan(reward.view(T, N), v_pred.view(T, N), next_v.view(T, N),
