@@ -638,6 +638,52 @@ def ppo_trace(name="ppo", steps=280, N=4):
     print("ppo_trace updates", ag.n_updates, "datasets", len(datasets))
 
 
+def a2c_trace(name="a2c", steps=120, N=4):
+    sys.path.insert(0, os.path.join(HERE, "..", ".."))
+    import tempfile
+
+    from pfrl import agents, experiments
+    from pfrl.policies import SoftmaxCategoricalHead
+
+    from pfrl_amd.envs.synthetic import HostSyntheticAtariVectorEnv
+
+    for use_gae in (True, False):
+        pfrl.utils.set_random_seed(0)
+        env = HostSyntheticAtariVectorEnv(N, seed=7, frame_shape=(12, 12), p_done=0.08)
+
+        def phi(x):
+            return np.asarray(x, dtype=np.float32) / 255
+
+        model = make_ppo_model(4 * 144, 6, SoftmaxCategoricalHead, pfrl.nn.Branched)
+        opt = torch.optim.SGD(model.parameters(), lr=1e-2)
+        ag = agents.A2C(model, opt, gamma=0.99, num_processes=N, gpu=-1, update_steps=5, phi=phi,
+                        use_gae=use_gae, tau=0.95, max_grad_norm=0.5)
+        actions, returns = [], []
+        orig_act = ag.batch_act
+
+        def spy_act(obs, _orig=orig_act, _a=actions):
+            a = _orig(obs)
+            _a.append([int(x) for x in a])
+            return a
+
+        ag.batch_act = spy_act
+        orig_upd = ag.update
+
+        def spy_upd(_orig=orig_upd, _ag=ag, _r=returns):
+            _orig()
+            _r.append(_ag.returns.numpy().copy())
+
+        ag.update = spy_upd
+        experiments.train_agent_batch(ag, env, steps, tempfile.mkdtemp())
+        out = dict(actions=np.asarray(actions), returns=np.asarray(returns),
+                   final_params=np.concatenate([p.detach().numpy().ravel()
+                                                for p in model.parameters()]),
+                   stats=np.asarray([v for _, v in ag.get_statistics()]))
+        np.savez_compressed(os.path.join(HERE, "agent_trace_%s_gae%d.npz" % (name, int(use_gae))),
+                            **out)
+        print("a2c_trace gae", use_gae, "updates", len(returns))
+
+
 if __name__ == "__main__":
     random.seed(0)
     torch.manual_seed(0)
@@ -662,3 +708,4 @@ if __name__ == "__main__":
     agent_trace("dqn_uniform_n1", False, 1, False)
     agent_trace("ddqn_per_n3", True, 3, True)
     ppo_trace()
+    a2c_trace()
