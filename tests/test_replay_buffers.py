@@ -201,10 +201,11 @@ def test_prioritized_replay_buffer_api_device():
                                                  error_min=None, error_max=None)
     for i in range(4):
         rb2.append(np.float32([i]), i, 1.0, np.float32([i + 1]))
-    rb2.sample(4)
-    rb2.update_errors([1.0, 2.0, 4.0, 8.0])
+    first = rb2.sample(4)
+    errs = [1.0, 2.0, 4.0, 8.0]
+    rb2.update_errors(errs)   # priorities go to the sampled items, in sampled order
+    pri = {e[0]["action"]: p for e, p in zip(first, errs)}
     s = rb2.sample(2)
-    pri = {0: 1.0, 1: 2.0, 2: 4.0, 3: 8.0}
     for e in s:
         # w = (p/total / (min/total)) ** -1 = min / p
         assert e[0]["weight"] == pytest.approx(1.0 / pri[e[0]["action"]], rel=1e-6)
