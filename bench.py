@@ -48,6 +48,12 @@ def parse_args():
                    help="transitions to prefill (default: capacity, i.e. full buffer)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-baseline-seconds", type=float, default=12.0)
+    p.add_argument("--no-cudnn-benchmark", dest="cudnn_benchmark", action="store_false",
+                   help="do not let MIOpen search conv algorithms")
+    p.add_argument("--nchw", dest="channels_last", action="store_false",
+                   help="keep the network in NCHW (default: channels_last)")
+    p.add_argument("--torch-optimizer", action="store_true",
+                   help="stock torch.optim.RMSprop instead of the fused HIP step")
     p.add_argument("--profile-every", type=int, default=1,
                    help="bracket every n-th batch_experiences launch with HIP events")
     return p.parse_args()
@@ -71,8 +77,15 @@ def build_agent(args, device, rank):
         DiscreteActionValueHead(),
     )
     # ... :199-206
-    opt = torch.optim.RMSprop(q_func.parameters(), lr=2.5e-4, alpha=0.95, momentum=0.0, eps=1e-2,
-                              centered=True)
+    from pfrl_amd.optimizers import FusedRMSprop
+
+    opt_cls = torch.optim.RMSprop if args.torch_optimizer else FusedRMSprop
+    opt = opt_cls(q_func.parameters(), lr=2.5e-4, alpha=0.95, momentum=0.0, eps=1e-2,
+                  centered=True)
+    if args.cudnn_benchmark:
+        torch.backends.cudnn.benchmark = True
+    if args.channels_last:
+        q_func = q_func.to(memory_format=torch.channels_last)
     frame_slots = args.capacity + N * 16 + 8192
     store = DeviceFrameStore(frame_slots, (84, 84), torch.uint8, device, stack=4)
     env = SyntheticAtariVectorEnv(N, store=store, seed=args.seed, env_id0=rank * N,

@@ -34,6 +34,7 @@ extern "C" {
 #define PFRL_MAX_NSTEP 16
 #define PFRL_MAX_STACK 8
 
+#define PFRL_OPT_MAX_TENSORS 24
 #define PFRL_ERR_ARG (-2)
 
 int pfrl_amd_version(void);
@@ -228,6 +229,19 @@ int pfrl_ppo_minibatch(int64_t M, const int64_t *idx, const float *adv, const fl
                        const float *v_teacher, const int64_t *action, const int32_t *state_refs,
                        int32_t k, float *out_adv, float *out_logp, float *out_v, float *out_vt,
                        int64_t *out_action, int32_t *out_refs, void *stream);
+
+/* ------------------------------------------------------------------------
+ * Optimizer step of the DQN update (pfrl/agents/dqn.py:360-365 calls
+ * optimizer.step(); examples/atari/train_dqn_batch_ale.py:199-206 builds
+ * torch.optim.RMSprop(alpha=0.95, eps=1e-2, centered=True)).  One fused
+ * multi-tensor launch with torch's RMSprop arithmetic.  The pointer arrays are
+ * HOST arrays of device pointers (they are passed to the kernel by value, so
+ * the launch can be captured in a HIP graph).  grad_avg may be NULL when
+ * centered == 0. */
+int pfrl_rmsprop_step(int32_t n_tensors, float *const *host_params,
+                      const float *const *host_grads, float *const *host_square_avg,
+                      float *const *host_grad_avg, const int64_t *host_numel, float lr,
+                      float alpha, float eps, float weight_decay, int centered, void *stream);
 
 #ifdef __cplusplus
 }

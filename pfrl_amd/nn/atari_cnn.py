@@ -31,7 +31,7 @@ class _AtariCNN(nn.Module):
         h = state
         for layer in self.layers:
             h = self.activation(layer(h))
-        return self.activation(self.output(h.view(h.size(0), -1)))
+        return self.activation(self.output(h.reshape(h.size(0), -1)))
 
 
 class LargeAtariCNN(_AtariCNN):

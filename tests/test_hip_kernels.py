@@ -458,3 +458,33 @@ def test_ppo_minibatch(dev):
     np.testing.assert_array_equal(out["v_teacher"].cpu().numpy(), vt[idx])
     np.testing.assert_array_equal(out["action"].cpu().numpy(), act[idx])
     np.testing.assert_array_equal(out["refs"].cpu().numpy(), refs[idx])
+
+
+# ---------------------------------------------------------------------------
+# fused optimizer
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("centered", [True, False])
+def test_fused_rmsprop_matches_torch(dev, centered):
+    """pfrl_rmsprop_step vs torch.optim.RMSprop on the same gradients.
+    Tolerance 1e-6 relative: same formula, torch's kernels may contract a*b+c."""
+    from pfrl_amd.optimizers import FusedRMSprop
+
+    torch.manual_seed(0)
+    shapes = [(32, 4, 8, 8), (32,), (64, 32, 4, 4), (512, 3136), (512,), (6, 512), (6,), (1,)]
+    pa = [torch.nn.Parameter(torch.randn(s, device=dev)) for s in shapes]
+    pb = [torch.nn.Parameter(p.detach().clone()) for p in pa]
+    oa = FusedRMSprop(pa, lr=2.5e-4, alpha=0.95, eps=1e-2, centered=centered)
+    ob = torch.optim.RMSprop(pb, lr=2.5e-4, alpha=0.95, eps=1e-2, centered=centered)
+    for it in range(5):
+        for a, b in zip(pa, pb):
+            g = torch.randn_like(a) * (10.0 ** (it - 2))
+            a.grad = g.clone()
+            b.grad = g.clone()
+        oa.step()
+        ob.step()
+    for a, b in zip(pa, pb):
+        np.testing.assert_allclose(a.detach().cpu().numpy(), b.detach().cpu().numpy(), rtol=1e-6,
+                                   atol=1e-7)
+    for a, b in zip(pa, pb):
+        np.testing.assert_allclose(oa.state[a]["square_avg"].cpu().numpy(),
+                                   ob.state[b]["square_avg"].cpu().numpy(), rtol=1e-6, atol=1e-12)
