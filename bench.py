@@ -266,6 +266,18 @@ def main():
             "entries_per_launch": int(np.mean([b for _, _, b in evs])),
             "avg_launch_us": round(tot_s / len(evs) * 1e6, 2), "launches_timed": len(evs),
         }
+        # HBM traffic cannot be sampled from inside the process: it is taken from
+        # the committed rocprofv3 --pmc passes of this same command
+        # (profiles/r01_pmc_gather.json), valid for the 2048-entry launch only.
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_gather.json")))
+            kk = pmc["kernels"]["k_batch_experiences<0,long> (2048 entries)"]
+            if roofline["entries_per_launch"] == 2048:
+                roofline["traffic"] = kk["traffic_bytes_per_launch"]
+                roofline["traffic_source"] = "profiles/r01_pmc_gather.json (rocprofv3 --pmc " \
+                                             "FETCH_SIZE / WRITE_SIZE, separate passes, corrected)"
+        except Exception:
+            pass
 
     if rank == 0:
         total_env_steps = world * N * args.steps
