@@ -1,0 +1,109 @@
+"""Categorical (C51) DQN and its Double variant -- the Rainbow update.
+
+Mirrors ``pfrl.agents.categorical_dqn`` (/root/reference/pfrl/agents/
+categorical_dqn.py: projection :7-57, losses :60-104, agent :107-204) and
+``categorical_double_dqn.py`` (:7-52).  The categorical projection, the
+cross-entropy loss and the per-sample KL priorities stay stock PyTorch on the
+device; they plug into the same device replay path as DQN (fused gather,
+HIP-graph update, PER priorities handed over as a device tensor).
+"""
+import torch
+
+from pfrl_amd.agents import dqn
+from pfrl_amd.utils.contexts import evaluating
+
+
+def _apply_categorical_projection(y, y_probs, z):
+    """Algorithm 1 of https://arxiv.org/abs/1707.06887: project the atoms
+    ``y`` (batch, n_atoms) carrying mass ``y_probs`` onto the fixed, evenly
+    spaced support ``z`` (n_atoms,)."""
+    batch_size, n_atoms = y.shape
+    assert z.shape == (n_atoms,)
+    assert y_probs.shape == (batch_size, n_atoms)
+    delta_z = z[1] - z[0]
+    v_min, v_max = z[0], z[-1]
+    y = torch.clamp(y, v_min, v_max)
+    bj = torch.clamp((y - v_min) / delta_z, 0, n_atoms - 1)   # guards inexact delta_z
+    lo, up = torch.floor(bj), torch.ceil(bj)
+    z_probs = torch.zeros((batch_size, n_atoms), dtype=torch.float32, device=y.device)
+    offset = torch.arange(0, batch_size * n_atoms, n_atoms, dtype=torch.int32,
+                          device=y.device)[..., None]
+    frac = bj - lo
+    # mass to the lower neighbour uses 1 - (bj - l) so that integer bj keeps all its mass
+    z_probs.view(-1).scatter_add_(0, (lo.long() + offset).view(-1), (y_probs * (1 - frac)).view(-1))
+    z_probs.view(-1).scatter_add_(0, (up.long() + offset).view(-1), (y_probs * frac).view(-1))
+    return z_probs
+
+
+def compute_value_loss(eltwise_loss, batch_accumulator="mean"):
+    assert batch_accumulator in ("mean", "sum")
+    if batch_accumulator == "sum":
+        return eltwise_loss.sum()
+    return eltwise_loss.sum(dim=1).mean()
+
+
+def compute_weighted_value_loss(eltwise_loss, batch_size, weights, batch_accumulator="mean"):
+    assert batch_accumulator in ("mean", "sum")
+    loss_sum = torch.matmul(eltwise_loss.sum(dim=1), weights.to(eltwise_loss.device))
+    if batch_accumulator == "mean":
+        return loss_sum / batch_size
+    return loss_sum
+
+
+class CategoricalDQN(dqn.DQN):
+    """q_function must return DistributionalDiscreteActionValue; clip_delta is
+    ignored (reference :107-113)."""
+
+    def _project(self, exp_batch, next_dist, z_values):
+        Tz = (exp_batch["reward"][..., None]
+              + (1.0 - exp_batch["is_state_terminal"][..., None])
+              * torch.unsqueeze(exp_batch["discount"], 1) * z_values[None])
+        return _apply_categorical_projection(Tz, next_dist, z_values)
+
+    def _compute_target_values(self, exp_batch):
+        target_next_qout = self.target_model(exp_batch["next_state"])
+        next_q_max = target_next_qout.max_as_distribution.detach()
+        return self._project(exp_batch, next_q_max, target_next_qout.z_values)
+
+    def _compute_y_and_t(self, exp_batch):
+        qout = self.model(exp_batch["state"])
+        batch_actions = exp_batch["action"]
+        batch_q = qout.evaluate_actions_as_distribution(batch_actions)
+        with torch.no_grad():
+            batch_q_target = self._compute_target_values(exp_batch)
+            self._q_scalars = qout.evaluate_actions(batch_actions).detach()
+        return batch_q, batch_q_target
+
+    def _compute_loss(self, exp_batch, errors_out=None, want_errors=False, record=True):
+        y, t = self._compute_y_and_t(exp_batch)
+        self._last_y = self._q_scalars
+        if record:
+            self.q_record.extend(self._q_scalars)
+        # cross entropy; y clipped to avoid log(0)
+        eltwise_loss = -t * torch.log(torch.clamp(y, 1e-10, 1.0))
+        delta = None
+        if errors_out is not None or want_errors:
+            delta = eltwise_loss.detach().sum(dim=1)   # prioritise by KL divergence
+            if errors_out is not None:
+                del errors_out[:]
+                errors_out.extend(delta.cpu().numpy())
+        if "weights" in exp_batch:
+            loss = compute_weighted_value_loss(eltwise_loss, y.shape[0], exp_batch["weights"],
+                                               batch_accumulator=self.batch_accumulator)
+        else:
+            loss = compute_value_loss(eltwise_loss, batch_accumulator=self.batch_accumulator)
+        return loss, delta
+
+
+class CategoricalDoubleDQN(CategoricalDQN):
+    """Action chosen by the online network, distribution taken from the target
+    network (reference categorical_double_dqn.py:10-52)."""
+
+    def _compute_target_values(self, exp_batch):
+        batch_next_state = exp_batch["next_state"]
+        with evaluating(self.target_model), evaluating(self.model):
+            target_next_qout = self.target_model(batch_next_state)
+            next_qout = self.model(batch_next_state)
+        next_q_max = target_next_qout.evaluate_actions_as_distribution(
+            next_qout.greedy_actions.detach())
+        return self._project(exp_batch, next_q_max, target_next_qout.z_values)

@@ -27,3 +27,22 @@ class FCStateQFunctionWithDiscreteAction(SingleModelStateQFunctionWithDiscreteAc
         super().__init__(model=MLP(in_size=ndim_obs, out_size=n_actions,
                                    hidden_sizes=[n_hidden_channels] * n_hidden_layers,
                                    nonlinearity=nonlinearity, last_wscale=last_wscale))
+
+
+class DistributionalSingleModelStateQFunctionWithDiscreteAction(nn.Module):
+    """model(x) -> (batch, n_actions, n_atoms) probabilities over ``z_values``."""
+
+    def __init__(self, model, z_values):
+        super().__init__()
+        import torch as _t
+
+        self.model = model
+        self.register_buffer("z_values", _t.as_tensor(z_values, dtype=_t.float32))
+
+    def forward(self, x):
+        from pfrl_amd.action_value import DistributionalDiscreteActionValue
+
+        return DistributionalDiscreteActionValue(self.model(x), self.z_values)
+
+
+from pfrl_amd.q_functions.dueling_dqn import DistributionalDuelingDQN, DuelingDQN  # NOQA,E402

@@ -1,0 +1,80 @@
+"""Dueling heads (reference pfrl/q_functions/dueling_dqn.py: DuelingDQN :20-58,
+DistributionalDuelingDQN :61-129).  Stock PyTorch."""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from pfrl_amd import action_value
+from pfrl_amd.initializers import init_chainer_default
+from pfrl_amd.nn.atari_cnn import constant_bias_initializer
+from pfrl_amd.nn.mlp import MLP
+
+
+def _nature_convs(n_input_channels):
+    return nn.ModuleList([nn.Conv2d(n_input_channels, 32, 8, stride=4),
+                          nn.Conv2d(32, 64, 4, stride=2),
+                          nn.Conv2d(64, 64, 3, stride=1)])
+
+
+class DuelingDQN(nn.Module):
+    """http://arxiv.org/abs/1511.06581"""
+
+    def __init__(self, n_actions, n_input_channels=4, activation=F.relu, bias=0.1):
+        super().__init__()
+        self.n_actions = n_actions
+        self.n_input_channels = n_input_channels
+        self.activation = activation
+        self.conv_layers = _nature_convs(n_input_channels)
+        self.a_stream = MLP(3136, n_actions, [512])
+        self.v_stream = MLP(3136, 1, [512])
+        self.conv_layers.apply(init_chainer_default)
+        self.conv_layers.apply(constant_bias_initializer(bias=bias))
+
+    def forward(self, x):
+        h = x
+        for layer in self.conv_layers:
+            h = self.activation(layer(h))
+        batch_size = x.shape[0]
+        h = h.reshape(batch_size, -1)
+        ya = self.a_stream(h)
+        mean = torch.reshape(torch.sum(ya, dim=1) / self.n_actions, (batch_size, 1))
+        ya = ya - mean
+        ys = self.v_stream(h)
+        return action_value.DiscreteActionValue(ya + ys)
+
+
+class DistributionalDuelingDQN(nn.Module):
+    """Distributional dueling Q-function (Rainbow head)."""
+
+    def __init__(self, n_actions, n_atoms, v_min, v_max, n_input_channels=4,
+                 activation=torch.relu, bias=0.1):
+        assert n_atoms >= 2
+        assert v_min < v_max
+        super().__init__()
+        self.n_actions = n_actions
+        self.n_input_channels = n_input_channels
+        self.activation = activation
+        self.n_atoms = n_atoms
+        self.register_buffer("z_values",
+                             torch.linspace(v_min, v_max, n_atoms, dtype=torch.float32),
+                             persistent=False)
+        self.conv_layers = _nature_convs(n_input_channels)
+        self.main_stream = nn.Linear(3136, 1024)
+        self.a_stream = nn.Linear(512, n_actions * n_atoms)
+        self.v_stream = nn.Linear(512, n_atoms)
+        self.apply(init_chainer_default)
+        self.conv_layers.apply(constant_bias_initializer(bias=bias))
+
+    def forward(self, x):
+        h = x
+        for layer in self.conv_layers:
+            h = self.activation(layer(h))
+        batch_size = x.shape[0]
+        h = self.activation(self.main_stream(h.reshape(batch_size, -1)))
+        h_a, h_v = torch.chunk(h, 2, dim=1)
+        ya = self.a_stream(h_a).reshape((batch_size, self.n_actions, self.n_atoms))
+        mean = ya.sum(dim=1, keepdim=True) / self.n_actions
+        ya = ya - mean
+        ys = self.v_stream(h_v).reshape((batch_size, 1, self.n_atoms))
+        q = F.softmax(ya + ys, dim=2)
+        return action_value.DistributionalDiscreteActionValue(q, self.z_values)

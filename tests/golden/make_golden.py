@@ -684,6 +684,95 @@ def a2c_trace(name="a2c", steps=120, N=4):
         print("a2c_trace gae", use_gae, "updates", len(returns))
 
 
+# --------------------------------------------------------------------------
+# I. C51: categorical projection known answers + CategoricalDoubleDQN trace
+# --------------------------------------------------------------------------
+class DistNet(torch.nn.Module):
+    """Tiny distributional Q-network: (B, 4, 12, 12) -> (B, 6, 11) probabilities."""
+
+    def __init__(self, n_in=4 * 144, n_actions=6, n_atoms=11):
+        super().__init__()
+        torch.manual_seed(2468)
+        self.l1 = torch.nn.Linear(n_in, 32)
+        self.l2 = torch.nn.Linear(32, n_actions * n_atoms)
+        self.n_actions, self.n_atoms = n_actions, n_atoms
+
+    def forward(self, x):
+        h = self.l2(torch.relu(self.l1(x.reshape(x.shape[0], -1))))
+        return torch.softmax(h.reshape(-1, self.n_actions, self.n_atoms), dim=2)
+
+
+def c51_projection_golden():
+    from pfrl.agents.categorical_dqn import _apply_categorical_projection
+
+    rs = np.random.RandomState(9)
+    out = {}
+    for ci, (B, n_atoms, vmin, vmax) in enumerate([(16, 51, -10.0, 10.0), (7, 11, -2.0, 2.0),
+                                                   (4, 5, 0.0, 1.0)]):
+        z = torch.linspace(vmin, vmax, n_atoms, dtype=torch.float32)
+        y = torch.tensor(rs.uniform(vmin - 2, vmax + 2, size=(B, n_atoms)).astype(np.float32))
+        y[0] = z                       # exactly on the support
+        y[1, :] = vmax + 5.0           # all mass clipped to the top atom
+        p = rs.rand(B, n_atoms).astype(np.float32)
+        p /= p.sum(axis=1, keepdims=True)
+        proj = _apply_categorical_projection(y, torch.tensor(p), z)
+        out["c%d_z" % ci] = z.numpy()
+        out["c%d_y" % ci] = y.numpy()
+        out["c%d_p" % ci] = p
+        out["c%d_proj" % ci] = proj.numpy()
+    np.savez_compressed(os.path.join(HERE, "c51_projection.npz"), **out)
+    print("c51 projection cases 3")
+
+
+def c51_agent_trace(steps=640, N=4):
+    sys.path.insert(0, os.path.join(HERE, "..", ".."))
+    import tempfile
+
+    from pfrl import agents, explorers, experiments, replay_buffers
+    from pfrl.q_functions import DistributionalSingleModelStateQFunctionWithDiscreteAction
+
+    from pfrl_amd.envs.synthetic import HostSyntheticAtariVectorEnv
+
+    pfrl.utils.set_random_seed(0)
+    env = HostSyntheticAtariVectorEnv(N, seed=11, frame_shape=(12, 12), p_done=0.04)
+
+    def phi(x):
+        return np.asarray(x, dtype=np.float32) / 255
+
+    q = DistributionalSingleModelStateQFunctionWithDiscreteAction(
+        DistNet(), np.linspace(-3, 3, 11, dtype=np.float32))
+    opt = torch.optim.SGD(q.parameters(), lr=1e-2)
+    rbuf = replay_buffers.PrioritizedReplayBuffer(200, alpha=0.5, beta0=0.4, betasteps=100,
+                                                  num_steps=3, normalize_by_max="memory")
+    ex = explorers.LinearDecayEpsilonGreedy(1.0, 0.1, 400, lambda: np.random.randint(6))
+    ag = agents.CategoricalDoubleDQN(q, opt, rbuf, 0.99, ex, gpu=-1, replay_start_size=40,
+                                     minibatch_size=8, update_interval=4,
+                                     target_update_interval=60, phi=phi, batch_accumulator="mean")
+    actions, losses = [], []
+    orig_act = ag.batch_act
+
+    def spy_act(obs):
+        a = orig_act(obs)
+        actions.append([int(x) for x in a])
+        return a
+
+    ag.batch_act = spy_act
+    orig_update = ag.update
+
+    def spy_update(exps, errors_out=None):
+        orig_update(exps, errors_out)
+        losses.append(ag.loss_record[-1])
+
+    ag.replay_updater.update_func = spy_update
+    experiments.train_agent_batch(ag, env, steps, tempfile.mkdtemp())
+    np.savez_compressed(
+        os.path.join(HERE, "agent_trace_c51_per_n3.npz"), actions=np.asarray(actions),
+        losses=np.asarray(losses),
+        final_params=np.concatenate([p.detach().numpy().ravel() for p in q.parameters()]),
+        final_tree_sum=np.asarray(float(rbuf.memory.priority_sums.sum())))
+    print("c51 agent trace updates", len(losses))
+
+
 if __name__ == "__main__":
     random.seed(0)
     torch.manual_seed(0)
@@ -709,3 +798,5 @@ if __name__ == "__main__":
     agent_trace("ddqn_per_n3", True, 3, True)
     ppo_trace()
     a2c_trace()
+    c51_projection_golden()
+    c51_agent_trace()

@@ -259,3 +259,82 @@ def test_a2c_device_rollout_matches_reference(use_gae):
     np.testing.assert_allclose(params, g["final_params"], rtol=1e-4, atol=1e-5)
     np.testing.assert_allclose([v for _, v in ag.get_statistics()], g["stats"], rtol=1e-3,
                                atol=1e-6)
+
+
+def test_categorical_projection_matches_reference():
+    """C51 projection known answers recorded from the reference (CPU tensor op,
+    the same code runs on the device)."""
+    from pfrl_amd.agents.categorical_dqn import _apply_categorical_projection
+
+    g = np.load(os.path.join(GOLDEN, "c51_projection.npz"))
+    for c in range(3):
+        proj = _apply_categorical_projection(torch.tensor(g["c%d_y" % c]),
+                                             torch.tensor(g["c%d_p" % c]),
+                                             torch.tensor(g["c%d_z" % c]))
+        # tolerance 1e-6: scatter_add order is the only freedom
+        np.testing.assert_allclose(proj.numpy(), g["c%d_proj" % c], rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(proj.sum(dim=1).numpy(), 1.0, rtol=1e-5)
+
+
+class _DistNet(torch.nn.Module):
+    def __init__(self, n_in=4 * 144, n_actions=6, n_atoms=11):
+        super().__init__()
+        torch.manual_seed(2468)
+        self.l1 = torch.nn.Linear(n_in, 32)
+        self.l2 = torch.nn.Linear(32, n_actions * n_atoms)
+        self.n_actions, self.n_atoms = n_actions, n_atoms
+
+    def forward(self, x):
+        h = self.l2(torch.relu(self.l1(x.reshape(x.shape[0], -1))))
+        return torch.softmax(h.reshape(-1, self.n_actions, self.n_atoms), dim=2)
+
+
+@pytest.mark.gpu
+def test_categorical_double_dqn_prioritized_matches_reference():
+    """Rainbow data path (config 3): CategoricalDoubleDQN + PrioritizedReplayBuffer
+    (num_steps=3, normalize_by_max='memory'), KL priorities as a device tensor."""
+    import pfrl_amd as pfrl
+    from pfrl_amd import agents, explorers, replay_buffers
+    from pfrl_amd.envs.synthetic import HostSyntheticAtariVectorEnv
+    from pfrl_amd.q_functions import DistributionalSingleModelStateQFunctionWithDiscreteAction
+
+    g = np.load(os.path.join(GOLDEN, "agent_trace_c51_per_n3.npz"))
+    pfrl.utils.set_random_seed(0)
+    env = HostSyntheticAtariVectorEnv(4, seed=11, frame_shape=(12, 12), p_done=0.04)
+
+    def phi(x):
+        return np.asarray(x, dtype=np.float32) / 255
+
+    q = DistributionalSingleModelStateQFunctionWithDiscreteAction(
+        _DistNet(), np.linspace(-3, 3, 11, dtype=np.float32))
+    opt = torch.optim.SGD(q.parameters(), lr=1e-2)
+    rbuf = replay_buffers.PrioritizedReplayBuffer(200, alpha=0.5, beta0=0.4, betasteps=100,
+                                                  num_steps=3, normalize_by_max="memory")
+    ex = explorers.LinearDecayEpsilonGreedy(1.0, 0.1, 400, lambda: np.random.randint(6))
+    ag = agents.CategoricalDoubleDQN(q, opt, rbuf, 0.99, ex, gpu=0, replay_start_size=40,
+                                     minibatch_size=8, update_interval=4,
+                                     target_update_interval=60, phi=phi, batch_accumulator="mean")
+    actions, losses = [], []
+    orig_act = ag.batch_act
+
+    def spy_act(obs):
+        a = orig_act(obs)
+        actions.append([int(x) for x in a])
+        return a
+
+    ag.batch_act = spy_act
+    orig_core = ag._update_from_batch
+
+    def spy_core(*a, **kw):
+        orig_core(*a, **kw)
+        losses.append(float(ag.loss_record.values()[-1]))
+
+    ag._update_from_batch = spy_core
+    pfrl.experiments.train_agent_batch(ag, env, 640, tempfile.mkdtemp())
+    np.testing.assert_array_equal(np.asarray(actions), g["actions"])
+    np.testing.assert_allclose(losses[:40], g["losses"][:40], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(losses, g["losses"], rtol=2e-4, atol=2e-5)
+    params = np.concatenate([p.detach().cpu().numpy().ravel() for p in q.parameters()])
+    np.testing.assert_allclose(params, g["final_params"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(rbuf.memory.tree.root_stats()[0][0], float(g["final_tree_sum"]),
+                               rtol=1e-4)
