@@ -3,3 +3,4 @@ from pfrl_amd.agents.double_dqn import DoubleDQN  # NOQA
 from pfrl_amd.agents.ppo import PPO  # NOQA
 from pfrl_amd.agents.a2c import A2C  # NOQA
 from pfrl_amd.agents.categorical_dqn import CategoricalDQN, CategoricalDoubleDQN  # NOQA
+from pfrl_amd.agents.soft_actor_critic import SoftActorCritic  # NOQA

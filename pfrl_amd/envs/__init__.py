@@ -1,1 +1,2 @@
-from pfrl_amd.envs.synthetic import HostSyntheticAtariVectorEnv, SyntheticAtariVectorEnv  # NOQA
+from pfrl_amd.envs.synthetic import (HostSyntheticAtariVectorEnv, HostSyntheticVectorObsEnv,  # NOQA
+                                     SyntheticAtariVectorEnv)

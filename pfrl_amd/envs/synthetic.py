@@ -184,3 +184,41 @@ class HostSyntheticAtariVectorEnv(_env.VectorEnv):
             self.frames[i] = self.frames[i][1:] + [self._frame(i)]
         rewards, dones = reward_done_stream(self.seed_value, self.env_ids, self.t, self.p_done)
         return [HostLazyFrames(list(fr)) for fr in self.frames], rewards, dones, self._infos
+
+
+class HostSyntheticVectorObsEnv(_env.VectorEnv):
+    """MuJoCo-shaped synthetic env: float32 observations
+    ~ N(0, 1) of size obs_dim, reward ~ N(0, 1), done w.p. p_done; continuous
+    actions are ignored.  Deterministic in (seed, env, t)."""
+
+    def __init__(self, num_envs, obs_dim=376, act_dim=17, seed=0, p_done=1.0 / 1000):
+        self.num_envs = num_envs
+        self.obs_dim, self.act_dim = obs_dim, act_dim
+        self.p_done = p_done
+        self.rs = [np.random.RandomState(seed * num_envs + i) for i in range(num_envs)]
+        self.obs = [None] * num_envs
+        self._infos = [{} for _ in range(num_envs)]
+
+    def seed(self, seeds):
+        pass
+
+    def close(self):
+        pass
+
+    def _draw(self, i):
+        return self.rs[i].randn(self.obs_dim).astype(np.float32)
+
+    def reset(self, mask=None):
+        idx = range(self.num_envs) if mask is None else np.flatnonzero(~np.asarray(mask, bool))
+        for i in idx:
+            self.obs[i] = self._draw(i)
+        return list(self.obs)
+
+    def step(self, actions):
+        rewards = np.zeros(self.num_envs)
+        dones = np.zeros(self.num_envs, dtype=bool)
+        for i in range(self.num_envs):
+            self.obs[i] = self._draw(i)
+            rewards[i] = self.rs[i].randn()
+            dones[i] = self.rs[i].rand() < self.p_done
+        return list(self.obs), rewards, dones, self._infos

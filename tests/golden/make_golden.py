@@ -773,6 +773,97 @@ def c51_agent_trace(steps=640, N=4):
     print("c51 agent trace updates", len(losses))
 
 
+# --------------------------------------------------------------------------
+# J. SAC trace (vector observations, continuous actions).  The Gaussian noise
+#    is switched off on both sides (sample == mean) because CPU and GPU torch
+#    generators differ; everything else is the reference's update.
+# --------------------------------------------------------------------------
+def squashed_diagonal_gaussian_head(x):
+    # examples/mujoco/reproduction/soft_actor_critic/train_soft_actor_critic.py:155-170
+    from torch import distributions
+
+    mean, log_scale = torch.chunk(x, 2, dim=1)
+    log_scale = torch.clamp(log_scale, -20.0, 2.0)
+    var = torch.exp(log_scale * 2)
+    base = distributions.Independent(distributions.Normal(loc=mean, scale=torch.sqrt(var)), 1)
+    return distributions.transformed_distribution.TransformedDistribution(
+        base, [distributions.transforms.TanhTransform(cache_size=1)])
+
+
+class _NoNoise:
+    def __enter__(self):
+        import torch.distributions as D
+
+        self.saved = (D.Normal.rsample, D.Normal.sample)
+        D.Normal.rsample = lambda self_, sample_shape=torch.Size(): self_.loc.expand(
+            self_._extended_shape(sample_shape))
+        D.Normal.sample = lambda self_, sample_shape=torch.Size(): self_.loc.expand(
+            self_._extended_shape(sample_shape)).detach()
+
+    def __exit__(self, *a):
+        import torch.distributions as D
+
+        D.Normal.rsample, D.Normal.sample = self.saved
+
+
+def make_sac_nets(obs_dim, act_dim, ConcatObsAndAction, Lambda):
+    torch.manual_seed(1357)
+    policy = torch.nn.Sequential(torch.nn.Linear(obs_dim, 32), torch.nn.ReLU(),
+                                 torch.nn.Linear(32, act_dim * 2),
+                                 Lambda(squashed_diagonal_gaussian_head))
+
+    def q():
+        return torch.nn.Sequential(ConcatObsAndAction(), torch.nn.Linear(obs_dim + act_dim, 32),
+                                   torch.nn.ReLU(), torch.nn.Linear(32, 1))
+
+    return policy, q(), q()
+
+
+def sac_trace(steps=240, N=2, obs_dim=24, act_dim=3):
+    sys.path.insert(0, os.path.join(HERE, "..", ".."))
+    import tempfile
+
+    from pfrl import agents, experiments, replay_buffers
+
+    from pfrl_amd.envs.synthetic import HostSyntheticVectorObsEnv
+
+    pfrl.utils.set_random_seed(0)
+    env = HostSyntheticVectorObsEnv(N, obs_dim=obs_dim, act_dim=act_dim, seed=2, p_done=0.03)
+    policy, q1, q2 = make_sac_nets(obs_dim, act_dim, pfrl.nn.ConcatObsAndAction, pfrl.nn.Lambda)
+    opts = [torch.optim.SGD(m.parameters(), lr=1e-2) for m in (policy, q1, q2)]
+    rbuf = replay_buffers.ReplayBuffer(500)
+    ag = agents.SoftActorCritic(
+        policy, q1, q2, opts[0], opts[1], opts[2], rbuf, gamma=0.99, gpu=-1,
+        replay_start_size=40, minibatch_size=16, update_interval=1,
+        burnin_action_func=lambda: np.random.uniform(-1, 1, size=act_dim).astype(np.float32),
+        entropy_target=None, initial_temperature=0.2, soft_update_tau=5e-3)
+    actions, q1_losses = [], []
+    orig_act = ag.batch_act
+
+    def spy_act(obs):
+        a = orig_act(obs)
+        actions.append(np.asarray(a, dtype=np.float32))
+        return a
+
+    ag.batch_act = spy_act
+    orig_update = ag.update
+
+    def spy_update(exps, errors_out=None):
+        orig_update(exps, errors_out)
+        q1_losses.append([ag.q_func1_loss_record[-1], ag.q_func2_loss_record[-1]])
+
+    ag.replay_updater.update_func = spy_update
+    with _NoNoise():
+        experiments.train_agent_batch(ag, env, steps, tempfile.mkdtemp())
+    flat = lambda m: np.concatenate([p.detach().numpy().ravel() for p in m.parameters()])
+    np.savez_compressed(
+        os.path.join(HERE, "agent_trace_sac.npz"), actions=np.asarray(actions),
+        q_losses=np.asarray(q1_losses), policy_params=flat(policy), q1_params=flat(q1),
+        target_q1_params=flat(ag.target_q_func1),
+        stats=np.asarray([float(v) for _, v in ag.get_statistics()]))
+    print("sac trace updates", len(q1_losses))
+
+
 if __name__ == "__main__":
     random.seed(0)
     torch.manual_seed(0)
@@ -800,3 +891,4 @@ if __name__ == "__main__":
     a2c_trace()
     c51_projection_golden()
     c51_agent_trace()
+    sac_trace()

@@ -338,3 +338,104 @@ def test_categorical_double_dqn_prioritized_matches_reference():
     np.testing.assert_allclose(params, g["final_params"], rtol=1e-4, atol=1e-5)
     np.testing.assert_allclose(rbuf.memory.tree.root_stats()[0][0], float(g["final_tree_sum"]),
                                rtol=1e-4)
+
+
+def _squashed_head(x):
+    from torch import distributions
+
+    mean, log_scale = torch.chunk(x, 2, dim=1)
+    log_scale = torch.clamp(log_scale, -20.0, 2.0)
+    var = torch.exp(log_scale * 2)
+    base = distributions.Independent(distributions.Normal(loc=mean, scale=torch.sqrt(var)), 1)
+    return distributions.transformed_distribution.TransformedDistribution(
+        base, [distributions.transforms.TanhTransform(cache_size=1)])
+
+
+class _NoNoise:
+    """sample == mean on both sides (CPU / GPU generators differ)."""
+
+    def __enter__(self):
+        import torch.distributions as D
+
+        self.saved = (D.Normal.rsample, D.Normal.sample)
+        D.Normal.rsample = lambda s, sample_shape=torch.Size(): s.loc.expand(
+            s._extended_shape(sample_shape))
+        D.Normal.sample = lambda s, sample_shape=torch.Size(): s.loc.expand(
+            s._extended_shape(sample_shape)).detach()
+
+    def __exit__(self, *a):
+        import torch.distributions as D
+
+        D.Normal.rsample, D.Normal.sample = self.saved
+
+
+def _run_sac(gpu):
+    import pfrl_amd as pfrl
+    from pfrl_amd import agents, replay_buffers
+    from pfrl_amd.envs.synthetic import HostSyntheticVectorObsEnv
+    from pfrl_amd.nn import ConcatObsAndAction, Lambda
+
+    obs_dim, act_dim, N = 24, 3, 2
+    pfrl.utils.set_random_seed(0)
+    env = HostSyntheticVectorObsEnv(N, obs_dim=obs_dim, act_dim=act_dim, seed=2, p_done=0.03)
+    torch.manual_seed(1357)
+    policy = torch.nn.Sequential(torch.nn.Linear(obs_dim, 32), torch.nn.ReLU(),
+                                 torch.nn.Linear(32, act_dim * 2), Lambda(_squashed_head))
+
+    def q():
+        return torch.nn.Sequential(ConcatObsAndAction(), torch.nn.Linear(obs_dim + act_dim, 32),
+                                   torch.nn.ReLU(), torch.nn.Linear(32, 1))
+
+    q1, q2 = q(), q()
+    opts = [torch.optim.SGD(m.parameters(), lr=1e-2) for m in (policy, q1, q2)]
+    rbuf = replay_buffers.ReplayBuffer(500)
+    ag = agents.SoftActorCritic(
+        policy, q1, q2, opts[0], opts[1], opts[2], rbuf, gamma=0.99, gpu=gpu,
+        replay_start_size=40, minibatch_size=16, update_interval=1,
+        burnin_action_func=lambda: np.random.uniform(-1, 1, size=act_dim).astype(np.float32),
+        entropy_target=None, initial_temperature=0.2, soft_update_tau=5e-3)
+    actions, q_losses = [], []
+    orig_act = ag.batch_act
+
+    def spy_act(obs):
+        a = orig_act(obs)
+        actions.append(np.asarray(a, dtype=np.float32))
+        return a
+
+    ag.batch_act = spy_act
+    orig_update = ag.update
+
+    def spy_update(exps, errors_out=None):
+        orig_update(exps, errors_out)
+        q_losses.append([float(ag.q_func1_loss_record.values()[-1]),
+                         float(ag.q_func2_loss_record.values()[-1])])
+
+    ag.replay_updater.update_func = spy_update
+    with _NoNoise():
+        pfrl.experiments.train_agent_batch(ag, env, 240, tempfile.mkdtemp())
+    flat = lambda m: np.concatenate([p.detach().cpu().numpy().ravel() for p in m.parameters()])
+    return dict(actions=np.asarray(actions), q_losses=np.asarray(q_losses),
+                policy_params=flat(policy), q1_params=flat(q1),
+                target_q1_params=flat(ag.target_q_func1), rbuf=rbuf)
+
+
+def _compare_sac(got, g):
+    np.testing.assert_allclose(got["actions"], g["actions"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(got["q_losses"], g["q_losses"], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(got["q1_params"], g["q1_params"], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(got["target_q1_params"], g["target_q1_params"], rtol=1e-4,
+                               atol=1e-6)
+    np.testing.assert_allclose(got["policy_params"], g["policy_params"], rtol=1e-4, atol=1e-6)
+
+
+def test_sac_host_mode_matches_reference():
+    _compare_sac(_run_sac(None), np.load(os.path.join(GOLDEN, "agent_trace_sac.npz")))
+
+
+@pytest.mark.gpu
+def test_sac_device_replay_matches_reference():
+    """config 5 data path: float32 vector observations / actions in the HBM
+    replay store, fused gather as plain f32 copies."""
+    got = _run_sac(0)
+    assert got["rbuf"].is_device
+    _compare_sac(got, np.load(os.path.join(GOLDEN, "agent_trace_sac.npz")))
