@@ -114,13 +114,15 @@ class DistributionalDiscreteActionValue(ActionValue):
 
     @property
     def max_as_distribution(self):
-        return self.q_dist[torch.arange(self.q_values.shape[0]), self.greedy_actions.detach()]
+        rows = torch.arange(self.q_values.shape[0], device=self.q_dist.device)
+        return self.q_dist[rows, self.greedy_actions.detach()]
 
     def evaluate_actions(self, actions):
         return torch.gather(self.q_values, 1, actions[:, None])[:, 0]
 
     def evaluate_actions_as_distribution(self, actions):
-        return self.q_dist[torch.arange(self.q_values.shape[0]), actions]
+        rows = torch.arange(self.q_values.shape[0], device=self.q_dist.device)
+        return self.q_dist[rows, actions]
 
     def compute_advantage(self, actions):
         return self.evaluate_actions(actions) - self.max
