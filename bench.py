@@ -37,9 +37,12 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 def parse_args():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=20)
+    p.add_argument("--algo", choices=["dqn", "rainbow", "ppo"], default="dqn",
+                   help="dqn = BASELINE configs[1] (headline); rainbow = configs[2]; ppo = configs[3]")
+    p.add_argument("--steps", type=int, default=None,
+                   help="timed batched env steps (default 20; 128 = one rollout + update for ppo)")
     p.add_argument("--warmup", type=int, default=5)
-    p.add_argument("--num-envs", type=int, default=256)
+    p.add_argument("--num-envs", type=int, default=None, help="default 256 (512 for ppo)")
     p.add_argument("--capacity", type=int, default=10 ** 6)
     p.add_argument("--minibatch", type=int, default=32)
     p.add_argument("--update-interval", type=int, default=4)
@@ -56,10 +59,104 @@ def parse_args():
                    help="stock torch.optim.RMSprop instead of the fused HIP step")
     p.add_argument("--profile-every", type=int, default=1,
                    help="bracket every n-th batch_experiences launch with HIP events")
-    return p.parse_args()
+    args = p.parse_args()
+    if args.steps is None:
+        args.steps = 128 if args.algo == "ppo" else 20
+    if args.num_envs is None:
+        args.num_envs = 512 if args.algo == "ppo" else 256
+    return args
+
+
+def build_rainbow(args, device, rank):
+    """BASELINE configs[2]: examples/atari/reproduction/rainbow/train_rainbow.py:110-159 --
+    CategoricalDoubleDQN, DistributionalDuelingDQN(51 atoms, [-10, 10]) with factorised
+    NoisyNet (sigma 0.5), PrioritizedReplayBuffer(alpha 0.5, beta0 0.4, num_steps 3,
+    normalize_by_max='memory'), Adam(6.25e-5, eps 1.5e-4), Greedy explorer."""
+    import pfrl_amd as pfrl
+    from pfrl_amd import agents, explorers, replay_buffers
+    from pfrl_amd.device_store import DeviceFrameStore
+    from pfrl_amd.envs import SyntheticAtariVectorEnv
+    from pfrl_amd.q_functions import DistributionalDuelingDQN
+
+    N, n_actions = args.num_envs, 6
+    pfrl.utils.set_random_seed(args.seed * 64 + rank)
+    q_func = DistributionalDuelingDQN(n_actions, 51, -10, 10)
+    pfrl.nn.to_factorized_noisy(q_func, sigma_scale=0.5)
+    if args.cudnn_benchmark:
+        torch.backends.cudnn.benchmark = True
+    if args.channels_last:
+        q_func = q_func.to(memory_format=torch.channels_last)
+    opt = torch.optim.Adam(q_func.parameters(), 6.25e-5, eps=1.5 * 10 ** -4)
+    store = DeviceFrameStore(args.capacity + N * 24 + 8192, (84, 84), torch.uint8, device, stack=4)
+    env = SyntheticAtariVectorEnv(N, store=store, seed=args.seed, env_id0=rank * N,
+                                  n_actions=n_actions)
+    rbuf = replay_buffers.PrioritizedReplayBuffer(
+        args.capacity, alpha=0.5, beta0=0.4, betasteps=2 * 10 ** 6, num_steps=3,
+        normalize_by_max="memory")
+
+    def phi(x):
+        return np.asarray(x, dtype=np.float32) / 255
+
+    agent = agents.CategoricalDoubleDQN(
+        q_func, opt, rbuf, gpu=device.index, gamma=0.99, explorer=explorers.Greedy(),
+        minibatch_size=args.minibatch, replay_start_size=2 * 10 ** 4,
+        target_update_interval=32000, update_interval=args.update_interval,
+        batch_accumulator="mean", phi=phi)
+    agent.grad_reducer.broadcast_parameters(agent.model)
+    agent.sync_target_network()
+    return agent, env, rbuf
+
+
+def build_ppo(args, device, rank):
+    """BASELINE configs[3]: examples/atari/train_ppo_ale.py:247-264 model, Adam(2.5e-4,
+    eps 1e-5), update_interval = N*128, minibatch 32*N, 4 epochs, clip 0.1, grad clip 0.5."""
+    import pfrl_amd as pfrl
+    from pfrl_amd import agents
+    from pfrl_amd.device_store import DeviceFrameStore
+    from pfrl_amd.envs import SyntheticAtariVectorEnv
+    from pfrl_amd.initializers import init_lecun_normal
+    from pfrl_amd.policies import SoftmaxCategoricalHead
+
+    N, n_actions = args.num_envs, 6
+    pfrl.utils.set_random_seed(args.seed * 64 + rank)
+
+    def lecun_init(layer, gain=1):
+        init_lecun_normal(layer.weight, gain)
+        torch.nn.init.zeros_(layer.bias)
+        return layer
+
+    nn = torch.nn
+    model = nn.Sequential(
+        lecun_init(nn.Conv2d(4, 32, 8, stride=4)), nn.ReLU(),
+        lecun_init(nn.Conv2d(32, 64, 4, stride=2)), nn.ReLU(),
+        lecun_init(nn.Conv2d(64, 64, 3, stride=1)), nn.ReLU(), nn.Flatten(),
+        lecun_init(nn.Linear(3136, 512)), nn.ReLU(),
+        pfrl.nn.Branched(
+            nn.Sequential(lecun_init(nn.Linear(512, n_actions), 1e-2), SoftmaxCategoricalHead()),
+            lecun_init(nn.Linear(512, 1))))
+    if args.cudnn_benchmark:
+        torch.backends.cudnn.benchmark = True
+    opt = torch.optim.Adam(model.parameters(), lr=2.5e-4, eps=1e-5)
+    T = 128
+    store = DeviceFrameStore((T + 8) * N + 8192, (84, 84), torch.uint8, device, stack=4)
+    env = SyntheticAtariVectorEnv(N, store=store, seed=args.seed, env_id0=rank * N,
+                                  n_actions=n_actions)
+
+    def phi(x):
+        return np.asarray(x, dtype=np.float32) / 255
+
+    agent = agents.PPO(model, opt, gpu=device.index, phi=phi, update_interval=N * T,
+                       minibatch_size=32 * N, epochs=4, clip_eps=0.1, clip_eps_vf=None,
+                       standardize_advantages=True, entropy_coef=1e-2, max_grad_norm=0.5)
+    agent.grad_reducer.broadcast_parameters(agent.model)
+    return agent, env, None
 
 
 def build_agent(args, device, rank):
+    if args.algo == "rainbow":
+        return build_rainbow(args, device, rank)
+    if args.algo == "ppo":
+        return build_ppo(args, device, rank)
     import pfrl_amd as pfrl
     from pfrl_amd import agents, explorers, replay_buffers
     from pfrl_amd.device_store import DeviceFrameStore
@@ -105,6 +202,25 @@ def build_agent(args, device, rank):
     agent.grad_reducer.broadcast_parameters(agent.model)
     agent.sync_target_network()
     return agent, env, rbuf
+
+
+def workload_description(args, N, rbuf):
+    if args.algo == "dqn":
+        return ("BASELINE.json configs[1]: DQN Nature-CNN, %d synthetic Atari-shaped envs/GPU "
+                "(84x84x4 u8), ReplayBuffer(%d) on device prefilled to %d, B=%d, update_interval=%d "
+                "(replay ratio %.1f sampled transitions per env-step), RMSprop centered, "
+                "batch_accumulator=sum" % (N, args.capacity, len(rbuf), args.minibatch,
+                                           args.update_interval,
+                                           args.minibatch / args.update_interval))
+    if args.algo == "rainbow":
+        return ("BASELINE.json configs[2]: CategoricalDoubleDQN + DistributionalDuelingDQN(51 atoms) "
+                "+ NoisyNet, %d synthetic Atari-shaped envs/GPU, PrioritizedReplayBuffer(%d, "
+                "alpha=0.5, beta0=0.4, num_steps=3, normalize_by_max=memory) with sum/min trees in "
+                "HBM prefilled to %d, B=%d, update_interval=%d, Adam"
+                % (N, args.capacity, len(rbuf), args.minibatch, args.update_interval))
+    return ("BASELINE.json configs[3]: PPO, %d synthetic Atari-shaped envs/GPU x 128-step rollouts, "
+            "update_interval=%d, minibatch=%d, 4 epochs, GAE + advantage standardisation kernels, "
+            "Adam" % (N, N * 128, 32 * N))
 
 
 def one_step(agent, env, obss, num_envs):
@@ -215,10 +331,11 @@ def main():
     agent, env, rbuf = build_agent(args, device, rank)
     N = args.num_envs
     obss = env.reset()
-    target = args.prefill if args.prefill is not None else args.capacity
-    target = max(min(target, args.capacity), 5 * 10 ** 4)
     t_fill = time.perf_counter()
-    obss = prefill(agent, env, obss, N, target)
+    if rbuf is not None:
+        target = args.prefill if args.prefill is not None else args.capacity
+        target = max(min(target, args.capacity), 5 * 10 ** 4)
+        obss = prefill(agent, env, obss, N, target)
     torch.cuda.synchronize()
     t_fill = time.perf_counter() - t_fill
 
@@ -228,7 +345,7 @@ def main():
 
     for _ in range(args.warmup):
         obss = one_step(agent, env, obss, N)
-    optim_before = agent.optim_t
+    optim_before = agent.optim_t if hasattr(agent, "optim_t") else agent.n_updates
     ops.PROFILE_EVERY = args.profile_every
     ops.PROFILE_EVENTS = []
     barrier()
@@ -240,7 +357,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     ops.PROFILE_EVERY = 0
-    n_updates = agent.optim_t - optim_before
+    n_updates = (agent.optim_t if hasattr(agent, "optim_t") else agent.n_updates) - optim_before
 
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
@@ -283,18 +400,13 @@ def main():
         total_env_steps = world * N * args.steps
         value = total_env_steps / elapsed
         out = {
-            "metric": "env-steps/sec whole node (DQN 256 envs per GPU)",
+            "metric": "env-steps/sec whole node (%s %d envs per GPU)" % (args.algo.upper(), N),
             "value": round(value, 1), "unit": "env-steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {
-                "workload": "BASELINE.json configs[1]: DQN Nature-CNN, %d synthetic Atari-shaped "
-                            "envs/GPU (84x84x4 u8), ReplayBuffer(%d) on device prefilled to %d, "
-                            "B=%d, update_interval=%d (replay ratio %.1f sampled transitions per "
-                            "env-step), RMSprop centered, batch_accumulator=sum"
-                            % (N, args.capacity, len(rbuf), args.minibatch, args.update_interval,
-                               args.minibatch / args.update_interval),
+                "workload": workload_description(args, N, rbuf),
                 "global_envs": world * N, "updates_in_timed_region": n_updates,
                 "parallelism": "env-sharded dp%d, per-GPU-local replay" % world,
                 "prefill_s": round(t_fill, 1),
