@@ -41,7 +41,8 @@ def parse_args():
                    help="dqn = BASELINE configs[1] (headline); rainbow = configs[2]; ppo = configs[3]")
     p.add_argument("--steps", type=int, default=None,
                    help="timed batched env steps (default 20; 128 = one rollout + update for ppo)")
-    p.add_argument("--warmup", type=int, default=5)
+    p.add_argument("--warmup", type=int, default=None,
+                   help="untimed steps (default 5; 128 = one full rollout + update for ppo)")
     p.add_argument("--num-envs", type=int, default=None, help="default 256 (512 for ppo)")
     p.add_argument("--capacity", type=int, default=10 ** 6)
     p.add_argument("--minibatch", type=int, default=32)
@@ -62,6 +63,8 @@ def parse_args():
     args = p.parse_args()
     if args.steps is None:
         args.steps = 128 if args.algo == "ppo" else 20
+    if args.warmup is None:
+        args.warmup = 128 if args.algo == "ppo" else 5
     if args.num_envs is None:
         args.num_envs = 512 if args.algo == "ppo" else 256
     return args
@@ -413,7 +416,7 @@ def main():
             },
             "roofline": roofline,
         }
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and args.algo == "dqn":
             out["cpu_baseline"] = cpu_baseline(args, args.cpu_baseline_seconds)
         print(json.dumps(out))
     if world > 1:
