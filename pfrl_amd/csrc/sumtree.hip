@@ -13,6 +13,8 @@
 //
 // These kernels are latency-bound (B sequential 20-level descents), not
 // bandwidth-bound: ~27 KB of tree traffic per DQN update.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -281,6 +283,182 @@ __global__ __launch_bounds__(64) void k_tree_sample(pfrl_tree_t T, int64_t B,
     }
 }
 
+// ---------------------------------------------------------------------------
+// LDS-staged sampler.  The B draws are sequentially dependent, so the cost is
+// a latency chain; this version shortens every link of it:
+//   * the top of the tree (levels L .. r, r = min(L, 9)) is copied once into an
+//     LDS heap (<= 8192 nodes, 72 KB) and stays authoritative for the whole
+//     launch: 12 of the 21 levels of a 1M-leaf tree descend at LDS latency;
+//   * the 2^(r+1)-1 nodes below the chosen level-r node are fetched by the 64
+//     lanes in ONE parallel round trip into a second LDS heap, so the bottom
+//     r levels also descend at LDS latency (instead of r dependent HBM/L2
+//     round trips);
+//   * the zero-and-repair pass runs on the LDS copies and the touched path is
+//     written back to HBM by one lane per level.
+// Arithmetic and visiting order are exactly those of k_tree_sample.
+// ---------------------------------------------------------------------------
+constexpr int kBotLevels = 9;   // r: bottom subtree root level
+constexpr int kMaxTopLog2 = 13; // top heap holds levels L..r, at most 13 levels
+
+__global__ __launch_bounds__(64) void k_tree_sample_lds(
+    pfrl_tree_t T, int64_t B, const double *__restrict__ u01, int64_t *__restrict__ out_x,
+    double *__restrict__ out_pri, uint8_t *__restrict__ out_pri_tag, double *__restrict__ out_prob,
+    float *__restrict__ out_weight, double *__restrict__ out_total,
+    uint8_t *__restrict__ out_total_tag, double *__restrict__ out_min_prob, int normalize,
+    double beta, int64_t slot_mod, int32_t *__restrict__ out_slot) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int L = T.log2_size;
+    const int r = L < kBotLevels ? L : kBotLevels;
+    const int top_levels = L - r + 1;           // levels L..r  -> depths 0..top_levels-1
+    const int top_n = 1 << top_levels;          // heap indices 1..top_n-1
+    const int bot_n = 1 << (r + 1);             // heap indices 1..bot_n-1 (levels r..0)
+    double *top_v = reinterpret_cast<double *>(smem);
+    double *bot_v = top_v + top_n;
+    uint8_t *top_t = reinterpret_cast<uint8_t *>(bot_v + bot_n);
+    uint8_t *bot_t = top_t + top_n;
+    __shared__ double s_total_v, s_min_v;
+    __shared__ int s_total_t, s_min_t;
+    const int lane = threadIdx.x;
+
+    // stage the top of the sum tree
+    for (int h = 1 + lane; h < top_n; h += 64) {
+        const int d = 31 - __clz(h);
+        const int l = L - d;
+        const int64_t j = h - (1 << d);
+        const int64_t gi = node_idx(T, l, T.base + (j << l));
+        top_v[h] = T.sum_val[gi];
+        top_t[h] = T.sum_tag[gi];
+    }
+    if (lane == 0) {
+        const int64_t iroot = node_idx(T, L, T.base);
+        s_total_v = T.sum_val[iroot];
+        s_total_t = T.sum_tag[iroot];
+        s_min_v = T.min_val[iroot];
+        s_min_t = T.min_tag[iroot];
+    }
+    __syncthreads();
+
+    for (int64_t i = 0; i < B; ++i) {
+        // ---- descend the top heap (uniform across the wave) ----
+        TV root = mk_tv(top_v[1], top_t[1]);
+        TV pos = mk_tv(__dadd_rn(0.0, __dmul_rn(root.v, u01[i])), PFRL_TAG_PY);
+        int h = 1;
+        for (int d = 0; d < top_levels - 1; ++d) {
+            TV lc = mk_tv(top_v[2 * h], top_t[2 * h]);
+            TV left = lc.t != PFRL_TAG_ABSENT ? lc : mk_tv(0.0, PFRL_TAG_PY);
+            if (tv_lt(pos, left)) {
+                h = 2 * h;
+            } else {
+                pos = tv_sub(pos, left);
+                h = 2 * h + 1;
+            }
+        }
+        // h is a depth (top_levels-1) node = level r; its frame offset:
+        const int64_t x0 = T.base + ((int64_t)(h - (top_n >> 1)) << r);
+        // ---- fan-out load of the subtree below it ----
+        for (int g = 1 + lane; g < bot_n; g += 64) {
+            const int d = 31 - __clz(g);
+            const int l = r - d;
+            const int64_t j = g - (1 << d);
+            const int64_t gi = node_idx(T, l, x0 + (j << l));
+            bot_v[g] = T.sum_val[gi];
+            bot_t[g] = T.sum_tag[gi];
+        }
+        __syncthreads();
+        // ---- descend the bottom heap ----
+        int g = 1;
+        for (int d = 0; d < r; ++d) {
+            TV lc = mk_tv(bot_v[2 * g], bot_t[2 * g]);
+            TV left = lc.t != PFRL_TAG_ABSENT ? lc : mk_tv(0.0, PFRL_TAG_PY);
+            if (tv_lt(pos, left)) {
+                g = 2 * g;
+            } else {
+                pos = tv_sub(pos, left);
+                g = 2 * g + 1;
+            }
+        }
+        const int64_t x = x0 + (g - (bot_n >> 1));
+        __syncthreads();
+        if (lane == 0) {
+            out_x[i] = x;
+            out_pri[i] = bot_v[g];
+            out_pri_tag[i] = bot_t[g];
+            // ---- zero the leaf and repair the path on the LDS copies ----
+            bot_v[g] = 0.0;
+            bot_t[g] = PFRL_TAG_PY;
+            int c = g;
+            while (c > 1) {
+                const int p = c >> 1;
+                TV a = mk_tv(bot_v[2 * p], bot_t[2 * p]);
+                TV b = mk_tv(bot_v[2 * p + 1], bot_t[2 * p + 1]);
+                TV sres = reduce_sum(a, b);
+                bot_v[p] = sres.v;
+                bot_t[p] = (uint8_t)sres.t;
+                c = p;
+            }
+            top_v[h] = bot_v[1];
+            top_t[h] = bot_t[1];
+            c = h;
+            while (c > 1) {
+                const int p = c >> 1;
+                TV a = mk_tv(top_v[2 * p], top_t[2 * p]);
+                TV b = mk_tv(top_v[2 * p + 1], top_t[2 * p + 1]);
+                TV sres = reduce_sum(a, b);
+                top_v[p] = sres.v;
+                top_t[p] = (uint8_t)sres.t;
+                c = p;
+            }
+        }
+        __syncthreads();
+        // ---- write the touched path back to HBM: one lane per level ----
+        if (lane <= L) {
+            const int l = lane;
+            double v;
+            uint8_t tg;
+            if (l <= r) {
+                const int gg = g >> l;          // ancestor of the leaf at level l
+                v = bot_v[gg];
+                tg = bot_t[gg];
+            } else {
+                const int hh = h >> (l - r);
+                v = top_v[hh];
+                tg = top_t[hh];
+            }
+            const int64_t gi = node_idx(T, l, x);
+            T.sum_val[gi] = v;
+            T.sum_tag[gi] = tg;
+        }
+        __syncthreads();
+    }
+    if (lane == 0) {
+        *out_total = s_total_v;
+        *out_total_tag = (uint8_t)s_total_t;
+    }
+    __threadfence_block();
+    __syncthreads();
+    const TV total = mk_tv(s_total_v, s_total_t);
+    double local_min = __builtin_huge_val();
+    for (int64_t i = lane; i < B; i += 64) {
+        TV pr = tv_add(mk_tv(0.0, PFRL_TAG_PY), tv_div(mk_tv(out_pri[i], out_pri_tag[i]), total));
+        out_prob[i] = pr.v;
+        local_min = fmin(local_min, pr.v);
+    }
+    for (int off = 32; off > 0; off >>= 1) local_min = fmin(local_min, __shfl_xor(local_min, off));
+    double min_prob = tv_div(mk_tv(s_min_v, s_min_t), total).v;
+    if (lane == 0) *out_min_prob = min_prob;
+    if (normalize == 1) min_prob = local_min;
+    for (int64_t i = lane; i < B; i += 64) {
+        const double p = out_prob[i];
+        double w;
+        if (normalize)
+            w = pow(p / min_prob, -beta);
+        else
+            w = pow((double)T.length * p, -beta);
+        out_weight[i] = (float)w;
+        if (out_slot) out_slot[i] = (int32_t)(out_x[i] % slot_mod);
+    }
+}
+
 }  // namespace
 
 extern "C" int pfrl_tree_write(const pfrl_tree_t *tree, int64_t n, const int64_t *x,
@@ -302,9 +480,32 @@ extern "C" int pfrl_tree_sample(const pfrl_tree_t *tree, int64_t B, const double
     PFRL_CHECK_ARG(tree && B >= 0, "pfrl_tree_sample: bad args");
     PFRL_CHECK_ARG(tree->length >= B, "pfrl_tree_sample: fewer items than requested");
     if (B == 0) return 0;
-    hipLaunchKernelGGL(k_tree_sample, dim3(1), dim3(64), 0, (hipStream_t)stream, *tree, B, u01,
-                       out_x, out_pri, out_pri_tag, out_prob, out_weight, out_total, out_total_tag,
-                       out_min_prob, normalize, beta, slot_mod > 0 ? slot_mod : 1, out_slot);
+    const int L = tree->log2_size;
+    const int r = L < kBotLevels ? L : kBotLevels;
+    static int use_lds = -1;
+    if (use_lds < 0) {
+        const char *e = getenv("PFRL_TREE_SAMPLE_LDS");
+        use_lds = (e && e[0] == '0') ? 0 : 1;
+    }
+    if (use_lds && L - r + 1 <= kMaxTopLog2) {
+        const size_t top_n = (size_t)1 << (L - r + 1), bot_n = (size_t)1 << (r + 1);
+        const size_t lds = (top_n + bot_n) * (sizeof(double) + 1);
+        static bool attr_set = false;
+        if (!attr_set) {
+            hipFuncSetAttribute(reinterpret_cast<const void *>(k_tree_sample_lds),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(k_tree_sample_lds, dim3(1), dim3(64), lds, (hipStream_t)stream, *tree, B,
+                           u01, out_x, out_pri, out_pri_tag, out_prob, out_weight, out_total,
+                           out_total_tag, out_min_prob, normalize, beta,
+                           slot_mod > 0 ? slot_mod : 1, out_slot);
+    } else {
+        hipLaunchKernelGGL(k_tree_sample, dim3(1), dim3(64), 0, (hipStream_t)stream, *tree, B, u01,
+                           out_x, out_pri, out_pri_tag, out_prob, out_weight, out_total,
+                           out_total_tag, out_min_prob, normalize, beta,
+                           slot_mod > 0 ? slot_mod : 1, out_slot);
+    }
     PFRL_LAUNCH_CHECK();
 }
 

@@ -488,3 +488,41 @@ def test_fused_rmsprop_matches_torch(dev, centered):
     for a, b in zip(pa, pb):
         np.testing.assert_allclose(oa.state[a]["square_avg"].cpu().numpy(),
                                    ob.state[b]["square_avg"].cpu().numpy(), rtol=1e-6, atol=1e-12)
+
+
+def test_prioritized_buffer_large_tree_lds_sampler(dev):
+    """L = 19 frame (13-level LDS top heap + 512-leaf fan-out): indices,
+    removed priorities and the repaired tree equal the oracle's."""
+    from pfrl_amd.collections.prioritized import PrioritizedBuffer
+
+    cap = (1 << 18) + 5
+    rs = np.random.RandomState(5)
+    buf = PrioritizedBuffer(cap, device=dev)
+    orc = oracle.OraclePrioritizedBuffer(cap)
+    for i in range(cap + 1000):
+        buf.append(i)
+        orc.append(i)
+    assert buf.frame.log2_size >= 18
+    for rnd in range(6):
+        B = [64, 32, 1, 7, 200, 32][rnd]
+        u = rs.random_sample(B)
+        want = orc.sample(u)
+        out = buf.sample_device(B, u01=u, normalize=2, beta=0.6)
+        np.testing.assert_array_equal(out["x"].cpu().numpy() - buf.frame.head, want["indices"])
+        np.testing.assert_array_equal(out["pri"].cpu().numpy(), want["priorities"])
+        np.testing.assert_array_equal(out["pri_tag"].cpu().numpy(), want["priority_tags"])
+        vals = rs.rand(B) * 3 + 1e-3
+        tags = rs.choice([1, 2, 2, 3], size=B)
+        vals = np.where(tags == 2, vals.astype(np.float32).astype(np.float64), vals)
+        orc.set_last_priority(vals, tags)
+        buf.set_last_priority([_np_scalar(v, t) for v, t in zip(vals, tags)])
+        st, so = buf.root_stats(), orc.stats()
+        assert st[0] == so["sum"] and st[1] == so["min"] and st[2] == so["max_priority"]
+        for k in range(50):
+            buf.append(-k)
+            orc.append(-k)
+    for l in (0, 5, 9, 10, 14, buf.frame.log2_size):
+        gv, gt = buf.dump_level(0, l)
+        ov, ot = orc.dump_level(0, 1 << l)
+        np.testing.assert_array_equal(gt, ot)
+        np.testing.assert_array_equal(gv, ov)
