@@ -318,19 +318,45 @@ __global__ __launch_bounds__(64) void k_tree_sample_lds(
     uint8_t *bot_t = top_t + top_n;
     __shared__ double s_total_v, s_min_v;
     __shared__ int s_total_t, s_min_t;
+    // per-level addressing constants (kernel-argument arrays indexed per lane would
+    // otherwise become memory loads in the hot loops)
+    __shared__ int64_t lv_off[PFRL_MAX_LEVELS], lv_org[PFRL_MAX_LEVELS], lv_mask[PFRL_MAX_LEVELS];
     const int lane = threadIdx.x;
+    if (lane <= L) {
+        const int sh = T.log2_smax - lane;
+        lv_off[lane] = T.level_off[lane];
+        lv_org[lane] = T.origin[lane];
+        lv_mask[lane] = (sh > 0 ? ((int64_t)1 << sh) : 1) - 1;
+    }
+    __syncthreads();
+#define NODE_AT(l, x) (lv_off[l] + ((((x) - lv_org[l]) >> (l)) & lv_mask[l]))
 
-    // stage the top of the sum tree
-    for (int h = 1 + lane; h < top_n; h += 64) {
-        const int d = 31 - __clz(h);
-        const int l = L - d;
-        const int64_t j = h - (1 << d);
-        const int64_t gi = node_idx(T, l, T.base + (j << l));
-        top_v[h] = T.sum_val[gi];
-        top_t[h] = T.sum_tag[gi];
+    // stage the top of the sum tree (loads batched 16 deep per lane)
+    for (int h0 = 1; h0 < top_n; h0 += 64 * 16) {
+        double v[16];
+        uint8_t tg[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int h = h0 + k * 64 + lane;
+            if (h < top_n) {
+                const int d = 31 - __clz(h);
+                const int l = L - d;
+                const int64_t gi = NODE_AT(l, T.base + ((int64_t)(h - (1 << d)) << l));
+                v[k] = T.sum_val[gi];
+                tg[k] = T.sum_tag[gi];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int h = h0 + k * 64 + lane;
+            if (h < top_n) {
+                top_v[h] = v[k];
+                top_t[h] = tg[k];
+            }
+        }
     }
     if (lane == 0) {
-        const int64_t iroot = node_idx(T, L, T.base);
+        const int64_t iroot = NODE_AT(L, T.base);
         s_total_v = T.sum_val[iroot];
         s_total_t = T.sum_tag[iroot];
         s_min_v = T.min_val[iroot];
@@ -339,74 +365,111 @@ __global__ __launch_bounds__(64) void k_tree_sample_lds(
     __syncthreads();
 
     for (int64_t i = 0; i < B; ++i) {
-        // ---- descend the top heap (uniform across the wave) ----
+        // siblings met on the way down, kept in registers for the repair pass
+        double sv[kMaxTopLog2 + kBotLevels];
+        int st[kMaxTopLog2 + kBotLevels];
+        bool went_right[kMaxTopLog2 + kBotLevels];
+        // ---- descend the top heap (every lane computes the same path) ----
         TV root = mk_tv(top_v[1], top_t[1]);
         TV pos = mk_tv(__dadd_rn(0.0, __dmul_rn(root.v, u01[i])), PFRL_TAG_PY);
         int h = 1;
-        for (int d = 0; d < top_levels - 1; ++d) {
-            TV lc = mk_tv(top_v[2 * h], top_t[2 * h]);
-            TV left = lc.t != PFRL_TAG_ABSENT ? lc : mk_tv(0.0, PFRL_TAG_PY);
-            if (tv_lt(pos, left)) {
-                h = 2 * h;
-            } else {
-                pos = tv_sub(pos, left);
-                h = 2 * h + 1;
+#pragma unroll
+        for (int d = 0; d < kMaxTopLog2 - 1; ++d) {
+            if (d < top_levels - 1) {
+                TV lc = mk_tv(top_v[2 * h], top_t[2 * h]);
+                TV rc = mk_tv(top_v[2 * h + 1], top_t[2 * h + 1]);
+                TV left = lc.t != PFRL_TAG_ABSENT ? lc : mk_tv(0.0, PFRL_TAG_PY);
+                const bool go_left = tv_lt(pos, left);
+                if (!go_left) pos = tv_sub(pos, left);
+                sv[d] = go_left ? rc.v : lc.v;
+                st[d] = go_left ? rc.t : lc.t;
+                went_right[d] = !go_left;
+                h = 2 * h + (go_left ? 0 : 1);
             }
         }
-        // h is a depth (top_levels-1) node = level r; its frame offset:
         const int64_t x0 = T.base + ((int64_t)(h - (top_n >> 1)) << r);
-        // ---- fan-out load of the subtree below it ----
-        for (int g = 1 + lane; g < bot_n; g += 64) {
-            const int d = 31 - __clz(g);
-            const int l = r - d;
-            const int64_t j = g - (1 << d);
-            const int64_t gi = node_idx(T, l, x0 + (j << l));
-            bot_v[g] = T.sum_val[gi];
-            bot_t[g] = T.sum_tag[gi];
+        // ---- fan-out: the whole subtree below in one parallel round trip ----
+        {
+            double v[16];
+            uint8_t tg[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int g = 1 + k * 64 + lane;
+                if (g < bot_n) {
+                    const int d = 31 - __clz(g);
+                    const int l = r - d;
+                    const int64_t gi = NODE_AT(l, x0 + ((int64_t)(g - (1 << d)) << l));
+                    v[k] = T.sum_val[gi];
+                    tg[k] = T.sum_tag[gi];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int g = 1 + k * 64 + lane;
+                if (g < bot_n) {
+                    bot_v[g] = v[k];
+                    bot_t[g] = tg[k];
+                }
+            }
         }
         __syncthreads();
         // ---- descend the bottom heap ----
         int g = 1;
-        for (int d = 0; d < r; ++d) {
-            TV lc = mk_tv(bot_v[2 * g], bot_t[2 * g]);
-            TV left = lc.t != PFRL_TAG_ABSENT ? lc : mk_tv(0.0, PFRL_TAG_PY);
-            if (tv_lt(pos, left)) {
-                g = 2 * g;
-            } else {
-                pos = tv_sub(pos, left);
-                g = 2 * g + 1;
+#pragma unroll
+        for (int d = 0; d < kBotLevels; ++d) {
+            if (d < r) {
+                TV lc = mk_tv(bot_v[2 * g], bot_t[2 * g]);
+                TV rc = mk_tv(bot_v[2 * g + 1], bot_t[2 * g + 1]);
+                TV left = lc.t != PFRL_TAG_ABSENT ? lc : mk_tv(0.0, PFRL_TAG_PY);
+                const bool go_left = tv_lt(pos, left);
+                if (!go_left) pos = tv_sub(pos, left);
+                sv[kMaxTopLog2 + d] = go_left ? rc.v : lc.v;
+                st[kMaxTopLog2 + d] = go_left ? rc.t : lc.t;
+                went_right[kMaxTopLog2 + d] = !go_left;
+                g = 2 * g + (go_left ? 0 : 1);
             }
         }
         const int64_t x = x0 + (g - (bot_n >> 1));
+        const double leaf_v = bot_v[g];
+        const uint8_t leaf_t = bot_t[g];
         __syncthreads();
+        // ---- zero the leaf, repair the path from the remembered siblings ----
+        TV cur = mk_tv(0.0, PFRL_TAG_PY);
         if (lane == 0) {
             out_x[i] = x;
-            out_pri[i] = bot_v[g];
-            out_pri_tag[i] = bot_t[g];
-            // ---- zero the leaf and repair the path on the LDS copies ----
+            out_pri[i] = leaf_v;
+            out_pri_tag[i] = leaf_t;
             bot_v[g] = 0.0;
             bot_t[g] = PFRL_TAG_PY;
-            int c = g;
-            while (c > 1) {
-                const int p = c >> 1;
-                TV a = mk_tv(bot_v[2 * p], bot_t[2 * p]);
-                TV b = mk_tv(bot_v[2 * p + 1], bot_t[2 * p + 1]);
-                TV sres = reduce_sum(a, b);
-                bot_v[p] = sres.v;
-                bot_t[p] = (uint8_t)sres.t;
-                c = p;
+        }
+        int c = g;
+#pragma unroll
+        for (int d = kBotLevels - 1; d >= 0; --d) {
+            if (d < r) {
+                TV sib = mk_tv(sv[kMaxTopLog2 + d], st[kMaxTopLog2 + d]);
+                cur = went_right[kMaxTopLog2 + d] ? reduce_sum(sib, cur) : reduce_sum(cur, sib);
+                c >>= 1;
+                if (lane == 0) {
+                    bot_v[c] = cur.v;
+                    bot_t[c] = (uint8_t)cur.t;
+                }
             }
-            top_v[h] = bot_v[1];
-            top_t[h] = bot_t[1];
-            c = h;
-            while (c > 1) {
-                const int p = c >> 1;
-                TV a = mk_tv(top_v[2 * p], top_t[2 * p]);
-                TV b = mk_tv(top_v[2 * p + 1], top_t[2 * p + 1]);
-                TV sres = reduce_sum(a, b);
-                top_v[p] = sres.v;
-                top_t[p] = (uint8_t)sres.t;
-                c = p;
+        }
+        c = h;
+        if (lane == 0) {
+            top_v[c] = cur.v;
+            top_t[c] = (uint8_t)cur.t;
+        }
+#pragma unroll
+        for (int d = kMaxTopLog2 - 2; d >= 0; --d) {
+            if (d < top_levels - 1) {
+                TV sib = mk_tv(sv[d], st[d]);
+                cur = went_right[d] ? reduce_sum(sib, cur) : reduce_sum(cur, sib);
+                c >>= 1;
+                if (lane == 0) {
+                    top_v[c] = cur.v;
+                    top_t[c] = (uint8_t)cur.t;
+                }
             }
         }
         __syncthreads();
@@ -424,12 +487,13 @@ __global__ __launch_bounds__(64) void k_tree_sample_lds(
                 v = top_v[hh];
                 tg = top_t[hh];
             }
-            const int64_t gi = node_idx(T, l, x);
+            const int64_t gi = NODE_AT(l, x);
             T.sum_val[gi] = v;
             T.sum_tag[gi] = tg;
         }
         __syncthreads();
     }
+#undef NODE_AT
     if (lane == 0) {
         *out_total = s_total_v;
         *out_total_tag = (uint8_t)s_total_t;
