@@ -43,31 +43,37 @@ __device__ __forceinline__ TV mk_tv(double v, int t) {
     return r;
 }
 
-__device__ __forceinline__ int tv_res_type(int a, int b) {
-    if (a == PFRL_TAG_F64 || b == PFRL_TAG_F64) return PFRL_TAG_F64;
-    if (a == PFRL_TAG_F32 || b == PFRL_TAG_F32) return PFRL_TAG_F32;
-    return PFRL_TAG_PY;
-}
+// Result type of a binary op between two PRESENT scalars.  The tags are ordered
+// PY(1) < F32(2) < F64(3) exactly like the NEP-50 promotion lattice, so the
+// result type is the larger tag.
+__device__ __forceinline__ int tv_res_type(int a, int b) { return a > b ? a : b; }
 
+// The arithmetic helpers are branch-free on purpose: both the f32 and the f64
+// candidate are computed and one is selected.  The tree kernels are latency
+// chains executed by a single wave, and tag-dependent branches (scalar
+// compare + s_cbranch + waitcnt per typed op) were the dominant cost.
 __device__ __forceinline__ TV tv_add(TV a, TV b) {
-    int t = tv_res_type(a.t, b.t);
-    if (t == PFRL_TAG_F32) return mk_tv((double)__fadd_rn((float)a.v, (float)b.v), t);
-    return mk_tv(__dadd_rn(a.v, b.v), t);
+    const int t = tv_res_type(a.t, b.t);
+    const double r32 = (double)__fadd_rn((float)a.v, (float)b.v);
+    const double r64 = __dadd_rn(a.v, b.v);
+    return mk_tv(t == PFRL_TAG_F32 ? r32 : r64, t);
 }
 
 __device__ __forceinline__ TV tv_sub(TV a, TV b) {
-    int t = tv_res_type(a.t, b.t);
-    if (t == PFRL_TAG_F32) return mk_tv((double)__fsub_rn((float)a.v, (float)b.v), t);
-    return mk_tv(__dsub_rn(a.v, b.v), t);
+    const int t = tv_res_type(a.t, b.t);
+    const double r32 = (double)__fsub_rn((float)a.v, (float)b.v);
+    const double r64 = __dsub_rn(a.v, b.v);
+    return mk_tv(t == PFRL_TAG_F32 ? r32 : r64, t);
 }
 
 __device__ __forceinline__ TV tv_div(TV a, TV b) {
-    int t = tv_res_type(a.t, b.t);
+    const int t = tv_res_type(a.t, b.t);
     if (t == PFRL_TAG_F32) return mk_tv((double)__fdiv_rn((float)a.v, (float)b.v), t);
     return mk_tv(__ddiv_rn(a.v, b.v), t);
 }
 
 __device__ __forceinline__ bool tv_lt(TV a, TV b) {
-    if (tv_res_type(a.t, b.t) == PFRL_TAG_F32) return (float)a.v < (float)b.v;
-    return a.v < b.v;
+    const bool l32 = (float)a.v < (float)b.v;
+    const bool l64 = a.v < b.v;
+    return tv_res_type(a.t, b.t) == PFRL_TAG_F32 ? l32 : l64;
 }

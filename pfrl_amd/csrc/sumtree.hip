@@ -30,18 +30,16 @@ __device__ __forceinline__ int64_t node_idx(const pfrl_tree_t &T, int l, int64_t
 
 __device__ __forceinline__ TV reduce_sum(TV l, TV r) {
     const bool lp = l.t != PFRL_TAG_ABSENT, rp = r.t != PFRL_TAG_ABSENT;
-    if (lp && rp) return tv_add(l, r);
-    if (lp) return l;
-    if (rp) return r;
-    return mk_tv(0.0, PFRL_TAG_ABSENT);
+    const TV both = tv_add(l, r);
+    const TV one = lp ? l : r;   // also the absent (0, tag 0) result when neither is present
+    return (lp && rp) ? both : mk_tv(one.t != PFRL_TAG_ABSENT ? one.v : 0.0, one.t);
 }
 
 __device__ __forceinline__ TV reduce_min(TV l, TV r) {
     const bool lp = l.t != PFRL_TAG_ABSENT, rp = r.t != PFRL_TAG_ABSENT;
-    if (lp && rp) return tv_lt(r, l) ? r : l;
-    if (lp) return l;
-    if (rp) return r;
-    return mk_tv(0.0, PFRL_TAG_ABSENT);
+    const TV m = tv_lt(r, l) ? r : l;
+    const TV one = lp ? l : r;
+    return (lp && rp) ? m : mk_tv(one.t != PFRL_TAG_ABSENT ? one.v : 0.0, one.t);
 }
 
 // Re-reduce the ancestors of leaf x (levels 1..log2_size) in both trees.
@@ -297,6 +295,13 @@ __global__ __launch_bounds__(64) void k_tree_sample(pfrl_tree_t T, int64_t B,
 //     written back to HBM by one lane per level.
 // Arithmetic and visiting order are exactly those of k_tree_sample.
 // ---------------------------------------------------------------------------
+#ifdef PFRL_TREE_DEBUG
+__device__ unsigned long long g_dbg[8];
+#define DBG_T(k) do { if (lane == 0) { unsigned long long t__ = wall_clock64(); g_dbg[k] += t__ - t_prev; t_prev = t__; } } while (0)
+#else
+#define DBG_T(k)
+#endif
+
 constexpr int kBotLevels = 9;   // r: bottom subtree root level
 constexpr int kMaxTopLog2 = 13; // top heap holds levels L..r, at most 13 levels
 
@@ -364,6 +369,10 @@ __global__ __launch_bounds__(64) void k_tree_sample_lds(
     }
     __syncthreads();
 
+#ifdef PFRL_TREE_DEBUG
+    unsigned long long t_prev = wall_clock64();
+    if (lane == 0) for (int k = 0; k < 8; ++k) g_dbg[k] = 0;
+#endif
     for (int64_t i = 0; i < B; ++i) {
         // siblings met on the way down, kept in registers for the repair pass
         double sv[kMaxTopLog2 + kBotLevels];
@@ -388,31 +397,54 @@ __global__ __launch_bounds__(64) void k_tree_sample_lds(
             }
         }
         const int64_t x0 = T.base + ((int64_t)(h - (top_n >> 1)) << r);
+        DBG_T(0);
         // ---- fan-out: the whole subtree below in one parallel round trip ----
+        // level l of the subtree is 2^(r-l) consecutive ring slots: lanes read
+        // consecutive addresses (coalesced), all loads issued before any use.
         {
-            double v[16];
-            uint8_t tg[16];
+            double v[8 + 4 + 2 + kBotLevels - 2];
+            uint8_t tg[8 + 4 + 2 + kBotLevels - 2];
+            // slot numbering below is a compile-time function of (l, k): the
+            // arrays stay in registers
+            int n_ld = 0;
 #pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                const int g = 1 + k * 64 + lane;
-                if (g < bot_n) {
-                    const int d = 31 - __clz(g);
-                    const int l = r - d;
-                    const int64_t gi = NODE_AT(l, x0 + ((int64_t)(g - (1 << d)) << l));
-                    v[k] = T.sum_val[gi];
-                    tg[k] = T.sum_tag[gi];
+            for (int l = 0; l <= kBotLevels; ++l) {
+                const int lr = l <= r ? l : r;               // clamp (uniform)
+                const int cnt = l <= r ? (1 << (r - l)) : 0;
+                const int64_t q0 = (x0 - lv_org[lr]) >> lr;
+                const int64_t off = lv_off[lr], mask = lv_mask[lr];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    if (k * 64 < (1 << (kBotLevels - l))) {
+                        // unconditional load from a clamped (always valid) slot: keeps
+                        // all loads in one basic block so they are issued back to back
+                        const int j = k * 64 + lane;
+                        const int64_t gi = off + ((q0 + (j < cnt ? j : 0)) & mask);
+                        v[n_ld] = T.sum_val[gi];
+                        tg[n_ld] = T.sum_tag[gi];
+                        ++n_ld;
+                    }
                 }
             }
+            n_ld = 0;
 #pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                const int g = 1 + k * 64 + lane;
-                if (g < bot_n) {
-                    bot_v[g] = v[k];
-                    bot_t[g] = tg[k];
+            for (int l = 0; l <= kBotLevels; ++l) {
+                const int cnt = l <= r ? (1 << (r - l)) : 0;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    if (k * 64 < (1 << (kBotLevels - l))) {
+                        const int j = k * 64 + lane;
+                        if (j < cnt) {
+                            bot_v[cnt + j] = v[n_ld];   // heap index of (level l, j)
+                            bot_t[cnt + j] = tg[n_ld];
+                        }
+                        ++n_ld;
+                    }
                 }
             }
         }
         __syncthreads();
+        DBG_T(1);
         // ---- descend the bottom heap ----
         int g = 1;
 #pragma unroll
@@ -433,6 +465,7 @@ __global__ __launch_bounds__(64) void k_tree_sample_lds(
         const double leaf_v = bot_v[g];
         const uint8_t leaf_t = bot_t[g];
         __syncthreads();
+        DBG_T(2);
         // ---- zero the leaf, repair the path from the remembered siblings ----
         TV cur = mk_tv(0.0, PFRL_TAG_PY);
         if (lane == 0) {
@@ -447,7 +480,7 @@ __global__ __launch_bounds__(64) void k_tree_sample_lds(
         for (int d = kBotLevels - 1; d >= 0; --d) {
             if (d < r) {
                 TV sib = mk_tv(sv[kMaxTopLog2 + d], st[kMaxTopLog2 + d]);
-                cur = went_right[kMaxTopLog2 + d] ? reduce_sum(sib, cur) : reduce_sum(cur, sib);
+                cur = reduce_sum(cur, sib);   // IEEE add commutes, so operand order is immaterial
                 c >>= 1;
                 if (lane == 0) {
                     bot_v[c] = cur.v;
@@ -464,7 +497,7 @@ __global__ __launch_bounds__(64) void k_tree_sample_lds(
         for (int d = kMaxTopLog2 - 2; d >= 0; --d) {
             if (d < top_levels - 1) {
                 TV sib = mk_tv(sv[d], st[d]);
-                cur = went_right[d] ? reduce_sum(sib, cur) : reduce_sum(cur, sib);
+                cur = reduce_sum(cur, sib);
                 c >>= 1;
                 if (lane == 0) {
                     top_v[c] = cur.v;
@@ -473,6 +506,7 @@ __global__ __launch_bounds__(64) void k_tree_sample_lds(
             }
         }
         __syncthreads();
+        DBG_T(3);
         // ---- write the touched path back to HBM: one lane per level ----
         if (lane <= L) {
             const int l = lane;
@@ -492,6 +526,7 @@ __global__ __launch_bounds__(64) void k_tree_sample_lds(
             T.sum_tag[gi] = tg;
         }
         __syncthreads();
+        DBG_T(4);
     }
 #undef NODE_AT
     if (lane == 0) {
@@ -524,6 +559,12 @@ __global__ __launch_bounds__(64) void k_tree_sample_lds(
 }
 
 }  // namespace
+
+#ifdef PFRL_TREE_DEBUG
+extern "C" int pfrl_tree_debug_read(unsigned long long *out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dbg), sizeof(unsigned long long) * 8);
+}
+#endif
 
 extern "C" int pfrl_tree_write(const pfrl_tree_t *tree, int64_t n, const int64_t *x,
                                const double *val, const uint8_t *tag, const uint8_t *use_maxp,
