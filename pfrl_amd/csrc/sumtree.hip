@@ -597,8 +597,8 @@ extern "C" int pfrl_tree_sample(const pfrl_tree_t *tree, int64_t B, const double
         const size_t lds = (top_n + bot_n) * (sizeof(double) + 1);
         static bool attr_set = false;
         if (!attr_set) {
-            hipFuncSetAttribute(reinterpret_cast<const void *>(k_tree_sample_lds),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_tree_sample_lds),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
             attr_set = true;
         }
         hipLaunchKernelGGL(k_tree_sample_lds, dim3(1), dim3(64), lds, (hipStream_t)stream, *tree, B,
