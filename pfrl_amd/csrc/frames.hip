@@ -37,8 +37,9 @@ __device__ __forceinline__ float4 cvt_only(uint32_t w) {
     return o;
 }
 
-// One workgroup converts one frame of `nd` dwords.
-template <bool DIV>
+// One workgroup converts one frame of `nd` dwords.  NT = non-temporal stores,
+// selected for launches whose output is far larger than L2 + MALL.
+template <bool DIV, bool NT>
 __device__ __forceinline__ void convert_frame(const uint32_t *__restrict__ src,
                                               float4 *__restrict__ dst, int nd, float d) {
     const int tid = threadIdx.x;
@@ -52,12 +53,22 @@ __device__ __forceinline__ void convert_frame(const uint32_t *__restrict__ src,
 #pragma unroll
         for (int u = 0; u < kUnroll; ++u) {
             int i = base + u * kThreads + tid;
-            if (i < nd) dst[i] = DIV ? cvt_div(w[u], d) : cvt_only(w[u]);
+            if (i < nd) {
+                const float4 o = DIV ? cvt_div(w[u], d) : cvt_only(w[u]);
+                if (NT) {
+                    __builtin_nontemporal_store(o.x, &dst[i].x);
+                    __builtin_nontemporal_store(o.y, &dst[i].y);
+                    __builtin_nontemporal_store(o.z, &dst[i].z);
+                    __builtin_nontemporal_store(o.w, &dst[i].w);
+                } else {
+                    dst[i] = o;
+                }
+            }
         }
     }
 }
 
-template <bool DIV>
+template <bool DIV, bool NT>
 __global__ __launch_bounds__(kThreads) void k_batch_states_u8(const uint8_t *__restrict__ frames,
                                                               int64_t frame_bytes,
                                                               const int32_t *__restrict__ refs,
@@ -66,7 +77,7 @@ __global__ __launch_bounds__(kThreads) void k_batch_states_u8(const uint8_t *__r
     const int64_t slot = refs[f];
     const uint32_t *src = reinterpret_cast<const uint32_t *>(frames + slot * frame_bytes);
     float4 *dst = reinterpret_cast<float4 *>(out + f * frame_bytes);
-    convert_frame<DIV>(src, dst, (int)(frame_bytes >> 2), d);
+    convert_frame<DIV, NT>(src, dst, (int)(frame_bytes >> 2), d);
 }
 
 // f32 frames: plain gather, 16 B per lane when the frame size allows.
@@ -150,14 +161,25 @@ extern "C" int pfrl_batch_states_u8(const void *frames, int64_t frame_bytes, con
                                     int64_t n_refs, float divisor, float *out, void *stream) {
     PFRL_CHECK_ARG(frame_bytes > 0 && (frame_bytes & 3) == 0, "frame_bytes must be a multiple of 4");
     if (n_refs <= 0) return 0;
-    if (divisor == 1.0f)
-        hipLaunchKernelGGL(k_batch_states_u8<false>, dim3((unsigned)n_refs), dim3(kThreads), 0,
-                           (hipStream_t)stream, (const uint8_t *)frames, frame_bytes, refs, divisor,
-                           out);
-    else
-        hipLaunchKernelGGL(k_batch_states_u8<true>, dim3((unsigned)n_refs), dim3(kThreads), 0,
-                           (hipStream_t)stream, (const uint8_t *)frames, frame_bytes, refs, divisor,
-                           out);
+    const bool nt = n_refs * frame_bytes * 4 >= ((int64_t)128 << 20);
+    const dim3 grid((unsigned)n_refs), block(kThreads);
+    hipStream_t st = (hipStream_t)stream;
+    const uint8_t *fr = (const uint8_t *)frames;
+    if (divisor == 1.0f) {
+        if (nt)
+            hipLaunchKernelGGL((k_batch_states_u8<false, true>), grid, block, 0, st, fr,
+                               frame_bytes, refs, divisor, out);
+        else
+            hipLaunchKernelGGL((k_batch_states_u8<false, false>), grid, block, 0, st, fr,
+                               frame_bytes, refs, divisor, out);
+    } else {
+        if (nt)
+            hipLaunchKernelGGL((k_batch_states_u8<true, true>), grid, block, 0, st, fr,
+                               frame_bytes, refs, divisor, out);
+        else
+            hipLaunchKernelGGL((k_batch_states_u8<true, false>), grid, block, 0, st, fr,
+                               frame_bytes, refs, divisor, out);
+    }
     PFRL_LAUNCH_CHECK();
 }
 
