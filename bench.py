@@ -327,7 +327,7 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs the MI355X"
     if world != args.gpus:
         assert world == 1 and args.gpus == 1, "--gpus must equal WORLD_SIZE (use torchrun for N>1)"
-    device = torch.device("cuda", local)
+    device = torch.device("cuda", local % torch.cuda.device_count())
     torch.cuda.set_device(device)
     _native.lib()
 

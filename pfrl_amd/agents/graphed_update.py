@@ -15,6 +15,7 @@ training.
 """
 import copy
 import logging
+import os
 
 import torch
 
@@ -59,7 +60,8 @@ class GraphedUpdate:
         self.max_graphs = max_graphs
         self.logger = logging.getLogger(__name__)
         self._capturable_done = False
-        self.split_for_allreduce = distributed.world_size() > 1
+        self.split_for_allreduce = (distributed.world_size() > 1
+                                    or os.environ.get("PFRL_FORCE_SPLIT_GRAPH") == "1")
 
     def _key(self, exp_batch):
         return tuple(sorted((k, v.data_ptr(), tuple(v.shape)) for k, v in exp_batch.items()
