@@ -21,3 +21,4 @@ from pfrl_amd import q_functions  # NOQA
 from pfrl_amd import replay_buffer  # NOQA
 from pfrl_amd import replay_buffers  # NOQA
 from pfrl_amd import utils  # NOQA
+from pfrl_amd import wrappers  # NOQA

@@ -96,3 +96,37 @@ def train_agent_batch(agent, env, steps, outdir, checkpoint_freq=None, log_inter
         save_agent(agent, t, outdir, logger, suffix="_finish")
 
     return eval_stats_history
+
+
+def train_agent_batch_with_evaluation(agent, env, steps, eval_n_steps, eval_n_episodes,
+                                      eval_interval, outdir, checkpoint_freq=None,
+                                      max_episode_len=None, step_offset=0, eval_max_episode_len=None,
+                                      return_window_size=100, eval_env=None, log_interval=None,
+                                      successful_score=None, step_hooks=(), evaluation_hooks=(),
+                                      save_best_so_far_agent=True, use_tensorboard=False,
+                                      logger=None):
+    """train_agent_batch + periodic evaluation (reference :157-263)."""
+    from pfrl_amd.experiments.evaluator import Evaluator
+
+    logger = logger or logging.getLogger(__name__)
+    for hook in evaluation_hooks:
+        if not getattr(hook, "support_train_agent_batch", True):
+            raise ValueError(
+                "{} does not support train_agent_batch_with_evaluation().".format(hook))
+    os.makedirs(outdir, exist_ok=True)
+    if eval_env is None:
+        eval_env = env
+    if eval_max_episode_len is None:
+        eval_max_episode_len = max_episode_len
+    evaluator = Evaluator(agent=agent, n_steps=eval_n_steps, n_episodes=eval_n_episodes,
+                          eval_interval=eval_interval, outdir=outdir,
+                          max_episode_len=eval_max_episode_len, env=eval_env,
+                          step_offset=step_offset, evaluation_hooks=evaluation_hooks,
+                          save_best_so_far_agent=save_best_so_far_agent,
+                          use_tensorboard=use_tensorboard, logger=logger)
+    eval_stats_history = train_agent_batch(
+        agent, env, steps, outdir, checkpoint_freq=checkpoint_freq,
+        max_episode_len=max_episode_len, step_offset=step_offset, evaluator=evaluator,
+        successful_score=successful_score, return_window_size=return_window_size,
+        log_interval=log_interval, step_hooks=step_hooks, logger=logger)
+    return agent, eval_stats_history

@@ -210,3 +210,59 @@ def test_prioritized_replay_buffer_api_device():
         # w = (p/total / (min/total)) ** -1 = min / p
         assert e[0]["weight"] == pytest.approx(1.0 / pri[e[0]["action"]], rel=1e-6)
     rb2.update_errors([1.0, 1.0])
+
+
+@pytest.mark.gpu
+def test_host_lazyframes_ingest_dedupes_frames_and_matches_phi():
+    """Real-env ingest: LazyFrames from VectorFrameStack are uploaded one frame
+    at a time, shared frames exactly once, and batch_experiences reproduces
+    phi(np.asarray(obs)) bit-for-bit (reference train_dqn_batch_ale.py:229-231)."""
+    from pfrl_amd import replay_buffers
+    from pfrl_amd.envs import SerialVectorEnv
+    from pfrl_amd.replay_buffer import batch_experiences
+    from pfrl_amd.wrappers import VectorFrameStack
+
+    class Env:
+        def __init__(self, seed):
+            self.rs = np.random.RandomState(seed)
+
+        def reset(self):
+            return self.rs.randint(0, 256, size=(1, 84, 84)).astype(np.uint8)
+
+        def step(self, a):
+            return (self.rs.randint(0, 256, size=(1, 84, 84)).astype(np.uint8), 1.0,
+                    bool(self.rs.rand() < 0.1), {})
+
+        def close(self):
+            pass
+
+    def phi(x):
+        return np.asarray(x, dtype=np.float32) / 255
+
+    N, steps = 3, 40
+    venv = VectorFrameStack(SerialVectorEnv([Env(i) for i in range(N)]), 4, stack_axis=0)
+    rbuf = replay_buffers.ReplayBuffer(1000, device="cuda:0")
+    rbuf.store.set_phi(phi)
+    obs = venv.reset()
+    host_log = []
+    n_frames = N
+    for t in range(steps):
+        nobs, r, dones, _ = venv.step([0] * N)
+        n_frames += N
+        for i in range(N):
+            rbuf.append(obs[i], 1, r[i], nobs[i], is_state_terminal=dones[i], env_id=i,
+                        idx=len(host_log))
+            host_log.append((np.asarray(obs[i]), np.asarray(nobs[i])))
+        obs = venv.reset(np.logical_not(dones))
+        n_frames += int(np.sum(dones))
+    np.random.seed(0)
+    exps = rbuf.sample(32)
+    be = batch_experiences(exps, torch.device("cuda:0"), phi, 0.99)
+    ids = [e[0]["idx"] for e in exps]
+    np.testing.assert_array_equal(be["state"].cpu().numpy(),
+                                  np.stack([phi(host_log[i][0]) for i in ids]))
+    np.testing.assert_array_equal(be["next_state"].cpu().numpy(),
+                                  np.stack([phi(host_log[i][1]) for i in ids]))
+    assert be["state"].shape == (32, 4, 84, 84)
+    # every distinct frame went to HBM exactly once
+    assert rbuf.store.frames.next_seq == n_frames
