@@ -61,7 +61,7 @@ class CategoricalDQN(dqn.DQN):
         return _apply_categorical_projection(Tz, next_dist, z_values)
 
     def _compute_target_values(self, exp_batch):
-        target_next_qout = self.target_model(exp_batch["next_state"])
+        target_next_qout = self._target_next_action_value(exp_batch)
         next_q_max = target_next_qout.max_as_distribution.detach()
         return self._project(exp_batch, next_q_max, target_next_qout.z_values)
 
@@ -102,7 +102,7 @@ class CategoricalDoubleDQN(CategoricalDQN):
     def _compute_target_values(self, exp_batch):
         batch_next_state = exp_batch["next_state"]
         with evaluating(self.target_model), evaluating(self.model):
-            target_next_qout = self.target_model(batch_next_state)
+            target_next_qout = self._target_next_action_value(exp_batch)
             next_qout = self.model(batch_next_state)
         next_q_max = target_next_qout.evaluate_actions_as_distribution(
             next_qout.greedy_actions.detach())

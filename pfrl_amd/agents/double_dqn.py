@@ -9,7 +9,7 @@ class DoubleDQN(dqn.DQN):
         batch_next_state = exp_batch["next_state"]
         with evaluating(self.model):
             next_qout = self.model(batch_next_state)
-        target_next_qout = self.target_model(batch_next_state)
+        target_next_qout = self._target_next_action_value(exp_batch)
         next_q_max = target_next_qout.evaluate_actions(next_qout.greedy_actions)
         return (exp_batch["reward"]
                 + exp_batch["discount"] * (1.0 - exp_batch["is_state_terminal"]) * next_q_max)

@@ -109,7 +109,7 @@ class DQN(agent.AttributeSavingMixin, agent.BatchAgent):
                  target_update_method="hard", soft_update_tau=1e-2, n_times_update=1,
                  batch_accumulator="mean", episodic_update_len=None, logger=getLogger(__name__),
                  batch_states=batch_states, recurrent=False, max_grad_norm=None,
-                 use_graphs=None, step_fused_gather=None):
+                 use_graphs=None, step_fused_gather=None, batch_target_pass=None):
         self.model = q_function
         if gpu is not None and gpu >= 0:
             assert torch.cuda.is_available()
@@ -169,6 +169,11 @@ class DQN(agent.AttributeSavingMixin, agent.BatchAgent):
         self.use_graphs = on_gpu if use_graphs is None else bool(use_graphs and on_gpu)
         self.step_fused_gather = on_gpu if step_fused_gather is None else \
             bool(step_fused_gather and on_gpu)
+        # one target-network forward for all minibatches of an env step (the target
+        # network is frozen between syncs, so the values are the same function of
+        # the same inputs; only the batch size of the conv/GEMM kernels changes)
+        self.batch_target_pass = self.step_fused_gather if batch_target_pass is None else \
+            bool(batch_target_pass and self.step_fused_gather)
         self._graphed = None
         self._last_y = None
 
@@ -242,8 +247,39 @@ class DQN(agent.AttributeSavingMixin, agent.BatchAgent):
         self.q_record.extend(y.clone())
         return loss, delta
 
+    # -- step-batched target pass ------------------------------------------------
+    def _target_is_deterministic(self):
+        """The frozen target network may be evaluated for all minibatches of an
+        env step in one batch only if its forward pass draws no noise."""
+        from pfrl_amd.nn.noisy_linear import FactorizedNoisyLinear
+
+        return not any(isinstance(m, (FactorizedNoisyLinear, torch.nn.Dropout))
+                       for m in self.target_model.modules())
+
+    def _precompute_target_raw(self, next_states):
+        """target_model over ALL next-states of the step (U*B observations) in one
+        forward pass; returns the raw tensor the ActionValue is rebuilt from."""
+        with torch.no_grad():
+            av = self.target_model(next_states)
+        if hasattr(av, "q_dist"):
+            self._target_z_values = av.z_values
+            return av.q_dist
+        return av.q_values
+
+    def _target_next_action_value(self, exp_batch):
+        raw = exp_batch.get("target_next_raw")
+        if raw is None:
+            return self.target_model(exp_batch["next_state"])
+        if raw.ndim == 3:
+            from pfrl_amd.action_value import DistributionalDiscreteActionValue
+
+            return DistributionalDiscreteActionValue(raw, self._target_z_values)
+        from pfrl_amd.action_value import DiscreteActionValue
+
+        return DiscreteActionValue(raw)
+
     def _compute_target_values(self, exp_batch):
-        target_next_qout = self.target_model(exp_batch["next_state"])
+        target_next_qout = self._target_next_action_value(exp_batch)
         next_q_max = target_next_qout.max
         return (exp_batch["reward"]
                 + exp_batch["discount"] * (1.0 - exp_batch["is_state_terminal"]) * next_q_max)
@@ -348,6 +384,14 @@ class DQN(agent.AttributeSavingMixin, agent.BatchAgent):
                     plan_env.append(i)
                     plan_seqs.append(rbuf.lookahead_sample(up.batchsize))
         big = rbuf.fetch_many(plan_seqs, self.phi, self.gamma) if plan_seqs else None
+        if big is not None and self.batch_target_pass and self._target_is_deterministic():
+            # no target sync may fall inside this step (the targets would go stale)
+            tui = self.target_update_interval
+            if (t0 + n_env) // tui == t0 // tui:
+                ns = big["next_state"]
+                U, B = ns.shape[0], ns.shape[1]
+                raw = self._precompute_target_raw(ns.view((U * B,) + tuple(ns.shape[2:])))
+                big["target_next_raw"] = raw.view((U, B) + tuple(raw.shape[1:]))
         p = 0
         for i in range(n_env):
             self.t += 1
