@@ -58,8 +58,6 @@ def parse_args():
                    help="keep the network in NCHW (default: channels_last)")
     p.add_argument("--torch-optimizer", action="store_true",
                    help="stock torch.optim.RMSprop instead of the fused HIP step")
-    p.add_argument("--profile-every", type=int, default=1,
-                   help="bracket every n-th batch_experiences launch with HIP events")
     args = p.parse_args()
     if args.steps is None:
         args.steps = 128 if args.algo == "ppo" else 20
@@ -349,8 +347,7 @@ def main():
     for _ in range(args.warmup):
         obss = one_step(agent, env, obss, N)
     optim_before = agent.optim_t if hasattr(agent, "optim_t") else agent.n_updates
-    ops.PROFILE_EVERY = args.profile_every
-    ops.PROFILE_EVENTS = []
+    ops.profile_enable(True)
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -359,7 +356,7 @@ def main():
     barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    ops.PROFILE_EVERY = 0
+    ops.profile_enable(False)
     n_updates = (agent.optim_t if hasattr(agent, "optim_t") else agent.n_updates) - optim_before
 
     if world > 1:
@@ -368,23 +365,25 @@ def main():
         elapsed = float(tmax.item())
 
     # dominant HIP kernel: the fused batch_experiences gather
-    evs = ops.PROFILE_EVENTS
+    k_us, k_entries = ops.profile_collect()
     k, fb = 4, 84 * 84
     roofline = None
-    if evs:
+    if k_us:
         # algorithmic bytes per sampled entry: state + next_state,
         # each k frames read as u8 and written as f32
         per_entry = 2 * k * (fb + 4 * fb)
-        tot_bytes = sum(per_entry * b for _, _, b in evs)
-        tot_s = sum(a.elapsed_time(b_) for a, b_, _ in evs) * 1e-3
+        tot_bytes = sum(per_entry * b for b in k_entries)
+        tot_s = sum(k_us) * 1e-6
         achieved = tot_bytes / tot_s / 1e9
         roofline = {
-            "bound": "hbm", "kernel": "k_batch_experiences<0,long>",
+            "bound": "hbm", "kernel": "k_batch_experiences",
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-            "bytes_per_launch": int(tot_bytes / len(evs)),
-            "entries_per_launch": int(np.mean([b for _, _, b in evs])),
-            "avg_launch_us": round(tot_s / len(evs) * 1e6, 2), "launches_timed": len(evs),
+            "bytes_per_launch": int(tot_bytes / len(k_us)),
+            "entries_per_launch": int(np.mean(k_entries)),
+            "avg_launch_us": round(tot_s / len(k_us) * 1e6, 2), "launches_timed": len(k_us),
+            "timing": "hipEvent pair attached to each dispatch (hipExtLaunchKernelGGL) on the "
+                      "launch stream, inside the timed region",
         }
         # HBM traffic cannot be sampled from inside the process: it is taken from
         # the committed rocprofv3 --pmc passes of this same command

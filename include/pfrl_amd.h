@@ -243,6 +243,14 @@ int pfrl_rmsprop_step(int32_t n_tensors, float *const *host_params,
                       float *const *host_grad_avg, const int64_t *host_numel, float lr,
                       float alpha, float eps, float weight_decay, int centered, void *stream);
 
+/* ------------------------------------------------------------------------
+ * Measurement support (bench.py roofline): time every pfrl_batch_experiences
+ * launch with a hipEvent pair attached to the dispatch, on its own stream.
+ * pfrl_profile_collect synchronises, returns durations in microseconds and
+ * the entry count of each timed launch. */
+int pfrl_profile_enable(int on);
+int64_t pfrl_profile_collect(double *host_out_us, int64_t *host_out_entries, int64_t cap);
+
 #ifdef __cplusplus
 }
 #endif

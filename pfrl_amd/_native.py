@@ -115,6 +115,8 @@ EXPORTS = {
     "pfrl_adv_stats": (ctypes.c_int, "pqppp"),
     "pfrl_ppo_minibatch": (ctypes.c_int, "qpppipppppippppppp"),
     "pfrl_rmsprop_step": (ctypes.c_int, "ipppppffffip"),
+    "pfrl_profile_enable": (ctypes.c_int, "i"),
+    "pfrl_profile_collect": (ctypes.c_int64, "ppq"),
 }
 
 _CODES = {

@@ -6,12 +6,27 @@
 // Roofline: HBM.  Algorithmic bytes per sampled entry =
 //   2 * k * frame_bytes read + 2 * k * 4 * frame_bytes written (u8 frames)
 // plus < 0.1 % metadata.
+#include <hip/hip_ext.h>
+
+#include <vector>
+
 #include "common.h"
 
 namespace {
 
 constexpr int kThreads = 256;
 constexpr int kUnroll = 8;
+
+// Optional in-library timing of the fused gather: when enabled, every launch
+// carries a start/stop hipEvent pair attached to the dispatch itself
+// (hipExtLaunchKernelGGL), i.e. the kernel's own begin/end timestamps on the
+// stream it runs on -- what bench.py reports as roofline.avg_launch_us.
+struct TimedLaunch {
+    hipEvent_t start, stop;
+    int64_t entries;
+};
+bool g_profile = false;
+std::vector<TimedLaunch> g_timed;
 
 struct GammaPow {
     double g[PFRL_MAX_NSTEP + 1];
@@ -205,16 +220,24 @@ static void launch_be2(const pfrl_table_t *tab, const void *frames, int64_t fram
                        float *out_reward, float *out_terminal, float *out_discount,
                        hipStream_t stream) {
     const unsigned blocks = (unsigned)(2 * B * tab->k + (B + kThreads - 1) / kThreads);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (g_profile) {
+        (void)hipEventCreate(&e0);
+        (void)hipEventCreate(&e1);
+        g_timed.push_back({e0, e1, B});
+    }
     if (tab->act_dim > 0)
-        hipLaunchKernelGGL((k_batch_experiences<MODE, float, NT>), dim3(blocks), dim3(kThreads), 0,
-                           stream, *tab, (const uint8_t *)frames, frame_bytes, divisor, entry_slots,
-                           B, gp, (uint8_t *)out_state, (uint8_t *)out_next_state,
-                           (float *)out_action, out_reward, out_terminal, out_discount);
+        hipExtLaunchKernelGGL((k_batch_experiences<MODE, float, NT>), dim3(blocks), dim3(kThreads),
+                              0, stream, e0, e1, 0, *tab, (const uint8_t *)frames, frame_bytes,
+                              divisor, entry_slots, B, gp, (uint8_t *)out_state,
+                              (uint8_t *)out_next_state, (float *)out_action, out_reward,
+                              out_terminal, out_discount);
     else
-        hipLaunchKernelGGL((k_batch_experiences<MODE, int64_t, NT>), dim3(blocks), dim3(kThreads),
-                           0, stream, *tab, (const uint8_t *)frames, frame_bytes, divisor,
-                           entry_slots, B, gp, (uint8_t *)out_state, (uint8_t *)out_next_state,
-                           (int64_t *)out_action, out_reward, out_terminal, out_discount);
+        hipExtLaunchKernelGGL((k_batch_experiences<MODE, int64_t, NT>), dim3(blocks),
+                              dim3(kThreads), 0, stream, e0, e1, 0, *tab, (const uint8_t *)frames,
+                              frame_bytes, divisor, entry_slots, B, gp, (uint8_t *)out_state,
+                              (uint8_t *)out_next_state, (int64_t *)out_action, out_reward,
+                              out_terminal, out_discount);
 }
 
 template <int MODE>
@@ -257,4 +280,28 @@ extern "C" int pfrl_batch_experiences(const pfrl_table_t *tab, const void *frame
         launch_be<0>(tab, frames, frame_bytes, divisor, entry_slots, B, gp, out_state,
                      out_next_state, out_action, out_reward, out_terminal, out_discount, s);
     PFRL_LAUNCH_CHECK();
+}
+
+extern "C" int pfrl_profile_enable(int on) {
+    g_profile = on != 0;
+    return 0;
+}
+
+// Waits for the timed launches, writes their durations (microseconds) and entry
+// counts, frees the events.  Returns the number of launches written.
+extern "C" int64_t pfrl_profile_collect(double *out_us, int64_t *out_entries, int64_t cap) {
+    int64_t n = 0;
+    for (auto &t : g_timed) {
+        (void)hipEventSynchronize(t.stop);
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, t.start, t.stop) == hipSuccess && n < cap) {
+            out_us[n] = (double)ms * 1e3;
+            out_entries[n] = t.entries;
+            ++n;
+        }
+        (void)hipEventDestroy(t.start);
+        (void)hipEventDestroy(t.stop);
+    }
+    g_timed.clear();
+    return n;
 }

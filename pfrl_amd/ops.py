@@ -84,35 +84,31 @@ def entries_append(desc, e_slots, tids, lens):
                                             _ptr(tids), _ptr(lens), _stream()), "entries_append")
 
 
-# bench.py sets these to bracket every n-th fused-gather launch with HIP events
-# recorded on the launch stream (roofline measurement).
-PROFILE_EVERY = 0
-PROFILE_EVENTS = []
-_profile_count = 0
+def profile_enable(on):
+    """Attach a hipEvent pair to every fused-gather dispatch (bench.py roofline)."""
+    check(_native.lib().pfrl_profile_enable(int(bool(on))), "profile_enable")
+
+
+def profile_collect(cap=4096):
+    """-> (durations_us, entries) of the launches timed since profile_enable(True)."""
+    us = (ctypes.c_double * cap)()
+    ent = (ctypes.c_int64 * cap)()
+    n = _native.lib().pfrl_profile_collect(us, ent, cap)
+    return list(us[:n]), list(ent[:n])
 
 
 def batch_experiences(desc, frames, divisor, entry_slots, gamma_pow, out):
     """Fused n-step collapse + state/next_state gathers.  ``out`` is a dict of
     preallocated tensors: state, next_state, action, reward, is_state_terminal,
     discount."""
-    global _profile_count
     B = entry_slots.numel()
     gp = (ctypes.c_double * len(gamma_pow))(*gamma_pow)
-    ev = None
-    if PROFILE_EVERY:
-        _profile_count += 1
-        if _profile_count % PROFILE_EVERY == 0:
-            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-            ev[0].record()
     check(_native.lib().pfrl_batch_experiences(
         ctypes.byref(desc), _ptr(frames), frame_bytes_of(frames),
         int(frames.dtype == torch.float32), float(divisor), _ptr(entry_slots), B,
         ctypes.cast(gp, ctypes.c_void_p), _ptr(out["state"]), _ptr(out["next_state"]),
         _ptr(out["action"]), _ptr(out["reward"]), _ptr(out["is_state_terminal"]),
         _ptr(out["discount"]), _stream()), "batch_experiences")
-    if ev is not None:
-        ev[1].record()
-        PROFILE_EVENTS.append((ev[0], ev[1], B))
     return out
 
 
