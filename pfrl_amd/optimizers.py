@@ -14,6 +14,10 @@ import torch
 from pfrl_amd import _native
 
 
+def _dense(t):
+    return t.is_contiguous() or (t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last))
+
+
 class FusedRMSprop(torch.optim.RMSprop):
     def _fusable(self, group):
         return (group["momentum"] == 0 and not group.get("maximize", False)
@@ -29,9 +33,13 @@ class FusedRMSprop(torch.optim.RMSprop):
             params = [p for p in group["params"] if p.grad is not None]
             if not params:
                 continue
+            # The update is elementwise, so any dense layout works as long as the
+            # parameter, its gradient and its state share it (channels_last conv
+            # weights are dense permutations: the kernel walks storage order).
             ok = self._fusable(group) and all(
-                p.is_cuda and p.dtype == torch.float32 and p.is_contiguous()
-                and p.grad.is_contiguous() and not p.grad.is_sparse for p in params)
+                p.is_cuda and p.dtype == torch.float32 and _dense(p) and not p.grad.is_sparse
+                and p.grad.dtype == torch.float32 and p.grad.stride() == p.stride()
+                for p in params)
             if not ok:
                 return super().step(closure=None) if loss is None else loss
             centered = bool(group["centered"])
@@ -43,6 +51,8 @@ class FusedRMSprop(torch.optim.RMSprop):
                     st["square_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     if centered:
                         st["grad_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                if st["square_avg"].stride() != p.stride():
+                    return super().step(closure=None) if loss is None else loss
             n = len(params)
             P = (ctypes.c_void_p * n)(*[p.data_ptr() for p in params])
             G = (ctypes.c_void_p * n)(*[p.grad.data_ptr() for p in params])

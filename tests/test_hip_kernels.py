@@ -472,6 +472,8 @@ def test_fused_rmsprop_matches_torch(dev, centered):
     torch.manual_seed(0)
     shapes = [(32, 4, 8, 8), (32,), (64, 32, 4, 4), (512, 3136), (512,), (6, 512), (6,), (1,)]
     pa = [torch.nn.Parameter(torch.randn(s, device=dev)) for s in shapes]
+    # conv weights of a channels_last network are dense permutations
+    pa[0] = torch.nn.Parameter(pa[0].detach().contiguous(memory_format=torch.channels_last))
     pb = [torch.nn.Parameter(p.detach().clone()) for p in pa]
     oa = FusedRMSprop(pa, lr=2.5e-4, alpha=0.95, eps=1e-2, centered=centered)
     ob = torch.optim.RMSprop(pb, lr=2.5e-4, alpha=0.95, eps=1e-2, centered=centered)
@@ -482,6 +484,7 @@ def test_fused_rmsprop_matches_torch(dev, centered):
             b.grad = g.clone()
         oa.step()
         ob.step()
+    assert oa.state[pa[0]]["square_avg"].stride() == pa[0].stride()
     for a, b in zip(pa, pb):
         np.testing.assert_allclose(a.detach().cpu().numpy(), b.detach().cpu().numpy(), rtol=1e-6,
                                    atol=1e-7)
