@@ -1,0 +1,16 @@
+"""Host-side containers and the device-resident prioritized buffer.
+
+``RandomAccessQueue``  FIFO with O(1) indexing for the CPU (gpu=-1) path
+``TreeFrame``          integer bookkeeping of the reference's sliding tree frame
+``PrioritizedBuffer``  sum / min trees in HBM (imported lazily: needs a GPU)
+"""
+from pfrl_amd.collections.random_access_queue import RandomAccessQueue  # NOQA
+from pfrl_amd.collections.tree_frame import TreeFrame  # NOQA
+
+
+def __getattr__(name):
+    if name == "PrioritizedBuffer":
+        from pfrl_amd.collections.prioritized import PrioritizedBuffer
+
+        return PrioritizedBuffer
+    raise AttributeError(name)

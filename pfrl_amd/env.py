@@ -1,41 +1,50 @@
-"""Environment interfaces (reference pfrl/env.py:4-55)."""
-from abc import ABCMeta, abstractmethod
+"""Environment interfaces the drivers and agents are written against.
+
+The contract is the reference's (pfrl/env.py): a single ``Env`` has
+step/reset/close; a ``VectorEnv`` steps ``num_envs`` environments in lockstep,
+``step(actions)`` returning ``(observations, rewards, dones, infos)`` and
+``reset(mask)`` restarting exactly the environments whose mask entry is False
+while handing back the current observation of every environment.  Device
+vector envs (pfrl_amd.envs.SyntheticAtariVectorEnv) return a
+``DeviceObsBatch`` as the observation container; host ones return lists.
+"""
+import abc
 
 
-class Env(object, metaclass=ABCMeta):
-    @abstractmethod
-    def step(self, action):
-        raise NotImplementedError()
+class Env(abc.ABC):
+    """One environment."""
 
-    @abstractmethod
+    @abc.abstractmethod
     def reset(self):
-        raise NotImplementedError()
+        """Start an episode; returns the first observation."""
 
-    @abstractmethod
+    @abc.abstractmethod
+    def step(self, action):
+        """-> (observation, reward, done, info)"""
+
+    @abc.abstractmethod
     def close(self):
-        raise NotImplementedError()
+        """Release resources."""
 
 
-class VectorEnv(object, metaclass=ABCMeta):
-    """Batch of envs stepping in lockstep: ``step(actions)`` returns
-    (observations, rewards, dones, infos); ``reset(mask)`` restarts the envs
-    whose mask entry is False and returns all current observations."""
+class VectorEnv(abc.ABC):
+    """``num_envs`` environments advancing together."""
 
-    @abstractmethod
-    def step(self, actions):
-        raise NotImplementedError()
-
-    @abstractmethod
+    @abc.abstractmethod
     def reset(self, mask):
-        raise NotImplementedError()
+        """Restart envs with ``mask[i] == False``; returns all observations."""
 
-    @abstractmethod
+    @abc.abstractmethod
+    def step(self, actions):
+        """-> (observations, rewards, dones, infos), one entry per env."""
+
+    @abc.abstractmethod
     def seed(self, seeds):
-        raise NotImplementedError()
+        """Seed every env."""
 
-    @abstractmethod
+    @abc.abstractmethod
     def close(self):
-        raise NotImplementedError()
+        """Release resources."""
 
     @property
     def unwrapped(self):

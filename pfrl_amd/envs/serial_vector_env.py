@@ -1,39 +1,47 @@
-"""In-process vector env (reference pfrl/envs/serial_vector_env.py): steps a
-list of single envs one after another; ``reset(mask)`` restarts the envs whose
-mask entry is False and keeps the last observation of the others."""
+"""VectorEnv over a list of in-process envs, stepped one after another.
+
+Same behaviour as the reference's SerialVectorEnv (pfrl/envs/
+serial_vector_env.py): ``reset(mask)`` restarts the envs whose mask entry is
+False and returns the remembered observation for the rest."""
 import numpy as np
 
-from pfrl_amd import env as _env
+from pfrl_amd.env import VectorEnv
 
 
-class SerialVectorEnv(_env.VectorEnv):
+class SerialVectorEnv(VectorEnv):
     def __init__(self, envs):
-        self.envs = envs
-        self.last_obs = [None] * self.num_envs
-        self.action_space = getattr(envs[0], "action_space", None)
-        self.observation_space = getattr(envs[0], "observation_space", None)
-        self.spec = getattr(envs[0], "spec", None)
-
-    def step(self, actions):
-        results = [env.step(a) for env, a in zip(self.envs, actions)]
-        self.last_obs, rews, dones, infos = zip(*results)
-        return self.last_obs, rews, dones, infos
-
-    def reset(self, mask=None):
-        if mask is None:
-            mask = np.zeros(self.num_envs)
-        obs = [env.reset() if not m else o for m, env, o in zip(mask, self.envs, self.last_obs)]
-        self.last_obs = obs
-        return obs
-
-    def seed(self, seeds):
-        for env, seed in zip(self.envs, seeds):
-            env.seed(seed)
-
-    def close(self):
-        for env in self.envs:
-            env.close()
+        self.envs = list(envs)
+        first = self.envs[0]
+        self.action_space = getattr(first, "action_space", None)
+        self.observation_space = getattr(first, "observation_space", None)
+        self.spec = getattr(first, "spec", None)
+        self.last_obs = [None for _ in self.envs]
 
     @property
     def num_envs(self):
         return len(self.envs)
+
+    def step(self, actions):
+        obs, rewards, dones, infos = [], [], [], []
+        for env, action in zip(self.envs, actions):
+            o, r, d, info = env.step(action)
+            obs.append(o)
+            rewards.append(r)
+            dones.append(d)
+            infos.append(info)
+        self.last_obs = tuple(obs)
+        return self.last_obs, tuple(rewards), tuple(dones), tuple(infos)
+
+    def reset(self, mask=None):
+        keep = np.zeros(self.num_envs, dtype=bool) if mask is None else np.asarray(mask, bool)
+        self.last_obs = [old if k else env.reset()
+                         for k, env, old in zip(keep, self.envs, self.last_obs)]
+        return self.last_obs
+
+    def seed(self, seeds):
+        for env, s in zip(self.envs, seeds):
+            env.seed(s)
+
+    def close(self):
+        for env in self.envs:
+            env.close()

@@ -1,2 +1,14 @@
-from pfrl_amd.explorers.epsilon_greedy import ConstantEpsilonGreedy, ExponentialDecayEpsilonGreedy, LinearDecayEpsilonGreedy  # NOQA
-from pfrl_amd.explorers.greedy import Greedy  # NOQA
+from pfrl_amd import explorer as _explorer
+from pfrl_amd.explorers.epsilon_greedy import (ConstantEpsilonGreedy,  # NOQA
+                                               ExponentialDecayEpsilonGreedy,
+                                               LinearDecayEpsilonGreedy)
+
+
+class Greedy(_explorer.Explorer):
+    """Always takes the greedy action (no exploration; used by NoisyNet agents)."""
+
+    def select_action(self, t, greedy_action_func, action_value=None):
+        return greedy_action_func()
+
+    def __repr__(self):
+        return "Greedy()"

@@ -1,14 +1,18 @@
-"""``evaluating(net)`` context (reference pfrl/utils/contexts.py:4-13)."""
-from contextlib import contextmanager
+"""``evaluating(module)``: run a block with the module in eval mode and put it
+back into its previous mode afterwards (reference pfrl/utils/contexts.py)."""
 
 
-@contextmanager
-def evaluating(net):
-    """Temporarily switch a module to evaluation mode."""
-    was_training = net.training
-    try:
-        net.eval()
-        yield net
-    finally:
-        if was_training:
-            net.train()
+class evaluating(object):
+    def __init__(self, module):
+        self.module = module
+        self._restore_train = False
+
+    def __enter__(self):
+        self._restore_train = self.module.training
+        self.module.eval()
+        return self.module
+
+    def __exit__(self, exc_type, exc, tb):
+        if self._restore_train:
+            self.module.train()
+        return False
