@@ -87,7 +87,7 @@ def build_rainbow(args, device, rank):
         torch.backends.cudnn.benchmark = True
     if args.channels_last:
         q_func = q_func.to(memory_format=torch.channels_last)
-    opt = torch.optim.Adam(q_func.parameters(), 6.25e-5, eps=1.5 * 10 ** -4)
+    opt = torch.optim.Adam(q_func.parameters(), 6.25e-5, eps=1.5 * 10 ** -4, fused=True)
     store = DeviceFrameStore(args.capacity + N * 24 + 8192, (84, 84), torch.uint8, device, stack=4)
     env = SyntheticAtariVectorEnv(N, store=store, seed=args.seed, env_id0=rank * N,
                                   n_actions=n_actions)
@@ -137,7 +137,9 @@ def build_ppo(args, device, rank):
             lecun_init(nn.Linear(512, 1))))
     if args.cudnn_benchmark:
         torch.backends.cudnn.benchmark = True
-    opt = torch.optim.Adam(model.parameters(), lr=2.5e-4, eps=1e-5)
+    if args.channels_last:
+        model = model.to(memory_format=torch.channels_last)
+    opt = torch.optim.Adam(model.parameters(), lr=2.5e-4, eps=1e-5, fused=True)
     T = 128
     store = DeviceFrameStore((T + 8) * N + 8192, (84, 84), torch.uint8, device, stack=4)
     env = SyntheticAtariVectorEnv(N, store=store, seed=args.seed, env_id0=rank * N,

@@ -58,3 +58,66 @@ def test_c_abi_exports_every_declared_symbol():
         assert hasattr(lib, name), "library does not export %s" % name
     assert set(_native.EXPORTS) == declared
     assert lib.pfrl_amd_version() >= 100
+
+
+def test_product_never_imports_the_oracle():
+    """oracle/ is test infrastructure: nothing under pfrl_amd/ may import, link
+    or load it (the device path must fail loudly instead of falling back)."""
+    import glob
+
+    bad = []
+    for path in glob.glob(os.path.join(ROOT, "pfrl_amd", "**", "*.py"), recursive=True):
+        src = open(path).read()
+        if re.search(r"^\s*(import|from)\s+oracle\b", src, re.M) or "libpfrl_oracle" in src:
+            bad.append(path)
+    for path in glob.glob(os.path.join(ROOT, "pfrl_amd", "csrc", "*")):
+        if "oracle" in open(path).read():
+            bad.append(path)
+    assert not bad, bad
+
+
+def test_device_paths_fail_loudly_without_the_hip_library(monkeypatch):
+    from pfrl_amd import _native
+
+    monkeypatch.setattr(_native, "_lib", None)
+    monkeypatch.setattr(_native, "LIB_PATH", os.path.join(ROOT, "pfrl_amd", "lib", "missing.so"))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        _native.lib()
+
+
+def test_multiprocess_vector_env_matches_serial():
+    from pfrl_amd.envs import MultiprocessVectorEnv, SerialVectorEnv
+
+    envs_a = MultiprocessVectorEnv([_CountingEnv, _CountingEnv])
+    envs_b = SerialVectorEnv([_CountingEnv(), _CountingEnv()])
+    try:
+        assert envs_a.num_envs == 2
+        assert list(envs_a.reset()) == list(envs_b.reset())
+        for actions in ([1, 2], [3, 4], [0, 0]):
+            ra, rb = envs_a.step(actions), envs_b.step(actions)
+            assert [list(x) for x in ra[:3]] == [list(x) for x in rb[:3]]
+        mask = [True, False]
+        assert list(envs_a.reset(mask)) == list(envs_b.reset(mask))
+    finally:
+        envs_a.close()
+    with pytest.raises(AssertionError):
+        envs_a.step([0, 0])
+
+
+class _CountingEnv:
+    def __init__(self):
+        self.t = 0
+
+    def reset(self):
+        self.t = 0
+        return 0
+
+    def step(self, a):
+        self.t += a + 1
+        return self.t, float(a), self.t > 6, {}
+
+    def seed(self, s):
+        return [s]
+
+    def close(self):
+        pass
