@@ -326,8 +326,12 @@ class PPO(agent.AttributeSavingMixin, agent.BatchAgent):
                                       self._reward_mode)
         adv = adv.view(-1)
         v_teacher = v_teacher.view(-1)
-        mean_std = ops.adv_stats(adv) if self.standardize_advantages else \
-            torch.zeros(2, dtype=torch.float32, device=dev)
+        if self.standardize_advantages:
+            from pfrl_amd.distributed import global_mean_std
+
+            mean_std = global_mean_std(ops.adv_stats(adv), n)
+        else:
+            mean_std = torch.zeros(2, dtype=torch.float32, device=dev)
         actions_i64 = actions if actions.dtype == torch.int64 else None
         self._last_dataset = dict(order=order, adv=adv, v_teacher=v_teacher, v_pred=v_pred,
                                   log_prob=log_probs, mean_std=mean_std)

@@ -82,3 +82,20 @@ class GradientAllReducer:
             return
         for t in list(module.parameters()) + list(module.buffers()):
             dist.broadcast(t.data, src=src)
+
+
+def global_mean_std(mean_std, n):
+    """Combine per-rank (mean, biased std) over ``n`` local samples into the
+    statistics of the union of all ranks' samples: one 3-scalar all-reduce
+    (count, sum, sum of squares).  PPO standardises advantages over the whole
+    dataset (reference ppo.py:476-478); with env sharding the dataset is the
+    union of the shards.  No-op for a single process."""
+    if world_size() == 1:
+        return mean_std
+    m, s = mean_std[0].double(), mean_std[1].double()
+    acc = torch.stack([torch.as_tensor(float(n), dtype=torch.float64, device=mean_std.device),
+                       m * n, (s * s + m * m) * n])
+    dist.all_reduce(acc, op=dist.ReduceOp.SUM)
+    gm = acc[1] / acc[0]
+    gv = torch.clamp(acc[2] / acc[0] - gm * gm, min=0.0)
+    return torch.stack([gm, torch.sqrt(gv)]).to(mean_std.dtype)

@@ -47,6 +47,13 @@ def _worker(rank, world, port, out_dir):
     red.all_reduce()
     flat = torch.cat([p.grad.reshape(-1) for p in model.parameters()])
     params = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
+    # PPO advantage statistics over the union of the shards
+    adv = torch.randn(1000 + 37 * rank, generator=torch.Generator().manual_seed(50 + rank)) * (
+        1 + rank) + 0.3 * rank
+    std, mean = torch.std_mean(adv, unbiased=False)
+    gms = distributed.global_mean_std(torch.stack([mean, std]), adv.numel())
+    np.save(os.path.join(out_dir, "gms%d.npy" % rank), gms.numpy())
+    np.save(os.path.join(out_dir, "adv%d.npy" % rank), adv.numpy())
     np.save(os.path.join(out_dir, "grad%d.npy" % rank), flat.numpy())
     np.save(os.path.join(out_dir, "param%d.npy" % rank), params.numpy())
     if rank == 0:
@@ -73,6 +80,10 @@ def test_gradient_all_reduce_two_ranks_gloo(tmp_path):
     np.testing.assert_allclose(g0, ref, rtol=1e-5, atol=1e-6)   # == 1-process run on the full batch
     np.testing.assert_array_equal(np.load(tmp_path / "param0.npy"),
                                   np.load(tmp_path / "param1.npy"))   # broadcast worked
+    allv = np.concatenate([np.load(tmp_path / "adv0.npy"), np.load(tmp_path / "adv1.npy")])
+    for r in range(2):
+        gms = np.load(tmp_path / ("gms%d.npy" % r))
+        np.testing.assert_allclose(gms, [allv.mean(), allv.std()], rtol=1e-5)
 
 
 def test_shard_envs_single_process():
