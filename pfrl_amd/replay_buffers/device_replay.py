@@ -419,3 +419,70 @@ class DeviceReplayStore:
         ln = int(self.h_e_len[slot])
         tids = [int(t) for t in self.h_e_tids[slot][:ln]]
         return [self.transition_view(t, weight if j == 0 else None) for j, t in enumerate(tids)]
+
+
+    # -- native checkpoint ------------------------------------
+    _TABLES = ("t_state_ref", "t_next_ref", "t_action", "t_reward", "t_terminal", "e_tids", "e_len")
+    _MIRRORS = ("h_state_ref", "h_next_ref", "h_action", "h_reward", "h_terminal", "h_min_fseq",
+                "h_e_tids", "h_e_len", "h_e_min_fseq")
+
+    def state_dict(self, head_seq):
+        """Everything needed to continue sampling: tables, host mirrors, counters
+        and the frames still referenced by live entries (only those are read back
+        from HBM).  ``head_seq`` is the entry sequence number of logical index 0."""
+        self.flush()
+        out = dict(version=1, n=self.n, k=self.k, act_dim=self.act_dim, bound=self.bound,
+                   slack=self.slack, n_trans=self.n_trans, n_entries=self.n_entries,
+                   extra=self.h_extra)
+        if self.desc is None:
+            return out
+        for name in self._TABLES:
+            out[name] = getattr(self, name).cpu()
+        for name in self._MIRRORS:
+            out[name] = getattr(self, name)
+        fr = self.frames
+        live = np.arange(head_seq, self.n_entries) % self.E
+        oldest = int(self.h_e_min_fseq[live].min()) if len(live) else fr.next_seq
+        oldest = max(oldest, fr.oldest_live_seq(), 0)
+        seqs = np.arange(oldest, fr.next_seq, dtype=np.int64)
+        idx = torch.from_numpy(seqs % fr.n_slots).to(self.device)
+        out.update(frame_shape=fr.frame_shape, frame_dtype=str(fr.dtype).replace("torch.", ""),
+                   frame_slots=fr.n_slots, frame_stack=fr.stack, frame_first_seq=oldest,
+                   frame_next_seq=fr.next_seq, frame_data=fr.frames[idx].cpu(),
+                   own_frames=self._own_frames, phi_at_ingest=self._phi_at_ingest)
+        return out
+
+    def load_state_dict(self, sd):
+        assert sd["version"] == 1 and sd["n"] == self.n
+        assert sd["bound"] == self.bound and sd["slack"] == self.slack, \
+            "checkpoint was written with a different capacity / slack"
+        self.n_trans, self.n_entries = sd["n_trans"], sd["n_entries"]
+        self.h_extra = sd.get("extra", {})
+        if "t_reward" not in sd:
+            return
+        if self.frames is None:
+            dtype = getattr(torch, sd["frame_dtype"])
+            self.frames = DeviceFrameStore(sd["frame_slots"], sd["frame_shape"], dtype,
+                                           self.device, stack=sd["frame_stack"])
+            self._own_frames = True
+            fb = self.frames.frame_bytes
+            rows = max(1, min(4096, (8 << 20) // fb))
+            self._frame_stage = StagingRing(self.device,
+                                            slot_bytes=rows * fb + 64 + rows * 4 + 64, n_slots=4)
+            self._frame_stage_rows = rows
+        fr = self.frames
+        assert fr.n_slots == sd["frame_slots"] and fr.frame_shape == tuple(sd["frame_shape"])
+        seqs = np.arange(sd["frame_first_seq"], sd["frame_next_seq"], dtype=np.int64)
+        if len(seqs):
+            idx = torch.from_numpy(seqs % fr.n_slots).to(self.device)
+            fr.frames[idx] = sd["frame_data"].to(self.device)
+        fr.next_seq = sd["frame_next_seq"]
+        self._phi_at_ingest = sd.get("phi_at_ingest", False)
+        action_probe = (np.zeros((), dtype=np.int64) if sd["act_dim"] == 0
+                        else np.zeros(sd["act_dim"], dtype=np.float32))
+        if self.desc is None:
+            self._alloc_tables(sd["k"], action_probe)
+        for name in self._TABLES:
+            getattr(self, name).copy_(sd[name].to(self.device))
+        for name in self._MIRRORS:
+            getattr(self, name)[...] = sd[name]

@@ -188,13 +188,34 @@ class ReplayBuffer(replay_buffer.AbstractReplayBuffer):
         returns a dict of tensors with a leading "update" dimension."""
         return self.store.fetch_many(seq_sets, phi, gamma)
 
-    def save(self, filename):
+    def save(self, filename, native=False):
+        """Reference-compatible pickle of the queue (replay_buffer.py:85-88) by
+        default -- device observations are read back and materialised; with
+        ``native=True`` a compact torch checkpoint of the HBM tables and only
+        the live frames (see :meth:`load`, which recognises both)."""
         self._ensure_bound()
+        if native and self.store is not None:
+            torch.save(self._native_state(), filename)
+            return
         with open(filename, "wb") as f:
             if self.store is None:
                 pickle.dump(self.memory, f)
             else:
                 pickle.dump(self._materialise_host(), f)
+
+    def _native_state(self):
+        return dict(kind="pfrl_amd.ReplayBuffer", capacity=self.capacity,
+                    num_steps=self.num_steps, head=self.memory.head,
+                    windows={k: list(v) for k, v in self.last_n_transitions.items()},
+                    store=self.store.state_dict(self.memory.head))
+
+    def _load_native(self, sd):
+        assert sd["capacity"] == self.capacity and sd["num_steps"] == self.num_steps
+        self.store.load_state_dict(sd["store"])
+        self.memory.head = sd["head"]
+        self.last_n_transitions.clear()
+        for k, v in sd["windows"].items():
+            self.last_n_transitions[k].extend(v)
 
     def _materialise_host(self):
         """Device contents as the reference's pickled queue of dict lists
@@ -206,6 +227,13 @@ class ReplayBuffer(replay_buffer.AbstractReplayBuffer):
         return q
 
     def load(self, filename):
+        if self.store is not None:
+            try:
+                sd = torch.load(filename, weights_only=False)
+            except Exception:
+                sd = None
+            if isinstance(sd, dict) and str(sd.get("kind", "")).startswith("pfrl_amd."):
+                return self._load_native(sd)
         with open(filename, "rb") as f:
             loaded = pickle.load(f)
         if isinstance(loaded, collections.deque):
