@@ -243,6 +243,23 @@ int pfrl_rmsprop_step(int32_t n_tensors, float *const *host_params,
                       float *const *host_grad_avg, const int64_t *host_numel, float lr,
                       float alpha, float eps, float weight_decay, int centered, void *stream);
 
+/* DQN / DoubleDQN TD loss and its gradient in one launch
+ * (pfrl/agents/dqn.py:388-470 _compute_target_values/_compute_y_and_t/
+ * _compute_loss, losses :44-104; pfrl/agents/double_dqn.py:12-40):
+ *   y_b    = q[b][action_b]
+ *   next_b = target_q[b][argmax_a sel[b][a]],  sel = next_q_online (Double DQN)
+ *            or target_q itself (DQN: max_a)
+ *   t_b    = reward_b + (discount_b * (1 - terminal_b)) * next_b
+ *   loss   = sum_b w_b * L(y_b - t_b)  [/ B if mean],  L = Huber(1) or d^2 / 2
+ * Outputs: loss[1], grad_q[B][A] = dloss/dq, y[B], abs_delta[B] = |y - t|
+ * (the TD errors handed to PrioritizedReplayBuffer.update_errors).
+ * next_q_online and weights may be NULL. */
+int pfrl_dqn_td_loss(const float *q, const int64_t *action, const float *target_q,
+                     const float *next_q_online, const float *reward, const float *discount,
+                     const float *terminal, const float *weights, int64_t B, int32_t A,
+                     int clip_delta, int mean, float *out_loss, float *out_grad_q, float *out_y,
+                     float *out_abs_delta, void *stream);
+
 /* ------------------------------------------------------------------------
  * Measurement support (bench.py roofline): time every pfrl_batch_experiences
  * launch with a hipEvent pair attached to the dispatch, on its own stream.

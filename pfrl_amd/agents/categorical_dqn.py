@@ -54,6 +54,8 @@ class CategoricalDQN(dqn.DQN):
     """q_function must return DistributionalDiscreteActionValue; clip_delta is
     ignored (reference :107-113)."""
 
+    _fused_td_double = None   # cross-entropy on distributions: not the scalar TD loss
+
     def _project(self, exp_batch, next_dist, z_values):
         Tz = (exp_batch["reward"][..., None]
               + (1.0 - exp_batch["is_state_terminal"][..., None])

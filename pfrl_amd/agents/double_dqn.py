@@ -5,6 +5,8 @@ from pfrl_amd.utils.contexts import evaluating
 
 
 class DoubleDQN(dqn.DQN):
+    _fused_td_double = True
+
     def _compute_target_values(self, exp_batch):
         batch_next_state = exp_batch["next_state"]
         with evaluating(self.model):

@@ -102,6 +102,7 @@ class DQN(agent.AttributeSavingMixin, agent.BatchAgent):
     it is the reference's)."""
 
     saved_attributes = ("model", "target_model", "optimizer")
+    _fused_td_double = False
 
     def __init__(self, q_function, optimizer, replay_buffer, gamma, explorer, gpu=None,
                  replay_start_size=50000, minibatch_size=32, update_interval=1,
@@ -109,7 +110,8 @@ class DQN(agent.AttributeSavingMixin, agent.BatchAgent):
                  target_update_method="hard", soft_update_tau=1e-2, n_times_update=1,
                  batch_accumulator="mean", episodic_update_len=None, logger=getLogger(__name__),
                  batch_states=batch_states, recurrent=False, max_grad_norm=None,
-                 use_graphs=None, step_fused_gather=None, batch_target_pass=None):
+                 use_graphs=None, step_fused_gather=None, batch_target_pass=None,
+                 fused_td_loss=True):
         self.model = q_function
         if gpu is not None and gpu >= 0:
             assert torch.cuda.is_available()
@@ -174,6 +176,7 @@ class DQN(agent.AttributeSavingMixin, agent.BatchAgent):
         # the same inputs; only the batch size of the conv/GEMM kernels changes)
         self.batch_target_pass = self.step_fused_gather if batch_target_pass is None else \
             bool(batch_target_pass and self.step_fused_gather)
+        self.fused_td_loss = bool(fused_td_loss)
         self._graphed = None
         self._last_y = None
 
@@ -292,9 +295,42 @@ class DQN(agent.AttributeSavingMixin, agent.BatchAgent):
             batch_q_target = torch.reshape(self._compute_target_values(exp_batch), (batch_size, 1))
         return batch_q, batch_q_target
 
+    # The fused TD-loss launch applies to DQN (_fused_td_double False) and
+    # DoubleDQN (True); subclasses that override the target / loss computation
+    # (categorical agents) set it to None and keep their own.
+
+    def _fused_td_loss_applicable(self):
+        return (self.fused_td_loss and self.device.type == "cuda"
+                and type(self)._fused_td_double is not None
+                and type(self)._compute_y_and_t is DQN._compute_y_and_t)
+
+    def _compute_loss_fused(self, exp_batch, errors_out, record):
+        from pfrl_amd import ops
+
+        qout = self.model(exp_batch["state"])
+        with torch.no_grad():
+            target_q = self._target_next_action_value(exp_batch).q_values
+            next_online = None
+            if type(self)._fused_td_double:
+                with evaluating(self.model):
+                    next_online = self.model(exp_batch["next_state"]).q_values
+        loss, y, delta = ops.dqn_td_loss(
+            qout.q_values, exp_batch["action"], target_q, next_online, exp_batch["reward"],
+            exp_batch["discount"], exp_batch["is_state_terminal"], exp_batch.get("weights"),
+            self.clip_delta, self.batch_accumulator == "mean")
+        self._last_y = y
+        if record:
+            self.q_record.extend(y)
+        if errors_out is not None:
+            del errors_out[:]
+            errors_out.extend(delta.cpu().numpy())
+        return loss, delta
+
     def _compute_loss(self, exp_batch, errors_out=None, want_errors=False, record=True):
         """Returns (loss, |y - t| per sample or None).  ``errors_out`` keeps the
         reference's list-filling form for callers that use it directly."""
+        if self._fused_td_loss_applicable():
+            return self._compute_loss_fused(exp_batch, errors_out, record)
         y, t = self._compute_y_and_t(exp_batch)
         self._last_y = y.detach()
         if record:

@@ -195,3 +195,39 @@ def ppo_minibatch(idx, adv, mean_std, standardize, log_prob, v_pred, v_teacher, 
         _ptr(out["log_prob"]), _ptr(out["v_pred"]), _ptr(out["v_teacher"]), _ptr(out["action"]),
         _ptr(out["refs"]), _stream()), "ppo_minibatch")
     return out
+
+
+class _DQNTDLoss(torch.autograd.Function):
+    """loss = sum/mean_b w_b L(Q(s)[a] - target); one HIP launch computes the loss,
+    its gradient w.r.t. Q(s), the selected Q values and |TD error|."""
+
+    @staticmethod
+    def forward(ctx, q, action, target_q, next_q_online, reward, discount, terminal, weights,
+                clip_delta, mean):
+        B, A = q.shape
+        qc = q.detach().contiguous()
+        loss = torch.empty(1, dtype=torch.float32, device=q.device)
+        grad_q = torch.empty((B, A), dtype=torch.float32, device=q.device)
+        y = torch.empty(B, dtype=torch.float32, device=q.device)
+        delta = torch.empty(B, dtype=torch.float32, device=q.device)
+        check(_native.lib().pfrl_dqn_td_loss(
+            _ptr(qc), _ptr(action.contiguous()), _ptr(target_q.contiguous()),
+            _ptr(next_q_online.contiguous()) if next_q_online is not None else None,
+            _ptr(reward), _ptr(discount), _ptr(terminal),
+            _ptr(weights.contiguous()) if weights is not None else None, B, A, int(clip_delta),
+            int(mean), _ptr(loss), _ptr(grad_q), _ptr(y), _ptr(delta), _stream()), "dqn_td_loss")
+        ctx.save_for_backward(grad_q)
+        ctx.mark_non_differentiable(y, delta)
+        return loss.view(()), y, delta
+
+    @staticmethod
+    def backward(ctx, g_loss, g_y, g_delta):
+        (grad_q,) = ctx.saved_tensors
+        return (grad_q * g_loss,) + (None,) * 9
+
+
+def dqn_td_loss(q, action, target_q, next_q_online, reward, discount, terminal, weights,
+                clip_delta, mean):
+    """-> (loss scalar with grad, y [B], |y - t| [B])"""
+    return _DQNTDLoss.apply(q, action, target_q, next_q_online, reward, discount, terminal,
+                            weights, clip_delta, mean)

@@ -529,3 +529,57 @@ def test_prioritized_buffer_large_tree_lds_sampler(dev):
         ov, ot = orc.dump_level(0, 1 << l)
         np.testing.assert_array_equal(gt, ot)
         np.testing.assert_array_equal(gv, ov)
+
+
+# ---------------------------------------------------------------------------
+# fused TD loss
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("double", [False, True])
+@pytest.mark.parametrize("clip_delta", [True, False])
+@pytest.mark.parametrize("accum", ["sum", "mean"])
+@pytest.mark.parametrize("weighted", [False, True])
+def test_fused_td_loss_matches_torch(dev, double, clip_delta, accum, weighted):
+    """pfrl_dqn_td_loss vs the reference formulation in torch ops
+    (pfrl/agents/dqn.py:44-104,388-470; known-answer style of the reference's
+    tests/agents_tests/test_dqn.py:138-208).  Tolerance 1e-6: the only freedom is
+    the order of the batch sum."""
+    import torch.nn.functional as F
+
+    from pfrl_amd import ops
+
+    torch.manual_seed(3)
+    B, A = 37, 6
+    q = (torch.randn(B, A, device=dev) * 2).requires_grad_(True)
+    tq = torch.randn(B, A, device=dev) * 2
+    nq = torch.randn(B, A, device=dev) if double else None
+    act = torch.randint(0, A, (B,), device=dev)
+    r = torch.randn(B, device=dev)
+    disc = torch.full((B,), 0.99, device=dev) ** torch.randint(1, 4, (B,), device=dev)
+    term = (torch.rand(B, device=dev) < 0.3).float()
+    w = torch.rand(B, device=dev) + 0.1 if weighted else None
+    loss, y, delta = ops.dqn_td_loss(q, act, tq, nq, r, disc, term, w, clip_delta,
+                                     accum == "mean")
+    loss.backward()
+    g_fused = q.grad.clone()
+    q.grad = None
+    # reference formulation
+    yy = q.gather(1, act[:, None]).flatten()
+    if double:
+        nxt = tq.gather(1, nq.argmax(dim=1)[:, None]).flatten()
+    else:
+        nxt = tq.max(dim=1).values
+    t = r + disc * (1.0 - term) * nxt
+    if weighted:
+        per = (F.smooth_l1_loss(yy, t, reduction="none") if clip_delta
+               else F.mse_loss(yy, t, reduction="none") / 2)
+        ref = torch.sum(per * w)
+        if accum == "mean":
+            ref = ref / B
+    else:
+        ref = (F.smooth_l1_loss(yy, t, reduction=accum) if clip_delta
+               else F.mse_loss(yy, t, reduction=accum) / 2)
+    ref.backward()
+    np.testing.assert_allclose(loss.item(), ref.item(), rtol=2e-6, atol=1e-6)
+    np.testing.assert_allclose(g_fused.cpu().numpy(), q.grad.cpu().numpy(), rtol=1e-6, atol=1e-7)
+    np.testing.assert_array_equal(y.cpu().numpy(), yy.detach().cpu().numpy())
+    np.testing.assert_array_equal(delta.cpu().numpy(), (yy - t).abs().detach().cpu().numpy())
