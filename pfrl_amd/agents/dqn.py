@@ -202,10 +202,14 @@ class DQN(agent.AttributeSavingMixin, agent.BatchAgent):
                                                 device=self.device, dtype=torch.float32)
         self._update_from_batch(exp_batch, has_weight, errors_out)
 
-    def _update_from_batch(self, exp_batch, has_weight=False, errors_out=None):
+    def _update_from_batch(self, exp_batch, has_weight=False, errors_out=None, deferred=None):
+        """``deferred``: a list that receives this update's (loss, y) graph outputs
+        instead of cloning them now -- valid when every update of the step replays
+        its own graph (step-fused path), so the outputs stay intact until the end
+        of the step and are recorded with one concatenation."""
         want_errors = has_weight or errors_out is not None
         if self.use_graphs:
-            loss, delta = self._graphed_step(exp_batch, want_errors)
+            loss, delta = self._graphed_step(exp_batch, want_errors, deferred)
         else:
             loss, delta = self._compute_loss(exp_batch, want_errors=want_errors)
         if errors_out is not None:
@@ -223,7 +227,7 @@ class DQN(agent.AttributeSavingMixin, agent.BatchAgent):
             self.optimizer.step()
         self.optim_t += 1
 
-    def _graphed_step(self, exp_batch, want_errors):
+    def _graphed_step(self, exp_batch, want_errors, deferred=None):
         """loss -> backward -> step replayed from a captured HIP graph."""
         if self._graphed is None:
             from pfrl_amd.agents.graphed_update import GraphedUpdate
@@ -246,8 +250,11 @@ class DQN(agent.AttributeSavingMixin, agent.BatchAgent):
             self.optimizer.step()
             return loss, delta
         # graph outputs are static buffers: copy what the records keep
-        self.loss_record.extend(loss.clone())
-        self.q_record.extend(y.clone())
+        if deferred is not None:
+            deferred.append((loss, y))
+        else:
+            self.loss_record.extend(loss.clone())
+            self.q_record.extend(y.clone())
         return loss, delta
 
     # -- step-batched target pass ------------------------------------------------
@@ -429,14 +436,24 @@ class DQN(agent.AttributeSavingMixin, agent.BatchAgent):
                 raw = self._precompute_target_raw(ns.view((U * B,) + tuple(ns.shape[2:])))
                 big["target_next_raw"] = raw.view((U, B) + tuple(raw.shape[1:]))
         p = 0
+        deferred = [] if self.use_graphs else None
         for i in range(n_env):
             self.t += 1
             self._cumulative_steps += 1
             if self.t % self.target_update_interval == 0:
                 self.sync_target_network()
             while p < len(plan_env) and plan_env[p] == i:
-                self._update_from_batch({k: v[p] for k, v in big.items()})
+                self._update_from_batch({k: v[p] for k, v in big.items()}, deferred=deferred)
                 p += 1
+        if deferred and self.use_graphs:
+            # every update above replayed its own graph, so all outputs are still live
+            if len({id(l) for l, _ in deferred}) == len(deferred):
+                self.loss_record.extend(torch.stack([l.reshape(()) for l, _ in deferred]))
+                self.q_record.extend(torch.cat([y.reshape(-1) for _, y in deferred]))
+            else:   # graphs were shared (should not happen): last values only
+                for l, y in deferred:
+                    self.loss_record.extend(l.clone())
+                    self.q_record.extend(y.clone())
 
     def _batch_observe_eval(self, batch_obs, batch_reward, batch_done, batch_reset):
         pass

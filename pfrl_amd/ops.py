@@ -218,6 +218,7 @@ class _DQNTDLoss(torch.autograd.Function):
             int(mean), _ptr(loss), _ptr(grad_q), _ptr(y), _ptr(delta), _stream()), "dqn_td_loss")
         ctx.save_for_backward(grad_q)
         ctx.mark_non_differentiable(y, delta)
+        ctx.set_materialize_grads(False)   # no zero-fill kernels for the unused outputs
         return loss.view(()), y, delta
 
     @staticmethod
