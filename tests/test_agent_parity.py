@@ -76,7 +76,11 @@ def _run(name, prioritized, num_steps, double, gpu, priority_pow="device", steps
 
     def spy_core(*a, **kw):
         orig_core(*a, **kw)
-        losses.append(float(ag.loss_record.values()[-1]))
+        d = kw.get("deferred")
+        if d:   # step-fused path: the loss is recorded at the end of the step
+            losses.append(float(d[-1][0]))
+        else:
+            losses.append(float(ag.loss_record.values()[-1]))
 
     ag._update_from_batch = spy_core
     pfrl.experiments.train_agent_batch(ag, env, steps, tempfile.mkdtemp())
@@ -327,7 +331,11 @@ def test_categorical_double_dqn_prioritized_matches_reference():
 
     def spy_core(*a, **kw):
         orig_core(*a, **kw)
-        losses.append(float(ag.loss_record.values()[-1]))
+        d = kw.get("deferred")
+        if d:   # step-fused path: the loss is recorded at the end of the step
+            losses.append(float(d[-1][0]))
+        else:
+            losses.append(float(ag.loss_record.values()[-1]))
 
     ag._update_from_batch = spy_core
     pfrl.experiments.train_agent_batch(ag, env, 640, tempfile.mkdtemp())
