@@ -583,3 +583,76 @@ def test_fused_td_loss_matches_torch(dev, double, clip_delta, accum, weighted):
     np.testing.assert_allclose(g_fused.cpu().numpy(), q.grad.cpu().numpy(), rtol=1e-6, atol=1e-7)
     np.testing.assert_array_equal(y.cpu().numpy(), yy.detach().cpu().numpy())
     np.testing.assert_array_equal(delta.cpu().numpy(), (yy - t).abs().detach().cpu().numpy())
+
+
+# ---------------------------------------------------------------------------
+# property-based differential test of the device trees vs the oracle
+# ---------------------------------------------------------------------------
+def test_prioritized_buffer_hypothesis_differential(dev):
+    """Random operation scripts (append with typed / default priority, popleft,
+    sample + set_last_priority with mixed NumPy scalar types) on small capacities,
+    where frame doubling / halving / re-rooting happens constantly: the device
+    buffer must equal the oracle after every script (root sum/min, max_priority,
+    bounds, all leaves with tags)."""
+    from hypothesis import HealthCheck, given, settings
+    from hypothesis import strategies as st
+
+    from pfrl_amd.collections.prioritized import PrioritizedBuffer
+
+    op = st.one_of(
+        st.tuples(st.just("append"), st.sampled_from([0, 1, 2, 3]),
+                  st.floats(min_value=1e-3, max_value=4.0, allow_nan=False)),
+        st.tuples(st.just("pop"), st.just(0), st.just(0.0)),
+        st.tuples(st.just("sample"), st.integers(min_value=1, max_value=5),
+                  st.floats(min_value=0.0, max_value=0.999)),
+    )
+
+    @settings(max_examples=40, deadline=None,
+              suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow])
+    @given(cap=st.sampled_from([1, 2, 3, 5, 8, 13]), script=st.lists(op, min_size=5, max_size=60),
+           seed=st.integers(min_value=0, max_value=10 ** 6))
+    def run(cap, script, seed):
+        rs = np.random.RandomState(seed)
+        buf = PrioritizedBuffer(cap, device=dev)
+        orc = oracle.OraclePrioritizedBuffer(cap)
+        k = 0
+        for kind, a, b in script:
+            if kind == "append":
+                if a == 0:
+                    buf.append(k)
+                    orc.append(k)
+                else:
+                    v = float(np.float32(b)) if a == 2 else float(b)
+                    buf.append(k, _np_scalar(v, a))
+                    oracle.lib().orc_pbuf_append(orc._h, k, v, a)
+                k += 1
+            elif kind == "pop":
+                if len(orc):
+                    buf.popleft()
+                    orc.popleft()
+            else:
+                n = min(a, len(orc))
+                if n == 0:
+                    continue
+                u = rs.random_sample(n)
+                want = orc.sample(u)
+                out = buf.sample_device(n, u01=u)
+                np.testing.assert_array_equal(out["x"].cpu().numpy() - buf.frame.head,
+                                              want["indices"])
+                np.testing.assert_array_equal(out["pri"].cpu().numpy(), want["priorities"])
+                vals = rs.rand(n) * 2 + 1e-3
+                tags = rs.choice([1, 2, 3], size=n)
+                vals = np.where(tags == 2, vals.astype(np.float32).astype(np.float64), vals)
+                orc.set_last_priority(vals, tags)
+                buf.set_last_priority([_np_scalar(v, t) for v, t in zip(vals, tags)])
+        assert len(buf) == len(orc)
+        if len(orc):
+            st_, so = buf.root_stats(), orc.stats()
+            assert st_[0] == so["sum"] and st_[1] == so["min"] and st_[2] == so["max_priority"]
+            assert buf.frame.bounds == so["bounds"]
+            gv, gt = buf.dump_level(0, 0)
+            ov, ot = orc.dump_level(0, 1)
+            np.testing.assert_array_equal(gt, ot)
+            np.testing.assert_array_equal(gv, ov)
+
+    run()
