@@ -260,6 +260,19 @@ int pfrl_dqn_td_loss(const float *q, const int64_t *action, const float *target_
                      int clip_delta, int mean, float *out_loss, float *out_grad_q, float *out_y,
                      float *out_abs_delta, void *stream);
 
+/* Fused bias + ReLU of the conv trunk (pfrl/nn/atari_cnn.py:40-47: activation(
+ * layer(h)) with conv bias) on row-major [rows][C] activations, i.e.
+ * channels_last conv outputs flattened over N*H*W.  Forward: y = max(x + b[c], 0)
+ * (C % 4 == 0).  Backward: gx = gy * (y > 0) and gb[c] = sum over rows of gx, in
+ * ONE launch (workgroup partials + last-arriver fold; C must divide 256).
+ * partial_ws: float[max_blocks * C]; counter: one zero-initialised uint32 that
+ * the kernel leaves at zero. */
+int pfrl_bias_relu_fwd(const float *x, const float *bias, float *y, int64_t rows, int32_t C,
+                       void *stream);
+int pfrl_bias_relu_bwd(const float *gy, const float *y, float *gx, float *gb, float *partial_ws,
+                       uint32_t *counter, int64_t rows, int32_t C, int32_t max_blocks,
+                       void *stream);
+
 /* ------------------------------------------------------------------------
  * Measurement support (bench.py roofline): time every pfrl_batch_experiences
  * launch with a hipEvent pair attached to the dispatch, on its own stream.

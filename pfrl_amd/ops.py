@@ -232,3 +232,71 @@ def dqn_td_loss(q, action, target_q, next_q_online, reward, discount, terminal, 
     """-> (loss scalar with grad, y [B], |y - t| [B])"""
     return _DQNTDLoss.apply(q, action, target_q, next_q_online, reward, discount, terminal,
                             weights, clip_delta, mean)
+
+
+_BIAS_RELU_MAX_BLOCKS = 1024
+_bias_relu_ws = {}
+
+
+def _bias_relu_workspace(device, C):
+    key = (device, C)
+    ws = _bias_relu_ws.get(key)
+    if ws is None:
+        ws = _bias_relu_ws[key] = (
+            torch.empty(_BIAS_RELU_MAX_BLOCKS * C, dtype=torch.float32, device=device),
+            torch.zeros(1, dtype=torch.int32, device=device))
+    return ws
+
+
+class _BiasReLU(torch.autograd.Function):
+    """y = relu(x + bias[c]) for channels_last conv outputs / [N, C] matrices."""
+
+    @staticmethod
+    def forward(ctx, x, bias):
+        C = bias.numel()
+        rows = x.numel() // C
+        y = torch.empty_like(x)   # preserves the (dense) layout of x
+        check(_native.lib().pfrl_bias_relu_fwd(_ptr_dense(x), _ptr(bias), _ptr_dense(y), rows, C,
+                                               _stream()), "bias_relu_fwd")
+        ctx.save_for_backward(y)
+        ctx.C = C
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (y,) = ctx.saved_tensors
+        C = ctx.C
+        rows = y.numel() // C
+        if gy.stride() != y.stride():
+            gy = gy.contiguous(memory_format=torch.channels_last) if y.dim() == 4 \
+                else gy.contiguous()
+        gx = torch.empty_like(y)
+        gb = torch.empty(C, dtype=torch.float32, device=y.device)
+        ws, counter = _bias_relu_workspace(y.device, C)
+        check(_native.lib().pfrl_bias_relu_bwd(_ptr_dense(gy), _ptr_dense(y), _ptr_dense(gx),
+                                               _ptr(gb), _ptr(ws), _ptr(counter), rows, C,
+                                               _BIAS_RELU_MAX_BLOCKS, _stream()), "bias_relu_bwd")
+        return gx, gb
+
+
+def _ptr_dense(t):
+    assert t.is_cuda
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def bias_relu_supported(x, bias):
+    """Row-major [rows][C] view available?  (channels_last 4-D or contiguous 2-D)"""
+    if not (x.is_cuda and x.dtype == torch.float32 and bias is not None):
+        return False
+    C = bias.numel()
+    if C % 4 or 256 % C:
+        return False
+    if x.dim() == 4:
+        return x.shape[1] == C and x.is_contiguous(memory_format=torch.channels_last)
+    if x.dim() == 2:
+        return x.shape[1] == C and x.is_contiguous()
+    return False
+
+
+def bias_relu(x, bias):
+    return _BiasReLU.apply(x, bias)
