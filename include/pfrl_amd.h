@@ -264,14 +264,16 @@ int pfrl_dqn_td_loss(const float *q, const int64_t *action, const float *target_
  * layer(h)) with conv bias) on row-major [rows][C] activations, i.e.
  * channels_last conv outputs flattened over N*H*W.  Forward: y = max(x + b[c], 0)
  * (C % 4 == 0).  Backward: gx = gy * (y > 0) and gb[c] = sum over rows of gx, in
- * ONE launch (workgroup partials + last-arriver fold; C must divide 256).
- * partial_ws: float[max_blocks * C]; counter: one zero-initialised uint32 that
- * the kernel leaves at zero. */
+ * ONE launch (workgroup partials published as {value, epoch} granules + fold by
+ * the last arriver; C must divide 256).  granule_ws: uint64[blocks * C];
+ * counters: uint64[2], zero-initialised once, owned by one (C, blocks) pair and
+ * never touched by the host afterwards (they carry the launch epoch, which keeps
+ * the kernel valid under HIP-graph replay).  Launches that share a workspace
+ * must be ordered on one stream.  The rows are split evenly over `blocks`. */
 int pfrl_bias_relu_fwd(const float *x, const float *bias, float *y, int64_t rows, int32_t C,
                        void *stream);
-int pfrl_bias_relu_bwd(const float *gy, const float *y, float *gx, float *gb, float *partial_ws,
-                       uint32_t *counter, int64_t rows, int32_t C, int32_t max_blocks,
-                       void *stream);
+int pfrl_bias_relu_bwd(const float *gy, const float *y, float *gx, float *gb, uint64_t *granule_ws,
+                       uint64_t *counters, int64_t rows, int32_t C, int32_t blocks, void *stream);
 
 /* ------------------------------------------------------------------------
  * Measurement support (bench.py roofline): time every pfrl_batch_experiences

@@ -8,9 +8,8 @@
 //   backward  gx = gy * (y > 0);  gb[c] = sum_rows gx[., c]          one launch
 // The backward kernel reduces columns inside each workgroup (registers -> LDS),
 // publishes one partial row per workgroup and lets the LAST arriving workgroup
-// fold the partials -- agent-scope release on the producers, acquire on the
-// reducer (cdna_hip_programming.md guideline 16): no second launch, no atomics
-// on floats (the result is deterministic).
+// fold the partials (cdna_hip_programming.md guideline 16, data-tagged granule
+// form): no second launch, no atomics on floats (the result is deterministic).
 #include "common.h"
 
 namespace {
@@ -38,12 +37,28 @@ __global__ __launch_bounds__(kThreads) void k_bias_relu_fwd(const float *__restr
 
 // grid = nblk workgroups; workgroup w owns rows [w*rows_per_blk, ...).
 // thread t: column c = t % C, row lane rl = t / C (kThreads % C == 0).
+//
+// Cross-workgroup fold without fences: every partial is published as ONE
+// naturally aligned 8-byte granule {value, epoch} with a write-through (sc1)
+// agent-scope store; the last arriver (relaxed ticket) reads the granules with
+// sc1 loads and accepts a granule only if its tag equals this launch's epoch,
+// so a stale line in another XCD's L2 can never be mistaken for fresh data.
+// The epoch comes from a monotonically increasing device counter, which keeps
+// the protocol valid under HIP-graph replay (kernel arguments are frozen there).
+// A release fence here would write back the whole L2 -- including the gx tile
+// this workgroup just produced -- and cost 15-35 us per launch (measured).
 __global__ __launch_bounds__(kThreads) void k_bias_relu_bwd(
     const float *__restrict__ gy, const float *__restrict__ y, float *__restrict__ gx,
-    float *__restrict__ gb, float *__restrict__ partial, unsigned int *__restrict__ counter,
-    int64_t rows, int C, int64_t rows_per_blk) {
+    float *__restrict__ gb, unsigned long long *__restrict__ granules,
+    unsigned long long *__restrict__ ctr, int64_t rows, int C, int64_t rows_per_blk) {
     __shared__ float s_acc[kThreads];
+    __shared__ unsigned int s_epoch;
     __shared__ int s_last;
+    if (threadIdx.x == 0) {
+        const unsigned long long e =
+            __hip_atomic_fetch_add(&ctr[0], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_epoch = (unsigned int)(e / gridDim.x) + 1u;
+    }
     const int c = threadIdx.x % C;
     const int rl = threadIdx.x / C;
     const int rstep = kThreads / C;
@@ -62,29 +77,35 @@ __global__ __launch_bounds__(kThreads) void k_bias_relu_bwd(
     if (rl == 0) {
         float tot = 0.0f;
         for (int k = 0; k < rstep; ++k) tot += s_acc[k * C + c];
-        partial[(int64_t)blockIdx.x * C + c] = tot;
+        const unsigned long long g =
+            ((unsigned long long)s_epoch << 32) | (unsigned long long)__float_as_uint(tot);
+        __hip_atomic_store(&granules[(int64_t)blockIdx.x * C + c], g, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
     }
-    // publish the partial row, take a ticket
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const unsigned int ticket =
-            __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_last = ticket == gridDim.x - 1;
-        if (s_last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        const unsigned long long t =
+            __hip_atomic_fetch_add(&ctr[1], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = (t % gridDim.x) == (unsigned long long)(gridDim.x - 1);
     }
     __syncthreads();
     if (!s_last) return;
     // last workgroup: fold the partial rows in a fixed order
     if (threadIdx.x < C) {
         float tot = 0.0f;
-        for (unsigned int w = 0; w < gridDim.x; ++w) tot += partial[(int64_t)w * C + threadIdx.x];
+        const unsigned int epoch = s_epoch;
+        for (unsigned int w = 0; w < gridDim.x; ++w) {
+            unsigned long long g;
+            int spins = 0;
+            do {
+                g = __hip_atomic_load(&granules[(int64_t)w * C + threadIdx.x], __ATOMIC_RELAXED,
+                                      __HIP_MEMORY_SCOPE_AGENT);
+            } while ((unsigned int)(g >> 32) != epoch && ++spins < (1 << 22));
+            tot += __uint_as_float((unsigned int)g);
+        }
         gb[threadIdx.x] = tot;
     }
-    if (threadIdx.x == 0)
-        __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 }  // namespace
@@ -102,22 +123,17 @@ extern "C" int pfrl_bias_relu_fwd(const float *x, const float *bias, float *y, i
 }
 
 extern "C" int pfrl_bias_relu_bwd(const float *gy, const float *y, float *gx, float *gb,
-                                  float *partial_ws, uint32_t *counter, int64_t rows, int32_t C,
-                                  int32_t max_blocks, void *stream) {
+                                  uint64_t *granule_ws, uint64_t *counters, int64_t rows,
+                                  int32_t C, int32_t blocks, void *stream) {
     PFRL_CHECK_ARG(C > 0 && C <= kThreads && kThreads % C == 0,
                    "pfrl_bias_relu_bwd: C must divide 256");
+    PFRL_CHECK_ARG(blocks > 0, "pfrl_bias_relu_bwd: blocks must be positive");
     if (rows <= 0) return 0;
-    // ~64 rows per row-lane keeps every workgroup busy and the partial table small
-    const int rstep = kThreads / C;
-    int64_t rows_per_blk = (int64_t)rstep * 16;
-    int64_t blocks = (rows + rows_per_blk - 1) / rows_per_blk;
-    if (blocks > max_blocks) {
-        blocks = max_blocks;
-        rows_per_blk = (rows + blocks - 1) / blocks;
-        blocks = (rows + rows_per_blk - 1) / rows_per_blk;
-    }
+    const int64_t rows_per_blk = (rows + blocks - 1) / blocks;
     hipLaunchKernelGGL(k_bias_relu_bwd, dim3((unsigned)blocks), dim3(kThreads), 0,
-                       (hipStream_t)stream, gy, y, gx, gb, partial_ws, counter, rows, (int)C,
+                       (hipStream_t)stream, gy, y, gx, gb,
+                       reinterpret_cast<unsigned long long *>(granule_ws),
+                       reinterpret_cast<unsigned long long *>(counters), rows, (int)C,
                        rows_per_blk);
     PFRL_LAUNCH_CHECK();
 }

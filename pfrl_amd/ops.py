@@ -234,17 +234,23 @@ def dqn_td_loss(q, action, target_q, next_q_online, reward, discount, terminal, 
                             weights, clip_delta, mean)
 
 
-_BIAS_RELU_MAX_BLOCKS = 1024
 _bias_relu_ws = {}
 
 
-def _bias_relu_workspace(device, C):
-    key = (device, C)
+def _bias_relu_plan(rows, C):
+    """Workgroups of the backward launch: ~16 rows per row-lane, at most 256."""
+    rstep = 256 // C
+    blocks = max(1, min(256, -(-rows // (rstep * 16))))
+    return blocks
+
+
+def _bias_relu_workspace(device, C, blocks):
+    key = (device, C, blocks)
     ws = _bias_relu_ws.get(key)
     if ws is None:
         ws = _bias_relu_ws[key] = (
-            torch.empty(_BIAS_RELU_MAX_BLOCKS * C, dtype=torch.float32, device=device),
-            torch.zeros(1, dtype=torch.int32, device=device))
+            torch.zeros(blocks * C, dtype=torch.int64, device=device),
+            torch.zeros(2, dtype=torch.int64, device=device))
     return ws
 
 
@@ -272,10 +278,11 @@ class _BiasReLU(torch.autograd.Function):
                 else gy.contiguous()
         gx = torch.empty_like(y)
         gb = torch.empty(C, dtype=torch.float32, device=y.device)
-        ws, counter = _bias_relu_workspace(y.device, C)
+        blocks = _bias_relu_plan(rows, C)
+        ws, counters = _bias_relu_workspace(y.device, C, blocks)
         check(_native.lib().pfrl_bias_relu_bwd(_ptr_dense(gy), _ptr_dense(y), _ptr_dense(gx),
-                                               _ptr(gb), _ptr(ws), _ptr(counter), rows, C,
-                                               _BIAS_RELU_MAX_BLOCKS, _stream()), "bias_relu_bwd")
+                                               _ptr(gb), _ptr(ws), _ptr(counters), rows, C,
+                                               blocks, _stream()), "bias_relu_bwd")
         return gx, gb
 
 

@@ -671,7 +671,7 @@ def test_fused_bias_relu_forward_backward(dev, shape):
 
     torch.manual_seed(1)
     C = shape[1]
-    for rep in range(3):
+    for rep in range(6):
         x = torch.randn(shape, device=dev)
         if len(shape) == 4:
             x = x.contiguous(memory_format=torch.channels_last)
@@ -688,8 +688,9 @@ def test_fused_bias_relu_forward_backward(dev, shape):
         ya.backward(gy)
         yb.backward(gy)
         assert torch.equal(xa.grad, xb.grad)
-        np.testing.assert_allclose(ba.grad.cpu().numpy(), bb.grad.cpu().numpy(), rtol=1e-5,
-                                   atol=1e-4)
+        rows = x.numel() // C
+        np.testing.assert_allclose(ba.grad.cpu().numpy(), bb.grad.cpu().numpy(), rtol=1e-4,
+                                   atol=2e-7 * rows)
 
 
 def test_atari_cnn_fused_path_matches_plain(dev):
