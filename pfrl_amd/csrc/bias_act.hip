@@ -91,20 +91,41 @@ __global__ __launch_bounds__(kThreads) void k_bias_relu_bwd(
     }
     __syncthreads();
     if (!s_last) return;
-    // last workgroup: fold the partial rows in a fixed order
-    if (threadIdx.x < C) {
-        float tot = 0.0f;
+    // last workgroup: fold the partial rows.  All 256 threads load granules in
+    // parallel (8 independent write-through loads in flight per thread; a serial
+    // walk would pay one uncached round trip per workgroup), then LDS-reduce.
+    {
         const unsigned int epoch = s_epoch;
-        for (unsigned int w = 0; w < gridDim.x; ++w) {
-            unsigned long long g;
-            int spins = 0;
-            do {
-                g = __hip_atomic_load(&granules[(int64_t)w * C + threadIdx.x], __ATOMIC_RELAXED,
-                                      __HIP_MEMORY_SCOPE_AGENT);
-            } while ((unsigned int)(g >> 32) != epoch && ++spins < (1 << 22));
-            tot += __uint_as_float((unsigned int)g);
+        const int64_t total = (int64_t)gridDim.x * C;   // granule (w, c) at w*C + c
+        float part = 0.0f;
+        for (int64_t base = threadIdx.x; base < total; base += (int64_t)kThreads * 8) {
+            unsigned long long g[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int64_t idx = base + (int64_t)u * kThreads;
+                g[u] = idx < total ? __hip_atomic_load(&granules[idx], __ATOMIC_RELAXED,
+                                                       __HIP_MEMORY_SCOPE_AGENT)
+                                   : ((unsigned long long)epoch << 32);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int64_t idx = base + (int64_t)u * kThreads;
+                int spins = 0;
+                while ((unsigned int)(g[u] >> 32) != epoch && ++spins < (1 << 22))
+                    g[u] = __hip_atomic_load(&granules[idx], __ATOMIC_RELAXED,
+                                             __HIP_MEMORY_SCOPE_AGENT);
+                part += __uint_as_float((unsigned int)g[u]);
+            }
         }
-        gb[threadIdx.x] = tot;
+        // kThreads % C == 0, so thread t only ever saw column t % C
+        __syncthreads();
+        s_acc[threadIdx.x] = part;
+        __syncthreads();
+        if (threadIdx.x < C) {
+            float tot = 0.0f;
+            for (int k = 0; k < kThreads / C; ++k) tot += s_acc[k * C + threadIdx.x];
+            gb[threadIdx.x] = tot;
+        }
     }
 }
 
