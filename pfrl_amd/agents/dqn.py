@@ -177,6 +177,7 @@ class DQN(agent.AttributeSavingMixin, agent.BatchAgent):
         self.batch_target_pass = self.step_fused_gather if batch_target_pass is None else \
             bool(batch_target_pass and self.step_fused_gather)
         self.fused_td_loss = bool(fused_td_loss)
+        self._analytic_backward = None
         self._graphed = None
         self._last_y = None
 
@@ -325,6 +326,10 @@ class DQN(agent.AttributeSavingMixin, agent.BatchAgent):
             qout.q_values, exp_batch["action"], target_q, next_online, exp_batch["reward"],
             exp_batch["discount"], exp_batch["is_state_terminal"], exp_batch.get("weights"),
             self.clip_delta, self.batch_accumulator == "mean")
+        # d(loss)/dQ(s) is already known: callers may start backward at Q(s) and skip
+        # the ones-fill and the multiply autograd would launch for loss.backward()
+        self._analytic_backward = (qout.q_values, loss.grad_fn.saved_tensors[0]
+                                   if loss.grad_fn is not None else None)
         self._last_y = y
         if record:
             self.q_record.extend(y)

@@ -70,8 +70,14 @@ class GraphedUpdate:
     # the work that gets captured ------------------------------------------------
     def _forward_backward(self, exp_batch, want_errors):
         ag = self.agent
+        ag._analytic_backward = None
         loss, delta = ag._compute_loss(exp_batch, want_errors=want_errors, record=False)
-        loss.backward()
+        ab = getattr(ag, "_analytic_backward", None)
+        if ab is not None and ab[1] is not None:
+            # fused TD loss: the gradient w.r.t. Q(s) came out of the same launch
+            torch.autograd.backward([ab[0]], [ab[1]])
+        else:
+            loss.backward()
         return loss, delta
 
     def _step(self):
