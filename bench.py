@@ -37,8 +37,13 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 def parse_args():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--algo", choices=["dqn", "rainbow", "ppo"], default="dqn",
-                   help="dqn = BASELINE configs[1] (headline); rainbow = configs[2]; ppo = configs[3]")
+    p.add_argument("--algo", choices=["dqn", "rainbow", "ppo", "sac"], default="dqn",
+                   help="dqn = BASELINE configs[1] (headline); rainbow = configs[2]; ppo = configs[3]; "
+                        "sac = configs[4]")
+    p.add_argument("--host-env", action="store_true",
+                   help="dqn only: frames are produced on the HOST (numpy) and ingested over PCIe "
+                        "through the pinned staging ring -- the PCIe-inclusive rate of DESIGN.md, "
+                        "never the headline value")
     p.add_argument("--steps", type=int, default=None,
                    help="timed batched env steps (default 20; 128 = one rollout + update for ppo)")
     p.add_argument("--warmup", type=int, default=None,
@@ -68,7 +73,9 @@ def parse_args():
         # exhaustive search costs minutes of GPU time for ~-8 % throughput here
         args.cudnn_benchmark = False
     if args.num_envs is None:
-        args.num_envs = 512 if args.algo == "ppo" else 256
+        args.num_envs = {"ppo": 512, "sac": 64}.get(args.algo, 256)
+    if args.algo == "sac" and args.minibatch == 32:
+        args.minibatch = 256
     return args
 
 
@@ -159,11 +166,61 @@ def build_ppo(args, device, rank):
     return agent, env, None
 
 
+def build_sac(args, device, rank):
+    """BASELINE configs[4]: examples/mujoco/reproduction/soft_actor_critic/
+    train_soft_actor_critic.py:172-243 -- 256-256 MLP policy (squashed Gaussian) and twin Q,
+    Adam(3e-4), ReplayBuffer(10**6), B=256, update_interval=1, learned temperature;
+    Humanoid-shaped synthetic env (obs f32[376], action f32[17])."""
+    import pfrl_amd as pfrl
+    from pfrl_amd import agents, replay_buffers
+    from pfrl_amd.envs.synthetic import HostSyntheticVectorObsEnv
+    from torch import distributions as D
+
+    N, obs_size, action_size = args.num_envs, 376, 17
+
+    def squashed_diagonal_gaussian_head(x):
+        # tanh-squashed diagonal Gaussian, log-scale clamped to [-20, 2]
+        mean, log_scale = torch.chunk(x, 2, dim=1)
+        scale = torch.sqrt(torch.exp(torch.clamp(log_scale, -20.0, 2.0) * 2))
+        return D.transformed_distribution.TransformedDistribution(
+            D.Independent(D.Normal(loc=mean, scale=scale), 1),
+            [D.transforms.TanhTransform(cache_size=1)])
+    pfrl.utils.set_random_seed(args.seed * 64 + rank)
+    nn = torch.nn
+    policy = nn.Sequential(nn.Linear(obs_size, 256), nn.ReLU(), nn.Linear(256, 256), nn.ReLU(),
+                           nn.Linear(256, action_size * 2),
+                           pfrl.nn.Lambda(squashed_diagonal_gaussian_head))
+    for i in (0, 2, 4):
+        nn.init.xavier_uniform_(policy[i].weight)
+    popt = torch.optim.Adam(policy.parameters(), lr=3e-4)
+
+    def make_q():
+        q = nn.Sequential(pfrl.nn.ConcatObsAndAction(), nn.Linear(obs_size + action_size, 256),
+                          nn.ReLU(), nn.Linear(256, 256), nn.ReLU(), nn.Linear(256, 1))
+        for i in (1, 3, 5):
+            nn.init.xavier_uniform_(q[i].weight)
+        return q, torch.optim.Adam(q.parameters(), lr=3e-4)
+
+    q1, q1opt = make_q()
+    q2, q2opt = make_q()
+    env = HostSyntheticVectorObsEnv(N, obs_dim=obs_size, act_dim=action_size,
+                                    seed=args.seed * 64 + rank)
+    rbuf = replay_buffers.ReplayBuffer(args.capacity)
+    agent = agents.SoftActorCritic(
+        policy, q1, q2, popt, q1opt, q2opt, rbuf, gamma=0.99, gpu=device.index,
+        replay_start_size=10000, minibatch_size=args.minibatch, update_interval=1,
+        burnin_action_func=lambda: np.random.uniform(-1, 1, size=action_size).astype(np.float32),
+        entropy_target=-action_size, temperature_optimizer_lr=3e-4)
+    return agent, env, rbuf
+
+
 def build_agent(args, device, rank):
     if args.algo == "rainbow":
         return build_rainbow(args, device, rank)
     if args.algo == "ppo":
         return build_ppo(args, device, rank)
+    if args.algo == "sac":
+        return build_sac(args, device, rank)
     import pfrl_amd as pfrl
     from pfrl_amd import agents, explorers, replay_buffers
     from pfrl_amd.device_store import DeviceFrameStore
@@ -190,10 +247,16 @@ def build_agent(args, device, rank):
         torch.backends.cudnn.benchmark = True
     if args.channels_last:
         q_func = q_func.to(memory_format=torch.channels_last)
-    frame_slots = args.capacity + N * 16 + 8192
-    store = DeviceFrameStore(frame_slots, (84, 84), torch.uint8, device, stack=4)
-    env = SyntheticAtariVectorEnv(N, store=store, seed=args.seed, env_id0=rank * N,
-                                  n_actions=n_actions)
+    if args.host_env:
+        from pfrl_amd.envs.synthetic import HostSyntheticAtariVectorEnv
+
+        env = HostSyntheticAtariVectorEnv(N, seed=args.seed * 64 + rank, n_actions=n_actions,
+                                          frame_pool=4096)
+    else:
+        frame_slots = args.capacity + N * 16 + 8192
+        store = DeviceFrameStore(frame_slots, (84, 84), torch.uint8, device, stack=4)
+        env = SyntheticAtariVectorEnv(N, store=store, seed=args.seed, env_id0=rank * N,
+                                      n_actions=n_actions)
     rbuf = replay_buffers.ReplayBuffer(args.capacity, num_steps=1)
     explorer = explorers.LinearDecayEpsilonGreedy(
         1.0, 0.01, 10 ** 6, lambda: np.random.randint(n_actions))
@@ -216,15 +279,22 @@ def workload_description(args, N, rbuf):
         return ("BASELINE.json configs[1]: DQN Nature-CNN, %d synthetic Atari-shaped envs/GPU "
                 "(84x84x4 u8), ReplayBuffer(%d) on device prefilled to %d, B=%d, update_interval=%d "
                 "(replay ratio %.1f sampled transitions per env-step), RMSprop centered, "
-                "batch_accumulator=sum" % (N, args.capacity, len(rbuf), args.minibatch,
-                                           args.update_interval,
-                                           args.minibatch / args.update_interval))
+                "batch_accumulator=sum%s" % (N, args.capacity, len(rbuf), args.minibatch,
+                                             args.update_interval,
+                                             args.minibatch / args.update_interval,
+                                             "; HOST env: frames ingested over PCIe (not the "
+                                             "headline)" if args.host_env else ""))
     if args.algo == "rainbow":
         return ("BASELINE.json configs[2]: CategoricalDoubleDQN + DistributionalDuelingDQN(51 atoms) "
                 "+ NoisyNet, %d synthetic Atari-shaped envs/GPU, PrioritizedReplayBuffer(%d, "
                 "alpha=0.5, beta0=0.4, num_steps=3, normalize_by_max=memory) with sum/min trees in "
                 "HBM prefilled to %d, B=%d, update_interval=%d, Adam"
                 % (N, args.capacity, len(rbuf), args.minibatch, args.update_interval))
+    if args.algo == "sac":
+        return ("BASELINE.json configs[4]: SAC, %d MuJoCo-shaped synthetic envs/GPU (obs f32[376], "
+                "action f32[17]; host env, observations ingested over PCIe), ReplayBuffer(%d) fp32 "
+                "on device prefilled to %d, B=%d, update_interval=1 (one update per env-step), "
+                "256-256 MLPs, Adam" % (N, args.capacity, len(rbuf), args.minibatch))
     return ("BASELINE.json configs[3]: PPO, %d synthetic Atari-shaped envs/GPU x 128-step rollouts, "
             "update_interval=%d, minibatch=%d, 4 epochs, GAE + advantage standardisation kernels, "
             "Adam" % (N, N * 128, 32 * N))
@@ -340,7 +410,8 @@ def main():
     obss = env.reset()
     t_fill = time.perf_counter()
     if rbuf is not None:
-        target = args.prefill if args.prefill is not None else args.capacity
+        target = args.prefill if args.prefill is not None else (
+            10 ** 5 if args.algo == "sac" else args.capacity)
         target = max(min(target, args.capacity), 5 * 10 ** 4)
         obss = prefill(agent, env, obss, N, target)
     torch.cuda.synchronize()
@@ -352,7 +423,13 @@ def main():
 
     for _ in range(args.warmup):
         obss = one_step(agent, env, obss, N)
-    optim_before = agent.optim_t if hasattr(agent, "optim_t") else agent.n_updates
+    def updates_done():
+        for name in ("optim_t", "n_updates", "n_policy_updates"):
+            if hasattr(agent, name):
+                return getattr(agent, name)
+        return 0
+
+    optim_before = updates_done()
     ops.profile_enable(True)
     barrier()
     torch.cuda.synchronize()
@@ -363,30 +440,43 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     ops.profile_enable(False)
-    n_updates = (agent.optim_t if hasattr(agent, "optim_t") else agent.n_updates) - optim_before
+    n_updates = updates_done() - optim_before
 
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
-    # dominant HIP kernel: the fused batch_experiences gather
-    k_us, k_entries = ops.profile_collect()
+    # dominant HIP kernel of the path: the fused batch_experiences gather for the
+    # replay agents, the batch_states gather (value pass + minibatches) for PPO
+    all_us, all_units, all_kinds = ops.profile_collect(kind=None)
     k, fb = 4, 84 * 84
+    if args.algo == "ppo":
+        kind, kname, unit_name = ops.PROFILE_BATCH_STATES_U8, "k_batch_states_u8", "frames"
+        # per gathered frame: fb bytes read as u8, 4*fb written as f32
+        per_unit = fb + 4 * fb
+    elif args.algo == "sac":
+        kind, kname, unit_name = ops.PROFILE_BATCH_EXPERIENCES, "k_batch_experiences", "entries"
+        # per sampled entry: state + next_state f32[376] read and written, action f32[17]
+        # read and written, reward/terminal/discount
+        per_unit = 2 * (2 * 376 * 4) + 2 * 17 * 4 + 2 * 12
+    else:
+        kind, kname, unit_name = ops.PROFILE_BATCH_EXPERIENCES, "k_batch_experiences", "entries"
+        # per sampled entry: state + next_state, each k frames read as u8, written as f32
+        per_unit = 2 * k * (fb + 4 * fb)
+    k_us = [u for u, kd in zip(all_us, all_kinds) if kd == kind]
+    k_units = [n for n, kd in zip(all_units, all_kinds) if kd == kind]
     roofline = None
     if k_us:
-        # algorithmic bytes per sampled entry: state + next_state,
-        # each k frames read as u8 and written as f32
-        per_entry = 2 * k * (fb + 4 * fb)
-        tot_bytes = sum(per_entry * b for b in k_entries)
+        tot_bytes = sum(per_unit * b for b in k_units)
         tot_s = sum(k_us) * 1e-6
         achieved = tot_bytes / tot_s / 1e9
         roofline = {
-            "bound": "hbm", "kernel": "k_batch_experiences",
+            "bound": "hbm", "kernel": kname,
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
             "bytes_per_launch": int(tot_bytes / len(k_us)),
-            "entries_per_launch": int(np.mean(k_entries)),
+            "%s_per_launch" % unit_name: int(np.mean(k_units)),
             "avg_launch_us": round(tot_s / len(k_us) * 1e6, 2), "launches_timed": len(k_us),
             "timing": "hipEvent pair attached to each dispatch (hipExtLaunchKernelGGL) on the "
                       "launch stream, inside the timed region",
@@ -397,7 +487,7 @@ def main():
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_gather.json")))
             kk = pmc["kernels"]["k_batch_experiences<0,long> (2048 entries)"]
-            if roofline["entries_per_launch"] == 2048:
+            if args.algo == "dqn" and roofline["entries_per_launch"] == 2048:
                 roofline["traffic"] = kk["traffic_bytes_per_launch"]
                 roofline["traffic_source"] = "profiles/r01_pmc_gather.json (rocprofv3 --pmc " \
                                              "FETCH_SIZE / WRITE_SIZE, separate passes, corrected)"
@@ -412,7 +502,8 @@ def main():
             "value": round(value, 1), "unit": "env-steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic (host frames over PCIe)" if args.host_env else "synthetic",
             "config": {
                 "workload": workload_description(args, N, rbuf),
                 "global_envs": world * N, "updates_in_timed_region": n_updates,

@@ -277,11 +277,13 @@ int pfrl_bias_relu_bwd(const float *gy, const float *y, float *gx, float *gb, ui
 
 /* ------------------------------------------------------------------------
  * Measurement support (bench.py roofline): time every pfrl_batch_experiences
- * launch with a hipEvent pair attached to the dispatch, on its own stream.
- * pfrl_profile_collect synchronises, returns durations in microseconds and
- * the entry count of each timed launch. */
+ * (kind 0, units = sampled entries) and pfrl_batch_states_u8 (kind 1, units =
+ * frame refs) launch with a hipEvent pair attached to the dispatch, on its own
+ * stream.  pfrl_profile_collect synchronises, returns durations in
+ * microseconds, the unit count and the kind of each timed launch. */
 int pfrl_profile_enable(int on);
-int64_t pfrl_profile_collect(double *host_out_us, int64_t *host_out_entries, int64_t cap);
+int64_t pfrl_profile_collect(double *host_out_us, int64_t *host_out_units, int32_t *host_out_kind,
+                             int64_t cap);
 
 #ifdef __cplusplus
 }

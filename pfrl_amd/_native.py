@@ -119,7 +119,7 @@ EXPORTS = {
     "pfrl_bias_relu_fwd": (ctypes.c_int, "pppqip"),
     "pfrl_bias_relu_bwd": (ctypes.c_int, "ppppppqiip"),
     "pfrl_profile_enable": (ctypes.c_int, "i"),
-    "pfrl_profile_collect": (ctypes.c_int64, "ppq"),
+    "pfrl_profile_collect": (ctypes.c_int64, "pppq"),
 }
 
 _CODES = {

@@ -7,6 +7,8 @@
 // workgroup per output frame; each lane loads dwords strided by the workgroup
 // (256 B per wave instruction) and stores one float4 per dword, so every store
 // instruction of a wave covers 1 KiB of contiguous HBM.
+#include <hip/hip_ext.h>
+
 #include "common.h"
 
 static char g_err[512] = "";
@@ -165,20 +167,22 @@ extern "C" int pfrl_batch_states_u8(const void *frames, int64_t frame_bytes, con
     const dim3 grid((unsigned)n_refs), block(kThreads);
     hipStream_t st = (hipStream_t)stream;
     const uint8_t *fr = (const uint8_t *)frames;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    pfrl_profile_events(PFRL_PROFILE_BATCH_STATES_U8, n_refs, &e0, &e1);
     if (divisor == 1.0f) {
         if (nt)
-            hipLaunchKernelGGL((k_batch_states_u8<false, true>), grid, block, 0, st, fr,
-                               frame_bytes, refs, divisor, out);
+            hipExtLaunchKernelGGL((k_batch_states_u8<false, true>), grid, block, 0, st, e0, e1, 0,
+                                  fr, frame_bytes, refs, divisor, out);
         else
-            hipLaunchKernelGGL((k_batch_states_u8<false, false>), grid, block, 0, st, fr,
-                               frame_bytes, refs, divisor, out);
+            hipExtLaunchKernelGGL((k_batch_states_u8<false, false>), grid, block, 0, st, e0, e1, 0,
+                                  fr, frame_bytes, refs, divisor, out);
     } else {
         if (nt)
-            hipLaunchKernelGGL((k_batch_states_u8<true, true>), grid, block, 0, st, fr,
-                               frame_bytes, refs, divisor, out);
+            hipExtLaunchKernelGGL((k_batch_states_u8<true, true>), grid, block, 0, st, e0, e1, 0,
+                                  fr, frame_bytes, refs, divisor, out);
         else
-            hipLaunchKernelGGL((k_batch_states_u8<true, false>), grid, block, 0, st, fr,
-                               frame_bytes, refs, divisor, out);
+            hipExtLaunchKernelGGL((k_batch_states_u8<true, false>), grid, block, 0, st, e0, e1, 0,
+                                  fr, frame_bytes, refs, divisor, out);
     }
     PFRL_LAUNCH_CHECK();
 }

@@ -23,7 +23,8 @@ constexpr int kUnroll = 8;
 // stream it runs on -- what bench.py reports as roofline.avg_launch_us.
 struct TimedLaunch {
     hipEvent_t start, stop;
-    int64_t entries;
+    int64_t units;
+    int32_t kind;
 };
 bool g_profile = false;
 std::vector<TimedLaunch> g_timed;
@@ -221,11 +222,7 @@ static void launch_be2(const pfrl_table_t *tab, const void *frames, int64_t fram
                        hipStream_t stream) {
     const unsigned blocks = (unsigned)(2 * B * tab->k + (B + kThreads - 1) / kThreads);
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (g_profile) {
-        (void)hipEventCreate(&e0);
-        (void)hipEventCreate(&e1);
-        g_timed.push_back({e0, e1, B});
-    }
+    pfrl_profile_events(PFRL_PROFILE_BATCH_EXPERIENCES, B, &e0, &e1);
     if (tab->act_dim > 0)
         hipExtLaunchKernelGGL((k_batch_experiences<MODE, float, NT>), dim3(blocks), dim3(kThreads),
                               0, stream, e0, e1, 0, *tab, (const uint8_t *)frames, frame_bytes,
@@ -282,21 +279,35 @@ extern "C" int pfrl_batch_experiences(const pfrl_table_t *tab, const void *frame
     PFRL_LAUNCH_CHECK();
 }
 
+// Shared with frames.hip (declared in common.h): hands out an event pair for one
+// dispatch when profiling is on, nullptrs otherwise.
+void pfrl_profile_events(int kind, int64_t units, hipEvent_t *start, hipEvent_t *stop) {
+    *start = *stop = nullptr;
+    if (!g_profile) return;
+    if (hipEventCreate(start) != hipSuccess || hipEventCreate(stop) != hipSuccess) {
+        *start = *stop = nullptr;
+        return;
+    }
+    g_timed.push_back({*start, *stop, units, (int32_t)kind});
+}
+
 extern "C" int pfrl_profile_enable(int on) {
     g_profile = on != 0;
     return 0;
 }
 
 // Waits for the timed launches, writes their durations (microseconds) and entry
-// counts, frees the events.  Returns the number of launches written.
-extern "C" int64_t pfrl_profile_collect(double *out_us, int64_t *out_entries, int64_t cap) {
+// counts and kinds, frees the events.  Returns the number of launches written.
+extern "C" int64_t pfrl_profile_collect(double *out_us, int64_t *out_units, int32_t *out_kind,
+                                        int64_t cap) {
     int64_t n = 0;
     for (auto &t : g_timed) {
         (void)hipEventSynchronize(t.stop);
         float ms = 0.0f;
         if (hipEventElapsedTime(&ms, t.start, t.stop) == hipSuccess && n < cap) {
             out_us[n] = (double)ms * 1e3;
-            out_entries[n] = t.entries;
+            out_units[n] = t.units;
+            out_kind[n] = t.kind;
             ++n;
         }
         (void)hipEventDestroy(t.start);

@@ -147,10 +147,16 @@ class HostSyntheticAtariVectorEnv(_env.VectorEnv):
     host numpy arrays from per-env RandomState (SURVEY.md 8d CPU baseline)."""
 
     def __init__(self, num_envs, seed=0, stack=4, frame_shape=(84, 84), n_actions=6,
-                 p_done=1.0 / 500):
+                 p_done=1.0 / 500, frame_pool=None):
         self.num_envs = num_envs
         self.stack = stack
         self.frame_shape = (1,) + tuple(frame_shape)
+        # frame_pool=P: frames are fresh copies out of P pre-drawn random frames, so
+        # that a benchmark measures ingest, not numpy's generator (env cost ~ 0)
+        self._pool = None
+        if frame_pool:
+            self._pool = np.random.RandomState(seed).randint(
+                0, 256, size=(int(frame_pool),) + self.frame_shape).astype(np.uint8)
         self.n_actions = n_actions
         self.p_done = p_done
         self.seed_value = seed
@@ -167,6 +173,8 @@ class HostSyntheticAtariVectorEnv(_env.VectorEnv):
         pass
 
     def _frame(self, i):
+        if self._pool is not None:
+            return self._pool[(i * 7919 + self.t * 104729) % len(self._pool)].copy()
         return self.rs[i].randint(0, 256, size=self.frame_shape).astype(np.uint8)
 
     def reset(self, mask=None):

@@ -89,12 +89,21 @@ def profile_enable(on):
     check(_native.lib().pfrl_profile_enable(int(bool(on))), "profile_enable")
 
 
-def profile_collect(cap=4096):
-    """-> (durations_us, entries) of the launches timed since profile_enable(True)."""
+PROFILE_BATCH_EXPERIENCES = 0
+PROFILE_BATCH_STATES_U8 = 1
+
+
+def profile_collect(kind=PROFILE_BATCH_EXPERIENCES, cap=1 << 16):
+    """-> (durations_us, units) of the launches of ``kind`` timed since
+    profile_enable(True); kind=None returns (durations_us, units, kinds) of all."""
     us = (ctypes.c_double * cap)()
     ent = (ctypes.c_int64 * cap)()
-    n = _native.lib().pfrl_profile_collect(us, ent, cap)
-    return list(us[:n]), list(ent[:n])
+    kinds = (ctypes.c_int32 * cap)()
+    n = _native.lib().pfrl_profile_collect(us, ent, kinds, cap)
+    if kind is None:
+        return list(us[:n]), list(ent[:n]), list(kinds[:n])
+    sel = [i for i in range(n) if kinds[i] == kind]
+    return [us[i] for i in sel], [ent[i] for i in sel]
 
 
 def batch_experiences(desc, frames, divisor, entry_slots, gamma_pow, out):
