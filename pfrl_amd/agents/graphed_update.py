@@ -177,3 +177,91 @@ class GraphedUpdate:
             self.agent.grad_reducer.all_reduce()
             gs[1].replay()
         return entry["loss"], entry["delta"], entry["y"]
+
+
+class CapturedStep:
+    """HIP-graph capture of an arbitrary training step ``fn(batch) -> dict of
+    tensors`` that touches several modules / optimizers (SAC: two Q updates, the
+    policy update, the temperature update and the soft target sync).
+
+    Same contract as :class:`GraphedUpdate`: one graph per set of minibatch
+    buffer addresses, warm-up on a snapshot that is restored (parameters,
+    buffers, optimizer state, RNG), stock optimizers switched to their
+    capturable code path.  The returned tensors are owned by the graph.
+    """
+
+    def __init__(self, fn, modules, optimizers, device, max_graphs=64):
+        self.fn = fn
+        self.modules = [m for m in modules if m is not None]
+        self.optimizers = [o for o in optimizers if o is not None]
+        self.device = device
+        self.graphs = {}
+        self.pool = None
+        self.max_graphs = max_graphs
+
+    @staticmethod
+    def _key(batch):
+        return tuple(sorted((k, v.data_ptr(), tuple(v.shape)) for k, v in batch.items()
+                            if isinstance(v, torch.Tensor)))
+
+    def _tensors(self):
+        out = []
+        for m in self.modules:
+            out.extend(p for p in m.parameters())
+            out.extend(b for b in m.buffers())
+        return out
+
+    def _capture(self, batch):
+        dev = self.device
+        for opt in self.optimizers:
+            if not _make_capturable(opt, dev):
+                raise RuntimeError("optimizer %s has no capturable mode" % type(opt))
+        saved = [t.detach().clone() for t in self._tensors()]
+        had_state = [len(o.state) > 0 for o in self.optimizers]
+        opt_saved = [[(st, k, v.detach().clone()) for st, k, v in _optimizer_tensors(o)]
+                     for o in self.optimizers]
+        rng = torch.cuda.get_rng_state(dev)
+        try:
+            torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
+        except AttributeError:
+            pass
+        cur = torch.cuda.current_stream(dev)
+        side = torch.cuda.Stream(dev)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                self.fn(batch)
+        cur.wait_stream(side)
+        for opt in self.optimizers:
+            _make_capturable(opt, dev)  # state created by the warm-up
+            opt.zero_grad(set_to_none=True)
+        g = torch.cuda.CUDAGraph()
+        kw = {} if self.pool is None else {"pool": self.pool}
+        with torch.cuda.graph(g, **kw):
+            out = self.fn(batch)
+        if self.pool is None:
+            self.pool = g.pool()
+        # undo the warm-up steps
+        with torch.no_grad():
+            for t, s in zip(self._tensors(), saved):
+                t.copy_(s)
+            for o, had, sv in zip(self.optimizers, had_state, opt_saved):
+                if had:
+                    for st, k, v in sv:
+                        st[k].copy_(v)
+                else:
+                    for st, k, v in _optimizer_tensors(o):
+                        v.zero_()
+        torch.cuda.set_rng_state(rng, dev)
+        return g, out
+
+    def run(self, batch):
+        key = self._key(batch)
+        entry = self.graphs.get(key)
+        if entry is None:
+            if len(self.graphs) >= self.max_graphs:
+                raise RuntimeError("too many distinct minibatch buffers for graph capture")
+            entry = self._capture(batch)
+            self.graphs[key] = entry
+        entry[0].replay()
+        return entry[1]

@@ -377,7 +377,7 @@ class _NoNoise:
         D.Normal.rsample, D.Normal.sample = self.saved
 
 
-def _run_sac(gpu):
+def _run_sac(gpu, **agent_kw):
     import pfrl_amd as pfrl
     from pfrl_amd import agents, replay_buffers
     from pfrl_amd.envs.synthetic import HostSyntheticVectorObsEnv
@@ -401,7 +401,7 @@ def _run_sac(gpu):
         policy, q1, q2, opts[0], opts[1], opts[2], rbuf, gamma=0.99, gpu=gpu,
         replay_start_size=40, minibatch_size=16, update_interval=1,
         burnin_action_func=lambda: np.random.uniform(-1, 1, size=act_dim).astype(np.float32),
-        entropy_target=None, initial_temperature=0.2, soft_update_tau=5e-3)
+        entropy_target=None, initial_temperature=0.2, soft_update_tau=5e-3, **agent_kw)
     actions, q_losses = [], []
     orig_act = ag.batch_act
 
@@ -424,7 +424,7 @@ def _run_sac(gpu):
     flat = lambda m: np.concatenate([p.detach().cpu().numpy().ravel() for p in m.parameters()])
     return dict(actions=np.asarray(actions), q_losses=np.asarray(q_losses),
                 policy_params=flat(policy), q1_params=flat(q1),
-                target_q1_params=flat(ag.target_q_func1), rbuf=rbuf)
+                target_q1_params=flat(ag.target_q_func1), rbuf=rbuf, agent=ag)
 
 
 def _compare_sac(got, g):
@@ -444,6 +444,17 @@ def test_sac_host_mode_matches_reference():
 def test_sac_device_replay_matches_reference():
     """config 5 data path: float32 vector observations / actions in the HBM
     replay store, fused gather as plain f32 copies."""
+    got = _run_sac(0, use_graphs=False)
+    assert got["rbuf"].is_device and got["agent"]._captured is None
+    _compare_sac(got, np.load(os.path.join(GOLDEN, "agent_trace_sac.npz")))
+
+
+@pytest.mark.gpu
+def test_sac_graph_captured_update_matches_reference():
+    """Default on the GPU: the whole SAC update (Q1, Q2, policy, soft target sync)
+    replays as one HIP graph; same trace as the reference."""
     got = _run_sac(0)
-    assert got["rbuf"].is_device
+    ag = got["agent"]
+    assert ag.use_graphs and ag._captured is not None and len(ag._captured.graphs) >= 1
+    assert ag.n_policy_updates == len(got["q_losses"])
     _compare_sac(got, np.load(os.path.join(GOLDEN, "agent_trace_sac.npz")))
