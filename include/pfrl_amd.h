@@ -276,6 +276,22 @@ int pfrl_bias_relu_bwd(const float *gy, const float *y, float *gx, float *gb, ui
                        uint64_t *counters, int64_t rows, int32_t C, int32_t blocks, void *stream);
 
 /* ------------------------------------------------------------------------
+ * Factorised NoisyNet weights (pfrl/nn/noisy_linear.py:52-70: `_eps` shaping,
+ * `torch.ger`, two `torch.addcmul`), forward and backward in one launch each.
+ *   r            f32 [in + out] unit Gaussians: r[0:in] -> eps_x, r[in:] -> eps_y
+ *   f(x)         sign(x) * sqrt(|x|)
+ *   w_out[o][i]  mu_w + sigma_w * (f(r[in+o]) * f(r[i]));  b_out[o] = mu_b + sigma_b * f(r[in+o])
+ *   g_sigma_w    g_w * (f(r[in+o]) * f(r[i]));             g_sigma_b = g_b * f(r[in+o])
+ * (the gradients of mu_w / mu_b are g_w / g_b themselves).  mu_b, sigma_b, b_out
+ * (and g_b, g_sigma_b) may be NULL for layers without bias.  Row-major, dense. */
+int pfrl_noisy_weights_fwd(const float *mu_w, const float *sigma_w, const float *mu_b,
+                           const float *sigma_b, const float *r, float *w_out, float *b_out,
+                           int64_t out_features, int64_t in_features, void *stream);
+int pfrl_noisy_weights_bwd(const float *g_w, const float *g_b, const float *r, float *g_sigma_w,
+                           float *g_sigma_b, int64_t out_features, int64_t in_features,
+                           void *stream);
+
+/* ------------------------------------------------------------------------
  * Measurement support (bench.py roofline): time every pfrl_batch_experiences
  * (kind 0, units = sampled entries) and pfrl_batch_states_u8 (kind 1, units =
  * frame refs) launch with a hipEvent pair attached to the dispatch, on its own

@@ -54,6 +54,18 @@ class FactorizedNoisyLinear(nn.Module):
 
     def forward(self, x):
         out_features, in_features = self.sigma.weight.shape
+        sw = self.sigma.weight
+        if sw.is_cuda:
+            from pfrl_amd import ops
+
+            if ops.noisy_weights_supported(sw) and self.mu.weight.is_contiguous():
+                # same draw as below (one normal_ of in + out values); shaping, outer
+                # product and both addcmul fused into one launch (and one for backward)
+                r = torch.randn(in_features + out_features, dtype=sw.dtype, device=sw.device)
+                weight, bias = ops.noisy_weights(
+                    self.mu.weight, sw, self.mu.bias if self.hasbias else None,
+                    self.sigma.bias if self.hasbias else None, r)
+                return F.linear(x, weight, bias)
         noise = _shaped_noise(in_features + out_features, self.sigma.weight)
         eps_in, eps_out = noise[:in_features], noise[in_features:]
         weight = torch.addcmul(self.mu.weight, self.sigma.weight, torch.outer(eps_out, eps_in))

@@ -316,3 +316,51 @@ def bias_relu_supported(x, bias):
 
 def bias_relu(x, bias):
     return _BiasReLU.apply(x, bias)
+
+
+class _NoisyWeights(torch.autograd.Function):
+    """(W, b) of a factorised noisy layer from (mu, sigma, r) in one launch;
+    b is None for layers without bias."""
+
+    @staticmethod
+    def forward(ctx, mu_w, sigma_w, mu_b, sigma_b, r):
+        out_f, in_f = sigma_w.shape
+        w = torch.empty((out_f, in_f), dtype=torch.float32, device=sigma_w.device)
+        hasbias = mu_b is not None
+        b = torch.empty(out_f, dtype=torch.float32, device=sigma_w.device) if hasbias else None
+        check(_native.lib().pfrl_noisy_weights_fwd(
+            _ptr(mu_w), _ptr(sigma_w), _ptr(mu_b) if hasbias else None,
+            _ptr(sigma_b) if hasbias else None, _ptr(r), _ptr(w), _ptr(b) if hasbias else None,
+            out_f, in_f, _stream()), "noisy_weights_fwd")
+        ctx.save_for_backward(r)
+        ctx.shape = (out_f, in_f)
+        ctx.hasbias = hasbias
+        ctx.set_materialize_grads(False)
+        return w, b
+
+    @staticmethod
+    def backward(ctx, g_w, g_b):
+        (r,) = ctx.saved_tensors
+        out_f, in_f = ctx.shape
+        if g_w is None:
+            g_w = torch.zeros((out_f, in_f), dtype=torch.float32, device=r.device)
+        g_w = g_w.contiguous()
+        want_b = ctx.hasbias and g_b is not None
+        if want_b:
+            g_b = g_b.contiguous()
+        g_sw = torch.empty_like(g_w)
+        g_sb = torch.empty_like(g_b) if want_b else None
+        check(_native.lib().pfrl_noisy_weights_bwd(
+            _ptr(g_w), _ptr(g_b) if want_b else None, _ptr(r), _ptr(g_sw),
+            _ptr(g_sb) if want_b else None, out_f, in_f, _stream()), "noisy_weights_bwd")
+        return g_w, g_sw, (g_b if want_b else None), g_sb, None
+
+
+def noisy_weights_supported(sigma_w):
+    return sigma_w.is_cuda and sigma_w.dtype == torch.float32 and sigma_w.is_contiguous()
+
+
+def noisy_weights(mu_w, sigma_w, mu_b, sigma_b, r):
+    """Perturbed (weight, bias) of a FactorizedNoisyLinear; ``r`` = in + out unit
+    Gaussians in the reference's order (eps_x first)."""
+    return _NoisyWeights.apply(mu_w, sigma_w, mu_b, sigma_b, r)

@@ -711,3 +711,63 @@ def test_atari_cnn_fused_path_matches_plain(dev):
     for pa, pb in zip(a.parameters(), b.parameters()):
         np.testing.assert_allclose(pa.grad.cpu().numpy(), pb.grad.cpu().numpy(), rtol=1e-3,
                                    atol=1e-3)
+
+
+# ---------------------------------------------------------------------------
+# factorised NoisyNet weights
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("out_f,in_f,bias", [(1024, 3136, True), (306, 512, True), (51, 512, True),
+                                             (7, 13, True), (16, 24, False)])
+def test_noisy_weights_forward_backward(dev, out_f, in_f, bias):
+    """pfrl/nn/noisy_linear.py:52-70 as a torch composite (fp32) vs the fused launches."""
+    torch.manual_seed(out_f * 7 + in_f)
+    mk = lambda *s: torch.randn(*s, device=dev).requires_grad_(True)
+    mu_w, sg_w = mk(out_f, in_f), mk(out_f, in_f)
+    mu_b, sg_b = (mk(out_f), mk(out_f)) if bias else (None, None)
+    r = torch.randn(in_f + out_f, device=dev)
+    r[3] = 0.0   # sign(0) = 0
+    leaves = [t for t in (mu_w, sg_w, mu_b, sg_b) if t is not None]
+    eps = torch.abs(torch.sqrt(torch.abs(r))) * torch.sign(r)
+    ex, ey = eps[:in_f], eps[in_f:]
+    w_ref = torch.addcmul(mu_w, sg_w, torch.ger(ey, ex))
+    b_ref = torch.addcmul(mu_b, sg_b, ey) if bias else None
+    gw = torch.randn(out_f, in_f, device=dev)
+    gb = torch.randn(out_f, device=dev) if bias else None
+    outs = [w_ref] + ([b_ref] if bias else [])
+    gref = torch.autograd.grad(outs, leaves, [gw] + ([gb] if bias else []))
+    w, b = ops.noisy_weights(mu_w, sg_w, mu_b, sg_b, r)
+    assert (b is None) == (not bias)
+    np.testing.assert_allclose(w.detach().cpu().numpy(), w_ref.detach().cpu().numpy(), rtol=2e-6,
+                               atol=1e-6)
+    if bias:
+        np.testing.assert_allclose(b.detach().cpu().numpy(), b_ref.detach().cpu().numpy(),
+                                   rtol=2e-6, atol=1e-6)
+    got = torch.autograd.grad([w] + ([b] if bias else []), leaves, [gw] + ([gb] if bias else []))
+    for a, e in zip(got, gref):
+        np.testing.assert_allclose(a.cpu().numpy(), e.cpu().numpy(), rtol=2e-6, atol=1e-6)
+
+
+def test_noisy_linear_module_uses_fused_path(dev):
+    """Same generator state -> the module's fused path equals the composite path."""
+    from pfrl_amd.nn import noisy_linear as nl
+
+    torch.manual_seed(3)
+    layer = nl.FactorizedNoisyLinear(torch.nn.Linear(64, 20), sigma_scale=0.5).to(dev)
+    x = torch.randn(9, 64, device=dev)
+    torch.manual_seed(11)
+    y = layer(x)
+    y.sum().backward()
+    g_fused = [p.grad.clone() for p in layer.parameters()]
+    layer.zero_grad()
+    torch.manual_seed(11)
+    saved = ops.noisy_weights_supported
+    ops.noisy_weights_supported = lambda *_: False
+    try:
+        y2 = layer(x)
+    finally:
+        ops.noisy_weights_supported = saved
+    y2.sum().backward()
+    np.testing.assert_allclose(y.detach().cpu().numpy(), y2.detach().cpu().numpy(), rtol=1e-5,
+                               atol=1e-5)
+    for a, p in zip(g_fused, layer.parameters()):
+        np.testing.assert_allclose(a.cpu().numpy(), p.grad.cpu().numpy(), rtol=1e-5, atol=1e-5)
