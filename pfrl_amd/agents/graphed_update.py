@@ -179,6 +179,24 @@ class GraphedUpdate:
         return entry["loss"], entry["delta"], entry["y"]
 
 
+class _no_distribution_validation:
+    """torch.distributions validates constructor arguments and samples with a
+    blocking ``bool(tensor)``: a D2H sync per distribution, and illegal while a
+    stream is capturing.  Inside a captured step the check is switched off (it
+    can only ever raise, never change a result)."""
+
+    def __enter__(self):
+        from torch.distributions import Distribution
+
+        self.saved = Distribution._validate_args
+        Distribution.set_default_validate_args(False)
+
+    def __exit__(self, *exc):
+        from torch.distributions import Distribution
+
+        Distribution.set_default_validate_args(self.saved)
+
+
 class CapturedStep:
     """HIP-graph capture of an arbitrary training step ``fn(batch) -> dict of
     tensors`` that touches several modules / optimizers (SAC: two Q updates, the
@@ -225,34 +243,41 @@ class CapturedStep:
             torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
         except AttributeError:
             pass
+
+        def restore():
+            # undo the warm-up steps (also when the capture itself fails)
+            with torch.no_grad():
+                for t, s in zip(self._tensors(), saved):
+                    t.copy_(s)
+                for o, had, sv in zip(self.optimizers, had_state, opt_saved):
+                    if had:
+                        for st, k, v in sv:
+                            st[k].copy_(v)
+                    else:
+                        for st, k, v in _optimizer_tensors(o):
+                            v.zero_()
+            torch.cuda.set_rng_state(rng, dev)
+
         cur = torch.cuda.current_stream(dev)
         side = torch.cuda.Stream(dev)
         side.wait_stream(cur)
-        with torch.cuda.stream(side):
-            for _ in range(2):
-                self.fn(batch)
-        cur.wait_stream(side)
-        for opt in self.optimizers:
-            _make_capturable(opt, dev)  # state created by the warm-up
-            opt.zero_grad(set_to_none=True)
-        g = torch.cuda.CUDAGraph()
-        kw = {} if self.pool is None else {"pool": self.pool}
-        with torch.cuda.graph(g, **kw):
-            out = self.fn(batch)
-        if self.pool is None:
-            self.pool = g.pool()
-        # undo the warm-up steps
-        with torch.no_grad():
-            for t, s in zip(self._tensors(), saved):
-                t.copy_(s)
-            for o, had, sv in zip(self.optimizers, had_state, opt_saved):
-                if had:
-                    for st, k, v in sv:
-                        st[k].copy_(v)
-                else:
-                    for st, k, v in _optimizer_tensors(o):
-                        v.zero_()
-        torch.cuda.set_rng_state(rng, dev)
+        try:
+            with torch.cuda.stream(side), _no_distribution_validation():
+                for _ in range(2):
+                    self.fn(batch)
+            cur.wait_stream(side)
+            for opt in self.optimizers:
+                _make_capturable(opt, dev)  # state created by the warm-up
+                opt.zero_grad(set_to_none=True)
+            g = torch.cuda.CUDAGraph()
+            kw = {} if self.pool is None else {"pool": self.pool}
+            with torch.cuda.graph(g, **kw), _no_distribution_validation():
+                out = self.fn(batch)
+            if self.pool is None:
+                self.pool = g.pool()
+        finally:
+            cur.wait_stream(side)
+            restore()
         return g, out
 
     def run(self, batch):

@@ -720,6 +720,8 @@ def test_atari_cnn_fused_path_matches_plain(dev):
                                              (7, 13, True), (16, 24, False)])
 def test_noisy_weights_forward_backward(dev, out_f, in_f, bias):
     """pfrl/nn/noisy_linear.py:52-70 as a torch composite (fp32) vs the fused launches."""
+    from pfrl_amd import ops
+
     torch.manual_seed(out_f * 7 + in_f)
     mk = lambda *s: torch.randn(*s, device=dev).requires_grad_(True)
     mu_w, sg_w = mk(out_f, in_f), mk(out_f, in_f)
@@ -749,6 +751,7 @@ def test_noisy_weights_forward_backward(dev, out_f, in_f, bias):
 
 def test_noisy_linear_module_uses_fused_path(dev):
     """Same generator state -> the module's fused path equals the composite path."""
+    from pfrl_amd import ops
     from pfrl_amd.nn import noisy_linear as nl
 
     torch.manual_seed(3)
