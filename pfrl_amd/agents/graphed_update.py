@@ -183,18 +183,34 @@ class _no_distribution_validation:
     """torch.distributions validates constructor arguments and samples with a
     blocking ``bool(tensor)``: a D2H sync per distribution, and illegal while a
     stream is capturing.  Inside a captured step the check is switched off (it
-    can only ever raise, never change a result)."""
+    can only ever raise, never change a result).
+
+    ``Normal.sample`` is ``torch.normal(loc, scale)``, which checks ``scale.min()
+    >= 0`` on the host; ATen then computes ``normal_(0, 1) * scale + loc``.  The
+    stand-in below draws the same ``normal_`` and applies the same two roundings
+    without the host check."""
 
     def __enter__(self):
-        from torch.distributions import Distribution
+        from torch.distributions import Distribution, Normal
+        from torch.distributions.utils import _standard_normal
 
-        self.saved = Distribution._validate_args
+        self.saved = (Distribution._validate_args, Normal.sample)
         Distribution.set_default_validate_args(False)
 
-    def __exit__(self, *exc):
-        from torch.distributions import Distribution
+        def sample(dist, sample_shape=torch.Size()):
+            shape = dist._extended_shape(sample_shape)
+            with torch.no_grad():
+                eps = _standard_normal(shape, dtype=dist.loc.dtype, device=dist.loc.device)
+                return eps * dist.scale.expand(shape) + dist.loc.expand(shape)
 
-        Distribution.set_default_validate_args(self.saved)
+        if Normal.sample.__module__ == "torch.distributions.normal":
+            Normal.sample = sample   # leave a test's own stand-in alone
+
+    def __exit__(self, *exc):
+        from torch.distributions import Distribution, Normal
+
+        Distribution.set_default_validate_args(self.saved[0])
+        Normal.sample = self.saved[1]
 
 
 class CapturedStep:

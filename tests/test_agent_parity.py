@@ -377,7 +377,7 @@ class _NoNoise:
         D.Normal.rsample, D.Normal.sample = self.saved
 
 
-def _run_sac(gpu, **agent_kw):
+def _run_sac(gpu, noise=False, **agent_kw):
     import pfrl_amd as pfrl
     from pfrl_amd import agents, replay_buffers
     from pfrl_amd.envs.synthetic import HostSyntheticVectorObsEnv
@@ -419,7 +419,9 @@ def _run_sac(gpu, **agent_kw):
                          float(ag.q_func2_loss_record.values()[-1])])
 
     ag.replay_updater.update_func = spy_update
-    with _NoNoise():
+    import contextlib
+
+    with (contextlib.nullcontext() if noise else _NoNoise()):
         pfrl.experiments.train_agent_batch(ag, env, 240, tempfile.mkdtemp())
     flat = lambda m: np.concatenate([p.detach().cpu().numpy().ravel() for p in m.parameters()])
     return dict(actions=np.asarray(actions), q_losses=np.asarray(q_losses),
@@ -458,3 +460,16 @@ def test_sac_graph_captured_update_matches_reference():
     assert ag.use_graphs and ag._captured is not None and len(ag._captured.graphs) >= 1
     assert ag.n_policy_updates == len(got["q_losses"])
     _compare_sac(got, np.load(os.path.join(GOLDEN, "agent_trace_sac.npz")))
+
+
+@pytest.mark.gpu
+def test_sac_graph_replay_equals_eager_with_sampling_noise():
+    """With the policy's sampling noise ON (device Philox stream): the captured
+    update consumes the generator exactly like the eager one."""
+    eager = _run_sac(0, noise=True, use_graphs=False)
+    graph = _run_sac(0, noise=True)
+    assert graph["agent"]._captured is not None and graph["agent"].use_graphs
+    np.testing.assert_allclose(graph["actions"], eager["actions"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(graph["q_losses"], eager["q_losses"], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(graph["policy_params"], eager["policy_params"], rtol=1e-4,
+                               atol=1e-6)
