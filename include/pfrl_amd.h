@@ -276,6 +276,27 @@ int pfrl_bias_relu_bwd(const float *gy, const float *y, float *gx, float *gb, ui
                        uint64_t *counters, int64_t rows, int32_t C, int32_t blocks, void *stream);
 
 /* ------------------------------------------------------------------------
+ * Categorical (C51) DQN loss in one launch: replaces
+ *   pfrl/agents/categorical_dqn.py:7-57   _apply_categorical_projection
+ *   pfrl/agents/categorical_dqn.py:60-104 compute_(weighted_)value_loss
+ *   pfrl/agents/categorical_dqn.py:150-204 _compute_target_values / _compute_y_and_t / _compute_loss
+ *   pfrl/agents/categorical_double_dqn.py:10-52 (next_select = online net at s')
+ *   pfrl/action_value.py:97-180 greedy_actions / evaluate_actions(_as_distribution)
+ * q_dist, next_dist, next_select: f32 [B][A][Z] probabilities (next_select NULL =
+ * next_dist, i.e. plain CategoricalDQN); z_values f32 [Z] evenly spaced, Z <= 64.
+ *   g        = first argmax_a sum_z next_select[b][a][z] * z_values[z]
+ *   Tz[j]    = reward[b] + ((1 - terminal[b]) * discount[b]) * z_values[j], clamped
+ *   t[b][.]  = projection of next_dist[b][g][.] carried by Tz onto z_values
+ *   delta[b] = sum_z -t[b][z] * log(clamp(q_dist[b][action[b]][z], 1e-10, 1))
+ *   loss     = sum_b w[b] * delta[b]  (w = 1 if weights NULL; / B if mean)
+ *   out_grad_q [B][A][Z] = d loss / d q_dist;  out_q[b] = sum_z q_dist[b][a_b][z] z_values[z] */
+int pfrl_c51_loss(const float *q_dist, const int64_t *action, const float *next_dist,
+                  const float *next_select, const float *z_values, const float *reward,
+                  const float *discount, const float *terminal, const float *weights, int32_t B,
+                  int32_t A, int32_t Z, int32_t mean, float *out_loss, float *out_grad_q,
+                  float *out_q, float *out_delta, void *stream);
+
+/* ------------------------------------------------------------------------
  * Factorised NoisyNet weights (pfrl/nn/noisy_linear.py:52-70: `_eps` shaping,
  * `torch.ger`, two `torch.addcmul`), forward and backward in one launch each.
  *   r            f32 [in + out] unit Gaussians: r[0:in] -> eps_x, r[in:] -> eps_y

@@ -2,10 +2,12 @@
 
 Mirrors ``pfrl.agents.categorical_dqn`` (/root/reference/pfrl/agents/
 categorical_dqn.py: projection :7-57, losses :60-104, agent :107-204) and
-``categorical_double_dqn.py`` (:7-52).  The categorical projection, the
-cross-entropy loss and the per-sample KL priorities stay stock PyTorch on the
-device; they plug into the same device replay path as DQN (fused gather,
-HIP-graph update, PER priorities handed over as a device tensor).
+``categorical_double_dqn.py`` (:7-52).  On the GPU the categorical projection, the
+cross-entropy loss, its gradient and the per-sample KL priorities are one HIP
+launch (``pfrl_c51_loss``); the stock-PyTorch composite below is the CPU path and
+the path of subclasses that override the target computation.  Both plug into
+the same device replay path as DQN (fused gather, HIP-graph update, PER
+priorities handed over as a device tensor).
 """
 import torch
 
@@ -55,6 +57,7 @@ class CategoricalDQN(dqn.DQN):
     ignored (reference :107-113)."""
 
     _fused_td_double = None   # cross-entropy on distributions: not the scalar TD loss
+    _c51_double = False       # greedy next action: target net (False) / online net (True)
 
     def _project(self, exp_batch, next_dist, z_values):
         Tz = (exp_batch["reward"][..., None]
@@ -76,7 +79,50 @@ class CategoricalDQN(dqn.DQN):
             self._q_scalars = qout.evaluate_actions(batch_actions).detach()
         return batch_q, batch_q_target
 
+    def _fused_c51_applicable(self):
+        cls = type(self)
+        stock = (CategoricalDQN, CategoricalDoubleDQN)
+        return (self.fused_td_loss and self.device.type == "cuda"
+                and any(cls._compute_target_values is c._compute_target_values for c in stock)
+                and cls._compute_y_and_t is CategoricalDQN._compute_y_and_t
+                and cls._project is CategoricalDQN._project)
+
+    def _compute_loss_fused_c51(self, exp_batch, errors_out, record):
+        """Same quantities as the composite path below out of ONE launch
+        (pfrl_c51_loss): projection, cross entropy, its gradient, Q(s, a), KL."""
+        from pfrl_amd import ops
+
+        qout = self.model(exp_batch["state"])
+        if not ops.c51_loss_supported(qout.q_dist):
+            return None
+        with torch.no_grad():
+            if type(self)._c51_double:
+                with evaluating(self.target_model), evaluating(self.model):
+                    target_next = self._target_next_action_value(exp_batch)
+                    select = self.model(exp_batch["next_state"]).q_dist
+            else:
+                target_next = self._target_next_action_value(exp_batch)
+                select = None
+        loss, qsa, delta = ops.c51_loss(
+            qout.q_dist, exp_batch["action"], target_next.q_dist, select, target_next.z_values,
+            exp_batch["reward"], exp_batch["discount"], exp_batch["is_state_terminal"],
+            exp_batch.get("weights"), self.batch_accumulator == "mean")
+        self._analytic_backward = (qout.q_dist, loss.grad_fn.saved_tensors[0]
+                                   if loss.grad_fn is not None else None)
+        self._q_scalars = qsa
+        self._last_y = qsa
+        if record:
+            self.q_record.extend(qsa)
+        if errors_out is not None:
+            del errors_out[:]
+            errors_out.extend(delta.cpu().numpy())
+        return loss, delta
+
     def _compute_loss(self, exp_batch, errors_out=None, want_errors=False, record=True):
+        if self._fused_c51_applicable():
+            out = self._compute_loss_fused_c51(exp_batch, errors_out, record)
+            if out is not None:
+                return out
         y, t = self._compute_y_and_t(exp_batch)
         self._last_y = self._q_scalars
         if record:
@@ -100,6 +146,8 @@ class CategoricalDQN(dqn.DQN):
 class CategoricalDoubleDQN(CategoricalDQN):
     """Action chosen by the online network, distribution taken from the target
     network (reference categorical_double_dqn.py:10-52)."""
+
+    _c51_double = True
 
     def _compute_target_values(self, exp_batch):
         batch_next_state = exp_batch["next_state"]

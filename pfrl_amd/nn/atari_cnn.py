@@ -17,10 +17,27 @@ def constant_bias_initializer(bias=0.0):
     return init_bias
 
 
-def _fused_bias_relu_ok(layer, h):
-    return (isinstance(layer, nn.Conv2d) and layer.bias is not None
-            and layer.weight.is_contiguous(memory_format=torch.channels_last)
-            and layer.padding_mode == "zeros")
+def _is_relu(activation):
+    return activation is F.relu or activation is torch.relu
+
+
+def conv_activation(layer, h, activation):
+    """``activation(layer(h))`` for a conv layer.  For ReLU on the GPU with
+    channels_last weights: the conv runs without bias, then ONE launch does bias +
+    ReLU (and one their backward) instead of PyTorch's separate add / clamp /
+    threshold / reduction kernels."""
+    if (_is_relu(activation) and h.is_cuda and h.dtype == torch.float32
+            and isinstance(layer, nn.Conv2d) and layer.bias is not None
+            and layer.padding_mode == "zeros"
+            and layer.weight.is_contiguous(memory_format=torch.channels_last)):
+        from pfrl_amd import ops
+
+        z = F.conv2d(h, layer.weight, None, layer.stride, layer.padding, layer.dilation,
+                     layer.groups)
+        if ops.bias_relu_supported(z, layer.bias):
+            return ops.bias_relu(z, layer.bias)
+        return activation(z + layer.bias.view(1, -1, 1, 1))
+    return activation(layer(h))
 
 
 class _AtariCNN(nn.Module):
@@ -35,21 +52,8 @@ class _AtariCNN(nn.Module):
 
     def forward(self, state):
         h = state
-        fuse = self.activation is F.relu and h.is_cuda and h.dtype == torch.float32
         for layer in self.layers:
-            if fuse and _fused_bias_relu_ok(layer, h):
-                # conv without bias, then ONE launch for bias + ReLU (and one for
-                # their backward) instead of PyTorch's separate add / clamp kernels
-                from pfrl_amd import ops
-
-                z = F.conv2d(h, layer.weight, None, layer.stride, layer.padding, layer.dilation,
-                             layer.groups)
-                if ops.bias_relu_supported(z, layer.bias):
-                    h = ops.bias_relu(z, layer.bias)
-                    continue
-                h = self.activation(z + layer.bias.view(1, -1, 1, 1))
-                continue
-            h = self.activation(layer(h))
+            h = conv_activation(layer, h, self.activation)
         return self.activation(self.output(h.reshape(h.size(0), -1)))
 
 

@@ -364,3 +364,46 @@ def noisy_weights(mu_w, sigma_w, mu_b, sigma_b, r):
     """Perturbed (weight, bias) of a FactorizedNoisyLinear; ``r`` = in + out unit
     Gaussians in the reference's order (eps_x first)."""
     return _NoisyWeights.apply(mu_w, sigma_w, mu_b, sigma_b, r)
+
+
+class _C51Loss(torch.autograd.Function):
+    """Categorical DQN loss (projection + cross entropy) in one HIP launch; the
+    same launch produces d loss / d q_dist, Q(s, a) and the per-sample KL."""
+
+    @staticmethod
+    def forward(ctx, q_dist, action, next_dist, next_select, z_values, reward, discount, terminal,
+                weights, mean):
+        B, A, Z = q_dist.shape
+        dev = q_dist.device
+        loss = torch.empty(1, dtype=torch.float32, device=dev)
+        grad_q = torch.empty((B, A, Z), dtype=torch.float32, device=dev)
+        qsa = torch.empty(B, dtype=torch.float32, device=dev)
+        delta = torch.empty(B, dtype=torch.float32, device=dev)
+        check(_native.lib().pfrl_c51_loss(
+            _ptr(q_dist.detach().contiguous()), _ptr(action.contiguous()),
+            _ptr(next_dist.contiguous()),
+            _ptr(next_select.contiguous()) if next_select is not None else None,
+            _ptr(z_values.contiguous()), _ptr(reward), _ptr(discount), _ptr(terminal),
+            _ptr(weights.contiguous()) if weights is not None else None, B, A, Z, int(mean),
+            _ptr(loss), _ptr(grad_q), _ptr(qsa), _ptr(delta), _stream()), "c51_loss")
+        ctx.save_for_backward(grad_q)
+        ctx.mark_non_differentiable(qsa, delta)
+        ctx.set_materialize_grads(False)
+        return loss.view(()), qsa, delta
+
+    @staticmethod
+    def backward(ctx, g_loss, g_q, g_delta):
+        (grad_q,) = ctx.saved_tensors
+        return (grad_q * g_loss,) + (None,) * 9
+
+
+def c51_loss_supported(q_dist):
+    return (q_dist.is_cuda and q_dist.dtype == torch.float32 and q_dist.ndim == 3
+            and 2 <= q_dist.shape[2] <= 64 and q_dist.shape[0] <= 4096)
+
+
+def c51_loss(q_dist, action, next_dist, next_select, z_values, reward, discount, terminal, weights,
+             mean):
+    """-> (loss scalar with grad, Q(s, a) [B], per-sample cross entropy [B])"""
+    return _C51Loss.apply(q_dist, action, next_dist, next_select, z_values, reward, discount,
+                          terminal, weights, mean)

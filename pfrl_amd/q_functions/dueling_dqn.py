@@ -6,7 +6,7 @@ import torch.nn.functional as F
 
 from pfrl_amd import action_value
 from pfrl_amd.initializers import init_chainer_default
-from pfrl_amd.nn.atari_cnn import constant_bias_initializer
+from pfrl_amd.nn.atari_cnn import constant_bias_initializer, conv_activation
 from pfrl_amd.nn.mlp import MLP
 
 
@@ -33,7 +33,7 @@ class DuelingDQN(nn.Module):
     def forward(self, x):
         h = x
         for layer in self.conv_layers:
-            h = self.activation(layer(h))
+            h = conv_activation(layer, h, self.activation)
         batch_size = x.shape[0]
         h = h.reshape(batch_size, -1)
         ya = self.a_stream(h)
@@ -68,7 +68,7 @@ class DistributionalDuelingDQN(nn.Module):
     def forward(self, x):
         h = x
         for layer in self.conv_layers:
-            h = self.activation(layer(h))
+            h = conv_activation(layer, h, self.activation)
         batch_size = x.shape[0]
         h = self.activation(self.main_stream(h.reshape(batch_size, -1)))
         h_a, h_v = torch.chunk(h, 2, dim=1)

@@ -724,6 +724,61 @@ def c51_projection_golden():
     print("c51 projection cases 3")
 
 
+def c51_loss_golden():
+    """Whole C51 loss path of the reference on fixed inputs: greedy next action,
+    Bellman shift, projection, cross entropy, accumulation, gradient w.r.t. the
+    online distribution (categorical_dqn.py:7-104,150-204; double: :10-52)."""
+    from pfrl.action_value import DistributionalDiscreteActionValue as DAV
+    from pfrl.agents import categorical_dqn as cd
+
+    out = {}
+    ci = 0
+    combos = [(d, w, a) for d in (False, True)
+              for w, a in ((False, "mean"), (False, "sum"), (True, "mean"), (True, "sum"))]
+    big = [(False, False, "mean"), (True, True, "mean"), (True, False, "sum"), (False, True, "sum")]
+    for (B, A, Z, vmin, vmax, sel) in [(16, 6, 51, -10.0, 10.0, big), (7, 3, 11, -2.0, 2.0, combos)]:
+        for double, weighted, acc in sel:
+            if True:
+                g = torch.Generator().manual_seed(1000 * ci + 17)
+                sm = lambda *s: torch.softmax(3 * torch.randn(*s, generator=g), dim=-1)
+                q_dist = sm(B, A, Z).requires_grad_(True)
+                next_dist, next_sel = sm(B, A, Z), sm(B, A, Z)
+                z = torch.linspace(vmin, vmax, Z, dtype=torch.float32)
+                action = torch.randint(0, A, (B,), generator=g)
+                reward = torch.randint(-1, 2, (B,), generator=g).float() * 0.7
+                discount = torch.full((B,), 0.99 ** 3)
+                terminal = (torch.rand(B, generator=g) < 0.3).float()
+                weights = torch.rand(B, generator=g) + 0.1
+                qout, tq = DAV(q_dist, z), DAV(next_dist, z)
+                greedy = (DAV(next_sel, z) if double else tq).greedy_actions
+                Tz = (reward[..., None] + (1.0 - terminal[..., None]) * discount[..., None]
+                      * z[None])
+                t = cd._apply_categorical_projection(
+                    Tz, tq.evaluate_actions_as_distribution(greedy).detach(), z)
+                y = qout.evaluate_actions_as_distribution(action)
+                elt = -t * torch.log(torch.clamp(y, 1e-10, 1.0))
+                loss = (cd.compute_weighted_value_loss(elt, B, weights, acc) if weighted
+                        else cd.compute_value_loss(elt, acc))
+                (grad,) = torch.autograd.grad(loss, q_dist)
+                pre = "k%d_" % ci
+                out.update({
+                    pre + "q_dist": q_dist.detach().numpy(), pre + "next_dist": next_dist.numpy(),
+                    pre + "next_sel": next_sel.numpy(), pre + "z": z.numpy(),
+                    pre + "action": action.numpy(), pre + "reward": reward.numpy(),
+                    pre + "discount": discount.numpy(), pre + "terminal": terminal.numpy(),
+                    pre + "weights": weights.numpy(),
+                    pre + "flags": np.asarray([int(double), int(weighted), int(acc == "mean")]),
+                    pre + "loss": np.asarray(loss.item(), dtype=np.float64),
+                    pre + "grad": grad.numpy(),
+                    pre + "delta": elt.detach().sum(dim=1).numpy(),
+                    pre + "qsa": qout.evaluate_actions(action).detach().numpy(),
+                    pre + "target": t.numpy()})
+                ci += 1
+    out["n_cases"] = np.asarray(ci)
+    np.savez_compressed(os.path.join(HERE, "c51_loss.npz"), **out)
+    print("c51 loss cases", ci)
+
+
 def c51_agent_trace(steps=640, N=4):
     sys.path.insert(0, os.path.join(HERE, "..", ".."))
     import tempfile
@@ -890,5 +945,6 @@ if __name__ == "__main__":
     ppo_trace()
     a2c_trace()
     c51_projection_golden()
+    c51_loss_golden()
     c51_agent_trace()
     sac_trace()

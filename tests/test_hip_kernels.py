@@ -774,3 +774,79 @@ def test_noisy_linear_module_uses_fused_path(dev):
                                atol=1e-5)
     for a, p in zip(g_fused, layer.parameters()):
         np.testing.assert_allclose(a.cpu().numpy(), p.grad.cpu().numpy(), rtol=1e-5, atol=1e-5)
+
+
+# ---------------------------------------------------------------------------
+# fused C51 loss
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("B,A,Z", [(32, 6, 51), (7, 3, 11), (64, 18, 51), (1, 2, 2), (33, 4, 64)])
+@pytest.mark.parametrize("double", [False, True])
+@pytest.mark.parametrize("weighted,mean", [(False, True), (False, False), (True, True),
+                                           (True, False)])
+def test_fused_c51_loss_matches_composite(dev, B, A, Z, double, weighted, mean):
+    """pfrl/agents/categorical_dqn.py:7-104,150-204 as the stock-PyTorch composite
+    (pfrl_amd.agents.categorical_dqn) vs pfrl_c51_loss."""
+    from pfrl_amd import ops
+    from pfrl_amd.action_value import DistributionalDiscreteActionValue as DAV
+    from pfrl_amd.agents import categorical_dqn as cd
+
+    g = torch.Generator(device="cpu").manual_seed(B * 1000 + A * 10 + Z + int(double))
+    sm = lambda *s: torch.softmax(3 * torch.randn(*s, generator=g), dim=-1).to(dev)
+    q_dist = sm(B, A, Z).requires_grad_(True)
+    next_dist, next_sel = sm(B, A, Z), sm(B, A, Z)
+    z = torch.linspace(-10, 10, Z).to(dev)
+    action = torch.randint(0, A, (B,), generator=g).to(dev)
+    reward = torch.randint(-1, 2, (B,), generator=g).float().to(dev) * 1.7
+    discount = torch.full((B,), 0.99 ** 3).to(dev)
+    terminal = (torch.rand(B, generator=g) < 0.3).float().to(dev)
+    weights = (torch.rand(B, generator=g) + 0.1).to(dev) if weighted else None
+    acc = "mean" if mean else "sum"
+    # composite
+    qout = DAV(q_dist, z)
+    tq = DAV(next_dist, z)
+    greedy = (DAV(next_sel, z) if double else tq).greedy_actions
+    Tz = reward[:, None] + (1.0 - terminal[:, None]) * discount[:, None] * z[None]
+    t = cd._apply_categorical_projection(Tz, tq.evaluate_actions_as_distribution(greedy), z)
+    y = qout.evaluate_actions_as_distribution(action)
+    elt = -t * torch.log(torch.clamp(y, 1e-10, 1.0))
+    loss_ref = (cd.compute_weighted_value_loss(elt, B, weights, acc) if weighted
+                else cd.compute_value_loss(elt, acc))
+    (g_ref,) = torch.autograd.grad(loss_ref, q_dist)
+    loss, qsa, delta = ops.c51_loss(q_dist, action, next_dist, next_sel if double else None, z,
+                                    reward, discount, terminal, weights, mean)
+    (g_got,) = torch.autograd.grad(loss, q_dist)
+    np.testing.assert_allclose(loss.item(), loss_ref.item(), rtol=2e-5, atol=1e-6)
+    np.testing.assert_allclose(delta.cpu().numpy(), elt.detach().sum(dim=1).cpu().numpy(),
+                               rtol=2e-5, atol=1e-6)
+    np.testing.assert_allclose(qsa.cpu().numpy(), qout.evaluate_actions(action).detach().cpu().numpy(),
+                               rtol=2e-5, atol=1e-6)
+    np.testing.assert_allclose(g_got.cpu().numpy(), g_ref.cpu().numpy(), rtol=2e-5, atol=1e-7)
+
+
+def test_fused_c51_loss_golden(dev):
+    """pfrl_c51_loss against vectors recorded from the REFERENCE's own functions
+    (tests/golden/c51_loss.npz; make_golden.c51_loss_golden): loss, gradient,
+    per-sample KL, Q(s, a), and the projected target recovered as -grad * y / coef."""
+    from pfrl_amd import ops
+
+    gold = np.load(os.path.join(GOLDEN, "c51_loss.npz"))
+    t_ = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    for ci in range(int(gold["n_cases"])):
+        k = lambda name: gold["k%d_%s" % (ci, name)]
+        double, weighted, mean = (bool(v) for v in k("flags"))
+        q = t_(k("q_dist")).requires_grad_(True)
+        loss, qsa, delta = ops.c51_loss(
+            q, t_(k("action")), t_(k("next_dist")), t_(k("next_sel")) if double else None,
+            t_(k("z")), t_(k("reward")), t_(k("discount")), t_(k("terminal")),
+            t_(k("weights")) if weighted else None, mean)
+        (gq,) = torch.autograd.grad(loss, q)
+        np.testing.assert_allclose(loss.item(), float(k("loss")), rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(gq.cpu().numpy(), k("grad"), rtol=1e-5, atol=1e-7)
+        np.testing.assert_allclose(delta.cpu().numpy(), k("delta"), rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(qsa.cpu().numpy(), k("qsa"), rtol=1e-5, atol=1e-6)
+        B = q.shape[0]
+        coef = (k("weights") if weighted else np.ones(B, np.float32)) / (B if mean else 1)
+        rows = np.arange(B)
+        y = k("q_dist")[rows, k("action")]
+        t_got = -gq.cpu().numpy()[rows, k("action")] * y / coef[:, None]
+        np.testing.assert_allclose(t_got, k("target"), rtol=1e-4, atol=1e-6)
