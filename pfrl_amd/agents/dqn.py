@@ -111,7 +111,7 @@ class DQN(agent.AttributeSavingMixin, agent.BatchAgent):
                  batch_accumulator="mean", episodic_update_len=None, logger=getLogger(__name__),
                  batch_states=batch_states, recurrent=False, max_grad_norm=None,
                  use_graphs=None, step_fused_gather=None, batch_target_pass=None,
-                 fused_td_loss=True):
+                 fused_td_loss=True, replay_overlap=None):
         self.model = q_function
         if gpu is not None and gpu >= 0:
             assert torch.cuda.is_available()
@@ -180,6 +180,22 @@ class DQN(agent.AttributeSavingMixin, agent.BatchAgent):
         self._analytic_backward = None
         self._graphed = None
         self._last_y = None
+        # Prioritized replay is a serial chain per update (priorities -> B dependent
+        # draws -> gather) that the next forward pass has to wait for, but the
+        # backward pass and the optimizer step do not: with graphs on, the buffer's
+        # launches move to their own HIP stream and overlap them (see
+        # _update_from_batch).  Same launches, same order within the replay stream.
+        self._replay_stream = None
+        self._fwd_event = None
+        from pfrl_amd.replay_buffers.prioritized import PrioritizedReplayBuffer
+
+        want_overlap = (self.use_graphs and isinstance(replay_buffer, PrioritizedReplayBuffer)
+                        and getattr(replay_buffer, "is_device", False))
+        if want_overlap if replay_overlap is None else (replay_overlap and want_overlap):
+            self._replay_stream = torch.cuda.Stream(self.device)
+            self._fwd_event = torch.cuda.Event()
+            self._replay_stream.wait_stream(torch.cuda.current_stream(self.device))
+            replay_buffer.set_replay_stream(self._replay_stream)
 
     @property
     def cumulative_steps(self):
@@ -198,6 +214,9 @@ class DQN(agent.AttributeSavingMixin, agent.BatchAgent):
             has_weight = "weight" in experiences[0][0]
         exp_batch = batch_experiences(experiences, device=self.device, phi=self.phi,
                                       gamma=self.gamma, batch_states=self.batch_states)
+        if self._replay_stream is not None and isinstance(experiences, DeviceExperienceBatch):
+            # the minibatch was sampled and gathered on the replay stream
+            torch.cuda.current_stream(self.device).wait_event(experiences.store.ready_event)
         if has_weight and "weights" not in exp_batch:
             exp_batch["weights"] = torch.tensor([e[0]["weight"] for e in experiences],
                                                 device=self.device, dtype=torch.float32)
@@ -209,14 +228,27 @@ class DQN(agent.AttributeSavingMixin, agent.BatchAgent):
         its own graph (step-fused path), so the outputs stay intact until the end
         of the step and are recorded with one concatenation."""
         want_errors = has_weight or errors_out is not None
+        handed_over = []
         if self.use_graphs:
-            loss, delta = self._graphed_step(exp_batch, want_errors, deferred)
+            hand_over = None
+            if has_weight and errors_out is None and self._replay_stream is not None:
+                def hand_over(delta):
+                    # TD errors exist as soon as the forward graph has run: the replay
+                    # stream takes them (priority update, then the next sample and
+                    # gather) while backward + optimizer step continue on this stream
+                    self._fwd_event.record(torch.cuda.current_stream(self.device))
+                    self._replay_stream.wait_event(self._fwd_event)
+                    self.replay_buffer.update_errors(delta)
+                    handed_over.append(True)
+            loss, delta = self._graphed_step(exp_batch, want_errors, deferred, hand_over)
         else:
             loss, delta = self._compute_loss(exp_batch, want_errors=want_errors)
         if errors_out is not None:
             del errors_out[:]
             errors_out.extend(delta.cpu().numpy())
-        if has_weight:
+        if has_weight and not handed_over:
+            if self._replay_stream is not None:
+                self.replay_buffer.replay_stream_wait_current()
             self.replay_buffer.update_errors(delta if errors_out is None else errors_out)
         if not self.use_graphs:
             self.loss_record.extend(loss)
@@ -228,14 +260,15 @@ class DQN(agent.AttributeSavingMixin, agent.BatchAgent):
             self.optimizer.step()
         self.optim_t += 1
 
-    def _graphed_step(self, exp_batch, want_errors, deferred=None):
+    def _graphed_step(self, exp_batch, want_errors, deferred=None, after_forward=None):
         """loss -> backward -> step replayed from a captured HIP graph."""
         if self._graphed is None:
             from pfrl_amd.agents.graphed_update import GraphedUpdate
 
             self._graphed = GraphedUpdate(self)
+            self._graphed.pipeline = self._replay_stream is not None
         try:
-            loss, delta, y = self._graphed.run(exp_batch, want_errors)
+            loss, delta, y = self._graphed.run(exp_batch, want_errors, after_forward)
         except Exception as e:  # capture not possible -> stay eager on the GPU
             if self._graphed.graphs:
                 raise
@@ -370,6 +403,9 @@ class DQN(agent.AttributeSavingMixin, agent.BatchAgent):
         return self.model(batch_xs)
 
     def batch_act(self, batch_obs):
+        if self._replay_stream is not None:
+            # frames the buffer uploaded on its own stream must be visible to the gather
+            self.replay_buffer.current_wait_replay_stream()
         with torch.no_grad(), evaluating(self.model):
             batch_av = self._evaluate_model(batch_obs)
             batch_argmax = batch_av.greedy_actions.detach().cpu().numpy()
@@ -399,6 +435,9 @@ class DQN(agent.AttributeSavingMixin, agent.BatchAgent):
 
     def _batch_observe_train(self, batch_obs, batch_reward, batch_done, batch_reset):
         rbuf = self.replay_buffer
+        if self._replay_stream is not None:
+            # this env step's frames (written on the compute stream) before any gather
+            rbuf.replay_stream_wait_current()
         if self.step_fused_gather and getattr(rbuf, "supports_lookahead", False):
             return self._batch_observe_train_fused(batch_obs, batch_reward, batch_done,
                                                    batch_reset)

@@ -62,22 +62,32 @@ class GraphedUpdate:
         self._capturable_done = False
         self.split_for_allreduce = (distributed.world_size() > 1
                                     or os.environ.get("PFRL_FORCE_SPLIT_GRAPH") == "1")
+        # pipeline=True: the forward/loss part is its own graph, so that the caller
+        # can hand the TD errors to the replay stream (priority update, next
+        # sample, next gather) while backward + optimizer step still run here
+        self.pipeline = False
 
     def _key(self, exp_batch):
         return tuple(sorted((k, v.data_ptr(), tuple(v.shape)) for k, v in exp_batch.items()
                             if isinstance(v, torch.Tensor)))
 
     # the work that gets captured ------------------------------------------------
-    def _forward_backward(self, exp_batch, want_errors):
+    def _forward(self, exp_batch, want_errors):
         ag = self.agent
         ag._analytic_backward = None
-        loss, delta = ag._compute_loss(exp_batch, want_errors=want_errors, record=False)
-        ab = getattr(ag, "_analytic_backward", None)
+        return ag._compute_loss(exp_batch, want_errors=want_errors, record=False)
+
+    def _backward(self, loss):
+        ab = getattr(self.agent, "_analytic_backward", None)
         if ab is not None and ab[1] is not None:
             # fused TD loss: the gradient w.r.t. Q(s) came out of the same launch
             torch.autograd.backward([ab[0]], [ab[1]])
         else:
             loss.backward()
+
+    def _forward_backward(self, exp_batch, want_errors):
+        loss, delta = self._forward(exp_batch, want_errors)
+        self._backward(loss)
         return loss, delta
 
     def _step(self):
@@ -137,33 +147,51 @@ class GraphedUpdate:
         _make_capturable(ag.optimizer, dev)  # state created by the warm-up
         entry = {}
         ag.optimizer.zero_grad(set_to_none=True)
-        g1 = torch.cuda.CUDAGraph()
-        kw = {} if self.pool is None else {"pool": self.pool}
-        if not self.split_for_allreduce:
-            with torch.cuda.graph(g1, **kw):
-                loss, delta = self._forward_backward(exp_batch, want_errors)
-                self._step()
+
+        def graph_of(fn):
+            g = torch.cuda.CUDAGraph()
+            kw = {} if self.pool is None else {"pool": self.pool}
+            with torch.cuda.graph(g, **kw):
+                r = fn()
             if self.pool is None:
-                self.pool = g1.pool()
-            entry["graphs"] = (g1,)
-        else:
+                self.pool = g.pool()
+            return g, r
+
+        # plan: graphs interleaved with the two things that cannot be captured --
+        # the caller's hand-over after the forward pass ("after_forward", pipeline
+        # mode) and the eager RCCL all-reduce (data parallel)
+        plan = []
+        if self.pipeline:
+            g, (loss, delta) = graph_of(lambda: self._forward(exp_batch, want_errors))
+            plan += [g, "after_forward"]
+            if self.split_for_allreduce:
+                plan += [graph_of(lambda: self._backward(loss))[0], "all_reduce",
+                         graph_of(self._step)[0]]
+            else:
+                plan += [graph_of(lambda: (self._backward(loss), self._step()))[0]]
+        elif self.split_for_allreduce:
             # data parallel: graph(fwd+bwd) -> eager RCCL all-reduce -> graph(step)
-            with torch.cuda.graph(g1, **kw):
-                loss, delta = self._forward_backward(exp_batch, want_errors)
-            if self.pool is None:
-                self.pool = g1.pool()
-            g2 = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g2, pool=self.pool):
+            g, (loss, delta) = graph_of(lambda: self._forward_backward(exp_batch, want_errors))
+            plan += [g, "all_reduce", graph_of(self._step)[0]]
+        else:
+            def whole():
+                r = self._forward_backward(exp_batch, want_errors)
                 self._step()
-            entry["graphs"] = (g1, g2)
+                return r
+
+            g, (loss, delta) = graph_of(whole)
+            plan += [g]
+        entry["plan"] = plan
         entry["loss"] = loss
         entry["delta"] = delta
         entry["y"] = ag._last_y
         self._restore(snap)
         return entry
 
-    def run(self, exp_batch, want_errors):
-        """Returns (loss, delta, y) tensors owned by the graph (static)."""
+    def run(self, exp_batch, want_errors, after_forward=None):
+        """Returns (loss, delta, y) tensors owned by the graph (static).  In
+        pipeline mode ``after_forward(delta)`` is called between the forward
+        graph and the backward/step graph."""
         key = (self._key(exp_batch), bool(want_errors))
         entry = self.graphs.get(key)
         if entry is None:
@@ -171,11 +199,18 @@ class GraphedUpdate:
                 raise RuntimeError("too many distinct minibatch buffers for graph capture")
             entry = self._capture(exp_batch, want_errors)
             self.graphs[key] = entry
-        gs = entry["graphs"]
-        gs[0].replay()
-        if len(gs) == 2:
-            self.agent.grad_reducer.all_reduce()
-            gs[1].replay()
+        called = False
+        for item in entry["plan"]:
+            if item == "all_reduce":
+                self.agent.grad_reducer.all_reduce()
+            elif item == "after_forward":
+                if after_forward is not None:
+                    after_forward(entry["delta"])
+                    called = True
+            else:
+                item.replay()
+        if after_forward is not None and not called:
+            after_forward(entry["delta"])
         return entry["loss"], entry["delta"], entry["y"]
 
 

@@ -15,7 +15,7 @@ import torch
 from pfrl_amd import ops
 from pfrl_amd._native import MAX_LEVELS, TreeDesc
 from pfrl_amd.collections.tree_frame import TreeFrame, smax_log2_for_capacity
-from pfrl_amd.staging import StagingRing
+from pfrl_amd.staging import StagingRing, on_stream
 
 TAG_ABSENT, TAG_PY, TAG_F32, TAG_F64 = 0, 1, 2, 3
 
@@ -71,6 +71,10 @@ class PrioritizedBuffer:
         self._pend_x, self._pend_v, self._pend_t, self._pend_m = [], [], [], []
         self._sampled_x = None  # device int64 tensor of the last sample
         self._sample_out = {}
+        # optional replay stream: all tree launches go there and the sample outputs
+        # alternate between two buffer sets (see DeviceReplayStore.set_side_stream)
+        self.side_stream = None
+        self._sample_parity = 0
         self._n_sampled = 0
         self._desc = TreeDesc()
         d = self._desc
@@ -105,15 +109,16 @@ class PrioritizedBuffer:
         if n == 0:
             return
         desc = self._sync_desc()
-        for lo in range(0, n, 1024):
-            hi = min(n, lo + 1024)
-            x, v, t, m = self._stage.upload([
-                np.asarray(self._pend_x[lo:hi], dtype=np.int64),
-                np.asarray(self._pend_v[lo:hi], dtype=np.float64),
-                np.asarray(self._pend_t[lo:hi], dtype=np.uint8),
-                np.asarray(self._pend_m[lo:hi], dtype=np.uint8),
-            ])
-            ops.tree_write(desc, x, v, t, m)
+        with on_stream(self.side_stream):
+            for lo in range(0, n, 1024):
+                hi = min(n, lo + 1024)
+                x, v, t, m = self._stage.upload([
+                    np.asarray(self._pend_x[lo:hi], dtype=np.int64),
+                    np.asarray(self._pend_v[lo:hi], dtype=np.float64),
+                    np.asarray(self._pend_t[lo:hi], dtype=np.uint8),
+                    np.asarray(self._pend_m[lo:hi], dtype=np.uint8),
+                ])
+                ops.tree_write(desc, x, v, t, m)
         self._pend_x, self._pend_v, self._pend_t, self._pend_m = [], [], [], []
 
     # -- reference API ------------------------------------------------------
@@ -151,11 +156,14 @@ class PrioritizedBuffer:
         self.flush()
         if u01 is None:
             u01 = np.random.random_sample(n)
-        (u_dev,) = self._stage.upload([np.asarray(u01, dtype=np.float64)])
-        out = self._sample_out.get(n)
+        key = n
+        if self.side_stream is not None:
+            self._sample_parity ^= 1
+            key = (n, self._sample_parity)
+        out = self._sample_out.get(key)
         if out is None:
             dev = self.device
-            out = self._sample_out[n] = dict(
+            out = self._sample_out[key] = dict(
                 x=torch.empty(n, dtype=torch.int64, device=dev),
                 pri=torch.empty(n, dtype=torch.float64, device=dev),
                 pri_tag=torch.empty(n, dtype=torch.uint8, device=dev),
@@ -169,7 +177,9 @@ class PrioritizedBuffer:
         out = dict(out)  # persistent buffers (stable addresses for graph replay)
         if not slot_mod:
             del out["slot"]
-        ops.tree_sample(self._sync_desc(), u_dev, out, normalize, beta, slot_mod)
+        with on_stream(self.side_stream):
+            (u_dev,) = self._stage.upload([np.asarray(u01, dtype=np.float64)])
+            ops.tree_sample(self._sync_desc(), u_dev, out, normalize, beta, slot_mod)
         self._sampled_x = out["x"]
         self._n_sampled = n
         self.flag_wait_priority = True
@@ -180,6 +190,7 @@ class PrioritizedBuffer:
         if uniform_ratio != 0:
             raise NotImplementedError("uniform_ratio > 0 is not used by the replay buffers")
         out = self.sample_device(n)
+        self._join()
         x = out["x"].cpu().numpy()
         idx = x - self.frame.head
         self.sampled_indices = [int(i) for i in idx]
@@ -192,11 +203,12 @@ class PrioritizedBuffer:
         assert not self.wait_priority_after_sampling or self.flag_wait_priority
         assert all([p > 0.0 for p in priority])
         assert self._n_sampled == len(priority)
-        v, t = self._stage.upload([
-            np.asarray([float(p) for p in priority], dtype=np.float64),
-            np.asarray([type_tag(p) for p in priority], dtype=np.uint8),
-        ])
-        ops.tree_set_priorities(self._sync_desc(), self._sampled_x, v, t, dedupe=True)
+        with on_stream(self.side_stream):
+            v, t = self._stage.upload([
+                np.asarray([float(p) for p in priority], dtype=np.float64),
+                np.asarray([type_tag(p) for p in priority], dtype=np.uint8),
+            ])
+            ops.tree_set_priorities(self._sync_desc(), self._sampled_x, v, t, dedupe=True)
         self.flag_wait_priority = False
         self.sampled_indices = []
         self._n_sampled = 0
@@ -205,15 +217,21 @@ class PrioritizedBuffer:
         """set_last_priority for f32 errors already on the device (DQN path)."""
         assert not self.wait_priority_after_sampling or self.flag_wait_priority
         assert self._n_sampled == err.numel()
-        ops.tree_update_errors_f32(self._sync_desc(), self._sampled_x, err, error_min, pri_at_min,
-                                   error_max, pri_at_max, eps, alpha, dedupe=True)
+        with on_stream(self.side_stream):
+            ops.tree_update_errors_f32(self._sync_desc(), self._sampled_x, err, error_min,
+                                       pri_at_min, error_max, pri_at_max, eps, alpha, dedupe=True)
         self.flag_wait_priority = False
         self.sampled_indices = []
         self._n_sampled = 0
 
     # -- inspection (tests / statistics) ------------------------------------
+    def _join(self):
+        if self.side_stream is not None:
+            self.side_stream.synchronize()
+
     @property
     def max_priority(self):
+        self._join()
         v = float(self._maxp_val.item())
         t = int(self._maxp_tag.item())
         return np.float32(v) if t == TAG_F32 else (np.float64(v) if t == TAG_F64 else v)
@@ -221,6 +239,7 @@ class PrioritizedBuffer:
     def root_stats(self):
         """((sum, tag), (min, tag), (max_priority, tag)) read back from HBM."""
         self.flush()
+        self._join()
         f = self.frame
         if f.length == 0:
             return None
@@ -234,6 +253,7 @@ class PrioritizedBuffer:
     def dump_level(self, which, l):
         """Nodes of level ``l`` (0 = leaves) in frame order: (values, tags)."""
         self.flush()
+        self._join()
         f = self.frame
         n = f.size >> l
         M = max((1 << self.log2_smax) >> l, 1)

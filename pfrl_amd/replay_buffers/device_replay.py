@@ -19,7 +19,7 @@ import torch
 
 from pfrl_amd import ops
 from pfrl_amd.device_store import DeviceFrameStore, DeviceObs, recognise_phi
-from pfrl_amd.staging import StagingRing
+from pfrl_amd.staging import StagingRing, on_stream
 
 _STAGE_ROWS = 4096
 
@@ -72,12 +72,28 @@ class DeviceReplayStore:
         self._pend_frames = []
         self._pend_frame_slots = []
         self._out_cache = {}
+        # optional replay stream (DQN + PER pipelining, see set_side_stream)
+        self.side_stream = None
+        self.double_buffer = False
+        self._out_parity = 0
+        self.ready_event = None
+        self._events = []
         # host mirrors, allocated with the tables
         self.h_state_ref = self.h_next_ref = self.h_action = None
         self.h_reward = self.h_terminal = self.h_min_fseq = None
         self.h_e_tids = self.h_e_len = self.h_e_min_fseq = self.h_extra = None
 
     # -- configuration --------------------------------------------------------
+    def set_side_stream(self, stream):
+        """Run every launch of this store (table / entry appends, frame uploads,
+        the fused gather) on ``stream`` instead of the caller's stream, and
+        alternate between two sets of minibatch buffers, so that the gather of
+        update u+1 can overlap the backward pass of update u.  After each
+        ``fetch`` :attr:`ready_event` marks the gather on that stream."""
+        self.side_stream = stream
+        self.double_buffer = stream is not None
+        self._events = [torch.cuda.Event() for _ in range(4)] if stream is not None else []
+
     def set_phi(self, phi):
         if phi is not self._phi:
             self._phi = phi
@@ -289,19 +305,23 @@ class DeviceReplayStore:
 
     def flush(self):
         """Ship staged frames, transition rows and entries to HBM (async)."""
-        if self._pend_frames:
-            self._flush_frames()
-        r = self._pend_rows
-        if r:
-            up = self._stage.upload([self._s_slot[:r], self._s_state[:r], self._s_next[:r],
-                                     self._s_action[:r], self._s_reward[:r], self._s_term[:r]])
-            ops.table_append(self.desc, *up)
-            self._pend_rows = 0
-        e = self._pend_entries
-        if e:
-            up = self._stage.upload([self._s_eslot[:e], self._s_etids[:e], self._s_elen[:e]])
-            ops.entries_append(self.desc, *up)
-            self._pend_entries = 0
+        if not (self._pend_frames or self._pend_rows or self._pend_entries):
+            return
+        with on_stream(self.side_stream):
+            if self._pend_frames:
+                self._flush_frames()
+            r = self._pend_rows
+            if r:
+                up = self._stage.upload([self._s_slot[:r], self._s_state[:r], self._s_next[:r],
+                                         self._s_action[:r], self._s_reward[:r],
+                                         self._s_term[:r]])
+                ops.table_append(self.desc, *up)
+                self._pend_rows = 0
+            e = self._pend_entries
+            if e:
+                up = self._stage.upload([self._s_eslot[:e], self._s_etids[:e], self._s_elen[:e]])
+                ops.entries_append(self.desc, *up)
+                self._pend_entries = 0
 
     # -- sampling -------------------------------------------------------------
     def slots_for(self, seqs):
@@ -315,7 +335,8 @@ class DeviceReplayStore:
                     "ring (n_slots=%d) has already wrapped past it; allocate the "
                     "DeviceFrameStore with at least capacity + num_envs * (stack + num_steps + 2)"
                     " slots" % (oldest, self.frames.n_slots))
-        (slots_dev,) = self._stage.upload([slots])
+        with on_stream(self.side_stream):
+            (slots_dev,) = self._stage.upload([slots])
         return slots_dev
 
     def divisor_for(self, phi):
@@ -374,10 +395,20 @@ class DeviceReplayStore:
         """The fused batch_experiences launch for a DeviceExperienceBatch."""
         self.flush()
         B = len(batch)
-        out = dict(self._out_buffers(B, "single"))
+        tag = "single"
+        if self.double_buffer:
+            self._out_parity ^= 1
+            tag = "single%d" % self._out_parity
+        out = dict(self._out_buffers(B, tag))
         gp = [gamma ** i for i in range(self.n + 1)]
-        ops.batch_experiences(self.desc, self.frames.frames, self.divisor_for(phi),
-                              batch.slots_dev, gp, out)
+        divisor = self.divisor_for(phi)
+        with on_stream(self.side_stream):
+            ops.batch_experiences(self.desc, self.frames.frames, divisor, batch.slots_dev, gp, out)
+            if self.side_stream is not None:
+                ev = self._events[0]
+                self._events = self._events[1:] + [ev]
+                ev.record()
+                self.ready_event = ev
         if batch.weights_dev is not None:
             out["weights"] = batch.weights_dev
         return out
@@ -391,8 +422,9 @@ class DeviceReplayStore:
         slots_dev = self.slots_for(seqs)
         flat = self._out_buffers(U * B, "many")
         gp = [gamma ** i for i in range(self.n + 1)]
-        ops.batch_experiences(self.desc, self.frames.frames, self.divisor_for(phi), slots_dev, gp,
-                              flat)
+        with on_stream(self.side_stream):
+            ops.batch_experiences(self.desc, self.frames.frames, self.divisor_for(phi), slots_dev,
+                                  gp, flat)
         return {k: v.view((U, B) + tuple(v.shape[1:])) for k, v in flat.items()}
 
     # -- API-compatible host views ---------------------------------------------

@@ -77,6 +77,7 @@ class _LazySeqs:
 
     def __getitem__(self, i):
         if self._host is None:
+            torch.cuda.synchronize(self._x.device)   # may have been drawn on a replay stream
             self._host = self._x.cpu().numpy()
         return self._host[i]
 
@@ -164,6 +165,7 @@ class PrioritizedReplayBuffer(ReplayBuffer, PriorityWeightError):
     def _native_state(self):
         tree = self.memory.tree
         tree.flush()
+        torch.cuda.synchronize(self.device)
         f = tree.frame
         sd = dict(kind="pfrl_amd.PrioritizedReplayBuffer", capacity=self.capacity,
                   num_steps=self.num_steps, head=self.memory.head, beta=self.beta,

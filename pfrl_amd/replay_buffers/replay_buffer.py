@@ -123,6 +123,35 @@ class ReplayBuffer(replay_buffer.AbstractReplayBuffer):
     def is_device(self):
         return self.store is not None
 
+    # -- replay stream (overlap of replay launches with the network update) ---------
+    def set_replay_stream(self, stream):
+        """Route every device launch of this buffer to ``stream`` (None = back to the
+        caller's stream).  The caller owns the ordering: see DQN._update_from_batch."""
+        self._ensure_bound()
+        if self.store is None:
+            raise RuntimeError("replay streams need the device back-end")
+        self.store.set_side_stream(stream)
+        tree = getattr(self.memory, "tree", None)
+        if tree is not None:
+            tree.side_stream = stream
+
+    @property
+    def replay_stream(self):
+        return None if self.store is None else self.store.side_stream
+
+    def replay_stream_wait_current(self):
+        """Everything enqueued so far on the caller's stream (e.g. the frames of
+        this env step) happens-before later replay launches."""
+        st = self.replay_stream
+        if st is not None:
+            st.wait_stream(torch.cuda.current_stream(self.device))
+
+    def current_wait_replay_stream(self):
+        """The caller's stream waits for the replay launches enqueued so far."""
+        st = self.replay_stream
+        if st is not None:
+            torch.cuda.current_stream(self.device).wait_stream(st)
+
     # -- reference API ------------------------------------------------------------
     def _emit(self, window):
         if self.store is not None:
@@ -194,6 +223,9 @@ class ReplayBuffer(replay_buffer.AbstractReplayBuffer):
         ``native=True`` a compact torch checkpoint of the HBM tables and only
         the live frames (see :meth:`load`, which recognises both)."""
         self._ensure_bound()
+        if self.store is not None:
+            self.store.flush()
+            torch.cuda.synchronize(self.device)
         if native and self.store is not None:
             torch.save(self._native_state(), filename)
             return

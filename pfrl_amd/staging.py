@@ -64,3 +64,20 @@ _TORCH_DTYPES = {
     np.dtype(np.float64): torch.float64,
     np.dtype(np.bool_): torch.bool,
 }
+
+
+class _NullScope:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NULL_SCOPE = _NullScope()
+
+
+def on_stream(stream):
+    """``with on_stream(s):`` -- launches inside go to HIP stream ``s``; a no-op
+    scope when ``s`` is None (everything stays on the caller's stream)."""
+    return _NULL_SCOPE if stream is None else torch.cuda.stream(stream)
