@@ -297,6 +297,17 @@ int pfrl_c51_loss(const float *q_dist, const int64_t *action, const float *next_
                   float *out_q, float *out_delta, void *stream);
 
 /* ------------------------------------------------------------------------
+ * Distributional dueling head (pfrl/q_functions/dueling_dqn.py:116-127), forward
+ * and backward in one launch each.  ya f32 [B][A][Z] advantage logits, ys f32 [B][Z]
+ * state-value logits, Z <= 64:
+ *   q[b][a][.] = softmax_z((ya[b][a][z] - sum_a' ya[b][a'][z] / A) + ys[b][z])
+ * backward: gq = d loss / d q  ->  g_ya [B][A][Z], g_ys [B][Z]. */
+int pfrl_dueling_softmax_fwd(const float *ya, const float *ys, float *q, int64_t B, int32_t A,
+                             int32_t Z, void *stream);
+int pfrl_dueling_softmax_bwd(const float *gq, const float *q, float *g_ya, float *g_ys, int64_t B,
+                             int32_t A, int32_t Z, void *stream);
+
+/* ------------------------------------------------------------------------
  * Factorised NoisyNet weights (pfrl/nn/noisy_linear.py:52-70: `_eps` shaping,
  * `torch.ger`, two `torch.addcmul`), forward and backward in one launch each.
  *   r            f32 [in + out] unit Gaussians: r[0:in] -> eps_x, r[in:] -> eps_y

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_DIR = os.path.join(_HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libpfrl_amd.so")
-SOURCES = ["frames.hip", "replay.hip", "sumtree.hip", "rollout.hip", "optim.hip", "tdloss.hip", "bias_act.hip", "noisy.hip", "c51.hip"]
+SOURCES = ["frames.hip", "replay.hip", "sumtree.hip", "rollout.hip", "optim.hip", "tdloss.hip", "bias_act.hip", "noisy.hip", "c51.hip", "dueling.hip"]
 HIPCC_FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
     # the parity contract is one correctly rounded IEEE op per source op
@@ -119,6 +119,8 @@ EXPORTS = {
     "pfrl_bias_relu_fwd": (ctypes.c_int, "pppqip"),
     "pfrl_bias_relu_bwd": (ctypes.c_int, "ppppppqiip"),
     "pfrl_c51_loss": (ctypes.c_int, "pppppppppiiiippppp"),
+    "pfrl_dueling_softmax_fwd": (ctypes.c_int, "pppqiip"),
+    "pfrl_dueling_softmax_bwd": (ctypes.c_int, "ppppqiip"),
     "pfrl_noisy_weights_fwd": (ctypes.c_int, "pppppppqqp"),
     "pfrl_noisy_weights_bwd": (ctypes.c_int, "pppppqqp"),
     "pfrl_profile_enable": (ctypes.c_int, "i"),

@@ -44,21 +44,46 @@ __global__ __launch_bounds__(kThreads) void k_c51_loss(
     const float delta_z = __fsub_rn(z_values[1], z_values[0]);
     const float inv_b = 1.0f / (float)B;
     for (int b = wave; b < B; b += kWaves) {
-        // greedy next action under next_select (first maximum, like torch.argmax)
+        // Everything this sample needs from HBM is requested up front (the loads are
+        // independent; issued one after another they would each cost a full memory
+        // round trip): the taken action's online distribution, and per action the
+        // selection distribution plus the target distribution, eight actions at a time.
+        const int64_t act = action[b];
+        const int zl = min(lane, Z - 1);
+        const float y_ = q_dist[((int64_t)b * A + act) * Z + zl];
+        const float y = on ? y_ : 1.0f;
+        const float rew = reward[b], term = terminal[b], disc = discount[b];
         const float *sel = next_select + (int64_t)b * A * Z;
-        int g = 0;
-        float best = 0.0f;
-        for (int a = 0; a < A; ++a) {
-            const float qv = wave_sum(on ? sel[a * Z + lane] * z : 0.0f);
-            if (a == 0 || qv > best) {
-                best = qv;
-                g = a;
+        const float *nd = next_dist + (int64_t)b * A * Z;
+        // greedy next action under next_select (first maximum, like torch.argmax);
+        // the target distribution of the running best is carried along
+        float best = 0.0f, p = 0.0f;
+        for (int a0 = 0; a0 < A; a0 += 8) {
+            float sv[8], pv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                // unconditional clamped loads keep all 16 in one basic block (in flight
+                // together); out-of-range lanes / actions are zeroed afterwards
+                const int aa = min(a0 + u, A - 1);
+                const float s_ = sel[aa * Z + zl];
+                const float p_ = nd[aa * Z + zl];
+                sv[u] = on ? s_ : 0.0f;
+                pv[u] = on ? p_ : 0.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (a0 + u < A) {
+                    const float qv = wave_sum(sv[u] * z);
+                    if ((a0 + u) == 0 || qv > best) {
+                        best = qv;
+                        p = pv[u];
+                    }
+                }
             }
         }
         // Bellman shift + projection weights of source atom j = lane
-        const float p = on ? next_dist[((int64_t)b * A + g) * Z + lane] : 0.0f;
-        const float scale = __fmul_rn(__fsub_rn(1.0f, terminal[b]), discount[b]);
-        float tz = __fadd_rn(reward[b], __fmul_rn(scale, z));
+        const float scale = __fmul_rn(__fsub_rn(1.0f, term), disc);
+        float tz = __fadd_rn(rew, __fmul_rn(scale, z));
         tz = fminf(fmaxf(tz, v_min), v_max);
         float bj = __fdiv_rn(__fsub_rn(tz, v_min), delta_z);
         bj = fminf(fmaxf(bj, 0.0f), (float)(Z - 1));
@@ -78,8 +103,6 @@ __global__ __launch_bounds__(kThreads) void k_c51_loss(
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
         // cross entropy against the online distribution of the taken action
-        const int64_t act = action[b];
-        const float y = on ? q_dist[((int64_t)b * A + act) * Z + lane] : 1.0f;
         const float yc = fminf(fmaxf(y, 1e-10f), 1.0f);
         const float el = on ? -t * logf(yc) : 0.0f;
         const float d = wave_sum(el);

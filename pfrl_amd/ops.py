@@ -407,3 +407,37 @@ def c51_loss(q_dist, action, next_dist, next_select, z_values, reward, discount,
     """-> (loss scalar with grad, Q(s, a) [B], per-sample cross entropy [B])"""
     return _C51Loss.apply(q_dist, action, next_dist, next_select, z_values, reward, discount,
                           terminal, weights, mean)
+
+
+class _DuelingSoftmax(torch.autograd.Function):
+    """q = softmax_atoms(ya - mean_actions(ya) + ys) for the distributional dueling head."""
+
+    @staticmethod
+    def forward(ctx, ya, ys, n_actions, n_atoms):
+        B = ya.shape[0]
+        q = torch.empty((B, n_actions, n_atoms), dtype=torch.float32, device=ya.device)
+        check(_native.lib().pfrl_dueling_softmax_fwd(_ptr(ya.contiguous()), _ptr(ys.contiguous()),
+                                                     _ptr(q), B, n_actions, n_atoms, _stream()),
+              "dueling_softmax_fwd")
+        ctx.save_for_backward(q)
+        return q
+
+    @staticmethod
+    def backward(ctx, gq):
+        (q,) = ctx.saved_tensors
+        B, A, Z = q.shape
+        g_ya = torch.empty((B, A * Z), dtype=torch.float32, device=q.device)
+        g_ys = torch.empty((B, Z), dtype=torch.float32, device=q.device)
+        check(_native.lib().pfrl_dueling_softmax_bwd(_ptr(gq.contiguous()), _ptr(q), _ptr(g_ya),
+                                                     _ptr(g_ys), B, A, Z, _stream()),
+              "dueling_softmax_bwd")
+        return g_ya, g_ys, None, None
+
+
+def dueling_softmax_supported(ya, n_atoms):
+    return ya.is_cuda and ya.dtype == torch.float32 and 1 <= n_atoms <= 64
+
+
+def dueling_softmax(ya, ys, n_actions, n_atoms):
+    """ya [B, A*Z] (or [B, A, Z]), ys [B, Z] -> q [B, A, Z]."""
+    return _DuelingSoftmax.apply(ya, ys, n_actions, n_atoms)

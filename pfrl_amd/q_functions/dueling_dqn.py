@@ -72,7 +72,15 @@ class DistributionalDuelingDQN(nn.Module):
         batch_size = x.shape[0]
         h = self.activation(self.main_stream(h.reshape(batch_size, -1)))
         h_a, h_v = torch.chunk(h, 2, dim=1)
-        ya = self.a_stream(h_a).reshape((batch_size, self.n_actions, self.n_atoms))
+        ya_flat = self.a_stream(h_a)
+        if h.is_cuda:
+            from pfrl_amd import ops
+
+            if ops.dueling_softmax_supported(ya_flat, self.n_atoms):
+                # centring, value add and softmax over atoms in one launch
+                q = ops.dueling_softmax(ya_flat, self.v_stream(h_v), self.n_actions, self.n_atoms)
+                return action_value.DistributionalDiscreteActionValue(q, self.z_values)
+        ya = ya_flat.reshape((batch_size, self.n_actions, self.n_atoms))
         mean = ya.sum(dim=1, keepdim=True) / self.n_actions
         ya = ya - mean
         ys = self.v_stream(h_v).reshape((batch_size, 1, self.n_atoms))

@@ -850,3 +850,46 @@ def test_fused_c51_loss_golden(dev):
         y = k("q_dist")[rows, k("action")]
         t_got = -gq.cpu().numpy()[rows, k("action")] * y / coef[:, None]
         np.testing.assert_allclose(t_got, k("target"), rtol=1e-4, atol=1e-6)
+
+
+# ---------------------------------------------------------------------------
+# fused distributional dueling head
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("B,A,Z", [(32, 6, 51), (256, 18, 51), (5, 3, 11), (1, 1, 2), (9, 9, 64)])
+def test_dueling_softmax_forward_backward(dev, B, A, Z):
+    """pfrl/q_functions/dueling_dqn.py:116-127 as torch ops (fp32) vs the fused launches."""
+    import torch.nn.functional as F
+
+    from pfrl_amd import ops
+
+    torch.manual_seed(B + A + Z)
+    ya = (2 * torch.randn(B, A * Z, device=dev)).requires_grad_(True)
+    ys = (2 * torch.randn(B, Z, device=dev)).requires_grad_(True)
+    y3 = ya.reshape(B, A, Z)
+    ref = F.softmax((y3 - y3.sum(dim=1, keepdim=True) / A) + ys.reshape(B, 1, Z), dim=2)
+    gq = torch.randn(B, A, Z, device=dev)
+    g_ref = torch.autograd.grad(ref, [ya, ys], gq)
+    q = ops.dueling_softmax(ya, ys, A, Z)
+    g_got = torch.autograd.grad(q, [ya, ys], gq)
+    np.testing.assert_allclose(q.detach().cpu().numpy(), ref.detach().cpu().numpy(), rtol=2e-6,
+                               atol=1e-7)
+    for a, e in zip(g_got, g_ref):
+        np.testing.assert_allclose(a.cpu().numpy(), e.cpu().numpy(), rtol=1e-4, atol=2e-6)
+
+
+def test_distributional_dueling_dqn_fused_head_matches_plain(dev):
+    from pfrl_amd import ops
+    from pfrl_amd.q_functions import DistributionalDuelingDQN
+
+    torch.manual_seed(0)
+    net = DistributionalDuelingDQN(6, 51, -10, 10).to(dev)
+    x = torch.rand(8, 4, 84, 84, device=dev)
+    q1 = net(x).q_dist
+    saved = ops.dueling_softmax_supported
+    ops.dueling_softmax_supported = lambda *_: False
+    try:
+        q2 = net(x).q_dist
+    finally:
+        ops.dueling_softmax_supported = saved
+    np.testing.assert_allclose(q1.detach().cpu().numpy(), q2.detach().cpu().numpy(), rtol=1e-5,
+                               atol=1e-7)
