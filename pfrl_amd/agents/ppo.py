@@ -120,7 +120,8 @@ class PPO(agent.AttributeSavingMixin, agent.BatchAgent):
                  standardize_advantages=True, batch_states=batch_states, recurrent=False,
                  max_recurrent_sequence_len=None, act_deterministically=False, max_grad_norm=None,
                  value_stats_window=1000, entropy_stats_window=1000, value_loss_stats_window=100,
-                 policy_loss_stats_window=100, value_pass_chunk=8192):
+                 policy_loss_stats_window=100, value_pass_chunk=8192,
+                 reuse_next_values=True):
         self.model = model
         self.optimizer = optimizer
         self.obs_normalizer = obs_normalizer
@@ -152,6 +153,10 @@ class PPO(agent.AttributeSavingMixin, agent.BatchAgent):
         self.act_deterministically = act_deterministically
         self.max_grad_norm = max_grad_norm
         self.value_pass_chunk = value_pass_chunk
+        # V(next_state) of a non-final transition is V(state) of the next step: skip
+        # the second pass over the whole rollout (reference ppo.py:119-133 evaluates
+        # both; same values up to fp32 batch-position effects of the conv kernels)
+        self.reuse_next_values = bool(reuse_next_values)
         self.logger = getLogger(__name__)
 
         self.rollout = None
@@ -303,6 +308,26 @@ class PPO(agent.AttributeSavingMixin, agent.BatchAgent):
                     log_probs[lo:hi] = distribs.log_prob(actions_dev[lo:hi])
         return log_probs, values
 
+    def _next_values_from_states(self, ro, T, N, v_pred, n_refs):
+        """V(next_state) without a second pass over the whole rollout: wherever the
+        next observation of (t, env) IS the observation of (t+1, env) -- the same
+        frame slots, i.e. no episode end / reset in between -- its value is
+        v_pred[t+1, env], computed by the same network in the same mode.  Only the
+        other rows (episode ends, and the last step of the rollout) are evaluated."""
+        same = (ro.h_next[:T - 1] == ro.h_state[1:T]).all(axis=-1) if T > 1 else \
+            np.zeros((0, N), dtype=bool)
+        need = np.ones((T, N), dtype=bool)
+        need[:T - 1] = ~same
+        need_idx = np.flatnonzero(need.reshape(-1))
+        (idx_dev,) = self._stage.upload([need_idx.astype(np.int64)])
+        idx_dev = idx_dev.clone()
+        _, vals = self._value_pass(n_refs[idx_dev], None)
+        next_v = torch.empty_like(v_pred)
+        if T > 1:
+            next_v[:(T - 1) * N] = v_pred[N:]
+        next_v[idx_dev] = vals
+        return next_v
+
     def _update(self):
         ro = self.rollout
         T, N, k = ro.T, ro.N, ro.k
@@ -320,7 +345,10 @@ class PPO(agent.AttributeSavingMixin, agent.BatchAgent):
         # uploads through the same ring): keep private device copies
         s_refs, n_refs, actions, reward, nonterm, cut, order_dev = [t.clone() for t in up]
         log_probs, v_pred = self._value_pass(s_refs, actions)
-        _, next_v = self._value_pass(n_refs, None)
+        if self.reuse_next_values:
+            next_v = self._next_values_from_states(ro, T, N, v_pred, n_refs)
+        else:
+            _, next_v = self._value_pass(n_refs, None)
         adv, v_teacher = ops.gae_scan(reward.view(T, N), v_pred.view(T, N), next_v.view(T, N),
                                       nonterm.view(T, N), cut.view(T, N), self.gamma, self.lambd,
                                       self._reward_mode)

@@ -162,8 +162,10 @@ def test_prioritized_replay_stream_overlap_is_exact():
 
 
 @pytest.mark.gpu
-def test_ppo_device_rollout_matches_reference():
-    """PPO on the device rollout path vs the reference trace.  The sampled
+@pytest.mark.parametrize("reuse_next_values", [True, False])
+def test_ppo_device_rollout_matches_reference(reuse_next_values):
+    """PPO on the device rollout path vs the reference trace (with and without
+    taking V(next_state) from the next step's V(state)).  The sampled
     actions are replayed (CPU and GPU torch RNG streams differ by construction);
     value pass, GAE kernel, advantage statistics, minibatch order (``random``
     stream), losses and the trained parameters must then agree."""
@@ -189,7 +191,8 @@ def test_ppo_device_rollout_matches_reference():
     opt = torch.optim.SGD(model.parameters(), lr=1e-2)
     ag = agents.PPO(model, opt, gpu=0, gamma=0.99, lambd=0.95, phi=phi, update_interval=64,
                     minibatch_size=16, epochs=2, clip_eps=0.1, clip_eps_vf=None,
-                    standardize_advantages=True, max_grad_norm=0.5)
+                    standardize_advantages=True, max_grad_norm=0.5,
+                    reuse_next_values=reuse_next_values)
     step = [0]
 
     def replay_action(distrib):
