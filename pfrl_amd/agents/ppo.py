@@ -319,6 +319,11 @@ class PPO(agent.AttributeSavingMixin, agent.BatchAgent):
         need = np.ones((T, N), dtype=bool)
         need[:T - 1] = ~same
         need_idx = np.flatnonzero(need.reshape(-1))
+        # pad to a multiple of N with repeats: a handful of distinct batch shapes
+        # instead of a new one (and a new MIOpen solver lookup) every rollout
+        pad = (-len(need_idx)) % N
+        if pad:
+            need_idx = np.concatenate([need_idx, np.repeat(need_idx[-1:], pad)])
         (idx_dev,) = self._stage.upload([need_idx.astype(np.int64)])
         idx_dev = idx_dev.clone()
         _, vals = self._value_pass(n_refs[idx_dev], None)
