@@ -418,7 +418,7 @@ def main():
     t_fill = time.perf_counter() - t_fill
 
     def barrier():
-        if world > 1:
+        if torch.distributed.is_initialized():
             torch.distributed.barrier()
 
     for _ in range(args.warmup):
@@ -515,7 +515,7 @@ def main():
         if not args.no_cpu_baseline and world == 1 and args.algo == "dqn":
             out["cpu_baseline"] = cpu_baseline(args, args.cpu_baseline_seconds)
         print(json.dumps(out))
-    if world > 1:
+    if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 
 

@@ -151,6 +151,9 @@ class GraphedUpdate:
         def graph_of(fn):
             g = torch.cuda.CUDAGraph()
             kw = {} if self.pool is None else {"pool": self.pool}
+            if torch.distributed.is_available() and torch.distributed.is_initialized():
+                # the process group's watchdog thread polls events while we capture
+                kw["capture_error_mode"] = "thread_local"
             with torch.cuda.graph(g, **kw):
                 r = fn()
             if self.pool is None:

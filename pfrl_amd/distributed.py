@@ -21,7 +21,10 @@ def init_process_group_from_env(backend=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    # PFRL_DIST_ALWAYS=1 initialises the group for a single rank too (a one-GPU box
+    # can then exercise RCCL init, the per-update all-reduce and the split graph)
+    always = os.environ.get("PFRL_DIST_ALWAYS") == "1"
+    if (world > 1 or always) and not dist.is_initialized():
         if backend is None:
             backend = os.environ.get("PFRL_DIST_BACKEND") or (
                 "nccl" if torch.cuda.is_available() else "gloo")
@@ -56,9 +59,9 @@ class GradientAllReducer:
         self._flat = None
 
     def all_reduce(self):
-        w = world_size()
-        if w == 1:
+        if not (dist.is_available() and dist.is_initialized()):
             return
+        w = world_size()
         grads = [p.grad for p in self.params if p.grad is not None]
         if not grads:
             return
@@ -73,12 +76,15 @@ class GradientAllReducer:
             views.append(v)
             off += g.numel()
         torch._foreach_copy_(views, grads)
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-        flat.div_(w)
+        if dist.get_backend() == "nccl":
+            dist.all_reduce(flat, op=dist.ReduceOp.AVG)   # RCCL averages in the collective
+        else:
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+            flat.div_(w)
         torch._foreach_copy_(grads, views)
 
     def broadcast_parameters(self, module, src=0):
-        if world_size() == 1:
+        if not (dist.is_available() and dist.is_initialized()):
             return
         for t in list(module.parameters()) + list(module.buffers()):
             dist.broadcast(t.data, src=src)
