@@ -30,9 +30,13 @@ def init_process_group_from_env(backend=None):
                 "nccl" if torch.cuda.is_available() else "gloo")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
+        kw = {}
         if torch.cuda.is_available():
-            torch.cuda.set_device(local % torch.cuda.device_count())
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+            idx = local % torch.cuda.device_count()
+            torch.cuda.set_device(idx)
+            if backend == "nccl":
+                kw["device_id"] = torch.device("cuda", idx)   # bind the communicator eagerly
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
     return rank, world, local
 
 
