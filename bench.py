@@ -514,9 +514,19 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1 and args.algo == "dqn":
             out["cpu_baseline"] = cpu_baseline(args, args.cpu_baseline_seconds)
-        print(json.dumps(out))
     if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
+    if rank == 0:
+        # RCCL prints its version banner through C stdio on stdout: drain it first so
+        # that the JSON line is the last line of this process's output
+        import ctypes
+
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

@@ -160,6 +160,7 @@ class GraphedUpdate:
                 self.pool = g.pool()
             return g, r
 
+        red = ag.grad_reducer   # pack / unpack (multi-tensor copies) live inside the graphs
         # plan: graphs interleaved with the two things that cannot be captured --
         # the caller's hand-over after the forward pass ("after_forward", pipeline
         # mode) and the eager RCCL all-reduce (data parallel)
@@ -168,14 +169,19 @@ class GraphedUpdate:
             g, (loss, delta) = graph_of(lambda: self._forward(exp_batch, want_errors))
             plan += [g, "after_forward"]
             if self.split_for_allreduce:
-                plan += [graph_of(lambda: self._backward(loss))[0], "all_reduce",
-                         graph_of(self._step)[0]]
+                plan += [graph_of(lambda: (self._backward(loss), red.pack()))[0], "all_reduce",
+                         graph_of(lambda: (red.unpack(), self._step()))[0]]
             else:
                 plan += [graph_of(lambda: (self._backward(loss), self._step()))[0]]
         elif self.split_for_allreduce:
             # data parallel: graph(fwd+bwd) -> eager RCCL all-reduce -> graph(step)
-            g, (loss, delta) = graph_of(lambda: self._forward_backward(exp_batch, want_errors))
-            plan += [g, "all_reduce", graph_of(self._step)[0]]
+            def fwd_bwd_pack():
+                r = self._forward_backward(exp_batch, want_errors)
+                red.pack()
+                return r
+
+            g, (loss, delta) = graph_of(fwd_bwd_pack)
+            plan += [g, "all_reduce", graph_of(lambda: (red.unpack(), self._step()))[0]]
         else:
             def whole():
                 r = self._forward_backward(exp_batch, want_errors)
@@ -205,7 +211,7 @@ class GraphedUpdate:
         called = False
         for item in entry["plan"]:
             if item == "all_reduce":
-                self.agent.grad_reducer.all_reduce()
+                self.agent.grad_reducer.reduce_flat()
             elif item == "after_forward":
                 if after_forward is not None:
                     after_forward(entry["delta"])

@@ -62,30 +62,57 @@ class GradientAllReducer:
         self.params = [p for p in module.parameters() if p.requires_grad]
         self._flat = None
 
-    def all_reduce(self):
-        if not (dist.is_available() and dist.is_initialized()):
-            return
-        w = world_size()
+    def active(self):
+        return dist.is_available() and dist.is_initialized()
+
+    def _views(self):
         grads = [p.grad for p in self.params if p.grad is not None]
         if not grads:
-            return
+            return None, None
         n = sum(g.numel() for g in grads)
         if self._flat is None or self._flat.numel() != n or self._flat.device != grads[0].device:
             self._flat = torch.empty(n, dtype=grads[0].dtype, device=grads[0].device)
-        flat = self._flat
         views = []
         off = 0
         for g in grads:
-            v = flat[off:off + g.numel()].view_as(g)
-            views.append(v)
+            views.append(self._flat[off:off + g.numel()].view_as(g))
             off += g.numel()
-        torch._foreach_copy_(views, grads)
+        return grads, views
+
+    # The three parts are separate so that a captured update can keep the two
+    # multi-tensor copies inside its graphs and leave only the collective eager.
+    def pack(self):
+        """gradients -> flat bucket (one multi-tensor copy)."""
+        if not self.active():
+            return
+        grads, views = self._views()
+        if grads:
+            torch._foreach_copy_(views, grads)
+
+    def reduce_flat(self):
+        """The collective itself: average the flat bucket over all ranks."""
+        if not self.active() or self._flat is None:
+            return
         if dist.get_backend() == "nccl":
-            dist.all_reduce(flat, op=dist.ReduceOp.AVG)   # RCCL averages in the collective
+            dist.all_reduce(self._flat, op=dist.ReduceOp.AVG)   # RCCL averages in the collective
         else:
-            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-            flat.div_(w)
-        torch._foreach_copy_(grads, views)
+            dist.all_reduce(self._flat, op=dist.ReduceOp.SUM)
+            self._flat.div_(world_size())
+
+    def unpack(self):
+        """flat bucket -> gradients."""
+        if not self.active():
+            return
+        grads, views = self._views()
+        if grads:
+            torch._foreach_copy_(grads, views)
+
+    def all_reduce(self):
+        if not self.active():
+            return
+        self.pack()
+        self.reduce_flat()
+        self.unpack()
 
     def broadcast_parameters(self, module, src=0):
         if not (dist.is_available() and dist.is_initialized()):

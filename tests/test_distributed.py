@@ -94,3 +94,37 @@ def test_shard_envs_single_process():
     assert distributed.shard_envs(512, rank=3, world=8) == (192, 256)
     with pytest.raises(AssertionError):
         distributed.shard_envs(10, rank=0, world=4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prioritized", [False, True])
+def test_split_graph_update_with_a_process_group_matches_reference(prioritized, tmp_path):
+    """The data-parallel form of the captured update -- graph(fwd + bwd + pack) ->
+    eager all-reduce -> graph(unpack + step), and with PER graph(fwd) | graph(bwd +
+    pack) -> all-reduce -> graph(unpack + step) -- run under a real (single-rank)
+    process group reproduces the reference trace."""
+    import torch.distributed as dist
+
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import test_agent_parity as T
+
+    assert not dist.is_initialized()
+    dist.init_process_group("gloo", init_method="file://%s" % (tmp_path / "pg"), rank=0,
+                            world_size=1)
+    os.environ["PFRL_FORCE_SPLIT_GRAPH"] = "1"
+    try:
+        if prioritized:
+            g = np.load(os.path.join(T.GOLDEN, "agent_trace_ddqn_per_n3.npz"))
+            got = T._run("ddqn", True, 3, True, gpu=0)
+        else:
+            g = np.load(os.path.join(T.GOLDEN, "agent_trace_dqn_uniform_n1.npz"))
+            got = T._run("dqn", False, 1, False, gpu=0)
+        ag = got["agent"]
+        assert ag._graphed is not None and ag._graphed.split_for_allreduce
+        plans = [e["plan"] for e in ag._graphed.graphs.values()]
+        assert plans and all("all_reduce" in p for p in plans)
+        assert ag.grad_reducer._flat is not None
+        T._compare(got, g)
+    finally:
+        os.environ.pop("PFRL_FORCE_SPLIT_GRAPH", None)
+        dist.destroy_process_group()
