@@ -66,6 +66,11 @@ class GraphedUpdate:
         # can hand the TD errors to the replay stream (priority update, next
         # sample, next gather) while backward + optimizer step still run here
         self.pipeline = False
+        # RCCL all-reduces are capturable: with the nccl backend the collective goes
+        # INTO the graph (one replay per update, no eager launches in between);
+        # PFRL_GRAPH_COLLECTIVE=0, a non-RCCL backend or a failed capture fall back
+        # to graph -> eager all-reduce -> graph
+        self.graph_collective = os.environ.get("PFRL_GRAPH_COLLECTIVE", "1") != "0"
 
     def _key(self, exp_batch):
         return tuple(sorted((k, v.data_ptr(), tuple(v.shape)) for k, v in exp_batch.items()
@@ -122,7 +127,22 @@ class GraphedUpdate:
                     v.zero_()
         torch.cuda.set_rng_state(rng, ag.device)
 
+    def _collective_capturable(self):
+        d = torch.distributed
+        return (self.graph_collective and d.is_available() and d.is_initialized()
+                and d.get_backend() == "nccl")
+
     def _capture(self, exp_batch, want_errors):
+        if self.split_for_allreduce and self._collective_capturable():
+            try:
+                return self._capture_plan(exp_batch, want_errors, collective_in_graph=True)
+            except Exception as e:
+                self.logger.warning("capturing the RCCL all-reduce inside the update graph "
+                                    "failed (%s); keeping it eager between two graphs", e)
+                self.graph_collective = False
+        return self._capture_plan(exp_batch, want_errors, collective_in_graph=False)
+
+    def _capture_plan(self, exp_batch, want_errors, collective_in_graph):
         ag = self.agent
         dev = ag.device
         if not self._capturable_done:
@@ -137,16 +157,25 @@ class GraphedUpdate:
         cur = torch.cuda.current_stream(dev)
         side = torch.cuda.Stream(dev)
         side.wait_stream(cur)
-        with torch.cuda.stream(side):
-            for _ in range(2):
-                ag.optimizer.zero_grad(set_to_none=True)
-                self._forward_backward(exp_batch, want_errors)
-                ag.grad_reducer.all_reduce()
-                self._step()
-        cur.wait_stream(side)
-        _make_capturable(ag.optimizer, dev)  # state created by the warm-up
+        try:
+            with torch.cuda.stream(side):
+                for _ in range(2):
+                    ag.optimizer.zero_grad(set_to_none=True)
+                    self._forward_backward(exp_batch, want_errors)
+                    ag.grad_reducer.all_reduce()
+                    self._step()
+            cur.wait_stream(side)
+            _make_capturable(ag.optimizer, dev)  # state created by the warm-up
+            ag.optimizer.zero_grad(set_to_none=True)
+            entry = self._capture_graphs(exp_batch, want_errors, collective_in_graph)
+        finally:
+            cur.wait_stream(side)
+            self._restore(snap)
+        return entry
+
+    def _capture_graphs(self, exp_batch, want_errors, collective_in_graph):
+        ag = self.agent
         entry = {}
-        ag.optimizer.zero_grad(set_to_none=True)
 
         def graph_of(fn):
             g = torch.cuda.CUDAGraph()
@@ -164,15 +193,31 @@ class GraphedUpdate:
         # plan: graphs interleaved with the two things that cannot be captured --
         # the caller's hand-over after the forward pass ("after_forward", pipeline
         # mode) and the eager RCCL all-reduce (data parallel)
+        def reduce_and_step():
+            red.pack()
+            red.reduce_flat()
+            red.unpack()
+            self._step()
+
         plan = []
         if self.pipeline:
             g, (loss, delta) = graph_of(lambda: self._forward(exp_batch, want_errors))
             plan += [g, "after_forward"]
-            if self.split_for_allreduce:
+            if collective_in_graph:
+                plan += [graph_of(lambda: (self._backward(loss), reduce_and_step()))[0]]
+            elif self.split_for_allreduce:
                 plan += [graph_of(lambda: (self._backward(loss), red.pack()))[0], "all_reduce",
                          graph_of(lambda: (red.unpack(), self._step()))[0]]
             else:
                 plan += [graph_of(lambda: (self._backward(loss), self._step()))[0]]
+        elif collective_in_graph:
+            def whole_dp():
+                r = self._forward_backward(exp_batch, want_errors)
+                reduce_and_step()
+                return r
+
+            g, (loss, delta) = graph_of(whole_dp)
+            plan += [g]
         elif self.split_for_allreduce:
             # data parallel: graph(fwd+bwd) -> eager RCCL all-reduce -> graph(step)
             def fwd_bwd_pack():
@@ -194,7 +239,6 @@ class GraphedUpdate:
         entry["loss"] = loss
         entry["delta"] = delta
         entry["y"] = ag._last_y
-        self._restore(snap)
         return entry
 
     def run(self, exp_batch, want_errors, after_forward=None):

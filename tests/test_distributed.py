@@ -97,20 +97,23 @@ def test_shard_envs_single_process():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("backend", ["gloo", "nccl"])
 @pytest.mark.parametrize("prioritized", [False, True])
-def test_split_graph_update_with_a_process_group_matches_reference(prioritized, tmp_path):
-    """The data-parallel form of the captured update -- graph(fwd + bwd + pack) ->
-    eager all-reduce -> graph(unpack + step), and with PER graph(fwd) | graph(bwd +
-    pack) -> all-reduce -> graph(unpack + step) -- run under a real (single-rank)
-    process group reproduces the reference trace."""
+def test_data_parallel_graph_plans_match_reference(prioritized, backend, tmp_path):
+    """The data-parallel forms of the captured update under a real (single-rank)
+    process group reproduce the reference trace:
+      gloo: graph(fwd + bwd + pack) -> eager all-reduce -> graph(unpack + step)
+      nccl: the RCCL all-reduce is captured INSIDE the graph (one replay per update)
+    and with PER the forward pass is its own graph in front (replay-stream hand-over)."""
     import torch.distributed as dist
 
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import test_agent_parity as T
 
     assert not dist.is_initialized()
-    dist.init_process_group("gloo", init_method="file://%s" % (tmp_path / "pg"), rank=0,
-                            world_size=1)
+    kw = {"device_id": torch.device("cuda", 0)} if backend == "nccl" else {}
+    dist.init_process_group(backend, init_method="file://%s" % (tmp_path / "pg"), rank=0,
+                            world_size=1, **kw)
     os.environ["PFRL_FORCE_SPLIT_GRAPH"] = "1"
     try:
         if prioritized:
@@ -122,7 +125,13 @@ def test_split_graph_update_with_a_process_group_matches_reference(prioritized, 
         ag = got["agent"]
         assert ag._graphed is not None and ag._graphed.split_for_allreduce
         plans = [e["plan"] for e in ag._graphed.graphs.values()]
-        assert plans and all("all_reduce" in p for p in plans)
+        assert plans
+        if backend == "nccl":
+            assert ag._graphed.graph_collective
+            assert all("all_reduce" not in p for p in plans)
+            assert all(len(p) == (3 if prioritized else 1) for p in plans)
+        else:
+            assert all("all_reduce" in p for p in plans)
         assert ag.grad_reducer._flat is not None
         T._compare(got, g)
     finally:
