@@ -394,6 +394,13 @@ def cpu_baseline(args, seconds):
 
 def main():
     args = parse_args()
+    # stdout carries exactly ONE line, the JSON result.  Native libraries (RCCL's
+    # version banner, MIOpen notes) write to fd 1 through C stdio at times of their
+    # own choosing: park fd 1 on stderr for the whole run and keep the real stdout
+    # for the result line.
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
     from pfrl_amd import _native, ops
     from pfrl_amd.distributed import init_process_group_from_env
 
@@ -516,17 +523,10 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args, args.cpu_baseline_seconds)
     if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
+    sys.stdout.flush()
     if rank == 0:
-        # RCCL prints its version banner through C stdio on stdout: drain it first so
-        # that the JSON line is the last line of this process's output
-        import ctypes
-
-        try:
-            ctypes.CDLL(None).fflush(None)
-        except Exception:
-            pass
-        sys.stdout.flush()
-        print(json.dumps(out), flush=True)
+        os.write(result_fd, (json.dumps(out) + "\n").encode())
+    os.close(result_fd)
 
 
 if __name__ == "__main__":
