@@ -2,3 +2,5 @@ from pfrl_amd.experiments.evaluator import (Evaluator, LinearInterpolationHook, 
                                             eval_performance)
 from pfrl_amd.experiments.train_agent_batch import (save_agent, train_agent_batch,  # NOQA
                                                     train_agent_batch_with_evaluation)
+from pfrl_amd.experiments.train_agent import (save_agent_replay_buffer, train_agent,  # NOQA
+                                              train_agent_with_evaluation)

@@ -724,6 +724,53 @@ def c51_projection_golden():
     print("c51 projection cases 3")
 
 
+def cartpole_trace(steps=1500):
+    """BASELINE configs[0]: examples/gym/train_dqn_gym.py settings (FC Q-function 100x2,
+    Adam, ReplayBuffer(5e5), LinearDecayEpsilonGreedy) through the reference's
+    train_agent on the CPU, on pfrl_amd's gym-free CartPole (numpy only)."""
+    sys.path.insert(0, os.path.join(HERE, "..", ".."))
+    import tempfile
+
+    from pfrl import agents, explorers, experiments, q_functions, replay_buffers
+
+    from pfrl_amd.envs.cartpole import CartPoleEnv
+
+    pfrl.utils.set_random_seed(0)
+    env = CartPoleEnv(seed=0)
+    torch.manual_seed(77)
+    q = q_functions.FCStateQFunctionWithDiscreteAction(4, 2, n_hidden_channels=100,
+                                                       n_hidden_layers=2)
+    opt = torch.optim.Adam(q.parameters())
+    rbuf = replay_buffers.ReplayBuffer(5 * 10 ** 5)
+    ex = explorers.LinearDecayEpsilonGreedy(1.0, 0.1, 1000, env.action_space.sample)
+    ag = agents.DQN(q, opt, rbuf, gpu=-1, gamma=0.99, explorer=ex, replay_start_size=200,
+                    target_update_interval=100, update_interval=1, minibatch_size=32,
+                    target_update_method="hard", soft_update_tau=1e-2)
+    actions, rewards, losses = [], [], []
+    orig_act = ag.act
+
+    def spy_act(obs):
+        a = orig_act(obs)
+        actions.append(int(a))
+        return a
+
+    ag.act = spy_act
+    orig_update = ag.update
+
+    def spy_update(exps, errors_out=None):
+        orig_update(exps, errors_out)
+        losses.append(float(ag.loss_record[-1]))
+
+    ag.replay_updater.update_func = spy_update
+    experiments.train_agent(ag, env, steps, tempfile.mkdtemp(), max_episode_len=200)
+    flat = np.concatenate([p.detach().numpy().ravel() for p in q.parameters()])
+    np.savez_compressed(os.path.join(HERE, "agent_trace_cartpole_dqn.npz"),
+                        actions=np.asarray(actions), losses=np.asarray(losses),
+                        final_params=flat, final_state=env.state,
+                        stats=np.asarray([float(v) for _, v in ag.get_statistics()]))
+    print("cartpole trace updates", len(losses), "actions", len(actions))
+
+
 def c51_loss_golden():
     """Whole C51 loss path of the reference on fixed inputs: greedy next action,
     Bellman shift, projection, cross entropy, accumulation, gradient w.r.t. the
@@ -944,6 +991,7 @@ if __name__ == "__main__":
     agent_trace("ddqn_per_n3", True, 3, True)
     ppo_trace()
     a2c_trace()
+    cartpole_trace()
     c51_projection_golden()
     c51_loss_golden()
     c51_agent_trace()

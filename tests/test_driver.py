@@ -7,6 +7,7 @@ import tempfile
 from unittest import mock
 
 import numpy as np
+import torch
 
 import pfrl_amd as pfrl
 from pfrl_amd.envs import SerialVectorEnv
@@ -115,3 +116,120 @@ def test_vector_frame_stack_shares_frames_by_identity():
     for i in range(3):
         assert o2[0]._frames[i] is o1[0]._frames[i + 1]          # shared, not copied
     np.testing.assert_array_equal(np.asarray(o2[1])[:3], np.asarray(o1[1])[1:])
+
+
+def test_cartpole_dqn_train_agent_matches_reference(tmp_path):
+    """BASELINE configs[0]: examples/gym/train_dqn_gym.py settings, one env, host path,
+    through pfrl_amd.experiments.train_agent -- against the trace the reference's
+    train_agent + DQN produced on the same CartPole (tests/golden/make_golden.py)."""
+    import pfrl_amd as pfrl
+    from pfrl_amd import agents, experiments, explorers, q_functions, replay_buffers
+    from pfrl_amd.envs import CartPoleEnv
+
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "agent_trace_cartpole_dqn.npz"))
+    pfrl.utils.set_random_seed(0)
+    env = CartPoleEnv(seed=0)
+    torch.manual_seed(77)
+    q = q_functions.FCStateQFunctionWithDiscreteAction(4, 2, n_hidden_channels=100,
+                                                       n_hidden_layers=2)
+    opt = torch.optim.Adam(q.parameters())
+    rbuf = replay_buffers.ReplayBuffer(5 * 10 ** 5)
+    ex = explorers.LinearDecayEpsilonGreedy(1.0, 0.1, 1000, env.action_space.sample)
+    ag = agents.DQN(q, opt, rbuf, gpu=-1, gamma=0.99, explorer=ex, replay_start_size=200,
+                    target_update_interval=100, update_interval=1, minibatch_size=32,
+                    target_update_method="hard", soft_update_tau=1e-2)
+    actions, losses = [], []
+    orig_act = ag.act
+
+    def spy_act(obs):
+        a = orig_act(obs)
+        actions.append(int(a))
+        return a
+
+    ag.act = spy_act
+    orig_core = ag._update_from_batch
+
+    def spy_core(*a, **kw):
+        orig_core(*a, **kw)
+        losses.append(float(ag.loss_record.values()[-1]))
+
+    ag._update_from_batch = spy_core
+    experiments.train_agent(ag, env, 1500, str(tmp_path), max_episode_len=200)
+    assert os.path.isdir(os.path.join(str(tmp_path), "1500_finish"))
+    np.testing.assert_array_equal(np.asarray(actions), g["actions"])
+    np.testing.assert_allclose(np.asarray(losses), g["losses"], rtol=1e-5, atol=1e-6)
+    flat = np.concatenate([p.detach().numpy().ravel() for p in q.parameters()])
+    np.testing.assert_allclose(flat, g["final_params"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(env.state, g["final_state"], rtol=0, atol=0)
+    np.testing.assert_allclose([float(v) for _, v in ag.get_statistics()], g["stats"], rtol=1e-5,
+                               atol=1e-6)
+
+
+def _scripted_env(reset_obs, transitions):
+    env = mock.Mock()
+    env.reset.side_effect = list(reset_obs)
+    env.step.side_effect = list(transitions)
+    return env
+
+
+def test_train_agent_call_contract(tmp_path):
+    """Reference tests/experiments_tests/test_train_agent.py:11-50: five steps to a
+    terminal state -- act/observe/step five times, one reset, hooks see steps 1..5."""
+    agent, hook = mock.Mock(), mock.Mock()
+    env = _scripted_env(["s0"], [("s1", 0, False, {}), ("s2", 0, False, {}),
+                                 ("s3", -0.5, False, {}), ("s4", 0, False, {}),
+                                 ("s5", 1, True, {})])
+    hist = pfrl.experiments.train_agent(agent=agent, env=env, steps=5, outdir=str(tmp_path),
+                                        step_hooks=[hook])
+    assert hist == []
+    assert agent.act.call_count == agent.observe.call_count == env.step.call_count == 5
+    assert env.reset.call_count == 1
+    assert agent.observe.call_args_list[4][0][2] is True          # done at s5
+    assert [c[0][2] for c in hook.call_args_list] == [1, 2, 3, 4, 5]
+    assert all(c[0][0] is env and c[0][1] is agent for c in hook.call_args_list)
+    agent.save.assert_called_once()                                 # <t>_finish
+
+
+def test_train_agent_needs_reset_and_max_episode_len(tmp_path):
+    """:52-93 -- info['needs_reset'] ends the episode with done=False, reset=True and a
+    second env.reset(); max_episode_len does the same by step count."""
+    agent = mock.Mock()
+    env = _scripted_env(["s0", "s4"], [("s1", 0, False, {}), ("s2", 0, False, {}),
+                                       ("s3", 0, False, {"needs_reset": True}),
+                                       ("s5", -0.5, False, {}), ("s6", 0, False, {}),
+                                       ("s7", 1, True, {})])
+    pfrl.experiments.train_agent(agent=agent, env=env, steps=5, outdir=str(tmp_path))
+    assert env.reset.call_count == 2 and env.step.call_count == 5
+    third = agent.observe.call_args_list[2][0]
+    assert third[2] is False and third[3] is True
+    agent2 = mock.Mock()
+    env2 = _scripted_env(["a", "b", "c"], [("x", 0, False, {})] * 6)
+    pfrl.experiments.train_agent(agent=agent2, env=env2, steps=6, outdir=str(tmp_path),
+                                 max_episode_len=2)
+    resets = [bool(c[0][3]) for c in agent2.observe.call_args_list]
+    assert resets == [False, True, False, True, False, True]
+    assert env2.reset.call_count == 3
+
+
+def test_train_agent_saves_on_exception(tmp_path):
+    agent = mock.Mock()
+    env = _scripted_env(["s0"], [("s1", 0, False, {}), RuntimeError("boom")])
+    try:
+        pfrl.experiments.train_agent(agent=agent, env=env, steps=5, outdir=str(tmp_path))
+    except RuntimeError:
+        pass
+    else:
+        raise AssertionError("exception swallowed")
+    assert agent.save.call_args[0][0].endswith("1_except")
+
+
+def test_train_agent_with_evaluation_rejects_unsupported_hook(tmp_path):
+    class Hook:
+        support_train_agent = False
+
+    import pytest
+
+    with pytest.raises(ValueError):
+        pfrl.experiments.train_agent_with_evaluation(
+            agent=mock.Mock(), env=mock.Mock(), steps=1, eval_n_steps=1, eval_n_episodes=None,
+            eval_interval=1, outdir=str(tmp_path), evaluation_hooks=[Hook()])
