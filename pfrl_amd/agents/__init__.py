@@ -4,3 +4,5 @@ from pfrl_amd.agents.ppo import PPO  # NOQA
 from pfrl_amd.agents.a2c import A2C  # NOQA
 from pfrl_amd.agents.categorical_dqn import CategoricalDQN, CategoricalDoubleDQN  # NOQA
 from pfrl_amd.agents.soft_actor_critic import SoftActorCritic  # NOQA
+from pfrl_amd.agents.td3 import TD3  # NOQA
+from pfrl_amd.agents.ddpg import DDPG  # NOQA

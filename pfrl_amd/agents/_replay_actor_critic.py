@@ -1,0 +1,170 @@
+"""Shared plumbing of the continuous-action replay agents (DDPG, TD3).
+
+Everything these agents have in common with the reference's own copies of the
+same code (pfrl/agents/ddpg.py:253-303, td3.py:262-317): burn-in / explorer
+acting, the per-env append + ``stop_current_episode`` + ``update_if_necessary``
+loop, device-resident statistics -- plus what is specific to this package: the
+HBM replay store binding and HIP-graph capture of the whole update
+(:class:`pfrl_amd.agents.graphed_update.CapturedStep`).
+"""
+import torch
+
+from pfrl_amd.agent import AttributeSavingMixin, BatchAgent
+from pfrl_amd.agents.dqn import _DeviceRecord, _mean_or_nan
+from pfrl_amd.replay_buffer import ReplayUpdater, batch_experiences
+from pfrl_amd.utils.contexts import evaluating
+
+
+class ReplayActorCritic(AttributeSavingMixin, BatchAgent):
+    # name -> window of the statistics the update produces (subclass)
+    _STATS = ()
+
+    def _setup(self, modules, gpu, replay_buffer, phi, gamma, explorer, batch_states, logger,
+               burnin_action_func, minibatch_size, replay_start_size, update_interval,
+               n_times_update, use_graphs):
+        if gpu is not None and gpu >= 0:
+            assert torch.cuda.is_available()
+            self.device = torch.device("cuda:{}".format(gpu))
+            for m in modules:
+                m.to(self.device)
+        else:
+            self.device = torch.device("cpu")
+        self.gpu = gpu
+        self.replay_buffer = replay_buffer
+        if hasattr(replay_buffer, "bind"):
+            replay_buffer.bind(self.device, phi)
+        self.phi = phi
+        self.gamma = gamma
+        self.explorer = explorer
+        self.batch_states = batch_states
+        self.logger = logger
+        self.burnin_action_func = burnin_action_func
+        self.replay_updater = ReplayUpdater(
+            replay_buffer=replay_buffer, update_func=self.update, batchsize=minibatch_size,
+            episodic_update=False, n_times_update=n_times_update,
+            replay_start_size=replay_start_size, update_interval=update_interval)
+        self.t = 0
+        self.batch_last_obs = []
+        self.batch_last_action = []
+        self._records = {name: _DeviceRecord(win) for name, win in self._STATS}
+        self._stat_sink = None
+        from pfrl_amd import distributed
+
+        on_gpu = (self.device.type == "cuda" and getattr(replay_buffer, "is_device", False)
+                  and distributed.world_size() == 1)
+        self.use_graphs = on_gpu if use_graphs is None else bool(use_graphs and on_gpu)
+        self._captured = None
+
+    # -- statistics ---------------------------------------------------------------
+    def _stat(self, **tensors):
+        if self._stat_sink is not None:
+            self._stat_sink.update({k: v.detach() for k, v in tensors.items()})
+        else:
+            self._record_stats(tensors)
+
+    def _record_stats(self, st):
+        for name, t in st.items():
+            self._records[name].extend(t)
+
+    def _mean_stat(self, name):
+        return _mean_or_nan(self._records[name].values())
+
+    # -- hooks for subclasses -------------------------------------------------------
+    def _policy(self):
+        raise NotImplementedError
+
+    def _burnin_over(self):
+        raise NotImplementedError
+
+    def _variant(self):
+        """Hashable description of what the NEXT update will do (one graph each)."""
+        return None
+
+    def _update_impl(self, batch, variant):
+        raise NotImplementedError
+
+    def _after_update(self, variant):
+        pass
+
+    def _graph_modules(self):
+        raise NotImplementedError
+
+    def _graph_optimizers(self):
+        raise NotImplementedError
+
+    def _on_env_step(self):
+        pass
+
+    # -- learning -----------------------------------------------------------------------
+    def _update_core(self, batch, variant=None):
+        """The captured step: statistics come back as one flat device vector."""
+        self._stat_sink = {}
+        try:
+            self._update_impl(batch, variant)
+            sink = self._stat_sink
+        finally:
+            self._stat_sink = None
+        names = sorted(sink)
+        return {"stats": torch.cat([sink[k].reshape(-1).float() for k in names]),
+                "names": names, "sizes": [sink[k].numel() for k in names]}
+
+    def update(self, experiences, errors_out=None):
+        batch = batch_experiences(experiences, self.device, self.phi, self.gamma)
+        variant = self._variant()
+        state = batch.get("state")
+        if self.use_graphs and isinstance(state, torch.Tensor) and state.is_cuda:
+            if self._captured is None:
+                from pfrl_amd.agents.graphed_update import CapturedStep
+
+                self._captured = CapturedStep(self._update_core, self._graph_modules(),
+                                              self._graph_optimizers(), self.device)
+            tensors = {k: v for k, v in batch.items() if isinstance(v, torch.Tensor)}
+            try:
+                out = self._captured.run(tensors, variant)
+            except Exception:
+                self.logger.exception("HIP-graph capture of the update failed; running eager")
+                self.use_graphs = False
+                self._captured = None
+                return self.update(experiences, errors_out)
+            flat = out["stats"].clone()   # the graph owns (and overwrites) its outputs
+            self._record_stats(dict(zip(out["names"], torch.split(flat, out["sizes"]))))
+        else:
+            self._update_impl(batch, variant)
+        self._after_update(variant)
+
+    # -- acting / observing -----------------------------------------------------------------
+    def _batch_select_actions(self, batch_obs):
+        with torch.no_grad(), evaluating(self._policy()):
+            xs = self.batch_states(batch_obs, self.device, self.phi)
+            return self._policy()(xs).sample().cpu().numpy()
+
+    def batch_act(self, batch_obs):
+        if not self.training:
+            return self._batch_select_actions(batch_obs)
+        if self.burnin_action_func is not None and not self._burnin_over():
+            actions = [self.burnin_action_func() for _ in range(len(batch_obs))]
+        else:
+            greedy = self._batch_select_actions(batch_obs)
+            actions = [self.explorer.select_action(self.t, lambda i=i: greedy[i])
+                       for i in range(len(greedy))]
+        self.batch_last_obs = list(batch_obs)
+        self.batch_last_action = list(actions)
+        return actions
+
+    def batch_observe(self, batch_obs, batch_reward, batch_done, batch_reset):
+        if not self.training:
+            return
+        rbuf = self.replay_buffer
+        for i in range(len(batch_obs)):
+            self.t += 1
+            self._on_env_step()
+            if self.batch_last_obs[i] is not None:
+                assert self.batch_last_action[i] is not None
+                rbuf.append(state=self.batch_last_obs[i], action=self.batch_last_action[i],
+                            reward=batch_reward[i], next_state=batch_obs[i], next_action=None,
+                            is_state_terminal=batch_done[i], env_id=i)
+                if batch_reset[i] or batch_done[i]:
+                    self.batch_last_obs[i] = None
+                    self.batch_last_action[i] = None
+                    rbuf.stop_current_episode(env_id=i)
+            self.replay_updater.update_if_necessary(self.t)

@@ -333,8 +333,9 @@ class CapturedStep:
             out.extend(b for b in m.buffers())
         return out
 
-    def _capture(self, batch):
+    def _capture(self, batch, variant=None):
         dev = self.device
+        step = (lambda: self.fn(batch)) if variant is None else (lambda: self.fn(batch, variant))
         for opt in self.optimizers:
             if not _make_capturable(opt, dev):
                 raise RuntimeError("optimizer %s has no capturable mode" % type(opt))
@@ -368,7 +369,7 @@ class CapturedStep:
         try:
             with torch.cuda.stream(side), _no_distribution_validation():
                 for _ in range(2):
-                    self.fn(batch)
+                    step()
             cur.wait_stream(side)
             for opt in self.optimizers:
                 _make_capturable(opt, dev)  # state created by the warm-up
@@ -376,7 +377,7 @@ class CapturedStep:
             g = torch.cuda.CUDAGraph()
             kw = {} if self.pool is None else {"pool": self.pool}
             with torch.cuda.graph(g, **kw), _no_distribution_validation():
-                out = self.fn(batch)
+                out = step()
             if self.pool is None:
                 self.pool = g.pool()
         finally:
@@ -384,13 +385,16 @@ class CapturedStep:
             restore()
         return g, out
 
-    def run(self, batch):
-        key = self._key(batch)
+    def run(self, batch, variant=None):
+        """``variant`` (hashable) selects between differently shaped steps over the
+        same buffers (TD3: with / without the delayed policy update); it is passed
+        to ``fn`` as a second argument when not None."""
+        key = (self._key(batch), variant)
         entry = self.graphs.get(key)
         if entry is None:
             if len(self.graphs) >= self.max_graphs:
                 raise RuntimeError("too many distinct minibatch buffers for graph capture")
-            entry = self._capture(batch)
+            entry = self._capture(batch, variant)
             self.graphs[key] = entry
         entry[0].replay()
         return entry[1]

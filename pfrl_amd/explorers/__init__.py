@@ -1,4 +1,5 @@
 from pfrl_amd import explorer as _explorer
+from pfrl_amd.explorers.additive_gaussian import AdditiveGaussian  # NOQA
 from pfrl_amd.explorers.epsilon_greedy import (ConstantEpsilonGreedy,  # NOQA
                                                ExponentialDecayEpsilonGreedy,
                                                LinearDecayEpsilonGreedy)

@@ -2,4 +2,5 @@ from pfrl_amd.nn.atari_cnn import LargeAtariCNN, SmallAtariCNN  # NOQA
 from pfrl_amd.nn.branched import Branched  # NOQA
 from pfrl_amd.nn.mlp import MLP  # NOQA
 from pfrl_amd.nn.noisy_linear import FactorizedNoisyLinear, to_factorized_noisy  # NOQA
-from pfrl_amd.nn.concat_obs_and_action import ConcatObsAndAction, Lambda  # NOQA
+from pfrl_amd.nn.concat_obs_and_action import (BoundByTanh, ConcatObsAndAction, Lambda,  # NOQA
+                                               bound_by_tanh)

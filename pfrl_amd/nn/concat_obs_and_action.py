@@ -20,3 +20,16 @@ class Lambda(nn.Module):
 
     def forward(self, x):
         return self.lambd(x)
+
+
+def bound_by_tanh(x, low, high):
+    """tanh-squash ``x`` into [low, high] (reference pfrl/functions/bound_by_tanh.py)."""
+    assert isinstance(x, torch.Tensor) and low is not None and high is not None
+    low = torch.as_tensor(low, dtype=x.dtype, device=x.device)
+    high = torch.as_tensor(high, dtype=x.dtype, device=x.device)
+    return torch.tanh(x) * ((high - low) / 2) + (high + low) / 2
+
+
+class BoundByTanh(Lambda):
+    def __init__(self, low, high):
+        super().__init__(lambda x: bound_by_tanh(x, low, high))

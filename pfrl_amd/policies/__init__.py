@@ -43,3 +43,13 @@ class GaussianHeadWithDiagonalCovariance(nn.Module):
         scale = self.var_func(pre_var).sqrt()
         return torch.distributions.Independent(
             torch.distributions.Normal(loc=mean, scale=scale), 1)
+
+
+class DeterministicHead(nn.Module):
+    """Deterministic policy output as a distribution (reference
+    pfrl/policies/deterministic_policy.py:7-11)."""
+
+    def forward(self, loc):
+        from pfrl_amd.distributions import Delta
+
+        return torch.distributions.Independent(Delta(loc=loc), 1)

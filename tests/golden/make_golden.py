@@ -724,6 +724,90 @@ def c51_projection_golden():
     print("c51 projection cases 3")
 
 
+def _det_nets(obs_dim, act_dim, nn_mod, policies_mod):
+    """Deterministic policy (tanh-bounded) and a Q-function for the DDPG / TD3 traces;
+    built from the given package's modules so both sides construct identical nets."""
+    policy = torch.nn.Sequential(
+        torch.nn.Linear(obs_dim, 32), torch.nn.ReLU(), torch.nn.Linear(32, act_dim),
+        nn_mod.BoundByTanh(low=-np.ones(act_dim, dtype=np.float32),
+                           high=np.ones(act_dim, dtype=np.float32)),
+        policies_mod.DeterministicHead())
+
+    def q():
+        return torch.nn.Sequential(nn_mod.ConcatObsAndAction(),
+                                   torch.nn.Linear(obs_dim + act_dim, 32), torch.nn.ReLU(),
+                                   torch.nn.Linear(32, 1))
+
+    return policy, q
+
+
+def _shifted_smoothing(a):
+    # deterministic stand-in for the clipped Gaussian target smoothing (the device and
+    # host torch generators differ by construction)
+    return torch.clamp(a + 0.05, -1, 1)
+
+
+def td3_ddpg_traces(steps=260, N=2, obs_dim=24, act_dim=3):
+    sys.path.insert(0, os.path.join(HERE, "..", ".."))
+    import tempfile
+
+    from pfrl import agents, experiments, explorers, replay_buffers
+
+    from pfrl_amd.envs.synthetic import HostSyntheticVectorObsEnv
+
+    flat = lambda m: np.concatenate([p.detach().numpy().ravel() for p in m.parameters()])
+    for kind in ("td3", "ddpg"):
+        pfrl.utils.set_random_seed(0)
+        env = HostSyntheticVectorObsEnv(N, obs_dim=obs_dim, act_dim=act_dim, seed=4, p_done=0.03)
+        torch.manual_seed(2468)
+        policy, q = _det_nets(obs_dim, act_dim, pfrl.nn, pfrl.policies)
+        ex = explorers.AdditiveGaussian(scale=0.1, low=-1.0, high=1.0)
+        burnin = lambda: np.random.uniform(-1, 1, size=act_dim).astype(np.float32)
+        rbuf = replay_buffers.ReplayBuffer(500)
+        if kind == "td3":
+            q1, q2 = q(), q()
+            opts = [torch.optim.SGD(m.parameters(), lr=1e-2) for m in (policy, q1, q2)]
+            ag = agents.TD3(policy, q1, q2, opts[0], opts[1], opts[2], rbuf, gamma=0.99,
+                            explorer=ex, gpu=-1, replay_start_size=40, minibatch_size=16,
+                            update_interval=1, soft_update_tau=5e-3, burnin_action_func=burnin,
+                            policy_update_delay=2,
+                            target_policy_smoothing_func=_shifted_smoothing)
+            crit, tgt = q1, ag.target_q_func1
+            loss_of = lambda: [ag.q_func1_loss_record[-1], ag.q_func2_loss_record[-1]]
+        else:
+            q1 = q()
+            opts = [torch.optim.SGD(m.parameters(), lr=1e-2) for m in (policy, q1)]
+            ag = agents.DDPG(policy, q1, opts[0], opts[1], rbuf, gamma=0.99, explorer=ex, gpu=-1,
+                             replay_start_size=40, minibatch_size=16, update_interval=1,
+                             target_update_interval=7, target_update_method="soft",
+                             soft_update_tau=5e-2, burnin_action_func=burnin)
+            crit, tgt = q1, ag.target_q_function
+            loss_of = lambda: [ag.critic_loss_record[-1], ag.actor_loss_record[-1]]
+        actions, losses = [], []
+        orig_act = ag.batch_act
+
+        def spy_act(obs, orig_act=orig_act):
+            a = orig_act(obs)
+            actions.append(np.asarray(a, dtype=np.float32))
+            return a
+
+        ag.batch_act = spy_act
+        orig_update = ag.update
+
+        def spy_update(exps, errors_out=None, orig_update=orig_update):
+            orig_update(exps, errors_out)
+            losses.append(loss_of())
+
+        ag.replay_updater.update_func = spy_update
+        experiments.train_agent_batch(ag, env, steps, tempfile.mkdtemp())
+        np.savez_compressed(
+            os.path.join(HERE, "agent_trace_%s.npz" % kind), actions=np.asarray(actions),
+            losses=np.asarray(losses), policy_params=flat(policy), critic_params=flat(crit),
+            target_critic_params=flat(tgt),
+            stats=np.asarray([float(v) for _, v in ag.get_statistics()]))
+        print(kind, "trace updates", len(losses))
+
+
 def cartpole_trace(steps=1500):
     """BASELINE configs[0]: examples/gym/train_dqn_gym.py settings (FC Q-function 100x2,
     Adam, ReplayBuffer(5e5), LinearDecayEpsilonGreedy) through the reference's
@@ -992,6 +1076,7 @@ if __name__ == "__main__":
     ppo_trace()
     a2c_trace()
     cartpole_trace()
+    td3_ddpg_traces()
     c51_projection_golden()
     c51_loss_golden()
     c51_agent_trace()

@@ -501,3 +501,108 @@ def test_sac_graph_replay_equals_eager_with_sampling_noise():
     np.testing.assert_allclose(graph["q_losses"], eager["q_losses"], rtol=1e-4, atol=1e-6)
     np.testing.assert_allclose(graph["policy_params"], eager["policy_params"], rtol=1e-4,
                                atol=1e-6)
+
+
+# ---------------------------------------------------------------------------
+# TD3 / DDPG (replay agents that reuse the a6-a11 data path)
+# ---------------------------------------------------------------------------
+def _shifted_smoothing(a):
+    return torch.clamp(a + 0.05, -1, 1)
+
+
+def _run_det_agent(kind, gpu, **agent_kw):
+    import pfrl_amd as pfrl
+    from pfrl_amd import agents, explorers, replay_buffers
+    from pfrl_amd.envs.synthetic import HostSyntheticVectorObsEnv
+
+    obs_dim, act_dim, N = 24, 3, 2
+    pfrl.utils.set_random_seed(0)
+    env = HostSyntheticVectorObsEnv(N, obs_dim=obs_dim, act_dim=act_dim, seed=4, p_done=0.03)
+    torch.manual_seed(2468)
+    policy = torch.nn.Sequential(
+        torch.nn.Linear(obs_dim, 32), torch.nn.ReLU(), torch.nn.Linear(32, act_dim),
+        pfrl.nn.BoundByTanh(low=-np.ones(act_dim, dtype=np.float32),
+                            high=np.ones(act_dim, dtype=np.float32)),
+        pfrl.policies.DeterministicHead())
+
+    def q():
+        return torch.nn.Sequential(pfrl.nn.ConcatObsAndAction(),
+                                   torch.nn.Linear(obs_dim + act_dim, 32), torch.nn.ReLU(),
+                                   torch.nn.Linear(32, 1))
+
+    ex = explorers.AdditiveGaussian(scale=0.1, low=-1.0, high=1.0)
+    burnin = lambda: np.random.uniform(-1, 1, size=act_dim).astype(np.float32)
+    rbuf = replay_buffers.ReplayBuffer(500)
+    if kind == "td3":
+        q1, q2 = q(), q()
+        opts = [torch.optim.SGD(m.parameters(), lr=1e-2) for m in (policy, q1, q2)]
+        ag = agents.TD3(policy, q1, q2, opts[0], opts[1], opts[2], rbuf, gamma=0.99, explorer=ex,
+                        gpu=gpu, replay_start_size=40, minibatch_size=16, update_interval=1,
+                        soft_update_tau=5e-3, burnin_action_func=burnin, policy_update_delay=2,
+                        target_policy_smoothing_func=_shifted_smoothing, **agent_kw)
+        crit, tgt = q1, ag.target_q_func1
+        loss_of = lambda: [float(ag._records["loss1"].values()[-1]),
+                           float(ag._records["loss2"].values()[-1])]
+    else:
+        q1 = q()
+        opts = [torch.optim.SGD(m.parameters(), lr=1e-2) for m in (policy, q1)]
+        ag = agents.DDPG(policy, q1, opts[0], opts[1], rbuf, gamma=0.99, explorer=ex, gpu=gpu,
+                         replay_start_size=40, minibatch_size=16, update_interval=1,
+                         target_update_interval=7, target_update_method="soft",
+                         soft_update_tau=5e-2, burnin_action_func=burnin, **agent_kw)
+        crit, tgt = q1, ag.target_q_function
+        loss_of = lambda: [float(ag._records["critic_loss"].values()[-1]),
+                           float(ag._records["actor_loss"].values()[-1])]
+    actions, losses = [], []
+    orig_act = ag.batch_act
+
+    def spy_act(obs):
+        a = orig_act(obs)
+        actions.append(np.asarray(a, dtype=np.float32))
+        return a
+
+    ag.batch_act = spy_act
+    orig_update = ag.update
+
+    def spy_update(exps, errors_out=None):
+        orig_update(exps, errors_out)
+        losses.append(loss_of())
+
+    ag.replay_updater.update_func = spy_update
+    pfrl.experiments.train_agent_batch(ag, env, 260, tempfile.mkdtemp())
+    flat = lambda m: np.concatenate([p.detach().cpu().numpy().ravel() for p in m.parameters()])
+    return dict(actions=np.asarray(actions), losses=np.asarray(losses),
+                policy_params=flat(policy), critic_params=flat(crit),
+                target_critic_params=flat(tgt), agent=ag, rbuf=rbuf,
+                stats=np.asarray([float(v) for _, v in ag.get_statistics()]))
+
+
+def _compare_det(got, g):
+    np.testing.assert_allclose(got["actions"], g["actions"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(got["losses"], g["losses"], rtol=1e-4, atol=1e-6)
+    for k in ("policy_params", "critic_params", "target_critic_params"):
+        np.testing.assert_allclose(got[k], g[k], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(got["stats"], g["stats"], rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("kind", ["td3", "ddpg"])
+def test_td3_ddpg_host_mode_matches_reference(kind):
+    _compare_det(_run_det_agent(kind, None), np.load(os.path.join(GOLDEN,
+                                                                  "agent_trace_%s.npz" % kind)))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("use_graphs", [False, True])
+@pytest.mark.parametrize("kind", ["td3", "ddpg"])
+def test_td3_ddpg_device_replay_matches_reference(kind, use_graphs):
+    """HBM replay store with float32 vector observations / actions; with graphs the
+    whole update (TD3: both step shapes) replays from captured HIP graphs."""
+    got = _run_det_agent(kind, 0, use_graphs=use_graphs)
+    ag = got["agent"]
+    assert got["rbuf"].is_device
+    if use_graphs:
+        assert ag.use_graphs and ag._captured is not None
+        assert len(ag._captured.graphs) >= (2 if kind == "td3" else 1)
+    else:
+        assert ag._captured is None
+    _compare_det(got, np.load(os.path.join(GOLDEN, "agent_trace_%s.npz" % kind)))
