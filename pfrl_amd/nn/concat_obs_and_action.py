@@ -30,6 +30,22 @@ def bound_by_tanh(x, low, high):
     return torch.tanh(x) * ((high - low) / 2) + (high + low) / 2
 
 
-class BoundByTanh(Lambda):
+class BoundByTanh(nn.Module):
+    """``bound_by_tanh`` as a module.  The bounds are uploaded once per (device,
+    dtype) instead of at every call (a host->device copy per forward pass, which
+    also cannot be captured in a HIP graph); same arithmetic."""
+
     def __init__(self, low, high):
-        super().__init__(lambda x: bound_by_tanh(x, low, high))
+        super().__init__()
+        assert low is not None and high is not None
+        self.low, self.high = low, high
+        self._consts = {}
+
+    def forward(self, x):
+        key = (x.device, x.dtype)
+        c = self._consts.get(key)
+        if c is None:
+            low = torch.as_tensor(self.low, dtype=x.dtype, device=x.device)
+            high = torch.as_tensor(self.high, dtype=x.dtype, device=x.device)
+            c = self._consts[key] = ((high - low) / 2, (high + low) / 2)
+        return torch.tanh(x) * c[0] + c[1]
