@@ -111,7 +111,7 @@ class DQN(agent.AttributeSavingMixin, agent.BatchAgent):
                  batch_accumulator="mean", episodic_update_len=None, logger=getLogger(__name__),
                  batch_states=batch_states, recurrent=False, max_grad_norm=None,
                  use_graphs=None, step_fused_gather=None, batch_target_pass=None,
-                 fused_td_loss=True, replay_overlap=None):
+                 fused_td_loss=True, replay_overlap=None, step_fused_chunks=(0.125,)):
         self.model = q_function
         if gpu is not None and gpu >= 0:
             assert torch.cuda.is_available()
@@ -177,6 +177,8 @@ class DQN(agent.AttributeSavingMixin, agent.BatchAgent):
         self.batch_target_pass = self.step_fused_gather if batch_target_pass is None else \
             bool(batch_target_pass and self.step_fused_gather)
         self.fused_td_loss = bool(fused_td_loss)
+        # env-range boundaries (fractions of num_envs) of the step-fused path
+        self.step_fused_chunks = tuple(step_fused_chunks)
         self._analytic_backward = None
         self._graphed = None
         self._last_y = None
@@ -460,28 +462,40 @@ class DQN(agent.AttributeSavingMixin, agent.BatchAgent):
         The entry ring keeps `slack` spare slots, so rows appended "early" never
         overwrite entries still visible to an earlier update of this step."""
         rbuf = self.replay_buffer
-        up = self.replay_updater
         n_env = len(batch_obs)
+        # The step is processed in a few env ranges, a small one first: while the GPU
+        # runs the first range's updates the host prepares the next range (appends,
+        # index draws, launches), instead of the GPU idling through the whole
+        # preparation.  Order of appends, RNG draws, target syncs and updates is the
+        # reference's in every case.
+        cuts = sorted({0, n_env} | {int(n_env * f) for f in self.step_fused_chunks})
+        for lo, hi in zip(cuts[:-1], cuts[1:]):
+            self._observe_range_fused(lo, hi, batch_obs, batch_reward, batch_done, batch_reset)
+
+    def _observe_range_fused(self, lo, hi, batch_obs, batch_reward, batch_done, batch_reset):
+        rbuf = self.replay_buffer
+        up = self.replay_updater
         t0 = self.t
         plan_env, plan_seqs = [], []
-        for i in range(n_env):
+        for i in range(lo, hi):
             self._append_transition(i, batch_obs, batch_reward, batch_done, batch_reset)
-            if len(rbuf) >= up.replay_start_size and (t0 + i + 1) % up.update_interval == 0:
+            if (len(rbuf) >= up.replay_start_size
+                    and (t0 + (i - lo) + 1) % up.update_interval == 0):
                 for _ in range(up.n_times_update):
                     plan_env.append(i)
                     plan_seqs.append(rbuf.lookahead_sample(up.batchsize))
         big = rbuf.fetch_many(plan_seqs, self.phi, self.gamma) if plan_seqs else None
         if big is not None and self.batch_target_pass and self._target_is_deterministic():
-            # no target sync may fall inside this step (the targets would go stale)
+            # no target sync may fall inside this range (the targets would go stale)
             tui = self.target_update_interval
-            if (t0 + n_env) // tui == t0 // tui:
+            if (t0 + (hi - lo)) // tui == t0 // tui:
                 ns = big["next_state"]
                 U, B = ns.shape[0], ns.shape[1]
                 raw = self._precompute_target_raw(ns.view((U * B,) + tuple(ns.shape[2:])))
                 big["target_next_raw"] = raw.view((U, B) + tuple(raw.shape[1:]))
         p = 0
         deferred = [] if self.use_graphs else None
-        for i in range(n_env):
+        for i in range(lo, hi):
             self.t += 1
             self._cumulative_steps += 1
             if self.t % self.target_update_interval == 0:

@@ -131,6 +131,17 @@ def test_dqn_uniform_device_matches_reference():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("chunks", [(), (0.5,), (0.25, 0.5, 0.75)])
+def test_dqn_step_fused_env_ranges_match_reference(chunks):
+    """The step-fused path cut into env ranges (host preparation of range k+1 overlaps
+    the GPU's updates of range k): same trace for every cut."""
+    g = np.load(os.path.join(GOLDEN, "agent_trace_dqn_uniform_n1.npz"))
+    got = _run("dqn", False, 1, False, gpu=0, step_fused_chunks=chunks)
+    assert got["agent"].step_fused_gather
+    _compare(got, g)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("priority_pow", ["host_libm", "device"])
 def test_double_dqn_prioritized_n3_device_matches_reference(priority_pow):
     """DoubleDQN + PrioritizedReplayBuffer(num_steps=3): sampled index stream,
