@@ -179,6 +179,7 @@ class DQN(agent.AttributeSavingMixin, agent.BatchAgent):
         self.fused_td_loss = bool(fused_td_loss)
         # env-range boundaries (fractions of num_envs) of the step-fused path
         self.step_fused_chunks = tuple(step_fused_chunks)
+        self._target_raw_bufs = {}
         self._analytic_backward = None
         self._graphed = None
         self._last_y = None
@@ -492,7 +493,15 @@ class DQN(agent.AttributeSavingMixin, agent.BatchAgent):
                 ns = big["next_state"]
                 U, B = ns.shape[0], ns.shape[1]
                 raw = self._precompute_target_raw(ns.view((U * B,) + tuple(ns.shape[2:])))
-                big["target_next_raw"] = raw.view((U, B) + tuple(raw.shape[1:]))
+                # captured updates are keyed by buffer addresses: park the values in a
+                # persistent buffer instead of whatever block the allocator handed out
+                key = (U, B) + tuple(raw.shape[1:])
+                buf = self._target_raw_bufs.get(key)
+                if buf is None:
+                    buf = self._target_raw_bufs[key] = torch.empty(
+                        key, dtype=raw.dtype, device=raw.device)
+                buf.view(raw.shape).copy_(raw)
+                big["target_next_raw"] = buf
         p = 0
         deferred = [] if self.use_graphs else None
         for i in range(lo, hi):
