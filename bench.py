@@ -61,6 +61,9 @@ def parse_args():
                    help="do not let MIOpen search conv algorithms")
     p.add_argument("--nchw", dest="channels_last", action="store_false",
                    help="keep the network in NCHW (default: channels_last)")
+    p.add_argument("--chunks", type=str, default=None,
+                   help="dqn: env-range cut points of the step-fused path as fractions, e.g. "
+                        "'0.125' (default) or '' for one range")
     p.add_argument("--torch-optimizer", action="store_true",
                    help="stock torch.optim.RMSprop instead of the fused HIP step")
     args = p.parse_args()
@@ -269,6 +272,8 @@ def build_agent(args, device, rank):
         replay_start_size=5 * 10 ** 4, target_update_interval=3 * 10 ** 4, clip_delta=True,
         update_interval=args.update_interval, minibatch_size=args.minibatch,
         batch_accumulator="sum", phi=phi)
+    if args.chunks is not None:
+        agent.step_fused_chunks = tuple(float(x) for x in args.chunks.split(",") if x)
     agent.grad_reducer.broadcast_parameters(agent.model)
     agent.sync_target_network()
     return agent, env, rbuf

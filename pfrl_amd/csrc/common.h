@@ -8,6 +8,11 @@
 
 extern "C" void pfrl_set_error(const char *msg);
 
+// Output size from which the gather kernels use non-temporal stores (the minibatch is
+// read once by the next kernel and would only evict useful lines from L2 / MALL).
+// PFRL_NT_MIN_BYTES overrides the default for tuning.
+int64_t pfrl_nt_min_bytes();
+
 // bench.py roofline support (defined in replay.hip): when profiling is enabled,
 // returns a start/stop event pair to attach to ONE dispatch with
 // hipExtLaunchKernelGGL; both are nullptr otherwise.

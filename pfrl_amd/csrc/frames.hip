@@ -163,7 +163,7 @@ extern "C" int pfrl_batch_states_u8(const void *frames, int64_t frame_bytes, con
                                     int64_t n_refs, float divisor, float *out, void *stream) {
     PFRL_CHECK_ARG(frame_bytes > 0 && (frame_bytes & 3) == 0, "frame_bytes must be a multiple of 4");
     if (n_refs <= 0) return 0;
-    const bool nt = n_refs * frame_bytes * 4 >= ((int64_t)128 << 20);
+    const bool nt = n_refs * frame_bytes * 4 >= pfrl_nt_min_bytes();
     const dim3 grid((unsigned)n_refs), block(kThreads);
     hipStream_t st = (hipStream_t)stream;
     const uint8_t *fr = (const uint8_t *)frames;

@@ -8,6 +8,8 @@
 // plus < 0.1 % metadata.
 #include <hip/hip_ext.h>
 
+#include <stdlib.h>
+
 #include <vector>
 
 #include "common.h"
@@ -244,7 +246,7 @@ static void launch_be(const pfrl_table_t *tab, const void *frames, int64_t frame
                       float *out_terminal, float *out_discount, hipStream_t stream) {
     // output of this launch (both stacks); beyond ~128 MB it cannot be cache resident
     const int64_t out_bytes = 2 * B * tab->k * frame_bytes * (MODE == 2 ? 1 : 4);
-    if (MODE != 2 && out_bytes >= ((int64_t)128 << 20))
+    if (MODE != 2 && out_bytes >= pfrl_nt_min_bytes())
         launch_be2<MODE, true>(tab, frames, frame_bytes, divisor, entry_slots, B, gp, out_state,
                                out_next_state, out_action, out_reward, out_terminal, out_discount,
                                stream);
@@ -277,6 +279,14 @@ extern "C" int pfrl_batch_experiences(const pfrl_table_t *tab, const void *frame
         launch_be<0>(tab, frames, frame_bytes, divisor, entry_slots, B, gp, out_state,
                      out_next_state, out_action, out_reward, out_terminal, out_discount, s);
     PFRL_LAUNCH_CHECK();
+}
+
+int64_t pfrl_nt_min_bytes() {
+    static const int64_t v = [] {
+        const char *e = getenv("PFRL_NT_MIN_BYTES");
+        return e != nullptr && *e ? (int64_t)atoll(e) : ((int64_t)32 << 20);
+    }();
+    return v;
 }
 
 // Shared with frames.hip (declared in common.h): hands out an event pair for one
