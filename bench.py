@@ -480,52 +480,49 @@ def main():
     k_units = [n for n, kd in zip(all_units, all_kinds) if kd == kind]
     roofline = None
     if k_us:
+        # The kernel is launched in a few shapes (DQN: a small and a large env range
+        # per step; PPO: acting, value pass and minibatch gathers).  The roofline
+        # object describes the shape that moves the most bytes; the aggregate over
+        # every timed launch of the kernel is reported next to it.
+        classes = {}
+        for u, n in zip(k_us, k_units):
+            c = classes.setdefault(n, [0, 0.0])
+            c[0] += 1
+            c[1] += u
+        main_units = max(classes, key=lambda n: n * classes[n][0])
+        n_main, us_main = classes[main_units]
+        bytes_main = per_unit * main_units
+        achieved = bytes_main * n_main / (us_main * 1e-6) / 1e9
         tot_bytes = sum(per_unit * b for b in k_units)
         tot_s = sum(k_us) * 1e-6
-        achieved = tot_bytes / tot_s / 1e9
         roofline = {
             "bound": "hbm", "kernel": kname,
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-            "bytes_per_launch": int(tot_bytes / len(k_us)),
-            "%s_per_launch" % unit_name: int(np.mean(k_units)),
-            "avg_launch_us": round(tot_s / len(k_us) * 1e6, 2), "launches_timed": len(k_us),
+            "bytes_per_launch": int(bytes_main),
+            "%s_per_launch" % unit_name: int(main_units),
+            "avg_launch_us": round(us_main / n_main, 2), "launches_timed": n_main,
+            "share_of_kernel_bytes": round(bytes_main * n_main / tot_bytes, 4),
+            "all_launches": {
+                "achieved": round(tot_bytes / tot_s / 1e9, 1), "launches": len(k_us),
+                "shapes": {str(n): {"launches": c[0], "avg_launch_us": round(c[1] / c[0], 2)}
+                           for n, c in sorted(classes.items())}},
             "timing": "hipEvent pair attached to each dispatch (hipExtLaunchKernelGGL) on the "
                       "launch stream, inside the timed region",
         }
         # HBM traffic cannot be sampled from inside the process: it is taken from
         # the committed rocprofv3 --pmc passes of this same command
-        # (profiles/r01_pmc_gather.json), valid for the 2048-entry launch only.
+        # (profiles/r01e_pmc_gather.json, tools/pmc_gather.py), per launch shape.
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_gather.json")))
-            kk = pmc["kernels"]["k_batch_experiences<0,long> (2048 entries)"]
-            if args.algo == "dqn" and roofline["entries_per_launch"] == 2048:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01e_pmc_gather.json")))
+            kk = pmc["kernels"].get("%s (%d %s)" % (kname, main_units, unit_name))
+            if kk and "traffic_bytes_per_launch" in kk:
                 roofline["traffic"] = kk["traffic_bytes_per_launch"]
-                roofline["traffic_source"] = "profiles/r01_pmc_gather.json (rocprofv3 --pmc " \
+                roofline["traffic_source"] = "profiles/r01e_pmc_gather.json (rocprofv3 --pmc " \
                                              "FETCH_SIZE / WRITE_SIZE, separate passes, corrected)"
         except Exception:
             pass
 
-    if rank == 0:
-        total_env_steps = world * N * args.steps
-        value = total_env_steps / elapsed
-        out = {
-            "metric": "env-steps/sec whole node (%s %d envs per GPU)" % (args.algo.upper(), N),
-            "value": round(value, 1), "unit": "env-steps/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-            "data": "synthetic (host frames over PCIe)" if args.host_env else "synthetic",
-            "config": {
-                "workload": workload_description(args, N, rbuf),
-                "global_envs": world * N, "updates_in_timed_region": n_updates,
-                "parallelism": "env-sharded dp%d, per-GPU-local replay" % world,
-                "prefill_s": round(t_fill, 1),
-            },
-            "roofline": roofline,
-        }
-        if not args.no_cpu_baseline and world == 1 and args.algo == "dqn":
-            out["cpu_baseline"] = cpu_baseline(args, args.cpu_baseline_seconds)
     if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
     sys.stdout.flush()

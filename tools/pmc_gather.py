@@ -1,0 +1,85 @@
+"""Summarise rocprofv3 --pmc passes for the two gather kernels.
+
+Usage (on the GPU box; one pass per counter, kernel-trace only):
+    cd /tmp && export TMPDIR=/tmp
+    rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -- python bench.py ...
+    rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -- python bench.py ...
+    python tools/pmc_gather.py $OUT/fetch $OUT/write > profiles/rNN_pmc_gather.json
+
+Counter_Value of FETCH_SIZE / WRITE_SIZE is in KiB.  WRITE_SIZE matches the
+algorithmic writes exactly; FETCH_SIZE under-reports streaming reads on gfx950
+(MI355X_MICROARCH.md, HBM section) and is calibrated on k_batch_states_u8 at 256
+observations, whose 1024 distinct frames are a known 7 225 344 B.
+"""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+FRAME = 84 * 84
+
+
+def load(d, counter):
+    out = defaultdict(list)
+    for path in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        with open(path) as f:
+            for r in csv.DictReader(f):
+                if r.get("Counter_Name") != counter:
+                    continue
+                name = r["Kernel_Name"]
+                if "k_batch_experiences" in name:
+                    kind = "k_batch_experiences"
+                elif "k_batch_states_u8" in name:
+                    kind = "k_batch_states_u8"
+                else:
+                    continue
+                blocks = int(r["Grid_Size"]) // int(r["Workgroup_Size"])
+                out[(kind, blocks)].append(float(r["Counter_Value"]))
+    return out
+
+
+def main():
+    fetch = load(sys.argv[1], "FETCH_SIZE")
+    write = load(sys.argv[2], "WRITE_SIZE")
+    res = {"unit_note": __doc__.split("Counter_Value")[1].strip().replace("\n", " "),
+           "kernels": {}}
+    # calibration: act gather of 256 observations = 1024 frame workgroups
+    cal = None
+    key = ("k_batch_states_u8", 1024)
+    if key in fetch:
+        kib = sum(fetch[key]) / len(fetch[key])
+        cal = 4 * 256 * FRAME / (kib * 1024)
+    res["fetch_calibration_factor"] = cal
+    for (kind, blocks) in sorted(set(fetch) | set(write)):
+        f = fetch.get((kind, blocks), [])
+        w = write.get((kind, blocks), [])
+        if kind == "k_batch_experiences":
+            entries = (blocks - 1) // 8          # 2 * B * k frame blocks + scalar blocks
+            alg_r, alg_w = entries * 8 * FRAME, entries * 8 * FRAME * 4
+            label = "%s (%d entries)" % (kind, entries)
+        else:
+            frames = blocks
+            alg_r, alg_w = frames * FRAME, frames * FRAME * 4
+            label = "%s (%d frames)" % (kind, frames)
+        item = {"launches": max(len(f), len(w)), "algorithmic_read_B": alg_r,
+                "algorithmic_write_B": alg_w}
+        if f:
+            item["FETCH_SIZE_KiB"] = round(sum(f) / len(f), 2)
+        if w:
+            item["WRITE_SIZE_KiB"] = round(sum(w) / len(w), 2)
+        if f and w and cal:
+            rb = item["FETCH_SIZE_KiB"] * 1024 * cal
+            wb = item["WRITE_SIZE_KiB"] * 1024
+            item["fetch_bytes_corrected"] = int(rb)
+            item["write_bytes"] = int(wb)
+            item["traffic_bytes_per_launch"] = int(rb + wb)
+            item["algorithmic_bytes_per_launch"] = alg_r + alg_w
+            item["traffic_over_algorithmic"] = round((rb + wb) / (alg_r + alg_w), 4)
+        res["kernels"][label] = item
+    json.dump(res, sys.stdout, indent=1)
+
+
+if __name__ == "__main__":
+    main()
