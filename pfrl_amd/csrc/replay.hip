@@ -186,6 +186,121 @@ __global__ __launch_bounds__(kThreads) void k_batch_experiences(
     for (int i = 0; i < ad; ++i) out_action[b * ad + i] = src[t0 * ad + i];
 }
 
+// Persistent form of the frame part: P workgroups walk the 2*B*k output frames
+// with stride P.  The slot of the NEXT frame is resolved (three dependent scalar
+// loads) and its dwords are requested before the current frame's stores are
+// issued, so neither the index chain nor the HBM read latency is exposed between
+// frames, and no workgroup launch/drain happens per 7 KB of input.
+// Requires frame_bytes / 4 <= kThreads * kUnroll (one pass per frame) and u8 input.
+template <int MODE, typename ActT, bool NT>
+__global__ __launch_bounds__(kThreads) void k_batch_experiences_persist(
+    pfrl_table_t tab, const uint8_t *__restrict__ frames, int64_t frame_bytes, float divisor,
+    const int32_t *__restrict__ entry_slots, int64_t B, GammaPow gp, uint8_t *__restrict__ out_state,
+    uint8_t *__restrict__ out_next, ActT *__restrict__ out_action, float *__restrict__ out_reward,
+    float *__restrict__ out_terminal, float *__restrict__ out_discount, int P) {
+    const int tid = threadIdx.x;
+    if ((int)blockIdx.x >= P) {
+        // scalar collapse (same as k_batch_experiences)
+        const int64_t b = (int64_t)(blockIdx.x - P) * kThreads + tid;
+        if (b >= B) return;
+        const int64_t e = entry_slots[b];
+        const int len = tab.e_len[e];
+        double acc = 0.0;
+        bool any = false;
+        for (int i = 0; i < len; ++i) {
+            const int64_t t = tab.e_tids[e * tab.n + i];
+            acc = __dadd_rn(acc, __dmul_rn(gp.g[i], tab.t_reward[t]));
+            any |= tab.t_terminal[t] != 0;
+        }
+        out_reward[b] = (float)acc;
+        out_terminal[b] = any ? 1.0f : 0.0f;
+        out_discount[b] = (float)gp.g[len];
+        const int64_t t0 = tab.e_tids[e * tab.n];
+        const int ad = tab.act_dim > 0 ? tab.act_dim : 1;
+        const ActT *src = reinterpret_cast<const ActT *>(tab.t_action);
+        for (int i = 0; i < ad; ++i) out_action[b * ad + i] = src[t0 * ad + i];
+        return;
+    }
+    const int64_t nf = B * tab.k;
+    const int64_t total = 2 * nf;
+    const int nd = (int)(frame_bytes >> 2);
+    const int64_t out_frame_bytes = 4 * frame_bytes;
+
+    auto resolve = [&](int64_t f, const uint32_t *&src, float4 *&dst) {
+        const bool is_next = f >= nf;
+        const int64_t ff = is_next ? f - nf : f;
+        const int64_t b = ff / tab.k;
+        const int j = (int)(ff - b * tab.k);
+        const int64_t e = entry_slots[b];
+        int64_t slot;
+        if (!is_next) {
+            slot = tab.t_state_ref[(int64_t)tab.e_tids[e * tab.n] * tab.k + j];
+        } else {
+            const int len = tab.e_len[e];
+            slot = tab.t_next_ref[(int64_t)tab.e_tids[e * tab.n + len - 1] * tab.k + j];
+        }
+        src = reinterpret_cast<const uint32_t *>(frames + slot * frame_bytes);
+        dst = reinterpret_cast<float4 *>((is_next ? out_next : out_state) + ff * out_frame_bytes);
+    };
+    auto load = [&](const uint32_t *src, uint32_t (&w)[kUnroll]) {
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) {
+            const int i = u * kThreads + tid;
+            w[u] = src[min(i, nd - 1)];   // unconditional: all loads in one basic block
+        }
+    };
+    auto store = [&](float4 *dst, const uint32_t (&w)[kUnroll]) {
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) {
+            const int i = u * kThreads + tid;
+            if (i < nd) {
+                const float4 o = (MODE == 0) ? cvt_div(w[u], divisor) : cvt_only(w[u]);
+                if (NT) {
+                    __builtin_nontemporal_store(o.x, &dst[i].x);
+                    __builtin_nontemporal_store(o.y, &dst[i].y);
+                    __builtin_nontemporal_store(o.z, &dst[i].z);
+                    __builtin_nontemporal_store(o.w, &dst[i].w);
+                } else {
+                    dst[i] = o;
+                }
+            }
+        }
+    };
+
+    int64_t f = blockIdx.x;
+    if (f >= total) return;
+    const uint32_t *src;
+    float4 *dst;
+    uint32_t w[kUnroll];
+    resolve(f, src, dst);
+    load(src, w);
+    for (;;) {
+        const int64_t fn = f + P;
+        if (fn >= total) {
+            store(dst, w);
+            break;
+        }
+        const uint32_t *src_n;
+        float4 *dst_n;
+        uint32_t wn[kUnroll];
+        resolve(fn, src_n, dst_n);
+        load(src_n, wn);
+        store(dst, w);
+        f = fn;
+        dst = dst_n;
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) w[u] = wn[u];
+    }
+}
+
+int pfrl_gather_persist_blocks() {
+    static const int v = [] {
+        const char *e = getenv("PFRL_GATHER_PERSIST");
+        return e != nullptr && *e ? atoi(e) : 0;
+    }();
+    return v;
+}
+
 }  // namespace
 
 extern "C" int pfrl_table_append(const pfrl_table_t *tab, int64_t n_rows, const int32_t *t_slots,
@@ -225,6 +340,27 @@ static void launch_be2(const pfrl_table_t *tab, const void *frames, int64_t fram
     const unsigned blocks = (unsigned)(2 * B * tab->k + (B + kThreads - 1) / kThreads);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     pfrl_profile_events(PFRL_PROFILE_BATCH_EXPERIENCES, B, &e0, &e1);
+    if constexpr (MODE != 2) {
+        const int P = pfrl_gather_persist_blocks();
+        if (P > 0 && (frame_bytes >> 2) <= kThreads * kUnroll && 2 * B * tab->k > P) {
+            const unsigned pb = (unsigned)(P + (B + kThreads - 1) / kThreads);
+            if (tab->act_dim > 0)
+                hipExtLaunchKernelGGL((k_batch_experiences_persist<MODE, float, NT>), dim3(pb),
+                                      dim3(kThreads), 0, stream, e0, e1, 0, *tab,
+                                      (const uint8_t *)frames, frame_bytes, divisor, entry_slots, B,
+                                      gp, (uint8_t *)out_state, (uint8_t *)out_next_state,
+                                      (float *)out_action, out_reward, out_terminal, out_discount,
+                                      P);
+            else
+                hipExtLaunchKernelGGL((k_batch_experiences_persist<MODE, int64_t, NT>), dim3(pb),
+                                      dim3(kThreads), 0, stream, e0, e1, 0, *tab,
+                                      (const uint8_t *)frames, frame_bytes, divisor, entry_slots, B,
+                                      gp, (uint8_t *)out_state, (uint8_t *)out_next_state,
+                                      (int64_t *)out_action, out_reward, out_terminal,
+                                      out_discount, P);
+            return;
+        }
+    }
     if (tab->act_dim > 0)
         hipExtLaunchKernelGGL((k_batch_experiences<MODE, float, NT>), dim3(blocks), dim3(kThreads),
                               0, stream, e0, e1, 0, *tab, (const uint8_t *)frames, frame_bytes,
