@@ -397,6 +397,96 @@ def cpu_baseline(args, seconds):
     }
 
 
+PROFILE_BATCH_EXPERIENCES, PROFILE_BATCH_STATES_U8 = 0, 1   # pfrl_amd.ops constants
+
+
+def compute_roofline(algo, all_us, all_units, all_kinds):
+    """``roofline`` object for the dominant HIP kernel of the path: the fused
+    batch_experiences gather for the replay agents, the batch_states gather (value
+    pass + minibatches) for PPO.  Inputs: per-launch durations (us), unit counts
+    and kinds as returned by ``ops.profile_collect(kind=None)``."""
+    k, fb = 4, 84 * 84
+    if algo == "ppo":
+        kind, kname, unit_name = PROFILE_BATCH_STATES_U8, "k_batch_states_u8", "frames"
+        # per gathered frame: fb bytes read as u8, 4*fb written as f32 (SURVEY.md 8d)
+        per_unit = fb + 4 * fb
+    elif algo == "sac":
+        kind, kname, unit_name = PROFILE_BATCH_EXPERIENCES, "k_batch_experiences", "entries"
+        # per sampled entry: state + next_state f32[376] read and written, action f32[17]
+        # read and written, reward/terminal/discount
+        per_unit = 2 * (2 * 376 * 4) + 2 * 17 * 4 + 2 * 12
+    else:
+        kind, kname, unit_name = PROFILE_BATCH_EXPERIENCES, "k_batch_experiences", "entries"
+        # per sampled entry: state + next_state, each k frames read as u8, written as f32
+        per_unit = 2 * k * (fb + 4 * fb)
+    k_us = [u for u, kd in zip(all_us, all_kinds) if kd == kind]
+    k_units = [n for n, kd in zip(all_units, all_kinds) if kd == kind]
+    if not k_us:
+        return None
+    # The kernel is launched in a few shapes (DQN: a small and a large env range per
+    # step; PPO: acting, value pass and minibatch gathers).  The roofline object
+    # describes the shape that moves the most bytes; the aggregate over every timed
+    # launch of the kernel is reported next to it.
+    classes = {}
+    for u, n in zip(k_us, k_units):
+        c = classes.setdefault(n, [0, 0.0])
+        c[0] += 1
+        c[1] += u
+    main_units = max(classes, key=lambda n: n * classes[n][0])
+    n_main, us_main = classes[main_units]
+    bytes_main = per_unit * main_units
+    achieved = bytes_main * n_main / (us_main * 1e-6) / 1e9
+    tot_bytes = sum(per_unit * b for b in k_units)
+    tot_s = sum(k_us) * 1e-6
+    roofline = {
+        "bound": "hbm", "kernel": kname,
+        "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+        "bytes_per_launch": int(bytes_main),
+        "%s_per_launch" % unit_name: int(main_units),
+        "avg_launch_us": round(us_main / n_main, 2), "launches_timed": n_main,
+        "share_of_kernel_bytes": round(bytes_main * n_main / tot_bytes, 4),
+        "all_launches": {
+            "achieved": round(tot_bytes / tot_s / 1e9, 1), "launches": len(k_us),
+            "shapes": {str(n): {"launches": c[0], "avg_launch_us": round(c[1] / c[0], 2)}
+                       for n, c in sorted(classes.items())}},
+        "timing": "hipEvent pair attached to each dispatch (hipExtLaunchKernelGGL) on the "
+                  "launch stream, inside the timed region",
+    }
+    # HBM traffic cannot be sampled from inside the process: it is taken from the
+    # committed rocprofv3 --pmc passes of this same command
+    # (profiles/r01e_pmc_gather.json, tools/pmc_gather.py), per launch shape.
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01e_pmc_gather.json")))
+        kk = pmc["kernels"].get("%s (%d %s)" % (kname, main_units, unit_name))
+        if kk and "traffic_bytes_per_launch" in kk:
+            roofline["traffic"] = kk["traffic_bytes_per_launch"]
+            roofline["traffic_source"] = "profiles/r01e_pmc_gather.json (rocprofv3 --pmc " \
+                                         "FETCH_SIZE / WRITE_SIZE, separate passes, corrected)"
+    except Exception:
+        pass
+    return roofline
+
+
+def assemble_result(args, world, N, elapsed, n_updates, t_fill, workload, roofline):
+    """The ONE JSON line of the driver contract (cpu_baseline is added by the caller)."""
+    return {
+        "metric": "env-steps/sec whole node (%s %d envs per GPU)" % (args.algo.upper(), N),
+        "value": round(world * N * args.steps / elapsed, 1), "unit": "env-steps/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic (host frames over PCIe)" if args.host_env else "synthetic",
+        "config": {
+            "workload": workload,
+            "global_envs": world * N, "updates_in_timed_region": n_updates,
+            "parallelism": "env-sharded dp%d, per-GPU-local replay" % world,
+            "prefill_s": round(t_fill, 1),
+        },
+        "roofline": roofline,
+    }
+
+
 def main():
     args = parse_args()
     # stdout carries exactly ONE line, the JSON result.  Native libraries (RCCL's
@@ -435,6 +525,7 @@ def main():
 
     for _ in range(args.warmup):
         obss = one_step(agent, env, obss, N)
+
     def updates_done():
         for name in ("optim_t", "n_updates", "n_policy_updates"):
             if hasattr(agent, name):
@@ -459,70 +550,14 @@ def main():
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
-    # dominant HIP kernel of the path: the fused batch_experiences gather for the
-    # replay agents, the batch_states gather (value pass + minibatches) for PPO
     all_us, all_units, all_kinds = ops.profile_collect(kind=None)
-    k, fb = 4, 84 * 84
-    if args.algo == "ppo":
-        kind, kname, unit_name = ops.PROFILE_BATCH_STATES_U8, "k_batch_states_u8", "frames"
-        # per gathered frame: fb bytes read as u8, 4*fb written as f32
-        per_unit = fb + 4 * fb
-    elif args.algo == "sac":
-        kind, kname, unit_name = ops.PROFILE_BATCH_EXPERIENCES, "k_batch_experiences", "entries"
-        # per sampled entry: state + next_state f32[376] read and written, action f32[17]
-        # read and written, reward/terminal/discount
-        per_unit = 2 * (2 * 376 * 4) + 2 * 17 * 4 + 2 * 12
-    else:
-        kind, kname, unit_name = ops.PROFILE_BATCH_EXPERIENCES, "k_batch_experiences", "entries"
-        # per sampled entry: state + next_state, each k frames read as u8, written as f32
-        per_unit = 2 * k * (fb + 4 * fb)
-    k_us = [u for u, kd in zip(all_us, all_kinds) if kd == kind]
-    k_units = [n for n, kd in zip(all_units, all_kinds) if kd == kind]
-    roofline = None
-    if k_us:
-        # The kernel is launched in a few shapes (DQN: a small and a large env range
-        # per step; PPO: acting, value pass and minibatch gathers).  The roofline
-        # object describes the shape that moves the most bytes; the aggregate over
-        # every timed launch of the kernel is reported next to it.
-        classes = {}
-        for u, n in zip(k_us, k_units):
-            c = classes.setdefault(n, [0, 0.0])
-            c[0] += 1
-            c[1] += u
-        main_units = max(classes, key=lambda n: n * classes[n][0])
-        n_main, us_main = classes[main_units]
-        bytes_main = per_unit * main_units
-        achieved = bytes_main * n_main / (us_main * 1e-6) / 1e9
-        tot_bytes = sum(per_unit * b for b in k_units)
-        tot_s = sum(k_us) * 1e-6
-        roofline = {
-            "bound": "hbm", "kernel": kname,
-            "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-            "bytes_per_launch": int(bytes_main),
-            "%s_per_launch" % unit_name: int(main_units),
-            "avg_launch_us": round(us_main / n_main, 2), "launches_timed": n_main,
-            "share_of_kernel_bytes": round(bytes_main * n_main / tot_bytes, 4),
-            "all_launches": {
-                "achieved": round(tot_bytes / tot_s / 1e9, 1), "launches": len(k_us),
-                "shapes": {str(n): {"launches": c[0], "avg_launch_us": round(c[1] / c[0], 2)}
-                           for n, c in sorted(classes.items())}},
-            "timing": "hipEvent pair attached to each dispatch (hipExtLaunchKernelGGL) on the "
-                      "launch stream, inside the timed region",
-        }
-        # HBM traffic cannot be sampled from inside the process: it is taken from
-        # the committed rocprofv3 --pmc passes of this same command
-        # (profiles/r01e_pmc_gather.json, tools/pmc_gather.py), per launch shape.
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01e_pmc_gather.json")))
-            kk = pmc["kernels"].get("%s (%d %s)" % (kname, main_units, unit_name))
-            if kk and "traffic_bytes_per_launch" in kk:
-                roofline["traffic"] = kk["traffic_bytes_per_launch"]
-                roofline["traffic_source"] = "profiles/r01e_pmc_gather.json (rocprofv3 --pmc " \
-                                             "FETCH_SIZE / WRITE_SIZE, separate passes, corrected)"
-        except Exception:
-            pass
-
+    roofline = compute_roofline(args.algo, all_us, all_units, all_kinds)
+    out = None
+    if rank == 0:
+        out = assemble_result(args, world, N, elapsed, n_updates, t_fill,
+                              workload_description(args, N, rbuf), roofline)
+        if not args.no_cpu_baseline and world == 1 and args.algo == "dqn":
+            out["cpu_baseline"] = cpu_baseline(args, args.cpu_baseline_seconds)
     if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
     sys.stdout.flush()

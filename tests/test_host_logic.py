@@ -121,3 +121,46 @@ class _CountingEnv:
 
     def close(self):
         pass
+
+
+def test_bench_result_line_contract(monkeypatch):
+    """bench.py's JSON line (driver contract + roofline object) assembled from
+    synthetic timings: every required key, the dominant launch shape, the aggregate."""
+    import json
+    import sys
+
+    sys.path.insert(0, ROOT)
+    import bench
+
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--steps", "20", "--warmup", "5"])
+    args = bench.parse_args()
+    assert (args.gpus, args.algo, args.num_envs) == (1, "dqn", 256)
+    # 20 steps: one 256-entry and one 1792-entry gather each, plus act gathers (kind 1)
+    us = [20.0, 100.0] * 20 + [9.5] * 20
+    units = [256, 1792] * 20 + [1024] * 20
+    kinds = [0, 0] * 20 + [1] * 20
+    roof = bench.compute_roofline("dqn", us, units, kinds)
+    assert roof["kernel"] == "k_batch_experiences" and roof["bound"] == "hbm"
+    assert roof["entries_per_launch"] == 1792 and roof["launches_timed"] == 20
+    per_entry = 2 * 4 * 5 * 84 * 84
+    assert roof["bytes_per_launch"] == 1792 * per_entry
+    np.testing.assert_allclose(roof["achieved"], 1792 * per_entry / 100e-6 / 1e9, rtol=1e-3)
+    np.testing.assert_allclose(roof["frac"], roof["achieved"] / roof["peak"], atol=1e-4)
+    np.testing.assert_allclose(roof["all_launches"]["achieved"],
+                               2048 * per_entry / 120e-6 / 1e9, rtol=1e-3)
+    assert roof["all_launches"]["launches"] == 40
+    assert roof["traffic"] is None or roof["traffic"] > roof["bytes_per_launch"] * 0.9
+    ppo = bench.compute_roofline("ppo", us, units, kinds)
+    assert ppo["kernel"] == "k_batch_states_u8" and ppo["frames_per_launch"] == 1024
+    assert bench.compute_roofline("dqn", [], [], []) is None
+    out = bench.assemble_result(args, 2, 256, 0.4, 1280, 8.3, "workload text", roof)
+    line = json.loads(json.dumps(out))
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step",
+                "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+                "roofline"):
+        assert key in line, key
+    assert line["value"] == 2 * 256 * 20 / 0.4 and line["n_gpus"] == 2
+    assert line["ms_per_step"] == 20.0 and line["scaling"] == "weak"
+    assert line["vs_baseline"] is None and line["higher_is_better"] is True
+    assert line["config"]["workload"] == "workload text" and "model" not in line["config"]
+    assert bench.PROFILE_BATCH_EXPERIENCES == 0 and bench.PROFILE_BATCH_STATES_U8 == 1
