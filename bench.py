@@ -61,6 +61,10 @@ def parse_args():
                    help="do not let MIOpen search conv algorithms")
     p.add_argument("--nchw", dest="channels_last", action="store_false",
                    help="keep the network in NCHW (default: channels_last)")
+    p.add_argument("--blas", choices=["default", "rocblas", "tunable"], default="default",
+                   help="GEMM back-end for the PyTorch side: torch default (hipBLASLt), rocBLAS, "
+                        "or torch's TunableOp (times every rocBLAS / hipBLASLt solution once per "
+                        "shape and keeps the fastest)")
     p.add_argument("--chunks", type=str, default=None,
                    help="dqn: env-range cut points of the step-fused path as fractions, e.g. "
                         "'0.125' (default) or '' for one range")
@@ -506,6 +510,14 @@ def main():
     device = torch.device("cuda", local % torch.cuda.device_count())
     torch.cuda.set_device(device)
     _native.lib()
+
+    if args.blas == "rocblas":
+        torch.backends.cuda.preferred_blas_library("cublas")
+    elif args.blas == "tunable":
+        torch.cuda.tunable.enable(True)
+        torch.cuda.tunable.tuning_enable(True)
+        torch.cuda.tunable.set_max_tuning_duration(10)
+        torch.cuda.tunable.set_filename("/tmp/pfrl_tunableop_rank%d.csv" % rank)
 
     agent, env, rbuf = build_agent(args, device, rank)
     N = args.num_envs
