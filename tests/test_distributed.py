@@ -115,6 +115,7 @@ def test_data_parallel_graph_plans_match_reference(prioritized, backend, tmp_pat
     dist.init_process_group(backend, init_method="file://%s" % (tmp_path / "pg"), rank=0,
                             world_size=1, **kw)
     os.environ["PFRL_FORCE_SPLIT_GRAPH"] = "1"
+    os.environ["PFRL_GRAPH_COLLECTIVE"] = "1"    # captured collective where the backend allows
     try:
         if prioritized:
             g = np.load(os.path.join(T.GOLDEN, "agent_trace_ddqn_per_n3.npz"))
@@ -136,4 +137,5 @@ def test_data_parallel_graph_plans_match_reference(prioritized, backend, tmp_pat
         T._compare(got, g)
     finally:
         os.environ.pop("PFRL_FORCE_SPLIT_GRAPH", None)
+        os.environ.pop("PFRL_GRAPH_COLLECTIVE", None)
         dist.destroy_process_group()
