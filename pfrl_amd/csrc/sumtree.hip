@@ -382,18 +382,43 @@ __global__ __launch_bounds__(64) void k_tree_sample_lds(
         TV root = mk_tv(top_v[1], top_t[1]);
         TV pos = mk_tv(__dadd_rn(0.0, __dmul_rn(root.v, u01[i])), PFRL_TAG_PY);
         int h = 1;
+        // Two levels per LDS round trip: the children AND the four grandchildren of h
+        // are requested together (12 independent LDS reads), then both decisions are
+        // taken in registers.  The dependent chain is what this kernel pays for, and
+        // an LDS read (~100 ns) is most of a level.
 #pragma unroll
-        for (int d = 0; d < kMaxTopLog2 - 1; ++d) {
+        for (int d = 0; d < kMaxTopLog2 - 1; d += 2) {
             if (d < top_levels - 1) {
-                TV lc = mk_tv(top_v[2 * h], top_t[2 * h]);
-                TV rc = mk_tv(top_v[2 * h + 1], top_t[2 * h + 1]);
-                TV left = lc.t != PFRL_TAG_ABSENT ? lc : mk_tv(0.0, PFRL_TAG_PY);
-                const bool go_left = tv_lt(pos, left);
-                if (!go_left) pos = tv_sub(pos, left);
-                sv[d] = go_left ? rc.v : lc.v;
-                st[d] = go_left ? rc.t : lc.t;
-                went_right[d] = !go_left;
-                h = 2 * h + (go_left ? 0 : 1);
+                const bool two = d + 1 < top_levels - 1;       // uniform
+                const int gbase = two ? 4 * h : 2 * h;          // always inside the heap
+                const double cv0 = top_v[2 * h], cv1 = top_v[2 * h + 1];
+                const int ct0 = top_t[2 * h], ct1 = top_t[2 * h + 1];
+                const double gv0 = top_v[gbase], gv1 = top_v[gbase + 1];
+                const double gv2 = top_v[gbase + (two ? 2 : 0)], gv3 = top_v[gbase + (two ? 3 : 1)];
+                const int gt0 = top_t[gbase], gt1 = top_t[gbase + 1];
+                const int gt2 = top_t[gbase + (two ? 2 : 0)], gt3 = top_t[gbase + (two ? 3 : 1)];
+                {
+                    TV lc = mk_tv(cv0, ct0), rc = mk_tv(cv1, ct1);
+                    TV left = lc.t != PFRL_TAG_ABSENT ? lc : mk_tv(0.0, PFRL_TAG_PY);
+                    const bool go_left = tv_lt(pos, left);
+                    if (!go_left) pos = tv_sub(pos, left);
+                    sv[d] = go_left ? rc.v : lc.v;
+                    st[d] = go_left ? rc.t : lc.t;
+                    went_right[d] = !go_left;
+                    h = 2 * h + (go_left ? 0 : 1);
+                }
+                if (d + 1 < kMaxTopLog2 - 1 && two) {
+                    const bool was_left = !went_right[d];
+                    TV lc = mk_tv(was_left ? gv0 : gv2, was_left ? gt0 : gt2);
+                    TV rc = mk_tv(was_left ? gv1 : gv3, was_left ? gt1 : gt3);
+                    TV left = lc.t != PFRL_TAG_ABSENT ? lc : mk_tv(0.0, PFRL_TAG_PY);
+                    const bool go_left = tv_lt(pos, left);
+                    if (!go_left) pos = tv_sub(pos, left);
+                    sv[d + 1] = go_left ? rc.v : lc.v;
+                    st[d + 1] = go_left ? rc.t : lc.t;
+                    went_right[d + 1] = !go_left;
+                    h = 2 * h + (go_left ? 0 : 1);
+                }
             }
         }
         const int64_t x0 = T.base + ((int64_t)(h - (top_n >> 1)) << r);
@@ -448,17 +473,38 @@ __global__ __launch_bounds__(64) void k_tree_sample_lds(
         // ---- descend the bottom heap ----
         int g = 1;
 #pragma unroll
-        for (int d = 0; d < kBotLevels; ++d) {
+        for (int d = 0; d < kBotLevels; d += 2) {
             if (d < r) {
-                TV lc = mk_tv(bot_v[2 * g], bot_t[2 * g]);
-                TV rc = mk_tv(bot_v[2 * g + 1], bot_t[2 * g + 1]);
-                TV left = lc.t != PFRL_TAG_ABSENT ? lc : mk_tv(0.0, PFRL_TAG_PY);
-                const bool go_left = tv_lt(pos, left);
-                if (!go_left) pos = tv_sub(pos, left);
-                sv[kMaxTopLog2 + d] = go_left ? rc.v : lc.v;
-                st[kMaxTopLog2 + d] = go_left ? rc.t : lc.t;
-                went_right[kMaxTopLog2 + d] = !go_left;
-                g = 2 * g + (go_left ? 0 : 1);
+                const bool two = d + 1 < r;                     // uniform
+                const int gbase = two ? 4 * g : 2 * g;
+                const double cv0 = bot_v[2 * g], cv1 = bot_v[2 * g + 1];
+                const int ct0 = bot_t[2 * g], ct1 = bot_t[2 * g + 1];
+                const double gv0 = bot_v[gbase], gv1 = bot_v[gbase + 1];
+                const double gv2 = bot_v[gbase + (two ? 2 : 0)], gv3 = bot_v[gbase + (two ? 3 : 1)];
+                const int gt0 = bot_t[gbase], gt1 = bot_t[gbase + 1];
+                const int gt2 = bot_t[gbase + (two ? 2 : 0)], gt3 = bot_t[gbase + (two ? 3 : 1)];
+                {
+                    TV lc = mk_tv(cv0, ct0), rc = mk_tv(cv1, ct1);
+                    TV left = lc.t != PFRL_TAG_ABSENT ? lc : mk_tv(0.0, PFRL_TAG_PY);
+                    const bool go_left = tv_lt(pos, left);
+                    if (!go_left) pos = tv_sub(pos, left);
+                    sv[kMaxTopLog2 + d] = go_left ? rc.v : lc.v;
+                    st[kMaxTopLog2 + d] = go_left ? rc.t : lc.t;
+                    went_right[kMaxTopLog2 + d] = !go_left;
+                    g = 2 * g + (go_left ? 0 : 1);
+                }
+                if (d + 1 < kBotLevels && two) {
+                    const bool was_left = !went_right[kMaxTopLog2 + d];
+                    TV lc = mk_tv(was_left ? gv0 : gv2, was_left ? gt0 : gt2);
+                    TV rc = mk_tv(was_left ? gv1 : gv3, was_left ? gt1 : gt3);
+                    TV left = lc.t != PFRL_TAG_ABSENT ? lc : mk_tv(0.0, PFRL_TAG_PY);
+                    const bool go_left = tv_lt(pos, left);
+                    if (!go_left) pos = tv_sub(pos, left);
+                    sv[kMaxTopLog2 + d + 1] = go_left ? rc.v : lc.v;
+                    st[kMaxTopLog2 + d + 1] = go_left ? rc.t : lc.t;
+                    went_right[kMaxTopLog2 + d + 1] = !go_left;
+                    g = 2 * g + (go_left ? 0 : 1);
+                }
             }
         }
         const int64_t x = x0 + (g - (bot_n >> 1));
