@@ -280,3 +280,27 @@ def adv_stats(adv):
     s = np.zeros(1)
     lib().orc_adv_stats(len(adv), _p(adv), _p(m), _p(s))
     return float(m[0]), float(s[0])
+
+
+def c51_loss(q_dist, action, next_dist, next_select, z, reward, discount, terminal, weights, mean):
+    """Whole C51 loss path (orc_c51_loss): returns dict(loss, grad, qsa, delta, target)."""
+    f32 = lambda a: None if a is None else np.ascontiguousarray(a, dtype=np.float32)
+    q_dist, next_dist, next_select = f32(q_dist), f32(next_dist), f32(next_select)
+    z, reward, discount, terminal, weights = (f32(a) for a in (z, reward, discount, terminal,
+                                                              weights))
+    action = np.ascontiguousarray(action, dtype=np.int64)
+    B, A, Z = q_dist.shape
+    loss = ctypes.c_double()
+    grad = np.empty((B, A, Z), dtype=np.float32)
+    qsa = np.empty(B, dtype=np.float32)
+    delta = np.empty(B, dtype=np.float32)
+    target = np.empty((B, Z), dtype=np.float32)
+    L = lib()
+    L.orc_c51_loss.restype = None
+    L.orc_c51_loss.argtypes = [ctypes.c_void_p] * 9 + [ctypes.c_long] * 3 + [ctypes.c_int] + \
+        [ctypes.c_void_p] * 5
+    ptr = lambda a: None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+    L.orc_c51_loss(ptr(q_dist), ptr(action), ptr(next_dist), ptr(next_select), ptr(z), ptr(reward),
+                   ptr(discount), ptr(terminal), ptr(weights), B, A, Z, int(bool(mean)),
+                   ctypes.byref(loss), ptr(grad), ptr(qsa), ptr(delta), ptr(target))
+    return dict(loss=loss.value, grad=grad, qsa=qsa, delta=delta, target=target)

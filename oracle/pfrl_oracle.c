@@ -16,6 +16,8 @@
  *   pfrl/agents/ppo.py:36-47                 (GAE reverse scan)
  *   pfrl/agents/ppo.py:476-478,494-495       (advantage standardisation)
  *   pfrl/agents/a2c.py:150-167               (A2C return scan)
+ *   pfrl/agents/categorical_dqn.py:7-104,150-204 + categorical_double_dqn.py:25-47
+ *                                            (C51 projection and loss)
  *
  * Parity pinning: every function here is checked against golden vectors that
  * tests/golden/make_golden.py recorded by running the reference itself
@@ -768,4 +770,77 @@ void orc_adv_stats(long n, const float *adv, double *mean, double *std) {
     for (i = 0; i < n; i++) s += (adv[i] - m) * (adv[i] - m);
     *mean = m;
     *std = sqrt(s / (double)n);
+}
+
+/* ------------------------------------------------------------------------
+ * Categorical (C51) DQN loss:
+ *   pfrl/action_value.py:97-180          q_values = q_dist @ z, greedy = argmax
+ *   pfrl/agents/categorical_dqn.py:150-171 (double: categorical_double_dqn.py:25-47)
+ *       Tz = r + (1 - terminal) * discount * z
+ *   pfrl/agents/categorical_dqn.py:7-57   _apply_categorical_projection: clamp,
+ *       bj = (y - v_min) / delta_z clamped to [0, Z-1], l = floor, u = ceil,
+ *       z_probs[l] += p * (1 - (bj - l))  for all j, then  z_probs[u] += p * (bj - l)
+ *       (the CPU scatter_add_ accumulates in index order, in float32)
+ *   pfrl/agents/categorical_dqn.py:373-401 eltwise = -t * log(clamp(y, 1e-10, 1))
+ *   pfrl/agents/categorical_dqn.py:60-104  loss accumulation
+ * out_grad = d loss / d q_dist (zero except the taken action's row).
+ * ------------------------------------------------------------------------ */
+void orc_c51_loss(const float *q_dist, const int64_t *action, const float *next_dist,
+                  const float *next_select, const float *z, const float *reward,
+                  const float *discount, const float *terminal, const float *weights, long B,
+                  long A, long Z, int mean, double *out_loss, float *out_grad, float *out_q,
+                  float *out_delta, float *out_target) {
+    const float v_min = z[0], v_max = z[Z - 1];
+    const float delta_z = z[1] - z[0];
+    if (next_select == NULL) next_select = next_dist;
+    double loss = 0.0;
+    memset(out_grad, 0, sizeof(float) * (size_t)(B * A * Z));
+    for (long b = 0; b < B; ++b) {
+        /* greedy next action: first maximum of the expected values */
+        long g = 0;
+        double best = 0.0;
+        for (long a = 0; a < A; ++a) {
+            double qv = 0.0;
+            for (long k = 0; k < Z; ++k) qv += (double)next_select[(b * A + a) * Z + k] * z[k];
+            if (a == 0 || (float)qv > (float)best) {
+                best = qv;
+                g = a;
+            }
+        }
+        const float *p = next_dist + (b * A + g) * Z;
+        float *t = out_target + b * Z;
+        for (long k = 0; k < Z; ++k) t[k] = 0.0f;
+        const float scale = (1.0f - terminal[b]) * discount[b];
+        /* lower neighbours first, then upper neighbours (two scatter_add_ calls) */
+        for (int pass = 0; pass < 2; ++pass) {
+            for (long j = 0; j < Z; ++j) {
+                float y = reward[b] + scale * z[j];
+                y = y < v_min ? v_min : (y > v_max ? v_max : y);
+                float bj = (y - v_min) / delta_z;
+                bj = bj < 0.0f ? 0.0f : (bj > (float)(Z - 1) ? (float)(Z - 1) : bj);
+                const float lo = floorf(bj), up = ceilf(bj);
+                const float frac = bj - lo;
+                if (pass == 0)
+                    t[(long)lo] += p[j] * (1.0f - frac);
+                else
+                    t[(long)up] += p[j] * frac;
+            }
+        }
+        const long act = action[b];
+        const float *y = q_dist + (b * A + act) * Z;
+        float coef = weights != NULL ? weights[b] : 1.0f;
+        if (mean) coef /= (float)B;
+        double d = 0.0, qsa = 0.0;
+        for (long k = 0; k < Z; ++k) {
+            const float yc = y[k] < 1e-10f ? 1e-10f : (y[k] > 1.0f ? 1.0f : y[k]);
+            d += (double)(-t[k] * logf(yc));
+            qsa += (double)y[k] * z[k];
+            if (y[k] >= 1e-10f && y[k] <= 1.0f)
+                out_grad[(b * A + act) * Z + k] = -t[k] / yc * coef;
+        }
+        out_delta[b] = (float)d;
+        out_q[b] = (float)qsa;
+        loss += d * (weights != NULL ? (double)weights[b] : 1.0);
+    }
+    *out_loss = mean ? loss / (double)B : loss;
 }

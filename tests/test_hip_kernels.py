@@ -893,3 +893,35 @@ def test_distributional_dueling_dqn_fused_head_matches_plain(dev):
         ops.dueling_softmax_supported = saved
     np.testing.assert_allclose(q1.detach().cpu().numpy(), q2.detach().cpu().numpy(), rtol=1e-5,
                                atol=1e-7)
+
+
+@pytest.mark.parametrize("B,A,Z,double,weighted,mean", [(256, 18, 51, True, True, True),
+                                                        (32, 6, 51, False, False, False),
+                                                        (500, 4, 33, True, False, True)])
+def test_fused_c51_loss_vs_oracle(dev, B, A, Z, double, weighted, mean):
+    """pfrl_c51_loss against the C oracle (orc_c51_loss, pinned on the reference's golden
+    vectors) on seeded random inputs, including every terminal / clipping case."""
+    from pfrl_amd import ops
+
+    rs = np.random.RandomState(B + A + Z)
+    sm = lambda *s: torch.softmax(torch.from_numpy(3 * rs.randn(*s).astype(np.float32)), dim=-1)
+    q_dist, next_dist, next_sel = sm(B, A, Z), sm(B, A, Z), sm(B, A, Z)
+    z = torch.linspace(-10, 10, Z)
+    action = torch.from_numpy(rs.randint(0, A, size=B))
+    reward = torch.from_numpy(rs.choice([-15.0, -1.0, 0.0, 0.3, 1.0, 15.0], size=B).astype(np.float32))
+    discount = torch.from_numpy((0.99 ** rs.randint(1, 4, size=B)).astype(np.float32))
+    terminal = torch.from_numpy((rs.rand(B) < 0.3).astype(np.float32))
+    weights = torch.from_numpy((rs.rand(B) + 0.1).astype(np.float32)) if weighted else None
+    ref = oracle.c51_loss(q_dist.numpy(), action.numpy(), next_dist.numpy(),
+                          next_sel.numpy() if double else None, z.numpy(), reward.numpy(),
+                          discount.numpy(), terminal.numpy(),
+                          None if weights is None else weights.numpy(), mean)
+    q = q_dist.to(dev).requires_grad_(True)
+    t_ = lambda a: None if a is None else a.to(dev)
+    loss, qsa, delta = ops.c51_loss(q, t_(action), t_(next_dist), t_(next_sel) if double else None,
+                                    t_(z), t_(reward), t_(discount), t_(terminal), t_(weights), mean)
+    (gq,) = torch.autograd.grad(loss, q)
+    np.testing.assert_allclose(loss.item(), ref["loss"], rtol=1e-5)
+    np.testing.assert_allclose(gq.cpu().numpy(), ref["grad"], rtol=1e-5, atol=1e-8)
+    np.testing.assert_allclose(delta.cpu().numpy(), ref["delta"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(qsa.cpu().numpy(), ref["qsa"], rtol=1e-5, atol=1e-6)

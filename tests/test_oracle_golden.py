@@ -238,3 +238,22 @@ def test_a2c_returns():
             np.testing.assert_array_equal(ret[:T], want[:T])
         else:
             np.testing.assert_array_equal(ret, want)
+
+
+def test_c51_loss_oracle_matches_reference_golden():
+    """orc_c51_loss (plain C) against the vectors recorded from the reference's own
+    functions: projected target bit-exact (same float32 accumulation order as the CPU
+    scatter_add_), loss / gradient / KL / Q(s, a) to float32 rounding of log and sums."""
+    g = np.load(os.path.join(GOLDEN, "c51_loss.npz"))
+    for ci in range(int(g["n_cases"])):
+        k = lambda name: g["k%d_%s" % (ci, name)]
+        double, weighted, mean = (bool(v) for v in k("flags"))
+        out = oracle.c51_loss(k("q_dist"), k("action"), k("next_dist"),
+                              k("next_sel") if double else None, k("z"), k("reward"),
+                              k("discount"), k("terminal"), k("weights") if weighted else None,
+                              mean)
+        np.testing.assert_array_equal(out["target"], k("target"))
+        np.testing.assert_allclose(out["loss"], float(k("loss")), rtol=2e-6)
+        np.testing.assert_allclose(out["grad"], k("grad"), rtol=2e-6, atol=1e-9)
+        np.testing.assert_allclose(out["delta"], k("delta"), rtol=2e-6, atol=1e-7)
+        np.testing.assert_allclose(out["qsa"], k("qsa"), rtol=2e-6, atol=1e-7)
