@@ -304,3 +304,26 @@ def c51_loss(q_dist, action, next_dist, next_select, z, reward, discount, termin
                    ptr(discount), ptr(terminal), ptr(weights), B, A, Z, int(bool(mean)),
                    ctypes.byref(loss), ptr(grad), ptr(qsa), ptr(delta), ptr(target))
     return dict(loss=loss.value, grad=grad, qsa=qsa, delta=delta, target=target)
+
+
+def dqn_td_loss(q, action, target_q, next_q_online, reward, discount, terminal, weights,
+                clip_delta, mean):
+    """(Double-)DQN TD loss (orc_dqn_td_loss): dict(loss, grad, y, t)."""
+    f32 = lambda a: None if a is None else np.ascontiguousarray(a, dtype=np.float32)
+    q, target_q, next_q_online = f32(q), f32(target_q), f32(next_q_online)
+    reward, discount, terminal, weights = (f32(a) for a in (reward, discount, terminal, weights))
+    action = np.ascontiguousarray(action, dtype=np.int64)
+    B, A = q.shape
+    loss = ctypes.c_double()
+    grad = np.empty((B, A), dtype=np.float32)
+    y = np.empty(B, dtype=np.float32)
+    t = np.empty(B, dtype=np.float32)
+    L = lib()
+    L.orc_dqn_td_loss.restype = None
+    L.orc_dqn_td_loss.argtypes = [ctypes.c_void_p] * 8 + [ctypes.c_long] * 2 + \
+        [ctypes.c_int] * 2 + [ctypes.c_void_p] * 4
+    ptr = lambda a: None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+    L.orc_dqn_td_loss(ptr(q), ptr(action), ptr(target_q), ptr(next_q_online), ptr(reward),
+                      ptr(discount), ptr(terminal), ptr(weights), B, A, int(bool(clip_delta)),
+                      int(bool(mean)), ctypes.byref(loss), ptr(grad), ptr(y), ptr(t))
+    return dict(loss=loss.value, grad=grad, y=y, t=t)

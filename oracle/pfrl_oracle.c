@@ -844,3 +844,46 @@ void orc_c51_loss(const float *q_dist, const int64_t *action, const float *next_
     }
     *out_loss = mean ? loss / (double)B : loss;
 }
+
+/* ------------------------------------------------------------------------
+ * (Double-)DQN TD loss:
+ *   pfrl/agents/dqn.py:424-445   y = Q(s)[a]
+ *   pfrl/agents/dqn.py:406-422   t = r + discount * (1 - terminal) * max_a Q_target(s')
+ *   pfrl/agents/double_dqn.py:15-40  ... Q_target(s')[argmax_a Q_online(s')]
+ *   pfrl/agents/dqn.py:44-104    smooth_l1 (delta = 1) or mse / 2; 'sum' | 'mean';
+ *                                weighted: sum(loss * w) [/ B]
+ * out_grad = d loss / d Q(s)  (zero except the taken action).
+ * ------------------------------------------------------------------------ */
+void orc_dqn_td_loss(const float *q, const int64_t *action, const float *target_q,
+                     const float *next_q_online, const float *reward, const float *discount,
+                     const float *terminal, const float *weights, long B, long A, int clip_delta,
+                     int mean, double *out_loss, float *out_grad, float *out_y, float *out_t) {
+    double loss = 0.0;
+    memset(out_grad, 0, sizeof(float) * (size_t)(B * A));
+    for (long b = 0; b < B; ++b) {
+        const float *sel = next_q_online != NULL ? next_q_online + b * A : target_q + b * A;
+        long g = 0;
+        for (long a = 1; a < A; ++a)
+            if (sel[a] > sel[g]) g = a;          /* first maximum */
+        const float nxt = target_q[b * A + g];
+        const float t = reward[b] + (discount[b] * (1.0f - terminal[b])) * nxt;
+        const float y = q[b * A + action[b]];
+        const float d = y - t;
+        float l, gl;
+        if (clip_delta) {                        /* F.smooth_l1_loss, beta = 1 */
+            const float ad = fabsf(d);
+            l = ad < 1.0f ? 0.5f * d * d : ad - 0.5f;
+            gl = ad < 1.0f ? d : (d > 0.0f ? 1.0f : -1.0f);
+        } else {                                 /* F.mse_loss / 2 */
+            l = 0.5f * d * d;
+            gl = d;
+        }
+        float coef = weights != NULL ? weights[b] : 1.0f;
+        if (mean) coef /= (float)B;
+        loss += (double)l * (weights != NULL ? (double)weights[b] : 1.0);
+        out_grad[b * A + action[b]] = gl * coef;
+        out_y[b] = y;
+        out_t[b] = t;
+    }
+    *out_loss = mean ? loss / (double)B : loss;
+}

@@ -855,6 +855,59 @@ def cartpole_trace(steps=1500):
     print("cartpole trace updates", len(losses), "actions", len(actions))
 
 
+def td_loss_golden():
+    """(Double-)DQN target + Huber / MSE loss of the reference on fixed inputs
+    (dqn.py:44-104, 424-470; double_dqn.py:15-40), with the gradient w.r.t. Q(s)."""
+    from pfrl.action_value import DiscreteActionValue as DAV
+    from pfrl.agents import dqn as rdqn
+
+    out = {}
+    ci = 0
+    B, A = 16, 6
+    for double in (False, True):
+        for clip in (True, False):
+            for acc in ("mean", "sum"):
+                for weighted in (False, True):
+                    g = torch.Generator().manual_seed(500 + ci)
+                    q = (2 * torch.randn(B, A, generator=g)).requires_grad_(True)
+                    tq = 2 * torch.randn(B, A, generator=g)
+                    nq = torch.randn(B, A, generator=g)
+                    act = torch.randint(0, A, (B,), generator=g)
+                    r = torch.randn(B, generator=g)
+                    disc = torch.full((B,), 0.99) ** torch.randint(1, 4, (B,), generator=g)
+                    term = (torch.rand(B, generator=g) < 0.3).float()
+                    w = torch.rand(B, generator=g) + 0.1
+                    qout, tout = DAV(q), DAV(tq)
+                    y = qout.evaluate_actions(act)
+                    if double:
+                        nxt = tout.evaluate_actions(DAV(nq).greedy_actions)
+                    else:
+                        nxt = tout.max
+                    t = r + disc * (1.0 - term) * nxt
+                    if weighted:
+                        loss = rdqn.compute_weighted_value_loss(y, t, w, clip_delta=clip,
+                                                                batch_accumulator=acc)
+                    else:
+                        loss = rdqn.compute_value_loss(y, t, clip_delta=clip,
+                                                       batch_accumulator=acc)
+                    (grad,) = torch.autograd.grad(loss, q)
+                    pre = "k%d_" % ci
+                    out.update({
+                        pre + "q": q.detach().numpy(), pre + "tq": tq.numpy(), pre + "nq": nq.numpy(),
+                        pre + "action": act.numpy(), pre + "reward": r.numpy(),
+                        pre + "discount": disc.numpy(), pre + "terminal": term.numpy(),
+                        pre + "weights": w.numpy(),
+                        pre + "flags": np.asarray([int(double), int(clip), int(acc == "mean"),
+                                                   int(weighted)]),
+                        pre + "loss": np.asarray(loss.item(), dtype=np.float64),
+                        pre + "grad": grad.numpy(), pre + "y": y.detach().numpy(),
+                        pre + "t": t.numpy()})
+                    ci += 1
+    out["n_cases"] = np.asarray(ci)
+    np.savez_compressed(os.path.join(HERE, "td_loss.npz"), **out)
+    print("td loss cases", ci)
+
+
 def c51_loss_golden():
     """Whole C51 loss path of the reference on fixed inputs: greedy next action,
     Bellman shift, projection, cross entropy, accumulation, gradient w.r.t. the
@@ -1078,6 +1131,7 @@ if __name__ == "__main__":
     cartpole_trace()
     td3_ddpg_traces()
     c51_projection_golden()
+    td_loss_golden()
     c51_loss_golden()
     c51_agent_trace()
     sac_trace()

@@ -925,3 +925,48 @@ def test_fused_c51_loss_vs_oracle(dev, B, A, Z, double, weighted, mean):
     np.testing.assert_allclose(gq.cpu().numpy(), ref["grad"], rtol=1e-5, atol=1e-8)
     np.testing.assert_allclose(delta.cpu().numpy(), ref["delta"], rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(qsa.cpu().numpy(), ref["qsa"], rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("double", [False, True])
+@pytest.mark.parametrize("clip,weighted,mean", [(True, False, False), (False, True, True),
+                                                (True, True, False)])
+def test_fused_td_loss_vs_oracle_and_golden(dev, double, clip, weighted, mean):
+    """pfrl_dqn_td_loss against the C oracle on seeded inputs and against the vectors
+    recorded from the reference (tests/golden/td_loss.npz)."""
+    from pfrl_amd import ops
+
+    def run(q, action, tq, nq, r, disc, term, w):
+        t_ = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+        qd = t_(q).requires_grad_(True)
+        loss, y, delta = ops.dqn_td_loss(qd, t_(action), t_(tq), t_(nq), t_(r), t_(disc), t_(term),
+                                         t_(w), clip, mean)
+        (gq,) = torch.autograd.grad(loss, qd)
+        return loss.item(), gq.cpu().numpy(), y.detach().cpu().numpy(), delta.cpu().numpy()
+
+    rs = np.random.RandomState(11 + int(double))
+    B, A = 300, 18
+    q, tq, nq = (2 * rs.randn(B, A).astype(np.float32) for _ in range(3))
+    action = rs.randint(0, A, size=B)
+    r = rs.randn(B).astype(np.float32)
+    disc = (0.99 ** rs.randint(1, 4, size=B)).astype(np.float32)
+    term = (rs.rand(B) < 0.3).astype(np.float32)
+    w = (rs.rand(B) + 0.1).astype(np.float32) if weighted else None
+    ref = oracle.dqn_td_loss(q, action, tq, nq if double else None, r, disc, term, w, clip, mean)
+    loss, gq, y, delta = run(q, action, tq, nq if double else None, r, disc, term, w)
+    np.testing.assert_allclose(loss, ref["loss"], rtol=1e-5)
+    np.testing.assert_allclose(gq, ref["grad"], rtol=1e-6, atol=1e-9)
+    np.testing.assert_array_equal(y, ref["y"])
+    np.testing.assert_allclose(delta, np.abs(ref["y"] - ref["t"]), rtol=1e-6, atol=1e-7)
+    g = np.load(os.path.join(GOLDEN, "td_loss.npz"))
+    for ci in range(int(g["n_cases"])):
+        k = lambda name: g["k%d_%s" % (ci, name)]
+        gd, gc, gm, gw = (bool(v) for v in k("flags"))
+        if (gd, gc, gm, gw) != (double, clip, mean, weighted):
+            continue
+        loss, gq, y, delta = run(k("q"), k("action"), k("tq"), k("nq") if gd else None,
+                                 k("reward"), k("discount"), k("terminal"),
+                                 k("weights") if gw else None)
+        np.testing.assert_allclose(loss, float(k("loss")), rtol=1e-5)
+        np.testing.assert_allclose(gq, k("grad"), rtol=1e-6, atol=1e-9)
+        np.testing.assert_array_equal(y, k("y"))
+        np.testing.assert_allclose(delta, np.abs(k("y") - k("t")), rtol=1e-6, atol=1e-7)

@@ -257,3 +257,19 @@ def test_c51_loss_oracle_matches_reference_golden():
         np.testing.assert_allclose(out["grad"], k("grad"), rtol=2e-6, atol=1e-9)
         np.testing.assert_allclose(out["delta"], k("delta"), rtol=2e-6, atol=1e-7)
         np.testing.assert_allclose(out["qsa"], k("qsa"), rtol=2e-6, atol=1e-7)
+
+
+def test_dqn_td_loss_oracle_matches_reference_golden():
+    """orc_dqn_td_loss against the reference's compute_(weighted_)value_loss and
+    (Double-)DQN targets: y and t bit-exact, loss / gradient to sum rounding."""
+    g = np.load(os.path.join(GOLDEN, "td_loss.npz"))
+    for ci in range(int(g["n_cases"])):
+        k = lambda name: g["k%d_%s" % (ci, name)]
+        double, clip, mean, weighted = (bool(v) for v in k("flags"))
+        out = oracle.dqn_td_loss(k("q"), k("action"), k("tq"), k("nq") if double else None,
+                                 k("reward"), k("discount"), k("terminal"),
+                                 k("weights") if weighted else None, clip, mean)
+        np.testing.assert_array_equal(out["y"], k("y"))
+        np.testing.assert_array_equal(out["t"], k("t"))
+        np.testing.assert_allclose(out["loss"], float(k("loss")), rtol=2e-6)
+        np.testing.assert_allclose(out["grad"], k("grad"), rtol=2e-6, atol=1e-9)
