@@ -7,7 +7,10 @@ Mirrors ``pfrl.agents.soft_actor_critic.SoftActorCritic``
 The replay side is the same HBM store as DQN with float32 vector observations
 and float32 action vectors (one fused gather per minibatch, plain f32 copies);
 statistics stay on the device instead of the reference's per-update
-``.cpu().numpy()`` / ``.item()`` round trips (:241-244, :303-308).
+``.cpu().numpy()`` / ``.item()`` round trips (:241-244, :303-308); the whole
+update (two Q steps, policy step, temperature step, soft target sync) replays as
+one HIP graph.  Acting / observing plumbing is shared with TD3 and DDPG
+(:mod:`pfrl_amd.agents._replay_actor_critic`).
 """
 import copy
 from logging import getLogger
@@ -17,9 +20,7 @@ import torch
 from torch import nn
 from torch.nn import functional as F
 
-from pfrl_amd.agent import AttributeSavingMixin, BatchAgent
-from pfrl_amd.agents.dqn import _DeviceRecord, _mean_or_nan
-from pfrl_amd.replay_buffer import ReplayUpdater, batch_experiences
+from pfrl_amd.agents._replay_actor_critic import ReplayActorCritic
 from pfrl_amd.utils.batch_states import batch_states
 from pfrl_amd.utils.clip_l2_grad_norm import clip_l2_grad_norm_
 from pfrl_amd.utils.contexts import evaluating
@@ -39,10 +40,12 @@ class TemperatureHolder(nn.Module):
         return torch.exp(self.log_temperature)
 
 
-class SoftActorCritic(AttributeSavingMixin, BatchAgent):
+class SoftActorCritic(ReplayActorCritic):
     saved_attributes = ("policy", "q_func1", "q_func2", "target_q_func1", "target_q_func2",
                         "policy_optimizer", "q_func1_optimizer", "q_func2_optimizer",
                         "temperature_holder", "temperature_optimizer")
+    _STATS = (("q1", 1000), ("q2", 1000), ("entropy", 1000), ("loss1", 100), ("loss2", 100),
+              ("policy_loss", 1))
 
     def __init__(self, policy, q_func1, q_func2, policy_optimizer, q_func1_optimizer,
                  q_func2_optimizer, replay_buffer, gamma, gpu=None, replay_start_size=10000,
@@ -50,71 +53,42 @@ class SoftActorCritic(AttributeSavingMixin, BatchAgent):
                  max_grad_norm=None, logger=getLogger(__name__), batch_states=batch_states,
                  burnin_action_func=None, initial_temperature=1.0, entropy_target=None,
                  temperature_optimizer_lr=None, act_deterministically=True, use_graphs=None):
-        self.policy = policy
-        self.q_func1 = q_func1
-        self.q_func2 = q_func2
-        if gpu is not None and gpu >= 0:
-            assert torch.cuda.is_available()
-            self.device = torch.device("cuda:{}".format(gpu))
-            self.policy.to(self.device)
-            self.q_func1.to(self.device)
-            self.q_func2.to(self.device)
-        else:
-            self.device = torch.device("cpu")
-        self.replay_buffer = replay_buffer
-        if hasattr(replay_buffer, "bind"):
-            replay_buffer.bind(self.device, phi)
-        self.gamma = gamma
-        self.gpu = gpu
-        self.phi = phi
-        self.soft_update_tau = soft_update_tau
-        self.logger = logger
+        self.policy, self.q_func1, self.q_func2 = policy, q_func1, q_func2
         self.policy_optimizer = policy_optimizer
         self.q_func1_optimizer = q_func1_optimizer
         self.q_func2_optimizer = q_func2_optimizer
-        self.replay_updater = ReplayUpdater(
-            replay_buffer=replay_buffer, update_func=self.update, batchsize=minibatch_size,
-            n_times_update=1, replay_start_size=replay_start_size,
-            update_interval=update_interval, episodic_update=False)
+        self.soft_update_tau = soft_update_tau
         self.max_grad_norm = max_grad_norm
-        self.batch_states = batch_states
-        self.burnin_action_func = burnin_action_func
         self.initial_temperature = initial_temperature
         self.entropy_target = entropy_target
-        if self.entropy_target is not None:
+        self.act_deterministically = act_deterministically
+        self.n_policy_updates = 0
+        self._setup([policy, q_func1, q_func2], gpu, replay_buffer, phi, gamma, None,
+                    batch_states, logger, burnin_action_func, minibatch_size, replay_start_size,
+                    update_interval, 1, use_graphs)
+        if entropy_target is not None:
             self.temperature_holder = TemperatureHolder(
                 initial_log_temperature=np.log(initial_temperature))
-            if temperature_optimizer_lr is not None:
-                self.temperature_optimizer = torch.optim.Adam(
-                    self.temperature_holder.parameters(), lr=temperature_optimizer_lr)
-            else:
-                self.temperature_optimizer = torch.optim.Adam(self.temperature_holder.parameters())
+            kw = {} if temperature_optimizer_lr is None else {"lr": temperature_optimizer_lr}
+            self.temperature_optimizer = torch.optim.Adam(self.temperature_holder.parameters(),
+                                                          **kw)
             self.temperature_holder.to(self.device)
         else:
             self.temperature_holder = None
             self.temperature_optimizer = None
-        self.act_deterministically = act_deterministically
-        self.t = 0
-        self.target_q_func1 = copy.deepcopy(self.q_func1).eval().requires_grad_(False)
-        self.target_q_func2 = copy.deepcopy(self.q_func2).eval().requires_grad_(False)
-        self.q1_record = _DeviceRecord(1000)
-        self.q2_record = _DeviceRecord(1000)
-        self.entropy_record = _DeviceRecord(1000)
-        self.q_func1_loss_record = _DeviceRecord(100)
-        self.q_func2_loss_record = _DeviceRecord(100)
-        self.n_policy_updates = 0
-        from pfrl_amd import distributed
+        frozen = lambda m: copy.deepcopy(m).eval().requires_grad_(False)
+        self.target_q_func1 = frozen(q_func1)
+        self.target_q_func2 = frozen(q_func2)
         from pfrl_amd.distributed import GradientAllReducer
 
-        # HIP-graph capture of the whole update (two Q steps, policy step, temperature
-        # step, soft target sync: ~250 small kernels, host-dispatch bound when eager).
-        # Single GPU only: with world_size > 1 the three all-reduces stay eager.
-        on_gpu = (self.device.type == "cuda" and getattr(replay_buffer, "is_device", False)
-                  and distributed.world_size() == 1)
-        self.use_graphs = on_gpu if use_graphs is None else bool(use_graphs and on_gpu)
-        self._captured = None
+        self._reducers = {m: GradientAllReducer(m) for m in (policy, q_func1, q_func2)}
 
-        self._reducers = [GradientAllReducer(m) for m in (self.q_func1, self.q_func2, self.policy)]
+    # reference attribute names of the statistics windows
+    q1_record = property(lambda self: self._records["q1"])
+    q2_record = property(lambda self: self._records["q2"])
+    entropy_record = property(lambda self: self._records["entropy"])
+    q_func1_loss_record = property(lambda self: self._records["loss1"])
+    q_func2_loss_record = property(lambda self: self._records["loss2"])
 
     @property
     def temperature(self):
@@ -131,11 +105,36 @@ class SoftActorCritic(AttributeSavingMixin, BatchAgent):
         with torch.no_grad():
             return self.temperature_holder().detach()
 
+    # -- hooks -------------------------------------------------------------------------
+    def _policy(self):
+        return self.policy
+
+    def _burnin_over(self):
+        return self.n_policy_updates > 0
+
+    def _graph_modules(self):
+        return [self.policy, self.q_func1, self.q_func2, self.target_q_func1,
+                self.target_q_func2, self.temperature_holder]
+
+    def _graph_optimizers(self):
+        return [self.policy_optimizer, self.q_func1_optimizer, self.q_func2_optimizer,
+                self.temperature_optimizer]
+
     def sync_target_network(self):
         synchronize_parameters(src=self.q_func1, dst=self.target_q_func1, method="soft",
                                tau=self.soft_update_tau)
         synchronize_parameters(src=self.q_func2, dst=self.target_q_func2, method="soft",
                                tau=self.soft_update_tau)
+
+    # -- learning ----------------------------------------------------------------------------
+    def _step(self, loss, module, optimizer):
+        optimizer.zero_grad()
+        loss.backward()
+        if module in self._reducers:
+            self._reducers[module].all_reduce()
+        if self.max_grad_norm is not None:
+            clip_l2_grad_norm_(module.parameters(), self.max_grad_norm)
+        optimizer.step()
 
     def update_q_func(self, batch):
         batch_next_state = batch["next_state"]
@@ -156,23 +155,13 @@ class SoftActorCritic(AttributeSavingMixin, BatchAgent):
         loss1 = 0.5 * F.mse_loss(target_q, predict_q1)
         loss2 = 0.5 * F.mse_loss(target_q, predict_q2)
         self._stat(q1=predict_q1, q2=predict_q2, loss1=loss1, loss2=loss2)
-        for loss, qf, opt, red in ((loss1, self.q_func1, self.q_func1_optimizer, self._reducers[0]),
-                                   (loss2, self.q_func2, self.q_func2_optimizer, self._reducers[1])):
-            opt.zero_grad()
-            loss.backward()
-            red.all_reduce()
-            if self.max_grad_norm is not None:
-                clip_l2_grad_norm_(qf.parameters(), self.max_grad_norm)
-            opt.step()
+        self._step(loss1, self.q_func1, self.q_func1_optimizer)
+        self._step(loss2, self.q_func2, self.q_func2_optimizer)
 
     def update_temperature(self, log_prob):
         assert not log_prob.requires_grad
         loss = -torch.mean(self.temperature_holder() * (log_prob + self.entropy_target))
-        self.temperature_optimizer.zero_grad()
-        loss.backward()
-        if self.max_grad_norm is not None:
-            clip_l2_grad_norm_(self.temperature_holder.parameters(), self.max_grad_norm)
-        self.temperature_optimizer.step()
+        self._step(loss, self.temperature_holder, self.temperature_optimizer)
 
     def update_policy_and_temperature(self, batch):
         batch_state = batch["state"]
@@ -185,14 +174,7 @@ class SoftActorCritic(AttributeSavingMixin, BatchAgent):
         entropy_term = self._temperature_value() * log_prob[..., None]
         assert q.shape == entropy_term.shape
         loss = torch.mean(entropy_term - q)
-        self.policy_optimizer.zero_grad()
-        loss.backward()
-        self._reducers[2].all_reduce()
-        if self.max_grad_norm is not None:
-            clip_l2_grad_norm_(self.policy.parameters(), self.max_grad_norm)
-        self.policy_optimizer.step()
-        if self._stat_sink is None:
-            self.n_policy_updates += 1
+        self._step(loss, self.policy, self.policy_optimizer)
         if self.entropy_target is not None:
             self.update_temperature(log_prob.detach())
         with torch.no_grad():
@@ -202,72 +184,15 @@ class SoftActorCritic(AttributeSavingMixin, BatchAgent):
                 ent = -log_prob
         self._stat(entropy=ent, policy_loss=loss)
 
-    # -- statistics: recorded directly when eager, collected when capturing --------
-    _stat_sink = None
-
-    def _stat(self, **tensors):
-        if self._stat_sink is not None:
-            self._stat_sink.update({k: v.detach() for k, v in tensors.items()})
-            return
-        self._record_stats(tensors)
-
-    def _record_stats(self, st):
-        for name, rec in (("q1", self.q1_record), ("q2", self.q2_record),
-                          ("loss1", self.q_func1_loss_record),
-                          ("loss2", self.q_func2_loss_record), ("entropy", self.entropy_record)):
-            if name in st:
-                rec.extend(st[name])
-        if "policy_loss" in st:
-            self._last_policy_loss = st["policy_loss"].detach()
-
-    _STAT_ORDER = ("q1", "q2", "loss1", "loss2", "entropy", "policy_loss")
-
-    def _update_core(self, batch):
-        """The captured step: returns all statistics as ONE flat device vector."""
-        self._stat_sink = {}
-        try:
-            self.update_q_func(batch)
-            self.update_policy_and_temperature(batch)
-            self.sync_target_network()
-            sink = self._stat_sink
-        finally:
-            self._stat_sink = None
-        return {"stats": torch.cat([sink[k].reshape(-1).float() for k in self._STAT_ORDER]),
-                "sizes": [sink[k].numel() for k in self._STAT_ORDER]}
-
-    def _graph_capturable(self, batch):
-        return (self.use_graphs and isinstance(batch.get("state"), torch.Tensor)
-                and batch["state"].is_cuda)
-
-    def update(self, experiences, errors_out=None):
-        batch = batch_experiences(experiences, self.device, self.phi, self.gamma)
-        if self._graph_capturable(batch):
-            if self._captured is None:
-                from pfrl_amd.agents.graphed_update import CapturedStep
-
-                self._captured = CapturedStep(
-                    self._update_core,
-                    [self.policy, self.q_func1, self.q_func2, self.target_q_func1,
-                     self.target_q_func2, self.temperature_holder],
-                    [self.policy_optimizer, self.q_func1_optimizer, self.q_func2_optimizer,
-                     self.temperature_optimizer], self.device)
-            tensors = {k: v for k, v in batch.items() if isinstance(v, torch.Tensor)}
-            try:
-                out = self._captured.run(tensors)
-            except Exception:
-                self.logger.exception("HIP-graph capture of the SAC update failed; running eager")
-                self.use_graphs = False
-                self._captured = None
-                return self.update(experiences, errors_out)
-            self.n_policy_updates += 1
-            flat = out["stats"].clone()   # the graph owns (and overwrites) its outputs
-            pieces = torch.split(flat, out["sizes"])
-            self._record_stats(dict(zip(self._STAT_ORDER, pieces)))
-            return
+    def _update_impl(self, batch, variant=None):
         self.update_q_func(batch)
         self.update_policy_and_temperature(batch)
         self.sync_target_network()
 
+    def _after_update(self, variant=None):
+        self.n_policy_updates += 1
+
+    # -- acting (no explorer: the stochastic policy explores) -----------------------------------
     def batch_select_greedy_action(self, batch_obs, deterministic=False):
         with torch.no_grad(), evaluating(self.policy):
             batch_xs = self.batch_states(batch_obs, self.device, self.phi)
@@ -277,21 +202,9 @@ class SoftActorCritic(AttributeSavingMixin, BatchAgent):
             return policy_out.sample().cpu().numpy()
 
     def batch_act(self, batch_obs):
-        if self.training:
-            return self._batch_act_train(batch_obs)
-        return self._batch_act_eval(batch_obs)
-
-    def batch_observe(self, batch_obs, batch_reward, batch_done, batch_reset):
-        if self.training:
-            self._batch_observe_train(batch_obs, batch_reward, batch_done, batch_reset)
-
-    def _batch_act_eval(self, batch_obs):
-        assert not self.training
-        return self.batch_select_greedy_action(batch_obs,
-                                               deterministic=self.act_deterministically)
-
-    def _batch_act_train(self, batch_obs):
-        assert self.training
+        if not self.training:
+            return self.batch_select_greedy_action(batch_obs,
+                                                   deterministic=self.act_deterministically)
         if self.burnin_action_func is not None and self.n_policy_updates == 0:
             batch_action = [self.burnin_action_func() for _ in range(len(batch_obs))]
         else:
@@ -300,29 +213,13 @@ class SoftActorCritic(AttributeSavingMixin, BatchAgent):
         self.batch_last_action = list(batch_action)
         return batch_action
 
-    def _batch_observe_train(self, batch_obs, batch_reward, batch_done, batch_reset):
-        assert self.training
-        for i in range(len(batch_obs)):
-            self.t += 1
-            if self.batch_last_obs[i] is not None:
-                assert self.batch_last_action[i] is not None
-                self.replay_buffer.append(
-                    state=self.batch_last_obs[i], action=self.batch_last_action[i],
-                    reward=batch_reward[i], next_state=batch_obs[i], next_action=None,
-                    is_state_terminal=batch_done[i], env_id=i)
-                if batch_reset[i] or batch_done[i]:
-                    self.batch_last_obs[i] = None
-                    self.batch_last_action[i] = None
-                    self.replay_buffer.stop_current_episode(env_id=i)
-            self.replay_updater.update_if_necessary(self.t)
-
     def get_statistics(self):
         return [
-            ("average_q1", _mean_or_nan(self.q1_record.values())),
-            ("average_q2", _mean_or_nan(self.q2_record.values())),
-            ("average_q_func1_loss", _mean_or_nan(self.q_func1_loss_record.values())),
-            ("average_q_func2_loss", _mean_or_nan(self.q_func2_loss_record.values())),
+            ("average_q1", self._mean_stat("q1")),
+            ("average_q2", self._mean_stat("q2")),
+            ("average_q_func1_loss", self._mean_stat("loss1")),
+            ("average_q_func2_loss", self._mean_stat("loss2")),
             ("n_updates", self.n_policy_updates),
-            ("average_entropy", _mean_or_nan(self.entropy_record.values())),
+            ("average_entropy", self._mean_stat("entropy")),
             ("temperature", self.temperature),
         ]
