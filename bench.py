@@ -57,6 +57,9 @@ def parse_args():
                    help="transitions to prefill (default: capacity, i.e. full buffer)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-baseline-seconds", type=float, default=12.0)
+    p.add_argument("--cpu-baseline-threads", type=int, default=16,
+                   help="torch CPU threads for the baseline's network (capped by the host; at "
+                        "B=32 the Nature CNN is slower with all 128 threads than with 16)")
     p.add_argument("--no-cudnn-benchmark", dest="cudnn_benchmark", action="store_false",
                    help="do not let MIOpen search conv algorithms")
     p.add_argument("--nchw", dest="channels_last", action="store_false",
@@ -336,6 +339,17 @@ def cpu_baseline(args, seconds):
     """The same workload through the CPU oracle (oracle/pfrl_oracle.c = plain C
     restatement of the reference's data path) plus the same network in torch
     CPU, on this box's host cores, for a bounded sample.  kind = "port"."""
+    N, B = args.num_envs, args.minibatch
+    avail = torch.get_num_threads()
+    cores = max(1, min(avail, args.cpu_baseline_threads))
+    torch.set_num_threads(cores)
+    try:
+        return _cpu_baseline_run(args, seconds, N, B, cores)
+    finally:
+        torch.set_num_threads(avail)
+
+
+def _cpu_baseline_run(args, seconds, N, B, cores):
     import oracle
     import pfrl_amd as pfrl
     from pfrl_amd.agents.dqn import compute_value_loss
@@ -343,8 +357,6 @@ def cpu_baseline(args, seconds):
     from pfrl_amd.q_functions import DiscreteActionValueHead
     from pfrl_amd.utils.random import sample_n_k
 
-    N, B = args.num_envs, args.minibatch
-    cores = torch.get_num_threads()
     rs = np.random.RandomState(0)
     F = 20000
     frames = rs.randint(0, 256, size=(F, 84 * 84)).astype(np.uint8)
@@ -364,9 +376,10 @@ def cpu_baseline(args, seconds):
     opt = torch.optim.RMSprop(q.parameters(), lr=2.5e-4, alpha=0.95, eps=1e-2, centered=True)
     n_updates_per_step = N // args.update_interval
     t0 = time.perf_counter()
-    steps = 0
+    updates = 0
     data_s = 0.0
-    while True:
+    done = False
+    while not done:
         d0 = time.perf_counter()
         refs = rs.randint(0, F, size=(N, 4)).astype(np.int32)
         x = oracle.batch_states_u8(frames, refs, 255.0).reshape(N, 4, 84, 84)
@@ -391,16 +404,20 @@ def cpu_baseline(args, seconds):
             opt.zero_grad()
             loss.backward()
             opt.step()
-        steps += 1
-        el = time.perf_counter() - t0
-        if el >= seconds:
-            break
+            updates += 1
+            # the sample is bounded by time, at update granularity: a batched step is
+            # 64 updates (several seconds on the host), so fractions of a step count
+            if time.perf_counter() - t0 >= seconds:
+                done = True
+                break
+    el = time.perf_counter() - t0
+    steps = updates / n_updates_per_step
     return {
         "value": round(steps * N / el, 2), "unit": "env-steps/s", "cores": cores, "kind": "port",
         "data_path_only_value": round(steps * N / max(data_s, 1e-9), 2),
-        "sample": "%d batched steps of %d envs (%d updates of B=%d) in %.1f s; oracle C data path "
-                  "(single thread) + torch-CPU Nature CNN (%d threads); replay capacity 1e5 on the "
-                  "host" % (steps, N, steps * n_updates_per_step, B, el, cores),
+        "sample": "%.2f batched steps of %d envs (%d updates of B=%d) in %.1f s; oracle C data "
+                  "path (single thread) + torch-CPU Nature CNN (%d threads); replay capacity 1e5 on "
+                  "the host" % (steps, N, updates, B, el, cores),
     }
 
 
