@@ -4,3 +4,5 @@ from pfrl_amd.experiments.train_agent_batch import (save_agent, train_agent_batc
                                                     train_agent_batch_with_evaluation)
 from pfrl_amd.experiments.train_agent import (save_agent_replay_buffer, train_agent,  # NOQA
                                               train_agent_with_evaluation)
+from pfrl_amd.experiments.prepare_output_dir import (generate_exp_id,  # NOQA
+                                                     is_under_git_control, prepare_output_dir)

@@ -233,3 +233,45 @@ def test_train_agent_with_evaluation_rejects_unsupported_hook(tmp_path):
         pfrl.experiments.train_agent_with_evaluation(
             agent=mock.Mock(), env=mock.Mock(), steps=1, eval_n_steps=1, eval_n_episodes=None,
             eval_interval=1, outdir=str(tmp_path), evaluation_hooks=[Hook()])
+
+
+def test_prepare_output_dir(tmp_path, monkeypatch):
+    """Reference tests/experiments_tests/test_prepare_output_dir.py:70-130: files written,
+    explicit and generated ids, backup of an existing directory."""
+    import argparse
+    import json
+    import subprocess
+
+    work = tmp_path / "work"
+    work.mkdir()
+    monkeypatch.chdir(work)
+    args = argparse.Namespace(a=1, b="two")
+    # not under git: the id is the timestamp
+    d = pfrl.experiments.prepare_output_dir(args, basedir=str(tmp_path / "out"), argv=["x", "--y"])
+    assert os.path.dirname(d) == str(tmp_path / "out")
+    assert json.load(open(os.path.join(d, "args.txt"))) == {"a": 1, "b": "two"}
+    assert open(os.path.join(d, "command.txt")).read() == "x --y"
+    assert "PATH" in json.load(open(os.path.join(d, "environ.txt")))
+    assert len(open(os.path.join(d, "start.txt")).read().splitlines()) == 1
+    assert not os.path.exists(os.path.join(d, "git-head.txt"))
+    # explicit id, second start: appended timestamp and a backup of the first state
+    d1 = pfrl.experiments.prepare_output_dir({"k": 3}, basedir=str(tmp_path / "out"), exp_id="run")
+    d2 = pfrl.experiments.prepare_output_dir({"k": 4}, basedir=str(tmp_path / "out"), exp_id="run")
+    assert d1 == d2 and len(open(os.path.join(d2, "start.txt")).read().splitlines()) == 2
+    assert json.load(open(os.path.join(d2, "args.txt"))) == {"k": 4}
+    assert any(n.startswith("run.") and n.endswith(".backup")
+               for n in os.listdir(str(tmp_path / "out")))
+    # under git: deterministic id from HEAD, the diff and argv; git records are saved
+    env = dict(os.environ, GIT_AUTHOR_NAME="t", GIT_AUTHOR_EMAIL="t@t", GIT_COMMITTER_NAME="t",
+               GIT_COMMITTER_EMAIL="t@t")
+    subprocess.check_call(["git", "init", "-q"], cwd=str(work))
+    (work / "f.txt").write_text("hello")
+    subprocess.check_call(["git", "add", "f.txt"], cwd=str(work))
+    subprocess.check_call(["git", "commit", "-q", "-m", "init"], cwd=str(work), env=env)
+    assert pfrl.experiments.is_under_git_control()
+    i1 = pfrl.experiments.generate_exp_id(prefix="p", argv=["a"])
+    assert i1 == pfrl.experiments.generate_exp_id(prefix="p", argv=["a"]) and i1.startswith("p-")
+    assert i1 != pfrl.experiments.generate_exp_id(prefix="p", argv=["b"])
+    d3 = pfrl.experiments.prepare_output_dir(args, basedir=str(tmp_path / "out2"))
+    for name in ("git-head.txt", "git-status.txt", "git-log.txt", "git-diff.txt"):
+        assert os.path.exists(os.path.join(d3, name))
