@@ -66,6 +66,14 @@ int pfrl_frames_synth_u8(void *frames, int64_t frame_bytes, const int32_t *slots
 int pfrl_batch_states_u8(const void *frames, int64_t frame_bytes, const int32_t *refs,
                          int64_t n_refs, float divisor, float *out, void *stream);
 
+/* Same values for stacks of FOUR frames, emitted channels-last: out is f32
+ * [n_obs][frame_bytes][4] = the memory of an NCHW [n_obs][4][H][W] tensor in
+ * torch.channels_last format, which a channels_last network reads without the layout
+ * conversion PyTorch otherwise performs on every forward and backward pass.
+ * refs = int32 [n_obs][4]. */
+int pfrl_batch_states_u8_nhwc4(const void *frames, int64_t frame_bytes, const int32_t *refs,
+                               int64_t n_obs, float divisor, float *out, void *stream);
+
 /* batch_states with the identity phi on float32 observations
  * (examples/gym/train_dqn_gym.py, mujoco examples): plain gather. */
 int pfrl_batch_states_f32(const void *frames, int64_t frame_bytes, const int32_t *refs,
@@ -124,6 +132,14 @@ int pfrl_batch_experiences(const pfrl_table_t *tab, const void *frames, int64_t 
                            const double *host_gamma_pow, float *out_state, float *out_next_state,
                            void *out_action, float *out_reward, float *out_terminal,
                            float *out_discount, void *stream);
+
+/* The same launch with out_state / out_next_state emitted channels-last
+ * ([B][frame_bytes][4] f32; see pfrl_batch_states_u8_nhwc4): u8 frames, tab->k == 4. */
+int pfrl_batch_experiences_nhwc4(const pfrl_table_t *tab, const void *frames, int64_t frame_bytes,
+                                 float divisor, const int32_t *entry_slots, int64_t B,
+                                 const double *host_gamma_pow, float *out_state,
+                                 float *out_next_state, void *out_action, float *out_reward,
+                                 float *out_terminal, float *out_discount, void *stream);
 
 /* ------------------------------------------------------------------------
  * Prioritized buffer: the sliding sum/min trees of

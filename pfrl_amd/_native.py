@@ -102,10 +102,12 @@ EXPORTS = {
     "pfrl_frames_scatter": (ctypes.c_int, "pqppqp"),
     "pfrl_frames_synth_u8": (ctypes.c_int, "pqpqQqqp"),
     "pfrl_batch_states_u8": (ctypes.c_int, "pqpqfpp"),
+    "pfrl_batch_states_u8_nhwc4": (ctypes.c_int, "pqpqfpp"),
     "pfrl_batch_states_f32": (ctypes.c_int, "pqpqpp"),
     "pfrl_table_append": (ctypes.c_int, "Tqppppppp"),
     "pfrl_entries_append": (ctypes.c_int, "Tqpppp"),
     "pfrl_batch_experiences": (ctypes.c_int, "Tpqifpqpppppppp"),
+    "pfrl_batch_experiences_nhwc4": (ctypes.c_int, "Tpqfpqpppppppp"),
     "pfrl_tree_write": (ctypes.c_int, "Rqppppp"),
     "pfrl_tree_sample": (ctypes.c_int, "Rqpppppppppidqpp"),
     "pfrl_tree_update_errors_f32": (ctypes.c_int, "Rqppifdifdddip"),

@@ -401,7 +401,25 @@ class DQN(agent.AttributeSavingMixin, agent.BatchAgent):
         return loss, delta
 
     # -- acting ---------------------------------------------------------------
+    def _route_observation_layout(self, batch_obs=None):
+        """A channels_last network gets its minibatches gathered straight into that
+        memory format (stacks of four u8 planes); checked per call because the model
+        may be converted after the agent was built."""
+        from pfrl_amd.device_store import DeviceObs, DeviceObsBatch
+        from pfrl_amd.nn.atari_cnn import wants_channels_last
+
+        want = self.device.type == "cuda" and wants_channels_last(self.model)
+        store = getattr(getattr(self.replay_buffer, "store", None), "frames", None)
+        if store is not None:
+            store.emit_channels_last = want
+        if batch_obs is not None:
+            first = batch_obs if isinstance(batch_obs, DeviceObsBatch) else (
+                batch_obs[0] if len(batch_obs) else None)
+            if isinstance(first, (DeviceObs, DeviceObsBatch)):
+                first.store.emit_channels_last = want
+
     def _evaluate_model(self, batch_obs):
+        self._route_observation_layout(batch_obs)
         batch_xs = self.batch_states(batch_obs, self.device, self.phi)
         return self.model(batch_xs)
 

@@ -212,7 +212,12 @@ class PPO(agent.AttributeSavingMixin, agent.BatchAgent):
         return d
 
     def _gather(self, refs_dev):
+        from pfrl_amd.nn.atari_cnn import wants_channels_last
+
+        self.frames.emit_channels_last = wants_channels_last(self.model)
         x = self.frames.gather(refs_dev, self._divisor())
+        if x.dim() == 4 and not x.is_contiguous():
+            return x    # channels_last [M, 4, H, W]: already the network's input
         fs = self.frames.frame_shape
         if refs_dev.shape[1] == 1:
             return x.view((x.shape[0],) + fs)

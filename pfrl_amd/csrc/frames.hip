@@ -10,6 +10,7 @@
 #include <hip/hip_ext.h>
 
 #include "common.h"
+#include "nhwc.h"
 
 static char g_err[512] = "";
 extern "C" void pfrl_set_error(const char *msg) { snprintf(g_err, sizeof(g_err), "%s", msg); }
@@ -80,6 +81,22 @@ __global__ __launch_bounds__(kThreads) void k_batch_states_u8(const uint8_t *__r
     const uint32_t *src = reinterpret_cast<const uint32_t *>(frames + slot * frame_bytes);
     float4 *dst = reinterpret_cast<float4 *>(out + f * frame_bytes);
     convert_frame<DIV, NT>(src, dst, (int)(frame_bytes >> 2), d);
+}
+
+// Channels-last variant for stacks of four frames: grid = n_obs * tiles workgroups.
+template <bool DIV, bool NT>
+__global__ __launch_bounds__(kThreads) void k_batch_states_u8_nhwc4(
+    const uint8_t *__restrict__ frames, int64_t frame_bytes, const int32_t *__restrict__ refs,
+    float d, float *__restrict__ out, int tiles) {
+    const int64_t obs = blockIdx.x / tiles;
+    const int tile = (int)(blockIdx.x - obs * tiles);
+    const int32_t *r = refs + obs * 4;
+    const uint8_t *f0 = frames + (int64_t)r[0] * frame_bytes;
+    const uint8_t *f1 = frames + (int64_t)r[1] * frame_bytes;
+    const uint8_t *f2 = frames + (int64_t)r[2] * frame_bytes;
+    const uint8_t *f3 = frames + (int64_t)r[3] * frame_bytes;
+    float4 *dst = reinterpret_cast<float4 *>(out + obs * 4 * frame_bytes);
+    pfrl_nhwc::convert_tile<DIV, NT>(f0, f1, f2, f3, dst, tile, (int)frame_bytes, d);
 }
 
 // f32 frames: plain gather, 16 B per lane when the frame size allows.
@@ -183,6 +200,36 @@ extern "C" int pfrl_batch_states_u8(const void *frames, int64_t frame_bytes, con
         else
             hipExtLaunchKernelGGL((k_batch_states_u8<true, false>), grid, block, 0, st, e0, e1, 0,
                                   fr, frame_bytes, refs, divisor, out);
+    }
+    PFRL_LAUNCH_CHECK();
+}
+
+extern "C" int pfrl_batch_states_u8_nhwc4(const void *frames, int64_t frame_bytes,
+                                          const int32_t *refs, int64_t n_obs, float divisor,
+                                          float *out, void *stream) {
+    PFRL_CHECK_ARG(frame_bytes > 0 && (frame_bytes & 3) == 0, "frame_bytes must be a multiple of 4");
+    if (n_obs <= 0) return 0;
+    const int tiles = (int)((frame_bytes + pfrl_nhwc::kTilePixels - 1) / pfrl_nhwc::kTilePixels);
+    const bool nt = n_obs * 4 * frame_bytes * 4 >= pfrl_nt_min_bytes();
+    const dim3 grid((unsigned)(n_obs * tiles)), block(kThreads);
+    hipStream_t st = (hipStream_t)stream;
+    const uint8_t *fr = (const uint8_t *)frames;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    pfrl_profile_events(PFRL_PROFILE_BATCH_STATES_U8, n_obs * 4, &e0, &e1);
+    if (divisor == 1.0f) {
+        if (nt)
+            hipExtLaunchKernelGGL((k_batch_states_u8_nhwc4<false, true>), grid, block, 0, st, e0,
+                                  e1, 0, fr, frame_bytes, refs, divisor, out, tiles);
+        else
+            hipExtLaunchKernelGGL((k_batch_states_u8_nhwc4<false, false>), grid, block, 0, st, e0,
+                                  e1, 0, fr, frame_bytes, refs, divisor, out, tiles);
+    } else {
+        if (nt)
+            hipExtLaunchKernelGGL((k_batch_states_u8_nhwc4<true, true>), grid, block, 0, st, e0,
+                                  e1, 0, fr, frame_bytes, refs, divisor, out, tiles);
+        else
+            hipExtLaunchKernelGGL((k_batch_states_u8_nhwc4<true, false>), grid, block, 0, st, e0,
+                                  e1, 0, fr, frame_bytes, refs, divisor, out, tiles);
     }
     PFRL_LAUNCH_CHECK();
 }

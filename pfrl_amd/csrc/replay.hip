@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "common.h"
+#include "nhwc.h"
 
 namespace {
 
@@ -293,6 +294,58 @@ __global__ __launch_bounds__(kThreads) void k_batch_experiences_persist(
     }
 }
 
+// Channels-last form (k == 4, u8 frames): grid.x = 2*B*tiles observation-tile blocks
+// followed by ceil(B/256) scalar blocks; see nhwc.h for the tile scheme.
+template <int MODE, typename ActT, bool NT>
+__global__ __launch_bounds__(kThreads) void k_batch_experiences_nhwc4(
+    pfrl_table_t tab, const uint8_t *__restrict__ frames, int64_t frame_bytes, float divisor,
+    const int32_t *__restrict__ entry_slots, int64_t B, GammaPow gp, uint8_t *__restrict__ out_state,
+    uint8_t *__restrict__ out_next, ActT *__restrict__ out_action, float *__restrict__ out_reward,
+    float *__restrict__ out_terminal, float *__restrict__ out_discount, int tiles) {
+    const int64_t nt_blocks = 2 * B * tiles;
+    if ((int64_t)blockIdx.x < nt_blocks) {
+        const int64_t ot = blockIdx.x / tiles;               // observation index in [0, 2B)
+        const int tile = (int)(blockIdx.x - ot * tiles);
+        const bool is_next = ot >= B;
+        const int64_t b = is_next ? ot - B : ot;
+        const int64_t e = entry_slots[b];
+        const int32_t *r;
+        if (!is_next) {
+            r = tab.t_state_ref + (int64_t)tab.e_tids[e * tab.n] * 4;
+        } else {
+            const int len = tab.e_len[e];
+            r = tab.t_next_ref + (int64_t)tab.e_tids[e * tab.n + len - 1] * 4;
+        }
+        const uint8_t *f0 = frames + (int64_t)r[0] * frame_bytes;
+        const uint8_t *f1 = frames + (int64_t)r[1] * frame_bytes;
+        const uint8_t *f2 = frames + (int64_t)r[2] * frame_bytes;
+        const uint8_t *f3 = frames + (int64_t)r[3] * frame_bytes;
+        float4 *dst = reinterpret_cast<float4 *>((is_next ? out_next : out_state) +
+                                                 b * 16 * frame_bytes);
+        pfrl_nhwc::convert_tile<MODE == 0, NT>(f0, f1, f2, f3, dst, tile, (int)frame_bytes,
+                                               divisor);
+        return;
+    }
+    const int64_t b = ((int64_t)blockIdx.x - nt_blocks) * kThreads + threadIdx.x;
+    if (b >= B) return;
+    const int64_t e = entry_slots[b];
+    const int len = tab.e_len[e];
+    double acc = 0.0;
+    bool any = false;
+    for (int i = 0; i < len; ++i) {
+        const int64_t t = tab.e_tids[e * tab.n + i];
+        acc = __dadd_rn(acc, __dmul_rn(gp.g[i], tab.t_reward[t]));
+        any |= tab.t_terminal[t] != 0;
+    }
+    out_reward[b] = (float)acc;
+    out_terminal[b] = any ? 1.0f : 0.0f;
+    out_discount[b] = (float)gp.g[len];
+    const int64_t t0 = tab.e_tids[e * tab.n];
+    const int ad = tab.act_dim > 0 ? tab.act_dim : 1;
+    const ActT *src = reinterpret_cast<const ActT *>(tab.t_action);
+    for (int i = 0; i < ad; ++i) out_action[b * ad + i] = src[t0 * ad + i];
+}
+
 int pfrl_gather_persist_blocks() {
     static const int v = [] {
         const char *e = getenv("PFRL_GATHER_PERSIST");
@@ -461,4 +514,65 @@ extern "C" int64_t pfrl_profile_collect(double *out_us, int64_t *out_units, int3
     }
     g_timed.clear();
     return n;
+}
+
+template <int MODE, bool NT>
+static void launch_be_nhwc4(const pfrl_table_t *tab, const void *frames, int64_t frame_bytes,
+                            float divisor, const int32_t *entry_slots, int64_t B,
+                            const GammaPow &gp, float *out_state, float *out_next_state,
+                            void *out_action, float *out_reward, float *out_terminal,
+                            float *out_discount, hipStream_t stream) {
+    const int tiles = (int)((frame_bytes + pfrl_nhwc::kTilePixels - 1) / pfrl_nhwc::kTilePixels);
+    const unsigned blocks = (unsigned)(2 * B * tiles + (B + kThreads - 1) / kThreads);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    pfrl_profile_events(PFRL_PROFILE_BATCH_EXPERIENCES, B, &e0, &e1);
+    if (tab->act_dim > 0)
+        hipExtLaunchKernelGGL((k_batch_experiences_nhwc4<MODE, float, NT>), dim3(blocks),
+                              dim3(kThreads), 0, stream, e0, e1, 0, *tab, (const uint8_t *)frames,
+                              frame_bytes, divisor, entry_slots, B, gp, (uint8_t *)out_state,
+                              (uint8_t *)out_next_state, (float *)out_action, out_reward,
+                              out_terminal, out_discount, tiles);
+    else
+        hipExtLaunchKernelGGL((k_batch_experiences_nhwc4<MODE, int64_t, NT>), dim3(blocks),
+                              dim3(kThreads), 0, stream, e0, e1, 0, *tab, (const uint8_t *)frames,
+                              frame_bytes, divisor, entry_slots, B, gp, (uint8_t *)out_state,
+                              (uint8_t *)out_next_state, (int64_t *)out_action, out_reward,
+                              out_terminal, out_discount, tiles);
+}
+
+extern "C" int pfrl_batch_experiences_nhwc4(const pfrl_table_t *tab, const void *frames,
+                                            int64_t frame_bytes, float divisor,
+                                            const int32_t *entry_slots, int64_t B,
+                                            const double *host_gamma_pow, float *out_state,
+                                            float *out_next_state, void *out_action,
+                                            float *out_reward, float *out_terminal,
+                                            float *out_discount, void *stream) {
+    PFRL_CHECK_ARG(tab && tab->k == 4, "pfrl_batch_experiences_nhwc4: stacks of 4 frames only");
+    PFRL_CHECK_ARG(tab->n >= 1 && tab->n <= PFRL_MAX_NSTEP, "bad table.n");
+    PFRL_CHECK_ARG(frame_bytes > 0 && (frame_bytes & 3) == 0, "frame_bytes must be a multiple of 4");
+    if (B <= 0) return 0;
+    GammaPow gp;
+    for (int i = 0; i <= tab->n; ++i) gp.g[i] = host_gamma_pow[i];
+    hipStream_t s = (hipStream_t)stream;
+    const bool nt = 2 * B * 16 * frame_bytes >= pfrl_nt_min_bytes();
+    if (divisor == 1.0f) {
+        if (nt)
+            launch_be_nhwc4<1, true>(tab, frames, frame_bytes, divisor, entry_slots, B, gp,
+                                     out_state, out_next_state, out_action, out_reward,
+                                     out_terminal, out_discount, s);
+        else
+            launch_be_nhwc4<1, false>(tab, frames, frame_bytes, divisor, entry_slots, B, gp,
+                                      out_state, out_next_state, out_action, out_reward,
+                                      out_terminal, out_discount, s);
+    } else {
+        if (nt)
+            launch_be_nhwc4<0, true>(tab, frames, frame_bytes, divisor, entry_slots, B, gp,
+                                     out_state, out_next_state, out_action, out_reward,
+                                     out_terminal, out_discount, s);
+        else
+            launch_be_nhwc4<0, false>(tab, frames, frame_bytes, divisor, entry_slots, B, gp,
+                                      out_state, out_next_state, out_action, out_reward,
+                                      out_terminal, out_discount, s);
+    }
+    PFRL_LAUNCH_CHECK();
 }

@@ -49,7 +49,14 @@ class DeviceFrameStore:
         """frames[slots] <- src (device tensor [n, *frame_shape])."""
         ops.frames_scatter(self.frames, src.contiguous(), slots_dev)
 
+    # Set by an agent whose network runs in torch.channels_last: stacks of four u8
+    # planes are then gathered straight into that memory format (pfrl_*_nhwc4) and the
+    # network's per-pass NCHW -> NHWC conversion of the minibatch disappears.
+    emit_channels_last = False
+
     def gather(self, refs_dev, divisor=255.0, out=None):
+        if self.emit_channels_last and ops.channels_last_supported(self.frames, refs_dev.shape[1]):
+            return ops.batch_states_nhwc4(self.frames, refs_dev, divisor, out=out)
         return ops.batch_states(self.frames, refs_dev, divisor, out=out)
 
 

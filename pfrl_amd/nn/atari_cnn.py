@@ -17,6 +17,18 @@ def constant_bias_initializer(bias=0.0):
     return init_bias
 
 
+def wants_channels_last(model):
+    """True if the first convolution of ``model`` keeps its weights in
+    torch.channels_last (``model.to(memory_format=torch.channels_last)``): its input is
+    then best delivered in that format too."""
+    for m in model.modules():
+        if isinstance(m, nn.Conv2d):
+            w = m.weight
+            return (w.dim() == 4 and w.is_contiguous(memory_format=torch.channels_last)
+                    and not w.is_contiguous())
+    return False
+
+
 def _is_relu(activation):
     return activation is F.relu or activation is torch.relu
 

@@ -40,6 +40,40 @@ def frames_synth_u8(frames, slots, seed, env_id0, step):
           "frames_synth_u8")
 
 
+def _spatial_hw(fshape):
+    """(H, W) if the frame is one 2-D plane ((H, W) or (1, H, W)), else None."""
+    dims = [d for d in fshape]
+    while len(dims) > 2 and dims[0] == 1:
+        dims = dims[1:]
+    return tuple(dims) if len(dims) == 2 else None
+
+
+def channels_last_supported(frames, k):
+    """Stacks of four u8 planes can be emitted directly in torch.channels_last."""
+    return (frames.dtype == torch.uint8 and k == 4 and _spatial_hw(tuple(frames.shape[1:]))
+            is not None)
+
+
+def empty_channels_last(M, hw, device):
+    """f32 [M, 4, H, W] tensor whose memory is [M][H][W][4]."""
+    return torch.empty((M, hw[0], hw[1], 4), dtype=torch.float32,
+                       device=device).permute(0, 3, 1, 2)
+
+
+def batch_states_nhwc4(frames, refs, divisor=255.0, out=None):
+    """refs: int32 [M, 4] -> f32 [M, 4, H, W] in channels_last memory format."""
+    M, k = refs.shape
+    assert channels_last_supported(frames, k)
+    hw = _spatial_hw(tuple(frames.shape[1:]))
+    if out is None:
+        out = empty_channels_last(M, hw, frames.device)
+    assert out.is_contiguous(memory_format=torch.channels_last)
+    check(_native.lib().pfrl_batch_states_u8_nhwc4(
+        _ptr(frames), frame_bytes_of(frames), _ptr(refs), M, float(divisor),
+        ctypes.c_void_p(out.data_ptr()), _stream()), "batch_states_u8_nhwc4")
+    return out
+
+
 def batch_states(frames, refs, divisor=255.0, out=None):
     """refs: int32 [M, k] -> f32 [M, k, *frame_shape]."""
     M, k = refs.shape
@@ -112,6 +146,19 @@ def batch_experiences(desc, frames, divisor, entry_slots, gamma_pow, out):
     discount."""
     B = entry_slots.numel()
     gp = (ctypes.c_double * len(gamma_pow))(*gamma_pow)
+    st = out["state"]
+    if st.dim() == 4 and not st.is_contiguous() and \
+            st.is_contiguous(memory_format=torch.channels_last):
+        # channels_last minibatch buffers: the kernel writes [B][H][W][4] directly
+        assert channels_last_supported(frames, desc.k)
+        assert out["next_state"].is_contiguous(memory_format=torch.channels_last)
+        check(_native.lib().pfrl_batch_experiences_nhwc4(
+            ctypes.byref(desc), _ptr(frames), frame_bytes_of(frames), float(divisor),
+            _ptr(entry_slots), B, ctypes.cast(gp, ctypes.c_void_p),
+            ctypes.c_void_p(st.data_ptr()), ctypes.c_void_p(out["next_state"].data_ptr()),
+            _ptr(out["action"]), _ptr(out["reward"]), _ptr(out["is_state_terminal"]),
+            _ptr(out["discount"]), _stream()), "batch_experiences_nhwc4")
+        return out
     check(_native.lib().pfrl_batch_experiences(
         ctypes.byref(desc), _ptr(frames), frame_bytes_of(frames),
         int(frames.dtype == torch.float32), float(divisor), _ptr(entry_slots), B,

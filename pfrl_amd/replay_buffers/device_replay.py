@@ -366,7 +366,9 @@ class DeviceReplayStore:
     def _out_buffers(self, B, tag):
         """Persistent fp32 minibatch buffers (stable addresses let the update
         be replayed from a captured HIP graph)."""
-        key = (tag, B)
+        nhwc = bool(self.frames.emit_channels_last
+                    and ops.channels_last_supported(self.frames.frames, self.k))
+        key = (tag, B, nhwc)
         out = self._out_cache.get(key)
         if out is not None:
             return out
@@ -379,9 +381,14 @@ class DeviceReplayStore:
             oshape = (B, k) + fshape[1:]        # LazyFrames: concatenate on axis 0
         else:
             oshape = (B, k) + fshape
+        if nhwc:
+            hw = oshape[-2:]
+            new_obs = lambda: ops.empty_channels_last(B, hw, dev)
+        else:
+            new_obs = lambda: torch.empty(oshape, dtype=torch.float32, device=dev)
         out = dict(
-            state=torch.empty(oshape, dtype=torch.float32, device=dev),
-            next_state=torch.empty(oshape, dtype=torch.float32, device=dev),
+            state=new_obs(),
+            next_state=new_obs(),
             action=(torch.empty(B, dtype=torch.int64, device=dev) if self.act_dim == 0 else
                     torch.empty((B, self.act_dim), dtype=torch.float32, device=dev)),
             reward=torch.empty(B, dtype=torch.float32, device=dev),

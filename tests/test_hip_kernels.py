@@ -970,3 +970,111 @@ def test_fused_td_loss_vs_oracle_and_golden(dev, double, clip, weighted, mean):
         np.testing.assert_allclose(gq, k("grad"), rtol=1e-6, atol=1e-9)
         np.testing.assert_array_equal(y, k("y"))
         np.testing.assert_allclose(delta, np.abs(k("y") - k("t")), rtol=1e-6, atol=1e-7)
+
+
+# ---------------------------------------------------------------------------
+# channels_last (NHWC) emission of 4-frame stacks
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("fshape,M", [((84, 84), 256), ((1, 84, 84), 37), ((12, 12), 5),
+                                      ((50, 50), 33), ((64, 16), 600)])
+@pytest.mark.parametrize("divisor", [255.0, 1.0])
+def test_batch_states_nhwc4_equals_planar(dev, fshape, M, divisor):
+    """pfrl_batch_states_u8_nhwc4: same values as the planar gather (bit-exact), memory in
+    torch.channels_last; partial tiles, several tiles per observation, both phi forms."""
+    from pfrl_amd import ops
+
+    g = torch.Generator().manual_seed(sum(fshape) + M)
+    F = 300
+    frames = torch.randint(0, 256, (F,) + fshape, dtype=torch.uint8, generator=g).to(dev)
+    refs = torch.randint(0, F, (M, 4), dtype=torch.int32, generator=g).to(dev)
+    assert ops.channels_last_supported(frames, 4)
+    planar = ops.batch_states(frames, refs, divisor)
+    hw = fshape[-2:]
+    planar = planar.reshape(M, 4, hw[0], hw[1])
+    got = ops.batch_states_nhwc4(frames, refs, divisor)
+    assert got.shape == (M, 4, hw[0], hw[1])
+    assert got.is_contiguous(memory_format=torch.channels_last)
+    assert torch.equal(got, planar)
+    # the memory really is [M][H][W][4]
+    assert torch.equal(got.permute(0, 2, 3, 1).contiguous().view(-1),
+                       torch.as_strided(got, (got.numel(),), (1,)))
+
+
+@pytest.mark.parametrize("n,B", [(1, 32), (3, 200)])
+def test_batch_experiences_nhwc4_equals_planar(dev, n, B):
+    """Fused batch_experiences with channels_last minibatch buffers == planar launch."""
+    from pfrl_amd import ops
+
+    rs = np.random.RandomState(n + B)
+    F, R, k = 500, 400, 4
+    frames = torch.from_numpy(rs.randint(0, 256, size=(F, 20, 24)).astype(np.uint8)).to(dev)
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    d_state = T(rs.randint(0, F, size=(R, k)).astype(np.int32))
+    d_next = T(rs.randint(0, F, size=(R, k)).astype(np.int32))
+    d_act = T(rs.randint(0, 6, size=R).astype(np.int64))
+    d_rew = T(rs.randn(R))
+    d_term = T((rs.rand(R) < 0.1).astype(np.uint8))
+    E = 300
+    lens = rs.randint(1, n + 1, size=E).astype(np.int32)
+    tids = -np.ones((E, n), dtype=np.int32)
+    for e in range(E):
+        tids[e, :lens[e]] = rs.randint(0, R, size=lens[e])
+    desc = ops.make_table_desc(d_state, d_next, d_act, d_rew, d_term, T(tids), T(lens), k, n, 0)
+    slots = T(rs.randint(0, E, size=B).astype(np.int32))
+    gp = [0.99 ** i for i in range(n + 1)]
+
+    def outs(nhwc):
+        mk = (lambda: ops.empty_channels_last(B, (20, 24), dev)) if nhwc else \\
+            (lambda: torch.empty((B, k, 20, 24), dtype=torch.float32, device=dev))
+        return dict(state=mk(), next_state=mk(),
+                    action=torch.empty(B, dtype=torch.int64, device=dev),
+                    reward=torch.empty(B, dtype=torch.float32, device=dev),
+                    is_state_terminal=torch.empty(B, dtype=torch.float32, device=dev),
+                    discount=torch.empty(B, dtype=torch.float32, device=dev))
+
+    a = ops.batch_experiences(desc, frames, 255.0, slots, gp, outs(False))
+    b = ops.batch_experiences(desc, frames, 255.0, slots, gp, outs(True))
+    assert b["state"].is_contiguous(memory_format=torch.channels_last)
+    for key in a:
+        assert torch.equal(a[key], b[key]), key
+
+
+def test_dqn_channels_last_observations_equal_planar(dev):
+    """A channels_last conv Q-network fed by NHWC gathers trains bit-identically to the
+    same network fed planar minibatches (PyTorch converts those itself)."""
+    import tempfile
+
+    import pfrl_amd as pfrl
+    from pfrl_amd import agents, explorers, replay_buffers
+    from pfrl_amd.device_store import DeviceFrameStore
+    from pfrl_amd.envs import SyntheticAtariVectorEnv
+    from pfrl_amd.nn import atari_cnn
+    from pfrl_amd.q_functions import DiscreteActionValueHead
+
+    def run(route):
+        pfrl.utils.set_random_seed(0)
+        N = 8
+        store = DeviceFrameStore(4096, (84, 84), torch.uint8, dev, stack=4)
+        env = SyntheticAtariVectorEnv(N, store=store, seed=1, n_actions=4)
+        torch.manual_seed(5)
+        q = torch.nn.Sequential(pfrl.nn.SmallAtariCNN(), torch.nn.Linear(256, 4),
+                                DiscreteActionValueHead()).to(memory_format=torch.channels_last)
+        opt = torch.optim.SGD(q.parameters(), lr=1e-3)
+        rbuf = replay_buffers.ReplayBuffer(1000)
+        ex = explorers.ConstantEpsilonGreedy(0.3, lambda: np.random.randint(4))
+        ag = agents.DQN(q, opt, rbuf, 0.99, ex, gpu=0, replay_start_size=64, minibatch_size=16,
+                        update_interval=4, target_update_interval=50,
+                        phi=lambda x: np.asarray(x, dtype=np.float32) / 255)
+        if not route:
+            ag._route_observation_layout = lambda *a, **k: None
+        pfrl.experiments.train_agent_batch(ag, env, 400, tempfile.mkdtemp())
+        assert store.emit_channels_last == route
+        assert atari_cnn.wants_channels_last(q)
+        return (np.concatenate([p.detach().cpu().numpy().ravel() for p in q.parameters()]),
+                ag.loss_record.values(), ag.optim_t)
+
+    pa, la, ta = run(True)
+    pb, lb, tb = run(False)
+    assert ta == tb > 20
+    np.testing.assert_array_equal(la, lb)
+    np.testing.assert_array_equal(pa, pb)

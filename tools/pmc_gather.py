@@ -8,8 +8,8 @@ Usage (on the GPU box; one pass per counter, kernel-trace only):
 
 Counter_Value of FETCH_SIZE / WRITE_SIZE is in KiB.  WRITE_SIZE matches the
 algorithmic writes exactly; FETCH_SIZE under-reports streaming reads on gfx950
-(MI355X_MICROARCH.md, HBM section) and is calibrated on k_batch_states_u8 at 256
-observations, whose 1024 distinct frames are a known 7 225 344 B.
+(MI355X_MICROARCH.md, HBM section) and is calibrated on the smallest k_batch_states_u8
+launch (the acting gather: every frame of the launch is distinct, so its bytes are known).
 """
 import csv
 import glob
@@ -45,12 +45,15 @@ def main():
     write = load(sys.argv[2], "WRITE_SIZE")
     res = {"unit_note": __doc__.split("Counter_Value")[1].strip().replace("\n", " "),
            "kernels": {}}
-    # calibration: act gather of 256 observations = 1024 frame workgroups
+    # calibration: the smallest acting gather (N observations = 4N frame workgroups, all
+    # frames distinct within one launch): known bytes / reported bytes
     cal = None
-    key = ("k_batch_states_u8", 1024)
-    if key in fetch:
+    acts = sorted(b for (kind, b) in fetch if kind == "k_batch_states_u8")
+    if acts:
+        key = ("k_batch_states_u8", acts[0])
         kib = sum(fetch[key]) / len(fetch[key])
-        cal = 4 * 256 * FRAME / (kib * 1024)
+        cal = acts[0] * FRAME / (kib * 1024)
+        res["fetch_calibrated_on"] = "k_batch_states_u8 (%d frames)" % acts[0]
     res["fetch_calibration_factor"] = cal
     for (kind, blocks) in sorted(set(fetch) | set(write)):
         f = fetch.get((kind, blocks), [])
@@ -78,6 +81,8 @@ def main():
             item["algorithmic_bytes_per_launch"] = alg_r + alg_w
             item["traffic_over_algorithmic"] = round((rb + wb) / (alg_r + alg_w), 4)
         res["kernels"][label] = item
+    if len(sys.argv) > 3:     # keep only the kernel named on the command line
+        res["kernels"] = {k: v for k, v in res["kernels"].items() if k.startswith(sys.argv[3])}
     json.dump(res, sys.stdout, indent=1)
 
 
