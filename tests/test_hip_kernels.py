@@ -1024,7 +1024,7 @@ def test_batch_experiences_nhwc4_equals_planar(dev, n, B):
     gp = [0.99 ** i for i in range(n + 1)]
 
     def outs(nhwc):
-        mk = (lambda: ops.empty_channels_last(B, (20, 24), dev)) if nhwc else \\
+        mk = (lambda: ops.empty_channels_last(B, (20, 24), dev)) if nhwc else \
             (lambda: torch.empty((B, k, 20, 24), dtype=torch.float32, device=dev))
         return dict(state=mk(), next_state=mk(),
                     action=torch.empty(B, dtype=torch.int64, device=dev),
