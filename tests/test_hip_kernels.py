@@ -1019,7 +1019,8 @@ def test_batch_experiences_nhwc4_equals_planar(dev, n, B):
     tids = -np.ones((E, n), dtype=np.int32)
     for e in range(E):
         tids[e, :lens[e]] = rs.randint(0, R, size=lens[e])
-    desc = ops.make_table_desc(d_state, d_next, d_act, d_rew, d_term, T(tids), T(lens), k, n, 0)
+    d_tids, d_lens = T(tids), T(lens)    # the descriptor holds raw pointers: keep these alive
+    desc = ops.make_table_desc(d_state, d_next, d_act, d_rew, d_term, d_tids, d_lens, k, n, 0)
     slots = T(rs.randint(0, E, size=B).astype(np.int32))
     gp = [0.99 ** i for i in range(n + 1)]
 
