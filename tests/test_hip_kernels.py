@@ -1064,7 +1064,7 @@ def test_dqn_channels_last_observations_equal_planar(dev):
         rbuf = replay_buffers.ReplayBuffer(1000)
         ex = explorers.ConstantEpsilonGreedy(0.3, lambda: np.random.randint(4))
         ag = agents.DQN(q, opt, rbuf, 0.99, ex, gpu=0, replay_start_size=64, minibatch_size=16,
-                        update_interval=4, target_update_interval=50,
+                        update_interval=4, target_update_interval=48,
                         phi=lambda x: np.asarray(x, dtype=np.float32) / 255)
         if not route:
             ag._route_observation_layout = lambda *a, **k: None
