@@ -162,7 +162,9 @@ def build_ppo(args, device, rank):
     if args.cudnn_benchmark:
         torch.backends.cudnn.benchmark = True
     if args.channels_last:
-        model = model.to(memory_format=torch.channels_last)
+        # Conv2d + ReLU pairs of the Sequential -> MIOpen conv + one fused bias/ReLU
+        # launch (same parameters, same state_dict)
+        model = pfrl.nn.fuse_conv_bias_relu(model).to(memory_format=torch.channels_last)
     opt = torch.optim.Adam(model.parameters(), lr=2.5e-4, eps=1e-5, fused=True)
     T = 128
     store = DeviceFrameStore((T + 8) * N + 8192, (84, 84), torch.uint8, device, stack=4)

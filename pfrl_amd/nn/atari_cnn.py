@@ -45,11 +45,49 @@ def conv_activation(layer, h, activation):
         from pfrl_amd import ops
 
         z = F.conv2d(h, layer.weight, None, layer.stride, layer.padding, layer.dilation,
-                     layer.groups)
+                     layer.groups)   # (the functional form: layer may be a _ConvSlot)
         if ops.bias_relu_supported(z, layer.bias):
             return ops.bias_relu(z, layer.bias)
         return activation(z + layer.bias.view(1, -1, 1, 1))
+    if isinstance(layer, nn.Conv2d):
+        return activation(nn.Conv2d.forward(layer, h))   # (layer may be a _ConvSlot)
     return activation(layer(h))
+
+
+class _Identity(nn.Module):
+    def forward(self, x):
+        return x
+
+
+def fuse_conv_bias_relu(model):
+    """Rewrite every ``Conv2d`` directly followed by ``ReLU`` inside an ``nn.Sequential``
+    of ``model`` so that bias add + ReLU (and their backward) run as the fused HIP
+    launches; the convolution stays MIOpen's.  Parameters are shared, not copied; the
+    ReLU slot becomes an identity so that indices (and checkpoints' key prefixes,
+    via the ``_ConvSlot`` wrapper's ``weight`` / ``bias`` attributes) are unchanged."""
+    for seq in [m for m in model.modules() if isinstance(m, nn.Sequential)]:
+        mods = list(seq._modules.items())
+        for (ka, a), (kb, b) in zip(mods[:-1], mods[1:]):
+            if isinstance(a, nn.Conv2d) and isinstance(b, nn.ReLU):
+                seq._modules[ka] = _ConvSlot(a)
+                seq._modules[kb] = _Identity()
+    return model
+
+
+class _ConvSlot(nn.Conv2d):
+    """A Conv2d (same class, same parameter names) whose forward also applies bias +
+    ReLU through the fused path; built around the tensors of an existing layer."""
+
+    def __init__(self, conv):
+        nn.Module.__init__(self)
+        self.__dict__.update({k: v for k, v in conv.__dict__.items()
+                              if k not in ("_parameters", "_buffers", "_modules")})
+        self._parameters = conv._parameters
+        self._buffers = conv._buffers
+        self._modules = conv._modules
+
+    def forward(self, x):
+        return conv_activation(self, x, F.relu)
 
 
 class _AtariCNN(nn.Module):

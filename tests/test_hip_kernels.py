@@ -1081,3 +1081,31 @@ def test_dqn_channels_last_observations_equal_planar(dev):
     assert ta == tb > 20
     np.testing.assert_allclose(la, lb, rtol=2e-5, atol=1e-7)
     np.testing.assert_allclose(pa, pb, rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("batch", [8, 1200])
+def test_fuse_conv_bias_relu_sequential(dev, batch):
+    """pfrl.nn.fuse_conv_bias_relu on the PPO example's Sequential: same state_dict, same
+    outputs and gradients as the unfused model (the large batch takes the many-workgroup
+    plan of the bias-gradient reduction)."""
+    import copy
+
+    import pfrl_amd as pfrl
+
+    torch.manual_seed(0)
+    nn = torch.nn
+    plain = nn.Sequential(nn.Conv2d(4, 32, 8, stride=4), nn.ReLU(), nn.Conv2d(32, 64, 4, stride=2),
+                          nn.ReLU(), nn.Conv2d(64, 64, 3, stride=1), nn.ReLU(), nn.Flatten(),
+                          nn.Linear(3136, 16)).to(dev).to(memory_format=torch.channels_last)
+    fused = pfrl.nn.fuse_conv_bias_relu(copy.deepcopy(plain))
+    assert list(fused.state_dict().keys()) == list(plain.state_dict().keys())
+    x = torch.rand(batch, 4, 84, 84, device=dev).contiguous(memory_format=torch.channels_last)
+    ya, yb = fused(x), plain(x)
+    np.testing.assert_allclose(ya.detach().cpu().numpy(), yb.detach().cpu().numpy(), rtol=1e-4,
+                               atol=1e-5)
+    ya.square().mean().backward()
+    yb.square().mean().backward()
+    for (n, pa), pb in zip(fused.named_parameters(), plain.parameters()):
+        scale = max(float(pb.grad.abs().max()), 1e-12)
+        np.testing.assert_allclose(pa.grad.cpu().numpy() / scale, pb.grad.cpu().numpy() / scale,
+                                   rtol=0, atol=2e-4, err_msg=n)
