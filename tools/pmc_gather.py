@@ -19,6 +19,7 @@ import sys
 from collections import defaultdict
 
 FRAME = 84 * 84
+TILES = -(-FRAME // 1024)
 
 
 def load(d, counter):
@@ -36,6 +37,13 @@ def load(d, counter):
                 else:
                     continue
                 blocks = int(r["Grid_Size"]) // int(r["Workgroup_Size"])
+                # normalise the grid to "frame workgroups": the channels-last kernels
+                # launch TILES (ceil(7056 / 1024) = 7) workgroups per 4-frame observation
+                if "nhwc4" in name:
+                    if kind == "k_batch_experiences":
+                        blocks = (blocks // (2 * TILES)) * 8 + 1
+                    else:
+                        blocks = (blocks // TILES) * 4
                 out[(kind, blocks)].append(float(r["Counter_Value"]))
     return out
 
