@@ -482,15 +482,17 @@ def compute_roofline(algo, all_us, all_units, all_kinds):
     # HBM traffic cannot be sampled from inside the process: it is taken from the
     # committed rocprofv3 --pmc passes of this same command
     # (profiles/r01f_pmc_gather.json, tools/pmc_gather.py), per launch shape.
-    try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01f_pmc_gather.json")))
-        kk = pmc["kernels"].get("%s (%d %s)" % (kname, main_units, unit_name))
-        if kk and "traffic_bytes_per_launch" in kk:
-            roofline["traffic"] = kk["traffic_bytes_per_launch"]
-            roofline["traffic_source"] = "profiles/r01f_pmc_gather.json (rocprofv3 --pmc " \
-                                         "FETCH_SIZE / WRITE_SIZE, separate passes, corrected)"
-    except Exception:
-        pass
+    for name in ("r01f_pmc_gather.json", "r01f_pmc_ppo.json"):
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
+            kk = pmc["kernels"].get("%s (%d %s)" % (kname, main_units, unit_name))
+            if kk and "traffic_bytes_per_launch" in kk:
+                roofline["traffic"] = kk["traffic_bytes_per_launch"]
+                roofline["traffic_source"] = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / " \
+                                             "WRITE_SIZE, separate passes, corrected)" % name
+                break
+        except Exception:
+            pass
     return roofline
 
 
