@@ -145,3 +145,30 @@ class DistributionalDiscreteActionValue(ActionValue):
     def __getitem__(self, i):
         return DistributionalDiscreteActionValue(self.q_dist[i], self.z_values,
                                                  q_values_formatter=self.q_values_formatter)
+
+
+class QuantileDiscreteActionValue(DiscreteActionValue):
+    """Return quantiles per action: ``quantiles`` is (batch, n_taus, n_actions); the
+    action values are their mean over the taus (reference :183-229)."""
+
+    def __init__(self, quantiles, q_values_formatter=lambda x: x):
+        assert quantiles.ndim == 3
+        self.quantiles = quantiles
+        super().__init__(quantiles.mean(1), q_values_formatter)
+
+    def evaluate_actions_as_quantiles(self, actions):
+        rows = torch.arange(self.quantiles.shape[0], dtype=torch.long,
+                            device=self.quantiles.device)
+        return self.quantiles[rows, :, actions.long()]
+
+    def __repr__(self):
+        return "QuantileDiscreteActionValue greedy_actions:{} q_values:{}".format(
+            self.greedy_actions.detach().cpu().numpy(),
+            self.q_values_formatter(self.q_values.detach().cpu().numpy()))
+
+    @property
+    def params(self):
+        return (self.quantiles,)
+
+    def __getitem__(self, i):
+        return QuantileDiscreteActionValue(self.quantiles[i], self.q_values_formatter)

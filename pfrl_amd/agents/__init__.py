@@ -6,3 +6,4 @@ from pfrl_amd.agents.categorical_dqn import CategoricalDQN, CategoricalDoubleDQN
 from pfrl_amd.agents.soft_actor_critic import SoftActorCritic  # NOQA
 from pfrl_amd.agents.td3 import TD3  # NOQA
 from pfrl_amd.agents.ddpg import DDPG  # NOQA
+from pfrl_amd.agents.iqn import IQN  # NOQA

@@ -808,6 +808,66 @@ def td3_ddpg_traces(steps=260, N=2, obs_dim=24, act_dim=3):
         print(kind, "trace updates", len(losses))
 
 
+def iqn_trace(steps=640, N=4, prioritized=True):
+    """IQN + PrioritizedReplayBuffer(num_steps=3) on the CPU: thresholds come from the
+    CPU torch generator (three draws per update + one per act), actions / losses /
+    parameters recorded."""
+    sys.path.insert(0, os.path.join(HERE, "..", ".."))
+    import tempfile
+
+    from pfrl import agents, explorers, experiments, replay_buffers
+    from pfrl.agents import iqn as riqn
+
+    from pfrl_amd.envs.synthetic import HostSyntheticAtariVectorEnv
+
+    pfrl.utils.set_random_seed(0)
+    env = HostSyntheticAtariVectorEnv(N, seed=13, frame_shape=(12, 12), p_done=0.04)
+
+    def phi(x):
+        return np.asarray(x, dtype=np.float32) / 255
+
+    torch.manual_seed(9753)
+    q = riqn.ImplicitQuantileQFunction(
+        psi=torch.nn.Sequential(torch.nn.Flatten(), torch.nn.Linear(4 * 144, 32), torch.nn.ReLU()),
+        phi=torch.nn.Sequential(riqn.CosineBasisLinear(16, 32), torch.nn.ReLU()),
+        f=torch.nn.Linear(32, 6))
+    opt = torch.optim.SGD(q.parameters(), lr=1e-2)
+    if prioritized:
+        rbuf = replay_buffers.PrioritizedReplayBuffer(200, alpha=0.5, beta0=0.4, betasteps=100,
+                                                      num_steps=3, normalize_by_max="memory")
+    else:
+        rbuf = replay_buffers.ReplayBuffer(200)
+    ex = explorers.LinearDecayEpsilonGreedy(1.0, 0.1, 400, lambda: np.random.randint(6))
+    ag = agents.IQN(q, opt, rbuf, 0.99, ex, gpu=-1, replay_start_size=40, minibatch_size=8,
+                    update_interval=4, target_update_interval=60, phi=phi,
+                    batch_accumulator="mean", quantile_thresholds_N=8,
+                    quantile_thresholds_N_prime=8, quantile_thresholds_K=4)
+    actions, losses = [], []
+    orig_act = ag.batch_act
+
+    def spy_act(obs):
+        a = orig_act(obs)
+        actions.append([int(x) for x in a])
+        return a
+
+    ag.batch_act = spy_act
+    orig_update = ag.update
+
+    def spy_update(exps, errors_out=None):
+        orig_update(exps, errors_out)
+        losses.append(float(ag.loss_record[-1]))
+
+    ag.replay_updater.update_func = spy_update
+    experiments.train_agent_batch(ag, env, steps, tempfile.mkdtemp())
+    flat = np.concatenate([p.detach().numpy().ravel() for p in q.parameters()])
+    name = "agent_trace_iqn_per_n3.npz" if prioritized else "agent_trace_iqn_uniform.npz"
+    np.savez_compressed(os.path.join(HERE, name),
+                        actions=np.asarray(actions), losses=np.asarray(losses),
+                        final_params=flat,
+                        stats=np.asarray([float(v) for _, v in ag.get_statistics()]))
+    print("iqn trace updates", len(losses))
+
+
 def cartpole_trace(steps=1500):
     """BASELINE configs[0]: examples/gym/train_dqn_gym.py settings (FC Q-function 100x2,
     Adam, ReplayBuffer(5e5), LinearDecayEpsilonGreedy) through the reference's
@@ -1129,6 +1189,8 @@ if __name__ == "__main__":
     ppo_trace()
     a2c_trace()
     cartpole_trace()
+    iqn_trace(prioritized=True)
+    iqn_trace(prioritized=False)
     td3_ddpg_traces()
     c51_projection_golden()
     td_loss_golden()

@@ -617,3 +617,97 @@ def test_td3_ddpg_device_replay_matches_reference(kind, use_graphs):
     else:
         assert ag._captured is None
     _compare_det(got, np.load(os.path.join(GOLDEN, "agent_trace_%s.npz" % kind)))
+
+
+# ---------------------------------------------------------------------------
+# IQN
+# ---------------------------------------------------------------------------
+def _run_iqn(gpu, prioritized, host_thresholds=False, **agent_kw):
+    import pfrl_amd as pfrl
+    from pfrl_amd import agents, explorers, replay_buffers
+    from pfrl_amd.agents import iqn
+    from pfrl_amd.envs.synthetic import HostSyntheticAtariVectorEnv
+
+    N = 4
+    pfrl.utils.set_random_seed(0)
+    env = HostSyntheticAtariVectorEnv(N, seed=13, frame_shape=(12, 12), p_done=0.04)
+
+    def phi(x):
+        return np.asarray(x, dtype=np.float32) / 255
+
+    torch.manual_seed(9753)
+    q = iqn.ImplicitQuantileQFunction(
+        psi=torch.nn.Sequential(torch.nn.Flatten(), torch.nn.Linear(4 * 144, 32), torch.nn.ReLU()),
+        phi=torch.nn.Sequential(iqn.CosineBasisLinear(16, 32), torch.nn.ReLU()),
+        f=torch.nn.Linear(32, 6))
+    opt = torch.optim.SGD(q.parameters(), lr=1e-2)
+    if prioritized:
+        rbuf = replay_buffers.PrioritizedReplayBuffer(200, alpha=0.5, beta0=0.4, betasteps=100,
+                                                      num_steps=3, normalize_by_max="memory")
+    else:
+        rbuf = replay_buffers.ReplayBuffer(200)
+    ex = explorers.LinearDecayEpsilonGreedy(1.0, 0.1, 400, lambda: np.random.randint(6))
+    ag = agents.IQN(q, opt, rbuf, 0.99, ex, gpu=gpu, replay_start_size=40, minibatch_size=8,
+                    update_interval=4, target_update_interval=60, phi=phi,
+                    batch_accumulator="mean", quantile_thresholds_N=8,
+                    quantile_thresholds_N_prime=8, quantile_thresholds_K=4, **agent_kw)
+    if host_thresholds:
+        # the reference trace was recorded with the CPU generator: draw the thresholds
+        # there (same calls, same order) and ship them to the device
+        ag._rand = lambda rows, cols: torch.rand(rows, cols, dtype=torch.float).to(ag.device)
+    actions, losses = [], []
+    orig_act = ag.batch_act
+
+    def spy_act(obs):
+        a = orig_act(obs)
+        actions.append([int(x) for x in a])
+        return a
+
+    ag.batch_act = spy_act
+    orig_core = ag._update_from_batch
+
+    def spy_core(*a, **kw):
+        orig_core(*a, **kw)
+        d = kw.get("deferred")
+        losses.append(float(d[-1][0].detach()) if d else float(ag.loss_record.values()[-1]))
+
+    ag._update_from_batch = spy_core
+    pfrl.experiments.train_agent_batch(ag, env, 640, tempfile.mkdtemp())
+    params = np.concatenate([p.detach().cpu().numpy().ravel() for p in q.parameters()])
+    return dict(actions=np.asarray(actions), losses=np.asarray(losses), final_params=params,
+                agent=ag, rbuf=rbuf)
+
+
+def _compare_iqn(got, g):
+    np.testing.assert_array_equal(got["actions"], g["actions"])
+    np.testing.assert_allclose(got["losses"][:40], g["losses"][:40], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(got["losses"], g["losses"], rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(got["final_params"], g["final_params"], rtol=1e-4, atol=1e-5)
+
+
+def test_iqn_host_mode_matches_reference():
+    g = np.load(os.path.join(GOLDEN, "agent_trace_iqn_uniform.npz"))
+    _compare_iqn(_run_iqn(None, prioritized=False), g)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prioritized", [False, True])
+def test_iqn_device_replay_matches_reference(prioritized):
+    """IQN on the HBM replay path (uniform: step-fused gathers; PER n=3: device trees and
+    KL... quantile-loss priorities), thresholds replayed from the CPU generator."""
+    name = "agent_trace_iqn_per_n3.npz" if prioritized else "agent_trace_iqn_uniform.npz"
+    got = _run_iqn(0, prioritized, host_thresholds=True, use_graphs=False)
+    assert got["rbuf"].is_device
+    _compare_iqn(got, np.load(os.path.join(GOLDEN, name)))
+
+
+@pytest.mark.gpu
+def test_iqn_graph_replay_equals_eager_with_device_thresholds():
+    """Thresholds from the device generator: the captured update draws exactly what the
+    eager update draws (same Philox offsets), so both runs train identically."""
+    eager = _run_iqn(0, True, use_graphs=False)
+    graph = _run_iqn(0, True)
+    assert graph["agent"].use_graphs and graph["agent"]._graphed is not None
+    np.testing.assert_array_equal(graph["actions"], eager["actions"])
+    np.testing.assert_allclose(graph["losses"], eager["losses"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(graph["final_params"], eager["final_params"], rtol=1e-5, atol=1e-6)
