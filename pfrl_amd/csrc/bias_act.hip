@@ -36,7 +36,7 @@ __global__ __launch_bounds__(kThreads) void k_bias_relu_fwd(const float *__restr
 }
 
 // grid = nblk workgroups; workgroup w owns rows [w*rows_per_blk, ...).
-// thread t: column c = t % C, row lane rl = t / C (kThreads % C == 0).
+// thread t: column quad t % (C/4), row lane t / (C/4)  (C % 4 == 0, C <= 256, 256 % C == 0).
 //
 // Cross-workgroup fold without fences: every partial is published as ONE
 // naturally aligned 8-byte granule {value, epoch} with a write-through (sc1)
@@ -51,6 +51,7 @@ __global__ __launch_bounds__(kThreads) void k_bias_relu_bwd(
     const float *__restrict__ gy, const float *__restrict__ y, float *__restrict__ gx,
     float *__restrict__ gb, unsigned long long *__restrict__ granules,
     unsigned long long *__restrict__ ctr, int64_t rows, int C, int64_t rows_per_blk) {
+    __shared__ float4 s_acc4[kThreads];
     __shared__ float s_acc[kThreads];
     __shared__ unsigned int s_epoch;
     __shared__ int s_last;
@@ -59,24 +60,43 @@ __global__ __launch_bounds__(kThreads) void k_bias_relu_bwd(
             __hip_atomic_fetch_add(&ctr[0], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         s_epoch = (unsigned int)(e / gridDim.x) + 1u;
     }
-    const int c = threadIdx.x % C;
-    const int rl = threadIdx.x / C;
-    const int rstep = kThreads / C;
+    // Main pass, four channels per thread (float4; C % 4 == 0): thread t owns column
+    // quad cq = t % (C/4) and walks rows rl, rl + rstep, ...  A wave covers 1 KiB of
+    // contiguous memory per load instruction.
+    const int cq_n = C >> 2;
+    const int cq = threadIdx.x % cq_n;
+    const int rl = threadIdx.x / cq_n;
+    const int rstep = kThreads / cq_n;
     const int64_t r0 = (int64_t)blockIdx.x * rows_per_blk;
     int64_t r1 = r0 + rows_per_blk;
     if (r1 > rows) r1 = rows;
-    float acc = 0.0f;
+    float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    const float4 *y4 = reinterpret_cast<const float4 *>(y);
+    const float4 *gy4 = reinterpret_cast<const float4 *>(gy);
+    float4 *gx4 = reinterpret_cast<float4 *>(gx);
     for (int64_t r = r0 + rl; r < r1; r += rstep) {
-        const int64_t i = r * C + c;
-        const float g = y[i] > 0.0f ? gy[i] : 0.0f;
-        gx[i] = g;
-        acc += g;
+        const int64_t i = r * cq_n + cq;
+        const float4 yv = y4[i];
+        const float4 gv = gy4[i];
+        float4 g;
+        g.x = yv.x > 0.0f ? gv.x : 0.0f;
+        g.y = yv.y > 0.0f ? gv.y : 0.0f;
+        g.z = yv.z > 0.0f ? gv.z : 0.0f;
+        g.w = yv.w > 0.0f ? gv.w : 0.0f;
+        gx4[i] = g;
+        acc.x += g.x;
+        acc.y += g.y;
+        acc.z += g.z;
+        acc.w += g.w;
     }
-    s_acc[threadIdx.x] = acc;
+    // per-workgroup column sums: s_acc4[row lane][column]
+    float *s_flat = reinterpret_cast<float *>(s_acc4);
+    s_acc4[threadIdx.x] = acc;          // thread t = (rl, cq): element t*4 + j = rl*C + cq*4 + j
     __syncthreads();
-    if (rl == 0) {
+    if (threadIdx.x < C) {
+        const int c = threadIdx.x;
         float tot = 0.0f;
-        for (int k = 0; k < rstep; ++k) tot += s_acc[k * C + c];
+        for (int k = 0; k < rstep; ++k) tot += s_flat[k * C + c];
         const unsigned long long g =
             ((unsigned long long)s_epoch << 32) | (unsigned long long)__float_as_uint(tot);
         __hip_atomic_store(&granules[(int64_t)blockIdx.x * C + c], g, __ATOMIC_RELAXED,

@@ -294,12 +294,12 @@ _bias_relu_ws = {}
 
 
 def _bias_relu_plan(rows, C):
-    """Workgroups of the backward launch: ~16 rows per row-lane; at most 256 for the
+    """Workgroups of the backward launch: ~8 rows per row-lane; at most 256 for the
     small minibatches of the replay agents (the last workgroup folds blocks * C
     partials), up to 2048 for rollout-sized batches, which need the whole chip."""
-    rstep = 256 // C
+    rstep = 1024 // C                 # row lanes of a workgroup (float4 per thread)
     cap = 256 if rows <= (1 << 18) else 2048
-    return max(1, min(cap, -(-rows // (rstep * 16))))
+    return max(1, min(cap, -(-rows // (rstep * 8))))
 
 
 def _bias_relu_workspace(device, C, blocks):
