@@ -285,11 +285,17 @@ int pfrl_dqn_td_loss(const float *q, const int64_t *action, const float *target_
  * counters: uint64[2], zero-initialised once, owned by one (C, blocks) pair and
  * never touched by the host afterwards (they carry the launch epoch, which keeps
  * the kernel valid under HIP-graph replay).  Launches that share a workspace
- * must be ordered on one stream.  The rows are split evenly over `blocks`. */
+ * must be ordered on one stream.  The rows are split evenly over `blocks`.
+ * planar_hw > 0: y (forward output; y and gy in backward) is PLANAR, [N][C][planar_hw]
+ * (plain NCHW) instead of rows of C channels -- for the last convolution of a trunk,
+ * whose output is flattened for a linear layer (`h.view(h.size(0), -1)`,
+ * pfrl/nn/atari_cnn.py:46): the flatten and its backward are then views instead of
+ * layout-copy launches.  x and gx stay channels-last rows. */
 int pfrl_bias_relu_fwd(const float *x, const float *bias, float *y, int64_t rows, int32_t C,
-                       void *stream);
+                       int64_t planar_hw, void *stream);
 int pfrl_bias_relu_bwd(const float *gy, const float *y, float *gx, float *gb, uint64_t *granule_ws,
-                       uint64_t *counters, int64_t rows, int32_t C, int32_t blocks, void *stream);
+                       uint64_t *counters, int64_t rows, int32_t C, int32_t blocks,
+                       int64_t planar_hw, void *stream);
 
 /* ------------------------------------------------------------------------
  * Categorical (C51) DQN loss in one launch: replaces

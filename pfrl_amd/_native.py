@@ -118,8 +118,8 @@ EXPORTS = {
     "pfrl_ppo_minibatch": (ctypes.c_int, "qpppipppppippppppp"),
     "pfrl_rmsprop_step": (ctypes.c_int, "ipppppffffip"),
     "pfrl_dqn_td_loss": (ctypes.c_int, "ppppppppqiiippppp"),
-    "pfrl_bias_relu_fwd": (ctypes.c_int, "pppqip"),
-    "pfrl_bias_relu_bwd": (ctypes.c_int, "ppppppqiip"),
+    "pfrl_bias_relu_fwd": (ctypes.c_int, "pppqiqp"),
+    "pfrl_bias_relu_bwd": (ctypes.c_int, "ppppppqiiqp"),
     "pfrl_c51_loss": (ctypes.c_int, "pppppppppiiiippppp"),
     "pfrl_dueling_softmax_fwd": (ctypes.c_int, "pppqiip"),
     "pfrl_dueling_softmax_bwd": (ctypes.c_int, "ppppqiip"),

@@ -35,6 +35,32 @@ __global__ __launch_bounds__(kThreads) void k_bias_relu_fwd(const float *__restr
     }
 }
 
+// Same, but y is written PLANAR ([N][C][HW], i.e. plain NCHW) from a channels-last x:
+// used for the last convolution of a trunk, whose output is flattened for a linear
+// layer -- the flatten is then a view instead of a layout-copy launch (and the same in
+// backward, see k_bias_relu_bwd<true>).  Consecutive threads take consecutive pixels of
+// one channel quad: coalesced stores, strided 16 B loads of a tensor the convolution
+// has just left in L2.
+__global__ __launch_bounds__(kThreads) void k_bias_relu_fwd_planar(
+    const float *__restrict__ x, const float *__restrict__ bias, float *__restrict__ y,
+    int64_t n4, int C, int HW) {
+    const int64_t stride = (int64_t)gridDim.x * kThreads;
+    const int cq_n = C >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n4; i += stride) {
+        const int p = (int)(i % HW);
+        const int64_t t = i / HW;
+        const int cq = (int)(t % cq_n);
+        const int64_t n = t / cq_n;
+        const float4 v = reinterpret_cast<const float4 *>(x)[(n * HW + p) * cq_n + cq];
+        const float4 b = reinterpret_cast<const float4 *>(bias)[cq];
+        float *o = y + (n * C + cq * 4) * HW + p;
+        o[0] = fmaxf(__fadd_rn(v.x, b.x), 0.0f);
+        o[HW] = fmaxf(__fadd_rn(v.y, b.y), 0.0f);
+        o[2 * (int64_t)HW] = fmaxf(__fadd_rn(v.z, b.z), 0.0f);
+        o[3 * (int64_t)HW] = fmaxf(__fadd_rn(v.w, b.w), 0.0f);
+    }
+}
+
 // grid = nblk workgroups; workgroup w owns rows [w*rows_per_blk, ...).
 // thread t: column quad t % (C/4), row lane t / (C/4)  (C % 4 == 0, C <= 256, 256 % C == 0).
 //
@@ -47,10 +73,12 @@ __global__ __launch_bounds__(kThreads) void k_bias_relu_fwd(const float *__restr
 // the protocol valid under HIP-graph replay (kernel arguments are frozen there).
 // A release fence here would write back the whole L2 -- including the gx tile
 // this workgroup just produced -- and cost 15-35 us per launch (measured).
+// PLANAR: gy and y are [N][C][HW] (NCHW); gx is always channels-last rows.
+template <bool PLANAR>
 __global__ __launch_bounds__(kThreads) void k_bias_relu_bwd(
     const float *__restrict__ gy, const float *__restrict__ y, float *__restrict__ gx,
     float *__restrict__ gb, unsigned long long *__restrict__ granules,
-    unsigned long long *__restrict__ ctr, int64_t rows, int C, int64_t rows_per_blk) {
+    unsigned long long *__restrict__ ctr, int64_t rows, int C, int64_t rows_per_blk, int HW) {
     __shared__ float4 s_acc4[kThreads];
     __shared__ float s_acc[kThreads];
     __shared__ unsigned int s_epoch;
@@ -76,8 +104,18 @@ __global__ __launch_bounds__(kThreads) void k_bias_relu_bwd(
     float4 *gx4 = reinterpret_cast<float4 *>(gx);
     for (int64_t r = r0 + rl; r < r1; r += rstep) {
         const int64_t i = r * cq_n + cq;
-        const float4 yv = y4[i];
-        const float4 gv = gy4[i];
+        float4 yv, gv;
+        if (PLANAR) {
+            const int64_t n = r / HW;
+            const int64_t base = (n * C + cq * 4) * HW + (r - n * HW);
+            yv = make_float4(y[base], y[base + HW], y[base + 2 * (int64_t)HW],
+                             y[base + 3 * (int64_t)HW]);
+            gv = make_float4(gy[base], gy[base + HW], gy[base + 2 * (int64_t)HW],
+                             gy[base + 3 * (int64_t)HW]);
+        } else {
+            yv = y4[i];
+            gv = gy4[i];
+        }
         float4 g;
         g.x = yv.x > 0.0f ? gv.x : 0.0f;
         g.y = yv.y > 0.0f ? gv.y : 0.0f;
@@ -152,29 +190,42 @@ __global__ __launch_bounds__(kThreads) void k_bias_relu_bwd(
 }  // namespace
 
 extern "C" int pfrl_bias_relu_fwd(const float *x, const float *bias, float *y, int64_t rows,
-                                  int32_t C, void *stream) {
+                                  int32_t C, int64_t planar_hw, void *stream) {
     PFRL_CHECK_ARG(C > 0 && (C & 3) == 0, "pfrl_bias_relu_fwd: C must be a multiple of 4");
+    PFRL_CHECK_ARG(planar_hw >= 0 && (planar_hw == 0 || rows % planar_hw == 0),
+                   "pfrl_bias_relu_fwd: rows must be a multiple of planar_hw");
     if (rows <= 0) return 0;
     const int64_t n4 = rows * C / 4;
     int64_t blocks = (n4 + kThreads - 1) / kThreads;
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(k_bias_relu_fwd, dim3((unsigned)blocks), dim3(kThreads), 0,
-                       (hipStream_t)stream, x, bias, y, n4, (int)C);
+    if (planar_hw > 0)
+        hipLaunchKernelGGL(k_bias_relu_fwd_planar, dim3((unsigned)blocks), dim3(kThreads), 0,
+                           (hipStream_t)stream, x, bias, y, n4, (int)C, (int)planar_hw);
+    else
+        hipLaunchKernelGGL(k_bias_relu_fwd, dim3((unsigned)blocks), dim3(kThreads), 0,
+                           (hipStream_t)stream, x, bias, y, n4, (int)C);
     PFRL_LAUNCH_CHECK();
 }
 
 extern "C" int pfrl_bias_relu_bwd(const float *gy, const float *y, float *gx, float *gb,
                                   uint64_t *granule_ws, uint64_t *counters, int64_t rows,
-                                  int32_t C, int32_t blocks, void *stream) {
-    PFRL_CHECK_ARG(C > 0 && C <= kThreads && kThreads % C == 0,
-                   "pfrl_bias_relu_bwd: C must divide 256");
+                                  int32_t C, int32_t blocks, int64_t planar_hw, void *stream) {
+    PFRL_CHECK_ARG(C > 0 && C <= kThreads && kThreads % C == 0 && (C & 3) == 0,
+                   "pfrl_bias_relu_bwd: C must be a multiple of 4 that divides 256");
     PFRL_CHECK_ARG(blocks > 0, "pfrl_bias_relu_bwd: blocks must be positive");
+    PFRL_CHECK_ARG(planar_hw >= 0 && (planar_hw == 0 || rows % planar_hw == 0),
+                   "pfrl_bias_relu_bwd: rows must be a multiple of planar_hw");
     if (rows <= 0) return 0;
     const int64_t rows_per_blk = (rows + blocks - 1) / blocks;
-    hipLaunchKernelGGL(k_bias_relu_bwd, dim3((unsigned)blocks), dim3(kThreads), 0,
-                       (hipStream_t)stream, gy, y, gx, gb,
-                       reinterpret_cast<unsigned long long *>(granule_ws),
-                       reinterpret_cast<unsigned long long *>(counters), rows, (int)C,
-                       rows_per_blk);
+    unsigned long long *gr = reinterpret_cast<unsigned long long *>(granule_ws);
+    unsigned long long *ct = reinterpret_cast<unsigned long long *>(counters);
+    if (planar_hw > 0)
+        hipLaunchKernelGGL(k_bias_relu_bwd<true>, dim3((unsigned)blocks), dim3(kThreads), 0,
+                           (hipStream_t)stream, gy, y, gx, gb, gr, ct, rows, (int)C, rows_per_blk,
+                           (int)planar_hw);
+    else
+        hipLaunchKernelGGL(k_bias_relu_bwd<false>, dim3((unsigned)blocks), dim3(kThreads), 0,
+                           (hipStream_t)stream, gy, y, gx, gb, gr, ct, rows, (int)C, rows_per_blk,
+                           1);
     PFRL_LAUNCH_CHECK();
 }

@@ -33,11 +33,13 @@ def _is_relu(activation):
     return activation is F.relu or activation is torch.relu
 
 
-def conv_activation(layer, h, activation):
+def conv_activation(layer, h, activation, planar_out=False):
     """``activation(layer(h))`` for a conv layer.  For ReLU on the GPU with
     channels_last weights: the conv runs without bias, then ONE launch does bias +
     ReLU (and one their backward) instead of PyTorch's separate add / clamp /
-    threshold / reduction kernels."""
+    threshold / reduction kernels.  ``planar_out`` (the last convolution before a
+    flatten): the fused launch also writes the result in plain NCHW, so the flatten
+    and its backward are views rather than layout copies."""
     if (_is_relu(activation) and h.is_cuda and h.dtype == torch.float32
             and isinstance(layer, nn.Conv2d) and layer.bias is not None
             and layer.padding_mode == "zeros"
@@ -47,7 +49,7 @@ def conv_activation(layer, h, activation):
         z = F.conv2d(h, layer.weight, None, layer.stride, layer.padding, layer.dilation,
                      layer.groups)   # (the functional form: layer may be a _ConvSlot)
         if ops.bias_relu_supported(z, layer.bias):
-            return ops.bias_relu(z, layer.bias)
+            return ops.bias_relu(z, layer.bias, planar=planar_out)
         return activation(z + layer.bias.view(1, -1, 1, 1))
     if isinstance(layer, nn.Conv2d):
         return activation(nn.Conv2d.forward(layer, h))   # (layer may be a _ConvSlot)
@@ -102,8 +104,9 @@ class _AtariCNN(nn.Module):
 
     def forward(self, state):
         h = state
-        for layer in self.layers:
-            h = conv_activation(layer, h, self.activation)
+        last = len(self.layers) - 1
+        for i, layer in enumerate(self.layers):
+            h = conv_activation(layer, h, self.activation, planar_out=(i == last))
         return self.activation(self.output(h.reshape(h.size(0), -1)))
 
 

@@ -313,17 +313,25 @@ def _bias_relu_workspace(device, C, blocks):
 
 
 class _BiasReLU(torch.autograd.Function):
-    """y = relu(x + bias[c]) for channels_last conv outputs / [N, C] matrices."""
+    """y = relu(x + bias[c]) for channels_last conv outputs / [N, C] matrices.  With
+    ``planar`` (4-D channels_last x only) y comes out as a plain contiguous NCHW tensor,
+    so that a following flatten is a view; the gradient is then expected in NCHW too."""
 
     @staticmethod
-    def forward(ctx, x, bias):
+    def forward(ctx, x, bias, planar=False):
         C = bias.numel()
         rows = x.numel() // C
-        y = torch.empty_like(x)   # preserves the (dense) layout of x
+        hw = 0
+        if planar:
+            hw = x.shape[2] * x.shape[3]
+            y = torch.empty(x.shape, dtype=torch.float32, device=x.device)   # NCHW
+        else:
+            y = torch.empty_like(x)   # preserves the (dense) layout of x
         check(_native.lib().pfrl_bias_relu_fwd(_ptr_dense(x), _ptr(bias), _ptr_dense(y), rows, C,
-                                               _stream()), "bias_relu_fwd")
+                                               hw, _stream()), "bias_relu_fwd")
         ctx.save_for_backward(y)
         ctx.C = C
+        ctx.hw = hw
         return y
 
     @staticmethod
@@ -332,16 +340,20 @@ class _BiasReLU(torch.autograd.Function):
         C = ctx.C
         rows = y.numel() // C
         if gy.stride() != y.stride():
-            gy = gy.contiguous(memory_format=torch.channels_last) if y.dim() == 4 \
-                else gy.contiguous()
-        gx = torch.empty_like(y)
+            gy = gy.contiguous(memory_format=torch.channels_last) \
+                if (y.dim() == 4 and not ctx.hw) else gy.contiguous()
+        if ctx.hw:
+            gx = torch.empty(y.shape, dtype=torch.float32, device=y.device).contiguous(
+                memory_format=torch.channels_last)
+        else:
+            gx = torch.empty_like(y)
         gb = torch.empty(C, dtype=torch.float32, device=y.device)
         blocks = _bias_relu_plan(rows, C)
         ws, counters = _bias_relu_workspace(y.device, C, blocks)
         check(_native.lib().pfrl_bias_relu_bwd(_ptr_dense(gy), _ptr_dense(y), _ptr_dense(gx),
                                                _ptr(gb), _ptr(ws), _ptr(counters), rows, C,
-                                               blocks, _stream()), "bias_relu_bwd")
-        return gx, gb
+                                               blocks, ctx.hw, _stream()), "bias_relu_bwd")
+        return gx, gb, None
 
 
 def _ptr_dense(t):
@@ -363,8 +375,9 @@ def bias_relu_supported(x, bias):
     return False
 
 
-def bias_relu(x, bias):
-    return _BiasReLU.apply(x, bias)
+def bias_relu(x, bias, planar=False):
+    """``planar=True``: NCHW-contiguous result from a channels_last ``x`` (see _BiasReLU)."""
+    return _BiasReLU.apply(x, bias, bool(planar and x.dim() == 4))
 
 
 class _NoisyWeights(torch.autograd.Function):

@@ -32,8 +32,9 @@ class DuelingDQN(nn.Module):
 
     def forward(self, x):
         h = x
-        for layer in self.conv_layers:
-            h = conv_activation(layer, h, self.activation)
+        last = len(self.conv_layers) - 1
+        for i, layer in enumerate(self.conv_layers):
+            h = conv_activation(layer, h, self.activation, planar_out=(i == last))
         batch_size = x.shape[0]
         h = h.reshape(batch_size, -1)
         ya = self.a_stream(h)
@@ -67,8 +68,9 @@ class DistributionalDuelingDQN(nn.Module):
 
     def forward(self, x):
         h = x
-        for layer in self.conv_layers:
-            h = conv_activation(layer, h, self.activation)
+        last = len(self.conv_layers) - 1
+        for i, layer in enumerate(self.conv_layers):
+            h = conv_activation(layer, h, self.activation, planar_out=(i == last))
         batch_size = x.shape[0]
         h = self.activation(self.main_stream(h.reshape(batch_size, -1)))
         h_a, h_v = torch.chunk(h, 2, dim=1)

@@ -1109,3 +1109,30 @@ def test_fuse_conv_bias_relu_sequential(dev, batch):
         scale = max(float(pb.grad.abs().max()), 1e-12)
         np.testing.assert_allclose(pa.grad.cpu().numpy() / scale, pb.grad.cpu().numpy() / scale,
                                    rtol=0, atol=2e-4, err_msg=n)
+
+
+@pytest.mark.parametrize("shape", [(32, 64, 7, 7), (5, 32, 3, 3), (256, 64, 7, 7), (3, 16, 20, 20)])
+def test_fused_bias_relu_planar_output(dev, shape):
+    """bias_relu(planar=True): channels_last input -> plain NCHW output (and NCHW gradient
+    in, channels_last gradient out); values equal to relu(x + b) and its backward."""
+    from pfrl_amd import ops
+
+    torch.manual_seed(sum(shape))
+    C = shape[1]
+    x = torch.randn(shape, device=dev).contiguous(memory_format=torch.channels_last)
+    xa = x.clone().requires_grad_(True)
+    xb = x.clone().requires_grad_(True)
+    ba = torch.randn(C, device=dev).requires_grad_(True)
+    bb = ba.detach().clone().requires_grad_(True)
+    ya = ops.bias_relu(xa, ba, planar=True)
+    yb = torch.relu(xb + bb.view(1, -1, 1, 1))
+    assert ya.is_contiguous() and ya.shape == yb.shape
+    assert torch.equal(ya, yb)
+    gy = torch.randn(shape, device=dev)     # NCHW, as the backward of a flatten delivers it
+    ya.backward(gy)
+    yb.backward(gy)
+    assert xa.grad.is_contiguous(memory_format=torch.channels_last)
+    assert torch.equal(xa.grad, xb.grad)
+    rows = x.numel() // C
+    np.testing.assert_allclose(ba.grad.cpu().numpy(), bb.grad.cpu().numpy(), rtol=1e-4,
+                               atol=2e-7 * rows)
