@@ -286,6 +286,9 @@ int pfrl_dqn_td_loss(const float *q, const int64_t *action, const float *target_
  * never touched by the host afterwards (they carry the launch epoch, which keeps
  * the kernel valid under HIP-graph replay).  Launches that share a workspace
  * must be ordered on one stream.  The rows are split evenly over `blocks`.
+ * blocks == 0 selects the single-workgroup form for few rows of any width (rows <= 1024,
+ * e.g. the hidden linear layer at minibatch 32): no workspace, granule_ws / counters may
+ * be NULL.
  * planar_hw > 0: y (forward output; y and gy in backward) is PLANAR, [N][C][planar_hw]
  * (plain NCHW) instead of rows of C channels -- for the last convolution of a trunk,
  * whose output is flattened for a linear layer (`h.view(h.size(0), -1)`,

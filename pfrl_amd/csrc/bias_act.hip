@@ -187,6 +187,24 @@ __global__ __launch_bounds__(kThreads) void k_bias_relu_bwd(
     }
 }
 
+// Few rows, any width (the hidden linear layer of a Q-network at minibatch 32: rows = 32,
+// C = 512): ONE workgroup, thread t owns columns t, t + 256, ... and walks the rows;
+// loads are coalesced across the threads and nothing crosses workgroups.
+__global__ __launch_bounds__(kThreads) void k_bias_relu_bwd_small(
+    const float *__restrict__ gy, const float *__restrict__ y, float *__restrict__ gx,
+    float *__restrict__ gb, int rows, int C) {
+    for (int c = threadIdx.x; c < C; c += kThreads) {
+        float acc = 0.0f;
+        for (int r = 0; r < rows; ++r) {
+            const int64_t i = (int64_t)r * C + c;
+            const float g = y[i] > 0.0f ? gy[i] : 0.0f;
+            gx[i] = g;
+            acc += g;
+        }
+        gb[c] = acc;
+    }
+}
+
 }  // namespace
 
 extern "C" int pfrl_bias_relu_fwd(const float *x, const float *bias, float *y, int64_t rows,
@@ -210,6 +228,15 @@ extern "C" int pfrl_bias_relu_fwd(const float *x, const float *bias, float *y, i
 extern "C" int pfrl_bias_relu_bwd(const float *gy, const float *y, float *gx, float *gb,
                                   uint64_t *granule_ws, uint64_t *counters, int64_t rows,
                                   int32_t C, int32_t blocks, int64_t planar_hw, void *stream) {
+    if (blocks == 0) {
+        // single-workgroup form: no workspace, no cross-workgroup fold
+        PFRL_CHECK_ARG(C > 0 && rows <= 1024 && planar_hw == 0,
+                       "pfrl_bias_relu_bwd: the single-workgroup form takes <= 1024 plain rows");
+        if (rows <= 0) return 0;
+        hipLaunchKernelGGL(k_bias_relu_bwd_small, dim3(1), dim3(kThreads), 0, (hipStream_t)stream,
+                           gy, y, gx, gb, (int)rows, (int)C);
+        PFRL_LAUNCH_CHECK();
+    }
     PFRL_CHECK_ARG(C > 0 && C <= kThreads && kThreads % C == 0 && (C & 3) == 0,
                    "pfrl_bias_relu_bwd: C must be a multiple of 4 that divides 256");
     PFRL_CHECK_ARG(blocks > 0, "pfrl_bias_relu_bwd: blocks must be positive");

@@ -56,6 +56,22 @@ def conv_activation(layer, h, activation, planar_out=False):
     return activation(layer(h))
 
 
+def linear_activation(layer, h, activation):
+    """``activation(layer(h))`` for a linear layer: at minibatch sizes on the GPU the
+    bias add + ReLU (forward) and ReLU mask + bias gradient (backward) are one launch
+    each next to the GEMMs."""
+    if (_is_relu(activation) and h.is_cuda and h.dtype == torch.float32 and h.dim() == 2
+            and isinstance(layer, nn.Linear) and layer.bias is not None
+            and h.shape[0] <= 256 and layer.out_features % 4 == 0):
+        from pfrl_amd import ops
+
+        z = F.linear(h, layer.weight)
+        if ops.bias_relu_supported(z, layer.bias):
+            return ops.bias_relu(z, layer.bias)
+        return activation(z + layer.bias)
+    return activation(layer(h))   # large batches: the GEMM's own bias epilogue
+
+
 class _Identity(nn.Module):
     def forward(self, x):
         return x
@@ -107,7 +123,7 @@ class _AtariCNN(nn.Module):
         last = len(self.layers) - 1
         for i, layer in enumerate(self.layers):
             h = conv_activation(layer, h, self.activation, planar_out=(i == last))
-        return self.activation(self.output(h.reshape(h.size(0), -1)))
+        return linear_activation(self.output, h.reshape(h.size(0), -1), self.activation)
 
 
 class LargeAtariCNN(_AtariCNN):

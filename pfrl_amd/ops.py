@@ -348,6 +348,11 @@ class _BiasReLU(torch.autograd.Function):
         else:
             gx = torch.empty_like(y)
         gb = torch.empty(C, dtype=torch.float32, device=y.device)
+        if _bias_relu_small(y, C):
+            check(_native.lib().pfrl_bias_relu_bwd(_ptr_dense(gy), _ptr_dense(y), _ptr_dense(gx),
+                                                   _ptr(gb), None, None, rows, C, 0, 0,
+                                                   _stream()), "bias_relu_bwd")
+            return gx, gb, None
         blocks = _bias_relu_plan(rows, C)
         ws, counters = _bias_relu_workspace(y.device, C, blocks)
         check(_native.lib().pfrl_bias_relu_bwd(_ptr_dense(gy), _ptr_dense(y), _ptr_dense(gx),
@@ -361,11 +366,19 @@ def _ptr_dense(t):
     return ctypes.c_void_p(t.data_ptr())
 
 
+def _bias_relu_small(x, C):
+    """2-D activations with few rows (a hidden linear layer at minibatch size): the
+    single-workgroup backward, any C % 4 == 0."""
+    return x.dim() == 2 and x.shape[0] <= 256 and C % 4 == 0
+
+
 def bias_relu_supported(x, bias):
     """Row-major [rows][C] view available?  (channels_last 4-D or contiguous 2-D)"""
     if not (x.is_cuda and x.dtype == torch.float32 and bias is not None):
         return False
     C = bias.numel()
+    if x.dim() == 2 and x.shape[1] == C and x.is_contiguous() and _bias_relu_small(x, C):
+        return True
     if C % 4 or 256 % C:
         return False
     if x.dim() == 4:

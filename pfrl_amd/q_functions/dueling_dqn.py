@@ -6,7 +6,8 @@ import torch.nn.functional as F
 
 from pfrl_amd import action_value
 from pfrl_amd.initializers import init_chainer_default
-from pfrl_amd.nn.atari_cnn import constant_bias_initializer, conv_activation
+from pfrl_amd.nn.atari_cnn import (constant_bias_initializer, conv_activation,
+                                   linear_activation)
 from pfrl_amd.nn.mlp import MLP
 
 
@@ -72,7 +73,7 @@ class DistributionalDuelingDQN(nn.Module):
         for i, layer in enumerate(self.conv_layers):
             h = conv_activation(layer, h, self.activation, planar_out=(i == last))
         batch_size = x.shape[0]
-        h = self.activation(self.main_stream(h.reshape(batch_size, -1)))
+        h = linear_activation(self.main_stream, h.reshape(batch_size, -1), self.activation)
         h_a, h_v = torch.chunk(h, 2, dim=1)
         ya_flat = self.a_stream(h_a)
         if h.is_cuda:

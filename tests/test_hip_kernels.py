@@ -1136,3 +1136,24 @@ def test_fused_bias_relu_planar_output(dev, shape):
     rows = x.numel() // C
     np.testing.assert_allclose(ba.grad.cpu().numpy(), bb.grad.cpu().numpy(), rtol=1e-4,
                                atol=2e-7 * rows)
+
+
+@pytest.mark.parametrize("rows,C", [(32, 512), (256, 1024), (7, 12), (1, 4)])
+def test_fused_bias_relu_linear_small(dev, rows, C):
+    """The single-workgroup backward for [rows, C] activations of a hidden linear layer."""
+    from pfrl_amd import ops
+
+    torch.manual_seed(rows + C)
+    x = torch.randn(rows, C, device=dev)
+    xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    ba = torch.randn(C, device=dev).requires_grad_(True)
+    bb = ba.detach().clone().requires_grad_(True)
+    assert ops.bias_relu_supported(xa, ba)
+    ya = ops.bias_relu(xa, ba)
+    yb = torch.relu(xb + bb)
+    assert torch.equal(ya, yb)
+    gy = torch.randn(rows, C, device=dev)
+    ya.backward(gy)
+    yb.backward(gy)
+    assert torch.equal(xa.grad, xb.grad)
+    np.testing.assert_allclose(ba.grad.cpu().numpy(), bb.grad.cpu().numpy(), rtol=1e-5, atol=1e-5)
