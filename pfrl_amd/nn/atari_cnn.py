@@ -1,6 +1,8 @@
 """Nature-DQN convolutional trunks (reference pfrl/nn/atari_cnn.py:17-80).
 These are the MFMA part of the workload and stay stock PyTorch-ROCm
 (MIOpen conv + hipBLASLt GEMM)."""
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -56,12 +58,15 @@ def conv_activation(layer, h, activation, planar_out=False):
     return activation(layer(h))
 
 
+_FUSE_LINEAR = os.environ.get("PFRL_FUSE_LINEAR", "1") != "0"
+
+
 def linear_activation(layer, h, activation):
     """``activation(layer(h))`` for a linear layer: at minibatch sizes on the GPU the
     bias add + ReLU (forward) and ReLU mask + bias gradient (backward) are one launch
     each next to the GEMMs."""
-    if (_is_relu(activation) and h.is_cuda and h.dtype == torch.float32 and h.dim() == 2
-            and isinstance(layer, nn.Linear) and layer.bias is not None
+    if (_FUSE_LINEAR and _is_relu(activation) and h.is_cuda and h.dtype == torch.float32
+            and h.dim() == 2 and isinstance(layer, nn.Linear) and layer.bias is not None
             and h.shape[0] <= 256 and layer.out_features % 4 == 0):
         from pfrl_amd import ops
 
