@@ -58,7 +58,10 @@ def conv_activation(layer, h, activation, planar_out=False):
     return activation(layer(h))
 
 
-_FUSE_LINEAR = os.environ.get("PFRL_FUSE_LINEAR", "1") != "0"
+# Measured on the DQN bench: 16.4 k env-steps/s with this fusion vs 17.7 k without (the
+# GEMM without its bias epilogue takes a slower hipBLASLt kernel than the one it
+# replaces), so it is off unless PFRL_FUSE_LINEAR=1.
+_FUSE_LINEAR = os.environ.get("PFRL_FUSE_LINEAR", "0") == "1"
 
 
 def linear_activation(layer, h, activation):
