@@ -13,7 +13,6 @@ launches.  The warm-up iterations PyTorch needs before capture run on a
 snapshot that is restored afterwards, so no extra optimizer step leaks into
 training.
 """
-import copy
 import logging
 import os
 

@@ -22,7 +22,6 @@ device:
 
 so the only per-update host work is the permutation draw.
 """
-import itertools
 import random
 from logging import getLogger
 

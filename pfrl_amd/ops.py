@@ -5,11 +5,10 @@ computation happens in the hand-written gfx950 kernels of pfrl_amd/csrc.
 """
 import ctypes
 
-import numpy as np
 import torch
 
 from pfrl_amd import _native
-from pfrl_amd._native import TableDesc, TreeDesc, check
+from pfrl_amd._native import TableDesc, check
 
 
 def _stream():

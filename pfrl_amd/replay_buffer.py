@@ -13,7 +13,6 @@ Mirrors ``pfrl.replay_buffer`` (/root/reference/pfrl/replay_buffer.py):
 """
 from abc import ABCMeta, abstractmethod
 
-import numpy as np
 import torch
 
 from pfrl_amd.utils.batch_states import batch_states

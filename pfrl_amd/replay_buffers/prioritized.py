@@ -10,7 +10,6 @@ uniform draws taken from the global NumPy stream (so seeds mean the same thing
 as in the reference) and per ``update_errors`` nothing at all when the TD
 errors are already a device tensor.
 """
-import collections
 
 import numpy as np
 import torch

@@ -1,5 +1,4 @@
 """Mode of a torch distribution (reference pfrl/utils/mode_of_distribution.py)."""
-import torch
 from torch import distributions as D
 
 

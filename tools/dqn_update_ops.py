@@ -3,7 +3,6 @@ few updates; prints per-op device time and the memcpy / copy callers."""
 import os
 import sys
 
-import numpy as np
 import torch
 from torch.profiler import ProfilerActivity, profile
 

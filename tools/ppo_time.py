@@ -5,7 +5,6 @@ import sys
 import time
 from collections import defaultdict
 
-import numpy as np
 import torch
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))

@@ -1,6 +1,5 @@
 """Can this stack capture an RCCL all-reduce inside a HIP graph?  (1 rank)"""
 import os
-import sys
 import time
 
 import torch
