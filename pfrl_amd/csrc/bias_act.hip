@@ -131,7 +131,7 @@ __global__ __launch_bounds__(kThreads) void k_bias_relu_bwd(
     float *s_flat = reinterpret_cast<float *>(s_acc4);
     s_acc4[threadIdx.x] = acc;          // thread t = (rl, cq): element t*4 + j = rl*C + cq*4 + j
     __syncthreads();
-    if (threadIdx.x < C) {
+    if ((int)threadIdx.x < C) {
         const int c = threadIdx.x;
         float tot = 0.0f;
         for (int k = 0; k < rstep; ++k) tot += s_flat[k * C + c];
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(kThreads) void k_bias_relu_bwd(
         __syncthreads();
         s_acc[threadIdx.x] = part;
         __syncthreads();
-        if (threadIdx.x < C) {
+        if ((int)threadIdx.x < C) {
             float tot = 0.0f;
             for (int k = 0; k < kThreads / C; ++k) tot += s_acc[k * C + threadIdx.x];
             gb[threadIdx.x] = tot;
