@@ -139,3 +139,89 @@ def test_data_parallel_graph_plans_match_reference(prioritized, backend, tmp_pat
         os.environ.pop("PFRL_FORCE_SPLIT_GRAPH", None)
         os.environ.pop("PFRL_GRAPH_COLLECTIVE", None)
         dist.destroy_process_group()
+
+
+def _agent_worker(rank, world, port, out_dir, kind):
+    """Each rank trains on its own env shard (different env seeds, different replay
+    contents); after the broadcast of rank 0's initial weights and with one averaged
+    gradient per update, the replicas must stay bit-identical."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import tempfile
+
+    import torch.distributed as dist
+
+    import pfrl_amd as pfrl
+    from pfrl_amd import agents, distributed, explorers, replay_buffers
+    from pfrl_amd.envs.synthetic import HostSyntheticAtariVectorEnv, HostSyntheticVectorObsEnv
+
+    distributed.init_process_group_from_env(backend="gloo")
+    torch.set_num_threads(1)
+    pfrl.utils.set_random_seed(100 + rank)     # different init and different exploration per rank
+    lo, hi = distributed.shard_envs(8)
+    n_local = hi - lo
+    if kind == "dqn":
+        env = HostSyntheticAtariVectorEnv(n_local, seed=10 + rank, frame_shape=(8, 8), p_done=0.05)
+        q = torch.nn.Sequential(torch.nn.Flatten(), torch.nn.Linear(4 * 64, 16), torch.nn.ReLU(),
+                                torch.nn.Linear(16, 6), pfrl.q_functions.DiscreteActionValueHead())
+        opt = torch.optim.SGD(q.parameters(), lr=1e-2)
+        ag = agents.DQN(q, opt, replay_buffers.ReplayBuffer(500), 0.99,
+                        explorers.ConstantEpsilonGreedy(0.3, lambda: np.random.randint(6)),
+                        gpu=-1, replay_start_size=20, minibatch_size=8, update_interval=4,
+                        target_update_interval=40,
+                        phi=lambda x: np.asarray(x, dtype=np.float32) / 255)
+        ag.grad_reducer.broadcast_parameters(ag.model)
+        ag.sync_target_network()
+        nets = [q]
+    else:
+        obs_dim, act_dim = 10, 2
+        env = HostSyntheticVectorObsEnv(n_local, obs_dim=obs_dim, act_dim=act_dim, seed=20 + rank,
+                                        p_done=0.05)
+        policy = torch.nn.Sequential(
+            torch.nn.Linear(obs_dim, 16), torch.nn.ReLU(), torch.nn.Linear(16, act_dim),
+            pfrl.nn.BoundByTanh(low=-np.ones(act_dim, dtype=np.float32),
+                                high=np.ones(act_dim, dtype=np.float32)),
+            pfrl.policies.DeterministicHead())
+        mkq = lambda: torch.nn.Sequential(pfrl.nn.ConcatObsAndAction(),
+                                          torch.nn.Linear(obs_dim + act_dim, 16),
+                                          torch.nn.ReLU(), torch.nn.Linear(16, 1))
+        q1, q2 = mkq(), mkq()
+        opts = [torch.optim.SGD(m.parameters(), lr=1e-2) for m in (policy, q1, q2)]
+        ag = agents.TD3(policy, q1, q2, opts[0], opts[1], opts[2], replay_buffers.ReplayBuffer(500),
+                        gamma=0.99, explorer=explorers.AdditiveGaussian(0.1, -1.0, 1.0), gpu=-1,
+                        replay_start_size=20, minibatch_size=8, update_interval=1,
+                        burnin_action_func=lambda: np.random.uniform(-1, 1, act_dim).astype(
+                            np.float32),
+                        target_policy_smoothing_func=lambda a: torch.clamp(a + 0.05, -1, 1))
+        nets = [policy, q1, q2]
+        for m in nets:
+            ag._reducers[m].broadcast_parameters(m)
+        for src, dst in ((policy, ag.target_policy), (q1, ag.target_q_func1),
+                         (q2, ag.target_q_func2)):
+            dst.load_state_dict(src.state_dict())
+    pfrl.experiments.train_agent_batch(ag, env, 200 * n_local // 4, tempfile.mkdtemp())
+    flat = np.concatenate([p.detach().numpy().ravel() for m in nets for p in m.parameters()])
+    n_updates = ag.optim_t if kind == "dqn" else ag.q_func_n_updates
+    np.save(os.path.join(out_dir, "%s_params%d.npy" % (kind, rank)), flat)
+    np.save(os.path.join(out_dir, "%s_updates%d.npy" % (kind, rank)), np.asarray(n_updates))
+    np.save(os.path.join(out_dir, "%s_rlen%d.npy" % (kind, rank)),
+            np.asarray(len(ag.replay_buffer)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("kind", ["dqn", "td3"])
+def test_env_sharded_agents_stay_in_sync_two_ranks_gloo(tmp_path, kind):
+    """world_size 2, gloo, host replay: env shards and replay contents differ per rank,
+    the replicas do not (one averaged gradient per optimizer step)."""
+    world = 2
+    mp.spawn(_agent_worker, args=(world, _free_port(), str(tmp_path), kind), nprocs=world,
+             join=True)
+    p0 = np.load(tmp_path / ("%s_params0.npy" % kind))
+    p1 = np.load(tmp_path / ("%s_params1.npy" % kind))
+    u0 = int(np.load(tmp_path / ("%s_updates0.npy" % kind)))
+    u1 = int(np.load(tmp_path / ("%s_updates1.npy" % kind)))
+    assert u0 == u1 > 10
+    np.testing.assert_array_equal(p0, p1)
+    assert np.isfinite(p0).all()
