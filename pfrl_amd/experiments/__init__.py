@@ -6,3 +6,4 @@ from pfrl_amd.experiments.train_agent import (save_agent_replay_buffer, train_ag
                                               train_agent_with_evaluation)
 from pfrl_amd.experiments.prepare_output_dir import (generate_exp_id,  # NOQA
                                                      is_under_git_control, prepare_output_dir)
+from pfrl_amd.experiments.hooks import EvaluationHook, StepHook  # NOQA

@@ -1,5 +1,7 @@
 from pfrl_amd import explorer as _explorer
 from pfrl_amd.explorers.additive_gaussian import AdditiveGaussian  # NOQA
+from pfrl_amd.explorers.additive_ou import AdditiveOU  # NOQA
+from pfrl_amd.explorers.boltzmann import Boltzmann  # NOQA
 from pfrl_amd.explorers.epsilon_greedy import (ConstantEpsilonGreedy,  # NOQA
                                                ExponentialDecayEpsilonGreedy,
                                                LinearDecayEpsilonGreedy)

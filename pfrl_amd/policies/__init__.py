@@ -45,6 +45,19 @@ class GaussianHeadWithDiagonalCovariance(nn.Module):
             torch.distributions.Normal(loc=mean, scale=scale), 1)
 
 
+class GaussianHeadWithFixedCovariance(nn.Module):
+    """Diagonal Gaussian around the network output with a constant scale (reference
+    gaussian_policy.py:97-124)."""
+
+    def __init__(self, scale=1):
+        super().__init__()
+        self.scale = scale
+
+    def forward(self, mean):
+        return torch.distributions.Independent(
+            torch.distributions.Normal(loc=mean, scale=self.scale), 1)
+
+
 class DeterministicHead(nn.Module):
     """Deterministic policy output as a distribution (reference
     pfrl/policies/deterministic_policy.py:7-11)."""

@@ -90,3 +90,8 @@ class VectorFrameStack(VectorEnvWrapper):
         assert len(self.frames) == self.env.num_envs
         assert len(self.frames[0]) == self.k
         return [LazyFrames(list(frames), stack_axis=self.stack_axis) for frames in self.frames]
+
+
+from pfrl_amd.wrappers.env_wrappers import (CastObservation, CastObservationToFloat32,  # NOQA,E402
+                                            ContinuingTimeLimit, NormalizeActionSpace,
+                                            RandomizeAction, ScaleReward, Wrapper)
