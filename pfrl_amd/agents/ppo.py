@@ -126,13 +126,13 @@ class PPO(agent.AttributeSavingMixin, agent.BatchAgent):
         self.obs_normalizer = obs_normalizer
         if recurrent:
             raise NotImplementedError("recurrent PPO is outside the batched hot path")
-        if obs_normalizer is not None:
-            raise NotImplementedError("obs_normalizer (MuJoCo PPO) is not on the Atari hot path")
         if gpu is None or gpu < 0:
             raise RuntimeError("pfrl_amd.PPO keeps its rollout in HBM and needs gpu >= 0")
         assert torch.cuda.is_available()
         self.device = torch.device("cuda:{}".format(gpu))
         self.model.to(self.device)
+        if self.obs_normalizer is not None:
+            self.obs_normalizer.to(self.device)
         from pfrl_amd import _native
 
         _native.lib()
@@ -224,6 +224,16 @@ class PPO(agent.AttributeSavingMixin, agent.BatchAgent):
             return x.view((x.shape[0], refs_dev.shape[1]) + fs[1:])
         return x
 
+    def _features(self, refs_dev):
+        """Network input for a batch of observation refs: the gathered fp32 batch,
+        normalised with the CURRENT statistics of ``obs_normalizer`` if there is one
+        (reference ppo.py:75-77,124-126,486-487,689-690: always ``update=False``; the
+        statistics only learn in :meth:`_update`, once per rollout)."""
+        x = self._gather(refs_dev)
+        if self.obs_normalizer is not None:
+            x = self.obs_normalizer(x, update=False)
+        return x
+
     # -- acting --------------------------------------------------------------------
     def _sample_action(self, action_distrib):
         return action_distrib.sample()
@@ -233,7 +243,7 @@ class PPO(agent.AttributeSavingMixin, agent.BatchAgent):
         refs, dev_batch = self._refs_of(batch_obs)
         self._sample_obs = dev_batch[0]
         (refs_dev,) = self._stage.upload([refs])
-        b_state = self._gather(refs_dev)
+        b_state = self._features(refs_dev)
         with torch.no_grad(), evaluating(self.model):
             action_distrib, batch_value = self.model(b_state)
             action_dev = self._sample_action(action_distrib)
@@ -250,7 +260,7 @@ class PPO(agent.AttributeSavingMixin, agent.BatchAgent):
         refs, dev_batch = self._refs_of(batch_obs)
         self._sample_obs = dev_batch[0]
         (refs_dev,) = self._stage.upload([refs])
-        b_state = self._gather(refs_dev)
+        b_state = self._features(refs_dev)
         with torch.no_grad(), evaluating(self.model):
             action_distrib, _ = self.model(b_state)
             if self.act_deterministically:
@@ -306,7 +316,7 @@ class PPO(agent.AttributeSavingMixin, agent.BatchAgent):
         with torch.no_grad(), evaluating(self.model):
             for lo in range(0, M, self.value_pass_chunk):
                 hi = min(M, lo + self.value_pass_chunk)
-                distribs, vs = self.model(self._gather(refs_dev[lo:hi]))
+                distribs, vs = self.model(self._features(refs_dev[lo:hi]))
                 values[lo:hi] = vs.reshape(-1)
                 if actions_dev is not None:
                     log_probs[lo:hi] = distribs.log_prob(actions_dev[lo:hi])
@@ -369,6 +379,11 @@ class PPO(agent.AttributeSavingMixin, agent.BatchAgent):
             mean_std = global_mean_std(ops.adv_stats(adv), n)
         else:
             mean_std = torch.zeros(2, dtype=torch.float32, device=dev)
+        if self.obs_normalizer is not None:
+            # the statistics learn from all states of the rollout at once, after the
+            # value pass and before the epochs (reference ppo.py:460-471)
+            with torch.no_grad():
+                self.obs_normalizer.experience(self._gather(s_refs))
         actions_i64 = actions if actions.dtype == torch.int64 else None
         self._last_dataset = dict(order=order, adv=adv, v_teacher=v_teacher, v_pred=v_pred,
                                   log_prob=log_probs, mean_std=mean_std)
@@ -385,7 +400,7 @@ class PPO(agent.AttributeSavingMixin, agent.BatchAgent):
                 mb = ops.ppo_minibatch(idx, adv, mean_std, self.standardize_advantages, log_probs,
                                        v_pred, v_teacher, dummy, s_refs)
                 mb_actions = actions[idx]
-            states = self._gather(mb["refs"])
+            states = self._features(mb["refs"])
             distribs, vs_pred = self.model(states)
             self.model.zero_grad()
             loss = self._lossfun(

@@ -5,3 +5,4 @@ from pfrl_amd.nn.mlp import MLP  # NOQA
 from pfrl_amd.nn.noisy_linear import FactorizedNoisyLinear, to_factorized_noisy  # NOQA
 from pfrl_amd.nn.concat_obs_and_action import (BoundByTanh, ConcatObsAndAction, Lambda,  # NOQA
                                                bound_by_tanh)
+from pfrl_amd.nn.empirical_normalization import EmpiricalNormalization  # NOQA

@@ -638,6 +638,83 @@ def ppo_trace(name="ppo", steps=280, N=4):
     print("ppo_trace updates", ag.n_updates, "datasets", len(datasets))
 
 
+def _exp2(x):
+    return torch.exp(2 * x)
+
+
+def make_ppo_gaussian_model(obs_dim, act_dim, policies_mod, nn_mod):
+    """The policy / value model of examples/mujoco/reproduction/ppo/train_ppo.py:112-134 in
+    small: tanh MLP, state-independent diagonal covariance, separate value head."""
+    torch.manual_seed(8642)
+    return torch.nn.Sequential(
+        torch.nn.Linear(obs_dim, 16), torch.nn.Tanh(),
+        nn_mod.Branched(
+            torch.nn.Sequential(
+                torch.nn.Linear(16, act_dim),
+                policies_mod.GaussianHeadWithStateIndependentCovariance(
+                    action_size=act_dim, var_type="diagonal", var_func=_exp2, var_param_init=0)),
+            torch.nn.Linear(16, 1)))
+
+
+def ppo_mujoco_trace(steps=280, N=4, obs_dim=11, act_dim=3):
+    """PPO with float32 vector observations, continuous actions and an
+    EmpiricalNormalization obs_normalizer (clip 5), as the MuJoCo examples use it."""
+    sys.path.insert(0, os.path.join(HERE, "..", ".."))
+    import tempfile
+
+    from pfrl import agents, experiments
+
+    from pfrl_amd.envs.synthetic import HostSyntheticVectorObsEnv
+
+    pfrl.utils.set_random_seed(0)
+    env = HostSyntheticVectorObsEnv(N, obs_dim=obs_dim, act_dim=act_dim, seed=6, p_done=0.05)
+    model = make_ppo_gaussian_model(obs_dim, act_dim, pfrl.policies, pfrl.nn)
+    normalizer = pfrl.nn.EmpiricalNormalization(obs_dim, clip_threshold=5)
+    opt = torch.optim.SGD(model.parameters(), lr=1e-2)
+    ag = agents.PPO(model, opt, obs_normalizer=normalizer, gpu=-1, gamma=0.99, lambd=0.95,
+                    update_interval=64, minibatch_size=16, epochs=2, clip_eps=0.2,
+                    clip_eps_vf=None, standardize_advantages=True, entropy_coef=0.0,
+                    max_grad_norm=0.5)
+    actions, losses, datasets, norm_stats = [], [], [], []
+    orig_act = ag.batch_act
+
+    def spy_act(obs):
+        a = orig_act(obs)
+        actions.append(np.asarray(a, dtype=np.float32))
+        return a
+
+    ag.batch_act = spy_act
+    orig_loss = ag._lossfun
+
+    def spy_loss(*a, **kw):
+        out = orig_loss(*a, **kw)
+        losses.append([float(out), ag.value_loss_record[-1], ag.policy_loss_record[-1]])
+        return out
+
+    ag._lossfun = spy_loss
+    orig_update = ag._update
+
+    def spy_update(dataset):
+        datasets.append(np.asarray([[float(b["adv"]), float(b["v_teacher"]), float(b["v_pred"]),
+                                     float(b["log_prob"])] for b in dataset]))
+        r = orig_update(dataset)
+        norm_stats.append(np.concatenate([normalizer.mean.numpy(), normalizer.std.numpy(),
+                                          [float(normalizer.count)]]))
+        return r
+
+    ag._update = spy_update
+    experiments.train_agent_batch(ag, env, steps, tempfile.mkdtemp())
+    out = dict(actions=np.asarray(actions), losses=np.asarray(losses),
+               final_params=np.concatenate([p.detach().numpy().ravel()
+                                            for p in model.parameters()]),
+               n_updates=np.asarray(ag.n_updates), norm_stats=np.asarray(norm_stats))
+    for i, d in enumerate(datasets):
+        out["dataset%d" % i] = d
+    out["n_datasets"] = np.asarray(len(datasets))
+    np.savez_compressed(os.path.join(HERE, "agent_trace_ppo_mujoco.npz"), **out)
+    print("ppo_mujoco_trace updates", ag.n_updates, "datasets", len(datasets))
+
+
 def a2c_trace(name="a2c", steps=120, N=4):
     sys.path.insert(0, os.path.join(HERE, "..", ".."))
     import tempfile
@@ -1187,6 +1264,7 @@ if __name__ == "__main__":
     agent_trace("dqn_uniform_n1", False, 1, False)
     agent_trace("ddqn_per_n3", True, 3, True)
     ppo_trace()
+    ppo_mujoco_trace()
     a2c_trace()
     cartpole_trace()
     iqn_trace(prioritized=True)

@@ -711,3 +711,80 @@ def test_iqn_graph_replay_equals_eager_with_device_thresholds():
     np.testing.assert_array_equal(graph["actions"], eager["actions"])
     np.testing.assert_allclose(graph["losses"], eager["losses"], rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(graph["final_params"], eager["final_params"], rtol=1e-5, atol=1e-6)
+
+
+def _exp2(x):
+    return torch.exp(2 * x)
+
+
+@pytest.mark.gpu
+def test_ppo_vector_obs_with_obs_normalizer_matches_reference():
+    """MuJoCo-style PPO: float32 vector observations in the HBM store, continuous actions,
+    EmpiricalNormalization learning once per rollout -- against the reference trace
+    (actions replayed: device and host generators differ)."""
+    import pfrl_amd as pfrl
+    from pfrl_amd import agents
+    from pfrl_amd.envs.synthetic import HostSyntheticVectorObsEnv
+
+    g = np.load(os.path.join(GOLDEN, "agent_trace_ppo_mujoco.npz"))
+    N, obs_dim, act_dim = 4, 11, 3
+    pfrl.utils.set_random_seed(0)
+    env = HostSyntheticVectorObsEnv(N, obs_dim=obs_dim, act_dim=act_dim, seed=6, p_done=0.05)
+    torch.manual_seed(8642)
+    model = torch.nn.Sequential(
+        torch.nn.Linear(obs_dim, 16), torch.nn.Tanh(),
+        pfrl.nn.Branched(
+            torch.nn.Sequential(
+                torch.nn.Linear(16, act_dim),
+                pfrl.policies.GaussianHeadWithStateIndependentCovariance(
+                    action_size=act_dim, var_type="diagonal", var_func=_exp2, var_param_init=0)),
+            torch.nn.Linear(16, 1)))
+    normalizer = pfrl.nn.EmpiricalNormalization(obs_dim, clip_threshold=5)
+    opt = torch.optim.SGD(model.parameters(), lr=1e-2)
+    ag = agents.PPO(model, opt, obs_normalizer=normalizer, gpu=0, gamma=0.99, lambd=0.95,
+                    update_interval=64, minibatch_size=16, epochs=2, clip_eps=0.2,
+                    clip_eps_vf=None, standardize_advantages=True, entropy_coef=0.0,
+                    max_grad_norm=0.5)
+    step = [0]
+
+    def replay_action(distrib):
+        a = torch.as_tensor(g["actions"][step[0]], device=ag.device)
+        step[0] += 1
+        return a
+
+    ag._sample_action = replay_action
+    losses, datasets, norm_stats = [], [], []
+    orig_loss = ag._lossfun
+
+    def spy_loss(*a, **kw):
+        out = orig_loss(*a, **kw)
+        losses.append([float(out.detach()), float(ag.value_loss_record.values()[-1]),
+                       float(ag.policy_loss_record.values()[-1])])
+        return out
+
+    ag._lossfun = spy_loss
+    orig_update = ag._update
+
+    def spy_update():
+        orig_update()
+        d = ag._last_dataset
+        o = torch.from_numpy(d["order"]).to(ag.device)
+        datasets.append(np.stack([d["adv"][o].cpu().numpy(), d["v_teacher"][o].cpu().numpy(),
+                                  d["v_pred"][o].cpu().numpy(), d["log_prob"][o].cpu().numpy()],
+                                 axis=1))
+        norm_stats.append(np.concatenate([normalizer.mean.cpu().numpy(),
+                                          normalizer.std.cpu().numpy(),
+                                          [float(normalizer.count)]]))
+
+    ag._update = spy_update
+    pfrl.experiments.train_agent_batch(ag, env, 280, tempfile.mkdtemp())
+    assert ag.n_updates == int(g["n_updates"]) and len(datasets) == int(g["n_datasets"])
+    np.testing.assert_allclose(np.asarray(norm_stats), g["norm_stats"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(datasets[0], g["dataset0"], rtol=1e-5, atol=1e-5)
+    for i in range(1, len(datasets)):
+        np.testing.assert_allclose(datasets[i], g["dataset%d" % i], rtol=1e-4, atol=1e-4)
+    got = np.asarray(losses)
+    np.testing.assert_allclose(got[:8], g["losses"][:8], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(got, g["losses"], rtol=1e-4, atol=1e-4)
+    params = np.concatenate([p.detach().cpu().numpy().ravel() for p in model.parameters()])
+    np.testing.assert_allclose(params, g["final_params"], rtol=1e-4, atol=1e-5)

@@ -309,3 +309,31 @@ def test_distributional_fc_q_function():
     import pickle
 
     pickle.loads(pickle.dumps(q))
+
+
+def test_empirical_normalization_matches_batch_statistics():
+    """pfrl/nn/empirical_normalization.py: after seeing batches the running mean / variance
+    equal those of all data seen; clip and ``until``; forward(update=False) leaves them."""
+    torch.manual_seed(0)
+    en = pfrl.nn.EmpiricalNormalization(3, clip_threshold=2.0)
+    xs = [torch.randn(n, 3) * 2 + 1 for n in (5, 17, 1)]
+    for x in xs:
+        en.experience(x)
+    allx = torch.cat(xs)
+    np.testing.assert_allclose(en.mean.numpy(), allx.mean(0).numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(en.std.numpy(), allx.std(0, unbiased=False).numpy(), rtol=1e-5)
+    assert int(en.count) == 23
+    y = en(allx, update=False)
+    assert int(en.count) == 23 and float(y.abs().max()) <= 2.0
+    want = torch.clamp((allx - allx.mean(0)) / torch.sqrt(allx.var(0, unbiased=False) + 1e-2),
+                       -2.0, 2.0)
+    np.testing.assert_allclose(y.numpy(), want.numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(en.inverse((allx - en.mean) / torch.sqrt(en.std ** 2 + 1e-2)).numpy(),
+                               allx.numpy(), rtol=1e-4, atol=1e-4)
+    lim = pfrl.nn.EmpiricalNormalization(3, until=10)
+    lim(torch.randn(8, 3))
+    lim(torch.randn(8, 3))
+    m = lim.mean.clone()
+    lim(torch.randn(8, 3))            # count 16 >= 10: frozen
+    assert int(lim.count) == 16 and torch.equal(lim.mean, m)
+    assert set(en.state_dict().keys()) == {"_mean", "_var", "count"}
