@@ -7,3 +7,5 @@ from pfrl_amd.agents.soft_actor_critic import SoftActorCritic  # NOQA
 from pfrl_amd.agents.td3 import TD3  # NOQA
 from pfrl_amd.agents.ddpg import DDPG  # NOQA
 from pfrl_amd.agents.iqn import IQN  # NOQA
+from pfrl_amd.agents.advantage_learning import AL, PAL, DoublePAL  # NOQA
+from pfrl_amd.agents.dpp import DPP, DPPL, DPPGreedy  # NOQA

@@ -503,7 +503,8 @@ def make_q_function(n_in, n_actions, head):
         torch.nn.Linear(32, n_actions), head)
 
 
-def agent_trace(name, prioritized, num_steps, double, steps=640, N=4):
+def agent_trace(name, prioritized, num_steps, double, steps=640, N=4, agent_cls=None,
+                **agent_kw):
     sys.path.insert(0, os.path.join(HERE, "..", ".."))
     from pfrl_amd.envs.synthetic import HostSyntheticAtariVectorEnv  # env only (numpy)
 
@@ -528,8 +529,11 @@ def agent_trace(name, prioritized, num_steps, double, steps=640, N=4):
         rbuf = replay_buffers.ReplayBuffer(200, num_steps=num_steps)
     ex = explorers.LinearDecayEpsilonGreedy(1.0, 0.1, 400, lambda: np.random.randint(6))
     cls = agents.DoubleDQN if double else agents.DQN
+    if agent_cls is not None:
+        cls = getattr(agents, agent_cls, None) or getattr(agents.dpp, agent_cls)
     ag = cls(q, opt, rbuf, 0.99, ex, gpu=-1, replay_start_size=40, minibatch_size=8,
-             update_interval=4, target_update_interval=60, phi=phi, batch_accumulator="sum")
+             update_interval=4, target_update_interval=60, phi=phi, batch_accumulator="sum",
+             **agent_kw)
     actions, losses, sampled = [], [], []
     orig_act = ag.batch_act
 
@@ -568,6 +572,12 @@ def agent_trace(name, prioritized, num_steps, double, steps=640, N=4):
 #    standardisation, minibatch order from `random`, losses) is then
 #    comparable.
 # --------------------------------------------------------------------------
+# DQN variants that only change the target (advantage learning, dynamic policy programming)
+DQN_FAMILY = [("al", "AL", dict(alpha=0.9)), ("pal", "PAL", dict(alpha=0.8)),
+              ("double_pal", "DoublePAL", dict(alpha=0.9)), ("dpp", "DPP", dict(eta=2.0)),
+              ("dppl", "DPPL", dict(eta=0.5)), ("dpp_greedy", "DPPGreedy", dict())]
+
+
 def make_ppo_model(n_in, n_actions, SoftmaxCategoricalHead, Branched):
     torch.manual_seed(4321)
     return torch.nn.Sequential(
@@ -1267,6 +1277,8 @@ if __name__ == "__main__":
     ppo_mujoco_trace()
     a2c_trace()
     cartpole_trace()
+    for fam in DQN_FAMILY:
+        agent_trace(fam[0], False, 1, False, agent_cls=fam[1], **fam[2])
     iqn_trace(prioritized=True)
     iqn_trace(prioritized=False)
     td3_ddpg_traces()

@@ -13,7 +13,7 @@ GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
 
 
 def _run(name, prioritized, num_steps, double, gpu, priority_pow="device", steps=640, N=4,
-         spies=True, **agent_kw):
+         spies=True, agent_cls=None, **agent_kw):
     import pfrl_amd as pfrl
     from pfrl_amd import agents, explorers, replay_buffers
     from pfrl_amd.envs.synthetic import HostSyntheticAtariVectorEnv
@@ -37,6 +37,8 @@ def _run(name, prioritized, num_steps, double, gpu, priority_pow="device", steps
         rbuf = replay_buffers.ReplayBuffer(200, num_steps=num_steps)
     ex = explorers.LinearDecayEpsilonGreedy(1.0, 0.1, 400, lambda: np.random.randint(6))
     cls = agents.DoubleDQN if double else agents.DQN
+    if agent_cls is not None:
+        cls = getattr(agents, agent_cls)
     ag = cls(q, opt, rbuf, 0.99, ex, gpu=gpu, replay_start_size=40, minibatch_size=8,
              update_interval=4, target_update_interval=60, phi=phi, batch_accumulator="sum",
              **agent_kw)
@@ -788,3 +790,28 @@ def test_ppo_vector_obs_with_obs_normalizer_matches_reference():
     np.testing.assert_allclose(got, g["losses"], rtol=1e-4, atol=1e-4)
     params = np.concatenate([p.detach().cpu().numpy().ravel() for p in model.parameters()])
     np.testing.assert_allclose(params, g["final_params"], rtol=1e-4, atol=1e-5)
+
+
+# ---------------------------------------------------------------------------
+# DQN variants that only change the target: AL / PAL / DoublePAL / DPP / DPPL / DPPGreedy
+# ---------------------------------------------------------------------------
+DQN_FAMILY = [("al", "AL", dict(alpha=0.9)), ("pal", "PAL", dict(alpha=0.8)),
+              ("double_pal", "DoublePAL", dict(alpha=0.9)), ("dpp", "DPP", dict(eta=2.0)),
+              ("dppl", "DPPL", dict(eta=0.5)), ("dpp_greedy", "DPPGreedy", dict())]
+
+
+@pytest.mark.parametrize("name,cls,kw", DQN_FAMILY, ids=[f[0] for f in DQN_FAMILY])
+def test_dqn_family_host_mode_matches_reference(name, cls, kw):
+    g = np.load(os.path.join(GOLDEN, "agent_trace_%s.npz" % name))
+    _compare(_run(name, False, 1, False, gpu=None, agent_cls=cls, **kw), g)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,cls,kw", DQN_FAMILY, ids=[f[0] for f in DQN_FAMILY])
+def test_dqn_family_device_matches_reference(name, cls, kw):
+    """Same agents on the HBM replay path (step-fused gathers, batched target pass,
+    captured update with the composite torch loss)."""
+    g = np.load(os.path.join(GOLDEN, "agent_trace_%s.npz" % name))
+    got = _run(name, False, 1, False, gpu=0, agent_cls=cls, **kw)
+    assert got["rbuf"].is_device and not got["agent"]._fused_td_loss_applicable()
+    _compare(got, g)
