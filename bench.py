@@ -534,6 +534,9 @@ def main():
     device = torch.device("cuda", local % torch.cuda.device_count())
     torch.cuda.set_device(device)
     _native.lib()
+    if world > 1:
+        # one process per GPU: keep each rank's host-side torch ops on its share of cores
+        torch.set_num_threads(max(1, (os.cpu_count() or world) // world))
 
     if args.blas == "rocblas":
         torch.backends.cuda.preferred_blas_library("cublas")
