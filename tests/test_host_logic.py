@@ -164,3 +164,13 @@ def test_bench_result_line_contract(monkeypatch):
     assert line["vs_baseline"] is None and line["higher_is_better"] is True
     assert line["config"]["workload"] == "workload text" and "model" not in line["config"]
     assert bench.PROFILE_BATCH_EXPERIENCES == 0 and bench.PROFILE_BATCH_STATES_U8 == 1
+
+
+def test_integration_doc_names_every_entry_point():
+    """INTEGRATION.md maps every C entry point of include/pfrl_amd.h to the reference
+    code it replaces."""
+    hdr = open(os.path.join(ROOT, "include", "pfrl_amd.h")).read()
+    names = set(re.findall(r"^\w[\w\s\*]*?\b(pfrl_\w+)\(", hdr, flags=re.M))
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    assert len(names) >= 30
+    assert not [n for n in sorted(names) if n not in doc]
