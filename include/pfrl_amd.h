@@ -48,11 +48,14 @@ const char *pfrl_amd_last_error(void);
  * ------------------------------------------------------------------------ */
 
 /* frames[slots[i]] <- src[i]  (i < n); frame_bytes must be a multiple of 4.
- * New frames of one env step, already on the device. */
+ * New frames of one env step, already on the device: the storage side of
+ * VectorFrameStack.step (pfrl/wrappers/vector_frame_stack.py:93-105) and of the
+ * `.to(device)` in pfrl/utils/batch_states.py:18-36, done once per frame. */
 int pfrl_frames_scatter(void *frames, int64_t frame_bytes, const void *src, const int32_t *slots,
                         int64_t n, void *stream);
 
-/* Synthetic Atari-shaped env: fills frames[slots[i]]
+/* Synthetic Atari-shaped env (benchmark input only, no
+ * counterpart in pfrl/): fills frames[slots[i]]
  * with iid U{0..255} bytes from a counter-based generator keyed by
  * (seed, env_id0 + i, step). */
 int pfrl_frames_synth_u8(void *frames, int64_t frame_bytes, const int32_t *slots, int64_t n,
@@ -66,7 +69,8 @@ int pfrl_frames_synth_u8(void *frames, int64_t frame_bytes, const int32_t *slots
 int pfrl_batch_states_u8(const void *frames, int64_t frame_bytes, const int32_t *refs,
                          int64_t n_refs, float divisor, float *out, void *stream);
 
-/* Same values for stacks of FOUR frames, emitted channels-last: out is f32
+/* Same values (pfrl/utils/batch_states.py:18-36 with the Atari phi) for stacks of FOUR
+ * frames, emitted channels-last: out is f32
  * [n_obs][frame_bytes][4] = the memory of an NCHW [n_obs][4][H][W] tensor in
  * torch.channels_last format, which a channels_last network reads without the layout
  * conversion PyTorch otherwise performs on every forward and backward pass.
@@ -112,7 +116,7 @@ int pfrl_table_append(const pfrl_table_t *tab, int64_t n_rows, const int32_t *t_
                       const int32_t *state_ref, const int32_t *next_ref, const void *action,
                       const double *reward, const uint8_t *terminal, void *stream);
 
-/* Emitted n-step windows (replay_buffer.py:53-62,64-76): entry slot
+/* Emitted n-step windows (pfrl/replay_buffers/replay_buffer.py:53-62,64-76): entry slot
  * e_slots[i] <- (tids[i][0..n), len[i]). */
 int pfrl_entries_append(const pfrl_table_t *tab, int64_t n_rows, const int32_t *e_slots,
                         const int32_t *tids, const int32_t *lens, void *stream);
@@ -133,7 +137,8 @@ int pfrl_batch_experiences(const pfrl_table_t *tab, const void *frames, int64_t 
                            void *out_action, float *out_reward, float *out_terminal,
                            float *out_discount, void *stream);
 
-/* The same launch with out_state / out_next_state emitted channels-last
+/* The same launch (pfrl/replay_buffer.py:157-212) with out_state / out_next_state emitted
+ * channels-last
  * ([B][frame_bytes][4] f32; see pfrl_batch_states_u8_nhwc4): u8 frames, tab->k == 4. */
 int pfrl_batch_experiences_nhwc4(const pfrl_table_t *tab, const void *frames, int64_t frame_bytes,
                                  float divisor, const int32_t *entry_slots, int64_t B,
@@ -166,7 +171,8 @@ typedef struct {
     int32_t log2_smax;
 } pfrl_tree_t;
 
-/* PrioritizedBuffer.append / popleft for a batch (prioritized.py:39-54):
+/* PrioritizedBuffer.append / popleft for a batch (pfrl/collections/prioritized.py:39-54;
+ * TreeQueue._write :154-180):
  * leaves x[i] are written in both trees and every ancestor is re-reduced.
  * tag[i] == PFRL_TAG_ABSENT deletes the leaf (popleft);
  * use_maxp[i] != 0 writes the current max_priority (append with
@@ -206,8 +212,9 @@ int pfrl_tree_update_errors_f32(const pfrl_tree_t *tree, int64_t B, const int64_
                                 int has_max, float error_max, double pri_at_max, double eps,
                                 double alpha, int dedupe, void *stream);
 
-/* set_last_priority with explicit typed priorities (host-computed, e.g. from
- * Python-float errors): val/tag are device arrays. */
+/* PrioritizedBuffer.set_last_priority (pfrl/collections/prioritized.py:107-116) with
+ * explicit typed priorities (host-computed, e.g. from Python-float errors): val/tag
+ * are device arrays. */
 int pfrl_tree_set_priorities(const pfrl_tree_t *tree, int64_t B, const int64_t *x,
                              const double *val, const uint8_t *tag, int dedupe, void *stream);
 
@@ -215,7 +222,7 @@ int pfrl_tree_set_priorities(const pfrl_tree_t *tree, int64_t B, const int64_t *
  * On-policy rollouts (pfrl/agents/ppo.py, a2c.py).  Layout [T][N], env minor.
  * ------------------------------------------------------------------------ */
 
-/* _add_advantage_and_value_target_to_episode (ppo.py:36-47) for every episode
+/* _add_advantage_and_value_target_to_episode (pfrl/agents/ppo.py:36-47) for every episode
  * fragment of a T x N rollout.  cut[t][e] != 0 marks the last transition of a
  * fragment (done, reset or rollout end): the scan restarts with adv = 0.
  * mode 0: Python-float rewards (all f32 arithmetic); mode 1: np.float64
@@ -225,18 +232,18 @@ int pfrl_gae_scan(int64_t T, int64_t N, const double *reward, const float *v_pre
                   double gamma, double lambd, int mode, float *adv, float *v_teacher,
                   void *stream);
 
-/* A2C._compute_returns (a2c.py:150-167); value_preds/returns are [T+1][N]
+/* A2C._compute_returns (pfrl/agents/a2c.py:150-167); value_preds/returns are [T+1][N]
  * with row T already holding next_value as the reference sets it. */
 int pfrl_a2c_returns(int64_t T, int64_t N, const float *rewards, const float *masks,
                      const float *value_preds, float *returns, double gamma, double tau,
                      int use_gae, void *stream);
 
-/* torch.std_mean(all_advs, unbiased=False) (ppo.py:476-478): out[0] = mean,
+/* torch.std_mean(all_advs, unbiased=False) (pfrl/agents/ppo.py:476-478): out[0] = mean,
  * out[1] = std, f32, accumulated in f64 with wavefront shuffle reductions. */
 int pfrl_adv_stats(const float *adv, int64_t n, float *out_mean_std, void *partial_ws,
                    void *stream);
 
-/* PPO minibatch assembly (ppo.py:483-511): for dataset positions idx[i]
+/* PPO minibatch assembly (pfrl/agents/ppo.py:483-511): for dataset positions idx[i]
  *   out_adv   = (adv[idx] - mean) / (std + 1e-8)   if standardize
  *   out_logp  = log_prob[idx], out_v = v_pred[idx], out_vt = v_teacher[idx],
  *   out_action= action[idx] (int64),  out_refs[i][:] = state_refs[idx][:]. */
