@@ -13,6 +13,7 @@ Mirrors ``pfrl.replay_buffer`` (/root/reference/pfrl/replay_buffer.py):
 """
 from abc import ABCMeta, abstractmethod
 
+import numpy as np
 import torch
 
 from pfrl_amd.utils.batch_states import batch_states
@@ -122,9 +123,16 @@ def batch_experiences(experiences, device, phi, gamma, batch_states=batch_states
             flag = flag or bool(tr["is_state_terminal"])
         rewards.append(acc)
         terminals.append(flag)
+    def as_tensor(values):
+        # array-valued entries (continuous actions): stack on the host first -- one
+        # conversion instead of torch's element-wise walk over a list of ndarrays
+        if len(values) and isinstance(values[0], np.ndarray):
+            values = np.stack(values)
+        return torch.as_tensor(values, device=device)
+
     out = {
         "state": batch_states([t["state"] for t in first], device, phi),
-        "action": torch.as_tensor([t["action"] for t in first], device=device),
+        "action": as_tensor([t["action"] for t in first]),
         "reward": torch.as_tensor(rewards, dtype=torch.float32, device=device),
         "next_state": batch_states([t["next_state"] for t in last], device, phi),
         "is_state_terminal": torch.as_tensor(terminals, dtype=torch.float32, device=device),
@@ -132,7 +140,7 @@ def batch_experiences(experiences, device, phi, gamma, batch_states=batch_states
                                     device=device),
     }
     if all(t["next_action"] is not None for t in last):
-        out["next_action"] = torch.as_tensor([t["next_action"] for t in last], device=device)
+        out["next_action"] = as_tensor([t["next_action"] for t in last])
     return out
 
 

@@ -337,3 +337,74 @@ def test_empirical_normalization_matches_batch_statistics():
     lim(torch.randn(8, 3))            # count 16 >= 10: frozen
     assert int(lim.count) == 16 and torch.equal(lim.mean, m)
     assert set(en.state_dict().keys()) == {"_mean", "_var", "count"}
+
+
+def _tiny_continuous_agents():
+    from pfrl_amd import agents, explorers, replay_buffers
+
+    obs_dim, act_dim = 5, 2
+
+    def policy_det():
+        return torch.nn.Sequential(
+            torch.nn.Linear(obs_dim, 8), torch.nn.ReLU(), torch.nn.Linear(8, act_dim),
+            pfrl.nn.BoundByTanh(low=-np.ones(act_dim, dtype=np.float32),
+                                high=np.ones(act_dim, dtype=np.float32)),
+            pfrl.policies.DeterministicHead())
+
+    def qf():
+        return torch.nn.Sequential(pfrl.nn.ConcatObsAndAction(),
+                                   torch.nn.Linear(obs_dim + act_dim, 8), torch.nn.ReLU(),
+                                   torch.nn.Linear(8, 1))
+
+    sgd = lambda m: torch.optim.SGD(m.parameters(), lr=1e-2)
+    ex = explorers.AdditiveGaussian(0.1, -1.0, 1.0)
+    p, q1, q2 = policy_det(), qf(), qf()
+    td3 = agents.TD3(p, q1, q2, sgd(p), sgd(q1), sgd(q2), replay_buffers.ReplayBuffer(100),
+                     gamma=0.99, explorer=ex, gpu=-1, replay_start_size=10, minibatch_size=4)
+    p, q = policy_det(), qf()
+    ddpg = agents.DDPG(p, q, sgd(p), sgd(q), replay_buffers.ReplayBuffer(100), gamma=0.99,
+                       explorer=ex, gpu=-1, replay_start_size=10, minibatch_size=4)
+    gp = torch.nn.Sequential(
+        torch.nn.Linear(obs_dim, 8), torch.nn.ReLU(), torch.nn.Linear(8, act_dim),
+        pfrl.policies.GaussianHeadWithFixedCovariance(0.3))
+    q1, q2 = qf(), qf()
+    sac = agents.SoftActorCritic(gp, q1, q2, sgd(gp), sgd(q1), sgd(q2),
+                                 replay_buffers.ReplayBuffer(100), gamma=0.99, gpu=-1,
+                                 replay_start_size=10, minibatch_size=4, entropy_target=-2.0,
+                                 temperature_optimizer_lr=1e-3)
+    return obs_dim, act_dim, dict(td3=td3, ddpg=ddpg, sac=sac)
+
+
+def test_continuous_agents_train_save_load_on_the_host(tmp_path):
+    """TD3 / DDPG / SAC in host mode: a few dozen updates, statistics names of the
+    reference, save() / load() round trip of every saved attribute."""
+    from pfrl_amd.envs.synthetic import HostSyntheticVectorObsEnv
+
+    obs_dim, act_dim, ags = _tiny_continuous_agents()
+    want_stats = {
+        "td3": ["average_q1", "average_q2", "average_q_func1_loss", "average_q_func2_loss",
+                "average_policy_loss", "policy_n_updates", "q_func_n_updates"],
+        "ddpg": ["average_q", "average_actor_loss", "average_critic_loss", "n_updates"],
+        "sac": ["average_q1", "average_q2", "average_q_func1_loss", "average_q_func2_loss",
+                "n_updates", "average_entropy", "temperature"],
+    }
+    for name, ag in ags.items():
+        env = HostSyntheticVectorObsEnv(2, obs_dim=obs_dim, act_dim=act_dim, seed=1, p_done=0.1)
+        pfrl.experiments.train_agent_batch(ag, env, 60, str(tmp_path / ("run_" + name)))
+        stats = ag.get_statistics()
+        assert [k for k, _ in stats] == want_stats[name]
+        assert all(np.isfinite(float(v)) for _, v in stats), (name, stats)
+        d = str(tmp_path / ("save_" + name))
+        ag.save(d)
+        before = {k: v.clone() for k, v in ag._policy().state_dict().items()}
+        with torch.no_grad():
+            for p in ag._policy().parameters():
+                p.add_(1.0)
+        ag.load(d)
+        for k, v in ag._policy().state_dict().items():
+            assert torch.equal(v, before[k]), (name, k)
+        with ag.eval_mode():
+            a = ag.batch_act([np.zeros(obs_dim, dtype=np.float32)] * 3)
+            assert np.asarray(a).shape == (3, act_dim)
+            ag.batch_observe([np.zeros(obs_dim, dtype=np.float32)] * 3, [0.0] * 3, [False] * 3,
+                             [False] * 3)
