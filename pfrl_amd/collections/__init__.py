@@ -6,6 +6,7 @@
 """
 from pfrl_amd.collections.random_access_queue import RandomAccessQueue  # NOQA
 from pfrl_amd.collections.tree_frame import TreeFrame  # NOQA
+from pfrl_amd.collections.persistent_collections import PersistentRandomAccessQueue  # NOQA
 
 
 def __getattr__(name):

@@ -6,3 +6,4 @@ from pfrl_amd.nn.noisy_linear import FactorizedNoisyLinear, to_factorized_noisy 
 from pfrl_amd.nn.concat_obs_and_action import (BoundByTanh, ConcatObsAndAction, Lambda,  # NOQA
                                                bound_by_tanh)
 from pfrl_amd.nn.empirical_normalization import EmpiricalNormalization  # NOQA
+from pfrl_amd.nn.recurrent import Recurrent, RecurrentBranched, RecurrentSequential  # NOQA

@@ -144,6 +144,54 @@ def batch_experiences(experiences, device, phi, gamma, batch_states=batch_states
     return out
 
 
+def random_subseq(seq, subseq_len):
+    """A uniformly placed window of ``subseq_len`` items, or all of ``seq`` when it is not longer
+    (reference :149-154; one ``np.random.randint`` draw only when a window is cut)."""
+    excess = len(seq) - subseq_len
+    if excess <= 0:
+        return seq
+    start = np.random.randint(0, excess + 1)
+    return seq[start:start + subseq_len]
+
+
+def batch_recurrent_experiences(experiences, device, phi, gamma, batch_states=batch_states):
+    """Vectorise sampled episodes for a recurrent update (reference :219-287).
+
+    ``experiences`` is a list of episodes (lists of transition dicts) sorted by descending length,
+    as ``pack_sequence`` needs.  ``state`` / ``next_state`` stay per-episode lists of
+    ``(len, ...)`` batches; the per-transition columns are flat in packed (time-major) order; the
+    recurrent states are those stored with each episode's FIRST transition, stacked on axis 1."""
+    from pfrl_amd.utils.recurrent import (concatenate_recurrent_states,
+                                          flatten_sequences_time_first,
+                                          recurrent_state_from_numpy)
+
+    lengths = [len(ep) for ep in experiences]
+    assert all(a >= b for a, b in zip(lengths, lengths[1:])), "episodes must be sorted by length"
+    flat = flatten_sequences_time_first(experiences)
+
+    def column(key, **kw):
+        return torch.as_tensor([tr[key] for tr in flat], device=device, **kw)
+
+    def initial_state(key):
+        return recurrent_state_from_numpy(
+            concatenate_recurrent_states([ep[0][key] for ep in experiences]), device)
+
+    out = {
+        "state": [batch_states([tr["state"] for tr in ep], device, phi) for ep in experiences],
+        "action": column("action"),
+        "reward": column("reward", dtype=torch.float),
+        "next_state": [batch_states([tr["next_state"] for tr in ep], device, phi)
+                       for ep in experiences],
+        "is_state_terminal": column("is_state_terminal", dtype=torch.float),
+        "discount": torch.full((len(flat),), gamma, dtype=torch.float, device=device),
+        "recurrent_state": initial_state("recurrent_state"),
+        "next_recurrent_state": initial_state("next_recurrent_state"),
+    }
+    if all(tr["next_action"] is not None for tr in flat):
+        out["next_action"] = column("next_action")
+    return out
+
+
 class ReplayUpdater(object):
     """Update schedule (reference :290-356): skip until ``replay_start_size``
     transitions are stored, then every ``update_interval`` steps draw

@@ -1,0 +1,68 @@
+"""Prioritized replay of whole episodes.
+
+Mirrors ``pfrl.replay_buffers.PrioritizedEpisodicReplayBuffer``
+(/root/reference/pfrl/replay_buffers/prioritized_episodic.py:9-77): the unit of prioritisation is
+the EPISODE -- ``episodic_memory`` is a ``PrioritizedBuffer`` whose payloads are episodes -- while
+``memory`` is a plain FIFO of single transitions bounded by ``capacity``; ``capacity_left`` counts
+transitions and evicts whole episodes, oldest first, once it goes negative (:60-76).
+
+The sum / min trees are the HBM-resident ``pfrl_amd.collections.PrioritizedBuffer`` (the same HIP
+kernels as the flat prioritized buffer; there is no host tree), so this class needs a GPU.  The
+episode payloads stay on the host, as in the reference.
+"""
+import collections
+
+from pfrl_amd.collections.random_access_queue import RandomAccessQueue
+from pfrl_amd.replay_buffer import random_subseq
+from pfrl_amd.replay_buffers.episodic import EpisodicReplayBuffer
+from pfrl_amd.replay_buffers.prioritized import PriorityWeightError
+
+
+def _device_tree(wait_priority_after_sampling, device, max_episodes):
+    from pfrl_amd.collections.prioritized import PrioritizedBuffer
+
+    return PrioritizedBuffer(capacity=None, device=device, max_size=max_episodes,
+                             wait_priority_after_sampling=wait_priority_after_sampling)
+
+
+class PrioritizedEpisodicReplayBuffer(EpisodicReplayBuffer, PriorityWeightError):
+    def __init__(self, capacity=None, alpha=0.6, beta0=0.4, betasteps=2e5, eps=1e-8,
+                 normalize_by_max=True, default_priority_func=None, uniform_ratio=0,
+                 wait_priority_after_sampling=True, return_sample_weights=True,
+                 error_min=None, error_max=None, device=None, max_episodes=1 << 20,
+                 _tree_factory=_device_tree):
+        self.current_episode = collections.defaultdict(list)
+        self.episodic_memory = _tree_factory(wait_priority_after_sampling, device, max_episodes)
+        self.memory = RandomAccessQueue(maxlen=capacity)
+        self.capacity = capacity
+        self.capacity_left = capacity
+        self.default_priority_func = default_priority_func
+        self.uniform_ratio = uniform_ratio
+        self.return_sample_weights = return_sample_weights
+        PriorityWeightError.__init__(self, alpha, beta0, betasteps, eps, normalize_by_max,
+                                     error_min=error_min, error_max=error_max)
+
+    def _commit(self, episode):
+        priority = None
+        if self.default_priority_func is not None:
+            priority = self.default_priority_func(episode)
+        self.memory.extend(episode)
+        self.episodic_memory.append(episode, priority=priority)
+        if self.capacity_left is None:
+            return
+        self.capacity_left -= len(episode)
+        while self.capacity_left < 0:
+            self.capacity_left += len(self.episodic_memory.popleft())
+
+    def sample_episodes(self, n_episodes, max_len=None):
+        assert len(self.episodic_memory) >= n_episodes
+        episodes, probabilities, min_prob = self.episodic_memory.sample(
+            n_episodes, uniform_ratio=self.uniform_ratio)
+        if max_len is not None:
+            episodes = [random_subseq(ep, max_len) for ep in episodes]
+        if not self.return_sample_weights:
+            return episodes
+        return episodes, self.weights_from_probabilities(probabilities, min_prob)
+
+    def update_errors(self, errors):
+        self.episodic_memory.set_last_priority(self.priority_from_errors(errors))

@@ -1250,7 +1250,263 @@ def sac_trace(steps=240, N=2, obs_dim=24, act_dim=3):
     print("sac trace updates", len(q1_losses))
 
 
+
+# --------------------------------------------------------------------------
+# R. episodic replay, recurrent containers, persistent queues
+# --------------------------------------------------------------------------
+def episodic_trace(name, seed, capacity, n_ops, n_envs, batch=4, max_len=5):
+    """Random append / stop traffic over several env_ids into the reference's
+    EpisodicReplayBuffer; after each op the sizes, and at random points what
+    sample_episodes (with and without max_len) and sample return, by transition id."""
+    from pfrl.replay_buffers import EpisodicReplayBuffer
+
+    np.random.seed(seed)
+    rs = np.random.RandomState(seed + 5)
+    rbuf = EpisodicReplayBuffer(capacity=capacity)
+    rec = dict(op_kind=[], op_env=[], op_term=[], length=[], n_episodes=[])
+    smp = dict(at_op=[], kind=[], ep_len=[], tids=[])
+    tid = 0
+    for k in range(n_ops):
+        env = int(rs.randint(n_envs))
+        if rs.rand() < 0.08:
+            rbuf.stop_current_episode(env_id=env)
+            rec["op_kind"].append(1); rec["op_env"].append(env); rec["op_term"].append(0)
+        else:
+            term = bool(rs.rand() < 0.15)
+            rbuf.append(state=tid, action=tid % 3, reward=float(tid), next_state=tid + 1,
+                        is_state_terminal=term, env_id=env, tid=tid)
+            rec["op_kind"].append(0); rec["op_env"].append(env); rec["op_term"].append(int(term))
+            tid += 1
+        rec["length"].append(len(rbuf)); rec["n_episodes"].append(rbuf.n_episodes)
+        if rbuf.n_episodes >= batch and rs.rand() < 0.25:
+            which = int(rs.randint(3))
+            if which == 0:
+                eps = rbuf.sample_episodes(batch)
+            elif which == 1:
+                eps = rbuf.sample_episodes(batch, max_len=max_len)
+            else:
+                eps = rbuf.sample(batch)
+            smp["at_op"].append(k); smp["kind"].append(which)
+            for ep in eps:
+                smp["ep_len"].append(len(ep))
+                smp["tids"].extend(tr["tid"] for tr in ep)
+    out = {k2: np.asarray(v, dtype=np.int64) for k2, v in rec.items()}
+    out.update({"s_" + k2: np.asarray(v, dtype=np.int64) for k2, v in smp.items()})
+    out["final_episode_len"] = np.asarray([len(ep) for ep in rbuf.episodic_memory], dtype=np.int64)
+    out["final_tids"] = np.asarray([e[0]["tid"] for e in rbuf.memory], dtype=np.int64)
+    out["meta"] = np.array([seed, -1 if capacity is None else capacity, n_envs, batch, max_len])
+    np.savez_compressed(os.path.join(HERE, "episodic_trace_%s.npz" % name), **out)
+    print("episodic_trace", name, "len", len(rbuf), "episodes", rbuf.n_episodes,
+          "samples", len(smp["at_op"]))
+
+
+def prioritized_episodic_trace(name, seed, capacity, n_ops, n_envs, batch=3, max_len=4,
+                               normalize_by_max=True):
+    """The reference's PrioritizedEpisodicReplayBuffer under random traffic: sizes and
+    capacity_left after every op; sampled (sub-)episodes, importance weights and the errors fed
+    back, at random points."""
+    from pfrl.replay_buffers import PrioritizedEpisodicReplayBuffer
+
+    np.random.seed(seed)
+    rs = np.random.RandomState(seed + 5)
+    rbuf = PrioritizedEpisodicReplayBuffer(capacity=capacity, normalize_by_max=normalize_by_max,
+                                           betasteps=50, error_max=2.0)
+    rec = dict(op_kind=[], op_env=[], op_term=[], length=[], n_episodes=[], cap_left=[])
+    smp = dict(at_op=[], ep_len=[], first_tid=[], weights=[], errors=[], beta=[])
+    tid = 0
+    for k in range(n_ops):
+        env = int(rs.randint(n_envs))
+        if rs.rand() < 0.08:
+            rbuf.stop_current_episode(env_id=env)
+            rec["op_kind"].append(1); rec["op_env"].append(env); rec["op_term"].append(0)
+        else:
+            term = bool(rs.rand() < 0.2)
+            rbuf.append(state=tid, action=0, reward=0.0, next_state=tid + 1,
+                        is_state_terminal=term, env_id=env, tid=tid)
+            rec["op_kind"].append(0); rec["op_env"].append(env); rec["op_term"].append(int(term))
+            tid += 1
+        rec["length"].append(len(rbuf)); rec["n_episodes"].append(rbuf.n_episodes)
+        rec["cap_left"].append(-1 if rbuf.capacity_left is None else rbuf.capacity_left)
+        if rbuf.n_episodes >= batch and rs.rand() < 0.3:
+            eps, weights = rbuf.sample_episodes(batch, max_len=max_len)
+            errors = [float(e) for e in rs.rand(batch) * 3]
+            rbuf.update_errors(errors)
+            smp["at_op"].append(k)
+            smp["ep_len"].extend(len(ep) for ep in eps)
+            smp["first_tid"].extend(ep[0]["tid"] for ep in eps)
+            smp["weights"].extend(float(w) for w in weights)
+            smp["errors"].extend(errors)
+            smp["beta"].append(rbuf.beta)
+    out = {k2: np.asarray(v, dtype=np.int64) for k2, v in rec.items()}
+    for k2, v in smp.items():
+        out["s_" + k2] = np.asarray(v, dtype=np.float64 if k2 in ("weights", "errors", "beta")
+                                    else np.int64)
+    out["meta"] = np.array([seed, -1 if capacity is None else capacity, n_envs, batch, max_len])
+    out["normalize"] = np.asarray({True: 1, "batch": 1, "memory": 2, False: 0}[normalize_by_max])
+    np.savez_compressed(os.path.join(HERE, "prioritized_episodic_trace_%s.npz" % name), **out)
+    print("prioritized_episodic_trace", name, "len", len(rbuf), "episodes", rbuf.n_episodes,
+          "samples", len(smp["at_op"]))
+
+
+def episodic_golden():
+    episodic_trace("unbounded", 30, None, 300, 3)
+    episodic_trace("cap40", 31, 40, 600, 4)
+    episodic_trace("cap7", 32, 7, 400, 2, batch=2, max_len=2)
+    prioritized_episodic_trace("cap30", 40, 30, 500, 3)
+    prioritized_episodic_trace("unbounded_memory", 41, None, 300, 2, normalize_by_max="memory")
+    prioritized_episodic_trace("cap12_nonorm", 42, 12, 300, 2, batch=2, normalize_by_max=False)
+
+
+def make_recurrent_model(nn_mod):
+    """LSTM trunk between stateless layers, then a branched head (one branch recurrent)."""
+    tnn = torch.nn
+    return nn_mod.RecurrentSequential(
+        tnn.Linear(5, 8), tnn.ReLU(), tnn.LSTM(8, 6),
+        nn_mod.RecurrentBranched(
+            tnn.GRU(6, 4),
+            nn_mod.RecurrentSequential(tnn.Linear(6, 3), tnn.Tanh())))
+
+
+def recurrent_golden():
+    """RecurrentSequential / RecurrentBranched outputs and states for packed sequences and for a
+    one-step batch continuing them, the masking / indexing / stacking helpers, and
+    batch_recurrent_experiences on episodes that carry stored recurrent states."""
+    from pfrl.replay_buffer import batch_recurrent_experiences
+    from pfrl.utils import recurrent as R
+
+    torch.manual_seed(123)
+    rs = np.random.RandomState(9)
+    model = make_recurrent_model(pfrl.nn)
+    out = {"sd_" + k: v.numpy() for k, v in model.state_dict().items()}
+    lens = [4, 2, 2, 1]
+    seqs = [torch.from_numpy(rs.randn(n, 5).astype(np.float32)) for n in lens]
+    with torch.no_grad():
+        (y_gru, y_mlp), state = R.pack_and_forward(model, seqs, None)
+        step_in = torch.from_numpy(rs.randn(len(lens), 5).astype(np.float32))
+        masked = R.mask_recurrent_state_at(state, [1, 3])
+        (z_gru, z_mlp), state2 = R.one_step_forward(model, step_in, masked)
+    picked = R.get_recurrent_state_at(state2, 2, detach=True)
+    restacked = R.concatenate_recurrent_states(
+        [R.get_recurrent_state_at(state2, i, detach=True) if i != 1 else None for i in range(4)])
+
+    def flat(prefix, tree):
+        leaves = []
+
+        def walk(t):
+            if isinstance(t, tuple):
+                for u in t:
+                    walk(u)
+            else:
+                leaves.append(t)
+        walk(tree)
+        for i, leaf in enumerate(leaves):
+            out["%s_%d" % (prefix, i)] = leaf.numpy()
+
+    out["lens"] = np.asarray(lens)
+    for i, s in enumerate(seqs):
+        out["seq_%d" % i] = s.numpy()
+    out["step_in"] = step_in.numpy()
+    out["y_gru"], out["y_mlp"] = y_gru.numpy(), y_mlp.numpy()
+    out["z_gru"], out["z_mlp"] = z_gru.numpy(), z_mlp.numpy()
+    flat("state", state); flat("masked", masked); flat("state2", state2)
+    flat("picked", picked); flat("restacked", restacked)
+
+    # batch_recurrent_experiences: three episodes, sorted by length, LSTM-shaped stored states
+    def rstate():
+        return (rs.randn(1, 6).astype(np.float32), rs.randn(1, 6).astype(np.float32))
+
+    episodes, tid = [], 0
+    for n in (3, 2, 1):
+        ep = []
+        for j in range(n):
+            ep.append(dict(state=rs.randn(5).astype(np.float32), action=int(rs.randint(4)),
+                           reward=float(rs.randn()), next_state=rs.randn(5).astype(np.float32),
+                           next_action=int(rs.randint(4)), is_state_terminal=(j == n - 1 and n != 2),
+                           recurrent_state=rstate() if (j or n != 1) else None,
+                           next_recurrent_state=rstate()))
+            tid += 1
+        episodes.append(ep)
+    be = batch_recurrent_experiences(episodes, torch.device("cpu"), lambda x: x, 0.97)
+    for key in ("action", "reward", "is_state_terminal", "discount", "next_action"):
+        out["be_" + key] = be[key].numpy()
+    for i in range(3):
+        out["be_state_%d" % i] = be["state"][i].numpy()
+        out["be_next_state_%d" % i] = be["next_state"][i].numpy()
+    flat("be_rs", be["recurrent_state"]); flat("be_nrs", be["next_recurrent_state"])
+    out["ep_lens"] = np.asarray([len(ep) for ep in episodes])
+    col = lambda key, dt: np.asarray([tr[key] for ep in episodes for tr in ep], dtype=dt)  # noqa: E731
+    out["ep_state"], out["ep_next_state"] = col("state", np.float32), col("next_state", np.float32)
+    out["ep_action"], out["ep_next_action"] = col("action", np.int64), col("next_action", np.int64)
+    out["ep_reward"], out["ep_terminal"] = col("reward", np.float64), col("is_state_terminal", np.int64)
+    for i, ep in enumerate(episodes):
+        for key in ("recurrent_state", "next_recurrent_state"):
+            s0 = ep[0][key]
+            out["ep%d_%s_none" % (i, key)] = np.asarray(s0 is None)
+            if s0 is not None:
+                out["ep%d_%s_h" % (i, key)], out["ep%d_%s_c" % (i, key)] = s0
+    np.savez_compressed(os.path.join(HERE, "recurrent.npz"), **out)
+    print("recurrent golden:", len(out), "arrays")
+
+
+PERSISTENT_ITEMS = [[dict(state=np.arange(3, dtype=np.float32) + i, action=i % 2, reward=0.5 * i,
+                          next_state=np.arange(3, dtype=np.float32) + i + 1, next_action=None,
+                          is_state_terminal=(i % 4 == 3))] for i in range(11)]
+
+
+def persistent_golden():
+    """Directories written by the reference's PersistentRandomAccessQueue: ``base`` in two
+    sessions (5 + 3 items) with small chunks so that generations rotate, and ``child`` whose
+    ancestor is ``base`` (3 more items).  Paths inside meta.pkl are relative to tests/golden and
+    the timestamp is pinned, so regeneration is byte-stable."""
+    import datetime as _dt
+    import shutil
+
+    import pfrl.collections.persistent_collections as pc
+
+    class PinnedClock:
+        @staticmethod
+        def today():
+            return _dt.datetime(2024, 8, 7, 12, 0, 0)
+
+        @staticmethod
+        def strftime(d, fmt):
+            return d.strftime(fmt)
+
+    pc.datetime = PinnedClock
+
+    class SmallChunks(pc.PersistentRandomAccessQueue):
+        chunk_size = 700      # bytes; an item pickles to ~330 B => a generation holds 3 items
+
+    root = os.path.join(HERE, "persistent_queue")
+    shutil.rmtree(root, ignore_errors=True)
+    cwd = os.getcwd()
+    os.chdir(HERE)
+    try:
+        q = SmallChunks("persistent_queue/base", 6)
+        for item in PERSISTENT_ITEMS[:5]:
+            q.append(item)
+        q.close()
+        q = SmallChunks("persistent_queue/base", 6)
+        assert len(q) == 5
+        q.extend(PERSISTENT_ITEMS[5:8])
+        assert len(q) == 6
+        q.close()
+        c = SmallChunks("persistent_queue/child", 4, ancestor="persistent_queue/base")
+        assert len(c) == 4
+        for item in PERSISTENT_ITEMS[8:]:
+            c.append(item)
+        c.close()
+    finally:
+        os.chdir(cwd)
+    print("persistent golden:", sorted(os.listdir(os.path.join(root, "base", "rank0"))),
+          sorted(os.listdir(os.path.join(root, "child", "rank0"))))
+
+
 if __name__ == "__main__":
+    if sys.argv[1:]:          # regenerate selected fixtures only: make_golden.py recurrent_golden ...
+        for fn in sys.argv[1:]:
+            globals()[fn]()
+        sys.exit(0)
     random.seed(0)
     torch.manual_seed(0)
     pbuf_trace("cap5", 0, 5, 400, 2)
@@ -1287,3 +1543,6 @@ if __name__ == "__main__":
     c51_loss_golden()
     c51_agent_trace()
     sac_trace()
+    episodic_golden()
+    recurrent_golden()
+    persistent_golden()

@@ -1,0 +1,442 @@
+"""SURVEY.md 8(f) rows 2 and 4 on the host: episodic replay, recurrent containers and helpers,
+``batch_recurrent_experiences`` and the persistent (chunk / index / CRC-32) queue files, each
+against fixtures recorded from the reference (tests/golden/make_golden.py: ``episodic_golden``,
+``recurrent_golden``, ``persistent_golden``)."""
+import collections
+import filecmp
+import glob
+import os
+import pickle
+import shutil
+
+import numpy as np
+import pytest
+import torch
+
+import pfrl_amd
+from pfrl_amd.replay_buffer import batch_recurrent_experiences, random_subseq
+from pfrl_amd.replay_buffers import (EpisodicReplayBuffer, PersistentEpisodicReplayBuffer,
+                                     PersistentReplayBuffer, PrioritizedEpisodicReplayBuffer)
+from pfrl_amd.utils import recurrent as R
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+# ---- episodic replay ---------------------------------------------------------------------------
+def _drive(rbuf, g, k, tid):
+    if g["op_kind"][k] == 1:
+        rbuf.stop_current_episode(env_id=int(g["op_env"][k]))
+        return tid
+    rbuf.append(state=tid, action=tid % 3, reward=float(tid), next_state=tid + 1,
+                is_state_terminal=bool(g["op_term"][k]), env_id=int(g["op_env"][k]), tid=tid)
+    return tid + 1
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "episodic_trace_*.npz"))),
+                         ids=os.path.basename)
+def test_episodic_buffer_follows_reference_trace(path):
+    """Sizes after every op, and -- consuming the global NumPy stream like the reference -- the
+    episodes, max_len windows and single transitions that are sampled."""
+    g = np.load(path)
+    seed, cap, _, batch, max_len = (int(v) for v in g["meta"])
+    np.random.seed(seed)
+    rbuf = EpisodicReplayBuffer(capacity=None if cap < 0 else cap)
+    sample_at = {int(k): i for i, k in enumerate(g["s_at_op"])}
+    tid = ep_i = tid_i = 0
+    for k in range(len(g["op_kind"])):
+        tid = _drive(rbuf, g, k, tid)
+        assert (len(rbuf), rbuf.n_episodes) == (g["length"][k], g["n_episodes"][k]), k
+        if k in sample_at:
+            kind = int(g["s_kind"][sample_at[k]])
+            got = (rbuf.sample_episodes(batch) if kind == 0 else
+                   rbuf.sample_episodes(batch, max_len=max_len) if kind == 1 else
+                   rbuf.sample(batch))
+            for ep in got:
+                n = int(g["s_ep_len"][ep_i])
+                assert [tr["tid"] for tr in ep] == list(g["s_tids"][tid_i:tid_i + n]), k
+                ep_i += 1
+                tid_i += n
+    assert ep_i == len(g["s_ep_len"])
+    assert [len(ep) for ep in rbuf.episodic_memory] == list(g["final_episode_len"])
+    assert [e[0]["tid"] for e in rbuf.memory] == list(g["final_tids"])
+    if cap >= 0:
+        assert len(rbuf) <= cap
+
+
+def test_episodic_buffer_shares_transitions_and_round_trips(tmp_path):
+    rbuf = EpisodicReplayBuffer(capacity=None)
+    for env, n in ((0, 3), (1, 2)):
+        for j in range(n):
+            rbuf.append(state=(env, j), action=j, reward=1.0, next_state=(env, j + 1),
+                        is_state_terminal=(j == n - 1), env_id=env)
+    rbuf.append(state="open", action=0, reward=0.0, next_state="open2", env_id=2)
+    assert (len(rbuf), rbuf.n_episodes) == (5, 2)          # the open episode is not visible yet
+    assert rbuf.memory[0][0] is rbuf.episodic_memory[0][0]  # same dict objects, as in the reference
+    with pytest.raises(AssertionError):
+        rbuf.sample_episodes(3)
+    with pytest.raises(AssertionError):
+        rbuf.sample(6)
+    f = str(tmp_path / "episodic.pkl")
+    rbuf.save(f)
+    other = EpisodicReplayBuffer()
+    other.load(f)
+    assert (len(other), other.n_episodes) == (5, 2)
+    assert other.memory[0][0] is other.episodic_memory[0][0]   # sharing survives the pickle memo
+    assert [tr["state"] for tr in other.episodic_memory[1]] == [(1, 0), (1, 1)]
+    # the pre-episodic flat format: episodes are recovered at terminal transitions
+    flat = [dict(state=i, is_state_terminal=(i in (1, 4))) for i in range(6)]
+    with open(f, "wb") as fh:
+        pickle.dump(flat, fh)
+    other.load(f)
+    assert (len(other), other.n_episodes) == (6, 2)
+    assert [[tr["state"] for tr in ep] for ep in other.episodic_memory] == [[0, 1], [2, 3, 4]]
+
+
+def test_random_subseq_draws_only_when_it_cuts():
+    np.random.seed(0)
+    before = np.random.get_state()[1].copy()
+    seq = list(range(5))
+    assert random_subseq(seq, 5) is seq and random_subseq(seq, 9) is seq
+    assert np.array_equal(np.random.get_state()[1], before)
+    np.random.seed(3)
+    starts = [random_subseq(seq, 2)[0] for _ in range(200)]
+    np.random.seed(3)
+    assert starts == [int(np.random.randint(0, 4)) for _ in range(200)]
+    assert set(starts) == {0, 1, 2, 3}
+
+
+class _OracleTree:
+    """The reference's PrioritizedBuffer interface over the CPU oracle's tree: stands in for the
+    HBM-resident tree so that the episodic wrapper's host logic can be checked without a GPU."""
+
+    def __init__(self, wait_priority_after_sampling, device, max_episodes):
+        from oracle import OraclePrioritizedBuffer
+
+        assert wait_priority_after_sampling
+        self.tree = OraclePrioritizedBuffer(None)
+        self.data = collections.deque()
+
+    def __len__(self):
+        return len(self.data)
+
+    def append(self, value, priority=None):
+        self.tree.append(0, priority)
+        self.data.append(value)
+
+    def popleft(self):
+        self.tree.popleft()
+        return self.data.popleft()
+
+    def sample(self, n, uniform_ratio=0):
+        assert uniform_ratio == 0
+        out = self.tree.sample(np.random.random_sample(n))
+        return ([self.data[int(i)] for i in out["indices"]], list(out["probabilities"]),
+                out["min_prob"])
+
+    def set_last_priority(self, priority):
+        from oracle import type_tag
+
+        self.tree.set_last_priority([float(p) for p in priority], [type_tag(p) for p in priority])
+
+
+@pytest.mark.parametrize(
+    "path", sorted(glob.glob(os.path.join(GOLDEN, "prioritized_episodic_trace_*.npz"))),
+    ids=os.path.basename)
+def test_prioritized_episodic_host_logic_follows_reference_trace(path):
+    """Episode commit / whole-episode eviction by ``capacity_left``, the order of the NumPy draws
+    (tree sample, then one window draw per cut episode), weights and the beta schedule."""
+    g = np.load(path)
+    seed, cap, _, batch, max_len = (int(v) for v in g["meta"])
+    norm = {0: False, 1: True, 2: "memory"}[int(g["normalize"])]
+    np.random.seed(seed)
+    rbuf = PrioritizedEpisodicReplayBuffer(capacity=None if cap < 0 else cap, betasteps=50,
+                                           normalize_by_max=norm, error_max=2.0,
+                                           _tree_factory=_OracleTree)
+    sample_at = {int(k): i for i, k in enumerate(g["s_at_op"])}
+    tid = 0
+    for k in range(len(g["op_kind"])):
+        if g["op_kind"][k] == 1:
+            rbuf.stop_current_episode(env_id=int(g["op_env"][k]))
+        else:
+            rbuf.append(state=tid, action=0, reward=0.0, next_state=tid + 1,
+                        is_state_terminal=bool(g["op_term"][k]), env_id=int(g["op_env"][k]),
+                        tid=tid)
+            tid += 1
+        left = -1 if rbuf.capacity_left is None else rbuf.capacity_left
+        assert (len(rbuf), rbuf.n_episodes, left) == (
+            g["length"][k], g["n_episodes"][k], g["cap_left"][k]), k
+        if k in sample_at:
+            i = sample_at[k]
+            sl = slice(i * batch, (i + 1) * batch)
+            episodes, weights = rbuf.sample_episodes(batch, max_len=max_len)
+            assert [len(ep) for ep in episodes] == list(g["s_ep_len"][sl]), k
+            assert [ep[0]["tid"] for ep in episodes] == list(g["s_first_tid"][sl]), k
+            np.testing.assert_allclose(weights, g["s_weights"][sl], rtol=1e-12)
+            rbuf.update_errors([float(e) for e in g["s_errors"][sl]])
+            assert rbuf.beta == g["s_beta"][i]
+
+
+def test_prioritized_episodic_needs_the_device_tree():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises((RuntimeError, AssertionError)):
+        PrioritizedEpisodicReplayBuffer(capacity=10)
+
+
+# ---- recurrent containers and helpers ----------------------------------------------------------
+def _recurrent_model():
+    tnn = torch.nn
+    return pfrl_amd.nn.RecurrentSequential(
+        tnn.Linear(5, 8), tnn.ReLU(), tnn.LSTM(8, 6),
+        pfrl_amd.nn.RecurrentBranched(
+            tnn.GRU(6, 4),
+            pfrl_amd.nn.RecurrentSequential(tnn.Linear(6, 3), tnn.Tanh())))
+
+
+def _leaves(tree):
+    if isinstance(tree, tuple):
+        return [leaf for t in tree for leaf in _leaves(t)]
+    return [tree]
+
+
+def _assert_tree(g, prefix, tree, **tol):
+    leaves = _leaves(tree)
+    n_golden = sum(1 for k in g.files if k.startswith(prefix + "_") and
+                   k[len(prefix) + 1:].isdigit())
+    assert len(leaves) == n_golden, prefix
+    for i, leaf in enumerate(leaves):
+        np.testing.assert_allclose(np.asarray(leaf), g["%s_%d" % (prefix, i)], err_msg=prefix,
+                                   **tol)
+
+
+def test_recurrent_containers_match_reference_outputs():
+    """Same parameter names (strict state_dict load), same packed outputs, same state trees, for
+    a multi-step packed forward and for a one-step batch that continues it after masking."""
+    g = np.load(os.path.join(GOLDEN, "recurrent.npz"))
+    tol = dict(rtol=1e-5, atol=1e-6)
+    model = _recurrent_model()
+    model.load_state_dict({k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd_")},
+                          strict=True)
+    assert [type(m).__name__ for m in model.recurrent_children] == ["LSTM", "RecurrentBranched"]
+    assert R.is_recurrent(model) and R.is_recurrent(model[2]) and not R.is_recurrent(model[0])
+    seqs = [torch.from_numpy(g["seq_%d" % i]) for i in range(len(g["lens"]))]
+    with torch.no_grad():
+        (y_gru, y_mlp), state = R.pack_and_forward(model, seqs, None)
+        masked = R.mask_recurrent_state_at(state, [1, 3])
+        (z_gru, z_mlp), state2 = R.one_step_forward(model, torch.from_numpy(g["step_in"]), masked)
+    np.testing.assert_allclose(y_gru.numpy(), g["y_gru"], **tol)
+    np.testing.assert_allclose(y_mlp.numpy(), g["y_mlp"], **tol)
+    np.testing.assert_allclose(z_gru.numpy(), g["z_gru"], **tol)
+    np.testing.assert_allclose(z_mlp.numpy(), g["z_mlp"], **tol)
+    _assert_tree(g, "state", state, **tol)
+    _assert_tree(g, "masked", masked, **tol)
+    _assert_tree(g, "state2", state2, **tol)
+    # the stateless branch carries an empty state; masked columns are exactly zero
+    assert state[1][1] == ()
+    for leaf in _leaves(masked):
+        assert torch.count_nonzero(leaf[:, [1, 3]]) == 0
+    picked = R.get_recurrent_state_at(state2, 2, detach=True)
+    _assert_tree(g, "picked", picked, **tol)
+    restacked = R.concatenate_recurrent_states(
+        [R.get_recurrent_state_at(state2, i, detach=True) if i != 1 else None for i in range(4)])
+    _assert_tree(g, "restacked", restacked, **tol)
+    assert R.concatenate_recurrent_states([None, None]) is None
+    assert R.mask_recurrent_state_at(None, 0) is None
+    with pytest.raises(ValueError):
+        R.detach_recurrent_state([1, 2])
+
+
+def test_recurrent_sequential_runs_stateless_layers_once_on_the_flat_tensor():
+    calls = []
+
+    class Probe(torch.nn.Module):
+        def forward(self, x):
+            calls.append(tuple(x.shape))
+            return x
+
+    model = pfrl_amd.nn.RecurrentSequential(Probe(), torch.nn.LSTM(3, 3), Probe())
+    seqs = [torch.randn(4, 3), torch.randn(2, 3), torch.randn(1, 3)]
+    packed = R.pack_sequences_recursive(seqs)
+    out, state = model(packed, None)
+    assert calls == [(7, 3), (7, 3)]
+    assert isinstance(out, torch.nn.utils.rnn.PackedSequence)
+    assert torch.equal(out.batch_sizes, packed.batch_sizes)
+    # time-major flat order is what flatten_sequences_time_first produces
+    order = R.flatten_sequences_time_first([[(b, t) for t in range(len(s))]
+                                            for b, s in enumerate(seqs)])
+    assert order == [(0, 0), (1, 0), (2, 0), (0, 1), (1, 1), (0, 2), (0, 3)]
+    flat = torch.stack([seqs[b][t] for b, t in order])
+    assert torch.equal(packed.data, flat)
+    # tuples of tensors pack member-wise
+    both = R.pack_sequences_recursive([(s, s * 2) for s in seqs])
+    assert isinstance(both, tuple) and torch.equal(both[1].data, flat * 2)
+    assert R.get_packed_sequence_info((None, both))[0] is both[0].batch_sizes
+    arr = R.recurrent_state_as_numpy(state)
+    back = R.recurrent_state_from_numpy(arr, torch.device("cpu"))
+    assert isinstance(arr[0][0], np.ndarray) and torch.equal(back[0][0], state[0][0].detach())
+
+
+def test_batch_recurrent_experiences_matches_reference():
+    g = np.load(os.path.join(GOLDEN, "recurrent.npz"))
+    episodes, row = [], 0
+    for i, n in enumerate(g["ep_lens"]):
+        ep = []
+        for j in range(int(n)):
+            tr = dict(state=g["ep_state"][row], action=int(g["ep_action"][row]),
+                      reward=float(g["ep_reward"][row]), next_state=g["ep_next_state"][row],
+                      next_action=int(g["ep_next_action"][row]),
+                      is_state_terminal=bool(g["ep_terminal"][row]),
+                      recurrent_state=None, next_recurrent_state=None)
+            if j == 0:
+                for key in ("recurrent_state", "next_recurrent_state"):
+                    if not bool(g["ep%d_%s_none" % (i, key)]):
+                        tr[key] = (g["ep%d_%s_h" % (i, key)], g["ep%d_%s_c" % (i, key)])
+            ep.append(tr)
+            row += 1
+        episodes.append(ep)
+    be = batch_recurrent_experiences(episodes, torch.device("cpu"), lambda x: x, 0.97)
+    for key in ("action", "reward", "is_state_terminal", "discount", "next_action"):
+        assert be[key].dtype == torch.from_numpy(g["be_" + key]).dtype, key
+        np.testing.assert_array_equal(be[key].numpy(), g["be_" + key], err_msg=key)
+    for i in range(len(episodes)):
+        np.testing.assert_array_equal(be["state"][i].numpy(), g["be_state_%d" % i])
+        np.testing.assert_array_equal(be["next_state"][i].numpy(), g["be_next_state_%d" % i])
+    _assert_tree(g, "be_rs", be["recurrent_state"])
+    _assert_tree(g, "be_nrs", be["next_recurrent_state"])
+    assert be["recurrent_state"][0].shape == (1, 3, 6)
+    with pytest.raises(AssertionError):
+        batch_recurrent_experiences(episodes[::-1], torch.device("cpu"), lambda x: x, 0.97)
+    for ep in episodes:
+        ep[-1]["next_action"] = None
+    assert "next_action" not in batch_recurrent_experiences(episodes, torch.device("cpu"),
+                                                            lambda x: x, 0.97)
+
+
+# ---- persistent queues -------------------------------------------------------------------------
+def _persistent_items():
+    return [[dict(state=np.arange(3, dtype=np.float32) + i, action=i % 2, reward=0.5 * i,
+                  next_state=np.arange(3, dtype=np.float32) + i + 1, next_action=None,
+                  is_state_terminal=(i % 4 == 3))] for i in range(11)]
+
+
+def _same(a, b):
+    return pickle.dumps(a) == pickle.dumps(b)
+
+
+class _SmallChunks(pfrl_amd.collections.PersistentRandomAccessQueue):
+    chunk_size = 700
+
+
+def test_persistent_queue_reads_directories_written_by_the_reference(tmp_path, monkeypatch):
+    """maxlen trimming over generations, the ancestor chain, and the generation a new session
+    continues with."""
+    shutil.copytree(os.path.join(GOLDEN, "persistent_queue"), str(tmp_path / "persistent_queue"))
+    monkeypatch.chdir(tmp_path)          # meta.pkl of the fixture holds relative paths
+    items = _persistent_items()
+    q = _SmallChunks("persistent_queue/base", 6)
+    assert q.maxlen == 6 and len(q) == 6 and q.gen == 4        # three generations on disk
+    assert all(_same(a, b) for a, b in zip(q, items[2:8]))
+    q.close()
+    every = _SmallChunks("persistent_queue/base", None)
+    assert len(every) == 8 and _same(every[0], items[0]) and _same(every[-1], items[7])
+    every.close()
+    tail = _SmallChunks("persistent_queue/base", 2)
+    # whole generations are loaded newest-first until maxlen is covered; the FIFO keeps the tail
+    assert len(tail) == 2 and _same(tail[0], items[6])
+    tail.close()
+    child = _SmallChunks("persistent_queue/child", 4)
+    assert len(child) == 3 and _same(child[0], items[8])       # own data only
+    child.close()
+    grandchild = _SmallChunks("persistent_queue/grandchild", 9, ancestor="persistent_queue/child")
+    # child holds 3 < 9, so its ancestor "base" is read first (older data first)
+    assert len(grandchild) == 9
+    assert all(_same(a, b) for a, b in zip(grandchild, items[2:11]))
+    assert grandchild.ancestor_meta["ancestor"] == "persistent_queue/base"
+    assert not os.listdir("persistent_queue/grandchild/rank0") == []
+    grandchild.close()
+
+
+def test_persistent_queue_writes_the_reference_files_byte_for_byte(tmp_path, monkeypatch):
+    monkeypatch.chdir(tmp_path)
+    items = _persistent_items()
+    q = _SmallChunks("persistent_queue/base", 6)
+    for item in items[:5]:
+        q.append(item)
+    q.close()
+    q = _SmallChunks("persistent_queue/base", 6)
+    assert len(q) == 5
+    q.extend(items[5:8])
+    assert len(q) == 6
+    with pytest.raises(NotImplementedError):
+        q[0] = items[0]
+    assert q.popleft() is None and len(q) == 5
+    q.close()
+    c = _SmallChunks("persistent_queue/child", 4, ancestor="persistent_queue/base")
+    assert len(c) == 4
+    for item in items[8:]:
+        c.append(item)
+    c.close()
+    golden = os.path.join(GOLDEN, "persistent_queue")
+    for sub in ("base/rank0", "child/rank0"):
+        names = sorted(os.listdir(os.path.join(golden, sub)))
+        assert sorted(os.listdir(os.path.join("persistent_queue", sub))) == names
+        match, mismatch, errors = filecmp.cmpfiles(os.path.join(golden, sub),
+                                                   os.path.join("persistent_queue", sub), names,
+                                                   shallow=False)
+        assert (mismatch, errors) == ([], []), sub
+    for sub in ("base", "child"):
+        with open(os.path.join(golden, sub, "meta.pkl"), "rb") as f:
+            want = pickle.load(f)
+        with open(os.path.join("persistent_queue", sub, "meta.pkl"), "rb") as f:
+            got = pickle.load(f)
+        want.pop("timestamp"), got.pop("timestamp")
+        assert got == want
+
+
+def test_persistent_queue_detects_corruption(tmp_path):
+    q = pfrl_amd.collections.PersistentRandomAccessQueue(str(tmp_path / "q"), 10)
+    q.append({"x": 1})
+    q.append({"x": 2})
+    q.close()
+    data = tmp_path / "q" / "rank0" / "chunk.0.data"
+    raw = bytearray(data.read_bytes())
+    raw[-3] ^= 0xFF
+    data.write_bytes(bytes(raw))
+    with pytest.raises(AssertionError):
+        pfrl_amd.collections.PersistentRandomAccessQueue(str(tmp_path / "q"), 10)
+
+
+def test_persistent_replay_buffers_resume_from_their_directory(tmp_path):
+    d = str(tmp_path / "flat")
+    rbuf = PersistentReplayBuffer(d, 5)
+    assert rbuf.bind(torch.device("cpu")) is rbuf and not rbuf.is_device
+    for i in range(7):
+        rbuf.append(state=np.float32(i), action=i, reward=1.0, next_state=np.float32(i + 1),
+                    is_state_terminal=(i == 6))
+    assert len(rbuf) == 5
+    rbuf.save("ignored")
+    with pytest.warns(UserWarning):
+        rbuf.load("ignored")
+    rbuf.memory.close()
+    again = PersistentReplayBuffer(d, 5)
+    assert len(again) == 5
+    assert [e[0]["action"] for e in again.memory] == [2, 3, 4, 5, 6]
+    np.random.seed(0)
+    assert len(again.sample(3)) == 3
+    again.memory.close()
+    with pytest.raises(RuntimeError):
+        PersistentReplayBuffer(str(tmp_path / "mn"), 5, distributed=True)
+
+    d = str(tmp_path / "episodic")
+    ebuf = PersistentEpisodicReplayBuffer(d, 100)
+    for ep, n in enumerate((3, 2)):
+        for j in range(n):
+            ebuf.append(state=(ep, j), action=j, reward=0.0, next_state=(ep, j + 1),
+                        is_state_terminal=(j == n - 1))
+    assert (len(ebuf), ebuf.n_episodes) == (5, 2)
+    ebuf.memory.close(), ebuf.episodic_memory.close()
+    again = PersistentEpisodicReplayBuffer(d, 100)
+    assert (len(again), again.n_episodes) == (5, 2)
+    assert [tr["state"] for tr in again.episodic_memory[0]] == [(0, 0), (0, 1), (0, 2)]
+    with pytest.warns(UserWarning):
+        again.load("ignored")
