@@ -14,6 +14,8 @@ from pfrl_amd.utils.contexts import evaluating
 class AL(dqn.DQN):
     """T_AL Q = T Q + alpha * (Q'(s, a) - max_b Q'(s, b))."""
 
+    _recurrent_capable = False
+
     def __init__(self, *args, **kwargs):
         self.alpha = kwargs.pop("alpha", 0.9)
         super().__init__(*args, **kwargs)

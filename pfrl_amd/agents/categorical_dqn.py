@@ -57,6 +57,7 @@ class CategoricalDQN(dqn.DQN):
     ignored (reference :107-113)."""
 
     _fused_td_double = None   # cross-entropy on distributions: not the scalar TD loss
+    _recurrent_capable = False
     _c51_double = False       # greedy next action: target net (False) / online net (True)
 
     def _project(self, exp_batch, next_dist, z_values):

@@ -10,7 +10,8 @@ class DoubleDQN(dqn.DQN):
     def _compute_target_values(self, exp_batch):
         batch_next_state = exp_batch["next_state"]
         with evaluating(self.model):
-            next_qout = self.model(batch_next_state)
+            next_qout = self._action_value(self.model, batch_next_state,
+                                           exp_batch.get("next_recurrent_state"))
         target_next_qout = self._target_next_action_value(exp_batch)
         next_q_max = target_next_qout.evaluate_actions(next_qout.greedy_actions)
         return (exp_batch["reward"]

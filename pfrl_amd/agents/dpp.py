@@ -12,6 +12,8 @@ from pfrl_amd.agents.dqn import DQN
 
 
 class AbstractDPP(DQN, metaclass=ABCMeta):
+    _recurrent_capable = False
+
     @abstractmethod
     def _l_operator(self, qout):
         raise NotImplementedError()

@@ -27,11 +27,16 @@ import torch
 import torch.nn.functional as F
 
 from pfrl_amd import agent
-from pfrl_amd.replay_buffer import DeviceExperienceBatch, ReplayUpdater, batch_experiences
+from pfrl_amd.replay_buffer import (AbstractEpisodicReplayBuffer, DeviceExperienceBatch,
+                                    ReplayUpdater, batch_experiences,
+                                    batch_recurrent_experiences)
 from pfrl_amd.utils.batch_states import batch_states
 from pfrl_amd.utils.clip_l2_grad_norm import clip_l2_grad_norm_
 from pfrl_amd.utils.contexts import evaluating
 from pfrl_amd.utils.copy_param import synchronize_parameters
+from pfrl_amd.utils.recurrent import (get_recurrent_state_at, mask_recurrent_state_at,
+                                      one_step_forward, pack_and_forward,
+                                      recurrent_state_as_numpy)
 
 
 def _mean_or_nan(xs):
@@ -103,6 +108,8 @@ class DQN(agent.AttributeSavingMixin, agent.BatchAgent):
 
     saved_attributes = ("model", "target_model", "optimizer")
     _fused_td_double = False
+    # recurrent=True needs every model call of the loss to go through _action_value
+    _recurrent_capable = True
 
     def __init__(self, q_function, optimizer, replay_buffer, gamma, explorer, gpu=None,
                  replay_start_size=50000, minibatch_size=32, update_interval=1,
@@ -119,8 +126,15 @@ class DQN(agent.AttributeSavingMixin, agent.BatchAgent):
             self.model.to(self.device)
         else:
             self.device = torch.device("cpu")
-        if recurrent:
-            raise NotImplementedError("recurrent DQN is outside the batched hot path")
+        self.recurrent = bool(recurrent)
+        if self.recurrent:
+            # DRQN (reference :232-241): whole episodes are replayed as packed sequences, so
+            # shapes vary from update to update -- this mode runs eagerly on stock torch ops.
+            if not type(self)._recurrent_capable:
+                raise NotImplementedError(
+                    "%s does not implement recurrent updates" % type(self).__name__)
+            assert isinstance(replay_buffer, AbstractEpisodicReplayBuffer)
+            use_graphs = step_fused_gather = fused_td_loss = False
         self.replay_buffer = replay_buffer
         if hasattr(replay_buffer, "bind"):
             replay_buffer.bind(self.device, phi)
@@ -137,10 +151,11 @@ class DQN(agent.AttributeSavingMixin, agent.BatchAgent):
         assert batch_accumulator in ("mean", "sum")
         self.logger = logger
         self.batch_states = batch_states
-        self.recurrent = False
         self.replay_updater = ReplayUpdater(
-            replay_buffer=replay_buffer, update_func=self.update, batchsize=minibatch_size,
-            episodic_update=False, episodic_update_len=episodic_update_len,
+            replay_buffer=replay_buffer,
+            update_func=self.update_from_episodes if self.recurrent else self.update,
+            batchsize=minibatch_size,
+            episodic_update=self.recurrent, episodic_update_len=episodic_update_len,
             n_times_update=n_times_update, replay_start_size=replay_start_size,
             update_interval=update_interval)
         self.minibatch_size = minibatch_size
@@ -158,6 +173,10 @@ class DQN(agent.AttributeSavingMixin, agent.BatchAgent):
         self.loss_record = _DeviceRecord(100)
         self.batch_last_obs = []
         self.batch_last_action = []
+        # recurrent states of the model (reference :266-269)
+        self.train_recurrent_states = None
+        self.train_prev_recurrent_states = None
+        self.test_recurrent_states = None
         if (self.replay_buffer.capacity is not None
                 and self.replay_buffer.capacity < self.replay_updater.replay_start_size):
             raise ValueError("Replay start size cannot exceed replay buffer capacity.")
@@ -224,6 +243,14 @@ class DQN(agent.AttributeSavingMixin, agent.BatchAgent):
             exp_batch["weights"] = torch.tensor([e[0]["weight"] for e in experiences],
                                                 device=self.device, dtype=torch.float32)
         self._update_from_batch(exp_batch, has_weight, errors_out)
+
+    def update_from_episodes(self, episodes, errors_out=None):
+        """One update from sampled episodes, longest first (reference :367-386)."""
+        assert errors_out is None, "Recurrent DQN does not support PrioritizedBuffer"
+        episodes = sorted(episodes, key=len, reverse=True)
+        exp_batch = batch_recurrent_experiences(episodes, device=self.device, phi=self.phi,
+                                                gamma=self.gamma, batch_states=self.batch_states)
+        self._update_from_batch(exp_batch)
 
     def _update_from_batch(self, exp_batch, has_weight=False, errors_out=None, deferred=None):
         """``deferred``: a list that receives this update's (loss, y) graph outputs
@@ -313,10 +340,18 @@ class DQN(agent.AttributeSavingMixin, agent.BatchAgent):
             return av.q_dist
         return av.q_values
 
+    def _action_value(self, model, states, recurrent_state):
+        """``model(states)``; for a recurrent model ``states`` is a list of per-episode batches
+        and the result is flat in packed (time-major) order (reference :391-399, :415-420)."""
+        if self.recurrent:
+            return pack_and_forward(model, states, recurrent_state)[0]
+        return model(states)
+
     def _target_next_action_value(self, exp_batch):
         raw = exp_batch.get("target_next_raw")
         if raw is None:
-            return self.target_model(exp_batch["next_state"])
+            return self._action_value(self.target_model, exp_batch["next_state"],
+                                      exp_batch.get("next_recurrent_state"))
         if raw.ndim == 3:
             from pfrl_amd.action_value import DistributionalDiscreteActionValue
 
@@ -333,7 +368,7 @@ class DQN(agent.AttributeSavingMixin, agent.BatchAgent):
 
     def _compute_y_and_t(self, exp_batch):
         batch_size = exp_batch["reward"].shape[0]
-        qout = self.model(exp_batch["state"])
+        qout = self._action_value(self.model, exp_batch["state"], exp_batch.get("recurrent_state"))
         batch_q = torch.reshape(qout.evaluate_actions(exp_batch["action"]), (batch_size, 1))
         with torch.no_grad():
             batch_q_target = torch.reshape(self._compute_target_values(exp_batch), (batch_size, 1))
@@ -344,7 +379,7 @@ class DQN(agent.AttributeSavingMixin, agent.BatchAgent):
     # (categorical agents) set it to None and keep their own.
 
     def _fused_td_loss_applicable(self):
-        return (self.fused_td_loss and self.device.type == "cuda"
+        return (self.fused_td_loss and self.device.type == "cuda" and not self.recurrent
                 and type(self)._fused_td_double is not None
                 and type(self)._compute_y_and_t is DQN._compute_y_and_t)
 
@@ -421,7 +456,24 @@ class DQN(agent.AttributeSavingMixin, agent.BatchAgent):
     def _evaluate_model(self, batch_obs):
         self._route_observation_layout(batch_obs)
         batch_xs = self.batch_states(batch_obs, self.device, self.phi)
-        return self.model(batch_xs)
+        if not self.recurrent:
+            return self.model(batch_xs)
+        # one step for every env; training keeps the state from before the step too, because
+        # it is stored with the transition (reference :472-488)
+        if self.training:
+            self.train_prev_recurrent_states = self.train_recurrent_states
+            batch_av, self.train_recurrent_states = one_step_forward(
+                self.model, batch_xs, self.train_recurrent_states)
+        else:
+            batch_av, self.test_recurrent_states = one_step_forward(
+                self.model, batch_xs, self.test_recurrent_states)
+        return batch_av
+
+    @staticmethod
+    def _restart_ended(recurrent_states, batch_done, batch_reset):
+        """Zero the state of every env whose episode ended (reference :107-128)."""
+        ended = [i for i, (d, r) in enumerate(zip(batch_done, batch_reset)) if d or r]
+        return mask_recurrent_state_at(recurrent_states, ended) if ended else recurrent_states
 
     def batch_act(self, batch_obs):
         if self._replay_stream is not None:
@@ -446,9 +498,15 @@ class DQN(agent.AttributeSavingMixin, agent.BatchAgent):
         rbuf = self.replay_buffer
         if self.batch_last_obs[i] is not None:
             assert self.batch_last_action[i] is not None
+            extra = {}
+            if self.recurrent:
+                for key, states in (("recurrent_state", self.train_prev_recurrent_states),
+                                    ("next_recurrent_state", self.train_recurrent_states)):
+                    extra[key] = recurrent_state_as_numpy(
+                        get_recurrent_state_at(states, i, detach=True))
             rbuf.append(state=self.batch_last_obs[i], action=self.batch_last_action[i],
                         reward=batch_reward[i], next_state=batch_obs[i], next_action=None,
-                        is_state_terminal=batch_done[i], env_id=i)
+                        is_state_terminal=batch_done[i], env_id=i, **extra)
             if batch_reset[i] or batch_done[i]:
                 self.batch_last_obs[i] = None
                 self.batch_last_action[i] = None
@@ -470,6 +528,10 @@ class DQN(agent.AttributeSavingMixin, agent.BatchAgent):
                 self.sync_target_network()
             self._append_transition(i, batch_obs, batch_reward, batch_done, batch_reset)
             updater.update_if_necessary(self.t)
+        if self.recurrent:
+            self.train_prev_recurrent_states = None
+            self.train_recurrent_states = self._restart_ended(
+                self.train_recurrent_states, batch_done, batch_reset)
 
     def _batch_observe_train_fused(self, batch_obs, batch_reward, batch_done, batch_reset):
         """Same schedule as the loop above (reference :516-549), reorganised
@@ -541,7 +603,9 @@ class DQN(agent.AttributeSavingMixin, agent.BatchAgent):
                     self.q_record.extend(y.clone())
 
     def _batch_observe_eval(self, batch_obs, batch_reward, batch_done, batch_reset):
-        pass
+        if self.recurrent:
+            self.test_recurrent_states = self._restart_ended(
+                self.test_recurrent_states, batch_done, batch_reset)
 
     def batch_observe(self, batch_obs, batch_reward, batch_done, batch_reset):
         if self.training:
@@ -549,10 +613,13 @@ class DQN(agent.AttributeSavingMixin, agent.BatchAgent):
         return self._batch_observe_eval(batch_obs, batch_reward, batch_done, batch_reset)
 
     def _can_start_replay(self):
-        return len(self.replay_buffer) >= self.replay_start_size
+        if len(self.replay_buffer) < self.replay_start_size:
+            return False
+        return not self.recurrent or self.replay_buffer.n_episodes >= self.minibatch_size
 
     def stop_episode(self):
-        pass
+        if self.recurrent:
+            self.test_recurrent_states = None
 
     # -- persistence / statistics ----------------------------------------------
     def save_snapshot(self, dirname):

@@ -87,6 +87,7 @@ class IQN(dqn.DQN):
     (64), ``quantile_thresholds_K`` (32) and ``act_deterministically`` (False)."""
 
     _fused_td_double = None   # quantile regression: not the scalar TD loss
+    _recurrent_capable = False
 
     def __init__(self, *args, **kwargs):
         self.quantile_thresholds_N = kwargs.pop("quantile_thresholds_N", 64)

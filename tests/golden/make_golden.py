@@ -1348,6 +1348,73 @@ def prioritized_episodic_trace(name, seed, capacity, n_ops, n_envs, batch=3, max
           "samples", len(smp["at_op"]))
 
 
+def make_recurrent_q_function(n_in, n_actions, nn_mod, head):
+    torch.manual_seed(2468)
+    tnn = torch.nn
+    return nn_mod.RecurrentSequential(
+        tnn.Flatten(), tnn.Linear(n_in, 32), tnn.ReLU(), tnn.LSTM(32, 16),
+        tnn.Linear(16, n_actions), head)
+
+
+def drqn_trace(steps=480, N=4):
+    """examples/atari/train_drqn_ale.py in small: DoubleDQN(recurrent=True) over an
+    EpisodicReplayBuffer, episodes cut to episodic_update_len, LSTM state stored per transition."""
+    sys.path.insert(0, os.path.join(HERE, "..", ".."))
+    import tempfile
+
+    from pfrl import agents, experiments, explorers, replay_buffers
+    from pfrl.q_functions import DiscreteActionValueHead
+
+    from pfrl_amd.envs.synthetic import HostSyntheticAtariVectorEnv
+
+    pfrl.utils.set_random_seed(0)
+    env = HostSyntheticAtariVectorEnv(N, seed=7, frame_shape=(12, 12), p_done=0.08)
+
+    def phi(x):
+        return np.asarray(x, dtype=np.float32) / 255
+
+    q = make_recurrent_q_function(4 * 144, 6, pfrl.nn, DiscreteActionValueHead())
+    opt = torch.optim.RMSprop(q.parameters(), lr=2.5e-4, alpha=0.95, eps=1e-2)
+    rbuf = replay_buffers.EpisodicReplayBuffer(300)
+    ex = explorers.LinearDecayEpsilonGreedy(1.0, 0.1, 300, lambda: np.random.randint(6))
+    ag = agents.DoubleDQN(q, opt, rbuf, 0.99, ex, gpu=-1, replay_start_size=40, minibatch_size=4,
+                          update_interval=4, target_update_interval=60, phi=phi,
+                          batch_accumulator="mean", recurrent=True, episodic_update_len=6)
+    actions, losses, sampled = [], [], []
+    orig_act = ag.batch_act
+
+    def spy_act(obs):
+        a = orig_act(obs)
+        actions.append([int(x) for x in a])
+        return a
+
+    ag.batch_act = spy_act
+    orig_update = ag.update_from_episodes
+
+    def spy_update(episodes, errors_out=None):
+        sampled.append([len(ep) for ep in episodes])
+        orig_update(episodes, errors_out)
+        losses.append(ag.loss_record[-1])
+
+    ag.replay_updater.update_func = spy_update
+    experiments.train_agent_batch(ag, env, steps, tempfile.mkdtemp())
+    with ag.eval_mode():                       # evaluation keeps its own recurrent state
+        obs = env.reset()
+        eval_actions = []
+        for _ in range(6):
+            a = orig_act(obs)
+            obs, r, done, info = env.step(a)
+            ag.batch_observe(obs, r, done, [False] * N)
+            eval_actions.append([int(x) for x in a])
+    out = dict(actions=np.asarray(actions), losses=np.asarray(losses),
+               sampled_len=np.asarray(sampled), eval_actions=np.asarray(eval_actions),
+               final_params=np.concatenate([p.detach().numpy().ravel() for p in q.parameters()]),
+               stats=np.asarray([float(v) for _, v in ag.get_statistics()]),
+               rlen=np.asarray([len(rbuf), rbuf.n_episodes]))
+    np.savez_compressed(os.path.join(HERE, "agent_trace_drqn.npz"), **out)
+    print("drqn_trace updates", len(losses), "final loss", losses[-1], "episodes", rbuf.n_episodes)
+
+
 def episodic_golden():
     episodic_trace("unbounded", 30, None, 300, 3)
     episodic_trace("cap40", 31, 40, 600, 4)
@@ -1546,3 +1613,4 @@ if __name__ == "__main__":
     episodic_golden()
     recurrent_golden()
     persistent_golden()
+    drqn_trace()

@@ -440,3 +440,99 @@ def test_persistent_replay_buffers_resume_from_their_directory(tmp_path):
     assert [tr["state"] for tr in again.episodic_memory[0]] == [(0, 0), (0, 1), (0, 2)]
     with pytest.warns(UserWarning):
         again.load("ignored")
+
+
+# ---- recurrent agents --------------------------------------------------------------------------
+def _recurrent_q_function(n_in, n_actions):
+    from pfrl_amd.q_functions import DiscreteActionValueHead
+
+    torch.manual_seed(2468)
+    tnn = torch.nn
+    return pfrl_amd.nn.RecurrentSequential(
+        tnn.Flatten(), tnn.Linear(n_in, 32), tnn.ReLU(), tnn.LSTM(32, 16),
+        tnn.Linear(16, n_actions), DiscreteActionValueHead())
+
+
+def _phi(x):
+    return np.asarray(x, dtype=np.float32) / 255
+
+
+def test_recurrent_double_dqn_matches_reference_trace(tmp_path):
+    """DRQN (examples/atari/train_drqn_ale.py in small) on the host: every action, the lengths of
+    the replayed episode windows, every loss and the final parameters against the reference's
+    DoubleDQN(recurrent=True) on the same synthetic env and seeds."""
+    from pfrl_amd import agents, experiments, explorers
+    from pfrl_amd.envs.synthetic import HostSyntheticAtariVectorEnv
+
+    g = np.load(os.path.join(GOLDEN, "agent_trace_drqn.npz"))
+    N = 4
+    pfrl_amd.utils.set_random_seed(0)
+    env = HostSyntheticAtariVectorEnv(N, seed=7, frame_shape=(12, 12), p_done=0.08)
+    q = _recurrent_q_function(4 * 144, 6)
+    opt = torch.optim.RMSprop(q.parameters(), lr=2.5e-4, alpha=0.95, eps=1e-2)
+    rbuf = EpisodicReplayBuffer(300)
+    ex = explorers.LinearDecayEpsilonGreedy(1.0, 0.1, 300, lambda: np.random.randint(6))
+    ag = agents.DoubleDQN(q, opt, rbuf, 0.99, ex, gpu=-1, replay_start_size=40, minibatch_size=4,
+                          update_interval=4, target_update_interval=60, phi=_phi,
+                          batch_accumulator="mean", recurrent=True, episodic_update_len=6)
+    assert not ag.use_graphs and ag.replay_updater.episodic_update
+    actions, losses, sampled = [], [], []
+    orig_act = ag.batch_act
+
+    def spy_act(obs):
+        a = orig_act(obs)
+        actions.append([int(x) for x in a])
+        return a
+
+    ag.batch_act = spy_act
+    orig_update = ag.update_from_episodes
+
+    def spy_update(episodes, errors_out=None):
+        sampled.append([len(ep) for ep in episodes])
+        orig_update(episodes, errors_out)
+        losses.append(float(ag.loss_record.values()[-1]))
+
+    ag.replay_updater.update_func = spy_update
+    experiments.train_agent_batch(ag, env, 480, str(tmp_path))
+    np.testing.assert_array_equal(np.asarray(actions), g["actions"])
+    np.testing.assert_array_equal(np.asarray(sampled), g["sampled_len"])
+    np.testing.assert_allclose(np.asarray(losses), g["losses"], rtol=1e-4, atol=1e-6)
+    flat = np.concatenate([p.detach().numpy().ravel() for p in q.parameters()])
+    np.testing.assert_allclose(flat, g["final_params"], rtol=1e-4, atol=1e-6)
+    assert [len(rbuf), rbuf.n_episodes] == list(g["rlen"])
+    np.testing.assert_allclose([float(v) for _, v in ag.get_statistics()], g["stats"], rtol=1e-4,
+                               atol=1e-6)
+    # stored transitions carry the LSTM state before and after the step, as numpy pairs
+    episode = next(ep for ep in rbuf.episodic_memory if len(ep) >= 3)
+    for tr in episode[1:]:
+        (h, c), = tr["recurrent_state"]
+        assert isinstance(h, np.ndarray) and h.shape == c.shape == (1, 16)
+    for a, b in zip(episode, episode[1:]):      # the state after one step is the next one's input
+        np.testing.assert_array_equal(a["next_recurrent_state"][0][0], b["recurrent_state"][0][0])
+    first = episode[0]["recurrent_state"]       # episode start: no state yet, or a zeroed one
+    assert first is None or not np.any(first[0][0])
+    with ag.eval_mode():
+        obs = env.reset()
+        eval_actions = []
+        for _ in range(6):
+            a = orig_act(obs)
+            obs, r, done, info = env.step(a)
+            ag.batch_observe(obs, r, done, [False] * N)
+            eval_actions.append([int(x) for x in a])
+        assert ag.test_recurrent_states is not None
+        ag.stop_episode()
+        assert ag.test_recurrent_states is None
+    np.testing.assert_array_equal(np.asarray(eval_actions), g["eval_actions"])
+
+
+def test_recurrent_flag_is_refused_where_the_loss_bypasses_it():
+    from pfrl_amd import agents, explorers
+    from pfrl_amd.replay_buffers import ReplayBuffer
+
+    q = _recurrent_q_function(16, 3)
+    opt = torch.optim.SGD(q.parameters(), lr=0.1)
+    ex = explorers.ConstantEpsilonGreedy(0.1, lambda: 0)
+    with pytest.raises(AssertionError):          # needs an episodic buffer (reference :233)
+        agents.DQN(q, opt, ReplayBuffer(100), 0.9, ex, gpu=-1, recurrent=True)
+    with pytest.raises(NotImplementedError):
+        agents.PAL(q, opt, EpisodicReplayBuffer(100), 0.9, ex, gpu=-1, recurrent=True)
