@@ -65,3 +65,73 @@ class FusedRMSprop(torch.optim.RMSprop):
                 n, P, G, S, A, L, float(group["lr"]), float(group["alpha"]), float(group["eps"]),
                 float(group["weight_decay"]), int(centered), stream), "rmsprop_step")
         return loss
+
+
+class RMSpropEpsInsideSqrt(torch.optim.RMSprop):
+    """``torch.optim.RMSprop`` whose denominator is ``sqrt(v + eps)`` instead of ``sqrt(v) + eps``
+    -- the A3C / A2C papers' form, used by examples/atari/train_a2c_ale.py (reference
+    pfrl/optimizers/rmsprop_eps_inside_sqrt.py:5-63).  Constructor and state keys (``step``,
+    ``square_avg``, ``grad_avg``, ``momentum_buffer``) are the reference's; the arithmetic runs
+    as a handful of multi-tensor (foreach) launches per parameter group rather than per tensor."""
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        for group in self.param_groups:
+            params = [p for p in group["params"] if p.grad is not None]
+            if not params:
+                continue
+            if any(p.grad.is_sparse for p in params):
+                raise RuntimeError("RMSprop does not support sparse gradients")
+            alpha, eps, lr = group["alpha"], group["eps"], group["lr"]
+            momentum, centered = group["momentum"], group["centered"]
+            for p in params:
+                self._init_state(p, group)
+                self.state[p]["step"] += 1
+            grads = [p.grad for p in params]
+            if group["weight_decay"] != 0:
+                grads = torch._foreach_add(grads, params, alpha=group["weight_decay"])
+            square_avg = [self.state[p]["square_avg"] for p in params]
+            torch._foreach_mul_(square_avg, alpha)
+            torch._foreach_addcmul_(square_avg, grads, grads, value=1 - alpha)
+            if centered:
+                grad_avg = [self.state[p]["grad_avg"] for p in params]
+                torch._foreach_mul_(grad_avg, alpha)
+                torch._foreach_add_(grad_avg, grads, alpha=1 - alpha)
+                denom = torch._foreach_addcmul(square_avg, grad_avg, grad_avg, value=-1)
+                torch._foreach_add_(denom, eps)
+            else:
+                denom = torch._foreach_add(square_avg, eps)
+            torch._foreach_sqrt_(denom)
+            if momentum > 0:
+                bufs = [self.state[p]["momentum_buffer"] for p in params]
+                torch._foreach_mul_(bufs, momentum)
+                torch._foreach_addcdiv_(bufs, grads, denom)
+                torch._foreach_add_(params, bufs, alpha=-lr)
+            else:
+                torch._foreach_addcdiv_(params, grads, denom, value=-lr)
+        return loss
+
+    def _init_state(self, p, group):
+        state = self.state[p]
+        if len(state) == 0:
+            state["step"] = 0
+            state["square_avg"] = torch.zeros_like(p)
+            if group["momentum"] > 0:
+                state["momentum_buffer"] = torch.zeros_like(p)
+            if group["centered"]:
+                state["grad_avg"] = torch.zeros_like(p)
+
+
+class SharedRMSpropEpsInsideSqrt(RMSpropEpsInsideSqrt):
+    """The same with the state allocated at construction, so that it exists before the
+    parameters are shared between processes (reference :66-82)."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        for group in self.param_groups:
+            for p in group["params"]:
+                self._init_state(p, group)

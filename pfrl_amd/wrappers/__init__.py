@@ -94,4 +94,4 @@ class VectorFrameStack(VectorEnvWrapper):
 
 from pfrl_amd.wrappers.env_wrappers import (CastObservation, CastObservationToFloat32,  # NOQA,E402
                                             ContinuingTimeLimit, NormalizeActionSpace,
-                                            RandomizeAction, ScaleReward, Wrapper)
+                                            RandomizeAction, Render, ScaleReward, Wrapper)

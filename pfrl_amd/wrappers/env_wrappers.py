@@ -151,3 +151,22 @@ class NormalizeActionSpace(Wrapper):
 
     def step(self, action):
         return self.env.step(self.action(action))
+
+
+class Render(Wrapper):
+    """Call ``env.render(**kwargs)`` after every reset and step (reference
+    pfrl/wrappers/render.py:4-24)."""
+
+    def __init__(self, env, **kwargs):
+        super().__init__(env)
+        self._kwargs = kwargs
+
+    def reset(self, **kwargs):
+        ret = self.env.reset(**kwargs)
+        self.env.render(**self._kwargs)
+        return ret
+
+    def step(self, action):
+        ret = self.env.step(action)
+        self.env.render(**self._kwargs)
+        return ret

@@ -1415,6 +1415,89 @@ def drqn_trace(steps=480, N=4):
     print("drqn_trace updates", len(losses), "final loss", losses[-1], "episodes", rbuf.n_episodes)
 
 
+def rmsprop_eps_inside_sqrt_golden():
+    """Four steps of the reference's RMSpropEpsInsideSqrt on two tensors, for the plain,
+    centered, momentum and weight-decay configurations."""
+    import warnings
+
+    rs = np.random.RandomState(17)
+    w0 = [rs.randn(3, 4).astype(np.float32), rs.randn(5).astype(np.float32)]
+    grads = [[rs.randn(*w.shape).astype(np.float32) for w in w0] for _ in range(4)]
+    out = {"w0_0": w0[0], "w0_1": w0[1]}
+    for t, gs in enumerate(grads):
+        out["g%d_0" % t], out["g%d_1" % t] = gs
+    configs = dict(plain=dict(), centered=dict(centered=True), momentum=dict(momentum=0.9),
+                   decay=dict(weight_decay=0.01, centered=True, momentum=0.5))
+    for name, kw in configs.items():
+        ps = [torch.nn.Parameter(torch.from_numpy(w.copy())) for w in w0]
+        cls = (pfrl.optimizers.SharedRMSpropEpsInsideSqrt if name == "momentum"
+               else pfrl.optimizers.RMSpropEpsInsideSqrt)
+        opt = cls(ps, lr=7e-4, eps=1e-1, alpha=0.99, **kw)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            for t, gs in enumerate(grads):
+                for p_, g_ in zip(ps, gs):
+                    p_.grad = torch.from_numpy(g_.copy())
+                opt.step()
+                for i, p_ in enumerate(ps):
+                    out["%s_w%d_%d" % (name, t, i)] = p_.detach().numpy().copy()
+        for i, p_ in enumerate(ps):
+            for key, v in opt.state[p_].items():
+                out["%s_state_%s_%d" % (name, key, i)] = np.asarray(v)
+    np.savez_compressed(os.path.join(HERE, "rmsprop_eps_inside_sqrt.npz"), **out)
+    print("rmsprop_eps_inside_sqrt golden:", len(out), "arrays")
+
+
+def atari_wrappers_golden(steps=400):
+    """The reference's wrapper stack (minus WarpFrame: cv2 is absent) over the scripted FakeALE:
+    per step the stacked observation's checksum and newest frame, reward, done, needs_reset,
+    and how often the game itself was reset / stepped."""
+    sys.path.insert(0, os.path.join(HERE, ".."))
+    from _fake_ale import FakeALE
+
+    from pfrl.wrappers import ContinuingTimeLimit, atari_wrappers as aw
+
+    out = {}
+    for name, fire, flicker, scale in (("plain", False, False, False),
+                                       ("fire_flicker_scaled", True, True, True)):
+        game = FakeALE(seed=3)
+        env = ContinuingTimeLimit(game, max_episode_steps=90)
+        env = aw.MaxAndSkipEnv(aw.NoopResetEnv(env, noop_max=5), skip=4)
+        env = aw.EpisodicLifeEnv(env)
+        if fire:
+            env = aw.FireResetEnv(env)
+        if scale:
+            env = aw.ScaledFloatFrame(env)
+        env = aw.ClipRewardEnv(env)
+        if flicker:
+            env = aw.FlickerFrame(env)
+        env = aw.FrameStack(env, 4, channel_order="chw")
+        rs = np.random.RandomState(11)
+        rec = dict(obs_sum=[], newest=[], reward=[], done=[], needs_reset=[], resets=[], steps=[],
+                   shared=[])
+        obs = env.reset()
+        prev = obs
+        for t in range(steps):
+            a = int(rs.randint(3))
+            obs, r, done, info = env.step(a)
+            rec["obs_sum"].append(float(np.asarray(obs, dtype=np.float64).sum()))
+            rec["newest"].append(np.asarray(obs)[-1].astype(np.float32))
+            rec["reward"].append(float(r)); rec["done"].append(bool(done))
+            rec["needs_reset"].append(bool(info.get("needs_reset", False)))
+            rec["shared"].append(sum(a_ is b_ for a_, b_ in zip(obs._frames[:-1], prev._frames[1:])))
+            if done or info.get("needs_reset", False):
+                obs = env.reset()
+            prev = obs
+            rec["resets"].append(game.n_resets); rec["steps"].append(game.n_steps)
+        for k, v in rec.items():
+            out["%s_%s" % (name, k)] = np.asarray(v)
+        out["%s_space_low" % name] = env.observation_space.low
+        out["%s_space_high" % name] = env.observation_space.high
+    np.savez_compressed(os.path.join(HERE, "atari_wrappers.npz"), **out)
+    print("atari_wrappers golden: dones", int(out["plain_done"].sum()),
+          "game resets", int(out["plain_resets"][-1]))
+
+
 def episodic_golden():
     episodic_trace("unbounded", 30, None, 300, 3)
     episodic_trace("cap40", 31, 40, 600, 4)
@@ -1614,3 +1697,5 @@ if __name__ == "__main__":
     recurrent_golden()
     persistent_golden()
     drqn_trace()
+    rmsprop_eps_inside_sqrt_golden()
+    atari_wrappers_golden()

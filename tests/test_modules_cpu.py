@@ -1,6 +1,7 @@
 """Host-side pieces of the API mirror that need no GPU: small modules, explorers,
 distributions, action values, the gym-free CartPole (known answers)."""
 import math
+import os
 
 import numpy as np
 import pytest
@@ -408,3 +409,40 @@ def test_continuous_agents_train_save_load_on_the_host(tmp_path):
             assert np.asarray(a).shape == (3, act_dim)
             ag.batch_observe([np.zeros(obs_dim, dtype=np.float32)] * 3, [0.0] * 3, [False] * 3,
                              [False] * 3)
+
+
+def test_rmsprop_eps_inside_sqrt_matches_reference_steps():
+    """tests/golden/rmsprop_eps_inside_sqrt.npz: parameters after each of four steps and the final
+    optimizer state, for the plain / centered / momentum / weight-decay configurations."""
+    from pfrl_amd import optimizers
+
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "rmsprop_eps_inside_sqrt.npz"))
+    configs = dict(plain=dict(), centered=dict(centered=True), momentum=dict(momentum=0.9),
+                   decay=dict(weight_decay=0.01, centered=True, momentum=0.5))
+    for name, kw in configs.items():
+        ps = [torch.nn.Parameter(torch.from_numpy(g["w0_%d" % i].copy())) for i in range(2)]
+        cls = (optimizers.SharedRMSpropEpsInsideSqrt if name == "momentum"
+               else optimizers.RMSpropEpsInsideSqrt)
+        opt = cls(ps, lr=7e-4, eps=1e-1, alpha=0.99, **kw)
+        if name == "momentum":      # state exists before the first step
+            assert set(opt.state[ps[0]]) == {"step", "square_avg", "momentum_buffer"}
+        for t in range(4):
+            for i, p in enumerate(ps):
+                p.grad = torch.from_numpy(g["g%d_%d" % (t, i)].copy())
+            opt.step()
+            for i, p in enumerate(ps):
+                np.testing.assert_allclose(p.detach().numpy(), g["%s_w%d_%d" % (name, t, i)],
+                                           rtol=1e-6, atol=1e-7, err_msg="%s step %d" % (name, t))
+        for i, p in enumerate(ps):
+            keys = {k[len(name) + 7:-2] for k in g.files if k.startswith(name + "_state_")}
+            assert set(opt.state[p]) == keys
+            for key in keys:
+                np.testing.assert_allclose(np.asarray(opt.state[p][key]),
+                                           g["%s_state_%s_%d" % (name, key, i)], rtol=1e-6,
+                                           atol=1e-7)
+    # eps inside the root: a zero-gradient-history parameter moves by lr * g / sqrt(v + eps)
+    p = torch.nn.Parameter(torch.zeros(1))
+    opt = optimizers.RMSpropEpsInsideSqrt([p], lr=1.0, alpha=0.0, eps=3.0)
+    p.grad = torch.ones(1)
+    opt.step()
+    assert float(p.detach()) == -0.5
