@@ -9,6 +9,11 @@ values with mean m_x and (biased) variance v_x and the new total count c,
 ``forward(x, update=True)`` learns from x (until ``until`` values have been seen) and
 returns ``clip((x - mean) / sqrt(var + eps), +-clip_threshold)``.  All buffers live on
 the module's device; nothing is read back to the host except the ``until`` check.
+
+With ``torch.distributed`` initialised (env-sharded data parallelism) the batch
+that is folded in is the UNION of the ranks' batches: one all-reduce of (n, sum x, sum x^2) in
+float64, then the same update rule -- every rank keeps the statistics a single process would
+have after seeing the concatenated batch.  ``sync_across_ranks=False`` keeps them rank-local.
 """
 import numpy as np
 import torch
@@ -29,6 +34,7 @@ class EmpiricalNormalization(nn.Module):
         self.register_buffer("_var", expand(np.ones(shape, dtype=dtype)))
         self.register_buffer("count", torch.tensor(0))
         self._cached_std_inverse = None
+        self.sync_across_ranks = True
 
     @property
     def mean(self):
@@ -49,15 +55,36 @@ class EmpiricalNormalization(nn.Module):
         if self.until is not None and self.count >= self.until:
             return
         n = x.shape[self.batch_axis]
-        if n == 0:
+        from pfrl_amd import distributed
+
+        if self.sync_across_ranks and distributed.world_size() > 1:
+            n, mean_x, var_x = self._union_batch_stats(x, n)   # collective: every rank calls it
+        elif n == 0:
             return
+        else:
+            var_x, mean_x = torch.var_mean(x, dim=self.batch_axis, keepdim=True, unbiased=False)
         self.count += n
         rate = n / self.count.float()
-        var_x, mean_x = torch.var_mean(x, dim=self.batch_axis, keepdim=True, unbiased=False)
         delta = mean_x - self._mean
         self._mean += rate * delta
         self._var += rate * (var_x - self._var + delta * (mean_x - self._mean))
         self._cached_std_inverse = None
+
+    def _union_batch_stats(self, x, n):
+        """(count, mean, biased variance) of all ranks' batches together, as tensors."""
+        import torch.distributed as dist
+
+        x64 = x.double()
+        s1 = x64.sum(dim=self.batch_axis, keepdim=True)
+        s2 = (x64 * x64).sum(dim=self.batch_axis, keepdim=True)
+        acc = torch.cat([s1.reshape(-1), s2.reshape(-1),
+                         torch.full((1,), float(n), dtype=torch.float64, device=x.device)])
+        dist.all_reduce(acc, op=dist.ReduceOp.SUM)
+        d = s1.numel()
+        total = acc[-1].clamp(min=1.0)
+        mean = (acc[:d] / total).view_as(s1)
+        var = (acc[d:2 * d] / total).view_as(s1) - mean * mean
+        return acc[-1].to(self.count.dtype), mean.to(x.dtype), var.clamp(min=0.0).to(x.dtype)
 
     def forward(self, x, update=True):
         if update:

@@ -53,6 +53,24 @@ def _worker(rank, world, port, out_dir):
     std, mean = torch.std_mean(adv, unbiased=False)
     gms = distributed.global_mean_std(torch.stack([mean, std]), adv.numel())
     np.save(os.path.join(out_dir, "gms%d.npy" % rank), gms.numpy())
+    # observation statistics over the union of the shards, batch after batch
+    from pfrl_amd.nn import EmpiricalNormalization
+
+    norm = EmpiricalNormalization(5, clip_threshold=5)
+    gen = torch.Generator().manual_seed(90)
+    batches = [torch.randn(6 + 4 * k, 5, generator=gen) * (1 + k) + k for k in range(3)]
+    for b in batches:
+        half = b.shape[0] // 2 + 1      # unequal shards
+        norm(b[:half] if rank == 0 else b[half:])
+    np.save(os.path.join(out_dir, "norm%d.npy" % rank),
+            torch.cat([norm.mean, norm.std, norm.count.float().reshape(1)]).numpy())
+    if rank == 0:
+        single = EmpiricalNormalization(5, clip_threshold=5)
+        single.sync_across_ranks = False
+        for b in batches:
+            single(b)
+        np.save(os.path.join(out_dir, "norm_ref.npy"),
+                torch.cat([single.mean, single.std, single.count.float().reshape(1)]).numpy())
     np.save(os.path.join(out_dir, "adv%d.npy" % rank), adv.numpy())
     np.save(os.path.join(out_dir, "grad%d.npy" % rank), flat.numpy())
     np.save(os.path.join(out_dir, "param%d.npy" % rank), params.numpy())
@@ -80,6 +98,9 @@ def test_gradient_all_reduce_two_ranks_gloo(tmp_path):
     np.testing.assert_allclose(g0, ref, rtol=1e-5, atol=1e-6)   # == 1-process run on the full batch
     np.testing.assert_array_equal(np.load(tmp_path / "param0.npy"),
                                   np.load(tmp_path / "param1.npy"))   # broadcast worked
+    np.testing.assert_array_equal(np.load(tmp_path / "norm0.npy"), np.load(tmp_path / "norm1.npy"))
+    np.testing.assert_allclose(np.load(tmp_path / "norm0.npy"), np.load(tmp_path / "norm_ref.npy"),
+                               rtol=1e-5, atol=1e-6)    # == one process fed the concatenated batches
     allv = np.concatenate([np.load(tmp_path / "adv0.npy"), np.load(tmp_path / "adv1.npy")])
     for r in range(2):
         gms = np.load(tmp_path / ("gms%d.npy" % r))
