@@ -7,8 +7,8 @@ from torch import nn
 class ConcatObsAndAction(nn.Module):
     """(obs, action) -> concat along the last axis (batch-flattened)."""
 
-    def forward(self, obs_and_action):
-        obs, action = obs_and_action
+    def forward(self, x):
+        obs, action = x
         return torch.cat([obs.reshape(obs.shape[0], -1), action.reshape(action.shape[0], -1)],
                          dim=-1)
 

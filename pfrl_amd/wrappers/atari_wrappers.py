@@ -73,6 +73,9 @@ class NoopResetEnv(Wrapper):
                 obs = self.env.reset(**kwargs)
         return obs
 
+    def step(self, ac):
+        return self.env.step(ac)
+
 
 class FireResetEnv(Wrapper):
     """Press FIRE (1) then action 2 after a reset, for games that wait for it (reference :57-75)."""
@@ -89,6 +92,9 @@ class FireResetEnv(Wrapper):
             if _over(done, info):
                 self.env.reset(**kwargs)
         return obs
+
+    def step(self, ac):
+        return self.env.step(ac)
 
 
 class EpisodicLifeEnv(Wrapper):

@@ -1498,6 +1498,19 @@ def atari_wrappers_golden(steps=400):
           "game resets", int(out["plain_resets"][-1]))
 
 
+def api_signatures_golden():
+    """Parameter names, kinds and literal defaults of every callable of the boundary."""
+    import json
+
+    sys.path.insert(0, os.path.join(HERE, ".."))
+    from _api_surface import describe_api
+
+    desc = describe_api("pfrl")
+    with open(os.path.join(HERE, "api_signatures.json"), "w") as f:
+        json.dump(desc, f, indent=0, sort_keys=True)
+    print("api signatures:", len(desc), "callables")
+
+
 def episodic_golden():
     episodic_trace("unbounded", 30, None, 300, 3)
     episodic_trace("cap40", 31, 40, 600, 4)
@@ -1699,3 +1712,4 @@ if __name__ == "__main__":
     drqn_trace()
     rmsprop_eps_inside_sqrt_golden()
     atari_wrappers_golden()
+    api_signatures_golden()

@@ -174,3 +174,54 @@ def test_integration_doc_names_every_entry_point():
     doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
     assert len(names) >= 30
     assert not [n for n in sorted(names) if n not in doc]
+
+
+def test_python_boundary_signatures_match_the_reference():
+    """a user switches ``import pfrl`` to ``import pfrl_amd as pfrl``.  For the 291
+    callables of tests/_api_surface.py (constructors, functions and the methods drivers call), every
+    parameter the reference declares exists here with the same name, kind, order and literal
+    default (tests/golden/api_signatures.json, recorded from the reference); pfrl_amd may add
+    parameters, but only optional ones."""
+    import json
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from _api_surface import describe_api
+
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden",
+                           "api_signatures.json")) as f:
+        ref = json.load(f)
+    mine = describe_api("pfrl_amd")
+    assert len(ref) > 250
+    problems = []
+    for key, want in sorted(ref.items()):
+        if key not in mine:
+            problems.append("%s: missing" % key)
+            continue
+        got = mine[key]
+        if want is None or got is None:
+            if (want is None) != (got is None):
+                problems.append("%s: signature introspection differs" % key)
+            continue
+        by_name = {p[0]: p for p in got}
+        order = [p[0] for p in got]
+        last = -1
+        declared = set()
+        for name, kind, default in want:
+            declared.add(name)
+            if kind in ("VAR_KEYWORD", "VAR_POSITIONAL"):
+                continue
+            if name not in by_name:
+                problems.append("%s: no parameter %r" % (key, name))
+                continue
+            if by_name[name][1] != kind or by_name[name][2] != default:
+                problems.append("%s: %r is %s=%s, reference %s=%s" % (
+                    key, name, by_name[name][1], by_name[name][2], kind, default))
+            if order.index(name) < last:
+                problems.append("%s: %r out of order" % (key, name))
+            last = order.index(name)
+        for name, kind, default in got:
+            if name not in declared and default == "<required>" and kind not in (
+                    "VAR_KEYWORD", "VAR_POSITIONAL"):
+                problems.append("%s: extra required parameter %r" % (key, name))
+    assert not problems, "\n".join(problems)
