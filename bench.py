@@ -226,6 +226,9 @@ def build_sac(args, device, rank):
         replay_start_size=10000, minibatch_size=args.minibatch, update_interval=1,
         burnin_action_func=lambda: np.random.uniform(-1, 1, size=action_size).astype(np.float32),
         entropy_target=-action_size, temperature_optimizer_lr=3e-4)
+    from pfrl_amd import distributed
+
+    distributed.broadcast_agent(agent)
     return agent, env, rbuf
 
 

@@ -82,6 +82,9 @@ class SoftActorCritic(ReplayActorCritic):
         from pfrl_amd.distributed import GradientAllReducer
 
         self._reducers = {m: GradientAllReducer(m) for m in (policy, q_func1, q_func2)}
+        if self.temperature_holder is not None:
+            # one more (scalar) all-reduce so that the replicas' temperatures stay equal
+            self._reducers[self.temperature_holder] = GradientAllReducer(self.temperature_holder)
 
     # reference attribute names of the statistics windows
     q1_record = property(lambda self: self._records["q1"])

@@ -121,6 +121,22 @@ class GradientAllReducer:
             dist.broadcast(t.data, src=src)
 
 
+def broadcast_agent(agent, src=0):
+    """Make every replica start from rank ``src``'s weights: broadcasts the parameters and
+    buffers of all ``nn.Module`` attributes an agent saves (online and target networks,
+    normalisers, SAC's temperature).  Optimizer state is created lazily and therefore still
+    empty at this point.  No-op without a process group."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return
+    seen = set()
+    for name in getattr(agent, "saved_attributes", ()):
+        module = getattr(agent, name, None)
+        if isinstance(module, torch.nn.Module) and id(module) not in seen:
+            seen.add(id(module))
+            for t in list(module.parameters()) + list(module.buffers()):
+                dist.broadcast(t.data, src=src)
+
+
 def global_mean_std(mean_std, n):
     """Combine per-rank (mean, biased std) over ``n`` local samples into the
     statistics of the union of all ranks' samples: one 3-scalar all-reduce

@@ -195,6 +195,26 @@ def _agent_worker(rank, world, port, out_dir, kind):
         ag.grad_reducer.broadcast_parameters(ag.model)
         ag.sync_target_network()
         nets = [q]
+    elif kind == "sac":
+        obs_dim, act_dim = 10, 2
+        env = HostSyntheticVectorObsEnv(n_local, obs_dim=obs_dim, act_dim=act_dim, seed=20 + rank,
+                                        p_done=0.05)
+        policy = torch.nn.Sequential(
+            torch.nn.Linear(obs_dim, 16), torch.nn.ReLU(), torch.nn.Linear(16, act_dim),
+            pfrl.policies.GaussianHeadWithFixedCovariance(0.3))
+        mkq = lambda: torch.nn.Sequential(pfrl.nn.ConcatObsAndAction(),
+                                          torch.nn.Linear(obs_dim + act_dim, 16),
+                                          torch.nn.ReLU(), torch.nn.Linear(16, 1))
+        q1, q2 = mkq(), mkq()
+        opts = [torch.optim.SGD(m.parameters(), lr=1e-2) for m in (policy, q1, q2)]
+        ag = agents.SoftActorCritic(
+            policy, q1, q2, opts[0], opts[1], opts[2], replay_buffers.ReplayBuffer(500),
+            gamma=0.99, gpu=-1, replay_start_size=20, minibatch_size=8, update_interval=1,
+            entropy_target=-float(act_dim), temperature_optimizer_lr=1e-2,
+            initial_temperature=1.0 + rank,       # replicas start apart on purpose
+            burnin_action_func=lambda: np.random.uniform(-1, 1, act_dim).astype(np.float32))
+        distributed.broadcast_agent(ag)           # every saved module, targets and temperature
+        nets = [policy, q1, q2, ag.target_q_func1, ag.target_q_func2, ag.temperature_holder]
     else:
         obs_dim, act_dim = 10, 2
         env = HostSyntheticVectorObsEnv(n_local, obs_dim=obs_dim, act_dim=act_dim, seed=20 + rank,
@@ -223,7 +243,8 @@ def _agent_worker(rank, world, port, out_dir, kind):
             dst.load_state_dict(src.state_dict())
     pfrl.experiments.train_agent_batch(ag, env, 200 * n_local // 4, tempfile.mkdtemp())
     flat = np.concatenate([p.detach().numpy().ravel() for m in nets for p in m.parameters()])
-    n_updates = ag.optim_t if kind == "dqn" else ag.q_func_n_updates
+    n_updates = {"dqn": lambda: ag.optim_t, "td3": lambda: ag.q_func_n_updates,
+                 "sac": lambda: ag.n_policy_updates}[kind]()
     np.save(os.path.join(out_dir, "%s_params%d.npy" % (kind, rank)), flat)
     np.save(os.path.join(out_dir, "%s_updates%d.npy" % (kind, rank)), np.asarray(n_updates))
     np.save(os.path.join(out_dir, "%s_rlen%d.npy" % (kind, rank)),
@@ -232,7 +253,7 @@ def _agent_worker(rank, world, port, out_dir, kind):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("kind", ["dqn", "td3"])
+@pytest.mark.parametrize("kind", ["dqn", "td3", "sac"])
 def test_env_sharded_agents_stay_in_sync_two_ranks_gloo(tmp_path, kind):
     """world_size 2, gloo, host replay: env shards and replay contents differ per rank,
     the replicas do not (one averaged gradient per optimizer step)."""
