@@ -47,54 +47,65 @@ class _ObservationWrapper(Wrapper):
         return self.observation(obs), reward, done, info
 
 
-class NoopResetEnv(Wrapper):
-    """1..noop_max no-op steps (action 0) after every reset; the count comes from the env's own
-    ``np_random`` (reference :23-54)."""
+class _ScriptedReset(Wrapper):
+    """Base of the wrappers that play a fixed action prefix after every reset.  If the game ends
+    (or asks for a reset) inside the prefix it is reset again; ``_resume_from_reset`` says whether
+    the observation of that second reset replaces the one of the interrupted step."""
 
-    def __init__(self, env, noop_max=30):
-        super().__init__(env)
-        self.noop_max = noop_max
-        self.override_num_noops = None
-        self.noop_action = 0
-        assert env.unwrapped.get_action_meanings()[0] == "NOOP"
+    _resume_from_reset = True
+
+    def _prefix(self):
+        raise NotImplementedError
 
     def reset(self, **kwargs):
-        self.env.reset(**kwargs)
-        noops = self.override_num_noops
-        if noops is None:
-            rng = self.unwrapped.np_random
-            draw = rng.integers if hasattr(rng, "integers") else rng.randint
-            noops = draw(1, self.noop_max + 1)
-        assert noops > 0
-        obs = None
-        for _ in range(noops):
-            obs, _, done, info = self.env.step(self.noop_action)
+        obs = self.env.reset(**kwargs)
+        for action in self._prefix():
+            obs, _, done, info = self.env.step(action)
             if _over(done, info):
-                obs = self.env.reset(**kwargs)
+                fresh = self.env.reset(**kwargs)
+                if self._resume_from_reset:
+                    obs = fresh
         return obs
 
     def step(self, ac):
         return self.env.step(ac)
 
 
-class FireResetEnv(Wrapper):
-    """Press FIRE (1) then action 2 after a reset, for games that wait for it (reference :57-75)."""
+class NoopResetEnv(_ScriptedReset):
+    """1..noop_max no-op steps (action 0) after every reset; the count is drawn from the env's
+    own ``np_random`` unless ``override_num_noops`` is set (reference :23-54)."""
+
+    def __init__(self, env, noop_max=30):
+        super().__init__(env)
+        assert env.unwrapped.get_action_meanings()[0] == "NOOP"
+        self.noop_action = 0
+        self.noop_max = noop_max
+        self.override_num_noops = None
+
+    def _prefix(self):
+        noops = self.override_num_noops
+        if noops is None:
+            rng = self.unwrapped.np_random
+            draw = rng.integers if hasattr(rng, "integers") else rng.randint   # Generator / RandomState
+            noops = draw(1, self.noop_max + 1)
+        assert noops > 0
+        return [self.noop_action] * int(noops)
+
+
+class FireResetEnv(_ScriptedReset):
+    """Press FIRE (1) and then action 2 after a reset, for games that wait for it.  As in the
+    reference (:57-75) the returned observation is the one of the last scripted step even when
+    that step ended the game and triggered another reset."""
+
+    _resume_from_reset = False
 
     def __init__(self, env):
         super().__init__(env)
         meanings = env.unwrapped.get_action_meanings()
-        assert meanings[1] == "FIRE" and len(meanings) >= 3
+        assert len(meanings) >= 3 and meanings[1] == "FIRE"
 
-    def reset(self, **kwargs):
-        self.env.reset(**kwargs)
-        for action in (1, 2):
-            obs, _, done, info = self.env.step(action)
-            if _over(done, info):
-                self.env.reset(**kwargs)
-        return obs
-
-    def step(self, ac):
-        return self.env.step(ac)
+    def _prefix(self):
+        return (1, 2)
 
 
 class EpisodicLifeEnv(Wrapper):
@@ -251,18 +262,18 @@ def make_atari(env_id, max_frames=30 * 60 * 60):
 
 def wrap_deepmind(env, episode_life=True, clip_rewards=True, frame_stack=True, scale=False,
                   fire_reset=False, channel_order="chw", flicker=False):
-    """The Nature-DQN preprocessing stack, in the reference's order (:301-330)."""
-    if episode_life:
-        env = EpisodicLifeEnv(env)
-    if fire_reset and "FIRE" in env.unwrapped.get_action_meanings():
-        env = FireResetEnv(env)
-    env = WarpFrame(env, channel_order=channel_order)
-    if scale:
-        env = ScaledFloatFrame(env)
-    if clip_rewards:
-        env = ClipRewardEnv(env)
-    if flicker:
-        env = FlickerFrame(env)
-    if frame_stack:
-        env = FrameStack(env, 4, channel_order=channel_order)
+    """The Nature-DQN preprocessing stack, innermost first, in the reference's order (:301-330)."""
+    wants_fire = fire_reset and "FIRE" in env.unwrapped.get_action_meanings()
+    stack = [
+        (episode_life, EpisodicLifeEnv, {}),
+        (wants_fire, FireResetEnv, {}),
+        (True, WarpFrame, dict(channel_order=channel_order)),
+        (scale, ScaledFloatFrame, {}),
+        (clip_rewards, ClipRewardEnv, {}),
+        (flicker, FlickerFrame, {}),
+        (frame_stack, FrameStack, dict(k=4, channel_order=channel_order)),
+    ]
+    for enabled, wrapper, kwargs in stack:
+        if enabled:
+            env = wrapper(env, **kwargs)
     return env
