@@ -22,69 +22,88 @@ def save_agent(agent, t, outdir, logger, suffix=""):
     logger.info("Saved the agent to %s", dirname)
 
 
+class _EpisodeBook:
+    """Per-env episode accounting of the batched loop: running return and length, finished
+    episode count, and the window of recent returns the progress line averages."""
+
+    def __init__(self, num_envs, return_window_size):
+        self.ret = np.zeros(num_envs, dtype=np.float64)
+        self.length = np.zeros(num_envs, dtype="i")
+        self.count = np.zeros(num_envs, dtype="i")
+        self.recent_returns = deque(maxlen=return_window_size)
+
+    def after_step(self, rewards, dones, infos, max_episode_len):
+        """Fold one env step in; returns (resets, end): which envs are cut without being terminal
+        (length limit or the env's own ``needs_reset`` flag, reference :74-80) and which episodes
+        are over for either reason."""
+        self.ret += rewards
+        self.length += 1
+        asked = np.asarray([info.get("needs_reset", False) for info in infos], dtype=bool)
+        if max_episode_len is None:
+            resets = asked
+        else:
+            resets = np.logical_or(self.length == max_episode_len, asked)
+        end = np.logical_or(resets, dones)
+        self.count += end
+        self.recent_returns.extend(self.ret[end])
+        return resets, end
+
+    def start_new_episodes(self, end):
+        self.ret[end] = 0
+        self.length[end] = 0
+
+    @property
+    def episodes(self):
+        return np.sum(self.count)
+
+    def progress(self):
+        if not self.recent_returns:
+            return np.nan, np.nan
+        return self.recent_returns[-1], np.mean(self.recent_returns)
+
+
 def train_agent_batch(agent, env, steps, outdir, checkpoint_freq=None, log_interval=None,
                       max_episode_len=None, step_offset=0, evaluator=None, successful_score=None,
                       step_hooks=(), return_window_size=100, logger=None):
     logger = logger or logging.getLogger(__name__)
-    recent_returns = deque(maxlen=return_window_size)
     num_envs = env.num_envs
-    episode_r = np.zeros(num_envs, dtype=np.float64)
-    episode_idx = np.zeros(num_envs, dtype="i")
-    episode_len = np.zeros(num_envs, dtype="i")
+    book = _EpisodeBook(num_envs, return_window_size)
+    eval_stats_history = []
 
     obss = env.reset()
     t = step_offset
     if hasattr(agent, "t"):
         agent.t = step_offset
-
-    eval_stats_history = []
     try:
         while True:
             actions = agent.batch_act(obss)
             obss, rs, dones, infos = env.step(actions)
-            episode_r += rs
-            episode_len += 1
-
-            if max_episode_len is None:
-                resets = np.zeros(num_envs, dtype=bool)
-            else:
-                resets = episode_len == max_episode_len
-            resets = np.logical_or(resets, [info.get("needs_reset", False) for info in infos])
+            resets, end = book.after_step(rs, dones, infos, max_episode_len)
             agent.batch_observe(obss, rs, dones, resets)
 
-            end = np.logical_or(resets, dones)
-            not_end = np.logical_not(end)
-            episode_idx += end
-            recent_returns.extend(episode_r[end])
-
-            for _ in range(num_envs):
-                t += 1
+            # one global step per env: checkpoints and hooks see every value of t (:98-104)
+            for t in range(t + 1, t + num_envs + 1):
                 if checkpoint_freq and t % checkpoint_freq == 0:
                     save_agent(agent, t, outdir, logger, suffix="_checkpoint")
                 for hook in step_hooks:
                     hook(env, agent, t)
 
             if log_interval is not None and t >= log_interval and t % log_interval < num_envs:
+                last_r, average_r = book.progress()
                 logger.info("outdir:%s step:%s episode:%s last_R: %s average_R:%s", outdir, t,
-                            np.sum(episode_idx),
-                            recent_returns[-1] if recent_returns else np.nan,
-                            np.mean(recent_returns) if recent_returns else np.nan)
+                            book.episodes, last_r, average_r)
                 logger.info("statistics: %s", agent.get_statistics())
             if evaluator:
-                eval_score = evaluator.evaluate_if_necessary(t=t, episodes=np.sum(episode_idx))
+                eval_score = evaluator.evaluate_if_necessary(t=t, episodes=book.episodes)
                 if eval_score is not None:
-                    eval_stats = dict(agent.get_statistics())
-                    eval_stats["eval_score"] = eval_score
-                    eval_stats_history.append(eval_stats)
+                    eval_stats_history.append(dict(agent.get_statistics(), eval_score=eval_score))
                     if successful_score is not None and evaluator.max_score >= successful_score:
                         break
-
             if t >= steps:
                 break
 
-            episode_r[end] = 0
-            episode_len[end] = 0
-            obss = env.reset(not_end)
+            book.start_new_episodes(end)
+            obss = env.reset(np.logical_not(end))
 
     except (Exception, KeyboardInterrupt):
         save_agent(agent, t, outdir, logger, suffix="_except")

@@ -1,7 +1,14 @@
 """Ornstein-Uhlenbeck action noise (https://arxiv.org/abs/1509.02971; reference
 pfrl/explorers/additive_ou.py:8-66).  State x evolves as x += theta (mu - x) + N(0,
 sigma); the first call draws x from the stationary distribution unless
-``start_with_mu``.  Draws come from the global NumPy stream."""
+``start_with_mu``.  Draws come from the global NumPy stream.
+
+The noise state is shaped like the first action it sees and kept as float32; it is shared by all
+calls, i.e. one process = one noise process (the reference's DDPG example explores a single env).
+``evolve`` is public because tests and the reference's own callers step the process directly.
+Order of draws per call: nothing on the first call with ``start_with_mu``; otherwise exactly one
+``np.random.normal`` of the action's shape -- the stationary draw first, an Euler step after.
+"""
 from logging import getLogger
 
 import numpy as np

@@ -1,6 +1,14 @@
 """Boltzmann (softmax) exploration over discrete action values (reference
-pfrl/explorers/boltzmann.py:8-30): one ``np.random.choice`` draw per action from the
-global NumPy stream."""
+pfrl/explorers/boltzmann.py:8-30).
+
+``select_action`` ignores the greedy action: it needs the action values themselves, so the agent
+has to pass ``action_value`` (a ``DiscreteActionValue`` holding ONE row; the softmax is taken over
+its flattened Q-values at temperature ``T``).  The action is one ``np.random.choice`` draw from
+the global legacy NumPy stream -- the same stream epsilon-greedy and ``sample_n_k`` consume, which
+is what makes seeded runs comparable with the reference.  The probabilities are computed on the
+action value's device and cross to the host once per call; with hundreds of envs per step an
+agent should prefer a batched sampler, this class exists for drop-in compatibility.
+"""
 import numpy as np
 import torch
 

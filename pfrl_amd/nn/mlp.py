@@ -1,4 +1,18 @@
-"""Multi-layer perceptron (reference pfrl/nn/mlp.py)."""
+"""Multi-layer perceptron (reference pfrl/nn/mlp.py:7-36).
+
+What has to match the reference for seeded parity is not only the function computed but the ORDER
+in which the global torch RNG is consumed while the module is built: every ``nn.Linear`` draws
+its default initialisation when it is constructed, and the LeCun-normal weights that actually
+stay are drawn afterwards.  The order here is: construct all hidden layers, re-draw their weights
+(zero biases), construct the output layer, re-draw its weight with ``last_wscale``.  With the same
+seed this reproduces the reference's parameters bit for bit (the CartPole and SAC / TD3 / DDPG
+traces under tests/golden start from such models).
+
+Parameter names (``hidden_layers.<i>.weight|bias``, ``output.weight|bias``) are the reference's,
+so its ``model.pt`` files load with ``strict=True``; with no hidden layer the ``ModuleList`` is
+empty and contributes no keys.  ``hidden_layers`` / ``output`` are plain ``nn.Linear`` modules:
+the NoisyNet conversion (``to_factorized_noisy``) swaps them in place by attribute name.
+"""
 import torch.nn as nn
 import torch.nn.functional as F
 
