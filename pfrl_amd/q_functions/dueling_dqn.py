@@ -1,5 +1,20 @@
 """Dueling heads (reference pfrl/q_functions/dueling_dqn.py: DuelingDQN :20-58,
-DistributionalDuelingDQN :61-129).  Stock PyTorch."""
+DistributionalDuelingDQN :61-129).
+
+Module and parameter names (``conv_layers.<i>``, ``a_stream``, ``v_stream``, ``main_stream``) and
+the construction order -- hence the consumption of the torch RNG under a seed -- follow the
+reference, so its checkpoints load strictly and seeded runs start from the same weights.
+
+Where the device path differs from a plain forward pass (same values, fewer launches):
+
+* each convolution's bias + ReLU runs as one fused HIP launch (``conv_activation``; the last
+  one writes the flattened NCHW layout the first linear layer expects even when the trunk is
+  channels-last, ``planar_out``);
+* ``DistributionalDuelingDQN`` combines advantage and value logits, subtracts the advantage
+  mean and takes the per-action softmax over atoms in one launch forwards and one backwards
+  (``ops.dueling_softmax`` -> ``pfrl_dueling_softmax_fwd`` / ``_bwd``) on a GPU; on the CPU the
+  same arithmetic is spelled out with torch ops.
+"""
 import torch
 import torch.nn as nn
 import torch.nn.functional as F

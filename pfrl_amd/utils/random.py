@@ -4,6 +4,13 @@ Restates ``pfrl.utils.random.sample_n_k`` (/root/reference/pfrl/utils/random.py:
 4-28).  Parity needs the *same consumption* of the global ``np.random`` stream,
 so the draws stay on the host (they are a few dozen integers); only the
 resulting indices travel to the device.
+
+Two regimes, as in the reference.  Dense (3k >= n): one ``choice(n, k, replace=False)``, i.e. a
+full permutation draw.  Sparse: draw 2k candidates with replacement, keep the first k, and repair
+duplicates among them from the spare half in order; if the spares run out (rare), redraw k spares.
+For replay sampling (k = 32 out of 10^6) the sparse branch is one 64-integer draw and a set
+walk.  ``tests/golden/sample_n_k.npz`` pins both the indices and the stream position afterwards
+(the next draw of the global stream), since everything downstream shares that stream.
 """
 import numpy as np
 
