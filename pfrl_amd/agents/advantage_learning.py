@@ -14,8 +14,6 @@ from pfrl_amd.utils.contexts import evaluating
 class AL(dqn.DQN):
     """T_AL Q = T Q + alpha * (Q'(s, a) - max_b Q'(s, b))."""
 
-    _recurrent_capable = False
-
     def __init__(self, *args, **kwargs):
         self.alpha = kwargs.pop("alpha", 0.9)
         super().__init__(*args, **kwargs)
@@ -30,9 +28,11 @@ class AL(dqn.DQN):
     def _compute_y_and_t(self, exp_batch):
         n = exp_batch["reward"].shape[0]
         actions = exp_batch["action"]
-        batch_q = self.model(exp_batch["state"]).evaluate_actions(actions)
+        start = exp_batch.get("recurrent_state")
+        batch_q = self._action_value(self.model, exp_batch["state"], start).evaluate_actions(
+            actions)
         with torch.no_grad():
-            target_qout = self.target_model(exp_batch["state"])
+            target_qout = self._action_value(self.target_model, exp_batch["state"], start)
             target_next_qout = self._target_next_action_value(exp_batch)
             next_q = self._next_q(exp_batch, target_next_qout).reshape(n)
             t_q = exp_batch["reward"] + exp_batch["discount"] * (
@@ -55,5 +55,6 @@ class DoublePAL(PAL):
 
     def _next_q(self, exp_batch, target_next_qout):
         with evaluating(self.model):
-            next_qout = self.model(exp_batch["next_state"])
+            next_qout = self._action_value(self.model, exp_batch["next_state"],
+                                           exp_batch.get("next_recurrent_state"))
         return target_next_qout.evaluate_actions(next_qout.greedy_actions)

@@ -57,7 +57,6 @@ class CategoricalDQN(dqn.DQN):
     ignored (reference :107-113)."""
 
     _fused_td_double = None   # cross-entropy on distributions: not the scalar TD loss
-    _recurrent_capable = False
     _c51_double = False       # greedy next action: target net (False) / online net (True)
 
     def _project(self, exp_batch, next_dist, z_values):
@@ -72,7 +71,7 @@ class CategoricalDQN(dqn.DQN):
         return self._project(exp_batch, next_q_max, target_next_qout.z_values)
 
     def _compute_y_and_t(self, exp_batch):
-        qout = self.model(exp_batch["state"])
+        qout = self._action_value(self.model, exp_batch["state"], exp_batch.get("recurrent_state"))
         batch_actions = exp_batch["action"]
         batch_q = qout.evaluate_actions_as_distribution(batch_actions)
         with torch.no_grad():
@@ -154,7 +153,8 @@ class CategoricalDoubleDQN(CategoricalDQN):
         batch_next_state = exp_batch["next_state"]
         with evaluating(self.target_model), evaluating(self.model):
             target_next_qout = self._target_next_action_value(exp_batch)
-            next_qout = self.model(batch_next_state)
+            next_qout = self._action_value(self.model, batch_next_state,
+                                           exp_batch.get("next_recurrent_state"))
         next_q_max = target_next_qout.evaluate_actions_as_distribution(
             next_qout.greedy_actions.detach())
         return self._project(exp_batch, next_q_max, target_next_qout.z_values)

@@ -12,8 +12,6 @@ from pfrl_amd.agents.dqn import DQN
 
 
 class AbstractDPP(DQN, metaclass=ABCMeta):
-    _recurrent_capable = False
-
     @abstractmethod
     def _l_operator(self, qout):
         raise NotImplementedError()
@@ -26,9 +24,11 @@ class AbstractDPP(DQN, metaclass=ABCMeta):
     def _compute_y_and_t(self, exp_batch):
         n = exp_batch["reward"].shape[0]
         actions = exp_batch["action"]
-        batch_q = self.model(exp_batch["state"]).evaluate_actions(actions).reshape((n, 1))
+        start = exp_batch.get("recurrent_state")
+        batch_q = self._action_value(self.model, exp_batch["state"], start).evaluate_actions(
+            actions).reshape((n, 1))
         with torch.no_grad():
-            target_qout = self.target_model(exp_batch["state"])
+            target_qout = self._action_value(self.target_model, exp_batch["state"], start)
             target_q = target_qout.evaluate_actions(actions).reshape((n, 1))
             here = self._l_operator(target_qout).reshape((n, 1))
             ahead = self._compute_target_values(exp_batch).reshape((n, 1))

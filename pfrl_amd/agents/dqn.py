@@ -108,8 +108,7 @@ class DQN(agent.AttributeSavingMixin, agent.BatchAgent):
 
     saved_attributes = ("model", "target_model", "optimizer")
     _fused_td_double = False
-    # recurrent=True needs every model call of the loss to go through _action_value
-    _recurrent_capable = True
+    # recurrent=True: every model call of a loss goes through _action_value (subclasses too)
 
     def __init__(self, q_function, optimizer, replay_buffer, gamma, explorer, gpu=None,
                  replay_start_size=50000, minibatch_size=32, update_interval=1,
@@ -130,9 +129,6 @@ class DQN(agent.AttributeSavingMixin, agent.BatchAgent):
         if self.recurrent:
             # DRQN (reference :232-241): whole episodes are replayed as packed sequences, so
             # shapes vary from update to update -- this mode runs eagerly on stock torch ops.
-            if not type(self)._recurrent_capable:
-                raise NotImplementedError(
-                    "%s does not implement recurrent updates" % type(self).__name__)
             assert isinstance(replay_buffer, AbstractEpisodicReplayBuffer)
             use_graphs = step_fused_gather = fused_td_loss = False
         self.replay_buffer = replay_buffer
@@ -484,10 +480,17 @@ class DQN(agent.AttributeSavingMixin, agent.BatchAgent):
             batch_argmax = batch_av.greedy_actions.detach().cpu().numpy()
         if self.training:
             select = self.explorer.select_action
-            batch_action = [
-                select(self.t, lambda i=i: batch_argmax[i], action_value=None)
-                for i in range(len(batch_obs))
-            ]
+            if getattr(self.explorer, "uses_action_value", True):
+                # e.g. Boltzmann: every env gets its own row (reference :494-502)
+                batch_action = [
+                    select(self.t, lambda i=i: batch_argmax[i], action_value=batch_av[i:i + 1])
+                    for i in range(len(batch_obs))
+                ]
+            else:
+                batch_action = [
+                    select(self.t, lambda i=i: batch_argmax[i], action_value=None)
+                    for i in range(len(batch_obs))
+                ]
             self.batch_last_obs = list(batch_obs)
             self.batch_last_action = list(batch_action)
         else:

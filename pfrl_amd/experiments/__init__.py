@@ -7,3 +7,5 @@ from pfrl_amd.experiments.train_agent import (save_agent_replay_buffer, train_ag
 from pfrl_amd.experiments.prepare_output_dir import (generate_exp_id,  # NOQA
                                                      is_under_git_control, prepare_output_dir)
 from pfrl_amd.experiments.hooks import EvaluationHook, StepHook  # NOQA
+from pfrl_amd.experiments import evaluation_hooks  # NOQA
+from pfrl_amd.experiments.evaluation_hooks import OptunaPrunerHook  # NOQA

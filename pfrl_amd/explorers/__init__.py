@@ -10,6 +10,8 @@ from pfrl_amd.explorers.epsilon_greedy import (ConstantEpsilonGreedy,  # NOQA
 class Greedy(_explorer.Explorer):
     """Always takes the greedy action (no exploration; used by NoisyNet agents)."""
 
+    uses_action_value = False
+
     def select_action(self, t, greedy_action_func, action_value=None):
         return greedy_action_func()
 

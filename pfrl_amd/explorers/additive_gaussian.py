@@ -7,6 +7,8 @@ from pfrl_amd import explorer
 
 
 class AdditiveGaussian(explorer.Explorer):
+    uses_action_value = False
+
     def __init__(self, scale, low=None, high=None):
         self.scale = scale
         self.low = low

@@ -17,6 +17,8 @@ from pfrl_amd import explorer
 
 
 class AdditiveOU(explorer.Explorer):
+    uses_action_value = False
+
     def __init__(self, mu=0.0, theta=0.15, sigma=0.3, start_with_mu=False,
                  logger=getLogger(__name__)):
         self.mu, self.theta, self.sigma = mu, theta, sigma

@@ -18,6 +18,8 @@ def select_action_epsilon_greedily(epsilon, random_action_func, greedy_action_fu
 
 
 class _EpsilonGreedyBase(explorer.Explorer):
+    uses_action_value = False
+
     def compute_epsilon(self, t):
         return self.epsilon
 

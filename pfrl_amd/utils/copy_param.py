@@ -17,6 +17,7 @@ def soft_copy_param(target_link, source_link, tau):
         if dst.dtype in (torch.int32, torch.int64):
             dst.copy_(src)  # e.g. BatchNorm.num_batches_tracked
         else:
+            assert dst.shape == src.shape, name     # no silent broadcasting (reference :16)
             fdst.append(dst)
             fsrc.append(src)
     if not fdst:
@@ -34,6 +35,7 @@ def soft_copy_param(target_link, source_link, tau):
 
 def copy_grad(target_link, source_link):
     for tp, sp in zip(target_link.parameters(), source_link.parameters()):
+        assert tp.shape == sp.shape
         tp.grad = None if sp.grad is None else sp.grad.clone()
 
 

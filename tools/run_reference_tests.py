@@ -1,0 +1,106 @@
+#!/usr/bin/env python
+"""Run the REFERENCE's own test files against pfrl_amd (build container only).
+
+``import pfrl`` inside those files is redirected to ``pfrl_amd`` (every ``pfrl.x.y`` resolves to
+``pfrl_amd.x.y``), so the reference's test-suite becomes a drop-in check of the Python boundary
+(SURVEY.md 8b).  Nothing is copied: the test files are collected where they lie under
+/root/reference.  No GPU here, so this exercises the host paths; tests that need gym
+environments, CUDA, or components outside SURVEY.md 8 fail or are not selected.
+
+    python tools/run_reference_tests.py                      # the default selection below
+    python tools/run_reference_tests.py tests/utils_tests/test_random.py -k sample
+"""
+import importlib
+import importlib.abc
+import importlib.util
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REFERENCE = os.environ.get("PFRL_REFERENCE", "/root/reference")
+
+DEFAULT = [
+    "tests/collections_tests/test_random_access_queue.py",
+    "tests/collections_tests/test_persistent_collections.py",
+    "tests/replay_buffers_test/test_replay_buffer.py",
+    "tests/replay_buffers_test/test_persistent_replay_buffer.py",
+    "tests/utils_tests/test_random.py",
+    "tests/utils_tests/test_batch_states.py",
+    "tests/utils_tests/test_copy_param.py",
+    "tests/utils_tests/test_clip_l2_grad_norm.py",
+    "tests/utils_tests/test_contexts.py",
+    "tests/utils_tests/test_mode_of_distribution.py",
+    "tests/utils_tests/test_random_seed.py",
+    "tests/utils_tests/test_recurrent.py",
+    "tests/nn_tests/test_branched.py",
+    "tests/nn_tests/test_empirical_normalization.py",
+    "tests/nn_tests/test_lmbda.py",
+    "tests/nn_tests/test_noisy_linear.py",
+    "tests/nn_tests/test_noisy_chain.py",
+    "tests/nn_tests/test_recurrent_branched.py",
+    "tests/nn_tests/test_recurrent_sequential.py",
+    "tests/explorers_tests/test_additive_gaussian.py",
+    "tests/explorers_tests/test_additive_ou.py",
+    "tests/explorers_tests/test_boltzmann.py",
+    "tests/explorers_tests/test_epsilon_greedy.py",
+    "tests/experiments_tests/test_train_agent.py",
+    "tests/experiments_tests/test_train_agent_batch.py",
+    "tests/experiments_tests/test_evaluator.py",
+    "tests/experiments_tests/test_hooks.py",
+    "tests/experiments_tests/test_prepare_output_dir.py",
+    "tests/wrappers_tests/test_continuing_time_limit.py",
+    "tests/wrappers_tests/test_cast_observation.py",
+    "tests/wrappers_tests/test_scale_reward.py",
+    "tests/wrappers_tests/test_randomize_action.py",
+    "tests/wrappers_tests/test_render.py",
+    "tests/wrappers_tests/test_vector_frame_stack.py",
+    "tests/test_action_value.py",
+]
+
+
+class _Redirect(importlib.abc.MetaPathFinder, importlib.abc.Loader):
+    """``pfrl`` / ``pfrl.<sub>`` -> the already-importable ``pfrl_amd`` / ``pfrl_amd.<sub>``."""
+
+    def find_spec(self, fullname, path=None, target=None):
+        if fullname == "pfrl" or fullname.startswith("pfrl."):
+            return importlib.util.spec_from_loader(fullname, self)
+        return None
+
+    def create_module(self, spec):
+        real = importlib.import_module("pfrl_amd" + spec.name[len("pfrl"):])
+        return real
+
+    def exec_module(self, module):
+        pass
+
+
+def _stub_out_of_scope():
+    """Names the reference's test helpers import at module level but SURVEY.md 8 leaves out:
+    present only inside this runner, and failing loudly if a test really calls them."""
+    import pfrl_amd.experiments as experiments
+
+    def train_agent_async(*args, **kwargs):
+        raise NotImplementedError("train_agent_async is out of scope (SURVEY.md 8)")
+
+    if not hasattr(experiments, "train_agent_async"):
+        experiments.train_agent_async = train_agent_async
+
+
+def main(argv):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests", "_gymshim"))   # the reference's tests import gym
+    sys.meta_path.insert(0, _Redirect())
+    _stub_out_of_scope()
+    import pytest
+
+    files = [a for a in argv if not a.startswith("-") and a.endswith(".py")]
+    opts = [a for a in argv if a not in files]
+    files = files or DEFAULT
+    os.chdir(REFERENCE)
+    args = ["-q", "-p", "no:cacheprovider", "--rootdir", REFERENCE, "-o", "addopts=",
+            "-W", "ignore"] + opts + files
+    return pytest.main(args)
+
+
+if __name__ == "__main__":
+    sys.exit(main(sys.argv[1:]))
