@@ -14,34 +14,7 @@ their softmax (``np.random.choice`` on the global stream, like the reference).
 import numpy as np
 
 from pfrl_amd import env
-
-
-class _DiscreteSpace:
-    def __init__(self, n):
-        self.n = n
-        self.shape = ()
-        self.dtype = np.dtype(np.int64)
-
-    def sample(self):
-        return np.random.randint(self.n)
-
-    def contains(self, x):
-        return 0 <= int(x) < self.n
-
-
-class _BoxSpace:
-    def __init__(self, low, high, shape, dtype=np.float32):
-        self.shape = tuple(shape)
-        self.dtype = np.dtype(dtype)
-        self.low = np.full(self.shape, low, dtype=dtype)
-        self.high = np.full(self.shape, high, dtype=dtype)
-
-    def sample(self):
-        return np.random.uniform(self.low, self.high).astype(self.dtype)
-
-    def contains(self, x):
-        x = np.asarray(x)
-        return x.shape == self.shape and bool(np.all(x >= self.low) and np.all(x <= self.high))
+from pfrl_amd.spaces import Box, Discrete
 
 
 class ABC(env.Env):
@@ -54,8 +27,8 @@ class ABC(env.Env):
         self.deterministic = deterministic
         self.n_max_offset = 1
         self.n_dim_obs = size + 1 + self.n_max_offset
-        self.observation_space = _BoxSpace(-np.inf, np.inf, (self.n_dim_obs,))
-        self.action_space = _DiscreteSpace(size) if discrete else _BoxSpace(-1.0, 1.0, (size,))
+        self.observation_space = Box(-np.inf, np.inf, (self.n_dim_obs,))
+        self.action_space = Discrete(size) if discrete else Box(-1.0, 1.0, (size,))
         self._continuous = not discrete
 
     def observe(self):

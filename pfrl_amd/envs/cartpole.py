@@ -12,21 +12,7 @@ import math
 
 import numpy as np
 
-
-class _Discrete:
-    def __init__(self, n, rng):
-        self.n = n
-        self._rng = rng
-
-    def sample(self):
-        return int(self._rng.randint(self.n))
-
-
-class _Box:
-    def __init__(self, low, high):
-        self.low = np.asarray(low, dtype=np.float32)
-        self.high = np.asarray(high, dtype=np.float32)
-        self.shape = self.low.shape
+from pfrl_amd.spaces import Box, Discrete
 
 
 class CartPoleEnv:
@@ -37,10 +23,10 @@ class CartPoleEnv:
     def __init__(self, seed=0, max_episode_steps=500):
         self.rng = np.random.RandomState(seed)
         self.max_episode_steps = max_episode_steps
-        self.action_space = _Discrete(2, np.random.RandomState(seed + 1))
+        self.action_space = Discrete(2, np.random.RandomState(seed + 1))
         hi = [2 * self.X_LIMIT, np.finfo(np.float32).max, 2 * self.THETA_LIMIT,
               np.finfo(np.float32).max]
-        self.observation_space = _Box([-v for v in hi], hi)
+        self.observation_space = Box([-v for v in hi], hi)
         self.state = None
         self._t = 0
 

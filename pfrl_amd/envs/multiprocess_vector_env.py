@@ -48,7 +48,9 @@ class MultiprocessVectorEnv(VectorEnv):
     def __init__(self, env_fns):
         pipes = [mp.Pipe() for _ in env_fns]
         self.remotes = [p[0] for p in pipes]
-        self.procs = [mp.Process(target=_child_main, args=(p[1], fn))
+        # daemonic: a parent that exits without close() (a failed test, an exception before
+        # the env goes out of scope) must not hang in multiprocessing's atexit join
+        self.procs = [mp.Process(target=_child_main, args=(p[1], fn), daemon=True)
                       for p, fn in zip(pipes, env_fns)]
         for proc in self.procs:
             proc.start()

@@ -69,6 +69,14 @@ class VectorFrameStack(VectorEnvWrapper):
         self.k = k
         self.stack_axis = stack_axis
         self.frames = [deque([], maxlen=k) for _ in range(env.num_envs)]
+        space = self.observation_space
+        if hasattr(space, "low") and hasattr(space, "high"):
+            # what one stacked observation looks like (reference vector_frame_stack.py:74-80)
+            from pfrl_amd.spaces import Box
+
+            self.observation_space = Box(np.repeat(space.low, k, axis=stack_axis),
+                                         np.repeat(space.high, k, axis=stack_axis),
+                                         dtype=space.dtype)
 
     def reset(self, mask=None):
         batch_ob = self.env.reset(mask=mask)

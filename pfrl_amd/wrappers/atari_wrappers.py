@@ -13,6 +13,7 @@ from collections import deque
 
 import numpy as np
 
+from pfrl_amd.spaces import Box
 from pfrl_amd.wrappers import LazyFrames  # NOQA  (the reference exports it from here, :251-272)
 from pfrl_amd.wrappers.env_wrappers import ContinuingTimeLimit, Wrapper
 
@@ -26,16 +27,6 @@ except Exception:    # not installed (or a broken native library)
 
 def _over(done, info):
     return done or info.get("needs_reset", False)
-
-
-class _Box(object):
-    """The part of ``gym.spaces.Box`` the wrappers below publish."""
-
-    def __init__(self, low, high, dtype):
-        self.low = np.asarray(low, dtype=dtype)
-        self.high = np.asarray(high, dtype=dtype)
-        self.shape = self.low.shape
-        self.dtype = np.dtype(dtype)
 
 
 class _ObservationWrapper(Wrapper):
@@ -181,7 +172,7 @@ class WarpFrame(_ObservationWrapper):
         super().__init__(env)
         self.width = self.height = 84
         shape = {"hwc": (84, 84, 1), "chw": (1, 84, 84)}[channel_order]
-        self.observation_space = _Box(np.zeros(shape), np.full(shape, 255), np.uint8)
+        self.observation_space = Box(0, 255, shape, np.uint8)
 
     def observation(self, frame):
         frame = cv2.cvtColor(frame, cv2.COLOR_RGB2GRAY)
@@ -200,8 +191,9 @@ class FrameStack(Wrapper):
         self.frames = deque([], maxlen=k)
         self.stack_axis = {"hwc": 2, "chw": 0}[channel_order]
         space = env.observation_space
-        self.observation_space = _Box(np.repeat(space.low, k, axis=self.stack_axis),
-                                      np.repeat(space.high, k, axis=self.stack_axis), space.dtype)
+        self.observation_space = Box(np.repeat(space.low, k, axis=self.stack_axis),
+                                     np.repeat(space.high, k, axis=self.stack_axis),
+                                     dtype=space.dtype)
 
     def reset(self):
         ob = self.env.reset()
@@ -227,8 +219,8 @@ class ScaledFloatFrame(_ObservationWrapper):
         super().__init__(env)
         self.scale = 255.0
         space = env.observation_space
-        self.observation_space = _Box(self.observation(space.low), self.observation(space.high),
-                                      np.float32)
+        self.observation_space = Box(self.observation(space.low), self.observation(space.high),
+                                     dtype=np.float32)
 
     def observation(self, observation):
         return np.array(observation).astype(np.float32) / self.scale

@@ -8,6 +8,8 @@ with ``reset() -> obs`` and ``step(a) -> (obs, reward, done, info)`` can be wrap
 """
 import numpy as np
 
+from pfrl_amd.spaces import Box
+
 
 class Wrapper(object):
     def __init__(self, env):
@@ -129,13 +131,6 @@ class RandomizeAction(Wrapper):
         self._np_random.seed(seed)
 
 
-class _UnitBox(object):
-    def __init__(self, like):
-        self.low = -np.ones_like(like)
-        self.high = np.ones_like(like)
-        self.shape = self.low.shape
-
-
 class NormalizeActionSpace(Wrapper):
     """The agent acts in [-1, 1]^n; actions are mapped affinely onto the env's box."""
 
@@ -143,7 +138,8 @@ class NormalizeActionSpace(Wrapper):
         super().__init__(env)
         space = env.action_space
         assert hasattr(space, "low") and hasattr(space, "high"), "needs a box action space"
-        self.action_space = _UnitBox(space.low)
+        self.action_space = Box(-np.ones_like(space.low), np.ones_like(space.low),
+                                dtype=np.asarray(space.low).dtype)
 
     def action(self, action):
         space = self.env.action_space

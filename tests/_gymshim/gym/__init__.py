@@ -29,6 +29,12 @@ class Box(Space):
     def sample(self):
         return np.random.uniform(self.low, self.high).astype(self.dtype)
 
+    def __eq__(self, other):
+        return (isinstance(other, Box) and self.shape == other.shape
+                and np.array_equal(self.low, other.low) and np.array_equal(self.high, other.high))
+
+    __hash__ = None
+
 
 class Discrete(Space):
     def __init__(self, n):
@@ -37,6 +43,11 @@ class Discrete(Space):
 
     def sample(self):
         return np.random.randint(self.n)
+
+    def __eq__(self, other):
+        return isinstance(other, Discrete) and self.n == other.n
+
+    __hash__ = None
 
 
 spaces = types.ModuleType("gym.spaces")
@@ -161,8 +172,34 @@ wrappers = types.ModuleType("gym.wrappers")
 wrappers.TimeLimit = _TimeLimit
 
 
-def make(*args, **kwargs):
-    raise RuntimeError("gym shim: no registered environments")
+def make(env_id, *args, **kwargs):
+    """Only CartPole exists here: pfrl_amd's numpy CartPole (gym's published dynamics) behind
+    the terminating TimeLimit gym would put around it.  Enough for the reference's vector-env
+    and wrapper tests to run under tools/run_reference_tests.py."""
+    limits = {"CartPole-v0": 200, "CartPole-v1": 500}
+    if env_id not in limits:
+        raise RuntimeError("gym shim: no environment %r" % (env_id,))
+    from pfrl_amd.envs.cartpole import CartPoleEnv
+
+    class _CartPole(Env):
+        def __init__(self):
+            self._env = CartPoleEnv(seed=0, max_episode_steps=10 ** 9)
+            self.action_space = Discrete(2)
+            high = np.asarray(self._env.observation_space.high, dtype=np.float32)
+            self.observation_space = Box(-high, high, dtype=np.float32)
+            self.spec = types.SimpleNamespace(id=env_id)
+
+        def seed(self, seed=None):
+            self._env.seed(0 if seed is None else seed)
+            return [seed]
+
+        def reset(self):
+            return self._env.reset()
+
+        def step(self, action):
+            return self._env.step(action)
+
+    return _TimeLimit(_CartPole(), max_episode_steps=limits[env_id])
 
 
 import sys  # noqa: E402

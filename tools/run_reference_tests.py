@@ -7,8 +7,12 @@
 /root/reference.  No GPU here, so this exercises the host paths; tests that need gym
 environments, CUDA, or components outside SURVEY.md 8 fail or are not selected.
 
-    python tools/run_reference_tests.py                      # the default selection below
+    python tools/run_reference_tests.py -m "not slow and not gpu"   # the default selection below
     python tools/run_reference_tests.py tests/utils_tests/test_random.py -k sample
+
+Redirect the output to a file rather than a pipe when running unattended: tests that start env
+worker processes keep an inherited pipe open if the run is killed from outside.
+Results of the last run: COVERAGE.md, "(b) the reference's own tests".
 """
 import importlib
 import importlib.abc
@@ -55,6 +59,20 @@ DEFAULT = [
     "tests/wrappers_tests/test_render.py",
     "tests/wrappers_tests/test_vector_frame_stack.py",
     "tests/test_action_value.py",
+    "tests/test_agent.py",
+    "tests/envs_tests/test_vector_envs.py",
+    "tests/agents_tests/test_dqn.py",
+    "tests/agents_tests/test_double_dqn.py",
+    "tests/agents_tests/test_categorical_dqn.py",
+    "tests/agents_tests/test_double_categorical_dqn.py",
+    "tests/agents_tests/test_iqn.py",
+    "tests/agents_tests/test_al.py",
+    "tests/agents_tests/test_pal.py",
+    "tests/agents_tests/test_double_pal.py",
+    "tests/agents_tests/test_dpp.py",
+    "tests/agents_tests/test_soft_actor_critic.py",
+    "tests/agents_tests/test_td3.py",
+    "tests/agents_tests/test_ddpg.py",
 ]
 
 
