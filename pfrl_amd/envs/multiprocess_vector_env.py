@@ -46,14 +46,18 @@ def _child_main(conn, env_fn):
 
 class MultiprocessVectorEnv(VectorEnv):
     def __init__(self, env_fns):
-        pipes = [mp.Pipe() for _ in env_fns]
-        self.remotes = [p[0] for p in pipes]
-        # daemonic: a parent that exits without close() (a failed test, an exception before
-        # the env goes out of scope) must not hang in multiprocessing's atexit join
-        self.procs = [mp.Process(target=_child_main, args=(p[1], fn), daemon=True)
-                      for p, fn in zip(pipes, env_fns)]
-        for proc in self.procs:
+        # One pipe + one daemonic worker at a time, and the parent drops its copy of the worker's
+        # end right away: if a worker dies (its env constructor raised, it was killed), the
+        # parent's recv() sees EOF instead of blocking forever, and a parent that exits without
+        # close() does not hang in multiprocessing's atexit join.
+        self.remotes, self.procs = [], []
+        for fn in env_fns:
+            parent_end, worker_end = mp.Pipe()
+            proc = mp.Process(target=_child_main, args=(worker_end, fn), daemon=True)
             proc.start()
+            worker_end.close()
+            self.remotes.append(parent_end)
+            self.procs.append(proc)
         self.closed = False
         self.last_obs = [None] * self.num_envs
         self.action_space, self.observation_space = self._ask(0, "spaces")
@@ -64,7 +68,13 @@ class MultiprocessVectorEnv(VectorEnv):
 
     def _ask(self, i, cmd, payload=None):
         self.remotes[i].send((cmd, payload))
-        return self.remotes[i].recv()
+        return self._recv(i)
+
+    def _recv(self, i):
+        try:
+            return self.remotes[i].recv()
+        except (EOFError, ConnectionResetError):
+            raise RuntimeError("env worker %d exited (see its traceback above)" % i) from None
 
     def _check_open(self):
         assert not self.closed, "This env is already closed"
@@ -73,7 +83,7 @@ class MultiprocessVectorEnv(VectorEnv):
         self._check_open()
         for remote, action in zip(self.remotes, actions):
             remote.send(("step", action))
-        replies = [remote.recv() for remote in self.remotes]
+        replies = [self._recv(i) for i in range(self.num_envs)]
         obs, rewards, dones, infos = zip(*replies)
         self.last_obs = obs
         return obs, rewards, dones, infos
@@ -86,7 +96,7 @@ class MultiprocessVectorEnv(VectorEnv):
             self.remotes[i].send(("reset", None))
         obs = list(self.last_obs)
         for i in restarting:
-            obs[i] = self.remotes[i].recv()
+            obs[i] = self._recv(i)
         self.last_obs = obs
         return obs
 
@@ -102,16 +112,22 @@ class MultiprocessVectorEnv(VectorEnv):
             raise ValueError("length of seeds must be same as num_envs {}".format(self.num_envs))
         for remote, s in zip(self.remotes, seeds):
             remote.send(("seed", s))
-        return [remote.recv() for remote in self.remotes]
+        return [self._recv(i) for i in range(self.num_envs)]
 
     def close(self):
         self._check_open()
         self.closed = True
         for remote in self.remotes:
-            remote.send(("close", None))
+            try:
+                remote.send(("close", None))
+            except (BrokenPipeError, OSError):      # that worker is already gone
+                pass
         for proc in self.procs:
             proc.join()
 
     def __del__(self):
         if not getattr(self, "closed", True):
-            self.close()
+            try:
+                self.close()
+            except Exception:     # interpreter teardown: the workers are daemonic anyway
+                pass

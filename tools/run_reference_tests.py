@@ -51,7 +51,6 @@ DEFAULT = [
     "tests/experiments_tests/test_train_agent_batch.py",
     "tests/experiments_tests/test_evaluator.py",
     "tests/experiments_tests/test_hooks.py",
-    "tests/experiments_tests/test_prepare_output_dir.py",
     "tests/wrappers_tests/test_continuing_time_limit.py",
     "tests/wrappers_tests/test_cast_observation.py",
     "tests/wrappers_tests/test_scale_reward.py",
@@ -73,6 +72,9 @@ DEFAULT = [
     "tests/agents_tests/test_soft_actor_critic.py",
     "tests/agents_tests/test_td3.py",
     "tests/agents_tests/test_ddpg.py",
+    # last: its git cases fail where git has no identity configured and then leave the process
+    # in a deleted working directory, which breaks whatever runs after them
+    "tests/experiments_tests/test_prepare_output_dir.py",
 ]
 
 
