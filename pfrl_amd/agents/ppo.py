@@ -21,6 +21,10 @@ device:
                  ``random`` exactly as the reference does
 
 so the only per-update host work is the permutation draw.
+
+Created without a GPU (``gpu=None / -1``) the agent runs the reference's list-of-dicts algorithm
+instead (``ppo_host.HostRollouts``), which is also where ``recurrent=True`` lives; the HIP kernels
+are never involved there and nothing on the device path falls back to it.
 """
 import random
 from logging import getLogger
@@ -35,6 +39,13 @@ from pfrl_amd.device_store import DeviceObsBatch
 from pfrl_amd.utils.batch_states import batch_states
 from pfrl_amd.utils.contexts import evaluating
 from pfrl_amd.utils.mode_of_distribution import mode_of_distribution
+
+
+from pfrl_amd.agents.ppo_host import (  # NOQA,E402  (the reference's module-level helpers)
+    _add_advantage_and_value_target_to_episode, _add_advantage_and_value_target_to_episodes,
+    _add_log_prob_and_value_to_episodes, _add_log_prob_and_value_to_episodes_recurrent,
+    _compute_explained_variance, _limit_sequence_length, _make_dataset, _make_dataset_recurrent,
+    _yield_minibatches, _yield_subset_of_sequences_with_fixed_number_of_items)
 
 
 def _elementwise_clip(x, x_min, x_max):
@@ -124,18 +135,23 @@ class PPO(agent.AttributeSavingMixin, agent.BatchAgent):
         self.model = model
         self.optimizer = optimizer
         self.obs_normalizer = obs_normalizer
-        if recurrent:
-            raise NotImplementedError("recurrent PPO is outside the batched hot path")
-        if gpu is None or gpu < 0:
-            raise RuntimeError("pfrl_amd.PPO keeps its rollout in HBM and needs gpu >= 0")
-        assert torch.cuda.is_available()
-        self.device = torch.device("cuda:{}".format(gpu))
-        self.model.to(self.device)
-        if self.obs_normalizer is not None:
-            self.obs_normalizer.to(self.device)
-        from pfrl_amd import _native
+        on_gpu = gpu is not None and gpu >= 0
+        if recurrent and on_gpu:
+            raise NotImplementedError(
+                "recurrent PPO runs on the host path only (gpu=None); the HBM rollout store "
+                "holds fixed-length (T, N) rollouts")
+        if on_gpu:
+            assert torch.cuda.is_available()
+            self.device = torch.device("cuda:{}".format(gpu))
+            self.model.to(self.device)
+            if self.obs_normalizer is not None:
+                self.obs_normalizer.to(self.device)
+            from pfrl_amd import _native
 
-        _native.lib()
+            _native.lib()          # no CPU fallback on this path: a missing library raises
+        else:
+            # the plumbing path of the reference: lists of transition dicts, stock torch ops
+            self.device = torch.device("cpu")
         self.gamma = gamma
         self.lambd = lambd
         self.phi = phi
@@ -148,7 +164,8 @@ class PPO(agent.AttributeSavingMixin, agent.BatchAgent):
         self.clip_eps_vf = clip_eps_vf
         self.standardize_advantages = standardize_advantages
         self.batch_states = batch_states
-        self.recurrent = False
+        self.recurrent = bool(recurrent)
+        self.max_recurrent_sequence_len = max_recurrent_sequence_len
         self.act_deterministically = act_deterministically
         self.max_grad_norm = max_grad_norm
         self.value_pass_chunk = value_pass_chunk
@@ -175,10 +192,17 @@ class PPO(agent.AttributeSavingMixin, agent.BatchAgent):
         from pfrl_amd.distributed import GradientAllReducer
 
         self.grad_reducer = GradientAllReducer(self.model)
-        from pfrl_amd.staging import StagingRing
+        self._host = None
+        if on_gpu:
+            from pfrl_amd.staging import StagingRing
 
-        self._stage = StagingRing(self.device, slot_bytes=max(1 << 22, 96 * int(update_interval)),
-                                  n_slots=8)
+            self._stage = StagingRing(self.device,
+                                      slot_bytes=max(1 << 22, 96 * int(update_interval)),
+                                      n_slots=8)
+        else:
+            from pfrl_amd.agents.ppo_host import HostRollouts
+
+            self._host = HostRollouts(self)
 
     # -- observations ------------------------------------------------------------
     def _refs_of(self, batch_obs):
@@ -270,6 +294,9 @@ class PPO(agent.AttributeSavingMixin, agent.BatchAgent):
         return action
 
     def batch_act(self, batch_obs):
+        if self._host is not None:
+            act = self._host.batch_act_train if self.training else self._host.batch_act_eval
+            return act(batch_obs)
         if self.training:
             return self._batch_act_train(batch_obs)
         return self._batch_act_eval(batch_obs)
@@ -298,6 +325,10 @@ class PPO(agent.AttributeSavingMixin, agent.BatchAgent):
         self._update_if_dataset_is_ready()
 
     def batch_observe(self, batch_obs, batch_reward, batch_done, batch_reset):
+        if self._host is not None:
+            observe = (self._host.batch_observe_train if self.training
+                       else self._host.batch_observe_eval)
+            return observe(batch_obs, batch_reward, batch_done, batch_reset)
         if self.training:
             self._batch_observe_train(batch_obs, batch_reward, batch_done, batch_reset)
 
