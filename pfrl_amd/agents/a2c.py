@@ -38,14 +38,20 @@ class A2C(agent.AttributeSavingMixin, agent.BatchAgent):
                  average_actor_loss_decay=0.999, average_entropy_decay=0.999,
                  average_value_decay=0.999, batch_states=batch_states):
         self.model = model
-        if gpu is None or gpu < 0:
-            raise RuntimeError("pfrl_amd.A2C keeps its rollout in HBM and needs gpu >= 0")
-        assert torch.cuda.is_available()
-        self.device = torch.device("cuda:{}".format(gpu))
-        self.model.to(self.device)
-        from pfrl_amd import _native
+        # With a GPU: observations are frame slots in HBM, returns come from pfrl_a2c_returns
+        # (a missing library raises).  Without one (gpu=None / -1): the plumbing path -- the
+        # (T+1, N, ...) observation tensor is collated on the host and the return scan is the
+        # reference's T-step torch loop.
+        self._on_gpu = gpu is not None and gpu >= 0
+        if self._on_gpu:
+            assert torch.cuda.is_available()
+            self.device = torch.device("cuda:{}".format(gpu))
+            self.model.to(self.device)
+            from pfrl_amd import _native
 
-        _native.lib()
+            _native.lib()
+        else:
+            self.device = torch.device("cpu")
         self.optimizer = optimizer
         self.update_steps = update_steps
         self.num_processes = num_processes
@@ -69,10 +75,12 @@ class A2C(agent.AttributeSavingMixin, agent.BatchAgent):
         self.frames = None
         self.refs = None          # int32 [T+1, N, k] on the device
         from pfrl_amd.distributed import GradientAllReducer
-        from pfrl_amd.staging import StagingRing
 
         self.grad_reducer = GradientAllReducer(self.model)
-        self._stage = StagingRing(self.device, slot_bytes=1 << 20, n_slots=32)
+        if self._on_gpu:
+            from pfrl_amd.staging import StagingRing
+
+            self._stage = StagingRing(self.device, slot_bytes=1 << 20, n_slots=32)
 
     # -- observations (shared with PPO) ----------------------------------------
     def _refs_of(self, batch_obs):
@@ -103,6 +111,8 @@ class A2C(agent.AttributeSavingMixin, agent.BatchAgent):
         return d
 
     def _gather(self, refs_dev):
+        if not self._on_gpu:
+            return refs_dev
         x = self.frames.gather(refs_dev, self._divisor())
         fs = self.frames.frame_shape
         if refs_dev.shape[1] == 1:
@@ -114,10 +124,21 @@ class A2C(agent.AttributeSavingMixin, agent.BatchAgent):
     def _sample_action(self, pout):
         return pout.sample()
 
+    def _observe(self, batch_obs):
+        """What the rollout stores per step and what ``_gather`` turns into the network input:
+        frame-slot refs [N, k] on the device path, the collated batch itself on the host."""
+        if not self._on_gpu:
+            return self.batch_states(batch_obs, self.device, self.phi)
+        (refs_dev,) = self._stage.upload([self._refs_of(batch_obs)])
+        return refs_dev
+
     def _flush_storage(self, n_env, k, action):
         T, dev = self.update_steps, self.device
         self.action_shape = tuple(action.shape[1:])
-        self.refs = torch.zeros((T + 1, n_env, k), dtype=torch.int32, device=dev)
+        if self._on_gpu:
+            self.refs = torch.zeros((T + 1, n_env, k), dtype=torch.int32, device=dev)
+        else:       # k is the observation shape here
+            self.refs = torch.zeros((T + 1, n_env) + tuple(k), dtype=torch.float, device=dev)
         self.actions = torch.zeros((T, n_env) + self.action_shape, dtype=torch.float, device=dev)
         self.rewards = torch.zeros((T, n_env), dtype=torch.float, device=dev)
         self.value_preds = torch.zeros((T + 1, n_env), dtype=torch.float, device=dev)
@@ -131,8 +152,19 @@ class A2C(agent.AttributeSavingMixin, agent.BatchAgent):
             self.value_preds[-1] = next_value
         else:
             self.returns[-1] = next_value
-        ops.a2c_returns(self.rewards, self.masks, self.value_preds, self.returns, self.gamma,
-                        self.tau, self.use_gae)
+        if self._on_gpu:
+            ops.a2c_returns(self.rewards, self.masks, self.value_preds, self.returns, self.gamma,
+                            self.tau, self.use_gae)
+            return
+        running = 0
+        for i in reversed(range(self.update_steps)):
+            if self.use_gae:
+                delta = (self.rewards[i] + self.gamma * self.value_preds[i + 1] * self.masks[i]
+                         - self.value_preds[i])
+                running = delta + self.gamma * self.tau * self.masks[i] * running
+                self.returns[i] = running + self.value_preds[i]
+            else:
+                self.returns[i] = self.rewards[i] + self.gamma * self.returns[i + 1] * self.masks[i]
 
     def update(self):
         T, N = self.update_steps, self.num_processes
@@ -140,7 +172,8 @@ class A2C(agent.AttributeSavingMixin, agent.BatchAgent):
             _, next_value = self.model(self._gather(self.refs[-1]))
             next_value = next_value[:, 0]
         self._compute_returns(next_value)
-        pout, values = self.model(self._gather(self.refs[:-1].reshape(T * N, -1)))
+        pout, values = self.model(self._gather(
+            self.refs[:-1].reshape((T * N,) + tuple(self.refs.shape[2:]))))
         actions = self.actions.reshape(-1, *self.action_shape)
         dist_entropy = pout.entropy().mean()
         action_log_probs = pout.log_prob(actions)
@@ -179,14 +212,14 @@ class A2C(agent.AttributeSavingMixin, agent.BatchAgent):
 
     def _batch_act_train(self, batch_obs):
         assert self.training
-        refs = self._refs_of(batch_obs)
-        (refs_dev,) = self._stage.upload([refs])
+        refs_dev = self._observe(batch_obs)
         statevar = self._gather(refs_dev)
         if self.t == 0:
             with torch.no_grad():
                 pout, _ = self.model(statevar)
                 action = pout.sample()   # shape probe; the reference draws here too (:231-234)
-            self._flush_storage(refs.shape[0], refs.shape[1], action)
+            self._flush_storage(refs_dev.shape[0], refs_dev.shape[1] if self._on_gpu
+                                else refs_dev.shape[1:], action)
         self.refs[self.t - self.t_start] = refs_dev
         if self.t - self.t_start == self.update_steps:
             self.update()
@@ -199,10 +232,8 @@ class A2C(agent.AttributeSavingMixin, agent.BatchAgent):
 
     def _batch_act_eval(self, batch_obs):
         assert not self.training
-        refs = self._refs_of(batch_obs)
-        (refs_dev,) = self._stage.upload([refs])
         with torch.no_grad():
-            pout, _ = self.model(self._gather(refs_dev))
+            pout, _ = self.model(self._gather(self._observe(batch_obs)))
             action = mode_of_distribution(pout) if self.act_deterministically else pout.sample()
         return action.cpu().numpy()
 
@@ -215,10 +246,14 @@ class A2C(agent.AttributeSavingMixin, agent.BatchAgent):
                 " terminal state during training. When receiving True in batch_reset,"
                 " A2C considers it as True in batch_done instead.")
             batch_done = [bool(d) or bool(r) for d, r in zip(batch_done, batch_reset)]
-        refs = self._refs_of(batch_obs)
         masks = np.array([0.0 if d else 1.0 for d in batch_done], dtype=np.float32)
         rewards = np.asarray(batch_reward, dtype=np.float32)
-        refs_dev, masks_dev, rewards_dev = self._stage.upload([refs, masks, rewards])
+        if self._on_gpu:
+            refs_dev, masks_dev, rewards_dev = self._stage.upload(
+                [self._refs_of(batch_obs), masks, rewards])
+        else:
+            refs_dev = self._observe(batch_obs)
+            masks_dev, rewards_dev = torch.from_numpy(masks), torch.from_numpy(rewards)
         i = self.t - self.t_start
         self.masks[i - 1] = masks_dev
         self.rewards[i - 1] = rewards_dev

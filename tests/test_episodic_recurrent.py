@@ -605,3 +605,47 @@ def test_ppo_sequence_helpers():
     ppo._add_advantage_and_value_target_to_episode(ep, gamma=0.5, lambd=0.5)
     assert ep[1]["adv"] == -0.25 and ep[1]["v_teacher"] == 0.0
     assert ep[0]["adv"] == (1.0 + 0.5 * 0.25 - 0.5) + 0.25 * -0.25
+
+
+@pytest.mark.parametrize("use_gae", [False, True])
+def test_a2c_host_path_matches_reference_trace(tmp_path, use_gae):
+    """A2C created without a GPU against ``agent_trace_a2c_gae{0,1}.npz``: the sampled actions
+    (same CPU RNG streams, not replayed), the return tables of every update, trained parameters
+    and the moving statistics."""
+    from pfrl_amd import agents, experiments
+    from pfrl_amd.envs.synthetic import HostSyntheticAtariVectorEnv
+    from pfrl_amd.nn import Branched
+    from pfrl_amd.policies import SoftmaxCategoricalHead
+
+    g = np.load(os.path.join(GOLDEN, "agent_trace_a2c_gae%d.npz" % int(use_gae)))
+    pfrl_amd.utils.set_random_seed(0)
+    env = HostSyntheticAtariVectorEnv(4, seed=7, frame_shape=(12, 12), p_done=0.08)
+    torch.manual_seed(4321)
+    model = torch.nn.Sequential(
+        torch.nn.Flatten(), torch.nn.Linear(4 * 144, 32), torch.nn.ReLU(),
+        Branched(torch.nn.Sequential(torch.nn.Linear(32, 6), SoftmaxCategoricalHead()),
+                 torch.nn.Linear(32, 1)))
+    opt = torch.optim.SGD(model.parameters(), lr=1e-2)
+    ag = agents.A2C(model, opt, gamma=0.99, num_processes=4, gpu=-1, update_steps=5, phi=_phi,
+                    use_gae=use_gae, tau=0.95, max_grad_norm=0.5)
+    actions, returns = [], []
+    orig_act, orig_upd = ag.batch_act, ag.update
+
+    def spy_act(obs):
+        a = orig_act(obs)
+        actions.append([int(x) for x in a])
+        return a
+
+    def spy_upd():
+        orig_upd()
+        returns.append(ag.returns.numpy().copy())
+
+    ag.batch_act, ag.update = spy_act, spy_upd
+    experiments.train_agent_batch(ag, env, 120, str(tmp_path))
+    np.testing.assert_array_equal(np.asarray(actions), g["actions"])
+    np.testing.assert_allclose(np.asarray(returns)[:, :5], g["returns"][:, :5], rtol=1e-5,
+                               atol=1e-6)
+    params = np.concatenate([p.detach().numpy().ravel() for p in model.parameters()])
+    np.testing.assert_allclose(params, g["final_params"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose([v for _, v in ag.get_statistics()], g["stats"], rtol=1e-4,
+                               atol=1e-6)

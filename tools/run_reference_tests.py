@@ -72,6 +72,8 @@ DEFAULT = [
     "tests/agents_tests/test_soft_actor_critic.py",
     "tests/agents_tests/test_td3.py",
     "tests/agents_tests/test_ddpg.py",
+    "tests/agents_tests/test_ppo.py",
+    "tests/agents_tests/test_a2c.py",
     # last: its git cases fail where git has no identity configured and then leave the process
     # in a deleted working directory, which breaks whatever runs after them
     "tests/experiments_tests/test_prepare_output_dir.py",
