@@ -143,9 +143,11 @@ class PrioritizedReplayBuffer(ReplayBuffer, PriorityWeightError):
             self.bind(device)
 
     def _make_memory_host(self):
-        raise RuntimeError(
-            "pfrl_amd.PrioritizedReplayBuffer keeps its sum/min trees in HBM and needs a GPU "
-            "(construct with device='cuda:0' or use an agent with gpu>=0)")
+        # the gpu=None plumbing path: host trees over the caller's own scalars (bit-exact with
+        # the reference by construction); the device path never comes here
+        from pfrl_amd.collections.host_prioritized import HostPrioritizedBuffer
+
+        return HostPrioritizedBuffer(capacity=self.capacity)
 
     def _make_memory_device(self):
         return _DevicePrioritizedQueue(self.store, self.capacity, self._device_opts["max_size"])
@@ -153,6 +155,13 @@ class PrioritizedReplayBuffer(ReplayBuffer, PriorityWeightError):
     def sample(self, n):
         self._ensure_bound()
         assert len(self.memory) >= n
+        if self.store is None:
+            # host lists of dicts: the weight rides on the first transition (reference :117-123)
+            sampled, probabilities, min_prob = self.memory.sample(n)
+            weights = self.weights_from_probabilities(probabilities, min_prob)
+            for entry, w in zip(sampled, weights):
+                entry[0]["weight"] = w
+            return sampled
         tree = self.memory.tree
         out = tree.sample_device(n, normalize=_NORMALIZE_CODE[self.normalize_by_max],
                                  beta=self.beta, slot_mod=self.store.E)
@@ -203,6 +212,11 @@ class PrioritizedReplayBuffer(ReplayBuffer, PriorityWeightError):
 
         ``errors`` may be a float32 device tensor (no host round trip), or a
         sequence of host scalars as in the reference."""
+        if self.store is None:
+            if isinstance(errors, torch.Tensor):
+                errors = list(errors.detach().cpu().numpy().reshape(-1))
+            self.memory.set_last_priority(self.priority_from_errors(errors))
+            return
         tree = self.memory.tree
         if isinstance(errors, torch.Tensor):
             if self.priority_pow == "device" and errors.is_cuda:

@@ -6,9 +6,10 @@ the EPISODE -- ``episodic_memory`` is a ``PrioritizedBuffer`` whose payloads are
 ``memory`` is a plain FIFO of single transitions bounded by ``capacity``; ``capacity_left`` counts
 transitions and evicts whole episodes, oldest first, once it goes negative (:60-76).
 
-The sum / min trees are the HBM-resident ``pfrl_amd.collections.PrioritizedBuffer`` (the same HIP
-kernels as the flat prioritized buffer; there is no host tree), so this class needs a GPU.  The
-episode payloads stay on the host, as in the reference.
+The episode payloads stay on the host, as in the reference.  The sum / min trees over the
+episodes are host trees by default (``collections.host_prioritized``: one leaf per EPISODE, a few
+thousand at most) and the HBM-resident ``pfrl_amd.collections.PrioritizedBuffer`` when a
+``device`` is given explicitly.
 """
 import collections
 
@@ -18,7 +19,12 @@ from pfrl_amd.replay_buffers.episodic import EpisodicReplayBuffer
 from pfrl_amd.replay_buffers.prioritized import PriorityWeightError
 
 
-def _device_tree(wait_priority_after_sampling, device, max_episodes):
+def _make_tree(wait_priority_after_sampling, device, max_episodes):
+    if device is None:
+        from pfrl_amd.collections.host_prioritized import HostPrioritizedBuffer
+
+        return HostPrioritizedBuffer(capacity=None,
+                                     wait_priority_after_sampling=wait_priority_after_sampling)
     from pfrl_amd.collections.prioritized import PrioritizedBuffer
 
     return PrioritizedBuffer(capacity=None, device=device, max_size=max_episodes,
@@ -30,7 +36,7 @@ class PrioritizedEpisodicReplayBuffer(EpisodicReplayBuffer, PriorityWeightError)
                  normalize_by_max=True, default_priority_func=None, uniform_ratio=0,
                  wait_priority_after_sampling=True, return_sample_weights=True,
                  error_min=None, error_max=None, device=None, max_episodes=1 << 20,
-                 _tree_factory=_device_tree):
+                 _tree_factory=_make_tree):
         self.current_episode = collections.defaultdict(list)
         self.episodic_memory = _tree_factory(wait_priority_after_sampling, device, max_episodes)
         self.memory = RandomAccessQueue(maxlen=capacity)

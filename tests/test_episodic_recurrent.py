@@ -176,11 +176,35 @@ def test_prioritized_episodic_host_logic_follows_reference_trace(path):
             assert rbuf.beta == g["s_beta"][i]
 
 
-def test_prioritized_episodic_needs_the_device_tree():
-    if torch.cuda.is_available():
-        pytest.skip("GPU present")
-    with pytest.raises((RuntimeError, AssertionError)):
-        PrioritizedEpisodicReplayBuffer(capacity=10)
+def test_prioritized_episodic_defaults_to_host_trees_and_matches_the_oracle_backed_run():
+    """Without ``device=`` the episode priorities live in host trees; the same trace as above
+    must come out (the oracle-backed run and the host trees are independent implementations)."""
+    from pfrl_amd.collections.host_prioritized import HostPrioritizedBuffer
+
+    path = os.path.join(GOLDEN, "prioritized_episodic_trace_cap30.npz")
+    g = np.load(path)
+    seed, cap, _, batch, max_len = (int(v) for v in g["meta"])
+    np.random.seed(seed)
+    rbuf = PrioritizedEpisodicReplayBuffer(capacity=cap, betasteps=50, normalize_by_max=True,
+                                           error_max=2.0)
+    assert isinstance(rbuf.episodic_memory, HostPrioritizedBuffer)
+    sample_at = {int(k): i for i, k in enumerate(g["s_at_op"])}
+    tid = 0
+    for k in range(len(g["op_kind"])):
+        if g["op_kind"][k] == 1:
+            rbuf.stop_current_episode(env_id=int(g["op_env"][k]))
+        else:
+            rbuf.append(state=tid, action=0, reward=0.0, next_state=tid + 1,
+                        is_state_terminal=bool(g["op_term"][k]), env_id=int(g["op_env"][k]),
+                        tid=tid)
+            tid += 1
+        if k in sample_at:
+            sl = slice(sample_at[k] * batch, (sample_at[k] + 1) * batch)
+            episodes, weights = rbuf.sample_episodes(batch, max_len=max_len)
+            assert [ep[0]["tid"] for ep in episodes] == list(g["s_first_tid"][sl]), k
+            np.testing.assert_allclose(weights, g["s_weights"][sl], rtol=1e-12)
+            rbuf.update_errors([float(e) for e in g["s_errors"][sl]])
+    assert (len(rbuf), rbuf.n_episodes) == (g["length"][-1], g["n_episodes"][-1])
 
 
 # ---- recurrent containers and helpers ----------------------------------------------------------

@@ -31,7 +31,7 @@ def check_prioritized_episodic(path):
     np.random.seed(seed)
     rbuf = PrioritizedEpisodicReplayBuffer(capacity=None if cap < 0 else cap, betasteps=50,
                                            normalize_by_max=norm, error_max=2.0,
-                                           device="cuda:0", max_episodes=4096)
+                                           device="cuda:0", max_episodes=4096)   # HBM trees
     sample_at = {int(k): i for i, k in enumerate(g["s_at_op"])}
     tid = 0
     for k in range(len(g["op_kind"])):

@@ -26,6 +26,7 @@ REFERENCE = os.environ.get("PFRL_REFERENCE", "/root/reference")
 DEFAULT = [
     "tests/collections_tests/test_random_access_queue.py",
     "tests/collections_tests/test_persistent_collections.py",
+    "tests/collections_tests/test_prioritized.py",
     "tests/replay_buffers_test/test_replay_buffer.py",
     "tests/replay_buffers_test/test_persistent_replay_buffer.py",
     "tests/utils_tests/test_random.py",
@@ -106,6 +107,18 @@ def _stub_out_of_scope():
 
     if not hasattr(experiments, "train_agent_async"):
         experiments.train_agent_async = train_agent_async
+    import torch
+
+    if not torch.cuda.is_available():
+        # pfrl.collections.prioritized.PrioritizedBuffer is the HBM-resident class; without a GPU
+        # the reference's direct tests of it are pointed at the host implementation that the
+        # gpu=None replay buffers use
+        import pfrl_amd.collections.prioritized as device_trees
+        from pfrl_amd.collections import host_prioritized
+
+        device_trees.PrioritizedBuffer = host_prioritized.HostPrioritizedBuffer
+        device_trees.SumTreeQueue = host_prioritized._SumTreeQueue
+        device_trees.MinTreeQueue = host_prioritized._MinTreeQueue
 
 
 def main(argv):
