@@ -3,6 +3,8 @@
 ``RandomAccessQueue``  FIFO with O(1) indexing for the CPU (gpu=-1) path
 ``TreeFrame``          integer bookkeeping of the reference's sliding tree frame
 ``PrioritizedBuffer``  sum / min trees in HBM (imported lazily: needs a GPU)
+``HostPrioritizedBuffer`` (``host_prioritized``)  the same interface on the host, for buffers
+                       that are used without a GPU (gpu=None plumbing path)
 """
 from pfrl_amd.collections.random_access_queue import RandomAccessQueue  # NOQA
 from pfrl_amd.collections.tree_frame import TreeFrame  # NOQA

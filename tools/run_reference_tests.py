@@ -126,6 +126,14 @@ def main(argv):
     sys.path.insert(0, os.path.join(ROOT, "tests", "_gymshim"))   # the reference's tests import gym
     sys.meta_path.insert(0, _Redirect())
     _stub_out_of_scope()
+    # Everything pfrl_amd has imported by now also answers to its pfrl.* name, so that a later
+    # ``import pfrl.utils.batch_states`` is a sys.modules hit: a fresh submodule import would
+    # re-bind ``batch_states`` on the parent package and shadow the function of the same name.
+    import pfrl_amd  # noqa: F401
+
+    for name, module in list(sys.modules.items()):
+        if name == "pfrl_amd" or name.startswith("pfrl_amd."):
+            sys.modules.setdefault("pfrl" + name[len("pfrl_amd"):], module)
     import pytest
 
     files = [a for a in argv if not a.startswith("-") and a.endswith(".py")]
