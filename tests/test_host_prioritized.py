@@ -187,3 +187,69 @@ def test_dqn_family_host_mode_matches_reference_traces(tmp_path, name, prioritiz
                                    float(g["final_tree_sum"]), rtol=1e-6)
         np.testing.assert_allclose(float(rbuf.memory.max_priority),
                                    float(g["final_max_priority"]), rtol=1e-6)
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "per_trace_*.npz"))),
+                         ids=os.path.basename)
+def test_host_prioritized_replay_buffer_follows_reference_trace(path):
+    """``PrioritizedReplayBuffer`` used without a GPU, on top of the n-step windows: sampled
+    entries, probabilities, importance weights and the beta schedule, the typed priorities that
+    ``update_errors`` writes (f32 / Python-float errors mixed), the typed root sum / min /
+    max_priority and the frame bounds after every operation, and the full trees at the
+    checkpoints the fixture holds."""
+    from pfrl_amd.replay_buffers import PrioritizedReplayBuffer
+
+    g = np.load(path)
+    seed, cap, n_steps, batch, n_envs = (int(x) for x in g["meta"])
+    alpha, beta0, betasteps, eps = (float(x) for x in g["hyper"])
+    norm = {0: False, 1: True, 2: "memory"}[int(g["normalize_by_max"])]
+    np.random.seed(seed)
+    rbuf = PrioritizedReplayBuffer(capacity=None if cap < 0 else cap, alpha=alpha, beta0=beta0,
+                                   betasteps=betasteps, normalize_by_max=norm, num_steps=n_steps)
+    assert eps == rbuf.eps
+    tid = iu = ismp = idump = 0
+    for k, (kind, a, b) in enumerate(zip(g["op_kind"], g["op_a"], g["op_b"])):
+        if kind == 0:
+            rbuf.append(state=tid, action=0, reward=0.0, next_state=tid + 1,
+                        is_state_terminal=bool(b), env_id=int(a), tid=tid)
+            tid += 1
+        elif kind == 1:
+            rbuf.stop_current_episode(env_id=int(a))
+        else:
+            mem = rbuf.memory
+            sl = slice(iu, iu + batch)
+            assert _typed(mem.priority_sums.sum()) == (g["smp_total_v"][ismp], g["smp_total_t"][ismp])
+            assert rbuf.beta == g["beta"][ismp]
+            sampled = rbuf.sample(batch)
+            assert mem.sampled_indices == list(g["idx"][sl]), k
+            for j, entry in enumerate(sampled):
+                want = g["entry_tids"][(iu + j) * n_steps:(iu + j + 1) * n_steps]
+                assert [tr["tid"] for tr in entry] == [int(x) for x in want if x >= 0]
+            np.testing.assert_allclose([e[0]["weight"] for e in sampled], g["weight"][sl],
+                                       rtol=1e-12)
+            errors = [float(e) if is_py else np.float32(e)
+                      for e, is_py in zip(g["err"][sl], g["err_is_py"][sl])]
+            written = {}
+            real = mem.set_last_priority
+            mem.set_last_priority = lambda pri, _w=written, _r=real: (_w.update(p=list(pri)),
+                                                                      _r(pri))[1]
+            rbuf.update_errors(errors)
+            del mem.set_last_priority
+            assert [_typed(p) for p in written["p"]] == list(zip(g["new_pri_v"][sl],
+                                                                 g["new_pri_t"][sl])), k
+            iu += batch
+            ismp += 1
+        mem = rbuf.memory
+        assert len(mem) == g["length"][k], k
+        if len(mem):
+            assert _typed(mem.priority_sums.sum()) == (g["sum_v"][k], g["sum_t"][k]), k
+            assert _typed(mem.priority_mins.min()) == (g["min_v"][k], g["min_t"][k]), k
+            assert mem.priority_sums.bounds == (g["ixl"][k], g["ixr"][k]), k
+        assert _typed(mem.max_priority) == (g["maxp_v"][k], g["maxp_t"][k]), k
+        if idump < len(g["dump_op"]) and g["dump_op"][idump] == k:
+            lo, hi = g["dump_off"][idump], g["dump_off"][idump + 1]
+            if hi > lo:
+                _check_levels(mem.priority_sums, g["dump_sum_v"][lo:hi], g["dump_sum_t"][lo:hi])
+                _check_levels(mem.priority_mins, g["dump_min_v"][lo:hi], g["dump_min_t"][lo:hi])
+            idump += 1
+    assert idump == len(g["dump_op"]) and ismp == len(g["beta"])
