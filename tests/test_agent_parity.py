@@ -334,16 +334,14 @@ class _DistNet(torch.nn.Module):
         return torch.softmax(h.reshape(-1, self.n_actions, self.n_atoms), dim=2)
 
 
-@pytest.mark.gpu
-def test_categorical_double_dqn_prioritized_matches_reference():
-    """Rainbow data path (config 3): CategoricalDoubleDQN + PrioritizedReplayBuffer
-    (num_steps=3, normalize_by_max='memory'), KL priorities as a device tensor."""
+def _run_c51(gpu):
+    """Rainbow data path (config 3) in small: CategoricalDoubleDQN + PrioritizedReplayBuffer
+    (num_steps=3, normalize_by_max='memory')."""
     import pfrl_amd as pfrl
     from pfrl_amd import agents, explorers, replay_buffers
     from pfrl_amd.envs.synthetic import HostSyntheticAtariVectorEnv
     from pfrl_amd.q_functions import DistributionalSingleModelStateQFunctionWithDiscreteAction
 
-    g = np.load(os.path.join(GOLDEN, "agent_trace_c51_per_n3.npz"))
     pfrl.utils.set_random_seed(0)
     env = HostSyntheticAtariVectorEnv(4, seed=11, frame_shape=(12, 12), p_done=0.04)
 
@@ -356,7 +354,7 @@ def test_categorical_double_dqn_prioritized_matches_reference():
     rbuf = replay_buffers.PrioritizedReplayBuffer(200, alpha=0.5, beta0=0.4, betasteps=100,
                                                   num_steps=3, normalize_by_max="memory")
     ex = explorers.LinearDecayEpsilonGreedy(1.0, 0.1, 400, lambda: np.random.randint(6))
-    ag = agents.CategoricalDoubleDQN(q, opt, rbuf, 0.99, ex, gpu=0, replay_start_size=40,
+    ag = agents.CategoricalDoubleDQN(q, opt, rbuf, 0.99, ex, gpu=gpu, replay_start_size=40,
                                      minibatch_size=8, update_interval=4,
                                      target_update_interval=60, phi=phi, batch_accumulator="mean")
     actions, losses = [], []
@@ -380,13 +378,34 @@ def test_categorical_double_dqn_prioritized_matches_reference():
 
     ag._update_from_batch = spy_core
     pfrl.experiments.train_agent_batch(ag, env, 640, tempfile.mkdtemp())
-    np.testing.assert_array_equal(np.asarray(actions), g["actions"])
+    params = np.concatenate([p.detach().cpu().numpy().ravel() for p in q.parameters()])
+    return dict(actions=np.asarray(actions), losses=losses, params=params, rbuf=rbuf)
+
+
+@pytest.mark.gpu
+def test_categorical_double_dqn_prioritized_matches_reference():
+    """KL priorities as a device tensor, sum / min trees in HBM."""
+    g = np.load(os.path.join(GOLDEN, "agent_trace_c51_per_n3.npz"))
+    got = _run_c51(0)
+    losses, rbuf = got["losses"], got["rbuf"]
+    np.testing.assert_array_equal(got["actions"], g["actions"])
     np.testing.assert_allclose(losses[:40], g["losses"][:40], rtol=1e-5, atol=1e-5)
     np.testing.assert_allclose(losses, g["losses"], rtol=2e-4, atol=2e-5)
-    params = np.concatenate([p.detach().cpu().numpy().ravel() for p in q.parameters()])
-    np.testing.assert_allclose(params, g["final_params"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(got["params"], g["final_params"], rtol=1e-4, atol=1e-5)
     np.testing.assert_allclose(rbuf.memory.tree.root_stats()[0][0], float(g["final_tree_sum"]),
                                rtol=1e-4)
+
+
+def test_categorical_double_dqn_prioritized_host_mode_matches_reference():
+    """The same agent without a GPU: host replay, host priority trees."""
+    g = np.load(os.path.join(GOLDEN, "agent_trace_c51_per_n3.npz"))
+    got = _run_c51(-1)
+    assert not got["rbuf"].is_device
+    np.testing.assert_array_equal(got["actions"], g["actions"])
+    np.testing.assert_allclose(got["losses"], g["losses"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(got["params"], g["final_params"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(float(got["rbuf"].memory.priority_sums.sum()),
+                               float(g["final_tree_sum"]), rtol=1e-6)
 
 
 def _squashed_head(x):
@@ -690,6 +709,14 @@ def _compare_iqn(got, g):
 def test_iqn_host_mode_matches_reference():
     g = np.load(os.path.join(GOLDEN, "agent_trace_iqn_uniform.npz"))
     _compare_iqn(_run_iqn(None, prioritized=False), g)
+
+
+def test_iqn_prioritized_host_mode_matches_reference():
+    """IQN + PER (n = 3) without a GPU: host priority trees."""
+    g = np.load(os.path.join(GOLDEN, "agent_trace_iqn_per_n3.npz"))
+    got = _run_iqn(None, prioritized=True)
+    assert not got["rbuf"].is_device
+    _compare_iqn(got, g)
 
 
 @pytest.mark.gpu
