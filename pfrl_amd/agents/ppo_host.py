@@ -42,6 +42,12 @@ def _add_advantage_and_value_target_to_episodes(episodes, gamma, lambd):
         _add_advantage_and_value_target_to_episode(episode, gamma=gamma, lambd=lambd)
 
 
+def _actions(transitions, device):
+    """Stored actions as one tensor (stacked on the host first: array-valued actions would
+    otherwise be converted element by element)."""
+    return torch.as_tensor(np.asarray([tr["action"] for tr in transitions]), device=device)
+
+
 def _states(transitions, key, batch_states, device, phi, obs_normalizer):
     x = batch_states([tr[key] for tr in transitions], device, phi)
     return obs_normalizer(x, update=False) if obs_normalizer else x
@@ -56,7 +62,7 @@ def _add_log_prob_and_value_to_episodes(episodes, model, phi, batch_states, obs_
         distribs, vs = model(_states(dataset, "state", batch_states, device, phi, obs_normalizer))
         _, next_vs = model(_states(dataset, "next_state", batch_states, device, phi,
                                    obs_normalizer))
-        actions = torch.tensor([tr["action"] for tr in dataset], device=device)
+        actions = _actions(dataset, device)
         columns = (distribs.log_prob(actions).cpu().numpy(), vs.cpu().numpy().ravel(),
                    next_vs.cpu().numpy().ravel())
     for tr, log_prob, v, next_v in zip(dataset, *columns):
@@ -78,7 +84,7 @@ def _add_log_prob_and_value_to_episodes_recurrent(episodes, model, phi, batch_st
 
         distribs, vs = run("state", "recurrent_state")
         _, next_vs = run("next_state", "next_recurrent_state")
-        actions = torch.tensor([tr["action"] for tr in flat], device=device)
+        actions = _actions(flat, device)
         columns = (distribs.log_prob(actions).cpu().numpy(), vs.cpu().numpy(),
                    next_vs.cpu().numpy())
     for tr, log_prob, v, next_v in zip(flat, *columns):
@@ -292,7 +298,7 @@ class HostRollouts:
         """Loss, backward, clip, optimizer step for one minibatch given the fresh model outputs
         for ``transitions`` (flat, in the order the outputs are in)."""
         a = self.agent
-        actions = torch.tensor([tr["action"] for tr in transitions], device=a.device)
+        actions = _actions(transitions, a.device)
         advs = self._column(transitions, "adv")
         if a.standardize_advantages:
             advs = (advs - mean_advs) / (std_advs + 1e-8)

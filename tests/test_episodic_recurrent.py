@@ -673,3 +673,63 @@ def test_a2c_host_path_matches_reference_trace(tmp_path, use_gae):
     np.testing.assert_allclose(params, g["final_params"], rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose([v for _, v in ag.get_statistics()], g["stats"], rtol=1e-4,
                                atol=1e-6)
+
+
+def _exp2(x):
+    return torch.exp(2 * x)
+
+
+def test_ppo_host_path_with_obs_normalizer_matches_reference_trace(tmp_path):
+    """MuJoCo-style PPO on the host: float32 vector observations, Gaussian policy,
+    ``EmpiricalNormalization`` learning once per rollout (``agent_trace_ppo_mujoco.npz``):
+    continuous actions drawn on the same CPU stream, normaliser statistics after every update,
+    losses, trained parameters."""
+    from pfrl_amd import agents, experiments
+    from pfrl_amd.envs.synthetic import HostSyntheticVectorObsEnv
+
+    g = np.load(os.path.join(GOLDEN, "agent_trace_ppo_mujoco.npz"))
+    N, obs_dim, act_dim = 4, 11, 3
+    pfrl_amd.utils.set_random_seed(0)
+    env = HostSyntheticVectorObsEnv(N, obs_dim=obs_dim, act_dim=act_dim, seed=6, p_done=0.05)
+    torch.manual_seed(8642)
+    model = torch.nn.Sequential(
+        torch.nn.Linear(obs_dim, 16), torch.nn.Tanh(),
+        pfrl_amd.nn.Branched(
+            torch.nn.Sequential(
+                torch.nn.Linear(16, act_dim),
+                pfrl_amd.policies.GaussianHeadWithStateIndependentCovariance(
+                    action_size=act_dim, var_type="diagonal", var_func=_exp2, var_param_init=0)),
+            torch.nn.Linear(16, 1)))
+    normalizer = pfrl_amd.nn.EmpiricalNormalization(obs_dim, clip_threshold=5)
+    opt = torch.optim.SGD(model.parameters(), lr=1e-2)
+    ag = agents.PPO(model, opt, obs_normalizer=normalizer, gpu=-1, gamma=0.99, lambd=0.95,
+                    update_interval=64, minibatch_size=16, epochs=2, clip_eps=0.2,
+                    clip_eps_vf=None, standardize_advantages=True, entropy_coef=0.0,
+                    max_grad_norm=0.5)
+    actions, losses, norm_stats = [], [], []
+    orig_act, orig_loss, orig_update = ag.batch_act, ag._lossfun, ag._host._update
+
+    def spy_act(obs):
+        a = orig_act(obs)
+        actions.append(np.asarray(a, dtype=np.float32))
+        return a
+
+    def spy_loss(*a, **kw):
+        out = orig_loss(*a, **kw)
+        losses.append([float(out.detach()), float(ag.value_loss_record.values()[-1]),
+                       float(ag.policy_loss_record.values()[-1])])
+        return out
+
+    def spy_update(dataset):
+        orig_update(dataset)
+        norm_stats.append(np.concatenate([normalizer.mean.numpy(), normalizer.std.numpy(),
+                                          [float(normalizer.count)]]))
+
+    ag.batch_act, ag._lossfun, ag._host._update = spy_act, spy_loss, spy_update
+    experiments.train_agent_batch(ag, env, 280, str(tmp_path))
+    np.testing.assert_allclose(np.asarray(actions), g["actions"], rtol=1e-5, atol=1e-6)
+    assert ag.n_updates == int(g["n_updates"]) and len(norm_stats) == int(g["n_datasets"])
+    np.testing.assert_allclose(np.asarray(norm_stats), g["norm_stats"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(np.asarray(losses), g["losses"], rtol=1e-4, atol=1e-5)
+    params = np.concatenate([p.detach().numpy().ravel() for p in model.parameters()])
+    np.testing.assert_allclose(params, g["final_params"], rtol=1e-5, atol=1e-6)
