@@ -204,6 +204,14 @@ class PPO(agent.AttributeSavingMixin, agent.BatchAgent):
 
             self._host = HostRollouts(self)
 
+    @property
+    def memory(self):
+        """Finished fragments of the current rollout as lists of transition dicts -- host path
+        only (reference attribute; the device path keeps columns in HBM, see ``rollout``)."""
+        if self._host is None:
+            raise AttributeError("PPO.memory exists on the host path only (gpu=None)")
+        return self._host.memory
+
     # -- observations ------------------------------------------------------------
     def _refs_of(self, batch_obs):
         """Frame slots [N, k] of a batch of observations (device or host)."""
