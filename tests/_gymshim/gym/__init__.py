@@ -187,7 +187,7 @@ def make(env_id, *args, **kwargs):
             self.action_space = Discrete(2)
             high = np.asarray(self._env.observation_space.high, dtype=np.float32)
             self.observation_space = Box(-high, high, dtype=np.float32)
-            self.spec = types.SimpleNamespace(id=env_id)
+            self.spec = types.SimpleNamespace(id=env_id, max_episode_steps=limits[env_id])
 
         def seed(self, seed=None):
             self._env.seed(0 if seed is None else seed)
