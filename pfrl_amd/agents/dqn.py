@@ -16,6 +16,11 @@ not in what is computed:
   dqn.py:358,445);
 * with ``torch.distributed`` initialised, gradients are all-reduced (RCCL over
   xGMI) before the optimizer step -- env-sharded data parallelism.
+
+``recurrent=True`` (reference :232-241, :367-386, :472-488) replays whole episodes from an
+episodic buffer as packed sequences; shapes vary per update, so that mode runs eagerly on stock
+torch ops (no graphs, no fused gathers) with the episodes on the host.  Every model call of a
+loss goes through ``_action_value`` so that the DQN-family subclasses inherit it.
 """
 import collections
 import copy
