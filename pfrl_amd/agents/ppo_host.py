@@ -288,6 +288,11 @@ class HostRollouts:
             return None, None
         advs = torch.tensor([tr["adv"] for tr in transitions], device=a.device)
         std, mean = torch.std_mean(advs, unbiased=False)
+        # env-sharded data parallelism: statistics of the union of the ranks' rollouts
+        # (no-op for a single process)
+        from pfrl_amd.distributed import global_mean_std
+
+        mean, std = global_mean_std(torch.stack([mean, std]), advs.numel())
         return mean, std
 
     def _column(self, transitions, key, column=False):

@@ -195,6 +195,26 @@ def _agent_worker(rank, world, port, out_dir, kind):
         ag.grad_reducer.broadcast_parameters(ag.model)
         ag.sync_target_network()
         nets = [q]
+    elif kind in ("ppo", "a2c"):
+        env = HostSyntheticAtariVectorEnv(n_local, seed=30 + rank, frame_shape=(8, 8), p_done=0.05)
+        model = torch.nn.Sequential(
+            torch.nn.Flatten(), torch.nn.Linear(4 * 64, 16), torch.nn.ReLU(),
+            pfrl.nn.Branched(torch.nn.Sequential(torch.nn.Linear(16, 6),
+                                                 pfrl.policies.SoftmaxCategoricalHead()),
+                             torch.nn.Linear(16, 1)))
+        opt = torch.optim.SGD(model.parameters(), lr=1e-2)
+        phi = lambda x: np.asarray(x, dtype=np.float32) / 255     # noqa: E731
+        if kind == "ppo":
+            ag = agents.PPO(model, opt, gpu=-1, phi=phi, update_interval=32, minibatch_size=8,
+                            epochs=2, standardize_advantages=True, max_grad_norm=0.5)
+            seen = []
+            real = ag._host._advantage_statistics
+            ag._host._advantage_statistics = lambda tr: (seen.append(real(tr)) or seen[-1])
+        else:
+            ag = agents.A2C(model, opt, gamma=0.99, num_processes=n_local, gpu=-1, update_steps=5,
+                            phi=phi, max_grad_norm=0.5)
+        distributed.broadcast_agent(ag)
+        nets = [model]
     elif kind == "sac":
         obs_dim, act_dim = 10, 2
         env = HostSyntheticVectorObsEnv(n_local, obs_dim=obs_dim, act_dim=act_dim, seed=20 + rank,
@@ -244,16 +264,20 @@ def _agent_worker(rank, world, port, out_dir, kind):
     pfrl.experiments.train_agent_batch(ag, env, 200 * n_local // 4, tempfile.mkdtemp())
     flat = np.concatenate([p.detach().numpy().ravel() for m in nets for p in m.parameters()])
     n_updates = {"dqn": lambda: ag.optim_t, "td3": lambda: ag.q_func_n_updates,
-                 "sac": lambda: ag.n_policy_updates}[kind]()
+                 "sac": lambda: ag.n_policy_updates, "ppo": lambda: ag.n_updates,
+                 "a2c": lambda: ag.t // 5}[kind]()
+    if kind == "ppo":      # advantage statistics are those of the union of the shards
+        np.save(os.path.join(out_dir, "ppo_advstats%d.npy" % rank),
+                np.asarray([[float(m), float(s)] for m, s in seen]))
     np.save(os.path.join(out_dir, "%s_params%d.npy" % (kind, rank)), flat)
     np.save(os.path.join(out_dir, "%s_updates%d.npy" % (kind, rank)), np.asarray(n_updates))
     np.save(os.path.join(out_dir, "%s_rlen%d.npy" % (kind, rank)),
-            np.asarray(len(ag.replay_buffer)))
+            np.asarray(len(ag.replay_buffer) if hasattr(ag, "replay_buffer") else 0))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("kind", ["dqn", "td3", "sac"])
+@pytest.mark.parametrize("kind", ["dqn", "td3", "sac", "ppo", "a2c"])
 def test_env_sharded_agents_stay_in_sync_two_ranks_gloo(tmp_path, kind):
     """world_size 2, gloo, host replay: env shards and replay contents differ per rank,
     the replicas do not (one averaged gradient per optimizer step)."""
@@ -264,6 +288,10 @@ def test_env_sharded_agents_stay_in_sync_two_ranks_gloo(tmp_path, kind):
     p1 = np.load(tmp_path / ("%s_params1.npy" % kind))
     u0 = int(np.load(tmp_path / ("%s_updates0.npy" % kind)))
     u1 = int(np.load(tmp_path / ("%s_updates1.npy" % kind)))
-    assert u0 == u1 > 10
+    assert u0 == u1 >= 10
     np.testing.assert_array_equal(p0, p1)
     assert np.isfinite(p0).all()
+    if kind == "ppo":
+        s0, s1 = np.load(tmp_path / "ppo_advstats0.npy"), np.load(tmp_path / "ppo_advstats1.npy")
+        assert len(s0) > 3
+        np.testing.assert_array_equal(s0, s1)
