@@ -1,0 +1,74 @@
+"""Runs a fast, self-contained subset of the REFERENCE's own test files against pfrl_amd through
+tools/run_reference_tests.py (``import pfrl`` -> ``pfrl_amd``).  Only where the reference is
+mounted (the build container); skipped on the GPU box.  The full selection and its accounting are
+in COVERAGE.md (b)."""
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REFERENCE = os.environ.get("PFRL_REFERENCE", "/root/reference")
+
+# no gym environments, no worker processes, no git: nothing environmental can fail in these
+# (deselected: NAF Q-functions and actor-learner mode, outside SURVEY 8; the PPO dataset
+# equivalence test, which the reference itself fails here at rtol 1e-7)
+FILES = [
+    "tests/collections_tests/test_random_access_queue.py",
+    "tests/collections_tests/test_persistent_collections.py",
+    "tests/collections_tests/test_prioritized.py",
+    "tests/replay_buffers_test/test_replay_buffer.py",
+    "tests/replay_buffers_test/test_persistent_replay_buffer.py",
+    "tests/utils_tests/test_random.py",
+    "tests/utils_tests/test_batch_states.py",
+    "tests/utils_tests/test_copy_param.py",
+    "tests/utils_tests/test_recurrent.py",
+    "tests/utils_tests/test_mode_of_distribution.py",
+    "tests/nn_tests/test_recurrent_sequential.py",
+    "tests/nn_tests/test_recurrent_branched.py",
+    "tests/nn_tests/test_empirical_normalization.py",
+    "tests/nn_tests/test_noisy_linear.py",
+    "tests/explorers_tests/test_epsilon_greedy.py",
+    "tests/explorers_tests/test_boltzmann.py",
+    "tests/explorers_tests/test_additive_ou.py",
+    "tests/experiments_tests/test_train_agent.py",
+    "tests/experiments_tests/test_train_agent_batch.py",
+    "tests/experiments_tests/test_hooks.py",
+    "tests/test_agent.py",
+    "tests/agents_tests/test_dqn.py",
+    "tests/agents_tests/test_double_dqn.py",
+    "tests/agents_tests/test_categorical_dqn.py",
+    "tests/agents_tests/test_double_categorical_dqn.py",
+    "tests/agents_tests/test_iqn.py",
+    "tests/agents_tests/test_al.py",
+    "tests/agents_tests/test_pal.py",
+    "tests/agents_tests/test_double_pal.py",
+    "tests/agents_tests/test_dpp.py",
+    "tests/agents_tests/test_ppo.py",
+    "tests/agents_tests/test_soft_actor_critic.py",
+    "tests/agents_tests/test_td3.py",
+    "tests/agents_tests/test_ddpg.py",
+    "tests/agents_tests/test_a2c.py",
+]
+
+
+@pytest.mark.skipif(not os.path.isdir(os.path.join(REFERENCE, "tests")),
+                    reason="the reference is not mounted here")
+def test_reference_tests_pass_against_pfrl_amd(tmp_path):
+    log = tmp_path / "reference_tests.log"
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "run_reference_tests.py"),
+           "--timeout", "300", "-m", "not slow and not gpu",
+           "-k", "not ContinuousABC and not actor_learner and not non_recurrent_equivalence"] + FILES
+    env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1")
+    with open(log, "w") as out:       # a file, not a pipe: see the runner's docstring
+        proc = subprocess.run(cmd, stdout=out, stderr=subprocess.STDOUT, env=env, cwd=str(tmp_path),
+                              timeout=1500, start_new_session=True)
+    text = log.read_text()
+    summary = [line for line in text.splitlines() if re.search(r"\d+ passed", line)]
+    assert summary, text[-3000:]
+    passed = int(re.search(r"(\d+) passed", summary[-1]).group(1))
+    assert proc.returncode == 0 and " failed" not in summary[-1] and " error" not in summary[-1], \
+        text[-4000:]
+    assert passed >= 430, summary[-1]
