@@ -19,6 +19,17 @@ API_SURFACE = {
                     "train_agent_with_evaluation", "eval_performance", "prepare_output_dir",
                     "LinearInterpolationHook"],
     "envs": ["MultiprocessVectorEnv", "SerialVectorEnv"],
+    "envs.abc": ["ABC"],
+    "agents.iqn": ["ImplicitQuantileQFunction", "RecurrentImplicitQuantileQFunction",
+                   "CosineBasisLinear", "cosine_basis_functions",
+                   "compute_eltwise_huber_quantile_loss"],
+    "agents.ppo": ["_make_dataset", "_make_dataset_recurrent", "_yield_minibatches",
+                   "_limit_sequence_length",
+                   "_yield_subset_of_sequences_with_fixed_number_of_items",
+                   "_add_advantage_and_value_target_to_episode"],
+    "agents.dqn": ["compute_value_loss", "compute_weighted_value_loss"],
+    "experiments.evaluation_hooks": ["EvaluationHook", "OptunaPrunerHook"],
+    "testing": ["torch_assert_allclose"],
     "wrappers": ["VectorFrameStack", "ContinuingTimeLimit", "CastObservationToFloat32",
                  "ScaleReward", "RandomizeAction", "NormalizeActionSpace"],
     "wrappers.atari_wrappers": ["FrameStack", "MaxAndSkipEnv", "NoopResetEnv", "wrap_deepmind",
