@@ -138,6 +138,11 @@ class ReplayActorCritic(AttributeSavingMixin, BatchAgent):
             xs = self.batch_states(batch_obs, self.device, self.phi)
             return self._policy()(xs).sample().cpu().numpy()
 
+    def batch_select_onpolicy_action(self, batch_obs):
+        """The policy's own action for every observation, without exploration noise, as a list
+        (reference td3.py:261-265, ddpg.py ``_batch_select_greedy_actions``)."""
+        return list(self._batch_select_actions(batch_obs))
+
     def batch_act(self, batch_obs):
         if not self.training:
             return self._batch_select_actions(batch_obs)

@@ -76,6 +76,14 @@ class MultiprocessVectorEnv(VectorEnv):
         except (EOFError, ConnectionResetError):
             raise RuntimeError("env worker %d exited (see its traceback above)" % i) from None
 
+    @property
+    def spec(self):
+        """The ``spec`` of the first env (fetched from its worker once)."""
+        if not hasattr(self, "_spec"):
+            self._check_open()
+            self._spec = self._ask(0, "spec")
+        return self._spec
+
     def _check_open(self):
         assert not self.closed, "This env is already closed"
 

@@ -50,6 +50,9 @@ class VectorEnvWrapper(VectorEnv):
     def close(self):
         return self.env.close()
 
+    def render(self, *args, **kwargs):
+        return self.env.render(*args, **kwargs)
+
     def seed(self, seed=None):
         return self.env.seed(seed)
 
