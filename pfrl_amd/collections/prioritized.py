@@ -264,3 +264,9 @@ class PrioritizedBuffer:
         tag = (self.min_tag if which else self.sum_tag)[idx].cpu().numpy()
         val = np.where(tag == 0, 0.0, val)
         return val, tag.astype(np.int32)
+
+
+# The reference exposes its pointer-tree queues from this module; here the device trees are flat
+# arrays in HBM (above), and these names are the host-side queues of the gpu=None path.
+from pfrl_amd.collections.host_prioritized import (  # NOQA,E402
+    _MinTreeQueue as MinTreeQueue, _SumTreeQueue as SumTreeQueue, _TreeQueue as TreeQueue)

@@ -2,7 +2,8 @@ from pfrl_amd.experiments.evaluator import (Evaluator, LinearInterpolationHook, 
                                             eval_performance)
 from pfrl_amd.experiments.train_agent_batch import (save_agent, train_agent_batch,  # NOQA
                                                     train_agent_batch_with_evaluation)
-from pfrl_amd.experiments.train_agent import (save_agent_replay_buffer, train_agent,  # NOQA
+from pfrl_amd.experiments.train_agent import (ask_and_save_agent_replay_buffer,  # NOQA
+                                              save_agent_replay_buffer, train_agent,
                                               train_agent_with_evaluation)
 from pfrl_amd.experiments.prepare_output_dir import (generate_exp_id,  # NOQA
                                                      is_under_git_control, prepare_output_dir)

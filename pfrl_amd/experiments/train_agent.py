@@ -20,6 +20,16 @@ def save_agent_replay_buffer(agent, t, outdir, suffix="", logger=None):
     logger.info("Saved the current replay buffer to %s", path)
 
 
+def ask_and_save_agent_replay_buffer(agent, t, outdir, suffix=""):
+    """Offer, on the terminal, to dump the replay buffer next to the agent (reference :15-21)."""
+    from pfrl_amd.utils.ask_yes_no import ask_yes_no
+
+    if hasattr(agent, "replay_buffer") and ask_yes_no(
+            "Replay buffer has {} transitions. Do you save them to a file?".format(
+                len(agent.replay_buffer))):
+        save_agent_replay_buffer(agent, t, outdir, suffix=suffix)
+
+
 def train_agent(agent, env, steps, outdir, checkpoint_freq=None, max_episode_len=None,
                 step_offset=0, evaluator=None, successful_score=None, step_hooks=(),
                 eval_during_episode=False, logger=None):

@@ -3,3 +3,4 @@ from pfrl_amd.utils.contexts import evaluating  # NOQA
 from pfrl_amd.utils import copy_param  # NOQA  (the MODULE, as in the reference: utils.copy_param.soft_copy_param)
 from pfrl_amd.utils.random_seed import set_random_seed  # NOQA
 from pfrl_amd.utils.clip_l2_grad_norm import clip_l2_grad_norm_  # NOQA
+from pfrl_amd.utils.ask_yes_no import ask_yes_no  # NOQA
