@@ -26,6 +26,11 @@ FILES = [
     "tests/utils_tests/test_copy_param.py",
     "tests/utils_tests/test_recurrent.py",
     "tests/utils_tests/test_mode_of_distribution.py",
+    "tests/utils_tests/test_conjugate_gradient.py",
+    "tests/utils_tests/test_is_return_code_zero.py",
+    "tests/utils_tests/test_stoppable_thread.py",
+    "tests/utils_tests/test_clip_l2_grad_norm.py",
+    "tests/utils_tests/test_contexts.py",
     "tests/nn_tests/test_recurrent_sequential.py",
     "tests/nn_tests/test_recurrent_branched.py",
     "tests/nn_tests/test_empirical_normalization.py",
