@@ -136,7 +136,8 @@ def main(argv):
             sys.modules.setdefault("pfrl" + name[len("pfrl_amd"):], module)
     import pytest
 
-    files = [a for a in argv if not a.startswith("-") and a.endswith(".py")]
+    # test files or node ids (tests/x.py::Class::test[param])
+    files = [a for a in argv if not a.startswith("-") and (a.endswith(".py") or ".py::" in a)]
     opts = [a for a in argv if a not in files]
     files = files or DEFAULT
     os.chdir(REFERENCE)
