@@ -172,3 +172,115 @@ class QuantileDiscreteActionValue(DiscreteActionValue):
 
     def __getitem__(self, i):
         return QuantileDiscreteActionValue(self.quantiles[i], self.q_values_formatter)
+
+
+class QuadraticActionValue(ActionValue):
+    """Normalized advantage function (http://arxiv.org/abs/1603.00748; reference :231-325):
+    ``Q(s, a) = V(s) - 1/2 (a - mu(s))^T P(s) (a - mu(s))`` with P positive definite, so the
+    maximiser over a box is ``mu`` clipped to the box.
+
+    ``mu`` (B, n), ``mat`` (B, n, n), ``v`` (B, 1); ``min_action`` / ``max_action`` are unbatched
+    bounds (scalars or length-n sequences) or None."""
+
+    def __init__(self, mu, mat, v, min_action=None, max_action=None):
+        self.mu, self.mat, self.v = mu, mat, v
+        self.device = mu.device
+        self.batch_size = mu.shape[0]
+        self.min_action = self._bound(min_action)
+        self.max_action = self._bound(max_action)
+        self._greedy = self._max = None
+
+    def _bound(self, value):
+        if value is None:
+            return None
+        if isinstance(value, (int, float)):
+            value = [value]
+        return torch.as_tensor(value).to(self.device).float()
+
+    @property
+    def greedy_actions(self):
+        if self._greedy is None:
+            a = self.mu
+            if self.min_action is not None:
+                a = torch.max(self.min_action.unsqueeze(0).expand_as(a), a)
+            if self.max_action is not None:
+                a = torch.min(self.max_action.unsqueeze(0).expand_as(a), a)
+            self._greedy = a
+        return self._greedy
+
+    @property
+    def max(self):
+        if self._max is None:
+            if self.min_action is None and self.max_action is None:
+                self._max = self.v.reshape(self.batch_size)       # attained at mu itself
+            else:
+                self._max = self.evaluate_actions(self.greedy_actions)
+        return self._max
+
+    def evaluate_actions(self, actions):
+        d = actions - self.mu
+        quad = torch.matmul(torch.matmul(d[:, None, :], self.mat), d[:, :, None])[:, 0, 0]
+        return self.v.reshape(self.batch_size) - 0.5 * quad
+
+    def compute_advantage(self, actions):
+        return self.evaluate_actions(actions) - self.max
+
+    def compute_double_advantage(self, actions, argmax_actions):
+        return self.evaluate_actions(actions) - self.evaluate_actions(argmax_actions)
+
+    @property
+    def params(self):
+        return (self.mu, self.mat, self.v)
+
+    def __getitem__(self, i):
+        return QuadraticActionValue(self.mu[i], self.mat[i], self.v[i],
+                                    min_action=self.min_action, max_action=self.max_action)
+
+    def __repr__(self):
+        return "QuadraticActionValue greedy_actions:{} v:{}".format(
+            self.greedy_actions.detach().cpu().numpy(), self.v.detach().cpu().numpy())
+
+
+class SingleActionValue(ActionValue):
+    """Action value given as two callables: ``evaluator(actions) -> Q`` and, optionally,
+    ``maximizer() -> greedy actions`` (reference :328-365).  Both are evaluated lazily, once."""
+
+    def __init__(self, evaluator, maximizer=None):
+        self.evaluator = evaluator
+        self.maximizer = maximizer
+        self._greedy = self._max = None
+
+    @property
+    def greedy_actions(self):
+        if self._greedy is None:
+            self._greedy = self.maximizer()
+        return self._greedy
+
+    @property
+    def max(self):
+        if self._max is None:
+            self._max = self.evaluator(self.greedy_actions)
+        return self._max
+
+    def evaluate_actions(self, actions):
+        return self.evaluator(actions)
+
+    def compute_advantage(self, actions):
+        return self.evaluator(actions) - self.max
+
+    def compute_double_advantage(self, actions, argmax_actions):
+        return self.evaluate_actions(actions) - self.evaluate_actions(argmax_actions)
+
+    @property
+    def params(self):
+        import warnings
+
+        warnings.warn("SingleActionValue has no learnable parameters until it is evaluated on "
+                      "some action; use the tensor returned by evaluate_actions instead.")
+        return ()
+
+    def __getitem__(self, i):
+        raise NotImplementedError
+
+    def __repr__(self):
+        return "SingleActionValue"
