@@ -40,7 +40,8 @@ API_SURFACE = {
            "LargeAtariCNN", "SmallAtariCNN", "BoundByTanh", "ConcatObsAndAction", "Lambda", "Branched",
            "RecurrentSequential", "RecurrentBranched"],
     "q_functions": ["DuelingDQN", "DistributionalDuelingDQN", "FCStateQFunctionWithDiscreteAction",
-                    "DistributionalFCStateQFunctionWithDiscreteAction", "DiscreteActionValueHead"],
+                    "DistributionalFCStateQFunctionWithDiscreteAction", "DiscreteActionValueHead",
+                    "FCQuadraticStateQFunction"],
     "policies": ["SoftmaxCategoricalHead", "GaussianHeadWithStateIndependentCovariance",
                  "GaussianHeadWithDiagonalCovariance", "GaussianHeadWithFixedCovariance",
                  "DeterministicHead"],
@@ -49,7 +50,11 @@ API_SURFACE = {
     "collections.prioritized": ["PrioritizedBuffer"],
     "optimizers": ["RMSpropEpsInsideSqrt", "SharedRMSpropEpsInsideSqrt"],
     "action_value": ["DiscreteActionValue", "DistributionalDiscreteActionValue",
-                     "QuantileDiscreteActionValue"],
+                     "QuantileDiscreteActionValue", "QuadraticActionValue", "SingleActionValue"],
+    "functions": ["lower_triangular_matrix", "bound_by_tanh"],
+    "utils.env_modifiers": ["make_rendered", "make_timestep_limited", "make_action_filtered",
+                            "make_reward_filtered"],
+    "utils.conjugate_gradient": ["conjugate_gradient"],
 }
 API_METHODS = ["append", "sample", "sample_episodes", "update_errors", "stop_current_episode", "save",
                "load", "batch_act", "batch_observe", "act", "observe", "get_statistics",

@@ -177,7 +177,7 @@ def test_integration_doc_names_every_entry_point():
 
 
 def test_python_boundary_signatures_match_the_reference():
-    """a user switches ``import pfrl`` to ``import pfrl_amd as pfrl``.  For the 314
+    """a user switches ``import pfrl`` to ``import pfrl_amd as pfrl``.  For the 325
     callables of tests/_api_surface.py (constructors, functions and the methods drivers call), every
     parameter the reference declares exists here with the same name, kind, order and literal
     default (tests/golden/api_signatures.json, recorded from the reference); pfrl_amd may add
