@@ -51,7 +51,8 @@ API_SURFACE = {
     "optimizers": ["RMSpropEpsInsideSqrt", "SharedRMSpropEpsInsideSqrt"],
     "action_value": ["DiscreteActionValue", "DistributionalDiscreteActionValue",
                      "QuantileDiscreteActionValue", "QuadraticActionValue", "SingleActionValue"],
-    "functions": ["lower_triangular_matrix", "bound_by_tanh"],
+    "functions.lower_triangular_matrix": ["lower_triangular_matrix"],
+    "functions.bound_by_tanh": ["bound_by_tanh"],
     "utils.env_modifiers": ["make_rendered", "make_timestep_limited", "make_action_filtered",
                             "make_reward_filtered"],
     "utils.conjugate_gradient": ["conjugate_gradient"],
