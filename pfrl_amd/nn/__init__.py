@@ -3,7 +3,7 @@ from pfrl_amd.nn.atari_cnn import (LargeAtariCNN, SmallAtariCNN,  # NOQA
 from pfrl_amd.nn.branched import Branched  # NOQA
 from pfrl_amd.nn.mlp import MLP  # NOQA
 from pfrl_amd.nn.noisy_linear import FactorizedNoisyLinear, to_factorized_noisy  # NOQA
-from pfrl_amd.nn.concat_obs_and_action import (BoundByTanh, ConcatObsAndAction, Lambda,  # NOQA
-                                               bound_by_tanh)
+from pfrl_amd.nn.concat_obs_and_action import BoundByTanh, ConcatObsAndAction, Lambda  # NOQA
+from pfrl_amd.nn import bound_by_tanh  # NOQA  (the MODULE, as in the reference)
 from pfrl_amd.nn.empirical_normalization import EmpiricalNormalization  # NOQA
 from pfrl_amd.nn.recurrent import Recurrent, RecurrentBranched, RecurrentSequential  # NOQA

@@ -39,7 +39,8 @@ def test_bound_by_tanh():
     np.testing.assert_allclose(y[1].numpy(), [2.0, 0.0], atol=1e-5)
     np.testing.assert_allclose(y[2].numpy(), [2 * math.tanh(0.3), 5 * math.tanh(1.2) + 5],
                                rtol=1e-6)
-    assert torch.equal(y, pfrl.nn.bound_by_tanh(x, low, high))
+    assert torch.equal(y, pfrl.nn.bound_by_tanh.bound_by_tanh(x, low, high))
+    assert torch.equal(y, pfrl.functions.bound_by_tanh.bound_by_tanh(x, low, high))
 
 
 def test_additive_gaussian_explorer_uses_the_numpy_stream():
