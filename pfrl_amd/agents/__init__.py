@@ -9,3 +9,4 @@ from pfrl_amd.agents.ddpg import DDPG  # NOQA
 from pfrl_amd.agents.iqn import IQN  # NOQA
 from pfrl_amd.agents.advantage_learning import AL, PAL, DoublePAL  # NOQA
 from pfrl_amd.agents.dpp import DPP, DPPL, DPPGreedy  # NOQA
+from pfrl_amd.agents import al, categorical_double_dqn, double_pal, pal  # NOQA,E402  (reference module paths)

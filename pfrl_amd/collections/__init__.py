@@ -12,6 +12,11 @@ from pfrl_amd.collections.persistent_collections import PersistentRandomAccessQu
 
 
 def __getattr__(name):
+    # lazily: the module pulls in the HIP bindings
+    if name == "prioritized":
+        import importlib
+
+        return importlib.import_module("pfrl_amd.collections.prioritized")
     if name == "PrioritizedBuffer":
         from pfrl_amd.collections.prioritized import PrioritizedBuffer
 

@@ -51,3 +51,4 @@ class Delta(Distribution):
 
     def entropy(self):
         raise RuntimeError("Not defined")
+from pfrl_amd.distributions import delta  # NOQA,E402  (reference module path)

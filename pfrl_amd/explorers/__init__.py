@@ -17,3 +17,4 @@ class Greedy(_explorer.Explorer):
 
     def __repr__(self):
         return "Greedy()"
+from pfrl_amd.explorers import greedy  # NOQA,E402  (reference module path)

@@ -20,3 +20,4 @@ def init_chainer_default(layer):
         if layer.bias is not None:
             nn.init.zeros_(layer.bias)
     return layer
+from pfrl_amd.initializers import chainer_default, lecun_normal  # NOQA,E402  (reference module paths)

@@ -7,3 +7,4 @@ from pfrl_amd.nn.concat_obs_and_action import BoundByTanh, ConcatObsAndAction, L
 from pfrl_amd.nn import bound_by_tanh  # NOQA  (the MODULE, as in the reference)
 from pfrl_amd.nn.empirical_normalization import EmpiricalNormalization  # NOQA
 from pfrl_amd.nn.recurrent import Recurrent, RecurrentBranched, RecurrentSequential  # NOQA
+from pfrl_amd.nn import lmbda, noisy_chain, recurrent_branched, recurrent_sequential  # NOQA,E402

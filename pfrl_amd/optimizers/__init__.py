@@ -135,3 +135,4 @@ class SharedRMSpropEpsInsideSqrt(RMSpropEpsInsideSqrt):
         for group in self.param_groups:
             for p in group["params"]:
                 self._init_state(p, group)
+from pfrl_amd.optimizers import rmsprop_eps_inside_sqrt  # NOQA,E402  (reference module path)

@@ -66,3 +66,4 @@ class DeterministicHead(nn.Module):
         from pfrl_amd.distributions import Delta
 
         return torch.distributions.Independent(Delta(loc=loc), 1)
+from pfrl_amd.policies import deterministic_policy, gaussian_policy, softmax_policy  # NOQA,E402

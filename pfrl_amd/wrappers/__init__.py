@@ -106,3 +106,6 @@ class VectorFrameStack(VectorEnvWrapper):
 from pfrl_amd.wrappers.env_wrappers import (CastObservation, CastObservationToFloat32,  # NOQA,E402
                                             ContinuingTimeLimit, NormalizeActionSpace,
                                             RandomizeAction, Render, ScaleReward, Wrapper)
+from pfrl_amd.wrappers import (atari_wrappers, cast_observation, continuing_time_limit,  # NOQA,E402
+                               normalize_action_space, randomize_action, render, scale_reward,
+                               vector_frame_stack)
