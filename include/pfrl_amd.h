@@ -356,6 +356,55 @@ int pfrl_noisy_weights_bwd(const float *g_w, const float *g_b, const float *r, f
                            void *stream);
 
 /* ------------------------------------------------------------------------
+ * Q-network trunk at minibatch sizes (pfrl/nn/atari_cnn.py:17-47 `activation(layer(h))`
+ * for the three Nature convolutions and the hidden linear layer, and their autograd
+ * backward inside DQN.update, pfrl/agents/dqn.py:316-365): f32 MFMA implicit-GEMM
+ * kernels (v_mfma_f32_16x16x4_f32: exact f32 fmaf chains) with bias / ReLU / ReLU-mask
+ * epilogues, sized for B = 32 where the library kernels are launch bound.
+ * Layouts: activations NHWC (torch.channels_last memory), weights [Cout][R][S][Cin]
+ * (a channels_last Conv2d weight); no padding, dilation 1, groups 1; S*C % 32 == 0.
+ * A linear layer is the case H = W = R = S = stride = 1, C = in_features.
+ *
+ * pfrl_conv2d_nhwc_fwd: y = conv(x, w) + bias, ReLU if `relu`; y is NHWC rows
+ *   [N*OH*OW][Cout], or plain NCHW if `planar_out` (the convolution in front of a
+ *   flatten).  splits > 1: split-K; y receives `splits` raw partial slabs
+ *   [splits][N*OH*OW][Cout] (no bias, no ReLU) for pfrl_splitk_reduce.
+ * pfrl_conv2d_nhwc_bwd_data: dx = conv_transpose(dy, w) masked by (a_prev > 0) when
+ *   a_prev (the ReLU output that is this layer's input; dx's layout) is given; dy is
+ *   first masked by (dy_mask > 0) when dy_mask (same layout as dy) is given.  Needs
+ *   Cout % 32 == 0, C % 16 == 0, R, S, H, W multiples of stride.  perm_p > 0
+ *   (linear layers after a planar flatten, C = perm_c * perm_p): a_prev is read
+ *   planar [c][p] and dx is written as NHWC rows [p][c].
+ * pfrl_conv2d_nhwc_bwd_weight: dw[co][r][s][ci] and db[co], reduction over the
+ *   N*OH*OW rows cut into `splits` ranges; split z writes dw_part + z*dw_stride and
+ *   db_part + z*db_stride (splits == 1: the gradients themselves).  db_part may be NULL.
+ * pfrl_splitk_reduce: out[e] = act(sum_s part[s*stride + e] + bias[e % ncol]) for up
+ *   to 12 tensors in one launch (host arrays of device pointers, passed by value).
+ * pfrl_linear_small_fwd / _bwd: a narrow head, y = x w^T + b with out_features <= 16
+ *   (Linear(512, n_actions), pfrl/q_functions/state_q_functions.py) and its backward
+ *   (dx may be NULL). */
+int pfrl_conv2d_nhwc_fwd(const float *x, const float *w, const float *bias, float *y, int32_t N,
+                         int32_t H, int32_t W, int32_t C, int32_t Cout, int32_t R, int32_t S,
+                         int32_t stride, int32_t relu, int32_t planar_out, int32_t splits,
+                         void *stream);
+int pfrl_conv2d_nhwc_bwd_data(const float *dy, const float *dy_mask, const float *w,
+                              const float *a_prev, float *dx, int32_t N, int32_t H, int32_t W,
+                              int32_t C, int32_t Cout, int32_t R, int32_t S, int32_t stride,
+                              int32_t perm_p, int32_t perm_c, void *stream);
+int pfrl_conv2d_nhwc_bwd_weight(const float *dy, const float *dy_mask, const float *x, float *dw_part,
+                                float *db_part, int64_t dw_stride, int64_t db_stride, int32_t N,
+                                int32_t H, int32_t W, int32_t C, int32_t Cout, int32_t R, int32_t S,
+                                int32_t stride, int32_t splits, void *stream);
+int pfrl_splitk_reduce(int32_t n_tasks, const float *const *host_part, float *const *host_out,
+                       const float *const *host_bias, const int64_t *host_stride,
+                       const int32_t *host_n, const int32_t *host_splits, const int32_t *host_ncol,
+                       const int32_t *host_relu, void *stream);
+int pfrl_linear_small_fwd(const float *x, const float *w, const float *bias, float *y, int32_t M,
+                          int32_t K, int32_t N, void *stream);
+int pfrl_linear_small_bwd(const float *dy, const float *x, const float *w, float *dx, float *dw,
+                          float *db, int32_t M, int32_t K, int32_t N, void *stream);
+
+/* ------------------------------------------------------------------------
  * Measurement support (bench.py roofline): time every pfrl_batch_experiences
  * (kind 0, units = sampled entries) and pfrl_batch_states_u8 (kind 1, units =
  * frame refs) launch with a hipEvent pair attached to the dispatch, on its own

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_DIR = os.path.join(_HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libpfrl_amd.so")
-SOURCES = ["frames.hip", "replay.hip", "sumtree.hip", "rollout.hip", "optim.hip", "tdloss.hip", "bias_act.hip", "noisy.hip", "c51.hip", "dueling.hip"]
+SOURCES = ["frames.hip", "replay.hip", "sumtree.hip", "rollout.hip", "optim.hip", "tdloss.hip", "bias_act.hip", "noisy.hip", "c51.hip", "dueling.hip", "qnet.hip"]
 HIPCC_FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
     # the parity contract is one correctly rounded IEEE op per source op
@@ -125,6 +125,12 @@ EXPORTS = {
     "pfrl_dueling_softmax_bwd": (ctypes.c_int, "ppppqiip"),
     "pfrl_noisy_weights_fwd": (ctypes.c_int, "pppppppqqp"),
     "pfrl_noisy_weights_bwd": (ctypes.c_int, "pppppqqp"),
+    "pfrl_conv2d_nhwc_fwd": (ctypes.c_int, "ppppiiiiiiiiiiip"),
+    "pfrl_conv2d_nhwc_bwd_data": (ctypes.c_int, "pppppiiiiiiiiiip"),
+    "pfrl_conv2d_nhwc_bwd_weight": (ctypes.c_int, "pppppqqiiiiiiiiip"),
+    "pfrl_splitk_reduce": (ctypes.c_int, "ippppppppp"),
+    "pfrl_linear_small_fwd": (ctypes.c_int, "ppppiiip"),
+    "pfrl_linear_small_bwd": (ctypes.c_int, "ppppppiiip"),
     "pfrl_profile_enable": (ctypes.c_int, "i"),
     "pfrl_profile_collect": (ctypes.c_int64, "pppq"),
 }

@@ -128,6 +128,11 @@ class DQN(agent.AttributeSavingMixin, agent.BatchAgent):
             assert torch.cuda.is_available()
             self.device = torch.device("cuda:{}".format(gpu))
             self.model.to(self.device)
+            # narrow output layers (Linear(512, n_actions)) take the one-launch head kernels;
+            # same module class, parameters and state_dict
+            from pfrl_amd.nn.mfma_trunk import accelerate_heads
+
+            accelerate_heads(self.model)
         else:
             self.device = torch.device("cpu")
         self.recurrent = bool(recurrent)

@@ -1,0 +1,913 @@
+// Q-network trunk at minibatch sizes: f32 MFMA implicit-GEMM kernels for gfx950.
+//
+// Replaces, for the DQN / PPO example networks (pfrl/nn/atari_cnn.py:17-47 and the
+// nn.Sequential of examples/atari/train_ppo_ale.py:247-264), the MIOpen / hipBLASLt
+// launches behind `activation(layer(h))` and their autograd backward at the batch
+// sizes of the update loop (pfrl/agents/dqn.py:316-365: B = 32 per update, 64
+// dependent updates per batched env step).  At that size every library kernel is a
+// 5-17 us launch for <1 us of work, plus zero-fill and bias / ReLU helper launches.
+//
+// One tile engine, three problems (all C[M x N] = sum_k A[m][k] * B[k][n] on
+// v_mfma_f32_16x16x4_f32: exact f32 fmaf chains, no reduced precision):
+//   forward   y[m][co]   = relu(sum_k xcol[m][k] * w[co][k] + b[co])   m = (n, oh, ow), k = (r, s, ci)
+//   dgrad     dx[m][ci]  = (sum_{tap, co} dy[m - tap][co] * w[co][tap][ci]) * (a_prev > 0)
+//   wgrad     dw[co][k]  = sum_m dy[m][co] * xcol[m][k]                 split over m, partials
+// A linear layer is the 1x1 case (H = W = 1).  Activations are NHWC, weights
+// [Cout][R][S][Cin] (torch.channels_last memory), so every im2col row is R runs of
+// S*Cin contiguous floats: the loaders move 32-float pieces of those runs (one
+// float4 per lane, 128 B contiguous per 8 lanes) and never materialise im2col.
+//
+// Tile engine: 256 threads = 4 waves arranged WM x WN x WK over a BM x BN tile; the
+// reduction is staged through LDS in chunks of 32 (double buffered, register
+// prefetch of the next chunk, one barrier per chunk).  Two LDS layouts:
+//   (R) [row][k], stride 36: operand rows contiguous in k; a lane reads 4 consecutive
+//       k with one ds_read_b128 and feeds 4 MFMA steps with them
+//   (C) [k][col], stride BT + 4: operand contiguous across the tile dimension
+//       (weights in dgrad, both operands in wgrad); 4 ds_read_b32, conflict free
+// Both use the same k -> (lane group, step) map k = 16*sc + 4*(lane >> 4) + t.
+// MFMA issue is never the bound here (<= 2 us per layer even from one wave per
+// SIMD); grids are sized so that >= 256 workgroups exist at B = 32, with split-K
+// (partials + one multi-tensor reduce) where the output is small.
+#include "common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int KC = 32;
+constexpr int LDR = KC + 4;
+
+struct ConvGeom {
+    int N, H, W, C, Cout, R, S, ST, OH, OW;
+};
+
+// Loads are issued unconditionally (invalid rows read a valid dummy address and are
+// zeroed when the slot is parked in LDS): a predicated load is an exec-masked branch,
+// and behind one the compiler drains every outstanding load (s_waitcnt vmcnt(0)),
+// which would serialise the chunk pipeline below.
+__device__ __forceinline__ float4 ldg4(const float *p) {
+    return *reinterpret_cast<const float4 *>(p);
+}
+__device__ __forceinline__ float4 zero_unless(float4 v, bool ok) {
+    v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
+    return v;
+}
+__device__ __forceinline__ float4 relu_mask(float4 v, float4 h) {
+    v.x = h.x > 0.f ? v.x : 0.f; v.y = h.y > 0.f ? v.y : 0.f;
+    v.z = h.z > 0.f ? v.z : 0.f; v.w = h.w > 0.f ? v.w : 0.f;
+    return v;
+}
+
+// One 16-wide sub-chunk (4 MFMA steps) of the current LDS chunk.
+template <int AM, int AN, int P, bool A_R, bool B_R, int LDA, int LDB>
+__device__ __forceinline__ void mma_sub(const float *As, const float *Bs, int wm0, int wn0, int sc,
+                                        int lane, f32x4 (&acc)[AM][AN][P]) {
+    const int i = lane & 15, kq = lane >> 4;
+    float a[AM][4], b[AN][4];
+#pragma unroll
+    for (int am = 0; am < AM; ++am) {
+        if (A_R) {
+            const float4 v = *reinterpret_cast<const float4 *>(
+                &As[(wm0 + 16 * am + i) * LDA + 16 * sc + 4 * kq]);
+            a[am][0] = v.x; a[am][1] = v.y; a[am][2] = v.z; a[am][3] = v.w;
+        } else {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) a[am][t] = As[(16 * sc + 4 * kq + t) * LDA + wm0 + 16 * am + i];
+        }
+    }
+#pragma unroll
+    for (int an = 0; an < AN; ++an) {
+        if (B_R) {
+            const float4 v = *reinterpret_cast<const float4 *>(
+                &Bs[(wn0 + 16 * an + i) * LDB + 16 * sc + 4 * kq]);
+            b[an][0] = v.x; b[an][1] = v.y; b[an][2] = v.z; b[an][3] = v.w;
+        } else {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) b[an][t] = Bs[(16 * sc + 4 * kq + t) * LDB + wn0 + 16 * an + i];
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int am = 0; am < AM; ++am)
+#pragma unroll
+            for (int an = 0; an < AN; ++an)
+                acc[am][an][t % P] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[am][t], b[an][t],
+                                                                           acc[am][an][t % P], 0, 0, 0);
+}
+
+// Fold the P interleaved accumulators and the WK wave slices of a tile; afterwards the
+// waves with wk == 0 hold the result in acc[..][..][0].
+template <int AM, int AN, int P, int WK, int NRED>
+__device__ __forceinline__ void fold_acc(f32x4 (&acc)[AM][AN][P], f32x4 *red, int tile_wave, int wk,
+                                         int lane) {
+#pragma unroll
+    for (int am = 0; am < AM; ++am)
+#pragma unroll
+        for (int an = 0; an < AN; ++an)
+#pragma unroll
+            for (int pp = 1; pp < P; ++pp) acc[am][an][0] += acc[am][an][pp];
+    if (WK > 1) {
+        // wk = 1 .. WK-1 park their tiles, wk = 0 adds them in wave order
+        if (wk > 0) {
+#pragma unroll
+            for (int am = 0; am < AM; ++am)
+#pragma unroll
+                for (int an = 0; an < AN; ++an)
+                    red[(((wk - 1) * NRED + tile_wave) * AM * AN + am * AN + an) * 64 + lane] =
+                        acc[am][an][0];
+        }
+        __syncthreads();
+        if (wk == 0) {
+            for (int s = 0; s < WK - 1; ++s)
+#pragma unroll
+                for (int am = 0; am < AM; ++am)
+#pragma unroll
+                    for (int an = 0; an < AN; ++an)
+                        acc[am][an][0] += red[((s * NRED + tile_wave) * AM * AN + am * AN + an) * 64 + lane];
+        }
+    }
+}
+
+// Chunk pipeline.  At B = 32 a workgroup walks only 7-18 chunks of 32 and nothing but
+// its own loads hides the ~0.7 us memory round trip; measured on MI355X, a barrier round
+// per chunk (LDS write -> barrier -> LDS read -> 4 MFMAs) costs ~0.35 us, far more than
+// the MFMAs in it.  So chunks move in STAGES of G: all loads of the next stage (G float4
+// per operand piece and thread) are in flight while the current stage computes out of
+// LDS, and a stage costs two barriers.  G = 4 for the small latency-bound tiles, 2 for the
+// large throughput tiles (LDS budget).  fetch(c, slot) issues the loads of chunk c,
+// stash(u, c, slot) parks a landed slot in LDS chunk buffer u, compute(u) runs the MFMAs
+// of the chunk in buffer u.  Chunk indices past the end are clamped (re-read, never
+// computed), which keeps the loads free of divergent branches.
+template <typename Slot, int G, typename Fetch, typename Stash, typename Compute>
+__device__ __forceinline__ void run_pipeline(int c0, int c1, Fetch fetch, Stash stash,
+                                             Compute compute) {
+    if (c0 >= c1) return;
+    Slot slot[G];
+#pragma unroll
+    for (int u = 0; u < G; ++u) fetch(min(c0 + u, c1 - 1), slot[u]);
+#pragma unroll
+    for (int u = 0; u < G; ++u) stash(u, min(c0 + u, c1 - 1), slot[u]);
+    __syncthreads();
+    for (int cb = c0; cb < c1; cb += G) {
+        const bool more = cb + G < c1;
+        if (more) {
+#pragma unroll
+            for (int u = 0; u < G; ++u) fetch(min(cb + G + u, c1 - 1), slot[u]);
+        }
+        const int nc = min(G, c1 - cb);
+#pragma unroll
+        for (int u = 0; u < G; ++u)
+            if (u < nc) compute(u);
+        __syncthreads();
+        if (more) {
+#pragma unroll
+            for (int u = 0; u < G; ++u) stash(u, min(cb + G + u, c1 - 1), slot[u]);
+            __syncthreads();
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// forward: y = act(conv(x, w) + b), also the split-K partial form for linear layers
+// ---------------------------------------------------------------------------------
+struct FwdArgs {
+    const float *x, *w, *bias;
+    float *y;
+    ConvGeom g;
+    int M, K, cps;
+    int relu, planar, partial;
+};
+
+template <int BM, int BN, int WM, int WN, int WK, int G>
+__global__ __launch_bounds__(256) void k_conv_fwd(FwdArgs p) {
+    static_assert(WM * WN * WK == 4, "four waves");
+    constexpr int AM = BM / (16 * WM), AN = BN / (16 * WN);
+    constexpr int P = (AM * AN == 1) ? 2 : 1;
+    constexpr int NPA = (BM * 8 + 255) / 256, NPB = (BN * 8 + 255) / 256;
+    __shared__ __attribute__((aligned(16))) float As[G][BM * LDR];
+    __shared__ __attribute__((aligned(16))) float Bs[G][BN * LDR];
+    __shared__ f32x4 red[WK > 1 ? (WK - 1) * WM * WN * AM * AN * 64 : 1];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wk = wave % WK, wn = (wave / WK) % WN, wm = wave / (WK * WN);
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const ConvGeom g = p.g;
+    const int ohow = g.OH * g.OW;
+    const int c0 = blockIdx.z * p.cps;
+    const int c1 = min(c0 + p.cps, p.K / KC);
+
+    struct Slot {
+        float4 a[NPA], b[NPB];
+    };
+    const float *ap[NPA], *bp[NPB];
+    bool aok[NPA], bok[NPB];
+#pragma unroll
+    for (int pp = 0; pp < NPA; ++pp) {
+        const int f = tid + 256 * pp, row = f >> 3, q = f & 7;
+        const int m = m0 + row;
+        const bool ok = row < BM && m < p.M;
+        const int mm = ok ? m : 0;
+        const int n = mm / ohow, rem = mm - n * ohow;
+        const int oh = rem / g.OW, ow = rem - oh * g.OW;
+        ap[pp] = p.x + ((size_t)(n * g.H + oh * g.ST) * g.W + ow * g.ST) * g.C + 4 * q;
+        aok[pp] = ok;
+    }
+#pragma unroll
+    for (int pp = 0; pp < NPB; ++pp) {
+        const int f = tid + 256 * pp, row = f >> 3, q = f & 7;
+        const int co = n0 + row;
+        const bool ok = row < BN && co < g.Cout;
+        bp[pp] = p.w + (size_t)(ok ? co : 0) * p.K + 4 * q;
+        bok[pp] = ok;
+    }
+    const int SC = g.S * g.C, WC = g.W * g.C;
+    auto fetch = [&](int c, Slot &sl) {
+        const int k0 = c * KC;
+        const int r = k0 / SC, o = k0 - r * SC;
+        const int ad = r * WC + o;
+#pragma unroll
+        for (int pp = 0; pp < NPA; ++pp) sl.a[pp] = ldg4(ap[pp] + ad);
+#pragma unroll
+        for (int pp = 0; pp < NPB; ++pp) sl.b[pp] = ldg4(bp[pp] + k0);
+    };
+    auto stash = [&](int buf, int, const Slot &sl) {
+#pragma unroll
+        for (int pp = 0; pp < NPA; ++pp) {
+            const int f = tid + 256 * pp, row = f >> 3, q = f & 7;
+            if (row < BM)
+                *reinterpret_cast<float4 *>(&As[buf][row * LDR + 4 * q]) = zero_unless(sl.a[pp], aok[pp]);
+        }
+#pragma unroll
+        for (int pp = 0; pp < NPB; ++pp) {
+            const int f = tid + 256 * pp, row = f >> 3, q = f & 7;
+            if (row < BN)
+                *reinterpret_cast<float4 *>(&Bs[buf][row * LDR + 4 * q]) = zero_unless(sl.b[pp], bok[pp]);
+        }
+    };
+
+    f32x4 acc[AM][AN][P];
+#pragma unroll
+    for (int am = 0; am < AM; ++am)
+#pragma unroll
+        for (int an = 0; an < AN; ++an)
+#pragma unroll
+            for (int pp = 0; pp < P; ++pp) acc[am][an][pp] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    auto compute = [&](int buf) {
+#pragma unroll
+        for (int sc = 0; sc < 2; ++sc)
+            if (sc % WK == wk)
+                mma_sub<AM, AN, P, true, true, LDR, LDR>(As[buf], Bs[buf], wm * 16 * AM, wn * 16 * AN,
+                                                          sc, lane, acc);
+    };
+    run_pipeline<Slot, G>(c0, c1, fetch, stash, compute);
+    fold_acc<AM, AN, P, WK, WM * WN>(acc, red, wm * WN + wn, wk, lane);
+    if (wk != 0) return;
+#pragma unroll
+    for (int am = 0; am < AM; ++am)
+#pragma unroll
+        for (int an = 0; an < AN; ++an) {
+            const int n = n0 + wn * 16 * AN + 16 * an + (lane & 15);
+            if (n >= g.Cout) continue;
+            const float bias = p.partial ? 0.f : p.bias[n];
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int m = m0 + wm * 16 * AM + 16 * am + 4 * (lane >> 4) + reg;
+                if (m >= p.M) continue;
+                float v = acc[am][an][0][reg];
+                if (p.partial) {
+                    p.y[((size_t)blockIdx.z * p.M + m) * g.Cout + n] = v;
+                    continue;
+                }
+                v = v + bias;
+                if (p.relu) v = fmaxf(v, 0.f);
+                if (p.planar) {
+                    const int img = m / ohow, pix = m - img * ohow;
+                    p.y[((size_t)img * g.Cout + n) * ohow + pix] = v;
+                } else {
+                    p.y[(size_t)m * g.Cout + n] = v;
+                }
+            }
+        }
+}
+
+// ---------------------------------------------------------------------------------
+// dgrad: gradient w.r.t. the layer input, masked by the ReLU of the layer below
+// ---------------------------------------------------------------------------------
+struct DgradArgs {
+    const float *dy, *dymask, *w, *aprev;
+    float *dx;
+    ConvGeom g;          // forward geometry (H, W = input extents)
+    int AH, AW, Mc;      // rows per parity class: n x AH x AW, AH = H / ST
+    int TH, TW, K;       // taps per class and dimension; K = TH * TW * Cout
+    int permP, permC;    // dx written as [n][p][c] for c*P + p (planar -> NHWC), 0 = off
+};
+
+template <int BM, int BN, int WM, int WN, int WK, int G>
+__global__ __launch_bounds__(256) void k_conv_dgrad(DgradArgs p) {
+    static_assert(WM * WN * WK == 4, "four waves");
+    constexpr int AM = BM / (16 * WM), AN = BN / (16 * WN);
+    constexpr int P = (AM * AN == 1) ? 2 : 1;
+    constexpr int NPA = (BM * 8 + 255) / 256;
+    constexpr int QPR = BN / 4, NPB = (32 * QPR + 255) / 256, LDB = BN + 4;
+    __shared__ __attribute__((aligned(16))) float As[G][BM * LDR];
+    __shared__ __attribute__((aligned(16))) float Bs[G][32 * LDB];
+    __shared__ f32x4 red[WK > 1 ? (WK - 1) * WM * WN * AM * AN * 64 : 1];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wk = wave % WK, wn = (wave / WK) % WN, wm = wave / (WK * WN);
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const ConvGeom g = p.g;
+    const int ph = blockIdx.z / g.ST, pw = blockIdx.z - ph * g.ST;
+    const int ahw = p.AH * p.AW;
+
+    int rn[NPA], rah[NPA], raw[NPA];
+    bool aok[NPA];
+#pragma unroll
+    for (int pp = 0; pp < NPA; ++pp) {
+        const int f = tid + 256 * pp, row = f >> 3;
+        const int m = m0 + row;
+        const bool ok = row < BM && m < p.Mc;
+        const int mm = ok ? m : 0;
+        rn[pp] = mm / ahw;
+        const int rem = mm - rn[pp] * ahw;
+        rah[pp] = rem / p.AW;
+        raw[pp] = rem - rah[pp] * p.AW;
+        aok[pp] = ok;
+    }
+    struct Slot {
+        float4 a[NPA], h[NPA], b[NPB];
+    };
+    const bool has_mask = p.dymask != nullptr;
+    // validity and address of this thread's A piece for chunk c (depends on the tap)
+    auto a_addr = [&](int c, int pp, bool &ok) -> size_t {
+        const int k0 = c * KC;
+        const int tap = k0 / g.Cout, co0 = k0 - tap * g.Cout;
+        const int tb = tap / p.TW, tb2 = tap - tb * p.TW;
+        const int q = (tid + 256 * pp) & 7;
+        const int oh = rah[pp] - tb, ow = raw[pp] - tb2;
+        ok = aok[pp] && oh >= 0 && oh < g.OH && ow >= 0 && ow < g.OW;
+        return ok ? ((size_t)(rn[pp] * g.OH + oh) * g.OW + ow) * g.Cout + co0 + 4 * q : (size_t)0;
+    };
+    auto fetch = [&](int c, Slot &sl) {
+        const int k0 = c * KC;
+        const int tap = k0 / g.Cout, co0 = k0 - tap * g.Cout;
+        const int tb = tap / p.TW, tb2 = tap - tb * p.TW;
+#pragma unroll
+        for (int pp = 0; pp < NPA; ++pp) {
+            bool ok;
+            const size_t off = a_addr(c, pp, ok);
+            sl.a[pp] = ldg4(p.dy + off);
+            if (has_mask) sl.h[pp] = ldg4(p.dymask + off);
+        }
+        const int r = tb * g.ST + ph, s = tb2 * g.ST + pw;
+#pragma unroll
+        for (int pp = 0; pp < NPB; ++pp) {
+            const int f = tid + 256 * pp, kk = f / QPR, q = f - kk * QPR;
+            const int co = co0 + (kk < 32 ? kk : 0);
+            sl.b[pp] = ldg4(p.w + ((size_t)(co * g.R + r) * g.S + s) * g.C + n0 + 4 * q);
+        }
+    };
+    auto stash = [&](int buf, int c, const Slot &sl) {
+#pragma unroll
+        for (int pp = 0; pp < NPA; ++pp) {
+            const int f = tid + 256 * pp, row = f >> 3, q = f & 7;
+            bool ok;
+            a_addr(c, pp, ok);
+            float4 v = zero_unless(sl.a[pp], ok);
+            if (has_mask) v = relu_mask(v, sl.h[pp]);
+            if (row < BM) *reinterpret_cast<float4 *>(&As[buf][row * LDR + 4 * q]) = v;
+        }
+#pragma unroll
+        for (int pp = 0; pp < NPB; ++pp) {
+            const int f = tid + 256 * pp, kk = f / QPR, q = f - kk * QPR;
+            if (kk < 32) *reinterpret_cast<float4 *>(&Bs[buf][kk * LDB + 4 * q]) = sl.b[pp];
+        }
+    };
+
+    f32x4 acc[AM][AN][P];
+#pragma unroll
+    for (int am = 0; am < AM; ++am)
+#pragma unroll
+        for (int an = 0; an < AN; ++an)
+#pragma unroll
+            for (int pp = 0; pp < P; ++pp) acc[am][an][pp] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    auto compute = [&](int buf) {
+#pragma unroll
+        for (int sc = 0; sc < 2; ++sc)
+            if (sc % WK == wk)
+                mma_sub<AM, AN, P, true, false, LDR, LDB>(As[buf], Bs[buf], wm * 16 * AM, wn * 16 * AN,
+                                                           sc, lane, acc);
+    };
+    run_pipeline<Slot, G>(0, p.K / KC, fetch, stash, compute);
+    fold_acc<AM, AN, P, WK, WM * WN>(acc, red, wm * WN + wn, wk, lane);
+    if (wk != 0) return;
+#pragma unroll
+    for (int am = 0; am < AM; ++am)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int m = m0 + wm * 16 * AM + 16 * am + 4 * (lane >> 4) + reg;
+            if (m >= p.Mc) continue;
+            const int n = m / ahw, rem = m - n * ahw;
+            const int a = rem / p.AW, a2 = rem - a * p.AW;
+            const int ih = a * g.ST + ph, iw = a2 * g.ST + pw;
+            const size_t base = ((size_t)(n * g.H + ih) * g.W + iw) * g.C;
+#pragma unroll
+            for (int an = 0; an < AN; ++an) {
+                const int ci = n0 + wn * 16 * AN + 16 * an + (lane & 15);
+                if (ci >= g.C) continue;
+                float v = acc[am][an][0][reg];
+                if (p.aprev != nullptr) v = p.aprev[base + ci] > 0.f ? v : 0.f;
+                size_t o = base + ci;
+                if (p.permP > 0) {
+                    const int c = ci / p.permP, px = ci - c * p.permP;
+                    o = base + (size_t)px * p.permC + c;
+                }
+                p.dx[o] = v;
+            }
+        }
+}
+
+// ---------------------------------------------------------------------------------
+// wgrad: dw[co][k] and db[co], reduction over m split across grid.z
+// ---------------------------------------------------------------------------------
+struct WgradArgs {
+    const float *dy, *dymask, *x;
+    float *dw, *db;
+    long long dw_stride, db_stride;   // between the partials of consecutive splits
+    ConvGeom g;
+    int M, K, cps;
+};
+
+template <int BI, int BJ, int WM, int WN, int WK, int G>
+__global__ __launch_bounds__(256) void k_conv_wgrad(WgradArgs p) {
+    static_assert(WM * WN * WK == 4, "four waves");
+    constexpr int AM = BI / (16 * WM), AN = BJ / (16 * WN);
+    constexpr int P = (AM * AN == 1) ? 2 : 1;
+    constexpr int QA = BI / 4, NPA = (32 * QA + 255) / 256, LDA = BI + 4;
+    constexpr int QB = BJ / 4, NPB = (32 * QB + 255) / 256, LDB = BJ + 4;
+    __shared__ __attribute__((aligned(16))) float As[G][32 * LDA];
+    __shared__ __attribute__((aligned(16))) float Bs[G][32 * LDB];
+    __shared__ f32x4 red[WK > 1 ? (WK - 1) * WM * WN * AM * AN * 64 : 1];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wk = wave % WK, wn = (wave / WK) % WN, wm = wave / (WK * WN);
+    const int i0 = blockIdx.x * BI, j0 = blockIdx.y * BJ;
+    const ConvGeom g = p.g;
+    const int ohow = g.OH * g.OW, SC = g.S * g.C, WC = g.W * g.C;
+    const int nch_total = (p.M + KC - 1) / KC;
+    const int c0 = blockIdx.z * p.cps;
+    const int c1 = min(c0 + p.cps, nch_total);
+
+    int bkk[NPB], bcol[NPB], bq[NPB];
+#pragma unroll
+    for (int pp = 0; pp < NPB; ++pp) {
+        const int f = tid + 256 * pp;
+        bkk[pp] = f / QB;
+        bq[pp] = f - bkk[pp] * QB;
+        const int j = j0 + 4 * bq[pp];
+        const int r = j / SC;
+        bcol[pp] = r * WC + (j - r * SC);
+    }
+    struct Slot {
+        float4 a[NPA], h[NPA], b[NPB];
+    };
+    const bool has_mask = p.dymask != nullptr;
+    auto fetch = [&](int c, Slot &sl) {
+        const int mbase = c * KC;
+#pragma unroll
+        for (int pp = 0; pp < NPA; ++pp) {
+            const int f = tid + 256 * pp, kk = f / QA, q = f - kk * QA;
+            const int m = mbase + kk;
+            const bool ok = kk < 32 && m < p.M && i0 + 4 * q < g.Cout;
+            const size_t off = ok ? (size_t)m * g.Cout + i0 + 4 * q : (size_t)0;
+            sl.a[pp] = ldg4(p.dy + off);
+            if (has_mask) sl.h[pp] = ldg4(p.dymask + off);
+        }
+#pragma unroll
+        for (int pp = 0; pp < NPB; ++pp) {
+            const int m = mbase + bkk[pp];
+            const bool ok = bkk[pp] < 32 && m < p.M;
+            const int mm = ok ? m : 0;
+            const int n = mm / ohow, rem = mm - n * ohow;
+            const int oh = rem / g.OW, ow = rem - oh * g.OW;
+            sl.b[pp] = ldg4(p.x + ((size_t)(n * g.H + oh * g.ST) * g.W + ow * g.ST) * g.C + bcol[pp]);
+        }
+    };
+    auto stash = [&](int buf, int c, const Slot &sl) {
+        const int mbase = c * KC;
+#pragma unroll
+        for (int pp = 0; pp < NPA; ++pp) {
+            const int f = tid + 256 * pp, kk = f / QA, q = f - kk * QA;
+            const bool ok = kk < 32 && mbase + kk < p.M && i0 + 4 * q < g.Cout;
+            float4 v = zero_unless(sl.a[pp], ok);
+            if (has_mask) v = relu_mask(v, sl.h[pp]);
+            if (kk < 32) *reinterpret_cast<float4 *>(&As[buf][kk * LDA + 4 * q]) = v;
+        }
+#pragma unroll
+        for (int pp = 0; pp < NPB; ++pp) {
+            const bool ok = bkk[pp] < 32 && mbase + bkk[pp] < p.M;
+            if (bkk[pp] < 32)
+                *reinterpret_cast<float4 *>(&Bs[buf][bkk[pp] * LDB + 4 * bq[pp]]) = zero_unless(sl.b[pp], ok);
+        }
+    };
+
+    f32x4 acc[AM][AN][P];
+#pragma unroll
+    for (int am = 0; am < AM; ++am)
+#pragma unroll
+        for (int an = 0; an < AN; ++an)
+#pragma unroll
+            for (int pp = 0; pp < P; ++pp) acc[am][an][pp] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float bsum = 0.f;
+    const bool do_bias = blockIdx.y == 0 && p.db != nullptr;
+
+    auto compute = [&](int buf) {
+#pragma unroll
+        for (int sc = 0; sc < 2; ++sc)
+            if (sc % WK == wk)
+                mma_sub<AM, AN, P, false, false, LDA, LDB>(As[buf], Bs[buf], wm * 16 * AM, wn * 16 * AN,
+                                                            sc, lane, acc);
+        if (do_bias && tid < BI) {
+#pragma unroll 8
+            for (int kk = 0; kk < 32; ++kk) bsum += As[buf][kk * LDA + tid];
+        }
+    };
+    run_pipeline<Slot, G>(c0, c1, fetch, stash, compute);
+    if (do_bias && tid < BI && i0 + tid < g.Cout)
+        p.db[(size_t)blockIdx.z * p.db_stride + i0 + tid] = bsum;
+    fold_acc<AM, AN, P, WK, WM * WN>(acc, red, wm * WN + wn, wk, lane);
+    if (wk != 0) return;
+    float *dw = p.dw + (size_t)blockIdx.z * p.dw_stride;
+#pragma unroll
+    for (int am = 0; am < AM; ++am)
+#pragma unroll
+        for (int an = 0; an < AN; ++an) {
+            const int j = j0 + wn * 16 * AN + 16 * an + (lane & 15);
+            if (j >= p.K) continue;
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int co = i0 + wm * 16 * AM + 16 * am + 4 * (lane >> 4) + reg;
+                if (co < g.Cout) dw[(size_t)co * p.K + j] = acc[am][an][0][reg];
+            }
+        }
+}
+
+// ---------------------------------------------------------------------------------
+// split-K fold: out[e] = act(sum_s part[s][e] + bias[e % ncol]), several tensors per launch
+// ---------------------------------------------------------------------------------
+constexpr int RED_MAX = 12;
+constexpr int RED_CHUNK = 1024;
+
+struct RedArgs {
+    const float *part[RED_MAX];
+    float *out[RED_MAX];
+    const float *bias[RED_MAX];
+    long long stride[RED_MAX];
+    int n[RED_MAX], splits[RED_MAX], ncol[RED_MAX], relu[RED_MAX];
+    int block_end[RED_MAX];
+    int ntask;
+};
+
+__global__ __launch_bounds__(256) void k_splitk_reduce(RedArgs a) {
+    int t = 0;
+    const int b = blockIdx.x;
+    while (t < a.ntask - 1 && b >= a.block_end[t]) ++t;
+    const int first = t == 0 ? 0 : a.block_end[t - 1];
+    const int e = (b - first) * RED_CHUNK + threadIdx.x * 4;
+    const int n = a.n[t];
+    if (e >= n) return;
+    const float *part = a.part[t];
+    const long long stride = a.stride[t];
+    const int S = a.splits[t];
+    if (e + 4 <= n) {
+        // 8 partial slabs in flight per thread: the slabs were written by the previous
+        // launch and come from memory, one round trip each if read one after the other
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        int k = 0;
+        for (; k + 8 <= S; k += 8) {
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                v[u] = *reinterpret_cast<const float4 *>(part + (long long)(k + u) * stride + e);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w;
+            }
+        }
+        {
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                v[u] = *reinterpret_cast<const float4 *>(part + (long long)min(k + u, S - 1) * stride + e);
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (k + u < S) {
+                    s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w;
+                }
+        }
+        if (a.bias[t] != nullptr) {
+            const int col = e % a.ncol[t];   // ncol % 4 == 0: the four lanes stay in one row
+            const float4 bb = *reinterpret_cast<const float4 *>(a.bias[t] + col);
+            s.x += bb.x; s.y += bb.y; s.z += bb.z; s.w += bb.w;
+        }
+        if (a.relu[t]) {
+            s.x = fmaxf(s.x, 0.f); s.y = fmaxf(s.y, 0.f); s.z = fmaxf(s.z, 0.f); s.w = fmaxf(s.w, 0.f);
+        }
+        *reinterpret_cast<float4 *>(a.out[t] + e) = s;
+    } else {
+        for (int u = e; u < n; ++u) {
+            float s = part[u];
+            for (int k = 1; k < S; ++k) s += part[k * stride + u];
+            if (a.bias[t] != nullptr) s += a.bias[t][u % a.ncol[t]];
+            if (a.relu[t]) s = fmaxf(s, 0.f);
+            a.out[t][u] = s;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// narrow linear head (out_features <= 16), e.g. Linear(512, n_actions)
+// ---------------------------------------------------------------------------------
+constexpr int SMALL_N = 16;
+
+// y[m][n] = sum_k x[m][k] w[n][k] + b[n]; one workgroup per row, every load of a pass
+// (4 k per thread: 4 of x, 4 N of w) issued before the first use
+template <int N>
+__global__ __launch_bounds__(256) void k_linear_small_fwd(const float *__restrict__ x,
+                                                          const float *__restrict__ w,
+                                                          const float *__restrict__ bias,
+                                                          float *__restrict__ y, int K) {
+    __shared__ float part[4][N];
+    const int m = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float acc[N];
+#pragma unroll
+    for (int n = 0; n < N; ++n) acc[n] = 0.f;
+    for (int k0 = 0; k0 < K; k0 += 1024) {
+        float xv[4], wv[N][4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int k = k0 + tid + 256 * u;
+            const int kk = k < K ? k : K - 1;
+            xv[u] = x[(size_t)m * K + kk];
+#pragma unroll
+            for (int n = 0; n < N; ++n) wv[n][u] = w[(size_t)n * K + kk];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float xs = (k0 + tid + 256 * u) < K ? xv[u] : 0.f;
+#pragma unroll
+            for (int n = 0; n < N; ++n) acc[n] = fmaf(xs, wv[n][u], acc[n]);
+        }
+    }
+#pragma unroll
+    for (int n = 0; n < N; ++n) {
+        float v = acc[n];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        if (lane == 0) part[wave][n] = v;
+    }
+    __syncthreads();
+    if (tid < N) {
+        float v = ((part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]));
+        if (bias != nullptr) v += bias[tid];
+        y[(size_t)m * N + tid] = v;
+    }
+}
+
+// dx[m][k] = sum_n dy[m][n] w[n][k];  dw[n][k] = sum_m dy[m][n] x[m][k];  db[n] = sum_m dy[m][n]
+// grid (K / 256, 1 + M / 8): row y = 0 of the grid owns dw / db (one k column per thread, x
+// read 8 rows at a time, loads first), rows y >= 1 own dx for 8 batch rows each.
+template <int N>
+__global__ __launch_bounds__(256) void k_linear_small_bwd(const float *__restrict__ dy,
+                                                          const float *__restrict__ x,
+                                                          const float *__restrict__ w,
+                                                          float *__restrict__ dx, float *__restrict__ dw,
+                                                          float *__restrict__ db, int M, int K) {
+    extern __shared__ float sdy[];   // [M][N]
+    const int tid = threadIdx.x;
+    for (int e = tid; e < M * N; e += 256) sdy[e] = dy[e];
+    __syncthreads();
+    const int k = blockIdx.x * 256 + tid;
+    const bool valid = k < K;
+    const int kk = valid ? k : K - 1;
+    if (blockIdx.y == 0) {
+        if (blockIdx.x == 0 && tid < N && db != nullptr) {
+            float s = 0.f;
+            for (int m = 0; m < M; ++m) s += sdy[m * N + tid];
+            db[tid] = s;
+        }
+        float gw[N];
+#pragma unroll
+        for (int n = 0; n < N; ++n) gw[n] = 0.f;
+        for (int m0 = 0; m0 < M; m0 += 8) {
+            float xv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) xv[u] = x[(size_t)min(m0 + u, M - 1) * K + kk];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (m0 + u < M) {
+#pragma unroll
+                    for (int n = 0; n < N; ++n) gw[n] = fmaf(sdy[(m0 + u) * N + n], xv[u], gw[n]);
+                }
+        }
+        if (valid) {
+#pragma unroll
+            for (int n = 0; n < N; ++n) dw[(size_t)n * K + k] = gw[n];
+        }
+    } else {
+        float wk[N];
+#pragma unroll
+        for (int n = 0; n < N; ++n) wk[n] = w[(size_t)n * K + kk];
+        const int m0 = (blockIdx.y - 1) * 8;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int m = m0 + u;
+            if (m < M && valid) {
+                float g = 0.f;
+#pragma unroll
+                for (int n = 0; n < N; ++n) g = fmaf(sdy[m * N + n], wk[n], g);
+                dx[(size_t)m * K + k] = g;
+            }
+        }
+    }
+}
+
+bool geom_ok(const ConvGeom &g) {
+    return g.N > 0 && g.C > 0 && g.Cout > 0 && g.R > 0 && g.S > 0 && g.ST > 0 &&
+           g.H >= g.R && g.W >= g.S && g.OH == (g.H - g.R) / g.ST + 1 &&
+           g.OW == (g.W - g.S) / g.ST + 1 && (g.S * g.C) % KC == 0 && g.C % 4 == 0;
+}
+
+}  // namespace
+
+// ===================================================================================
+// C ABI
+// ===================================================================================
+
+extern "C" int pfrl_conv2d_nhwc_fwd(const float *x, const float *w, const float *bias, float *y,
+                                    int32_t N, int32_t H, int32_t W, int32_t C, int32_t Cout, int32_t R,
+                                    int32_t S, int32_t stride, int32_t relu, int32_t planar_out,
+                                    int32_t splits, void *stream) {
+    ConvGeom g{N, H, W, C, Cout, R, S, stride, (H - R) / stride + 1, (W - S) / stride + 1};
+    PFRL_CHECK_ARG(geom_ok(g), "pfrl_conv2d_nhwc_fwd: unsupported geometry (need S*C % 32 == 0)");
+    PFRL_CHECK_ARG(splits >= 1, "pfrl_conv2d_nhwc_fwd: splits >= 1");
+    FwdArgs a;
+    a.x = x; a.w = w; a.bias = bias; a.y = y; a.g = g;
+    a.M = N * g.OH * g.OW;
+    a.K = R * S * C;
+    const int nch = a.K / KC;
+    a.cps = (nch + splits - 1) / splits;
+    a.relu = relu; a.planar = planar_out; a.partial = splits > 1;
+    PFRL_CHECK_ARG(a.partial || bias != nullptr, "pfrl_conv2d_nhwc_fwd: bias required");
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned z = (unsigned)splits;
+    auto blocks = [&](int bm, int bn) { return (long long)((a.M + bm - 1) / bm) * ((Cout + bn - 1) / bn) * z; };
+#define FWD(BM, BN, WM, WN, WK, G)                                                                   \
+    hipLaunchKernelGGL((k_conv_fwd<BM, BN, WM, WN, WK, G>),                                          \
+                       dim3((a.M + BM - 1) / BM, (Cout + BN - 1) / BN, z), dim3(256), 0, st, a)
+    if (Cout % 32 != 0) {
+        // narrow outputs (16 channels)
+        if (blocks(64, 16) >= 512) FWD(64, 16, 4, 1, 1, 2);
+        else FWD(32, 16, 2, 1, 2, 4);
+    } else if (Cout % 64 == 0 && blocks(64, 64) >= 1024) {
+        FWD(64, 64, 2, 2, 1, 2);
+    } else if (blocks(64, 32) >= 1024) {
+        FWD(64, 32, 2, 2, 1, 2);
+    } else if (blocks(32, 32) >= 384) {
+        FWD(32, 32, 2, 2, 1, 4);
+    } else if (a.cps >= 12) {
+        FWD(16, 32, 1, 2, 2, 8);   // few workgroups, long reduction: stages of 8 chunks
+    } else {
+        FWD(16, 32, 1, 2, 2, 4);
+    }
+#undef FWD
+    PFRL_LAUNCH_CHECK();
+}
+
+extern "C" int pfrl_conv2d_nhwc_bwd_data(const float *dy, const float *dy_mask, const float *w,
+                                         const float *a_prev, float *dx, int32_t N, int32_t H, int32_t W,
+                                         int32_t C, int32_t Cout, int32_t R, int32_t S, int32_t stride,
+                                         int32_t perm_p, int32_t perm_c, void *stream) {
+    ConvGeom g{N, H, W, C, Cout, R, S, stride, (H - R) / stride + 1, (W - S) / stride + 1};
+    PFRL_CHECK_ARG(g.OH >= 1 && g.OW >= 1 && Cout % KC == 0 && C % 16 == 0 && R % stride == 0 &&
+                       S % stride == 0 && H % stride == 0 && W % stride == 0,
+                   "pfrl_conv2d_nhwc_bwd_data: unsupported geometry");
+    PFRL_CHECK_ARG(perm_p == 0 || (H == 1 && W == 1 && perm_p * perm_c == C),
+                   "pfrl_conv2d_nhwc_bwd_data: bad permutation");
+    DgradArgs a;
+    a.dy = dy; a.dymask = dy_mask; a.w = w; a.aprev = a_prev; a.dx = dx; a.g = g;
+    a.AH = H / stride; a.AW = W / stride;
+    a.Mc = N * a.AH * a.AW;
+    a.TH = R / stride; a.TW = S / stride;
+    a.K = a.TH * a.TW * Cout;
+    a.permP = perm_p; a.permC = perm_c;
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned z = (unsigned)(stride * stride);
+    auto blocks = [&](int bm, int bn) { return (long long)((a.Mc + bm - 1) / bm) * (C / bn) * z; };
+#define DG(BM, BN, WM, WN, WK, G)                                                                    \
+    hipLaunchKernelGGL((k_conv_dgrad<BM, BN, WM, WN, WK, G>), dim3((a.Mc + BM - 1) / BM, C / BN, z), \
+                       dim3(256), 0, st, a)
+    if (C % 32 != 0) {
+        DG(32, 16, 2, 1, 2, 4);
+    } else if (C % 64 == 0 && blocks(64, 64) >= 1024) {
+        DG(64, 64, 2, 2, 1, 2);
+    } else if (blocks(64, 32) >= 1024) {
+        DG(64, 32, 2, 2, 1, 2);
+    } else if (blocks(32, 32) >= 384) {
+        DG(32, 32, 2, 2, 1, 4);
+    } else if (a.K / KC >= 12) {
+        // 32 input channels per workgroup: whole 128 B lines of the weight rows
+        DG(16, 32, 1, 2, 2, 8);
+    } else {
+        DG(16, 32, 1, 2, 2, 4);
+    }
+#undef DG
+    PFRL_LAUNCH_CHECK();
+}
+
+extern "C" int pfrl_conv2d_nhwc_bwd_weight(const float *dy, const float *dy_mask, const float *x,
+                                           float *dw_part, float *db_part, int64_t dw_stride,
+                                           int64_t db_stride, int32_t N, int32_t H, int32_t W, int32_t C,
+                                           int32_t Cout, int32_t R, int32_t S, int32_t stride,
+                                           int32_t splits, void *stream) {
+    ConvGeom g{N, H, W, C, Cout, R, S, stride, (H - R) / stride + 1, (W - S) / stride + 1};
+    PFRL_CHECK_ARG(geom_ok(g) && Cout % 16 == 0, "pfrl_conv2d_nhwc_bwd_weight: unsupported geometry");
+    PFRL_CHECK_ARG(splits >= 1, "pfrl_conv2d_nhwc_bwd_weight: splits >= 1");
+    WgradArgs a;
+    a.dy = dy; a.dymask = dy_mask; a.x = x; a.dw = dw_part; a.db = db_part;
+    a.dw_stride = dw_stride; a.db_stride = db_stride; a.g = g;
+    a.M = N * g.OH * g.OW;
+    a.K = R * S * C;
+    const int nch = (a.M + KC - 1) / KC;
+    a.cps = (nch + splits - 1) / splits;
+    hipStream_t st = (hipStream_t)stream;
+    if (Cout % 32 == 0)
+        hipLaunchKernelGGL((k_conv_wgrad<32, 32, 2, 2, 1, 4>), dim3(Cout / 32, a.K / 32, splits), dim3(256),
+                           0, st, a);
+    else
+        hipLaunchKernelGGL((k_conv_wgrad<16, 32, 1, 2, 2, 4>), dim3(Cout / 16, a.K / 32, splits), dim3(256),
+                           0, st, a);
+    PFRL_LAUNCH_CHECK();
+}
+
+extern "C" int pfrl_splitk_reduce(int32_t n_tasks, const float *const *host_part, float *const *host_out,
+                                  const float *const *host_bias, const int64_t *host_stride,
+                                  const int32_t *host_n, const int32_t *host_splits,
+                                  const int32_t *host_ncol, const int32_t *host_relu, void *stream) {
+    PFRL_CHECK_ARG(n_tasks >= 0 && n_tasks <= RED_MAX, "pfrl_splitk_reduce: too many tensors");
+    if (n_tasks == 0) return 0;
+    RedArgs a;
+    int blocks = 0;
+    for (int t = 0; t < n_tasks; ++t) {
+        a.part[t] = host_part[t];
+        a.out[t] = host_out[t];
+        a.bias[t] = host_bias ? host_bias[t] : nullptr;
+        a.stride[t] = host_stride[t];
+        a.n[t] = host_n[t];
+        a.splits[t] = host_splits[t];
+        a.ncol[t] = host_ncol ? host_ncol[t] : 4;
+        a.relu[t] = host_relu ? host_relu[t] : 0;
+        PFRL_CHECK_ARG(a.bias[t] == nullptr || a.ncol[t] % 4 == 0, "pfrl_splitk_reduce: ncol % 4");
+        PFRL_CHECK_ARG(a.stride[t] % 4 == 0, "pfrl_splitk_reduce: stride % 4");
+        blocks += (host_n[t] + RED_CHUNK - 1) / RED_CHUNK;
+        a.block_end[t] = blocks;
+    }
+    a.ntask = n_tasks;
+    if (blocks == 0) return 0;
+    hipLaunchKernelGGL(k_splitk_reduce, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+    PFRL_LAUNCH_CHECK();
+}
+
+#define SMALL_DISPATCH(N, CALL)                                            \
+    switch (N) {                                                           \
+        case 1: CALL(1); break;   case 2: CALL(2); break;   case 3: CALL(3); break;   \
+        case 4: CALL(4); break;   case 5: CALL(5); break;   case 6: CALL(6); break;   \
+        case 7: CALL(7); break;   case 8: CALL(8); break;   case 9: CALL(9); break;   \
+        case 10: CALL(10); break; case 11: CALL(11); break; case 12: CALL(12); break; \
+        case 13: CALL(13); break; case 14: CALL(14); break; case 15: CALL(15); break; \
+        default: CALL(16); break;                                          \
+    }
+
+extern "C" int pfrl_linear_small_fwd(const float *x, const float *w, const float *bias, float *y,
+                                     int32_t M, int32_t K, int32_t N, void *stream) {
+    PFRL_CHECK_ARG(N >= 1 && N <= SMALL_N && M >= 1 && K >= 1, "pfrl_linear_small_fwd: N <= 16");
+#define CALL_FWD(NN)                                                                              \
+    hipLaunchKernelGGL(k_linear_small_fwd<NN>, dim3(M), dim3(256), 0, (hipStream_t)stream, x, w, \
+                       bias, y, K)
+    SMALL_DISPATCH(N, CALL_FWD)
+#undef CALL_FWD
+    PFRL_LAUNCH_CHECK();
+}
+
+extern "C" int pfrl_linear_small_bwd(const float *dy, const float *x, const float *w, float *dx,
+                                     float *dw, float *db, int32_t M, int32_t K, int32_t N,
+                                     void *stream) {
+    PFRL_CHECK_ARG(N >= 1 && N <= SMALL_N && M >= 1 && K >= 1 && (size_t)M * N * 4 <= 48 * 1024,
+                   "pfrl_linear_small_bwd: N <= 16, M * N <= 12288");
+    const dim3 grid((K + 255) / 256, dx != nullptr ? 1 + (M + 7) / 8 : 1);
+#define CALL_BWD(NN)                                                                              \
+    hipLaunchKernelGGL(k_linear_small_bwd<NN>, grid, dim3(256), (size_t)M * N * sizeof(float),   \
+                       (hipStream_t)stream, dy, x, w, dx, dw, db, M, K)
+    SMALL_DISPATCH(N, CALL_BWD)
+#undef CALL_BWD
+    PFRL_LAUNCH_CHECK();
+}

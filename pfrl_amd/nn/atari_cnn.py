@@ -1,6 +1,8 @@
 """Nature-DQN convolutional trunks (reference pfrl/nn/atari_cnn.py:17-80).
-These are the MFMA part of the workload and stay stock PyTorch-ROCm
-(MIOpen conv + hipBLASLt GEMM)."""
+On the GPU with channels_last weights and ReLU the trunk runs as the hand-written f32
+MFMA kernels of csrc/qnet.hip (pfrl_amd/nn/mfma_trunk.py); any other configuration
+takes stock PyTorch-ROCm (MIOpen conv + hipBLASLt GEMM) with the fused bias + ReLU
+launches below."""
 import os
 
 import torch
@@ -127,6 +129,14 @@ class _AtariCNN(nn.Module):
         self.apply(constant_bias_initializer(bias=bias))
 
     def forward(self, state):
+        if _is_relu(self.activation) and state.is_cuda:
+            # the whole trunk as hand-written MFMA kernels (one autograd node) when the
+            # shapes are inside what csrc/qnet.hip covers; stock route otherwise
+            from pfrl_amd.nn import mfma_trunk
+
+            specs = mfma_trunk.plan_for(self.layers, self.output, state)
+            if specs is not None:
+                return mfma_trunk.trunk_forward(state, specs, list(self.layers), self.output)
         h = state
         last = len(self.layers) - 1
         for i, layer in enumerate(self.layers):

@@ -1,0 +1,386 @@
+"""Conv trunk + hidden linear layer of the example Q-networks as hand-written gfx950
+kernels (``csrc/qnet.hip``): ``activation(layer(h))`` of ``pfrl/nn/atari_cnn.py:40-47``
+and of the ``nn.Sequential`` in ``examples/atari/train_ppo_ale.py:247-264``, forward and
+backward, for ReLU networks whose convolutions keep channels_last weights.
+
+Why: at the minibatch of the replay agents (B = 32, ``pfrl/agents/dqn.py:316-365``, 64
+dependent updates per batched env step) the MIOpen / hipBLASLt route is ~33 launches of
+5-17 us per update, each with <1 us of work.  Here one update's network part is 5
+forward and 8 backward launches: implicit-GEMM f32 MFMA kernels with bias + ReLU (forward)
+and ReLU mask (backward) in the epilogues, split-K partials folded by one multi-tensor
+launch, no zero-fill helpers, no layout copies.
+
+Numerics: f32 in, f32 accumulate (``v_mfma_f32_16x16x4_f32`` is an exact fmaf chain);
+only the summation order differs from MIOpen's.
+
+The whole trunk is ONE autograd node, so every intermediate layout is private: the last
+convolution's output is written planar (NCHW) because the linear layer's weight columns
+are in that order, and the linear layer's input gradient is written back as NHWC rows for
+the convolution backward.  There is no fallback inside: ``supported()`` decides up
+front, and unsupported shapes take the stock PyTorch route.
+"""
+import ctypes
+import os
+
+import torch
+import torch.nn as nn
+
+from pfrl_amd import _native
+from pfrl_amd._native import check
+
+_ENABLED = os.environ.get("PFRL_MFMA_TRUNK", "1") != "0"
+# batches above this keep the library kernels (0 = no limit)
+_MAX_BATCH = int(os.environ.get("PFRL_MFMA_TRUNK_MAX_BATCH", "0"))
+SMALL_LINEAR_MAX_OUT = 16
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _ceil_div(a, b):
+    return -(-a // b)
+
+
+def _is_relu(act):
+    import torch.nn.functional as F
+
+    return act is F.relu or act is torch.relu or isinstance(act, nn.ReLU)
+
+
+class ConvSpec:
+    """Geometry of one convolution of the trunk (forward view)."""
+
+    __slots__ = ("C", "Cout", "R", "S", "ST", "H", "W", "OH", "OW")
+
+    def __init__(self, conv, H, W):
+        self.C, self.Cout = conv.in_channels, conv.out_channels
+        self.R, self.S = conv.kernel_size
+        self.ST = conv.stride[0]
+        self.H, self.W = H, W
+        self.OH = (H - self.R) // self.ST + 1
+        self.OW = (W - self.S) // self.ST + 1
+
+
+def _conv_ok(conv):
+    return (isinstance(conv, nn.Conv2d) and conv.bias is not None and conv.groups == 1
+            and conv.padding == (0, 0) and conv.dilation == (1, 1) and conv.padding_mode == "zeros"
+            and conv.stride[0] == conv.stride[1] and conv.weight.dtype == torch.float32
+            and conv.weight.is_cuda
+            and conv.weight.is_contiguous(memory_format=torch.channels_last)
+            and (conv.kernel_size[1] * conv.in_channels) % 32 == 0 and conv.in_channels % 4 == 0
+            and conv.out_channels % 16 == 0)
+
+
+def plan_for(convs, linear, x):
+    """ConvSpec list if (convs..., flatten, linear) on input ``x`` [N, C, H, W] is inside what
+    the kernels cover, else None."""
+    if not (_ENABLED and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4
+            and not x.requires_grad and _native.available()):
+        return None
+    if _MAX_BATCH and x.shape[0] > _MAX_BATCH:
+        return None
+    if not (isinstance(linear, nn.Linear) and linear.bias is not None
+            and linear.weight.dtype == torch.float32 and linear.weight.is_contiguous()
+            and linear.in_features % 32 == 0 and linear.out_features % 32 == 0):
+        return None
+    H, W = x.shape[2], x.shape[3]
+    specs = []
+    for i, conv in enumerate(convs):
+        if not _conv_ok(conv) or H < conv.kernel_size[0] or W < conv.kernel_size[1]:
+            return None
+        sp = ConvSpec(conv, H, W)
+        if i == 0:
+            if sp.C != x.shape[1]:
+                return None
+        else:
+            # the backward-data kernel of layers that have a layer below
+            if not (sp.Cout % 32 == 0 and sp.C % 16 == 0 and sp.R % sp.ST == 0
+                    and sp.S % sp.ST == 0 and sp.H % sp.ST == 0 and sp.W % sp.ST == 0
+                    and sp.C == specs[-1].Cout):
+                return None
+        specs.append(sp)
+        H, W = sp.OH, sp.OW
+    last = specs[-1]
+    if last.Cout * last.OH * last.OW != linear.in_features or linear.in_features % 16:
+        return None
+    if x.shape[0] * max(s.OH * s.OW * max(s.Cout, s.C) for s in specs) >= 2 ** 31 // 8:
+        return None
+    return specs
+
+
+def _fwd_splits(M, F, K):
+    nch = K // 32
+    tiles16 = _ceil_div(M, 16) * _ceil_div(F, 32)
+    if tiles16 >= 1024:
+        return 1
+    want = max(448 // tiles16, _ceil_div(nch, 16), 1)
+    want = min(want, nch)
+    cps = _ceil_div(nch, want)
+    return _ceil_div(nch, cps)
+
+
+def _wgrad_splits(M, Cout, K):
+    nch = _ceil_div(M, 32)
+    tiles = _ceil_div(Cout, 32) * (K // 32)
+    # enough workgroups to fill the chip, and at most 16 chunks walked per workgroup
+    want = min(max(448 // tiles, _ceil_div(nch, 16), 1), nch, 1024)
+    cps = _ceil_div(nch, want)
+    return _ceil_div(nch, cps)
+
+
+def _reduce(tasks):
+    """tasks: (part, out, bias or None, stride, n, splits, ncol, relu)"""
+    n = len(tasks)
+    L = _native.lib()
+    P = (ctypes.c_void_p * n)(*[t[0].data_ptr() for t in tasks])
+    O = (ctypes.c_void_p * n)(*[t[1].data_ptr() for t in tasks])
+    B = (ctypes.c_void_p * n)(*[t[2].data_ptr() if t[2] is not None else 0 for t in tasks])
+    S = (ctypes.c_int64 * n)(*[t[3] for t in tasks])
+    N = (ctypes.c_int32 * n)(*[t[4] for t in tasks])
+    K = (ctypes.c_int32 * n)(*[t[5] for t in tasks])
+    C = (ctypes.c_int32 * n)(*[t[6] for t in tasks])
+    R = (ctypes.c_int32 * n)(*[t[7] for t in tasks])
+    check(L.pfrl_splitk_reduce(n, P, O, B, S, N, K, C, R, _stream()), "splitk_reduce")
+
+
+def conv_fwd(x, w, b, sp, N, relu=True, planar=False):
+    """x: NHWC memory of [N, H, W, C]; returns NHWC [N, OH, OW, Cout] or planar [N, Cout, OH*OW]."""
+    shape = (N, sp.Cout, sp.OH * sp.OW) if planar else (N, sp.OH, sp.OW, sp.Cout)
+    y = torch.empty(shape, dtype=torch.float32, device=x.device)
+    check(_native.lib().pfrl_conv2d_nhwc_fwd(_p(x), _p(w), _p(b), _p(y), N, sp.H, sp.W, sp.C, sp.Cout,
+                                             sp.R, sp.S, sp.ST, int(relu), int(planar), 1, _stream()),
+          "conv2d_nhwc_fwd")
+    return y
+
+
+def linear_fwd(x, w, b, relu=True):
+    """x: [M, K] contiguous -> relu(x w^T + b) [M, F]; split-K + fold for small M."""
+    M, K = x.shape
+    F = w.shape[0]
+    splits = _fwd_splits(M, F, K)
+    y = torch.empty((M, F), dtype=torch.float32, device=x.device)
+    if splits == 1:
+        check(_native.lib().pfrl_conv2d_nhwc_fwd(_p(x), _p(w), _p(b), _p(y), M, 1, 1, K, F, 1, 1, 1,
+                                                 int(relu), 0, 1, _stream()), "linear_fwd")
+        return y
+    part = torch.empty((splits, M, F), dtype=torch.float32, device=x.device)
+    check(_native.lib().pfrl_conv2d_nhwc_fwd(_p(x), _p(w), None, _p(part), M, 1, 1, K, F, 1, 1, 1, 0,
+                                             0, splits, _stream()), "linear_fwd_splitk")
+    _reduce([(part, y, b, M * F, M * F, splits, F, int(relu))])
+    return y
+
+
+class _Trunk(torch.autograd.Function):
+    """h = relu(linear(flatten(relu(conv_L(... relu(conv_1(x))))))) as one autograd node."""
+
+    @staticmethod
+    def forward(ctx, x, specs, *params):
+        N = x.shape[0]
+        if not x.is_contiguous(memory_format=torch.channels_last):
+            x = x.contiguous(memory_format=torch.channels_last)
+        L = len(specs)
+        acts = []
+        h = x
+        for i, sp in enumerate(specs):
+            h = conv_fwd(h, params[2 * i], params[2 * i + 1], sp, N, relu=True, planar=(i == L - 1))
+            acts.append(h)
+        wf, bf = params[2 * L], params[2 * L + 1]
+        out = linear_fwd(h.view(N, -1), wf, bf, relu=True)
+        if any(ctx.needs_input_grad[2:]):
+            ctx.specs = specs
+            ctx.save_for_backward(x, out, *acts, *params)
+        return out
+
+    @staticmethod
+    def backward(ctx, dh):
+        specs = ctx.specs
+        L = len(specs)
+        saved = ctx.saved_tensors
+        x, out = saved[0], saved[1]
+        acts = saved[2:2 + L]
+        params = saved[2 + L:]
+        N = x.shape[0]
+        lib = _native.lib()
+        dev = x.device
+        dh = dh.contiguous()
+        wf = params[2 * L]
+        F, Kf = wf.shape
+        last = specs[-1]
+        P = last.OH * last.OW
+        # hidden linear layer: input gradient straight into NHWC rows of the last conv
+        dy = torch.empty((N, last.OH, last.OW, last.Cout), dtype=torch.float32, device=dev)
+        check(lib.pfrl_conv2d_nhwc_bwd_data(_p(dh), _p(out), _p(wf), _p(acts[-1]), _p(dy), N, 1, 1, Kf,
+                                            F, 1, 1, 1, P, last.Cout, _stream()), "linear_bwd_data")
+        dwf = torch.empty_like(wf)
+        dbf = torch.empty(F, dtype=torch.float32, device=dev)
+        check(lib.pfrl_conv2d_nhwc_bwd_weight(_p(dh), _p(out), _p(acts[-1]), _p(dwf), _p(dbf), 0, 0, N,
+                                              1, 1, Kf, F, 1, 1, 1, 1, _stream()), "linear_bwd_weight")
+        grads = [None] * (2 * L) + [dwf, dbf]
+        tasks = []
+        for i in range(L - 1, -1, -1):
+            sp = specs[i]
+            w = params[2 * i]
+            below = acts[i - 1] if i > 0 else x
+            nW = w.numel()
+            M = N * sp.OH * sp.OW
+            splits = _wgrad_splits(M, sp.Cout, sp.R * sp.S * sp.C)
+            stride = nW + sp.Cout
+            dw = torch.empty_like(w)
+            db = torch.empty(sp.Cout, dtype=torch.float32, device=dev)
+            if splits == 1:
+                pw, pb, st = dw, db, 0
+            else:
+                part = torch.empty(splits * stride, dtype=torch.float32, device=dev)
+                pw, pb, st = part, part[nW:], stride
+                tasks.append((part, dw, None, stride, nW, splits, 4, 0))
+                tasks.append((pb, db, None, stride, sp.Cout, splits, 4, 0))
+            check(lib.pfrl_conv2d_nhwc_bwd_weight(_p(dy), None, _p(below), _p(pw), _p(pb), st, st, N,
+                                                  sp.H, sp.W, sp.C, sp.Cout, sp.R, sp.S, sp.ST, splits,
+                                                  _stream()), "conv2d_nhwc_bwd_weight")
+            grads[2 * i], grads[2 * i + 1] = dw, db
+            if i > 0:
+                dx = torch.empty((N, sp.H, sp.W, sp.C), dtype=torch.float32, device=dev)
+                check(lib.pfrl_conv2d_nhwc_bwd_data(_p(dy), None, _p(w), _p(below), _p(dx), N, sp.H,
+                                                    sp.W, sp.C, sp.Cout, sp.R, sp.S, sp.ST, 0, 0,
+                                                    _stream()), "conv2d_nhwc_bwd_data")
+                dy = dx
+        if tasks:
+            _reduce(tasks)
+        return (None, None) + tuple(grads)
+
+
+def trunk_forward(x, specs, convs, linear):
+    params = []
+    for c in convs:
+        params += [c.weight, c.bias]
+    params += [linear.weight, linear.bias]
+    return _Trunk.apply(x, specs, *params)
+
+
+class _SmallLinear(torch.autograd.Function):
+    """y = x w^T + b for a narrow head (out_features <= 16): one launch forward, one
+    launch for (dx, dw, db)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        M, K = x.shape
+        Nout = w.shape[0]
+        x = x.contiguous()
+        y = torch.empty((M, Nout), dtype=torch.float32, device=x.device)
+        check(_native.lib().pfrl_linear_small_fwd(_p(x), _p(w), _p(b), _p(y), M, K, Nout, _stream()),
+              "linear_small_fwd")
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        M, K = x.shape
+        Nout = w.shape[0]
+        dy = dy.contiguous()
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dw = torch.empty_like(w)
+        db = torch.empty(Nout, dtype=torch.float32, device=x.device) if ctx.has_bias else None
+        check(_native.lib().pfrl_linear_small_bwd(_p(dy), _p(x), _p(w), _p(dx), _p(dw), _p(db), M, K,
+                                                  Nout, _stream()), "linear_small_bwd")
+        return dx, dw, db
+
+
+def small_linear_supported(layer, x):
+    return (_ENABLED and isinstance(layer, nn.Linear) and x.is_cuda and x.dim() == 2
+            and x.dtype == torch.float32 and layer.out_features <= SMALL_LINEAR_MAX_OUT
+            and layer.weight.dtype == torch.float32 and layer.weight.is_contiguous()
+            and x.shape[0] * layer.out_features <= 12288 and x.shape[0] <= 4096
+            and _native.available())
+
+
+def small_linear(x, layer):
+    return _SmallLinear.apply(x, layer.weight, layer.bias)
+
+
+class _SmallLinearSlot(nn.Linear):
+    """An ``nn.Linear`` (same class, same parameter names, same state_dict) whose forward
+    takes the narrow-head kernels on the GPU; built around the tensors of an existing layer."""
+
+    def __init__(self, linear):
+        nn.Module.__init__(self)
+        self.__dict__.update({k: v for k, v in linear.__dict__.items()
+                              if k not in ("_parameters", "_buffers", "_modules")})
+        self._parameters = linear._parameters
+        self._buffers = linear._buffers
+        self._modules = linear._modules
+
+    def forward(self, x):
+        if small_linear_supported(self, x):
+            return small_linear(x, self)
+        return nn.Linear.forward(self, x)
+
+
+class _TrunkSequential(nn.Sequential):
+    """An ``nn.Sequential`` (same children, same indices, same state_dict) whose forward runs a
+    ``(Conv2d, ReLU)+, Flatten, Linear, ReLU`` stretch of its children as the MFMA trunk when
+    the input is inside what the kernels cover, and child by child otherwise."""
+
+    def forward(self, x):
+        start, end, conv_idx, lin_idx = self._trunk_run
+        mods = list(self._modules.values())
+        i = 0
+        while i < len(mods):
+            if i == start:
+                convs = [mods[k] for k in conv_idx]
+                specs = plan_for(convs, mods[lin_idx], x)
+                if specs is not None:
+                    x = trunk_forward(x, specs, convs, mods[lin_idx])
+                    i = end
+                    continue
+            x = mods[i](x)
+            i += 1
+        return x
+
+
+def _find_trunk_run(mods):
+    """(start, end, conv indices, linear index) of the first ``(Conv2d, ReLU)+, Flatten, Linear,
+    ReLU`` stretch in a list of modules (a ReLU slot may hold the identity that
+    ``fuse_conv_bias_relu`` leaves behind), or None."""
+    from pfrl_amd.nn.atari_cnn import _Identity
+
+    relu_like = (nn.ReLU, _Identity, nn.Identity)
+    for start in range(len(mods)):
+        j, convs = start, []
+        while (j + 1 < len(mods) and isinstance(mods[j], nn.Conv2d)
+               and isinstance(mods[j + 1], relu_like)):
+            convs.append(j)
+            j += 2
+        if (convs and j + 2 < len(mods) + 0 and isinstance(mods[j], nn.Flatten)
+                and isinstance(mods[j + 1], nn.Linear) and isinstance(mods[j + 2], nn.ReLU)):
+            return start, j + 3, convs, j + 1
+    return None
+
+
+def fuse_sequential_trunk(model):
+    """Make every ``nn.Sequential`` inside ``model`` that contains a ``(Conv2d, ReLU)+, Flatten,
+    Linear, ReLU`` stretch (the PPO / A2C example networks, examples/atari/train_ppo_ale.py:247-264)
+    execute that stretch as the MFMA trunk.  Children, parameters and state_dict keys are
+    untouched: only the container's class changes."""
+    for seq in [m for m in model.modules() if type(m) is nn.Sequential]:
+        run = _find_trunk_run(list(seq._modules.values()))
+        if run is not None:
+            seq.__class__ = _TrunkSequential
+            object.__setattr__(seq, "_trunk_run", run)
+    return model
+
+
+def accelerate_heads(model):
+    """Replace every narrow ``nn.Linear`` (out_features <= 16, plain class) inside ``model``
+    by a ``_SmallLinearSlot`` sharing its parameters."""
+    for parent in list(model.modules()):
+        for name, child in list(parent._modules.items()):
+            if type(child) is nn.Linear and child.out_features <= SMALL_LINEAR_MAX_OUT:
+                parent._modules[name] = _SmallLinearSlot(child)
+    return model
