@@ -74,6 +74,16 @@ class AttributeSavingMixin(object):
 
     def load(self, dirname):
         self._load_from(dirname, [])
+        self._drop_captured_graphs()
+
+    def _drop_captured_graphs(self):
+        """Captured HIP graphs bake in the addresses of the optimizer's state tensors, and
+        ``optimizer.load_state_dict`` replaces those tensors: after a load the graphs would
+        keep stepping the old (freed) state.  Forget them; the next update captures again
+        against the loaded state."""
+        for name in ("_graphed", "_captured"):
+            if getattr(self, name, None) is not None:
+                setattr(self, name, None)
 
     def _load_from(self, dirname, ancestors):
         map_location = torch.device("cpu") if not torch.cuda.is_available() else None

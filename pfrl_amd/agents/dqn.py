@@ -205,6 +205,7 @@ class DQN(agent.AttributeSavingMixin, agent.BatchAgent):
         # env-range boundaries (fractions of num_envs) of the step-fused path
         self.step_fused_chunks = tuple(step_fused_chunks)
         self._target_raw_bufs = {}
+        self.range_graphs = os.environ.get("PFRL_RANGE_GRAPHS", "1") != "0"
         self._analytic_backward = None
         self._graphed = None
         self._last_y = None
@@ -385,9 +386,22 @@ class DQN(agent.AttributeSavingMixin, agent.BatchAgent):
     # (categorical agents) set it to None and keep their own.
 
     def _fused_td_loss_applicable(self):
-        return (self.fused_td_loss and self.device.type == "cuda" and not self.recurrent
-                and type(self)._fused_td_double is not None
-                and type(self)._compute_y_and_t is DQN._compute_y_and_t)
+        """The fused launch computes the stock DQN target (``_fused_td_double`` False) or the
+        stock Double-DQN target (True).  ``_compute_target_values`` / ``_compute_y_and_t`` /
+        ``_compute_loss`` are the reference's extension points (its own DoubleDQN overrides
+        the first): a subclass that overrides any of them keeps the composite path, on
+        every device."""
+        cls = type(self)
+        if not (self.fused_td_loss and self.device.type == "cuda" and not self.recurrent
+                and cls._fused_td_double is not None
+                and cls._compute_y_and_t is DQN._compute_y_and_t
+                and cls._compute_loss is DQN._compute_loss):
+            return False
+        if cls._fused_td_double:
+            from pfrl_amd.agents.double_dqn import DoubleDQN
+
+            return cls._compute_target_values is DoubleDQN._compute_target_values
+        return cls._compute_target_values is DQN._compute_target_values
 
     def _compute_loss_fused(self, exp_batch, errors_out, record):
         from pfrl_amd import ops
@@ -595,6 +609,17 @@ class DQN(agent.AttributeSavingMixin, agent.BatchAgent):
                         key, dtype=raw.dtype, device=raw.device)
                 buf.view(raw.shape).copy_(raw)
                 big["target_next_raw"] = buf
+        if big is not None and self._range_as_one_graph(t0, hi - lo):
+            # nothing happens on the host between this range's updates (no target sync
+            # inside it): the whole range replays as ONE captured graph
+            self.t += hi - lo
+            self._cumulative_steps += hi - lo
+            losses, ys = self._graphed.run_range(big)
+            # graph-owned outputs: the next replay overwrites them
+            self.loss_record.extend(losses.clone())
+            self.q_record.extend(ys.clone())
+            self.optim_t += len(plan_env)
+            return
         p = 0
         deferred = [] if self.use_graphs else None
         for i in range(lo, hi):
@@ -614,6 +639,22 @@ class DQN(agent.AttributeSavingMixin, agent.BatchAgent):
                 for l, y in deferred:
                     self.loss_record.extend(l.clone())
                     self.q_record.extend(y.clone())
+
+    def _range_as_one_graph(self, t0, n):
+        """All updates of an env range as one HIP graph: graphs on, no prioritized replay
+        (priorities feed back between updates), no data-parallel collective between
+        backward and step, and no target sync inside the range."""
+        if not (self.use_graphs and self.range_graphs):
+            return False
+        tui = self.target_update_interval
+        if (t0 + n) // tui != t0 // tui:
+            return False
+        if self._graphed is None:
+            from pfrl_amd.agents.graphed_update import GraphedUpdate
+
+            self._graphed = GraphedUpdate(self)
+            self._graphed.pipeline = self._replay_stream is not None
+        return self._graphed.range_capturable()
 
     def _batch_observe_eval(self, batch_obs, batch_reward, batch_done, batch_reset):
         if self.recurrent:

@@ -241,6 +241,76 @@ class GraphedUpdate:
         entry["y"] = ag._last_y
         return entry
 
+    # -- a whole env range as ONE graph ---------------------------------------------
+    def range_capturable(self):
+        """Several consecutive updates can share one graph when nothing has to happen
+        between them on the host: no eager collective, no hand-over to a replay stream."""
+        return not (self.split_for_allreduce or self.pipeline)
+
+    def run_range(self, big):
+        """``big``: dict of tensors with a leading update axis U (the step-fused gather's
+        buffers).  Replays ONE graph holding the U updates back to back (each: forward,
+        loss, backward, clip, optimizer step -- the same launches as U single replays,
+        without U - 1 graph launches and the idle gaps between them).  Returns
+        (losses [U], ys [U * B]) owned by the graph."""
+        key = ("range", self._key(big))
+        entry = self.graphs.get(key)
+        if entry is None:
+            if len(self.graphs) >= self.max_graphs:
+                raise RuntimeError("too many distinct minibatch buffers for graph capture")
+            entry = self._capture_range(big)
+            self.graphs[key] = entry
+        entry["graph"].replay()
+        return entry["losses"], entry["ys"]
+
+    def _capture_range(self, big):
+        ag = self.agent
+        dev = ag.device
+        U = next(iter(big.values())).shape[0]
+        if not self._capturable_done:
+            if not _make_capturable(ag.optimizer, dev):
+                raise RuntimeError("optimizer %s has no capturable mode" % type(ag.optimizer))
+            self._capturable_done = True
+
+        def body():
+            losses, ys = [], []
+            for p in range(U):
+                ag.optimizer.zero_grad(set_to_none=True)
+                loss, _ = self._forward_backward({k: v[p] for k, v in big.items()}, False)
+                self._step()
+                losses.append(loss.reshape(()))
+                ys.append(ag._last_y.reshape(-1))
+            return torch.stack(losses), torch.cat(ys)
+
+        snap = self._snapshot()
+        try:
+            torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
+        except AttributeError:
+            pass
+        cur = torch.cuda.current_stream(dev)
+        side = torch.cuda.Stream(dev)
+        side.wait_stream(cur)
+        try:
+            with torch.cuda.stream(side):
+                # warm-up on the first update of the range only (same kernels for all U)
+                for _ in range(2):
+                    ag.optimizer.zero_grad(set_to_none=True)
+                    self._forward_backward({k: v[0] for k, v in big.items()}, False)
+                    self._step()
+            cur.wait_stream(side)
+            _make_capturable(ag.optimizer, dev)
+            ag.optimizer.zero_grad(set_to_none=True)
+            g = torch.cuda.CUDAGraph()
+            kw = {} if self.pool is None else {"pool": self.pool}
+            with torch.cuda.graph(g, **kw):
+                losses, ys = body()
+            if self.pool is None:
+                self.pool = g.pool()
+        finally:
+            cur.wait_stream(side)
+            self._restore(snap)
+        return {"graph": g, "losses": losses, "ys": ys}
+
     def run(self, exp_batch, want_errors, after_forward=None):
         """Returns (loss, delta, y) tensors owned by the graph (static).  In
         pipeline mode ``after_forward(delta)`` is called between the forward

@@ -35,7 +35,7 @@ import torch.nn.functional as F
 
 from pfrl_amd import agent, ops
 from pfrl_amd.agents.dqn import _DeviceRecord, _mean_or_nan
-from pfrl_amd.device_store import DeviceObsBatch
+from pfrl_amd.device_store import DeviceObs, DeviceObsBatch
 from pfrl_amd.utils.batch_states import batch_states
 from pfrl_amd.utils.contexts import evaluating
 from pfrl_amd.utils.mode_of_distribution import mode_of_distribution
@@ -80,6 +80,11 @@ class _Rollout:
         self.h_action = np.zeros((t_cap, n_envs) + tuple(act_shape), dtype=act_dtype)
         self.closed = []          # (env, t_start, t_end) in completion order
         self.open_start = np.zeros(n_envs, dtype=np.int64)
+        self.min_seq = None       # oldest frame-ring sequence number any stored ref points at
+
+    def note_frames(self, min_seq):
+        m = int(np.min(min_seq))
+        self.min_seq = m if self.min_seq is None else min(self.min_seq, m)
 
     def add_step(self, s_refs, n_refs, action, reward, done, reset):
         t = self.T
@@ -117,6 +122,7 @@ class _Rollout:
         self.T = 0
         self.closed = []
         self.open_start[:] = 0
+        self.min_seq = None
 
 
 class PPO(agent.AttributeSavingMixin, agent.BatchAgent):
@@ -283,16 +289,26 @@ class PPO(agent.AttributeSavingMixin, agent.BatchAgent):
             self.value_record.extend(batch_value)
         batch_action = action_dev.cpu().numpy()
         self._last_refs = refs.copy()
+        self._last_min_seq = int(np.min(dev_batch.min_seq))
         self.batch_last_state = list(range(len(batch_obs)))
         self.batch_last_action = list(batch_action)
         return batch_action
 
     def _batch_act_eval(self, batch_obs):
         assert not self.training
-        refs, dev_batch = self._refs_of(batch_obs)
-        self._sample_obs = dev_batch[0]
-        (refs_dev,) = self._stage.upload([refs])
-        b_state = self._features(refs_dev)
+        if isinstance(batch_obs, DeviceObsBatch) or (
+                len(batch_obs) > 0 and isinstance(batch_obs[0], DeviceObs)):
+            refs, dev_batch = self._refs_of(batch_obs)
+            self._sample_obs = dev_batch[0]
+            (refs_dev,) = self._stage.upload([refs])
+            b_state = self._features(refs_dev)
+        else:
+            # Host observations of an evaluation episode are uploaded directly (the
+            # reference's batch_states, pfrl/agents/ppo.py:689-690): they must not take
+            # slots of the frame ring the pending rollout's transitions point into.
+            b_state = self.batch_states(batch_obs, self.device, self.phi)
+            if self.obs_normalizer is not None:
+                b_state = self.obs_normalizer(b_state, update=False)
         with torch.no_grad(), evaluating(self.model):
             action_distrib, _ = self.model(b_state)
             if self.act_deterministically:
@@ -313,7 +329,7 @@ class PPO(agent.AttributeSavingMixin, agent.BatchAgent):
     def _batch_observe_train(self, batch_obs, batch_reward, batch_done, batch_reset):
         assert self.training
         n_env = len(batch_obs)
-        next_refs, _ = self._refs_of(batch_obs)
+        next_refs, next_batch = self._refs_of(batch_obs)
         actions = np.asarray(self.batch_last_action)
         if self.rollout is None:
             t_cap = -(-self.update_interval // n_env) + 2
@@ -328,6 +344,7 @@ class PPO(agent.AttributeSavingMixin, agent.BatchAgent):
         reset = np.asarray(batch_reset, dtype=bool)
         self.rollout.add_step(self._last_refs, next_refs, actions,
                               np.asarray(batch_reward, dtype=np.float64), done, reset)
+        self.rollout.note_frames(min(self._last_min_seq, int(np.min(next_batch.min_seq))))
         self.batch_last_state = [None] * n_env
         self.batch_last_action = [None] * n_env
         self._update_if_dataset_is_ready()
@@ -393,6 +410,14 @@ class PPO(agent.AttributeSavingMixin, agent.BatchAgent):
         order = ro.dataset_order()
         n = len(order)
         assert n == T * N
+        if (ro.min_seq is not None and self.frames is not None
+                and ro.min_seq < self.frames.oldest_live_seq()):
+            # same liveness rule as the replay store's slots_for(): a rollout whose oldest
+            # frame has been overwritten would train on other observations, silently
+            raise RuntimeError(
+                "PPO rollout refers to frame %d but the frame ring (%d slots) has wrapped past "
+                "it (oldest live frame %d); give the frame store more slots than one rollout "
+                "writes" % (ro.min_seq, self.frames.n_slots, self.frames.oldest_live_seq()))
         # ship the rollout columns (one transfer)
         up = self._stage.upload([
             ro.h_state[:T].reshape(T * N, k), ro.h_next[:T].reshape(T * N, k),

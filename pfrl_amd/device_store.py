@@ -136,13 +136,35 @@ class ScaleU8:
         return np.asarray(x, dtype=np.float32) / np.float32(self.divisor)
 
 
+def _scale_of(x, y):
+    """d such that y == float32(x) / d elementwise (same shape, y float32), or None; an
+    all-zero x is inconclusive and also gives None."""
+    if y.shape != x.shape or y.dtype != np.float32:
+        return None
+    xf = x.astype(np.float32)
+    nz = xf != 0
+    if not np.any(nz):
+        return None
+    if np.array_equal(y, xf):
+        return 1.0
+    m = float(np.median(xf[nz] / y[nz]))
+    for cand in (m, round(m)):
+        if cand > 0 and np.array_equal(y, xf / np.float32(cand)):
+            return float(cand)
+    return None
+
+
 def recognise_phi(phi, sample_obs):
-    """Classify ``phi`` by evaluating it on a real observation.
+    """Classify ``phi`` by evaluating it on a real observation and on a synthetic probe.
 
     Returns the divisor d such that phi(x) == float32(x) / d elementwise with
     the same shape (d == 1.0 covers cast-only and identity), or None if phi is
-    something else.  Arbitrary Python callables cannot run on the device; the
-    three forms used by the reference's example scripts can."""
+    something else (or cannot be decided yet).  Arbitrary Python callables cannot run
+    on the device; the three forms used by the reference's example scripts can.
+
+    One sample is not enough: an all-zero observation cannot tell x from x / 255, and a
+    clipping or non-linear phi can act as a pure scale on it.  The probe covers the value
+    range of the observation dtype; both have to agree."""
     if isinstance(phi, ScaleU8):
         return phi.divisor
     x = np.asarray(sample_obs)
@@ -152,17 +174,21 @@ def recognise_phi(phi, sample_obs):
         return None
     if y.shape != x.shape or y.dtype != np.float32:
         return None
-    xf = x.astype(np.float32)
-    if np.array_equal(y, xf):
-        # identity / cast-only; make sure it is not a coincidence of an all-zero frame
-        if np.any(xf != 0) or x.dtype == np.float32:
-            return 1.0
-    nz = xf != 0
-    if not np.any(nz):
+    d = _scale_of(x, y)
+    if d is None and np.any(x != 0):
         return None
-    ratio = xf[nz] / y[nz]
-    d = float(np.median(ratio))
-    for cand in (d, round(d)):
-        if cand > 0 and np.array_equal(y, xf / np.float32(cand)):
-            return float(cand)
-    return None
+    if np.issubdtype(x.dtype, np.integer):
+        info = np.iinfo(x.dtype)
+        probe = (np.arange(x.size, dtype=np.int64) * 7919 % (int(info.max) - int(info.min) + 1)
+                 + int(info.min)).astype(x.dtype).reshape(x.shape)
+    elif x.size == 1:
+        probe = np.full(x.shape, 1000.0, dtype=x.dtype)
+    else:
+        probe = np.linspace(-1000.0, 1000.0, x.size).astype(x.dtype).reshape(x.shape)
+    try:
+        dp = _scale_of(probe, np.asarray(phi(probe)))
+    except Exception:
+        return d    # phi only accepts its own observation type: the sample decides
+    if dp is None or (d is not None and d != dp):
+        return None
+    return dp

@@ -25,8 +25,12 @@ def _divisor_for(phi, sample_obs_fn):
     hit = _phi_cache.get(key)
     if hit is not None and hit[0] is phi:
         return hit[1]
-    d = recognise_phi(phi, sample_obs_fn())
-    _phi_cache[key] = (phi, d)
+    sample = sample_obs_fn()
+    d = recognise_phi(phi, sample)
+    arr = np.asarray(sample)
+    if d is not None or bool(np.any(arr != 0)):
+        # an all-zero sample is inconclusive: do not cache, look again at a later observation
+        _phi_cache[key] = (phi, d)
     return d
 
 

@@ -12,6 +12,20 @@ import torch
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
 
 
+
+def _spy_losses(ag, losses):
+    """Append the loss of every update to ``losses``, whichever path the agent takes (eager,
+    one graph per update, step-fused with deferred statistics, or a whole env range replayed
+    as one graph): every path hands its losses to ``loss_record.extend``."""
+    orig = ag.loss_record.extend
+
+    def extend(t):
+        orig(t)
+        losses.extend(float(v) for v in t.detach().float().reshape(-1).cpu().numpy())
+
+    ag.loss_record.extend = extend
+
+
 def _run(name, prioritized, num_steps, double, gpu, priority_pow="device", steps=640, N=4,
          spies=True, agent_cls=None, **agent_kw):
     import pfrl_amd as pfrl
@@ -84,17 +98,7 @@ def _run(name, prioritized, num_steps, double, gpu, priority_pow="device", steps
             return seqs
 
         rbuf.lookahead_sample = spy_look
-    orig_core = ag._update_from_batch
-
-    def spy_core(*a, **kw):
-        orig_core(*a, **kw)
-        d = kw.get("deferred")
-        if d:   # step-fused path: the loss is recorded at the end of the step
-            losses.append(float(d[-1][0]))
-        else:
-            losses.append(float(ag.loss_record.values()[-1]))
-
-    ag._update_from_batch = spy_core
+    _spy_losses(ag, losses)
     pfrl.experiments.train_agent_batch(ag, env, steps, tempfile.mkdtemp())
     params = np.concatenate([p.detach().cpu().numpy().ravel() for p in q.parameters()])
     return dict(actions=np.asarray(actions), losses=np.asarray(losses),
@@ -366,17 +370,7 @@ def _run_c51(gpu):
         return a
 
     ag.batch_act = spy_act
-    orig_core = ag._update_from_batch
-
-    def spy_core(*a, **kw):
-        orig_core(*a, **kw)
-        d = kw.get("deferred")
-        if d:   # step-fused path: the loss is recorded at the end of the step
-            losses.append(float(d[-1][0]))
-        else:
-            losses.append(float(ag.loss_record.values()[-1]))
-
-    ag._update_from_batch = spy_core
+    _spy_losses(ag, losses)
     pfrl.experiments.train_agent_batch(ag, env, 640, tempfile.mkdtemp())
     params = np.concatenate([p.detach().cpu().numpy().ravel() for p in q.parameters()])
     return dict(actions=np.asarray(actions), losses=losses, params=params, rbuf=rbuf)
@@ -685,14 +679,7 @@ def _run_iqn(gpu, prioritized, host_thresholds=False, **agent_kw):
         return a
 
     ag.batch_act = spy_act
-    orig_core = ag._update_from_batch
-
-    def spy_core(*a, **kw):
-        orig_core(*a, **kw)
-        d = kw.get("deferred")
-        losses.append(float(d[-1][0].detach()) if d else float(ag.loss_record.values()[-1]))
-
-    ag._update_from_batch = spy_core
+    _spy_losses(ag, losses)
     pfrl.experiments.train_agent_batch(ag, env, 640, tempfile.mkdtemp())
     params = np.concatenate([p.detach().cpu().numpy().ravel() for p in q.parameters()])
     return dict(actions=np.asarray(actions), losses=np.asarray(losses), final_params=params,

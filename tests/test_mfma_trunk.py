@@ -1,0 +1,322 @@
+"""csrc/qnet.hip -- the f32 MFMA trunk kernels -- against the same ops in stock PyTorch fp32
+(CPU), through the C ABI; plus the host-side plumbing that routes models onto them.
+
+Tolerances: the kernels accumulate in f32 like PyTorch does, in a different order; every
+check is relative to the largest magnitude of the reference tensor."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+import pfrl_amd
+from pfrl_amd.nn import mfma_trunk as mt
+
+gpu = pytest.mark.gpu
+
+
+def _close(a, b, rel):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    scale = float(b.abs().max()) + 1e-30
+    err = float((a - b).abs().max()) / scale
+    assert err <= rel, "relative error %.3e > %.1e" % (err, rel)
+
+
+def _nature_q(n_actions=6):
+    torch.manual_seed(0)
+    return nn.Sequential(pfrl_amd.nn.LargeAtariCNN(), nn.Linear(512, n_actions))
+
+
+# ---------------------------------------------------------------------------- host logic
+def test_trunk_plan_is_none_off_the_device():
+    m = pfrl_amd.nn.LargeAtariCNN()
+    x = torch.zeros(2, 4, 84, 84)
+    assert mt.plan_for(m.layers, m.output, x) is None
+    assert m(x).shape == (2, 512)       # stock route
+
+
+def test_sequential_trunk_run_detection_and_state_dict():
+    seq = nn.Sequential(nn.Conv2d(4, 32, 8, stride=4), nn.ReLU(), nn.Conv2d(32, 64, 4, stride=2),
+                        nn.ReLU(), nn.Conv2d(64, 64, 3), nn.ReLU(), nn.Flatten(),
+                        nn.Linear(3136, 512), nn.ReLU(), nn.Linear(512, 7))
+    keys = list(seq.state_dict().keys())
+    x = torch.rand(3, 4, 84, 84)
+    want = seq(x)
+    pfrl_amd.nn.fuse_sequential_trunk(seq)
+    pfrl_amd.nn.accelerate_heads(seq)
+    assert type(seq).__name__ == "_TrunkSequential" and seq._trunk_run == (0, 9, [0, 2, 4], 7)
+    assert list(seq.state_dict().keys()) == keys
+    assert torch.equal(seq(x), want)    # CPU input: child by child, unchanged
+    clone = copy.deepcopy(seq)
+    assert clone._trunk_run == seq._trunk_run and torch.equal(clone(x), want)
+    # a model without such a stretch is left alone
+    mlp = nn.Sequential(nn.Linear(4, 8), nn.ReLU(), nn.Linear(8, 2))
+    assert type(pfrl_amd.nn.fuse_sequential_trunk(mlp)) is nn.Sequential
+
+
+def test_split_heuristics_cover_the_reduction():
+    for M, F_, K in [(32, 512, 3136), (256, 512, 3136), (2048, 512, 3136), (5, 512, 3136)]:
+        s = mt._fwd_splits(M, F_, K)
+        cps = -(-(K // 32) // s)
+        assert 1 <= s <= K // 32 and cps * s >= K // 32 and cps * (s - 1) < K // 32
+    for M, Co, K in [(12800, 32, 256), (2592, 64, 512), (1568, 64, 576), (102400, 32, 256), (7, 64, 576)]:
+        s = mt._wgrad_splits(M, Co, K)
+        nch = -(-M // 32)
+        cps = -(-nch // s)
+        assert 1 <= s <= nch and cps * s >= nch and cps * (s - 1) < nch
+
+
+# ---------------------------------------------------------------------------- kernels
+GEOMS = [(4, 32, 8, 4, 84), (32, 64, 4, 2, 20), (64, 64, 3, 1, 9),      # Nature
+         (4, 16, 8, 4, 84), (16, 32, 4, 2, 20)]                        # NIPS-2013 (16-wide tiles)
+
+
+@gpu
+@pytest.mark.parametrize("B", [32, 5])
+@pytest.mark.parametrize("geom", GEOMS)
+def test_conv_kernels_match_torch(geom, B):
+    C, Co, R, ST, H = geom
+    dev = torch.device("cuda:0")
+    torch.manual_seed(B * 100 + C)
+    conv = nn.Conv2d(C, Co, R, stride=ST)
+    x = torch.rand(B, C, H, H)
+    xr = x.clone().requires_grad_(True)
+    yr = F.relu(conv(xr))
+    gy = torch.randn_like(yr)
+    yr.backward(gy)
+    cg = copy.deepcopy(conv).to(dev).to(memory_format=torch.channels_last)
+    xg = x.to(dev).contiguous(memory_format=torch.channels_last)
+    sp = mt.ConvSpec(cg, H, H)
+    y = mt.conv_fwd(xg, cg.weight, cg.bias, sp, B, relu=True, planar=False)
+    _close(y.permute(0, 3, 1, 2), yr, 2e-6)
+    yp = mt.conv_fwd(xg, cg.weight, cg.bias, sp, B, relu=True, planar=True)
+    assert torch.equal(yp.view(B, Co, sp.OH, sp.OW), y.permute(0, 3, 1, 2))
+    lib = mt._native.lib()
+    dy = (gy * (yr > 0)).permute(0, 2, 3, 1).contiguous().to(dev)
+    nW, M = cg.weight.numel(), B * sp.OH * sp.OW
+    splits = mt._wgrad_splits(M, Co, R * R * C)
+    stride = nW + Co
+    part = torch.empty(max(splits, 1) * stride, device=dev)
+    dw, db = torch.empty_like(cg.weight), torch.empty(Co, device=dev)
+    mt.check(lib.pfrl_conv2d_nhwc_bwd_weight(mt._p(dy), None, mt._p(xg), mt._p(part), mt._p(part[nW:]),
+                                              stride, stride, B, H, H, C, Co, R, R, ST, splits,
+                                              mt._stream()), "wgrad")
+    mt._reduce([(part, dw, None, stride, nW, splits, 4, 0), (part[nW:], db, None, stride, Co, splits, 4, 0)])
+    assert dw.stride() == cg.weight.stride()
+    _close(dw, conv.weight.grad, 5e-6)
+    _close(db, conv.bias.grad, 5e-6)
+    if C % 16 == 0:
+        aprev = torch.rand(B, H, H, C, device=dev) - 0.3
+        dx = torch.full((B, H, H, C), float("nan"), device=dev)
+        mt.check(lib.pfrl_conv2d_nhwc_bwd_data(mt._p(dy), None, mt._p(cg.weight), mt._p(aprev), mt._p(dx),
+                                               B, H, H, C, Co, R, R, ST, 0, 0, mt._stream()), "dgrad")
+        _close(dx, xr.grad.permute(0, 2, 3, 1) * (aprev.cpu() > 0), 5e-6)
+
+
+@gpu
+@pytest.mark.parametrize("B", [32, 7, 256])
+def test_nature_trunk_forward_backward_matches_torch(B):
+    dev = torch.device("cuda:0")
+    ref = _nature_q()
+    dut = copy.deepcopy(ref).to(dev).to(memory_format=torch.channels_last)
+    mt.accelerate_heads(dut)
+    torch.manual_seed(B)
+    x = torch.rand(B, 4, 84, 84)
+    xg = x.to(dev).contiguous(memory_format=torch.channels_last)
+    assert mt.plan_for(dut[0].layers, dut[0].output, xg) is not None     # the kernels do run
+    q_ref, q = ref(x), dut(xg)
+    _close(q, q_ref, 5e-6)
+    g = torch.randn_like(q_ref)
+    q_ref.backward(g)
+    q.backward(g.to(dev))
+    for (name, p), (_, pr) in zip(dut.named_parameters(), ref.named_parameters()):
+        assert p.grad.stride() == p.stride(), name
+        # conv1's gradient sums 400 B terms with heavy cancellation in f32 on both sides
+        _close(p.grad, pr.grad, 1e-3 if B >= 256 else 1e-5)
+    # planar NCHW input is converted, not rejected
+    _close(dut(x.to(dev)), q_ref, 5e-6)
+    # no_grad: same values, nothing saved
+    with torch.no_grad():
+        assert torch.equal(dut(xg), q)
+
+
+@gpu
+def test_small_atari_cnn_trunk_matches_torch():
+    dev = torch.device("cuda:0")
+    torch.manual_seed(3)
+    ref = nn.Sequential(pfrl_amd.nn.SmallAtariCNN(), nn.Linear(256, 4))
+    dut = copy.deepcopy(ref).to(dev).to(memory_format=torch.channels_last)
+    mt.accelerate_heads(dut)
+    x = torch.rand(32, 4, 84, 84)
+    xg = x.to(dev).contiguous(memory_format=torch.channels_last)
+    assert mt.plan_for(dut[0].layers, dut[0].output, xg) is not None
+    q_ref, q = ref(x), dut(xg)
+    _close(q, q_ref, 5e-6)
+    g = torch.randn_like(q_ref)
+    q_ref.backward(g)
+    q.backward(g.to(dev))
+    for (name, p), (_, pr) in zip(dut.named_parameters(), ref.named_parameters()):
+        _close(p.grad, pr.grad, 1e-5)
+
+
+@gpu
+def test_sequential_trunk_fusion_on_device_matches_stock():
+    """The PPO example network (examples/atari/train_ppo_ale.py:247-264) as an nn.Sequential."""
+    dev = torch.device("cuda:0")
+    torch.manual_seed(5)
+    ref = nn.Sequential(nn.Conv2d(4, 32, 8, stride=4), nn.ReLU(), nn.Conv2d(32, 64, 4, stride=2),
+                        nn.ReLU(), nn.Conv2d(64, 64, 3), nn.ReLU(), nn.Flatten(),
+                        nn.Linear(3136, 512), nn.ReLU(), nn.Linear(512, 1))
+    dut = copy.deepcopy(ref).to(dev).to(memory_format=torch.channels_last)
+    pfrl_amd.nn.fuse_sequential_trunk(dut)
+    x = torch.rand(64, 4, 84, 84)
+    v_ref = ref(x)
+    v = dut(x.to(dev).contiguous(memory_format=torch.channels_last))
+    _close(v, v_ref, 5e-6)
+    v_ref.sum().backward()
+    v.sum().backward()
+    for (name, p), (_, pr) in zip(dut.named_parameters(), ref.named_parameters()):
+        _close(p.grad, pr.grad, 2e-5)
+
+
+@gpu
+def test_trunk_in_a_captured_graph_equals_eager():
+    """Forward + backward of the trunk replayed from a HIP graph (how the agents run an
+    update, agents/graphed_update.py) gives the eager results bit for bit."""
+    dev = torch.device("cuda:0")
+    dut = _nature_q().to(dev).to(memory_format=torch.channels_last)
+    mt.accelerate_heads(dut)
+    xg = torch.rand(32, 4, 84, 84, device=dev).contiguous(memory_format=torch.channels_last)
+    g_out = torch.randn(32, 6, device=dev)
+    params = list(dut.parameters())
+
+    def step():
+        q = dut(xg)
+        torch.autograd.backward([q], [g_out * 1.0])
+        return q
+
+    cur = torch.cuda.current_stream()
+    side = torch.cuda.Stream()
+    side.wait_stream(cur)
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            for p in params:
+                p.grad = None
+            step()
+    cur.wait_stream(side)
+    for p in params:
+        p.grad = None
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        q_graph = step()
+    xg.copy_(torch.rand_like(xg))       # new input: replay, then eager on the same input
+    graph.replay()
+    got = [p.grad.clone() for p in params]
+    q_got = q_graph.clone()
+    for p in params:
+        p.grad = None
+    q_eager = step()
+    assert torch.equal(q_got, q_eager)
+    for a, p in zip(got, params):
+        assert torch.equal(a, p.grad)
+
+
+@gpu
+def test_small_linear_head_matches_torch():
+    dev = torch.device("cuda:0")
+    torch.manual_seed(2)
+    for M, K, N in [(32, 512, 6), (5, 512, 18 - 2), (256, 256, 1), (32, 1000, 3)]:
+        head = nn.Linear(K, N)
+        hg = copy.deepcopy(head).to(dev)
+        h = torch.randn(M, K)
+        hr = h.clone().requires_grad_(True)
+        q = head(hr)
+        gq = torch.randn_like(q)
+        q.backward(gq)
+        hx = h.to(dev).requires_grad_(True)
+        assert mt.small_linear_supported(hg, hx)
+        qg = mt.small_linear(hx, hg)
+        qg.backward(gq.to(dev))
+        _close(qg, q, 2e-6)
+        _close(hx.grad, hr.grad, 2e-6)
+        _close(hg.weight.grad, head.weight.grad, 5e-6)
+        _close(hg.bias.grad, head.bias.grad, 5e-6)
+
+
+def _device_dqn(dev, range_graphs, steps, n_envs=8, seed=0, optimizer="sgd"):
+    import tempfile
+
+    import pfrl_amd as pfrl
+    from pfrl_amd import agents, explorers, replay_buffers
+    from pfrl_amd.device_store import DeviceFrameStore
+    from pfrl_amd.envs import SyntheticAtariVectorEnv
+    from pfrl_amd.q_functions import DiscreteActionValueHead
+
+    pfrl.utils.set_random_seed(seed)
+    store = DeviceFrameStore(4096, (84, 84), torch.uint8, dev, stack=4)
+    env = SyntheticAtariVectorEnv(n_envs, store=store, seed=1, n_actions=4)
+    torch.manual_seed(5)
+    q = torch.nn.Sequential(pfrl.nn.LargeAtariCNN(), torch.nn.Linear(512, 4),
+                            DiscreteActionValueHead()).to(memory_format=torch.channels_last)
+    if optimizer == "sgd":
+        opt = torch.optim.SGD(q.parameters(), lr=1e-3)
+    else:
+        from pfrl_amd.optimizers import FusedRMSprop
+
+        opt = FusedRMSprop(q.parameters(), lr=2.5e-4, alpha=0.95, eps=1e-2, centered=True)
+    rbuf = replay_buffers.ReplayBuffer(1000)
+    ex = explorers.ConstantEpsilonGreedy(0.3, lambda: np.random.randint(4))
+    ag = agents.DQN(q, opt, rbuf, 0.99, ex, gpu=0, replay_start_size=64, minibatch_size=16,
+                    update_interval=4, target_update_interval=48,
+                    phi=lambda x: np.asarray(x, dtype=np.float32) / 255)
+    ag.range_graphs = range_graphs
+    if steps:
+        pfrl.experiments.train_agent_batch(ag, env, steps, tempfile.mkdtemp())
+    return ag, env, q
+
+
+@gpu
+def test_dqn_range_graph_equals_per_update_graphs():
+    """All updates of an env range replayed as ONE captured graph (agents/dqn.py
+    _range_as_one_graph) are the same launches in the same order as one graph per update:
+    bit-identical parameters, losses and update counts, target syncs included."""
+    dev = torch.device("cuda:0")
+    out = []
+    for rg in (True, False):
+        ag, _, q = _device_dqn(dev, rg, 400)
+        out.append((np.concatenate([p.detach().cpu().numpy().ravel() for p in q.parameters()]),
+                    ag.loss_record.values(), ag.q_record.values(), ag.optim_t, ag.t,
+                    any(k[0] == "range" for k in ag._graphed.graphs)))
+    (pa, la, qa, ua, ta, ra), (pb, lb, qb, ub, tb, rb) = out
+    assert ra and not rb
+    assert ua == ub > 20 and ta == tb
+    assert np.array_equal(la, lb) and np.array_equal(qa, qb)
+    assert np.array_equal(pa, pb)
+
+
+@gpu
+def test_load_after_captured_updates_keeps_training_on_the_loaded_state(tmp_path):
+    """optimizer.load_state_dict replaces the state tensors the captured graphs
+    point at; load() must drop the graphs so that the next update steps the loaded state."""
+    dev = torch.device("cuda:0")
+    ag, env, q = _device_dqn(dev, True, 120, optimizer="rmsprop")
+    assert ag._graphed is not None and ag._graphed.graphs
+    ag.save(str(tmp_path / "ckpt"))
+    saved = {k: v.clone() for k, v in q.state_dict().items()}
+    import pfrl_amd as pfrl
+
+    pfrl.experiments.train_agent_batch(ag, env, 40, str(tmp_path / "o1"), step_offset=120)
+    ag.load(str(tmp_path / "ckpt"))
+    assert ag._graphed is None
+    for k, v in q.state_dict().items():
+        assert torch.equal(v, saved[k]), k
+    sq_before = [ag.optimizer.state[p]["square_avg"].clone() for p in q.parameters()]
+    n0 = ag.optim_t
+    pfrl.experiments.train_agent_batch(ag, env, 40, str(tmp_path / "o2"), step_offset=160)
+    assert ag.optim_t > n0
+    sq_after = [ag.optimizer.state[p]["square_avg"] for p in q.parameters()]
+    assert any(not torch.equal(a, b) for a, b in zip(sq_before, sq_after)), \
+        "the optimizer state in use is not the loaded one"
