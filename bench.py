@@ -53,6 +53,12 @@ def parse_args():
     p.add_argument("--minibatch", type=int, default=32)
     p.add_argument("--update-interval", type=int, default=4)
     p.add_argument("--seed", type=int, default=0)
+    p.add_argument("--replay-start", type=int, default=None,
+                   help="replay_start_size (default: the example scripts' 5e4 dqn / 2e4 rainbow / 1e4 sac)")
+    p.add_argument("--frame-slots", type=int, default=None,
+                   help="slots of the HBM frame ring (default: capacity + room for the windows of all envs)")
+    p.add_argument("--slack", type=int, default=None,
+                   help="spare rows of the entry / transition rings (default 65536)")
     p.add_argument("--prefill", type=int, default=None,
                    help="transitions to prefill (default: capacity, i.e. full buffer)")
     p.add_argument("--no-cpu-baseline", action="store_true")
@@ -72,6 +78,11 @@ def parse_args():
     p.add_argument("--chunks", type=str, default=None,
                    help="dqn: env-range cut points of the step-fused path as fractions, e.g. "
                         "'0.125' (default) or '' for one range")
+    p.add_argument("--priority-pow", choices=["device", "host_libm"], default="device",
+                   help="rainbow: where (clip(err) + eps) ** alpha is evaluated.  device = one "
+                        "launch, correctly rounded (<= 1 ulp from NumPy's powf in <1 %% of inputs); "
+                        "host_libm = this host's libm as NumPy does (bit-exact priority trees, one "
+                        "D2H per update)")
     p.add_argument("--torch-optimizer", action="store_true",
                    help="stock torch.optim.RMSprop instead of the fused HIP step")
     args = p.parse_args()
@@ -112,19 +123,22 @@ def build_rainbow(args, device, rank):
     if args.channels_last:
         q_func = q_func.to(memory_format=torch.channels_last)
     opt = torch.optim.Adam(q_func.parameters(), 6.25e-5, eps=1.5 * 10 ** -4, fused=True)
-    store = DeviceFrameStore(args.capacity + N * 24 + 8192, (84, 84), torch.uint8, device, stack=4)
+    store = DeviceFrameStore(getattr(args, "frame_slots", None) or args.capacity + N * 24 + 8192,
+                             (84, 84), torch.uint8, device, stack=4)
     env = SyntheticAtariVectorEnv(N, store=store, seed=args.seed, env_id0=rank * N,
                                   n_actions=n_actions)
     rbuf = replay_buffers.PrioritizedReplayBuffer(
         args.capacity, alpha=0.5, beta0=0.4, betasteps=2 * 10 ** 6, num_steps=3,
-        normalize_by_max="memory")
+        normalize_by_max="memory", slack=getattr(args, "slack", None),
+        priority_pow=getattr(args, "priority_pow", "device"))
 
     def phi(x):
         return np.asarray(x, dtype=np.float32) / 255
 
     agent = agents.CategoricalDoubleDQN(
         q_func, opt, rbuf, gpu=device.index, gamma=0.99, explorer=explorers.Greedy(),
-        minibatch_size=args.minibatch, replay_start_size=2 * 10 ** 4,
+        minibatch_size=args.minibatch,
+        replay_start_size=getattr(args, "replay_start", None) or 2 * 10 ** 4,
         target_update_interval=32000, update_interval=args.update_interval,
         batch_accumulator="mean", phi=phi)
     agent.grad_reducer.broadcast_parameters(agent.model)
@@ -271,11 +285,11 @@ def build_agent(args, device, rank):
         env = HostSyntheticAtariVectorEnv(N, seed=args.seed * 64 + rank, n_actions=n_actions,
                                           frame_pool=4096)
     else:
-        frame_slots = args.capacity + N * 16 + 8192
+        frame_slots = getattr(args, "frame_slots", None) or args.capacity + N * 16 + 8192
         store = DeviceFrameStore(frame_slots, (84, 84), torch.uint8, device, stack=4)
         env = SyntheticAtariVectorEnv(N, store=store, seed=args.seed, env_id0=rank * N,
                                       n_actions=n_actions)
-    rbuf = replay_buffers.ReplayBuffer(args.capacity, num_steps=1)
+    rbuf = replay_buffers.ReplayBuffer(args.capacity, num_steps=1, slack=getattr(args, "slack", None))
     explorer = explorers.LinearDecayEpsilonGreedy(
         1.0, 0.01, 10 ** 6, lambda: np.random.randint(n_actions))
 
@@ -284,7 +298,8 @@ def build_agent(args, device, rank):
 
     agent = agents.DQN(
         q_func, opt, rbuf, gpu=device.index, gamma=0.99, explorer=explorer,
-        replay_start_size=5 * 10 ** 4, target_update_interval=3 * 10 ** 4, clip_delta=True,
+        replay_start_size=getattr(args, "replay_start", None) or 5 * 10 ** 4,
+        target_update_interval=3 * 10 ** 4, clip_delta=True,
         update_interval=args.update_interval, minibatch_size=args.minibatch,
         batch_accumulator="sum", phi=phi)
     if args.chunks is not None:

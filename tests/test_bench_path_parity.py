@@ -1,0 +1,297 @@
+"""Parity of the EXACT paths ``bench.py`` times, at their own shapes, against the oracle.
+
+The agent-trace tests (test_agent_parity.py) compare small host-env runs with traces recorded
+from the reference.  These tests pin what the benchmark runs: the device env
+(``SyntheticAtariVectorEnv`` writing 84x84 u8 frames into the HBM ring), 256 / 512 envs, the
+Nature CNN in channels_last, the step-fused gather in two env ranges, rings small enough to
+wrap the entry ring, the frame ring and the ``slack`` rows several times.  The expectation is
+built independently of the product code: a Python deque of what the reference's loop would
+append (pfrl/agents/dqn.py:509-549), index sets drawn by a restatement of
+pfrl/utils/random.py:4-28 from the same NumPy stream position, and minibatches computed by the
+C oracle (oracle/pfrl_oracle.c) from a D2H copy of the frame ring.  Everything integer / byte
+is compared bit-exact.
+"""
+import argparse
+import collections
+import copy
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+pytestmark = pytest.mark.gpu
+
+
+def _bench_args(**kw):
+    d = dict(gpus=1, algo="dqn", host_env=False, steps=1, warmup=0, num_envs=256, capacity=10 ** 6,
+             minibatch=32, update_interval=4, seed=0, prefill=None, no_cpu_baseline=True,
+             cpu_baseline_seconds=0.0, cpu_baseline_threads=1, cudnn_benchmark=False,
+             channels_last=True, blas="default", chunks=None, torch_optimizer=False,
+             replay_start=None, frame_slots=None, slack=None, priority_pow="device")
+    d.update(kw)
+    return argparse.Namespace(**d)
+
+
+def _ref_sample_n_k(n, k):
+    """k distinct uniform indices from range(n), consuming the legacy global NumPy stream the
+    way pfrl/utils/random.py:4-28 does (choice without replacement when 3k >= n; otherwise 2k
+    draws with replacement, first-come acceptance, refill of the spare half when exhausted)."""
+    if 3 * k >= n:
+        return np.random.choice(n, k, replace=False)
+    res = np.random.choice(n, 2 * k)
+    seen = set()
+    spare = k
+    for i in range(k):
+        x = res[i]
+        while x in seen:
+            x = res[i] = res[spare]
+            spare += 1
+            if spare == 2 * k:
+                res[k:] = np.random.choice(n, k)
+                spare = k
+        seen.add(x)
+    return res[:k]
+
+
+def _same_rng_state(a, b):
+    return a[0] == b[0] and np.array_equal(a[1], b[1]) and a[2:] == b[2:]
+
+
+def test_dqn_bench_path_minibatches_match_oracle():
+    """BASELINE configs[1] as bench.py builds it (256 envs, 84x84x4, Nature CNN channels_last,
+    step_fused_chunks=(0.125,), B=32, update_interval=4): for checked steps after every ring
+    has wrapped, all 64 minibatches of the step -- index sets, action / reward / terminal /
+    discount and the gathered fp32 state / next_state stacks -- equal the oracle bit for bit,
+    the NumPy stream ends at the same position, and the first TD loss of the step agrees with
+    the same network evaluated by stock PyTorch on the CPU to 1e-5."""
+    import bench
+    import oracle
+
+    dev = torch.device("cuda:0")
+    N, B, CAP, START = 256, 32, 1500, 1024
+    args = _bench_args(capacity=CAP, frame_slots=6144, slack=512, replay_start=START)
+    agent, env, rbuf = bench.build_agent(args, dev, 0)
+    assert agent.step_fused_chunks == (0.125,) and agent.step_fused_gather and agent.use_graphs
+    gamma = agent.gamma
+
+    fetched, keep = [], [False]
+    orig_fetch = rbuf.fetch_many
+
+    def spy_fetch(seq_sets, phi, g):
+        big = orig_fetch(seq_sets, phi, g)
+        if keep[0]:
+            fetched.append({k: v.detach().cpu().numpy() for k, v in big.items()
+                            if k != "target_next_raw"})
+        return big
+
+    rbuf.fetch_many = spy_fetch
+    losses = []
+    orig_extend = agent.loss_record.extend
+
+    def spy_extend(t):
+        orig_extend(t)
+        losses.append(t.detach().float().reshape(-1).cpu().numpy())
+
+    agent.loss_record.extend = spy_extend
+
+    model = collections.deque(maxlen=CAP)     # what pfrl's ReplayBuffer(CAP).memory would hold
+    t_counter = 0
+    checked = {30: 0, 52: 0, 71: 0}
+    obss = env.reset()
+    frames_written0 = env.store.next_seq
+    for step in range(72):
+        state_refs = obss.refs.copy()
+        actions = np.asarray(agent.batch_act(obss))
+        obss2, rs, dones, _ = env.step(actions)
+        next_refs = obss2.refs.copy()
+        keep[0] = step in checked
+        del fetched[:]
+        del losses[:]
+        if keep[0]:
+            cpu_q = copy.deepcopy(agent.model).cpu().to(memory_format=torch.contiguous_format)
+            cpu_t = copy.deepcopy(agent.target_model).cpu().to(memory_format=torch.contiguous_format)
+        s0 = np.random.get_state()
+        agent.batch_observe(obss2, rs, dones, np.zeros(N, dtype=bool))
+        s1 = np.random.get_state()
+        # the reference's loop, on the model (pfrl/agents/dqn.py:516-549)
+        np.random.set_state(s0)
+        expected = []
+        for i in range(N):
+            t_counter += 1
+            model.append((state_refs[i], int(actions[i]), float(rs[i]), next_refs[i], bool(dones[i])))
+            if len(model) >= START and t_counter % 4 == 0:
+                expected.append([model[j] for j in _ref_sample_n_k(len(model), B)])
+        assert _same_rng_state(np.random.get_state(), s1), "NumPy stream position differs"
+        assert agent.t == t_counter and len(rbuf) == len(model)
+        if keep[0]:
+            assert len(expected) == 64
+            got = {k: np.concatenate([f[k] for f in fetched]) for k in fetched[0]}
+            assert got["state"].shape == (64, B, 4, 84, 84)
+            torch.cuda.synchronize()
+            frames = env.store.frames.cpu().numpy().reshape(env.store.n_slots, -1)
+            for u, ents in enumerate(expected):
+                want_s = oracle.batch_states_u8(frames, np.stack([e[0] for e in ents]), 255.0)
+                want_n = oracle.batch_states_u8(frames, np.stack([e[3] for e in ents]), 255.0)
+                assert np.array_equal(got["state"][u].reshape(B, -1), want_s.reshape(B, -1)), (step, u)
+                assert np.array_equal(got["next_state"][u].reshape(B, -1), want_n.reshape(B, -1)), (step, u)
+                sc = oracle.batch_experiences_scalars(
+                    [[b] for b in range(B)], np.array([e[2] for e in ents]),
+                    np.array([e[4] for e in ents], dtype=np.uint8), gamma, 1)
+                assert np.array_equal(got["action"][u], np.array([e[1] for e in ents]))
+                for key in ("reward", "is_state_terminal", "discount"):
+                    assert np.array_equal(got[key][u], sc[key]), (step, u, key)
+            # TD loss of the step's first update, same weights, stock PyTorch on the CPU
+            e0 = expected[0]
+            s = torch.from_numpy(oracle.batch_states_u8(frames, np.stack([e[0] for e in e0]), 255.0)
+                                 ).view(B, 4, 84, 84)
+            ns = torch.from_numpy(oracle.batch_states_u8(frames, np.stack([e[3] for e in e0]), 255.0)
+                                  ).view(B, 4, 84, 84)
+            with torch.no_grad():
+                y = cpu_q(s).evaluate_actions(torch.tensor([e[1] for e in e0]))
+                nq = cpu_t(ns).max
+                r = torch.tensor([e[2] for e in e0], dtype=torch.float32)
+                term = torch.tensor([float(e[4]) for e in e0])
+                tgt = r + (gamma * (1.0 - term)) * nq
+                want_loss = float(torch.nn.functional.smooth_l1_loss(y, tgt, reduction="sum"))
+            got_loss = float(np.concatenate(losses)[0])
+            assert abs(got_loss - want_loss) <= 1e-5 * max(1.0, abs(want_loss)), (got_loss, want_loss)
+            checked[step] = 1
+        obss = env.reset(~np.asarray(dones))
+    assert all(checked.values())
+    st = rbuf.store
+    # every ring wrapped: entries / transitions (E = R = CAP + slack), frames
+    assert st.n_entries > 3 * st.E and st.n_trans > 3 * st.R
+    assert env.store.next_seq - frames_written0 > 2 * env.store.n_slots
+    assert any(k[0] == "range" for k in agent._graphed.graphs)   # the path bench.py times
+
+
+def test_rainbow_bench_path_tree_matches_oracle():
+    """BASELINE configs[2] as bench.py builds it (CategoricalDoubleDQN, 256 envs, PER n = 3,
+    normalize_by_max='memory', replay stream on): every sample's indices and importance
+    weights and the tree's root sum / min / max_priority after every update_errors equal
+    ``OraclePrioritizedBuffer`` fed the same appends, the same uniform draws and the device's
+    TD errors.  priority_pow='host_libm' (bit-exact leaves; the bench's default 'device' mode
+    differs from NumPy's powf by <= 1 ulp in < 1 % of inputs, test_hip_kernels.py)."""
+    import bench
+    import oracle
+    from pfrl_amd.collections import prioritized as dev_pri
+
+    dev = torch.device("cuda:0")
+    N, CAP, START = 256, 3000, 1024
+    args = _bench_args(algo="rainbow", capacity=CAP, frame_slots=3000 + 24 * N + 512, slack=1024,
+                       replay_start=START, priority_pow="host_libm")
+    agent, env, rbuf = bench.build_agent(args, dev, 0)
+    assert agent._replay_stream is not None
+    orc = oracle.OraclePrioritizedBuffer(CAP)
+    counts = dict(samples=0, updates=0, appends=0)
+    pending = {}
+
+    orig_append = dev_pri.PrioritizedBuffer.append
+    orig_sample = dev_pri.PrioritizedBuffer.sample_device
+
+    def spy_append(self, value, priority=None):
+        assert priority is None
+        orc.append(value)
+        counts["appends"] += 1
+        return orig_append(self, value, priority)
+
+    def spy_sample(self, n, u01=None, normalize=1, beta=0.0, slot_mod=0):
+        assert u01 is None
+        u = np.random.random_sample(n)          # the draws np.random.uniform would consume
+        want = orc.sample(u)
+        out = orig_sample(self, n, u01=u, normalize=normalize, beta=beta, slot_mod=slot_mod)
+        self._join()
+        x = out["x"].cpu().numpy()
+        np.testing.assert_array_equal(x - self.frame.head, want["indices"])
+        np.testing.assert_array_equal(out["pri"].cpu().numpy(), want["priorities"])
+        # reference weights (pfrl/replay_buffers/prioritized.py:57-66, normalize_by_max="memory")
+        w = (want["probabilities"] / want["min_prob"]) ** (-beta)
+        np.testing.assert_allclose(out["weight"].cpu().numpy(), w, rtol=1e-5)
+        counts["samples"] += 1
+        pending["x"] = x
+        return out
+
+    dev_pri.PrioritizedBuffer.append = spy_append
+    dev_pri.PrioritizedBuffer.sample_device = spy_sample
+    orig_update = rbuf.update_errors
+
+    def spy_update(errors):
+        err = errors.detach().float().cpu().numpy().reshape(-1)
+        v, t = oracle.priority_from_errors_f32(err, rbuf.error_min, rbuf.error_max, rbuf.eps,
+                                               rbuf.alpha)
+        orc.set_last_priority(v, t)
+        orig_update(errors)
+        got, so = rbuf.memory.tree.root_stats(), orc.stats()
+        assert got[0] == so["sum"] and got[1] == so["min"] and got[2] == so["max_priority"], \
+            (counts, got, so)
+        counts["updates"] += 1
+
+    rbuf.update_errors = spy_update
+    try:
+        obss = env.reset()
+        for step in range(16):
+            obss = bench.one_step(agent, env, obss, N)
+    finally:
+        dev_pri.PrioritizedBuffer.append = orig_append
+        dev_pri.PrioritizedBuffer.sample_device = orig_sample
+    assert counts["updates"] >= 300 and counts["samples"] >= counts["updates"]
+    assert counts["appends"] > CAP          # the tree frame slid / re-rooted past capacity
+    assert len(rbuf) == len(orc) == CAP
+
+
+def test_ppo_bench_path_gae_and_advantage_statistics_match_oracle(monkeypatch):
+    """BASELINE configs[3] as bench.py builds it (512 envs x 128 steps): the rollout the agent
+    hands to ``gae_scan`` / ``adv_stats`` gives, fragment by fragment, the oracle's advantages
+    and value targets bit for bit, and its mean / std to 1e-6."""
+    import bench
+    import oracle
+    from pfrl_amd import ops
+
+    dev = torch.device("cuda:0")
+    N, T = 512, 128
+    args = _bench_args(algo="ppo", num_envs=N)
+    agent, env, _ = bench.build_agent(args, dev, 0)
+    seen = {}
+    orig_gae, orig_stats = ops.gae_scan, ops.adv_stats
+
+    def spy_gae(reward, v_pred, next_v, nonterm, cut, gamma, lambd, mode=0):
+        adv, vt = orig_gae(reward, v_pred, next_v, nonterm, cut, gamma, lambd, mode)
+        seen["gae"] = [x.detach().cpu().numpy() for x in (reward, v_pred, next_v, nonterm, cut, adv, vt)]
+        seen["gae_args"] = (gamma, lambd, mode)
+        return adv, vt
+
+    def spy_stats(adv):
+        out = orig_stats(adv)
+        seen["stats"] = (adv.detach().cpu().numpy().copy(), [float(x) for x in out.reshape(-1)[:2].cpu()])
+        return out
+
+    monkeypatch.setattr(ops, "gae_scan", spy_gae)
+    monkeypatch.setattr(ops, "adv_stats", spy_stats)
+    obss = env.reset()
+    for _ in range(T):
+        obss = bench.one_step(agent, env, obss, N)
+    assert agent.n_updates > 0 and "gae" in seen and "stats" in seen
+    reward, v_pred, next_v, nonterm, cut, adv, vt = seen["gae"]
+    gamma, lambd, mode = seen["gae_args"]
+    assert reward.shape == (T, N) and cut[-1].all()
+    n_frag = 0
+    for e in range(N):
+        a = 0
+        for t in range(T):
+            if cut[t, e]:
+                wa, wv = oracle.gae_fragment(reward[a:t + 1, e], v_pred[a:t + 1, e],
+                                             next_v[a:t + 1, e], nonterm[a:t + 1, e], gamma, lambd, mode)
+                assert np.array_equal(adv[a:t + 1, e], wa.astype(adv.dtype)), (e, a, t)
+                assert np.array_equal(vt[a:t + 1, e], wv.astype(vt.dtype)), (e, a, t)
+                a = t + 1
+                n_frag += 1
+    assert n_frag > N        # episode ends inside the rollout: more fragments than envs
+    flat, (mean, std) = seen["stats"]
+    wm, ws = oracle.adv_stats(flat)
+    assert abs(mean - wm) <= 1e-6 * max(1.0, abs(wm)) and abs(std - ws) <= 1e-6 * max(1.0, abs(ws))
