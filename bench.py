@@ -45,7 +45,7 @@ def parse_args():
                         "through the pinned staging ring -- the PCIe-inclusive rate of DESIGN.md, "
                         "never the headline value")
     p.add_argument("--steps", type=int, default=None,
-                   help="timed batched env steps (default 20; 128 = one rollout + update for ppo)")
+                   help="timed batched env steps (default 200; 128 = one rollout + update for ppo)")
     p.add_argument("--warmup", type=int, default=None,
                    help="untimed steps (default 5; 128 = one full rollout + update for ppo)")
     p.add_argument("--num-envs", type=int, default=None, help="default 256 (512 for ppo)")
@@ -62,6 +62,14 @@ def parse_args():
     p.add_argument("--prefill", type=int, default=None,
                    help="transitions to prefill (default: capacity, i.e. full buffer)")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-data-path-only", action="store_true",
+                   help="dqn: skip the second measurement with a zero-FLOP q_function")
+    p.add_argument("--no-also", action="store_true",
+                   help="dqn: do not append the PPO configs[3] measurement ('also') to the line")
+    p.add_argument("--scaling", choices=["weak", "strong"], default=None,
+                   help="N > 1: weak = --num-envs envs on EVERY GPU; strong = --num-envs envs "
+                        "sharded N/G per GPU as BASELINE.json's metric and SURVEY.md 8(e) describe "
+                        "(default: strong)")
     p.add_argument("--cpu-baseline-seconds", type=float, default=12.0)
     p.add_argument("--cpu-baseline-threads", type=int, default=16,
                    help="torch CPU threads for the baseline's network (capped by the host; at "
@@ -86,8 +94,10 @@ def parse_args():
     p.add_argument("--torch-optimizer", action="store_true",
                    help="stock torch.optim.RMSprop instead of the fused HIP step")
     args = p.parse_args()
+    if args.scaling is None:
+        args.scaling = "strong"
     if args.steps is None:
-        args.steps = 128 if args.algo == "ppo" else 20
+        args.steps = 128 if args.algo == "ppo" else 200
     if args.warmup is None:
         args.warmup = 128 if args.algo == "ppo" else 5
     if args.algo == "ppo":
@@ -179,6 +189,9 @@ def build_ppo(args, device, rank):
         # Conv2d + ReLU pairs of the Sequential -> MIOpen conv + one fused bias/ReLU
         # launch (same parameters, same state_dict)
         model = pfrl.nn.fuse_conv_bias_relu(model).to(memory_format=torch.channels_last)
+        if os.environ.get("PFRL_PPO_TRUNK", "0") == "1":
+            # conv stack + hidden layer as the f32 MFMA trunk kernels (csrc/qnet.hip)
+            pfrl.nn.fuse_sequential_trunk(model)
     opt = torch.optim.Adam(model.parameters(), lr=2.5e-4, eps=1e-5, fused=True)
     T = 128
     store = DeviceFrameStore((T + 8) * N + 8192, (84, 84), torch.uint8, device, stack=4)
@@ -514,18 +527,37 @@ def compute_roofline(algo, all_us, all_units, all_kinds):
     return roofline
 
 
+def algorithmic_bytes_per_step(algo, N, minibatch, update_interval):
+    """SURVEY.md 8(d) per env-step figures x envs per batched step."""
+    fb, k = 84 * 84, 4
+    if algo in ("dqn", "rainbow"):
+        rho = minibatch / update_interval
+        return N * (fb + (k * fb + 4 * k * fb) + rho * 2 * (k * fb + 4 * k * fb))
+    if algo == "ppo":
+        return N * 994932
+    return N * (2 * minibatch * 3084 + 3084)   # sac
+
+
 def assemble_result(args, world, N, elapsed, n_updates, t_fill, workload, roofline):
-    """The ONE JSON line of the driver contract (cpu_baseline is added by the caller)."""
+    """The ONE JSON line of the driver contract (cpu_baseline etc. are added by the caller)."""
+    ms = elapsed / args.steps * 1e3
+    if roofline is not None:
+        # the step as a whole against the same roofline: the kernel fraction above is for
+        # the dominant gather alone and must not be read as the end-to-end figure
+        step_bytes = algorithmic_bytes_per_step(args.algo, N, args.minibatch, args.update_interval)
+        roofline["step_algorithmic_bytes"] = int(step_bytes)
+        roofline["step_frac"] = round(step_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
+    per = "per GPU" if args.scaling == "weak" else "sharded over the GPUs"
     return {
-        "metric": "env-steps/sec whole node (%s %d envs per GPU)" % (args.algo.upper(), N),
+        "metric": "env-steps/sec whole node (%s %d envs %s)" % (args.algo.upper(), N if args.scaling == "weak" else N * world, per),
         "value": round(world * N * args.steps / elapsed, 1), "unit": "env-steps/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "ms_per_step": round(ms, 3), "higher_is_better": True,
+        "scaling": args.scaling, "vs_baseline": None, "dtype": "f32",
         "data": "synthetic (host frames over PCIe)" if args.host_env else "synthetic",
         "config": {
             "workload": workload,
-            "global_envs": world * N, "updates_in_timed_region": n_updates,
+            "global_envs": world * N, "envs_per_gpu": N, "updates_in_timed_region": n_updates,
             "parallelism": "env-sharded dp%d, per-GPU-local replay" % world,
             "prefill_s": round(t_fill, 1),
         },
@@ -533,36 +565,73 @@ def assemble_result(args, world, N, elapsed, n_updates, t_fill, workload, roofli
     }
 
 
-def main():
-    args = parse_args()
-    # stdout carries exactly ONE line, the JSON result.  Native libraries (RCCL's
-    # version banner, MIOpen notes) write to fd 1 through C stdio at times of their
-    # own choosing: park fd 1 on stderr for the whole run and keep the real stdout
-    # for the result line.
-    sys.stdout.flush()
-    result_fd = os.dup(1)
-    os.dup2(2, 1)
-    from pfrl_amd import _native, ops
-    from pfrl_amd.distributed import init_process_group_from_env
+class _ZeroFlopQ(torch.nn.Module):
+    """q_function stand-in for the data-path-only figure: Q-values that do
+    not depend on the observation, one learnable row, so that every replay / gather / loss /
+    optimizer launch of the step still happens and the network costs nothing."""
 
-    rank, world, local = init_process_group_from_env()
-    assert torch.cuda.is_available(), "bench.py needs the MI355X"
-    if world != args.gpus:
-        assert world == 1 and args.gpus == 1, "--gpus must equal WORLD_SIZE (use torchrun for N>1)"
-    device = torch.device("cuda", local % torch.cuda.device_count())
-    torch.cuda.set_device(device)
-    _native.lib()
-    if world > 1:
-        # one process per GPU: keep each rank's host-side torch ops on its share of cores
-        torch.set_num_threads(max(1, (os.cpu_count() or world) // world))
+    def __init__(self, n_actions):
+        super().__init__()
+        self.q = torch.nn.Parameter(torch.zeros(1, n_actions))
 
-    if args.blas == "rocblas":
-        torch.backends.cuda.preferred_blas_library("cublas")
-    elif args.blas == "tunable":
-        torch.cuda.tunable.enable(True)
-        torch.cuda.tunable.tuning_enable(True)
-        torch.cuda.tunable.set_max_tuning_duration(10)
-        torch.cuda.tunable.set_filename("/tmp/pfrl_tunableop_rank%d.csv" % rank)
+    def forward(self, x):
+        from pfrl_amd.action_value import DiscreteActionValue
+
+        return DiscreteActionValue(self.q.expand(x.shape[0], self.q.shape[1]))
+
+
+def data_path_only(args, device, agent, env, rbuf, obss, steps):
+    """The same batched step over the same (full) replay buffer and env with a zero-FLOP
+    q_function: appends, index draws, the fused gathers, TD loss and optimizer step remain."""
+    from pfrl_amd import agents
+    from pfrl_amd.optimizers import FusedRMSprop
+
+    N = args.num_envs
+    q = _ZeroFlopQ(6)
+    opt = FusedRMSprop(q.parameters(), lr=2.5e-4, alpha=0.95, eps=1e-2, centered=True)
+    stub = agents.DQN(q, opt, rbuf, gpu=device.index, gamma=0.99, explorer=agent.explorer,
+                      replay_start_size=agent.replay_start_size,
+                      target_update_interval=3 * 10 ** 4, clip_delta=True,
+                      update_interval=args.update_interval, minibatch_size=args.minibatch,
+                      batch_accumulator="sum", phi=agent.phi)
+    stub.step_fused_chunks = agent.step_fused_chunks
+    stub.t = agent.t
+    for _ in range(3):
+        obss = one_step(stub, env, obss, N)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        obss = one_step(stub, env, obss, N)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    return {"value": round(N * steps / el, 1), "unit": "env-steps/s", "steps": steps,
+            "ms_per_step": round(el / steps * 1e3, 3),
+            "what": "the same step with a zero-FLOP q_function (SURVEY.md 8d): env frames, "
+                    "act gather, appends, index draws, fused minibatch gathers of the full "
+                    "schedule, TD loss, optimizer step on one row"}, obss
+
+
+def reference_baseline():
+    """The reference's own numbers for this workload, recorded in the build container by
+    tools/reference_cpu_baseline.py (the reference cannot travel to the GPU box)."""
+    for name in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True):
+        if name.endswith("_reference_cpu_baseline.json"):
+            try:
+                d = json.load(open(os.path.join(ROOT, "profiles", name)))
+                return {"reference_value": d["end_to_end"]["value"],
+                        "reference_data_path_only_value": d["data_path_only"]["value"],
+                        "reference_cores": d["cores"],
+                        "reference_source": "profiles/%s: pfnet/pfrl itself (gpu=-1) on the same "
+                                            "synthetic workload, capacity %d, timed in the build "
+                                            "container (not on this box)" % (name, d["capacity"])}
+            except Exception:
+                pass
+    return {}
+
+
+def run_workload(args, device, rank, world, result_extras=True):
+    """Build, prefill, warm up and time one workload; returns the result dict (rank 0) or None."""
+    from pfrl_amd import ops
 
     agent, env, rbuf = build_agent(args, device, rank)
     N = args.num_envs
@@ -571,7 +640,9 @@ def main():
     if rbuf is not None:
         target = args.prefill if args.prefill is not None else (
             10 ** 5 if args.algo == "sac" else args.capacity)
-        target = max(min(target, args.capacity), 5 * 10 ** 4)
+        target = max(min(target, args.capacity),
+                     getattr(agent, "replay_start_size", None)
+                     or agent.replay_updater.replay_start_size)
         obss = prefill(agent, env, obss, N, target)
     torch.cuda.synchronize()
     t_fill = time.perf_counter() - t_fill
@@ -597,6 +668,7 @@ def main():
         return 0
 
     optim_before = updates_done()
+    ops.profile_collect(kind=None)      # drop launches timed by an earlier workload
     ops.profile_enable(True)
     barrier()
     torch.cuda.synchronize()
@@ -616,12 +688,76 @@ def main():
 
     all_us, all_units, all_kinds = ops.profile_collect(kind=None)
     roofline = compute_roofline(args.algo, all_us, all_units, all_kinds)
-    out = None
+    out = assemble_result(args, world, N, elapsed, n_updates, t_fill,
+                          workload_description(args, N, rbuf), roofline)
+    out["config"]["ranks_seen"] = world
+    if args.algo == "rainbow":
+        out["config"]["priority_pow"] = rbuf.priority_pow
+    if result_extras and args.algo == "dqn" and not args.host_env and not args.no_data_path_only:
+        # every rank runs it (the agents are symmetric); rank 0 reports its own
+        dpo, obss = data_path_only(args, device, agent, env, rbuf, obss, min(args.steps, 100))
+        out["data_path_only"] = dpo
+    del agent, env, rbuf
+    torch.cuda.empty_cache()
+    return out if rank == 0 else None
+
+
+def main():
+    args = parse_args()
+    # stdout carries exactly ONE line, the JSON result.  Native libraries (RCCL's
+    # version banner, MIOpen notes) write to fd 1 through C stdio at times of their
+    # own choosing: park fd 1 on stderr for the whole run and keep the real stdout
+    # for the result line.
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
+    from pfrl_amd import _native
+    from pfrl_amd.distributed import init_process_group_from_env
+
+    rank, world, local = init_process_group_from_env()
+    assert torch.cuda.is_available(), "bench.py needs the MI355X"
+    if world != args.gpus:
+        assert world == 1 and args.gpus == 1, "--gpus must equal WORLD_SIZE (use torchrun for N>1)"
+    device = torch.device("cuda", local % torch.cuda.device_count())
+    torch.cuda.set_device(device)
+    _native.lib()
+    if world > 1:
+        # one process per GPU: keep each rank's host-side torch ops on its share of cores
+        torch.set_num_threads(max(1, (os.cpu_count() or world) // world))
+    if args.scaling == "strong":
+        # the metric's envs are sharded, GPU g owns envs [g N/G, (g+1) N/G)
+        assert args.num_envs % world == 0, "--num-envs must divide by the number of GPUs"
+        args.total_envs = args.num_envs
+        args.num_envs //= world
+
+    if args.blas == "rocblas":
+        torch.backends.cuda.preferred_blas_library("cublas")
+    elif args.blas == "tunable":
+        torch.cuda.tunable.enable(True)
+        torch.cuda.tunable.tuning_enable(True)
+        torch.cuda.tunable.set_max_tuning_duration(10)
+        torch.cuda.tunable.set_filename("/tmp/pfrl_tunableop_rank%d.csv" % rank)
+
+    out = run_workload(args, device, rank, world)
+    if args.algo == "dqn" and not args.host_env and not args.no_also:
+        # the other half of BASELINE.json's metric ("DQN 256 envs, PPO 512 envs"): the PPO
+        # configs[3] workload, timed by the same process right after
+        import copy
+
+        pargs = copy.copy(args)
+        pargs.algo, pargs.steps, pargs.warmup = "ppo", 128, 128
+        pargs.num_envs = 512 if args.scaling == "weak" else 512 // world
+        pargs.cudnn_benchmark = False
+        torch.backends.cudnn.benchmark = False
+        also = run_workload(pargs, device, rank, world, result_extras=False)
+        if rank == 0:
+            out["also"] = {"ppo": {k: also[k] for k in ("metric", "value", "unit", "steps", "warmup",
+                                                       "ms_per_step", "scaling", "config",
+                                                       "roofline")}}
     if rank == 0:
-        out = assemble_result(args, world, N, elapsed, n_updates, t_fill,
-                              workload_description(args, N, rbuf), roofline)
         if not args.no_cpu_baseline and world == 1 and args.algo == "dqn":
             out["cpu_baseline"] = cpu_baseline(args, args.cpu_baseline_seconds)
+            out["cpu_baseline"].update(reference_baseline())
     if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
     sys.stdout.flush()

@@ -160,7 +160,14 @@ def test_bench_result_line_contract(monkeypatch):
                 "roofline"):
         assert key in line, key
     assert line["value"] == 2 * 256 * 20 / 0.4 and line["n_gpus"] == 2
-    assert line["ms_per_step"] == 20.0 and line["scaling"] == "weak"
+    assert line["ms_per_step"] == 20.0 and line["scaling"] == "strong"   # 256 envs sharded N/G
+    # the step as a whole against the HBM roofline (not the gather kernel's fraction)
+    step_bytes = bench.algorithmic_bytes_per_step("dqn", 256, 32, 4)
+    assert step_bytes == 256 * (7056 + 141120 + 8 * 282240)      # 2,406,096 B / env-step
+    np.testing.assert_allclose(line["roofline"]["step_frac"], step_bytes / 20e-3 / 8e12, rtol=1e-3)
+    monkeypatch.setattr(sys, "argv", ["bench.py"])
+    dflt = bench.parse_args()
+    assert dflt.steps >= 200 and dflt.scaling == "strong"
     assert line["vs_baseline"] is None and line["higher_is_better"] is True
     assert line["config"]["workload"] == "workload text" and "model" not in line["config"]
     assert bench.PROFILE_BATCH_EXPERIENCES == 0 and bench.PROFILE_BATCH_STATES_U8 == 1
