@@ -395,6 +395,14 @@ int pfrl_conv2d_nhwc_bwd_weight(const float *dy, const float *dy_mask, const flo
                                 float *db_part, int64_t dw_stride, int64_t db_stride, int32_t N,
                                 int32_t H, int32_t W, int32_t C, int32_t Cout, int32_t R, int32_t S,
                                 int32_t stride, int32_t splits, void *stream);
+/* Both gradients of one layer in ONE launch (same dy): arguments of _bwd_data and _bwd_weight
+ * combined.  Minibatch-sized problems only; returns PFRL_ERR_ARG for larger ones (the caller
+ * then issues the two launches). */
+int pfrl_conv2d_nhwc_bwd(const float *dy, const float *dy_mask, const float *w, const float *a_prev,
+                         const float *x, float *dx, float *dw_part, float *db_part, int64_t dw_stride,
+                         int64_t db_stride, int32_t N, int32_t H, int32_t W, int32_t C, int32_t Cout,
+                         int32_t R, int32_t S, int32_t stride, int32_t perm_p, int32_t perm_c,
+                         int32_t splits, void *stream);
 int pfrl_splitk_reduce(int32_t n_tasks, const float *const *host_part, float *const *host_out,
                        const float *const *host_bias, const int64_t *host_stride,
                        const int32_t *host_n, const int32_t *host_splits, const int32_t *host_ncol,

@@ -128,6 +128,7 @@ EXPORTS = {
     "pfrl_conv2d_nhwc_fwd": (ctypes.c_int, "ppppiiiiiiiiiiip"),
     "pfrl_conv2d_nhwc_bwd_data": (ctypes.c_int, "pppppiiiiiiiiiip"),
     "pfrl_conv2d_nhwc_bwd_weight": (ctypes.c_int, "pppppqqiiiiiiiiip"),
+    "pfrl_conv2d_nhwc_bwd": (ctypes.c_int, "ppppppppqqiiiiiiiiiiip"),
     "pfrl_splitk_reduce": (ctypes.c_int, "ippppppppp"),
     "pfrl_linear_small_fwd": (ctypes.c_int, "ppppiiip"),
     "pfrl_linear_small_bwd": (ctypes.c_int, "ppppppiiip"),

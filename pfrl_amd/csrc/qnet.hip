@@ -303,20 +303,21 @@ struct DgradArgs {
 };
 
 template <int BM, int BN, int WM, int WN, int WK, int G>
-__global__ __launch_bounds__(256) void k_conv_dgrad(DgradArgs p) {
+__device__ __forceinline__ void dgrad_body(const DgradArgs &p, const int bx, const int by,
+                                           const int bz, float *smem) {
     static_assert(WM * WN * WK == 4, "four waves");
     constexpr int AM = BM / (16 * WM), AN = BN / (16 * WN);
     constexpr int P = (AM * AN == 1) ? 2 : 1;
     constexpr int NPA = (BM * 8 + 255) / 256;
     constexpr int QPR = BN / 4, NPB = (32 * QPR + 255) / 256, LDB = BN + 4;
-    __shared__ __attribute__((aligned(16))) float As[G][BM * LDR];
-    __shared__ __attribute__((aligned(16))) float Bs[G][32 * LDB];
-    __shared__ f32x4 red[WK > 1 ? (WK - 1) * WM * WN * AM * AN * 64 : 1];
+    float(*As)[BM * LDR] = reinterpret_cast<float(*)[BM * LDR]>(smem);
+    float(*Bs)[32 * LDB] = reinterpret_cast<float(*)[32 * LDB]>(smem + G * BM * LDR);
+    f32x4 *red = reinterpret_cast<f32x4 *>(smem + G * BM * LDR + G * 32 * LDB);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wk = wave % WK, wn = (wave / WK) % WN, wm = wave / (WK * WN);
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int m0 = bx * BM, n0 = by * BN;
     const ConvGeom g = p.g;
-    const int ph = blockIdx.z / g.ST, pw = blockIdx.z - ph * g.ST;
+    const int ph = bz / g.ST, pw = bz - ph * g.ST;
     const int ahw = p.AH * p.AW;
 
     int rn[NPA], rah[NPA], raw[NPA];
@@ -427,6 +428,24 @@ __global__ __launch_bounds__(256) void k_conv_dgrad(DgradArgs p) {
         }
 }
 
+// LDS floats of a tile program: G chunk buffers per operand + the split-K fold area
+constexpr int red_floats(int BM, int BN, int WM, int WN, int WK) {
+    return WK > 1 ? (WK - 1) * WM * WN * (BM / (16 * WM)) * (BN / (16 * WN)) * 256 : 4;
+}
+constexpr int dgrad_smem(int BM, int BN, int WM, int WN, int WK, int G) {
+    return G * BM * LDR + G * 32 * (BN + 4) + red_floats(BM, BN, WM, WN, WK);
+}
+constexpr int wgrad_smem(int BI, int BJ, int WM, int WN, int WK, int G) {
+    return G * 32 * (BI + 4) + G * 32 * (BJ + 4) + red_floats(BI, BJ, WM, WN, WK);
+}
+constexpr int cmax(int a, int b) { return a > b ? a : b; }
+
+template <int BM, int BN, int WM, int WN, int WK, int G>
+__global__ __launch_bounds__(256) void k_conv_dgrad(DgradArgs p) {
+    __shared__ __attribute__((aligned(16))) float smem[dgrad_smem(BM, BN, WM, WN, WK, G)];
+    dgrad_body<BM, BN, WM, WN, WK, G>(p, blockIdx.x, blockIdx.y, blockIdx.z, smem);
+}
+
 // ---------------------------------------------------------------------------------
 // wgrad: dw[co][k] and db[co], reduction over m split across grid.z
 // ---------------------------------------------------------------------------------
@@ -439,22 +458,23 @@ struct WgradArgs {
 };
 
 template <int BI, int BJ, int WM, int WN, int WK, int G>
-__global__ __launch_bounds__(256) void k_conv_wgrad(WgradArgs p) {
+__device__ __forceinline__ void wgrad_body(const WgradArgs &p, const int bx, const int by,
+                                           const int bz, float *smem) {
     static_assert(WM * WN * WK == 4, "four waves");
     constexpr int AM = BI / (16 * WM), AN = BJ / (16 * WN);
     constexpr int P = (AM * AN == 1) ? 2 : 1;
     constexpr int QA = BI / 4, NPA = (32 * QA + 255) / 256, LDA = BI + 4;
     constexpr int QB = BJ / 4, NPB = (32 * QB + 255) / 256, LDB = BJ + 4;
-    __shared__ __attribute__((aligned(16))) float As[G][32 * LDA];
-    __shared__ __attribute__((aligned(16))) float Bs[G][32 * LDB];
-    __shared__ f32x4 red[WK > 1 ? (WK - 1) * WM * WN * AM * AN * 64 : 1];
+    float(*As)[32 * LDA] = reinterpret_cast<float(*)[32 * LDA]>(smem);
+    float(*Bs)[32 * LDB] = reinterpret_cast<float(*)[32 * LDB]>(smem + G * 32 * LDA);
+    f32x4 *red = reinterpret_cast<f32x4 *>(smem + G * 32 * LDA + G * 32 * LDB);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wk = wave % WK, wn = (wave / WK) % WN, wm = wave / (WK * WN);
-    const int i0 = blockIdx.x * BI, j0 = blockIdx.y * BJ;
+    const int i0 = bx * BI, j0 = by * BJ;
     const ConvGeom g = p.g;
     const int ohow = g.OH * g.OW, SC = g.S * g.C, WC = g.W * g.C;
     const int nch_total = (p.M + KC - 1) / KC;
-    const int c0 = blockIdx.z * p.cps;
+    const int c0 = bz * p.cps;
     const int c1 = min(c0 + p.cps, nch_total);
 
     int bkk[NPB], bcol[NPB], bq[NPB];
@@ -518,7 +538,7 @@ __global__ __launch_bounds__(256) void k_conv_wgrad(WgradArgs p) {
 #pragma unroll
             for (int pp = 0; pp < P; ++pp) acc[am][an][pp] = (f32x4){0.f, 0.f, 0.f, 0.f};
     float bsum = 0.f;
-    const bool do_bias = blockIdx.y == 0 && p.db != nullptr;
+    const bool do_bias = by == 0 && p.db != nullptr;
 
     auto compute = [&](int buf) {
 #pragma unroll
@@ -533,10 +553,10 @@ __global__ __launch_bounds__(256) void k_conv_wgrad(WgradArgs p) {
     };
     run_pipeline<Slot, G>(c0, c1, fetch, stash, compute);
     if (do_bias && tid < BI && i0 + tid < g.Cout)
-        p.db[(size_t)blockIdx.z * p.db_stride + i0 + tid] = bsum;
+        p.db[(size_t)bz * p.db_stride + i0 + tid] = bsum;
     fold_acc<AM, AN, P, WK, WM * WN>(acc, red, wm * WN + wn, wk, lane);
     if (wk != 0) return;
-    float *dw = p.dw + (size_t)blockIdx.z * p.dw_stride;
+    float *dw = p.dw + (size_t)bz * p.dw_stride;
 #pragma unroll
     for (int am = 0; am < AM; ++am)
 #pragma unroll
@@ -549,6 +569,36 @@ __global__ __launch_bounds__(256) void k_conv_wgrad(WgradArgs p) {
                 if (co < g.Cout) dw[(size_t)co * p.K + j] = acc[am][an][0][reg];
             }
         }
+}
+
+template <int BI, int BJ, int WM, int WN, int WK, int G>
+__global__ __launch_bounds__(256) void k_conv_wgrad(WgradArgs p) {
+    __shared__ __attribute__((aligned(16))) float smem[wgrad_smem(BI, BJ, WM, WN, WK, G)];
+    wgrad_body<BI, BJ, WM, WN, WK, G>(p, blockIdx.x, blockIdx.y, blockIdx.z, smem);
+}
+
+// Input gradient and weight gradient of one layer in ONE launch: both consume the same dy
+// and neither depends on the other.  At B = 32 each is a few hundred latency-bound
+// workgroups that leave most of every CU idle; side by side they overlap almost fully and
+// one launch boundary (and one cold start of the load pipeline) disappears per layer.  A
+// fork / join inside a captured graph costs ~8 us on this stack, so the fusion is by grid:
+// workgroups [0, n_dgrad) run the dgrad tile program, the rest the wgrad one.
+template <int DM, int DN, int DWM, int DWN, int DWK, int DG_, int WI, int WWM, int WWN, int WWK>
+__global__ __launch_bounds__(256) void k_conv_bwd(DgradArgs d, WgradArgs w, int dgx, int dgy, int dgz,
+                                                  int wgx, int wgy) {
+    // one LDS area, laid out by whichever tile program this workgroup runs
+    __shared__ __attribute__((aligned(16))) float
+        smem[cmax(dgrad_smem(DM, DN, DWM, DWN, DWK, DG_), wgrad_smem(WI, 32, WWM, WWN, WWK, 4))];
+    const int b = blockIdx.x;
+    const int nd = dgx * dgy * dgz;
+    if (b < nd) {
+        const int bx = b % dgx, r = b / dgx;
+        dgrad_body<DM, DN, DWM, DWN, DWK, DG_>(d, bx, r % dgy, r / dgy, smem);
+    } else {
+        const int c = b - nd;
+        const int bx = c % wgx, r = c / wgx;
+        wgrad_body<WI, 32, WWM, WWN, WWK, 4>(w, bx, r % wgy, r / wgy, smem);
+    }
 }
 
 // ---------------------------------------------------------------------------------
@@ -783,42 +833,75 @@ extern "C" int pfrl_conv2d_nhwc_fwd(const float *x, const float *w, const float 
     PFRL_LAUNCH_CHECK();
 }
 
-extern "C" int pfrl_conv2d_nhwc_bwd_data(const float *dy, const float *dy_mask, const float *w,
-                                         const float *a_prev, float *dx, int32_t N, int32_t H, int32_t W,
-                                         int32_t C, int32_t Cout, int32_t R, int32_t S, int32_t stride,
-                                         int32_t perm_p, int32_t perm_c, void *stream) {
+static int make_dgrad_args(DgradArgs &a, const float *dy, const float *dy_mask, const float *w,
+                           const float *a_prev, float *dx, int32_t N, int32_t H, int32_t W, int32_t C,
+                           int32_t Cout, int32_t R, int32_t S, int32_t stride, int32_t perm_p,
+                           int32_t perm_c) {
     ConvGeom g{N, H, W, C, Cout, R, S, stride, (H - R) / stride + 1, (W - S) / stride + 1};
     PFRL_CHECK_ARG(g.OH >= 1 && g.OW >= 1 && Cout % KC == 0 && C % 16 == 0 && R % stride == 0 &&
                        S % stride == 0 && H % stride == 0 && W % stride == 0,
                    "pfrl_conv2d_nhwc_bwd_data: unsupported geometry");
     PFRL_CHECK_ARG(perm_p == 0 || (H == 1 && W == 1 && perm_p * perm_c == C),
                    "pfrl_conv2d_nhwc_bwd_data: bad permutation");
-    DgradArgs a;
     a.dy = dy; a.dymask = dy_mask; a.w = w; a.aprev = a_prev; a.dx = dx; a.g = g;
     a.AH = H / stride; a.AW = W / stride;
     a.Mc = N * a.AH * a.AW;
     a.TH = R / stride; a.TW = S / stride;
     a.K = a.TH * a.TW * Cout;
     a.permP = perm_p; a.permC = perm_c;
+    return 0;
+}
+
+static int make_wgrad_args(WgradArgs &a, const float *dy, const float *dy_mask, const float *x,
+                           float *dw_part, float *db_part, int64_t dw_stride, int64_t db_stride,
+                           int32_t N, int32_t H, int32_t W, int32_t C, int32_t Cout, int32_t R,
+                           int32_t S, int32_t stride, int32_t splits) {
+    ConvGeom g{N, H, W, C, Cout, R, S, stride, (H - R) / stride + 1, (W - S) / stride + 1};
+    PFRL_CHECK_ARG(geom_ok(g) && Cout % 16 == 0, "pfrl_conv2d_nhwc_bwd_weight: unsupported geometry");
+    PFRL_CHECK_ARG(splits >= 1, "pfrl_conv2d_nhwc_bwd_weight: splits >= 1");
+    a.dy = dy; a.dymask = dy_mask; a.x = x; a.dw = dw_part; a.db = db_part;
+    a.dw_stride = dw_stride; a.db_stride = db_stride; a.g = g;
+    a.M = N * g.OH * g.OW;
+    a.K = R * S * C;
+    const int nch = (a.M + KC - 1) / KC;
+    a.cps = (nch + splits - 1) / splits;
+    return 0;
+}
+
+// tile program of the input-gradient kernel for a problem: 0 = <64,64> 1 = <64,32> (throughput
+// tiles, stages of 2), 2 = <32,32,G4>, 3 = <16,32,G8>, 4 = <16,32,G4>, 5 = <32,16,G4>
+static int dgrad_program(const DgradArgs &a, int z) {
+    const int C = a.g.C;
+    auto blocks = [&](int bm, int bn) { return (long long)((a.Mc + bm - 1) / bm) * (C / bn) * z; };
+    if (C % 32 != 0) return 5;
+    if (C % 64 == 0 && blocks(64, 64) >= 1024) return 0;
+    if (blocks(64, 32) >= 1024) return 1;
+    if (blocks(32, 32) >= 384) return 2;
+    // few workgroups: 32 input channels per workgroup (whole 128 B lines of the weight rows),
+    // long reductions in stages of 8 chunks
+    return a.K / KC >= 12 ? 3 : 4;
+}
+
+extern "C" int pfrl_conv2d_nhwc_bwd_data(const float *dy, const float *dy_mask, const float *w,
+                                         const float *a_prev, float *dx, int32_t N, int32_t H, int32_t W,
+                                         int32_t C, int32_t Cout, int32_t R, int32_t S, int32_t stride,
+                                         int32_t perm_p, int32_t perm_c, void *stream) {
+    DgradArgs a;
+    if (int rc = make_dgrad_args(a, dy, dy_mask, w, a_prev, dx, N, H, W, C, Cout, R, S, stride, perm_p,
+                                 perm_c))
+        return rc;
     hipStream_t st = (hipStream_t)stream;
     const unsigned z = (unsigned)(stride * stride);
-    auto blocks = [&](int bm, int bn) { return (long long)((a.Mc + bm - 1) / bm) * (C / bn) * z; };
 #define DG(BM, BN, WM, WN, WK, G)                                                                    \
     hipLaunchKernelGGL((k_conv_dgrad<BM, BN, WM, WN, WK, G>), dim3((a.Mc + BM - 1) / BM, C / BN, z), \
                        dim3(256), 0, st, a)
-    if (C % 32 != 0) {
-        DG(32, 16, 2, 1, 2, 4);
-    } else if (C % 64 == 0 && blocks(64, 64) >= 1024) {
-        DG(64, 64, 2, 2, 1, 2);
-    } else if (blocks(64, 32) >= 1024) {
-        DG(64, 32, 2, 2, 1, 2);
-    } else if (blocks(32, 32) >= 384) {
-        DG(32, 32, 2, 2, 1, 4);
-    } else if (a.K / KC >= 12) {
-        // 32 input channels per workgroup: whole 128 B lines of the weight rows
-        DG(16, 32, 1, 2, 2, 8);
-    } else {
-        DG(16, 32, 1, 2, 2, 4);
+    switch (dgrad_program(a, (int)z)) {
+        case 0: DG(64, 64, 2, 2, 1, 2); break;
+        case 1: DG(64, 32, 2, 2, 1, 2); break;
+        case 2: DG(32, 32, 2, 2, 1, 4); break;
+        case 3: DG(16, 32, 1, 2, 2, 8); break;
+        case 4: DG(16, 32, 1, 2, 2, 4); break;
+        default: DG(32, 16, 2, 1, 2, 4); break;
     }
 #undef DG
     PFRL_LAUNCH_CHECK();
@@ -829,23 +912,63 @@ extern "C" int pfrl_conv2d_nhwc_bwd_weight(const float *dy, const float *dy_mask
                                            int64_t db_stride, int32_t N, int32_t H, int32_t W, int32_t C,
                                            int32_t Cout, int32_t R, int32_t S, int32_t stride,
                                            int32_t splits, void *stream) {
-    ConvGeom g{N, H, W, C, Cout, R, S, stride, (H - R) / stride + 1, (W - S) / stride + 1};
-    PFRL_CHECK_ARG(geom_ok(g) && Cout % 16 == 0, "pfrl_conv2d_nhwc_bwd_weight: unsupported geometry");
-    PFRL_CHECK_ARG(splits >= 1, "pfrl_conv2d_nhwc_bwd_weight: splits >= 1");
     WgradArgs a;
-    a.dy = dy; a.dymask = dy_mask; a.x = x; a.dw = dw_part; a.db = db_part;
-    a.dw_stride = dw_stride; a.db_stride = db_stride; a.g = g;
-    a.M = N * g.OH * g.OW;
-    a.K = R * S * C;
-    const int nch = (a.M + KC - 1) / KC;
-    a.cps = (nch + splits - 1) / splits;
+    if (int rc = make_wgrad_args(a, dy, dy_mask, x, dw_part, db_part, dw_stride, db_stride, N, H, W, C,
+                                 Cout, R, S, stride, splits))
+        return rc;
     hipStream_t st = (hipStream_t)stream;
     if (Cout % 32 == 0)
-        hipLaunchKernelGGL((k_conv_wgrad<32, 32, 2, 2, 1, 4>), dim3(Cout / 32, a.K / 32, splits), dim3(256),
-                           0, st, a);
+        hipLaunchKernelGGL((k_conv_wgrad<32, 32, 2, 2, 1, 4>), dim3(Cout / 32, a.K / 32, splits),
+                           dim3(256), 0, st, a);
     else
-        hipLaunchKernelGGL((k_conv_wgrad<16, 32, 1, 2, 2, 4>), dim3(Cout / 16, a.K / 32, splits), dim3(256),
-                           0, st, a);
+        hipLaunchKernelGGL((k_conv_wgrad<16, 32, 1, 2, 2, 4>), dim3(Cout / 16, a.K / 32, splits),
+                           dim3(256), 0, st, a);
+    PFRL_LAUNCH_CHECK();
+}
+
+// Both gradients of one layer in one launch (k_conv_bwd).  The dgrad arguments describe the
+// layer as pfrl_conv2d_nhwc_bwd_data does, the wgrad arguments as pfrl_conv2d_nhwc_bwd_weight;
+// dy / dy_mask are shared.  Minibatch-sized problems only (the small tile programs); larger
+// ones return PFRL_ERR_ARG and the caller issues the two launches.
+extern "C" int pfrl_conv2d_nhwc_bwd(const float *dy, const float *dy_mask, const float *w,
+                                    const float *a_prev, const float *x, float *dx, float *dw_part,
+                                    float *db_part, int64_t dw_stride, int64_t db_stride, int32_t N,
+                                    int32_t H, int32_t W, int32_t C, int32_t Cout, int32_t R, int32_t S,
+                                    int32_t stride, int32_t perm_p, int32_t perm_c, int32_t splits,
+                                    void *stream) {
+    DgradArgs d;
+    WgradArgs wa;
+    if (int rc = make_dgrad_args(d, dy, dy_mask, w, a_prev, dx, N, H, W, C, Cout, R, S, stride, perm_p,
+                                 perm_c))
+        return rc;
+    if (int rc = make_wgrad_args(wa, dy, dy_mask, x, dw_part, db_part, dw_stride, db_stride, N, H, W, C,
+                                 Cout, R, S, stride, splits))
+        return rc;
+    const int z = stride * stride;
+    const int prog = dgrad_program(d, z);
+    PFRL_CHECK_ARG(prog >= 2, "pfrl_conv2d_nhwc_bwd: problem too large for the fused launch");
+    hipStream_t st = (hipStream_t)stream;
+    const bool w32 = Cout % 32 == 0;
+    const int wgx = w32 ? Cout / 32 : Cout / 16, wgy = wa.K / 32;
+    const int nw = wgx * wgy * splits;
+#define BWD(DM, DN, DWM, DWN, DWK, DGG)                                                              \
+    do {                                                                                             \
+        const int dgx = (d.Mc + DM - 1) / DM, dgy = C / DN;                                          \
+        const unsigned grid = (unsigned)(dgx * dgy * z + nw);                                        \
+        if (w32)                                                                                     \
+            hipLaunchKernelGGL((k_conv_bwd<DM, DN, DWM, DWN, DWK, DGG, 32, 2, 2, 1>), dim3(grid),    \
+                               dim3(256), 0, st, d, wa, dgx, dgy, z, wgx, wgy);                      \
+        else                                                                                         \
+            hipLaunchKernelGGL((k_conv_bwd<DM, DN, DWM, DWN, DWK, DGG, 16, 1, 2, 2>), dim3(grid),    \
+                               dim3(256), 0, st, d, wa, dgx, dgy, z, wgx, wgy);                      \
+    } while (0)
+    switch (prog) {
+        case 2: BWD(32, 32, 2, 2, 1, 4); break;
+        case 3:   // (stages of 4 here: the LDS budget decides how many workgroups share a CU)
+        case 4: BWD(16, 32, 1, 2, 2, 4); break;
+        default: BWD(32, 16, 2, 1, 2, 4); break;
+    }
+#undef BWD
     PFRL_LAUNCH_CHECK();
 }
 

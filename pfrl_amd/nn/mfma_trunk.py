@@ -133,6 +133,23 @@ def _wgrad_splits(M, Cout, K):
     return _ceil_div(nch, cps)
 
 
+_FUSE_BWD = os.environ.get("PFRL_FUSE_BWD", "1") != "0"
+
+
+def _fused_bwd_ok(N, H, W, C, ST):
+    """Both gradients of a layer in one launch: only where the input-gradient kernel runs
+    one of its small tile programs (the rule of dgrad_program() in csrc/qnet.hip)."""
+    if not _FUSE_BWD:
+        return False
+    mc = N * (H // ST) * (W // ST)
+    z = ST * ST
+    if C % 32 == 0 and _ceil_div(mc, 64) * (C // 32) * z >= 1024:
+        return False
+    if C % 64 == 0 and _ceil_div(mc, 64) * (C // 64) * z >= 1024:
+        return False
+    return True
+
+
 def _reduce(tasks):
     """tasks: (part, out, bias or None, stride, n, splits, ncol, relu)"""
     n = len(tasks)
@@ -212,14 +229,22 @@ class _Trunk(torch.autograd.Function):
         F, Kf = wf.shape
         last = specs[-1]
         P = last.OH * last.OW
-        # hidden linear layer: input gradient straight into NHWC rows of the last conv
+        # hidden linear layer: input gradient straight into NHWC rows of the last conv, and
+        # the weight gradient, in one launch when the batch is minibatch-sized
         dy = torch.empty((N, last.OH, last.OW, last.Cout), dtype=torch.float32, device=dev)
-        check(lib.pfrl_conv2d_nhwc_bwd_data(_p(dh), _p(out), _p(wf), _p(acts[-1]), _p(dy), N, 1, 1, Kf,
-                                            F, 1, 1, 1, P, last.Cout, _stream()), "linear_bwd_data")
         dwf = torch.empty_like(wf)
         dbf = torch.empty(F, dtype=torch.float32, device=dev)
-        check(lib.pfrl_conv2d_nhwc_bwd_weight(_p(dh), _p(out), _p(acts[-1]), _p(dwf), _p(dbf), 0, 0, N,
-                                              1, 1, Kf, F, 1, 1, 1, 1, _stream()), "linear_bwd_weight")
+        if _fused_bwd_ok(N, 1, 1, Kf, 1):
+            check(lib.pfrl_conv2d_nhwc_bwd(_p(dh), _p(out), _p(wf), _p(acts[-1]), _p(acts[-1]), _p(dy),
+                                           _p(dwf), _p(dbf), 0, 0, N, 1, 1, Kf, F, 1, 1, 1, P,
+                                           last.Cout, 1, _stream()), "linear_bwd")
+        else:
+            check(lib.pfrl_conv2d_nhwc_bwd_data(_p(dh), _p(out), _p(wf), _p(acts[-1]), _p(dy), N, 1, 1,
+                                                Kf, F, 1, 1, 1, P, last.Cout, _stream()),
+                  "linear_bwd_data")
+            check(lib.pfrl_conv2d_nhwc_bwd_weight(_p(dh), _p(out), _p(acts[-1]), _p(dwf), _p(dbf), 0, 0,
+                                                  N, 1, 1, Kf, F, 1, 1, 1, 1, _stream()),
+                  "linear_bwd_weight")
         grads = [None] * (2 * L) + [dwf, dbf]
         tasks = []
         for i in range(L - 1, -1, -1):
@@ -239,10 +264,17 @@ class _Trunk(torch.autograd.Function):
                 pw, pb, st = part, part[nW:], stride
                 tasks.append((part, dw, None, stride, nW, splits, 4, 0))
                 tasks.append((pb, db, None, stride, sp.Cout, splits, 4, 0))
+            grads[2 * i], grads[2 * i + 1] = dw, db
+            if i > 0 and _fused_bwd_ok(N, sp.H, sp.W, sp.C, sp.ST):
+                dx = torch.empty((N, sp.H, sp.W, sp.C), dtype=torch.float32, device=dev)
+                check(lib.pfrl_conv2d_nhwc_bwd(_p(dy), None, _p(w), _p(below), _p(below), _p(dx), _p(pw),
+                                               _p(pb), st, st, N, sp.H, sp.W, sp.C, sp.Cout, sp.R, sp.S,
+                                               sp.ST, 0, 0, splits, _stream()), "conv2d_nhwc_bwd")
+                dy = dx
+                continue
             check(lib.pfrl_conv2d_nhwc_bwd_weight(_p(dy), None, _p(below), _p(pw), _p(pb), st, st, N,
                                                   sp.H, sp.W, sp.C, sp.Cout, sp.R, sp.S, sp.ST, splits,
                                                   _stream()), "conv2d_nhwc_bwd_weight")
-            grads[2 * i], grads[2 * i + 1] = dw, db
             if i > 0:
                 dx = torch.empty((N, sp.H, sp.W, sp.C), dtype=torch.float32, device=dev)
                 check(lib.pfrl_conv2d_nhwc_bwd_data(_p(dy), None, _p(w), _p(below), _p(dx), N, sp.H,
