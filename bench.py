@@ -594,7 +594,7 @@ def data_path_only(args, device, agent, env, rbuf, obss, steps):
                       target_update_interval=3 * 10 ** 4, clip_delta=True,
                       update_interval=args.update_interval, minibatch_size=args.minibatch,
                       batch_accumulator="sum", phi=agent.phi)
-    stub.step_fused_chunks = agent.step_fused_chunks
+    stub.step_fused_chunks = ()   # nothing to overlap host preparation with: one range
     stub.t = agent.t
     for _ in range(3):
         obss = one_step(stub, env, obss, N)

@@ -122,7 +122,7 @@ class DQN(agent.AttributeSavingMixin, agent.BatchAgent):
                  batch_accumulator="mean", episodic_update_len=None, logger=getLogger(__name__),
                  batch_states=batch_states, recurrent=False, max_grad_norm=None,
                  use_graphs=None, step_fused_gather=None, batch_target_pass=None,
-                 fused_td_loss=True, replay_overlap=None, step_fused_chunks=(0.125,)):
+                 fused_td_loss=True, replay_overlap=None, step_fused_chunks=(0.1, 0.4)):
         self.model = q_function
         if gpu is not None and gpu >= 0:
             assert torch.cuda.is_available()

@@ -65,7 +65,7 @@ def _same_rng_state(a, b):
 
 def test_dqn_bench_path_minibatches_match_oracle():
     """BASELINE configs[1] as bench.py builds it (256 envs, 84x84x4, Nature CNN channels_last,
-    step_fused_chunks=(0.125,), B=32, update_interval=4): for checked steps after every ring
+    step_fused_chunks=(0.1, 0.4), B=32, update_interval=4): for checked steps after every ring
     has wrapped, all 64 minibatches of the step -- index sets, action / reward / terminal /
     discount and the gathered fp32 state / next_state stacks -- equal the oracle bit for bit,
     the NumPy stream ends at the same position, and the first TD loss of the step agrees with
@@ -77,7 +77,7 @@ def test_dqn_bench_path_minibatches_match_oracle():
     N, B, CAP, START = 256, 32, 1500, 1024
     args = _bench_args(capacity=CAP, frame_slots=6144, slack=512, replay_start=START)
     agent, env, rbuf = bench.build_agent(args, dev, 0)
-    assert agent.step_fused_chunks == (0.125,) and agent.step_fused_gather and agent.use_graphs
+    assert agent.step_fused_chunks == (0.1, 0.4) and agent.step_fused_gather and agent.use_graphs
     gamma = agent.gamma
 
     fetched, keep = [], [False]
