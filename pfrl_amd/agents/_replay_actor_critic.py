@@ -156,9 +156,70 @@ class ReplayActorCritic(AttributeSavingMixin, BatchAgent):
         self.batch_last_action = list(actions)
         return actions
 
+    # -- step-fused path (uniform device replay) ---------------------------------------------
+    step_fused = True
+
+    def _step_fusable(self):
+        """All updates of one batched env step from ONE gather launch and ONE captured
+        graph: the index sets of uniform replay depend only on len(buffer) and the NumPy
+        stream, in order (the same argument as DQN._batch_observe_train_fused), and nothing
+        else may have to happen on the host between the updates."""
+        rbuf = self.replay_buffer
+        return (self.step_fused and self.use_graphs
+                and getattr(rbuf, "supports_lookahead", False)
+                and type(self)._on_env_step is ReplayActorCritic._on_env_step)
+
+    def _append(self, i, batch_obs, batch_reward, batch_done, batch_reset):
+        rbuf = self.replay_buffer
+        if self.batch_last_obs[i] is not None:
+            assert self.batch_last_action[i] is not None
+            rbuf.append(state=self.batch_last_obs[i], action=self.batch_last_action[i],
+                        reward=batch_reward[i], next_state=batch_obs[i], next_action=None,
+                        is_state_terminal=batch_done[i], env_id=i)
+            if batch_reset[i] or batch_done[i]:
+                self.batch_last_obs[i] = None
+                self.batch_last_action[i] = None
+                rbuf.stop_current_episode(env_id=i)
+
+    def _batch_observe_fused(self, batch_obs, batch_reward, batch_done, batch_reset):
+        """The per-env loop below (reference soft_actor_critic.py:354-374, td3.py:283-303)
+        reorganised for the device: appends and index draws in the reference's order, one
+        fused gather of every minibatch of the step (U * B entries: HBM-bound instead of U
+        small launches), then the U updates replayed as one graph."""
+        rbuf, up = self.replay_buffer, self.replay_updater
+        t0 = self.t
+        plan = []
+        for i in range(len(batch_obs)):
+            self._append(i, batch_obs, batch_reward, batch_done, batch_reset)
+            if len(rbuf) >= up.replay_start_size and (t0 + i + 1) % up.update_interval == 0:
+                for _ in range(up.n_times_update):
+                    plan.append(rbuf.lookahead_sample(up.batchsize))
+        self.t = t0 + len(batch_obs)
+        if not plan:
+            return
+        big = rbuf.fetch_many(plan, self.phi, self.gamma)
+        variants = []
+        for _ in plan:          # host counters only: what each update is going to be
+            v = self._variant()
+            variants.append(v)
+            self._after_update(v)
+        if self._captured is None:
+            from pfrl_amd.agents.graphed_update import CapturedStep
+
+            self._captured = CapturedStep(self._update_core, self._graph_modules(),
+                                          self._graph_optimizers(), self.device)
+        tensors = {k: v for k, v in big.items() if isinstance(v, torch.Tensor)}
+        outs = self._captured.run_range(tensors, variants)
+        # the graph owns (and overwrites) its outputs: one copy per distinct stats layout
+        for out in outs:
+            flat = out["stats"].clone()
+            self._record_stats(dict(zip(out["names"], torch.split(flat, out["sizes"]))))
+
     def batch_observe(self, batch_obs, batch_reward, batch_done, batch_reset):
         if not self.training:
             return
+        if self._step_fusable():
+            return self._batch_observe_fused(batch_obs, batch_reward, batch_done, batch_reset)
         rbuf = self.replay_buffer
         for i in range(len(batch_obs)):
             self.t += 1

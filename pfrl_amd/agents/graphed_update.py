@@ -403,9 +403,12 @@ class CapturedStep:
             out.extend(b for b in m.buffers())
         return out
 
-    def _capture(self, batch, variant=None):
+    def _capture(self, batch, variant=None, step=None, warm=None):
         dev = self.device
-        step = (lambda: self.fn(batch)) if variant is None else (lambda: self.fn(batch, variant))
+        if step is None:
+            step = (lambda: self.fn(batch)) if variant is None else (lambda: self.fn(batch, variant))
+        if warm is None:
+            warm = step
         for opt in self.optimizers:
             if not _make_capturable(opt, dev):
                 raise RuntimeError("optimizer %s has no capturable mode" % type(opt))
@@ -439,7 +442,7 @@ class CapturedStep:
         try:
             with torch.cuda.stream(side), _no_distribution_validation():
                 for _ in range(2):
-                    step()
+                    warm()
             cur.wait_stream(side)
             for opt in self.optimizers:
                 _make_capturable(opt, dev)  # state created by the warm-up
@@ -454,6 +457,31 @@ class CapturedStep:
             cur.wait_stream(side)
             restore()
         return g, out
+
+    def run_range(self, big, variants):
+        """``big``: dict of tensors with a leading update axis U (one fused gather for all
+        updates of a batched env step); ``variants``: the U variants in order.  ONE graph
+        holds the U steps back to back.  Returns the list of the U ``fn`` results (tensors
+        owned by the graph)."""
+        U = len(variants)
+        key = ("range", self._key(big), tuple(variants))
+        entry = self.graphs.get(key)
+        if entry is None:
+            if len(self.graphs) >= self.max_graphs:
+                raise RuntimeError("too many distinct minibatch buffers for graph capture")
+
+            def slice_of(p):
+                return {k: v[p] for k, v in big.items()}
+
+            def call(p):
+                v = variants[p]
+                return self.fn(slice_of(p)) if v is None else self.fn(slice_of(p), v)
+
+            entry = self._capture(None, None, step=lambda: [call(p) for p in range(U)],
+                                  warm=lambda: call(0))
+            self.graphs[key] = entry
+        entry[0].replay()
+        return entry[1]
 
     def run(self, batch, variant=None):
         """``variant`` (hashable) selects between differently shaped steps over the

@@ -303,9 +303,13 @@ __global__ __launch_bounds__(kThreads) void k_batch_experiences_nhwc4(
     uint8_t *__restrict__ out_next, ActT *__restrict__ out_action, float *__restrict__ out_reward,
     float *__restrict__ out_terminal, float *__restrict__ out_discount, int tiles) {
     const int64_t nt_blocks = 2 * B * tiles;
-    if ((int64_t)blockIdx.x < nt_blocks) {
-        const int64_t ot = blockIdx.x / tiles;               // observation index in [0, 2B)
-        const int tile = (int)(blockIdx.x - ot * tiles);
+    // scalar-collapse workgroups (serial chains of dependent loads) come FIRST in the grid so
+    // that they run under the streaming tiles instead of forming the tail of the launch
+    const int64_t scalar_blocks = (int64_t)gridDim.x - nt_blocks;
+    if ((int64_t)blockIdx.x >= scalar_blocks) {
+        const int64_t tb = (int64_t)blockIdx.x - scalar_blocks;
+        const int64_t ot = tb / tiles;                       // observation index in [0, 2B)
+        const int tile = (int)(tb - ot * tiles);
         const bool is_next = ot >= B;
         const int64_t b = is_next ? ot - B : ot;
         const int64_t e = entry_slots[b];
@@ -326,7 +330,7 @@ __global__ __launch_bounds__(kThreads) void k_batch_experiences_nhwc4(
                                                divisor);
         return;
     }
-    const int64_t b = ((int64_t)blockIdx.x - nt_blocks) * kThreads + threadIdx.x;
+    const int64_t b = (int64_t)blockIdx.x * kThreads + threadIdx.x;
     if (b >= B) return;
     const int64_t e = entry_slots[b];
     const int len = tab.e_len[e];
@@ -384,6 +388,82 @@ extern "C" int pfrl_entries_append(const pfrl_table_t *tab, int64_t n_rows, cons
     PFRL_LAUNCH_CHECK();
 }
 
+// f32 vector observations of a few KB (MuJoCo-shaped: 376 floats): one WAVE per output frame
+// instead of one workgroup (94 of 256 lanes busy, and a three-deep index chain per
+// workgroup).  Each wave resolves kFPW frames, issues all their loads, then stores; the
+// scalar collapse rides in extra workgroups as above.  frame_bytes % 16 == 0.
+constexpr int kFPW = 4;
+
+template <typename ActT>
+__global__ __launch_bounds__(kThreads) void k_batch_experiences_f32_small(
+    pfrl_table_t tab, const uint8_t *__restrict__ frames, int64_t frame_bytes,
+    const int32_t *__restrict__ entry_slots, int64_t B, GammaPow gp, uint8_t *__restrict__ out_state,
+    uint8_t *__restrict__ out_next, ActT *__restrict__ out_action, float *__restrict__ out_reward,
+    float *__restrict__ out_terminal, float *__restrict__ out_discount, int frame_blocks) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // the scalar collapse (a serial chain of dependent loads per thread, 17 strided action
+    // floats) goes FIRST in the grid: dispatched last it would be the tail of the launch
+    const int scalar_blocks = (int)gridDim.x - frame_blocks;
+    if ((int)blockIdx.x < scalar_blocks) {
+        const int64_t b = (int64_t)blockIdx.x * kThreads + tid;
+        if (b >= B) return;
+        const int64_t e = entry_slots[b];
+        const int len = tab.e_len[e];
+        double acc = 0.0;
+        bool any = false;
+        for (int i = 0; i < len; ++i) {
+            const int64_t t = tab.e_tids[e * tab.n + i];
+            acc = __dadd_rn(acc, __dmul_rn(gp.g[i], tab.t_reward[t]));
+            any |= tab.t_terminal[t] != 0;
+        }
+        out_reward[b] = (float)acc;
+        out_terminal[b] = any ? 1.0f : 0.0f;
+        out_discount[b] = (float)gp.g[len];
+        const int64_t t0 = tab.e_tids[e * tab.n];
+        const int ad = tab.act_dim > 0 ? tab.act_dim : 1;
+        const ActT *src = reinterpret_cast<const ActT *>(tab.t_action);
+        for (int i = 0; i < ad; ++i) out_action[b * ad + i] = src[t0 * ad + i];
+        return;
+    }
+    const int64_t nf = B * tab.k, total = 2 * nf;
+    const int nv = (int)(frame_bytes >> 4);            // uint4 per frame
+    const int64_t f0 = ((int64_t)(blockIdx.x - scalar_blocks) * 4 + wave) * kFPW;
+    const uint4 *src[kFPW];
+    uint4 *dst[kFPW];
+#pragma unroll
+    for (int u = 0; u < kFPW; ++u) {
+        const int64_t f = f0 + u < total ? f0 + u : total - 1;
+        const bool is_next = f >= nf;
+        const int64_t ff = is_next ? f - nf : f;
+        const int64_t b = ff / tab.k;
+        const int j = (int)(ff - b * tab.k);
+        const int64_t e = entry_slots[b];
+        int64_t slot;
+        if (!is_next) {
+            slot = tab.t_state_ref[(int64_t)tab.e_tids[e * tab.n] * tab.k + j];
+        } else {
+            const int len = tab.e_len[e];
+            slot = tab.t_next_ref[(int64_t)tab.e_tids[e * tab.n + len - 1] * tab.k + j];
+        }
+        src[u] = reinterpret_cast<const uint4 *>(frames + slot * frame_bytes);
+        dst[u] = reinterpret_cast<uint4 *>((is_next ? out_next : out_state) + ff * frame_bytes);
+    }
+    for (int base = 0; base < nv; base += 128) {
+        uint4 v[kFPW][2];
+#pragma unroll
+        for (int u = 0; u < kFPW; ++u)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) v[u][h] = src[u][min(base + h * 64 + lane, nv - 1)];
+#pragma unroll
+        for (int u = 0; u < kFPW; ++u)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int i = base + h * 64 + lane;
+                if (i < nv && f0 + u < total) dst[u][i] = v[u][h];
+            }
+    }
+}
+
 template <int MODE, bool NT>
 static void launch_be2(const pfrl_table_t *tab, const void *frames, int64_t frame_bytes,
                        float divisor, const int32_t *entry_slots, int64_t B, const GammaPow &gp,
@@ -393,6 +473,26 @@ static void launch_be2(const pfrl_table_t *tab, const void *frames, int64_t fram
     const unsigned blocks = (unsigned)(2 * B * tab->k + (B + kThreads - 1) / kThreads);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     pfrl_profile_events(PFRL_PROFILE_BATCH_EXPERIENCES, B, &e0, &e1);
+    if constexpr (MODE == 2) {
+        if ((frame_bytes & 15) == 0 && frame_bytes <= 8192 && 2 * B * tab->k >= 4096) {
+            const int fb = (int)((2 * B * tab->k + 4 * kFPW - 1) / (4 * kFPW));
+            const unsigned gb = (unsigned)(fb + (B + kThreads - 1) / kThreads);
+            if (tab->act_dim > 0)
+                hipExtLaunchKernelGGL((k_batch_experiences_f32_small<float>), dim3(gb), dim3(kThreads),
+                                      0, stream, e0, e1, 0, *tab, (const uint8_t *)frames, frame_bytes,
+                                      entry_slots, B, gp, (uint8_t *)out_state,
+                                      (uint8_t *)out_next_state, (float *)out_action, out_reward,
+                                      out_terminal, out_discount, fb);
+            else
+                hipExtLaunchKernelGGL((k_batch_experiences_f32_small<int64_t>), dim3(gb),
+                                      dim3(kThreads), 0, stream, e0, e1, 0, *tab,
+                                      (const uint8_t *)frames, frame_bytes, entry_slots, B, gp,
+                                      (uint8_t *)out_state, (uint8_t *)out_next_state,
+                                      (int64_t *)out_action, out_reward, out_terminal, out_discount,
+                                      fb);
+            return;
+        }
+    }
     if constexpr (MODE != 2) {
         const int P = pfrl_gather_persist_blocks();
         if (P > 0 && (frame_bytes >> 2) <= kThreads * kUnroll && 2 * B * tab->k > P) {

@@ -465,19 +465,24 @@ def _run_sac(gpu, noise=False, **agent_kw):
         return a
 
     ag.batch_act = spy_act
-    orig_update = ag.update
+    # every path (eager, one graph per update, all updates of a step in one graph) hands each
+    # update's statistics to _record_stats, one value per name and update
+    seen = {"loss1": [], "loss2": []}
+    orig_record = ag._record_stats
 
-    def spy_update(exps, errors_out=None):
-        orig_update(exps, errors_out)
-        q_losses.append([float(ag.q_func1_loss_record.values()[-1]),
-                         float(ag.q_func2_loss_record.values()[-1])])
+    def spy_record(st):
+        orig_record(st)
+        for name in seen:
+            if name in st:
+                seen[name].extend(float(v) for v in st[name].detach().reshape(-1).cpu().numpy())
 
-    ag.replay_updater.update_func = spy_update
+    ag._record_stats = spy_record
     import contextlib
 
     with (contextlib.nullcontext() if noise else _NoNoise()):
         pfrl.experiments.train_agent_batch(ag, env, 240, tempfile.mkdtemp())
     flat = lambda m: np.concatenate([p.detach().cpu().numpy().ravel() for p in m.parameters()])
+    q_losses = list(zip(seen["loss1"], seen["loss2"]))
     return dict(actions=np.asarray(actions), q_losses=np.asarray(q_losses),
                 policy_params=flat(policy), q1_params=flat(q1),
                 target_q1_params=flat(ag.target_q_func1), rbuf=rbuf, agent=ag)
@@ -567,8 +572,7 @@ def _run_det_agent(kind, gpu, **agent_kw):
                         soft_update_tau=5e-3, burnin_action_func=burnin, policy_update_delay=2,
                         target_policy_smoothing_func=_shifted_smoothing, **agent_kw)
         crit, tgt = q1, ag.target_q_func1
-        loss_of = lambda: [float(ag._records["loss1"].values()[-1]),
-                           float(ag._records["loss2"].values()[-1])]
+        loss_names = ("loss1", "loss2")
     else:
         q1 = q()
         opts = [torch.optim.SGD(m.parameters(), lr=1e-2) for m in (policy, q1)]
@@ -577,8 +581,7 @@ def _run_det_agent(kind, gpu, **agent_kw):
                          target_update_interval=7, target_update_method="soft",
                          soft_update_tau=5e-2, burnin_action_func=burnin, **agent_kw)
         crit, tgt = q1, ag.target_q_function
-        loss_of = lambda: [float(ag._records["critic_loss"].values()[-1]),
-                           float(ag._records["actor_loss"].values()[-1])]
+        loss_names = ("critic_loss", "actor_loss")
     actions, losses = [], []
     orig_act = ag.batch_act
 
@@ -588,14 +591,20 @@ def _run_det_agent(kind, gpu, **agent_kw):
         return a
 
     ag.batch_act = spy_act
-    orig_update = ag.update
+    # both losses are produced by every update; every path (eager, one graph per update, all
+    # updates of a step in one graph) hands them to _record_stats
+    seen = {name: [] for name in loss_names}
+    orig_record = ag._record_stats
 
-    def spy_update(exps, errors_out=None):
-        orig_update(exps, errors_out)
-        losses.append(loss_of())
+    def spy_record(st):
+        orig_record(st)
+        for name in loss_names:
+            if name in st:
+                seen[name].extend(float(v) for v in st[name].detach().reshape(-1).cpu().numpy())
 
-    ag.replay_updater.update_func = spy_update
+    ag._record_stats = spy_record
     pfrl.experiments.train_agent_batch(ag, env, 260, tempfile.mkdtemp())
+    losses = list(zip(*(seen[n] for n in loss_names)))
     flat = lambda m: np.concatenate([p.detach().cpu().numpy().ravel() for p in m.parameters()])
     return dict(actions=np.asarray(actions), losses=np.asarray(losses),
                 policy_params=flat(policy), critic_params=flat(crit),

@@ -172,6 +172,20 @@ def test_device_replay_vector_obs_continuous_actions():
     want = oracle.batch_experiences_scalars([[i] for i in ids], rew, term, 0.99, 1)
     np.testing.assert_array_equal(be["reward"].cpu().numpy(), want["reward"])
     np.testing.assert_array_equal(be["is_state_terminal"].cpu().numpy(), want["is_state_terminal"])
+    # all minibatches of a batched env step in one launch (SAC / TD3 step-fused path): 17 x 256
+    # entries take the wave-per-frame kernel; every value against the host arrays / the oracle
+    sets = [rbuf.lookahead_sample(B) for _ in range(17)]
+    big = rbuf.fetch_many(sets, lambda x: x, 0.99)
+    assert big["state"].shape == (17, B, 376)
+    head = rbuf.memory.head
+    for u, seqs in enumerate(sets):
+        ids = [rbuf.memory[int(q - head)][0]["idx"] for q in seqs]
+        np.testing.assert_array_equal(big["state"][u].cpu().numpy(), obs[ids])
+        np.testing.assert_array_equal(big["next_state"][u].cpu().numpy(), obs[np.asarray(ids) + 1])
+        np.testing.assert_array_equal(big["action"][u].cpu().numpy(), act[ids])
+        want = oracle.batch_experiences_scalars([[i] for i in ids], rew, term, 0.99, 1)
+        for key in ("reward", "is_state_terminal", "discount"):
+            np.testing.assert_array_equal(big[key][u].cpu().numpy(), want[key])
 
 
 @pytest.mark.gpu
