@@ -18,6 +18,17 @@ class RandomAccessQueue(object):
         self._head = 0
         self._apply_maxlen()
 
+    def __setstate__(self, state):
+        """Also accepts the attribute dict of the reference's class (two lists,
+        ``_queue_front`` reversed + ``_queue_back``; random_access_queue.py:13-17), so that a
+        queue pickled by the reference loads into this one."""
+        if "_queue_back" in state:
+            self.maxlen = state.get("maxlen")
+            self._items = list(reversed(state["_queue_front"])) + list(state["_queue_back"])
+            self._head = 0
+        else:
+            self.__dict__.update(state)
+
     def _apply_maxlen(self):
         if self.maxlen is not None:
             while len(self) > self.maxlen:

@@ -182,8 +182,10 @@ class DeviceReplayStore:
     def ingest(self, obs):
         """Any observation -> (refs int32[k], min_seq)."""
         if isinstance(obs, DeviceObs):
-            self._adopt_store(obs.store)
-            return obs.refs, obs.min_seq
+            if self.frames is None or self.frames is obs.store:
+                self._adopt_store(obs.store)
+                return obs.refs, obs.min_seq
+            return self._ingest_foreign(obs)
         key = id(obs)
         hit = self._obs_cache.get(key)
         if hit is not None and hit[0] is obs:
@@ -216,6 +218,48 @@ class DeviceReplayStore:
         if len(self._obs_cache) > 4096:
             self._obs_cache.popitem(last=False)
         return refs, min_seq
+
+    def _ingest_foreign(self, obs):
+        """A device observation whose frames live in ANOTHER frame store (a device env that
+        keeps feeding a buffer which already owns a store, e.g. after ``load()`` of a
+        reference-format checkpoint): each frame is copied device-to-device into this
+        buffer's ring once (consecutive observations share k - 1 frames)."""
+        src = obs.store
+        self._flush_frames()          # keep ring writes in allocation order
+        last = src.next_seq - 1
+        seqs_there = [last - ((last - int(r)) % src.n_slots) for r in obs.refs]   # latest writes
+        own = self.frames
+        if src.dtype != own.dtype:
+            raise ValueError("observation dtype %s does not fit this buffer's frame store (%s)"
+                             % (src.dtype, own.dtype))
+        if src.frame_shape == own.frame_shape and self.k == len(obs.refs):
+            pairs = []
+            for slot, seq_there in zip((int(r) for r in obs.refs), seqs_there):
+                key = ("dev", id(src), seq_there)
+                hit = self._frame_cache.get(key)
+                if hit is None:
+                    seqs, slots = own.alloc(1)
+                    own.frames[int(slots[0])].copy_(src.frames[slot])
+                    hit = self._frame_cache[key] = (src, int(seqs[0]), int(slots[0]))
+                    if len(self._frame_cache) > 4096:
+                        self._frame_cache.popitem(last=False)
+                pairs.append((hit[1], hit[2]))
+            return (np.array([p[1] for p in pairs], dtype=np.int32), min(p[0] for p in pairs))
+        if self.k == 1 and int(np.prod(own.frame_shape)) == len(obs.refs) * int(np.prod(src.frame_shape)):
+            # this buffer stores whole observations (it was filled from materialised arrays,
+            # e.g. a reference-format checkpoint): stack the k frames into one of its frames
+            key = ("devobs", id(src)) + tuple(seqs_there)
+            hit = self._frame_cache.get(key)
+            if hit is None:
+                seqs, slots = own.alloc(1)
+                idx = torch.as_tensor(np.asarray(obs.refs, dtype=np.int64), device=self.device)
+                own.frames[int(slots[0])].view(-1).copy_(src.frames.index_select(0, idx).view(-1))
+                hit = self._frame_cache[key] = (src, int(seqs[0]), int(slots[0]))
+                if len(self._frame_cache) > 4096:
+                    self._frame_cache.popitem(last=False)
+            return np.array([hit[2]], dtype=np.int32), hit[1]
+        raise ValueError("observation frames %s x %d do not fit this buffer's frame store %s x %d"
+                         % (src.frame_shape, len(obs.refs), own.frame_shape, self.k))
 
     def _needs_phi_at_ingest(self, obs):
         """Arbitrary phi: apply it once on the host when the observation enters

@@ -28,6 +28,21 @@ from pfrl_amd.replay_buffer import DeviceExperienceBatch
 from pfrl_amd.utils.random import sample_n_k
 
 
+class _ReferenceUnpickler(pickle.Unpickler):
+    """Reads pickles written by the reference itself (``pickle.dump(self.memory)`` names
+    ``pfrl.collections.random_access_queue.RandomAccessQueue`` and, for LazyFrames
+    observations, ``pfrl.wrappers.atari_wrappers.LazyFrames``) when only this package is
+    installed: ``pfrl.x.y`` resolves to ``pfrl_amd.x.y``."""
+
+    def find_class(self, module, name):
+        if module == "pfrl" or module.startswith("pfrl."):
+            try:
+                return super().find_class(module, name)
+            except (ImportError, AttributeError):
+                return super().find_class("pfrl_amd" + module[len("pfrl"):], name)
+        return super().find_class(module, name)
+
+
 class _DeviceQueue:
     """FIFO view over the entry ring: logical index i <-> entry seq head + i
     (the role RandomAccessQueue plays in the reference)."""
@@ -230,10 +245,24 @@ class ReplayBuffer(replay_buffer.AbstractReplayBuffer):
             torch.save(self._native_state(), filename)
             return
         with open(filename, "wb") as f:
-            if self.store is None:
-                pickle.dump(self.memory, f)
-            else:
-                pickle.dump(self._materialise_host(), f)
+            pickle.dump(self._portable_queue(), f)
+
+    def _portable_queue(self):
+        """The queue as a plain ``collections.deque`` of n-step entries (lists of transition
+        dicts) whose observations are NumPy arrays: no class of this package appears in the
+        pickle, so the reference's ``ReplayBuffer.load`` reads it as it reads its own v0.2
+        files (pfrl/replay_buffers/replay_buffer.py:89-94 wraps a deque into its
+        RandomAccessQueue) without pfrl_amd installed.  Device observations are read back
+        from HBM; host LazyFrames are materialised."""
+        def plain(t):
+            d = dict(t)
+            for key in ("state", "next_state"):
+                if d.get(key) is not None and not isinstance(d[key], (np.ndarray, tuple)):
+                    d[key] = np.asarray(d[key])
+            return d
+
+        return collections.deque(([plain(t) for t in entry] for entry in self.memory),
+                                 maxlen=self.capacity)
 
     def _native_state(self):
         return dict(kind="pfrl_amd.ReplayBuffer", capacity=self.capacity,
@@ -249,15 +278,6 @@ class ReplayBuffer(replay_buffer.AbstractReplayBuffer):
         for k, v in sd["windows"].items():
             self.last_n_transitions[k].extend(v)
 
-    def _materialise_host(self):
-        """Device contents as the reference's pickled queue of dict lists
-        (observations read back from HBM)."""
-        q = RandomAccessQueue(maxlen=self.capacity)
-        for entry in self.memory:
-            q.append([dict(t, state=np.asarray(t["state"]), next_state=np.asarray(t["next_state"]))
-                      for t in entry])
-        return q
-
     def load(self, filename):
         if self.store is not None:
             try:
@@ -267,7 +287,7 @@ class ReplayBuffer(replay_buffer.AbstractReplayBuffer):
             if isinstance(sd, dict) and str(sd.get("kind", "")).startswith("pfrl_amd."):
                 return self._load_native(sd)
         with open(filename, "rb") as f:
-            loaded = pickle.load(f)
+            loaded = _ReferenceUnpickler(f).load()
         if isinstance(loaded, collections.deque):
             loaded = RandomAccessQueue(loaded, maxlen=loaded.maxlen)
         if self.store is None:
@@ -280,3 +300,6 @@ class ReplayBuffer(replay_buffer.AbstractReplayBuffer):
                                               t["next_state"], t["is_state_terminal"])
                     for t in entry]
             self.memory.append_entry(tids)
+        # pending frame uploads and table rows reach HBM now: the loaded contents are
+        # readable (entry views, DeviceObs.to_numpy) without a sample() in between
+        self.store.flush()

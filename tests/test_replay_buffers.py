@@ -329,3 +329,160 @@ def test_native_checkpoint_round_trip(tmp_path, prioritized):
             buf.update_errors(torch.full((16,), 0.5, device="cuda:0"))
         buf.append(obs[500], 1, 1.0, obs[501], env_id=0)
     assert len(a) == len(b)
+
+
+# ---------------------------------------------------------------------------------------------
+# replay checkpoints the reference can read
+# ---------------------------------------------------------------------------------------------
+REFERENCE = os.environ.get("PFRL_REFERENCE", "/root/reference")
+_needs_reference = pytest.mark.skipif(not os.path.isdir(os.path.join(REFERENCE, "pfrl")),
+                                      reason="the reference checkout exists in the build container only")
+
+
+def _run_with_reference(code):
+    """Run ``code`` in a fresh interpreter that can import the REFERENCE (and the test-only gym
+    stand-in) but NOT pfrl_amd: what a user of the reference has installed."""
+    import subprocess
+    import sys
+
+    env = dict(os.environ)
+    env["PYTHONPATH"] = os.pathsep.join([REFERENCE, os.path.join(os.path.dirname(__file__), "_gymshim")])
+    out = subprocess.run([sys.executable, "-c", code], env=env, cwd="/tmp", capture_output=True,
+                         text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    return out.stdout
+
+
+@_needs_reference
+def test_saved_replay_is_read_by_the_reference_and_back(tmp_path):
+    """ReplayBuffer.save writes a plain deque of dict lists with NumPy observations: the
+    reference's load (pfrl/replay_buffers/replay_buffer.py:89-94) reads it with no pfrl_amd
+    class on its path; and a file the reference wrote loads here with no pfrl installed."""
+    from pfrl_amd import replay_buffers
+    from pfrl_amd.wrappers.atari_wrappers import LazyFrames
+
+    rs = np.random.RandomState(0)
+    rbuf = replay_buffers.ReplayBuffer(50, num_steps=2)
+    frames = [rs.randint(0, 256, size=(1, 6, 6)).astype(np.uint8) for _ in range(40)]
+    for i in range(30):
+        s = LazyFrames(frames[i:i + 4], stack_axis=0)
+        ns = LazyFrames(frames[i + 1:i + 5], stack_axis=0)
+        rbuf.append(s, i % 3, float(i), ns, is_state_terminal=(i % 7 == 6))
+        if i % 7 == 6:
+            rbuf.stop_current_episode()
+    ours = str(tmp_path / "ours.pkl")
+    rbuf.save(ours)
+    assert b"pfrl_amd" not in open(ours, "rb").read()
+    theirs = str(tmp_path / "theirs.pkl")
+    out = _run_with_reference(
+        "import sys, numpy as np\n"
+        "assert not any('pfrl_amd' in m for m in sys.modules)\n"
+        "import pfrl\n"
+        "rb = pfrl.replay_buffers.ReplayBuffer(50, num_steps=2)\n"
+        "rb.load(%r)\n"
+        "assert type(rb.memory).__module__ == 'pfrl.collections.random_access_queue'\n"
+        "ents = [rb.memory[i] for i in range(len(rb))]\n"
+        "print(len(rb), sum(len(e) for e in ents), float(sum(t['reward'] for e in ents for t in e)),"
+        " int(sum(int(np.asarray(e[0]['state']).sum()) for e in ents)))\n"
+        "np.random.seed(1); be = pfrl.replay_buffer.batch_experiences(rb.sample(4), 'cpu', lambda x: x, 0.9)\n"
+        "assert be['state'].shape == (4, 4, 6, 6)\n"
+        "rb.save(%r)\n" % (ours, theirs))
+    n, n_trans, rsum, ssum = out.split()
+    ents = [rbuf.memory[i] for i in range(len(rbuf))]
+    assert int(n) == len(rbuf) and int(n_trans) == sum(len(e) for e in ents)
+    assert float(rsum) == sum(t["reward"] for e in ents for t in e)
+    assert int(ssum) == sum(int(np.asarray(e[0]["state"]).sum()) for e in ents)
+    # and back: the reference's own pickle (its RandomAccessQueue class) into this package
+    assert b"pfrl.collections.random_access_queue" in open(theirs, "rb").read()
+    back = replay_buffers.ReplayBuffer(50, num_steps=2)
+    back.load(theirs)
+    assert len(back) == len(rbuf)
+    for a, b in zip(back.memory, rbuf.memory):
+        assert len(a) == len(b)
+        for ta, tb in zip(a, b):
+            assert ta["reward"] == tb["reward"] and ta["action"] == tb["action"]
+            assert np.array_equal(np.asarray(ta["state"]), np.asarray(tb["state"]))
+
+
+@_needs_reference
+def test_device_buffer_checkpoint_is_read_by_the_reference():
+    """tests/golden/device_replay_save.pkl was written on the MI355X by ``save()`` of an
+    HBM-resident buffer (make_device_replay_pickle.py); the reference reads it and finds the
+    observations / scalars recorded next to it."""
+    pkl = os.path.join(GOLDEN, "device_replay_save.pkl")
+    if not os.path.exists(pkl):
+        pytest.skip("fixture not generated yet (needs the GPU box)")
+    g = np.load(os.path.join(GOLDEN, "device_replay_save.npz"))
+    assert b"pfrl_amd" not in open(pkl, "rb").read()
+    out = _run_with_reference(
+        "import numpy as np, pfrl, json\n"
+        "rb = pfrl.replay_buffers.ReplayBuffer(40, num_steps=3)\n"
+        "rb.load(%r)\n"
+        "ents = [rb.memory[i] for i in range(len(rb))]\n"
+        "np.savez('/tmp/_ref_read.npz', lens=np.array([len(e) for e in ents]),"
+        " first_state=np.stack([np.asarray(e[0]['state']) for e in ents]),"
+        " last_next_state=np.stack([np.asarray(e[-1]['next_state']) for e in ents]),"
+        " actions=np.array([e[0]['action'] for e in ents]),"
+        " terminal=np.array([e[-1]['is_state_terminal'] for e in ents]))\n"
+        "np.random.seed(0); be = pfrl.replay_buffer.batch_experiences(rb.sample(8), 'cpu',"
+        " lambda x: np.asarray(x, dtype=np.float32) / 255, 0.99)\n"
+        "print(tuple(be['state'].shape))\n" % pkl)
+    assert out.strip() == "(8, 4, 12, 12)"
+    r = np.load("/tmp/_ref_read.npz")
+    for key in ("lens", "first_state", "last_next_state", "actions", "terminal"):
+        assert np.array_equal(r[key], g[key]), key
+
+
+@pytest.mark.gpu
+def test_device_buffer_save_is_portable_and_dqn_snapshot_round_trips(tmp_path):
+    """save() of an HBM-resident buffer names no pfrl_amd class; a host buffer loads it;
+    DQN.save_snapshot / load_snapshot (reference pfrl/agents/dqn.py:794-810) restore t, optim_t,
+    the replay contents and the networks on the device path, and training continues."""
+    import pfrl_amd as pfrl
+    from pfrl_amd import agents, explorers, replay_buffers
+    from pfrl_amd.device_store import DeviceFrameStore
+    from pfrl_amd.envs import SyntheticAtariVectorEnv
+    from pfrl_amd.q_functions import DiscreteActionValueHead
+
+    dev = torch.device("cuda:0")
+
+    def make():
+        pfrl.utils.set_random_seed(0)
+        store = DeviceFrameStore(2048, (12, 12), torch.uint8, dev, stack=4)
+        env = SyntheticAtariVectorEnv(4, store=store, seed=3, n_actions=4, p_done=0.05)
+        torch.manual_seed(1)
+        q = torch.nn.Sequential(torch.nn.Flatten(), torch.nn.Linear(4 * 144, 32), torch.nn.ReLU(),
+                                torch.nn.Linear(32, 4), DiscreteActionValueHead())
+        opt = torch.optim.RMSprop(q.parameters(), lr=1e-3)
+        rbuf = replay_buffers.ReplayBuffer(300, num_steps=2)
+        ex = explorers.ConstantEpsilonGreedy(0.3, lambda: np.random.randint(4))
+        ag = agents.DQN(q, opt, rbuf, 0.99, ex, gpu=0, replay_start_size=32, minibatch_size=8,
+                        update_interval=4, target_update_interval=40,
+                        phi=lambda x: np.asarray(x, dtype=np.float32) / 255)
+        return ag, env, q, rbuf
+
+    ag, env, q, rbuf = make()
+    pfrl.experiments.train_agent_batch(ag, env, 400, str(tmp_path / "o"))
+    snap = str(tmp_path / "snap")
+    os.makedirs(snap)
+    ag.save_snapshot(snap)
+    raw = open(os.path.join(snap, "replay_buffer.pkl"), "rb").read()
+    assert b"pfrl_amd" not in raw
+    host = replay_buffers.ReplayBuffer(300, num_steps=2)
+    host.load(os.path.join(snap, "replay_buffer.pkl"))
+    assert len(host) == len(rbuf)
+    for a, b in zip(host.memory, rbuf.memory):
+        assert [t["reward"] for t in a] == [t["reward"] for t in b]
+        assert np.array_equal(np.asarray(a[0]["state"]), np.asarray(b[0]["state"]))
+    ag2, env2, q2, rbuf2 = make()
+    ag2.load_snapshot(snap)
+    assert (ag2.t, ag2.optim_t, ag2.cumulative_steps) == (ag.t, ag.optim_t, ag.cumulative_steps)
+    assert len(rbuf2) == len(rbuf) and rbuf2.is_device
+    for (k, v), (_, w) in zip(q2.state_dict().items(), q.state_dict().items()):
+        assert torch.equal(v, w), k
+    for a, b in zip(rbuf2.memory, rbuf.memory):
+        assert [t["action"] for t in a] == [t["action"] for t in b]
+        assert np.array_equal(np.asarray(a[-1]["next_state"]), np.asarray(b[-1]["next_state"]))
+    n0 = ag2.optim_t
+    pfrl.experiments.train_agent_batch(ag2, env2, 80, str(tmp_path / "o2"), step_offset=ag2.t)
+    assert ag2.optim_t > n0
