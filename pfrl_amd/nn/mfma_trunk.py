@@ -150,6 +150,11 @@ def _fused_bwd_ok(N, H, W, C, ST):
     return True
 
 
+def _dist_initialized():
+    d = torch.distributed
+    return d.is_available() and d.is_initialized()
+
+
 def _reduce(tasks):
     """tasks: (part, out, bias or None, stride, n, splits, ncol, relu)"""
     n = len(tasks)
@@ -245,6 +250,12 @@ class _Trunk(torch.autograd.Function):
             check(lib.pfrl_conv2d_nhwc_bwd_weight(_p(dh), _p(out), _p(acts[-1]), _p(dwf), _p(dbf), 0, 0,
                                                   N, 1, 1, Kf, F, 1, 1, 1, 1, _stream()),
                   "linear_bwd_weight")
+        if _dist_initialized():
+            # data parallel: the hidden layer's gradient (95 % of the bytes) starts its
+            # all-reduce now, under the convolution backward that follows
+            from pfrl_amd.distributed import announce_grad
+
+            announce_grad(wf, dwf)
         grads = [None] * (2 * L) + [dwf, dbf]
         tasks = []
         for i in range(L - 1, -1, -1):

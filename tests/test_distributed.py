@@ -87,6 +87,59 @@ def _worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
+def _early_worker(rank, world, port, out_dir):
+    """Split plan of GradientAllReducer: the large tensor's all-reduce starts as soon as its
+    gradient exists (post-accumulate hook, or the producer's announce_grad), the rest goes
+    in the flat bucket; must equal the single-bucket plan bit for bit."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import copy
+
+    import torch.distributed as dist
+
+    from pfrl_amd import distributed
+
+    distributed.init_process_group_from_env(backend="gloo")
+    torch.manual_seed(5)
+    model = torch.nn.Sequential(torch.nn.Linear(16, 8), torch.nn.ReLU(), torch.nn.Linear(8, 4096),
+                                torch.nn.ReLU(), torch.nn.Linear(4096, 3))
+    twin = copy.deepcopy(model)
+    twin2 = copy.deepcopy(model)
+    single = distributed.GradientAllReducer(twin, early_bytes=0)
+    split = distributed.GradientAllReducer(model, early_bytes=100_000)      # 8 x 4096 x 4 B = 128 KB
+    manual = distributed.GradientAllReducer(twin2, early_bytes=40_000)      # both wide layers
+    assert len(split._early) == 1 and len(single._early) == 0 and len(manual._early) == 2
+    for h in manual._hooks:      # this one is driven by the producer's announcement only
+        h.remove()
+    x = torch.randn(6, 16, generator=torch.Generator().manual_seed(10 + rank))
+    started = []
+    orig = split._start
+    split._start = lambda t: (started.append(tuple(t.shape)), orig(t))[1]
+    for m in (model, twin, twin2):
+        m.zero_grad(set_to_none=True)
+        m(x).pow(2).sum().backward()
+    assert started == [(4096, 8)]            # launched from inside backward, by the hook
+    for p in twin2.parameters():
+        distributed.announce_grad(p, p.grad)  # what a fused backward node does per tensor
+    assert len(manual._pending) == 2
+    for r in (single, split, manual):
+        r.all_reduce()
+        assert not r._pending
+    a, b, c = (torch.cat([p.grad.reshape(-1) for p in m.parameters()]) for m in (twin, model, twin2))
+    assert torch.equal(a, b) and torch.equal(a, c)
+    np.save(os.path.join(out_dir, "early%d.npy" % rank), b.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_early_all_reduce_of_the_large_gradient_equals_single_bucket(tmp_path):
+    port = _free_port()
+    mp.spawn(_early_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    g0, g1 = (np.load(os.path.join(str(tmp_path), "early%d.npy" % r)) for r in (0, 1))
+    assert np.array_equal(g0, g1) and np.abs(g0).sum() > 0
+
+
 def test_gradient_all_reduce_two_ranks_gloo(tmp_path):
     world = 2
     port = _free_port()
