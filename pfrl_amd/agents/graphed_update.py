@@ -21,6 +21,16 @@ import torch
 from pfrl_amd import distributed
 
 
+def _capture_kwargs(pool):
+    """Arguments of ``torch.cuda.graph``: the shared memory pool, and thread-local capture
+    error mode when a process group exists (its watchdog thread polls HIP events while this
+    thread captures; in the default global mode that poll aborts the process)."""
+    kw = {} if pool is None else {"pool": pool}
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
+        kw["capture_error_mode"] = "thread_local"
+    return kw
+
+
 def _optimizer_tensors(optimizer):
     out = []
     for st in optimizer.state.values():
@@ -179,10 +189,7 @@ class GraphedUpdate:
 
         def graph_of(fn):
             g = torch.cuda.CUDAGraph()
-            kw = {} if self.pool is None else {"pool": self.pool}
-            if torch.distributed.is_available() and torch.distributed.is_initialized():
-                # the process group's watchdog thread polls events while we capture
-                kw["capture_error_mode"] = "thread_local"
+            kw = _capture_kwargs(self.pool)
             with torch.cuda.graph(g, **kw):
                 r = fn()
             if self.pool is None:
@@ -301,7 +308,7 @@ class GraphedUpdate:
             _make_capturable(ag.optimizer, dev)
             ag.optimizer.zero_grad(set_to_none=True)
             g = torch.cuda.CUDAGraph()
-            kw = {} if self.pool is None else {"pool": self.pool}
+            kw = _capture_kwargs(self.pool)
             with torch.cuda.graph(g, **kw):
                 losses, ys = body()
             if self.pool is None:
@@ -448,7 +455,7 @@ class CapturedStep:
                 _make_capturable(opt, dev)  # state created by the warm-up
                 opt.zero_grad(set_to_none=True)
             g = torch.cuda.CUDAGraph()
-            kw = {} if self.pool is None else {"pool": self.pool}
+            kw = _capture_kwargs(self.pool)
             with torch.cuda.graph(g, **kw), _no_distribution_validation():
                 out = step()
             if self.pool is None:
