@@ -44,6 +44,20 @@ def main():
     print("window %.2f ms, %d launches, kernels busy %.2f ms (%.1f %%), sum of kernel durations %.2f ms"
           % (span / 1e6, len(rows), busy / 1e6, 100.0 * busy / span,
              sum(v[0] for v in tot.values()) / 1e6))
+    # where the GPU idles: gaps between consecutive kernels, by (kernel before -> kernel after)
+    gaps = defaultdict(lambda: [0, 0])
+    prev_e, prev_n = rows[0][1], short(rows[0][2])
+    for s_, e_, n_ in rows[1:]:
+        if s_ > prev_e + 3000:
+            key = "%s -> %s" % (prev_n[:40], short(n_)[:40])
+            gaps[key][0] += s_ - prev_e
+            gaps[key][1] += 1
+        if e_ > prev_e:
+            prev_e, prev_n = e_, short(n_)
+    print("idle gaps > 3 us: %.2f ms in %d gaps" % (sum(v[0] for v in gaps.values()) / 1e6,
+                                                    sum(v[1] for v in gaps.values())))
+    for k, (ns, c) in sorted(gaps.items(), key=lambda kv: -kv[1][0])[:12]:
+        print("   %8.3f ms %5d x %8.1f us  %s" % (ns / 1e6, c, ns / c / 1e3, k))
     for k, (ns, c) in sorted(tot.items(), key=lambda kv: -kv[1][0])[:a.top]:
         print("%8.3f ms %6d x %8.2f us  %5.1f %%  %s" % (ns / 1e6, c, ns / c / 1e3, 100.0 * ns / span, k))
 
