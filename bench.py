@@ -512,10 +512,13 @@ def compute_roofline(algo, all_us, all_units, all_kinds):
     }
     # HBM traffic cannot be sampled from inside the process: it is taken from the
     # committed rocprofv3 --pmc passes of this same command
-    # (profiles/r01f_pmc_gather.json, tools/pmc_gather.py), per launch shape.
-    for name in ("r01f_pmc_gather.json", "r01f_pmc_ppo.json"):
+    # (profiles/rNN_pmc_gather.json, tools/pmc_gather.py), per launch shape.
+    prof_dir = os.path.join(ROOT, "profiles")
+    names = sorted((n for n in os.listdir(prof_dir) if n.endswith(("_pmc_gather.json", "_pmc_ppo.json"))),
+                   reverse=True)      # newest round first
+    for name in names:
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
+            pmc = json.load(open(os.path.join(prof_dir, name)))
             kk = pmc["kernels"].get("%s (%d %s)" % (kname, main_units, unit_name))
             if kk and "traffic_bytes_per_launch" in kk:
                 roofline["traffic"] = kk["traffic_bytes_per_launch"]
