@@ -36,6 +36,7 @@ from pfrl_amd.replay_buffer import (AbstractEpisodicReplayBuffer, DeviceExperien
                                     ReplayUpdater, batch_experiences,
                                     batch_recurrent_experiences)
 from pfrl_amd.utils.batch_states import batch_states
+from pfrl_amd.utils.random import sample_n_k
 from pfrl_amd.utils.clip_l2_grad_norm import clip_l2_grad_norm_
 from pfrl_amd.utils.contexts import evaluating
 from pfrl_amd.utils.copy_param import synchronize_parameters
@@ -536,6 +537,7 @@ class DQN(agent.AttributeSavingMixin, agent.BatchAgent):
                                 for i, a in enumerate(batch_action)]
             self.batch_last_obs = list(batch_obs)
             self.batch_last_action = list(batch_action)
+            self._last_obs_batch = batch_obs
             return batch_action
         batch_argmax = greedy_dev.cpu().numpy()
         if self.training:
@@ -553,6 +555,7 @@ class DQN(agent.AttributeSavingMixin, agent.BatchAgent):
                 ]
             self.batch_last_obs = list(batch_obs)
             self.batch_last_action = list(batch_action)
+            self._last_obs_batch = batch_obs
         else:
             batch_action = batch_argmax
         return batch_action
@@ -621,13 +624,38 @@ class DQN(agent.AttributeSavingMixin, agent.BatchAgent):
         up = self.replay_updater
         t0 = self.t
         plan_env, plan_seqs = [], []
-        for i in range(lo, hi):
-            self._append_transition(i, batch_obs, batch_reward, batch_done, batch_reset)
-            if (len(rbuf) >= up.replay_start_size
-                    and (t0 + (i - lo) + 1) % up.update_interval == 0):
-                for _ in range(up.n_times_update):
-                    plan_env.append(i)
-                    plan_seqs.append(rbuf.lookahead_sample(up.batchsize))
+        if self._batched_append_ok(lo, hi, batch_obs):
+            # the per-env loop below as array writes: every env of the range has a pending
+            # transition, entries are one transition long, so len(buffer) and the queue head at
+            # each point of the loop are known in advance and the index draws (same NumPy
+            # stream, same order) can follow the appends
+            prev = self._last_obs_batch
+            lens, heads = rbuf.append_batch_n1(
+                prev.refs[lo:hi], prev.min_seq[lo:hi],
+                np.asarray(self.batch_last_action[lo:hi], dtype=np.int64),
+                np.asarray(batch_reward[lo:hi], dtype=np.float64),
+                batch_obs.refs[lo:hi], batch_obs.min_seq[lo:hi],
+                np.asarray(batch_done[lo:hi], dtype=np.uint8))
+            for i in range(lo, hi):
+                if batch_reset[i] or batch_done[i]:
+                    self.batch_last_obs[i] = None
+                    self.batch_last_action[i] = None
+                j = i - lo
+                if (lens[j] >= up.replay_start_size
+                        and (t0 + j + 1) % up.update_interval == 0):
+                    for _ in range(up.n_times_update):
+                        plan_env.append(i)
+                        assert lens[j] >= up.batchsize
+                        plan_seqs.append(heads[j] + np.asarray(
+                            sample_n_k(int(lens[j]), up.batchsize), dtype=np.int64))
+        else:
+            for i in range(lo, hi):
+                self._append_transition(i, batch_obs, batch_reward, batch_done, batch_reset)
+                if (len(rbuf) >= up.replay_start_size
+                        and (t0 + (i - lo) + 1) % up.update_interval == 0):
+                    for _ in range(up.n_times_update):
+                        plan_env.append(i)
+                        plan_seqs.append(rbuf.lookahead_sample(up.batchsize))
         big = rbuf.fetch_many(plan_seqs, self.phi, self.gamma) if plan_seqs else None
         if big is not None and self.batch_target_pass and self._target_is_deterministic():
             # no target sync may fall inside this range (the targets would go stale)
@@ -675,6 +703,17 @@ class DQN(agent.AttributeSavingMixin, agent.BatchAgent):
                 for l, y in deferred:
                     self.loss_record.extend(l.clone())
                     self.q_record.extend(y.clone())
+
+    def _batched_append_ok(self, lo, hi, batch_obs):
+        from pfrl_amd.device_store import DeviceObsBatch
+
+        prev = getattr(self, "_last_obs_batch", None)
+        rbuf = self.replay_buffer
+        return (not self.recurrent and isinstance(batch_obs, DeviceObsBatch)
+                and isinstance(prev, DeviceObsBatch) and prev.store is batch_obs.store
+                and len(prev) == len(batch_obs)
+                and hasattr(rbuf, "batch_append_supported") and rbuf.batch_append_supported(batch_obs)
+                and all(o is not None for o in self.batch_last_obs[lo:hi]))
 
     def _range_as_one_graph(self, t0, n):
         """All updates of an env range as one HIP graph: graphs on, no prioritized replay

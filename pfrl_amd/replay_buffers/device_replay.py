@@ -315,6 +315,54 @@ class DeviceReplayStore:
         self.n_trans = tid + 1
         return tid
 
+    def add_transitions_n1(self, s_refs, n_refs, actions, rewards, terminals, min_seq):
+        """``m`` transitions AND their one-transition entries at once (num_steps == 1: every
+        append emits exactly the window [tid], pfrl/replay_buffers/replay_buffer.py:53-62):
+        the same rows, mirrors and counters as ``m`` calls of add_transition + add_entry,
+        written with array operations.  Observations are frame-slot refs of this buffer's own
+        frame store.  Returns the first new entry seq."""
+        m = len(rewards)
+        assert self.n == 1 and self.desc is not None and self.act_dim == 0
+        first_seq = self.n_entries
+        done = 0
+        while done < m:
+            room = _STAGE_ROWS - max(self._pend_rows, self._pend_entries)
+            if room == 0:
+                self.flush()
+                continue
+            c = min(room, m - done)
+            sl = slice(done, done + c)
+            tid = np.arange(self.n_trans, self.n_trans + c, dtype=np.int64)
+            tslot = tid % self.R
+            i = self._pend_rows
+            self._s_slot[i:i + c] = tslot
+            self._s_state[i:i + c] = s_refs[sl]
+            self._s_next[i:i + c] = n_refs[sl]
+            self._s_action[i:i + c] = actions[sl]
+            self._s_reward[i:i + c] = rewards[sl]
+            self._s_term[i:i + c] = terminals[sl]
+            self._pend_rows = i + c
+            self.h_state_ref[tslot] = s_refs[sl]
+            self.h_next_ref[tslot] = n_refs[sl]
+            self.h_action[tslot] = actions[sl]
+            self.h_reward[tslot] = rewards[sl]
+            self.h_terminal[tslot] = terminals[sl]
+            self.h_min_fseq[tslot] = min_seq[sl]
+            self.n_trans += c
+            seq = np.arange(self.n_entries, self.n_entries + c, dtype=np.int64)
+            eslot = seq % self.E
+            j = self._pend_entries
+            self._s_eslot[j:j + c] = eslot
+            self._s_etids[j:j + c, 0] = tslot
+            self._s_elen[j:j + c] = 1
+            self.h_e_tids[eslot, 0] = tid
+            self.h_e_len[eslot] = 1
+            self.h_e_min_fseq[eslot] = min_seq[sl]
+            self._pend_entries = j + c
+            self.n_entries += c
+            done += c
+        return first_seq
+
     def add_entry(self, tids):
         """An emitted n-step window (list of absolute tids) -> entry seq."""
         first = tids[0]

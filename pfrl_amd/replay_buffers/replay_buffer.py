@@ -220,6 +220,37 @@ class ReplayBuffer(replay_buffer.AbstractReplayBuffer):
     def supports_lookahead(self):
         return self.store is not None and type(self.memory) is _DeviceQueue
 
+    def batch_append_supported(self, obs_batch):
+        """The array form of ``append`` below applies: uniform device replay with one-step
+        entries whose tables exist, discrete actions, and observations that are refs into this
+        buffer's own frame store."""
+        st = self.store
+        return (st is not None and type(self.memory) is _DeviceQueue and self.num_steps == 1
+                and st.desc is not None and st.act_dim == 0 and st.frames is not None
+                and getattr(obs_batch, "store", None) is st.frames and not st._phi_at_ingest)
+
+    def append_batch_n1(self, s_refs, s_min_seq, actions, rewards, n_refs, n_min_seq, terminals):
+        """``append(...)`` for m envs in env order, num_steps == 1 (each append emits its own
+        one-transition entry at once; reference replay_buffer.py:33-62), as array writes.
+        Returns (len(self), head) AFTER EACH of the m appends (int64 arrays): what ``len`` and
+        the queue head were at that point of the reference's per-env loop, which is all that
+        index draws made between the appends depend on."""
+        m = len(rewards)
+        st, q = self.store, self.memory
+        n0, head0 = st.n_entries, q.head
+        st.add_transitions_n1(s_refs, n_refs, actions, rewards, terminals,
+                              np.minimum(s_min_seq, n_min_seq))
+        total = n0 + 1 + np.arange(m, dtype=np.int64)          # entries appended so far
+        if q.maxlen is not None:
+            heads = np.maximum(head0, total - q.maxlen)
+        else:
+            if st.n_entries - head0 > st.bound:
+                raise RuntimeError("unbounded ReplayBuffer exceeded its device allocation "
+                                   "(max_size=%d)" % st.bound)
+            heads = np.full(m, head0, dtype=np.int64)
+        q.head = int(heads[-1])
+        return total - heads, heads
+
     def lookahead_sample(self, k):
         """Draw the indices ``sample(k)`` would draw NOW (same NumPy stream use)
         and return the entry sequence numbers, without touching the device."""
