@@ -218,6 +218,7 @@ class DQN(agent.AttributeSavingMixin, agent.BatchAgent):
         # env-range boundaries (fractions of num_envs) of the step-fused path
         self.step_fused_chunks = tuple(step_fused_chunks)
         self._target_raw_bufs = {}
+        self._single_bufs = {}
         self.range_graphs = os.environ.get("PFRL_RANGE_GRAPHS", "1") != "0"
         self._analytic_backward = None
         self._graphed = None
@@ -686,13 +687,25 @@ class DQN(agent.AttributeSavingMixin, agent.BatchAgent):
             return
         p = 0
         deferred = [] if self.use_graphs else None
+        # A range that normally replays as one graph but has a target sync inside it this
+        # time (once per target_update_interval) runs update by update.  Capturing one graph
+        # per minibatch slot for that rare case would cost tens of captures the first time
+        # each slot is met: instead every minibatch is copied into ONE persistent staging
+        # set (7 MB, a few us) and a single captured update is replayed on it.
+        staged = (big is not None and self.use_graphs and self.range_graphs
+                  and self._graphed is not None and self._graphed.range_capturable())
+        if staged:
+            deferred = None
         for i in range(lo, hi):
             self.t += 1
             self._cumulative_steps += 1
             if self.t % self.target_update_interval == 0:
                 self.sync_target_network()
             while p < len(plan_env) and plan_env[p] == i:
-                self._update_from_batch({k: v[p] for k, v in big.items()}, deferred=deferred)
+                mb = {k: v[p] for k, v in big.items()}
+                if staged:
+                    mb = self._stage_minibatch(mb)
+                self._update_from_batch(mb, deferred=deferred)
                 p += 1
         if deferred and self.use_graphs:
             # every update above replayed its own graph, so all outputs are still live
@@ -703,6 +716,18 @@ class DQN(agent.AttributeSavingMixin, agent.BatchAgent):
                 for l, y in deferred:
                     self.loss_record.extend(l.clone())
                     self.q_record.extend(y.clone())
+
+    def _stage_minibatch(self, mb):
+        """Copy one minibatch (dict of tensors) into the persistent staging set."""
+        key = tuple(sorted((k, tuple(v.shape), v.dtype, v.stride()) for k, v in mb.items()))
+        bufs = self._single_bufs.get(key)
+        if bufs is None:
+            bufs = self._single_bufs[key] = {k: torch.empty_strided(v.shape, v.stride(), dtype=v.dtype,
+                                                                    device=v.device)
+                                             for k, v in mb.items()}
+        for k, v in mb.items():
+            bufs[k].copy_(v)
+        return bufs
 
     def _batched_append_ok(self, lo, hi, batch_obs):
         from pfrl_amd.device_store import DeviceObsBatch
