@@ -36,7 +36,6 @@ from pfrl_amd.replay_buffer import (AbstractEpisodicReplayBuffer, DeviceExperien
                                     ReplayUpdater, batch_experiences,
                                     batch_recurrent_experiences)
 from pfrl_amd.utils.batch_states import batch_states
-from pfrl_amd.utils.random import sample_n_k
 from pfrl_amd.utils.clip_l2_grad_norm import clip_l2_grad_norm_
 from pfrl_amd.utils.contexts import evaluating
 from pfrl_amd.utils.copy_param import synchronize_parameters
@@ -509,6 +508,24 @@ class DQN(agent.AttributeSavingMixin, agent.BatchAgent):
         ended = [i for i, (d, r) in enumerate(zip(batch_done, batch_reset)) if d or r]
         return mask_recurrent_state_at(recurrent_states, ended) if ended else recurrent_states
 
+    def _host_batch_to_device(self, batch_obs):
+        """Training observations that arrive as host LazyFrames (a real VectorFrameStack /
+        MultiprocessVectorEnv) enter the replay buffer's frame ring HERE, once per batch:
+        only the frames not seen before cross PCIe (one 7 KB frame per env and step instead of
+        the 28 KB stack), identity is resolved for the whole batch in one pass, and from then
+        on the batch is a DeviceObsBatch -- acting gathers it on the device and the step-fused
+        path appends it with array writes, exactly as for a device env."""
+        from pfrl_amd.device_store import DeviceObs, DeviceObsBatch
+
+        store = getattr(self.replay_buffer, "store", None)
+        if (store is None or self.recurrent or isinstance(batch_obs, DeviceObsBatch)
+                or len(batch_obs) == 0 or isinstance(batch_obs[0], DeviceObs)):
+            return batch_obs
+        out = store.ingest_many(batch_obs)
+        if out is None:
+            return batch_obs
+        return DeviceObsBatch(store.frames, out[0], out[1])
+
     def _explorer_draws_before_greedy(self):
         from pfrl_amd.explorers.epsilon_greedy import _EpsilonGreedyBase
 
@@ -521,6 +538,8 @@ class DQN(agent.AttributeSavingMixin, agent.BatchAgent):
         if self._replay_stream is not None:
             # frames the buffer uploaded on its own stream must be visible to the gather
             self.replay_buffer.current_wait_replay_stream()
+        if self.training:
+            batch_obs = self._host_batch_to_device(batch_obs)
         with torch.no_grad(), evaluating(self.model):
             batch_av = self._evaluate_model(batch_obs)
             greedy_dev = batch_av.greedy_actions.detach()
@@ -581,6 +600,7 @@ class DQN(agent.AttributeSavingMixin, agent.BatchAgent):
 
     def _batch_observe_train(self, batch_obs, batch_reward, batch_done, batch_reset):
         rbuf = self.replay_buffer
+        batch_obs = self._host_batch_to_device(batch_obs)
         if self._replay_stream is not None:
             # this env step's frames (written on the compute stream) before any gather
             rbuf.replay_stream_wait_current()
@@ -646,9 +666,7 @@ class DQN(agent.AttributeSavingMixin, agent.BatchAgent):
                         and (t0 + j + 1) % up.update_interval == 0):
                     for _ in range(up.n_times_update):
                         plan_env.append(i)
-                        assert lens[j] >= up.batchsize
-                        plan_seqs.append(heads[j] + np.asarray(
-                            sample_n_k(int(lens[j]), up.batchsize), dtype=np.int64))
+                        plan_seqs.append(rbuf.lookahead_sample_at(lens[j], heads[j], up.batchsize))
         else:
             for i in range(lo, hi):
                 self._append_transition(i, batch_obs, batch_reward, batch_done, batch_reset)

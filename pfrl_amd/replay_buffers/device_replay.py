@@ -219,6 +219,79 @@ class DeviceReplayStore:
             self._obs_cache.popitem(last=False)
         return refs, min_seq
 
+    def ingest_many(self, obs_list):
+        """A whole batch of LazyFrames-like host observations (``_frames`` lists; consecutive
+        observations of an env share k - 1 frame objects, pfrl/wrappers/vector_frame_stack.py:
+        93-105) -> (refs int32 [N, k], min_seq int64 [N]) in ONE pass: frame identity is
+        resolved through the same cache as :meth:`ingest`, every frame not seen before gets a
+        ring slot from one allocation, and the new frames go up in one stacked transfer.
+        Returns None if the batch is not of that form (callers fall back to per-observation
+        ``ingest``)."""
+        n = len(obs_list)
+        if n == 0:
+            return None
+        first = _frames_of(obs_list[0])
+        if first is None:
+            return None
+        k = len(first)
+        if self.frames is None:
+            self._make_own_store(first[0], k)
+        if not self._own_frames or self.frames.stack != k:
+            return None
+        for obs in obs_list:
+            frs = getattr(obs, "_frames", None)
+            if not isinstance(frs, (list, tuple)) or len(frs) != k:
+                return None
+        refs = np.empty((n, k), dtype=np.int32)
+        seqs = np.empty((n, k), dtype=np.int64)
+        fcache, ocache = self._frame_cache, self._obs_cache
+        new_frames, new_pos = [], []
+        for i, obs in enumerate(obs_list):
+            hit = ocache.get(id(obs))
+            if hit is not None and hit[0] is obs:
+                refs[i] = hit[1]
+                seqs[i] = hit[2]
+                continue
+            for j, f in enumerate(obs._frames):
+                h = fcache.get(id(f))
+                if h is not None and h[0] is f:
+                    seqs[i, j] = h[1]
+                    refs[i, j] = h[2]
+                else:
+                    # first sighting in this pass too: later duplicates find the entry
+                    fcache[id(f)] = (f, -1, len(new_frames))
+                    new_frames.append(f)
+                    new_pos.append((i, j))
+                    seqs[i, j] = -1
+                    refs[i, j] = len(new_frames) - 1
+        if new_frames:
+            self._flush_frames()
+            aseq, aslot = self.frames.alloc(len(new_frames))
+            shape = self.frames.frame_shape
+            want = np.uint8 if self.frames.dtype == torch.uint8 else np.float32
+            block = np.empty((len(new_frames),) + shape, dtype=want)
+            for t, f in enumerate(new_frames):
+                block[t] = np.asarray(f).reshape(shape)
+                fcache[id(f)] = (f, int(aseq[t]), int(aslot[t]))
+            # entries that pointed at "the t-th new frame" (seq -1) get their slot now
+            pend = seqs < 0
+            idx = refs[pend]
+            refs[pend] = aslot[idx]
+            seqs[pend] = aseq[idx]
+            rows = self._frame_stage_rows
+            with on_stream(self.side_stream):
+                for a in range(0, len(new_frames), rows):
+                    src, sl = self._frame_stage.upload([block[a:a + rows], aslot[a:a + rows]])
+                    self.frames.write(src.view(self.frames.dtype).view((-1,) + shape), sl)
+            while len(fcache) > 8192:
+                fcache.popitem(last=False)
+        min_seq = seqs.min(axis=1)
+        for i, obs in enumerate(obs_list):
+            ocache[id(obs)] = (obs, refs[i].copy(), int(min_seq[i]))
+        while len(ocache) > 4096:
+            ocache.popitem(last=False)
+        return refs, min_seq
+
     def _ingest_foreign(self, obs):
         """A device observation whose frames live in ANOTHER frame store (a device env that
         keeps feeding a buffer which already owns a store, e.g. after ``load()`` of a

@@ -258,6 +258,13 @@ class ReplayBuffer(replay_buffer.AbstractReplayBuffer):
         idx = sample_n_k(len(self.memory), k)
         return self.memory.head + np.asarray(idx, dtype=np.int64)
 
+    def lookahead_sample_at(self, length, head, k):
+        """The draw ``sample(k)`` would make at a point of the per-env loop where
+        ``len(self) == length`` and the queue head was ``head`` (see append_batch_n1): same
+        NumPy stream use as :meth:`lookahead_sample`, entry sequence numbers returned."""
+        assert length >= k
+        return int(head) + np.asarray(sample_n_k(int(length), k), dtype=np.int64)
+
     def fetch_many(self, seq_sets, phi, gamma):
         """One fused batch_experiences launch for several planned minibatches;
         returns a dict of tensors with a leading "update" dimension."""

@@ -98,6 +98,14 @@ def _run(name, prioritized, num_steps, double, gpu, priority_pow="device", steps
             return seqs
 
         rbuf.lookahead_sample = spy_look
+        orig_look_at = rbuf.lookahead_sample_at
+
+        def spy_look_at(length, head, k):
+            seqs = orig_look_at(length, head, k)
+            note_sample([rbuf.store.entry_view(int(q)) for q in seqs])
+            return seqs
+
+        rbuf.lookahead_sample_at = spy_look_at
     _spy_losses(ag, losses)
     pfrl.experiments.train_agent_batch(ag, env, steps, tempfile.mkdtemp())
     params = np.concatenate([p.detach().cpu().numpy().ravel() for p in q.parameters()])
