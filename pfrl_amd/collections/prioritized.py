@@ -128,14 +128,44 @@ class PrioritizedBuffer:
             self.popleft()
         if self.frame.length >= self._bound and self.capacity is None:
             raise RuntimeError("unbounded PrioritizedBuffer exceeded max_size=%d" % self._bound)
+        doubling = False
         if self.frame.will_change_on_append():
             self.flush()
+            doubling = self.frame.length > 0
         x = self.frame.append()
+        if doubling:
+            self._clear_new_half()
         if priority is None:
             self._record(x, 0.0, TAG_PY, 1)
         else:
             self._record(x, float(priority), type_tag(priority), 0)
         self.data.append(value)
+
+    def _clear_new_half(self):
+        """The frame has just doubled (prioritized.py:214-220: the new root's right child is
+        an EMPTY subtree).  On the device the nodes of that half are physical ring slots that
+        an earlier incarnation of the frame may have used under other level origins and
+        left behind with values -- ancestors above the then-current root are not repaired when
+        their leaves are popped.  Mark every internal node of the new right half absent, so
+        that path repairs of the leaves about to be appended see the empty siblings the
+        reference has (found with an unbounded buffer and bursts of popleft, the prioritized
+        episodic buffer's pattern: root sum off by a stale level-2 node)."""
+        f = self.frame
+        L = f.log2_size
+        half = f.size // 2
+        x0 = f.base + half
+        smax = 1 << self.log2_smax
+        with on_stream(self.side_stream):
+            for l in range(1, L):
+                M = max(smax >> l, 1)
+                q0 = ((x0 - f.origin[l]) >> l) & (M - 1)
+                cnt = min(half >> l, M)
+                off = self._level_off[l]
+                first = min(cnt, M - q0)
+                for tags in (self.sum_tag, self.min_tag):
+                    tags[off + q0:off + q0 + first].zero_()
+                    if cnt > first:
+                        tags[off:off + cnt - first].zero_()
 
     def popleft(self):
         """prioritized.py:50-54"""

@@ -733,3 +733,40 @@ def test_ppo_host_path_with_obs_normalizer_matches_reference_trace(tmp_path):
     np.testing.assert_allclose(np.asarray(losses), g["losses"], rtol=1e-4, atol=1e-5)
     params = np.concatenate([p.detach().numpy().ravel() for p in model.parameters()])
     np.testing.assert_allclose(params, g["final_params"], rtol=1e-5, atol=1e-6)
+
+
+# ---------------------------------------------------------------------------------------------
+# device pairing (run on the MI355X): the HBM priority trees under the episodic buffers, the
+# recurrent DQN with its network on the GPU
+# ---------------------------------------------------------------------------------------------
+def _load_episodic_gpu_checks():
+    import importlib.util
+
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools",
+                        "check_episodic_gpu.py")
+    spec = importlib.util.spec_from_file_location("check_episodic_gpu", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+@pytest.mark.gpu
+def test_prioritized_episodic_buffer_on_device_trees_matches_reference_traces():
+    """PrioritizedEpisodicReplayBuffer(device=...) -- episodes on the host, sum / min trees
+    in HBM, unbounded tree with bursts of popleft when whole episodes are evicted -- against
+    the traces recorded from the reference: lengths, sampled episodes and weights at every
+    operation."""
+    import glob
+
+    mod = _load_episodic_gpu_checks()
+    paths = sorted(glob.glob(os.path.join(mod.GOLDEN, "prioritized_episodic_trace_*.npz")))
+    assert paths
+    for p in paths:
+        mod.check_prioritized_episodic(p)
+
+
+@pytest.mark.gpu
+def test_drqn_with_the_network_on_the_device_matches_reference_trace():
+    """DoubleDQN(recurrent=True, gpu=0): episodes replayed as packed sequences on the GPU;
+    sampled windows exactly, actions step for step, first losses to 1e-3."""
+    _load_episodic_gpu_checks().check_drqn()

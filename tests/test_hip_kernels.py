@@ -1157,3 +1157,42 @@ def test_fused_bias_relu_linear_small(dev, rows, C):
     yb.backward(gy)
     assert torch.equal(xa.grad, xb.grad)
     np.testing.assert_allclose(ba.grad.cpu().numpy(), bb.grad.cpu().numpy(), rtol=1e-5, atol=1e-5)
+
+
+def test_unbounded_tree_with_popleft_bursts_matches_oracle(dev):
+    """capacity=None with explicit bursts of popleft (how the prioritized episodic buffer
+    evicts whole episodes): the frame shrinks by several levels and grows again, so the
+    freshly doubled half consists of ring slots an earlier incarnation of the frame left
+    behind with values.  Root sum / min after every operation and every sample's indices
+    against the oracle (regression: a stale level-2 node used to survive the doubling)."""
+    from pfrl_amd.collections.prioritized import PrioritizedBuffer
+
+    for seed in range(12):
+        rs = np.random.RandomState(seed)
+        buf = PrioritizedBuffer(None, device=dev, max_size=4096)
+        orc = oracle.OraclePrioritizedBuffer(None)
+        k = 0
+        for step in range(300):
+            r = rs.rand()
+            if r < 0.5 or len(orc) < 3:
+                for _ in range(rs.randint(1, 4)):
+                    buf.append(k)
+                    orc.append(k)
+                    k += 1
+            elif r < 0.75:
+                for _ in range(min(rs.randint(1, 4), len(orc) - 1)):
+                    buf.popleft()
+                    orc.popleft()
+            else:
+                n = min(2, len(orc))
+                u = rs.random_sample(n)
+                want = orc.sample(u)
+                out = buf.sample_device(n, u01=u)
+                np.testing.assert_array_equal(out["x"].cpu().numpy() - buf.frame.head,
+                                              want["indices"])
+                vals = rs.rand(n) * 2 + 1e-3
+                orc.set_last_priority(vals, np.full(n, 1))
+                buf.set_last_priority([float(v) for v in vals])
+            got, so = buf.root_stats(), orc.stats()
+            assert got[0] == so["sum"] and got[1] == so["min"], (seed, step)
+            assert buf.frame.bounds == so["bounds"]

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
-"""Device pairing of the host containers added late in round 1, NOT yet run on hardware
-(DESIGN.md 8): run on an MI355X before promoting these checks to ``-m gpu`` tests.
+"""Device pairing of the episodic host containers; also run as ``-m gpu`` tests
+(tests/test_episodic_recurrent.py imports the two checks below).
 
   1. PrioritizedEpisodicReplayBuffer over the HBM priority trees, against the reference traces
      tests/golden/prioritized_episodic_trace_*.npz (the CPU test uses the oracle's tree).
