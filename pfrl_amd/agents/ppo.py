@@ -142,10 +142,6 @@ class PPO(agent.AttributeSavingMixin, agent.BatchAgent):
         self.optimizer = optimizer
         self.obs_normalizer = obs_normalizer
         on_gpu = gpu is not None and gpu >= 0
-        if recurrent and on_gpu:
-            raise NotImplementedError(
-                "recurrent PPO runs on the host path only (gpu=None); the HBM rollout store "
-                "holds fixed-length (T, N) rollouts")
         if on_gpu:
             assert torch.cuda.is_available()
             self.device = torch.device("cuda:{}".format(gpu))
@@ -199,13 +195,18 @@ class PPO(agent.AttributeSavingMixin, agent.BatchAgent):
 
         self.grad_reducer = GradientAllReducer(self.model)
         self._host = None
-        if on_gpu:
+        if on_gpu and not recurrent:
             from pfrl_amd.staging import StagingRing
 
             self._stage = StagingRing(self.device,
                                       slot_bytes=max(1 << 22, 96 * int(update_interval)),
                                       n_slots=8)
         else:
+            # gpu=None, and recurrent models on any device: the reference's fragments of
+            # transition dicts (reference ppo.py:56-107,534-632 cut them into sequences of
+            # varying length).  With a GPU the network, the packed sequences and every
+            # loss run on the device; the rollout bookkeeping stays on the host -- the HBM
+            # rollout store holds fixed-length (T, N) columns only.
             from pfrl_amd.agents.ppo_host import HostRollouts
 
             self._host = HostRollouts(self)

@@ -196,7 +196,7 @@ class HostRollouts:
                     a.model, self._input(batch_obs), self.train_prev_recurrent_states)
             else:
                 distrib, value = a.model(self._input(batch_obs))
-            batch_action = distrib.sample().cpu().numpy()
+            batch_action = a._sample_action(distrib).cpu().numpy()
             a.entropy_record.extend(distrib.entropy())
             a.value_record.extend(value)
         self.batch_last_state = list(batch_obs)

@@ -8,6 +8,7 @@ import glob
 import os
 import pickle
 import shutil
+import tempfile
 
 import numpy as np
 import pytest
@@ -770,3 +771,63 @@ def test_drqn_with_the_network_on_the_device_matches_reference_trace():
     """DoubleDQN(recurrent=True, gpu=0): episodes replayed as packed sequences on the GPU;
     sampled windows exactly, actions step for step, first losses to 1e-3."""
     _load_episodic_gpu_checks().check_drqn()
+
+
+def _run_recurrent_ppo(gpu, replay_actions=None):
+    from pfrl_amd import agents, experiments
+    from pfrl_amd.envs.synthetic import HostSyntheticAtariVectorEnv
+    from pfrl_amd.nn import Branched, RecurrentSequential
+    from pfrl_amd.policies import SoftmaxCategoricalHead
+
+    pfrl_amd.utils.set_random_seed(0)
+    env = HostSyntheticAtariVectorEnv(4, seed=5, frame_shape=(12, 12), p_done=0.06)
+    torch.manual_seed(4321)
+    tnn = torch.nn
+    model = RecurrentSequential(
+        tnn.Flatten(), tnn.Linear(4 * 144, 32), tnn.ReLU(), tnn.LSTM(32, 16),
+        Branched(tnn.Sequential(tnn.Linear(16, 6), SoftmaxCategoricalHead()), tnn.Linear(16, 1)))
+    opt = torch.optim.SGD(model.parameters(), lr=1e-2)
+    ag = agents.PPO(model, opt, gpu=gpu, gamma=0.99, lambd=0.95, phi=_phi, update_interval=64,
+                    minibatch_size=16, epochs=2, clip_eps=0.1, clip_eps_vf=None,
+                    standardize_advantages=True, max_grad_norm=0.5, recurrent=True,
+                    max_recurrent_sequence_len=8)
+    actions, losses = [], []
+    step = [0]
+    orig_sample, orig_loss = ag._sample_action, ag._lossfun
+
+    def sample(distrib):
+        if replay_actions is None:
+            a = orig_sample(distrib)
+        else:
+            a = torch.as_tensor(replay_actions[step[0]], device=ag.device)
+        step[0] += 1
+        actions.append(a.cpu().numpy().copy())
+        return a
+
+    def spy_loss(*a, **kw):
+        out = orig_loss(*a, **kw)
+        losses.append(float(out.detach()))
+        return out
+
+    ag._sample_action, ag._lossfun = sample, spy_loss
+    experiments.train_agent_batch(ag, env, 280, tempfile.mkdtemp())
+    params = np.concatenate([p.detach().cpu().numpy().ravel() for p in model.parameters()])
+    return dict(actions=np.asarray(actions), losses=np.asarray(losses), params=params, agent=ag)
+
+
+@pytest.mark.gpu
+def test_recurrent_ppo_with_the_network_on_the_device_matches_the_host_run():
+    """PPO(recurrent=True, gpu=0) (reference ppo.py:56-107,534-632): the network, the packed
+    sequences and the losses on the GPU, rollout fragments on the host.  Same seeds and the
+    host run's sampled actions (CPU and GPU generators differ by construction): every loss
+    and the trained parameters agree with the gpu=None run, which the reference's own
+    test-suite pins (COVERAGE.md)."""
+    host = _run_recurrent_ppo(None)
+    dev = _run_recurrent_ppo(0, replay_actions=host["actions"])
+    ag = dev["agent"]
+    assert ag.device.type == "cuda" and ag.recurrent and ag._host is not None
+    assert next(ag.model.parameters()).is_cuda
+    assert ag.n_updates == host["agent"].n_updates > 0
+    np.testing.assert_array_equal(dev["actions"], host["actions"])
+    np.testing.assert_allclose(dev["losses"], host["losses"], rtol=2e-4, atol=1e-5)
+    np.testing.assert_allclose(dev["params"], host["params"], rtol=2e-4, atol=1e-5)
