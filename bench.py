@@ -234,14 +234,20 @@ def build_sac(args, device, rank):
                            pfrl.nn.Lambda(squashed_diagonal_gaussian_head))
     for i in (0, 2, 4):
         nn.init.xavier_uniform_(policy[i].weight)
-    popt = torch.optim.Adam(policy.parameters(), lr=3e-4, fused=True)
+    if args.torch_optimizer:
+        Adam = lambda ps: torch.optim.Adam(ps, lr=3e-4, fused=True)
+    else:
+        from pfrl_amd.optimizers import FusedAdam
+
+        Adam = lambda ps: FusedAdam(ps, lr=3e-4)   # torch.optim.Adam's step as one launch
+    popt = Adam(policy.parameters())
 
     def make_q():
         q = nn.Sequential(pfrl.nn.ConcatObsAndAction(), nn.Linear(obs_size + action_size, 256),
                           nn.ReLU(), nn.Linear(256, 256), nn.ReLU(), nn.Linear(256, 1))
         for i in (1, 3, 5):
             nn.init.xavier_uniform_(q[i].weight)
-        return q, torch.optim.Adam(q.parameters(), lr=3e-4, fused=True)
+        return q, Adam(q.parameters())
 
     q1, q1opt = make_q()
     q2, q2opt = make_q()

@@ -382,7 +382,11 @@ int pfrl_noisy_weights_bwd(const float *g_w, const float *g_b, const float *r, f
  *   to 12 tensors in one launch (host arrays of device pointers, passed by value).
  * pfrl_linear_small_fwd / _bwd: a narrow head, y = x w^T + b with out_features <= 16
  *   (Linear(512, n_actions), pfrl/q_functions/state_q_functions.py) and its backward
- *   (dx may be NULL). */
+ *   (dx may be NULL).
+ * pfrl_linear_fwd: y = act(x w^T + b), x [M][K], w [N][K], any K and N, no alignment
+ *   requirement -- the `nn.Linear` layers of the MLP agents (obs 376 -> 256,
+ *   obs + action 393 -> 256: examples/mujoco/reproduction/soft_actor_critic/
+ *   train_soft_actor_critic.py:172-243).  splits > 1: partials for pfrl_splitk_reduce. */
 int pfrl_conv2d_nhwc_fwd(const float *x, const float *w, const float *bias, float *y, int32_t N,
                          int32_t H, int32_t W, int32_t C, int32_t Cout, int32_t R, int32_t S,
                          int32_t stride, int32_t relu, int32_t planar_out, int32_t splits,
@@ -407,10 +411,44 @@ int pfrl_splitk_reduce(int32_t n_tasks, const float *const *host_part, float *co
                        const float *const *host_bias, const int64_t *host_stride,
                        const int32_t *host_n, const int32_t *host_splits, const int32_t *host_ncol,
                        const int32_t *host_relu, void *stream);
+int pfrl_linear_fwd(const float *x, const float *w, const float *bias, float *y, int32_t M, int32_t K,
+                    int32_t N, int32_t relu, int32_t splits, void *stream);
 int pfrl_linear_small_fwd(const float *x, const float *w, const float *bias, float *y, int32_t M,
                           int32_t K, int32_t N, void *stream);
 int pfrl_linear_small_bwd(const float *dy, const float *x, const float *w, float *dx, float *dw,
                           float *db, int32_t M, int32_t K, int32_t N, void *stream);
+
+/* ------------------------------------------------------------------------
+ * Actor-critic update helpers (csrc/actor.hip): the elementwise stretches of the
+ * SAC / TD3 / DDPG update, pfrl/agents/soft_actor_critic.py:213-330.
+ *
+ * pfrl_squashed_gaussian_fwd: for the policy head of examples/mujoco/reproduction/
+ *   soft_actor_critic/train_soft_actor_critic.py:128-141 -- TransformedDistribution(
+ *   Independent(Normal(loc, scale), 1), [TanhTransform(cache_size=1)]) -- the
+ *   reparameterised sample action = tanh(loc + eps*scale) [B][A] and its
+ *   log-probability logp[B] (what `rsample()` + `log_prob()` compute, agents/
+ *   soft_actor_critic.py:228-229, 282-283).  loc / scale rows may be strided (ld in
+ *   elements); eps [B][A] is the caller's standard-normal draw.
+ * pfrl_squashed_gaussian_bwd: gradients w.r.t. loc and scale ([B][A] each) from
+ *   dL/daction (may be NULL) and dL/dlogp (may be NULL).
+ * pfrl_soft_update: dst <- (1 - tau) dst + tau src for n tensors in one launch
+ *   (pfrl/utils/copy_param.py:10-28; host arrays of device pointers, by value).
+ * pfrl_adam_step: torch.optim.Adam's update (no amsgrad; _single_tensor_adam
+ *   arithmetic) for n tensors in one launch.  steps[t] is the tensor's device-side f32
+ *   step counter: read as t - 1, advanced by one inside the launch.  `ticket` is a
+ *   zero-initialised device uint32 owned by the optimizer. */
+int pfrl_squashed_gaussian_fwd(const float *loc, int64_t ld_loc, const float *scale, int64_t ld_scale,
+                               const float *eps, float *action, float *logp, int32_t B, int32_t A,
+                               void *stream);
+int pfrl_squashed_gaussian_bwd(const float *g_action, const float *g_logp, const float *action,
+                               const float *eps, const float *scale, int64_t ld_scale, float *g_loc,
+                               float *g_scale, int32_t B, int32_t A, void *stream);
+int pfrl_soft_update(int32_t n_tensors, float *const *dst, const float *const *src,
+                     const int64_t *numel, double tau, void *stream);
+int pfrl_adam_step(int32_t n_tensors, float *const *params, const float *const *grads,
+                   float *const *exp_avg, float *const *exp_avg_sq, float *const *steps,
+                   const int64_t *numel, double lr, double beta1, double beta2, double eps,
+                   double weight_decay, void *ticket, void *stream);
 
 /* ------------------------------------------------------------------------
  * Measurement support (bench.py roofline): time every pfrl_batch_experiences

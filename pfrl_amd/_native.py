@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_DIR = os.path.join(_HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libpfrl_amd.so")
-SOURCES = ["frames.hip", "replay.hip", "sumtree.hip", "rollout.hip", "optim.hip", "tdloss.hip", "bias_act.hip", "noisy.hip", "c51.hip", "dueling.hip", "qnet.hip"]
+SOURCES = ["frames.hip", "replay.hip", "sumtree.hip", "rollout.hip", "optim.hip", "tdloss.hip", "bias_act.hip", "noisy.hip", "c51.hip", "dueling.hip", "qnet.hip", "actor.hip"]
 HIPCC_FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
     # the parity contract is one correctly rounded IEEE op per source op
@@ -130,8 +130,13 @@ EXPORTS = {
     "pfrl_conv2d_nhwc_bwd_weight": (ctypes.c_int, "pppppqqiiiiiiiiip"),
     "pfrl_conv2d_nhwc_bwd": (ctypes.c_int, "ppppppppqqiiiiiiiiiiip"),
     "pfrl_splitk_reduce": (ctypes.c_int, "ippppppppp"),
+    "pfrl_linear_fwd": (ctypes.c_int, "ppppiiiiip"),
     "pfrl_linear_small_fwd": (ctypes.c_int, "ppppiiip"),
     "pfrl_linear_small_bwd": (ctypes.c_int, "ppppppiiip"),
+    "pfrl_squashed_gaussian_fwd": (ctypes.c_int, "pqpqpppiip"),
+    "pfrl_squashed_gaussian_bwd": (ctypes.c_int, "pppppqppiip"),
+    "pfrl_soft_update": (ctypes.c_int, "ipppdp"),
+    "pfrl_adam_step": (ctypes.c_int, "ippppppdddddpp"),
     "pfrl_profile_enable": (ctypes.c_int, "i"),
     "pfrl_profile_collect": (ctypes.c_int64, "pppq"),
 }

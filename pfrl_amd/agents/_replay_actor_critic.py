@@ -25,8 +25,13 @@ class ReplayActorCritic(AttributeSavingMixin, BatchAgent):
         if gpu is not None and gpu >= 0:
             assert torch.cuda.is_available()
             self.device = torch.device("cuda:{}".format(gpu))
+            from pfrl_amd.nn import accelerate_mlp
+
             for m in modules:
                 m.to(self.device)
+                # nn.Linear (+ ReLU) at minibatch size on the MFMA kernels; the target
+                # networks are deep copies made after this and inherit it
+                accelerate_mlp(m)
         else:
             self.device = torch.device("cpu")
         self.gpu = gpu

@@ -17,7 +17,7 @@ from pfrl_amd.agents._replay_actor_critic import ReplayActorCritic
 from pfrl_amd.utils.batch_states import batch_states
 from pfrl_amd.utils.clip_l2_grad_norm import clip_l2_grad_norm_
 from pfrl_amd.utils.contexts import evaluating
-from pfrl_amd.utils.copy_param import synchronize_parameters
+from pfrl_amd.utils.copy_param import soft_copy_params
 
 
 def default_target_policy_smoothing_func(batch_action):
@@ -80,9 +80,8 @@ class TD3(ReplayActorCritic):
         return [self.policy_optimizer, self.q_func1_optimizer, self.q_func2_optimizer]
 
     def sync_target_network(self):
-        for src, dst in ((self.policy, self.target_policy), (self.q_func1, self.target_q_func1),
-                         (self.q_func2, self.target_q_func2)):
-            synchronize_parameters(src=src, dst=dst, method="soft", tau=self.soft_update_tau)
+        soft_copy_params([(self.target_policy, self.policy), (self.target_q_func1, self.q_func1),
+                          (self.target_q_func2, self.q_func2)], self.soft_update_tau)
 
     # -- learning -----------------------------------------------------------------------
     def _step(self, loss, module, optimizer):

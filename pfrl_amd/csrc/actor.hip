@@ -1,0 +1,269 @@
+// Actor-critic update helpers for gfx950: the stretches of the SAC / TD3 / DDPG update
+// (pfrl/agents/soft_actor_critic.py:213-330) that PyTorch issues as dozens of 256-element
+// elementwise launches, each ~4 us inside a captured graph whatever its size.
+//
+//   squashed Gaussian   a = tanh(loc + eps * scale) and log pi(a) of the example policy head
+//                       (TransformedDistribution(Independent(Normal), [TanhTransform]),
+//                       examples/mujoco/reproduction/soft_actor_critic/
+//                       train_soft_actor_critic.py:128-141): 23 launches -> 1, backward 45 -> 1
+//   soft target update  theta' <- (1 - tau) theta' + tau theta (pfrl/utils/copy_param.py:10-28)
+//                       for every tensor of several networks in one launch
+//   Adam                torch.optim.Adam's step for all parameters of an optimizer in one
+//                       launch, the step counters advanced by the last workgroup to finish
+//
+// All HBM / latency bound elementwise work; every arithmetic step is one rounded f32
+// operation in the order of the PyTorch code it replaces (built with -ffp-contract=off).
+#include "common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kChunk = 1024;
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// ---------------------------------------------------------------------------------
+// tanh-squashed diagonal Gaussian: sample and log-probability, one wave per row
+// ---------------------------------------------------------------------------------
+// torch.distributions arithmetic (Normal.log_prob, TanhTransform.log_abs_det_jacobian,
+// TransformedDistribution.log_prob with the transform's cached pre-image x):
+//   x = loc + eps * scale;  a = tanh(x)
+//   log N(x) = -((x - loc)^2) / (2 scale^2) - log(scale) - log(sqrt(2 pi))
+//   ladj(x)  = 2 (log 2 - x - softplus(-2 x))
+//   log pi   = (0 - sum_a ladj) + sum_a log N
+__global__ __launch_bounds__(kThreads) void k_squashed_gaussian_fwd(
+    const float *__restrict__ loc, int64_t ld_loc, const float *__restrict__ scale, int64_t ld_scale,
+    const float *__restrict__ eps, float *__restrict__ action, float *__restrict__ logp, int B, int A) {
+    const int row = blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= B) return;
+    float s_ladj = 0.f, s_nlp = 0.f;
+    for (int a = lane; a < A; a += 64) {
+        const float l = loc[(int64_t)row * ld_loc + a], s = scale[(int64_t)row * ld_scale + a];
+        const float e = eps[(int64_t)row * A + a];
+        const float x = l + e * s;
+        action[(int64_t)row * A + a] = tanhf(x);
+        const float d = x - l;
+        const float nlp = -(d * d) / (2.f * (s * s)) - logf(s) - 0.9189385332046727f;
+        const float z = -2.f * x;
+        const float sp = z > 20.f ? z : log1pf(expf(z));
+        s_ladj += 2.f * (0.6931471805599453f - x - sp);
+        s_nlp += nlp;
+    }
+    s_ladj = wave_sum(s_ladj);
+    s_nlp = wave_sum(s_nlp);
+    if (lane == 0) logp[row] = (0.f - s_ladj) + s_nlp;
+}
+
+// Gradients w.r.t. loc and scale given dL/da (g_action, may be null) and dL/dlog pi
+// (g_logp, may be null).  With y = tanh(x):  da/dloc = 1 - y^2, da/dscale = (1 - y^2) eps,
+// dlogpi/dloc = 2 y (the Normal term cancels between x and loc),
+// dlogpi/dscale = 2 y eps - 1 / scale.
+__global__ __launch_bounds__(kThreads) void k_squashed_gaussian_bwd(
+    const float *__restrict__ g_action, const float *__restrict__ g_logp,
+    const float *__restrict__ action, const float *__restrict__ eps, const float *__restrict__ scale,
+    int64_t ld_scale, float *__restrict__ g_loc, float *__restrict__ g_scale, int B, int A) {
+    const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (i >= (int64_t)B * A) return;
+    const int row = (int)(i / A), a = (int)(i - (int64_t)row * A);
+    const float y = action[i], e = eps[i], s = scale[(int64_t)row * ld_scale + a];
+    const float ga = g_action != nullptr ? g_action[i] : 0.f;
+    const float gl = g_logp != nullptr ? g_logp[row] : 0.f;
+    const float t = ga * (1.f - y * y);
+    const float y2 = 2.f * y;
+    g_loc[i] = t + gl * y2;
+    g_scale[i] = t * e + gl * (y2 * e - 1.f / s);
+}
+
+// ---------------------------------------------------------------------------------
+// multi-tensor elementwise launches
+// ---------------------------------------------------------------------------------
+struct SoftArgs {
+    float *dst[PFRL_OPT_MAX_TENSORS];
+    const float *src[PFRL_OPT_MAX_TENSORS];
+    int64_t numel[PFRL_OPT_MAX_TENSORS];
+    int32_t chunk_end[PFRL_OPT_MAX_TENSORS];
+    int32_t n;
+};
+
+__global__ __launch_bounds__(kThreads) void k_soft_update(SoftArgs a, float one_minus_tau, float tau) {
+    int t = 0;
+    const int b = blockIdx.x;
+    while (t < a.n - 1 && b >= a.chunk_end[t]) ++t;
+    const int first = t == 0 ? 0 : a.chunk_end[t - 1];
+    const int64_t base = (int64_t)(b - first) * kChunk;
+    float *__restrict__ dst = a.dst[t];
+    const float *__restrict__ src = a.src[t];
+    const int64_t n = a.numel[t];
+    float d[4], s[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int64_t i = base + u * kThreads + threadIdx.x;
+        const int64_t ii = i < n ? i : n - 1;
+        d[u] = dst[ii];
+        s[u] = src[ii];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int64_t i = base + u * kThreads + threadIdx.x;
+        // dst.mul_(1 - tau); dst.add_(tau * src)
+        if (i < n) dst[i] = __fadd_rn(__fmul_rn(d[u], one_minus_tau), __fmul_rn(tau, s[u]));
+    }
+}
+
+struct AdamArgs {
+    float *p[PFRL_OPT_MAX_TENSORS];
+    const float *g[PFRL_OPT_MAX_TENSORS];
+    float *m[PFRL_OPT_MAX_TENSORS];
+    float *v[PFRL_OPT_MAX_TENSORS];
+    float *step[PFRL_OPT_MAX_TENSORS];
+    int64_t numel[PFRL_OPT_MAX_TENSORS];
+    int32_t chunk_end[PFRL_OPT_MAX_TENSORS];
+    int32_t n;
+};
+
+// torch.optim.Adam (no amsgrad), the arithmetic of _single_tensor_adam:
+//   g += wd * p;  m.lerp_(g, 1 - b1);  v.mul_(b2).addcmul_(g, g, value = 1 - b2)
+//   denom = sqrt(v) / sqrt(1 - b2^t) + eps;  p.addcdiv_(m, denom, value = -lr / (1 - b1^t))
+// with t = step + 1 read from the tensor's device-side step counter.  The counters are
+// advanced by whichever workgroup finishes last (ticket), after every workgroup has read them.
+__global__ __launch_bounds__(kThreads) void k_adam(AdamArgs a, double lr, double b1d, double b2d,
+                                                   float eps, float weight_decay,
+                                                   unsigned int *ticket) {
+    __shared__ float s_step_size, s_bc2_sqrt;
+    __shared__ bool s_last;
+    int t = 0;
+    const int b = blockIdx.x;
+    while (t < a.n - 1 && b >= a.chunk_end[t]) ++t;
+    const int first = t == 0 ? 0 : a.chunk_end[t - 1];
+    const int64_t base = (int64_t)(b - first) * kChunk;
+    if (threadIdx.x == 0) {
+        const double step = (double)(*a.step[t]) + 1.0;
+        const double bc1 = 1.0 - pow(b1d, step), bc2 = 1.0 - pow(b2d, step);
+        s_step_size = (float)(-(lr / bc1));
+        s_bc2_sqrt = (float)sqrt(bc2);
+    }
+    float *__restrict__ p = a.p[t];
+    const float *__restrict__ g = a.g[t];
+    float *__restrict__ m = a.m[t];
+    float *__restrict__ v = a.v[t];
+    const int64_t n = a.numel[t];
+    float pv[4], gv[4], mv[4], vv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int64_t i = base + u * kThreads + threadIdx.x;
+        const int64_t ii = i < n ? i : n - 1;
+        pv[u] = p[ii]; gv[u] = g[ii]; mv[u] = m[ii]; vv[u] = v[ii];
+    }
+    __syncthreads();
+    const float step_size = s_step_size, bc2_sqrt = s_bc2_sqrt;
+    // the scalars as PyTorch hands them to f32 kernels: computed in double, then rounded
+    const float w1 = (float)(1.0 - b1d), b2 = (float)b2d, omb2 = (float)(1.0 - b2d);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int64_t i = base + u * kThreads + threadIdx.x;
+        if (i >= n) continue;
+        float gi = gv[u];
+        if (weight_decay != 0.0f) gi = __fadd_rn(gi, __fmul_rn(weight_decay, pv[u]));
+        // lerp_(g, w1): the two forms of at::native::lerp
+        const float dm = __fsub_rn(gi, mv[u]);
+        const float mi = w1 < 0.5f ? __fadd_rn(mv[u], __fmul_rn(w1, dm))
+                                   : __fsub_rn(gi, __fmul_rn(dm, __fsub_rn(1.0f, w1)));
+        const float vi = __fadd_rn(__fmul_rn(vv[u], b2), __fmul_rn(__fmul_rn(omb2, gi), gi));
+        const float denom = __fadd_rn(__fdiv_rn(__fsqrt_rn(vi), bc2_sqrt), eps);
+        m[i] = mi;
+        v[i] = vi;
+        p[i] = __fadd_rn(pv[u], __fdiv_rn(__fmul_rn(step_size, mi), denom));
+    }
+    // every workgroup has read its step counter before it takes a ticket
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = atomicAdd(ticket, 1u) == gridDim.x - 1;
+    __syncthreads();
+    if (s_last) {
+        if (threadIdx.x < a.n) *a.step[threadIdx.x] = *a.step[threadIdx.x] + 1.0f;
+        if (threadIdx.x == 0) *ticket = 0u;
+    }
+}
+
+template <typename Args>
+int fill_chunks(Args &a, int n, const int64_t *numel, int lo) {
+    int chunks = 0;
+    for (int t = 0; t < n; ++t) {
+        a.numel[t] = numel[lo + t];
+        chunks += (int)((numel[lo + t] + kChunk - 1) / kChunk);
+        a.chunk_end[t] = chunks;
+    }
+    a.n = n;
+    return chunks;
+}
+
+}  // namespace
+
+extern "C" int pfrl_squashed_gaussian_fwd(const float *loc, int64_t ld_loc, const float *scale,
+                                          int64_t ld_scale, const float *eps, float *action, float *logp,
+                                          int32_t B, int32_t A, void *stream) {
+    PFRL_CHECK_ARG(B >= 0 && A >= 1 && ld_loc >= A && ld_scale >= A, "pfrl_squashed_gaussian_fwd: bad shape");
+    if (B == 0) return 0;
+    hipLaunchKernelGGL(k_squashed_gaussian_fwd, dim3((B + 3) / 4), dim3(kThreads), 0, (hipStream_t)stream,
+                       loc, ld_loc, scale, ld_scale, eps, action, logp, B, A);
+    PFRL_LAUNCH_CHECK();
+}
+
+extern "C" int pfrl_squashed_gaussian_bwd(const float *g_action, const float *g_logp, const float *action,
+                                          const float *eps, const float *scale, int64_t ld_scale,
+                                          float *g_loc, float *g_scale, int32_t B, int32_t A,
+                                          void *stream) {
+    PFRL_CHECK_ARG(B >= 0 && A >= 1 && ld_scale >= A, "pfrl_squashed_gaussian_bwd: bad shape");
+    if (B == 0) return 0;
+    const int64_t n = (int64_t)B * A;
+    hipLaunchKernelGGL(k_squashed_gaussian_bwd, dim3((unsigned)((n + kThreads - 1) / kThreads)),
+                       dim3(kThreads), 0, (hipStream_t)stream, g_action, g_logp, action, eps, scale,
+                       ld_scale, g_loc, g_scale, B, A);
+    PFRL_LAUNCH_CHECK();
+}
+
+extern "C" int pfrl_soft_update(int32_t n_tensors, float *const *dst, const float *const *src,
+                                const int64_t *numel, double tau, void *stream) {
+    PFRL_CHECK_ARG(n_tensors >= 0, "pfrl_soft_update: bad tensor count");
+    for (int lo = 0; lo < n_tensors; lo += PFRL_OPT_MAX_TENSORS) {
+        const int n = (n_tensors - lo) < PFRL_OPT_MAX_TENSORS ? (n_tensors - lo) : PFRL_OPT_MAX_TENSORS;
+        SoftArgs a;
+        for (int t = 0; t < n; ++t) {
+            a.dst[t] = dst[lo + t];
+            a.src[t] = src[lo + t];
+        }
+        const int chunks = fill_chunks(a, n, numel, lo);
+        if (chunks == 0) continue;
+        // the scalars as PyTorch hands them to an f32 kernel: 1 - tau in double, then rounded
+        hipLaunchKernelGGL(k_soft_update, dim3(chunks), dim3(kThreads), 0, (hipStream_t)stream, a,
+                           (float)(1.0 - tau), (float)tau);
+    }
+    PFRL_LAUNCH_CHECK();
+}
+
+extern "C" int pfrl_adam_step(int32_t n_tensors, float *const *params, const float *const *grads,
+                              float *const *exp_avg, float *const *exp_avg_sq, float *const *steps,
+                              const int64_t *numel, double lr, double beta1, double beta2, double eps,
+                              double weight_decay, void *ticket, void *stream) {
+    PFRL_CHECK_ARG(n_tensors >= 0 && ticket != nullptr, "pfrl_adam_step: bad arguments");
+    for (int lo = 0; lo < n_tensors; lo += PFRL_OPT_MAX_TENSORS) {
+        const int n = (n_tensors - lo) < PFRL_OPT_MAX_TENSORS ? (n_tensors - lo) : PFRL_OPT_MAX_TENSORS;
+        AdamArgs a;
+        for (int t = 0; t < n; ++t) {
+            a.p[t] = params[lo + t];
+            a.g[t] = grads[lo + t];
+            a.m[t] = exp_avg[lo + t];
+            a.v[t] = exp_avg_sq[lo + t];
+            a.step[t] = steps[lo + t];
+        }
+        const int chunks = fill_chunks(a, n, numel, lo);
+        PFRL_CHECK_ARG(chunks > 0, "pfrl_adam_step: empty parameters");
+        hipLaunchKernelGGL(k_adam, dim3(chunks), dim3(kThreads), 0, (hipStream_t)stream, a, lr, beta1,
+                           beta2, (float)eps, (float)weight_decay, (unsigned int *)ticket);
+    }
+    PFRL_LAUNCH_CHECK();
+}

@@ -179,7 +179,10 @@ struct FwdArgs {
     int relu, planar, partial;
 };
 
-template <int BM, int BN, int WM, int WN, int WK, int G>
+// TAIL: linear layers (1x1) whose in_features are not a multiple of 32 or whose rows are
+// not 16-byte aligned (MLP inputs such as 376 observations, 376 + 17 with the action
+// appended): scalar loads, addresses clamped to the row, the overhang zeroed when parked.
+template <int BM, int BN, int WM, int WN, int WK, int G, bool TAIL = false>
 __global__ __launch_bounds__(256) void k_conv_fwd(FwdArgs p) {
     static_assert(WM * WN * WK == 4, "four waves");
     constexpr int AM = BM / (16 * WM), AN = BN / (16 * WN);
@@ -194,7 +197,7 @@ __global__ __launch_bounds__(256) void k_conv_fwd(FwdArgs p) {
     const ConvGeom g = p.g;
     const int ohow = g.OH * g.OW;
     const int c0 = blockIdx.z * p.cps;
-    const int c1 = min(c0 + p.cps, p.K / KC);
+    const int c1 = min(c0 + p.cps, TAIL ? (p.K + KC - 1) / KC : p.K / KC);
 
     struct Slot {
         float4 a[NPA], b[NPB];
@@ -209,7 +212,7 @@ __global__ __launch_bounds__(256) void k_conv_fwd(FwdArgs p) {
         const int mm = ok ? m : 0;
         const int n = mm / ohow, rem = mm - n * ohow;
         const int oh = rem / g.OW, ow = rem - oh * g.OW;
-        ap[pp] = p.x + ((size_t)(n * g.H + oh * g.ST) * g.W + ow * g.ST) * g.C + 4 * q;
+        ap[pp] = p.x + ((size_t)(n * g.H + oh * g.ST) * g.W + ow * g.ST) * g.C + (TAIL ? 0 : 4 * q);
         aok[pp] = ok;
     }
 #pragma unroll
@@ -217,12 +220,25 @@ __global__ __launch_bounds__(256) void k_conv_fwd(FwdArgs p) {
         const int f = tid + 256 * pp, row = f >> 3, q = f & 7;
         const int co = n0 + row;
         const bool ok = row < BN && co < g.Cout;
-        bp[pp] = p.w + (size_t)(ok ? co : 0) * p.K + 4 * q;
+        bp[pp] = p.w + (size_t)(ok ? co : 0) * p.K + (TAIL ? 0 : 4 * q);
         bok[pp] = ok;
     }
     const int SC = g.S * g.C, WC = g.W * g.C;
+    const int kq4 = 4 * (tid & 7);
     auto fetch = [&](int c, Slot &sl) {
         const int k0 = c * KC;
+        if (TAIL) {
+            const int kl = p.K - 1;
+            const int i0 = min(k0 + kq4, kl), i1 = min(k0 + kq4 + 1, kl), i2 = min(k0 + kq4 + 2, kl),
+                      i3 = min(k0 + kq4 + 3, kl);
+#pragma unroll
+            for (int pp = 0; pp < NPA; ++pp)
+                sl.a[pp] = make_float4(ap[pp][i0], ap[pp][i1], ap[pp][i2], ap[pp][i3]);
+#pragma unroll
+            for (int pp = 0; pp < NPB; ++pp)
+                sl.b[pp] = make_float4(bp[pp][i0], bp[pp][i1], bp[pp][i2], bp[pp][i3]);
+            return;
+        }
         const int r = k0 / SC, o = k0 - r * SC;
         const int ad = r * WC + o;
 #pragma unroll
@@ -230,18 +246,28 @@ __global__ __launch_bounds__(256) void k_conv_fwd(FwdArgs p) {
 #pragma unroll
         for (int pp = 0; pp < NPB; ++pp) sl.b[pp] = ldg4(bp[pp] + k0);
     };
-    auto stash = [&](int buf, int, const Slot &sl) {
+    auto stash = [&](int buf, int c, const Slot &sl) {
+        // (TAIL) elements of this lane that lie inside the row; the overhang is zeroed
+        const int left = TAIL ? p.K - (c * KC + kq4) : 4;
 #pragma unroll
         for (int pp = 0; pp < NPA; ++pp) {
             const int f = tid + 256 * pp, row = f >> 3, q = f & 7;
-            if (row < BM)
-                *reinterpret_cast<float4 *>(&As[buf][row * LDR + 4 * q]) = zero_unless(sl.a[pp], aok[pp]);
+            float4 v = zero_unless(sl.a[pp], aok[pp]);
+            if (TAIL) {
+                v.x = left > 0 ? v.x : 0.f; v.y = left > 1 ? v.y : 0.f;
+                v.z = left > 2 ? v.z : 0.f; v.w = left > 3 ? v.w : 0.f;
+            }
+            if (row < BM) *reinterpret_cast<float4 *>(&As[buf][row * LDR + 4 * q]) = v;
         }
 #pragma unroll
         for (int pp = 0; pp < NPB; ++pp) {
             const int f = tid + 256 * pp, row = f >> 3, q = f & 7;
-            if (row < BN)
-                *reinterpret_cast<float4 *>(&Bs[buf][row * LDR + 4 * q]) = zero_unless(sl.b[pp], bok[pp]);
+            float4 v = zero_unless(sl.b[pp], bok[pp]);
+            if (TAIL) {
+                v.x = left > 0 ? v.x : 0.f; v.y = left > 1 ? v.y : 0.f;
+                v.z = left > 2 ? v.z : 0.f; v.w = left > 3 ? v.w : 0.f;
+            }
+            if (row < BN) *reinterpret_cast<float4 *>(&Bs[buf][row * LDR + 4 * q]) = v;
         }
     };
 
@@ -724,50 +750,67 @@ __global__ __launch_bounds__(256) void k_linear_small_fwd(const float *__restric
 }
 
 // dx[m][k] = sum_n dy[m][n] w[n][k];  dw[n][k] = sum_m dy[m][n] x[m][k];  db[n] = sum_m dy[m][n]
-// grid (K / 256, 1 + M / 8): row y = 0 of the grid owns dw / db (one k column per thread, x
-// read 8 rows at a time, loads first), rows y >= 1 own dx for 8 batch rows each.
+// One launch, two kinds of workgroup.  The first ceil(K / 32) own dw (and db): 32 k columns
+// x 8 slices of the batch per workgroup, each thread walks its rows m = slice, slice + 8, ..
+// eight loads at a time, the slices are folded through LDS.  (A column per thread over the
+// whole batch is M / 8 dependent memory round trips: 30 us at M = 256.)  The others own dx
+// for 8 batch rows x 256 k columns each.
 template <int N>
 __global__ __launch_bounds__(256) void k_linear_small_bwd(const float *__restrict__ dy,
                                                           const float *__restrict__ x,
                                                           const float *__restrict__ w,
                                                           float *__restrict__ dx, float *__restrict__ dw,
-                                                          float *__restrict__ db, int M, int K) {
+                                                          float *__restrict__ db, int M, int K, int n_dw) {
     extern __shared__ float sdy[];   // [M][N]
+    __shared__ float red[8][32][N + 1];
     const int tid = threadIdx.x;
     for (int e = tid; e < M * N; e += 256) sdy[e] = dy[e];
     __syncthreads();
-    const int k = blockIdx.x * 256 + tid;
-    const bool valid = k < K;
-    const int kk = valid ? k : K - 1;
-    if (blockIdx.y == 0) {
+    if ((int)blockIdx.x < n_dw) {
         if (blockIdx.x == 0 && tid < N && db != nullptr) {
             float s = 0.f;
             for (int m = 0; m < M; ++m) s += sdy[m * N + tid];
             db[tid] = s;
         }
+        const int kc = tid & 31, slice = tid >> 5;
+        const int k = blockIdx.x * 32 + kc;
+        const int kk = k < K ? k : K - 1;
         float gw[N];
 #pragma unroll
         for (int n = 0; n < N; ++n) gw[n] = 0.f;
-        for (int m0 = 0; m0 < M; m0 += 8) {
+        for (int m0 = slice; m0 < M; m0 += 64) {
             float xv[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) xv[u] = x[(size_t)min(m0 + u, M - 1) * K + kk];
+            for (int u = 0; u < 8; ++u) xv[u] = x[(size_t)min(m0 + 8 * u, M - 1) * K + kk];
 #pragma unroll
             for (int u = 0; u < 8; ++u)
-                if (m0 + u < M) {
+                if (m0 + 8 * u < M) {
 #pragma unroll
-                    for (int n = 0; n < N; ++n) gw[n] = fmaf(sdy[(m0 + u) * N + n], xv[u], gw[n]);
+                    for (int n = 0; n < N; ++n) gw[n] = fmaf(sdy[(m0 + 8 * u) * N + n], xv[u], gw[n]);
                 }
         }
-        if (valid) {
 #pragma unroll
-            for (int n = 0; n < N; ++n) dw[(size_t)n * K + k] = gw[n];
+        for (int n = 0; n < N; ++n) red[slice][kc][n] = gw[n];
+        __syncthreads();
+        // 32 columns x N outputs folded by the first 32 * N threads (N <= 16: two passes at most)
+        for (int e = tid; e < 32 * N; e += 256) {
+            const int c = e & 31, n = e >> 5;
+            float s = red[0][c][n];
+#pragma unroll
+            for (int sl = 1; sl < 8; ++sl) s += red[sl][c][n];
+            const int ko = blockIdx.x * 32 + c;
+            if (ko < K) dw[(size_t)n * K + ko] = s;
         }
     } else {
+        const int kx = (K + 255) / 256;
+        const int r = blockIdx.x - n_dw;
+        const int k = (r % kx) * 256 + tid;
+        const bool valid = k < K;
+        const int kk = valid ? k : K - 1;
         float wk[N];
 #pragma unroll
         for (int n = 0; n < N; ++n) wk[n] = w[(size_t)n * K + kk];
-        const int m0 = (blockIdx.y - 1) * 8;
+        const int m0 = (r / kx) * 8;
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int m = m0 + u;
@@ -830,6 +873,35 @@ extern "C" int pfrl_conv2d_nhwc_fwd(const float *x, const float *w, const float 
         FWD(16, 32, 1, 2, 2, 4);
     }
 #undef FWD
+    PFRL_LAUNCH_CHECK();
+}
+
+// y = act(x w^T + b) for any in_features: the 1x1 case of the forward kernel, with the TAIL
+// loaders when K is not a multiple of 32 (rows need no alignment then).  splits > 1 writes
+// partials [splits][M][N] for pfrl_splitk_reduce, as pfrl_conv2d_nhwc_fwd does.
+extern "C" int pfrl_linear_fwd(const float *x, const float *w, const float *bias, float *y, int32_t M,
+                               int32_t K, int32_t N, int32_t relu, int32_t splits, void *stream) {
+    PFRL_CHECK_ARG(M >= 1 && K >= 1 && N >= 1 && splits >= 1, "pfrl_linear_fwd: empty problem");
+    if (K % KC == 0)
+        return pfrl_conv2d_nhwc_fwd(x, w, bias, y, M, 1, 1, K, N, 1, 1, 1, relu, 0, splits, stream);
+    FwdArgs a;
+    a.x = x; a.w = w; a.bias = bias; a.y = y;
+    a.g = ConvGeom{M, 1, 1, K, N, 1, 1, 1, 1, 1};
+    a.M = M;
+    a.K = K;
+    const int nch = (K + KC - 1) / KC;
+    a.cps = (nch + splits - 1) / splits;
+    a.relu = relu; a.planar = 0; a.partial = splits > 1;
+    PFRL_CHECK_ARG(a.partial || bias != nullptr, "pfrl_linear_fwd: bias required");
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned z = (unsigned)splits;
+#define FWDT(BM, BN, WM, WN, WK, G)                                                                  \
+    hipLaunchKernelGGL((k_conv_fwd<BM, BN, WM, WN, WK, G, true>),                                    \
+                       dim3((M + BM - 1) / BM, (N + BN - 1) / BN, z), dim3(256), 0, st, a)
+    if (N % 32 != 0 && N <= 16) FWDT(32, 16, 2, 1, 2, 4);
+    else if ((long long)((M + 31) / 32) * ((N + 31) / 32) * z >= 384) FWDT(32, 32, 2, 2, 1, 4);
+    else FWDT(16, 32, 1, 2, 2, 4);
+#undef FWDT
     PFRL_LAUNCH_CHECK();
 }
 
@@ -1024,12 +1096,13 @@ extern "C" int pfrl_linear_small_fwd(const float *x, const float *w, const float
 extern "C" int pfrl_linear_small_bwd(const float *dy, const float *x, const float *w, float *dx,
                                      float *dw, float *db, int32_t M, int32_t K, int32_t N,
                                      void *stream) {
-    PFRL_CHECK_ARG(N >= 1 && N <= SMALL_N && M >= 1 && K >= 1 && (size_t)M * N * 4 <= 48 * 1024,
-                   "pfrl_linear_small_bwd: N <= 16, M * N <= 12288");
-    const dim3 grid((K + 255) / 256, dx != nullptr ? 1 + (M + 7) / 8 : 1);
+    PFRL_CHECK_ARG(N >= 1 && N <= SMALL_N && M >= 1 && K >= 1 && (size_t)M * N * 4 <= 40 * 1024,
+                   "pfrl_linear_small_bwd: N <= 16, M * N <= 10240");
+    const int n_dw = (K + 31) / 32;
+    const dim3 grid(n_dw + (dx != nullptr ? ((K + 255) / 256) * ((M + 7) / 8) : 0));
 #define CALL_BWD(NN)                                                                              \
     hipLaunchKernelGGL(k_linear_small_bwd<NN>, grid, dim3(256), (size_t)M * N * sizeof(float),   \
-                       (hipStream_t)stream, dy, x, w, dx, dw, db, M, K)
+                       (hipStream_t)stream, dy, x, w, dx, dw, db, M, K, n_dw)
     SMALL_DISPATCH(N, CALL_BWD)
 #undef CALL_BWD
     PFRL_LAUNCH_CHECK();

@@ -1,6 +1,7 @@
 from pfrl_amd.nn.atari_cnn import (LargeAtariCNN, SmallAtariCNN,  # NOQA
                                    fuse_conv_bias_relu)
 from pfrl_amd.nn.mfma_trunk import accelerate_heads, fuse_sequential_trunk  # NOQA
+from pfrl_amd.nn.mfma_linear import accelerate_mlp  # NOQA
 from pfrl_amd.nn.branched import Branched  # NOQA
 from pfrl_amd.nn.mlp import MLP  # NOQA
 from pfrl_amd.nn.noisy_linear import FactorizedNoisyLinear, to_factorized_noisy  # NOQA

@@ -1,0 +1,185 @@
+"""``nn.Linear`` (+ ReLU) of the MLP agents as gfx950 MFMA kernels at minibatch size.
+
+The MLPs of the replay actor-critic agents (256-256 policy and twin Q of
+``examples/mujoco/reproduction/soft_actor_critic/train_soft_actor_critic.py:172-243``, the
+400-300 nets of TD3 / DDPG) are evaluated ~26 times per update at B = 100-256
+(``pfrl/agents/soft_actor_critic.py:213-330``).  Measured on MI355X inside a captured graph
+(``tools/linear_check.py``), the library picks one-workgroup tiles for these shapes: an
+``F.linear`` with a 256 x 256 output takes 63-96 us, and so do the 256 x 256 gradients.  The
+implicit-GEMM engine of ``csrc/qnet.hip`` runs the same layers (the 1 x 1 case) in 5-7 us with
+the bias and ReLU in its epilogue and the ReLU mask folded into both gradient kernels.
+
+``accelerate_mlp(model)`` changes no parameter, name or state_dict key: plain ``nn.Linear``
+children become ``_LinearSlot`` (an ``nn.Linear`` subclass around the same tensors) and plain
+``nn.Sequential`` containers become ``_MlpSequential`` (same children) so that a ``Linear``
+followed by ``nn.ReLU`` is one node.  Inputs outside what the kernels cover (CPU tensors,
+other dtypes, batches above ``PFRL_MFMA_LINEAR_MAX_BATCH``) take ``F.linear`` as before.
+
+Numerics: f32 in, f32 accumulate (exact fmaf chains); only the summation order differs from
+hipBLASLt's.
+"""
+import os
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from pfrl_amd import _native
+from pfrl_amd._native import check
+from pfrl_amd.nn import mfma_trunk as _t
+from pfrl_amd.nn.mfma_trunk import _ceil_div, _p, _stream
+
+_ENABLED = os.environ.get("PFRL_MFMA_LINEAR", "1") != "0"
+_MAX_BATCH = int(os.environ.get("PFRL_MFMA_LINEAR_MAX_BATCH", "1024"))
+# output tiles (16 x 32) from which a layer is launched without split-K
+_DIRECT_TILES = int(os.environ.get("PFRL_MFMA_LINEAR_DIRECT_TILES", "96"))
+MIN_OUT = 17   # narrower layers are the narrow-head kernels' (mfma_trunk._SmallLinear)
+
+
+def _fwd_splits(M, Fo, K):
+    nch = _ceil_div(K, 32)
+    tiles16 = _ceil_div(M, 16) * _ceil_div(Fo, 32)
+    if tiles16 >= _DIRECT_TILES or Fo % 4 != 0:   # (the fold kernel moves float4 columns)
+        return 1
+    want = min(max(448 // tiles16, _ceil_div(nch, 16), 1), nch)
+    cps = _ceil_div(nch, want)
+    return _ceil_div(nch, cps)
+
+
+def _bwd_kernels_cover(M, K, Fo):
+    """Both gradient kernels need a whole number of 32-chunks in their reductions."""
+    return K % 32 == 0 and Fo % 32 == 0
+
+
+class _Linear(torch.autograd.Function):
+    """y = act(x w^T + b), act = ReLU or identity, as one autograd node."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, relu):
+        M, K = x.shape
+        Fo = w.shape[0]
+        x = x.contiguous()
+        lib = _native.lib()
+        y = torch.empty((M, Fo), dtype=torch.float32, device=x.device)
+        splits = _fwd_splits(M, Fo, K)
+        if splits == 1:
+            check(lib.pfrl_linear_fwd(_p(x), _p(w), _p(b), _p(y), M, K, Fo, int(relu), 1, _stream()),
+                  "linear_fwd")
+        else:
+            part = torch.empty((splits, M, Fo), dtype=torch.float32, device=x.device)
+            check(lib.pfrl_linear_fwd(_p(x), _p(w), None, _p(part), M, K, Fo, 0, splits, _stream()),
+                  "linear_fwd_splitk")
+            _t._reduce([(part, y, b, M * Fo, M * Fo, splits, Fo, int(relu))])
+        ctx.relu = bool(relu)
+        ctx.save_for_backward(x, w, y if relu else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, y = ctx.saved_tensors
+        M, K = x.shape
+        Fo = w.shape[0]
+        need_dx = ctx.needs_input_grad[0]
+        dev = x.device
+        if not _bwd_kernels_cover(M, K, Fo):
+            # ragged layers (first layer of an MLP, 2 * action_size heads): library matmuls,
+            # whose outputs are not the 256 x 256 shapes that the heuristics mishandle
+            g = torch.where(y > 0, dy, torch.zeros((), dtype=dy.dtype, device=dev)) if ctx.relu else dy
+            dx = g @ w if need_dx else None
+            return dx, g.t() @ x, g.sum(0), None
+        dy = dy.contiguous()
+        lib = _native.lib()
+        dw = torch.empty_like(w)
+        db = torch.empty(Fo, dtype=torch.float32, device=dev)
+        splits = _t._wgrad_splits(M, Fo, K)
+        nW = w.numel()
+        stride = nW + Fo
+        if splits == 1:
+            pw, pb, st = dw, db, 0
+        else:
+            part = torch.empty(splits * stride, dtype=torch.float32, device=dev)
+            pw, pb, st = part, part[nW:], stride
+        dx = None
+        if need_dx:
+            dx = torch.empty_like(x)
+            if _t._fused_bwd_ok(M, 1, 1, K, 1):
+                check(lib.pfrl_conv2d_nhwc_bwd(_p(dy), _p(y), _p(w), None, _p(x), _p(dx), _p(pw), _p(pb),
+                                               st, st, M, 1, 1, K, Fo, 1, 1, 1, 0, 0, splits, _stream()),
+                      "linear_bwd")
+            else:
+                check(lib.pfrl_conv2d_nhwc_bwd_data(_p(dy), _p(y), _p(w), None, _p(dx), M, 1, 1, K, Fo,
+                                                    1, 1, 1, 0, 0, _stream()), "linear_bwd_data")
+                check(lib.pfrl_conv2d_nhwc_bwd_weight(_p(dy), _p(y), _p(x), _p(pw), _p(pb), st, st, M, 1,
+                                                      1, K, Fo, 1, 1, 1, splits, _stream()),
+                      "linear_bwd_weight")
+        else:
+            check(lib.pfrl_conv2d_nhwc_bwd_weight(_p(dy), _p(y), _p(x), _p(pw), _p(pb), st, st, M, 1, 1,
+                                                  K, Fo, 1, 1, 1, splits, _stream()),
+                  "linear_bwd_weight")
+        if splits > 1:
+            _t._reduce([(part, dw, None, stride, nW, splits, 4, 0),
+                        (pb, db, None, stride, Fo, splits, 4, 0)])
+        return dx, dw, db, None
+
+
+def supported(layer, x):
+    return (_ENABLED and x.is_cuda and x.dim() == 2 and x.dtype == torch.float32
+            and layer.bias is not None and layer.out_features >= MIN_OUT
+            and layer.weight.dtype == torch.float32 and layer.weight.is_contiguous()
+            and 0 < x.shape[0] <= _MAX_BATCH and _native.available())
+
+
+class _LinearSlot(nn.Linear):
+    """An ``nn.Linear`` (same class family, parameter names and state_dict) around the
+    tensors of an existing layer; forward takes the MFMA kernels where ``supported``."""
+
+    def __init__(self, linear):
+        nn.Module.__init__(self)
+        self.__dict__.update({k: v for k, v in linear.__dict__.items()
+                              if k not in ("_parameters", "_buffers", "_modules")})
+        self._parameters = linear._parameters
+        self._buffers = linear._buffers
+        self._modules = linear._modules
+
+    def forward(self, x, relu=False):
+        if supported(self, x):
+            return _Linear.apply(x, self.weight, self.bias, relu)
+        y = nn.Linear.forward(self, x)
+        return F.relu(y) if relu else y
+
+
+class _MlpSequential(nn.Sequential):
+    """An ``nn.Sequential`` (same children, indices, state_dict) that runs a ``_LinearSlot``
+    followed by a plain ``nn.ReLU`` as one node."""
+
+    def forward(self, x):
+        mods = list(self._modules.values())
+        i, n = 0, len(mods)
+        while i < n:
+            m = mods[i]
+            if (isinstance(m, _LinearSlot) and i + 1 < n and type(mods[i + 1]) is nn.ReLU
+                    and torch.is_tensor(x) and supported(m, x)):
+                x = m(x, relu=True)
+                i += 2
+                continue
+            x = m(x)
+            i += 1
+        return x
+
+
+def accelerate_mlp(model):
+    """Route the ``nn.Linear`` layers of ``model`` (plain class, with bias, out_features >= 17)
+    through the MFMA kernels and fuse ``Linear, ReLU`` neighbours of plain ``nn.Sequential``
+    containers; narrower layers get the narrow-head kernels (``accelerate_heads``).  Returns
+    ``model`` (modified in place; parameters, names and state_dict keys unchanged)."""
+    if model is None:
+        return model
+    for parent in list(model.modules()):
+        for name, child in list(parent._modules.items()):
+            if type(child) is nn.Linear and child.bias is not None and child.out_features >= MIN_OUT:
+                parent._modules[name] = _LinearSlot(child)
+    for seq in [m for m in model.modules() if type(m) is nn.Sequential]:
+        if any(isinstance(c, _LinearSlot) for c in seq._modules.values()):
+            seq.__class__ = _MlpSequential
+    _t.accelerate_heads(model)
+    return model

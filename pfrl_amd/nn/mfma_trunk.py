@@ -339,7 +339,7 @@ def small_linear_supported(layer, x):
     return (_ENABLED and isinstance(layer, nn.Linear) and x.is_cuda and x.dim() == 2
             and x.dtype == torch.float32 and layer.out_features <= SMALL_LINEAR_MAX_OUT
             and layer.weight.dtype == torch.float32 and layer.weight.is_contiguous()
-            and x.shape[0] * layer.out_features <= 12288 and x.shape[0] <= 4096
+            and x.shape[0] * layer.out_features <= 10240 and x.shape[0] <= 4096
             and _native.available())
 
 

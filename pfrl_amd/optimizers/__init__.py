@@ -67,6 +67,76 @@ class FusedRMSprop(torch.optim.RMSprop):
         return loss
 
 
+class FusedAdam(torch.optim.Adam):
+    """``torch.optim.Adam`` (same constructor, same state keys ``step`` / ``exp_avg`` /
+    ``exp_avg_sq``, the arithmetic of its single-tensor implementation) whose ``step()`` is
+    pfrl_adam_step: one launch for all parameters of a group, step counters included
+    (they live on the device, as with ``capturable=True``, so the step can be captured in a
+    graph).  torch's own ``fused=True`` kernel walks 65536-element chunks, i.e. ~7 workgroups
+    for the 170 k parameters of the SAC example networks: 40 us per step on MI355X against
+    ~5 us here.  Configurations outside the kernel (amsgrad, maximize, non-f32, CPU, sparse)
+    take torch's step."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0,
+                 amsgrad=False, **kw):
+        kw.pop("fused", None)
+        kw.pop("foreach", None)
+        super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay,
+                         amsgrad=amsgrad, **kw)
+    def _fusable(self, group, params):
+        return (not group["amsgrad"] and not group.get("maximize", False)
+                and not group.get("differentiable", False)
+                and not isinstance(group["lr"], torch.Tensor)
+                and all(p.is_cuda and p.dtype == torch.float32 and _dense(p)
+                        and not p.grad.is_sparse and p.grad.dtype == torch.float32
+                        and p.grad.stride() == p.stride() for p in params))
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        for group in self.param_groups:
+            params = [p for p in group["params"] if p.grad is not None]
+            if not params:
+                continue
+            if not self._fusable(group, params):
+                return super().step(closure=None) if loss is None else loss
+            dev = params[0].device
+            # device-side step counters, as torch's own capturable path keeps them (which is
+            # also what its step() needs should a later call fall outside the kernel)
+            group["capturable"] = True
+            for p in params:
+                st = self.state[p]
+                if len(st) == 0:
+                    st["step"] = torch.zeros((), dtype=torch.float32, device=p.device)
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                elif not st["step"].is_cuda:
+                    # state loaded from a checkpoint of a host-step optimizer
+                    st["step"] = st["step"].to(device=p.device, dtype=torch.float32)
+                if st["exp_avg"].stride() != p.stride() or st["exp_avg_sq"].stride() != p.stride():
+                    return super().step(closure=None) if loss is None else loss
+            tickets = self.__dict__.setdefault("_ticket", {})
+            if dev not in tickets:
+                tickets[dev] = torch.zeros(1, dtype=torch.int32, device=dev)
+            n = len(params)
+            V = ctypes.c_void_p
+            P = (V * n)(*[p.data_ptr() for p in params])
+            G = (V * n)(*[p.grad.data_ptr() for p in params])
+            M = (V * n)(*[self.state[p]["exp_avg"].data_ptr() for p in params])
+            S = (V * n)(*[self.state[p]["exp_avg_sq"].data_ptr() for p in params])
+            T = (V * n)(*[self.state[p]["step"].data_ptr() for p in params])
+            L = (ctypes.c_int64 * n)(*[p.numel() for p in params])
+            b1, b2 = group["betas"]
+            stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+            _native.check(_native.lib().pfrl_adam_step(
+                n, P, G, M, S, T, L, float(group["lr"]), float(b1), float(b2), float(group["eps"]),
+                float(group["weight_decay"]), V(tickets[dev].data_ptr()), stream), "adam_step")
+        return loss
+
+
 class RMSpropEpsInsideSqrt(torch.optim.RMSprop):
     """``torch.optim.RMSprop`` whose denominator is ``sqrt(v + eps)`` instead of ``sqrt(v) + eps``
     -- the A3C / A2C papers' form, used by examples/atari/train_a2c_ale.py (reference

@@ -283,7 +283,12 @@ class ReplayBuffer(replay_buffer.AbstractReplayBuffer):
             torch.save(self._native_state(), filename)
             return
         with open(filename, "wb") as f:
-            pickle.dump(self._portable_queue(), f)
+            if self.store is None and not isinstance(self.memory, RandomAccessQueue):
+                # host PrioritizedBuffer: the object itself, priorities included, as the
+                # reference pickles it (replay_buffer.py:85-88)
+                pickle.dump(self.memory, f)
+            else:
+                pickle.dump(self._portable_queue(), f)
 
     def _portable_queue(self):
         """The queue as a plain ``collections.deque`` of n-step entries (lists of transition

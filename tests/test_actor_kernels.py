@@ -1,0 +1,203 @@
+"""Actor-critic update helpers (csrc/actor.hip) against the PyTorch code they replace.
+
+GPU tests call through the C ABI (pfrl_squashed_gaussian_fwd/_bwd, pfrl_soft_update,
+pfrl_adam_step, pfrl_linear_small_bwd) and compare with torch.distributions / torch.optim /
+the reference's soft-update formula evaluated by torch on the same device.  Tolerances: the
+soft update is bit-exact (three rounded f32 operations in the reference's order); Adam and the
+distribution are the same f32 formulas with at most a different association inside libm calls
+and reductions: 1e-6 relative / 2e-5 on the summed log-probability.
+"""
+import copy
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+from torch import distributions as D
+
+from pfrl_amd.optimizers import FusedAdam
+from pfrl_amd.utils.copy_param import soft_copy_param, soft_copy_params
+from pfrl_amd.utils.squashed_gaussian import sample_with_log_prob, squashed_gaussian_params
+
+
+def _head(x, cache_size=1):
+    mean, log_scale = torch.chunk(x, 2, dim=1)
+    scale = torch.sqrt(torch.exp(torch.clamp(log_scale, -20.0, 2.0) * 2))
+    return D.TransformedDistribution(D.Independent(D.Normal(loc=mean, scale=scale), 1),
+                                     [D.transforms.TanhTransform(cache_size=cache_size)])
+
+
+def test_cpu_distributions_take_their_own_methods():
+    torch.manual_seed(0)
+    x = torch.randn(6, 8)
+    d = _head(x)
+    assert squashed_gaussian_params(d) is None      # CPU tensors
+    torch.manual_seed(1)
+    a, lp = sample_with_log_prob(d, True)
+    torch.manual_seed(1)
+    a2 = d.rsample()
+    assert torch.equal(a, a2) and torch.allclose(lp, d.log_prob(a2))
+
+
+def test_soft_update_cpu_is_the_reference_formula():
+    torch.manual_seed(0)
+    src, dst = nn.Linear(5, 3), nn.Linear(5, 3)
+    want = {k: (1 - 0.01) * v + 0.01 * src.state_dict()[k] for k, v in dst.state_dict().items()}
+    soft_copy_param(dst, src, 0.01)
+    for k, v in dst.state_dict().items():
+        assert torch.allclose(v, want[k], rtol=0, atol=1e-7)
+
+
+def test_fused_adam_on_cpu_is_torch_adam():
+    torch.manual_seed(0)
+    a, b = nn.Linear(4, 4), None
+    b = copy.deepcopy(a)
+    oa, ob = FusedAdam(a.parameters(), lr=1e-2), torch.optim.Adam(b.parameters(), lr=1e-2)
+    for _ in range(3):
+        for m, o in ((a, oa), (b, ob)):
+            o.zero_grad()
+            m(torch.ones(2, 4)).sum().backward()
+            o.step()
+    assert all(torch.equal(p, q) for p, q in zip(a.parameters(), b.parameters()))
+    assert isinstance(oa, torch.optim.Adam)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,A", [(256, 17), (32, 6), (1, 1), (100, 70), (7, 3)])
+def test_squashed_gaussian_matches_torch_distributions(B, A):
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(B * 100 + A)
+    raw = (torch.randn(B, 2 * A, generator=g) * 1.5).to(dev)
+    g_a = torch.randn(B, A, generator=g).to(dev)
+    g_lp = torch.randn(B, generator=g).to(dev)
+    outs = []
+    for fused in (True, False):
+        x = raw.clone().requires_grad_(True)
+        d = _head(x)
+        assert (squashed_gaussian_params(d) is not None) == True
+        torch.manual_seed(5)
+        if fused:
+            a, lp = sample_with_log_prob(d, True)
+        else:
+            a = d.rsample()
+            lp = d.log_prob(a)
+        (gx,) = torch.autograd.grad([a, lp], [x], [g_a, g_lp])
+        outs.append((a.detach(), lp.detach(), gx))
+    (a1, lp1, gx1), (a0, lp0, gx0) = outs
+    assert torch.allclose(a1, a0, rtol=1e-6, atol=1e-7)
+    assert torch.allclose(lp1, lp0, rtol=2e-5, atol=2e-5 * A)
+    scale = max(gx0.abs().max().item(), 1.0)
+    assert (gx1 - gx0).abs().max().item() < 2e-5 * scale
+    # sampling without reparameterisation: same draw, no graph
+    torch.manual_seed(5)
+    a2, lp2 = sample_with_log_prob(_head(raw), False)
+    assert torch.equal(a2, a1) and torch.equal(lp2, lp1) and not a2.requires_grad
+
+
+@pytest.mark.gpu
+def test_other_distributions_are_left_alone():
+    dev = torch.device("cuda:0")
+    raw = torch.randn(4, 6, device=dev)
+    assert squashed_gaussian_params(_head(raw, cache_size=0)) is None
+    n = D.Independent(D.Normal(raw[:, :3], torch.ones(4, 3, device=dev)), 1)
+    assert squashed_gaussian_params(n) is None
+    a, lp = sample_with_log_prob(n, True)
+    assert torch.allclose(lp, n.log_prob(a))
+
+
+@pytest.mark.gpu
+def test_soft_update_is_bit_exact_and_one_launch_covers_many_tensors():
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    mk = lambda: nn.Sequential(nn.Linear(393, 256), nn.ReLU(), nn.Linear(256, 256), nn.ReLU(),
+                               nn.Linear(256, 1), nn.BatchNorm1d(1)).to(dev)
+    srcs = [mk() for _ in range(5)]      # 5 x 8 float tensors: more than one kernel-argument block
+    dsts = [mk() for _ in range(5)]
+    for s in srcs:
+        s[5].num_batches_tracked += 3
+    tau = 5e-3
+    want = []
+    for s, d in zip(srcs, dsts):
+        want.append({k: ((1 - tau) * v + tau * s.state_dict()[k]) if v.is_floating_point()
+                     else s.state_dict()[k].clone() for k, v in d.state_dict().items()})
+    soft_copy_params(list(zip(dsts, srcs)), tau)
+    for d, w in zip(dsts, want):
+        for k, v in d.state_dict().items():
+            assert torch.equal(v, w[k]), k
+
+
+@pytest.mark.gpu
+def test_fused_adam_matches_torch_adam_and_keeps_its_state_layout():
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    net = nn.Sequential(nn.Linear(376, 256), nn.ReLU(), nn.Linear(256, 34))
+    ref = copy.deepcopy(net)                       # stays on the CPU: torch's single-tensor Adam
+    net.to(dev)
+    for wd in (0.0, 1e-2):
+        o = FusedAdam(net.parameters(), lr=3e-4, weight_decay=wd)
+        r = torch.optim.Adam(ref.parameters(), lr=3e-4, weight_decay=wd)
+        x = torch.randn(64, 376)
+        for step in range(6):
+            for m, opt, xx in ((net, o, x.to(dev)), (ref, r, x)):
+                opt.zero_grad()
+                (m(xx) ** 2).mean().backward()
+                opt.step()
+        for p, q in zip(net.parameters(), ref.parameters()):
+            assert (p.cpu() - q).abs().max().item() < 2e-6 * max(q.abs().max().item(), 1e-3)
+            st = o.state[p]
+            assert set(st) == {"step", "exp_avg", "exp_avg_sq"} and float(st["step"]) == 6.0
+            assert (st["exp_avg_sq"].cpu() - r.state[q]["exp_avg_sq"]).abs().max().item() <= 1e-6 * \
+                r.state[q]["exp_avg_sq"].abs().max().item()
+        # the state dict loads into a stock Adam and back
+        stock = torch.optim.Adam(net.parameters(), lr=3e-4, weight_decay=wd, capturable=True)
+        stock.load_state_dict(o.state_dict())
+        o.load_state_dict(stock.state_dict())
+        o.zero_grad()
+        (net(x.to(dev)) ** 2).mean().backward()
+        o.step()
+        assert float(o.state[next(net.parameters())]["step"]) == 7.0
+
+
+@pytest.mark.gpu
+def test_fused_adam_step_in_a_captured_graph():
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    p = nn.Parameter(torch.randn(5000, device=dev))
+    q = nn.Parameter(p.detach().clone())
+    o, r = FusedAdam([p], lr=1e-2), torch.optim.Adam([q], lr=1e-2, capturable=True)
+    grad = torch.randn(5000, device=dev)
+    p.grad, q.grad = grad.clone(), grad.clone()
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        o.step()
+        r.step()
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        o.step()
+    for _ in range(4):
+        graph.replay()
+        r.step()
+    torch.cuda.synchronize()
+    assert float(o.state[p]["step"]) == 5.0 + 0.0   # 1 eager + 4 replays (capture does not run)
+    assert (p - q).abs().max().item() < 2e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,K,N", [(256, 256, 1), (32, 512, 6), (100, 300, 1), (5, 40, 16), (256, 256, 16)])
+def test_narrow_head_backward_matches_torch(M, K, N):
+    from pfrl_amd.nn.mfma_trunk import _SmallLinear
+
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(M + K + N)
+    x = torch.randn(M, K, generator=g).to(dev).requires_grad_(True)
+    w = (torch.randn(N, K, generator=g) / np.sqrt(K)).to(dev).requires_grad_(True)
+    b = torch.randn(N, generator=g).to(dev).requires_grad_(True)
+    dy = torch.randn(M, N, generator=g).to(dev)
+    y = _SmallLinear.apply(x, w, b)
+    got = torch.autograd.grad(y, [x, w, b], dy)
+    y_ref = torch.nn.functional.linear(x, w, b)
+    want = torch.autograd.grad(y_ref, [x, w, b], dy)
+    assert torch.allclose(y, y_ref, rtol=1e-5, atol=1e-5)
+    for a, r in zip(got, want):
+        assert (a - r).abs().max().item() < 2e-5 * max(r.abs().max().item(), 1.0)
