@@ -128,34 +128,39 @@ def test_soft_update_is_bit_exact_and_one_launch_covers_many_tensors():
 
 @pytest.mark.gpu
 def test_fused_adam_matches_torch_adam_and_keeps_its_state_layout():
+    """Same gradients on both sides (Adam turns last-bit gradient differences of near-zero
+    entries into lr-sized update differences, so the gradients are not recomputed per device):
+    the device step against torch's single-tensor Adam on the CPU."""
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
     net = nn.Sequential(nn.Linear(376, 256), nn.ReLU(), nn.Linear(256, 34))
-    ref = copy.deepcopy(net)                       # stays on the CPU: torch's single-tensor Adam
+    ref = copy.deepcopy(net)                       # stays on the CPU
     net.to(dev)
+    g = torch.Generator().manual_seed(1)
     for wd in (0.0, 1e-2):
         o = FusedAdam(net.parameters(), lr=3e-4, weight_decay=wd)
         r = torch.optim.Adam(ref.parameters(), lr=3e-4, weight_decay=wd)
-        x = torch.randn(64, 376)
         for step in range(6):
-            for m, opt, xx in ((net, o, x.to(dev)), (ref, r, x)):
-                opt.zero_grad()
-                (m(xx) ** 2).mean().backward()
-                opt.step()
+            for p, q in zip(net.parameters(), ref.parameters()):
+                q.grad = torch.randn(q.shape, generator=g) * (10.0 ** float(torch.randint(-4, 1, (1,), generator=g)))
+                p.grad = q.grad.to(dev)
+            o.step()
+            r.step()
         for p, q in zip(net.parameters(), ref.parameters()):
-            assert (p.cpu() - q).abs().max().item() < 2e-6 * max(q.abs().max().item(), 1e-3)
+            assert (p.cpu() - q).abs().max().item() <= 2e-7 * max(q.abs().max().item(), 1e-3)
             st = o.state[p]
             assert set(st) == {"step", "exp_avg", "exp_avg_sq"} and float(st["step"]) == 6.0
-            assert (st["exp_avg_sq"].cpu() - r.state[q]["exp_avg_sq"]).abs().max().item() <= 1e-6 * \
-                r.state[q]["exp_avg_sq"].abs().max().item()
+            for key in ("exp_avg", "exp_avg_sq"):
+                ref_v = r.state[q][key]
+                assert (st[key].cpu() - ref_v).abs().max().item() <= 1e-6 * ref_v.abs().max().item()
         # the state dict loads into a stock Adam and back
         stock = torch.optim.Adam(net.parameters(), lr=3e-4, weight_decay=wd, capturable=True)
         stock.load_state_dict(o.state_dict())
         o.load_state_dict(stock.state_dict())
-        o.zero_grad()
-        (net(x.to(dev)) ** 2).mean().backward()
         o.step()
         assert float(o.state[next(net.parameters())]["step"]) == 7.0
+        for p, q in zip(net.parameters(), ref.parameters()):
+            q.data.copy_(p.detach().cpu())         # next round starts from equal parameters
 
 
 @pytest.mark.gpu
