@@ -449,6 +449,32 @@ int pfrl_adam_step(int32_t n_tensors, float *const *params, const float *const *
                    float *const *exp_avg, float *const *exp_avg_sq, float *const *steps,
                    const int64_t *numel, double lr, double beta1, double beta2, double eps,
                    double weight_decay, void *ticket, void *stream);
+/* SAC losses on [B] vectors, pfrl/agents/soft_actor_critic.py.  The temperature is
+ * exp(*log_temperature) when that device pointer is given (TemperatureHolder, :60-76),
+ * else the float argument.
+ * pfrl_sac_target_q (:226-240): target_q = reward + discount * (1 - terminal) *
+ *   (min(next_q1, next_q2) - T * next_log_prob).
+ * pfrl_half_mse_fwd/_bwd (:247-248): loss[0] = 0.5 * mean((target - pred)^2) and its
+ *   gradient w.r.t. pred given g_loss[0].
+ * pfrl_sac_policy_loss_fwd/_bwd (:284-291): loss[0] = mean(T * log_prob - min(q1, q2)) and
+ *   its gradients w.r.t. log_prob, q1, q2 (a tie in the minimum is split evenly). */
+/* pfrl_sac_temperature_loss (:264-271): loss[0] = -mean(exp(*log_temperature) * (log_prob +
+ *   entropy_target)); its derivative w.r.t. log_temperature is the loss itself. */
+int pfrl_sac_temperature_loss(const float *log_temperature, const float *log_prob,
+                              float entropy_target, float *loss, int32_t B, void *stream);
+int pfrl_sac_target_q(const float *reward, const float *discount, const float *terminal,
+                      const float *next_q1, const float *next_q2, const float *next_log_prob,
+                      const float *log_temperature, float temperature, float *target_q, int32_t B,
+                      void *stream);
+int pfrl_half_mse_fwd(const float *target, const float *pred, float *loss, int32_t B, void *stream);
+int pfrl_half_mse_bwd(const float *g_loss, const float *target, const float *pred, float *g_pred,
+                      int32_t B, void *stream);
+int pfrl_sac_policy_loss_fwd(const float *log_prob, const float *q1, const float *q2,
+                             const float *log_temperature, float temperature, float *loss, int32_t B,
+                             void *stream);
+int pfrl_sac_policy_loss_bwd(const float *g_loss, const float *q1, const float *q2,
+                             const float *log_temperature, float temperature, float *g_log_prob,
+                             float *g_q1, float *g_q2, int32_t B, void *stream);
 
 /* ------------------------------------------------------------------------
  * Measurement support (bench.py roofline): time every pfrl_batch_experiences

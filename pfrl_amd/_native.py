@@ -137,6 +137,12 @@ EXPORTS = {
     "pfrl_squashed_gaussian_bwd": (ctypes.c_int, "pppppqppiip"),
     "pfrl_soft_update": (ctypes.c_int, "ipppdp"),
     "pfrl_adam_step": (ctypes.c_int, "ippppppdddddpp"),
+    "pfrl_sac_temperature_loss": (ctypes.c_int, "ppfpip"),
+    "pfrl_sac_target_q": (ctypes.c_int, "pppppppfpip"),
+    "pfrl_half_mse_fwd": (ctypes.c_int, "pppip"),
+    "pfrl_half_mse_bwd": (ctypes.c_int, "ppppip"),
+    "pfrl_sac_policy_loss_fwd": (ctypes.c_int, "ppppfpip"),
+    "pfrl_sac_policy_loss_bwd": (ctypes.c_int, "ppppfpppip"),
     "pfrl_profile_enable": (ctypes.c_int, "i"),
     "pfrl_profile_collect": (ctypes.c_int64, "pppq"),
 }

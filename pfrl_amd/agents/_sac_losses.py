@@ -1,0 +1,146 @@
+"""The three elementwise chains of the SAC update as single launches on the GPU.
+
+``soft_target_q``, ``half_mse`` and ``policy_loss`` state the formulas of
+``pfrl/agents/soft_actor_critic.py:226-248, 284-291`` once in PyTorch operations (the route
+for CPU tensors and anything the kernels do not cover) and once through ``csrc/actor.hip``
+(f32 [B] vectors on the GPU): ~9 + 2 x 7 + ~20 launches of 256 elements become 1 + 2 x 2 + 2.
+``temperature`` is either the fixed float or the ``TemperatureHolder``'s ``log_temperature``
+parameter, whose ``exp`` the kernels take themselves.
+"""
+import ctypes
+
+import torch
+import torch.nn.functional as F
+
+from pfrl_amd import _native
+from pfrl_amd._native import check
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _vec_ok(*ts):
+    return (_native.available() and all(
+        torch.is_tensor(t) and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
+        for t in ts) and ts[0].numel() >= 1 and all(t.numel() == ts[0].numel() for t in ts))
+
+
+def _temperature_args(temperature):
+    """(device pointer to log T or None, float T) from a float or a log-temperature tensor."""
+    if torch.is_tensor(temperature):
+        return _p(temperature), 0.0
+    return None, float(temperature)
+
+
+def _temperature_value(temperature):
+    return torch.exp(temperature.detach()) if torch.is_tensor(temperature) else temperature
+
+
+def soft_target_q(reward, discount, terminal, next_q1, next_q2, next_log_prob, temperature):
+    """reward + discount * (1 - terminal) * (min(next_q1, next_q2) - T * next_log_prob), no
+    gradient.  ``temperature``: float, or the scalar log-temperature tensor (T = exp of it)."""
+    with torch.no_grad():
+        if (_vec_ok(reward, discount, terminal, next_q1, next_q2, next_log_prob)
+                and (not torch.is_tensor(temperature) or temperature.is_cuda)):
+            B = reward.numel()
+            out = torch.empty((B,), dtype=torch.float32, device=reward.device)
+            lt, tv = _temperature_args(temperature)
+            check(_native.lib().pfrl_sac_target_q(_p(reward), _p(discount), _p(terminal), _p(next_q1),
+                                                  _p(next_q2), _p(next_log_prob), lt, tv, _p(out), B,
+                                                  _stream()), "sac_target_q")
+            return out
+        next_q = torch.min(next_q1, next_q2)
+        entropy_term = _temperature_value(temperature) * next_log_prob[..., None]
+        assert next_q.shape == entropy_term.shape
+        return reward + discount * (1.0 - terminal) * torch.flatten(next_q - entropy_term)
+
+
+class _HalfMse(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, target, pred):
+        loss = torch.empty((), dtype=torch.float32, device=pred.device)
+        check(_native.lib().pfrl_half_mse_fwd(_p(target), _p(pred), _p(loss), pred.numel(), _stream()),
+              "half_mse_fwd")
+        ctx.save_for_backward(target, pred)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        target, pred = ctx.saved_tensors
+        g_pred = torch.empty_like(pred)
+        check(_native.lib().pfrl_half_mse_bwd(_p(g.contiguous()), _p(target), _p(pred), _p(g_pred),
+                                              pred.numel(), _stream()), "half_mse_bwd")
+        return None, g_pred
+
+
+def half_mse(target, pred):
+    """0.5 * F.mse_loss(target, pred); ``target`` carries no gradient."""
+    if _vec_ok(target, pred) and not target.requires_grad:
+        return _HalfMse.apply(target, pred)
+    return 0.5 * F.mse_loss(target, pred)
+
+
+class _PolicyLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, log_prob, q1, q2, temperature):
+        loss = torch.empty((), dtype=torch.float32, device=q1.device)
+        lt, tv = _temperature_args(temperature)
+        check(_native.lib().pfrl_sac_policy_loss_fwd(_p(log_prob), _p(q1), _p(q2), lt, tv, _p(loss),
+                                                     q1.numel(), _stream()), "sac_policy_loss_fwd")
+        ctx.save_for_backward(q1, q2, temperature if torch.is_tensor(temperature) else None)
+        ctx.t_val = tv
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        q1, q2, log_t = ctx.saved_tensors
+        g_lp = torch.empty(q1.numel(), dtype=torch.float32, device=q1.device)
+        g1, g2 = torch.empty_like(q1), torch.empty_like(q2)
+        check(_native.lib().pfrl_sac_policy_loss_bwd(_p(g.contiguous()), _p(q1), _p(q2), _p(log_t),
+                                                     ctx.t_val, _p(g_lp), _p(g1), _p(g2), q1.numel(),
+                                                     _stream()), "sac_policy_loss_bwd")
+        return g_lp, g1, g2, None
+
+
+def policy_loss(log_prob, q1, q2, temperature):
+    """mean(T * log_prob[:, None] - min(q1, q2)) for log_prob [B], q1, q2 [B, 1]; the temperature
+    carries no gradient here (it has its own loss)."""
+    if (_vec_ok(log_prob, q1, q2) and q1.dim() == 2
+            and (not torch.is_tensor(temperature) or temperature.is_cuda)):
+        t = temperature.detach() if torch.is_tensor(temperature) else temperature
+        return _PolicyLoss.apply(log_prob, q1, q2, t)
+    q = torch.min(q1, q2)
+    entropy_term = _temperature_value(temperature) * log_prob[..., None]
+    assert q.shape == entropy_term.shape
+    return torch.mean(entropy_term - q)
+
+
+class _TemperatureLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, log_temperature, log_prob, entropy_target):
+        loss = torch.empty((), dtype=torch.float32, device=log_prob.device)
+        check(_native.lib().pfrl_sac_temperature_loss(_p(log_temperature), _p(log_prob),
+                                                      float(entropy_target), _p(loss), log_prob.numel(),
+                                                      _stream()), "sac_temperature_loss")
+        ctx.save_for_backward(loss)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (loss,) = ctx.saved_tensors
+        # d/dlog T of -mean(exp(log T) * c) is the loss itself
+        return g * loss, None, None
+
+
+def temperature_loss(temperature_holder, log_prob, entropy_target):
+    """-mean(T * (log_prob + entropy_target)) with T = temperature_holder()."""
+    log_t = getattr(temperature_holder, "log_temperature", None)
+    if (log_t is not None and _vec_ok(log_prob) and log_t.is_cuda and log_t.dtype == torch.float32
+            and log_t.numel() == 1 and not log_prob.requires_grad):
+        return _TemperatureLoss.apply(log_t, log_prob, entropy_target)
+    return -torch.mean(temperature_holder() * (log_prob + entropy_target))

@@ -20,6 +20,7 @@ import torch
 from torch import nn
 from torch.nn import functional as F
 
+from pfrl_amd.agents import _sac_losses
 from pfrl_amd.agents._replay_actor_critic import ReplayActorCritic
 from pfrl_amd.utils.batch_states import batch_states
 from pfrl_amd.utils.clip_l2_grad_norm import clip_l2_grad_norm_
@@ -113,6 +114,13 @@ class SoftActorCritic(ReplayActorCritic):
         with torch.no_grad():
             return self.temperature_holder().detach()
 
+    def _loss_temperature(self):
+        """What the loss functions take: the fixed float, or the log-temperature parameter
+        (they use exp of it, detached, as ``_temperature_value`` does)."""
+        if self.entropy_target is None:
+            return self.initial_temperature
+        return self.temperature_holder.log_temperature
+
     # -- hooks -------------------------------------------------------------------------
     def _policy(self):
         return self.policy
@@ -151,22 +159,20 @@ class SoftActorCritic(ReplayActorCritic):
             next_actions, next_log_prob = sample_with_log_prob(next_action_distrib, False)
             next_q1 = self.target_q_func1((batch_next_state, next_actions))
             next_q2 = self.target_q_func2((batch_next_state, next_actions))
-            next_q = torch.min(next_q1, next_q2)
-            entropy_term = self._temperature_value() * next_log_prob[..., None]
-            assert next_q.shape == entropy_term.shape
-            target_q = batch["reward"] + batch["discount"] * (
-                1.0 - batch["is_state_terminal"]) * torch.flatten(next_q - entropy_term)
+            target_q = _sac_losses.soft_target_q(
+                batch["reward"], batch["discount"], batch["is_state_terminal"], next_q1, next_q2,
+                next_log_prob, self._loss_temperature())
         predict_q1 = torch.flatten(self.q_func1((batch["state"], batch["action"])))
         predict_q2 = torch.flatten(self.q_func2((batch["state"], batch["action"])))
-        loss1 = 0.5 * F.mse_loss(target_q, predict_q1)
-        loss2 = 0.5 * F.mse_loss(target_q, predict_q2)
+        loss1 = _sac_losses.half_mse(target_q, predict_q1)
+        loss2 = _sac_losses.half_mse(target_q, predict_q2)
         self._stat(q1=predict_q1, q2=predict_q2, loss1=loss1, loss2=loss2)
         self._step(loss1, self.q_func1, self.q_func1_optimizer)
         self._step(loss2, self.q_func2, self.q_func2_optimizer)
 
     def update_temperature(self, log_prob):
         assert not log_prob.requires_grad
-        loss = -torch.mean(self.temperature_holder() * (log_prob + self.entropy_target))
+        loss = _sac_losses.temperature_loss(self.temperature_holder, log_prob, self.entropy_target)
         self._step(loss, self.temperature_holder, self.temperature_optimizer)
 
     def update_policy_and_temperature(self, batch):
@@ -175,10 +181,7 @@ class SoftActorCritic(ReplayActorCritic):
         actions, log_prob = sample_with_log_prob(action_distrib, True)
         q1 = self.q_func1((batch_state, actions))
         q2 = self.q_func2((batch_state, actions))
-        q = torch.min(q1, q2)
-        entropy_term = self._temperature_value() * log_prob[..., None]
-        assert q.shape == entropy_term.shape
-        loss = torch.mean(entropy_term - q)
+        loss = _sac_losses.policy_loss(log_prob, q1, q2, self._loss_temperature())
         self._step(loss, self.policy, self.policy_optimizer)
         if self.entropy_target is not None:
             self.update_temperature(log_prob.detach())

@@ -178,15 +178,116 @@ __global__ __launch_bounds__(kThreads) void k_adam(AdamArgs a, double lr, double
         v[i] = vi;
         p[i] = __fadd_rn(pv[u], __fdiv_rn(__fmul_rn(step_size, mi), denom));
     }
-    // every workgroup has read its step counter before it takes a ticket
-    __threadfence();
+    // Every workgroup has read (and used) its step counter before it takes a ticket; nothing
+    // it wrote has to be visible to the others, so no fence here: a release fence is a whole
+    // L2 write-back on this part, ~15 us per launch when every workgroup issues one.
     __syncthreads();
-    if (threadIdx.x == 0) s_last = atomicAdd(ticket, 1u) == gridDim.x - 1;
+    if (threadIdx.x == 0)
+        s_last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ==
+                 gridDim.x - 1;
     __syncthreads();
     if (s_last) {
         if (threadIdx.x < a.n) *a.step[threadIdx.x] = *a.step[threadIdx.x] + 1.0f;
         if (threadIdx.x == 0) *ticket = 0u;
     }
+}
+
+// ---------------------------------------------------------------------------------
+// SAC losses (pfrl/agents/soft_actor_critic.py:214-308), each a single workgroup: B is the
+// minibatch (256), the cost is the launch, not the arithmetic
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ float block_sum(float v, float *sh) {
+    v = wave_sum(v);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+__device__ __forceinline__ float torch_min(float a, float b) {   // NaN-propagating, as torch.min
+    return (a < b || a != a) ? a : b;
+}
+
+__device__ __forceinline__ float temperature_of(const float *log_t, float t_val) {
+    return log_t != nullptr ? expf(*log_t) : t_val;   // TemperatureHolder: exp(log_temperature)
+}
+
+// target_q = reward + discount * (1 - terminal) * (min(next_q1, next_q2) - T * next_log_prob)
+__global__ __launch_bounds__(kThreads) void k_sac_target_q(
+    const float *__restrict__ reward, const float *__restrict__ discount, const float *__restrict__ terminal,
+    const float *__restrict__ nq1, const float *__restrict__ nq2, const float *__restrict__ nlogp,
+    const float *__restrict__ log_t, float t_val, float *__restrict__ out, int B) {
+    const int i = blockIdx.x * kThreads + threadIdx.x;
+    if (i >= B) return;
+    const float T = temperature_of(log_t, t_val);
+    const float soft = torch_min(nq1[i], nq2[i]) - T * nlogp[i];
+    out[i] = reward[i] + (discount[i] * (1.0f - terminal[i])) * soft;
+}
+
+// loss = 0.5 * mean((target - pred)^2)
+__global__ __launch_bounds__(kThreads) void k_half_mse_fwd(const float *__restrict__ target,
+                                                           const float *__restrict__ pred,
+                                                           float *__restrict__ loss, int B) {
+    __shared__ float sh[4];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < B; i += kThreads) {
+        const float d = target[i] - pred[i];
+        s += d * d;
+    }
+    s = block_sum(s, sh);
+    if (threadIdx.x == 0) loss[0] = 0.5f * (s / (float)B);
+}
+
+__global__ __launch_bounds__(kThreads) void k_half_mse_bwd(const float *__restrict__ g_loss,
+                                                           const float *__restrict__ target,
+                                                           const float *__restrict__ pred,
+                                                           float *__restrict__ g_pred, int B) {
+    const int i = blockIdx.x * kThreads + threadIdx.x;
+    if (i >= B) return;
+    const float g = 0.5f * g_loss[0];
+    g_pred[i] = -((2.0f * (target[i] - pred[i])) * (g / (float)B));
+}
+
+// loss = mean(T * log_prob - min(q1, q2))
+__global__ __launch_bounds__(kThreads) void k_sac_policy_loss_fwd(
+    const float *__restrict__ logp, const float *__restrict__ q1, const float *__restrict__ q2,
+    const float *__restrict__ log_t, float t_val, float *__restrict__ loss, int B) {
+    __shared__ float sh[4];
+    const float T = temperature_of(log_t, t_val);
+    float s = 0.f;
+    for (int i = threadIdx.x; i < B; i += kThreads) s += T * logp[i] - torch_min(q1[i], q2[i]);
+    s = block_sum(s, sh);
+    if (threadIdx.x == 0) loss[0] = s / (float)B;
+}
+
+// d loss / d log_prob = T / B;  d loss / d q = -1 / B to the smaller one (halves on a tie,
+// as torch.min's backward splits it)
+__global__ __launch_bounds__(kThreads) void k_sac_policy_loss_bwd(
+    const float *__restrict__ g_loss, const float *__restrict__ q1, const float *__restrict__ q2,
+    const float *__restrict__ log_t, float t_val, float *__restrict__ g_logp, float *__restrict__ g_q1,
+    float *__restrict__ g_q2, int B) {
+    const int i = blockIdx.x * kThreads + threadIdx.x;
+    if (i >= B) return;
+    const float T = temperature_of(log_t, t_val);
+    const float g = g_loss[0] / (float)B;
+    const float a = q1[i], b = q2[i];
+    g_logp[i] = g * T;
+    const float w1 = a < b ? 1.f : (a == b ? 0.5f : 0.f);
+    const float w2 = b < a ? 1.f : (a == b ? 0.5f : 0.f);
+    g_q1[i] = -(g * w1);
+    g_q2[i] = -(g * w2);
+}
+
+// loss = -mean(T * (log_prob + entropy_target)), T = exp(log_t)   (soft_actor_critic.py:264-271)
+__global__ __launch_bounds__(kThreads) void k_sac_temperature_loss(const float *__restrict__ log_t,
+                                                                   const float *__restrict__ logp,
+                                                                   float entropy_target,
+                                                                   float *__restrict__ loss, int B) {
+    __shared__ float sh[4];
+    const float T = expf(*log_t);
+    float s = 0.f;
+    for (int i = threadIdx.x; i < B; i += kThreads) s += T * (logp[i] + entropy_target);
+    s = block_sum(s, sh);
+    if (threadIdx.x == 0) loss[0] = -(s / (float)B);
 }
 
 template <typename Args>
@@ -265,5 +366,60 @@ extern "C" int pfrl_adam_step(int32_t n_tensors, float *const *params, const flo
         hipLaunchKernelGGL(k_adam, dim3(chunks), dim3(kThreads), 0, (hipStream_t)stream, a, lr, beta1,
                            beta2, (float)eps, (float)weight_decay, (unsigned int *)ticket);
     }
+    PFRL_LAUNCH_CHECK();
+}
+
+extern "C" int pfrl_sac_target_q(const float *reward, const float *discount, const float *terminal,
+                                 const float *next_q1, const float *next_q2, const float *next_log_prob,
+                                 const float *log_temperature, float temperature, float *target_q,
+                                 int32_t B, void *stream) {
+    PFRL_CHECK_ARG(B >= 0, "pfrl_sac_target_q: bad batch");
+    if (B == 0) return 0;
+    hipLaunchKernelGGL(k_sac_target_q, dim3((B + kThreads - 1) / kThreads), dim3(kThreads), 0,
+                       (hipStream_t)stream, reward, discount, terminal, next_q1, next_q2, next_log_prob,
+                       log_temperature, temperature, target_q, B);
+    PFRL_LAUNCH_CHECK();
+}
+
+extern "C" int pfrl_half_mse_fwd(const float *target, const float *pred, float *loss, int32_t B,
+                                 void *stream) {
+    PFRL_CHECK_ARG(B >= 1, "pfrl_half_mse_fwd: empty batch");
+    hipLaunchKernelGGL(k_half_mse_fwd, dim3(1), dim3(kThreads), 0, (hipStream_t)stream, target, pred,
+                       loss, B);
+    PFRL_LAUNCH_CHECK();
+}
+
+extern "C" int pfrl_half_mse_bwd(const float *g_loss, const float *target, const float *pred,
+                                 float *g_pred, int32_t B, void *stream) {
+    PFRL_CHECK_ARG(B >= 1, "pfrl_half_mse_bwd: empty batch");
+    hipLaunchKernelGGL(k_half_mse_bwd, dim3((B + kThreads - 1) / kThreads), dim3(kThreads), 0,
+                       (hipStream_t)stream, g_loss, target, pred, g_pred, B);
+    PFRL_LAUNCH_CHECK();
+}
+
+extern "C" int pfrl_sac_policy_loss_fwd(const float *log_prob, const float *q1, const float *q2,
+                                        const float *log_temperature, float temperature, float *loss,
+                                        int32_t B, void *stream) {
+    PFRL_CHECK_ARG(B >= 1, "pfrl_sac_policy_loss_fwd: empty batch");
+    hipLaunchKernelGGL(k_sac_policy_loss_fwd, dim3(1), dim3(kThreads), 0, (hipStream_t)stream, log_prob,
+                       q1, q2, log_temperature, temperature, loss, B);
+    PFRL_LAUNCH_CHECK();
+}
+
+extern "C" int pfrl_sac_policy_loss_bwd(const float *g_loss, const float *q1, const float *q2,
+                                        const float *log_temperature, float temperature, float *g_log_prob,
+                                        float *g_q1, float *g_q2, int32_t B, void *stream) {
+    PFRL_CHECK_ARG(B >= 1, "pfrl_sac_policy_loss_bwd: empty batch");
+    hipLaunchKernelGGL(k_sac_policy_loss_bwd, dim3((B + kThreads - 1) / kThreads), dim3(kThreads), 0,
+                       (hipStream_t)stream, g_loss, q1, q2, log_temperature, temperature, g_log_prob, g_q1,
+                       g_q2, B);
+    PFRL_LAUNCH_CHECK();
+}
+
+extern "C" int pfrl_sac_temperature_loss(const float *log_temperature, const float *log_prob,
+                                         float entropy_target, float *loss, int32_t B, void *stream) {
+    PFRL_CHECK_ARG(B >= 1 && log_temperature != nullptr, "pfrl_sac_temperature_loss: bad arguments");
+    hipLaunchKernelGGL(k_sac_temperature_loss, dim3(1), dim3(kThreads), 0, (hipStream_t)stream,
+                       log_temperature, log_prob, entropy_target, loss, B);
     PFRL_LAUNCH_CHECK();
 }

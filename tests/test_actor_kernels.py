@@ -206,3 +206,65 @@ def test_narrow_head_backward_matches_torch(M, K, N):
     assert torch.allclose(y, y_ref, rtol=1e-5, atol=1e-5)
     for a, r in zip(got, want):
         assert (a - r).abs().max().item() < 2e-5 * max(r.abs().max().item(), 1.0)
+
+
+def test_sac_losses_on_cpu_are_the_reference_formulas():
+    from pfrl_amd.agents import _sac_losses as L
+
+    torch.manual_seed(0)
+    B = 9
+    r, d, t = torch.randn(B), torch.rand(B), (torch.rand(B) < 0.3).float()
+    q1, q2, lp = torch.randn(B, 1), torch.randn(B, 1), torch.randn(B)
+    want = r + d * (1.0 - t) * torch.flatten(torch.min(q1, q2) - 0.2 * lp[..., None])
+    assert torch.allclose(L.soft_target_q(r, d, t, q1, q2, lp, 0.2), want)
+    log_t = torch.tensor(-0.7)
+    want = r + d * (1.0 - t) * torch.flatten(torch.min(q1, q2) - torch.exp(log_t) * lp[..., None])
+    assert torch.allclose(L.soft_target_q(r, d, t, q1, q2, lp, log_t), want)
+    p = torch.randn(B, requires_grad=True)
+    assert torch.allclose(L.half_mse(r, p), 0.5 * torch.nn.functional.mse_loss(r, p))
+    assert torch.allclose(L.policy_loss(lp, q1, q2, 0.2), torch.mean(0.2 * lp[..., None] - torch.min(q1, q2)))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B", [256, 1, 100, 1000])
+def test_sac_loss_kernels_match_the_torch_formulas(B):
+    from pfrl_amd.agents import _sac_losses as L
+
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(B)
+    rnd = lambda *s: torch.randn(*s, generator=g).to(dev)
+    r, d = rnd(B), torch.rand(B, generator=g).to(dev)
+    t = (torch.rand(B, generator=g) < 0.3).float().to(dev)
+    q1, q2, lp = rnd(B, 1), rnd(B, 1), rnd(B)
+    q2[::7] = q1[::7]                                   # ties in the minimum
+    log_t = torch.nn.Parameter(torch.tensor(-0.7, device=dev))
+    for temp, tval in ((0.2, 0.2), (log_t, torch.exp(log_t.detach()))):
+        want = r + d * (1.0 - t) * torch.flatten(torch.min(q1, q2) - tval * lp[..., None])
+        got = L.soft_target_q(r, d, t, q1, q2, lp, temp)
+        assert torch.allclose(got, want, rtol=1e-6, atol=1e-6)
+        # policy loss and its three gradients
+        a, b, c = (x.clone().requires_grad_(True) for x in (lp, q1, q2))
+        loss = L.policy_loss(a, b, c, temp)
+        ga = torch.autograd.grad(loss, [a, b, c])
+        a2, b2, c2 = (x.clone().requires_grad_(True) for x in (lp, q1, q2))
+        ref = torch.mean(tval * a2[..., None] - torch.min(b2, c2))
+        gr = torch.autograd.grad(ref, [a2, b2, c2])
+        assert torch.allclose(loss, ref, rtol=1e-5, atol=1e-6)
+        for x, y in zip(ga, gr):
+            assert torch.allclose(x, y, rtol=1e-5, atol=1e-8)
+    p = rnd(B).requires_grad_(True)
+    loss = L.half_mse(r, p)
+    (gp,) = torch.autograd.grad(loss, [p])
+    p2 = p.detach().clone().requires_grad_(True)
+    ref = 0.5 * torch.nn.functional.mse_loss(r, p2)
+    (gr,) = torch.autograd.grad(ref, [p2])
+    assert torch.allclose(loss, ref, rtol=1e-5) and torch.allclose(gp, gr, rtol=1e-5, atol=1e-8)
+    # temperature loss: value and d/dlog T
+    from pfrl_amd.agents.soft_actor_critic import TemperatureHolder
+
+    holder = TemperatureHolder(-0.7).to(dev)
+    loss = L.temperature_loss(holder, lp, -17.0)
+    (gt,) = torch.autograd.grad(loss, [holder.log_temperature])
+    ref = -torch.mean(holder() * (lp + (-17.0)))
+    (gr,) = torch.autograd.grad(ref, [holder.log_temperature])
+    assert torch.allclose(loss, ref, rtol=1e-5) and torch.allclose(gt, gr, rtol=1e-5)
