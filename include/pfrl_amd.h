@@ -382,7 +382,7 @@ int pfrl_noisy_weights_bwd(const float *g_w, const float *g_b, const float *r, f
  *   to 12 tensors in one launch (host arrays of device pointers, passed by value).
  * pfrl_linear_small_fwd / _bwd: a narrow head, y = x w^T + b with out_features <= 16
  *   (Linear(512, n_actions), pfrl/q_functions/state_q_functions.py) and its backward
- *   (dx may be NULL).
+ *   (dx may be NULL; dw and db may both be NULL for frozen weights).
  * pfrl_linear_fwd: y = act(x w^T + b), x [M][K], w [N][K], any K and N, no alignment
  *   requirement -- the `nn.Linear` layers of the MLP agents (obs 376 -> 256,
  *   obs + action 393 -> 256: examples/mujoco/reproduction/soft_actor_critic/
@@ -413,6 +413,11 @@ int pfrl_splitk_reduce(int32_t n_tasks, const float *const *host_part, float *co
                        const int32_t *host_relu, void *stream);
 int pfrl_linear_fwd(const float *x, const float *w, const float *bias, float *y, int32_t M, int32_t K,
                     int32_t N, int32_t relu, int32_t splits, void *stream);
+/* Weight and bias gradient of such a layer, any in_features (out_features % 16 == 0):
+ * partials for pfrl_splitk_reduce laid out as pfrl_conv2d_nhwc_bwd_weight's. */
+int pfrl_linear_bwd_weight(const float *dy, const float *dy_mask, const float *x, float *dw_part,
+                           float *db_part, int64_t dw_stride, int64_t db_stride, int32_t M, int32_t K,
+                           int32_t N, int32_t splits, void *stream);
 int pfrl_linear_small_fwd(const float *x, const float *w, const float *bias, float *y, int32_t M,
                           int32_t K, int32_t N, void *stream);
 int pfrl_linear_small_bwd(const float *dy, const float *x, const float *w, float *dx, float *dw,

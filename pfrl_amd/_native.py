@@ -131,6 +131,7 @@ EXPORTS = {
     "pfrl_conv2d_nhwc_bwd": (ctypes.c_int, "ppppppppqqiiiiiiiiiiip"),
     "pfrl_splitk_reduce": (ctypes.c_int, "ippppppppp"),
     "pfrl_linear_fwd": (ctypes.c_int, "ppppiiiiip"),
+    "pfrl_linear_bwd_weight": (ctypes.c_int, "pppppqqiiiip"),
     "pfrl_linear_small_fwd": (ctypes.c_int, "ppppiiip"),
     "pfrl_linear_small_bwd": (ctypes.c_int, "ppppppiiip"),
     "pfrl_squashed_gaussian_fwd": (ctypes.c_int, "pqpqpppiip"),

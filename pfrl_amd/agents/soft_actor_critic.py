@@ -12,6 +12,7 @@ update (two Q steps, policy step, temperature step, soft target sync) replays as
 one HIP graph.  Acting / observing plumbing is shared with TD3 and DDPG
 (:mod:`pfrl_amd.agents._replay_actor_critic`).
 """
+import contextlib
 import copy
 from logging import getLogger
 
@@ -28,6 +29,19 @@ from pfrl_amd.utils.contexts import evaluating
 from pfrl_amd.utils.copy_param import soft_copy_params
 from pfrl_amd.utils.mode_of_distribution import mode_of_distribution
 from pfrl_amd.utils.squashed_gaussian import sample_with_log_prob
+
+
+@contextlib.contextmanager
+def _frozen(*modules):
+    """requires_grad off for the parameters of ``modules`` while a graph is recorded."""
+    params = [p for m in modules for p in m.parameters() if p.requires_grad]
+    for p in params:
+        p.requires_grad_(False)
+    try:
+        yield
+    finally:
+        for p in params:
+            p.requires_grad_(True)
 
 
 class TemperatureHolder(nn.Module):
@@ -144,7 +158,14 @@ class SoftActorCritic(ReplayActorCritic):
     # -- learning ----------------------------------------------------------------------------
     def _step(self, loss, module, optimizer):
         optimizer.zero_grad()
-        loss.backward()
+        if loss.dim() == 0 and loss.dtype == torch.float32:
+            # dL/dL = 1 from a tensor kept around (backward() would fill a new one per loss)
+            one = self.__dict__.get("_one")
+            if one is None or one.device != loss.device:
+                one = self._one = torch.ones((), dtype=torch.float32, device=loss.device)
+            loss.backward(one)
+        else:
+            loss.backward()
         if module in self._reducers:
             self._reducers[module].all_reduce()
         if self.max_grad_norm is not None:
@@ -179,8 +200,13 @@ class SoftActorCritic(ReplayActorCritic):
         batch_state = batch["state"]
         action_distrib = self.policy(batch_state)
         actions, log_prob = sample_with_log_prob(action_distrib, True)
-        q1 = self.q_func1((batch_state, actions))
-        q2 = self.q_func2((batch_state, actions))
+        # The policy loss needs dQ/da only.  With the Q parameters' requires_grad off while
+        # this graph is recorded, backward skips their weight gradients, which the reference
+        # computes, accumulates into q_func*.grad and never reads (the next update_q_func
+        # starts with zero_grad): the parameters and every loss are unchanged.
+        with _frozen(self.q_func1, self.q_func2):
+            q1 = self.q_func1((batch_state, actions))
+            q2 = self.q_func2((batch_state, actions))
         loss = _sac_losses.policy_loss(log_prob, q1, q2, self._loss_temperature())
         self._step(loss, self.policy, self.policy_optimizer)
         if self.entropy_target is not None:

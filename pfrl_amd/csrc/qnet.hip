@@ -483,7 +483,9 @@ struct WgradArgs {
     int M, K, cps;
 };
 
-template <int BI, int BJ, int WM, int WN, int WK, int G>
+// TAIL: linear layers (1x1) whose in_features are not a multiple of 32 / whose rows are not
+// 16-byte aligned: the x loads are scalar, clamped to the row, the overhang zeroed.
+template <int BI, int BJ, int WM, int WN, int WK, int G, bool TAIL = false>
 __device__ __forceinline__ void wgrad_body(const WgradArgs &p, const int bx, const int by,
                                            const int bz, float *smem) {
     static_assert(WM * WN * WK == 4, "four waves");
@@ -533,6 +535,13 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs &p, const int bx, con
             const int m = mbase + bkk[pp];
             const bool ok = bkk[pp] < 32 && m < p.M;
             const int mm = ok ? m : 0;
+            if (TAIL) {
+                const float *row = p.x + (size_t)mm * p.K;
+                const int j = j0 + 4 * bq[pp], kl = p.K - 1;
+                sl.b[pp] = make_float4(row[min(j, kl)], row[min(j + 1, kl)], row[min(j + 2, kl)],
+                                       row[min(j + 3, kl)]);
+                continue;
+            }
             const int n = mm / ohow, rem = mm - n * ohow;
             const int oh = rem / g.OW, ow = rem - oh * g.OW;
             sl.b[pp] = ldg4(p.x + ((size_t)(n * g.H + oh * g.ST) * g.W + ow * g.ST) * g.C + bcol[pp]);
@@ -551,8 +560,13 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs &p, const int bx, con
 #pragma unroll
         for (int pp = 0; pp < NPB; ++pp) {
             const bool ok = bkk[pp] < 32 && mbase + bkk[pp] < p.M;
-            if (bkk[pp] < 32)
-                *reinterpret_cast<float4 *>(&Bs[buf][bkk[pp] * LDB + 4 * bq[pp]]) = zero_unless(sl.b[pp], ok);
+            float4 v = zero_unless(sl.b[pp], ok);
+            if (TAIL) {
+                const int left = p.K - (j0 + 4 * bq[pp]);
+                v.x = left > 0 ? v.x : 0.f; v.y = left > 1 ? v.y : 0.f;
+                v.z = left > 2 ? v.z : 0.f; v.w = left > 3 ? v.w : 0.f;
+            }
+            if (bkk[pp] < 32) *reinterpret_cast<float4 *>(&Bs[buf][bkk[pp] * LDB + 4 * bq[pp]]) = v;
         }
     };
 
@@ -597,10 +611,10 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs &p, const int bx, con
         }
 }
 
-template <int BI, int BJ, int WM, int WN, int WK, int G>
+template <int BI, int BJ, int WM, int WN, int WK, int G, bool TAIL = false>
 __global__ __launch_bounds__(256) void k_conv_wgrad(WgradArgs p) {
     __shared__ __attribute__((aligned(16))) float smem[wgrad_smem(BI, BJ, WM, WN, WK, G)];
-    wgrad_body<BI, BJ, WM, WN, WK, G>(p, blockIdx.x, blockIdx.y, blockIdx.z, smem);
+    wgrad_body<BI, BJ, WM, WN, WK, G, TAIL>(p, blockIdx.x, blockIdx.y, blockIdx.z, smem);
 }
 
 // Input gradient and weight gradient of one layer in ONE launch: both consume the same dy
@@ -998,6 +1012,37 @@ extern "C" int pfrl_conv2d_nhwc_bwd_weight(const float *dy, const float *dy_mask
     PFRL_LAUNCH_CHECK();
 }
 
+// dw[n][k] = sum_m (dy (.) mask)[m][n] x[m][k], db[n]: the weight gradient of a linear layer
+// with any in_features (the TAIL loaders when K is not a multiple of 32).  Partials as
+// pfrl_conv2d_nhwc_bwd_weight writes them.
+extern "C" int pfrl_linear_bwd_weight(const float *dy, const float *dy_mask, const float *x,
+                                      float *dw_part, float *db_part, int64_t dw_stride,
+                                      int64_t db_stride, int32_t M, int32_t K, int32_t N, int32_t splits,
+                                      void *stream) {
+    if (K % KC == 0)
+        return pfrl_conv2d_nhwc_bwd_weight(dy, dy_mask, x, dw_part, db_part, dw_stride, db_stride, M, 1,
+                                           1, K, N, 1, 1, 1, splits, stream);
+    PFRL_CHECK_ARG(M >= 1 && K >= 1 && N >= 16 && N % 16 == 0 && splits >= 1,
+                   "pfrl_linear_bwd_weight: out_features must be a multiple of 16");
+    WgradArgs a;
+    a.dy = dy; a.dymask = dy_mask; a.x = x; a.dw = dw_part; a.db = db_part;
+    a.dw_stride = dw_stride; a.db_stride = db_stride;
+    a.g = ConvGeom{M, 1, 1, K, N, 1, 1, 1, 1, 1};
+    a.M = M;
+    a.K = K;
+    const int nch = (M + KC - 1) / KC;
+    a.cps = (nch + splits - 1) / splits;
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned gy = (unsigned)((K + 31) / 32);
+    if (N % 32 == 0)
+        hipLaunchKernelGGL((k_conv_wgrad<32, 32, 2, 2, 1, 4, true>), dim3(N / 32, gy, splits), dim3(256),
+                           0, st, a);
+    else
+        hipLaunchKernelGGL((k_conv_wgrad<16, 32, 1, 2, 2, 4, true>), dim3(N / 16, gy, splits), dim3(256),
+                           0, st, a);
+    PFRL_LAUNCH_CHECK();
+}
+
 // Both gradients of one layer in one launch (k_conv_bwd).  The dgrad arguments describe the
 // layer as pfrl_conv2d_nhwc_bwd_data does, the wgrad arguments as pfrl_conv2d_nhwc_bwd_weight;
 // dy / dy_mask are shared.  Minibatch-sized problems only (the small tile programs); larger
@@ -1098,7 +1143,8 @@ extern "C" int pfrl_linear_small_bwd(const float *dy, const float *x, const floa
                                      void *stream) {
     PFRL_CHECK_ARG(N >= 1 && N <= SMALL_N && M >= 1 && K >= 1 && (size_t)M * N * 4 <= 40 * 1024,
                    "pfrl_linear_small_bwd: N <= 16, M * N <= 10240");
-    const int n_dw = (K + 31) / 32;
+    PFRL_CHECK_ARG(dw != nullptr || dx != nullptr, "pfrl_linear_small_bwd: nothing to compute");
+    const int n_dw = dw != nullptr ? (K + 31) / 32 : 0;   // dw == NULL: input gradient only
     const dim3 grid(n_dw + (dx != nullptr ? ((K + 255) / 256) * ((M + 7) / 8) : 0));
 #define CALL_BWD(NN)                                                                              \
     hipLaunchKernelGGL(k_linear_small_bwd<NN>, grid, dim3(256), (size_t)M * N * sizeof(float),   \

@@ -82,13 +82,49 @@ class _Linear(torch.autograd.Function):
         need_dx = ctx.needs_input_grad[0]
         dev = x.device
         if not _bwd_kernels_cover(M, K, Fo):
-            # ragged layers (first layer of an MLP, 2 * action_size heads): library matmuls,
-            # whose outputs are not the 256 x 256 shapes that the heuristics mishandle
-            g = torch.where(y > 0, dy, torch.zeros((), dtype=dy.dtype, device=dev)) if ctx.relu else dy
-            dx = g @ w if need_dx else None
-            return dx, g.t() @ x, g.sum(0), None
+            # ragged layers (first layer of an MLP, 2 * action_size heads)
+            need_w = ctx.needs_input_grad[1]
+            dx = dw = db = None
+            g = None
+            if need_dx or not (need_w and Fo % 16 == 0):
+                # library products: their outputs are not the 256 x 256 shapes that the
+                # library's heuristics mishandle
+                g = torch.ops.aten.threshold_backward(dy, y, 0.0) if ctx.relu else dy
+            if need_dx:
+                dx = g @ w
+            if need_w and Fo % 16 == 0:
+                # any in_features: the TAIL weight-gradient kernel, ReLU mask and db folded in
+                dyc = dy.contiguous()
+                dw = torch.empty_like(w)
+                db = torch.empty(Fo, dtype=torch.float32, device=dev)
+                splits = _t._wgrad_splits(M, Fo, _ceil_div(K, 32) * 32)
+                nW = w.numel()
+                stride = nW + Fo
+                if splits == 1:
+                    pw, pb, st = dw, db, 0
+                else:
+                    part = torch.empty(splits * stride, dtype=torch.float32, device=dev)
+                    pw, pb, st = part, part[nW:], stride
+                check(_native.lib().pfrl_linear_bwd_weight(_p(dyc), _p(y), _p(x), _p(pw), _p(pb), st, st,
+                                                           M, K, Fo, splits, _stream()),
+                      "linear_bwd_weight")
+                if splits > 1:
+                    _t._reduce([(part, dw, None, stride, nW, splits, 4, 0),
+                                (pb, db, None, stride, Fo, splits, 4, 0)])
+            elif need_w:
+                dw = g.t() @ x
+                db = g.sum(0) if ctx.needs_input_grad[2] else None
+            return dx, dw, db, None
         dy = dy.contiguous()
         lib = _native.lib()
+        if not ctx.needs_input_grad[1]:
+            # frozen weights (e.g. the Q-networks under the SAC policy loss): input gradient only
+            dx = None
+            if need_dx:
+                dx = torch.empty_like(x)
+                check(lib.pfrl_conv2d_nhwc_bwd_data(_p(dy), _p(y), _p(w), None, _p(dx), M, 1, 1, K, Fo,
+                                                    1, 1, 1, 0, 0, _stream()), "linear_bwd_data")
+            return dx, None, None, None
         dw = torch.empty_like(w)
         db = torch.empty(Fo, dtype=torch.float32, device=dev)
         splits = _t._wgrad_splits(M, Fo, K)

@@ -328,6 +328,13 @@ class _SmallLinear(torch.autograd.Function):
         Nout = w.shape[0]
         dy = dy.contiguous()
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        if not ctx.needs_input_grad[1]:
+            # frozen weights: the input gradient only
+            if dx is None:
+                return None, None, None
+            check(_native.lib().pfrl_linear_small_bwd(_p(dy), _p(x), _p(w), _p(dx), None, None, M, K,
+                                                      Nout, _stream()), "linear_small_bwd")
+            return dx, None, None
         dw = torch.empty_like(w)
         db = torch.empty(Nout, dtype=torch.float32, device=x.device) if ctx.has_bias else None
         check(_native.lib().pfrl_linear_small_bwd(_p(dy), _p(x), _p(w), _p(dx), _p(dw), _p(db), M, K,

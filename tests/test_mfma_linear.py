@@ -111,3 +111,28 @@ def test_accelerated_sac_networks_match_the_stock_route_and_survive_a_graph():
     graph.replay()
     torch.cuda.synchronize()
     assert torch.equal(captured, out.detach())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("K,N", [(256, 256), (393, 256), (256, 1), (256, 34)])
+def test_frozen_weights_give_the_input_gradient_only(K, N):
+    """requires_grad off on the layer (the Q-networks under the SAC policy loss): the input
+    gradient is unchanged and no weight gradient is produced."""
+    from pfrl_amd.nn import accelerate_mlp
+
+    dev = torch.device("cuda:0")
+    torch.manual_seed(K + N)
+    seq = nn.Sequential(nn.Linear(K, N), nn.ReLU()).to(dev) if N > 16 else nn.Sequential(nn.Linear(K, N)).to(dev)
+    ref = copy.deepcopy(seq)
+    accelerate_mlp(seq)
+    x = torch.randn(256, K, device=dev, requires_grad=True)
+    dy = torch.randn(256, N, device=dev)
+    for m in (seq, ref):
+        m.requires_grad_(False)
+    (gx,) = torch.autograd.grad(seq(x), [x], dy)
+    (gr,) = torch.autograd.grad(ref(x), [x], dy)
+    assert (gx - gr).abs().max().item() < 2e-5 * max(gr.abs().max().item(), 1.0)
+    seq.requires_grad_(True)
+    y = seq(x)
+    y.backward(dy)
+    assert all(p.grad is not None for p in seq.parameters())
