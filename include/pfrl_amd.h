@@ -424,6 +424,35 @@ int pfrl_linear_small_bwd(const float *dy, const float *x, const float *w, float
                           float *db, int32_t M, int32_t K, int32_t N, void *stream);
 
 /* ------------------------------------------------------------------------
+ * Twin launches (csrc/qnet.hip): the same layer of the two Q-networks of SAC / TD3
+ * (pfrl/agents/soft_actor_critic.py:97-110, always evaluated on the same inputs one after
+ * the other) as ONE grid.  Every `const float *const *` argument is a HOST array of two
+ * device pointers.  Same arithmetic as the single-network entry points.
+ * pfrl_linear_fwd_twin: y_t = act(x_t w_t^T + b_t), any in_features, out_features % 32 == 0.
+ * pfrl_linear_bwd_twin: dx == NULL: weight/bias gradient partials only (any in_features);
+ *   dw_part == NULL: input gradients only; both: all four gradients in one launch
+ *   (in_features % 32 == 0).
+ * pfrl_linear_small_fwd_twin / _bwd_twin: the narrow heads (out_features <= 16).
+ * pfrl_twin_input_grad: dx[m][j] = sum_t sum_n (dy_t (.) mask_t)[m][n] w_t[n][col0 + j],
+ *   j < ncol <= 32: the gradient w.r.t. the action columns of the twins' first layer, the only
+ *   input gradient the policy loss needs (:284-291).
+ * pfrl_half_mse_twin_fwd/_bwd (below): both critic losses of one target. */
+int pfrl_linear_fwd_twin(const float *const *x, const float *const *w, const float *const *bias,
+                         float *const *y, int32_t M, int32_t K, int32_t N, int32_t relu, void *stream);
+int pfrl_linear_bwd_twin(const float *const *dy, const float *const *dy_mask, const float *const *w,
+                         const float *const *x, float *const *dx, float *const *dw_part,
+                         float *const *db_part, int64_t dw_stride, int64_t db_stride, int32_t M,
+                         int32_t K, int32_t N, int32_t splits, void *stream);
+int pfrl_linear_small_fwd_twin(const float *const *x, const float *const *w, const float *const *bias,
+                               float *const *y, int32_t M, int32_t K, int32_t N, void *stream);
+int pfrl_linear_small_bwd_twin(const float *const *dy, const float *const *x, const float *const *w,
+                               float *const *dx, float *const *dw, float *const *db, int32_t M,
+                               int32_t K, int32_t N, void *stream);
+int pfrl_twin_input_grad(const float *const *dy, const float *const *dy_mask, const float *const *w,
+                         int32_t ldw, int32_t col0, int32_t ncol, float *dx, int32_t M, int32_t N,
+                         void *stream);
+
+/* ------------------------------------------------------------------------
  * Actor-critic update helpers (csrc/actor.hip): the elementwise stretches of the
  * SAC / TD3 / DDPG update, pfrl/agents/soft_actor_critic.py:213-330.
  *
@@ -474,6 +503,10 @@ int pfrl_sac_target_q(const float *reward, const float *discount, const float *t
 int pfrl_half_mse_fwd(const float *target, const float *pred, float *loss, int32_t B, void *stream);
 int pfrl_half_mse_bwd(const float *g_loss, const float *target, const float *pred, float *g_pred,
                       int32_t B, void *stream);
+int pfrl_half_mse_twin_fwd(const float *target, const float *const *pred, float *const *loss, int32_t B,
+                           void *stream);
+int pfrl_half_mse_twin_bwd(const float *const *g_loss, const float *target, const float *const *pred,
+                           float *const *g_pred, int32_t B, void *stream);
 int pfrl_sac_policy_loss_fwd(const float *log_prob, const float *q1, const float *q2,
                              const float *log_temperature, float temperature, float *loss, int32_t B,
                              void *stream);

@@ -85,6 +85,39 @@ def half_mse(target, pred):
     return 0.5 * F.mse_loss(target, pred)
 
 
+class _HalfMsePair(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, target, pred1, pred2):
+        loss = torch.empty((2,), dtype=torch.float32, device=target.device)
+        P = (ctypes.c_void_p * 2)(pred1.data_ptr(), pred2.data_ptr())
+        Lp = (ctypes.c_void_p * 2)(loss[0].data_ptr(), loss[1].data_ptr())
+        check(_native.lib().pfrl_half_mse_twin_fwd(_p(target), P, Lp, target.numel(), _stream()),
+              "half_mse_twin_fwd")
+        ctx.save_for_backward(target, pred1, pred2)
+        return loss[0], loss[1]
+
+    @staticmethod
+    def backward(ctx, g1, g2):
+        target, pred1, pred2 = ctx.saved_tensors
+        gp = torch.empty((2, target.numel()), dtype=torch.float32, device=target.device)
+        g1 = g1.contiguous() if g1 is not None else None
+        g2 = g2.contiguous() if g2 is not None else None
+        G = (ctypes.c_void_p * 2)(g1.data_ptr() if g1 is not None else 0,
+                                  g2.data_ptr() if g2 is not None else 0)
+        P = (ctypes.c_void_p * 2)(pred1.data_ptr(), pred2.data_ptr())
+        O = (ctypes.c_void_p * 2)(gp[0].data_ptr(), gp[1].data_ptr())
+        check(_native.lib().pfrl_half_mse_twin_bwd(G, _p(target), P, O, target.numel(), _stream()),
+              "half_mse_twin_bwd")
+        return None, gp[0].view(pred1.shape), gp[1].view(pred2.shape)
+
+
+def half_mse_pair(target, pred1, pred2):
+    """(half_mse(target, pred1), half_mse(target, pred2)), one launch each way on the GPU."""
+    if _vec_ok(target, pred1, pred2) and not target.requires_grad:
+        return _HalfMsePair.apply(target, pred1, pred2)
+    return half_mse(target, pred1), half_mse(target, pred2)
+
+
 class _PolicyLoss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, log_prob, q1, q2, temperature):

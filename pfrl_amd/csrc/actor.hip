@@ -223,28 +223,33 @@ __global__ __launch_bounds__(kThreads) void k_sac_target_q(
     out[i] = reward[i] + (discount[i] * (1.0f - terminal[i])) * soft;
 }
 
-// loss = 0.5 * mean((target - pred)^2)
-__global__ __launch_bounds__(kThreads) void k_half_mse_fwd(const float *__restrict__ target,
-                                                           const float *__restrict__ pred,
-                                                           float *__restrict__ loss, int B) {
+// loss = 0.5 * mean((target - pred)^2); blockIdx.y picks one of up to two predictions of the
+// same target (the twin Q-networks)
+struct HalfMseArgs {
+    const float *pred[2], *g_loss[2];
+    float *loss[2], *g_pred[2];
+};
+
+__global__ __launch_bounds__(kThreads) void k_half_mse_fwd(const float *__restrict__ target, HalfMseArgs a,
+                                                           int B) {
     __shared__ float sh[4];
+    const float *__restrict__ pred = a.pred[blockIdx.y];
     float s = 0.f;
     for (int i = threadIdx.x; i < B; i += kThreads) {
         const float d = target[i] - pred[i];
         s += d * d;
     }
     s = block_sum(s, sh);
-    if (threadIdx.x == 0) loss[0] = 0.5f * (s / (float)B);
+    if (threadIdx.x == 0) a.loss[blockIdx.y][0] = 0.5f * (s / (float)B);
 }
 
-__global__ __launch_bounds__(kThreads) void k_half_mse_bwd(const float *__restrict__ g_loss,
-                                                           const float *__restrict__ target,
-                                                           const float *__restrict__ pred,
-                                                           float *__restrict__ g_pred, int B) {
+__global__ __launch_bounds__(kThreads) void k_half_mse_bwd(const float *__restrict__ target, HalfMseArgs a,
+                                                           int B) {
     const int i = blockIdx.x * kThreads + threadIdx.x;
     if (i >= B) return;
-    const float g = 0.5f * g_loss[0];
-    g_pred[i] = -((2.0f * (target[i] - pred[i])) * (g / (float)B));
+    const float *g_loss = a.g_loss[blockIdx.y];
+    const float g = 0.5f * (g_loss != nullptr ? g_loss[0] : 0.f);
+    a.g_pred[blockIdx.y][i] = -((2.0f * (target[i] - a.pred[blockIdx.y][i])) * (g / (float)B));
 }
 
 // loss = mean(T * log_prob - min(q1, q2))
@@ -384,16 +389,37 @@ extern "C" int pfrl_sac_target_q(const float *reward, const float *discount, con
 extern "C" int pfrl_half_mse_fwd(const float *target, const float *pred, float *loss, int32_t B,
                                  void *stream) {
     PFRL_CHECK_ARG(B >= 1, "pfrl_half_mse_fwd: empty batch");
-    hipLaunchKernelGGL(k_half_mse_fwd, dim3(1), dim3(kThreads), 0, (hipStream_t)stream, target, pred,
-                       loss, B);
+    HalfMseArgs a{{pred, nullptr}, {nullptr, nullptr}, {loss, nullptr}, {nullptr, nullptr}};
+    hipLaunchKernelGGL(k_half_mse_fwd, dim3(1, 1), dim3(kThreads), 0, (hipStream_t)stream, target, a, B);
     PFRL_LAUNCH_CHECK();
 }
 
 extern "C" int pfrl_half_mse_bwd(const float *g_loss, const float *target, const float *pred,
                                  float *g_pred, int32_t B, void *stream) {
     PFRL_CHECK_ARG(B >= 1, "pfrl_half_mse_bwd: empty batch");
-    hipLaunchKernelGGL(k_half_mse_bwd, dim3((B + kThreads - 1) / kThreads), dim3(kThreads), 0,
-                       (hipStream_t)stream, g_loss, target, pred, g_pred, B);
+    HalfMseArgs a{{pred, nullptr}, {g_loss, nullptr}, {nullptr, nullptr}, {g_pred, nullptr}};
+    hipLaunchKernelGGL(k_half_mse_bwd, dim3((B + kThreads - 1) / kThreads, 1), dim3(kThreads), 0,
+                       (hipStream_t)stream, target, a, B);
+    PFRL_LAUNCH_CHECK();
+}
+
+// The two losses of twin predictions of one target, and both gradients, in one launch each
+// (host arrays of two device pointers; a NULL g_loss entry is a zero upstream gradient).
+extern "C" int pfrl_half_mse_twin_fwd(const float *target, const float *const *pred, float *const *loss,
+                                      int32_t B, void *stream) {
+    PFRL_CHECK_ARG(B >= 1, "pfrl_half_mse_twin_fwd: empty batch");
+    HalfMseArgs a{{pred[0], pred[1]}, {nullptr, nullptr}, {loss[0], loss[1]}, {nullptr, nullptr}};
+    hipLaunchKernelGGL(k_half_mse_fwd, dim3(1, 2), dim3(kThreads), 0, (hipStream_t)stream, target, a, B);
+    PFRL_LAUNCH_CHECK();
+}
+
+extern "C" int pfrl_half_mse_twin_bwd(const float *const *g_loss, const float *target,
+                                      const float *const *pred, float *const *g_pred, int32_t B,
+                                      void *stream) {
+    PFRL_CHECK_ARG(B >= 1, "pfrl_half_mse_twin_bwd: empty batch");
+    HalfMseArgs a{{pred[0], pred[1]}, {g_loss[0], g_loss[1]}, {nullptr, nullptr}, {g_pred[0], g_pred[1]}};
+    hipLaunchKernelGGL(k_half_mse_bwd, dim3((B + kThreads - 1) / kThreads, 2), dim3(kThreads), 0,
+                       (hipStream_t)stream, target, a, B);
     PFRL_LAUNCH_CHECK();
 }
 

@@ -183,7 +183,7 @@ struct FwdArgs {
 // not 16-byte aligned (MLP inputs such as 376 observations, 376 + 17 with the action
 // appended): scalar loads, addresses clamped to the row, the overhang zeroed when parked.
 template <int BM, int BN, int WM, int WN, int WK, int G, bool TAIL = false>
-__global__ __launch_bounds__(256) void k_conv_fwd(FwdArgs p) {
+__device__ __forceinline__ void fwd_body(const FwdArgs &p, const int bx, const int by, const int bz) {
     static_assert(WM * WN * WK == 4, "four waves");
     constexpr int AM = BM / (16 * WM), AN = BN / (16 * WN);
     constexpr int P = (AM * AN == 1) ? 2 : 1;
@@ -193,10 +193,10 @@ __global__ __launch_bounds__(256) void k_conv_fwd(FwdArgs p) {
     __shared__ f32x4 red[WK > 1 ? (WK - 1) * WM * WN * AM * AN * 64 : 1];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wk = wave % WK, wn = (wave / WK) % WN, wm = wave / (WK * WN);
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int m0 = bx * BM, n0 = by * BN;
     const ConvGeom g = p.g;
     const int ohow = g.OH * g.OW;
-    const int c0 = blockIdx.z * p.cps;
+    const int c0 = bz * p.cps;
     const int c1 = min(c0 + p.cps, TAIL ? (p.K + KC - 1) / KC : p.K / KC);
 
     struct Slot {
@@ -301,7 +301,7 @@ __global__ __launch_bounds__(256) void k_conv_fwd(FwdArgs p) {
                 if (m >= p.M) continue;
                 float v = acc[am][an][0][reg];
                 if (p.partial) {
-                    p.y[((size_t)blockIdx.z * p.M + m) * g.Cout + n] = v;
+                    p.y[((size_t)bz * p.M + m) * g.Cout + n] = v;
                     continue;
                 }
                 v = v + bias;
@@ -314,6 +314,20 @@ __global__ __launch_bounds__(256) void k_conv_fwd(FwdArgs p) {
                 }
             }
         }
+}
+
+template <int BM, int BN, int WM, int WN, int WK, int G, bool TAIL = false>
+__global__ __launch_bounds__(256) void k_conv_fwd(FwdArgs p) {
+    fwd_body<BM, BN, WM, WN, WK, G, TAIL>(p, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// Twin launch: two independent problems of the same shape (the twin Q-networks of SAC / TD3,
+// pfrl/agents/soft_actor_critic.py:97-110) side by side in one grid, blockIdx.z picks the
+// problem.  Inside a captured graph a launch costs ~4 us whatever it computes, and the twins
+// are always evaluated on the same inputs one after the other.  No split-K here.
+template <int BM, int BN, int WM, int WN, int WK, int G, bool TAIL>
+__global__ __launch_bounds__(256) void k_conv_fwd2(FwdArgs p0, FwdArgs p1) {
+    fwd_body<BM, BN, WM, WN, WK, G, TAIL>(blockIdx.z == 0 ? p0 : p1, blockIdx.x, blockIdx.y, 0);
 }
 
 // ---------------------------------------------------------------------------------
@@ -472,6 +486,12 @@ __global__ __launch_bounds__(256) void k_conv_dgrad(DgradArgs p) {
     dgrad_body<BM, BN, WM, WN, WK, G>(p, blockIdx.x, blockIdx.y, blockIdx.z, smem);
 }
 
+template <int BM, int BN, int WM, int WN, int WK, int G>
+__global__ __launch_bounds__(256) void k_conv_dgrad2(DgradArgs p0, DgradArgs p1) {
+    __shared__ __attribute__((aligned(16))) float smem[dgrad_smem(BM, BN, WM, WN, WK, G)];
+    dgrad_body<BM, BN, WM, WN, WK, G>(blockIdx.z == 0 ? p0 : p1, blockIdx.x, blockIdx.y, 0, smem);
+}
+
 // ---------------------------------------------------------------------------------
 // wgrad: dw[co][k] and db[co], reduction over m split across grid.z
 // ---------------------------------------------------------------------------------
@@ -617,6 +637,14 @@ __global__ __launch_bounds__(256) void k_conv_wgrad(WgradArgs p) {
     wgrad_body<BI, BJ, WM, WN, WK, G, TAIL>(p, blockIdx.x, blockIdx.y, blockIdx.z, smem);
 }
 
+template <int BI, int BJ, int WM, int WN, int WK, int G, bool TAIL>
+__global__ __launch_bounds__(256) void k_conv_wgrad2(WgradArgs p0, WgradArgs p1, int nz) {
+    __shared__ __attribute__((aligned(16))) float smem[wgrad_smem(BI, BJ, WM, WN, WK, G)];
+    const bool second = (int)blockIdx.z >= nz;
+    wgrad_body<BI, BJ, WM, WN, WK, G, TAIL>(second ? p1 : p0, blockIdx.x, blockIdx.y,
+                                            second ? blockIdx.z - nz : blockIdx.z, smem);
+}
+
 // Input gradient and weight gradient of one layer in ONE launch: both consume the same dy
 // and neither depends on the other.  At B = 32 each is a few hundred latency-bound
 // workgroups that leave most of every CU idle; side by side they overlap almost fully and
@@ -638,6 +666,23 @@ __global__ __launch_bounds__(256) void k_conv_bwd(DgradArgs d, WgradArgs w, int 
         const int c = b - nd;
         const int bx = c % wgx, r = c / wgx;
         wgrad_body<WI, 32, WWM, WWN, WWK, 4>(w, bx, r % wgy, r / wgy, smem);
+    }
+}
+
+template <int DM, int DN, int DWM, int DWN, int DWK, int DG_, int WI, int WWM, int WWN, int WWK>
+__global__ __launch_bounds__(256) void k_conv_bwd2(DgradArgs d0, WgradArgs w0, DgradArgs d1, WgradArgs w1,
+                                                   int dgx, int dgy, int wgx, int wgy) {
+    __shared__ __attribute__((aligned(16))) float
+        smem[cmax(dgrad_smem(DM, DN, DWM, DWN, DWK, DG_), wgrad_smem(WI, 32, WWM, WWN, WWK, 4))];
+    const bool second = blockIdx.y != 0;
+    const int b = blockIdx.x;
+    const int nd = dgx * dgy;
+    if (b < nd) {
+        dgrad_body<DM, DN, DWM, DWN, DWK, DG_>(second ? d1 : d0, b % dgx, b / dgx, 0, smem);
+    } else {
+        const int c = b - nd;
+        const int bx = c % wgx, r = c / wgx;
+        wgrad_body<WI, 32, WWM, WWN, WWK, 4>(second ? w1 : w0, bx, r % wgy, r / wgy, smem);
     }
 }
 
@@ -721,12 +766,19 @@ constexpr int SMALL_N = 16;
 
 // y[m][n] = sum_k x[m][k] w[n][k] + b[n]; one workgroup per row, every load of a pass
 // (4 k per thread: 4 of x, 4 N of w) issued before the first use
+// (blockIdx.y picks one of up to two independent heads: the twin launch)
+struct SmallFwdArgs {
+    const float *x[2], *w[2], *bias[2];
+    float *y[2];
+};
+
 template <int N>
-__global__ __launch_bounds__(256) void k_linear_small_fwd(const float *__restrict__ x,
-                                                          const float *__restrict__ w,
-                                                          const float *__restrict__ bias,
-                                                          float *__restrict__ y, int K) {
+__global__ __launch_bounds__(256) void k_linear_small_fwd(SmallFwdArgs a, int K) {
     __shared__ float part[4][N];
+    const float *__restrict__ x = a.x[blockIdx.y];
+    const float *__restrict__ w = a.w[blockIdx.y];
+    const float *__restrict__ bias = a.bias[blockIdx.y];
+    float *__restrict__ y = a.y[blockIdx.y];
     const int m = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float acc[N];
 #pragma unroll
@@ -769,13 +821,20 @@ __global__ __launch_bounds__(256) void k_linear_small_fwd(const float *__restric
 // eight loads at a time, the slices are folded through LDS.  (A column per thread over the
 // whole batch is M / 8 dependent memory round trips: 30 us at M = 256.)  The others own dx
 // for 8 batch rows x 256 k columns each.
+struct SmallBwdArgs {
+    const float *dy[2], *x[2], *w[2];
+    float *dx[2], *dw[2], *db[2];
+};
+
 template <int N>
-__global__ __launch_bounds__(256) void k_linear_small_bwd(const float *__restrict__ dy,
-                                                          const float *__restrict__ x,
-                                                          const float *__restrict__ w,
-                                                          float *__restrict__ dx, float *__restrict__ dw,
-                                                          float *__restrict__ db, int M, int K, int n_dw) {
+__global__ __launch_bounds__(256) void k_linear_small_bwd(SmallBwdArgs a, int M, int K, int n_dw) {
     extern __shared__ float sdy[];   // [M][N]
+    const float *__restrict__ dy = a.dy[blockIdx.y];
+    const float *__restrict__ x = a.x[blockIdx.y];
+    const float *__restrict__ w = a.w[blockIdx.y];
+    float *__restrict__ dx = a.dx[blockIdx.y];
+    float *__restrict__ dw = a.dw[blockIdx.y];
+    float *__restrict__ db = a.db[blockIdx.y];
     __shared__ float red[8][32][N + 1];
     const int tid = threadIdx.x;
     for (int e = tid; e < M * N; e += 256) sdy[e] = dy[e];
@@ -1127,29 +1186,193 @@ extern "C" int pfrl_splitk_reduce(int32_t n_tasks, const float *const *host_part
         default: CALL(16); break;                                          \
     }
 
-extern "C" int pfrl_linear_small_fwd(const float *x, const float *w, const float *bias, float *y,
-                                     int32_t M, int32_t K, int32_t N, void *stream) {
+static int small_fwd_launch(const SmallFwdArgs &a, int twins, int32_t M, int32_t K, int32_t N,
+                            void *stream) {
     PFRL_CHECK_ARG(N >= 1 && N <= SMALL_N && M >= 1 && K >= 1, "pfrl_linear_small_fwd: N <= 16");
-#define CALL_FWD(NN)                                                                              \
-    hipLaunchKernelGGL(k_linear_small_fwd<NN>, dim3(M), dim3(256), 0, (hipStream_t)stream, x, w, \
-                       bias, y, K)
+#define CALL_FWD(NN)                                                                             \
+    hipLaunchKernelGGL(k_linear_small_fwd<NN>, dim3(M, twins), dim3(256), 0, (hipStream_t)stream, a, K)
     SMALL_DISPATCH(N, CALL_FWD)
 #undef CALL_FWD
+    PFRL_LAUNCH_CHECK();
+}
+
+extern "C" int pfrl_linear_small_fwd(const float *x, const float *w, const float *bias, float *y,
+                                     int32_t M, int32_t K, int32_t N, void *stream) {
+    SmallFwdArgs a{{x, nullptr}, {w, nullptr}, {bias, nullptr}, {y, nullptr}};
+    return small_fwd_launch(a, 1, M, K, N, stream);
+}
+
+static int small_bwd_launch(const SmallBwdArgs &a, int twins, bool want_dx, bool want_dw, int32_t M,
+                            int32_t K, int32_t N, void *stream) {
+    PFRL_CHECK_ARG(N >= 1 && N <= SMALL_N && M >= 1 && K >= 1 && (size_t)M * N * 4 <= 40 * 1024,
+                   "pfrl_linear_small_bwd: N <= 16, M * N <= 10240");
+    PFRL_CHECK_ARG(want_dw || want_dx, "pfrl_linear_small_bwd: nothing to compute");
+    const int n_dw = want_dw ? (K + 31) / 32 : 0;   // dw == NULL: input gradient only
+    const dim3 grid(n_dw + (want_dx ? ((K + 255) / 256) * ((M + 7) / 8) : 0), twins);
+#define CALL_BWD(NN)                                                                              \
+    hipLaunchKernelGGL(k_linear_small_bwd<NN>, grid, dim3(256), (size_t)M * N * sizeof(float),   \
+                       (hipStream_t)stream, a, M, K, n_dw)
+    SMALL_DISPATCH(N, CALL_BWD)
+#undef CALL_BWD
     PFRL_LAUNCH_CHECK();
 }
 
 extern "C" int pfrl_linear_small_bwd(const float *dy, const float *x, const float *w, float *dx,
                                      float *dw, float *db, int32_t M, int32_t K, int32_t N,
                                      void *stream) {
-    PFRL_CHECK_ARG(N >= 1 && N <= SMALL_N && M >= 1 && K >= 1 && (size_t)M * N * 4 <= 40 * 1024,
-                   "pfrl_linear_small_bwd: N <= 16, M * N <= 10240");
-    PFRL_CHECK_ARG(dw != nullptr || dx != nullptr, "pfrl_linear_small_bwd: nothing to compute");
-    const int n_dw = dw != nullptr ? (K + 31) / 32 : 0;   // dw == NULL: input gradient only
-    const dim3 grid(n_dw + (dx != nullptr ? ((K + 255) / 256) * ((M + 7) / 8) : 0));
-#define CALL_BWD(NN)                                                                              \
-    hipLaunchKernelGGL(k_linear_small_bwd<NN>, grid, dim3(256), (size_t)M * N * sizeof(float),   \
-                       (hipStream_t)stream, dy, x, w, dx, dw, db, M, K, n_dw)
-    SMALL_DISPATCH(N, CALL_BWD)
-#undef CALL_BWD
+    SmallBwdArgs a{{dy, nullptr}, {x, nullptr}, {w, nullptr}, {dx, nullptr}, {dw, nullptr}, {db, nullptr}};
+    return small_bwd_launch(a, 1, dx != nullptr, dw != nullptr, M, K, N, stream);
+}
+
+// ===================================================================================
+// Twin launches: the same layer of two independent networks in one grid (host arrays of
+// two device pointers each).  Fixed small tile programs: these are minibatch-sized problems.
+// ===================================================================================
+namespace {
+
+// dx[m][j] = sum_t sum_n (dy_t (.) mask_t)[m][n] * w_t[n][col0 + j], j < ncol: the gradient
+// w.r.t. the last `ncol` input columns of the twins' first layer (the action appended to the
+// observation), the only input gradient the SAC / TD3 policy loss needs.  One workgroup per
+// 4 rows, a wave per row; lanes walk n, every lane keeps ncol partial sums.
+constexpr int DXT_MAX = 32;
+
+struct TwinDxArgs {
+    const float *dy[2], *mask[2], *w[2];
+};
+
+__global__ __launch_bounds__(256) void k_twin_input_grad(TwinDxArgs a, int ldw, int col0, int ncol,
+                                                         float *__restrict__ dx, int M, int N) {
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (m >= M) return;
+    float acc[DXT_MAX];
+#pragma unroll
+    for (int j = 0; j < DXT_MAX; ++j) acc[j] = 0.f;
+    for (int t = 0; t < 2; ++t) {
+        const float *__restrict__ dy = a.dy[t] + (size_t)m * N;
+        const float *__restrict__ mk = a.mask[t] != nullptr ? a.mask[t] + (size_t)m * N : nullptr;
+        const float *__restrict__ w = a.w[t];
+        for (int n = lane; n < N; n += 64) {
+            float g = dy[n];
+            if (mk != nullptr) g = mk[n] > 0.f ? g : 0.f;
+            const float *wr = w + (size_t)n * ldw + col0;
+#pragma unroll
+            for (int j = 0; j < DXT_MAX; ++j)
+                if (j < ncol) acc[j] = fmaf(g, wr[j], acc[j]);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < DXT_MAX; ++j) {
+        if (j < ncol) {   // (uniform; the loop stays unrolled so that acc lives in registers)
+            float v = acc[j];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+            if (lane == 0) dx[(size_t)m * ncol + j] = v;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int pfrl_linear_fwd_twin(const float *const *x, const float *const *w, const float *const *bias,
+                                    float *const *y, int32_t M, int32_t K, int32_t N, int32_t relu,
+                                    void *stream) {
+    PFRL_CHECK_ARG(M >= 1 && K >= 1 && N >= 32 && N % 32 == 0, "pfrl_linear_fwd_twin: out_features % 32");
+    FwdArgs a[2];
+    for (int t = 0; t < 2; ++t) {
+        PFRL_CHECK_ARG(x[t] && w[t] && bias[t] && y[t], "pfrl_linear_fwd_twin: null pointer");
+        a[t].x = x[t]; a[t].w = w[t]; a[t].bias = bias[t]; a[t].y = y[t];
+        a[t].g = ConvGeom{M, 1, 1, K, N, 1, 1, 1, 1, 1};
+        a[t].M = M;
+        a[t].K = K;
+        a[t].cps = (K + KC - 1) / KC;
+        a[t].relu = relu; a[t].planar = 0; a[t].partial = 0;
+    }
+    const dim3 grid((M + 15) / 16, N / 32, 2);
+    hipStream_t st = (hipStream_t)stream;
+    if (K % KC == 0)
+        hipLaunchKernelGGL((k_conv_fwd2<16, 32, 1, 2, 2, 4, false>), grid, dim3(256), 0, st, a[0], a[1]);
+    else
+        hipLaunchKernelGGL((k_conv_fwd2<16, 32, 1, 2, 2, 4, true>), grid, dim3(256), 0, st, a[0], a[1]);
+    PFRL_LAUNCH_CHECK();
+}
+
+// Gradients of a twin layer.  dx == NULL: weight gradients only (any in_features);
+// dw_part == NULL: input gradients only; both given: one launch for all four (needs
+// in_features % 32 == 0).  Partials as pfrl_conv2d_nhwc_bwd_weight writes them.
+extern "C" int pfrl_linear_bwd_twin(const float *const *dy, const float *const *dy_mask,
+                                    const float *const *w, const float *const *x, float *const *dx,
+                                    float *const *dw_part, float *const *db_part, int64_t dw_stride,
+                                    int64_t db_stride, int32_t M, int32_t K, int32_t N, int32_t splits,
+                                    void *stream) {
+    PFRL_CHECK_ARG(M >= 1 && K >= 1 && N >= 32 && N % 32 == 0 && splits >= 1,
+                   "pfrl_linear_bwd_twin: out_features % 32");
+    PFRL_CHECK_ARG(dx != nullptr || dw_part != nullptr, "pfrl_linear_bwd_twin: nothing to compute");
+    hipStream_t st = (hipStream_t)stream;
+    DgradArgs d[2];
+    WgradArgs wa[2];
+    for (int t = 0; t < 2; ++t) {
+        const float *mk = dy_mask != nullptr ? dy_mask[t] : nullptr;
+        if (dx != nullptr) {
+            PFRL_CHECK_ARG(K % KC == 0, "pfrl_linear_bwd_twin: input gradient needs in_features % 32");
+            if (int rc = make_dgrad_args(d[t], dy[t], mk, w[t], nullptr, dx[t], M, 1, 1, K, N, 1, 1, 1, 0, 0))
+                return rc;
+        }
+        if (dw_part != nullptr) {
+            wa[t].dy = dy[t]; wa[t].dymask = mk; wa[t].x = x[t];
+            wa[t].dw = dw_part[t]; wa[t].db = db_part != nullptr ? db_part[t] : nullptr;
+            wa[t].dw_stride = dw_stride; wa[t].db_stride = db_stride;
+            wa[t].g = ConvGeom{M, 1, 1, K, N, 1, 1, 1, 1, 1};
+            wa[t].M = M;
+            wa[t].K = K;
+            const int nch = (M + KC - 1) / KC;
+            wa[t].cps = (nch + splits - 1) / splits;
+        }
+    }
+    const int wgx = N / 32, wgy = (K + 31) / 32;
+    if (dx != nullptr && dw_part != nullptr) {
+        const int dgx = (M + 15) / 16, dgy = K / 32;
+        hipLaunchKernelGGL((k_conv_bwd2<16, 32, 1, 2, 2, 4, 32, 2, 2, 1>),
+                           dim3(dgx * dgy + wgx * wgy * splits, 2), dim3(256), 0, st, d[0], wa[0], d[1],
+                           wa[1], dgx, dgy, wgx, wgy);
+    } else if (dx != nullptr) {
+        hipLaunchKernelGGL((k_conv_dgrad2<16, 32, 1, 2, 2, 4>), dim3((M + 15) / 16, K / 32, 2), dim3(256),
+                           0, st, d[0], d[1]);
+    } else if (K % KC == 0) {
+        hipLaunchKernelGGL((k_conv_wgrad2<32, 32, 2, 2, 1, 4, false>), dim3(wgx, wgy, 2 * splits),
+                           dim3(256), 0, st, wa[0], wa[1], splits);
+    } else {
+        hipLaunchKernelGGL((k_conv_wgrad2<32, 32, 2, 2, 1, 4, true>), dim3(wgx, wgy, 2 * splits),
+                           dim3(256), 0, st, wa[0], wa[1], splits);
+    }
+    PFRL_LAUNCH_CHECK();
+}
+
+extern "C" int pfrl_linear_small_fwd_twin(const float *const *x, const float *const *w,
+                                          const float *const *bias, float *const *y, int32_t M, int32_t K,
+                                          int32_t N, void *stream) {
+    SmallFwdArgs a{{x[0], x[1]}, {w[0], w[1]}, {bias[0], bias[1]}, {y[0], y[1]}};
+    return small_fwd_launch(a, 2, M, K, N, stream);
+}
+
+extern "C" int pfrl_linear_small_bwd_twin(const float *const *dy, const float *const *x,
+                                          const float *const *w, float *const *dx, float *const *dw,
+                                          float *const *db, int32_t M, int32_t K, int32_t N, void *stream) {
+    SmallBwdArgs a{{dy[0], dy[1]}, {x[0], x[1]}, {w[0], w[1]},
+                   {dx ? dx[0] : nullptr, dx ? dx[1] : nullptr},
+                   {dw ? dw[0] : nullptr, dw ? dw[1] : nullptr},
+                   {db ? db[0] : nullptr, db ? db[1] : nullptr}};
+    return small_bwd_launch(a, 2, dx != nullptr, dw != nullptr, M, K, N, stream);
+}
+
+extern "C" int pfrl_twin_input_grad(const float *const *dy, const float *const *dy_mask,
+                                    const float *const *w, int32_t ldw, int32_t col0, int32_t ncol,
+                                    float *dx, int32_t M, int32_t N, void *stream) {
+    PFRL_CHECK_ARG(M >= 1 && N >= 1 && ncol >= 1 && ncol <= DXT_MAX && col0 >= 0 && col0 + ncol <= ldw,
+                   "pfrl_twin_input_grad: at most 32 columns");
+    TwinDxArgs a{{dy[0], dy[1]},
+                 {dy_mask ? dy_mask[0] : nullptr, dy_mask ? dy_mask[1] : nullptr},
+                 {w[0], w[1]}};
+    hipLaunchKernelGGL(k_twin_input_grad, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, a, ldw,
+                       col0, ncol, dx, M, N);
     PFRL_LAUNCH_CHECK();
 }

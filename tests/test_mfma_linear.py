@@ -136,3 +136,62 @@ def test_frozen_weights_give_the_input_gradient_only(K, N):
     y = seq(x)
     y.backward(dy)
     assert all(p.grad is not None for p in seq.parameters())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,obs,act,hid", [(256, 376, 17, 256), (100, 24, 3, 64), (7, 11, 33, 32)])
+def test_twin_q_networks_match_the_two_modules(M, obs, act, hid):
+    """twin_forward(q1, q2, (s, a)) against q1((s, a)), q2((s, a)) evaluated one by one by
+    stock PyTorch: values, all parameter gradients, the action gradient; then with frozen
+    parameters (the policy loss): the action gradient only."""
+    from pfrl_amd.nn import accelerate_mlp
+    from pfrl_amd.nn.twin_mlp import twin_forward, twin_plan
+
+    dev = torch.device("cuda:0")
+    torch.manual_seed(M + obs)
+
+    def mk():
+        import pfrl_amd as pfrl
+
+        return nn.Sequential(pfrl.nn.ConcatObsAndAction(), nn.Linear(obs + act, hid), nn.ReLU(),
+                             nn.Linear(hid, hid), nn.ReLU(), nn.Linear(hid, 1)).to(dev)
+
+    q1, q2 = mk(), mk()
+    r1, r2 = copy.deepcopy(q1), copy.deepcopy(q2)
+    accelerate_mlp(q1), accelerate_mlp(q2)
+    s = torch.randn(M, obs, device=dev)
+    a = torch.randn(M, act, device=dev, requires_grad=True)
+    a_ref = a.detach().clone().requires_grad_(True)
+    g1, g2 = torch.randn(M, 1, device=dev), torch.randn(M, 1, device=dev)
+    assert twin_plan(q1, q2, (s, a)) is not None
+    o1, o2 = twin_forward(q1, q2, (s, a))
+    w1, w2 = r1((s, a_ref)), r2((s, a_ref))
+    tol = lambda ref: 2e-5 * max(ref.abs().max().item(), 1.0)
+    assert (o1 - w1).abs().max().item() < tol(w1) and (o2 - w2).abs().max().item() < tol(w2)
+    torch.autograd.backward([o1, o2], [g1, g2])
+    torch.autograd.backward([w1, w2], [g1, g2])
+    assert (a.grad - a_ref.grad).abs().max().item() < tol(a_ref.grad)
+    for q, r in ((q1, r1), (q2, r2)):
+        for p, pr in zip(q.parameters(), r.parameters()):
+            assert (p.grad - pr.grad).abs().max().item() < tol(pr.grad)
+    # one network's loss only (the other output unused): its gradients only
+    for q in (q1, q2):
+        q.zero_grad()
+    o1, o2 = twin_forward(q1, q2, (s, a.detach()))
+    o1.backward(g1)
+    for p, pr in zip(q1.parameters(), r1.parameters()):
+        assert (p.grad - pr.grad).abs().max().item() < tol(pr.grad)
+    assert all(float(p.grad.abs().max()) == 0.0 for p in q2.parameters())
+    # frozen parameters
+    a.grad = None
+    for q in (q1, q2):
+        q.zero_grad()
+        q.requires_grad_(False)
+    o1, o2 = twin_forward(q1, q2, (s, a))
+    torch.autograd.backward([o1, o2], [g1, g2])
+    assert (a.grad - a_ref.grad).abs().max().item() < tol(a_ref.grad)
+    assert all(p.grad is None for q in (q1, q2) for p in q.parameters())
+    # mixed requires_grad, a CPU input, a different shape: not twinned
+    q1.requires_grad_(True)
+    assert twin_forward(q1, q2, (s, a)) is None
+    assert twin_forward(q1, q1, (s.cpu(), a.detach().cpu())) is None
