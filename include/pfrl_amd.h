@@ -429,6 +429,9 @@ int pfrl_linear_small_bwd(const float *dy, const float *x, const float *w, float
  * the other) as ONE grid.  Every `const float *const *` argument is a HOST array of two
  * device pointers.  Same arithmetic as the single-network entry points.
  * pfrl_linear_fwd_twin: y_t = act(x_t w_t^T + b_t), any in_features, out_features % 32 == 0.
+ *   With x2 != NULL the input rows are [x_t (K1 columns) | x2_t (K - K1 columns)]:
+ *   ConcatObsAndAction (pfrl/nn/concat_obs_and_action.py) without materialising the
+ *   concatenation; likewise for the weight gradient in pfrl_linear_bwd_twin.
  * pfrl_linear_bwd_twin: dx == NULL: weight/bias gradient partials only (any in_features);
  *   dw_part == NULL: input gradients only; both: all four gradients in one launch
  *   (in_features % 32 == 0).
@@ -437,10 +440,12 @@ int pfrl_linear_small_bwd(const float *dy, const float *x, const float *w, float
  *   j < ncol <= 32: the gradient w.r.t. the action columns of the twins' first layer, the only
  *   input gradient the policy loss needs (:284-291).
  * pfrl_half_mse_twin_fwd/_bwd (below): both critic losses of one target. */
-int pfrl_linear_fwd_twin(const float *const *x, const float *const *w, const float *const *bias,
-                         float *const *y, int32_t M, int32_t K, int32_t N, int32_t relu, void *stream);
+int pfrl_linear_fwd_twin(const float *const *x, const float *const *x2, int32_t K1,
+                         const float *const *w, const float *const *bias, float *const *y, int32_t M,
+                         int32_t K, int32_t N, int32_t relu, void *stream);
 int pfrl_linear_bwd_twin(const float *const *dy, const float *const *dy_mask, const float *const *w,
-                         const float *const *x, float *const *dx, float *const *dw_part,
+                         const float *const *x, const float *const *x2, int32_t K1, float *const *dx,
+                         float *const *dw_part,
                          float *const *db_part, int64_t dw_stride, int64_t db_stride, int32_t M,
                          int32_t K, int32_t N, int32_t splits, void *stream);
 int pfrl_linear_small_fwd_twin(const float *const *x, const float *const *w, const float *const *bias,

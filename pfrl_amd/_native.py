@@ -144,8 +144,8 @@ EXPORTS = {
     "pfrl_half_mse_bwd": (ctypes.c_int, "ppppip"),
     "pfrl_half_mse_twin_fwd": (ctypes.c_int, "pppip"),
     "pfrl_half_mse_twin_bwd": (ctypes.c_int, "ppppip"),
-    "pfrl_linear_fwd_twin": (ctypes.c_int, "ppppiiiip"),
-    "pfrl_linear_bwd_twin": (ctypes.c_int, "pppppppqqiiiip"),
+    "pfrl_linear_fwd_twin": (ctypes.c_int, "ppipppiiiip"),
+    "pfrl_linear_bwd_twin": (ctypes.c_int, "pppppipppqqiiiip"),
     "pfrl_linear_small_fwd_twin": (ctypes.c_int, "ppppiiip"),
     "pfrl_linear_small_bwd_twin": (ctypes.c_int, "ppppppiiip"),
     "pfrl_twin_input_grad": (ctypes.c_int, "pppiiipiip"),

@@ -180,13 +180,15 @@ class SoftActorCritic(ReplayActorCritic):
         self.q_func2_optimizer.zero_grad()
         one = self._unit_grad(loss1)
         torch.autograd.backward([loss1, loss2], [one, one])
-        for module, optimizer in ((self.q_func1, self.q_func1_optimizer),
-                                  (self.q_func2, self.q_func2_optimizer)):
+        for module in (self.q_func1, self.q_func2):
             if module in self._reducers:
                 self._reducers[module].all_reduce()
             if self.max_grad_norm is not None:
                 clip_l2_grad_norm_(module.parameters(), self.max_grad_norm)
-            optimizer.step()
+        from pfrl_amd.optimizers import FusedAdam
+
+        # (one launch for both when they are FusedAdam with equal hyperparameters)
+        FusedAdam.step_together([self.q_func1_optimizer, self.q_func2_optimizer])
 
     @staticmethod
     def _q_pair(q1, q2, inputs):

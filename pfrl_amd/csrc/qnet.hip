@@ -177,6 +177,10 @@ struct FwdArgs {
     ConvGeom g;
     int M, K, cps;
     int relu, planar, partial;
+    // (TAIL only) input rows split over two tensors: columns [0, K1) from x (row stride K1),
+    // [K1, K) from x2 (row stride K - K1) -- cat((obs, action)) without the copy
+    const float *x2 = nullptr;
+    int K1 = 0;
 };
 
 // TAIL: linear layers (1x1) whose in_features are not a multiple of 32 or whose rows are
@@ -202,8 +206,9 @@ __device__ __forceinline__ void fwd_body(const FwdArgs &p, const int bx, const i
     struct Slot {
         float4 a[NPA], b[NPB];
     };
-    const float *ap[NPA], *bp[NPB];
+    const float *ap[NPA], *ap2[NPA], *bp[NPB];
     bool aok[NPA], bok[NPB];
+    const int K1 = (TAIL && p.x2 != nullptr) ? p.K1 : p.K;
 #pragma unroll
     for (int pp = 0; pp < NPA; ++pp) {
         const int f = tid + 256 * pp, row = f >> 3, q = f & 7;
@@ -212,7 +217,13 @@ __device__ __forceinline__ void fwd_body(const FwdArgs &p, const int bx, const i
         const int mm = ok ? m : 0;
         const int n = mm / ohow, rem = mm - n * ohow;
         const int oh = rem / g.OW, ow = rem - oh * g.OW;
-        ap[pp] = p.x + ((size_t)(n * g.H + oh * g.ST) * g.W + ow * g.ST) * g.C + (TAIL ? 0 : 4 * q);
+        if (TAIL) {
+            ap[pp] = p.x + (size_t)mm * K1;
+            ap2[pp] = p.x2 != nullptr ? p.x2 + (size_t)mm * (p.K - K1) : ap[pp];
+        } else {
+            ap[pp] = p.x + ((size_t)(n * g.H + oh * g.ST) * g.W + ow * g.ST) * g.C + 4 * q;
+            ap2[pp] = ap[pp];
+        }
         aok[pp] = ok;
     }
 #pragma unroll
@@ -231,9 +242,13 @@ __device__ __forceinline__ void fwd_body(const FwdArgs &p, const int bx, const i
             const int kl = p.K - 1;
             const int i0 = min(k0 + kq4, kl), i1 = min(k0 + kq4 + 1, kl), i2 = min(k0 + kq4 + 2, kl),
                       i3 = min(k0 + kq4 + 3, kl);
+            // (the address is selected, not the load predicated: see ldg4)
+#define PFRL_A_AT(pp, i) (*((i) < K1 ? ap[pp] + (i) : ap2[pp] + ((i) - K1)))
 #pragma unroll
             for (int pp = 0; pp < NPA; ++pp)
-                sl.a[pp] = make_float4(ap[pp][i0], ap[pp][i1], ap[pp][i2], ap[pp][i3]);
+                sl.a[pp] = make_float4(PFRL_A_AT(pp, i0), PFRL_A_AT(pp, i1), PFRL_A_AT(pp, i2),
+                                       PFRL_A_AT(pp, i3));
+#undef PFRL_A_AT
 #pragma unroll
             for (int pp = 0; pp < NPB; ++pp)
                 sl.b[pp] = make_float4(bp[pp][i0], bp[pp][i1], bp[pp][i2], bp[pp][i3]);
@@ -501,6 +516,8 @@ struct WgradArgs {
     long long dw_stride, db_stride;   // between the partials of consecutive splits
     ConvGeom g;
     int M, K, cps;
+    const float *x2 = nullptr;   // (TAIL only) second input tensor, as in FwdArgs
+    int K1 = 0;
 };
 
 // TAIL: linear layers (1x1) whose in_features are not a multiple of 32 / whose rows are not
@@ -556,10 +573,17 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs &p, const int bx, con
             const bool ok = bkk[pp] < 32 && m < p.M;
             const int mm = ok ? m : 0;
             if (TAIL) {
-                const float *row = p.x + (size_t)mm * p.K;
+                const int K1 = p.x2 != nullptr ? p.K1 : p.K;
+                const float *row = p.x + (size_t)mm * K1;
+                const float *row2 = p.x2 != nullptr ? p.x2 + (size_t)mm * (p.K - K1) : row;
                 const int j = j0 + 4 * bq[pp], kl = p.K - 1;
-                sl.b[pp] = make_float4(row[min(j, kl)], row[min(j + 1, kl)], row[min(j + 2, kl)],
-                                       row[min(j + 3, kl)]);
+                float e[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int i = min(j + u, kl);
+                    e[u] = *(i < K1 ? row + i : row2 + (i - K1));
+                }
+                sl.b[pp] = make_float4(e[0], e[1], e[2], e[3]);
                 continue;
             }
             const int n = mm / ohow, rem = mm - n * ohow;
@@ -1242,41 +1266,76 @@ struct TwinDxArgs {
 
 __global__ __launch_bounds__(256) void k_twin_input_grad(TwinDxArgs a, int ldw, int col0, int ncol,
                                                          float *__restrict__ dx, int M, int N) {
+    extern __shared__ float ws[];   // [2][N][ncol]: the weight columns, staged once per workgroup
+    const int per = N * ncol, tot = 2 * per;
+    for (int e0 = threadIdx.x; e0 < tot; e0 += 256 * 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = min(e0 + 256 * u, tot - 1);
+            const int t = e >= per, r = e - t * per;
+            const int n = r / ncol, j = r - n * ncol;
+            v[u] = a.w[t][(size_t)n * ldw + col0 + j];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (e0 + 256 * u < tot) ws[e0 + 256 * u] = v[u];
+    }
     const int m = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (m >= M) return;
+    const int mm = m < M ? m : M - 1;
+    // every lane's dy (ReLU-masked) values of both networks, loads first
+    constexpr int NMAX = 8;   // N <= 512
+    float g[2][NMAX];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const float *__restrict__ dy = a.dy[t] + (size_t)mm * N;
+        const float *__restrict__ mk = a.mask[t] != nullptr ? a.mask[t] + (size_t)mm * N : dy;
+        float d[NMAX], h[NMAX];
+#pragma unroll
+        for (int u = 0; u < NMAX; ++u) {
+            const int n = min(lane + 64 * u, N - 1);
+            d[u] = dy[n];
+            h[u] = mk[n];
+        }
+#pragma unroll
+        for (int u = 0; u < NMAX; ++u) {
+            const bool in = lane + 64 * u < N;
+            g[t][u] = (in && (a.mask[t] == nullptr || h[u] > 0.f)) ? d[u] : 0.f;
+        }
+    }
+    __syncthreads();
     float acc[DXT_MAX];
 #pragma unroll
     for (int j = 0; j < DXT_MAX; ++j) acc[j] = 0.f;
-    for (int t = 0; t < 2; ++t) {
-        const float *__restrict__ dy = a.dy[t] + (size_t)m * N;
-        const float *__restrict__ mk = a.mask[t] != nullptr ? a.mask[t] + (size_t)m * N : nullptr;
-        const float *__restrict__ w = a.w[t];
-        for (int n = lane; n < N; n += 64) {
-            float g = dy[n];
-            if (mk != nullptr) g = mk[n] > 0.f ? g : 0.f;
-            const float *wr = w + (size_t)n * ldw + col0;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int u = 0; u < NMAX; ++u) {
+            if (64 * u >= N) continue;   // (uniform)
+            const int n = min(lane + 64 * u, N - 1);
+            const float *wr = ws + (size_t)(t * N + n) * ncol;
 #pragma unroll
             for (int j = 0; j < DXT_MAX; ++j)
-                if (j < ncol) acc[j] = fmaf(g, wr[j], acc[j]);
+                if (j < ncol) acc[j] = fmaf(g[t][u], wr[j], acc[j]);
         }
-    }
 #pragma unroll
     for (int j = 0; j < DXT_MAX; ++j) {
         if (j < ncol) {   // (uniform; the loop stays unrolled so that acc lives in registers)
             float v = acc[j];
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-            if (lane == 0) dx[(size_t)m * ncol + j] = v;
+            if (lane == 0 && m < M) dx[(size_t)m * ncol + j] = v;
         }
     }
 }
 
 }  // namespace
 
-extern "C" int pfrl_linear_fwd_twin(const float *const *x, const float *const *w, const float *const *bias,
-                                    float *const *y, int32_t M, int32_t K, int32_t N, int32_t relu,
-                                    void *stream) {
+extern "C" int pfrl_linear_fwd_twin(const float *const *x, const float *const *x2, int32_t K1,
+                                    const float *const *w, const float *const *bias, float *const *y,
+                                    int32_t M, int32_t K, int32_t N, int32_t relu, void *stream) {
     PFRL_CHECK_ARG(M >= 1 && K >= 1 && N >= 32 && N % 32 == 0, "pfrl_linear_fwd_twin: out_features % 32");
+    PFRL_CHECK_ARG(x2 == nullptr || (K1 >= 1 && K1 < K), "pfrl_linear_fwd_twin: bad column split");
     FwdArgs a[2];
     for (int t = 0; t < 2; ++t) {
         PFRL_CHECK_ARG(x[t] && w[t] && bias[t] && y[t], "pfrl_linear_fwd_twin: null pointer");
@@ -1286,10 +1345,14 @@ extern "C" int pfrl_linear_fwd_twin(const float *const *x, const float *const *w
         a[t].K = K;
         a[t].cps = (K + KC - 1) / KC;
         a[t].relu = relu; a[t].planar = 0; a[t].partial = 0;
+        if (x2 != nullptr) {
+            a[t].x2 = x2[t];
+            a[t].K1 = K1;
+        }
     }
     const dim3 grid((M + 15) / 16, N / 32, 2);
     hipStream_t st = (hipStream_t)stream;
-    if (K % KC == 0)
+    if (K % KC == 0 && x2 == nullptr)
         hipLaunchKernelGGL((k_conv_fwd2<16, 32, 1, 2, 2, 4, false>), grid, dim3(256), 0, st, a[0], a[1]);
     else
         hipLaunchKernelGGL((k_conv_fwd2<16, 32, 1, 2, 2, 4, true>), grid, dim3(256), 0, st, a[0], a[1]);
@@ -1300,7 +1363,8 @@ extern "C" int pfrl_linear_fwd_twin(const float *const *x, const float *const *w
 // dw_part == NULL: input gradients only; both given: one launch for all four (needs
 // in_features % 32 == 0).  Partials as pfrl_conv2d_nhwc_bwd_weight writes them.
 extern "C" int pfrl_linear_bwd_twin(const float *const *dy, const float *const *dy_mask,
-                                    const float *const *w, const float *const *x, float *const *dx,
+                                    const float *const *w, const float *const *x,
+                                    const float *const *x2, int32_t K1, float *const *dx,
                                     float *const *dw_part, float *const *db_part, int64_t dw_stride,
                                     int64_t db_stride, int32_t M, int32_t K, int32_t N, int32_t splits,
                                     void *stream) {
@@ -1326,6 +1390,11 @@ extern "C" int pfrl_linear_bwd_twin(const float *const *dy, const float *const *
             wa[t].K = K;
             const int nch = (M + KC - 1) / KC;
             wa[t].cps = (nch + splits - 1) / splits;
+            if (x2 != nullptr) {
+                PFRL_CHECK_ARG(dx == nullptr && K1 >= 1 && K1 < K, "pfrl_linear_bwd_twin: bad column split");
+                wa[t].x2 = x2[t];
+                wa[t].K1 = K1;
+            }
         }
     }
     const int wgx = N / 32, wgy = (K + 31) / 32;
@@ -1337,7 +1406,7 @@ extern "C" int pfrl_linear_bwd_twin(const float *const *dy, const float *const *
     } else if (dx != nullptr) {
         hipLaunchKernelGGL((k_conv_dgrad2<16, 32, 1, 2, 2, 4>), dim3((M + 15) / 16, K / 32, 2), dim3(256),
                            0, st, d[0], d[1]);
-    } else if (K % KC == 0) {
+    } else if (K % KC == 0 && x2 == nullptr) {
         hipLaunchKernelGGL((k_conv_wgrad2<32, 32, 2, 2, 1, 4, false>), dim3(wgx, wgy, 2 * splits),
                            dim3(256), 0, st, wa[0], wa[1], splits);
     } else {
@@ -1367,12 +1436,14 @@ extern "C" int pfrl_linear_small_bwd_twin(const float *const *dy, const float *c
 extern "C" int pfrl_twin_input_grad(const float *const *dy, const float *const *dy_mask,
                                     const float *const *w, int32_t ldw, int32_t col0, int32_t ncol,
                                     float *dx, int32_t M, int32_t N, void *stream) {
-    PFRL_CHECK_ARG(M >= 1 && N >= 1 && ncol >= 1 && ncol <= DXT_MAX && col0 >= 0 && col0 + ncol <= ldw,
-                   "pfrl_twin_input_grad: at most 32 columns");
+    PFRL_CHECK_ARG(M >= 1 && N >= 1 && N <= 512 && ncol >= 1 && ncol <= DXT_MAX && col0 >= 0 &&
+                       col0 + ncol <= ldw && (size_t)2 * N * ncol * sizeof(float) <= 60 * 1024,
+                   "pfrl_twin_input_grad: at most 32 columns, N <= 512, 2*N*ncol floats of LDS");
     TwinDxArgs a{{dy[0], dy[1]},
                  {dy_mask ? dy_mask[0] : nullptr, dy_mask ? dy_mask[1] : nullptr},
                  {w[0], w[1]}};
-    hipLaunchKernelGGL(k_twin_input_grad, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, a, ldw,
-                       col0, ncol, dx, M, N);
+    hipLaunchKernelGGL(k_twin_input_grad, dim3((M + 3) / 4), dim3(256),
+                       (size_t)2 * N * ncol * sizeof(float), (hipStream_t)stream, a, ldw, col0, ncol, dx, M,
+                       N);
     PFRL_LAUNCH_CHECK();
 }

@@ -91,29 +91,31 @@ class _TwinQ(torch.autograd.Function):
         w1a, b1a, w2a, b2a, w3a, b3a, w1b, b1b, w2b, b2b, w3b, b3b = params
         lib = _native.lib()
         dev = obs.device
-        x = torch.cat((obs, action), dim=1)
-        M, K = x.shape
+        M = obs.shape[0]
+        Ko, K = obs.shape[1], obs.shape[1] + action.shape[1]
         H1, H2, No = w1a.shape[0], w2a.shape[0], w3a.shape[0]
         h1 = torch.empty((2, M, H1), dtype=torch.float32, device=dev)
         h2 = torch.empty((2, M, H2), dtype=torch.float32, device=dev)
         q = torch.empty((2, M, No), dtype=torch.float32, device=dev)
         st = _stream()
-        check(lib.pfrl_linear_fwd_twin(_pair(x, x), _pair(w1a, w1b), _pair(b1a, b1b), _pair(h1[0], h1[1]),
-                                       M, K, H1, 1, st), "linear_fwd_twin")
-        check(lib.pfrl_linear_fwd_twin(_pair(h1[0], h1[1]), _pair(w2a, w2b), _pair(b2a, b2b),
+        # layer 1 reads its input rows from obs and action directly (no cat)
+        check(lib.pfrl_linear_fwd_twin(_pair(obs, obs), _pair(action, action), Ko, _pair(w1a, w1b),
+                                       _pair(b1a, b1b), _pair(h1[0], h1[1]), M, K, H1, 1, st),
+              "linear_fwd_twin")
+        check(lib.pfrl_linear_fwd_twin(_pair(h1[0], h1[1]), None, 0, _pair(w2a, w2b), _pair(b2a, b2b),
                                        _pair(h2[0], h2[1]), M, H1, H2, 1, st), "linear_fwd_twin")
         check(lib.pfrl_linear_small_fwd_twin(_pair(h2[0], h2[1]), _pair(w3a, w3b), _pair(b3a, b3b),
                                              _pair(q[0], q[1]), M, H2, No, st), "linear_small_fwd_twin")
-        ctx.save_for_backward(x, h1, h2, w1a, w2a, w3a, w1b, w2b, w3b)
-        ctx.n_obs = obs.shape[1]
+        ctx.save_for_backward(obs, action, h1, h2, w1a, w2a, w3a, w1b, w2b, w3b)
         return q[0], q[1]
 
     @staticmethod
     def backward(ctx, ga, gb):
-        x, h1, h2, w1a, w2a, w3a, w1b, w2b, w3b = ctx.saved_tensors
+        obs, action, h1, h2, w1a, w2a, w3a, w1b, w2b, w3b = ctx.saved_tensors
         lib = _native.lib()
-        dev = x.device
-        M, K = x.shape
+        dev = obs.device
+        M = obs.shape[0]
+        Ko, K = obs.shape[1], obs.shape[1] + action.shape[1]
         H1, H2, No = w1a.shape[0], w2a.shape[0], w3a.shape[0]
         need_da = ctx.needs_input_grad[1]
         need_w = any(ctx.needs_input_grad[2:])
@@ -142,12 +144,14 @@ class _TwinQ(torch.autograd.Function):
             p2 = torch.empty((2, s2 * st2), **f32)
             p1 = torch.empty((2, s1 * st1), **f32)
             check(lib.pfrl_linear_bwd_twin(_pair(dh2[0], dh2[1]), _pair(h2[0], h2[1]), _pair(w2a, w2b),
-                                           _pair(h1[0], h1[1]), _pair(dh1[0], dh1[1]), _pair(p2[0], p2[1]),
-                                           _pair(p2[0][n2:], p2[1][n2:]), st2, st2, M, H1, H2, s2, st),
+                                           _pair(h1[0], h1[1]), None, 0, _pair(dh1[0], dh1[1]),
+                                           _pair(p2[0], p2[1]), _pair(p2[0][n2:], p2[1][n2:]), st2, st2, M,
+                                           H1, H2, s2, st),
                   "linear_bwd_twin")
             check(lib.pfrl_linear_bwd_twin(_pair(dh1[0], dh1[1]), _pair(h1[0], h1[1]), _pair(w1a, w1b),
-                                           _pair(x, x), None, _pair(p1[0], p1[1]),
-                                           _pair(p1[0][n1:], p1[1][n1:]), st1, st1, M, K, H1, s1, st),
+                                           _pair(obs, obs), _pair(action, action), Ko, None,
+                                           _pair(p1[0], p1[1]), _pair(p1[0][n1:], p1[1][n1:]), st1, st1, M,
+                                           K, H1, s1, st),
                   "linear_bwd_twin")
             dw2 = torch.empty((2, H2, H1), **f32)
             db2 = torch.empty((2, H2), **f32)
@@ -166,18 +170,18 @@ class _TwinQ(torch.autograd.Function):
                   "linear_small_bwd_twin")
             if need_da:
                 check(lib.pfrl_linear_bwd_twin(_pair(dh2[0], dh2[1]), _pair(h2[0], h2[1]), _pair(w2a, w2b),
-                                               None, _pair(dh1[0], dh1[1]), None, None, 0, 0, M, H1, H2, 1,
-                                               st), "linear_bwd_twin")
+                                               None, None, 0, _pair(dh1[0], dh1[1]), None, None, 0, 0, M, H1,
+                                               H2, 1, st), "linear_bwd_twin")
         da = None
         if need_da:
-            A = K - ctx.n_obs
-            if A <= 32:
+            A = K - Ko
+            if A <= 32 and H1 <= 512 and 2 * H1 * A * 4 <= 60 * 1024:
                 da = torch.empty((M, A), **f32)
                 check(lib.pfrl_twin_input_grad(_pair(dh1[0], dh1[1]), _pair(h1[0], h1[1]), _pair(w1a, w1b),
-                                               K, ctx.n_obs, A, ctx_ptr(da), M, H1, st), "twin_input_grad")
+                                               K, Ko, A, ctx_ptr(da), M, H1, st), "twin_input_grad")
             else:
                 g = torch.ops.aten.threshold_backward(dh1, h1, 0.0)
-                da = g[0] @ w1a[:, ctx.n_obs:] + g[1] @ w1b[:, ctx.n_obs:]
+                da = g[0] @ w1a[:, Ko:] + g[1] @ w1b[:, Ko:]
         return (None, da) + tuple(grads)
 
 

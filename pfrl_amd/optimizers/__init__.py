@@ -91,6 +91,74 @@ class FusedAdam(torch.optim.Adam):
                         and not p.grad.is_sparse and p.grad.dtype == torch.float32
                         and p.grad.stride() == p.stride() for p in params))
 
+    @staticmethod
+    @torch.no_grad()
+    def step_together(optimizers):
+        """``step()`` of several optimizers; one launch for all of them when they are FusedAdam
+        instances with one parameter group each and equal hyperparameters (the two critics of
+        SAC / TD3), else one after the other."""
+        opts = list(optimizers)
+        same = (len(opts) > 1 and all(type(o) is FusedAdam and len(o.param_groups) == 1 for o in opts))
+        if same:
+            keys = ("lr", "betas", "eps", "weight_decay", "amsgrad", "maximize")
+            ref = opts[0].param_groups[0]
+            same = all(all(o.param_groups[0].get(k) == ref.get(k) for k in keys) for o in opts)
+        if not same:
+            for o in opts:
+                o.step()
+            return
+        groups = [o.param_groups[0] for o in opts]
+        params = [[p for p in g["params"] if p.grad is not None] for g in groups]
+        if (not all(params) or not all(o._fusable(g, ps) for o, g, ps in zip(opts, groups, params))
+                or len({ps[0].device for ps in params}) != 1):
+            for o in opts:
+                o.step()
+            return
+        for o, g, ps in zip(opts, groups, params):
+            if not o._prepare_state(g, ps):
+                for oo in opts:
+                    oo.step()
+                return
+        flat = [(o, p) for o, ps in zip(opts, params) for p in ps]
+        opts[0]._launch(ref, [p for _, p in flat], [o.state[p] for o, p in flat])
+
+    def _prepare_state(self, group, params):
+        """Device-side step counters (as torch's capturable path keeps them, which is also what
+        its own step() needs should a later call fall outside the kernel) and moment buffers;
+        False if an existing state does not have the parameters' layout."""
+        group["capturable"] = True
+        for p in params:
+            st = self.state[p]
+            if len(st) == 0:
+                st["step"] = torch.zeros((), dtype=torch.float32, device=p.device)
+                st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            elif not st["step"].is_cuda:
+                # state loaded from a checkpoint of a host-step optimizer
+                st["step"] = st["step"].to(device=p.device, dtype=torch.float32)
+            if st["exp_avg"].stride() != p.stride() or st["exp_avg_sq"].stride() != p.stride():
+                return False
+        return True
+
+    def _launch(self, group, params, states):
+        dev = params[0].device
+        tickets = self.__dict__.setdefault("_ticket", {})
+        if dev not in tickets:
+            tickets[dev] = torch.zeros(1, dtype=torch.int32, device=dev)
+        n = len(params)
+        V = ctypes.c_void_p
+        P = (V * n)(*[p.data_ptr() for p in params])
+        G = (V * n)(*[p.grad.data_ptr() for p in params])
+        M = (V * n)(*[st["exp_avg"].data_ptr() for st in states])
+        S = (V * n)(*[st["exp_avg_sq"].data_ptr() for st in states])
+        T = (V * n)(*[st["step"].data_ptr() for st in states])
+        L = (ctypes.c_int64 * n)(*[p.numel() for p in params])
+        b1, b2 = group["betas"]
+        stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        _native.check(_native.lib().pfrl_adam_step(
+            n, P, G, M, S, T, L, float(group["lr"]), float(b1), float(b2), float(group["eps"]),
+            float(group["weight_decay"]), V(tickets[dev].data_ptr()), stream), "adam_step")
+
     @torch.no_grad()
     def step(self, closure=None):
         loss = None
@@ -101,39 +169,9 @@ class FusedAdam(torch.optim.Adam):
             params = [p for p in group["params"] if p.grad is not None]
             if not params:
                 continue
-            if not self._fusable(group, params):
+            if not self._fusable(group, params) or not self._prepare_state(group, params):
                 return super().step(closure=None) if loss is None else loss
-            dev = params[0].device
-            # device-side step counters, as torch's own capturable path keeps them (which is
-            # also what its step() needs should a later call fall outside the kernel)
-            group["capturable"] = True
-            for p in params:
-                st = self.state[p]
-                if len(st) == 0:
-                    st["step"] = torch.zeros((), dtype=torch.float32, device=p.device)
-                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                elif not st["step"].is_cuda:
-                    # state loaded from a checkpoint of a host-step optimizer
-                    st["step"] = st["step"].to(device=p.device, dtype=torch.float32)
-                if st["exp_avg"].stride() != p.stride() or st["exp_avg_sq"].stride() != p.stride():
-                    return super().step(closure=None) if loss is None else loss
-            tickets = self.__dict__.setdefault("_ticket", {})
-            if dev not in tickets:
-                tickets[dev] = torch.zeros(1, dtype=torch.int32, device=dev)
-            n = len(params)
-            V = ctypes.c_void_p
-            P = (V * n)(*[p.data_ptr() for p in params])
-            G = (V * n)(*[p.grad.data_ptr() for p in params])
-            M = (V * n)(*[self.state[p]["exp_avg"].data_ptr() for p in params])
-            S = (V * n)(*[self.state[p]["exp_avg_sq"].data_ptr() for p in params])
-            T = (V * n)(*[self.state[p]["step"].data_ptr() for p in params])
-            L = (ctypes.c_int64 * n)(*[p.numel() for p in params])
-            b1, b2 = group["betas"]
-            stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-            _native.check(_native.lib().pfrl_adam_step(
-                n, P, G, M, S, T, L, float(group["lr"]), float(b1), float(b2), float(group["eps"]),
-                float(group["weight_decay"]), V(tickets[dev].data_ptr()), stream), "adam_step")
+            self._launch(group, params, [self.state[p] for p in params])
         return loss
 
 

@@ -268,3 +268,28 @@ def test_sac_loss_kernels_match_the_torch_formulas(B):
     ref = -torch.mean(holder() * (lp + (-17.0)))
     (gr,) = torch.autograd.grad(ref, [holder.log_temperature])
     assert torch.allclose(loss, ref, rtol=1e-5) and torch.allclose(gt, gr, rtol=1e-5)
+
+
+@pytest.mark.gpu
+def test_fused_adam_step_together_equals_separate_steps():
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    nets = [nn.Linear(393, 256).to(dev) for _ in range(2)]
+    refs = [copy.deepcopy(n) for n in nets]
+    opts = [FusedAdam(n.parameters(), lr=3e-4) for n in nets]
+    ropts = [FusedAdam(n.parameters(), lr=3e-4) for n in refs]
+    for _ in range(3):
+        for n, r in zip(nets, refs):
+            for p, q in zip(n.parameters(), r.parameters()):
+                p.grad = torch.randn_like(p)
+                q.grad = p.grad.clone()
+        FusedAdam.step_together(opts)
+        for o in ropts:
+            o.step()
+    for n, r, o in zip(nets, refs, opts):
+        for p, q in zip(n.parameters(), r.parameters()):
+            assert torch.equal(p, q) and float(o.state[p]["step"]) == 3.0
+    # different hyperparameters, or a stock optimizer in the list: one after the other
+    mixed = [opts[0], torch.optim.Adam(nets[1].parameters(), lr=1e-3, capturable=True)]
+    FusedAdam.step_together(mixed)
+    assert float(opts[0].state[next(nets[0].parameters())]["step"]) == 4.0
