@@ -1268,17 +1268,18 @@ __global__ __launch_bounds__(256) void k_twin_input_grad(TwinDxArgs a, int ldw, 
                                                          float *__restrict__ dx, int M, int N) {
     extern __shared__ float ws[];   // [2][N][ncol]: the weight columns, staged once per workgroup
     const int per = N * ncol, tot = 2 * per;
-    for (int e0 = threadIdx.x; e0 < tot; e0 += 256 * 8) {
-        float v[8];
+    // every thread's share of the staging loads in flight at once (up to 60 KB: 60 per thread)
+    for (int e0 = threadIdx.x; e0 < tot; e0 += 256 * 20) {
+        float v[20];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < 20; ++u) {
             const int e = min(e0 + 256 * u, tot - 1);
             const int t = e >= per, r = e - t * per;
             const int n = r / ncol, j = r - n * ncol;
             v[u] = a.w[t][(size_t)n * ldw + col0 + j];
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u)
+        for (int u = 0; u < 20; ++u)
             if (e0 + 256 * u < tot) ws[e0 + 256 * u] = v[u];
     }
     const int m = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -1286,6 +1287,7 @@ __global__ __launch_bounds__(256) void k_twin_input_grad(TwinDxArgs a, int ldw, 
     // every lane's dy (ReLU-masked) values of both networks, loads first
     constexpr int NMAX = 8;   // N <= 512
     float g[2][NMAX];
+    const int nu = (N + 63) / 64;
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         const float *__restrict__ dy = a.dy[t] + (size_t)mm * N;
@@ -1293,9 +1295,14 @@ __global__ __launch_bounds__(256) void k_twin_input_grad(TwinDxArgs a, int ldw, 
         float d[NMAX], h[NMAX];
 #pragma unroll
         for (int u = 0; u < NMAX; ++u) {
-            const int n = min(lane + 64 * u, N - 1);
-            d[u] = dy[n];
-            h[u] = mk[n];
+            if (u < nu) {   // (uniform)
+                const int n = min(lane + 64 * u, N - 1);
+                d[u] = dy[n];
+                h[u] = mk[n];
+            } else {
+                d[u] = 0.f;
+                h[u] = 0.f;
+            }
         }
 #pragma unroll
         for (int u = 0; u < NMAX; ++u) {
