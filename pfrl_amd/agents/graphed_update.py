@@ -16,6 +16,8 @@ training.
 import logging
 import os
 
+import collections
+
 import torch
 
 from pfrl_amd import distributed
@@ -58,12 +60,50 @@ def _make_capturable(optimizer, device):
     return ok
 
 
+class _GraphCache(collections.OrderedDict):
+    """Captured graphs by key, least recently used first.  When ``max_graphs`` entries exist the
+    oldest is dropped to admit a new one (its graph is released; the shared pool keeps the
+    memory for the next capture) instead of failing the update."""
+
+    def __init__(self, max_graphs):
+        super().__init__()
+        self.max_graphs = max_graphs
+
+    def lookup(self, key):
+        entry = self.get(key)
+        if entry is not None:
+            self.move_to_end(key)
+        return entry
+
+    def admit(self, key, entry):
+        while len(self) >= self.max_graphs:
+            self.popitem(last=False)
+        self[key] = entry
+
+
+def _hyper_signature(optimizers):
+    """What a captured optimizer launch bakes in as kernel arguments: the Python-number
+    hyperparameters of every parameter group.  Part of the graph key, so that a changed
+    learning rate (a schedule hook) captures anew instead of replaying the old value."""
+    sig = []
+    for opt in optimizers:
+        if opt is None:
+            continue
+        for g in opt.param_groups:
+            # (flags such as `capturable` are switched by the capture itself: numbers only)
+            sig.append(tuple((k, v if isinstance(v, (int, float, tuple)) else id(v))
+                             for k, v in sorted(g.items())
+                             if k != "params" and not isinstance(v, bool)
+                             and isinstance(v, (int, float, tuple, torch.Tensor))))
+    return tuple(sig)
+
+
 class GraphedUpdate:
     """Caches one captured graph per minibatch-buffer address set."""
 
     def __init__(self, agent, max_graphs=256):
         self.agent = agent
-        self.graphs = {}
+        self.graphs = _GraphCache(max_graphs)
         self.pool = None
         self.enabled = True
         self.max_graphs = max_graphs
@@ -83,8 +123,9 @@ class GraphedUpdate:
         self.graph_collective = os.environ.get("PFRL_GRAPH_COLLECTIVE", "0") == "1"
 
     def _key(self, exp_batch):
-        return tuple(sorted((k, v.data_ptr(), tuple(v.shape)) for k, v in exp_batch.items()
-                            if isinstance(v, torch.Tensor)))
+        return (tuple(sorted((k, v.data_ptr(), tuple(v.shape)) for k, v in exp_batch.items()
+                             if isinstance(v, torch.Tensor))),
+                _hyper_signature([self.agent.optimizer]))
 
     # the work that gets captured ------------------------------------------------
     def _forward(self, exp_batch, want_errors):
@@ -261,12 +302,10 @@ class GraphedUpdate:
         without U - 1 graph launches and the idle gaps between them).  Returns
         (losses [U], ys [U * B]) owned by the graph."""
         key = ("range", self._key(big))
-        entry = self.graphs.get(key)
+        entry = self.graphs.lookup(key)
         if entry is None:
-            if len(self.graphs) >= self.max_graphs:
-                raise RuntimeError("too many distinct minibatch buffers for graph capture")
             entry = self._capture_range(big)
-            self.graphs[key] = entry
+            self.graphs.admit(key, entry)
         entry["graph"].replay()
         return entry["losses"], entry["ys"]
 
@@ -323,12 +362,10 @@ class GraphedUpdate:
         pipeline mode ``after_forward(delta)`` is called between the forward
         graph and the backward/step graph."""
         key = (self._key(exp_batch), bool(want_errors))
-        entry = self.graphs.get(key)
+        entry = self.graphs.lookup(key)
         if entry is None:
-            if len(self.graphs) >= self.max_graphs:
-                raise RuntimeError("too many distinct minibatch buffers for graph capture")
             entry = self._capture(exp_batch, want_errors)
-            self.graphs[key] = entry
+            self.graphs.admit(key, entry)
         called = False
         for item in entry["plan"]:
             if item == "all_reduce":
@@ -394,7 +431,7 @@ class CapturedStep:
         self.modules = [m for m in modules if m is not None]
         self.optimizers = [o for o in optimizers if o is not None]
         self.device = device
-        self.graphs = {}
+        self.graphs = _GraphCache(max_graphs)
         self.pool = None
         self.max_graphs = max_graphs
 
@@ -471,11 +508,9 @@ class CapturedStep:
         holds the U steps back to back.  Returns the list of the U ``fn`` results (tensors
         owned by the graph)."""
         U = len(variants)
-        key = ("range", self._key(big), tuple(variants))
-        entry = self.graphs.get(key)
+        key = ("range", self._key(big), tuple(variants), _hyper_signature(self.optimizers))
+        entry = self.graphs.lookup(key)
         if entry is None:
-            if len(self.graphs) >= self.max_graphs:
-                raise RuntimeError("too many distinct minibatch buffers for graph capture")
 
             def slice_of(p):
                 return {k: v[p] for k, v in big.items()}
@@ -486,7 +521,7 @@ class CapturedStep:
 
             entry = self._capture(None, None, step=lambda: [call(p) for p in range(U)],
                                   warm=lambda: call(0))
-            self.graphs[key] = entry
+            self.graphs.admit(key, entry)
         entry[0].replay()
         return entry[1]
 
@@ -494,12 +529,10 @@ class CapturedStep:
         """``variant`` (hashable) selects between differently shaped steps over the
         same buffers (TD3: with / without the delayed policy update); it is passed
         to ``fn`` as a second argument when not None."""
-        key = (self._key(batch), variant)
-        entry = self.graphs.get(key)
+        key = (self._key(batch), variant, _hyper_signature(self.optimizers))
+        entry = self.graphs.lookup(key)
         if entry is None:
-            if len(self.graphs) >= self.max_graphs:
-                raise RuntimeError("too many distinct minibatch buffers for graph capture")
             entry = self._capture(batch, variant)
-            self.graphs[key] = entry
+            self.graphs.admit(key, entry)
         entry[0].replay()
         return entry[1]

@@ -320,3 +320,20 @@ def test_load_after_captured_updates_keeps_training_on_the_loaded_state(tmp_path
     sq_after = [ag.optimizer.state[p]["square_avg"] for p in q.parameters()]
     assert any(not torch.equal(a, b) for a, b in zip(sq_before, sq_after)), \
         "the optimizer state in use is not the loaded one"
+
+
+def test_graph_cache_evicts_the_least_recently_used_entry_and_keys_on_the_learning_rate():
+    from pfrl_amd.agents.graphed_update import _GraphCache, _hyper_signature
+
+    c = _GraphCache(2)
+    c.admit("a", 1), c.admit("b", 2)
+    assert c.lookup("a") == 1            # "a" is now the most recently used
+    c.admit("c", 3)
+    assert c.lookup("b") is None and c.lookup("a") == 1 and c.lookup("c") == 3
+    p = torch.nn.Parameter(torch.zeros(2))
+    opt = torch.optim.RMSprop([p], lr=1e-3)
+    s0 = _hyper_signature([opt])
+    opt.param_groups[0]["capturable"] = True      # what a capture switches on: not part of the key
+    assert _hyper_signature([opt]) == s0
+    opt.param_groups[0]["lr"] = 5e-4              # what a schedule hook changes: a new key
+    assert _hyper_signature([opt]) != s0
