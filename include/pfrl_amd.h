@@ -467,7 +467,8 @@ int pfrl_twin_input_grad(const float *const *dy, const float *const *dy_mask, co
  *   reparameterised sample action = tanh(loc + eps*scale) [B][A] and its
  *   log-probability logp[B] (what `rsample()` + `log_prob()` compute, agents/
  *   soft_actor_critic.py:228-229, 282-283).  loc / scale rows may be strided (ld in
- *   elements); eps [B][A] is the caller's standard-normal draw.
+ *   elements); eps [B][A] is the caller's standard-normal draw; neg_logp (may be NULL)
+ *   receives -logp, the entropy estimate recorded at :299-306.
  * pfrl_squashed_gaussian_bwd: gradients w.r.t. loc and scale ([B][A] each) from
  *   dL/daction (may be NULL) and dL/dlogp (may be NULL).
  * pfrl_soft_update: dst <- (1 - tau) dst + tau src for n tensors in one launch
@@ -477,8 +478,8 @@ int pfrl_twin_input_grad(const float *const *dy, const float *const *dy_mask, co
  *   step counter: read as t - 1, advanced by one inside the launch.  `ticket` is a
  *   zero-initialised device uint32 owned by the optimizer. */
 int pfrl_squashed_gaussian_fwd(const float *loc, int64_t ld_loc, const float *scale, int64_t ld_scale,
-                               const float *eps, float *action, float *logp, int32_t B, int32_t A,
-                               void *stream);
+                               const float *eps, float *action, float *logp, float *neg_logp, int32_t B,
+                               int32_t A, void *stream);
 int pfrl_squashed_gaussian_bwd(const float *g_action, const float *g_logp, const float *action,
                                const float *eps, const float *scale, int64_t ld_scale, float *g_loc,
                                float *g_scale, int32_t B, int32_t A, void *stream);

@@ -134,7 +134,7 @@ EXPORTS = {
     "pfrl_linear_bwd_weight": (ctypes.c_int, "pppppqqiiiip"),
     "pfrl_linear_small_fwd": (ctypes.c_int, "ppppiiip"),
     "pfrl_linear_small_bwd": (ctypes.c_int, "ppppppiiip"),
-    "pfrl_squashed_gaussian_fwd": (ctypes.c_int, "pqpqpppiip"),
+    "pfrl_squashed_gaussian_fwd": (ctypes.c_int, "pqpqppppiip"),
     "pfrl_squashed_gaussian_bwd": (ctypes.c_int, "pppppqppiip"),
     "pfrl_soft_update": (ctypes.c_int, "ipppdp"),
     "pfrl_adam_step": (ctypes.c_int, "ippppppdddddpp"),

@@ -232,13 +232,25 @@ class SoftActorCritic(ReplayActorCritic):
 
     def update_temperature(self, log_prob):
         assert not log_prob.requires_grad
+        from pfrl_amd import distributed
+
         loss = _sac_losses.temperature_loss(self.temperature_holder, log_prob, self.entropy_target)
+        if (isinstance(loss.grad_fn, _sac_losses._TemperatureLoss._backward_cls)
+                and distributed.world_size() == 1 and self.max_grad_norm is None):
+            # d loss / d log T is the loss itself (-mean(exp(log T) c)): hand it to the
+            # optimizer without an autograd pass
+            self.temperature_optimizer.zero_grad()
+            p = self.temperature_holder.log_temperature
+            p.grad = loss.detach().reshape(p.shape)
+            self.temperature_optimizer.step()
+            return
         self._step(loss, self.temperature_holder, self.temperature_optimizer)
 
     def update_policy_and_temperature(self, batch):
         batch_state = batch["state"]
         action_distrib = self.policy(batch_state)
-        actions, log_prob = sample_with_log_prob(action_distrib, True)
+        actions, log_prob, neg_log_prob = sample_with_log_prob(action_distrib, True,
+                                                               with_negation=True)
         # The policy loss needs dQ/da only.  With the Q parameters' requires_grad off while
         # this graph is recorded, backward skips their weight gradients, which the reference
         # computes, accumulates into q_func*.grad and never reads (the next update_q_func
@@ -253,7 +265,8 @@ class SoftActorCritic(ReplayActorCritic):
             try:
                 ent = action_distrib.entropy()
             except NotImplementedError:
-                ent = -log_prob
+                # (the fused sample wrote -log_prob alongside log_prob)
+                ent = neg_log_prob if neg_log_prob is not None else -log_prob
         self._stat(entropy=ent, policy_loss=loss)
 
     def _update_impl(self, batch, variant=None):

@@ -37,7 +37,8 @@ __device__ __forceinline__ float wave_sum(float v) {
 //   log pi   = (0 - sum_a ladj) + sum_a log N
 __global__ __launch_bounds__(kThreads) void k_squashed_gaussian_fwd(
     const float *__restrict__ loc, int64_t ld_loc, const float *__restrict__ scale, int64_t ld_scale,
-    const float *__restrict__ eps, float *__restrict__ action, float *__restrict__ logp, int B, int A) {
+    const float *__restrict__ eps, float *__restrict__ action, float *__restrict__ logp,
+    float *__restrict__ neg_logp, int B, int A) {
     const int row = blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= B) return;
     float s_ladj = 0.f, s_nlp = 0.f;
@@ -55,7 +56,11 @@ __global__ __launch_bounds__(kThreads) void k_squashed_gaussian_fwd(
     }
     s_ladj = wave_sum(s_ladj);
     s_nlp = wave_sum(s_nlp);
-    if (lane == 0) logp[row] = (0.f - s_ladj) + s_nlp;
+    if (lane == 0) {
+        const float lp = (0.f - s_ladj) + s_nlp;
+        logp[row] = lp;
+        if (neg_logp != nullptr) neg_logp[row] = -lp;   // the entropy estimate the agents record
+    }
 }
 
 // Gradients w.r.t. loc and scale given dL/da (g_action, may be null) and dL/dlog pi
@@ -311,11 +316,11 @@ int fill_chunks(Args &a, int n, const int64_t *numel, int lo) {
 
 extern "C" int pfrl_squashed_gaussian_fwd(const float *loc, int64_t ld_loc, const float *scale,
                                           int64_t ld_scale, const float *eps, float *action, float *logp,
-                                          int32_t B, int32_t A, void *stream) {
+                                          float *neg_logp, int32_t B, int32_t A, void *stream) {
     PFRL_CHECK_ARG(B >= 0 && A >= 1 && ld_loc >= A && ld_scale >= A, "pfrl_squashed_gaussian_fwd: bad shape");
     if (B == 0) return 0;
     hipLaunchKernelGGL(k_squashed_gaussian_fwd, dim3((B + 3) / 4), dim3(kThreads), 0, (hipStream_t)stream,
-                       loc, ld_loc, scale, ld_scale, eps, action, logp, B, A);
+                       loc, ld_loc, scale, ld_scale, eps, action, logp, neg_logp, B, A);
     PFRL_LAUNCH_CHECK();
 }
 

@@ -59,15 +59,17 @@ class _SquashedGaussian(torch.autograd.Function):
     def forward(ctx, loc, scale, eps):
         B, A = loc.shape
         action = torch.empty((B, A), dtype=torch.float32, device=loc.device)
-        logp = torch.empty((B,), dtype=torch.float32, device=loc.device)
+        both = torch.empty((2, B), dtype=torch.float32, device=loc.device)
+        logp, neg = both[0], both[1]
         check(_native.lib().pfrl_squashed_gaussian_fwd(_p(loc), loc.stride(0), _p(scale), scale.stride(0),
-                                                       _p(eps), _p(action), _p(logp), B, A, _stream()),
-              "squashed_gaussian_fwd")
+                                                       _p(eps), _p(action), _p(logp), _p(neg), B, A,
+                                                       _stream()), "squashed_gaussian_fwd")
         ctx.save_for_backward(action, eps, scale)
-        return action, logp
+        ctx.mark_non_differentiable(neg)
+        return action, logp, neg
 
     @staticmethod
-    def backward(ctx, g_action, g_logp):
+    def backward(ctx, g_action, g_logp, _g_neg):
         action, eps, scale = ctx.saved_tensors
         B, A = action.shape
         g_loc = torch.empty_like(action)
@@ -80,16 +82,20 @@ class _SquashedGaussian(torch.autograd.Function):
         return g_loc, g_scale, None
 
 
-def sample_with_log_prob(distrib, reparameterize):
+def sample_with_log_prob(distrib, reparameterize, with_negation=False):
     """``(a, distrib.log_prob(a))`` with ``a = distrib.rsample()`` (``reparameterize``) or
-    ``distrib.sample()``."""
+    ``distrib.sample()``; with ``with_negation`` a third element: ``-log_prob`` detached when the
+    fused launch produced it (else None)."""
     params = squashed_gaussian_params(distrib)
     if params is None:
         a = distrib.rsample() if reparameterize else distrib.sample()
-        return a, distrib.log_prob(a)
+        lp = distrib.log_prob(a)
+        return (a, lp, None) if with_negation else (a, lp)
     loc, scale = params
     eps = _standard_normal(loc.shape, dtype=loc.dtype, device=loc.device)
     if reparameterize:
-        return _SquashedGaussian.apply(loc, scale, eps)
-    with torch.no_grad():
-        return _SquashedGaussian.apply(loc, scale, eps)
+        a, lp, neg = _SquashedGaussian.apply(loc, scale, eps)
+    else:
+        with torch.no_grad():
+            a, lp, neg = _SquashedGaussian.apply(loc, scale, eps)
+    return (a, lp, neg) if with_negation else (a, lp)
