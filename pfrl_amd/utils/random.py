@@ -28,20 +28,57 @@ def sample_n_k(n, k):
     # checking (the dominant cost for k = 32).
     draws = np.random.randint(0, n, size=2 * k)
     head = draws[:k]
-    # no duplicate among the first k (the usual case: k^2 / 2n ~ 5e-4 for 32 of 10^6): the
-    # repair walk below would change nothing and consume nothing more
+    # Positions whose value already occurs earlier among the first k (stable sort: equal values
+    # keep their index order, so the earliest occurrence of a value owns it).  Usually none
+    # (k^2 / 2n ~ 5e-4 for 32 of 10^6): the repair walk would change and consume nothing.
     srt = np.sort(head)
     if not (srt[1:] == srt[:-1]).any():
         return head
-    seen = set()
+    order = np.argsort(head, kind="stable")
+    srt = head[order]
+    same = srt[1:] == srt[:-1]
+    # The reference walks i = 0 .. k-1 with a set of the values kept so far and replaces a
+    # value found in the set by the next spare (draws[k:], refilled when used up).  Only the
+    # duplicate positions ever change, so only those are visited here, in index order; a spare
+    # is rejected exactly when an EARLIER position holds its value at that moment, and a
+    # spare equal to the value of a LATER position takes it over (that position is then a
+    # duplicate in turn, as it would be found when the walk reaches it).
+    import bisect
+
+    pending = sorted(order[1:][same].tolist())
+    owner = {}                 # values whose owning position changed: value -> position
     spare = k
-    for i in range(k):
-        x = draws[i]
-        while x in seen:
-            x = draws[i] = draws[spare]
+    while pending:
+        d = pending.pop(0)
+        while True:
+            x = draws[spare]
             spare += 1
             if spare == 2 * k:
+                # (the refill draws happen at the same point of the stream as in the walk)
                 draws[k:] = np.random.randint(0, n, size=k)
                 spare = k
-        seen.add(x)
-    return draws[:k]
+            xi = int(x)
+            pos = owner.get(xi)
+            if pos is None:
+                j = np.searchsorted(srt, x)
+                if j < k and srt[j] == x:
+                    cand = int(order[j])           # earliest original holder of x ...
+                    # ... unless that position was itself a duplicate already replaced
+                    pos = cand if head[cand] == x else None
+                    if pos is None:
+                        # look for a later original holder that still has x
+                        jj = j + 1
+                        while jj < k and srt[jj] == x:
+                            c2 = int(order[jj])
+                            if head[c2] == x:
+                                pos = c2
+                                break
+                            jj += 1
+            if pos is not None and pos < d:
+                continue                            # in the set of kept values: next spare
+            head[d] = x
+            owner[xi] = d
+            if pos is not None:                     # pos > d: that position is now a duplicate
+                bisect.insort(pending, pos)
+            break
+    return head
