@@ -163,6 +163,9 @@ class ReplayActorCritic(AttributeSavingMixin, BatchAgent):
 
     # -- step-fused path (uniform device replay) ---------------------------------------------
     step_fused = True
+    # fractions of the env batch at which the fused step is cut into ranges (see
+    # _batch_observe_fused); () = one range
+    step_fused_chunks = (0.125,)
 
     def _step_fusable(self):
         """All updates of one batched env step from ONE gather launch and ONE captured
@@ -191,15 +194,25 @@ class ReplayActorCritic(AttributeSavingMixin, BatchAgent):
         reorganised for the device: appends and index draws in the reference's order, one
         fused gather of every minibatch of the step (U * B entries: HBM-bound instead of U
         small launches), then the U updates replayed as one graph."""
+        # A small env range first, the rest second: while the GPU runs the first range's
+        # updates the host prepares the second (appends, index draws, gather and graph launch)
+        # instead of the GPU idling through the whole preparation.  Appends, draws and updates
+        # keep the reference's order.
+        n_env = len(batch_obs)
+        cuts = sorted({0, n_env} | {int(n_env * f) for f in self.step_fused_chunks})
+        for lo, hi in zip(cuts[:-1], cuts[1:]):
+            self._observe_range_fused(lo, hi, batch_obs, batch_reward, batch_done, batch_reset)
+
+    def _observe_range_fused(self, lo, hi, batch_obs, batch_reward, batch_done, batch_reset):
         rbuf, up = self.replay_buffer, self.replay_updater
         t0 = self.t
         plan = []
-        for i in range(len(batch_obs)):
+        for i in range(lo, hi):
             self._append(i, batch_obs, batch_reward, batch_done, batch_reset)
-            if len(rbuf) >= up.replay_start_size and (t0 + i + 1) % up.update_interval == 0:
+            if len(rbuf) >= up.replay_start_size and (t0 + (i - lo) + 1) % up.update_interval == 0:
                 for _ in range(up.n_times_update):
                     plan.append(rbuf.lookahead_sample(up.batchsize))
-        self.t = t0 + len(batch_obs)
+        self.t = t0 + (hi - lo)
         if not plan:
             return
         big = rbuf.fetch_many(plan, self.phi, self.gamma)
