@@ -416,9 +416,64 @@ class DQN(agent.AttributeSavingMixin, agent.BatchAgent):
             return cls._compute_target_values is DoubleDQN._compute_target_values
         return cls._compute_target_values is DQN._compute_target_values
 
-    def _compute_loss_fused(self, exp_batch, errors_out, record):
-        from pfrl_amd import ops
+    def _head_split(self):
+        """(body modules, head layer) when the model is ``nn.Sequential(..., Linear(K, A),
+        DiscreteActionValueHead())`` with the narrow head on the GPU kernels (the example
+        Q-functions): the head then runs inside the loss launch.  None otherwise, and under data
+        parallelism (the gradient hooks of the early all-reduce hang on autograd's accumulation)."""
+        cached = self.__dict__.get("_head_split_cache")
+        if cached is not None and cached[0] is self.model:
+            return cached[1]
+        from pfrl_amd.nn.mfma_trunk import _SmallLinearSlot
+        from pfrl_amd.q_functions import DiscreteActionValueHead
 
+        out = None
+        m = self.model
+        if isinstance(m, torch.nn.Sequential) and len(m) >= 3:
+            mods = list(m._modules.values())
+            if (type(mods[-1]) is DiscreteActionValueHead and isinstance(mods[-2], _SmallLinearSlot)
+                    and mods[-2].bias is not None
+                    and os.environ.get("PFRL_FUSE_HEAD_LOSS", "1") != "0"):
+                out = (mods[:-2], mods[-2])
+        self._head_split_cache = (m, out)
+        return out
+
+    def _compute_loss_fused(self, exp_batch, errors_out, record):
+        from pfrl_amd import distributed, ops
+
+        split = self._head_split() if distributed.world_size() == 1 else None
+        if split is not None:
+            h = exp_batch["state"]
+            for mod in split[0]:
+                h = mod(h)
+            head = split[1]
+            if not (torch.is_tensor(h) and ops.dqn_head_td_loss_supported(h, head.weight, head.bias)):
+                split = None
+        if split is not None:
+            with torch.no_grad():
+                target_q = self._target_next_action_value(exp_batch).q_values
+                next_online = None
+                if type(self)._fused_td_double:
+                    with evaluating(self.model):
+                        next_online = self.model(exp_batch["next_state"]).q_values
+            loss, y, delta = ops.dqn_head_td_loss(
+                h, head.weight, head.bias, exp_batch["action"], target_q, next_online,
+                exp_batch["reward"], exp_batch["discount"], exp_batch["is_state_terminal"],
+                exp_batch.get("weights"), self.clip_delta, self.batch_accumulator == "mean")
+            # the gradients came out of the same launch: backward may start at h, and the
+            # head's own gradients are handed over as they are
+            if loss.grad_fn is not None:
+                dh, dw, db = loss.grad_fn.saved_tensors
+                self._analytic_backward = (h, dh, [(head.weight, dw), (head.bias, db)])
+            else:
+                self._analytic_backward = None
+            self._last_y = y
+            if record:
+                self.q_record.extend(y)
+            if errors_out is not None:
+                del errors_out[:]
+                errors_out.extend(delta.cpu().numpy())
+            return loss, delta
         qout = self.model(exp_batch["state"])
         with torch.no_grad():
             target_q = self._target_next_action_value(exp_batch).q_values

@@ -136,8 +136,13 @@ class GraphedUpdate:
     def _backward(self, loss):
         ab = getattr(self.agent, "_analytic_backward", None)
         if ab is not None and ab[1] is not None:
-            # fused TD loss: the gradient w.r.t. Q(s) came out of the same launch
-            torch.autograd.backward([ab[0]], [ab[1]])
+            # fused TD loss: the gradient w.r.t. Q(s) (or w.r.t. the head's input, with the
+            # head's own gradients beside it) came out of the same launch
+            if ab[0].requires_grad:
+                torch.autograd.backward([ab[0]], [ab[1]])
+            for p, g in (ab[2] if len(ab) > 2 else ()):
+                if p.requires_grad:
+                    p.grad = g if p.grad is None else p.grad + g
         else:
             loss.backward()
 

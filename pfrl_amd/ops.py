@@ -289,6 +289,57 @@ def dqn_td_loss(q, action, target_q, next_q_online, reward, discount, terminal, 
                             weights, clip_delta, mean)
 
 
+class _DQNHeadTDLoss(torch.autograd.Function):
+    """The narrow head ``q = h W^T + b``, the TD loss of ``_DQNTDLoss`` and the head's backward
+    in one launch (pfrl_dqn_head_td_loss): saves d loss / d(h, W, b) for backward."""
+
+    @staticmethod
+    def forward(ctx, h, w, b, action, target_q, next_q_online, reward, discount, terminal, weights,
+                clip_delta, mean):
+        B, K = h.shape
+        A = w.shape[0]
+        hc = h.detach().contiguous()
+        dev = h.device
+        loss = torch.empty(1, dtype=torch.float32, device=dev)
+        y = torch.empty(B, dtype=torch.float32, device=dev)
+        delta = torch.empty(B, dtype=torch.float32, device=dev)
+        dh = torch.empty((B, K), dtype=torch.float32, device=dev)
+        dw = torch.empty((A, K), dtype=torch.float32, device=dev)
+        db = torch.empty((A,), dtype=torch.float32, device=dev)
+        check(_native.lib().pfrl_dqn_head_td_loss(
+            _ptr(hc), _ptr(w.detach()), _ptr(b.detach()), _ptr(action.contiguous()),
+            _ptr(target_q.contiguous()),
+            _ptr(next_q_online.contiguous()) if next_q_online is not None else None,
+            _ptr(reward), _ptr(discount), _ptr(terminal),
+            _ptr(weights.contiguous()) if weights is not None else None, B, K, A, int(clip_delta),
+            int(mean), _ptr(loss), _ptr(y), _ptr(delta), _ptr(dh), _ptr(dw), _ptr(db), _stream()),
+            "dqn_head_td_loss")
+        ctx.save_for_backward(dh, dw, db)
+        ctx.mark_non_differentiable(y, delta)
+        ctx.set_materialize_grads(False)
+        return loss.view(()), y, delta
+
+    @staticmethod
+    def backward(ctx, g_loss, g_y, g_delta):
+        dh, dw, db = ctx.saved_tensors
+        return (dh * g_loss, dw * g_loss, db * g_loss) + (None,) * 9
+
+
+def dqn_head_td_loss_supported(h, w, b):
+    return (h.is_cuda and h.dim() == 2 and h.dtype == torch.float32 and w.dtype == torch.float32
+            and b is not None and w.is_contiguous() and 1 <= w.shape[0] <= 16
+            and h.shape[1] % 64 == 0 and 64 <= h.shape[1] <= 512 and 1 <= h.shape[0] <= 1024
+            and (w.shape[0] * h.shape[1] + 4 * h.shape[1] + 32 * w.shape[0] + 2 * h.shape[0] + 32) * 4
+            <= 64 * 1024 and _native.available())
+
+
+def dqn_head_td_loss(h, w, b, action, target_q, next_q_online, reward, discount, terminal, weights,
+                     clip_delta, mean):
+    """-> (loss scalar with grad w.r.t. h, w, b; y [B]; |y - t| [B])"""
+    return _DQNHeadTDLoss.apply(h, w, b, action, target_q, next_q_online, reward, discount, terminal,
+                                weights, clip_delta, mean)
+
+
 _bias_relu_ws = {}
 
 

@@ -337,3 +337,41 @@ def test_graph_cache_evicts_the_least_recently_used_entry_and_keys_on_the_learni
     assert _hyper_signature([opt]) == s0
     opt.param_groups[0]["lr"] = 5e-4              # what a schedule hook changes: a new key
     assert _hyper_signature([opt]) != s0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,K,A,clip,mean,weighted,double", [
+    (32, 512, 6, True, False, False, False), (32, 512, 6, True, True, True, True),
+    (48, 512, 16, False, True, False, False), (1, 64, 1, True, False, False, False),
+    (100, 256, 4, True, True, True, False), (33, 512, 18 - 2, False, False, True, True),
+])
+def test_head_td_loss_in_one_launch_matches_the_three_launches(B, K, A, clip, mean, weighted, double):
+    """pfrl_dqn_head_td_loss against: F.linear head -> the fused TD loss (itself pinned against the
+    reference's compute_value_loss in test_hip_kernels) -> autograd.  Loss, y, |delta| and the
+    three gradients at 1e-5 relative (same products, different summation order in the head)."""
+    from pfrl_amd import ops
+
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(B * 7 + A)
+    h = torch.randn(B, K, generator=g).to(dev).requires_grad_(True)
+    w = (torch.randn(A, K, generator=g) / np.sqrt(K)).to(dev).requires_grad_(True)
+    b = (torch.randn(A, generator=g) * 0.1).to(dev).requires_grad_(True)
+    action = torch.randint(0, A, (B,), generator=g).to(dev)
+    tq = torch.randn(B, A, generator=g).to(dev)
+    nq = torch.randn(B, A, generator=g).to(dev) if double else None
+    r = torch.randn(B, generator=g).to(dev)
+    disc = torch.full((B,), 0.99).to(dev)
+    term = (torch.rand(B, generator=g) < 0.2).float().to(dev)
+    wts = torch.rand(B, generator=g).to(dev) if weighted else None
+    assert ops.dqn_head_td_loss_supported(h, w, b)
+    loss, y, delta = ops.dqn_head_td_loss(h, w, b, action, tq, nq, r, disc, term, wts, clip, mean)
+    got = torch.autograd.grad(loss, [h, w, b])
+    h2, w2, b2 = (t.detach().clone().requires_grad_(True) for t in (h, w, b))
+    q = torch.nn.functional.linear(h2, w2, b2)
+    loss_r, y_r, delta_r = ops.dqn_td_loss(q, action, tq, nq, r, disc, term, wts, clip, mean)
+    want = torch.autograd.grad(loss_r, [h2, w2, b2])
+    tol = lambda ref: 1e-5 * max(ref.abs().max().item(), 1.0)
+    assert abs(loss.item() - loss_r.item()) < 1e-5 * max(abs(loss_r.item()), 1.0)
+    assert (y - y_r).abs().max().item() < tol(y_r) and (delta - delta_r).abs().max().item() < tol(delta_r)
+    for a, ref in zip(got, want):
+        assert (a - ref).abs().max().item() < tol(ref)
