@@ -69,6 +69,7 @@ class PrioritizedBuffer:
                                     device=dev)
         self._stage = StagingRing(dev, slot_bytes=1 << 16, n_slots=64)
         self._pend_x, self._pend_v, self._pend_t, self._pend_m = [], [], [], []
+        self._pend_at = {}      # leaf coordinate -> position in the pending lists
         self._sampled_x = None  # device int64 tensor of the last sample
         self._sample_out = {}
         # optional replay stream: all tree launches go there and the sample outputs
@@ -98,6 +99,14 @@ class PrioritizedBuffer:
 
     # -- pending leaf writes ------------------------------------------------
     def _record(self, x, val, tag, use_maxp):
+        # One launch applies all pending leaf writes concurrently: two writes to the same leaf
+        # (an element appended and popped again before the next flush -- tiny capacities only)
+        # would race, store by store.  Sequentially the later one wins: keep only that one.
+        at = self._pend_at.get(x)
+        if at is not None:
+            self._pend_v[at], self._pend_t[at], self._pend_m[at] = val, tag, use_maxp
+            return
+        self._pend_at[x] = len(self._pend_x)
         self._pend_x.append(x)
         self._pend_v.append(val)
         self._pend_t.append(tag)
@@ -120,6 +129,7 @@ class PrioritizedBuffer:
                 ])
                 ops.tree_write(desc, x, v, t, m)
         self._pend_x, self._pend_v, self._pend_t, self._pend_m = [], [], [], []
+        self._pend_at = {}
 
     # -- reference API ------------------------------------------------------
     def append(self, value, priority=None):

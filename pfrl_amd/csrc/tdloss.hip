@@ -124,7 +124,28 @@ __global__ __launch_bounds__(kThreads) void k_dqn_head_td_loss(
     float *lsum = reinterpret_cast<float *>(acts + B);   // [HT_ROWS]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int KJ = K >> 6;
-    for (int e = tid; e < A * K; e += kThreads) Ws[e] = W[e];
+    float hv[8][HT_KJ];
+    // this wave's 8 rows of a 32-row pass; every load is issued before anything waits
+    auto load_rows = [&](int m0) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int m = m0 + wave * 8 + r;
+            const int mm = m < B ? m : B - 1;
+#pragma unroll
+            for (int j = 0; j < HT_KJ; ++j)
+                hv[r][j] = (j < KJ) ? h[(size_t)mm * K + lane + 64 * j] : 0.f;
+        }
+    };
+    load_rows(0);
+    // W into LDS, eight loads in flight per thread
+    for (int e0 = tid; e0 < A * K; e0 += kThreads * 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = W[min(e0 + kThreads * u, A * K - 1)];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (e0 + kThreads * u < A * K) Ws[e0 + kThreads * u] = v[u];
+    }
     if (tid < HT_ROWS) lsum[tid] = 0.f;
     __syncthreads();
     const float scale = mean ? 1.0f / (float)B : 1.0f;
@@ -135,16 +156,19 @@ __global__ __launch_bounds__(kThreads) void k_dqn_head_td_loss(
         for (int j = 0; j < HT_KJ; ++j) dWacc[a][j] = 0.f;
 
     for (int m0 = 0; m0 < B; m0 += HT_ROWS) {
-        // this wave's 8 rows of the pass, all loads first
-        float hv[8][HT_KJ];
+        if (m0 > 0) load_rows(m0);
+        // the row's loss inputs, in flight while the head is computed
+        const bool rowt = tid < HT_ROWS && m0 + tid < B;
+        const int brow = rowt ? m0 + tid : 0;
+        float tqv[A], nqv[A];
 #pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            const int m = m0 + wave * 8 + r;
-            const int mm = m < B ? m : B - 1;
-#pragma unroll
-            for (int j = 0; j < HT_KJ; ++j)
-                hv[r][j] = (j < KJ) ? h[(size_t)mm * K + lane + 64 * j] : 0.f;
+        for (int a = 0; a < A; ++a) {
+            tqv[a] = target_q[(size_t)brow * A + a];
+            nqv[a] = next_q_online ? next_q_online[(size_t)brow * A + a] : tqv[a];
         }
+        const int act_in = (int)action[brow];
+        const float rew_in = reward[brow], disc_in = discount[brow], term_in = terminal[brow];
+        const float wt_in = weights ? weights[brow] : 1.0f;
         // q = h W^T + b
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
@@ -160,25 +184,24 @@ __global__ __launch_bounds__(kThreads) void k_dqn_head_td_loss(
         }
         __syncthreads();
         // TD loss of the pass's rows (one thread per row), as k_dqn_td_loss
-        if (tid < HT_ROWS && m0 + tid < B) {
-            const int b = m0 + tid;
-            const float *qt = target_q + (size_t)b * A;
-            const float *sel = next_q_online ? next_q_online + (size_t)b * A : qt;
+        if (rowt) {
+            const int b = brow;
             int best = 0;
-            float bestv = sel[0];
+            float bestv = nqv[0];
 #pragma unroll
             for (int a = 1; a < A; ++a) {
-                const float v = sel[a];
-                if (v > bestv) {
-                    bestv = v;
+                if (nqv[a] > bestv) {
+                    bestv = nqv[a];
                     best = a;
                 }
             }
-            const float next = qt[best];
-            const int act = (int)action[b];
+            float next = tqv[0];
+#pragma unroll
+            for (int a = 1; a < A; ++a) next = (a == best) ? tqv[a] : next;
+            const int act = act_in;
             const float y = qs[tid * A + act];
-            const float coef = __fmul_rn(discount[b], __fsub_rn(1.0f, terminal[b]));
-            const float t = __fadd_rn(reward[b], __fmul_rn(coef, next));
+            const float coef = __fmul_rn(disc_in, __fsub_rn(1.0f, term_in));
+            const float t = __fadd_rn(rew_in, __fmul_rn(coef, next));
             const float d = __fsub_rn(y, t);
             const float ad = fabsf(d);
             float l, g;
@@ -189,7 +212,7 @@ __global__ __launch_bounds__(kThreads) void k_dqn_head_td_loss(
                 l = __fmul_rn(0.5f, __fmul_rn(d, d));
                 g = d;
             }
-            const float w = weights ? weights[b] : 1.0f;
+            const float w = wt_in;
             lsum[tid] += l * w;
             gs[b] = g * w * scale;
             acts[b] = act;

@@ -585,6 +585,29 @@ def test_fused_td_loss_matches_torch(dev, double, clip_delta, accum, weighted):
     np.testing.assert_array_equal(delta.cpu().numpy(), (yy - t).abs().detach().cpu().numpy())
 
 
+def test_element_appended_and_popped_before_a_flush(dev):
+    """Found by the property test below (only in a process whose allocator hands out used
+    blocks): append, popleft of the same element, more appends -- the two pending writes of one
+    leaf raced inside one launch and could leave (0.0, present) in the min tree."""
+    from pfrl_amd.collections.prioritized import PrioritizedBuffer
+
+    for cap in (3, 1, 2):
+        buf = PrioritizedBuffer(cap, device=dev)
+        orc = oracle.OraclePrioritizedBuffer(cap)
+        buf.append(0), orc.append(0)
+        buf.popleft(), orc.popleft()
+        for k in range(1, 8):
+            buf.append(k), orc.append(k)
+        st_, so = buf.root_stats(), orc.stats()
+        assert st_[0] == so["sum"] and st_[1] == so["min"] and st_[2] == so["max_priority"]
+        gv, gt = buf.dump_level(0, 0)
+        ov, ot = orc.dump_level(0, 1)
+        np.testing.assert_array_equal(gt, ot)
+        np.testing.assert_array_equal(gv, ov)
+        mv, mt = buf.dump_level(1, 0)
+        np.testing.assert_array_equal(mv[mt != 0], gv[gt != 0])
+
+
 # ---------------------------------------------------------------------------
 # property-based differential test of the device trees vs the oracle
 # ---------------------------------------------------------------------------
