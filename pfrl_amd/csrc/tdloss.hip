@@ -137,6 +137,11 @@ __global__ __launch_bounds__(kThreads) void k_dqn_head_td_loss(
         }
     };
     load_rows(0);
+    // (inside the lane-0 branches below a global load would be waited for on the spot, 48
+    // times over: the bias lives in registers)
+    float bv[A];
+#pragma unroll
+    for (int a = 0; a < A; ++a) bv[a] = bias[a];
     // W into LDS, eight loads in flight per thread
     for (int e0 = tid; e0 < A * K; e0 += kThreads * 8) {
         float v[8];
@@ -179,7 +184,7 @@ __global__ __launch_bounds__(kThreads) void k_dqn_head_td_loss(
                 for (int j = 0; j < HT_KJ; ++j)
                     if (j < KJ) p = fmaf(hv[r][j], Ws[a * K + lane + 64 * j], p);
                 p = wave_sum_f(p);
-                if (lane == 0) qs[(wave * 8 + r) * A + a] = p + bias[a];
+                if (lane == 0) qs[(wave * 8 + r) * A + a] = p + bv[a];
             }
         }
         __syncthreads();
