@@ -106,6 +106,31 @@ namespace {
 constexpr int HT_KJ = 8;     // K <= 512
 constexpr int HT_ROWS = 32;  // rows per pass
 
+// 64 per-lane partial sums v[0..63] -> lane i returns sum over all lanes of v[i].  Halving
+// butterfly: at offset o a lane keeps the half of its values selected by its bit o and adds
+// the partner's copy of that half: 63 shuffles in all, against 6 per value (384) for one
+// xor-reduction each -- those, serialised behind one another, were 14 us of this kernel.
+template <int N>
+__device__ __forceinline__ void halve_step(float (&v)[64], int lane, int o) {
+    const bool up = (lane & o) != 0;
+#pragma unroll
+    for (int i = 0; i < N / 2; ++i) {
+        const float send = up ? v[i] : v[i + N / 2];
+        const float keep = up ? v[i + N / 2] : v[i];
+        v[i] = keep + __shfl_xor(send, o, 64);
+    }
+}
+
+__device__ __forceinline__ float wave_transpose_reduce64(float (&v)[64], int lane) {
+    halve_step<64>(v, lane, 32);
+    halve_step<32>(v, lane, 16);
+    halve_step<16>(v, lane, 8);
+    halve_step<8>(v, lane, 4);
+    halve_step<4>(v, lane, 2);
+    halve_step<2>(v, lane, 1);
+    return v[0];
+}
+
 template <int A>
 __global__ __launch_bounds__(kThreads) void k_dqn_head_td_loss(
     const float *__restrict__ h, const float *__restrict__ W, const float *__restrict__ bias,
@@ -174,18 +199,27 @@ __global__ __launch_bounds__(kThreads) void k_dqn_head_td_loss(
         const int act_in = (int)action[brow];
         const float rew_in = reward[brow], disc_in = discount[brow], term_in = terminal[brow];
         const float wt_in = weights ? weights[brow] : 1.0f;
-        // q = h W^T + b
+        // q = h W^T (+ b where it is read): every lane's partial dot products of the wave's
+        // 8 rows x A actions, then one transpose-reduction; lane i ends with element i
+        static_assert(8 * A <= 128, "two reductions of 64 cover 8 rows x 16 actions");
 #pragma unroll
-        for (int r = 0; r < 8; ++r) {
+        for (int part = 0; part < (8 * A + 63) / 64; ++part) {
+            float pv[64];
 #pragma unroll
-            for (int a = 0; a < A; ++a) {
+            for (int e = 0; e < 64; ++e) {
+                const int idx = part * 64 + e;           // = r * A + a
+                const int r = idx / A, a = idx - r * A;
                 float p = 0.f;
+                if (idx < 8 * A) {
 #pragma unroll
-                for (int j = 0; j < HT_KJ; ++j)
-                    if (j < KJ) p = fmaf(hv[r][j], Ws[a * K + lane + 64 * j], p);
-                p = wave_sum_f(p);
-                if (lane == 0) qs[(wave * 8 + r) * A + a] = p + bv[a];
+                    for (int j = 0; j < HT_KJ; ++j)
+                        if (j < KJ) p = fmaf(hv[r][j], Ws[a * K + lane + 64 * j], p);
+                }
+                pv[e] = p;
             }
+            const float tot = wave_transpose_reduce64(pv, lane);
+            const int idx = part * 64 + lane;
+            if (idx < 8 * A) qs[wave * 8 * A + idx] = tot;
         }
         __syncthreads();
         // TD loss of the pass's rows (one thread per row), as k_dqn_td_loss
@@ -204,7 +238,10 @@ __global__ __launch_bounds__(kThreads) void k_dqn_head_td_loss(
 #pragma unroll
             for (int a = 1; a < A; ++a) next = (a == best) ? tqv[a] : next;
             const int act = act_in;
-            const float y = qs[tid * A + act];
+            float bact = bv[0];
+#pragma unroll
+            for (int a = 1; a < A; ++a) bact = (a == act) ? bv[a] : bact;
+            const float y = qs[tid * A + act] + bact;
             const float coef = __fmul_rn(disc_in, __fsub_rn(1.0f, term_in));
             const float t = __fadd_rn(rew_in, __fmul_rn(coef, next));
             const float d = __fsub_rn(y, t);
