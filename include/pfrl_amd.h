@@ -285,7 +285,7 @@ int pfrl_dqn_td_loss(const float *q, const int64_t *action, const float *target_
 /* The narrow head Linear(K, A) (examples/atari/train_dqn_batch_ale.py:35-41), the TD loss above
  * and the head's backward in ONE launch: h [B][K] is the head's input, w [A][K], bias [A];
  * outputs as pfrl_dqn_td_loss plus dh [B][K], dw [A][K], db [A] (gradients of the loss, its
- * `mean` scaling included).  A <= 16, K a multiple of 64 up to 512. */
+ * `mean` scaling included).  A <= 16, K = 256 or 512. */
 int pfrl_dqn_head_td_loss(const float *h, const float *w, const float *bias, const int64_t *action,
                           const float *target_q, const float *next_q_online, const float *reward,
                           const float *discount, const float *terminal, const float *weights,

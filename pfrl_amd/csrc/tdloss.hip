@@ -103,7 +103,6 @@ extern "C" int pfrl_dqn_td_loss(const float *q, const int64_t *action, const flo
 // ===================================================================================
 namespace {
 
-constexpr int HT_KJ = 8;     // K <= 512
 constexpr int HT_ROWS = 32;  // rows per pass
 
 // 64 per-lane partial sums v[0..63] -> lane i returns sum over all lanes of v[i].  Halving
@@ -131,7 +130,10 @@ __device__ __forceinline__ float wave_transpose_reduce64(float (&v)[64], int lan
     return v[0];
 }
 
-template <int A>
+// HT_KJ = K / 64 is a template parameter: with a run-time bound every `if (j < KJ)` around a
+// load is a branch, and behind a branch the load is waited for on the spot (64 row loads one
+// after the other were 20 us of this kernel).
+template <int A, int HT_KJ>
 __global__ __launch_bounds__(kThreads) void k_dqn_head_td_loss(
     const float *__restrict__ h, const float *__restrict__ W, const float *__restrict__ bias,
     const int64_t *__restrict__ action, const float *__restrict__ target_q,
@@ -148,7 +150,6 @@ __global__ __launch_bounds__(kThreads) void k_dqn_head_td_loss(
     int *acts = reinterpret_cast<int *>(gs + B);   // [B]
     float *lsum = reinterpret_cast<float *>(acts + B);   // [HT_ROWS]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int KJ = K >> 6;
     float hv[8][HT_KJ];
     // this wave's 8 rows of a 32-row pass; every load is issued before anything waits
     auto load_rows = [&](int m0) {
@@ -158,7 +159,7 @@ __global__ __launch_bounds__(kThreads) void k_dqn_head_td_loss(
             const int mm = m < B ? m : B - 1;
 #pragma unroll
             for (int j = 0; j < HT_KJ; ++j)
-                hv[r][j] = (j < KJ) ? h[(size_t)mm * K + lane + 64 * j] : 0.f;
+                hv[r][j] = h[(size_t)mm * K + lane + 64 * j];
         }
     };
     load_rows(0);
@@ -212,8 +213,7 @@ __global__ __launch_bounds__(kThreads) void k_dqn_head_td_loss(
                 float p = 0.f;
                 if (idx < 8 * A) {
 #pragma unroll
-                    for (int j = 0; j < HT_KJ; ++j)
-                        if (j < KJ) p = fmaf(hv[r][j], Ws[a * K + lane + 64 * j], p);
+                    for (int j = 0; j < HT_KJ; ++j) p = fmaf(hv[r][j], Ws[a * K + lane + 64 * j], p);
                 }
                 pv[e] = p;
             }
@@ -271,7 +271,7 @@ __global__ __launch_bounds__(kThreads) void k_dqn_head_td_loss(
             const int am = acts[m];
 #pragma unroll
             for (int j = 0; j < HT_KJ; ++j)
-                if (j < KJ) dh[(size_t)m * K + lane + 64 * j] = g * Ws[am * K + lane + 64 * j];
+                dh[(size_t)m * K + lane + 64 * j] = g * Ws[am * K + lane + 64 * j];
 #pragma unroll
             for (int a = 0; a < A; ++a) {
                 const float ga = (a == am) ? g : 0.f;
@@ -297,8 +297,7 @@ __global__ __launch_bounds__(kThreads) void k_dqn_head_td_loss(
 #pragma unroll
     for (int a = 0; a < A; ++a) {
 #pragma unroll
-        for (int j = 0; j < HT_KJ; ++j)
-            if (j < KJ) red[wave * K + lane + 64 * j] = dWacc[a][j];
+        for (int j = 0; j < HT_KJ; ++j) red[wave * K + lane + 64 * j] = dWacc[a][j];
         __syncthreads();
         for (int k = tid; k < K; k += kThreads)
             dW[(size_t)a * K + k] = (red[k] + red[K + k]) + (red[2 * K + k] + red[3 * K + k]);
@@ -315,14 +314,23 @@ extern "C" int pfrl_dqn_head_td_loss(const float *h, const float *w, const float
                                      int32_t B, int32_t K, int32_t A, int clip_delta, int mean,
                                      float *out_loss, float *out_y, float *out_abs_delta, float *dh,
                                      float *dw, float *db, void *stream) {
-    PFRL_CHECK_ARG(B >= 1 && B <= 1024 && A >= 1 && A <= 16 && K >= 64 && K <= 64 * HT_KJ && K % 64 == 0,
-                   "pfrl_dqn_head_td_loss: B <= 1024, A <= 16, K a multiple of 64 up to 512");
+    PFRL_CHECK_ARG(B >= 1 && B <= 1024 && A >= 1 && A <= 16 && (K == 512 || K == 256),
+                   "pfrl_dqn_head_td_loss: B <= 1024, A <= 16, K = 256 or 512");
     const size_t lds = ((size_t)A * K + 4 * K + HT_ROWS * A + 2 * (size_t)B + HT_ROWS) * sizeof(float);
     PFRL_CHECK_ARG(lds <= 64 * 1024, "pfrl_dqn_head_td_loss: LDS budget");
-#define CALL_HT(AA)                                                                               \
-    hipLaunchKernelGGL(k_dqn_head_td_loss<AA>, dim3(1), dim3(kThreads), lds, (hipStream_t)stream, h, w, \
-                       bias, action, target_q, next_q_online, reward, discount, terminal, weights, B, K,  \
-                       clip_delta, mean, out_loss, out_y, out_abs_delta, dh, dw, db)
+#define CALL_HT(AA)                                                                                \
+    do {                                                                                           \
+        if (K == 512)                                                                              \
+            hipLaunchKernelGGL((k_dqn_head_td_loss<AA, 8>), dim3(1), dim3(kThreads), lds,          \
+                               (hipStream_t)stream, h, w, bias, action, target_q, next_q_online,   \
+                               reward, discount, terminal, weights, B, K, clip_delta, mean,        \
+                               out_loss, out_y, out_abs_delta, dh, dw, db);                        \
+        else                                                                                       \
+            hipLaunchKernelGGL((k_dqn_head_td_loss<AA, 4>), dim3(1), dim3(kThreads), lds,          \
+                               (hipStream_t)stream, h, w, bias, action, target_q, next_q_online,   \
+                               reward, discount, terminal, weights, B, K, clip_delta, mean,        \
+                               out_loss, out_y, out_abs_delta, dh, dw, db);                        \
+    } while (0)
     switch (A) {
         case 1: CALL_HT(1); break;   case 2: CALL_HT(2); break;   case 3: CALL_HT(3); break;
         case 4: CALL_HT(4); break;   case 5: CALL_HT(5); break;   case 6: CALL_HT(6); break;

@@ -328,7 +328,7 @@ class _DQNHeadTDLoss(torch.autograd.Function):
 def dqn_head_td_loss_supported(h, w, b):
     return (h.is_cuda and h.dim() == 2 and h.dtype == torch.float32 and w.dtype == torch.float32
             and b is not None and w.is_contiguous() and 1 <= w.shape[0] <= 16
-            and h.shape[1] % 64 == 0 and 64 <= h.shape[1] <= 512 and 1 <= h.shape[0] <= 1024
+            and h.shape[1] in (256, 512) and 1 <= h.shape[0] <= 1024
             and (w.shape[0] * h.shape[1] + 4 * h.shape[1] + 32 * w.shape[0] + 2 * h.shape[0] + 32) * 4
             <= 64 * 1024 and _native.available())
 

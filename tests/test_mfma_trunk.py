@@ -342,7 +342,7 @@ def test_graph_cache_evicts_the_least_recently_used_entry_and_keys_on_the_learni
 @pytest.mark.gpu
 @pytest.mark.parametrize("B,K,A,clip,mean,weighted,double", [
     (32, 512, 6, True, False, False, False), (32, 512, 6, True, True, True, True),
-    (48, 512, 16, False, True, False, False), (1, 64, 1, True, False, False, False),
+    (48, 512, 16, False, True, False, False), (1, 256, 1, True, False, False, False),
     (100, 256, 4, True, True, True, False), (33, 512, 18 - 2, False, False, True, True),
 ])
 def test_head_td_loss_in_one_launch_matches_the_three_launches(B, K, A, clip, mean, weighted, double):
