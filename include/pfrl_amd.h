@@ -283,15 +283,16 @@ int pfrl_dqn_td_loss(const float *q, const int64_t *action, const float *target_
                      int clip_delta, int mean, float *out_loss, float *out_grad_q, float *out_y,
                      float *out_abs_delta, void *stream);
 /* The narrow head Linear(K, A) (examples/atari/train_dqn_batch_ale.py:35-41), the TD loss above
- * and the head's backward in ONE launch: h [B][K] is the head's input, w [A][K], bias [A];
- * outputs as pfrl_dqn_td_loss plus dh [B][K], dw [A][K], db [A] (gradients of the loss, its
- * `mean` scaling included).  A <= 16, K = 256 or 512. */
+ * and the head's backward in ONE launch, a wave per row: h [B][K] is the head's input, w [A][K],
+ * bias [A]; out_y / out_abs_delta as pfrl_dqn_td_loss, dh [B][K] = dL/dh (the `mean` scaling
+ * included).  What couples the rows leaves as per-row partials [B][A*K + 32] for
+ * pfrl_splitk_reduce (splits = B, stride = A*K + 32): dL/dw = the fold of [0, A*K), dL/db of
+ * [A*K, A*K + A), the loss of [A*K + 16].  A <= 16, K = 256 or 512. */
 int pfrl_dqn_head_td_loss(const float *h, const float *w, const float *bias, const int64_t *action,
                           const float *target_q, const float *next_q_online, const float *reward,
                           const float *discount, const float *terminal, const float *weights,
-                          int32_t B, int32_t K, int32_t A, int clip_delta, int mean, float *out_loss,
-                          float *out_y, float *out_abs_delta, float *dh, float *dw, float *db,
-                          void *stream);
+                          int32_t B, int32_t K, int32_t A, int clip_delta, int mean, float *out_y,
+                          float *out_abs_delta, float *dh, float *partials, void *stream);
 
 /* Fused bias + ReLU of the conv trunk (pfrl/nn/atari_cnn.py:40-47: activation(
  * layer(h)) with conv bias) on row-major [rows][C] activations, i.e.

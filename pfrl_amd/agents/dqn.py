@@ -416,6 +416,10 @@ class DQN(agent.AttributeSavingMixin, agent.BatchAgent):
             return cls._compute_target_values is DoubleDQN._compute_target_values
         return cls._compute_target_values is DQN._compute_target_values
 
+    # set by the graph path (GraphedUpdate), which runs backward right after the loss and
+    # flushes the queue: the head's batch sums then ride on the trunk backward's fold launch
+    _defer_head_fold = False
+
     def _head_split(self):
         """(body modules, head layer) when the model is ``nn.Sequential(..., Linear(K, A),
         DiscreteActionValueHead())`` with the narrow head on the GPU kernels (the example
@@ -459,7 +463,8 @@ class DQN(agent.AttributeSavingMixin, agent.BatchAgent):
             loss, y, delta = ops.dqn_head_td_loss(
                 h, head.weight, head.bias, exp_batch["action"], target_q, next_online,
                 exp_batch["reward"], exp_batch["discount"], exp_batch["is_state_terminal"],
-                exp_batch.get("weights"), self.clip_delta, self.batch_accumulator == "mean")
+                exp_batch.get("weights"), self.clip_delta, self.batch_accumulator == "mean",
+                defer=self._defer_head_fold)
             # the gradients came out of the same launch: backward may start at h, and the
             # head's own gradients are handed over as they are
             if loss.grad_fn is not None:

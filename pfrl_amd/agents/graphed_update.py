@@ -131,7 +131,15 @@ class GraphedUpdate:
     def _forward(self, exp_batch, want_errors):
         ag = self.agent
         ag._analytic_backward = None
-        return ag._compute_loss(exp_batch, want_errors=want_errors, record=False)
+        # (pipeline mode hands the loss outputs over between forward and backward: no deferral)
+        ag._defer_head_fold = not self.pipeline
+        from pfrl_amd.nn import mfma_trunk
+
+        del mfma_trunk._DEFERRED_FOLDS[:]      # (leftovers of an update that raised)
+        try:
+            return ag._compute_loss(exp_batch, want_errors=want_errors, record=False)
+        finally:
+            ag._defer_head_fold = False
 
     def _backward(self, loss):
         ab = getattr(self.agent, "_analytic_backward", None)
@@ -140,6 +148,9 @@ class GraphedUpdate:
             # head's own gradients beside it) came out of the same launch
             if ab[0].requires_grad:
                 torch.autograd.backward([ab[0]], [ab[1]])
+            from pfrl_amd.nn import mfma_trunk
+
+            mfma_trunk.flush_deferred_folds()     # (no-op when the trunk's backward took them)
             for p, g in (ab[2] if len(ab) > 2 else ()):
                 if p.requires_grad:
                     p.grad = g if p.grad is None else p.grad + g

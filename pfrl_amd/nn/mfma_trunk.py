@@ -170,6 +170,23 @@ def _reduce(tasks):
     check(L.pfrl_splitk_reduce(n, P, O, B, S, N, K, C, R, _stream()), "splitk_reduce")
 
 
+# Folds queued by other nodes of the same backward pass (the fused head + loss launch of
+# ops.dqn_head_td_loss) for the fold launch that ends the trunk's backward: one launch less.
+_DEFERRED_FOLDS = []
+
+
+def defer_fold(tasks):
+    _DEFERRED_FOLDS.extend(tasks)
+
+
+def flush_deferred_folds():
+    """Launch whatever is still queued (no MFMA trunk ran a backward after it was queued)."""
+    while _DEFERRED_FOLDS:
+        batch = _DEFERRED_FOLDS[:12]
+        del _DEFERRED_FOLDS[:12]
+        _reduce(batch)
+
+
 def conv_fwd(x, w, b, sp, N, relu=True, planar=False):
     """x: NHWC memory of [N, H, W, C]; returns NHWC [N, OH, OW, Cout] or planar [N, Cout, OH*OW]."""
     shape = (N, sp.Cout, sp.OH * sp.OW) if planar else (N, sp.OH, sp.OW, sp.Cout)
@@ -292,6 +309,9 @@ class _Trunk(torch.autograd.Function):
                                                     sp.W, sp.C, sp.Cout, sp.R, sp.S, sp.ST, 0, 0,
                                                     _stream()), "conv2d_nhwc_bwd_data")
                 dy = dx
+        if _DEFERRED_FOLDS and len(tasks) + len(_DEFERRED_FOLDS) <= 12:
+            tasks += _DEFERRED_FOLDS
+            del _DEFERRED_FOLDS[:]
         if tasks:
             _reduce(tasks)
         return (None, None) + tuple(grads)

@@ -291,11 +291,16 @@ def dqn_td_loss(q, action, target_q, next_q_online, reward, discount, terminal, 
 
 class _DQNHeadTDLoss(torch.autograd.Function):
     """The narrow head ``q = h W^T + b``, the TD loss of ``_DQNTDLoss`` and the head's backward
-    in one launch (pfrl_dqn_head_td_loss): saves d loss / d(h, W, b) for backward."""
+    in one launch (pfrl_dqn_head_td_loss, a wave per row).  The sums over the batch (dL/dW,
+    dL/db, the loss) leave the launch as per-row partials; ``defer=True`` queues their fold for
+    the fold launch that ends the MFMA trunk's backward (``mfma_trunk.defer_fold``), otherwise
+    it is launched here."""
 
     @staticmethod
     def forward(ctx, h, w, b, action, target_q, next_q_online, reward, discount, terminal, weights,
-                clip_delta, mean):
+                clip_delta, mean, defer):
+        from pfrl_amd.nn import mfma_trunk
+
         B, K = h.shape
         A = w.shape[0]
         hc = h.detach().contiguous()
@@ -306,14 +311,22 @@ class _DQNHeadTDLoss(torch.autograd.Function):
         dh = torch.empty((B, K), dtype=torch.float32, device=dev)
         dw = torch.empty((A, K), dtype=torch.float32, device=dev)
         db = torch.empty((A,), dtype=torch.float32, device=dev)
+        stride = A * K + 32
+        part = torch.empty(B * stride, dtype=torch.float32, device=dev)
         check(_native.lib().pfrl_dqn_head_td_loss(
             _ptr(hc), _ptr(w.detach()), _ptr(b.detach()), _ptr(action.contiguous()),
             _ptr(target_q.contiguous()),
             _ptr(next_q_online.contiguous()) if next_q_online is not None else None,
             _ptr(reward), _ptr(discount), _ptr(terminal),
             _ptr(weights.contiguous()) if weights is not None else None, B, K, A, int(clip_delta),
-            int(mean), _ptr(loss), _ptr(y), _ptr(delta), _ptr(dh), _ptr(dw), _ptr(db), _stream()),
-            "dqn_head_td_loss")
+            int(mean), _ptr(y), _ptr(delta), _ptr(dh), _ptr(part), _stream()), "dqn_head_td_loss")
+        tasks = [(part, dw, None, stride, A * K, B, 4, 0),
+                 (part[A * K:], db, None, stride, A, B, 4, 0),
+                 (part[A * K + 16:], loss, None, stride, 1, B, 4, 0)]
+        if defer:
+            mfma_trunk.defer_fold(tasks)
+        else:
+            mfma_trunk._reduce(tasks)
         ctx.save_for_backward(dh, dw, db)
         ctx.mark_non_differentiable(y, delta)
         ctx.set_materialize_grads(False)
@@ -322,22 +335,22 @@ class _DQNHeadTDLoss(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_loss, g_y, g_delta):
         dh, dw, db = ctx.saved_tensors
-        return (dh * g_loss, dw * g_loss, db * g_loss) + (None,) * 9
+        return (dh * g_loss, dw * g_loss, db * g_loss) + (None,) * 10
 
 
 def dqn_head_td_loss_supported(h, w, b):
     return (h.is_cuda and h.dim() == 2 and h.dtype == torch.float32 and w.dtype == torch.float32
             and b is not None and w.is_contiguous() and 1 <= w.shape[0] <= 16
-            and h.shape[1] in (256, 512) and 1 <= h.shape[0] <= 1024
-            and (w.shape[0] * h.shape[1] + 4 * h.shape[1] + 32 * w.shape[0] + 2 * h.shape[0] + 32) * 4
-            <= 64 * 1024 and _native.available())
+            and h.shape[1] in (256, 512) and 1 <= h.shape[0] <= 4096 and _native.available())
 
 
 def dqn_head_td_loss(h, w, b, action, target_q, next_q_online, reward, discount, terminal, weights,
-                     clip_delta, mean):
-    """-> (loss scalar with grad w.r.t. h, w, b; y [B]; |y - t| [B])"""
+                     clip_delta, mean, defer=False):
+    """-> (loss scalar with grad w.r.t. h, w, b; y [B]; |y - t| [B]).  With ``defer`` the loss
+    value and the head's gradients are final only after the deferred fold has run (the trunk's
+    backward or ``mfma_trunk.flush_deferred_folds()``)."""
     return _DQNHeadTDLoss.apply(h, w, b, action, target_q, next_q_online, reward, discount, terminal,
-                                weights, clip_delta, mean)
+                                weights, clip_delta, mean, defer)
 
 
 _bias_relu_ws = {}
