@@ -132,7 +132,12 @@ def build_rainbow(args, device, rank):
         torch.backends.cudnn.benchmark = True
     if args.channels_last:
         q_func = q_func.to(memory_format=torch.channels_last)
-    opt = torch.optim.Adam(q_func.parameters(), 6.25e-5, eps=1.5 * 10 ** -4, fused=True)
+    if args.torch_optimizer:
+        opt = torch.optim.Adam(q_func.parameters(), 6.25e-5, eps=1.5 * 10 ** -4, fused=True)
+    else:
+        from pfrl_amd.optimizers import FusedAdam     # torch.optim.Adam's step as one launch
+
+        opt = FusedAdam(q_func.parameters(), 6.25e-5, eps=1.5 * 10 ** -4)
     store = DeviceFrameStore(getattr(args, "frame_slots", None) or args.capacity + N * 24 + 8192,
                              (84, 84), torch.uint8, device, stack=4)
     env = SyntheticAtariVectorEnv(N, store=store, seed=args.seed, env_id0=rank * N,
