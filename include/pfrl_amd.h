@@ -285,8 +285,8 @@ int pfrl_dqn_td_loss(const float *q, const int64_t *action, const float *target_
 /* The narrow head Linear(K, A) (examples/atari/train_dqn_batch_ale.py:35-41), the TD loss above
  * and the head's backward in ONE launch, a wave per row: h [B][K] is the head's input, w [A][K],
  * bias [A]; out_y / out_abs_delta as pfrl_dqn_td_loss, dh [B][K] = dL/dh (the `mean` scaling
- * included).  What couples the rows leaves as per-row partials [B][A*K + 32] for
- * pfrl_splitk_reduce (splits = B, stride = A*K + 32): dL/dw = the fold of [0, A*K), dL/db of
+ * included).  What couples the rows leaves as one partial slab per four rows,
+ * [ceil(B/4)][A*K + 32], for pfrl_splitk_reduce (splits = ceil(B/4), stride = A*K + 32): dL/dw = the fold of [0, A*K), dL/db of
  * [A*K, A*K + A), the loss of [A*K + 16].  A <= 16, K = 256 or 512. */
 int pfrl_dqn_head_td_loss(const float *h, const float *w, const float *bias, const int64_t *action,
                           const float *target_q, const float *next_q_online, const float *reward,

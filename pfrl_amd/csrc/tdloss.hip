@@ -101,27 +101,25 @@ extern "C" int pfrl_dqn_td_loss(const float *q, const int64_t *action, const flo
 // and all of W (lanes across k: k = lane + 64 j), reduces the A dot products, evaluates the
 // row's loss term in every lane, and writes dL/dh[m] = g_m W[a_m] (dL/dq has one nonzero per
 // row, the taken action).  What couples the rows -- dL/dW[a] = sum_{m: a_m = a} g_m h[m],
-// dL/db, the loss sum -- leaves as per-row partials [B][A*K + 32] (zeros for the other
-// actions), the layout pfrl_splitk_reduce folds; the caller puts them into the fold launch
-// that ends the trunk's backward anyway.  No LDS, no barriers, every load unconditional and
-// issued before the first use (a single workgroup walking 32 rows through LDS with barriers
-// measured 19-30 us).
+// dL/db, the loss sum -- leaves as one partial slab per workgroup (4 rows, folded in wave
+// order through LDS): [ceil(B/4)][A*K + 32], the layout pfrl_splitk_reduce folds; the caller
+// puts them into the fold launch that ends the trunk's backward anyway.  Every load is
+// unconditional and issued before the first use (a single workgroup walking 32 rows through
+// LDS with barriers measured 19-30 us).
 // ===================================================================================
 namespace {
 
 template <int A, int KJ>
-__global__ __launch_bounds__(kThreads) void k_dqn_head_td_rows(
+__device__ __forceinline__ void head_td_row(
     const float *__restrict__ h, const float *__restrict__ W, const float *__restrict__ bias,
     const int64_t *__restrict__ action, const float *__restrict__ target_q,
     const float *__restrict__ next_q_online, const float *__restrict__ reward,
     const float *__restrict__ discount, const float *__restrict__ terminal,
     const float *__restrict__ weights, int B, int clip_delta, int mean, float *__restrict__ out_y,
-    float *__restrict__ out_abs_delta, float *__restrict__ dh, float *__restrict__ part) {
+    float *__restrict__ out_abs_delta, float *__restrict__ dh, const int m, float (*s_c)[64 * KJ],
+    float *s_g, float *s_l, int *s_act) {
     constexpr int K = 64 * KJ;
-    constexpr int STRIDE = A * K + 32;
-    const int lane = threadIdx.x & 63;
-    const int m = blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);
-    if (m >= B) return;   // (uniform per wave)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // (optional inputs are read through a pointer that is always valid: no branch at a load)
     const float *__restrict__ sel_q = next_q_online ? next_q_online : target_q;
     const float *__restrict__ wt_src = weights ? weights : reward;
@@ -176,13 +174,6 @@ __global__ __launch_bounds__(kThreads) void k_dqn_head_td_rows(
         g = d;
     }
     const float gq = g * wt * scale;
-    float *pr = part + (size_t)m * STRIDE;
-#pragma unroll
-    for (int a = 0; a < A; ++a) {
-        const float ga = (a == act) ? gq : 0.f;
-#pragma unroll
-        for (int j = 0; j < KJ; ++j) pr[a * K + lane + 64 * j] = ga * hv[j];
-    }
     float wsel[KJ];
 #pragma unroll
     for (int j = 0; j < KJ; ++j) {
@@ -191,23 +182,72 @@ __global__ __launch_bounds__(kThreads) void k_dqn_head_td_rows(
         for (int a = 1; a < A; ++a) wsel[j] = (a == act) ? wv[a][j] : wsel[j];
         dh[(size_t)m * K + lane + 64 * j] = gq * wsel[j];
     }
-    if (lane < 32) {
-        // [A*K, A*K+16): dL/db of the row; [A*K+16]: its loss term; the rest zero
-        float v = 0.f;
-        if (lane < A) v = (lane == act) ? gq : 0.f;
-        if (lane == 16) v = l * wt * scale;
-        pr[A * K + lane] = v;
-    }
     if (lane == 0) {
         out_y[m] = y;
         out_abs_delta[m] = ad;
+    }
+    // the workgroup's four rows fold into ONE slab, in wave order (deterministic): each wave
+    // parks g_m h[m] and (a_m, g_m, loss term); then every thread sums, per action, the rows
+    // that took it
+#pragma unroll
+    for (int j = 0; j < KJ; ++j) s_c[wave][lane + 64 * j] = gq * hv[j];
+    if (lane == 0) {
+        s_act[wave] = act;
+        s_g[wave] = gq;
+        s_l[wave] = l * wt * scale;
+    }
+}
+
+template <int A, int KJ>
+__global__ __launch_bounds__(kThreads) void k_dqn_head_td_rows(
+    const float *__restrict__ h, const float *__restrict__ W, const float *__restrict__ bias,
+    const int64_t *__restrict__ action, const float *__restrict__ target_q,
+    const float *__restrict__ next_q_online, const float *__restrict__ reward,
+    const float *__restrict__ discount, const float *__restrict__ terminal,
+    const float *__restrict__ weights, int B, int clip_delta, int mean, float *__restrict__ out_y,
+    float *__restrict__ out_abs_delta, float *__restrict__ dh, float *__restrict__ part) {
+    constexpr int K = 64 * KJ;
+    constexpr int STRIDE = A * K + 32;
+    __shared__ float s_c[4][K];
+    __shared__ float s_g[4], s_l[4];
+    __shared__ int s_act[4];
+    const int tid = threadIdx.x, wave = tid >> 6;
+    if (tid < 4) {
+        s_act[tid] = -1;          // rows past the batch take no action
+        s_g[tid] = 0.f;
+        s_l[tid] = 0.f;
+    }
+    __syncthreads();
+    const int m = blockIdx.x * 4 + wave;
+    if (m < B)
+        head_td_row<A, KJ>(h, W, bias, action, target_q, next_q_online, reward, discount, terminal,
+                           weights, B, clip_delta, mean, out_y, out_abs_delta, dh, m, s_c, s_g, s_l,
+                           s_act);
+    __syncthreads();
+    float *pr = part + (size_t)blockIdx.x * STRIDE;
+    for (int e = tid; e < A * K; e += kThreads) {
+        const int a = e / K, k = e - a * K;
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) v += (s_act[w] == a) ? s_c[w][k] : 0.f;
+        pr[e] = v;
+    }
+    if (tid < 32) {
+        // [A*K, A*K+16): dL/db of the slab; [A*K+16]: its loss terms; the rest zero
+        float v = 0.f;
+        if (tid < A) {
+#pragma unroll
+            for (int w = 0; w < 4; ++w) v += (s_act[w] == tid) ? s_g[w] : 0.f;
+        }
+        if (tid == 16) v = (s_l[0] + s_l[1]) + (s_l[2] + s_l[3]);
+        pr[A * K + tid] = v;
     }
 }
 
 }  // namespace
 
-// partials: [B][A*K + 32] floats (see above); fold with pfrl_splitk_reduce: dw = sum over the
-// B slabs of [0, A*K), db of [A*K, A*K + A), loss of [A*K + 16].
+// partials: [ceil(B/4)][A*K + 32] floats (see above); fold with pfrl_splitk_reduce: dw = sum
+// over the slabs of [0, A*K), db of [A*K, A*K + A), loss of [A*K + 16].
 extern "C" int pfrl_dqn_head_td_loss(const float *h, const float *w, const float *bias,
                                      const int64_t *action, const float *target_q,
                                      const float *next_q_online, const float *reward,

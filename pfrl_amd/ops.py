@@ -312,7 +312,8 @@ class _DQNHeadTDLoss(torch.autograd.Function):
         dw = torch.empty((A, K), dtype=torch.float32, device=dev)
         db = torch.empty((A,), dtype=torch.float32, device=dev)
         stride = A * K + 32
-        part = torch.empty(B * stride, dtype=torch.float32, device=dev)
+        slabs = (B + 3) // 4          # one partial slab per workgroup of four rows
+        part = torch.empty(slabs * stride, dtype=torch.float32, device=dev)
         check(_native.lib().pfrl_dqn_head_td_loss(
             _ptr(hc), _ptr(w.detach()), _ptr(b.detach()), _ptr(action.contiguous()),
             _ptr(target_q.contiguous()),
@@ -320,9 +321,9 @@ class _DQNHeadTDLoss(torch.autograd.Function):
             _ptr(reward), _ptr(discount), _ptr(terminal),
             _ptr(weights.contiguous()) if weights is not None else None, B, K, A, int(clip_delta),
             int(mean), _ptr(y), _ptr(delta), _ptr(dh), _ptr(part), _stream()), "dqn_head_td_loss")
-        tasks = [(part, dw, None, stride, A * K, B, 4, 0),
-                 (part[A * K:], db, None, stride, A, B, 4, 0),
-                 (part[A * K + 16:], loss, None, stride, 1, B, 4, 0)]
+        tasks = [(part, dw, None, stride, A * K, slabs, 4, 0),
+                 (part[A * K:], db, None, stride, A, slabs, 4, 0),
+                 (part[A * K + 16:], loss, None, stride, 1, slabs, 4, 0)]
         if defer:
             mfma_trunk.defer_fold(tasks)
         else:
