@@ -165,7 +165,7 @@ class ReplayActorCritic(AttributeSavingMixin, BatchAgent):
     step_fused = True
     # fractions of the env batch at which the fused step is cut into ranges (see
     # _batch_observe_fused); () = one range
-    step_fused_chunks = (0.0625,)
+    step_fused_chunks = (0.125,)
 
     def _step_fusable(self):
         """All updates of one batched env step from ONE gather launch and ONE captured
