@@ -84,7 +84,10 @@ def plan_for(convs, linear, x):
         return None
     if _MAX_BATCH and x.shape[0] > _MAX_BATCH:
         return None
-    if not (isinstance(linear, nn.Linear) and linear.bias is not None
+    # linear is None: the convolutions alone (networks whose layer after the flatten is not a
+    # plain nn.Linear + ReLU, e.g. the NoisyNet streams of the Rainbow head)
+    if linear is not None and not (
+            isinstance(linear, nn.Linear) and linear.bias is not None
             and linear.weight.dtype == torch.float32 and linear.weight.is_contiguous()
             and linear.in_features % 32 == 0 and linear.out_features % 32 == 0):
         return None
@@ -106,7 +109,8 @@ def plan_for(convs, linear, x):
         specs.append(sp)
         H, W = sp.OH, sp.OW
     last = specs[-1]
-    if last.Cout * last.OH * last.OW != linear.in_features or linear.in_features % 16:
+    if linear is not None and (last.Cout * last.OH * last.OW != linear.in_features
+                               or linear.in_features % 16):
         return None
     if x.shape[0] * max(s.OH * s.OW * max(s.Cout, s.C) for s in specs) >= 2 ** 31 // 8:
         return None
@@ -228,8 +232,12 @@ class _Trunk(torch.autograd.Function):
         for i, sp in enumerate(specs):
             h = conv_fwd(h, params[2 * i], params[2 * i + 1], sp, N, relu=True, planar=(i == L - 1))
             acts.append(h)
-        wf, bf = params[2 * L], params[2 * L + 1]
-        out = linear_fwd(h.view(N, -1), wf, bf, relu=True)
+        if len(params) == 2 * L:
+            # convolutions only: the planar (NCHW) output of the last one, as [N, Cout, OH, OW]
+            out = h.view(N, specs[-1].Cout, specs[-1].OH, specs[-1].OW)
+        else:
+            wf, bf = params[2 * L], params[2 * L + 1]
+            out = linear_fwd(h.view(N, -1), wf, bf, relu=True)
         if any(ctx.needs_input_grad[2:]):
             ctx.specs = specs
             ctx.save_for_backward(x, out, *acts, *params)
@@ -247,10 +255,16 @@ class _Trunk(torch.autograd.Function):
         lib = _native.lib()
         dev = x.device
         dh = dh.contiguous()
-        wf = params[2 * L]
-        F, Kf = wf.shape
         last = specs[-1]
         P = last.OH * last.OW
+        if len(params) == 2 * L:
+            # convolutions only: ReLU mask of the last convolution and planar -> NHWC rows
+            g = torch.ops.aten.threshold_backward(dh.view(N, last.Cout, P), acts[-1].view(N, last.Cout, P),
+                                                  0.0)
+            dy = g.permute(0, 2, 1).contiguous().view(N, last.OH, last.OW, last.Cout)
+            return _Trunk._conv_backward(ctx, specs, params, acts, x, dy, N, dev, [None] * (2 * L))
+        wf = params[2 * L]
+        F, Kf = wf.shape
         # hidden linear layer: input gradient straight into NHWC rows of the last conv, and
         # the weight gradient, in one launch when the batch is minibatch-sized
         dy = torch.empty((N, last.OH, last.OW, last.Cout), dtype=torch.float32, device=dev)
@@ -274,6 +288,14 @@ class _Trunk(torch.autograd.Function):
 
             announce_grad(wf, dwf)
         grads = [None] * (2 * L) + [dwf, dbf]
+        return _Trunk._conv_backward(ctx, specs, params, acts, x, dy, N, dev, grads)
+
+    @staticmethod
+    def _conv_backward(ctx, specs, params, acts, x, dy, N, dev, grads):
+        """Gradients of the convolutions given dy = dL/d(output of the last one) as NHWC rows
+        (its ReLU mask applied)."""
+        lib = _native.lib()
+        L = len(specs)
         tasks = []
         for i in range(L - 1, -1, -1):
             sp = specs[i]
@@ -321,7 +343,8 @@ def trunk_forward(x, specs, convs, linear):
     params = []
     for c in convs:
         params += [c.weight, c.bias]
-    params += [linear.weight, linear.bias]
+    if linear is not None:
+        params += [linear.weight, linear.bias]
     return _Trunk.apply(x, specs, *params)
 
 

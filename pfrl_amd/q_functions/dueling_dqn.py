@@ -47,10 +47,7 @@ class DuelingDQN(nn.Module):
         self.conv_layers.apply(constant_bias_initializer(bias=bias))
 
     def forward(self, x):
-        h = x
-        last = len(self.conv_layers) - 1
-        for i, layer in enumerate(self.conv_layers):
-            h = conv_activation(layer, h, self.activation, planar_out=(i == last))
+        h = _conv_trunk(self.conv_layers, x, self.activation)
         batch_size = x.shape[0]
         h = h.reshape(batch_size, -1)
         ya = self.a_stream(h)
@@ -58,6 +55,25 @@ class DuelingDQN(nn.Module):
         ya = ya - mean
         ys = self.v_stream(h)
         return action_value.DiscreteActionValue(ya + ys)
+
+
+def _conv_trunk(conv_layers, x, activation):
+    """activation(conv(...)) over the layers; on the GPU as the MFMA trunk kernels (one
+    autograd node, bias + ReLU in the epilogues) when the shapes are inside what they cover,
+    else layer by layer.  Either way the result is [N, C, H, W] in plain NCHW memory."""
+    if x.is_cuda:
+        from pfrl_amd.nn import mfma_trunk
+        from pfrl_amd.nn.atari_cnn import _is_relu
+
+        if _is_relu(activation):
+            specs = mfma_trunk.plan_for(conv_layers, None, x)
+            if specs is not None:
+                return mfma_trunk.trunk_forward(x, specs, list(conv_layers), None)
+    h = x
+    last = len(conv_layers) - 1
+    for i, layer in enumerate(conv_layers):
+        h = conv_activation(layer, h, activation, planar_out=(i == last))
+    return h
 
 
 class DistributionalDuelingDQN(nn.Module):
@@ -83,10 +99,7 @@ class DistributionalDuelingDQN(nn.Module):
         self.conv_layers.apply(constant_bias_initializer(bias=bias))
 
     def forward(self, x):
-        h = x
-        last = len(self.conv_layers) - 1
-        for i, layer in enumerate(self.conv_layers):
-            h = conv_activation(layer, h, self.activation, planar_out=(i == last))
+        h = _conv_trunk(self.conv_layers, x, self.activation)
         batch_size = x.shape[0]
         h = linear_activation(self.main_stream, h.reshape(batch_size, -1), self.activation)
         h_a, h_v = torch.chunk(h, 2, dim=1)

@@ -375,3 +375,33 @@ def test_head_td_loss_in_one_launch_matches_the_three_launches(B, K, A, clip, me
     assert (y - y_r).abs().max().item() < tol(y_r) and (delta - delta_r).abs().max().item() < tol(delta_r)
     for a, ref in zip(got, want):
         assert (a - ref).abs().max().item() < tol(ref)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N", [32, 1, 64])
+def test_conv_only_trunk_matches_torch(N):
+    """The three convolutions alone (the Rainbow head's trunk): output [N, 64, 7, 7] in NCHW
+    memory and all gradients against stock PyTorch on the same device."""
+    from pfrl_amd.nn import mfma_trunk
+
+    dev = torch.device("cuda:0")
+    torch.manual_seed(N)
+    convs = torch.nn.ModuleList([torch.nn.Conv2d(4, 32, 8, stride=4), torch.nn.Conv2d(32, 64, 4, stride=2),
+                                 torch.nn.Conv2d(64, 64, 3, stride=1)]).to(dev)
+    convs = convs.to(memory_format=torch.channels_last)
+    x = torch.rand(N, 4, 84, 84, device=dev)
+    specs = mfma_trunk.plan_for(convs, None, x)
+    assert specs is not None
+    out = mfma_trunk.trunk_forward(x, specs, list(convs), None)
+    assert out.shape == (N, 64, 7, 7) and out.is_contiguous()
+    h = x
+    for c in convs:
+        h = torch.relu(c(h))
+    tol = lambda ref: 1e-5 * max(ref.abs().max().item(), 1.0)
+    assert (out - h).abs().max().item() < tol(h)
+    g = torch.randn(N, 3136, device=dev)
+    params = [p for c in convs for p in (c.weight, c.bias)]
+    got = torch.autograd.grad(out.reshape(N, -1), params, g)
+    want = torch.autograd.grad(h.reshape(N, -1), params, g)
+    for a, r in zip(got, want):
+        assert (a - r).abs().max().item() < 2e-5 * max(r.abs().max().item(), 1.0)
