@@ -394,14 +394,19 @@ def test_conv_only_trunk_matches_torch(N):
     assert specs is not None
     out = mfma_trunk.trunk_forward(x, specs, list(convs), None)
     assert out.shape == (N, 64, 7, 7) and out.is_contiguous()
-    h = x
-    for c in convs:
+    # reference: stock PyTorch fp32 on the CPU (as for the full trunk)
+    import copy
+
+    ref = copy.deepcopy(convs).cpu()
+    h = x.cpu()
+    for c in ref:
         h = torch.relu(c(h))
-    tol = lambda ref: 1e-5 * max(ref.abs().max().item(), 1.0)
-    assert (out - h).abs().max().item() < tol(h)
-    g = torch.randn(N, 3136, device=dev)
+    tol = lambda r: 1e-5 * max(r.abs().max().item(), 1.0)
+    assert (out.cpu() - h).abs().max().item() < tol(h)
+    g = torch.randn(N, 3136)
     params = [p for c in convs for p in (c.weight, c.bias)]
-    got = torch.autograd.grad(out.reshape(N, -1), params, g)
-    want = torch.autograd.grad(h.reshape(N, -1), params, g)
+    rparams = [p for c in ref for p in (c.weight, c.bias)]
+    got = torch.autograd.grad(out.reshape(N, -1), params, g.to(dev))
+    want = torch.autograd.grad(h.reshape(N, -1), rparams, g)
     for a, r in zip(got, want):
-        assert (a - r).abs().max().item() < 2e-5 * max(r.abs().max().item(), 1.0)
+        assert (a.cpu() - r).abs().max().item() < 2e-5 * max(r.abs().max().item(), 1.0)
