@@ -79,6 +79,10 @@ def linear_activation(layer, h, activation):
         if ops.bias_relu_supported(z, layer.bias):
             return ops.bias_relu(z, layer.bias)
         return activation(z + layer.bias)
+    from pfrl_amd.nn.noisy_linear import FactorizedNoisyLinear
+
+    if isinstance(layer, FactorizedNoisyLinear) and _is_relu(activation):
+        return layer(h, relu=True)
     return activation(layer(h))   # large batches: the GEMM's own bias epilogue
 
 

@@ -165,6 +165,13 @@ def supported(layer, x):
             and 0 < x.shape[0] <= _MAX_BATCH and _native.available())
 
 
+def supported_tensors(x, weight, bias):
+    """``supported`` for a weight / bias pair that is not an ``nn.Linear`` (noisy weights)."""
+    return (_ENABLED and x.is_cuda and x.dim() == 2 and x.dtype == torch.float32
+            and bias is not None and weight.shape[0] >= MIN_OUT and weight.dtype == torch.float32
+            and weight.is_contiguous() and 0 < x.shape[0] <= _MAX_BATCH and _native.available())
+
+
 class _LinearSlot(nn.Linear):
     """An ``nn.Linear`` (same class family, parameter names and state_dict) around the
     tensors of an existing layer; forward takes the MFMA kernels where ``supported``."""

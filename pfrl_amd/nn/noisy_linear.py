@@ -52,7 +52,13 @@ class FactorizedNoisyLinear(nn.Module):
         if self.hasbias:
             init_variance_scaling_constant(self.sigma.bias, scale=sigma_scale)
 
-    def forward(self, x):
+    def forward(self, x, relu=False):
+        """``relu=True`` (used by ``linear_activation``): ReLU applied to the result, inside the
+        GEMM's epilogue where the MFMA linear kernels take the layer."""
+        y = self._forward(x, relu)
+        return y
+
+    def _forward(self, x, relu):
         out_features, in_features = self.sigma.weight.shape
         sw = self.sigma.weight
         if sw.is_cuda:
@@ -65,12 +71,21 @@ class FactorizedNoisyLinear(nn.Module):
                 weight, bias = ops.noisy_weights(
                     self.mu.weight, sw, self.mu.bias if self.hasbias else None,
                     self.sigma.bias if self.hasbias else None, r)
-                return F.linear(x, weight, bias)
+                from pfrl_amd.nn import mfma_linear
+
+                if (bias is not None and weight.is_contiguous()
+                        and mfma_linear.supported_tensors(x, weight, bias)):
+                    # the noisy weights are a dense [out, in] matrix: the GEMM (and its
+                    # backward towards mu / sigma) on the MFMA linear kernels
+                    return mfma_linear._Linear.apply(x, weight, bias, bool(relu))
+                y = F.linear(x, weight, bias)
+                return F.relu(y) if relu else y
         noise = _shaped_noise(in_features + out_features, self.sigma.weight)
         eps_in, eps_out = noise[:in_features], noise[in_features:]
         weight = torch.addcmul(self.mu.weight, self.sigma.weight, torch.outer(eps_out, eps_in))
         bias = torch.addcmul(self.mu.bias, self.sigma.bias, eps_out) if self.hasbias else None
-        return F.linear(x, weight, bias)
+        y = F.linear(x, weight, bias)
+        return F.relu(y) if relu else y
 
 
 def to_factorized_noisy(module, *args, **kwargs):
