@@ -392,7 +392,10 @@ extern "C" int pfrl_entries_append(const pfrl_table_t *tab, int64_t n_rows, cons
 // instead of one workgroup (94 of 256 lanes busy, and a three-deep index chain per
 // workgroup).  Each wave resolves kFPW frames, issues all their loads, then stores; the
 // scalar collapse rides in extra workgroups as above.  frame_bytes % 16 == 0.
-constexpr int kFPW = 4;
+// Measured on the 14 336-entry launch of the SAC step (88.5 MB): kFPW = 8 / 4 / 2 / 1 ->
+// 24.2 / 22.1-23.4 / 21.9 / 20.8 us: more, shorter waves hide the index chain better than more
+// loads per wave.
+constexpr int kFPW = 1;
 
 template <typename ActT>
 __global__ __launch_bounds__(kThreads) void k_batch_experiences_f32_small(
