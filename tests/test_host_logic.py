@@ -232,3 +232,42 @@ def test_python_boundary_signatures_match_the_reference():
                     "VAR_KEYWORD", "VAR_POSITIONAL"):
                 problems.append("%s: extra required parameter %r" % (key, name))
     assert not problems, "\n".join(problems)
+
+
+def test_sample_n_k_equals_the_reference_walk_including_the_stream_position():
+    """pfrl_amd.utils.random.sample_n_k visits only the duplicate positions; the reference
+    (pfrl/utils/random.py:4-28, restated literally here) walks all k with a set.  Same indices
+    and same position of the global NumPy stream afterwards, also where duplicates are
+    frequent (k^2 / 2n ~ 0.3 for the SAC minibatch of 256 out of 10^5), where a spare is itself a
+    duplicate, where it equals the value of a later position, and where the spares run out."""
+    import numpy as np
+
+    from pfrl_amd.utils.random import sample_n_k
+
+    def reference(n, k):
+        if 3 * k >= n:
+            return np.random.choice(n, k, replace=False)
+        result = np.random.choice(n, 2 * k)
+        selected = set()
+        j = k
+        for i in range(k):
+            x = result[i]
+            while x in selected:
+                x = result[i] = result[j]
+                j += 1
+                if j == 2 * k:
+                    result[k:] = np.random.choice(n, k)
+                    j = k
+            selected.add(x)
+        return result[:k]
+
+    for n, k in ((100000, 256), (1000, 256), (800, 256), (10 ** 6, 32), (300, 90), (50, 10), (7, 2),
+                 (31, 10), (4, 1)):
+        for seed in range(60):
+            np.random.seed(seed)
+            want = reference(n, k)
+            pos_ref = np.random.randint(1 << 30)
+            np.random.seed(seed)
+            got = sample_n_k(n, k)
+            pos = np.random.randint(1 << 30)
+            assert np.array_equal(got, want) and pos == pos_ref, (n, k, seed)
