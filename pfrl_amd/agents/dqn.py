@@ -446,12 +446,16 @@ class DQN(agent.AttributeSavingMixin, agent.BatchAgent):
         from pfrl_amd import distributed, ops
 
         split = self._head_split() if distributed.world_size() == 1 else None
+        qout = None
         if split is not None:
             h = exp_batch["state"]
             for mod in split[0]:
                 h = mod(h)
             head = split[1]
             if not (torch.is_tensor(h) and ops.dqn_head_td_loss_supported(h, head.weight, head.bias)):
+                # outside the fused launch (e.g. a head input that is not [B, 256 | 512]): finish
+                # the forward pass from h, separate launches below
+                qout = list(self.model._modules.values())[-1](head(h))
                 split = None
         if split is not None:
             with torch.no_grad():
@@ -479,7 +483,8 @@ class DQN(agent.AttributeSavingMixin, agent.BatchAgent):
                 del errors_out[:]
                 errors_out.extend(delta.cpu().numpy())
             return loss, delta
-        qout = self.model(exp_batch["state"])
+        if qout is None:
+            qout = self.model(exp_batch["state"])
         with torch.no_grad():
             target_q = self._target_next_action_value(exp_batch).q_values
             next_online = None
