@@ -293,3 +293,41 @@ def test_fused_adam_step_together_equals_separate_steps():
     mixed = [opts[0], torch.optim.Adam(nets[1].parameters(), lr=1e-3, capturable=True)]
     FusedAdam.step_together(mixed)
     assert float(opts[0].state[next(nets[0].parameters())]["step"]) == 4.0
+
+
+def test_cpu_routes_of_the_round_two_helpers():
+    """Off the GPU every helper takes PyTorch's own route: several optimizers step one after the
+    other, several (target, source) pairs soft-update tensor by tensor, and the twin / MFMA
+    layer plans decline."""
+    from pfrl_amd.nn import accelerate_mlp
+    from pfrl_amd.nn.twin_mlp import twin_forward
+
+    import pfrl_amd as pfrl
+
+    torch.manual_seed(0)
+    nets = [nn.Linear(6, 4) for _ in range(2)]
+    refs = [copy.deepcopy(n) for n in nets]
+    opts = [FusedAdam(n.parameters(), lr=1e-2) for n in nets]
+    ropts = [torch.optim.Adam(n.parameters(), lr=1e-2) for n in refs]
+    for n, r in zip(nets, refs):
+        for p, q in zip(n.parameters(), r.parameters()):
+            p.grad = torch.randn_like(p)
+            q.grad = p.grad.clone()
+    FusedAdam.step_together(opts)
+    for o in ropts:
+        o.step()
+    for n, r in zip(nets, refs):
+        assert all(torch.equal(p, q) for p, q in zip(n.parameters(), r.parameters()))
+    # soft update of two pairs at once == one pair after the other
+    src, dst = [nn.Linear(5, 3) for _ in range(2)], [nn.Linear(5, 3) for _ in range(2)]
+    want = [copy.deepcopy(d) for d in dst]
+    for s, w in zip(src, want):
+        soft_copy_param(w, s, 0.05)
+    soft_copy_params(list(zip(dst, src)), 0.05)
+    for d, w in zip(dst, want):
+        assert all(torch.equal(a, b) for a, b in zip(d.state_dict().values(), w.state_dict().values()))
+    # twin plan: not on the CPU
+    q = lambda: accelerate_mlp(nn.Sequential(pfrl.nn.ConcatObsAndAction(), nn.Linear(11, 32), nn.ReLU(),
+                                             nn.Linear(32, 32), nn.ReLU(), nn.Linear(32, 1)))
+    q1, q2 = q(), q()
+    assert twin_forward(q1, q2, (torch.randn(4, 8), torch.randn(4, 3))) is None
