@@ -137,14 +137,17 @@ struct AdamArgs {
 // advanced by whichever workgroup finishes last (ticket), after every workgroup has read them.
 __global__ __launch_bounds__(kThreads) void k_adam(AdamArgs a, double lr, double b1d, double b2d,
                                                    float eps, float weight_decay,
-                                                   unsigned int *ticket) {
+                                                   unsigned int *ticket, int reps) {
     __shared__ float s_step_size, s_bc2_sqrt;
     __shared__ bool s_last;
     int t = 0;
     const int b = blockIdx.x;
     while (t < a.n - 1 && b >= a.chunk_end[t]) ++t;
     const int first = t == 0 ? 0 : a.chunk_end[t - 1];
-    const int64_t base = (int64_t)(b - first) * kChunk;
+    // a workgroup walks `reps` consecutive chunks of its tensor: the launch stays at a couple
+    // of thousand workgroups however large the network is (the ticket below is one atomic per
+    // workgroup on ONE address: 6 700 of them were 60 of the 86 us of a 6.9 M-parameter step)
+    const int64_t base0 = (int64_t)(b - first) * kChunk * reps;
     if (threadIdx.x == 0) {
         const double step = (double)(*a.step[t]) + 1.0;
         const double bc1 = 1.0 - pow(b1d, step), bc2 = 1.0 - pow(b2d, step);
@@ -156,32 +159,36 @@ __global__ __launch_bounds__(kThreads) void k_adam(AdamArgs a, double lr, double
     float *__restrict__ m = a.m[t];
     float *__restrict__ v = a.v[t];
     const int64_t n = a.numel[t];
-    float pv[4], gv[4], mv[4], vv[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        const int64_t i = base + u * kThreads + threadIdx.x;
-        const int64_t ii = i < n ? i : n - 1;
-        pv[u] = p[ii]; gv[u] = g[ii]; mv[u] = m[ii]; vv[u] = v[ii];
-    }
     __syncthreads();
     const float step_size = s_step_size, bc2_sqrt = s_bc2_sqrt;
     // the scalars as PyTorch hands them to f32 kernels: computed in double, then rounded
     const float w1 = (float)(1.0 - b1d), b2 = (float)b2d, omb2 = (float)(1.0 - b2d);
+    for (int r = 0; r < reps; ++r) {
+        const int64_t base = base0 + (int64_t)r * kChunk;
+        if (base >= n) break;   // (uniform)
+        float pv[4], gv[4], mv[4], vv[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        const int64_t i = base + u * kThreads + threadIdx.x;
-        if (i >= n) continue;
-        float gi = gv[u];
-        if (weight_decay != 0.0f) gi = __fadd_rn(gi, __fmul_rn(weight_decay, pv[u]));
-        // lerp_(g, w1): the two forms of at::native::lerp
-        const float dm = __fsub_rn(gi, mv[u]);
-        const float mi = w1 < 0.5f ? __fadd_rn(mv[u], __fmul_rn(w1, dm))
-                                   : __fsub_rn(gi, __fmul_rn(dm, __fsub_rn(1.0f, w1)));
-        const float vi = __fadd_rn(__fmul_rn(vv[u], b2), __fmul_rn(__fmul_rn(omb2, gi), gi));
-        const float denom = __fadd_rn(__fdiv_rn(__fsqrt_rn(vi), bc2_sqrt), eps);
-        m[i] = mi;
-        v[i] = vi;
-        p[i] = __fadd_rn(pv[u], __fdiv_rn(__fmul_rn(step_size, mi), denom));
+        for (int u = 0; u < 4; ++u) {
+            const int64_t i = base + u * kThreads + threadIdx.x;
+            const int64_t ii = i < n ? i : n - 1;
+            pv[u] = p[ii]; gv[u] = g[ii]; mv[u] = m[ii]; vv[u] = v[ii];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t i = base + u * kThreads + threadIdx.x;
+            if (i >= n) continue;
+            float gi = gv[u];
+            if (weight_decay != 0.0f) gi = __fadd_rn(gi, __fmul_rn(weight_decay, pv[u]));
+            // lerp_(g, w1): the two forms of at::native::lerp
+            const float dm = __fsub_rn(gi, mv[u]);
+            const float mi = w1 < 0.5f ? __fadd_rn(mv[u], __fmul_rn(w1, dm))
+                                       : __fsub_rn(gi, __fmul_rn(dm, __fsub_rn(1.0f, w1)));
+            const float vi = __fadd_rn(__fmul_rn(vv[u], b2), __fmul_rn(__fmul_rn(omb2, gi), gi));
+            const float denom = __fadd_rn(__fdiv_rn(__fsqrt_rn(vi), bc2_sqrt), eps);
+            m[i] = mi;
+            v[i] = vi;
+            p[i] = __fadd_rn(pv[u], __fdiv_rn(__fmul_rn(step_size, mi), denom));
+        }
     }
     // Every workgroup has read (and used) its step counter before it takes a ticket; nothing
     // it wrote has to be visible to the others, so no fence here: a release fence is a whole
@@ -301,11 +308,11 @@ __global__ __launch_bounds__(kThreads) void k_sac_temperature_loss(const float *
 }
 
 template <typename Args>
-int fill_chunks(Args &a, int n, const int64_t *numel, int lo) {
+int fill_chunks(Args &a, int n, const int64_t *numel, int lo, int64_t per_block = kChunk) {
     int chunks = 0;
     for (int t = 0; t < n; ++t) {
         a.numel[t] = numel[lo + t];
-        chunks += (int)((numel[lo + t] + kChunk - 1) / kChunk);
+        chunks += (int)((numel[lo + t] + per_block - 1) / per_block);
         a.chunk_end[t] = chunks;
     }
     a.n = n;
@@ -371,10 +378,15 @@ extern "C" int pfrl_adam_step(int32_t n_tensors, float *const *params, const flo
             a.v[t] = exp_avg_sq[lo + t];
             a.step[t] = steps[lo + t];
         }
-        const int chunks = fill_chunks(a, n, numel, lo);
+        int64_t total = 0;
+        for (int t = 0; t < n; ++t) total += numel[lo + t];
+        // chunks of 1 024 elements per workgroup, `reps` of them once that would exceed ~2 048
+        // workgroups
+        const int reps = (int)((total / kChunk + 2047) / 2048) > 1 ? (int)((total / kChunk + 2047) / 2048) : 1;
+        const int chunks = fill_chunks(a, n, numel, lo, (int64_t)kChunk * reps);
         PFRL_CHECK_ARG(chunks > 0, "pfrl_adam_step: empty parameters");
         hipLaunchKernelGGL(k_adam, dim3(chunks), dim3(kThreads), 0, (hipStream_t)stream, a, lr, beta1,
-                           beta2, (float)eps, (float)weight_decay, (unsigned int *)ticket);
+                           beta2, (float)eps, (float)weight_decay, (unsigned int *)ticket, reps);
     }
     PFRL_LAUNCH_CHECK();
 }
