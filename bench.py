@@ -86,11 +86,12 @@ def parse_args():
     p.add_argument("--chunks", type=str, default=None,
                    help="dqn: env-range cut points of the step-fused path as fractions, e.g. "
                         "'0.125' (default) or '' for one range")
-    p.add_argument("--priority-pow", choices=["device", "host_libm"], default="device",
+    p.add_argument("--priority-pow", choices=["device", "device_cr", "host_libm"], default="device",
                    help="rainbow: where (clip(err) + eps) ** alpha is evaluated.  device = one "
-                        "launch, correctly rounded (<= 1 ulp from NumPy's powf in <1 %% of inputs); "
-                        "host_libm = this host's libm as NumPy does (bit-exact priority trees, one "
-                        "D2H per update)")
+                        "launch, glibc's powf restated on the device (bit-exact priority trees); "
+                        "device_cr = one launch, correctly rounded power (<= 1 ulp from NumPy's "
+                        "powf in <1 %% of inputs; rounds 1-2); host_libm = this host's libm as "
+                        "NumPy does (one D2H per update)")
     p.add_argument("--torch-optimizer", action="store_true",
                    help="stock torch.optim.RMSprop instead of the fused HIP step")
     args = p.parse_args()

@@ -35,6 +35,11 @@ extern "C" {
 #define PFRL_MAX_STACK 8
 
 #define PFRL_OPT_MAX_TENSORS 24
+
+/* how np.float32 ** alpha of the priority transform is evaluated on the device */
+#define PFRL_POW_CORRECTLY_ROUNDED 0 /* (float)pow((double)x, alpha): <= 1 ulp from libm's powf */
+#define PFRL_POW_GLIBC 1             /* glibc 2.35 powf restated, separate multiply / add build */
+#define PFRL_POW_GLIBC_FMA 2         /* the same, fused multiply-add build (x86-64 -mfma ifunc) */
 #define PFRL_ERR_ARG (-2)
 
 int pfrl_amd_version(void);
@@ -205,12 +210,26 @@ int pfrl_tree_sample(const pfrl_tree_t *tree, int64_t B, const double *u01, int6
  * np.float32 errors resident on the device (|y-t| of DQN, dqn.py:447-454):
  * p = (clip(err, error_min, error_max) + eps) ** alpha with NEP-50 typing;
  * clipped values use the host-supplied constants (Python-float results of
- * (error_min + eps) ** alpha and (error_max + eps) ** alpha).
+ * (error_min + eps) ** alpha and (error_max + eps) ** alpha).  np.float32 ** alpha is libm's
+ * powf in the reference; pow_mode (PFRL_POW_*) selects its device restatement -- bit-exact
+ * leaves with the variant pfrl_powf_host_variant() reports for this host.
  * x must be unique unless dedupe != 0 (last occurrence wins). */
 int pfrl_tree_update_errors_f32(const pfrl_tree_t *tree, int64_t B, const int64_t *x,
                                 const float *err, int has_min, float error_min, double pri_at_min,
                                 int has_max, float error_max, double pri_at_max, double eps,
-                                double alpha, int dedupe, void *stream);
+                                double alpha, int dedupe, int pow_mode, void *stream);
+
+/* HOST helpers of the priority transform (no device work).  pfrl_powf_host evaluates the
+ * restated glibc powf (pow_mode PFRL_POW_GLIBC / _FMA) on host arrays; pfrl_powf_host_variant
+ * compares both restatements with THIS host's libm powf on n_probe pseudo-random inputs in
+ * (0, 2) plus the caller's alpha and returns the PFRL_POW_* mode that reproduces it bit for
+ * bit (the FMA build when both do), or -1 when neither does (callers then evaluate the power
+ * on the host, as NumPy does). */
+int pfrl_powf_host(int pow_mode, const float *host_x, float alpha, float *host_out, int64_t n);
+/* the same power as the update kernel evaluates per leaf, on device arrays (any PFRL_POW_*) */
+int pfrl_powf_device(int pow_mode, const float *x, float alpha, float *out, int64_t n,
+                     void *stream);
+int pfrl_powf_host_variant(float alpha, int64_t n_probe);
 
 /* PrioritizedBuffer.set_last_priority (pfrl/collections/prioritized.py:107-116) with
  * explicit typed priorities (host-computed, e.g. from Python-float errors): val/tag

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_DIR = os.path.join(_HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libpfrl_amd.so")
-SOURCES = ["frames.hip", "replay.hip", "sumtree.hip", "rollout.hip", "optim.hip", "tdloss.hip", "bias_act.hip", "noisy.hip", "c51.hip", "dueling.hip", "qnet.hip", "actor.hip"]
+SOURCES = ["frames.hip", "replay.hip", "sumtree.hip", "rollout.hip", "optim.hip", "tdloss.hip", "bias_act.hip", "noisy.hip", "c51.hip", "dueling.hip", "qnet.hip", "actor.hip", "hostplan.hip"]
 HIPCC_FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
     # the parity contract is one correctly rounded IEEE op per source op
@@ -36,7 +36,8 @@ def build(force=False, verbose=False):
     """Compile every HIP source for gfx950 and link libpfrl_amd.so (in-tree)."""
     os.makedirs(LIB_DIR, exist_ok=True)
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
-    deps = srcs + [os.path.join(CSRC, "common.h"),
+    deps = srcs + [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "powf_glibc.h"),
+                   os.path.join(CSRC, "nhwc.h"),
                    os.path.join(_HERE, "..", "include", "pfrl_amd.h")]
     if not force and os.path.exists(LIB_PATH):
         if all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
@@ -110,7 +111,10 @@ EXPORTS = {
     "pfrl_batch_experiences_nhwc4": (ctypes.c_int, "Tpqfpqpppppppp"),
     "pfrl_tree_write": (ctypes.c_int, "Rqppppp"),
     "pfrl_tree_sample": (ctypes.c_int, "Rqpppppppppidqpp"),
-    "pfrl_tree_update_errors_f32": (ctypes.c_int, "Rqppifdifdddip"),
+    "pfrl_tree_update_errors_f32": (ctypes.c_int, "Rqppifdifdddiip"),
+    "pfrl_powf_host": (ctypes.c_int, "ipfpq"),
+    "pfrl_powf_host_variant": (ctypes.c_int, "fq"),
+    "pfrl_powf_device": (ctypes.c_int, "ipfpqp"),
     "pfrl_tree_set_priorities": (ctypes.c_int, "Rqpppip"),
     "pfrl_gae_scan": (ctypes.c_int, "qqpppppddippp"),
     "pfrl_a2c_returns": (ctypes.c_int, "qqppppddip"),

@@ -253,13 +253,15 @@ class PrioritizedBuffer:
         self.sampled_indices = []
         self._n_sampled = 0
 
-    def update_errors_device(self, err, error_min, pri_at_min, error_max, pri_at_max, eps, alpha):
+    def update_errors_device(self, err, error_min, pri_at_min, error_max, pri_at_max, eps, alpha,
+                             pow_mode=0):
         """set_last_priority for f32 errors already on the device (DQN path)."""
         assert not self.wait_priority_after_sampling or self.flag_wait_priority
         assert self._n_sampled == err.numel()
         with on_stream(self.side_stream):
             ops.tree_update_errors_f32(self._sync_desc(), self._sampled_x, err, error_min,
-                                       pri_at_min, error_max, pri_at_max, eps, alpha, dedupe=True)
+                                       pri_at_min, error_max, pri_at_max, eps, alpha, dedupe=True,
+                                       pow_mode=pow_mode)
         self.flag_wait_priority = False
         self.sampled_indices = []
         self._n_sampled = 0

@@ -16,6 +16,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "powf_glibc.h"
 
 namespace {
 
@@ -154,6 +155,7 @@ struct ErrCfg {
     int has_min, has_max;
     float error_min, error_max;
     double pri_at_min, pri_at_max, eps, alpha;
+    int pow_mode;   // PFRL_POW_*
 };
 
 __global__ __launch_bounds__(kMaxBatch) void k_tree_update_errors(pfrl_tree_t T, int64_t B,
@@ -174,10 +176,17 @@ __global__ __launch_bounds__(kMaxBatch) void k_tree_update_errors(pfrl_tree_t T,
             p = mk_tv(c.pri_at_max, PFRL_TAG_PY);
         } else {
             const float s = __fadd_rn(e, (float)c.eps);
-            // np.float32 ** float -> powf(s, (float)alpha); evaluated here as the
-            // correctly rounded result (glibc powf differs by 1 ulp in ~0.05 % of
-            // inputs -- see DESIGN.md "priority transform").
-            p = mk_tv((double)(float)pow((double)s, (double)(float)c.alpha), PFRL_TAG_F32);
+            // np.float32 ** float -> powf(s, (float)alpha) of the host's libm: glibc's powf is
+            // not correctly rounded (1 ulp off in ~0.05 % of inputs), so it is restated
+            // operation by operation (powf_glibc.h) -- the leaves are the numbers NumPy gives.
+            float r;
+            if (c.pow_mode == PFRL_POW_GLIBC_FMA)
+                r = pfrl_powf::powf_glibc<true>(s, (float)c.alpha);
+            else if (c.pow_mode == PFRL_POW_GLIBC)
+                r = pfrl_powf::powf_glibc<false>(s, (float)c.alpha);
+            else   // PFRL_POW_CORRECTLY_ROUNDED (rounds 1 and 2)
+                r = (float)pow((double)s, (double)(float)c.alpha);
+            p = mk_tv((double)r, PFRL_TAG_F32);
         }
     }
     set_priorities_tail(T, B, x, p, dedupe, s_v, s_t, s_x);
@@ -664,8 +673,9 @@ extern "C" int pfrl_tree_update_errors_f32(const pfrl_tree_t *tree, int64_t B, c
                                            const float *err, int has_min, float error_min,
                                            double pri_at_min, int has_max, float error_max,
                                            double pri_at_max, double eps, double alpha, int dedupe,
-                                           void *stream) {
+                                           int pow_mode, void *stream) {
     PFRL_CHECK_ARG(tree && B <= kMaxBatch, "pfrl_tree_update_errors_f32: B must be <= 1024");
+    PFRL_CHECK_ARG(pow_mode >= 0 && pow_mode <= 2, "pfrl_tree_update_errors_f32: bad pow_mode");
     if (B <= 0) return 0;
     ErrCfg c;
     c.has_min = has_min;
@@ -676,9 +686,37 @@ extern "C" int pfrl_tree_update_errors_f32(const pfrl_tree_t *tree, int64_t B, c
     c.pri_at_max = pri_at_max;
     c.eps = eps;
     c.alpha = alpha;
+    c.pow_mode = pow_mode;
     int threads = (int)((B + 63) / 64 * 64);
     hipLaunchKernelGGL(k_tree_update_errors, dim3(1), dim3(threads), 0, (hipStream_t)stream, *tree,
                        B, x, err, c, dedupe);
+    PFRL_LAUNCH_CHECK();
+}
+
+// the priority transform's power on plain arrays (what k_tree_update_errors evaluates per
+// leaf): parity tests sweep it over millions of float32 values
+__global__ __launch_bounds__(256) void k_powf(int pow_mode, const float *__restrict__ x, float alpha,
+                                              float *__restrict__ out, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float s = x[i];
+    float r;
+    if (pow_mode == PFRL_POW_GLIBC_FMA)
+        r = pfrl_powf::powf_glibc<true>(s, alpha);
+    else if (pow_mode == PFRL_POW_GLIBC)
+        r = pfrl_powf::powf_glibc<false>(s, alpha);
+    else
+        r = (float)pow((double)s, (double)alpha);
+    out[i] = r;
+}
+
+extern "C" int pfrl_powf_device(int pow_mode, const float *x, float alpha, float *out, int64_t n,
+                                void *stream) {
+    PFRL_CHECK_ARG(x && out && n >= 0, "pfrl_powf_device: null argument");
+    PFRL_CHECK_ARG(pow_mode >= 0 && pow_mode <= 2, "pfrl_powf_device: bad pow_mode");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(k_powf, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       pow_mode, x, alpha, out, n);
     PFRL_LAUNCH_CHECK();
 }
 

@@ -5,6 +5,7 @@ computation happens in the hand-written gfx950 kernels of pfrl_amd/csrc.
 """
 import ctypes
 
+import numpy as np
 import torch
 
 from pfrl_amd import _native
@@ -182,13 +183,46 @@ def tree_sample(desc, u01, out, normalize, beta, slot_mod=0):
     return out
 
 
+POW_CORRECTLY_ROUNDED, POW_GLIBC, POW_GLIBC_FMA = 0, 1, 2   # PFRL_POW_* of include/pfrl_amd.h
+_powf_variant_cache = {}
+
+
+def powf_host_variant(alpha, n_probe=1 << 18):
+    """Which restatement of glibc's powf (POW_GLIBC / POW_GLIBC_FMA) reproduces THIS host's
+    libm bit for bit -- i.e. what ``np.float32(x) ** alpha`` gives here -- or None if neither
+    does (a libm that is not glibc's).  Probed once per alpha."""
+    key = float(np.float32(alpha))
+    if key not in _powf_variant_cache:
+        v = _native.lib().pfrl_powf_host_variant(key, int(n_probe))
+        _powf_variant_cache[key] = None if v < 0 else int(v)
+    return _powf_variant_cache[key]
+
+
+def powf_host(x, alpha, pow_mode):
+    """The restated powf on a host float32 array (tests)."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    out = np.empty_like(x)
+    check(_native.lib().pfrl_powf_host(int(pow_mode), x.ctypes.data, float(np.float32(alpha)),
+                                       out.ctypes.data, x.size), "powf_host")
+    return out
+
+
+def powf_device(x, alpha, pow_mode):
+    """The update kernel's power on a float32 device tensor (tests)."""
+    x = x.contiguous()
+    out = torch.empty_like(x)
+    check(_native.lib().pfrl_powf_device(int(pow_mode), _ptr(x), float(np.float32(alpha)), _ptr(out),
+                                         x.numel(), _stream()), "powf_device")
+    return out
+
+
 def tree_update_errors_f32(desc, x, err, error_min, pri_at_min, error_max, pri_at_max, eps, alpha,
-                           dedupe=True):
+                           dedupe=True, pow_mode=POW_CORRECTLY_ROUNDED):
     check(_native.lib().pfrl_tree_update_errors_f32(
         ctypes.byref(desc), x.numel(), _ptr(x), _ptr(err),
         int(error_min is not None), float(error_min or 0.0), float(pri_at_min or 0.0),
         int(error_max is not None), float(error_max or 0.0), float(pri_at_max or 0.0),
-        float(eps), float(alpha), int(dedupe), _stream()), "tree_update_errors_f32")
+        float(eps), float(alpha), int(dedupe), int(pow_mode), _stream()), "tree_update_errors_f32")
 
 
 def tree_set_priorities(desc, x, val, tag, dedupe=True):

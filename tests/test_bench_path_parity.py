@@ -171,13 +171,14 @@ def test_dqn_bench_path_minibatches_match_oracle():
     assert any(k[0] == "range" for k in agent._graphed.graphs)   # the path bench.py times
 
 
-def test_rainbow_bench_path_tree_matches_oracle():
+@pytest.mark.parametrize("priority_pow", ["device", "host_libm"])
+def test_rainbow_bench_path_tree_matches_oracle(priority_pow):
     """BASELINE configs[2] as bench.py builds it (CategoricalDoubleDQN, 256 envs, PER n = 3,
     normalize_by_max='memory', replay stream on): every sample's indices and importance
     weights and the tree's root sum / min / max_priority after every update_errors equal
     ``OraclePrioritizedBuffer`` fed the same appends, the same uniform draws and the device's
-    TD errors.  priority_pow='host_libm' (bit-exact leaves; the bench's default 'device' mode
-    differs from NumPy's powf by <= 1 ulp in < 1 % of inputs, test_hip_kernels.py)."""
+    TD errors -- bit for bit in the mode ``bench.py --algo rainbow`` runs ('device': glibc's
+    powf restated in the update kernel, csrc/powf_glibc.h) and in 'host_libm'."""
     import bench
     import oracle
     from pfrl_amd.collections import prioritized as dev_pri
@@ -185,9 +186,17 @@ def test_rainbow_bench_path_tree_matches_oracle():
     dev = torch.device("cuda:0")
     N, CAP, START = 256, 3000, 1024
     args = _bench_args(algo="rainbow", capacity=CAP, frame_slots=3000 + 24 * N + 512, slack=1024,
-                       replay_start=START, priority_pow="host_libm")
+                       replay_start=START, priority_pow=priority_pow)
     agent, env, rbuf = bench.build_agent(args, dev, 0)
     assert agent._replay_stream is not None
+    assert rbuf.priority_pow == priority_pow
+    if priority_pow == "device":
+        # ... which is what `bench.py --algo rainbow` runs when no flag is given
+        saved, sys.argv = sys.argv, ["bench.py", "--algo", "rainbow"]
+        try:
+            assert bench.parse_args().priority_pow == "device"
+        finally:
+            sys.argv = saved
     orc = oracle.OraclePrioritizedBuffer(CAP)
     counts = dict(samples=0, updates=0, appends=0)
     pending = {}
