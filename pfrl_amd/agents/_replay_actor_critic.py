@@ -227,7 +227,19 @@ class ReplayActorCritic(AttributeSavingMixin, BatchAgent):
             self._captured = CapturedStep(self._update_core, self._graph_modules(),
                                           self._graph_optimizers(), self.device)
         tensors = {k: v for k, v in big.items() if isinstance(v, torch.Tensor)}
-        outs = self._captured.run_range(tensors, variants)
+        try:
+            outs = self._captured.run_range(tensors, variants)
+        except Exception:
+            # as in update(): a step that cannot be captured runs eagerly.  The variants (host
+            # counters) of this range are already decided, so the same updates run one by one.
+            if self._captured.graphs:
+                raise
+            self.logger.exception("HIP-graph capture of the env range failed; running eager")
+            self.use_graphs = False
+            self._captured = None
+            for p, v in enumerate(variants):
+                self._update_impl({k: t[p] for k, t in tensors.items()}, v)
+            return
         # The graph owns (and overwrites) its outputs.  One stacked copy per run of updates
         # with the same statistics layout (64 separate clones were 64 x 32 us of host-paced
         # copies per step), recorded name by name in update order.

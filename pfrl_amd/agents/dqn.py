@@ -760,14 +760,25 @@ class DQN(agent.AttributeSavingMixin, agent.BatchAgent):
         if big is not None and self._range_as_one_graph(t0, hi - lo):
             # nothing happens on the host between this range's updates (no target sync
             # inside it): the whole range replays as ONE captured graph
-            self.t += hi - lo
-            self._cumulative_steps += hi - lo
-            losses, ys = self._graphed.run_range(big)
-            # graph-owned outputs: the next replay overwrites them
-            self.loss_record.extend(losses.clone())
-            self.q_record.extend(ys.clone())
-            self.optim_t += len(plan_env)
-            return
+            try:
+                losses, ys = self._graphed.run_range(big)
+            except Exception as e:
+                # a model / optimizer that cannot be captured: as in _graphed_step, stay on the
+                # GPU without the range graph (the per-update path below has its own eager
+                # fallback).  The capture restored its snapshot; no counter has moved yet.
+                if self._graphed.graphs:
+                    raise
+                self.logger.warning("HIP-graph capture of an env range failed (%s); updating "
+                                    "one minibatch at a time", e)
+                self.range_graphs = False
+            else:
+                self.t += hi - lo
+                self._cumulative_steps += hi - lo
+                # graph-owned outputs: the next replay overwrites them
+                self.loss_record.extend(losses.clone())
+                self.q_record.extend(ys.clone())
+                self.optim_t += len(plan_env)
+                return
         p = 0
         deferred = [] if self.use_graphs else None
         # A range that normally replays as one graph but has a target sync inside it this

@@ -187,15 +187,19 @@ def recognise_phi(phi, sample_obs):
     d = _scale_of(x, y)
     if d is None and np.any(x != 0):
         return None
-    if np.issubdtype(x.dtype, np.integer):
-        info = np.iinfo(x.dtype)
-        probe = (np.arange(x.size, dtype=np.int64) * 7919 % (int(info.max) - int(info.min) + 1)
-                 + int(info.min)).astype(x.dtype).reshape(x.shape)
-    elif x.size == 1:
-        probe = np.full(x.shape, 1000.0, dtype=x.dtype)
-    else:
-        probe = np.linspace(-1000.0, 1000.0, x.size).astype(x.dtype).reshape(x.shape)
     try:
+        if np.issubdtype(x.dtype, np.integer):
+            # the dtype's range, clamped to a 2^31 span (an int64 / uint64 span is 2^64 and
+            # overflows the modulus; wide ranges say nothing more about a cast / scale phi)
+            info = np.iinfo(x.dtype)
+            lo = max(int(info.min), -(1 << 30))
+            span = min(int(info.max), (1 << 30) - 1) - lo + 1
+            probe = (np.arange(x.size, dtype=np.int64) * 7919 % span + lo).astype(
+                x.dtype).reshape(x.shape)
+        elif x.size == 1:
+            probe = np.full(x.shape, 1000.0, dtype=x.dtype)
+        else:
+            probe = np.linspace(-1000.0, 1000.0, x.size).astype(x.dtype).reshape(x.shape)
         dp = _scale_of(probe, np.asarray(phi(probe)))
     except Exception:
         return d    # phi only accepts its own observation type: the sample decides

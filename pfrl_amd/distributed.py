@@ -10,6 +10,7 @@ is per-link bound, and at this size the collective is latency dominated -- one
 call is better than per-parameter buckets.
 """
 import os
+import weakref
 
 import torch
 import torch.distributed as dist
@@ -56,7 +57,7 @@ def shard_envs(num_envs, rank=None, world=None):
 
 
 # reducers that take early per-tensor all-reduces; gradient producers call announce_grad()
-_EARLY_REDUCERS = []
+_EARLY_REDUCERS = weakref.WeakSet()
 # set by a graph capture that wants collectives captured with it (graphed_update.py)
 _CAPTURE_COLLECTIVES = [False]
 
@@ -65,7 +66,7 @@ def announce_grad(param, grad):
     """Called by a gradient producer (pfrl_amd/nn/mfma_trunk.py backward) right after the
     launch that completes ``grad`` of ``param``: any data-parallel reducer that wants this
     tensor early starts its all-reduce now.  Free when no process group exists."""
-    for r in _EARLY_REDUCERS:
+    for r in list(_EARLY_REDUCERS):
         target = param
         if id(param) not in r._early:
             # the producer may hold another Python object for the same storage
@@ -103,10 +104,35 @@ class GradientAllReducer:
         self._pending = {}      # id(param) -> (work handle or None, gradient tensor)
         self._hooks = []
         if self._early and self.active():
-            _EARLY_REDUCERS.append(self)
+            # weak registration: a reducer lives as long as its agent does (evaluation copies,
+            # re-created agents and tests must not leave reducers behind that announce_grad
+            # would keep scanning), and the hooks hold the reducer weakly for the same reason
+            _EARLY_REDUCERS.add(self)
+            ref = weakref.ref(self)
+
+            def on_accumulated(p, ref=ref):
+                r = ref()
+                if r is not None:
+                    r._on_accumulated(p)
+
             for p in self._early.values():
                 if hasattr(p, "register_post_accumulate_grad_hook"):
-                    self._hooks.append(p.register_post_accumulate_grad_hook(self._on_accumulated))
+                    self._hooks.append(p.register_post_accumulate_grad_hook(on_accumulated))
+
+    def close(self):
+        """Detach from the early-announcement registry and remove the gradient hooks."""
+        _EARLY_REDUCERS.discard(self)
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+        self._pending = {}
+
+    def __del__(self):
+        try:
+            for h in self._hooks:
+                h.remove()
+        except Exception:
+            pass
 
     def active(self):
         return dist.is_available() and dist.is_initialized()

@@ -165,12 +165,19 @@ class FusedAdam(torch.optim.Adam):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        # decide for ALL groups before launching anything: a mix of fusable and non-fusable
+        # groups takes torch's step as a whole (launching some groups here and then calling
+        # super().step() would step those groups twice)
+        work = []
         for group in self.param_groups:
             params = [p for p in group["params"] if p.grad is not None]
             if not params:
                 continue
             if not self._fusable(group, params) or not self._prepare_state(group, params):
-                return super().step(closure=None) if loss is None else loss
+                super().step(closure=None)
+                return loss
+            work.append((group, params))
+        for group, params in work:
             self._launch(group, params, [self.state[p] for p in params])
         return loss
 

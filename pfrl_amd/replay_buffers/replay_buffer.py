@@ -270,11 +270,19 @@ class ReplayBuffer(replay_buffer.AbstractReplayBuffer):
         returns a dict of tensors with a leading "update" dimension."""
         return self.store.fetch_many(seq_sets, phi, gamma)
 
-    def save(self, filename, native=False):
-        """Reference-compatible pickle of the queue (replay_buffer.py:85-88) by
-        default -- device observations are read back and materialised; with
-        ``native=True`` a compact torch checkpoint of the HBM tables and only
-        the live frames (see :meth:`load`, which recognises both)."""
+    def save(self, filename, native=False, materialize=False):
+        """Reference-compatible pickle of the queue (replay_buffer.py:85-88).
+
+        Host back-end: the stored entries as they are (a plain deque of the entry lists), so
+        pickle's memo keeps what the reference's own ``save`` keeps -- one dict per transition
+        however many n-step windows hold it, one array per frame however many LazyFrames share
+        it.  ``materialize=True`` writes observations as NumPy arrays instead (one per distinct
+        observation object): a file without any class of the observation's package, which the
+        reference reads with nothing else installed, at 4x the size for frame stacks.
+
+        Device back-end: observations are read back from HBM and always materialised (one array
+        per distinct observation); with ``native=True`` a compact torch checkpoint of the HBM
+        tables and only the live frames instead (see :meth:`load`, which recognises both)."""
         self._ensure_bound()
         if self.store is not None:
             self.store.flush()
@@ -288,24 +296,57 @@ class ReplayBuffer(replay_buffer.AbstractReplayBuffer):
                 # reference pickles it (replay_buffer.py:85-88)
                 pickle.dump(self.memory, f)
             else:
-                pickle.dump(self._portable_queue(), f)
+                pickle.dump(self._portable_queue(materialize), f)
 
-    def _portable_queue(self):
+    def _portable_queue(self, materialize=False):
         """The queue as a plain ``collections.deque`` of n-step entries (lists of transition
-        dicts) whose observations are NumPy arrays: no class of this package appears in the
-        pickle, so the reference's ``ReplayBuffer.load`` reads it as it reads its own v0.2
-        files (pfrl/replay_buffers/replay_buffer.py:89-94 wraps a deque into its
-        RandomAccessQueue) without pfrl_amd installed.  Device observations are read back
-        from HBM; host LazyFrames are materialised."""
+        dicts), which the reference's ``ReplayBuffer.load`` reads as it reads its own v0.2 files
+        (pfrl/replay_buffers/replay_buffer.py:89-94 wraps a deque into its RandomAccessQueue).
+        Shared objects stay shared: a transition dict / observation is converted once, whatever
+        number of entries refer to it."""
+        if self.store is None and not materialize:
+            return collections.deque(iter(self.memory), maxlen=self.capacity)
+        obs_memo, trans_memo = {}, {}
+
+        def array_of(obs):
+            if obs is None or isinstance(obs, (np.ndarray, tuple)):
+                return obs
+            key = (tuple(int(r) for r in obs.refs), int(obs.min_seq)) if hasattr(obs, "refs") \
+                else id(obs)
+            hit = obs_memo.get(key)
+            if hit is None:
+                hit = obs_memo[key] = (obs, np.asarray(obs))     # (keeps id() keys alive)
+            return hit[1]
+
         def plain(t):
             d = dict(t)
             for key in ("state", "next_state"):
-                if d.get(key) is not None and not isinstance(d[key], (np.ndarray, tuple)):
-                    d[key] = np.asarray(d[key])
+                d[key] = array_of(d.get(key))
             return d
 
-        return collections.deque(([plain(t) for t in entry] for entry in self.memory),
-                                 maxlen=self.capacity)
+        out = collections.deque(maxlen=self.capacity)
+        if self.store is None:
+            for entry in self.memory:
+                row = []
+                for t in entry:
+                    d = trans_memo.get(id(t))
+                    if d is None:
+                        d = trans_memo[id(t)] = (t, plain(t))
+                    row.append(d[1])
+                out.append(row)
+            return out
+        head = self.memory.head
+        for i in range(len(self.memory)):
+            slot = (head + i) % self.store.E
+            ln = int(self.store.h_e_len[slot])
+            entry = []
+            for tid in (int(t) for t in self.store.h_e_tids[slot][:ln]):
+                d = trans_memo.get(tid)
+                if d is None:
+                    d = trans_memo[tid] = plain(self.store.transition_view(tid))
+                entry.append(d)
+            out.append(entry)
+        return out
 
     def _native_state(self):
         return dict(kind="pfrl_amd.ReplayBuffer", capacity=self.capacity,
