@@ -65,6 +65,22 @@ int pfrl_frames_scatter(void *frames, int64_t frame_bytes, const void *src, cons
  * (seed, env_id0 + i, step). */
 int pfrl_frames_synth_u8(void *frames, int64_t frame_bytes, const int32_t *slots, int64_t n,
                          uint64_t seed, int64_t env_id0, int64_t step, void *stream);
+/* The same for a whole env batch taking consecutive ring positions: frame i goes to slot
+ * (seq0 + i) % n_slots, no slot list crosses PCIe. */
+int pfrl_frames_synth_u8_ring(void *frames, int64_t frame_bytes, int64_t n_slots, int64_t seq0,
+                              int64_t n, uint64_t seed, int64_t env_id0, int64_t step, void *stream);
+/* Rewards / dones of that env on the HOST (pure functions of (seed, env, t), same hash as
+ * pfrl_amd/envs/synthetic.py reward_done_stream; benchmark input only). */
+int pfrl_synth_reward_done(uint64_t seed, int64_t env_id0, int64_t n, int64_t t, double p_done,
+                           double *host_reward, uint8_t *host_done);
+
+/* select_action_epsilon_greedily (pfrl/explorers/epsilon_greedy.py:8-12) for a batch, with the
+ * greedy actions still on the device (int32 as DiscreteActionValue.greedy_actions yields them,
+ * pfrl/action_value.py:59-61, or int64): out[i] = choice[i] >= 0 ? choice[i] : greedy[i], where
+ * choice holds the host's draws (pfrl_plan_eps_greedy; -1 = the draw said "greedy").  The
+ * actions never have to visit the host (DQN.batch_act, pfrl/agents/dqn.py:490-507). */
+int pfrl_select_actions(const void *greedy, int greedy_is_i32, const int32_t *choice, int64_t *out,
+                        int64_t n, void *stream);
 
 /* batch_states(states, device, phi) with phi(x) = asarray(x, float32) / divisor
  * (pfrl/utils/batch_states.py:18-36; examples/atari/train_dqn_batch_ale.py:
@@ -549,6 +565,63 @@ int pfrl_sac_policy_loss_fwd(const float *log_prob, const float *q1, const float
 int pfrl_sac_policy_loss_bwd(const float *g_loss, const float *q1, const float *q2,
                              const float *log_temperature, float temperature, float *g_log_prob,
                              float *g_q1, float *g_q2, int32_t B, void *stream);
+
+/* ------------------------------------------------------------------------
+ * HOST step planner (no device work; every pointer is host memory).  The reference's batched
+ * step consumes NumPy's legacy global stream in a fixed order (pfrl/agents/dqn.py:490-549):
+ * per env rand() [+ randint(n_actions)] in batch_act (pfrl/explorers/epsilon_greedy.py:8-12),
+ * then per env append and, when due, n_times_update x sample_n_k(len, B)
+ * (pfrl/replay_buffer.py:329-356, pfrl/utils/random.py:4-28).  These entry points make exactly
+ * those draws on NumPy's own generator: `bitgen` is the `bitgen_t *` NumPy publishes
+ * (numpy/random/bitgen.h; np.random.mtrand._rand._bit_generator.ctypes.bit_generator), so the
+ * stream position before and after is that of the Python loop. */
+
+/* host mirrors and geometry of a device replay store with one-step entries
+ * (pfrl_amd/replay_buffers/device_replay.py); arrays are the store's NumPy mirrors */
+typedef struct {
+    int32_t *h_state_ref;   /* [R][k] */
+    int32_t *h_next_ref;    /* [R][k] */
+    double *h_reward;       /* [R] */
+    uint8_t *h_terminal;    /* [R] */
+    int64_t *h_min_fseq;    /* [R] oldest frame sequence number a transition references */
+    int64_t *h_e_tids;      /* [E][n] absolute transition ids */
+    int32_t *h_e_len;       /* [E] */
+    int64_t *h_e_min_fseq;  /* [E] */
+    int64_t R, E;           /* ring sizes of the transition / entry tables */
+    int64_t maxlen;         /* ReplayBuffer capacity, -1 = unbounded */
+    int64_t bound;          /* device allocation of an unbounded buffer */
+    int32_t k, n;           /* frames per observation, num_steps (must be 1) */
+} pfrl_host_store_t;
+
+#define PFRL_PLAN_DENSE (-10)      /* 3 B >= len: np.random.choice(replace=False) regime; nothing
+                                      was drawn or written, take the Python path */
+#define PFRL_PLAN_OVERFLOW (-11)   /* unbounded buffer beyond its allocation */
+#define PFRL_PLAN_FRAME_RING (-12) /* a sampled entry's frames were overwritten: fatal */
+
+/* sample_n_k(n, k), sparse regime 3 k < n (pfrl/utils/random.py:13-28): k distinct indices. */
+int pfrl_plan_sample_n_k(void *bitgen, int64_t n, int32_t k, int64_t *host_out);
+
+/* n_envs x select_action_epsilon_greedily with random_action_func = np.random.randint(n_actions):
+ * host_choice[i] = the random action, or -1 where the draw chose the greedy action. */
+int pfrl_plan_eps_greedy(void *bitgen, int64_t n_envs, double epsilon, int64_t n_actions,
+                         int32_t *host_choice);
+
+/* The per-env loop of DQN._batch_observe_train (pfrl/agents/dqn.py:516-549) for m envs of one
+ * batched step with a uniform one-step ReplayBuffer: m appends (transition + entry rows, host
+ * mirrors updated, RandomAccessQueue head advanced) and every index set the loop draws between
+ * them.  counters = {n_trans, n_entries, head} in / out; t0 = agent.t before the first env.
+ * Everything the device needs goes into ONE pinned block (host_block; offs[0..8] = byte
+ * offsets of t_slots i32[m], state_ref i32[m][k], next_ref i32[m][k], reward f64[m], terminal
+ * u8[m], e_slots i32[m], e_tids i32[m], e_len i32[m], sampled entry slots i32[U][B];
+ * offs[9] = bytes used).  Returns U = number of index sets drawn (>= 0) or a negative
+ * PFRL_PLAN_* / PFRL_ERR_ARG code. */
+int64_t pfrl_plan_dqn_range(const pfrl_host_store_t *st, void *bitgen, int64_t m,
+                            const int32_t *s_refs, const int64_t *s_min_seq, const int32_t *n_refs,
+                            const int64_t *n_min_seq, const double *reward, const uint8_t *done,
+                            int64_t t0, int64_t replay_start, int64_t update_interval,
+                            int32_t n_times_update, int32_t B, int64_t oldest_live_fseq,
+                            int64_t *counters, uint8_t *host_block, int64_t block_bytes,
+                            int64_t *offs);
 
 /* ------------------------------------------------------------------------
  * Measurement support (bench.py roofline): time every pfrl_batch_experiences

@@ -76,6 +76,27 @@ class TableDesc(ctypes.Structure):
     ]
 
 
+class HostStoreDesc(ctypes.Structure):
+    """pfrl_host_store_t"""
+
+    _fields_ = [
+        ("h_state_ref", ctypes.c_void_p),
+        ("h_next_ref", ctypes.c_void_p),
+        ("h_reward", ctypes.c_void_p),
+        ("h_terminal", ctypes.c_void_p),
+        ("h_min_fseq", ctypes.c_void_p),
+        ("h_e_tids", ctypes.c_void_p),
+        ("h_e_len", ctypes.c_void_p),
+        ("h_e_min_fseq", ctypes.c_void_p),
+        ("R", ctypes.c_int64),
+        ("E", ctypes.c_int64),
+        ("maxlen", ctypes.c_int64),
+        ("bound", ctypes.c_int64),
+        ("k", ctypes.c_int32),
+        ("n", ctypes.c_int32),
+    ]
+
+
 class TreeDesc(ctypes.Structure):
     """pfrl_tree_t"""
 
@@ -102,6 +123,12 @@ EXPORTS = {
     "pfrl_amd_last_error": (ctypes.c_char_p, []),
     "pfrl_frames_scatter": (ctypes.c_int, "pqppqp"),
     "pfrl_frames_synth_u8": (ctypes.c_int, "pqpqQqqp"),
+    "pfrl_frames_synth_u8_ring": (ctypes.c_int, "pqqqqQqqp"),
+    "pfrl_synth_reward_done": (ctypes.c_int, "Qqqqdpp"),
+    "pfrl_select_actions": (ctypes.c_int, "pippqp"),
+    "pfrl_plan_sample_n_k": (ctypes.c_int, "pqip"),
+    "pfrl_plan_eps_greedy": (ctypes.c_int, "pqdqp"),
+    "pfrl_plan_dqn_range": (ctypes.c_int64, "HpqpppppPqqqiiqppqp"),
     "pfrl_batch_states_u8": (ctypes.c_int, "pqpqfpp"),
     "pfrl_batch_states_u8_nhwc4": (ctypes.c_int, "pqpqfpp"),
     "pfrl_batch_states_f32": (ctypes.c_int, "pqpqpp"),
@@ -164,6 +191,7 @@ _CODES = {
     "p": ctypes.c_void_p, "q": ctypes.c_int64, "Q": ctypes.c_uint64, "i": ctypes.c_int,
     "f": ctypes.c_float, "d": ctypes.c_double,
     "T": ctypes.POINTER(TableDesc), "R": ctypes.POINTER(TreeDesc),
+    "H": ctypes.POINTER(HostStoreDesc), "P": ctypes.c_void_p,
 }
 
 _lib = None

@@ -219,6 +219,10 @@ class DQN(agent.AttributeSavingMixin, agent.BatchAgent):
         self._target_raw_bufs = {}
         self._single_bufs = {}
         self.range_graphs = os.environ.get("PFRL_RANGE_GRAPHS", "1") != "0"
+        # no-host-round-trip step for device envs (agents/_dqn_device_step.py)
+        self.device_step = (on_gpu and self.step_fused_gather
+                            and os.environ.get("PFRL_DEVICE_STEP", "1") != "0")
+        self._last_actions_dev = None
         self._analytic_backward = None
         self._graphed = None
         self._last_y = None
@@ -605,6 +609,15 @@ class DQN(agent.AttributeSavingMixin, agent.BatchAgent):
             self.replay_buffer.current_wait_replay_stream()
         if self.training:
             batch_obs = self._host_batch_to_device(batch_obs)
+            if self.device_step:
+                # device env + uniform device replay: draws by the native planner, actions stay
+                # in HBM, no D2H inside the step (agents/_dqn_device_step.py)
+                from pfrl_amd.agents import _dqn_device_step
+
+                out = _dqn_device_step.act(self, batch_obs)
+                if out is not None:
+                    return out
+            self._last_actions_dev = None
         with torch.no_grad(), evaluating(self.model):
             batch_av = self._evaluate_model(batch_obs)
             greedy_dev = batch_av.greedy_actions.detach()
@@ -696,6 +709,10 @@ class DQN(agent.AttributeSavingMixin, agent.BatchAgent):
         overwrite entries still visible to an earlier update of this step."""
         rbuf = self.replay_buffer
         n_env = len(batch_obs)
+        if self.device_step:
+            from pfrl_amd.agents import _dqn_device_step
+
+            _dqn_device_step.begin_observe(self, batch_obs, batch_reward, batch_done, batch_reset)
         # The step is processed in a few env ranges, a small one first: while the GPU
         # runs the first range's updates the host prepares the next range (appends,
         # index draws, launches), instead of the GPU idling through the whole
@@ -710,7 +727,16 @@ class DQN(agent.AttributeSavingMixin, agent.BatchAgent):
         up = self.replay_updater
         t0 = self.t
         plan_env, plan_seqs = [], []
-        if self._batched_append_ok(lo, hi, batch_obs):
+        native = None
+        if self.device_step and self.__dict__.get("_obs_cols") is not None:
+            from pfrl_amd.agents import _dqn_device_step
+
+            native = _dqn_device_step.plan_range(self, lo, hi, batch_obs)
+        if native is not None:
+            # appends, queue bookkeeping and every index set of the range came from ONE native
+            # call and ONE transfer (same NumPy stream use as the loops below)
+            plan_env, slots_dev, U = native
+        elif self._batched_append_ok(lo, hi, batch_obs):
             # the per-env loop below as array writes: every env of the range has a pending
             # transition, entries are one transition long, so len(buffer) and the queue head at
             # each point of the loop are known in advance and the index draws (same NumPy
@@ -740,7 +766,11 @@ class DQN(agent.AttributeSavingMixin, agent.BatchAgent):
                     for _ in range(up.n_times_update):
                         plan_env.append(i)
                         plan_seqs.append(rbuf.lookahead_sample(up.batchsize))
-        big = rbuf.fetch_many(plan_seqs, self.phi, self.gamma) if plan_seqs else None
+        if native is not None:
+            big = rbuf.store.fetch_many_slots(slots_dev, U, up.batchsize, self.phi,
+                                              self.gamma) if U else None
+        else:
+            big = rbuf.fetch_many(plan_seqs, self.phi, self.gamma) if plan_seqs else None
         if big is not None and self.batch_target_pass and self._target_is_deterministic():
             # no target sync may fall inside this range (the targets would go stale)
             tui = self.target_update_interval

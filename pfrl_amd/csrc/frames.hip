@@ -134,13 +134,17 @@ __device__ __forceinline__ uint64_t mix64(uint64_t z) {
     return z ^ (z >> 31);
 }
 
+// slots == nullptr: frame f goes to ring position (seq0 + f) % n_slots (a whole env batch takes
+// consecutive positions, so the host need not upload a slot list)
 __global__ __launch_bounds__(kThreads) void k_frames_synth(uint8_t *__restrict__ frames,
                                                            int64_t frame_bytes,
                                                            const int32_t *__restrict__ slots,
+                                                           int64_t seq0, int64_t n_slots,
                                                            uint64_t seed, int64_t env_id0,
                                                            int64_t step) {
     const int64_t f = blockIdx.x;
-    uint2 *d = reinterpret_cast<uint2 *>(frames + (int64_t)slots[f] * frame_bytes);
+    const int64_t slot = slots ? (int64_t)slots[f] : (seq0 + f) % n_slots;
+    uint2 *d = reinterpret_cast<uint2 *>(frames + slot * frame_bytes);
     const int nq = (int)(frame_bytes >> 3);
     const uint64_t key = mix64(seed ^ mix64((uint64_t)(env_id0 + f) * 0x9e3779b97f4a7c15ull +
                                             (uint64_t)step));
@@ -172,7 +176,46 @@ extern "C" int pfrl_frames_synth_u8(void *frames, int64_t frame_bytes, const int
     PFRL_CHECK_ARG(frame_bytes > 0 && (frame_bytes & 3) == 0, "frame_bytes must be a multiple of 4");
     if (n <= 0) return 0;
     hipLaunchKernelGGL(k_frames_synth, dim3((unsigned)n), dim3(kThreads), 0, (hipStream_t)stream,
-                       (uint8_t *)frames, frame_bytes, slots, seed, env_id0, step);
+                       (uint8_t *)frames, frame_bytes, slots, (int64_t)0, (int64_t)1, seed, env_id0,
+                       step);
+    PFRL_LAUNCH_CHECK();
+}
+
+extern "C" int pfrl_frames_synth_u8_ring(void *frames, int64_t frame_bytes, int64_t n_slots,
+                                         int64_t seq0, int64_t n, uint64_t seed, int64_t env_id0,
+                                         int64_t step, void *stream) {
+    PFRL_CHECK_ARG(frame_bytes > 0 && (frame_bytes & 3) == 0, "frame_bytes must be a multiple of 4");
+    PFRL_CHECK_ARG(n_slots > 0 && seq0 >= 0 && n <= n_slots, "pfrl_frames_synth_u8_ring: bad ring");
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(k_frames_synth, dim3((unsigned)n), dim3(kThreads), 0, (hipStream_t)stream,
+                       (uint8_t *)frames, frame_bytes, (const int32_t *)nullptr, seq0, n_slots, seed,
+                       env_id0, step);
+    PFRL_LAUNCH_CHECK();
+}
+
+// epsilon-greedy on the device: action[i] = choice[i] >= 0 ? choice[i] : greedy[i]
+// (pfrl/explorers/epsilon_greedy.py:8-12 with the host's draws in `choice`, -1 = greedy)
+template <typename G>
+__global__ __launch_bounds__(kThreads) void k_select_actions(const G *__restrict__ greedy,
+                                                             const int32_t *__restrict__ choice,
+                                                             int64_t *__restrict__ out, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (i >= n) return;
+    const int32_t c = choice[i];
+    out[i] = c >= 0 ? (int64_t)c : (int64_t)greedy[i];
+}
+
+extern "C" int pfrl_select_actions(const void *greedy, int greedy_is_i32, const int32_t *choice,
+                                   int64_t *out, int64_t n, void *stream) {
+    PFRL_CHECK_ARG(greedy && choice && out, "pfrl_select_actions: null argument");
+    if (n <= 0) return 0;
+    const dim3 grid((unsigned)((n + kThreads - 1) / kThreads)), block(kThreads);
+    if (greedy_is_i32)
+        hipLaunchKernelGGL(k_select_actions<int32_t>, grid, block, 0, (hipStream_t)stream,
+                           (const int32_t *)greedy, choice, out, n);
+    else
+        hipLaunchKernelGGL(k_select_actions<int64_t>, grid, block, 0, (hipStream_t)stream,
+                           (const int64_t *)greedy, choice, out, n);
     PFRL_LAUNCH_CHECK();
 }
 

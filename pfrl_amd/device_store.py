@@ -131,6 +131,44 @@ class DeviceObsBatch:
         return self._refs_dev
 
 
+class DeviceActions:
+    """The actions of one batched step, resident on the device (int64 [N]).
+
+    What ``DQN.batch_act`` returns on the device fast path: epsilon-greedy is resolved on the
+    GPU from the host's draws (``ops.select_actions``), the replay append reads the action
+    column straight from this tensor, and nothing waits for a D2H copy.  A driver or env that
+    looks at the values (``env.step(actions)`` of a host env: indexing, iteration,
+    ``np.asarray``) gets them through ONE copy made on first use -- the reference's
+    ``batch_argmax = ....detach().cpu().numpy()`` (pfrl/agents/dqn.py:497), deferred."""
+
+    __slots__ = ("tensor", "_host")
+
+    def __init__(self, tensor):
+        self.tensor = tensor
+        self._host = None
+
+    def numpy(self):
+        if self._host is None:
+            self._host = self.tensor.cpu().numpy()
+        return self._host
+
+    def __len__(self):
+        return self.tensor.shape[0]
+
+    def __getitem__(self, i):
+        return self.numpy()[i]
+
+    def __iter__(self):
+        return iter(self.numpy())
+
+    def __array__(self, dtype=None, copy=None):
+        out = self.numpy()
+        return out.astype(dtype) if dtype is not None else out
+
+    def tolist(self):
+        return self.numpy().tolist()
+
+
 # ---------------------------------------------------------------------------
 # phi recognition
 # ---------------------------------------------------------------------------

@@ -84,9 +84,9 @@ class SyntheticAtariVectorEnv(_env.VectorEnv):
         n = len(idx)
         seqs, slots = self.store.alloc(n)
         if n == self.num_envs:
-            (slots_dev,) = self._stage.upload([slots])
-            ops.frames_synth_u8(self.store.frames, slots_dev, self.seed_value, self.env_id0,
-                                self.t)
+            # the whole batch takes consecutive ring positions: the kernel derives the slots
+            ops.frames_synth_u8_ring(self.store.frames, int(seqs[0]), n, self.seed_value,
+                                     self.env_id0, self.t)
         else:
             # subset (resets): one launch per contiguous run keeps env keys right
             (slots_dev,) = self._stage.upload([slots])
@@ -122,8 +122,21 @@ class SyntheticAtariVectorEnv(_env.VectorEnv):
         self.refs[:, -1] = slots
         self.seqs[:, :-1] = self.seqs[:, 1:]
         self.seqs[:, -1] = seqs
-        rewards, dones = reward_done_stream(self.seed_value, self.env_ids, self.t, self.p_done)
+        rewards, dones = self._reward_done()
         return self._obs(), rewards, dones, self._infos
+
+    def _reward_done(self):
+        """``reward_done_stream`` for this env batch, evaluated natively on the host (same
+        hash; tests/test_host_plan.py compares the two)."""
+        from pfrl_amd import _native
+
+        n = self.num_envs
+        rewards = np.empty(n, dtype=np.float64)
+        dones = np.empty(n, dtype=np.bool_)
+        _native.check(_native.lib().pfrl_synth_reward_done(
+            self.seed_value % (1 << 64), self.env_id0, n, self.t, float(self.p_done),
+            rewards.ctypes.data, dones.ctypes.data), "synth_reward_done")
+        return rewards, dones
 
 
 class HostLazyFrames(object):

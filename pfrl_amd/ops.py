@@ -40,6 +40,24 @@ def frames_synth_u8(frames, slots, seed, env_id0, step):
           "frames_synth_u8")
 
 
+def frames_synth_u8_ring(frames, seq0, n, seed, env_id0, step):
+    """n fresh frames at ring positions seq0 .. seq0 + n - 1 (mod n_slots): no slot upload."""
+    check(_native.lib().pfrl_frames_synth_u8_ring(_ptr(frames), frame_bytes_of(frames),
+                                                  frames.shape[0], int(seq0), int(n), seed,
+                                                  env_id0, step, _stream()), "frames_synth_u8_ring")
+
+
+def select_actions(greedy, choice, out=None):
+    """out[i] = choice[i] >= 0 ? choice[i] : greedy[i] (epsilon-greedy with the host's draws)."""
+    assert greedy.dtype in (torch.int32, torch.int64) and choice.dtype == torch.int32
+    if out is None:
+        out = torch.empty(greedy.shape, dtype=torch.int64, device=greedy.device)
+    check(_native.lib().pfrl_select_actions(_ptr(greedy), int(greedy.dtype == torch.int32),
+                                            _ptr(choice), _ptr(out), greedy.numel(), _stream()),
+          "select_actions")
+    return out
+
+
 def _spatial_hw(fshape):
     """(H, W) if the frame is one 2-D plane ((H, W) or (1, H, W)), else None."""
     dims = [d for d in fshape]

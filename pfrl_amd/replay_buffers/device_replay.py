@@ -72,6 +72,8 @@ class DeviceReplayStore:
         self._pend_frames = []
         self._pend_frame_slots = []
         self._out_cache = {}
+        self._many_views = {}
+        self.h_action_stale = False
         # optional replay stream (DQN + PER pipelining, see set_side_stream)
         self.side_stream = None
         self.double_buffer = False
@@ -599,8 +601,35 @@ class DeviceReplayStore:
                                   gp, flat)
         return {k: v.view((U, B) + tuple(v.shape[1:])) for k, v in flat.items()}
 
+    def fetch_many_slots(self, slots_dev, U, B, phi, gamma):
+        """``fetch_many`` for entry slots that are already on the device (planned natively,
+        liveness checked by the planner): the one fused gather, [U, B, ...] views."""
+        self.flush()
+        flat = self._out_buffers(U * B, "many")
+        gp = [gamma ** i for i in range(self.n + 1)]
+        with on_stream(self.side_stream):
+            ops.batch_experiences(self.desc, self.frames.frames, self.divisor_for(phi), slots_dev,
+                                  gp, flat)
+        key = (U, B, id(flat))
+        views = self._many_views.get(key)
+        if views is None or views[0] is not flat:
+            if len(self._many_views) > 16:
+                self._many_views.clear()
+            views = self._many_views[key] = (
+                flat, {k: v.view((U, B) + tuple(v.shape[1:])) for k, v in flat.items()})
+        return dict(views[1])
+
+    def _sync_actions(self):
+        """The native append path leaves the action column on the device only; host views
+        (entry_view, save) read it back once."""
+        if self.h_action_stale:
+            self.flush()
+            self.h_action[...] = self.t_action.cpu().numpy()
+            self.h_action_stale = False
+
     # -- API-compatible host views ---------------------------------------------
     def transition_view(self, tid, weight=None):
+        self._sync_actions()
         slot = tid % self.R
         store = self.frames
         d = dict(
@@ -635,6 +664,8 @@ class DeviceReplayStore:
         and the frames still referenced by live entries (only those are read back
         from HBM).  ``head_seq`` is the entry sequence number of logical index 0."""
         self.flush()
+        if self.desc is not None:
+            self._sync_actions()
         out = dict(version=1, n=self.n, k=self.k, act_dim=self.act_dim, bound=self.bound,
                    slack=self.slack, n_trans=self.n_trans, n_entries=self.n_entries,
                    extra=self.h_extra)

@@ -22,6 +22,35 @@ class StagingRing:
         self._events = [None] * n_slots
         self._i = 0
 
+    def reserve(self):
+        """Next pinned slot for the caller to fill in place: (numpy uint8 view, token).  Waits
+        for the slot's previous transfer.  Follow with :meth:`commit`."""
+        i = self._i
+        self._i = (i + 1) % self.n_slots
+        ev = self._events[i]
+        if ev is not None:
+            ev.synchronize()
+            self._events[i] = None
+        return self._host_np[i], i
+
+    def commit(self, token, nbytes):
+        """Ship the first ``nbytes`` of a reserved slot in ONE async transfer; returns the
+        device uint8 buffer of that slot (valid until the ring wraps)."""
+        i = token
+        total = (int(nbytes) + 15) & ~15
+        dev = self._dev[i]
+        dev[:total].copy_(self._host[i][:total], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._events[i] = ev
+        return dev
+
+    @staticmethod
+    def view(dev, offset, count, dtype, shape=None):
+        """Typed view of ``count`` elements at byte ``offset`` of a staged device buffer."""
+        t = dev[offset:offset + count * dtype.itemsize].view(dtype)
+        return t if shape is None else t.view(shape)
+
     def upload(self, arrays):
         """Copy a list of numpy arrays to the device in ONE async transfer.
         Returns device tensors viewing the staged bytes (valid until the ring

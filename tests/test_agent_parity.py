@@ -106,6 +106,17 @@ def _run(name, prioritized, num_steps, double, gpu, priority_pow="device", steps
             return seqs
 
         rbuf.lookahead_sample_at = spy_look_at
+        if getattr(rbuf, "store", None) is not None and hasattr(rbuf.store, "fetch_many_slots"):
+            # native step (agents/_dqn_device_step.py): index sets are drawn by the planner and
+            # arrive as entry ring slots on the device
+            orig_slots = rbuf.store.fetch_many_slots
+
+            def spy_slots(slots_dev, U, B, phi, gamma):
+                for row in slots_dev.cpu().numpy().reshape(U, B):
+                    note_sample([rbuf.store.entry_view(int(q)) for q in row])
+                return orig_slots(slots_dev, U, B, phi, gamma)
+
+            rbuf.store.fetch_many_slots = spy_slots
     _spy_losses(ag, losses)
     pfrl.experiments.train_agent_batch(ag, env, steps, tempfile.mkdtemp())
     params = np.concatenate([p.detach().cpu().numpy().ravel() for p in q.parameters()])

@@ -91,6 +91,19 @@ def test_dqn_bench_path_minibatches_match_oracle():
         return big
 
     rbuf.fetch_many = spy_fetch
+    # the native step (agents/_dqn_device_step.py) gathers from slots planned in C
+    orig_fetch_slots = rbuf.store.fetch_many_slots
+    native_calls = [0]
+
+    def spy_fetch_slots(slots_dev, U, B_, phi, g):
+        big = orig_fetch_slots(slots_dev, U, B_, phi, g)
+        native_calls[0] += 1
+        if keep[0]:
+            fetched.append({k: v.detach().cpu().numpy() for k, v in big.items()
+                            if k != "target_next_raw"})
+        return big
+
+    rbuf.store.fetch_many_slots = spy_fetch_slots
     losses = []
     orig_extend = agent.loss_record.extend
 
@@ -169,6 +182,11 @@ def test_dqn_bench_path_minibatches_match_oracle():
     assert st.n_entries > 3 * st.E and st.n_trans > 3 * st.R
     assert env.store.next_seq - frames_written0 > 2 * env.store.n_slots
     assert any(k[0] == "range" for k in agent._graphed.graphs)   # the path bench.py times
+    # ... including the native step: device-resident actions, planner-drawn index sets
+    from pfrl_amd.device_store import DeviceActions
+
+    assert agent.device_step and native_calls[0] > 150
+    assert isinstance(agent.batch_last_action.batch, DeviceActions)
 
 
 @pytest.mark.parametrize("priority_pow", ["device", "host_libm"])

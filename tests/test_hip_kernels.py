@@ -1246,3 +1246,18 @@ def test_unbounded_tree_with_popleft_bursts_matches_oracle(dev):
             got, so = buf.root_stats(), orc.stats()
             assert got[0] == so["sum"] and got[1] == so["min"], (seed, step)
             assert buf.frame.bounds == so["bounds"]
+
+
+@pytest.mark.parametrize("dtype", [torch.int32, torch.int64])
+def test_select_actions(dev, dtype):
+    """pfrl_select_actions: epsilon-greedy resolved on the device from the host's draws; the
+    greedy column is int32 (DiscreteActionValue.greedy_actions) or int64."""
+    from pfrl_amd import ops
+
+    rs = np.random.RandomState(0)
+    greedy = rs.randint(0, 18, size=1000)
+    choice = np.where(rs.rand(1000) < 0.3, rs.randint(0, 18, size=1000), -1).astype(np.int32)
+    out = ops.select_actions(torch.from_numpy(greedy).to(dev).to(dtype),
+                             torch.from_numpy(choice).to(dev))
+    assert out.dtype == torch.int64
+    np.testing.assert_array_equal(out.cpu().numpy(), np.where(choice >= 0, choice, greedy))
