@@ -26,6 +26,8 @@ stub = agents.DQN(q, opt, rbuf, gpu=0, gamma=0.99, explorer=agent.explorer, repl
                   target_update_interval=30000, update_interval=4, minibatch_size=32,
                   batch_accumulator="sum", phi=agent.phi)
 stub.t = agent.t
+if os.environ.get("FULL") == "1":
+    stub = agent      # the real network: where the host spends its time when the GPU is busy
 for _ in range(5):
     obss = bench.one_step(stub, env, obss, args.num_envs)
 pr = cProfile.Profile()
