@@ -70,7 +70,8 @@ def parse_args():
                    help="N > 1: weak = --num-envs envs on EVERY GPU; strong = --num-envs envs "
                         "sharded N/G per GPU as BASELINE.json's metric and SURVEY.md 8(e) describe "
                         "(default: strong)")
-    p.add_argument("--cpu-baseline-seconds", type=float, default=12.0)
+    p.add_argument("--cpu-baseline-seconds", type=float, default=14.0,
+                   help="end-to-end sample of the reference on this box's host cores")
     p.add_argument("--cpu-baseline-threads", type=int, default=16,
                    help="torch CPU threads for the baseline's network (capped by the host; at "
                         "B=32 the Nature CNN is slower with all 128 threads than with 16)")
@@ -542,6 +543,36 @@ def compute_roofline(algo, all_us, all_units, all_kinds):
     return roofline
 
 
+NATURE_FWD_FLOPS = 2 * (20 * 20 * 32 * 8 * 8 * 4 + 9 * 9 * 64 * 4 * 4 * 32 + 7 * 7 * 64 * 3 * 3 * 64
+                        + 3136 * 512 + 512 * 6)      # per observation, pfrl/nn/atari_cnn.py:17-47
+NATURE_CONV1_FLOPS = 2 * 20 * 20 * 32 * 8 * 8 * 4
+MFMA_F32_PEAK_TFLOPS = 155.0    # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, measured
+
+
+def step_flops_dqn(N, minibatch, update_interval):
+    """Arithmetic of one batched DQN step: acting forward on N observations + per update the
+    online forward / backward on B (backward = 2 x forward minus conv1's input gradient, which
+    does not exist) and the target forward on B."""
+    updates = N // update_interval
+    per_update = minibatch * (NATURE_FWD_FLOPS + 2 * NATURE_FWD_FLOPS - NATURE_CONV1_FLOPS
+                              + NATURE_FWD_FLOPS)
+    return N * NATURE_FWD_FLOPS + updates * per_update
+
+
+def launches_per_update():
+    """Kernel launches of one update, from the committed rocprofv3 timeline of this build
+    (profiles/rNN_dqn_update_timeline.txt, tools/update_timeline.py), newest round first."""
+    import re
+
+    prof_dir = os.path.join(ROOT, "profiles")
+    for name in sorted(os.listdir(prof_dir), reverse=True):
+        if name.endswith("_dqn_update_timeline.txt"):
+            m = re.search(r"kernels (\d+),", open(os.path.join(prof_dir, name)).read())
+            if m:
+                return {"value": int(m.group(1)), "source": "profiles/" + name}
+    return None
+
+
 def algorithmic_bytes_per_step(algo, N, minibatch, update_interval):
     """SURVEY.md 8(d) per env-step figures x envs per batched step."""
     fb, k = 84 * 84, 4
@@ -562,6 +593,14 @@ def assemble_result(args, world, N, elapsed, n_updates, t_fill, workload, roofli
         step_bytes = algorithmic_bytes_per_step(args.algo, N, args.minibatch, args.update_interval)
         roofline["step_algorithmic_bytes"] = int(step_bytes)
         roofline["step_frac"] = round(step_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
+        if args.algo == "dqn":
+            # the step against the OTHER roofline: its arithmetic / the f32 MFMA peak (the data
+            # path is HBM-bound, the step as a whole is bound by the B = 32 update chain)
+            fl = step_flops_dqn(N, args.minibatch, args.update_interval)
+            tf = fl / (ms * 1e-3) / 1e12
+            roofline["mfma"] = {"step_flops": int(fl), "achieved": round(tf, 2),
+                                "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 4)}
     per = "per GPU" if args.scaling == "weak" else "sharded over the GPUs"
     return {
         "metric": "env-steps/sec whole node (%s %d envs %s)" % (args.algo.upper(), N if args.scaling == "weak" else N * world, per),
@@ -626,22 +665,43 @@ def data_path_only(args, device, agent, env, rbuf, obss, steps):
                     "schedule, TD loss, optimizer step on one row"}, obss
 
 
-def reference_baseline():
-    """The reference's own numbers for this workload, recorded in the build container by
-    tools/reference_cpu_baseline.py (the reference cannot travel to the GPU box)."""
-    for name in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True):
-        if name.endswith("_reference_cpu_baseline.json"):
-            try:
-                d = json.load(open(os.path.join(ROOT, "profiles", name)))
-                return {"reference_value": d["end_to_end"]["value"],
-                        "reference_data_path_only_value": d["data_path_only"]["value"],
-                        "reference_cores": d["cores"],
-                        "reference_source": "profiles/%s: pfnet/pfrl itself (gpu=-1) on the same "
-                                            "synthetic workload, capacity %d, timed in the build "
-                                            "container (not on this box)" % (name, d["capacity"])}
-            except Exception:
-                pass
-    return {}
+def reference_baseline(args):
+    """pfnet/pfrl ITSELF (gpu=-1) on the same synthetic workload, timed on THIS box's host cores
+    by tools/reference_cpu_baseline.py in a subprocess that imports the reference from
+    oracle/_ref/ (its modules compiled to .pyc by oracle/build_ref.py; /root/reference does not
+    exist on the GPU box).  A bounded sample: BASELINE.md section 3's full protocol (>= 2e4
+    env-steps, 3 seeds) is profiles/r03_reference_cpu_baseline_gpubox.json."""
+    import subprocess
+
+    ref_dir = os.path.join(ROOT, "oracle", "_ref")
+    if not os.path.isdir(os.path.join(ref_dir, "pfrl")):
+        return None
+    env = dict(os.environ, PFRL_REFERENCE=ref_dir, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "reference_cpu_baseline.py"),
+           "--seconds", str(args.cpu_baseline_seconds), "--dp-seconds",
+           str(max(2.0, args.cpu_baseline_seconds * 0.4)), "--prefill", "5120",
+           "--threads", str(args.cpu_baseline_threads), "--num-envs", str(args.num_envs)]
+    try:
+        out = subprocess.run(cmd, env=env, cwd="/tmp", capture_output=True, text=True, timeout=600)
+        d = json.loads(out.stdout.strip().splitlines()[-1])
+    except Exception as e:     # the baseline must never cost the line its GPU numbers
+        sys.stderr.write("reference cpu baseline failed: %r\n" % (e,))
+        return None
+    return {
+        "value": d["end_to_end"]["value"], "unit": "env-steps/s", "cores": d["cores"],
+        "kind": "reference",
+        "data_path_only_value": d["data_path_only"]["value"],
+        "host_cores": d["host_cores"],
+        "sample": "pfnet/pfrl itself (compiled from /root/reference into oracle/_ref), gpu=-1, "
+                  "train loop of pfrl/agents/dqn.py on %d in-process synthetic Atari-shaped envs, "
+                  "ReplayBuffer(1e5) holding %d transitions at the start: %d env-steps end to end "
+                  "in %.0f s with %d torch threads, %d env-steps with a zero-FLOP q_function; "
+                  "full protocol (>= 2e4 env-steps, 3 seeds, median): profiles/"
+                  "r03_reference_cpu_baseline_gpubox.json"
+                  % (d["num_envs"], d["replay_len_at_start"],
+                     d["end_to_end"]["env_steps_per_sample"][0], args.cpu_baseline_seconds,
+                     d["cores"], d["data_path_only"]["env_steps_per_sample"][0]),
+    }
 
 
 def run_workload(args, device, rank, world, result_extras=True):
@@ -685,6 +745,9 @@ def run_workload(args, device, rank, world, result_extras=True):
     optim_before = updates_done()
     ops.profile_collect(kind=None)      # drop launches timed by an earlier workload
     ops.profile_enable(True)
+    graphed = getattr(agent, "_graphed", None)
+    if graphed is not None and hasattr(graphed, "run_range"):
+        graphed.time_ranges = []
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -705,6 +768,16 @@ def run_workload(args, device, rank, world, result_extras=True):
     roofline = compute_roofline(args.algo, all_us, all_units, all_kinds)
     out = assemble_result(args, world, N, elapsed, n_updates, t_fill,
                           workload_description(args, N, rbuf), roofline)
+    if graphed is not None and getattr(graphed, "time_ranges", None):
+        timed, graphed.time_ranges = graphed.time_ranges, None
+        big_u = max(u for u, _, _ in timed)
+        us = [e0.elapsed_time(e1) * 1e3 / u for u, e0, e1 in timed if u == big_u]
+        if roofline is not None and us:
+            roofline.setdefault("mfma", {})["update_us"] = round(sum(us) / len(us), 2)
+            roofline["mfma"]["update_us_what"] = (
+                "device time of ONE optimizer update (forward, TD loss, backward, optimizer step) "
+                "inside the captured %d-update range graph, hipEvents around the replay" % big_u)
+            roofline["mfma"]["launches_per_update"] = launches_per_update()
     out["config"]["ranks_seen"] = world
     if args.algo == "rainbow":
         out["config"]["priority_pow"] = rbuf.priority_pow
@@ -765,14 +838,35 @@ def main():
         pargs.cudnn_benchmark = False
         torch.backends.cudnn.benchmark = False
         also = run_workload(pargs, device, rank, world, result_extras=False)
+        keys = ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "scaling", "config",
+                "roofline")
         if rank == 0:
-            out["also"] = {"ppo": {k: also[k] for k in ("metric", "value", "unit", "steps", "warmup",
-                                                       "ms_per_step", "scaling", "config",
-                                                       "roofline")}}
+            out["also"] = {"ppo": {k: also[k] for k in keys}}
+        if world == 1:
+            # configs[2] and configs[4], short: every GPU config of BASELINE.json on one line
+            for algo, n_envs, mb, blas in (("rainbow", 256, 32, "default"), ("sac", 64, 256, "tunable")):
+                a2 = copy.copy(args)
+                a2.algo, a2.steps, a2.warmup = algo, 50, 5
+                a2.num_envs, a2.minibatch, a2.blas = n_envs, mb, blas
+                a2.cudnn_benchmark = True
+                torch.backends.cudnn.benchmark = True
+                if blas == "tunable":
+                    torch.cuda.tunable.enable(True)
+                    torch.cuda.tunable.tuning_enable(True)
+                else:
+                    torch.cuda.tunable.enable(False)
+                r2 = run_workload(a2, device, rank, world, result_extras=False)
+                if rank == 0:
+                    out["also"][algo] = {k: r2[k] for k in keys}
     if rank == 0:
         if not args.no_cpu_baseline and world == 1 and args.algo == "dqn":
-            out["cpu_baseline"] = cpu_baseline(args, args.cpu_baseline_seconds)
-            out["cpu_baseline"].update(reference_baseline())
+            port = cpu_baseline(args, min(args.cpu_baseline_seconds, 8.0))
+            ref = reference_baseline(args)
+            if ref is not None:
+                ref["port"] = port       # the C oracle + torch-CPU port, as rounds 1-2 reported
+                out["cpu_baseline"] = ref
+            else:
+                out["cpu_baseline"] = port
     if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
     sys.stdout.flush()

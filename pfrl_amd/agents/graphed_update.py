@@ -306,6 +306,9 @@ class GraphedUpdate:
         return entry
 
     # -- a whole env range as ONE graph ---------------------------------------------
+    # set to a list by bench.py: (updates in the range, start event, end event) per replay
+    time_ranges = None
+
     def range_capturable(self):
         """Several consecutive updates can share one graph when nothing has to happen
         between them on the host: no eager collective, no hand-over to a replay stream."""
@@ -322,7 +325,16 @@ class GraphedUpdate:
         if entry is None:
             entry = self._capture_range(big)
             self.graphs.admit(key, entry)
-        entry["graph"].replay()
+        timing = self.time_ranges
+        if timing is not None:
+            # bench.py: device time of a whole range graph (events on the launch stream)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            entry["graph"].replay()
+            e1.record()
+            timing.append((int(entry["losses"].shape[0]), e0, e1))
+        else:
+            entry["graph"].replay()
         return entry["losses"], entry["ys"]
 
     def _capture_range(self, big):

@@ -1,9 +1,10 @@
 #!/usr/bin/env python
-"""The REFERENCE ITSELF (pfnet/pfrl from /root/reference, unmodified, ``gpu=-1``) on the
-benchmark's synthetic workload, timed on the host cores of the BUILD container (SURVEY.md 8d,
-"CPU baseline timing").  /root/reference does not exist on the GPU box, so this number cannot
-be taken there: it is recorded here, once per round, into profiles/ and bench.py quotes it as
-``cpu_baseline.reference_value`` next to the port it times on the GPU box's own cores.
+"""The REFERENCE ITSELF (pfnet/pfrl, unmodified, ``gpu=-1``) on the benchmark's synthetic
+workload, timed on the host cores of whatever box this runs on ("CPU baseline
+timing").  The reference is imported from /root/reference where that exists (the build
+container) and otherwise from ``oracle/_ref/`` -- its own modules compiled to sourceless .pyc by
+``oracle/build_ref.py``, which travel to the GPU box with the tree -- so ``bench.py`` times it
+THERE, next to the MI355X numbers (``cpu_baseline.kind = "reference"``).
 
 Workload = BASELINE.json configs[1] with the replay capacity cut to 1e5 for host memory:
 256 in-process synthetic Atari-shaped envs (VectorFrameStack semantics: LazyFrames of four
@@ -14,6 +15,7 @@ B = 32, update_interval = 4, RMSprop(centered).  Two figures:
   data_path_only   the same loop with a zero-FLOP q_function
 
     python tools/reference_cpu_baseline.py --seconds 40 --out profiles/r02_reference_cpu_baseline.json
+    python tools/reference_cpu_baseline.py --min-steps 20000 --seeds 0,1,2 --threads all,16
 """
 import argparse
 import json
@@ -24,12 +26,20 @@ import time
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-REFERENCE = os.environ.get("PFRL_REFERENCE", "/root/reference")
+REFERENCE = os.environ.get("PFRL_REFERENCE") or (
+    "/root/reference" if os.path.isdir("/root/reference/pfrl") else os.path.join(ROOT, "oracle", "_ref"))
 
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--seconds", type=float, default=40.0)
+    ap.add_argument("--seconds", type=float, default=40.0, help="end-to-end sample per (seed, threads)")
+    ap.add_argument("--dp-seconds", type=float, default=None, help="data-path-only sample (default 0.4 x)")
+    ap.add_argument("--min-steps", type=int, default=0,
+                    help="keep sampling until this many env-steps as well (BASELINE.md: >= 2e4)")
+    ap.add_argument("--seeds", default="0", help="comma list; the median over seeds is reported")
+    ap.add_argument("--threads", default="all",
+                    help="comma list of torch CPU thread counts for the end-to-end figure ('all' = "
+                         "os.cpu_count()); the best one is the headline")
     ap.add_argument("--num-envs", type=int, default=256)
     ap.add_argument("--capacity", type=int, default=10 ** 5)
     ap.add_argument("--prefill", type=int, default=20000)
@@ -44,9 +54,11 @@ def main():
     from pfrl.q_functions import DiscreteActionValueHead
     from pfrl.wrappers.atari_wrappers import LazyFrames
 
-    assert os.path.realpath(os.path.dirname(pfrl.__file__)).startswith(os.path.realpath(REFERENCE))
+    assert os.path.realpath(os.path.dirname(pfrl.__file__)).startswith(os.path.realpath(REFERENCE)), \
+        "not the reference: %s" % pfrl.__file__
     cores = os.cpu_count()
-    torch.set_num_threads(cores)
+    thread_counts = [cores if t == "all" else min(cores, int(t)) for t in args.threads.split(",")]
+    torch.set_num_threads(thread_counts[0])
     N, n_actions = args.num_envs, 6
 
     class SyntheticAtari(pfrl.env.VectorEnv):
@@ -115,45 +127,68 @@ def main():
         agent.batch_observe(obss, rs, dones, [False] * N)
         return env.reset([not d for d in dones])
 
-    pfrl.utils.set_random_seed(0)
-    rbuf = replay_buffers.ReplayBuffer(args.capacity)
-    env = SyntheticAtari()
-    stub = make_agent(ZeroFlopQ(), rbuf)
-    obss = env.reset()
-    t0 = time.perf_counter()
-    while len(rbuf) < args.prefill:
-        obss = one_step(stub, env, obss)
-    t_fill = time.perf_counter() - t0
+    from pfrl.nn import LargeAtariCNN   # train_dqn_batch_ale.py:35-41, arch "nature"
+    from pfrl.initializers import init_chainer_default
 
-    def measure(agent, obss, seconds):
+    def measure(agent, env, obss, seconds, min_steps):
         steps, t0 = 0, time.perf_counter()
         while True:
             obss = one_step(agent, env, obss)
             steps += 1
             el = time.perf_counter() - t0
-            if el >= seconds:
+            if el >= seconds and steps * N >= min_steps:
                 return steps, el, obss
 
-    s_dp, el_dp, obss = measure(stub, obss, args.seconds * 0.4)
-    from pfrl.nn import LargeAtariCNN   # train_dqn_batch_ale.py:35-41, arch "nature"
-    from pfrl.initializers import init_chainer_default
+    dp_seconds = args.dp_seconds if args.dp_seconds is not None else args.seconds * 0.4
+    runs = []
+    for seed in [int(x) for x in args.seeds.split(",")]:
+        pfrl.utils.set_random_seed(seed)
+        rbuf = replay_buffers.ReplayBuffer(args.capacity)
+        env = SyntheticAtari()
+        stub = make_agent(ZeroFlopQ(), rbuf)
+        obss = env.reset()
+        t0 = time.perf_counter()
+        while len(rbuf) < args.prefill:
+            obss = one_step(stub, env, obss)
+        t_fill = time.perf_counter() - t0
+        s_dp, el_dp, obss = measure(stub, env, obss, dp_seconds, args.min_steps)
+        run = {"seed": seed, "prefill_s": round(t_fill, 1),
+               "data_path_only": {"value": round(s_dp * N / el_dp, 2), "steps": s_dp,
+                                  "seconds": round(el_dp, 1)},
+               "end_to_end": {}}
+        q = torch.nn.Sequential(LargeAtariCNN(),
+                                init_chainer_default(torch.nn.Linear(512, n_actions)),
+                                DiscreteActionValueHead())
+        real = make_agent(q, rbuf)
+        real.t = stub.t
+        for th in thread_counts:
+            torch.set_num_threads(th)
+            s_e2e, el_e2e, obss = measure(real, env, obss, args.seconds, args.min_steps)
+            run["end_to_end"][str(th)] = {"value": round(s_e2e * N / el_e2e, 2), "steps": s_e2e,
+                                          "seconds": round(el_e2e, 1), "updates": s_e2e * N // 4}
+        runs.append(run)
 
-    q = torch.nn.Sequential(LargeAtariCNN(), init_chainer_default(torch.nn.Linear(512, n_actions)),
-                            DiscreteActionValueHead())
-    real = make_agent(q, rbuf)
-    real.t = stub.t
-    s_e2e, el_e2e, obss = measure(real, obss, args.seconds)
+    def median(xs):
+        xs = sorted(xs)
+        return xs[len(xs) // 2] if len(xs) % 2 else 0.5 * (xs[len(xs) // 2 - 1] + xs[len(xs) // 2])
+
+    by_threads = {str(th): median([r["end_to_end"][str(th)]["value"] for r in runs])
+                  for th in thread_counts}
+    best = max(by_threads, key=lambda k: by_threads[k])
     out = {
-        "what": "reference pfnet/pfrl (gpu=-1) on the synthetic configs[1] workload, build container",
-        "cores": cores, "torch_threads": cores, "num_envs": N, "capacity": args.capacity,
-        "replay_len_at_start": args.prefill, "prefill_s": round(t_fill, 1),
-        "end_to_end": {"value": round(s_e2e * N / el_e2e, 2), "unit": "env-steps/s",
-                       "steps": s_e2e, "seconds": round(el_e2e, 1),
-                       "updates": s_e2e * N // 4},
-        "data_path_only": {"value": round(s_dp * N / el_dp, 2), "unit": "env-steps/s",
-                           "steps": s_dp, "seconds": round(el_dp, 1),
+        "what": "reference pfnet/pfrl (gpu=-1) on the synthetic configs[1] workload",
+        "reference_from": REFERENCE, "host_cores": cores, "torch_threads": int(best),
+        "cores": int(best), "num_envs": N, "capacity": args.capacity,
+        "replay_len_at_start": args.prefill, "seeds": [r["seed"] for r in runs],
+        "end_to_end": {"value": round(by_threads[best], 2), "unit": "env-steps/s",
+                       "median_over_seeds_by_threads": by_threads,
+                       "env_steps_per_sample": [r["end_to_end"][best]["steps"] * N for r in runs]},
+        "data_path_only": {"value": round(median([r["data_path_only"]["value"] for r in runs]), 2),
+                           "unit": "env-steps/s",
+                           "env_steps_per_sample": [r["data_path_only"]["steps"] * N for r in runs],
                            "note": "zero-FLOP q_function: batch_states, append, sample, "
                                    "batch_experiences, loss on a [32, 6] constant"},
+        "runs": runs,
         "torch": torch.__version__, "numpy": np.__version__,
     }
     print(json.dumps(out))
