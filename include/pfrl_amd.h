@@ -301,6 +301,42 @@ int pfrl_rmsprop_step(int32_t n_tensors, float *const *host_params,
                       float *const *host_grad_avg, const int64_t *host_numel, float lr,
                       float alpha, float eps, float weight_decay, int centered, void *stream);
 
+/* The optimizer step that finishes the gradients (same reference lines, pfrl/agents/dqn.py:
+ * 360-365, at minibatch size).  Each task updates one parameter tensor with RMSprop taking its
+ * gradient in the form the backward pass left it:
+ *   PLAIN         src = the gradient tensor
+ *   SLABS         src = first of n_slabs split-K partial slabs, slab_stride floats apart: summed
+ *                 while loading (what pfrl_splitk_reduce would have written)
+ *   LOWRANK       the weight of a Linear(K, F) layer whose gradient is dy^T x over a batch of M
+ *                 rows: src = dy [M][F] (counted where mask [M][F] > 0: the ReLU of the layer's
+ *                 output; mask may be NULL), x [M][K]; formed tile by tile on the matrix cores
+ *                 (f32 16x16x4 MFMA, exact f32) and applied from the accumulators -- the F x K
+ *                 gradient never exists in memory.  K % 64 == 0, F % 16 == 0, M % 4 == 0, M <= 32
+ *   LOWRANK_BIAS  that layer's bias: sum over the M rows of the masked dy column
+ *   FOLD          no parameter: out[i] = sum of the slabs (loss terms that rode on the fold)
+ * host_tasks is a host array (copied into the kernel arguments: graph-capturable). */
+#define PFRL_OPT_MAX_TASKS 16
+#define PFRL_OPT_PLAIN 0
+#define PFRL_OPT_SLABS 1
+#define PFRL_OPT_LOWRANK 2
+#define PFRL_OPT_LOWRANK_BIAS 3
+#define PFRL_OPT_FOLD 4
+typedef struct {
+    float *p, *sq, *ga;     /* parameter, square_avg, grad_avg (centered) */
+    const float *src;
+    float *out;             /* FOLD */
+    const float *mask;      /* LOWRANK / LOWRANK_BIAS */
+    const float *x;         /* LOWRANK */
+    int64_t numel;
+    int64_t slab_stride;
+    int32_t n_slabs;
+    int32_t mode;
+    int32_t M, F, K;
+    int32_t reserved;
+} pfrl_opt_task_t;
+int pfrl_rmsprop_fused_step(int32_t n_tasks, const pfrl_opt_task_t *host_tasks, float lr,
+                            float alpha, float eps, float weight_decay, int centered, void *stream);
+
 /* DQN / DoubleDQN TD loss and its gradient in one launch
  * (pfrl/agents/dqn.py:388-470 _compute_target_values/_compute_y_and_t/
  * _compute_loss, losses :44-104; pfrl/agents/double_dqn.py:12-40):
@@ -565,6 +601,23 @@ int pfrl_sac_policy_loss_fwd(const float *log_prob, const float *q1, const float
 int pfrl_sac_policy_loss_bwd(const float *g_loss, const float *q1, const float *q2,
                              const float *log_temperature, float temperature, float *g_log_prob,
                              float *g_q1, float *g_q2, int32_t B, void *stream);
+
+/* Ragged gather of sampled episodes for recurrent updates: batch_recurrent_experiences
+ * (pfrl/replay_buffer.py:219-287) over EpisodicReplayBuffer.sample_episodes (pfrl/replay_buffers/
+ * episodic.py:48-85, windows cut by random_subseq).  An episode is a run of consecutive
+ * one-transition entries of the entry ring; ep_first[e] = entry slot of the first transition of
+ * sampled window e (windows sorted by descending length), ep_row0[0..n_eps] = prefix of their
+ * lengths, row_start[0..T] = first packed row of time step t (T = longest window).  Emits
+ * state / next_state episode-major ([rows][k][frame], u8 -> f32 / divisor as
+ * pfrl_batch_experiences) and action / reward / is_state_terminal / discount (= gamma) in
+ * time-major packed order (pfrl/utils/recurrent.py flatten_sequences_time_first).  Episode
+ * payloads never leave HBM; the host supplies three small int32 arrays per sample. */
+int pfrl_batch_episodes(const pfrl_table_t *tab, const void *frames, int64_t frame_bytes,
+                        int frames_are_f32, float divisor, const int32_t *ep_first,
+                        const int32_t *ep_row0, const int32_t *row_start, int32_t n_eps, int32_t T,
+                        int64_t rows, int64_t entry_ring, float gamma, void *out_state,
+                        void *out_next_state, void *out_action, float *out_reward,
+                        float *out_terminal, float *out_discount, void *stream);
 
 /* ------------------------------------------------------------------------
  * HOST step planner (no device work; every pointer is host memory).  The reference's batched

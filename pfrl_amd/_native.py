@@ -97,6 +97,20 @@ class HostStoreDesc(ctypes.Structure):
     ]
 
 
+class OptTask(ctypes.Structure):
+    """pfrl_opt_task_t"""
+
+    _fields_ = [
+        ("p", ctypes.c_void_p), ("sq", ctypes.c_void_p), ("ga", ctypes.c_void_p),
+        ("src", ctypes.c_void_p), ("out", ctypes.c_void_p), ("mask", ctypes.c_void_p),
+        ("x", ctypes.c_void_p),
+        ("numel", ctypes.c_int64), ("slab_stride", ctypes.c_int64),
+        ("n_slabs", ctypes.c_int32), ("mode", ctypes.c_int32),
+        ("M", ctypes.c_int32), ("F", ctypes.c_int32), ("K", ctypes.c_int32),
+        ("reserved", ctypes.c_int32),
+    ]
+
+
 class TreeDesc(ctypes.Structure):
     """pfrl_tree_t"""
 
@@ -136,6 +150,7 @@ EXPORTS = {
     "pfrl_entries_append": (ctypes.c_int, "Tqpppp"),
     "pfrl_batch_experiences": (ctypes.c_int, "Tpqifpqpppppppp"),
     "pfrl_batch_experiences_nhwc4": (ctypes.c_int, "Tpqfpqpppppppp"),
+    "pfrl_batch_episodes": (ctypes.c_int, "Tpqifpppiiqqfppppppp"),
     "pfrl_tree_write": (ctypes.c_int, "Rqppppp"),
     "pfrl_tree_sample": (ctypes.c_int, "Rqpppppppppidqpp"),
     "pfrl_tree_update_errors_f32": (ctypes.c_int, "Rqppifdifdddiip"),
@@ -148,6 +163,7 @@ EXPORTS = {
     "pfrl_adv_stats": (ctypes.c_int, "pqppp"),
     "pfrl_ppo_minibatch": (ctypes.c_int, "qpppipppppippppppp"),
     "pfrl_rmsprop_step": (ctypes.c_int, "ipppppffffip"),
+    "pfrl_rmsprop_fused_step": (ctypes.c_int, "ipffffip"),
     "pfrl_dqn_td_loss": (ctypes.c_int, "ppppppppqiiippppp"),
     "pfrl_dqn_head_td_loss": (ctypes.c_int, "ppppppppppiiiiippppp"),
     "pfrl_bias_relu_fwd": (ctypes.c_int, "pppqiqp"),

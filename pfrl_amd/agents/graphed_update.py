@@ -141,17 +141,52 @@ class GraphedUpdate:
         finally:
             ag._defer_head_fold = False
 
+    def _optimizer_finishes_gradients(self):
+        """The optimizer step takes split-K slabs and the hidden layer's batch matrices as they
+        are (FusedRMSprop.step_from_sources, csrc/optim.hip k_rmsprop_fused): one launch instead
+        of fold + step, and the hidden layer's weight gradient is never materialised.  Only when
+        nothing else reads the gradients: no clipping, no collective, one parameter group."""
+        ag = self.agent
+        opt = ag.optimizer
+        return (os.environ.get("PFRL_FUSED_OPT", "1") != "0" and ag.max_grad_norm is None
+                and not self.split_for_allreduce and not self.pipeline
+                and hasattr(opt, "step_from_sources") and opt.accepts_sources())
+
     def _backward(self, loss):
         ab = getattr(self.agent, "_analytic_backward", None)
+        self._sources, self._folds = None, ()
         if ab is not None and ab[1] is not None:
             # fused TD loss: the gradient w.r.t. Q(s) (or w.r.t. the head's input, with the
             # head's own gradients beside it) came out of the same launch
-            if ab[0].requires_grad:
-                torch.autograd.backward([ab[0]], [ab[1]])
             from pfrl_amd.nn import mfma_trunk
 
+            head = ab[2] if len(ab) > 2 else ()
+            defer = bool(head) and bool(mfma_trunk._DEFERRED_FOLDS) and \
+                self._optimizer_finishes_gradients()
+            if defer:
+                mfma_trunk.OPT_SOURCES = {}
+            try:
+                if ab[0].requires_grad:
+                    torch.autograd.backward([ab[0]], [ab[1]])
+                sources = mfma_trunk.OPT_SOURCES
+            finally:
+                mfma_trunk.OPT_SOURCES = None
+            if defer and sources:
+                # the head's per-row partials (queued by the loss launch for "the fold that ends
+                # the trunk's backward") become sources / folds of the optimizer launch too
+                from pfrl_amd.optimizers import GradSource
+
+                queued = list(mfma_trunk._DEFERRED_FOLDS)
+                del mfma_trunk._DEFERRED_FOLDS[:]
+                by_out = {t[1].data_ptr(): t for t in queued}
+                for p, g in head:
+                    t = by_out.pop(g.data_ptr())
+                    sources[p.data_ptr()] = GradSource.slabs(t[0], t[3], t[5])
+                self._folds = [(t[0], t[1], t[3], t[5]) for t in by_out.values()]
+                self._sources = sources
+                return
             mfma_trunk.flush_deferred_folds()     # (no-op when the trunk's backward took them)
-            for p, g in (ab[2] if len(ab) > 2 else ()):
+            for p, g in head:
                 if p.requires_grad:
                     p.grad = g if p.grad is None else p.grad + g
         else:
@@ -162,8 +197,17 @@ class GraphedUpdate:
         self._backward(loss)
         return loss, delta
 
+    _sources, _folds = None, ()
+
     def _step(self):
         ag = self.agent
+        if self._sources:
+            by_ptr = {p.data_ptr(): p for g in ag.optimizer.param_groups for p in g["params"]}
+            sources = {by_ptr[ptr]: src for ptr, src in self._sources.items()}
+            self._sources = None
+            ag.optimizer.step_from_sources(sources, self._folds)
+            self._folds = ()
+            return
         if ag.max_grad_norm is not None:
             torch.nn.utils.clip_grad_norm_(ag.model.parameters(), float(ag.max_grad_norm))
         ag.optimizer.step()

@@ -187,6 +187,70 @@ __global__ __launch_bounds__(kThreads) void k_batch_experiences(
     for (int i = 0; i < ad; ++i) out_action[b * ad + i] = src[t0 * ad + i];
 }
 
+// Ragged gather of sampled EPISODES (pfrl/replay_buffer.py:219-287 batch_recurrent_experiences
+// over pfrl/replay_buffers/episodic.py:48-85 sample_episodes): an episode is a run of consecutive
+// one-transition entries of the entry ring, (first entry slot, length); the launch gets the
+// sampled windows sorted by descending length and emits
+//   state / next_state  episode-major: the rows of episode 0, then episode 1, ... (what the
+//                       reference builds per episode with batch_states and the agent then packs)
+//   action / reward / is_state_terminal / discount  time-major packed: all episodes' step 0,
+//                       then every episode longer than 1 at step 1, ... (flatten_sequences_time_first)
+// ep_row0[e] = first episode-major row of episode e, row_start[t] = first time-major row of step t
+// (row_start[T] = rows).  MODE as k_batch_experiences.
+struct EpisodeArgs {
+    const int32_t *ep_first;   // [n_eps] entry slot of the window's first transition
+    const int32_t *ep_row0;    // [n_eps + 1]
+    const int32_t *row_start;  // [T + 1]
+    int32_t n_eps, T;
+    int64_t rows, E;
+};
+
+__device__ __forceinline__ int upper_index(const int32_t *__restrict__ a, int n, int64_t v) {
+    // largest i in [0, n) with a[i] <= v  (a ascending, a[0] <= v)
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (a[mid] <= v) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+
+template <int MODE, typename ActT>
+__global__ __launch_bounds__(kThreads) void k_batch_episodes(
+    pfrl_table_t tab, const uint8_t *__restrict__ frames, int64_t frame_bytes, float divisor,
+    EpisodeArgs ea, float gamma, uint8_t *__restrict__ out_state, uint8_t *__restrict__ out_next,
+    ActT *__restrict__ out_action, float *__restrict__ out_reward, float *__restrict__ out_terminal,
+    float *__restrict__ out_discount) {
+    const int64_t nf = ea.rows * tab.k;
+    const int64_t f = blockIdx.x;
+    const int64_t out_frame_bytes = MODE == 2 ? frame_bytes : 4 * frame_bytes;
+    if (f < 2 * nf) {
+        const bool is_next = f >= nf;
+        const int64_t ff = is_next ? f - nf : f;
+        const int64_t row = ff / tab.k;
+        const int j = (int)(ff - row * tab.k);
+        const int e = upper_index(ea.ep_row0, ea.n_eps, row);
+        const int64_t es = ((int64_t)ea.ep_first[e] + (row - ea.ep_row0[e])) % ea.E;
+        const int64_t t = tab.e_tids[es * tab.n];
+        const int64_t slot = is_next ? tab.t_next_ref[t * tab.k + j] : tab.t_state_ref[t * tab.k + j];
+        uint8_t *dst = (is_next ? out_next : out_state) + ff * out_frame_bytes;
+        move_frame<MODE, false>(frames + slot * frame_bytes, dst, frame_bytes, divisor);
+        return;
+    }
+    const int64_t r = (f - 2 * nf) * kThreads + threadIdx.x;
+    if (r >= ea.rows) return;
+    const int step = upper_index(ea.row_start, ea.T, r);
+    const int b = (int)(r - ea.row_start[step]);          // b-th longest episode, at this step
+    const int64_t es = ((int64_t)ea.ep_first[b] + step) % ea.E;
+    const int64_t t = tab.e_tids[es * tab.n];
+    out_reward[r] = (float)tab.t_reward[t];
+    out_terminal[r] = tab.t_terminal[t] != 0 ? 1.0f : 0.0f;
+    out_discount[r] = gamma;
+    const int ad = tab.act_dim > 0 ? tab.act_dim : 1;
+    const ActT *src = reinterpret_cast<const ActT *>(tab.t_action);
+    for (int i = 0; i < ad; ++i) out_action[r * ad + i] = src[t * ad + i];
+}
+
 // Persistent form of the frame part: P workgroups walk the 2*B*k output frames
 // with stride P.  The slot of the NEXT frame is resolved (three dependent scalar
 // loads) and its dwords are requested before the current frame's stores are
@@ -677,5 +741,36 @@ extern "C" int pfrl_batch_experiences_nhwc4(const pfrl_table_t *tab, const void 
                                       out_state, out_next_state, out_action, out_reward,
                                       out_terminal, out_discount, s);
     }
+    PFRL_LAUNCH_CHECK();
+}
+
+extern "C" int pfrl_batch_episodes(const pfrl_table_t *tab, const void *frames, int64_t frame_bytes,
+                                   int frames_are_f32, float divisor, const int32_t *ep_first,
+                                   const int32_t *ep_row0, const int32_t *row_start, int32_t n_eps,
+                                   int32_t T, int64_t rows, int64_t entry_ring, float gamma,
+                                   void *out_state, void *out_next_state, void *out_action,
+                                   float *out_reward, float *out_terminal, float *out_discount,
+                                   void *stream) {
+    PFRL_CHECK_ARG(tab && tab->n >= 1 && tab->k >= 1 && tab->k <= PFRL_MAX_STACK, "bad table");
+    PFRL_CHECK_ARG(frame_bytes > 0 && (frame_bytes & 3) == 0, "frame_bytes must be a multiple of 4");
+    PFRL_CHECK_ARG(n_eps >= 1 && T >= 1 && rows >= 1 && entry_ring >= 1 && ep_first && ep_row0 &&
+                       row_start, "pfrl_batch_episodes: bad episode table");
+    EpisodeArgs ea{ep_first, ep_row0, row_start, n_eps, T, rows, entry_ring};
+    const int64_t frame_blocks = 2 * rows * tab->k;
+    const dim3 grid((unsigned)(frame_blocks + (rows + kThreads - 1) / kThreads)), block(kThreads);
+    hipStream_t st = (hipStream_t)stream;
+    const uint8_t *fr = (const uint8_t *)frames;
+    uint8_t *os = (uint8_t *)out_state, *on = (uint8_t *)out_next_state;
+#define EP_LAUNCH(MODE, ACT)                                                                     \
+    hipLaunchKernelGGL((k_batch_episodes<MODE, ACT>), grid, block, 0, st, *tab, fr, frame_bytes, \
+                       divisor, ea, gamma, os, on, (ACT *)out_action, out_reward, out_terminal,  \
+                       out_discount)
+    const int mode = frames_are_f32 ? 2 : (divisor == 1.0f ? 1 : 0);
+    if (tab->act_dim > 0) {
+        if (mode == 2) EP_LAUNCH(2, float); else if (mode == 1) EP_LAUNCH(1, float); else EP_LAUNCH(0, float);
+    } else {
+        if (mode == 2) EP_LAUNCH(2, int64_t); else if (mode == 1) EP_LAUNCH(1, int64_t); else EP_LAUNCH(0, int64_t);
+    }
+#undef EP_LAUNCH
     PFRL_LAUNCH_CHECK();
 }

@@ -154,6 +154,19 @@ def _fused_bwd_ok(N, H, W, C, ST):
     return True
 
 
+# The hidden layer's weight gradient formed INSIDE the optimizer launch (GradSource.lowrank) is
+# off by default: measured on MI355X (profiles/r03_fused_optimizer.txt) the weight-gradient half
+# of the hidden layer's fused backward launch is nearly free (dgrad + wgrad 14.0 us, dgrad alone
+# 12.2 us), while the optimizer launch grows from 13 to 22-34 us when it has to build the tiles.
+_LOWRANK = os.environ.get("PFRL_FUSED_OPT_LOWRANK", "0") == "1"
+
+
+def _lowrank_ok(M, F, K, w):
+    from pfrl_amd.optimizers import GradSource
+
+    return w.is_contiguous() and GradSource.lowrank_supported(M, F, K)
+
+
 def _dist_initialized():
     d = torch.distributed
     return d.is_available() and d.is_initialized()
@@ -173,6 +186,13 @@ def _reduce(tasks):
     R = (ctypes.c_int32 * n)(*[t[7] for t in tasks])
     check(L.pfrl_splitk_reduce(n, P, O, B, S, N, K, C, R, _stream()), "splitk_reduce")
 
+
+# Set to a dict by a caller whose optimizer finishes the gradients itself
+# (pfrl_amd.optimizers.FusedRMSprop.step_from_sources, GraphedUpdate): the backward pass then
+# hands over split-K slabs and the hidden layer's batch matrices as GradSource objects, keyed by
+# the parameter's data_ptr(), instead of folding / forming the gradients -- and returns None as
+# the gradient of those parameters.
+OPT_SOURCES = None
 
 # Folds queued by other nodes of the same backward pass (the fused head + loss launch of
 # ops.dqn_head_td_loss) for the fold launch that ends the trunk's backward: one launch less.
@@ -268,6 +288,18 @@ class _Trunk(torch.autograd.Function):
         # hidden linear layer: input gradient straight into NHWC rows of the last conv, and
         # the weight gradient, in one launch when the batch is minibatch-sized
         dy = torch.empty((N, last.OH, last.OW, last.Cout), dtype=torch.float32, device=dev)
+        if OPT_SOURCES is not None and _LOWRANK and _lowrank_ok(N, F, Kf, wf):
+            # the optimizer forms dW = dh^T x itself, tile by tile, and applies it from the
+            # accumulators (csrc/optim.hip): only the input gradient is computed here
+            from pfrl_amd.optimizers import GradSource
+
+            check(lib.pfrl_conv2d_nhwc_bwd_data(_p(dh), _p(out), _p(wf), _p(acts[-1]), _p(dy), N, 1, 1,
+                                                Kf, F, 1, 1, 1, P, last.Cout, _stream()),
+                  "linear_bwd_data")
+            OPT_SOURCES[wf.data_ptr()] = GradSource.lowrank(dh, out, acts[-1].view(N, Kf))
+            OPT_SOURCES[params[2 * L + 1].data_ptr()] = GradSource.lowrank_bias(dh, out)
+            grads = [None] * (2 * L + 2)
+            return _Trunk._conv_backward(ctx, specs, params, acts, x, dy, N, dev, grads)
         dwf = torch.empty_like(wf)
         dbf = torch.empty(F, dtype=torch.float32, device=dev)
         if _fused_bwd_ok(N, 1, 1, Kf, 1):
@@ -315,6 +347,14 @@ class _Trunk(torch.autograd.Function):
                 tasks.append((part, dw, None, stride, nW, splits, 4, 0))
                 tasks.append((pb, db, None, stride, sp.Cout, splits, 4, 0))
             grads[2 * i], grads[2 * i + 1] = dw, db
+            if OPT_SOURCES is not None and splits > 1:
+                from pfrl_amd.optimizers import GradSource
+
+                # the slabs go to the optimizer as they are (no fold, no gradient tensor)
+                del tasks[-2:]
+                OPT_SOURCES[w.data_ptr()] = GradSource.slabs(part, stride, splits)
+                OPT_SOURCES[params[2 * i + 1].data_ptr()] = GradSource.slabs(pb, stride, splits)
+                grads[2 * i], grads[2 * i + 1] = None, None
             if i > 0 and _fused_bwd_ok(N, sp.H, sp.W, sp.C, sp.ST):
                 dx = torch.empty((N, sp.H, sp.W, sp.C), dtype=torch.float32, device=dev)
                 check(lib.pfrl_conv2d_nhwc_bwd(_p(dy), None, _p(w), _p(below), _p(below), _p(dx), _p(pw),
@@ -331,7 +371,7 @@ class _Trunk(torch.autograd.Function):
                                                     sp.W, sp.C, sp.Cout, sp.R, sp.S, sp.ST, 0, 0,
                                                     _stream()), "conv2d_nhwc_bwd_data")
                 dy = dx
-        if _DEFERRED_FOLDS and len(tasks) + len(_DEFERRED_FOLDS) <= 12:
+        if OPT_SOURCES is None and _DEFERRED_FOLDS and len(tasks) + len(_DEFERRED_FOLDS) <= 12:
             tasks += _DEFERRED_FOLDS
             del _DEFERRED_FOLDS[:]
         if tasks:

@@ -186,6 +186,19 @@ def batch_experiences(desc, frames, divisor, entry_slots, gamma_pow, out):
     return out
 
 
+def batch_episodes(desc, frames, divisor, ep_first, ep_row0, row_start, n_eps, T, rows, entry_ring,
+                   gamma, out):
+    """Ragged gather of sampled episode windows (pfrl_batch_episodes); ``out`` as for
+    batch_experiences, state / next_state episode-major, scalars time-major packed."""
+    check(_native.lib().pfrl_batch_episodes(
+        ctypes.byref(desc), _ptr(frames), frame_bytes_of(frames),
+        int(frames.dtype == torch.float32), float(divisor), _ptr(ep_first), _ptr(ep_row0),
+        _ptr(row_start), int(n_eps), int(T), int(rows), int(entry_ring), float(gamma),
+        _ptr(out["state"]), _ptr(out["next_state"]), _ptr(out["action"]), _ptr(out["reward"]),
+        _ptr(out["is_state_terminal"]), _ptr(out["discount"]), _stream()), "batch_episodes")
+    return out
+
+
 def tree_write(desc, x, val, tag, use_maxp):
     check(_native.lib().pfrl_tree_write(ctypes.byref(desc), x.numel(), _ptr(x), _ptr(val),
                                         _ptr(tag), _ptr(use_maxp), _stream()), "tree_write")

@@ -18,10 +18,104 @@ def _dense(t):
     return t.is_contiguous() or (t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last))
 
 
+OPT_PLAIN, OPT_SLABS, OPT_LOWRANK, OPT_LOWRANK_BIAS, OPT_FOLD = 0, 1, 2, 3, 4   # PFRL_OPT_*
+
+
+class GradSource:
+    """A gradient in the form the backward pass left it (see ``pfrl_rmsprop_fused_step``):
+    ``slabs(part, stride, n)`` = split-K partial slabs still to be summed; ``lowrank(dy, mask, x)``
+    = the weight of a Linear layer as the product dy^T x of its batch matrices; ``lowrank_bias(dy,
+    mask)`` = that layer's bias.  Tensors are kept alive by the source."""
+
+    __slots__ = ("mode", "src", "mask", "x", "stride", "n_slabs", "M", "F", "K")
+
+    def __init__(self, mode, src, mask=None, x=None, stride=0, n_slabs=0, M=0, F=0, K=0):
+        self.mode, self.src, self.mask, self.x = mode, src, mask, x
+        self.stride, self.n_slabs, self.M, self.F, self.K = stride, n_slabs, M, F, K
+
+    @classmethod
+    def slabs(cls, part, stride, n_slabs):
+        return cls(OPT_SLABS, part, stride=int(stride), n_slabs=int(n_slabs))
+
+    @classmethod
+    def lowrank(cls, dy, mask, x):
+        M, F = dy.shape
+        return cls(OPT_LOWRANK, dy, mask=mask, x=x, M=int(M), F=int(F), K=int(x.shape[1]))
+
+    @classmethod
+    def lowrank_bias(cls, dy, mask):
+        M, F = dy.shape
+        return cls(OPT_LOWRANK_BIAS, dy, mask=mask, M=int(M), F=int(F))
+
+    @staticmethod
+    def lowrank_supported(M, F, K):
+        return K % 64 == 0 and F % 16 == 0 and M % 4 == 0 and 4 <= M <= 32
+
+
 class FusedRMSprop(torch.optim.RMSprop):
     def _fusable(self, group):
         return (group["momentum"] == 0 and not group.get("maximize", False)
                 and not group.get("differentiable", False))
+
+    # -- the step that finishes the gradients (csrc/optim.hip k_rmsprop_fused) ---------------
+    def accepts_sources(self):
+        """One parameter group the kernel covers: the backward pass may then hand over
+        gradients as :class:`GradSource` s instead of materialising them."""
+        return len(self.param_groups) == 1 and self._fusable(self.param_groups[0])
+
+    def step_from_sources(self, sources, folds=()):
+        """``step()`` where the gradient of parameter ``p`` is ``sources[p]`` (a GradSource) if
+        present and ``p.grad`` otherwise; ``folds`` = (part, out, stride, n_slabs) slab sums with
+        no parameter behind them (loss terms), finished by the same launch."""
+        group = self.param_groups[0]
+        centered = bool(group["centered"])
+        tasks = []
+        keep = []
+        for p in group["params"]:
+            src = sources.get(p)
+            if src is None and p.grad is None:
+                continue
+            st = self.state[p]
+            if len(st) == 0:
+                st["step"] = (torch.zeros((), dtype=torch.float32, device=p.device)
+                              if group.get("capturable", False) else torch.tensor(0.0))
+                st["square_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                if centered:
+                    st["grad_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            assert p.is_cuda and p.dtype == torch.float32 and _dense(p) \
+                and st["square_avg"].stride() == p.stride()
+            t = _native.OptTask()
+            t.p, t.sq = p.data_ptr(), st["square_avg"].data_ptr()
+            t.ga = st["grad_avg"].data_ptr() if centered else None
+            t.numel = p.numel()
+            if src is None:
+                g = p.grad
+                assert g.dtype == torch.float32 and g.stride() == p.stride()
+                t.mode, t.src = OPT_PLAIN, g.data_ptr()
+            else:
+                t.mode, t.src = src.mode, src.src.data_ptr()
+                t.mask = src.mask.data_ptr() if src.mask is not None else None
+                t.x = src.x.data_ptr() if src.x is not None else None
+                t.slab_stride, t.n_slabs = src.stride, src.n_slabs
+                t.M, t.F, t.K = src.M, src.F, src.K
+                if src.mode in (OPT_LOWRANK, OPT_LOWRANK_BIAS):
+                    assert p.is_contiguous()
+                keep.append(src)
+            tasks.append(t)
+        for part, out, stride, n_slabs in folds:
+            t = _native.OptTask()
+            t.mode, t.src, t.out = OPT_FOLD, part.data_ptr(), out.data_ptr()
+            t.numel, t.slab_stride, t.n_slabs = out.numel(), int(stride), int(n_slabs)
+            tasks.append(t)
+        if not tasks:
+            return
+        arr = (_native.OptTask * len(tasks))(*tasks)
+        dev = group["params"][0].device
+        stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        _native.check(_native.lib().pfrl_rmsprop_fused_step(
+            len(tasks), ctypes.cast(arr, ctypes.c_void_p), float(group["lr"]), float(group["alpha"]),
+            float(group["eps"]), float(group["weight_decay"]), int(centered), stream),
+            "rmsprop_fused_step")
 
     @torch.no_grad()
     def step(self, closure=None):

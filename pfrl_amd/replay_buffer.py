@@ -154,6 +154,52 @@ def random_subseq(seq, subseq_len):
     return seq[start:start + subseq_len]
 
 
+class DeviceEpisode:
+    """A sampled episode (or a ``random_subseq`` window of one) of a device-resident
+    EpisodicReplayBuffer: ``length`` consecutive one-transition entries of the entry ring from
+    sequence number ``first``.  Behaves as the list of transition dicts the reference returns
+    (``len``, indexing, slicing -- views built from the host mirrors, observations as
+    ``DeviceObs``); ``batch_recurrent_experiences`` never looks at them: it hands the (first,
+    length) pairs to ONE ragged gather launch (pfrl_batch_episodes)."""
+
+    __slots__ = ("store", "first", "length")
+
+    def __init__(self, store, first, length):
+        self.store, self.first, self.length = store, int(first), int(length)
+
+    def __len__(self):
+        return self.length
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            start, stop, step = i.indices(self.length)
+            assert step == 1
+            return DeviceEpisode(self.store, self.first + start, max(0, stop - start))
+        if i < 0:
+            i += self.length
+        if not 0 <= i < self.length:
+            raise IndexError("episode index out of range")
+        return self.store.entry_view(self.first + i)[0]
+
+    def __iter__(self):
+        return (self[i] for i in range(self.length))
+
+
+def _batch_device_episodes(experiences, device, phi, gamma):
+    from pfrl_amd.utils.recurrent import concatenate_recurrent_states, recurrent_state_from_numpy
+
+    store = experiences[0].store
+    out = store.fetch_episodes([(ep.first, ep.length) for ep in experiences], phi, gamma)
+
+    def initial_state(key):
+        return recurrent_state_from_numpy(
+            concatenate_recurrent_states([ep[0][key] for ep in experiences]), device)
+
+    out["recurrent_state"] = initial_state("recurrent_state")
+    out["next_recurrent_state"] = initial_state("next_recurrent_state")
+    return out
+
+
 def batch_recurrent_experiences(experiences, device, phi, gamma, batch_states=batch_states):
     """Vectorise sampled episodes for a recurrent update (reference :219-287).
 
@@ -167,6 +213,10 @@ def batch_recurrent_experiences(experiences, device, phi, gamma, batch_states=ba
 
     lengths = [len(ep) for ep in experiences]
     assert all(a >= b for a, b in zip(lengths, lengths[1:])), "episodes must be sorted by length"
+    if experiences and all(isinstance(ep, DeviceEpisode) for ep in experiences):
+        # episode payloads live in HBM: one ragged gather launch, nothing crosses PCIe but
+        # three small index arrays
+        return _batch_device_episodes(experiences, device, phi, gamma)
     flat = flatten_sequences_time_first(experiences)
 
     def column(key, **kw):

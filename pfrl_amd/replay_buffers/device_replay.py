@@ -619,6 +619,53 @@ class DeviceReplayStore:
                 flat, {k: v.view((U, B) + tuple(v.shape[1:])) for k, v in flat.items()})
         return dict(views[1])
 
+    def fetch_episodes(self, windows, phi, gamma):
+        """Sampled episode windows [(first entry seq, length), ...] sorted by descending length
+        -> the dict of ``batch_recurrent_experiences`` (reference pfrl/replay_buffer.py:219-287):
+        ``state`` / ``next_state`` as per-episode views of ONE gathered tensor, the scalar
+        columns flat in packed (time-major) order.  One launch (pfrl_batch_episodes)."""
+        self.flush()
+        n = len(windows)
+        lens = np.array([w[1] for w in windows], dtype=np.int64)
+        assert n > 0 and lens.min() >= 1 and (lens[:-1] >= lens[1:]).all()
+        rows, T = int(lens.sum()), int(lens[0])
+        ep_first = np.array([w[0] % self.E for w in windows], dtype=np.int32)
+        ep_row0 = np.zeros(n + 1, dtype=np.int32)
+        ep_row0[1:] = np.cumsum(lens)
+        # row_start[t] = packed rows before step t = sum over episodes of min(len, t)
+        row_start = np.minimum(lens[None, :], np.arange(T + 1)[:, None]).sum(axis=1).astype(np.int32)
+        if self.frames is not None:
+            oldest = min(int(self.h_e_min_fseq[(w[0] + np.arange(w[1])) % self.E].min())
+                         for w in windows)
+            if oldest < self.frames.oldest_live_seq():
+                raise RuntimeError("frame ring too small: a sampled episode references frame %d "
+                                   "but the ring (n_slots=%d) has wrapped past it"
+                                   % (oldest, self.frames.n_slots))
+        with on_stream(self.side_stream):
+            f_dev, r0_dev, rs_dev = self._stage.upload([ep_first, ep_row0, row_start])
+            dev = self.device
+            fshape, k = self.frames.frame_shape, self.k
+            if k == 1:
+                oshape = (rows,) + fshape
+            elif len(fshape) >= 2 and fshape[0] == 1:
+                oshape = (rows, k) + fshape[1:]
+            else:
+                oshape = (rows, k) + fshape
+            out = dict(
+                state=torch.empty(oshape, dtype=torch.float32, device=dev),
+                next_state=torch.empty(oshape, dtype=torch.float32, device=dev),
+                action=(torch.empty(rows, dtype=torch.int64, device=dev) if self.act_dim == 0 else
+                        torch.empty((rows, self.act_dim), dtype=torch.float32, device=dev)),
+                reward=torch.empty(rows, dtype=torch.float32, device=dev),
+                is_state_terminal=torch.empty(rows, dtype=torch.float32, device=dev),
+                discount=torch.empty(rows, dtype=torch.float32, device=dev))
+            ops.batch_episodes(self.desc, self.frames.frames, self.divisor_for(phi), f_dev, r0_dev,
+                               rs_dev, n, T, rows, self.E, gamma, out)
+        bounds = ep_row0.tolist()
+        out["state"] = [out["state"][a:b] for a, b in zip(bounds[:-1], bounds[1:])]
+        out["next_state"] = [out["next_state"][a:b] for a, b in zip(bounds[:-1], bounds[1:])]
+        return out
+
     def _sync_actions(self):
         """The native append path leaves the action column on the device only; host views
         (entry_view, save) read it back once."""

@@ -172,11 +172,66 @@ wrappers = types.ModuleType("gym.wrappers")
 wrappers.TimeLimit = _TimeLimit
 
 
+class _ScriptedAtari(Env):
+    """An ALE-shaped stand-in for the reference's Atari example scripts (TEST SIDE ONLY; ALE is
+    not installed): 210 x 160 RGB frames, lives, FIRE among the actions, rewards and game-overs
+    from a private RandomState.  What examples/atari/*.py need from ``gym.make(
+    '...NoFrameskip-v4')`` to run their whole pipeline (make_atari -> wrap_deepmind ->
+    MultiprocessVectorEnv -> VectorFrameStack -> train_agent_batch_with_evaluation)."""
+
+    def __init__(self, env_id):
+        self.spec = types.SimpleNamespace(id=env_id, max_episode_steps=100000)
+        self.action_space = Discrete(6)
+        self.observation_space = Box(low=0, high=255, shape=(210, 160, 3), dtype=np.uint8)
+        self._rs = np.random.RandomState(0)
+        self.np_random = np.random.RandomState(1)
+        self._lives = 0
+        self._t = 0
+        self.ale = types.SimpleNamespace(lives=lambda: self._lives)
+
+    @property
+    def unwrapped(self):
+        return self
+
+    def get_action_meanings(self):
+        return ["NOOP", "FIRE", "RIGHT", "LEFT", "RIGHTFIRE", "LEFTFIRE"]
+
+    def seed(self, seed=None):
+        self._rs = np.random.RandomState(None if seed is None else int(seed) % (2 ** 32))
+        self.np_random = np.random.RandomState(None if seed is None else (int(seed) + 1) % (2 ** 32))
+        return [seed]
+
+    def _frame(self):
+        # a moving bright block on noise: cheap, and not constant under grey-scale / resize
+        f = self._rs.randint(0, 64, size=(210, 160, 3)).astype(np.uint8)
+        y, x = (7 * self._t) % 180, (11 * self._t) % 130
+        f[y:y + 20, x:x + 20] = 255
+        return f
+
+    def reset(self):
+        self._lives, self._t = 3, 0
+        return self._frame()
+
+    def step(self, action):
+        self._t += 1
+        u = self._rs.rand()
+        reward = float(self._rs.choice([-1.0, 0.0, 0.0, 0.0, 2.0])) if int(action) % 2 else 0.0
+        done = False
+        if u < 0.002:
+            done, self._lives = True, 0
+        elif u < 0.01 and self._lives > 0:
+            self._lives -= 1
+            done = self._lives == 0
+        return self._frame(), reward, done, {}
+
+
 def make(env_id, *args, **kwargs):
     """Only CartPole exists here: pfrl_amd's numpy CartPole (gym's published dynamics) behind
     the terminating TimeLimit gym would put around it.  Enough for the reference's vector-env
     and wrapper tests to run under tools/run_reference_tests.py."""
     limits = {"CartPole-v0": 200, "CartPole-v1": 500}
+    if "NoFrameskip" in env_id:
+        return _TimeLimit(_ScriptedAtari(env_id), max_episode_steps=100000)
     if env_id not in limits:
         raise RuntimeError("gym shim: no environment %r" % (env_id,))
     from pfrl_amd.envs.cartpole import CartPoleEnv
