@@ -67,7 +67,15 @@ class DeviceFrameStore:
     def gather(self, refs_dev, divisor=255.0, out=None):
         if self.emit_channels_last and ops.channels_last_supported(self.frames, refs_dev.shape[1]):
             return ops.batch_states_nhwc4(self.frames, refs_dev, divisor, out=out)
-        return ops.batch_states(self.frames, refs_dev, divisor, out=out)
+        x = ops.batch_states(self.frames, refs_dev, divisor, out=out)
+        # the observation as the host would see it: LazyFrames concatenates its (1, H, W) frames
+        # on axis 0 (pfrl/wrappers/atari_wrappers.py:262-266), a single frame is the observation
+        k, fs = refs_dev.shape[1], self.frame_shape
+        if k == 1:
+            return x.view((x.shape[0],) + fs)
+        if len(fs) >= 2 and fs[0] == 1:
+            return x.view((x.shape[0], k) + fs[1:])
+        return x
 
 
 class DeviceObs:

@@ -8,11 +8,19 @@ transition or ``stop_current_episode``).  ``capacity`` bounds the number of TRAN
 episodes are evicted oldest-first until it is respected (:91-97), so ``len(buffer)`` never exceeds
 it after a commit.
 
-This is the host container of SURVEY.md 8(f) row 4: episodes are lists of the caller's transition
-dicts, held by reference exactly as the reference does, and sampling consumes the global NumPy
-stream draw-for-draw (``sample_n_k`` for the episode choice, then one ``randint`` per episode that
-is cut to ``max_len``).  The HBM frame ring / fused gather of the flat buffers is not used here:
-variable-length episode gathers on the device are the next step of that row.
+Storage back-ends, as for the flat buffers:
+
+* device (``device='cuda:N'`` or bound by an agent created with ``gpu>=0``): SURVEY.md 8(f) row 4.
+  Transitions go into the HBM transition table / frame ring of a :class:`DeviceReplayStore` as
+  they arrive; when an episode ends its transitions become CONSECUTIVE one-transition entries of
+  the entry ring, so an episode is the pair (first entry, length) -- host integers, like every
+  other piece of bookkeeping.  ``sample_episodes`` returns :class:`DeviceEpisode` windows and
+  ``batch_recurrent_experiences`` turns them into packed minibatches with ONE ragged gather launch
+  (pfrl_batch_episodes): episode payloads never leave HBM.  Sampling consumes the global NumPy
+  stream draw-for-draw (``sample_n_k`` for the episode choice, then one ``randint`` per episode
+  that is cut to ``max_len``).
+* host (no device, or ``gpu=None/-1``): episodes are lists of the caller's transition dicts, held
+  by reference exactly as the reference does.
 """
 import collections
 import pickle
@@ -23,19 +31,66 @@ from pfrl_amd.replay_buffer import AbstractEpisodicReplayBuffer, random_subseq
 
 class EpisodicReplayBuffer(AbstractEpisodicReplayBuffer):
     capacity = None
+    # (class-level defaults: subclasses with their own __init__ start on the host back-end)
+    store = None
+    device = None
+    _bound = False
+    _device_opts = dict(max_size=None, slack=None, frame_slots=None)
 
-    def __init__(self, capacity=None):
+    def __init__(self, capacity=None, device=None, max_size=None, slack=None, frame_slots=None):
         self.capacity = capacity
         self.current_episode = collections.defaultdict(list)
         self.episodic_memory = RandomAccessQueue()
         self.memory = RandomAccessQueue()
+        self._device_opts = dict(max_size=max_size, slack=slack, frame_slots=frame_slots)
+        self.device = None
+        self.store = None
+        self._bound = False
+        if device is not None:
+            self.bind(device)
+
+    # -- back-end selection (same protocol as ReplayBuffer.bind) -------------------------------
+    def bind(self, device, phi=None):
+        import torch
+
+        device = torch.device(device)
+        if self._bound:
+            if self.device != device:
+                raise RuntimeError("replay buffer already bound to %s" % self.device)
+            if self.store is not None and phi is not None:
+                self.store.set_phi(phi)
+            return self
+        assert len(self.memory) == 0 and not any(self.current_episode.values()), \
+            "bind() before the first append"
+        self.device, self._bound = device, True
+        if device.type == "cuda":
+            from pfrl_amd.replay_buffers.device_replay import DeviceReplayStore
+            from pfrl_amd.replay_buffers.replay_buffer import _DeviceQueue
+
+            self.store = DeviceReplayStore(device, self.capacity, 1, **self._device_opts)
+            if phi is not None:
+                self.store.set_phi(phi)
+            # FIFO of one-transition entries whose head moves by whole episodes (below)
+            self.memory = _DeviceQueue(self.store, None)
+        return self
+
+    @property
+    def is_device(self):
+        return self.store is not None
 
     # -- ingest ------------------------------------------------------------------------------
     def append(self, state, action, reward, next_state=None, next_action=None,
                is_state_terminal=False, env_id=0, **kwargs):
-        self.current_episode[env_id].append(dict(
-            state=state, action=action, reward=reward, next_state=next_state,
-            next_action=next_action, is_state_terminal=is_state_terminal, **kwargs))
+        self._bound = True
+        if self.store is not None:
+            if next_action is not None:
+                kwargs = dict(kwargs, next_action=next_action)
+            item = self.store.add_transition(state, action, reward, next_state, is_state_terminal,
+                                             kwargs or None)
+        else:
+            item = dict(state=state, action=action, reward=reward, next_state=next_state,
+                        next_action=next_action, is_state_terminal=is_state_terminal, **kwargs)
+        self.current_episode[env_id].append(item)
         if is_state_terminal:
             self.stop_current_episode(env_id=env_id)
 
@@ -47,6 +102,8 @@ class EpisodicReplayBuffer(AbstractEpisodicReplayBuffer):
         self._commit(episode)
 
     def _commit(self, episode):
+        if self.store is not None:
+            return self._commit_device(episode)
         self.episodic_memory.append(episode)
         for transition in episode:
             self.memory.append([transition])
@@ -56,6 +113,21 @@ class EpisodicReplayBuffer(AbstractEpisodicReplayBuffer):
             for _ in self.episodic_memory.popleft():
                 self.memory.popleft()
 
+    def _commit_device(self, tids):
+        """The episode's transitions become consecutive entries: (first entry seq, length)."""
+        st = self.store
+        first = st.n_entries
+        for tid in tids:
+            st.add_entry([tid])
+        if st.n_entries - self.memory.head > st.bound and self.capacity is None:
+            raise RuntimeError("unbounded EpisodicReplayBuffer exceeded its device allocation "
+                               "(max_size=%d)" % st.bound)
+        self.episodic_memory.append(_EpisodeRef(first, len(tids)))
+        if self.capacity is None:
+            return
+        while len(self.memory) > self.capacity:
+            self.memory.head += len(self.episodic_memory.popleft())    # whole episodes leave
+
     # -- sampling ----------------------------------------------------------------------------
     def sample(self, n):
         assert len(self.memory) >= n
@@ -64,6 +136,10 @@ class EpisodicReplayBuffer(AbstractEpisodicReplayBuffer):
     def sample_episodes(self, n_episodes, max_len=None):
         assert len(self.episodic_memory) >= n_episodes
         episodes = self.episodic_memory.sample(n_episodes)
+        if self.store is not None:
+            from pfrl_amd.replay_buffer import DeviceEpisode
+
+            episodes = [DeviceEpisode(self.store, ep.first, ep.length) for ep in episodes]
         if max_len is None:
             return episodes
         return [random_subseq(ep, max_len) for ep in episodes]
@@ -78,13 +154,64 @@ class EpisodicReplayBuffer(AbstractEpisodicReplayBuffer):
     # -- checkpoints -------------------------------------------------------------------------
     def save(self, filename):
         """One pickle of ``(memory, episodic_memory)`` (reference :60-62); the shared transition
-        dicts are pickled once thanks to pickle's memo."""
+        dicts are pickled once thanks to pickle's memo.  Device back-end: the same structure with
+        observations read back from HBM (one dict per transition, one array per distinct
+        observation), which the reference's ``load`` reads."""
+        if self.store is None:
+            with open(filename, "wb") as f:
+                pickle.dump((self.memory, self.episodic_memory), f)
+            return
+        import numpy as np
+
+        obs_memo = {}
+
+        def array_of(obs):
+            if obs is None or isinstance(obs, np.ndarray):
+                return obs
+            key = (tuple(int(r) for r in obs.refs), int(obs.min_seq))
+            if key not in obs_memo:
+                obs_memo[key] = np.asarray(obs)
+            return obs_memo[key]
+
+        flat, episodes = RandomAccessQueue(), RandomAccessQueue()
+        for ref in self.episodic_memory:
+            ep = []
+            for i in range(ref.length):
+                d = dict(self.store.entry_view(ref.first + i)[0])
+                d["state"], d["next_state"] = array_of(d["state"]), array_of(d["next_state"])
+                ep.append(d)
+                flat.append([d])
+            episodes.append(ep)
         with open(filename, "wb") as f:
-            pickle.dump((self.memory, self.episodic_memory), f)
+            pickle.dump((flat, episodes), f)
 
     def load(self, filename):
         with open(filename, "rb") as f:
             loaded = pickle.load(f)
+        if self.store is not None:
+            # re-ingest episode by episode: the transitions go back into HBM
+            if isinstance(loaded, tuple):
+                episodes = list(loaded[1])
+            else:
+                episodes, run = [], []
+                for item in loaded:
+                    tr = item[0] if isinstance(item, list) else item
+                    run.append(tr)
+                    if tr["is_state_terminal"]:
+                        episodes.append(run)
+                        run = []
+            for ep in episodes:
+                tids = []
+                for t in ep:
+                    extra = {k: v for k, v in t.items() if k not in (
+                        "state", "action", "reward", "next_state", "is_state_terminal")
+                        and v is not None}
+                    tids.append(self.store.add_transition(t["state"], t["action"], t["reward"],
+                                                          t["next_state"], t["is_state_terminal"],
+                                                          extra or None))
+                self._commit_device(tids)
+            self.store.flush()
+            return
         if isinstance(loaded, tuple):
             self.memory, self.episodic_memory = loaded
             return
@@ -98,3 +225,15 @@ class EpisodicReplayBuffer(AbstractEpisodicReplayBuffer):
             if item["is_state_terminal"]:
                 self.episodic_memory.append(run)
                 run = []
+
+
+class _EpisodeRef:
+    """An episode of the device back-end: ``length`` consecutive entries from seq ``first``."""
+
+    __slots__ = ("first", "length")
+
+    def __init__(self, first, length):
+        self.first, self.length = first, length
+
+    def __len__(self):
+        return self.length

@@ -831,3 +831,140 @@ def test_recurrent_ppo_with_the_network_on_the_device_matches_the_host_run():
     np.testing.assert_array_equal(dev["actions"], host["actions"])
     np.testing.assert_allclose(dev["losses"], host["losses"], rtol=2e-4, atol=1e-5)
     np.testing.assert_allclose(dev["params"], host["params"], rtol=2e-4, atol=1e-5)
+
+
+# ---------------------------------------------------------------------------------------------
+# SURVEY.md 8(f) row 4 on the device: episode payloads in HBM, ragged gather kernel
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "episodic_trace_*.npz"))),
+                         ids=os.path.basename)
+def test_episodic_buffer_on_the_device_follows_reference_trace(path):
+    """The reference traces of test_episodic_buffer_follows_reference_trace with
+    ``EpisodicReplayBuffer(device='cuda:0')``: sizes after every op, sampled episodes / windows /
+    single transitions (same NumPy stream use), eviction of whole episodes."""
+    g = np.load(path)
+    seed, cap, _, batch, max_len = (int(v) for v in g["meta"])
+    np.random.seed(seed)
+    rbuf = EpisodicReplayBuffer(capacity=None if cap < 0 else cap, device="cuda:0", max_size=4096)
+    assert rbuf.is_device
+    sample_at = {int(k): i for i, k in enumerate(g["s_at_op"])}
+    tid = ep_i = tid_i = 0
+    for k in range(len(g["op_kind"])):
+        if g["op_kind"][k] == 1:
+            rbuf.stop_current_episode(env_id=int(g["op_env"][k]))
+        else:
+            rbuf.append(state=np.full(4, tid, np.float32), action=tid % 3, reward=float(tid),
+                        next_state=np.full(4, tid + 1, np.float32),
+                        is_state_terminal=bool(g["op_term"][k]), env_id=int(g["op_env"][k]), tid=tid)
+            tid += 1
+        assert (len(rbuf), rbuf.n_episodes) == (g["length"][k], g["n_episodes"][k]), k
+        if k in sample_at:
+            kind = int(g["s_kind"][sample_at[k]])
+            got = (rbuf.sample_episodes(batch) if kind == 0 else
+                   rbuf.sample_episodes(batch, max_len=max_len) if kind == 1 else
+                   rbuf.sample(batch))
+            for ep in got:
+                n = int(g["s_ep_len"][ep_i])
+                assert [tr["tid"] for tr in ep] == list(g["s_tids"][tid_i:tid_i + n]), k
+                ep_i += 1
+                tid_i += n
+    assert ep_i == len(g["s_ep_len"])
+    assert [len(ep) for ep in rbuf.episodic_memory] == list(g["final_episode_len"])
+    assert [e[0]["tid"] for e in rbuf.memory] == list(g["final_tids"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("obs_kind", ["u8_stack", "f32_vector"])
+def test_device_episode_gather_equals_host_batch_recurrent_experiences(obs_kind):
+    """pfrl_batch_episodes against the host path of the same function on the same episodes:
+    ``state`` / ``next_state`` per episode and action / reward / is_state_terminal / discount in
+    packed time-major order, bit for bit; windows cut by random_subseq included; the payload
+    never leaves the device (the gather reads the HBM transition table and frame ring)."""
+    from pfrl_amd.replay_buffer import DeviceEpisode, batch_recurrent_experiences
+    from pfrl_amd.wrappers.atari_wrappers import LazyFrames
+
+    dev = torch.device("cuda:0")
+    rs = np.random.RandomState(0)
+    dev_buf = EpisodicReplayBuffer(capacity=400, device=dev, max_size=1024)
+    host_buf = EpisodicReplayBuffer(capacity=400)
+    if obs_kind == "u8_stack":
+        frames = [rs.randint(0, 256, size=(1, 6, 6)).astype(np.uint8) for _ in range(700)]
+        obs = lambda i: LazyFrames(frames[i:i + 4], stack_axis=0)       # noqa: E731
+        phi = lambda x: np.asarray(x, dtype=np.float32) / 255           # noqa: E731
+    else:
+        vecs = rs.randn(700, 12).astype(np.float32)
+        obs = lambda i: vecs[i]                                         # noqa: E731
+        phi = lambda x: np.asarray(x, dtype=np.float32)                 # noqa: E731
+    dev_buf.bind(dev, phi)
+    i = 0
+    for ep in range(60):
+        n = int(rs.randint(1, 14))
+        for t in range(n):
+            kw = dict(state=obs(i), action=int(rs.randint(0, 5)), reward=float(rs.randn()),
+                      next_state=obs(i + 1), is_state_terminal=(t == n - 1 and ep % 3 != 0),
+                      env_id=ep % 3,
+                      recurrent_state=((np.full((1, 2), i, np.float32),) * 2,),
+                      next_recurrent_state=((np.full((1, 2), i + 1, np.float32),) * 2,))
+            dev_buf.append(**kw)
+            host_buf.append(**kw)
+            i += 1
+        dev_buf.stop_current_episode(env_id=ep % 3)
+        host_buf.stop_current_episode(env_id=ep % 3)
+    assert len(dev_buf) == len(host_buf) <= 400 and dev_buf.n_episodes == host_buf.n_episodes
+    for max_len, n_eps in ((None, 8), (4, 16), (1, 5), (None, dev_buf.n_episodes)):
+        np.random.seed(5)
+        a = sorted(dev_buf.sample_episodes(n_eps, max_len=max_len), key=len, reverse=True)
+        st = np.random.get_state()
+        np.random.seed(5)
+        b = sorted(host_buf.sample_episodes(n_eps, max_len=max_len), key=len, reverse=True)
+        assert np.array_equal(st[1], np.random.get_state()[1]) and st[2] == np.random.get_state()[2]
+        assert all(isinstance(ep, DeviceEpisode) for ep in a)
+        assert [len(x) for x in a] == [len(x) for x in b]
+        got = batch_recurrent_experiences(a, dev, phi, 0.97)
+        want = batch_recurrent_experiences(b, torch.device("cpu"), phi, 0.97)
+        for key in ("action", "reward", "is_state_terminal", "discount"):
+            assert torch.equal(got[key].cpu(), want[key]), (key, max_len)
+        for key in ("state", "next_state"):
+            assert len(got[key]) == len(want[key])
+            for x, y in zip(got[key], want[key]):
+                assert x.is_cuda and torch.equal(x.cpu(), y), (key, max_len)
+        for key in ("recurrent_state", "next_recurrent_state"):
+            for x, y in zip(got[key][0], want[key][0]):      # ((h, c),) of the first transitions
+                assert torch.equal(x.cpu(), y)
+
+
+@pytest.mark.gpu
+def test_drqn_replays_episodes_from_the_device_store(tmp_path):
+    """DoubleDQN(recurrent=True, gpu=0) binds its EpisodicReplayBuffer to the device: episodes are
+    DeviceEpisode windows gathered by pfrl_batch_episodes, the reference trace still holds
+    (window lengths exactly), and a saved buffer reloads into HBM."""
+    chk = _load_episodic_gpu_checks()
+    from pfrl_amd import ops
+    from pfrl_amd.replay_buffer import DeviceEpisode
+
+    calls = [0]
+    orig = ops.batch_episodes
+
+    def spy(*a, **k):
+        calls[0] += 1
+        return orig(*a, **k)
+
+    ops.batch_episodes = spy
+    seen = []
+    import pfrl_amd.agents.dqn as dqn_mod
+    orig_update = dqn_mod.DQN.update_from_episodes
+
+    def spy_update(self, episodes, errors_out=None):
+        seen.append(all(isinstance(ep, DeviceEpisode) for ep in episodes))
+        rb = self.replay_buffer
+        seen.append(rb.is_device)
+        return orig_update(self, episodes, errors_out)
+
+    dqn_mod.DQN.update_from_episodes = spy_update
+    try:
+        chk.check_drqn()
+    finally:
+        ops.batch_episodes = orig
+        dqn_mod.DQN.update_from_episodes = orig_update
+    assert calls[0] >= 50 and seen and all(seen)
