@@ -358,12 +358,16 @@ int pfrl_dqn_td_loss(const float *q, const int64_t *action, const float *target_
  * bias [A]; out_y / out_abs_delta as pfrl_dqn_td_loss, dh [B][K] = dL/dh (the `mean` scaling
  * included).  What couples the rows leaves as one partial slab per four rows,
  * [ceil(B/4)][A*K + 32], for pfrl_splitk_reduce (splits = ceil(B/4), stride = A*K + 32): dL/dw = the fold of [0, A*K), dL/db of
- * [A*K, A*K + A), the loss of [A*K + 16].  A <= 16, K = 256 or 512. */
+ * [A*K, A*K + A), the loss of [A*K + 16].  A <= 16, K = 256 or 512.  * h_part != NULL: the hidden layer's forward (pfrl_conv2d_nhwc_fwd with splits > 1) left h as
+ * h_splits split-K slabs of h_stride floats; each row folds them here (h = relu(sum + h_bias),
+ * the order of pfrl_splitk_reduce), uses h and writes it to h_out for the backward pass -- the
+ * fold launch between the two disappears.  h is then ignored. */
 int pfrl_dqn_head_td_loss(const float *h, const float *w, const float *bias, const int64_t *action,
                           const float *target_q, const float *next_q_online, const float *reward,
                           const float *discount, const float *terminal, const float *weights,
                           int32_t B, int32_t K, int32_t A, int clip_delta, int mean, float *out_y,
-                          float *out_abs_delta, float *dh, float *partials, void *stream);
+                          float *out_abs_delta, float *dh, float *partials, const float *h_part, int32_t h_splits,
+                          int64_t h_stride, const float *h_bias, float *h_out, void *stream);
 
 /* Fused bias + ReLU of the conv trunk (pfrl/nn/atari_cnn.py:40-47: activation(
  * layer(h)) with conv bias) on row-major [rows][C] activations, i.e.

@@ -165,7 +165,7 @@ EXPORTS = {
     "pfrl_rmsprop_step": (ctypes.c_int, "ipppppffffip"),
     "pfrl_rmsprop_fused_step": (ctypes.c_int, "ipffffip"),
     "pfrl_dqn_td_loss": (ctypes.c_int, "ppppppppqiiippppp"),
-    "pfrl_dqn_head_td_loss": (ctypes.c_int, "ppppppppppiiiiippppp"),
+    "pfrl_dqn_head_td_loss": (ctypes.c_int, "ppppppppppiiiiipppppiqppp"),
     "pfrl_bias_relu_fwd": (ctypes.c_int, "pppqiqp"),
     "pfrl_bias_relu_bwd": (ctypes.c_int, "ppppppqiiqp"),
     "pfrl_c51_loss": (ctypes.c_int, "pppppppppiiiippppp"),

@@ -451,12 +451,27 @@ class DQN(agent.AttributeSavingMixin, agent.BatchAgent):
 
         split = self._head_split() if distributed.world_size() == 1 else None
         qout = None
+        h_fold = None
         if split is not None:
+            from pfrl_amd.nn import mfma_trunk
+
             h = exp_batch["state"]
-            for mod in split[0]:
-                h = mod(h)
+            # the hidden layer may leave its output as split-K slabs for the head launch to fold
+            sink = mfma_trunk.FWD_FOLD_SINK = {} if (
+                self._defer_head_fold and os.environ.get("PFRL_FWD_FOLD", "1") != "0") else None
+            try:
+                for mod in split[0]:
+                    h = mod(h)
+            finally:
+                mfma_trunk.FWD_FOLD_SINK = None
             head = split[1]
-            if not (torch.is_tensor(h) and ops.dqn_head_td_loss_supported(h, head.weight, head.bias)):
+            usable = torch.is_tensor(h) and ops.dqn_head_td_loss_supported(h, head.weight, head.bias)
+            if sink:
+                rec = sink.pop(h.data_ptr(), None) if usable else None
+                mfma_trunk.flush_fwd_folds(sink)        # (anything that is not the head's input)
+                if rec is not None:
+                    h_fold = (rec[1], rec[2], rec[3], rec[4])
+            if not usable:
                 # outside the fused launch (e.g. a head input that is not [B, 256 | 512]): finish
                 # the forward pass from h, separate launches below
                 qout = list(self.model._modules.values())[-1](head(h))
@@ -472,7 +487,7 @@ class DQN(agent.AttributeSavingMixin, agent.BatchAgent):
                 h, head.weight, head.bias, exp_batch["action"], target_q, next_online,
                 exp_batch["reward"], exp_batch["discount"], exp_batch["is_state_terminal"],
                 exp_batch.get("weights"), self.clip_delta, self.batch_accumulator == "mean",
-                defer=self._defer_head_fold)
+                defer=self._defer_head_fold, h_fold=h_fold)
             # the gradients came out of the same launch: backward may start at h, and the
             # head's own gradients are handed over as they are
             if loss.grad_fn is not None:

@@ -117,15 +117,46 @@ __device__ __forceinline__ void head_td_row(
     const float *__restrict__ discount, const float *__restrict__ terminal,
     const float *__restrict__ weights, int B, int clip_delta, int mean, float *__restrict__ out_y,
     float *__restrict__ out_abs_delta, float *__restrict__ dh, const int m, float (*s_c)[64 * KJ],
-    float *s_g, float *s_l, int *s_act) {
+    float *s_g, float *s_l, int *s_act, const float *__restrict__ h_part, int h_splits,
+    int64_t h_stride, const float *__restrict__ h_bias, float *__restrict__ h_out) {
     constexpr int K = 64 * KJ;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // (optional inputs are read through a pointer that is always valid: no branch at a load)
     const float *__restrict__ sel_q = next_q_online ? next_q_online : target_q;
     const float *__restrict__ wt_src = weights ? weights : reward;
     float hv[KJ], wv[A][KJ], tqv[A], nqv[A], bv[A];
+    if (h_part == nullptr) {
 #pragma unroll
-    for (int j = 0; j < KJ; ++j) hv[j] = h[(size_t)m * K + lane + 64 * j];
+        for (int j = 0; j < KJ; ++j) hv[j] = h[(size_t)m * K + lane + 64 * j];
+    } else {
+        // the hidden layer's forward left split-K slabs [h_splits][B][K]: this row's part of the
+        // fold launch -- h = relu(0 + slab 0 + slab 1 + ... + bias), the order of
+        // pfrl_splitk_reduce -- happens here, eight slabs in flight, and h is written out for
+        // the backward pass (ReLU mask, the head's own weight gradient)
+#pragma unroll
+        for (int j = 0; j < KJ; ++j) hv[j] = 0.f;
+        const float *row = h_part + (size_t)m * K + lane;
+        for (int s0 = 0; s0 < h_splits; s0 += 8) {
+            float v[8][KJ];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int sc = min(s0 + u, h_splits - 1);
+#pragma unroll
+                for (int j = 0; j < KJ; ++j) v[u][j] = row[(size_t)sc * h_stride + 64 * j];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (s0 + u < h_splits) {
+#pragma unroll
+                    for (int j = 0; j < KJ; ++j) hv[j] = __fadd_rn(hv[j], v[u][j]);
+                }
+        }
+#pragma unroll
+        for (int j = 0; j < KJ; ++j) {
+            hv[j] = fmaxf(__fadd_rn(hv[j], h_bias[lane + 64 * j]), 0.f);
+            h_out[(size_t)m * K + lane + 64 * j] = hv[j];
+        }
+    }
 #pragma unroll
     for (int a = 0; a < A; ++a) {
 #pragma unroll
@@ -205,7 +236,9 @@ __global__ __launch_bounds__(kThreads) void k_dqn_head_td_rows(
     const float *__restrict__ next_q_online, const float *__restrict__ reward,
     const float *__restrict__ discount, const float *__restrict__ terminal,
     const float *__restrict__ weights, int B, int clip_delta, int mean, float *__restrict__ out_y,
-    float *__restrict__ out_abs_delta, float *__restrict__ dh, float *__restrict__ part) {
+    float *__restrict__ out_abs_delta, float *__restrict__ dh, float *__restrict__ part,
+    const float *__restrict__ h_part, int h_splits, int64_t h_stride,
+    const float *__restrict__ h_bias, float *__restrict__ h_out) {
     constexpr int K = 64 * KJ;
     constexpr int STRIDE = A * K + 32;
     __shared__ float s_c[4][K];
@@ -222,7 +255,7 @@ __global__ __launch_bounds__(kThreads) void k_dqn_head_td_rows(
     if (m < B)
         head_td_row<A, KJ>(h, W, bias, action, target_q, next_q_online, reward, discount, terminal,
                            weights, B, clip_delta, mean, out_y, out_abs_delta, dh, m, s_c, s_g, s_l,
-                           s_act);
+                           s_act, h_part, h_splits, h_stride, h_bias, h_out);
     __syncthreads();
     float *pr = part + (size_t)blockIdx.x * STRIDE;
     for (int e = tid; e < A * K; e += kThreads) {
@@ -254,9 +287,12 @@ extern "C" int pfrl_dqn_head_td_loss(const float *h, const float *w, const float
                                      const float *discount, const float *terminal, const float *weights,
                                      int32_t B, int32_t K, int32_t A, int clip_delta, int mean,
                                      float *out_y, float *out_abs_delta, float *dh, float *partials,
-                                     void *stream) {
+                                     const float *h_part, int32_t h_splits, int64_t h_stride,
+                                     const float *h_bias, float *h_out, void *stream) {
     PFRL_CHECK_ARG(B >= 1 && A >= 1 && A <= 16 && (K == 512 || K == 256),
                    "pfrl_dqn_head_td_loss: A <= 16, K = 256 or 512");
+    PFRL_CHECK_ARG(h_part == nullptr || (h_splits >= 1 && h_bias && h_out && h_stride >= (int64_t)B * K),
+                   "pfrl_dqn_head_td_loss: bad hidden-layer fold arguments");
     const dim3 grid((B + 3) / 4);
 #define CALL_HT(AA)                                                                                \
     do {                                                                                           \
@@ -264,12 +300,14 @@ extern "C" int pfrl_dqn_head_td_loss(const float *h, const float *w, const float
             hipLaunchKernelGGL((k_dqn_head_td_rows<AA, 8>), grid, dim3(kThreads), 0,               \
                                (hipStream_t)stream, h, w, bias, action, target_q, next_q_online,   \
                                reward, discount, terminal, weights, B, clip_delta, mean, out_y,    \
-                               out_abs_delta, dh, partials);                                       \
+                               out_abs_delta, dh, partials, h_part, h_splits, h_stride, h_bias,    \
+                               h_out);                                                             \
         else                                                                                       \
             hipLaunchKernelGGL((k_dqn_head_td_rows<AA, 4>), grid, dim3(kThreads), 0,               \
                                (hipStream_t)stream, h, w, bias, action, target_q, next_q_online,   \
                                reward, discount, terminal, weights, B, clip_delta, mean, out_y,    \
-                               out_abs_delta, dh, partials);                                       \
+                               out_abs_delta, dh, partials, h_part, h_splits, h_stride, h_bias,    \
+                               h_out);                                                             \
     } while (0)
     switch (A) {
         case 1: CALL_HT(1); break;   case 2: CALL_HT(2); break;   case 3: CALL_HT(3); break;

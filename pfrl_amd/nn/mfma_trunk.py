@@ -234,8 +234,25 @@ def linear_fwd(x, w, b, relu=True):
     part = torch.empty((splits, M, F), dtype=torch.float32, device=x.device)
     check(_native.lib().pfrl_conv2d_nhwc_fwd(_p(x), _p(w), None, _p(part), M, 1, 1, K, F, 1, 1, 1, 0,
                                              0, splits, _stream()), "linear_fwd_splitk")
+    if FWD_FOLD_SINK is not None and relu and b is not None:
+        # the consumer (the fused head + TD-loss launch) folds the slabs itself and fills y
+        FWD_FOLD_SINK[y.data_ptr()] = (y, part, b, M * F, splits)
+        return y
     _reduce([(part, y, b, M * F, M * F, splits, F, int(relu))])
     return y
+
+
+# Set to a dict by a caller that can fold the hidden layer's split-K slabs in its own launch
+# (DQN._compute_loss_fused -> ops.dqn_head_td_loss(h_fold=...)): linear_fwd then returns the
+# output tensor UNFILLED and records data_ptr -> (y, part, bias, stride, splits) here.  Whatever
+# the caller does not consume it must hand to flush_fwd_folds().
+FWD_FOLD_SINK = None
+
+
+def flush_fwd_folds(sink):
+    for y, part, b, stride, splits in sink.values():
+        _reduce([(part, y, b, stride, stride, splits, y.shape[1], 1)])
+    sink.clear()
 
 
 class _Trunk(torch.autograd.Function):

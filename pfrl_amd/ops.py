@@ -363,12 +363,20 @@ class _DQNHeadTDLoss(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, h, w, b, action, target_q, next_q_online, reward, discount, terminal, weights,
-                clip_delta, mean, defer):
+                clip_delta, mean, defer, h_fold=None):
         from pfrl_amd.nn import mfma_trunk
 
         B, K = h.shape
         A = w.shape[0]
         hc = h.detach().contiguous()
+        if h_fold is not None:
+            # h is still the hidden layer's split-K slabs: this launch folds them row by row and
+            # fills h itself (the tensor the trunk saved for its backward pass)
+            f_part, f_bias, f_stride, f_splits = h_fold
+            assert hc.data_ptr() == h.data_ptr()
+            fold_args = (_ptr(f_part), int(f_splits), int(f_stride), _ptr(f_bias), _ptr(hc))
+        else:
+            fold_args = (None, 0, 0, None, None)
         dev = h.device
         loss = torch.empty(1, dtype=torch.float32, device=dev)
         y = torch.empty(B, dtype=torch.float32, device=dev)
@@ -385,7 +393,8 @@ class _DQNHeadTDLoss(torch.autograd.Function):
             _ptr(next_q_online.contiguous()) if next_q_online is not None else None,
             _ptr(reward), _ptr(discount), _ptr(terminal),
             _ptr(weights.contiguous()) if weights is not None else None, B, K, A, int(clip_delta),
-            int(mean), _ptr(y), _ptr(delta), _ptr(dh), _ptr(part), _stream()), "dqn_head_td_loss")
+            int(mean), _ptr(y), _ptr(delta), _ptr(dh), _ptr(part), *fold_args, _stream()),
+            "dqn_head_td_loss")
         tasks = [(part, dw, None, stride, A * K, slabs, 4, 0),
                  (part[A * K:], db, None, stride, A, slabs, 4, 0),
                  (part[A * K + 16:], loss, None, stride, 1, slabs, 4, 0)]
@@ -401,7 +410,7 @@ class _DQNHeadTDLoss(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_loss, g_y, g_delta):
         dh, dw, db = ctx.saved_tensors
-        return (dh * g_loss, dw * g_loss, db * g_loss) + (None,) * 10
+        return (dh * g_loss, dw * g_loss, db * g_loss) + (None,) * 11
 
 
 def dqn_head_td_loss_supported(h, w, b):
@@ -411,12 +420,14 @@ def dqn_head_td_loss_supported(h, w, b):
 
 
 def dqn_head_td_loss(h, w, b, action, target_q, next_q_online, reward, discount, terminal, weights,
-                     clip_delta, mean, defer=False):
+                     clip_delta, mean, defer=False, h_fold=None):
     """-> (loss scalar with grad w.r.t. h, w, b; y [B]; |y - t| [B]).  With ``defer`` the loss
     value and the head's gradients are final only after the deferred fold has run (the trunk's
-    backward or ``mfma_trunk.flush_deferred_folds()``)."""
+    backward or ``mfma_trunk.flush_deferred_folds()``).  ``h_fold`` = (part, bias, stride,
+    splits): ``h`` has not been folded from the hidden layer's split-K slabs yet
+    (``mfma_trunk.FWD_FOLD_SINK``) -- this launch does it and fills ``h``."""
     return _DQNHeadTDLoss.apply(h, w, b, action, target_q, next_q_online, reward, discount, terminal,
-                                weights, clip_delta, mean, defer)
+                                weights, clip_delta, mean, defer, h_fold)
 
 
 _bias_relu_ws = {}

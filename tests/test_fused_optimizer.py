@@ -78,7 +78,7 @@ def test_lowrank_tile_layout_is_not_transposed():
     assert torch.allclose(w.detach(), want, rtol=1e-6, atol=1e-7)
 
 
-def _run_updates(fused, n_updates=6):
+def _run_updates(fused, n_updates=6, fwd_fold=True):
     import pfrl_amd as pfrl
     from pfrl_amd import agents, explorers, replay_buffers
     from pfrl_amd.device_store import DeviceFrameStore
@@ -88,6 +88,7 @@ def _run_updates(fused, n_updates=6):
     from pfrl_amd.q_functions import DiscreteActionValueHead
 
     os.environ["PFRL_FUSED_OPT"] = "1" if fused else "0"
+    os.environ["PFRL_FWD_FOLD"] = "1" if fwd_fold else "0"
     try:
         dev = torch.device("cuda:0")
         pfrl.utils.set_random_seed(0)
@@ -117,6 +118,7 @@ def _run_updates(fused, n_updates=6):
                 np.asarray(ag.loss_record.values()), used)
     finally:
         os.environ.pop("PFRL_FUSED_OPT", None)
+        os.environ.pop("PFRL_FWD_FOLD", None)
 
 
 def test_dqn_updates_with_the_gradient_finishing_optimizer_match_the_plain_step():
@@ -129,3 +131,15 @@ def test_dqn_updates_with_the_gradient_finishing_optimizer_match_the_plain_step(
     np.testing.assert_allclose(la, lb, rtol=2e-5, atol=1e-6)
     for a, b in zip(pa, pb):
         assert np.abs(a - b).max() <= 2e-5 * max(1e-3, np.abs(b).max())
+
+
+def test_hidden_layer_fold_inside_the_head_launch_is_bit_identical():
+    """The hidden layer's split-K slabs folded by the head + TD-loss launch (default) vs by their
+    own pfrl_splitk_reduce launch (PFRL_FWD_FOLD=0): same summation order, so the same bits --
+    losses and every parameter after 6 updates."""
+    pa, la, ua = _run_updates(True, fwd_fold=True)
+    pb, lb, ub = _run_updates(True, fwd_fold=False)
+    assert ua and ub
+    np.testing.assert_array_equal(la, lb)
+    for a, b in zip(pa, pb):
+        np.testing.assert_array_equal(a, b)
