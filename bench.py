@@ -330,6 +330,7 @@ def build_agent(args, device, rank):
         batch_accumulator="sum", phi=phi)
     if args.chunks is not None:
         agent.step_fused_chunks = tuple(float(x) for x in args.chunks.split(",") if x)
+        agent._chunks_set_by_caller = True
     agent.grad_reducer.broadcast_parameters(agent.model)
     agent.sync_target_network()
     return agent, env, rbuf

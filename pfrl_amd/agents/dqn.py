@@ -216,6 +216,7 @@ class DQN(agent.AttributeSavingMixin, agent.BatchAgent):
         self.fused_td_loss = bool(fused_td_loss)
         # env-range boundaries (fractions of num_envs) of the step-fused path
         self.step_fused_chunks = tuple(step_fused_chunks)
+        self._chunks_set_by_caller = tuple(step_fused_chunks) != (0.1, 0.4)
         self._target_raw_bufs = {}
         self._single_bufs = {}
         self.range_graphs = os.environ.get("PFRL_RANGE_GRAPHS", "1") != "0"
@@ -733,7 +734,13 @@ class DQN(agent.AttributeSavingMixin, agent.BatchAgent):
         # index draws, launches), instead of the GPU idling through the whole
         # preparation.  Order of appends, RNG draws, target syncs and updates is the
         # reference's in every case.
-        cuts = sorted({0, n_env} | {int(n_env * f) for f in self.step_fused_chunks})
+        chunks = self.step_fused_chunks
+        if self.__dict__.get("_obs_cols") is not None and not self._chunks_set_by_caller:
+            # native step: the host's share of a step is ~0.3 ms and nothing waits for the GPU, so
+            # there is no preparation to hide -- one range, one gather, one graph per step
+            # (measured 33.4 k vs 33.0 k env-steps/s with the (0.1, 0.4) cuts)
+            chunks = ()
+        cuts = sorted({0, n_env} | {int(n_env * f) for f in chunks})
         for lo, hi in zip(cuts[:-1], cuts[1:]):
             self._observe_range_fused(lo, hi, batch_obs, batch_reward, batch_done, batch_reset)
 

@@ -185,7 +185,7 @@ def test_dqn_bench_path_minibatches_match_oracle():
     # ... including the native step: device-resident actions, planner-drawn index sets
     from pfrl_amd.device_store import DeviceActions
 
-    assert agent.device_step and native_calls[0] > 150
+    assert agent.device_step and native_calls[0] >= 60      # one planned range per updating step
     assert isinstance(agent.batch_last_action.batch, DeviceActions)
 
 
