@@ -196,7 +196,7 @@ def build_ppo(args, device, rank):
         # Conv2d + ReLU pairs of the Sequential -> MIOpen conv + one fused bias/ReLU
         # launch (same parameters, same state_dict)
         model = pfrl.nn.fuse_conv_bias_relu(model).to(memory_format=torch.channels_last)
-        if os.environ.get("PFRL_PPO_TRUNK", "0") == "1":
+        if os.environ.get("PFRL_PPO_TRUNK", "1") == "1":
             # conv stack + hidden layer as the f32 MFMA trunk kernels (csrc/qnet.hip)
             pfrl.nn.fuse_sequential_trunk(model)
     opt = torch.optim.Adam(model.parameters(), lr=2.5e-4, eps=1e-5, fused=True)
