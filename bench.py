@@ -847,7 +847,7 @@ def main():
             # configs[2] and configs[4], short: every GPU config of BASELINE.json on one line
             for algo, n_envs, mb, blas in (("rainbow", 256, 32, "default"), ("sac", 64, 256, "tunable")):
                 a2 = copy.copy(args)
-                a2.algo, a2.steps, a2.warmup = algo, 50, 5
+                a2.algo, a2.steps, a2.warmup = algo, 50, 20   # (warm-up: every double-buffered minibatch set captures its graphs)
                 a2.num_envs, a2.minibatch, a2.blas = n_envs, mb, blas
                 a2.cudnn_benchmark = True
                 torch.backends.cudnn.benchmark = True

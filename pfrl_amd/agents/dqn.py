@@ -802,11 +802,11 @@ class DQN(agent.AttributeSavingMixin, agent.BatchAgent):
                 raw = self._precompute_target_raw(ns.view((U * B,) + tuple(ns.shape[2:])))
                 # captured updates are keyed by buffer addresses: park the values in a
                 # persistent buffer instead of whatever block the allocator handed out
-                key = (U, B) + tuple(raw.shape[1:])
+                key = (U, B, getattr(rbuf.store, "many_parity", 0)) + tuple(raw.shape[1:])
                 buf = self._target_raw_bufs.get(key)
                 if buf is None:
                     buf = self._target_raw_bufs[key] = torch.empty(
-                        key, dtype=raw.dtype, device=raw.device)
+                        (U, B) + tuple(raw.shape[1:]), dtype=raw.dtype, device=raw.device)
                 buf.view(raw.shape).copy_(raw)
                 big["target_next_raw"] = buf
         if big is not None and self._range_as_one_graph(t0, hi - lo):

@@ -6,10 +6,12 @@ the EPISODE -- ``episodic_memory`` is a ``PrioritizedBuffer`` whose payloads are
 ``memory`` is a plain FIFO of single transitions bounded by ``capacity``; ``capacity_left`` counts
 transitions and evicts whole episodes, oldest first, once it goes negative (:60-76).
 
-The episode payloads stay on the host, as in the reference.  The sum / min trees over the
-episodes are host trees by default (``collections.host_prioritized``: one leaf per EPISODE, a few
-thousand at most) and the HBM-resident ``pfrl_amd.collections.PrioritizedBuffer`` when a
-``device`` is given explicitly.
+The sum / min trees over the episodes are host trees by default (``collections.host_prioritized``:
+one leaf per EPISODE, a few thousand at most) and the HBM-resident
+``pfrl_amd.collections.PrioritizedBuffer`` when a ``device`` is given explicitly.  The episode
+PAYLOADS follow ``EpisodicReplayBuffer``: on the host as lists of dicts by default, and in HBM
+(transition table + frame ring, an episode = a run of consecutive entries, ragged gather by
+pfrl_batch_episodes) once an agent with ``gpu >= 0`` has bound the buffer (``bind``).
 """
 import collections
 
@@ -41,6 +43,7 @@ class PrioritizedEpisodicReplayBuffer(EpisodicReplayBuffer, PriorityWeightError)
         self.episodic_memory = _tree_factory(wait_priority_after_sampling, device, max_episodes)
         self.memory = RandomAccessQueue(maxlen=capacity)
         self.capacity = capacity
+        self._device_opts = dict(max_size=None, slack=None, frame_slots=None)
         self.capacity_left = capacity
         self.default_priority_func = default_priority_func
         self.uniform_ratio = uniform_ratio
@@ -49,6 +52,28 @@ class PrioritizedEpisodicReplayBuffer(EpisodicReplayBuffer, PriorityWeightError)
                                      error_min=error_min, error_max=error_max)
 
     def _commit(self, episode):
+        if self.store is not None:
+            # device payloads: the episode's transitions become consecutive entries
+            from pfrl_amd.replay_buffer import DeviceEpisode
+            from pfrl_amd.replay_buffers.episodic import _EpisodeRef
+
+            st = self.store
+            first = st.n_entries
+            for tid in episode:
+                st.add_entry([tid])
+            ref = _EpisodeRef(first, len(episode))
+            priority = None
+            if self.default_priority_func is not None:
+                priority = self.default_priority_func(DeviceEpisode(st, first, len(episode)))
+            self.episodic_memory.append(ref, priority=priority)
+            if self.capacity_left is None:
+                return
+            self.capacity_left -= len(ref)
+            while self.capacity_left < 0:
+                gone = len(self.episodic_memory.popleft())
+                self.capacity_left += gone
+                self.memory.head += gone
+            return
         priority = None
         if self.default_priority_func is not None:
             priority = self.default_priority_func(episode)
@@ -64,6 +89,10 @@ class PrioritizedEpisodicReplayBuffer(EpisodicReplayBuffer, PriorityWeightError)
         assert len(self.episodic_memory) >= n_episodes
         episodes, probabilities, min_prob = self.episodic_memory.sample(
             n_episodes, uniform_ratio=self.uniform_ratio)
+        if self.store is not None:
+            from pfrl_amd.replay_buffer import DeviceEpisode
+
+            episodes = [DeviceEpisode(self.store, ep.first, ep.length) for ep in episodes]
         if max_len is not None:
             episodes = [random_subseq(ep, max_len) for ep in episodes]
         if not self.return_sample_weights:

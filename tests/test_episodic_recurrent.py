@@ -968,3 +968,14 @@ def test_drqn_replays_episodes_from_the_device_store(tmp_path):
         ops.batch_episodes = orig
         dqn_mod.DQN.update_from_episodes = orig_update
     assert calls[0] >= 50 and seen and all(seen)
+
+
+@pytest.mark.gpu
+def test_prioritized_episodic_buffer_with_payloads_in_hbm_matches_reference_traces():
+    """PrioritizedEpisodicReplayBuffer bound to the device (priority trees AND episode payloads in
+    HBM) against the reference traces: sizes, capacity_left, sampled windows, weights."""
+    mod = _load_episodic_gpu_checks()
+    paths = sorted(glob.glob(os.path.join(mod.GOLDEN, "prioritized_episodic_trace_*.npz")))
+    assert paths
+    for p in paths:
+        mod.check_prioritized_episodic(p, payload_on_device=True)
