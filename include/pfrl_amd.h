@@ -623,6 +623,11 @@ int pfrl_batch_episodes(const pfrl_table_t *tab, const void *frames, int64_t fra
                         void *out_next_state, void *out_action, float *out_reward,
                         float *out_terminal, float *out_discount, void *stream);
 
+/* hipMemcpyAsync(dst, host_src, nbytes, HostToDevice, stream) for the pinned staging rings
+ * (pfrl_amd/staging.py): the H2D of the reference's `.to(device)` in pfrl/utils/batch_states.py:
+ * 18-36 and `torch.tensor([...], device=...)` conversions, reduced to index / draw traffic. */
+int pfrl_h2d_async(void *dst, const void *host_src, int64_t nbytes, void *stream);
+
 /* ------------------------------------------------------------------------
  * HOST step planner (no device work; every pointer is host memory).  The reference's batched
  * step consumes NumPy's legacy global stream in a fixed order (pfrl/agents/dqn.py:490-549):

@@ -131,6 +131,25 @@ class PrioritizedBuffer:
         self._pend_x, self._pend_v, self._pend_t, self._pend_m = [], [], [], []
         self._pend_at = {}
 
+    def take_pending(self):
+        """The recorded leaf writes as four arrays for a SHARED staging transfer (at most 1024
+        of them; None otherwise) and the launch to make once they are on the device -- so that
+        a sample's whole control traffic (these, the uniform draws, the store's new rows) crosses
+        PCIe as ONE copy in front of the launches instead of one copy in front of each."""
+        n = len(self._pend_x)
+        if n == 0 or n > 1024:
+            return None
+        arrays = [np.asarray(self._pend_x, dtype=np.int64), np.asarray(self._pend_v, dtype=np.float64),
+                  np.asarray(self._pend_t, dtype=np.uint8), np.asarray(self._pend_m, dtype=np.uint8)]
+        desc = self._sync_desc()
+        self._pend_x, self._pend_v, self._pend_t, self._pend_m = [], [], [], []
+        self._pend_at = {}
+
+        def launch(x, v, t, m):
+            ops.tree_write(desc, x, v, t, m)
+
+        return arrays, launch
+
     # -- reference API ------------------------------------------------------
     def append(self, value, priority=None):
         """prioritized.py:39-48"""
@@ -187,13 +206,17 @@ class PrioritizedBuffer:
         self.frame.popleft()
         return self.data.popleft()
 
-    def sample_device(self, n, u01=None, normalize=1, beta=0.0, slot_mod=0):
+    def sample_device(self, n, u01=None, normalize=1, beta=0.0, slot_mod=0, co_stage=None):
         """Device-side ``sample``: returns a dict of device tensors (x, pri,
         pri_tag, prob, weight, total, total_tag, min_prob[, slot]).  ``u01``
-        defaults to the draws np.random.uniform would consume (same stream)."""
+        defaults to the draws np.random.uniform would consume (same stream).
+        ``co_stage`` = (arrays, launch) of another object (the replay store's new rows) whose
+        control traffic rides in the same host->device copy."""
         assert not self.wait_priority_after_sampling or not self.flag_wait_priority
         assert len(self) >= n
-        self.flush()
+        pending = self.take_pending()
+        if pending is None:
+            self.flush()            # (nothing pending, or more than one launch's worth)
         if u01 is None:
             u01 = np.random.random_sample(n)
         key = n
@@ -218,8 +241,24 @@ class PrioritizedBuffer:
         if not slot_mod:
             del out["slot"]
         with on_stream(self.side_stream):
-            (u_dev,) = self._stage.upload([np.asarray(u01, dtype=np.float64)])
-            ops.tree_sample(self._sync_desc(), u_dev, out, normalize, beta, slot_mod)
+            # ONE transfer for everything this sample's launches read from the host
+            arrays = [np.asarray(u01, dtype=np.float64)]
+            n_t = n_c = 0
+            if pending is not None:
+                arrays += pending[0]
+                n_t = len(pending[0])
+            if co_stage is not None:
+                arrays += co_stage[0]
+                n_c = len(co_stage[0])
+            need = sum(((a.nbytes + 15) & ~15) for a in arrays)
+            if need > self._stage.slot_bytes:
+                self._stage = StagingRing(self.device, slot_bytes=2 * need, n_slots=32)
+            views = self._stage.upload(arrays)
+            if co_stage is not None:
+                co_stage[1](*views[1 + n_t:1 + n_t + n_c])
+            if pending is not None:
+                pending[1](*views[1:1 + n_t])
+            ops.tree_sample(self._sync_desc(), views[0], out, normalize, beta, slot_mod)
         self._sampled_x = out["x"]
         self._n_sampled = n
         self.flag_wait_priority = True

@@ -7,6 +7,21 @@
 #include "common.h"
 #include "powf_glibc.h"
 
+// One pinned-host -> device transfer on `stream` (hipMemcpyAsync): the staging rings' control
+// traffic (a few hundred bytes of indices / draws per call).  Through torch the same copy is two
+// slices + copy_ + dispatch, ~15 us of host time; Rainbow makes four such uploads per update.
+extern "C" int pfrl_h2d_async(void *dst, const void *host_src, int64_t nbytes, void *stream) {
+    PFRL_CHECK_ARG(dst && host_src && nbytes >= 0, "pfrl_h2d_async: null argument");
+    if (nbytes == 0) return 0;
+    hipError_t e = hipMemcpyAsync(dst, host_src, (size_t)nbytes, hipMemcpyHostToDevice,
+                                  (hipStream_t)stream);
+    if (e != hipSuccess) {
+        pfrl_set_error(hipGetErrorString(e));
+        return (int)e;
+    }
+    return 0;
+}
+
 extern "C" int pfrl_powf_host(int pow_mode, const float *host_x, float alpha, float *host_out,
                               int64_t n) {
     PFRL_CHECK_ARG(host_x && host_out && n >= 0, "pfrl_powf_host: null argument");

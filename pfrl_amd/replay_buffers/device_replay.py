@@ -473,6 +473,32 @@ class DeviceReplayStore:
         self.n_entries = seq + 1
         return seq
 
+    def take_pending(self):
+        """Staged transition rows and entries as arrays for a SHARED staging transfer, and the
+        launches to make once they are on the device (see PrioritizedBuffer.take_pending); None
+        when there is nothing to ship or host frames are waiting (those go through flush())."""
+        if self._pend_frames or not (self._pend_rows or self._pend_entries):
+            return None
+        r, e = self._pend_rows, self._pend_entries
+        arrays = []
+        if r:
+            arrays += [self._s_slot[:r].copy(), self._s_state[:r].copy(), self._s_next[:r].copy(),
+                       self._s_action[:r].copy(), self._s_reward[:r].copy(), self._s_term[:r].copy()]
+        if e:
+            arrays += [self._s_eslot[:e].copy(), self._s_etids[:e].copy(), self._s_elen[:e].copy()]
+        self._pend_rows = self._pend_entries = 0
+        desc = self.desc
+
+        def launch(*views):
+            k = 0
+            if r:
+                ops.table_append(desc, *views[:6])
+                k = 6
+            if e:
+                ops.entries_append(desc, *views[k:k + 3])
+
+        return arrays, launch
+
     def flush(self):
         """Ship staged frames, transition rows and entries to HBM (async)."""
         if not (self._pend_frames or self._pend_rows or self._pend_entries):

@@ -172,8 +172,11 @@ class PrioritizedReplayBuffer(ReplayBuffer, PriorityWeightError):
                 entry[0]["weight"] = w
             return sampled
         tree = self.memory.tree
+        # the store's new rows ride in the same host->device copy as the tree's pending leaf
+        # writes and the uniform draws: one copy in front of the launches of this sample
         out = tree.sample_device(n, normalize=_NORMALIZE_CODE[self.normalize_by_max],
-                                 beta=self.beta, slot_mod=self.store.E)
+                                 beta=self.beta, slot_mod=self.store.E,
+                                 co_stage=self.store.take_pending())
         self.beta = min(1.0, self.beta + self.beta_add)
         self._last_sample = out
         return DeviceExperienceBatch(self.store, out["slot"], _LazySeqs(out["x"], n),

@@ -66,13 +66,15 @@ class PrioritizedEpisodicReplayBuffer(EpisodicReplayBuffer, PriorityWeightError)
             if self.default_priority_func is not None:
                 priority = self.default_priority_func(DeviceEpisode(st, first, len(episode)))
             self.episodic_memory.append(ref, priority=priority)
+            if self.capacity is not None:
+                # ``memory`` is a FIFO of single transitions with maxlen = capacity (reference
+                # :47): the oldest TRANSITIONS leave one by one, whatever the episodes do
+                self.memory.head = max(self.memory.head, st.n_entries - self.capacity)
             if self.capacity_left is None:
                 return
             self.capacity_left -= len(ref)
             while self.capacity_left < 0:
-                gone = len(self.episodic_memory.popleft())
-                self.capacity_left += gone
-                self.memory.head += gone
+                self.capacity_left += len(self.episodic_memory.popleft())
             return
         priority = None
         if self.default_priority_func is not None:

@@ -10,6 +10,10 @@ import torch
 
 
 class StagingRing:
+    # seconds the host spent waiting for a slot's previous transfer (all rings): how far ahead of
+    # the device the host runs shows up here, not in its own work
+    wait_s = 0.0
+
     def __init__(self, device, slot_bytes=1 << 16, n_slots=64):
         self.device = torch.device(device)
         self.slot_bytes = slot_bytes
@@ -17,33 +21,57 @@ class StagingRing:
         self._host = [torch.empty(slot_bytes, dtype=torch.uint8).pin_memory()
                       for _ in range(n_slots)]
         self._host_np = [h.numpy() for h in self._host]
+        self._host_ptr = [h.data_ptr() for h in self._host]
         self._dev = [torch.empty(slot_bytes, dtype=torch.uint8, device=self.device)
                      for _ in range(n_slots)]
-        self._events = [None] * n_slots
+        self._dev_ptr = [d.data_ptr() for d in self._dev]
+        # one event object per slot, re-recorded on every use; typed views of the device slot
+        # cached by layout (the same few layouts come back on every call)
+        self._events = [torch.cuda.Event() for _ in range(n_slots)]
+        self._used = [False] * n_slots
+        self._views = [dict() for _ in range(n_slots)]
         self._i = 0
+        self._copy = None
+
+    def _wait(self, i):
+        if self._used[i]:
+            ev = self._events[i]
+            if not ev.query():
+                import time
+
+                t0 = time.perf_counter()
+                ev.synchronize()
+                StagingRing.wait_s += time.perf_counter() - t0
+
+    def _ship(self, i, total):
+        """The first ``total`` bytes of pinned slot i -> device slot i on the current stream."""
+        if self._copy is None:
+            import ctypes
+
+            from pfrl_amd import _native
+
+            self._copy = _native.lib().pfrl_h2d_async
+            self._vp = ctypes.c_void_p
+        rc = self._copy(self._dev_ptr[i], self._host_ptr[i], total,
+                        self._vp(torch.cuda.current_stream(self.device).cuda_stream))
+        if rc != 0:
+            raise RuntimeError("pfrl_h2d_async failed (%d)" % rc)
+        self._events[i].record()
+        self._used[i] = True
 
     def reserve(self):
         """Next pinned slot for the caller to fill in place: (numpy uint8 view, token).  Waits
         for the slot's previous transfer.  Follow with :meth:`commit`."""
         i = self._i
         self._i = (i + 1) % self.n_slots
-        ev = self._events[i]
-        if ev is not None:
-            ev.synchronize()
-            self._events[i] = None
+        self._wait(i)
         return self._host_np[i], i
 
     def commit(self, token, nbytes):
         """Ship the first ``nbytes`` of a reserved slot in ONE async transfer; returns the
         device uint8 buffer of that slot (valid until the ring wraps)."""
-        i = token
-        total = (int(nbytes) + 15) & ~15
-        dev = self._dev[i]
-        dev[:total].copy_(self._host[i][:total], non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record()
-        self._events[i] = ev
-        return dev
+        self._ship(token, (int(nbytes) + 15) & ~15)
+        return self._dev[token]
 
     @staticmethod
     def view(dev, offset, count, dtype, shape=None):
@@ -57,12 +85,10 @@ class StagingRing:
         wraps, i.e. for the next ``n_slots - 1`` uploads)."""
         i = self._i
         self._i = (i + 1) % self.n_slots
-        ev = self._events[i]
-        if ev is not None:
-            ev.synchronize()
+        self._wait(i)
         hb = self._host_np[i]
         off = 0
-        spans = []
+        key = []
         for a in arrays:
             a = np.ascontiguousarray(a)
             nb = a.nbytes
@@ -70,19 +96,21 @@ class StagingRing:
             if off + nb > self.slot_bytes:
                 raise ValueError("staging slot too small: need %d bytes" % (off + nb))
             hb[off:off + nb] = a.view(np.uint8).reshape(-1)
-            spans.append((off, nb, a.dtype, a.shape))
+            key.append((off, a.dtype.num, a.shape))
             off += nb
-        total = (off + 15) & ~15
-        dev = self._dev[i]
-        dev[:total].copy_(self._host[i][:total], non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record()
-        self._events[i] = ev
-        outs = []
-        for (o, nb, dt, shape) in spans:
-            t = dev[o:o + nb].view(_TORCH_DTYPES[np.dtype(dt)]).view(shape)
-            outs.append(t)
-        return outs
+        self._ship(i, (off + 15) & ~15)
+        key = tuple(key)
+        outs = self._views[i].get(key)
+        if outs is None:
+            dev = self._dev[i]
+            outs = []
+            for (o, _, shape), a in zip(key, arrays):
+                a = np.asarray(a)
+                outs.append(dev[o:o + a.nbytes].view(_TORCH_DTYPES[a.dtype]).view(shape))
+            if len(self._views[i]) > 32:
+                self._views[i].clear()
+            self._views[i][key] = outs
+        return list(outs)
 
 
 _TORCH_DTYPES = {

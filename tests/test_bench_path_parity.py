@@ -228,11 +228,11 @@ def test_rainbow_bench_path_tree_matches_oracle(priority_pow):
         counts["appends"] += 1
         return orig_append(self, value, priority)
 
-    def spy_sample(self, n, u01=None, normalize=1, beta=0.0, slot_mod=0):
+    def spy_sample(self, n, u01=None, normalize=1, beta=0.0, slot_mod=0, **kw):
         assert u01 is None
         u = np.random.random_sample(n)          # the draws np.random.uniform would consume
         want = orc.sample(u)
-        out = orig_sample(self, n, u01=u, normalize=normalize, beta=beta, slot_mod=slot_mod)
+        out = orig_sample(self, n, u01=u, normalize=normalize, beta=beta, slot_mod=slot_mod, **kw)
         self._join()
         x = out["x"].cpu().numpy()
         np.testing.assert_array_equal(x - self.frame.head, want["indices"])

@@ -192,10 +192,10 @@ def test_rainbow_configs2_at_capacity_1e6_tree_matches_oracle():
         log2_seen.add(self.frame.log2_size)
         return r
 
-    def spy_sample(self, n, u01=None, normalize=1, beta=0.0, slot_mod=0):
+    def spy_sample(self, n, u01=None, normalize=1, beta=0.0, slot_mod=0, **kw):
         u = np.random.random_sample(n)
         want = orc.sample(u)
-        out = orig_sample(self, n, u01=u, normalize=normalize, beta=beta, slot_mod=slot_mod)
+        out = orig_sample(self, n, u01=u, normalize=normalize, beta=beta, slot_mod=slot_mod, **kw)
         if checking[0]:
             self._join()
             x = out["x"].cpu().numpy()
