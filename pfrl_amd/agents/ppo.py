@@ -26,6 +26,7 @@ Created without a GPU (``gpu=None / -1``) the agent runs the reference's list-of
 instead (``ppo_host.HostRollouts``), which is also where ``recurrent=True`` lives; the HIP kernels
 are never involved there and nothing on the device path falls back to it.
 """
+import os
 import random
 from logging import getLogger
 
@@ -78,6 +79,7 @@ class _Rollout:
         self.h_nonterm = np.zeros((t_cap, n_envs), dtype=np.uint8)
         self.h_cut = np.zeros((t_cap, n_envs), dtype=np.uint8)
         self.h_action = np.zeros((t_cap, n_envs) + tuple(act_shape), dtype=act_dtype)
+        self.d_action = None      # [t_cap, N, ...] on the device when the actions never left it
         self.closed = []          # (env, t_start, t_end) in completion order
         self.open_start = np.zeros(n_envs, dtype=np.int64)
         self.min_seq = None       # oldest frame-ring sequence number any stored ref points at
@@ -91,7 +93,18 @@ class _Rollout:
         assert t < self.cap, "rollout longer than allocated"
         self.h_state[t] = s_refs
         self.h_next[t] = n_refs
-        self.h_action[t] = action
+        if isinstance(action, torch.Tensor):
+            # device-resident actions (device env: nothing on the host ever looks at them)
+            if self.d_action is None:
+                self.d_action = torch.zeros((self.cap,) + tuple(action.shape), dtype=action.dtype,
+                                            device=action.device)
+                if t > 0:
+                    self.d_action[:t].copy_(torch.from_numpy(self.h_action[:t]))
+            self.d_action[t].copy_(action)
+        else:
+            self.h_action[t] = action
+            if self.d_action is not None:
+                self.d_action[t].copy_(torch.from_numpy(np.asarray(action)))
         self.h_reward[t] = reward
         self.h_nonterm[t] = ~done
         end = done | reset
@@ -178,6 +191,8 @@ class PPO(agent.AttributeSavingMixin, agent.BatchAgent):
         self.logger = getLogger(__name__)
 
         self.rollout = None
+        self.device_actions = os.environ.get("PFRL_DEVICE_STEP", "1") != "0"
+        self._last_action_dev = None
         self.ingest = None         # DeviceReplayStore used for host-observation ingestion
         self.frames = None
         self.batch_last_state = None
@@ -288,10 +303,20 @@ class PPO(agent.AttributeSavingMixin, agent.BatchAgent):
             action_dev = self._sample_action(action_distrib)
             self.entropy_record.extend(action_distrib.entropy())
             self.value_record.extend(batch_value)
-        batch_action = action_dev.cpu().numpy()
         self._last_refs = refs.copy()
         self._last_min_seq = int(np.min(dev_batch.min_seq))
         self.batch_last_state = list(range(len(batch_obs)))
+        if isinstance(batch_obs, DeviceObsBatch) and self.device_actions:
+            # a device env: the sampled actions stay in HBM (one D2H only if the env or the
+            # driver looks at them), the rollout takes its action column from this tensor and
+            # the host never waits for the acting forward pass
+            from pfrl_amd.device_store import DeviceActions
+
+            self._last_action_dev = action_dev
+            self.batch_last_action = DeviceActions(action_dev)
+            return self.batch_last_action
+        self._last_action_dev = None
+        batch_action = action_dev.cpu().numpy()
         self.batch_last_action = list(batch_action)
         return batch_action
 
@@ -331,11 +356,14 @@ class PPO(agent.AttributeSavingMixin, agent.BatchAgent):
         assert self.training
         n_env = len(batch_obs)
         next_refs, next_batch = self._refs_of(batch_obs)
-        actions = np.asarray(self.batch_last_action)
+        actions = self.__dict__.get("_last_action_dev")
+        if actions is None:
+            actions = np.asarray(self.batch_last_action)
         if self.rollout is None:
             t_cap = -(-self.update_interval // n_env) + 2
-            self.rollout = _Rollout(self.device, n_env, next_refs.shape[1], t_cap,
-                                    actions.shape[1:], actions.dtype)
+            self.rollout = _Rollout(self.device, n_env, next_refs.shape[1], t_cap, actions.shape[1:],
+                                    actions.dtype if isinstance(actions, np.ndarray) else
+                                    np.dtype(str(actions.dtype).replace("torch.", "")))
         if self._reward_mode is None:
             r0 = batch_reward[0]
             # NEP 50: np.float64 rewards promote the GAE arithmetic to f64,
@@ -348,6 +376,7 @@ class PPO(agent.AttributeSavingMixin, agent.BatchAgent):
         self.rollout.note_frames(min(self._last_min_seq, int(np.min(next_batch.min_seq))))
         self.batch_last_state = [None] * n_env
         self.batch_last_action = [None] * n_env
+        self._last_action_dev = None
         self._update_if_dataset_is_ready()
 
     def batch_observe(self, batch_obs, batch_reward, batch_done, batch_reset):
@@ -420,14 +449,19 @@ class PPO(agent.AttributeSavingMixin, agent.BatchAgent):
                 "it (oldest live frame %d); give the frame store more slots than one rollout "
                 "writes" % (ro.min_seq, self.frames.n_slots, self.frames.oldest_live_seq()))
         # ship the rollout columns (one transfer)
+        on_dev = ro.d_action is not None
         up = self._stage.upload([
             ro.h_state[:T].reshape(T * N, k), ro.h_next[:T].reshape(T * N, k),
-            ro.h_action[:T].reshape((T * N,) + ro.h_action.shape[2:]),
+            (np.zeros(1, dtype=ro.h_action.dtype) if on_dev else
+             ro.h_action[:T].reshape((T * N,) + ro.h_action.shape[2:])),
             ro.h_reward[:T].reshape(-1), ro.h_nonterm[:T].reshape(-1),
             self._cut_with_rollout_end(ro, T).reshape(-1), order])
         # staging views are recycled when the ring wraps (the minibatch loop below
         # uploads through the same ring): keep private device copies
         s_refs, n_refs, actions, reward, nonterm, cut, order_dev = [t.clone() for t in up]
+        if on_dev:
+            # the action column never left the device
+            actions = ro.d_action[:T].reshape((T * N,) + tuple(ro.d_action.shape[2:])).clone()
         log_probs, v_pred = self._value_pass(s_refs, actions)
         if self.reuse_next_values:
             next_v = self._next_values_from_states(ro, T, N, v_pred, n_refs)

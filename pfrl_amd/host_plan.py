@@ -61,6 +61,13 @@ def recognise_randint(func, probes=48, max_actions=1 << 16):
     hit = _randint_cache.get(key)
     if hit is not None and hit[0] is func:
         return hit[1]
+    # Only a plain Python function that names ``randint`` is probed at all: calling an unknown
+    # callable 48 times could advance a generator of its own (``action_space.sample``) and change
+    # the run.  Anything else keeps the Python loop.
+    code = getattr(func, "__code__", None)
+    if code is None or "randint" not in code.co_names:
+        _randint_cache[key] = (func, None)
+        return None
     n_found = None
     saved = np.random.get_state()
     try:

@@ -38,13 +38,8 @@ def test_native_bounded_draw_equals_numpy_randint():
     """randint(n) for n from 1 to beyond 2^32: values and stream position."""
     for n in [1, 2, 3, 6, 7, 8, 18, 255, 256, 257, 10 ** 6, 2 ** 31, 2 ** 32 - 1, 2 ** 32,
               2 ** 32 + 1, 2 ** 40 + 12345]:
-        np.random.seed(n % 1000)
-        want = np.random.randint(0, n, size=64)
-        end = np.random.get_state()
-        np.random.seed(n % 1000)
-        # epsilon = 2: rand() < 2 always fires, so interleave manually: the bounded draw alone
-        # is what sample_n_k's first pass consumes -> compare through sample_n_k when it
-        # applies, else through eps_greedy with the rand() words skipped by NumPy too
+        # epsilon = 2: rand() < 2 always fires -> eps_greedy makes rand(), randint(n) per env;
+        # the bounded draw alone is what sample_n_k's first pass consumes
         if n <= 0x7fffffff:
             np.random.seed(n % 1000)
             want2 = []
@@ -63,7 +58,6 @@ def test_native_bounded_draw_equals_numpy_randint():
             got = host_plan.sample_n_k(n, 16)
             if len(set(first[:16].tolist())) == 16:
                 assert np.array_equal(got, first[:16]), n
-        del want, end
 
 
 def test_native_eps_greedy_equals_the_python_loop():
@@ -119,6 +113,14 @@ def test_recognise_randint():
     assert host_plan.recognise_randint(lambda: np.random.randint(0, 4)) == 4
     rs = np.random.RandomState(0)
     assert host_plan.recognise_randint(lambda: rs.randint(6)) is None          # own generator
+    calls = []
+
+    class Sampler:                                 # e.g. gym's action_space.sample: never called
+        def sample(self):
+            calls.append(1)
+            return 0
+
+    assert host_plan.recognise_randint(Sampler().sample) is None and not calls
     assert host_plan.recognise_randint(lambda: int(np.random.rand() * 6)) is None
     assert host_plan.recognise_randint(lambda: np.random.uniform(-1, 1, size=2)) is None
     st = np.random.get_state()

@@ -14,15 +14,16 @@ N = args.num_envs
 obss = env.reset()
 obss = bench.prefill(agent, env, obss, N, 60000 if args.algo != "sac" else 20000)
 delay = [0.0]
-target = agent._update_from_batch if hasattr(agent, "_update_from_batch") else None
-if target is not None:
-    def slowed(*a, **k):
-        t = time.perf_counter() + delay[0]
-        r = target(*a, **k)
-        while time.perf_counter() < t:
-            pass
-        return r
-    agent._update_from_batch = slowed
+name = "_update_from_batch" if hasattr(agent, "_update_from_batch") else "batch_observe"
+per_call = 1 if name == "_update_from_batch" else N      # SAC: one update per env, delay x N per step
+target = getattr(agent, name)
+def slowed(*a, **k):
+    t = time.perf_counter() + delay[0] * per_call
+    r = target(*a, **k)
+    while time.perf_counter() < t:
+        pass
+    return r
+setattr(agent, name, slowed)
 for _ in range(8):
     obss = bench.one_step(agent, env, obss, N)
 for d in (0, 50, 100, 200, 0):
