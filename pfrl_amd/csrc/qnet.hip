@@ -139,26 +139,57 @@ __device__ __forceinline__ void fold_acc(f32x4 (&acc)[AM][AN][P], f32x4 *red, in
 // stash(u, c, slot) parks a landed slot in LDS chunk buffer u, compute(u) runs the MFMAs
 // of the chunk in buffer u.  Chunk indices past the end are clamped (re-read, never
 // computed), which keeps the loads free of divergent branches.
+#ifdef PFRL_QNET_DEBUG
+// in-kernel phase clocks of the forward program (tools/qnet_phase.py): thread 0 of every workgroup
+// stores wall_clock64 (100 MHz) stamps into g_qstamp[workgroup][k] -- plain stores, no atomics:
+// k = 0 kernel entry, 1 loads of the first stage issued, 2 first stage parked in LDS (first data
+// landed), 3 pipeline done, 4 accumulators folded, 5 end, 6 / 7 first loop stage: next stage's loads
+// issued / its G chunks computed
+__device__ unsigned long long g_qstamp[4096][8];
+__device__ int g_qreps = 1;
+#define QSTAMP(k) do { if (threadIdx.x == 0 && q_wg < 4096) g_qstamp[q_wg][k] = wall_clock64(); } while (0)
+#else
+#define QSTAMP(k)
+#endif
+
 template <typename Slot, int G, typename Fetch, typename Stash, typename Compute>
 __device__ __forceinline__ void run_pipeline(int c0, int c1, Fetch fetch, Stash stash,
                                              Compute compute) {
     if (c0 >= c1) return;
+#ifdef PFRL_QNET_DEBUG
+    const int q_wg = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+#endif
     Slot slot[G];
 #pragma unroll
     for (int u = 0; u < G; ++u) fetch(min(c0 + u, c1 - 1), slot[u]);
+    QSTAMP(1);
 #pragma unroll
     for (int u = 0; u < G; ++u) stash(u, min(c0 + u, c1 - 1), slot[u]);
     __syncthreads();
+    QSTAMP(2);
     for (int cb = c0; cb < c1; cb += G) {
         const bool more = cb + G < c1;
         if (more) {
 #pragma unroll
             for (int u = 0; u < G; ++u) fetch(min(cb + G + u, c1 - 1), slot[u]);
         }
+#ifdef PFRL_QNET_DEBUG
+        if (cb == c0) QSTAMP(6);
+#endif
         const int nc = min(G, c1 - cb);
+        if (nc == G) {
+            // a full stage: no predicate between the chunks, the LDS reads of all G chunks can be
+            // issued ahead of the MFMA stream
 #pragma unroll
-        for (int u = 0; u < G; ++u)
-            if (u < nc) compute(u);
+            for (int u = 0; u < G; ++u) compute(u);
+        } else {
+#pragma unroll
+            for (int u = 0; u < G; ++u)
+                if (u < nc) compute(u);
+        }
+#ifdef PFRL_QNET_DEBUG
+        if (cb == c0) QSTAMP(7);
+#endif
         __syncthreads();
         if (more) {
 #pragma unroll
@@ -188,14 +219,17 @@ struct FwdArgs {
 // appended): scalar loads, addresses clamped to the row, the overhang zeroed when parked.
 template <int BM, int BN, int WM, int WN, int WK, int G, bool TAIL = false>
 __device__ __forceinline__ void fwd_body(const FwdArgs &p, const int bx, const int by, const int bz) {
-    static_assert(WM * WN * WK == 4, "four waves");
+    static_assert(WM * WN * WK == 4 && WK <= 2, "four waves");
     constexpr int AM = BM / (16 * WM), AN = BN / (16 * WN);
     constexpr int P = (AM * AN == 1) ? 2 : 1;
     constexpr int NPA = (BM * 8 + 255) / 256, NPB = (BN * 8 + 255) / 256;
     __shared__ __attribute__((aligned(16))) float As[G][BM * LDR];
     __shared__ __attribute__((aligned(16))) float Bs[G][BN * LDR];
     __shared__ f32x4 red[WK > 1 ? (WK - 1) * WM * WN * AM * AN * 64 : 1];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // (the wave index in an SGPR: everything decided per wave -- which K sub-chunk it multiplies, which
+    // operand piece it loads -- becomes a scalar branch instead of an exec-masked one; behind exec-masked
+    // branches the compiler emitted ds_read -> s_waitcnt lgkmcnt(0) -> 4 MFMAs per chunk, 258 clocks each)
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wk = wave % WK, wn = (wave / WK) % WN, wm = wave / (WK * WN);
     const int m0 = bx * BM, n0 = by * BN;
     const ConvGeom g = p.g;
@@ -236,6 +270,16 @@ __device__ __forceinline__ void fwd_body(const FwdArgs &p, const int bx, const i
     }
     const int SC = g.S * g.C, WC = g.W * g.C;
     const int kq4 = 4 * (tid & 7);
+    // operand pieces smaller than the workgroup (BM = 16: 128 float4) belong to the first waves only:
+    // decided per wave, so the others skip the load and the LDS write on a scalar branch
+    auto a_on = [&](int pp) { return BM * 8 >= 256 * (pp + 1) || wave * 64 + 256 * pp < BM * 8; };
+    auto b_on = [&](int pp) { return BN * 8 >= 256 * (pp + 1) || wave * 64 + 256 * pp < BN * 8; };
+    int f_c = c0, f_o = 0, f_ad = 0;
+    if (!TAIL) {
+        const int r = (c0 * KC) / SC;
+        f_o = c0 * KC - r * SC;
+        f_ad = r * WC + f_o;
+    }
     auto fetch = [&](int c, Slot &sl) {
         const int k0 = c * KC;
         if (TAIL) {
@@ -254,12 +298,23 @@ __device__ __forceinline__ void fwd_body(const FwdArgs &p, const int bx, const i
                 sl.b[pp] = make_float4(bp[pp][i0], bp[pp][i1], bp[pp][i2], bp[pp][i3]);
             return;
         }
-        const int r = k0 / SC, o = k0 - r * SC;
-        const int ad = r * WC + o;
+        // chunks are asked for in non-decreasing order (the clamp at the end repeats the last one):
+        // the (kernel row, offset in the row) of the chunk advances by scalar adds, no division
+        if (c > f_c) {
+            f_c = c;
+            f_o += KC;
+            f_ad += KC;
+            if (f_o >= SC) {
+                f_o -= SC;
+                f_ad += WC - SC;
+            }
+        }
 #pragma unroll
-        for (int pp = 0; pp < NPA; ++pp) sl.a[pp] = ldg4(ap[pp] + ad);
+        for (int pp = 0; pp < NPA; ++pp)
+            if (a_on(pp)) sl.a[pp] = ldg4(ap[pp] + f_ad);
 #pragma unroll
-        for (int pp = 0; pp < NPB; ++pp) sl.b[pp] = ldg4(bp[pp] + k0);
+        for (int pp = 0; pp < NPB; ++pp)
+            if (b_on(pp)) sl.b[pp] = ldg4(bp[pp] + k0);
     };
     auto stash = [&](int buf, int c, const Slot &sl) {
         // (TAIL) elements of this lane that lie inside the row; the overhang is zeroed
@@ -267,22 +322,24 @@ __device__ __forceinline__ void fwd_body(const FwdArgs &p, const int bx, const i
 #pragma unroll
         for (int pp = 0; pp < NPA; ++pp) {
             const int f = tid + 256 * pp, row = f >> 3, q = f & 7;
-            float4 v = zero_unless(sl.a[pp], aok[pp]);
+            // (rows past M / Cout are never zeroed: a row of A or B only reaches its own row / column
+            // of the product, and those are not stored)
+            float4 v = sl.a[pp];
             if (TAIL) {
                 v.x = left > 0 ? v.x : 0.f; v.y = left > 1 ? v.y : 0.f;
                 v.z = left > 2 ? v.z : 0.f; v.w = left > 3 ? v.w : 0.f;
             }
-            if (row < BM) *reinterpret_cast<float4 *>(&As[buf][row * LDR + 4 * q]) = v;
+            if (a_on(pp)) *reinterpret_cast<float4 *>(&As[buf][row * LDR + 4 * q]) = v;
         }
 #pragma unroll
         for (int pp = 0; pp < NPB; ++pp) {
             const int f = tid + 256 * pp, row = f >> 3, q = f & 7;
-            float4 v = zero_unless(sl.b[pp], bok[pp]);
+            float4 v = sl.b[pp];
             if (TAIL) {
                 v.x = left > 0 ? v.x : 0.f; v.y = left > 1 ? v.y : 0.f;
                 v.z = left > 2 ? v.z : 0.f; v.w = left > 3 ? v.w : 0.f;
             }
-            if (row < BN) *reinterpret_cast<float4 *>(&Bs[buf][row * LDR + 4 * q]) = v;
+            if (b_on(pp)) *reinterpret_cast<float4 *>(&Bs[buf][row * LDR + 4 * q]) = v;
         }
     };
 
@@ -294,14 +351,19 @@ __device__ __forceinline__ void fwd_body(const FwdArgs &p, const int bx, const i
 #pragma unroll
             for (int pp = 0; pp < P; ++pp) acc[am][an][pp] = (f32x4){0.f, 0.f, 0.f, 0.f};
     auto compute = [&](int buf) {
+        // (WK = 2: this wave's K half is an LDS address offset, not a branch)
 #pragma unroll
-        for (int sc = 0; sc < 2; ++sc)
-            if (sc % WK == wk)
-                mma_sub<AM, AN, P, true, true, LDR, LDR>(As[buf], Bs[buf], wm * 16 * AM, wn * 16 * AN,
-                                                          sc, lane, acc);
+        for (int s = 0; s < 2 / WK; ++s)
+            mma_sub<AM, AN, P, true, true, LDR, LDR>(As[buf], Bs[buf], wm * 16 * AM, wn * 16 * AN,
+                                                          WK == 2 ? wk : s, lane, acc);
     };
     run_pipeline<Slot, G>(c0, c1, fetch, stash, compute);
+#ifdef PFRL_QNET_DEBUG
+    const int q_wg = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+#endif
+    QSTAMP(3);
     fold_acc<AM, AN, P, WK, WM * WN>(acc, red, wm * WN + wn, wk, lane);
+    QSTAMP(4);
     if (wk != 0) return;
 #pragma unroll
     for (int am = 0; am < AM; ++am)
@@ -333,7 +395,19 @@ __device__ __forceinline__ void fwd_body(const FwdArgs &p, const int bx, const i
 
 template <int BM, int BN, int WM, int WN, int WK, int G, bool TAIL = false>
 __global__ __launch_bounds__(256) void k_conv_fwd(FwdArgs p) {
+#ifdef PFRL_QNET_DEBUG
+    // g_qreps = 2: the body runs twice and the stamps of the SECOND pass stay -- the same work with
+    // the code already fetched (what the instruction fetch of a cold launch costs)
+    const int q_wg = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    for (int rep = g_qreps; rep > 0; --rep) {
+        QSTAMP(0);
+        fwd_body<BM, BN, WM, WN, WK, G, TAIL>(p, blockIdx.x, blockIdx.y, blockIdx.z);
+        __syncthreads();
+        QSTAMP(5);
+    }
+#else
     fwd_body<BM, BN, WM, WN, WK, G, TAIL>(p, blockIdx.x, blockIdx.y, blockIdx.z);
+#endif
 }
 
 // Twin launch: two independent problems of the same shape (the twin Q-networks of SAC / TD3,
@@ -360,7 +434,7 @@ struct DgradArgs {
 template <int BM, int BN, int WM, int WN, int WK, int G>
 __device__ __forceinline__ void dgrad_body(const DgradArgs &p, const int bx, const int by,
                                            const int bz, float *smem) {
-    static_assert(WM * WN * WK == 4, "four waves");
+    static_assert(WM * WN * WK == 4 && WK <= 2, "four waves");
     constexpr int AM = BM / (16 * WM), AN = BN / (16 * WN);
     constexpr int P = (AM * AN == 1) ? 2 : 1;
     constexpr int NPA = (BM * 8 + 255) / 256;
@@ -368,7 +442,10 @@ __device__ __forceinline__ void dgrad_body(const DgradArgs &p, const int bx, con
     float(*As)[BM * LDR] = reinterpret_cast<float(*)[BM * LDR]>(smem);
     float(*Bs)[32 * LDB] = reinterpret_cast<float(*)[32 * LDB]>(smem + G * BM * LDR);
     f32x4 *red = reinterpret_cast<f32x4 *>(smem + G * BM * LDR + G * 32 * LDB);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // (the wave index in an SGPR: everything decided per wave -- which K sub-chunk it multiplies, which
+    // operand piece it loads -- becomes a scalar branch instead of an exec-masked one; behind exec-masked
+    // branches the compiler emitted ds_read -> s_waitcnt lgkmcnt(0) -> 4 MFMAs per chunk, 258 clocks each)
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wk = wave % WK, wn = (wave / WK) % WN, wm = wave / (WK * WN);
     const int m0 = bx * BM, n0 = by * BN;
     const ConvGeom g = p.g;
@@ -448,11 +525,11 @@ __device__ __forceinline__ void dgrad_body(const DgradArgs &p, const int bx, con
             for (int pp = 0; pp < P; ++pp) acc[am][an][pp] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     auto compute = [&](int buf) {
+        // (WK = 2: this wave's K half is an LDS address offset, not a branch)
 #pragma unroll
-        for (int sc = 0; sc < 2; ++sc)
-            if (sc % WK == wk)
-                mma_sub<AM, AN, P, true, false, LDR, LDB>(As[buf], Bs[buf], wm * 16 * AM, wn * 16 * AN,
-                                                           sc, lane, acc);
+        for (int s = 0; s < 2 / WK; ++s)
+            mma_sub<AM, AN, P, true, false, LDR, LDB>(As[buf], Bs[buf], wm * 16 * AM, wn * 16 * AN,
+                                                           WK == 2 ? wk : s, lane, acc);
     };
     run_pipeline<Slot, G>(0, p.K / KC, fetch, stash, compute);
     fold_acc<AM, AN, P, WK, WM * WN>(acc, red, wm * WN + wn, wk, lane);
@@ -525,7 +602,7 @@ struct WgradArgs {
 template <int BI, int BJ, int WM, int WN, int WK, int G, bool TAIL = false>
 __device__ __forceinline__ void wgrad_body(const WgradArgs &p, const int bx, const int by,
                                            const int bz, float *smem) {
-    static_assert(WM * WN * WK == 4, "four waves");
+    static_assert(WM * WN * WK == 4 && WK <= 2, "four waves");
     constexpr int AM = BI / (16 * WM), AN = BJ / (16 * WN);
     constexpr int P = (AM * AN == 1) ? 2 : 1;
     constexpr int QA = BI / 4, NPA = (32 * QA + 255) / 256, LDA = BI + 4;
@@ -533,7 +610,10 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs &p, const int bx, con
     float(*As)[32 * LDA] = reinterpret_cast<float(*)[32 * LDA]>(smem);
     float(*Bs)[32 * LDB] = reinterpret_cast<float(*)[32 * LDB]>(smem + G * 32 * LDA);
     f32x4 *red = reinterpret_cast<f32x4 *>(smem + G * 32 * LDA + G * 32 * LDB);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // (the wave index in an SGPR: everything decided per wave -- which K sub-chunk it multiplies, which
+    // operand piece it loads -- becomes a scalar branch instead of an exec-masked one; behind exec-masked
+    // branches the compiler emitted ds_read -> s_waitcnt lgkmcnt(0) -> 4 MFMAs per chunk, 258 clocks each)
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wk = wave % WK, wn = (wave / WK) % WN, wm = wave / (WK * WN);
     const int i0 = bx * BI, j0 = by * BJ;
     const ConvGeom g = p.g;
@@ -625,11 +705,11 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs &p, const int bx, con
     const bool do_bias = by == 0 && p.db != nullptr;
 
     auto compute = [&](int buf) {
+        // (WK = 2: this wave's K half is an LDS address offset, not a branch)
 #pragma unroll
-        for (int sc = 0; sc < 2; ++sc)
-            if (sc % WK == wk)
-                mma_sub<AM, AN, P, false, false, LDA, LDB>(As[buf], Bs[buf], wm * 16 * AM, wn * 16 * AN,
-                                                            sc, lane, acc);
+        for (int s = 0; s < 2 / WK; ++s)
+            mma_sub<AM, AN, P, false, false, LDA, LDB>(As[buf], Bs[buf], wm * 16 * AM, wn * 16 * AN,
+                                                            WK == 2 ? wk : s, lane, acc);
         if (do_bias && tid < BI) {
 #pragma unroll 8
             for (int kk = 0; kk < 32; ++kk) bsum += As[buf][kk * LDA + tid];
@@ -1454,3 +1534,17 @@ extern "C" int pfrl_twin_input_grad(const float *const *dy, const float *const *
                        N);
     PFRL_LAUNCH_CHECK();
 }
+
+#ifdef PFRL_QNET_DEBUG
+extern "C" int pfrl_qnet_debug_reset() {
+    void *p;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_qstamp)) != hipSuccess) return -1;
+    return (int)hipMemset(p, 0, sizeof(unsigned long long) * 4096 * 8);
+}
+extern "C" int pfrl_qnet_debug_set_reps(int reps) {
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_qreps), &reps, sizeof(int));
+}
+extern "C" int pfrl_qnet_debug_read(unsigned long long *out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_qstamp), sizeof(unsigned long long) * 4096 * 8);
+}
+#endif
