@@ -13,10 +13,10 @@ launches.  The warm-up iterations PyTorch needs before capture run on a
 snapshot that is restored afterwards, so no extra optimizer step leaks into
 training.
 """
+import collections
+import gc
 import logging
 import os
-
-import collections
 
 import torch
 
@@ -24,13 +24,37 @@ from pfrl_amd import distributed
 
 
 def _capture_kwargs(pool):
-    """Arguments of ``torch.cuda.graph``: the shared memory pool, and thread-local capture
-    error mode when a process group exists (its watchdog thread polls HIP events while this
-    thread captures; in the default global mode that poll aborts the process)."""
+    """Arguments of ``torch.cuda.graph``: the shared memory pool, and thread-local capture error
+    mode -- in the default global mode a HIP call from ANY other thread while this one captures
+    (a process group's watchdog polling events, a runtime helper thread) aborts the process."""
     kw = {} if pool is None else {"pool": pool}
-    if torch.distributed.is_available() and torch.distributed.is_initialized():
-        kw["capture_error_mode"] = "thread_local"
+    kw["capture_error_mode"] = "thread_local"
     return kw
+
+
+class _capturing:
+    """``with _capturing(g, pool):`` -- ``torch.cuda.graph`` with the collector paused.  A
+    collection that starts mid-capture runs finalizers on the capturing thread (graphs, pinned
+    buffers and events of an agent that went out of scope): their HIP calls are not allowed in a
+    capture, the error is thrown inside a destructor and the process aborts -- seen as a rare
+    "Fatal Python error: Aborted ... Garbage-collecting" when several agents are built in one
+    process.  ``torch.cuda.graph`` collects once on entry, before the capture begins."""
+
+    def __init__(self, g, pool):
+        self.ctx = torch.cuda.graph(g, **_capture_kwargs(pool))
+
+    def __enter__(self):
+        self.was_enabled = gc.isenabled()
+        r = self.ctx.__enter__()
+        gc.disable()
+        return r
+
+    def __exit__(self, *exc):
+        try:
+            return self.ctx.__exit__(*exc)
+        finally:
+            if self.was_enabled:
+                gc.enable()
 
 
 def _optimizer_tensors(optimizer):
@@ -290,8 +314,7 @@ class GraphedUpdate:
 
         def graph_of(fn):
             g = torch.cuda.CUDAGraph()
-            kw = _capture_kwargs(self.pool)
-            with torch.cuda.graph(g, **kw):
+            with _capturing(g, self.pool):
                 r = fn()
             if self.pool is None:
                 self.pool = g.pool()
@@ -419,8 +442,7 @@ class GraphedUpdate:
             _make_capturable(ag.optimizer, dev)
             ag.optimizer.zero_grad(set_to_none=True)
             g = torch.cuda.CUDAGraph()
-            kw = _capture_kwargs(self.pool)
-            with torch.cuda.graph(g, **kw):
+            with _capturing(g, self.pool):
                 losses, ys = body()
             if self.pool is None:
                 self.pool = g.pool()
@@ -564,8 +586,7 @@ class CapturedStep:
                 _make_capturable(opt, dev)  # state created by the warm-up
                 opt.zero_grad(set_to_none=True)
             g = torch.cuda.CUDAGraph()
-            kw = _capture_kwargs(self.pool)
-            with torch.cuda.graph(g, **kw), _no_distribution_validation():
+            with _capturing(g, self.pool), _no_distribution_validation():
                 out = step()
             if self.pool is None:
                 self.pool = g.pool()

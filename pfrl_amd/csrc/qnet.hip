@@ -37,9 +37,36 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int KC = 32;
 constexpr int LDR = KC + 4;
 
+// Exact unsigned division by a launch constant (Granlund-Montgomery round-up form, any 32-bit
+// numerator): the per-thread row -> (image, oh, ow) split of the weight-gradient loader runs once per
+// chunk, and a compiler-expanded 32-bit division is ~35 vector instructions each time.
+struct FastDiv {
+    uint32_t m = 1, s1 = 0, s2 = 0;   // (division by 1)
+};
+static FastDiv fast_div(uint32_t d) {
+    FastDiv f;
+    uint32_t l = 0;
+    while ((1ull << l) < d) ++l;
+    f.m = (uint32_t)((((1ull << l) - d) << 32) / d + 1);
+    f.s1 = l < 1 ? l : 1;
+    f.s2 = l < 1 ? 0 : l - 1;
+    return f;
+}
+__device__ __forceinline__ int fdiv(int n, const FastDiv &f) {
+    const uint32_t t = __umulhi(f.m, (uint32_t)n);
+    return (int)((t + (((uint32_t)n - t) >> f.s1)) >> f.s2);
+}
+
 struct ConvGeom {
     int N, H, W, C, Cout, R, S, ST, OH, OW;
+    FastDiv q_ohow, q_ow;    // by OH * OW and by OW (make_geom)
 };
+static ConvGeom make_geom(int N, int H, int W, int C, int Cout, int R, int S, int ST) {
+    ConvGeom g{N, H, W, C, Cout, R, S, ST, (H - R) / ST + 1, (W - S) / ST + 1};
+    g.q_ohow = fast_div((uint32_t)(g.OH > 0 && g.OW > 0 ? g.OH * g.OW : 1));
+    g.q_ow = fast_div((uint32_t)(g.OW > 0 ? g.OW : 1));
+    return g;
+}
 
 // Loads are issued unconditionally (invalid rows read a valid dummy address and are
 // zeroed when the slot is parked in LDS): a predicated load is an exec-masked branch,
@@ -452,68 +479,87 @@ __device__ __forceinline__ void dgrad_body(const DgradArgs &p, const int bx, con
     const int ph = bz / g.ST, pw = bz - ph * g.ST;
     const int ahw = p.AH * p.AW;
 
-    int rn[NPA], rah[NPA], raw[NPA];
+    // per-thread part of the dy address (tap (0, 0), first output channel) and of the weight address;
+    // what a chunk adds to both is the same for the whole workgroup
+    int rah[NPA], raw[NPA];
+    size_t abase[NPA];
     bool aok[NPA];
 #pragma unroll
     for (int pp = 0; pp < NPA; ++pp) {
-        const int f = tid + 256 * pp, row = f >> 3;
+        const int f = tid + 256 * pp, row = f >> 3, q = f & 7;
         const int m = m0 + row;
         const bool ok = row < BM && m < p.Mc;
         const int mm = ok ? m : 0;
-        rn[pp] = mm / ahw;
-        const int rem = mm - rn[pp] * ahw;
+        const int rn = mm / ahw;
+        const int rem = mm - rn * ahw;
         rah[pp] = rem / p.AW;
         raw[pp] = rem - rah[pp] * p.AW;
+        abase[pp] = ((size_t)(rn * g.OH + rah[pp]) * g.OW + raw[pp]) * g.Cout + 4 * q;
         aok[pp] = ok;
+    }
+    int bkk[NPB], bq4[NPB];
+    size_t bbase[NPB];
+#pragma unroll
+    for (int pp = 0; pp < NPB; ++pp) {
+        const int f = tid + 256 * pp;
+        bkk[pp] = f / QPR;
+        bq4[pp] = 4 * (f - bkk[pp] * QPR);
+        bbase[pp] = (size_t)bkk[pp] * g.R * g.S * g.C + n0 + bq4[pp];
     }
     struct Slot {
         float4 a[NPA], h[NPA], b[NPB];
+        bool ok[NPA];
     };
     const bool has_mask = p.dymask != nullptr;
-    // validity and address of this thread's A piece for chunk c (depends on the tap)
-    auto a_addr = [&](int c, int pp, bool &ok) -> size_t {
-        const int k0 = c * KC;
-        const int tap = k0 / g.Cout, co0 = k0 - tap * g.Cout;
-        const int tb = tap / p.TW, tb2 = tap - tb * p.TW;
-        const int q = (tid + 256 * pp) & 7;
-        const int oh = rah[pp] - tb, ow = raw[pp] - tb2;
-        ok = aok[pp] && oh >= 0 && oh < g.OH && ow >= 0 && ow < g.OW;
-        return ok ? ((size_t)(rn[pp] * g.OH + oh) * g.OW + ow) * g.Cout + co0 + 4 * q : (size_t)0;
-    };
+    // operand pieces smaller than the workgroup belong to the first waves only (scalar branches)
+    auto a_on = [&](int pp) { return BM * 8 >= 256 * (pp + 1) || wave * 64 + 256 * pp < BM * 8; };
+    auto b_on = [&](int pp) { return 32 * QPR >= 256 * (pp + 1) || wave * 64 + 256 * pp < 32 * QPR; };
+    // chunk -> (tap row, tap column, first output channel), advanced by scalar adds: chunks are asked
+    // for in non-decreasing order (Cout % 32 == 0: a chunk never straddles two taps)
+    int f_c = 0, f_co0 = 0, f_tb = 0, f_tb2 = 0;
     auto fetch = [&](int c, Slot &sl) {
-        const int k0 = c * KC;
-        const int tap = k0 / g.Cout, co0 = k0 - tap * g.Cout;
-        const int tb = tap / p.TW, tb2 = tap - tb * p.TW;
+        if (c > f_c) {
+            f_c = c;
+            f_co0 += KC;
+            if (f_co0 >= g.Cout) {
+                f_co0 = 0;
+                if (++f_tb2 >= p.TW) {
+                    f_tb2 = 0;
+                    ++f_tb;
+                }
+            }
+        }
+        // (uniform, may be "negative": wraps consistently in size_t arithmetic)
+        const size_t adelta = (size_t)f_co0 - (size_t)(f_tb * g.OW + f_tb2) * g.Cout;
 #pragma unroll
         for (int pp = 0; pp < NPA; ++pp) {
-            bool ok;
-            const size_t off = a_addr(c, pp, ok);
+            if (!a_on(pp)) continue;
+            const int oh = rah[pp] - f_tb, ow = raw[pp] - f_tb2;
+            const bool ok = aok[pp] && oh >= 0 && oh < g.OH && ow >= 0 && ow < g.OW;
+            const size_t off = ok ? abase[pp] + adelta : (size_t)0;
             sl.a[pp] = ldg4(p.dy + off);
             if (has_mask) sl.h[pp] = ldg4(p.dymask + off);
+            sl.ok[pp] = ok;
         }
-        const int r = tb * g.ST + ph, s = tb2 * g.ST + pw;
+        const int r = f_tb * g.ST + ph, s = f_tb2 * g.ST + pw;
+        const size_t bdelta = ((size_t)(f_co0 * g.R + r) * g.S + s) * g.C;
 #pragma unroll
-        for (int pp = 0; pp < NPB; ++pp) {
-            const int f = tid + 256 * pp, kk = f / QPR, q = f - kk * QPR;
-            const int co = co0 + (kk < 32 ? kk : 0);
-            sl.b[pp] = ldg4(p.w + ((size_t)(co * g.R + r) * g.S + s) * g.C + n0 + 4 * q);
-        }
+        for (int pp = 0; pp < NPB; ++pp)
+            if (b_on(pp)) sl.b[pp] = ldg4(p.w + bbase[pp] + bdelta);
     };
     auto stash = [&](int buf, int c, const Slot &sl) {
 #pragma unroll
         for (int pp = 0; pp < NPA; ++pp) {
+            if (!a_on(pp)) continue;
             const int f = tid + 256 * pp, row = f >> 3, q = f & 7;
-            bool ok;
-            a_addr(c, pp, ok);
-            float4 v = zero_unless(sl.a[pp], ok);
+            // (taps outside the output are zeroed: they are terms of the sum over K)
+            float4 v = zero_unless(sl.a[pp], sl.ok[pp]);
             if (has_mask) v = relu_mask(v, sl.h[pp]);
-            if (row < BM) *reinterpret_cast<float4 *>(&As[buf][row * LDR + 4 * q]) = v;
+            *reinterpret_cast<float4 *>(&As[buf][row * LDR + 4 * q]) = v;
         }
 #pragma unroll
-        for (int pp = 0; pp < NPB; ++pp) {
-            const int f = tid + 256 * pp, kk = f / QPR, q = f - kk * QPR;
-            if (kk < 32) *reinterpret_cast<float4 *>(&Bs[buf][kk * LDB + 4 * q]) = sl.b[pp];
-        }
+        for (int pp = 0; pp < NPB; ++pp)
+            if (b_on(pp)) *reinterpret_cast<float4 *>(&Bs[buf][bkk[pp] * LDB + bq4[pp]]) = sl.b[pp];
     };
 
     f32x4 acc[AM][AN][P];
@@ -634,24 +680,36 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs &p, const int bx, con
     }
     struct Slot {
         float4 a[NPA], h[NPA], b[NPB];
+        bool ok[NPA];
     };
     const bool has_mask = p.dymask != nullptr;
+    // operand pieces smaller than the workgroup belong to the first waves only (scalar branches)
+    auto a_on = [&](int pp) { return 32 * QA >= 256 * (pp + 1) || wave * 64 + 256 * pp < 32 * QA; };
+    auto b_on = [&](int pp) { return 32 * QB >= 256 * (pp + 1) || wave * 64 + 256 * pp < 32 * QB; };
+    int akk[NPA], acol[NPA];
+#pragma unroll
+    for (int pp = 0; pp < NPA; ++pp) {
+        const int f = tid + 256 * pp;
+        akk[pp] = f / QA;
+        acol[pp] = i0 + 4 * (f - akk[pp] * QA);
+    }
     auto fetch = [&](int c, Slot &sl) {
         const int mbase = c * KC;
 #pragma unroll
         for (int pp = 0; pp < NPA; ++pp) {
-            const int f = tid + 256 * pp, kk = f / QA, q = f - kk * QA;
-            const int m = mbase + kk;
-            const bool ok = kk < 32 && m < p.M && i0 + 4 * q < g.Cout;
-            const size_t off = ok ? (size_t)m * g.Cout + i0 + 4 * q : (size_t)0;
+            if (!a_on(pp)) continue;
+            const int m = mbase + akk[pp];
+            const bool ok = m < p.M && acol[pp] < g.Cout;
+            const size_t off = ok ? (size_t)m * g.Cout + acol[pp] : (size_t)0;
             sl.a[pp] = ldg4(p.dy + off);
             if (has_mask) sl.h[pp] = ldg4(p.dymask + off);
+            sl.ok[pp] = ok;
         }
 #pragma unroll
         for (int pp = 0; pp < NPB; ++pp) {
+            if (!b_on(pp)) continue;
             const int m = mbase + bkk[pp];
-            const bool ok = bkk[pp] < 32 && m < p.M;
-            const int mm = ok ? m : 0;
+            const int mm = m < p.M ? m : 0;
             if (TAIL) {
                 const int K1 = p.x2 != nullptr ? p.K1 : p.K;
                 const float *row = p.x + (size_t)mm * K1;
@@ -666,31 +724,31 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs &p, const int bx, con
                 sl.b[pp] = make_float4(e[0], e[1], e[2], e[3]);
                 continue;
             }
-            const int n = mm / ohow, rem = mm - n * ohow;
-            const int oh = rem / g.OW, ow = rem - oh * g.OW;
+            const int n = fdiv(mm, g.q_ohow), rem = mm - n * ohow;
+            const int oh = fdiv(rem, g.q_ow), ow = rem - oh * g.OW;
             sl.b[pp] = ldg4(p.x + ((size_t)(n * g.H + oh * g.ST) * g.W + ow * g.ST) * g.C + bcol[pp]);
         }
     };
     auto stash = [&](int buf, int c, const Slot &sl) {
-        const int mbase = c * KC;
 #pragma unroll
         for (int pp = 0; pp < NPA; ++pp) {
-            const int f = tid + 256 * pp, kk = f / QA, q = f - kk * QA;
-            const bool ok = kk < 32 && mbase + kk < p.M && i0 + 4 * q < g.Cout;
-            float4 v = zero_unless(sl.a[pp], ok);
+            if (!a_on(pp)) continue;
+            // rows past M are zeroed in dy only: the x rows beside them are real rows (row 0),
+            // and 0 * x adds nothing to the sum over m
+            float4 v = zero_unless(sl.a[pp], sl.ok[pp]);
             if (has_mask) v = relu_mask(v, sl.h[pp]);
-            if (kk < 32) *reinterpret_cast<float4 *>(&As[buf][kk * LDA + 4 * q]) = v;
+            *reinterpret_cast<float4 *>(&As[buf][akk[pp] * LDA + (acol[pp] - i0)]) = v;
         }
 #pragma unroll
         for (int pp = 0; pp < NPB; ++pp) {
-            const bool ok = bkk[pp] < 32 && mbase + bkk[pp] < p.M;
-            float4 v = zero_unless(sl.b[pp], ok);
+            if (!b_on(pp)) continue;
+            float4 v = sl.b[pp];
             if (TAIL) {
                 const int left = p.K - (j0 + 4 * bq[pp]);
                 v.x = left > 0 ? v.x : 0.f; v.y = left > 1 ? v.y : 0.f;
                 v.z = left > 2 ? v.z : 0.f; v.w = left > 3 ? v.w : 0.f;
             }
-            if (bkk[pp] < 32) *reinterpret_cast<float4 *>(&Bs[buf][bkk[pp] * LDB + 4 * bq[pp]]) = v;
+            *reinterpret_cast<float4 *>(&Bs[buf][bkk[pp] * LDB + 4 * bq[pp]]) = v;
         }
     };
 
@@ -1017,7 +1075,7 @@ extern "C" int pfrl_conv2d_nhwc_fwd(const float *x, const float *w, const float 
                                     int32_t N, int32_t H, int32_t W, int32_t C, int32_t Cout, int32_t R,
                                     int32_t S, int32_t stride, int32_t relu, int32_t planar_out,
                                     int32_t splits, void *stream) {
-    ConvGeom g{N, H, W, C, Cout, R, S, stride, (H - R) / stride + 1, (W - S) / stride + 1};
+    const ConvGeom g = make_geom(N, H, W, C, Cout, R, S, stride);
     PFRL_CHECK_ARG(geom_ok(g), "pfrl_conv2d_nhwc_fwd: unsupported geometry (need S*C % 32 == 0)");
     PFRL_CHECK_ARG(splits >= 1, "pfrl_conv2d_nhwc_fwd: splits >= 1");
     FwdArgs a;
@@ -1063,7 +1121,7 @@ extern "C" int pfrl_linear_fwd(const float *x, const float *w, const float *bias
         return pfrl_conv2d_nhwc_fwd(x, w, bias, y, M, 1, 1, K, N, 1, 1, 1, relu, 0, splits, stream);
     FwdArgs a;
     a.x = x; a.w = w; a.bias = bias; a.y = y;
-    a.g = ConvGeom{M, 1, 1, K, N, 1, 1, 1, 1, 1};
+    a.g = make_geom(M, 1, 1, K, N, 1, 1, 1);
     a.M = M;
     a.K = K;
     const int nch = (K + KC - 1) / KC;
@@ -1086,7 +1144,7 @@ static int make_dgrad_args(DgradArgs &a, const float *dy, const float *dy_mask, 
                            const float *a_prev, float *dx, int32_t N, int32_t H, int32_t W, int32_t C,
                            int32_t Cout, int32_t R, int32_t S, int32_t stride, int32_t perm_p,
                            int32_t perm_c) {
-    ConvGeom g{N, H, W, C, Cout, R, S, stride, (H - R) / stride + 1, (W - S) / stride + 1};
+    const ConvGeom g = make_geom(N, H, W, C, Cout, R, S, stride);
     PFRL_CHECK_ARG(g.OH >= 1 && g.OW >= 1 && Cout % KC == 0 && C % 16 == 0 && R % stride == 0 &&
                        S % stride == 0 && H % stride == 0 && W % stride == 0,
                    "pfrl_conv2d_nhwc_bwd_data: unsupported geometry");
@@ -1105,7 +1163,7 @@ static int make_wgrad_args(WgradArgs &a, const float *dy, const float *dy_mask, 
                            float *dw_part, float *db_part, int64_t dw_stride, int64_t db_stride,
                            int32_t N, int32_t H, int32_t W, int32_t C, int32_t Cout, int32_t R,
                            int32_t S, int32_t stride, int32_t splits) {
-    ConvGeom g{N, H, W, C, Cout, R, S, stride, (H - R) / stride + 1, (W - S) / stride + 1};
+    const ConvGeom g = make_geom(N, H, W, C, Cout, R, S, stride);
     PFRL_CHECK_ARG(geom_ok(g) && Cout % 16 == 0, "pfrl_conv2d_nhwc_bwd_weight: unsupported geometry");
     PFRL_CHECK_ARG(splits >= 1, "pfrl_conv2d_nhwc_bwd_weight: splits >= 1");
     a.dy = dy; a.dymask = dy_mask; a.x = x; a.dw = dw_part; a.db = db_part;
@@ -1190,7 +1248,7 @@ extern "C" int pfrl_linear_bwd_weight(const float *dy, const float *dy_mask, con
     WgradArgs a;
     a.dy = dy; a.dymask = dy_mask; a.x = x; a.dw = dw_part; a.db = db_part;
     a.dw_stride = dw_stride; a.db_stride = db_stride;
-    a.g = ConvGeom{M, 1, 1, K, N, 1, 1, 1, 1, 1};
+    a.g = make_geom(M, 1, 1, K, N, 1, 1, 1);
     a.M = M;
     a.K = K;
     const int nch = (M + KC - 1) / KC;
@@ -1427,7 +1485,7 @@ extern "C" int pfrl_linear_fwd_twin(const float *const *x, const float *const *x
     for (int t = 0; t < 2; ++t) {
         PFRL_CHECK_ARG(x[t] && w[t] && bias[t] && y[t], "pfrl_linear_fwd_twin: null pointer");
         a[t].x = x[t]; a[t].w = w[t]; a[t].bias = bias[t]; a[t].y = y[t];
-        a[t].g = ConvGeom{M, 1, 1, K, N, 1, 1, 1, 1, 1};
+        a[t].g = make_geom(M, 1, 1, K, N, 1, 1, 1);
         a[t].M = M;
         a[t].K = K;
         a[t].cps = (K + KC - 1) / KC;
@@ -1472,7 +1530,7 @@ extern "C" int pfrl_linear_bwd_twin(const float *const *dy, const float *const *
             wa[t].dy = dy[t]; wa[t].dymask = mk; wa[t].x = x[t];
             wa[t].dw = dw_part[t]; wa[t].db = db_part != nullptr ? db_part[t] : nullptr;
             wa[t].dw_stride = dw_stride; wa[t].db_stride = db_stride;
-            wa[t].g = ConvGeom{M, 1, 1, K, N, 1, 1, 1, 1, 1};
+            wa[t].g = make_geom(M, 1, 1, K, N, 1, 1, 1);
             wa[t].M = M;
             wa[t].K = K;
             const int nch = (M + KC - 1) / KC;
