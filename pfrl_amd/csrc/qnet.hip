@@ -59,12 +59,13 @@ __device__ __forceinline__ int fdiv(int n, const FastDiv &f) {
 
 struct ConvGeom {
     int N, H, W, C, Cout, R, S, ST, OH, OW;
-    FastDiv q_ohow, q_ow;    // by OH * OW and by OW (make_geom)
+    FastDiv q_ohow, q_ow, q_sc;    // by OH * OW, by OW, by S * C (make_geom)
 };
 static ConvGeom make_geom(int N, int H, int W, int C, int Cout, int R, int S, int ST) {
     ConvGeom g{N, H, W, C, Cout, R, S, ST, (H - R) / ST + 1, (W - S) / ST + 1};
     g.q_ohow = fast_div((uint32_t)(g.OH > 0 && g.OW > 0 ? g.OH * g.OW : 1));
     g.q_ow = fast_div((uint32_t)(g.OW > 0 ? g.OW : 1));
+    g.q_sc = fast_div((uint32_t)(S * C > 0 ? S * C : 1));
     return g;
 }
 
@@ -174,9 +175,23 @@ __device__ __forceinline__ void fold_acc(f32x4 (&acc)[AM][AN][P], f32x4 *red, in
 // issued / its G chunks computed
 __device__ unsigned long long g_qstamp[4096][8];
 __device__ int g_qreps = 1;
-#define QSTAMP(k) do { if (threadIdx.x == 0 && q_wg < 4096) g_qstamp[q_wg][k] = wall_clock64(); } while (0)
+// g_qgrid != 0: only the launch with that many workgroups records (one launch of a whole update)
+__device__ int g_qgrid = 0;
+#define QSTAMP(k)                                                                                   \
+    do {                                                                                            \
+        if (threadIdx.x == 0 && q_wg < 4096 &&                                                      \
+            (g_qgrid == 0 || (int)(gridDim.x * gridDim.y * gridDim.z) == g_qgrid))                  \
+            g_qstamp[q_wg][k] = wall_clock64();                                                     \
+    } while (0)
+#define QMARK(k, v)                                                                                 \
+    do {                                                                                            \
+        if (threadIdx.x == 0 && q_wg < 4096 &&                                                      \
+            (g_qgrid == 0 || (int)(gridDim.x * gridDim.y * gridDim.z) == g_qgrid))                  \
+            g_qstamp[q_wg][k] = (v);                                                                \
+    } while (0)
 #else
 #define QSTAMP(k)
+#define QMARK(k, v)
 #endif
 
 template <typename Slot, int G, typename Fetch, typename Stash, typename Compute>
@@ -276,8 +291,8 @@ __device__ __forceinline__ void fwd_body(const FwdArgs &p, const int bx, const i
         const int m = m0 + row;
         const bool ok = row < BM && m < p.M;
         const int mm = ok ? m : 0;
-        const int n = mm / ohow, rem = mm - n * ohow;
-        const int oh = rem / g.OW, ow = rem - oh * g.OW;
+        const int n = fdiv(mm, g.q_ohow), rem = mm - n * ohow;
+        const int oh = fdiv(rem, g.q_ow), ow = rem - oh * g.OW;
         if (TAIL) {
             ap[pp] = p.x + (size_t)mm * K1;
             ap2[pp] = p.x2 != nullptr ? p.x2 + (size_t)mm * (p.K - K1) : ap[pp];
@@ -303,7 +318,7 @@ __device__ __forceinline__ void fwd_body(const FwdArgs &p, const int bx, const i
     auto b_on = [&](int pp) { return BN * 8 >= 256 * (pp + 1) || wave * 64 + 256 * pp < BN * 8; };
     int f_c = c0, f_o = 0, f_ad = 0;
     if (!TAIL) {
-        const int r = (c0 * KC) / SC;
+        const int r = fdiv(c0 * KC, g.q_sc);
         f_o = c0 * KC - r * SC;
         f_ad = r * WC + f_o;
     }
@@ -411,7 +426,7 @@ __device__ __forceinline__ void fwd_body(const FwdArgs &p, const int bx, const i
                 v = v + bias;
                 if (p.relu) v = fmaxf(v, 0.f);
                 if (p.planar) {
-                    const int img = m / ohow, pix = m - img * ohow;
+                    const int img = fdiv(m, g.q_ohow), pix = m - img * ohow;
                     p.y[((size_t)img * g.Cout + n) * ohow + pix] = v;
                 } else {
                     p.y[(size_t)m * g.Cout + n] = v;
@@ -456,6 +471,7 @@ struct DgradArgs {
     int AH, AW, Mc;      // rows per parity class: n x AH x AW, AH = H / ST
     int TH, TW, K;       // taps per class and dimension; K = TH * TW * Cout
     int permP, permC;    // dx written as [n][p][c] for c*P + p (planar -> NHWC), 0 = off
+    FastDiv q_ahw, q_aw, q_st, q_permP;   // by AH * AW, AW, ST, permP
 };
 
 template <int BM, int BN, int WM, int WN, int WK, int G>
@@ -476,7 +492,7 @@ __device__ __forceinline__ void dgrad_body(const DgradArgs &p, const int bx, con
     const int wk = wave % WK, wn = (wave / WK) % WN, wm = wave / (WK * WN);
     const int m0 = bx * BM, n0 = by * BN;
     const ConvGeom g = p.g;
-    const int ph = bz / g.ST, pw = bz - ph * g.ST;
+    const int ph = fdiv(bz, p.q_st), pw = bz - ph * g.ST;
     const int ahw = p.AH * p.AW;
 
     // per-thread part of the dy address (tap (0, 0), first output channel) and of the weight address;
@@ -490,9 +506,9 @@ __device__ __forceinline__ void dgrad_body(const DgradArgs &p, const int bx, con
         const int m = m0 + row;
         const bool ok = row < BM && m < p.Mc;
         const int mm = ok ? m : 0;
-        const int rn = mm / ahw;
+        const int rn = fdiv(mm, p.q_ahw);
         const int rem = mm - rn * ahw;
-        rah[pp] = rem / p.AW;
+        rah[pp] = fdiv(rem, p.q_aw);
         raw[pp] = rem - rah[pp] * p.AW;
         abase[pp] = ((size_t)(rn * g.OH + rah[pp]) * g.OW + raw[pp]) * g.Cout + 4 * q;
         aok[pp] = ok;
@@ -586,8 +602,8 @@ __device__ __forceinline__ void dgrad_body(const DgradArgs &p, const int bx, con
         for (int reg = 0; reg < 4; ++reg) {
             const int m = m0 + wm * 16 * AM + 16 * am + 4 * (lane >> 4) + reg;
             if (m >= p.Mc) continue;
-            const int n = m / ahw, rem = m - n * ahw;
-            const int a = rem / p.AW, a2 = rem - a * p.AW;
+            const int n = fdiv(m, p.q_ahw), rem = m - n * ahw;
+            const int a = fdiv(rem, p.q_aw), a2 = rem - a * p.AW;
             const int ih = a * g.ST + ph, iw = a2 * g.ST + pw;
             const size_t base = ((size_t)(n * g.H + ih) * g.W + iw) * g.C;
 #pragma unroll
@@ -598,7 +614,7 @@ __device__ __forceinline__ void dgrad_body(const DgradArgs &p, const int bx, con
                 if (p.aprev != nullptr) v = p.aprev[base + ci] > 0.f ? v : 0.f;
                 size_t o = base + ci;
                 if (p.permP > 0) {
-                    const int c = ci / p.permP, px = ci - c * p.permP;
+                    const int c = fdiv(ci, p.q_permP), px = ci - c * p.permP;
                     o = base + (size_t)px * p.permC + c;
                 }
                 p.dx[o] = v;
@@ -675,7 +691,7 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs &p, const int bx, con
         bkk[pp] = f / QB;
         bq[pp] = f - bkk[pp] * QB;
         const int j = j0 + 4 * bq[pp];
-        const int r = j / SC;
+        const int r = fdiv(j, g.q_sc);
         bcol[pp] = r * WC + (j - r * SC);
     }
     struct Slot {
@@ -813,38 +829,68 @@ __global__ __launch_bounds__(256) void k_conv_wgrad2(WgradArgs p0, WgradArgs p1,
 // one launch boundary (and one cold start of the load pipeline) disappears per layer.  A
 // fork / join inside a captured graph costs ~8 us on this stack, so the fusion is by grid:
 // workgroups [0, n_dgrad) run the dgrad tile program, the rest the wgrad one.
+// workgroup -> (program, tile) of the fused launch, with the divisors prepared on the host
+struct BwdGrid {
+    int nd, dgx, dgy, wgx, wgy;
+    FastDiv q_dgx, q_dgy, q_wgx, q_wgy;
+};
+static BwdGrid make_bwd_grid(int dgx, int dgy, int dgz, int wgx, int wgy) {
+    BwdGrid b;
+    b.nd = dgx * dgy * dgz;
+    b.dgx = dgx; b.dgy = dgy; b.wgx = wgx; b.wgy = wgy;
+    b.q_dgx = fast_div((uint32_t)dgx); b.q_dgy = fast_div((uint32_t)dgy);
+    b.q_wgx = fast_div((uint32_t)wgx); b.q_wgy = fast_div((uint32_t)wgy);
+    return b;
+}
+
 template <int DM, int DN, int DWM, int DWN, int DWK, int DG_, int WI, int WWM, int WWN, int WWK>
-__global__ __launch_bounds__(256) void k_conv_bwd(DgradArgs d, WgradArgs w, int dgx, int dgy, int dgz,
-                                                  int wgx, int wgy) {
+// (nd first: a leading scalar is preloaded into an SGPR at wave launch -- the build passes
+// -amdgpu-kernarg-preload-count -- so the program split needs no kernarg round trip of its own.
+// Fetching the whole argument block with one vector load + v_readlane instead of the compiler's
+// 2-3 dependent scalar batches was tried and measured 3 us slower per update.)
+__global__ __launch_bounds__(256) void k_conv_bwd(int nd, DgradArgs d, WgradArgs w, BwdGrid bg) {
     // one LDS area, laid out by whichever tile program this workgroup runs
     __shared__ __attribute__((aligned(16))) float
         smem[cmax(dgrad_smem(DM, DN, DWM, DWN, DWK, DG_), wgrad_smem(WI, 32, WWM, WWN, WWK, 4))];
     const int b = blockIdx.x;
-    const int nd = dgx * dgy * dgz;
+#ifdef PFRL_QNET_DEBUG
+    // (tools/bwd_phase.py) 0 entry, 4 tile program (1 dgrad, 2 wgrad), 5 end; 1 2 6 7 from run_pipeline
+    const int q_wg = blockIdx.x;
+#endif
+    QSTAMP(0);
+    QMARK(4, b < nd ? 1ull : 2ull);
     if (b < nd) {
-        const int bx = b % dgx, r = b / dgx;
-        dgrad_body<DM, DN, DWM, DWN, DWK, DG_>(d, bx, r % dgy, r / dgy, smem);
+        const int r = fdiv(b, bg.q_dgx), bx = b - r * bg.dgx;
+        const int bz = fdiv(r, bg.q_dgy);
+        dgrad_body<DM, DN, DWM, DWN, DWK, DG_>(d, bx, r - bz * bg.dgy, bz, smem);
     } else {
         const int c = b - nd;
-        const int bx = c % wgx, r = c / wgx;
-        wgrad_body<WI, 32, WWM, WWN, WWK, 4>(w, bx, r % wgy, r / wgy, smem);
+        const int r = fdiv(c, bg.q_wgx), bx = c - r * bg.wgx;
+        const int bz = fdiv(r, bg.q_wgy);
+        wgrad_body<WI, 32, WWM, WWN, WWK, 4>(w, bx, r - bz * bg.wgy, bz, smem);
     }
+#ifdef PFRL_QNET_DEBUG
+    __syncthreads();
+#endif
+    QSTAMP(5);
 }
 
 template <int DM, int DN, int DWM, int DWN, int DWK, int DG_, int WI, int WWM, int WWN, int WWK>
 __global__ __launch_bounds__(256) void k_conv_bwd2(DgradArgs d0, WgradArgs w0, DgradArgs d1, WgradArgs w1,
-                                                   int dgx, int dgy, int wgx, int wgy) {
+                                                   BwdGrid bg) {
     __shared__ __attribute__((aligned(16))) float
         smem[cmax(dgrad_smem(DM, DN, DWM, DWN, DWK, DG_), wgrad_smem(WI, 32, WWM, WWN, WWK, 4))];
     const bool second = blockIdx.y != 0;
     const int b = blockIdx.x;
-    const int nd = dgx * dgy;
+    const int nd = bg.nd;
     if (b < nd) {
-        dgrad_body<DM, DN, DWM, DWN, DWK, DG_>(second ? d1 : d0, b % dgx, b / dgx, 0, smem);
+        const int by = fdiv(b, bg.q_dgx);
+        dgrad_body<DM, DN, DWM, DWN, DWK, DG_>(second ? d1 : d0, b - by * bg.dgx, by, 0, smem);
     } else {
         const int c = b - nd;
-        const int bx = c % wgx, r = c / wgx;
-        wgrad_body<WI, 32, WWM, WWN, WWK, 4>(second ? w1 : w0, bx, r % wgy, r / wgy, smem);
+        const int r = fdiv(c, bg.q_wgx), bx = c - r * bg.wgx;
+        const int bz = fdiv(r, bg.q_wgy);
+        wgrad_body<WI, 32, WWM, WWN, WWK, 4>(second ? w1 : w0, bx, r - bz * bg.wgy, bz, smem);
     }
 }
 
@@ -1156,6 +1202,10 @@ static int make_dgrad_args(DgradArgs &a, const float *dy, const float *dy_mask, 
     a.TH = R / stride; a.TW = S / stride;
     a.K = a.TH * a.TW * Cout;
     a.permP = perm_p; a.permC = perm_c;
+    a.q_ahw = fast_div((uint32_t)(a.AH * a.AW));
+    a.q_aw = fast_div((uint32_t)a.AW);
+    a.q_st = fast_div((uint32_t)stride);
+    a.q_permP = fast_div((uint32_t)(perm_p > 0 ? perm_p : 1));
     return 0;
 }
 
@@ -1295,14 +1345,18 @@ extern "C" int pfrl_conv2d_nhwc_bwd(const float *dy, const float *dy_mask, const
         const unsigned grid = (unsigned)(dgx * dgy * z + nw);                                        \
         if (w32)                                                                                     \
             hipLaunchKernelGGL((k_conv_bwd<DM, DN, DWM, DWN, DWK, DGG, 32, 2, 2, 1>), dim3(grid),    \
-                               dim3(256), 0, st, d, wa, dgx, dgy, z, wgx, wgy);                      \
+                               dim3(256), 0, st, dgx * dgy * z, d, wa,                               \
+                               make_bwd_grid(dgx, dgy, z, wgx, wgy));                                \
         else                                                                                         \
             hipLaunchKernelGGL((k_conv_bwd<DM, DN, DWM, DWN, DWK, DGG, 16, 1, 2, 2>), dim3(grid),    \
-                               dim3(256), 0, st, d, wa, dgx, dgy, z, wgx, wgy);                      \
+                               dim3(256), 0, st, dgx * dgy * z, d, wa,                               \
+                               make_bwd_grid(dgx, dgy, z, wgx, wgy));                                \
     } while (0)
     switch (prog) {
         case 2: BWD(32, 32, 2, 2, 1, 4); break;
-        case 3:   // (stages of 4 here: the LDS budget decides how many workgroups share a CU)
+        case 3:   // (stages of 4 here: with stages of 8 the input-gradient workgroups finish 1.7 us
+                  // sooner, but at 55 KB of LDS two workgroups fill a CU and the weight-gradient
+                  // workgroups queue behind them: the launch measured 2 us LONGER, tools/bwd_phase.py)
         case 4: BWD(16, 32, 1, 2, 2, 4); break;
         default: BWD(32, 16, 2, 1, 2, 4); break;
     }
@@ -1547,7 +1601,7 @@ extern "C" int pfrl_linear_bwd_twin(const float *const *dy, const float *const *
         const int dgx = (M + 15) / 16, dgy = K / 32;
         hipLaunchKernelGGL((k_conv_bwd2<16, 32, 1, 2, 2, 4, 32, 2, 2, 1>),
                            dim3(dgx * dgy + wgx * wgy * splits, 2), dim3(256), 0, st, d[0], wa[0], d[1],
-                           wa[1], dgx, dgy, wgx, wgy);
+                           wa[1], make_bwd_grid(dgx, dgy, 1, wgx, wgy));
     } else if (dx != nullptr) {
         hipLaunchKernelGGL((k_conv_dgrad2<16, 32, 1, 2, 2, 4>), dim3((M + 15) / 16, K / 32, 2), dim3(256),
                            0, st, d[0], d[1]);
@@ -1598,6 +1652,9 @@ extern "C" int pfrl_qnet_debug_reset() {
     void *p;
     if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_qstamp)) != hipSuccess) return -1;
     return (int)hipMemset(p, 0, sizeof(unsigned long long) * 4096 * 8);
+}
+extern "C" int pfrl_qnet_debug_set_grid(int workgroups) {
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_qgrid), &workgroups, sizeof(int));
 }
 extern "C" int pfrl_qnet_debug_set_reps(int reps) {
     return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_qreps), &reps, sizeof(int));
