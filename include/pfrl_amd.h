@@ -485,6 +485,21 @@ int pfrl_conv2d_nhwc_bwd_weight(const float *dy, const float *dy_mask, const flo
                                 float *db_part, int64_t dw_stride, int64_t db_stride, int32_t N,
                                 int32_t H, int32_t W, int32_t C, int32_t Cout, int32_t R, int32_t S,
                                 int32_t stride, int32_t splits, void *stream);
+/* pfrl_conv2d_nhwc_bwd_weight with the RMSprop steps of OTHER parameter tensors riding in the
+ * same launch (pfrl/agents/dqn.py:360-365 `loss.backward(); optimizer.step()` at minibatch size):
+ * the first layer's weight gradient is the last launch of the backward pass, a few hundred
+ * latency-bound workgroups; by then the gradients of the layers above are final (ride_grad[i],
+ * finished tensors) and their parameters are not read again in this update, so their
+ * elementwise steps (the arithmetic of pfrl_rmsprop_step) run as extra workgroups of this launch.
+ * 1 <= n_ride <= 4 HOST arrays of device pointers; 16-byte aligned, numel % 4 == 0;
+ * ride_grad_avg may be NULL when centered == 0.  The caller must not step these tensors again. */
+int pfrl_conv2d_nhwc_bwd_weight_ride(
+    const float *dy, const float *dy_mask, const float *x, float *dw_part, float *db_part,
+    int64_t dw_stride, int64_t db_stride, int32_t N, int32_t H, int32_t W, int32_t C, int32_t Cout,
+    int32_t R, int32_t S, int32_t stride, int32_t splits, int32_t n_ride, float *const *ride_param,
+    const float *const *ride_grad, float *const *ride_square_avg, float *const *ride_grad_avg,
+    const int64_t *ride_numel, float lr, float alpha, float eps, float weight_decay, int centered,
+    void *stream);
 /* Both gradients of one layer in ONE launch (same dy): arguments of _bwd_data and _bwd_weight
  * combined.  Minibatch-sized problems only; returns PFRL_ERR_ARG for larger ones (the caller
  * then issues the two launches). */

@@ -40,7 +40,7 @@ def build(force=False, verbose=False):
     """Compile every HIP source for gfx950 and link libpfrl_amd.so (in-tree)."""
     os.makedirs(LIB_DIR, exist_ok=True)
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
-    deps = srcs + [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "powf_glibc.h"),
+    deps = srcs + [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "powf_glibc.h"), os.path.join(CSRC, "rms_update.h"),
                    os.path.join(CSRC, "nhwc.h"),
                    os.path.join(_HERE, "..", "include", "pfrl_amd.h")]
     if not force and os.path.exists(LIB_PATH):
@@ -181,6 +181,7 @@ EXPORTS = {
     "pfrl_conv2d_nhwc_fwd": (ctypes.c_int, "ppppiiiiiiiiiiip"),
     "pfrl_conv2d_nhwc_bwd_data": (ctypes.c_int, "pppppiiiiiiiiiip"),
     "pfrl_conv2d_nhwc_bwd_weight": (ctypes.c_int, "pppppqqiiiiiiiiip"),
+    "pfrl_conv2d_nhwc_bwd_weight_ride": (ctypes.c_int, "pppppqqiiiiiiiiiipppppffffip"),
     "pfrl_conv2d_nhwc_bwd": (ctypes.c_int, "ppppppppqqiiiiiiiiiiip"),
     "pfrl_splitk_reduce": (ctypes.c_int, "ippppppppp"),
     "pfrl_linear_fwd": (ctypes.c_int, "ppppiiiiip"),

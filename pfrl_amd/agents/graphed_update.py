@@ -189,12 +189,14 @@ class GraphedUpdate:
                 self._optimizer_finishes_gradients()
             if defer:
                 mfma_trunk.OPT_SOURCES = {}
+                mfma_trunk.RIDE_ALONG = self.agent.optimizer
             try:
                 if ab[0].requires_grad:
                     torch.autograd.backward([ab[0]], [ab[1]])
                 sources = mfma_trunk.OPT_SOURCES
             finally:
                 mfma_trunk.OPT_SOURCES = None
+                mfma_trunk.RIDE_ALONG = None
             if defer and sources:
                 # the head's per-row partials (queued by the loss launch for "the fold that ends
                 # the trunk's backward") become sources / folds of the optimizer launch too

@@ -29,6 +29,7 @@
 // SIMD); grids are sized so that >= 256 workgroups exist at B = 32, with split-K
 // (partials + one multi-tensor reduce) where the output is small.
 #include "common.h"
+#include "rms_update.h"
 
 namespace {
 
@@ -823,6 +824,66 @@ __global__ __launch_bounds__(256) void k_conv_wgrad2(WgradArgs p0, WgradArgs p1,
                                             second ? blockIdx.z - nz : blockIdx.z, smem);
 }
 
+// The LAST backward launch of a minibatch-sized update (the first layer's weight gradient: a few
+// hundred latency-bound workgroups walking a long reduction) with optimizer blocks riding in it.
+// By then the gradients of the layers above are final, and their parameters are not read again in
+// this update; the hidden layer alone is 95 % of the example network's parameters, so most of the
+// optimizer's 47 MB of streaming runs under this launch's load latency instead of in a launch of
+// its own.  Workgroups [0, nw) run the weight-gradient tile program, the rest one RMSprop chunk
+// (1 024 elements) each: the arithmetic of pfrl_rmsprop_step, element by element.
+// (Tried and measured slower, 89.7 vs 87.2 us per update: the hidden layer riding WHOLE -- its
+// weight-gradient tiles formed in this launch and stepped from the accumulators, so that the 6.4 MB
+// gradient is never written or read.  The layer's own launch, left with the input gradient, got
+// 1.6 us shorter; this one 3 us longer: 32 x 32 tiles touch parameter and state in 128-byte pieces
+// 12.5 KB apart, against 1 KB contiguous per wave for the chunks below.)
+constexpr int RIDE_MAX = 4;
+constexpr int RIDE_CHUNK = 1024;
+struct RideArgs {
+    float *p[RIDE_MAX], *sq[RIDE_MAX], *ga[RIDE_MAX];
+    const float *g[RIDE_MAX];
+    long long numel[RIDE_MAX];
+    int block_end[RIDE_MAX];
+    int n;
+    float lr, alpha, eps, weight_decay;
+};
+struct WgradGrid {
+    int nw, wgx, wgy;
+    FastDiv q_wgx, q_wgy;
+};
+
+template <bool CENTERED>
+__device__ __forceinline__ void ride_block(const RideArgs &r, const int b, const int tid) {
+    int t = 0;
+    while (t < r.n - 1 && b >= r.block_end[t]) ++t;
+    const long long i0 = (long long)(b - (t == 0 ? 0 : r.block_end[t - 1])) * RIDE_CHUNK + 4 * tid;
+    if (i0 >= r.numel[t]) return;       // (numel % 4 == 0: whole float4)
+    const float oma = __fsub_rn(1.0f, r.alpha);
+    const float4 gv = *reinterpret_cast<const float4 *>(r.g[t] + i0);
+    float4 pv = *reinterpret_cast<float4 *>(r.p[t] + i0);
+    float4 sv = *reinterpret_cast<float4 *>(r.sq[t] + i0);
+    float4 mv = CENTERED ? *reinterpret_cast<float4 *>(r.ga[t] + i0) : make_float4(0.f, 0.f, 0.f, 0.f);
+    rms_update<CENTERED>(pv.x, gv.x, sv.x, mv.x, r.lr, r.alpha, oma, r.eps, r.weight_decay);
+    rms_update<CENTERED>(pv.y, gv.y, sv.y, mv.y, r.lr, r.alpha, oma, r.eps, r.weight_decay);
+    rms_update<CENTERED>(pv.z, gv.z, sv.z, mv.z, r.lr, r.alpha, oma, r.eps, r.weight_decay);
+    rms_update<CENTERED>(pv.w, gv.w, sv.w, mv.w, r.lr, r.alpha, oma, r.eps, r.weight_decay);
+    *reinterpret_cast<float4 *>(r.p[t] + i0) = pv;
+    *reinterpret_cast<float4 *>(r.sq[t] + i0) = sv;
+    if (CENTERED) *reinterpret_cast<float4 *>(r.ga[t] + i0) = mv;
+}
+
+template <int BI, int BJ, int WM, int WN, int WK, int G, bool CENTERED>
+__global__ __launch_bounds__(256) void k_conv_wgrad_ride(int nw, WgradArgs p, WgradGrid wg, RideArgs r) {
+    __shared__ __attribute__((aligned(16))) float smem[wgrad_smem(BI, BJ, WM, WN, WK, G)];
+    const int b = blockIdx.x;
+    if (b < nw) {
+        const int q = fdiv(b, wg.q_wgx), bx = b - q * wg.wgx;
+        const int bz = fdiv(q, wg.q_wgy);
+        wgrad_body<BI, BJ, WM, WN, WK, G>(p, bx, q - bz * wg.wgy, bz, smem);
+    } else {
+        ride_block<CENTERED>(r, b - nw, threadIdx.x);
+    }
+}
+
 // Input gradient and weight gradient of one layer in ONE launch: both consume the same dy
 // and neither depends on the other.  At B = 32 each is a few hundred latency-bound
 // workgroups that leave most of every CU idle; side by side they overlap almost fully and
@@ -1280,6 +1341,67 @@ extern "C" int pfrl_conv2d_nhwc_bwd_weight(const float *dy, const float *dy_mask
     else
         hipLaunchKernelGGL((k_conv_wgrad<16, 32, 1, 2, 2, 4>), dim3(Cout / 16, a.K / 32, splits),
                            dim3(256), 0, st, a);
+    PFRL_LAUNCH_CHECK();
+}
+
+// pfrl_conv2d_nhwc_bwd_weight with RMSprop steps of OTHER parameters riding in the launch
+// (k_conv_wgrad_ride): n_ride <= 4 tensors, each with its finished gradient tensor grad[i];
+// 16-byte aligned, numel % 4 == 0.  The caller guarantees that nothing later in the stream order
+// of this update reads those parameters or gradients before the launch completes.
+extern "C" int pfrl_conv2d_nhwc_bwd_weight_ride(
+    const float *dy, const float *dy_mask, const float *x, float *dw_part, float *db_part,
+    int64_t dw_stride, int64_t db_stride, int32_t N, int32_t H, int32_t W, int32_t C, int32_t Cout,
+    int32_t R, int32_t S, int32_t stride, int32_t splits, int32_t n_ride, float *const *ride_param,
+    const float *const *ride_grad, float *const *ride_square_avg, float *const *ride_grad_avg,
+    const int64_t *ride_numel, float lr, float alpha, float eps, float weight_decay, int centered,
+    void *stream) {
+    WgradArgs a;
+    if (int rc = make_wgrad_args(a, dy, dy_mask, x, dw_part, db_part, dw_stride, db_stride, N, H, W, C,
+                                 Cout, R, S, stride, splits))
+        return rc;
+    PFRL_CHECK_ARG(n_ride >= 1 && n_ride <= RIDE_MAX && ride_param && ride_grad && ride_square_avg &&
+                       ride_numel && (!centered || ride_grad_avg),
+                   "pfrl_conv2d_nhwc_bwd_weight_ride: 1..4 riding tensors");
+    RideArgs r;
+    int blocks = 0;
+    for (int i = 0; i < RIDE_MAX; ++i) {
+        const int j = i < n_ride ? i : 0;
+        r.p[i] = ride_param[j]; r.g[i] = ride_grad[j]; r.sq[i] = ride_square_avg[j];
+        r.ga[i] = centered ? ride_grad_avg[j] : nullptr;
+        r.numel[i] = i < n_ride ? ride_numel[j] : 0;
+        if (i < n_ride) {
+            const uintptr_t bits = (uintptr_t)r.p[i] | (uintptr_t)r.g[i] | (uintptr_t)r.sq[i] |
+                                   (uintptr_t)r.ga[i];
+            PFRL_CHECK_ARG(r.p[i] && r.g[i] && r.sq[i] && (bits & 15) == 0 && r.numel[i] > 0 &&
+                               r.numel[i] % 4 == 0 && r.numel[i] < (1ll << 40),
+                           "pfrl_conv2d_nhwc_bwd_weight_ride: riding tensors must be 16-byte aligned, "
+                           "numel % 4 == 0");
+            blocks += (int)((r.numel[i] + RIDE_CHUNK - 1) / RIDE_CHUNK);
+        }
+        r.block_end[i] = blocks;
+    }
+    r.n = n_ride;
+    r.lr = lr; r.alpha = alpha; r.eps = eps; r.weight_decay = weight_decay;
+    const bool w32 = Cout % 32 == 0;
+    WgradGrid wg;
+    wg.wgx = w32 ? Cout / 32 : Cout / 16;
+    wg.wgy = a.K / 32;
+    wg.nw = wg.wgx * wg.wgy * splits;
+    wg.q_wgx = fast_div((uint32_t)wg.wgx);
+    wg.q_wgy = fast_div((uint32_t)wg.wgy);
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid((unsigned)(wg.nw + blocks));
+#define RIDE(BI, WM, WN, WK, CEN)                                                                    \
+    hipLaunchKernelGGL((k_conv_wgrad_ride<BI, 32, WM, WN, WK, 4, CEN>), grid, dim3(256), 0, st, wg.nw, \
+                       a, wg, r)
+    if (w32) {
+        if (centered) RIDE(32, 2, 2, 1, true);
+        else RIDE(32, 2, 2, 1, false);
+    } else {
+        if (centered) RIDE(16, 1, 2, 2, true);
+        else RIDE(16, 1, 2, 2, false);
+    }
+#undef RIDE
     PFRL_LAUNCH_CHECK();
 }
 

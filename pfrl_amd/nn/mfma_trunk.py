@@ -193,6 +193,13 @@ def _reduce(tasks):
 # the parameter's data_ptr(), instead of folding / forming the gradients -- and returns None as
 # the gradient of those parameters.
 OPT_SOURCES = None
+# An optimizer (FusedRMSprop) whose steps may RIDE in the last backward launch: set next to
+# OPT_SOURCES by GraphedUpdate.  The hidden layer's weight and bias (95 % of the parameters; their
+# gradients are final after the first backward launch and nothing reads the parameters again in
+# the update) are then stepped by extra workgroups of the first convolution's weight-gradient
+# launch (pfrl_conv2d_nhwc_bwd_weight_ride) and marked GradSource.done() for the optimizer launch.
+RIDE_ALONG = None
+_RIDE = os.environ.get("PFRL_RIDE_ALONG", "1") != "0"
 
 # Folds queued by other nodes of the same backward pass (the fused head + loss launch of
 # ops.dqn_head_td_loss) for the fold launch that ends the trunk's backward: one launch less.
@@ -337,10 +344,14 @@ class _Trunk(torch.autograd.Function):
 
             announce_grad(wf, dwf)
         grads = [None] * (2 * L) + [dwf, dbf]
-        return _Trunk._conv_backward(ctx, specs, params, acts, x, dy, N, dev, grads)
+        ride = None
+        if (RIDE_ALONG is not None and OPT_SOURCES is not None and _RIDE and L >= 1
+                and not _dist_initialized()):
+            ride = [(wf, dwf, 2 * L), (params[2 * L + 1], dbf, 2 * L + 1)]
+        return _Trunk._conv_backward(ctx, specs, params, acts, x, dy, N, dev, grads, ride)
 
     @staticmethod
-    def _conv_backward(ctx, specs, params, acts, x, dy, N, dev, grads):
+    def _conv_backward(ctx, specs, params, acts, x, dy, N, dev, grads, ride=None):
         """Gradients of the convolutions given dy = dL/d(output of the last one) as NHWC rows
         (its ReLU mask applied)."""
         lib = _native.lib()
@@ -378,6 +389,18 @@ class _Trunk(torch.autograd.Function):
                                                _p(pb), st, st, N, sp.H, sp.W, sp.C, sp.Cout, sp.R, sp.S,
                                                sp.ST, 0, 0, splits, _stream()), "conv2d_nhwc_bwd")
                 dy = dx
+                continue
+            ra = RIDE_ALONG.ride_arrays([(p_, g_) for p_, g_, _ in ride]) if (ride and i == 0) else None
+            if ra is not None:
+                # the last launch of the backward pass: the finished layers' optimizer steps ride in it
+                from pfrl_amd.optimizers import GradSource
+
+                check(lib.pfrl_conv2d_nhwc_bwd_weight_ride(
+                    _p(dy), None, _p(below), _p(pw), _p(pb), st, st, N, sp.H, sp.W, sp.C, sp.Cout, sp.R,
+                    sp.S, sp.ST, splits, *ra, _stream()), "conv2d_nhwc_bwd_weight_ride")
+                for p_, g_, slot in ride:
+                    OPT_SOURCES[p_.data_ptr()] = GradSource.done()
+                    grads[slot] = None
                 continue
             check(lib.pfrl_conv2d_nhwc_bwd_weight(_p(dy), None, _p(below), _p(pw), _p(pb), st, st, N,
                                                   sp.H, sp.W, sp.C, sp.Cout, sp.R, sp.S, sp.ST, splits,

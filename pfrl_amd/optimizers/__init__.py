@@ -19,6 +19,7 @@ def _dense(t):
 
 
 OPT_PLAIN, OPT_SLABS, OPT_LOWRANK, OPT_LOWRANK_BIAS, OPT_FOLD = 0, 1, 2, 3, 4   # PFRL_OPT_*
+OPT_DONE = -1     # (host side only: GradSource.done())
 
 
 class GradSource:
@@ -47,6 +48,12 @@ class GradSource:
         M, F = dy.shape
         return cls(OPT_LOWRANK_BIAS, dy, mask=mask, M=int(M), F=int(F))
 
+    @classmethod
+    def done(cls):
+        """The parameter was already stepped in this update (its RMSprop step rode in a backward
+        launch, ``FusedRMSprop.ride_arrays``): the optimizer launch skips it."""
+        return cls(OPT_DONE, None)
+
     @staticmethod
     def lowrank_supported(M, F, K):
         return K % 64 == 0 and F % 16 == 0 and M % 4 == 0 and 4 <= M <= 32
@@ -63,6 +70,41 @@ class FusedRMSprop(torch.optim.RMSprop):
         gradients as :class:`GradSource` s instead of materialising them."""
         return len(self.param_groups) == 1 and self._fusable(self.param_groups[0])
 
+    def ride_arrays(self, pairs):
+        """Arguments of ``pfrl_conv2d_nhwc_bwd_weight_ride`` for ``pairs`` = [(parameter, finished
+        gradient tensor)]: the steps of these parameters run inside a backward launch instead of
+        the optimizer's own (``GradSource.done()`` then tells ``step_from_sources`` to skip them).
+        None when a tensor does not meet the kernel's layout requirements."""
+        if not self.accepts_sources() or not 1 <= len(pairs) <= 4:
+            return None
+        group = self.param_groups[0]
+        centered = bool(group["centered"])
+        ptrs = []
+        for p, g in pairs:
+            st = self.state[p]
+            if len(st) == 0:
+                st["step"] = (torch.zeros((), dtype=torch.float32, device=p.device)
+                              if group.get("capturable", False) else torch.tensor(0.0))
+                st["square_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                if centered:
+                    st["grad_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            sq = st["square_avg"]
+            ga = st["grad_avg"] if centered else None
+            ts = [p, g, sq] + ([ga] if centered else [])
+            if not all(t.is_cuda and t.dtype == torch.float32 and _dense(t)
+                       and t.stride() == p.stride() and t.data_ptr() % 16 == 0 for t in ts):
+                return None
+            if p.numel() % 4 != 0 or p.numel() == 0:
+                return None
+            ptrs.append((p.data_ptr(), g.data_ptr(), sq.data_ptr(), ga.data_ptr() if centered else 0,
+                         p.numel()))
+        n = len(ptrs)
+        V = ctypes.c_void_p * n
+        return (n, V(*[t[0] for t in ptrs]), V(*[t[1] for t in ptrs]), V(*[t[2] for t in ptrs]),
+                V(*[t[3] for t in ptrs]), (ctypes.c_int64 * n)(*[t[4] for t in ptrs]),
+                float(group["lr"]), float(group["alpha"]), float(group["eps"]),
+                float(group["weight_decay"]), int(centered))
+
     def step_from_sources(self, sources, folds=()):
         """``step()`` where the gradient of parameter ``p`` is ``sources[p]`` (a GradSource) if
         present and ``p.grad`` otherwise; ``folds`` = (part, out, stride, n_slabs) slab sums with
@@ -73,7 +115,7 @@ class FusedRMSprop(torch.optim.RMSprop):
         keep = []
         for p in group["params"]:
             src = sources.get(p)
-            if src is None and p.grad is None:
+            if (src is None and p.grad is None) or (src is not None and src.mode == OPT_DONE):
                 continue
             st = self.state[p]
             if len(st) == 0:

@@ -143,3 +143,43 @@ def test_hidden_layer_fold_inside_the_head_launch_is_bit_identical():
     np.testing.assert_array_equal(la, lb)
     for a, b in zip(pa, pb):
         np.testing.assert_array_equal(a, b)
+
+
+def test_optimizer_steps_riding_in_the_last_backward_launch_are_bit_identical():
+    """The hidden layer's RMSprop step as extra workgroups of the first convolution's
+    weight-gradient launch (default, pfrl_conv2d_nhwc_bwd_weight_ride) vs inside the optimizer
+    launch (PFRL_RIDE_ALONG=0): the same arithmetic on the same gradients, so the same bits --
+    losses and every parameter after 6 updates; and the ride is really taken."""
+    from pfrl_amd import _native
+    from pfrl_amd.nn import mfma_trunk
+
+    calls = []
+    lib = _native.lib()
+    real = lib.pfrl_conv2d_nhwc_bwd_weight_ride
+
+    class _Spy:
+        def __getattr__(self, name):
+            if name == "pfrl_conv2d_nhwc_bwd_weight_ride":
+                def f(*a):
+                    calls.append(1)
+                    return real(*a)
+                return f
+            return getattr(lib, name)
+
+    old_lib, old_ride = _native.lib, mfma_trunk._RIDE
+    _native.lib = lambda: _Spy()
+    mfma_trunk._native.lib = _native.lib
+    try:
+        mfma_trunk._RIDE = True
+        pa, la, ua = _run_updates(True)
+        n_on = len(calls)
+        mfma_trunk._RIDE = False
+        pb, lb, ub = _run_updates(True)
+        n_off = len(calls) - n_on
+    finally:
+        _native.lib = old_lib
+        mfma_trunk._RIDE = old_ride
+    assert ua and ub and n_on >= 1 and n_off == 0
+    np.testing.assert_array_equal(la, lb)
+    for a, b in zip(pa, pb):
+        np.testing.assert_array_equal(a, b)
