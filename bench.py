@@ -659,11 +659,44 @@ def data_path_only(args, device, agent, env, rbuf, obss, steps):
         obss = one_step(stub, env, obss, N)
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
-    return {"value": round(N * steps / el, 1), "unit": "env-steps/s", "steps": steps,
-            "ms_per_step": round(el / steps * 1e3, 3),
-            "what": "the same step with a zero-FLOP q_function (SURVEY.md 8d): env frames, "
-                    "act gather, appends, index draws, fused minibatch gathers of the full "
-                    "schedule, TD loss, optimizer step on one row"}, obss
+    out = {"value": round(N * steps / el, 1), "unit": "env-steps/s", "steps": steps,
+           "ms_per_step": round(el / steps * 1e3, 3),
+           "what": "the same step with a zero-FLOP q_function (SURVEY.md 8d): env frames, "
+                   "act gather, appends, index draws, fused minibatch gathers of the full "
+                   "schedule, TD loss, optimizer step on one row"}
+    # ... and with the per-update launches gone too (the zero-FLOP network still costs 4 launches
+    # per update, 256 per step, which is all that bounds the figure above): what the replay side
+    # ALONE sustains -- env frames, the acting gather + action select, the native planner, one
+    # transfer, appends and the 2 048-entry gather of the step's whole schedule.
+
+    class _NoUpdates:
+        graphs = {("range",): None}
+        pipeline = False
+
+        def range_capturable(self):
+            return True
+
+        def run_range(self, big):
+            U, B = big["reward"].shape[:2]
+            return (torch.zeros(U, device=device), torch.zeros(U * B, device=device))
+
+    stub._graphed = _NoUpdates()
+    stub.batch_target_pass = False
+    stub.target_update_interval = 10 ** 12     # (no sync inside a range: every range is "one graph")
+    for _ in range(3):
+        obss = one_step(stub, env, obss, N)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        obss = one_step(stub, env, obss, N)
+    torch.cuda.synchronize()
+    el2 = time.perf_counter() - t0
+    out["without_update_launches"] = {
+        "value": round(N * steps / el2, 1), "ms_per_step": round(el2 / steps * 1e3, 3),
+        "what": "the replay side alone: env frames, acting gather + action select, native "
+                "planner + one transfer, appends, the fused gather of all 64 minibatches of the "
+                "step; no per-update launch"}
+    return out, obss
 
 
 def reference_baseline(args):
