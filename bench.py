@@ -676,9 +676,15 @@ def data_path_only(args, device, agent, env, rbuf, obss, steps):
         def range_capturable(self):
             return True
 
+        zeros = {}
+
         def run_range(self, big):
             U, B = big["reward"].shape[:2]
-            return (torch.zeros(U, device=device), torch.zeros(U * B, device=device))
+            z = self.zeros.get((U, B))
+            if z is None:
+                z = self.zeros[(U, B)] = (torch.zeros(U, device=device),
+                                          torch.zeros(U * B, device=device))
+            return z
 
     stub._graphed = _NoUpdates()
     stub.batch_target_pass = False

@@ -39,7 +39,7 @@ __global__ __launch_bounds__(kThreads) void k_squashed_gaussian_fwd(
     const float *__restrict__ loc, int64_t ld_loc, const float *__restrict__ scale, int64_t ld_scale,
     const float *__restrict__ eps, float *__restrict__ action, float *__restrict__ logp,
     float *__restrict__ neg_logp, int B, int A) {
-    const int row = blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int row = blockIdx.x * (kThreads / 64) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= B) return;
     float s_ladj = 0.f, s_nlp = 0.f;
     for (int a = lane; a < A; a += 64) {

@@ -36,7 +36,8 @@ __global__ __launch_bounds__(kThreads) void k_c51_loss(
     __shared__ int s_up[kWaves][64];
     __shared__ float s_part[kMaxBatch];
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+    // (in an SGPR: the loop over this wave's samples and their scalar operands become uniform)
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const bool on = lane < Z;
     const float z = on ? z_values[lane] : 0.0f;
     const float v_min = z_values[0];

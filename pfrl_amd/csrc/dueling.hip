@@ -30,7 +30,7 @@ __global__ __launch_bounds__(kThreads) void k_dueling_softmax_fwd(
     const float *__restrict__ ya, const float *__restrict__ ys, float *__restrict__ q, int64_t B,
     int A, int Z) {
     const int lane = threadIdx.x & 63;
-    const int64_t b = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    const int64_t b = (int64_t)blockIdx.x * kWavesPerBlock + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (b >= B) return;
     const bool on = lane < Z;
     const int zl = min(lane, Z - 1);
@@ -68,7 +68,7 @@ __global__ __launch_bounds__(kThreads) void k_dueling_softmax_bwd(
     const float *__restrict__ gq, const float *__restrict__ q, float *__restrict__ g_ya,
     float *__restrict__ g_ys, int64_t B, int A, int Z) {
     const int lane = threadIdx.x & 63;
-    const int64_t b = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    const int64_t b = (int64_t)blockIdx.x * kWavesPerBlock + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (b >= B) return;
     const bool on = lane < Z;
     const int zl = min(lane, Z - 1);

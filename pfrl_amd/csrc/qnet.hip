@@ -1048,7 +1048,7 @@ __global__ __launch_bounds__(256) void k_linear_small_fwd(SmallFwdArgs a, int K)
     const float *__restrict__ w = a.w[blockIdx.y];
     const float *__restrict__ bias = a.bias[blockIdx.y];
     float *__restrict__ y = a.y[blockIdx.y];
-    const int m = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     float acc[N];
 #pragma unroll
     for (int n = 0; n < N; ++n) acc[n] = 0.f;
@@ -1596,7 +1596,7 @@ __global__ __launch_bounds__(256) void k_twin_input_grad(TwinDxArgs a, int ldw, 
         for (int u = 0; u < 20; ++u)
             if (e0 + 256 * u < tot) ws[e0 + 256 * u] = v[u];
     }
-    const int m = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int m = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int mm = m < M ? m : M - 1;
     // every lane's dy (ReLU-masked) values of both networks, loads first
     constexpr int NMAX = 8;   // N <= 512

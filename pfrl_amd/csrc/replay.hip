@@ -467,7 +467,7 @@ __global__ __launch_bounds__(kThreads) void k_batch_experiences_f32_small(
     const int32_t *__restrict__ entry_slots, int64_t B, GammaPow gp, uint8_t *__restrict__ out_state,
     uint8_t *__restrict__ out_next, ActT *__restrict__ out_action, float *__restrict__ out_reward,
     float *__restrict__ out_terminal, float *__restrict__ out_discount, int frame_blocks) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // the scalar collapse (a serial chain of dependent loads per thread, 17 strided action
     // floats) goes FIRST in the grid: dispatched last it would be the tail of the launch
     const int scalar_blocks = (int)gridDim.x - frame_blocks;

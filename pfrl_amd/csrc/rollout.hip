@@ -109,7 +109,7 @@ __global__ __launch_bounds__(kThreads) void k_adv_partial(const float *__restric
     }
     a = wave_sum(a);
     b = wave_sum(b);
-    const int w = threadIdx.x >> 6;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if ((threadIdx.x & 63) == 0) {
         s1[w] = a;
         s2[w] = b;

@@ -120,7 +120,7 @@ __device__ __forceinline__ void head_td_row(
     float *s_g, float *s_l, int *s_act, const float *__restrict__ h_part, int h_splits,
     int64_t h_stride, const float *__restrict__ h_bias, float *__restrict__ h_out) {
     constexpr int K = 64 * KJ;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // (optional inputs are read through a pointer that is always valid: no branch at a load)
     const float *__restrict__ sel_q = next_q_online ? next_q_online : target_q;
     const float *__restrict__ wt_src = weights ? weights : reward;
@@ -244,7 +244,7 @@ __global__ __launch_bounds__(kThreads) void k_dqn_head_td_rows(
     __shared__ float s_c[4][K];
     __shared__ float s_g[4], s_l[4];
     __shared__ int s_act[4];
-    const int tid = threadIdx.x, wave = tid >> 6;
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     if (tid < 4) {
         s_act[tid] = -1;          // rows past the batch take no action
         s_g[tid] = 0.f;
