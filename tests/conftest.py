@@ -18,3 +18,18 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture(autouse=True)
+def _finalize_between_tests():
+    """Objects of a finished test that own HIP resources (captured graphs and their private pools,
+    pinned staging rings, events) are collected HERE, at a safe point -- not whenever the
+    collector happens to run inside the next test, possibly in the middle of a stream capture,
+    where a finalizer's HIP call is an error thrown from a destructor (process abort)."""
+    yield
+    import gc
+
+    gc.collect()
+    torch = sys.modules.get("torch")
+    if torch is not None and torch.cuda.is_available():
+        torch.cuda.synchronize()
