@@ -407,6 +407,47 @@ __device__ __forceinline__ void fwd_body(const FwdArgs &p, const int bx, const i
     QSTAMP(3);
     fold_acc<AM, AN, P, WK, WM * WN>(acc, red, wm * WN + wn, wk, lane);
     QSTAMP(4);
+    if (!p.planar && n0 + BN <= g.Cout && (g.Cout & 3) == 0) {
+        // Row-major output (NHWC rows, split-K slabs) of a tile that lies inside the channel range:
+        // the accumulators go through LDS (the chunk buffers are free now) and every thread stores
+        // whole float4 pieces of a row -- BN/4 lanes cover a contiguous 4*BN bytes -- instead of 4-byte
+        // pieces of four rows behind per-element bounds branches (the 64 x 64 program's epilogue was
+        // ~1 000 instructions, as long as its 8-chunk main loop for the first convolution).
+        constexpr int LDT = BN + 4;
+        static_assert(BM * LDT <= G * BM * LDR, "the tile fits in the A chunk buffers");
+        float *tile = &As[0][0];
+        __syncthreads();          // every wave is done reading the chunk buffers
+        if (wk == 0) {
+#pragma unroll
+            for (int am = 0; am < AM; ++am)
+#pragma unroll
+                for (int an = 0; an < AN; ++an) {
+                    const int col = wn * 16 * AN + 16 * an + (lane & 15);
+                    const float bias = p.partial ? 0.f : p.bias[n0 + col];
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) {
+                        float v = acc[am][an][0][reg];
+                        if (!p.partial) {
+                            v = v + bias;
+                            if (p.relu) v = fmaxf(v, 0.f);
+                        }
+                        tile[(wm * 16 * AM + 16 * am + 4 * (lane >> 4) + reg) * LDT + col] = v;
+                    }
+                }
+        }
+        __syncthreads();
+        constexpr int Q = BN / 4;
+        float *yb = p.y + (p.partial ? (size_t)bz * p.M * g.Cout : (size_t)0) + n0;
+#pragma unroll
+        for (int f = tid; f < BM * Q; f += 256) {
+            const int row = f / Q, c4 = 4 * (f - row * Q);
+            const int m = m0 + row;
+            if (m < p.M)
+                *reinterpret_cast<float4 *>(yb + (size_t)m * g.Cout + c4) =
+                    *reinterpret_cast<const float4 *>(&tile[row * LDT + c4]);
+        }
+        return;
+    }
     if (wk != 0) return;
 #pragma unroll
     for (int am = 0; am < AM; ++am)
