@@ -637,6 +637,41 @@ __device__ __forceinline__ void dgrad_body(const DgradArgs &p, const int bx, con
     };
     run_pipeline<Slot, G>(0, p.K / KC, fetch, stash, compute);
     fold_acc<AM, AN, P, WK, WM * WN>(acc, red, wm * WN + wn, wk, lane);
+    if (p.permP == 0 && n0 + BN <= g.C && (g.C & 3) == 0) {
+        // NHWC rows of a tile inside the channel range: through LDS (the A chunk buffers are free),
+        // so that a thread masks and stores a float4 of one row and the row -> (image, ih, iw) split
+        // runs once per 16 bytes instead of once per element
+        constexpr int LDT = BN + 4;
+        static_assert(BM * LDT <= G * BM * LDR, "the tile fits in the A chunk buffers");
+        float *tile = &As[0][0];
+        __syncthreads();
+        if (wk == 0) {
+#pragma unroll
+            for (int am = 0; am < AM; ++am)
+#pragma unroll
+                for (int an = 0; an < AN; ++an)
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg)
+                        tile[(wm * 16 * AM + 16 * am + 4 * (lane >> 4) + reg) * LDT + wn * 16 * AN + 16 * an +
+                             (lane & 15)] = acc[am][an][0][reg];
+        }
+        __syncthreads();
+        constexpr int Q = BN / 4;
+#pragma unroll
+        for (int f = tid; f < BM * Q; f += 256) {
+            const int row = f / Q, c4 = 4 * (f - row * Q);
+            const int m = m0 + row;
+            if (m >= p.Mc) continue;
+            const int n = fdiv(m, p.q_ahw), rem = m - n * ahw;
+            const int a = fdiv(rem, p.q_aw), a2 = rem - a * p.AW;
+            const int ih = a * g.ST + ph, iw = a2 * g.ST + pw;
+            const size_t o = ((size_t)(n * g.H + ih) * g.W + iw) * g.C + n0 + c4;
+            float4 v = *reinterpret_cast<const float4 *>(&tile[row * LDT + c4]);
+            if (p.aprev != nullptr) v = relu_mask(v, *reinterpret_cast<const float4 *>(p.aprev + o));
+            *reinterpret_cast<float4 *>(p.dx + o) = v;
+        }
+        return;
+    }
     if (wk != 0) return;
 #pragma unroll
     for (int am = 0; am < AM; ++am)
