@@ -165,6 +165,10 @@ class FusedRMSprop(torch.optim.RMSprop):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        # Fusability is decided for ALL groups before anything is launched: falling back to
+        # torch's step() in the middle would step the groups already updated a second time, and
+        # the step happens whether or not a closure was given.
+        plan = []
         for group in self.param_groups:
             params = [p for p in group["params"] if p.grad is not None]
             if not params:
@@ -176,8 +180,13 @@ class FusedRMSprop(torch.optim.RMSprop):
                 p.is_cuda and p.dtype == torch.float32 and _dense(p) and not p.grad.is_sparse
                 and p.grad.dtype == torch.float32 and p.grad.stride() == p.stride()
                 for p in params)
+            ok = ok and all(len(self.state[p]) == 0 or self.state[p]["square_avg"].stride() == p.stride()
+                            for p in params)
             if not ok:
-                return super().step(closure=None) if loss is None else loss
+                super().step(closure=None)
+                return loss
+            plan.append((group, params))
+        for group, params in plan:
             centered = bool(group["centered"])
             for p in params:
                 st = self.state[p]
@@ -187,8 +196,6 @@ class FusedRMSprop(torch.optim.RMSprop):
                     st["square_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     if centered:
                         st["grad_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                if st["square_avg"].stride() != p.stride():
-                    return super().step(closure=None) if loss is None else loss
             n = len(params)
             P = (ctypes.c_void_p * n)(*[p.data_ptr() for p in params])
             G = (ctypes.c_void_p * n)(*[p.grad.data_ptr() for p in params])

@@ -62,6 +62,37 @@ def test_fused_adam_on_cpu_is_torch_adam():
     assert isinstance(oa, torch.optim.Adam)
 
 
+@pytest.mark.parametrize("with_closure", [False, True])
+def test_fused_rmsprop_off_the_gpu_is_torch_rmsprop_once_per_call(with_closure):
+    """Parameters the kernel does not cover (here: CPU tensors, two groups) take torch's step --
+    exactly one step per call for every group, also when a closure is passed (the fused class
+    used to return the closure's loss without stepping at all)."""
+    from pfrl_amd.optimizers import FusedRMSprop
+
+    torch.manual_seed(0)
+    a = nn.Sequential(nn.Linear(4, 4), nn.Linear(4, 2))
+    b = copy.deepcopy(a)
+
+    def groups(m):
+        return [{"params": m[0].parameters()}, {"params": m[1].parameters(), "lr": 3e-3}]
+
+    oa = FusedRMSprop(groups(a), lr=1e-2, alpha=0.95, eps=1e-2, centered=True)
+    ob = torch.optim.RMSprop(groups(b), lr=1e-2, alpha=0.95, eps=1e-2, centered=True)
+    for _ in range(3):
+        for m, o in ((a, oa), (b, ob)):
+            def closure(m=m, o=o):
+                o.zero_grad()
+                loss = m(torch.ones(2, 4)).sum()
+                loss.backward()
+                return loss
+            if with_closure:
+                assert o.step(closure) is not None
+            else:
+                closure()
+                o.step()
+    assert all(torch.equal(p, q) for p, q in zip(a.parameters(), b.parameters()))
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("B,A", [(256, 17), (32, 6), (1, 1), (100, 70), (7, 3)])
 def test_squashed_gaussian_matches_torch_distributions(B, A):
