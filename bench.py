@@ -686,22 +686,29 @@ def data_path_only(args, device, agent, env, rbuf, obss, steps):
                                           torch.zeros(U * B, device=device))
             return z
 
-    stub._graphed = _NoUpdates()
-    stub.batch_target_pass = False
-    stub.target_update_interval = 10 ** 12     # (no sync inside a range: every range is "one graph")
-    for _ in range(3):
-        obss = one_step(stub, env, obss, N)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        obss = one_step(stub, env, obss, N)
-    torch.cuda.synchronize()
-    el2 = time.perf_counter() - t0
-    out["without_update_launches"] = {
-        "value": round(N * steps / el2, 1), "ms_per_step": round(el2 / steps * 1e3, 3),
-        "what": "the replay side alone: env frames, acting gather + action select, native "
-                "planner + one transfer, appends, the fused gather of all 64 minibatches of the "
-                "step; no per-update launch"}
+    single = not (torch.distributed.is_available() and torch.distributed.is_initialized()
+                  and torch.distributed.get_world_size() > 1)
+    if not (single and stub.use_graphs and stub.range_graphs):
+        return out, obss       # (the range-graph path is what the stand-in below replaces)
+    try:
+        stub._graphed = _NoUpdates()
+        stub.batch_target_pass = False
+        stub.target_update_interval = 10 ** 12   # (no sync inside a range: every range is "one graph")
+        for _ in range(3):
+            obss = one_step(stub, env, obss, N)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            obss = one_step(stub, env, obss, N)
+        torch.cuda.synchronize()
+        el2 = time.perf_counter() - t0
+        out["without_update_launches"] = {
+            "value": round(N * steps / el2, 1), "ms_per_step": round(el2 / steps * 1e3, 3),
+            "what": "the replay side alone: env frames, acting gather + action select, native "
+                    "planner + one transfer, appends, the fused gather of all 64 minibatches of the "
+                    "step; no per-update launch"}
+    except Exception as e:      # an extra figure must never cost the line its numbers
+        sys.stderr.write("data_path_only.without_update_launches failed: %r\n" % (e,))
     return out, obss
 
 
