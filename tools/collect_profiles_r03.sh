@@ -38,7 +38,7 @@ python $R/tools/update_timeline.py /tmp/p3/*/*_kernel_trace.csv --marker k_adam 
 rm -rf /tmp/p3
 rocprofv3 --kernel-trace --output-format csv -d /tmp/p4 -- \
     python $R/bench.py --algo sac --no-cpu-baseline --steps 20 --warmup 3 > /dev/null 2>&1
-python $R/tools/update_timeline.py /tmp/p4/*/*_kernel_trace.csv > $O/sac_update_timeline.txt 2>&1
+python $R/tools/update_timeline.py /tmp/p4/*/*_kernel_trace.csv --marker k_adam --every 3 > $O/sac_update_timeline.txt 2>&1
 rm -rf /tmp/p4
 # 5. the bench lines
 python $R/bench.py > $O/bench_default.json 2> $O/bench_default.err

@@ -19,6 +19,15 @@ a = ap.parse_args()
 rows = [r for r in csv.DictReader(open(a.csv))]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 idx = [i for i, r in enumerate(rows) if a.marker in r["Kernel_Name"]]
+if len(idx) <= 2 * a.every:
+    # (too few marker launches for this --every: say what the trace holds instead of a traceback)
+    import collections
+
+    names = collections.Counter(short(r["Kernel_Name"]) for r in rows)
+    print("marker %r found %d times (need > %d); most frequent kernels:" % (a.marker, len(idx), 2 * a.every))
+    for n, c in names.most_common(25):
+        print("%8d  %s" % (c, n))
+    raise SystemExit(0)
 i1 = idx[-1 - a.every]
 i0 = idx[-1 - 2 * a.every]
 t0 = int(rows[i0]["End_Timestamp"])
