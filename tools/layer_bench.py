@@ -1,0 +1,116 @@
+#!/usr/bin/env python
+"""Per-layer, per-direction time of the csrc/qnet.hip tile programs at the batch sizes of the
+PPO rollout / update (512, 16384) and of the DQN update (32), against the f32 MFMA peak and the
+HBM time of the layer's unique bytes.  Runs ON THE GPU BOX:
+
+    python tools/layer_bench.py [--batches 16384,512] [--iters 10] [--only fwd,dgrad,wgrad]
+
+Every row: kernel time (hipEvents around `iters` back-to-back launches), the FLOPs the layer
+needs (useful: taps outside the output are not counted), TFLOP/s and the fraction of the 155
+TFLOP/s f32 MFMA peak; `hbm_us` = unique bytes of the layer / 6.29 TB/s (what the launch would
+take if it were a pure copy of its operands).
+"""
+import argparse
+import ctypes
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from pfrl_amd import _native   # noqa: E402
+from pfrl_amd._native import check   # noqa: E402
+
+PEAK_TF = 155.0
+HBM_TBS = 6.29
+
+# (name, C, Cout, R, ST, H) of train_ppo_ale.py:247-264 / atari_cnn.py:17-47; the linear layer is 1x1
+LAYERS = [("conv1", 4, 32, 8, 4, 84), ("conv2", 32, 64, 4, 2, 20), ("conv3", 64, 64, 3, 1, 9),
+          ("fc", 3136, 512, 1, 1, 1)]
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def time_us(fn, iters):
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / iters
+
+
+def wgrad_splits(M, Cout, K):
+    from pfrl_amd.nn.mfma_trunk import _wgrad_splits
+
+    return _wgrad_splits(M, Cout, K)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batches", default="16384,512,32")
+    ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--only", default="fwd,dgrad,wgrad")
+    ap.add_argument("--layers", default="conv1,conv2,conv3,fc")
+    args = ap.parse_args()
+    only = set(args.only.split(","))
+    lib = _native.lib()
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(0)
+    print("%-6s %-6s %6s %10s %9s %8s %6s %9s" % ("layer", "dir", "B", "us", "GFLOP", "TF/s", "frac",
+                                                   "hbm_us"))
+    for B in [int(b) for b in args.batches.split(",")]:
+        for name, C, Co, R, ST, H in LAYERS:
+            if name not in args.layers.split(","):
+                continue
+            OH = (H - R) // ST + 1
+            x = torch.randn(B, H, H, C, device=dev)
+            w = torch.randn(Co, R, R, C, device=dev) * 0.05
+            b = torch.randn(Co, device=dev)
+            y = torch.empty(B, OH, OH, Co, device=dev)
+            dy = torch.randn(B, OH, OH, Co, device=dev)
+            dx = torch.empty_like(x)
+            M = B * OH * OH
+            K = R * R * C
+            flop = 2.0 * M * K * Co
+            bx, by, bw = x.numel() * 4, y.numel() * 4, w.numel() * 4
+            rows = []
+            if "fwd" in only:
+                t = time_us(lambda: check(lib.pfrl_conv2d_nhwc_fwd(
+                    _p(x), _p(w), _p(b), _p(y), B, H, H, C, Co, R, R, ST, 1, 0, 1, _stream()), "fwd"),
+                    args.iters)
+                rows.append(("fwd", t, flop, bx + by + bw))
+            if "dgrad" in only and name != "conv1":
+                t = time_us(lambda: check(lib.pfrl_conv2d_nhwc_bwd_data(
+                    _p(dy), None, _p(w), _p(x), _p(dx), B, H, H, C, Co, R, R, ST, 0, 0, _stream()),
+                    "dgrad"), args.iters)
+                rows.append(("dgrad", t, flop, 2 * bx + by + bw))
+            if "wgrad" in only:
+                splits = wgrad_splits(M, Co, K)
+                stride = w.numel() + Co
+                part = torch.empty(splits * stride, device=dev)
+                t = time_us(lambda: check(lib.pfrl_conv2d_nhwc_bwd_weight(
+                    _p(dy), None, _p(x), _p(part), _p(part[w.numel():]), stride, stride, B, H, H, C, Co,
+                    R, R, ST, splits, _stream()), "wgrad"), args.iters)
+                rows.append(("wgrad/%d" % splits, t, flop, bx + by + splits * stride * 4))
+            for d, t, f, nbytes in rows:
+                tf = f / t * 1e-6
+                print("%-6s %-9s %6d %10.1f %9.2f %8.1f %6.3f %9.1f" % (
+                    name, d, B, t, f * 1e-9, tf, tf / PEAK_TF, nbytes / HBM_TBS * 1e-6))
+            del x, w, y, dy, dx
+            torch.cuda.empty_cache()
+
+
+if __name__ == "__main__":
+    main()
