@@ -461,7 +461,12 @@ class DQN(agent.AttributeSavingMixin, agent.BatchAgent):
             sink = mfma_trunk.FWD_FOLD_SINK = {} if (
                 self._defer_head_fold and os.environ.get("PFRL_FWD_FOLD", "1") != "0") else None
             try:
-                for mod in split[0]:
+                body = split[0]
+                for k, mod in enumerate(body):
+                    if sink and k > 0:
+                        # slabs left by an earlier module are only legal as the HEAD's input: a module
+                        # in between (e.g. an extra hidden layer) must see the folded tensor
+                        mfma_trunk.flush_fwd_folds(sink)
                     h = mod(h)
             finally:
                 mfma_trunk.FWD_FOLD_SINK = None

@@ -511,6 +511,10 @@ class _TrunkSequential(nn.Sequential):
                 if specs is not None:
                     x = trunk_forward(x, specs, convs, mods[lin_idx])
                     i = end
+                    if FWD_FOLD_SINK and i < len(mods):
+                        # slabs may only be handed to the narrow head behind this container; a
+                        # child that follows the stretch reads the folded tensor
+                        flush_fwd_folds(FWD_FOLD_SINK)
                     continue
             x = mods[i](x)
             i += 1

@@ -387,6 +387,12 @@ class DeviceReplayStore:
         self.h_reward[slot] = reward
         self.h_terminal[slot] = terminal
         self.h_min_fseq[slot] = s_seq if s_seq < n_seq else n_seq
+        if self.h_extra:
+            # the row this append overwrites (tid - R) takes its extras with it: the tables stay
+            # bounded by the ring, like every other column (they used to grow with total steps)
+            dead = tid - self.R
+            for table in self.h_extra.values():
+                table.pop(dead, None)
         if extra:
             for key, val in extra.items():
                 self.h_extra.setdefault(key, {})[tid] = val
@@ -441,10 +447,12 @@ class DeviceReplayStore:
             done += c
         return first_seq
 
-    def add_entry(self, tids):
-        """An emitted n-step window (list of absolute tids) -> entry seq."""
+    def add_entry(self, tids, span_check=True):
+        """An emitted n-step window (list of absolute tids) -> entry seq.  ``span_check=False``:
+        the caller (episodic back-ends, whose windows are single transitions of episodes that
+        interleave with every other env's) guards the ring itself."""
         first = tids[0]
-        if self.n_trans - first > self.slack:
+        if span_check and self.n_trans - first > self.slack:
             raise RuntimeError(
                 "replay transition ring too small: an n-step window spans %d transitions; "
                 "increase `slack`" % (self.n_trans - first))

@@ -85,6 +85,7 @@ class EpisodicReplayBuffer(AbstractEpisodicReplayBuffer):
         if self.store is not None:
             if next_action is not None:
                 kwargs = dict(kwargs, next_action=next_action)
+            self._guard_ring()
             item = self.store.add_transition(state, action, reward, next_state, is_state_terminal,
                                              kwargs or None)
         else:
@@ -93,6 +94,43 @@ class EpisodicReplayBuffer(AbstractEpisodicReplayBuffer):
         self.current_episode[env_id].append(item)
         if is_state_terminal:
             self.stop_current_episode(env_id=env_id)
+
+    # -- device back-end: the transition ring vs the episodes that are still alive ---------------
+    # An episode's rows sit at tid % R, interleaved with the rows of every other env, from its first
+    # step until it is evicted -- a span that is NOT bounded by the n-step slack of the flat buffers
+    # (n_envs x episode length + capacity).  `_live_first` holds the first tid of every committed
+    # episode in commit (= eviction) order; the oldest live tid only ever grows, so it is cached
+    # and recomputed when the ring catches up with it.
+    _live_first = None
+    _oldest_live = 0
+
+    def _guard_ring(self):
+        """Called before transition ``n_trans`` is written: the row it overwrites
+        (``n_trans - R``) must not belong to a live (committed or running) episode."""
+        st = self.store
+        dead = st.n_trans - st.R
+        if dead < self._oldest_live:
+            return
+        cands = [ep[0] for ep in self.current_episode.values() if ep]
+        if self._live_first:
+            cands.append(min(self._live_first))
+        self._oldest_live = min(cands) if cands else st.n_trans
+        if dead >= self._oldest_live:
+            raise RuntimeError(
+                "episodic replay: the device transition ring (%d rows = capacity %s + slack %d) "
+                "would overwrite a live episode (oldest live transition %d, next %d): episodes of "
+                "all envs interleave in the ring, so it must hold capacity + n_envs x episode "
+                "length rows -- pass a larger `slack` (or `max_size` for an unbounded buffer)"
+                % (st.R, self.capacity, st.slack, self._oldest_live, st.n_trans))
+
+    def _note_commit(self, tids):
+        if self._live_first is None:
+            self._live_first = collections.deque()
+        self._live_first.append(tids[0])
+
+    def _note_evict(self):
+        if self._live_first:
+            self._live_first.popleft()
 
     def stop_current_episode(self, env_id=0):
         episode = self.current_episode[env_id]
@@ -118,15 +156,17 @@ class EpisodicReplayBuffer(AbstractEpisodicReplayBuffer):
         st = self.store
         first = st.n_entries
         for tid in tids:
-            st.add_entry([tid])
+            st.add_entry([tid], span_check=False)
         if st.n_entries - self.memory.head > st.bound and self.capacity is None:
             raise RuntimeError("unbounded EpisodicReplayBuffer exceeded its device allocation "
                                "(max_size=%d)" % st.bound)
         self.episodic_memory.append(_EpisodeRef(first, len(tids)))
+        self._note_commit(tids)
         if self.capacity is None:
             return
         while len(self.memory) > self.capacity:
             self.memory.head += len(self.episodic_memory.popleft())    # whole episodes leave
+            self._note_evict()
 
     # -- sampling ----------------------------------------------------------------------------
     def sample(self, n):
@@ -206,6 +246,7 @@ class EpisodicReplayBuffer(AbstractEpisodicReplayBuffer):
                     extra = {k: v for k, v in t.items() if k not in (
                         "state", "action", "reward", "next_state", "is_state_terminal")
                         and v is not None}
+                    self._guard_ring()
                     tids.append(self.store.add_transition(t["state"], t["action"], t["reward"],
                                                           t["next_state"], t["is_state_terminal"],
                                                           extra or None))

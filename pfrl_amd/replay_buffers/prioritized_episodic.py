@@ -60,8 +60,9 @@ class PrioritizedEpisodicReplayBuffer(EpisodicReplayBuffer, PriorityWeightError)
             st = self.store
             first = st.n_entries
             for tid in episode:
-                st.add_entry([tid])
+                st.add_entry([tid], span_check=False)
             ref = _EpisodeRef(first, len(episode))
+            self._note_commit(episode)
             priority = None
             if self.default_priority_func is not None:
                 priority = self.default_priority_func(DeviceEpisode(st, first, len(episode)))
@@ -71,10 +72,15 @@ class PrioritizedEpisodicReplayBuffer(EpisodicReplayBuffer, PriorityWeightError)
                 # :47): the oldest TRANSITIONS leave one by one, whatever the episodes do
                 self.memory.head = max(self.memory.head, st.n_entries - self.capacity)
             if self.capacity_left is None:
+                # unbounded: nothing is ever evicted, the entry ring is the limit
+                if st.n_entries > st.bound:
+                    raise RuntimeError("unbounded PrioritizedEpisodicReplayBuffer exceeded its device "
+                                       "allocation (max_size=%d)" % st.bound)
                 return
             self.capacity_left -= len(ref)
             while self.capacity_left < 0:
                 self.capacity_left += len(self.episodic_memory.popleft())
+                self._note_evict()
             return
         priority = None
         if self.default_priority_func is not None:

@@ -979,3 +979,49 @@ def test_prioritized_episodic_buffer_with_payloads_in_hbm_matches_reference_trac
     assert paths
     for p in paths:
         mod.check_prioritized_episodic(p, payload_on_device=True)
+
+
+@pytest.mark.gpu
+def test_device_episodic_ring_holds_interleaved_envs_and_extras_stay_bounded():
+    """(a) batched envs interleave their episodes in the transition ring, so an
+    episode's tids span n_envs x length rows: the commit is guarded against the RING (live
+    episodes vs rows), not against the n-step slack of the flat buffers.  (b) per-transition extras (recurrent states) are
+    dropped with the row they belong to: the host tables stay bounded by the ring.  (c) when the
+    ring really is too small for the live episodes the error says so BEFORE a row is overwritten."""
+    dev = torch.device("cuda:0")
+    n_envs, ep_len = 48, 40                      # 1 920 interleaved rows per round of episodes
+    buf = EpisodicReplayBuffer(capacity=3000, device=dev, slack=4000)      # R = 7 000 > 3 rounds
+    host = EpisodicReplayBuffer(capacity=3000)
+    phi = lambda x: np.asarray(x, dtype=np.float32)   # noqa: E731
+    buf.bind(dev, phi)
+    vec = np.zeros(3, dtype=np.float32)
+    t = 0
+    for rnd in range(6):
+        for step in range(ep_len):
+            for e in range(n_envs):
+                kw = dict(state=vec + t, action=t % 3, reward=float(t), next_state=vec + t + 1,
+                          is_state_terminal=(step == ep_len - 1), env_id=e,
+                          recurrent_state=np.full(2, t, np.float32))
+                buf.append(**kw)
+                host.append(**kw)
+                t += 1
+    assert len(buf) == len(host) and buf.n_episodes == host.n_episodes
+    st = buf.store
+    assert all(len(tab) <= st.R for tab in st.h_extra.values())
+    assert min(min(tab) for tab in st.h_extra.values()) >= st.n_trans - st.R
+    np.random.seed(3)
+    a = buf.sample_episodes(4)
+    np.random.seed(3)
+    b = host.sample_episodes(4)
+    for x, y in zip(a, b):
+        assert [tr["reward"] for tr in x] == [tr["reward"] for tr in y]
+        assert [float(tr["recurrent_state"][0]) for tr in x] == [float(tr["recurrent_state"][0]) for tr in y]
+    # (c) a ring smaller than capacity + the episodes in flight
+    small = EpisodicReplayBuffer(capacity=3000, device=dev, slack=100)     # R = 3 100
+    small.bind(dev, phi)
+    with pytest.raises(RuntimeError, match="overwrite a live episode"):
+        t = 0
+        for step in range(200):
+            for e in range(n_envs):
+                small.append(state=vec, action=0, reward=0.0, next_state=vec,
+                             is_state_terminal=(step % ep_len == ep_len - 1), env_id=e)

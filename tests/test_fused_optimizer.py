@@ -78,7 +78,7 @@ def test_lowrank_tile_layout_is_not_transposed():
     assert torch.allclose(w.detach(), want, rtol=1e-6, atol=1e-7)
 
 
-def _run_updates(fused, n_updates=6, fwd_fold=True):
+def _run_updates(fused, n_updates=6, fwd_fold=True, extra_hidden=False):
     import pfrl_amd as pfrl
     from pfrl_amd import agents, explorers, replay_buffers
     from pfrl_amd.device_store import DeviceFrameStore
@@ -93,7 +93,8 @@ def _run_updates(fused, n_updates=6, fwd_fold=True):
         dev = torch.device("cuda:0")
         pfrl.utils.set_random_seed(0)
         torch.manual_seed(0)
-        q = torch.nn.Sequential(pfrl.nn.LargeAtariCNN(),
+        mid = [init_chainer_default(torch.nn.Linear(512, 512)), torch.nn.ReLU()] if extra_hidden else []
+        q = torch.nn.Sequential(pfrl.nn.LargeAtariCNN(), *mid,
                                 init_chainer_default(torch.nn.Linear(512, 6)),
                                 DiscreteActionValueHead()).to(memory_format=torch.channels_last)
         opt = FusedRMSprop(q.parameters(), lr=2.5e-4, alpha=0.95, eps=1e-2, centered=True)
@@ -140,6 +141,18 @@ def test_hidden_layer_fold_inside_the_head_launch_is_bit_identical():
     pa, la, ua = _run_updates(True, fwd_fold=True)
     pb, lb, ub = _run_updates(True, fwd_fold=False)
     assert ua and ub
+    np.testing.assert_array_equal(la, lb)
+    for a, b in zip(pa, pb):
+        np.testing.assert_array_equal(a, b)
+
+
+def test_module_between_trunk_and_head_reads_the_folded_hidden_layer():
+    """Sequential(cnn, Linear(512, 512), ReLU, Linear(512, A), head): the trunk's split-K slabs
+    may only be handed to the narrow head's launch; the layer in between must see the folded
+    tensor (it read an unfilled buffer).  Same bits with and without the sink."""
+    pa, la, ua = _run_updates(True, fwd_fold=True, extra_hidden=True)
+    pb, lb, ub = _run_updates(True, fwd_fold=False, extra_hidden=True)
+    assert ua and ub and np.all(np.isfinite(la))
     np.testing.assert_array_equal(la, lb)
     for a, b in zip(pa, pb):
         np.testing.assert_array_equal(a, b)
