@@ -174,7 +174,15 @@ class GraphedUpdate:
         opt = ag.optimizer
         return (os.environ.get("PFRL_FUSED_OPT", "1") != "0" and ag.max_grad_norm is None
                 and not self.split_for_allreduce and not self.pipeline
-                and hasattr(opt, "step_from_sources") and opt.accepts_sources())
+                and hasattr(opt, "step_from_sources") and opt.accepts_sources()
+                and self._optimizer_owns_every_parameter())
+
+    def _optimizer_owns_every_parameter(self):
+        """Sources are keyed by parameter: a trainable parameter outside the optimizer's groups
+        (a frozen-by-omission layer, a partial optimizer) would have nobody to hand its slabs to."""
+        ag = self.agent
+        owned = {p.data_ptr() for g in ag.optimizer.param_groups for p in g["params"]}
+        return all(p.data_ptr() in owned for p in ag.model.parameters() if p.requires_grad)
 
     def _backward(self, loss):
         ab = getattr(self.agent, "_analytic_backward", None)

@@ -211,9 +211,14 @@ class PrioritizedBuffer:
         pri_tag, prob, weight, total, total_tag, min_prob[, slot]).  ``u01``
         defaults to the draws np.random.uniform would consume (same stream).
         ``co_stage`` = (arrays, launch) of another object (the replay store's new rows) whose
-        control traffic rides in the same host->device copy."""
+        control traffic rides in the same host->device copy, or a callable returning that pair
+        (or None), called after the preconditions hold."""
         assert not self.wait_priority_after_sampling or not self.flag_wait_priority
         assert len(self) >= n
+        if callable(co_stage):
+            # taken only now: take_pending() clears the other object's pending rows, which must
+            # not be lost to a failed assert above
+            co_stage = co_stage()
         pending = self.take_pending()
         if pending is None:
             self.flush()            # (nothing pending, or more than one launch's worth)
@@ -252,6 +257,9 @@ class PrioritizedBuffer:
                 n_c = len(co_stage[0])
             need = sum(((a.nbytes + 15) & ~15) for a in arrays)
             if need > self._stage.slot_bytes:
+                # copies issued through the native h2d path (and side-stream kernels reading the
+                # slots) may still be in flight: the old ring's pinned buffers stay alive
+                self._retired_stages = getattr(self, "_retired_stages", []) + [self._stage]
                 self._stage = StagingRing(self.device, slot_bytes=2 * need, n_slots=32)
             views = self._stage.upload(arrays)
             if co_stage is not None:

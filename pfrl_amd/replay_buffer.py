@@ -197,7 +197,21 @@ def _batch_device_episodes(experiences, device, phi, gamma):
 
     out["recurrent_state"] = initial_state("recurrent_state")
     out["next_recurrent_state"] = initial_state("next_recurrent_state")
+    # `next_action` (SARSA-style agents) lives in the store's per-transition extras; emitted, as
+    # the reference does (:283-285), only when every transition has one -- in packed time-major order
+    table = (store.h_extra or {}).get("next_action")
+    if table:
+        from pfrl_amd.utils.recurrent import flatten_sequences_time_first
+
+        tids = flatten_sequences_time_first(
+            [[int(store.h_e_tids[(ep.first + i) % store.E][0]) for i in range(ep.length)]
+             for ep in experiences])
+        if all(t in table for t in tids):
+            out["next_action"] = torch.as_tensor([table[t] for t in tids], device=device)
     return out
+
+
+_DEFAULT_BATCH_STATES = batch_states
 
 
 def batch_recurrent_experiences(experiences, device, phi, gamma, batch_states=batch_states):
@@ -213,7 +227,8 @@ def batch_recurrent_experiences(experiences, device, phi, gamma, batch_states=ba
 
     lengths = [len(ep) for ep in experiences]
     assert all(a >= b for a, b in zip(lengths, lengths[1:])), "episodes must be sorted by length"
-    if experiences and all(isinstance(ep, DeviceEpisode) for ep in experiences):
+    if (experiences and all(isinstance(ep, DeviceEpisode) for ep in experiences)
+            and batch_states is _DEFAULT_BATCH_STATES):
         # episode payloads live in HBM: one ragged gather launch, nothing crosses PCIe but
         # three small index arrays
         return _batch_device_episodes(experiences, device, phi, gamma)

@@ -176,7 +176,7 @@ class PrioritizedReplayBuffer(ReplayBuffer, PriorityWeightError):
         # writes and the uniform draws: one copy in front of the launches of this sample
         out = tree.sample_device(n, normalize=_NORMALIZE_CODE[self.normalize_by_max],
                                  beta=self.beta, slot_mod=self.store.E,
-                                 co_stage=self.store.take_pending())
+                                 co_stage=self.store.take_pending)
         self.beta = min(1.0, self.beta + self.beta_add)
         self._last_sample = out
         return DeviceExperienceBatch(self.store, out["slot"], _LazySeqs(out["x"], n),
