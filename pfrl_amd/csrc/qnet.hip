@@ -1242,6 +1242,13 @@ __global__ __launch_bounds__(256) void k_linear_small_bwd(SmallBwdArgs a, int M,
     }
 }
 
+// PFRL_QNET_FWD / _DGRAD / _WGRAD = tile program id: measurement hook of tools/layer_bench.py
+// (-1 = the rule below decides).  Read per call; a launch is microseconds, getenv nanoseconds.
+int prog_override(const char *name) {
+    const char *e = getenv(name);
+    return e != nullptr && *e ? atoi(e) : -1;
+}
+
 bool geom_ok(const ConvGeom &g) {
     return g.N > 0 && g.C > 0 && g.Cout > 0 && g.R > 0 && g.S > 0 && g.ST > 0 &&
            g.H >= g.R && g.W >= g.S && g.OH == (g.H - g.R) / g.ST + 1 &&
@@ -1275,20 +1282,33 @@ extern "C" int pfrl_conv2d_nhwc_fwd(const float *x, const float *w, const float 
 #define FWD(BM, BN, WM, WN, WK, G)                                                                   \
     hipLaunchKernelGGL((k_conv_fwd<BM, BN, WM, WN, WK, G>),                                          \
                        dim3((a.M + BM - 1) / BM, (Cout + BN - 1) / BN, z), dim3(256), 0, st, a)
-    if (Cout % 32 != 0) {
-        // narrow outputs (16 channels)
-        if (blocks(64, 16) >= 512) FWD(64, 16, 4, 1, 1, 2);
-        else FWD(32, 16, 2, 1, 2, 4);
-    } else if (Cout % 64 == 0 && blocks(64, 64) >= 1024) {
-        FWD(64, 64, 2, 2, 1, 2);
-    } else if (blocks(64, 32) >= 1024) {
-        FWD(64, 32, 2, 2, 1, 2);
-    } else if (blocks(32, 32) >= 384) {
-        FWD(32, 32, 2, 2, 1, 4);
-    } else if (a.cps >= 12) {
-        FWD(16, 32, 1, 2, 2, 8);   // few workgroups, long reduction: stages of 8 chunks
-    } else {
-        FWD(16, 32, 1, 2, 2, 4);
+    // Rollout- and update-sized batches (M in the millions of rows): 128-row tiles.  What bounds the
+    // 64-row programs there is the global -> LDS fill (measured: conv1 / conv2 forward and the 32 x 32
+    // weight-gradient program all sit at 6.4-7.5 TB/s of fill whatever their MFMA share), so the lever
+    // is FLOP per filled byte: 128 x 64 is 21.8 against 16 for 64 x 64, 128 x 32 13.1 against 10.9.
+    const int force = prog_override("PFRL_QNET_FWD");
+    int prog;
+    if (Cout % 32 != 0) prog = blocks(64, 16) >= 512 ? 0 : 1;        // narrow outputs (16 channels)
+    else if (Cout % 64 == 0 && blocks(128, 64) >= 2048) prog = 7;
+    else if (blocks(128, 32) >= 4096) prog = 8;
+    else if (Cout % 64 == 0 && blocks(64, 64) >= 1024) prog = 2;
+    else if (blocks(64, 32) >= 1024) prog = 3;
+    else if (blocks(32, 32) >= 384) prog = 4;
+    else prog = a.cps >= 12 ? 5 : 6;   // few workgroups, long reduction: stages of 8 chunks
+    if (force >= 0 && force <= 8) {
+        const bool narrow = Cout % 32 != 0, wide = force == 2 || force == 7;
+        if (narrow ? force <= 1 : (force >= 2 && (!wide || Cout % 64 == 0))) prog = force;
+    }
+    switch (prog) {
+        case 0: FWD(64, 16, 4, 1, 1, 2); break;
+        case 1: FWD(32, 16, 2, 1, 2, 4); break;
+        case 2: FWD(64, 64, 2, 2, 1, 2); break;
+        case 3: FWD(64, 32, 2, 2, 1, 2); break;
+        case 4: FWD(32, 32, 2, 2, 1, 4); break;
+        case 5: FWD(16, 32, 1, 2, 2, 8); break;
+        case 6: FWD(16, 32, 1, 2, 2, 4); break;
+        case 7: FWD(128, 64, 2, 2, 1, 2); break;
+        default: FWD(128, 32, 4, 1, 1, 2); break;
     }
 #undef FWD
     PFRL_LAUNCH_CHECK();
@@ -1368,6 +1388,11 @@ static int dgrad_program(const DgradArgs &a, int z) {
     const int C = a.g.C;
     auto blocks = [&](int bm, int bn) { return (long long)((a.Mc + bm - 1) / bm) * (C / bn) * z; };
     if (C % 32 != 0) return 5;
+    const int force = prog_override("PFRL_QNET_DGRAD");
+    if (force >= 0 && force != 5 && (C % 64 == 0 || (force != 0 && force != 6))) return force;
+    // 6 = <128,64>, 7 = <128,32>: update-sized batches (see pfrl_conv2d_nhwc_fwd)
+    if (C % 64 == 0 && blocks(128, 64) >= 2048) return 6;
+    if (blocks(128, 32) >= 4096) return 7;
     if (C % 64 == 0 && blocks(64, 64) >= 1024) return 0;
     if (blocks(64, 32) >= 1024) return 1;
     if (blocks(32, 32) >= 384) return 2;
@@ -1395,6 +1420,8 @@ extern "C" int pfrl_conv2d_nhwc_bwd_data(const float *dy, const float *dy_mask, 
         case 2: DG(32, 32, 2, 2, 1, 4); break;
         case 3: DG(16, 32, 1, 2, 2, 8); break;
         case 4: DG(16, 32, 1, 2, 2, 4); break;
+        case 6: DG(128, 64, 2, 2, 1, 2); break;
+        case 7: DG(128, 32, 4, 1, 1, 2); break;
         default: DG(32, 16, 2, 1, 2, 4); break;
     }
 #undef DG
@@ -1411,12 +1438,34 @@ extern "C" int pfrl_conv2d_nhwc_bwd_weight(const float *dy, const float *dy_mask
                                  Cout, R, S, stride, splits))
         return rc;
     hipStream_t st = (hipStream_t)stream;
-    if (Cout % 32 == 0)
-        hipLaunchKernelGGL((k_conv_wgrad<32, 32, 2, 2, 1, 4>), dim3(Cout / 32, a.K / 32, splits),
-                           dim3(256), 0, st, a);
-    else
-        hipLaunchKernelGGL((k_conv_wgrad<16, 32, 1, 2, 2, 4>), dim3(Cout / 16, a.K / 32, splits),
-                           dim3(256), 0, st, a);
+    // Long reductions (update-sized batches: thousands of chunks per split): large output tiles, for
+    // FLOP per filled byte (32 x 32 is 8, 64 x 128 is 21.8, 32 x 256 14.2) -- see pfrl_conv2d_nhwc_fwd.
+    // 0 = <32,32,G4>, 1 = <16,32,G4>, 2 = <64,64>, 3 = <64,128>, 4 = <32,128>, 5 = <32,256>
+    int prog = Cout % 32 == 0 ? 0 : 1;
+    if (a.cps >= 64 && Cout % 32 == 0) {
+        if (Cout % 64 == 0 && a.K % 128 == 0) prog = 3;
+        else if (Cout % 64 == 0 && a.K % 64 == 0) prog = 2;
+        else if (a.K % 256 == 0) prog = 5;
+        else if (a.K % 128 == 0) prog = 4;
+    }
+    const int force = prog_override("PFRL_QNET_WGRAD");
+    if (force >= 0 && Cout % 32 == 0 && force != 1) {
+        const int bi = (force == 2 || force == 3) ? 64 : 32;
+        const int bj = force == 0 ? 32 : force == 2 ? 64 : force == 5 ? 256 : 128;
+        if (Cout % bi == 0 && a.K % bj == 0) prog = force;
+    }
+#define WG(BI, BJ, WM, WN, WK, G)                                                                    \
+    hipLaunchKernelGGL((k_conv_wgrad<BI, BJ, WM, WN, WK, G>), dim3(Cout / BI, a.K / BJ, splits),    \
+                       dim3(256), 0, st, a)
+    switch (prog) {
+        case 0: WG(32, 32, 2, 2, 1, 4); break;
+        case 1: WG(16, 32, 1, 2, 2, 4); break;
+        case 2: WG(64, 64, 2, 2, 1, 2); break;
+        case 3: WG(64, 128, 2, 2, 1, 2); break;
+        case 4: WG(32, 128, 1, 4, 1, 2); break;
+        default: WG(32, 256, 1, 4, 1, 2); break;
+    }
+#undef WG
     PFRL_LAUNCH_CHECK();
 }
 
@@ -1532,7 +1581,7 @@ extern "C" int pfrl_conv2d_nhwc_bwd(const float *dy, const float *dy_mask, const
         return rc;
     const int z = stride * stride;
     const int prog = dgrad_program(d, z);
-    PFRL_CHECK_ARG(prog >= 2, "pfrl_conv2d_nhwc_bwd: problem too large for the fused launch");
+    PFRL_CHECK_ARG(prog >= 2 && prog <= 5, "pfrl_conv2d_nhwc_bwd: problem too large for the fused launch");
     hipStream_t st = (hipStream_t)stream;
     const bool w32 = Cout % 32 == 0;
     const int wgx = w32 ? Cout / 32 : Cout / 16, wgy = wa.K / 32;

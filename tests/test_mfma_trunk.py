@@ -117,6 +117,67 @@ def test_conv_kernels_match_torch(geom, B):
 
 
 @gpu
+@pytest.mark.parametrize("geom", [(4, 32, 8, 4, 84), (32, 64, 4, 2, 20), (64, 64, 3, 1, 9), (3136, 512, 1, 1, 1)])
+def test_large_tile_programs_equal_the_minibatch_ones_bit_for_bit(geom, monkeypatch):
+    """The 128-row forward / input-gradient programs and the 64 x 64 ... 32 x 256 weight-gradient
+    programs that update-sized batches select (pfrl_conv2d_nhwc_fwd / _bwd_data / _bwd_weight) walk
+    the reduction in the same order as the 64- and 32-wide ones: forced one after the other through
+    the measurement hook (PFRL_QNET_FWD / _DGRAD / _WGRAD) on a ragged batch (B = 203: the last
+    tile of every program is partial), every output is the same bits; and the small programs are the
+    ones test_conv_kernels_match_torch checks against stock PyTorch."""
+    C, Co, R, ST, H = geom
+    dev = torch.device("cuda:0")
+    B = 203
+    torch.manual_seed(C)
+    OH = (H - R) // ST + 1
+    x = torch.randn(B, H, H, C, device=dev)
+    w = torch.randn(Co, R, R, C, device=dev) * 0.05
+    b = torch.randn(Co, device=dev)
+    dy = torch.randn(B, OH, OH, Co, device=dev)
+    aprev = torch.rand(B, H, H, C, device=dev) - 0.3
+    lib = mt._native.lib()
+    M, K = B * OH * OH, R * R * C
+    nW, stride = w.numel(), w.numel() + Co
+    splits = 3
+
+    def fwd():
+        y = torch.full((B, OH, OH, Co), float("nan"), device=dev)
+        mt.check(lib.pfrl_conv2d_nhwc_fwd(mt._p(x), mt._p(w), mt._p(b), mt._p(y), B, H, H, C, Co, R, R, ST,
+                                          1, 0, 1, mt._stream()), "fwd")
+        return y
+
+    def dgrad():
+        dx = torch.full((B, H, H, C), float("nan"), device=dev)
+        mt.check(lib.pfrl_conv2d_nhwc_bwd_data(mt._p(dy), None, mt._p(w), mt._p(aprev), mt._p(dx), B, H, H, C,
+                                               Co, R, R, ST, 0, 0, mt._stream()), "dgrad")
+        return dx
+
+    def wgrad():
+        part = torch.full((splits * stride,), float("nan"), device=dev)
+        mt.check(lib.pfrl_conv2d_nhwc_bwd_weight(mt._p(dy), None, mt._p(x), mt._p(part), mt._p(part[nW:]),
+                                                 stride, stride, B, H, H, C, Co, R, R, ST, splits,
+                                                 mt._stream()), "wgrad")
+        return part
+
+    wide = Co % 64 == 0
+    cases = [("PFRL_QNET_FWD", fwd, [3, 8] + ([2, 7] if wide else []))]
+    if C % 32 == 0:
+        cases.append(("PFRL_QNET_DGRAD", dgrad, [1, 7] + ([0, 6] if C % 64 == 0 else [])))
+    cases.append(("PFRL_QNET_WGRAD", wgrad, [0] + ([2] if wide and K % 64 == 0 else [])
+                  + ([3] if wide and K % 128 == 0 else []) + ([4] if K % 128 == 0 else [])
+                  + ([5] if K % 256 == 0 else [])))
+    for env, fn, progs in cases:
+        outs = []
+        for prog in progs:
+            monkeypatch.setenv(env, str(prog))
+            outs.append(fn())
+        monkeypatch.delenv(env)
+        assert not torch.isnan(outs[0]).any()
+        for prog, o in zip(progs[1:], outs[1:]):
+            assert torch.equal(o, outs[0]), (env, prog)
+
+
+@gpu
 @pytest.mark.parametrize("B", [32, 7, 256])
 def test_nature_trunk_forward_backward_matches_torch(B):
     dev = torch.device("cuda:0")

@@ -63,12 +63,15 @@ def main():
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--only", default="fwd,dgrad,wgrad")
     ap.add_argument("--layers", default="conv1,conv2,conv3,fc")
+    ap.add_argument("--sweep", action="store_true",
+                    help="every tile program that fits the layer (PFRL_QNET_FWD / _DGRAD / _WGRAD), each "
+                         "checked bit for bit against the round-3 program of the same layer")
     args = ap.parse_args()
     only = set(args.only.split(","))
     lib = _native.lib()
     dev = torch.device("cuda", 0)
     torch.manual_seed(0)
-    print("%-6s %-6s %6s %10s %9s %8s %6s %9s" % ("layer", "dir", "B", "us", "GFLOP", "TF/s", "frac",
+    print("%-6s %-16s %6s %10s %9s %8s %6s %9s" % ("layer", "dir", "B", "us", "GFLOP", "TF/s", "frac",
                                                    "hbm_us"))
     for B in [int(b) for b in args.batches.split(",")]:
         for name, C, Co, R, ST, H in LAYERS:
@@ -86,27 +89,57 @@ def main():
             flop = 2.0 * M * K * Co
             bx, by, bw = x.numel() * 4, y.numel() * 4, w.numel() * 4
             rows = []
-            if "fwd" in only:
-                t = time_us(lambda: check(lib.pfrl_conv2d_nhwc_fwd(
-                    _p(x), _p(w), _p(b), _p(y), B, H, H, C, Co, R, R, ST, 1, 0, 1, _stream()), "fwd"),
-                    args.iters)
-                rows.append(("fwd", t, flop, bx + by + bw))
-            if "dgrad" in only and name != "conv1":
-                t = time_us(lambda: check(lib.pfrl_conv2d_nhwc_bwd_data(
-                    _p(dy), None, _p(w), _p(x), _p(dx), B, H, H, C, Co, R, R, ST, 0, 0, _stream()),
-                    "dgrad"), args.iters)
-                rows.append(("dgrad", t, flop, 2 * bx + by + bw))
-            if "wgrad" in only:
-                splits = wgrad_splits(M, Co, K)
-                stride = w.numel() + Co
-                part = torch.empty(splits * stride, device=dev)
-                t = time_us(lambda: check(lib.pfrl_conv2d_nhwc_bwd_weight(
-                    _p(dy), None, _p(x), _p(part), _p(part[w.numel():]), stride, stride, B, H, H, C, Co,
-                    R, R, ST, splits, _stream()), "wgrad"), args.iters)
-                rows.append(("wgrad/%d" % splits, t, flop, bx + by + splits * stride * 4))
+
+            def run_fwd():
+                check(lib.pfrl_conv2d_nhwc_fwd(_p(x), _p(w), _p(b), _p(y), B, H, H, C, Co, R, R, ST, 1, 0, 1,
+                                               _stream()), "fwd")
+
+            def run_dgrad():
+                check(lib.pfrl_conv2d_nhwc_bwd_data(_p(dy), None, _p(w), _p(x), _p(dx), B, H, H, C, Co, R, R,
+                                                    ST, 0, 0, _stream()), "dgrad")
+
+            splits = wgrad_splits(M, Co, K)
+            stride = w.numel() + Co
+            part = torch.empty(splits * stride, device=dev)
+
+            def run_wgrad():
+                check(lib.pfrl_conv2d_nhwc_bwd_weight(_p(dy), None, _p(x), _p(part), _p(part[w.numel():]),
+                                                      stride, stride, B, H, H, C, Co, R, R, ST, splits,
+                                                      _stream()), "wgrad")
+
+            wide = Co % 64 == 0
+            plans = [("fwd", "PFRL_QNET_FWD", run_fwd, lambda: y, bx + by + bw,
+                      ([2, 7] if wide else []) + [3, 8] if args.sweep else [None]),
+                     ("dgrad", "PFRL_QNET_DGRAD", run_dgrad, lambda: dx, 2 * bx + by + bw,
+                      ([0, 6] if C % 64 == 0 else []) + [1, 7] if args.sweep else [None]),
+                     ("wgrad/%d" % splits, "PFRL_QNET_WGRAD", run_wgrad, lambda: part,
+                      bx + by + splits * stride * 4,
+                      [0] + ([2] if wide and K % 64 == 0 else []) + ([3] if wide and K % 128 == 0 else [])
+                      + ([4] if K % 128 == 0 else []) + ([5] if K % 256 == 0 else [])
+                      if args.sweep else [None])]
+            for d, env, fn, out, nbytes, progs in plans:
+                if d.split("/")[0] not in only or (d == "dgrad" and name == "conv1"):
+                    continue
+                ref = None
+                for prog in progs:
+                    if prog is None:
+                        os.environ.pop(env, None)
+                    else:
+                        os.environ[env] = str(prog)
+                    t = time_us(fn, args.iters)
+                    tag = d if prog is None else "%s#%d" % (d, prog)
+                    if args.sweep:
+                        got = out().clone()
+                        if ref is None:
+                            ref = got
+                        else:
+                            diff = float((got - ref).abs().max())
+                            tag += " ==" if torch.equal(got, ref) else " d=%.1e" % diff
+                    rows.append((tag, t, flop, nbytes))
+                os.environ.pop(env, None)
             for d, t, f, nbytes in rows:
                 tf = f / t * 1e-6
-                print("%-6s %-9s %6d %10.1f %9.2f %8.1f %6.3f %9.1f" % (
+                print("%-6s %-16s %6d %10.1f %9.2f %8.1f %6.3f %9.1f" % (
                     name, d, B, t, f * 1e-9, tf, tf / PEAK_TF, nbytes / HBM_TBS * 1e-6))
             del x, w, y, dy, dx
             torch.cuda.empty_cache()
