@@ -13,6 +13,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_DIR = os.path.join(_HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libpfrl_amd.so")
+# measurement hook (tools/build_variant.sh): another build of the same sources, e.g. other compiler
+# flags, loaded instead of the in-tree library.  Never set by the package, the tests or bench.py.
+_LIB_OVERRIDE = os.environ.get("PFRL_AMD_LIB")
 SOURCES = ["frames.hip", "replay.hip", "sumtree.hip", "rollout.hip", "optim.hip", "tdloss.hip", "bias_act.hip", "noisy.hip", "c51.hip", "dueling.hip", "qnet.hip", "actor.hip", "hostplan.hip"]
 HIPCC_FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
@@ -229,7 +232,7 @@ def lib():
             "pfrl_amd: %s is missing.  The device replay path has no CPU fallback; "
             "run `python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc)." % LIB_PATH
         )
-    L = ctypes.CDLL(LIB_PATH)
+    L = ctypes.CDLL(_LIB_OVERRIDE or LIB_PATH)
     for name, (res, args) in EXPORTS.items():
         fn = getattr(L, name)  # AttributeError if the symbol is not exported
         fn.restype = res

@@ -1282,15 +1282,17 @@ extern "C" int pfrl_conv2d_nhwc_fwd(const float *x, const float *w, const float 
 #define FWD(BM, BN, WM, WN, WK, G)                                                                   \
     hipLaunchKernelGGL((k_conv_fwd<BM, BN, WM, WN, WK, G>),                                          \
                        dim3((a.M + BM - 1) / BM, (Cout + BN - 1) / BN, z), dim3(256), 0, st, a)
-    // Rollout- and update-sized batches (M in the millions of rows): 128-row tiles.  What bounds the
-    // 64-row programs there is the global -> LDS fill (measured: conv1 / conv2 forward and the 32 x 32
-    // weight-gradient program all sit at 6.4-7.5 TB/s of fill whatever their MFMA share), so the lever
-    // is FLOP per filled byte: 128 x 64 is 21.8 against 16 for 64 x 64, 128 x 32 13.1 against 10.9.
+    // Rollout- and update-sized batches (M in the millions of rows).  Measured on MI355X at B = 16384
+    // (tools/layer_bench.py --sweep, profiles/r04_layer_sweep.txt): what separates the programs is the
+    // instruction overhead per MFMA (per-chunk address arithmetic, LDS traffic, barriers: 2.0 VALU per
+    // MFMA for 64 x 64, 3.1 for 64 x 32 by SQ_INSTS_*), not bytes: 128 x 32 beats 64 x 32 for the first
+    // convolution (1241 vs 1436 us), 128 x 64 beats 64 x 64 only for the long reduction of the linear
+    // layer (485 vs 535 us) and loses below ~1000 workgroups.
     const int force = prog_override("PFRL_QNET_FWD");
     int prog;
     if (Cout % 32 != 0) prog = blocks(64, 16) >= 512 ? 0 : 1;        // narrow outputs (16 channels)
-    else if (Cout % 64 == 0 && blocks(128, 64) >= 2048) prog = 7;
-    else if (blocks(128, 32) >= 4096) prog = 8;
+    else if (Cout % 64 == 0 && a.K >= 2048 && blocks(128, 64) >= 1024) prog = 7;
+    else if (Cout % 64 != 0 && blocks(128, 32) >= 16384) prog = 8;
     else if (Cout % 64 == 0 && blocks(64, 64) >= 1024) prog = 2;
     else if (blocks(64, 32) >= 1024) prog = 3;
     else if (blocks(32, 32) >= 384) prog = 4;
@@ -1388,11 +1390,10 @@ static int dgrad_program(const DgradArgs &a, int z) {
     const int C = a.g.C;
     auto blocks = [&](int bm, int bn) { return (long long)((a.Mc + bm - 1) / bm) * (C / bn) * z; };
     if (C % 32 != 0) return 5;
+    // (128-row programs measured SLOWER here at every size -- 188 VGPRs, two waves per SIMD -- and
+    // were dropped: conv2 1580 vs 1343 us, conv3 1036 vs 960 us at B = 16384)
     const int force = prog_override("PFRL_QNET_DGRAD");
-    if (force >= 0 && force != 5 && (C % 64 == 0 || (force != 0 && force != 6))) return force;
-    // 6 = <128,64>, 7 = <128,32>: update-sized batches (see pfrl_conv2d_nhwc_fwd)
-    if (C % 64 == 0 && blocks(128, 64) >= 2048) return 6;
-    if (blocks(128, 32) >= 4096) return 7;
+    if (force >= 0 && force <= 4 && (C % 64 == 0 || force != 0)) return force;
     if (C % 64 == 0 && blocks(64, 64) >= 1024) return 0;
     if (blocks(64, 32) >= 1024) return 1;
     if (blocks(32, 32) >= 384) return 2;
@@ -1420,8 +1421,6 @@ extern "C" int pfrl_conv2d_nhwc_bwd_data(const float *dy, const float *dy_mask, 
         case 2: DG(32, 32, 2, 2, 1, 4); break;
         case 3: DG(16, 32, 1, 2, 2, 8); break;
         case 4: DG(16, 32, 1, 2, 2, 4); break;
-        case 6: DG(128, 64, 2, 2, 1, 2); break;
-        case 7: DG(128, 32, 4, 1, 1, 2); break;
         default: DG(32, 16, 2, 1, 2, 4); break;
     }
 #undef DG
@@ -1438,12 +1437,18 @@ extern "C" int pfrl_conv2d_nhwc_bwd_weight(const float *dy, const float *dy_mask
                                  Cout, R, S, stride, splits))
         return rc;
     hipStream_t st = (hipStream_t)stream;
-    // Long reductions (update-sized batches: thousands of chunks per split): large output tiles, for
-    // FLOP per filled byte (32 x 32 is 8, 64 x 128 is 21.8, 32 x 256 14.2) -- see pfrl_conv2d_nhwc_fwd.
+    // From a few thousand rows up: large output tiles.  A 32 x 32 tile is ONE MFMA tile per wave, so
+    // every chunk's loads, address arithmetic, LDS traffic and barriers are paid per 8 MFMAs (6.2 VALU
+    // instructions per MFMA by SQ_INSTS_*); 64 x 128 is eight tiles per wave.  Measured (tools/
+    // layer_bench.py --sweep): conv1 2062 -> 1290 us (32 x 256), conv2 1358 -> 934 (64 x 128), conv3
+    // 844 -> 669 (64 x 64), linear 670 -> 552 at B = 16384; also ahead at B = 512 and 2048.  The
+    // minibatch-sized launches of the replay agents (M < 16384 rows) keep the 32 x 32 program and with
+    // it their bit-identity tests; the large programs sum in a different order (one accumulator
+    // instead of two interleaved ones).
     // 0 = <32,32,G4>, 1 = <16,32,G4>, 2 = <64,64>, 3 = <64,128>, 4 = <32,128>, 5 = <32,256>
     int prog = Cout % 32 == 0 ? 0 : 1;
-    if (a.cps >= 64 && Cout % 32 == 0) {
-        if (Cout % 64 == 0 && a.K % 128 == 0) prog = 3;
+    if (a.M >= 16384 && Cout % 32 == 0) {
+        if (Cout % 64 == 0 && a.K % 128 == 0 && a.cps >= 64) prog = 3;
         else if (Cout % 64 == 0 && a.K % 64 == 0) prog = 2;
         else if (a.K % 256 == 0) prog = 5;
         else if (a.K % 128 == 0) prog = 4;
