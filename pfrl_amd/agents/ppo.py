@@ -66,6 +66,24 @@ def _yield_minibatch_positions(n, minibatch_size, num_epochs):
         buf = buf[:-minibatch_size]
 
 
+def _all_minibatch_positions(n, minibatch_size, num_epochs):
+    """Every minibatch of :func:`_yield_minibatch_positions` at once, as int64 arrays: the same
+    ``random.sample`` draws in the same order (nothing else consumes Python's ``random`` during
+    an update), made before the loop instead of inside it -- while the value pass runs on the
+    device -- and kept as arrays: converting a 16 384-element Python list per minibatch was
+    0.7 ms of host time in front of every update (profiles/r04_ppo_trace_summary.txt)."""
+    out = []
+    buf = np.zeros(0, dtype=np.int64)
+    done = 0
+    while done < n * num_epochs:
+        while len(buf) < minibatch_size:
+            buf = np.concatenate([np.asarray(random.sample(range(n), k=n), dtype=np.int64), buf])
+        out.append(buf[len(buf) - minibatch_size:])
+        done += minibatch_size
+        buf = buf[:len(buf) - minibatch_size]
+    return out
+
+
 class _Rollout:
     """T x N on-device rollout (env index minor)."""
 
@@ -138,6 +156,74 @@ class _Rollout:
         self.min_seq = None
 
 
+class _ActGraph:
+    """The device side of ``batch_act`` during a rollout -- observation gather, network, sampling,
+    entropy -- as ONE captured HIP graph per batch shape (reference ppo.py:759-778).
+
+    A rollout step launches ~45 small kernels through the dispatcher (torch.distributions builds
+    a Categorical, normalises logits, samples, takes the entropy: ~0.74 ms of host time per step
+    for ~0.25 ms of device time, profiles/r04_ppo_trace_summary.txt: 100 ms of launch gaps per
+    330 ms rollout).  Replayed, the step costs the host one small copy and one hipGraphLaunch.
+    The graph reads the frame ring, the parameters and the normaliser statistics in place, so
+    optimizer steps and new frames need no re-capture; sampling draws from the default generator
+    through PyTorch's graph-safe Philox offsets (each replay advances the stream)."""
+
+    def __init__(self, agent):
+        self.agent = agent
+        self.entries = {}
+        self.pool = None
+
+    def applicable(self):
+        ag = self.agent
+        return (os.environ.get("PFRL_PPO_ACT_GRAPH", "1") != "0" and ag.device.type == "cuda"
+                and type(ag)._sample_action is PPO._sample_action
+                and "_sample_action" not in ag.__dict__)
+
+    def _body(self, refs):
+        ag = self.agent
+        b_state = ag._features(refs)
+        with torch.no_grad(), evaluating(ag.model):
+            distrib, value = ag.model(b_state)
+            action = distrib.sample()
+            stats = torch.stack([distrib.entropy().reshape(-1).float(),
+                                 value.reshape(-1).float()])
+        return action, stats
+
+    def _capture(self, refs_dev):
+        from pfrl_amd.agents.graphed_update import _capturing, _no_distribution_validation
+
+        dev = self.agent.device
+        refs = refs_dev.clone()
+        rng = torch.cuda.get_rng_state(dev)
+        cur = torch.cuda.current_stream(dev)
+        side = torch.cuda.Stream(dev)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side), _no_distribution_validation():
+            for _ in range(2):
+                self._body(refs)
+        cur.wait_stream(side)
+        torch.cuda.set_rng_state(rng, dev)      # the warm-up draws are not part of the run
+        g = torch.cuda.CUDAGraph()
+        with ops.profile_paused(), _capturing(g, self.pool), _no_distribution_validation():
+            action, stats = self._body(refs)
+        if self.pool is None:
+            self.pool = g.pool()
+        return g, refs, action, stats
+
+    def run(self, refs_dev):
+        """(actions [N], stats [2, N] = entropy, value): tensors OWNED BY THE GRAPH, overwritten by
+        the next replay -- callers copy what they keep."""
+        key = (tuple(refs_dev.shape), id(self.agent.model), self.agent.frames.emit_channels_last
+               if self.agent.frames is not None else None)
+        e = self.entries.get(key)
+        if e is None:
+            e = self.entries[key] = self._capture(refs_dev)
+        g, refs, action, stats = e
+        refs.copy_(refs_dev)
+        g.replay()
+        return action, stats
+
+
 class PPO(agent.AttributeSavingMixin, agent.BatchAgent):
     """Proximal Policy Optimization (arguments as in the reference)."""
 
@@ -191,6 +277,7 @@ class PPO(agent.AttributeSavingMixin, agent.BatchAgent):
         self.logger = getLogger(__name__)
 
         self.rollout = None
+        self._act_graph = None
         self.device_actions = os.environ.get("PFRL_DEVICE_STEP", "1") != "0"
         self._last_action_dev = None
         self.ingest = None         # DeviceReplayStore used for host-observation ingestion
@@ -297,12 +384,23 @@ class PPO(agent.AttributeSavingMixin, agent.BatchAgent):
         refs, dev_batch = self._refs_of(batch_obs)
         self._sample_obs = dev_batch[0]
         (refs_dev,) = self._stage.upload([refs])
-        b_state = self._features(refs_dev)
-        with torch.no_grad(), evaluating(self.model):
-            action_distrib, batch_value = self.model(b_state)
-            action_dev = self._sample_action(action_distrib)
-            self.entropy_record.extend(action_distrib.entropy())
-            self.value_record.extend(batch_value)
+        if self._act_graph is None:
+            self._act_graph = _ActGraph(self)
+        if (isinstance(batch_obs, DeviceObsBatch) and self.device_actions
+                and self._act_graph.applicable()):
+            # device env: nothing of this step is looked at on the host -- one graph replay
+            action_dev, stats = self._act_graph.run(refs_dev)
+            action_dev = action_dev.clone()
+            stats = stats.clone()
+            self.entropy_record.extend(stats[0])
+            self.value_record.extend(stats[1])
+        else:
+            b_state = self._features(refs_dev)
+            with torch.no_grad(), evaluating(self.model):
+                action_distrib, batch_value = self.model(b_state)
+                action_dev = self._sample_action(action_distrib)
+                self.entropy_record.extend(action_distrib.entropy())
+                self.value_record.extend(batch_value)
         self._last_refs = refs.copy()
         self._last_min_seq = int(np.min(dev_batch.min_seq))
         self.batch_last_state = list(range(len(batch_obs)))
@@ -463,6 +561,9 @@ class PPO(agent.AttributeSavingMixin, agent.BatchAgent):
             # the action column never left the device
             actions = ro.d_action[:T].reshape((T * N,) + tuple(ro.d_action.shape[2:])).clone()
         log_probs, v_pred = self._value_pass(s_refs, actions)
+        # (host work under the value pass the device is still running)
+        minibatches = [order[pos] for pos in
+                       _all_minibatch_positions(n, self.minibatch_size, self.epochs)]
         if self.reuse_next_values:
             next_v = self._next_values_from_states(ro, T, N, v_pred, n_refs)
         else:
@@ -487,8 +588,7 @@ class PPO(agent.AttributeSavingMixin, agent.BatchAgent):
         self._last_dataset = dict(order=order, adv=adv, v_teacher=v_teacher, v_pred=v_pred,
                                   log_prob=log_probs, mean_std=mean_std)
 
-        for pos in _yield_minibatch_positions(n, self.minibatch_size, self.epochs):
-            flat = order[np.asarray(pos, dtype=np.int64)]
+        for flat in minibatches:
             (idx,) = self._stage.upload([flat])
             if actions_i64 is not None:
                 mb = ops.ppo_minibatch(idx, adv, mean_std, self.standardize_advantages, log_probs,

@@ -262,6 +262,33 @@ def flush_fwd_folds(sink):
     sink.clear()
 
 
+# Rollout- and update-sized batches: the last convolution writes plain NHWC rows and the linear layer
+# reads them through a copy of its weight with the columns re-ordered (c, p) -> (p, c), instead of
+# the planar (NCHW) output / planar -> NHWC input gradient of the minibatch route.  Planar stores
+# and the permuted input-gradient stores are 4-byte accesses 196 B / 256 B apart: 51 M of them per
+# launch at B = 16384 (PPO's minibatch), where they -- not the MFMAs -- set the launch time.  The
+# re-ordered weight is 6.4 MB, cached per weight version (the parameters change 16 times per rollout,
+# the trunk runs ~170 times), the weight gradient is re-ordered back by one copy.  Never inside a
+# stream capture (a cached copy would be baked into the graph) and not for the replay agents'
+# minibatches, whose bit-identity tests pin the planar route.
+_NHWC_FC_MIN_BATCH = int(os.environ.get("PFRL_TRUNK_NHWC_FC_MIN_BATCH", "1024"))
+_WP_CACHE = {}
+
+
+def _reordered_weight(wf, C, P):
+    """wf [F, C * P] with columns (c, p) -> [F, P * C] with columns (p, c)."""
+    key = wf.data_ptr()
+    hit = _WP_CACHE.get(key)
+    if hit is not None and hit[0] == wf._version and hit[1].shape == wf.shape:
+        return hit[1]
+    F = wf.shape[0]
+    wp = wf.detach().view(F, C, P).transpose(1, 2).contiguous().view(F, P * C)
+    if len(_WP_CACHE) > 8:
+        _WP_CACHE.clear()
+    _WP_CACHE[key] = (wf._version, wp)
+    return wp
+
+
 class _Trunk(torch.autograd.Function):
     """h = relu(linear(flatten(relu(conv_L(... relu(conv_1(x))))))) as one autograd node."""
 
@@ -273,18 +300,27 @@ class _Trunk(torch.autograd.Function):
         L = len(specs)
         acts = []
         h = x
+        nhwc_fc = (len(params) > 2 * L and 0 < _NHWC_FC_MIN_BATCH <= N
+                   and not torch.cuda.is_current_stream_capturing())
         for i, sp in enumerate(specs):
-            h = conv_fwd(h, params[2 * i], params[2 * i + 1], sp, N, relu=True, planar=(i == L - 1))
+            h = conv_fwd(h, params[2 * i], params[2 * i + 1], sp, N, relu=True,
+                         planar=(i == L - 1 and not nhwc_fc))
             acts.append(h)
+        wp = None
         if len(params) == 2 * L:
             # convolutions only: the planar (NCHW) output of the last one, as [N, Cout, OH, OW]
             out = h.view(N, specs[-1].Cout, specs[-1].OH, specs[-1].OW)
         else:
             wf, bf = params[2 * L], params[2 * L + 1]
-            out = linear_fwd(h.view(N, -1), wf, bf, relu=True)
+            if nhwc_fc:
+                wp = _reordered_weight(wf, specs[-1].Cout, specs[-1].OH * specs[-1].OW)
+                out = linear_fwd(h.view(N, -1), wp, bf, relu=True)
+            else:
+                out = linear_fwd(h.view(N, -1), wf, bf, relu=True)
         if any(ctx.needs_input_grad[2:]):
             ctx.specs = specs
-            ctx.save_for_backward(x, out, *acts, *params)
+            ctx.nhwc_fc = nhwc_fc
+            ctx.save_for_backward(x, out, *acts, *params, *([wp] if nhwc_fc else []))
         return out
 
     @staticmethod
@@ -295,6 +331,9 @@ class _Trunk(torch.autograd.Function):
         x, out = saved[0], saved[1]
         acts = saved[2:2 + L]
         params = saved[2 + L:]
+        nhwc_fc = getattr(ctx, "nhwc_fc", False)
+        if nhwc_fc:
+            params, wp = params[:-1], params[-1]
         N = x.shape[0]
         lib = _native.lib()
         dev = x.device
@@ -312,6 +351,24 @@ class _Trunk(torch.autograd.Function):
         # hidden linear layer: input gradient straight into NHWC rows of the last conv, and
         # the weight gradient, in one launch when the batch is minibatch-sized
         dy = torch.empty((N, last.OH, last.OW, last.Cout), dtype=torch.float32, device=dev)
+        if nhwc_fc:
+            # everything in (p, c) column order: plain NHWC rows in, NHWC rows out, the mask of the
+            # convolution below read where the gradient is written; the weight gradient goes back
+            # to the parameter's (c, p) order with one copy
+            check(lib.pfrl_conv2d_nhwc_bwd_data(_p(dh), _p(out), _p(wp), _p(acts[-1]), _p(dy), N, 1, 1,
+                                                Kf, F, 1, 1, 1, 0, 0, _stream()), "linear_bwd_data")
+            dwp = torch.empty_like(wp)
+            dbf = torch.empty(F, dtype=torch.float32, device=dev)
+            check(lib.pfrl_conv2d_nhwc_bwd_weight(_p(dh), _p(out), _p(acts[-1]), _p(dwp), _p(dbf), 0, 0,
+                                                  N, 1, 1, Kf, F, 1, 1, 1, 1, _stream()),
+                  "linear_bwd_weight")
+            dwf = dwp.view(F, P, last.Cout).transpose(1, 2).contiguous().view(F, Kf)
+            if _dist_initialized():
+                from pfrl_amd.distributed import announce_grad
+
+                announce_grad(wf, dwf)
+            grads = [None] * (2 * L) + [dwf, dbf]
+            return _Trunk._conv_backward(ctx, specs, params, acts, x, dy, N, dev, grads)
         if OPT_SOURCES is not None and _LOWRANK and _lowrank_ok(N, F, Kf, wf):
             # the optimizer forms dW = dh^T x itself, tile by tile, and applies it from the
             # accumulators (csrc/optim.hip): only the input gradient is computed here

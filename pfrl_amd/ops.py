@@ -136,9 +136,27 @@ def entries_append(desc, e_slots, tids, lens):
                                             _ptr(tids), _ptr(lens), _stream()), "entries_append")
 
 
+_PROFILE_ON = [False]
+
+
 def profile_enable(on):
     """Attach a hipEvent pair to every fused-gather dispatch (bench.py roofline)."""
     check(_native.lib().pfrl_profile_enable(int(bool(on))), "profile_enable")
+    _PROFILE_ON[0] = bool(on)
+
+
+class profile_paused:
+    """No event pairs while a stream capture records launches (events created inside a capture
+    would belong to the capture, and a replay never signals them)."""
+
+    def __enter__(self):
+        self.was = _PROFILE_ON[0]
+        if self.was:
+            profile_enable(False)
+
+    def __exit__(self, *exc):
+        if self.was:
+            profile_enable(True)
 
 
 PROFILE_BATCH_EXPERIENCES = 0

@@ -322,3 +322,43 @@ def test_ppo_bench_path_gae_and_advantage_statistics_match_oracle(monkeypatch):
     flat, (mean, std) = seen["stats"]
     wm, ws = oracle.adv_stats(flat)
     assert abs(mean - wm) <= 1e-6 * max(1.0, abs(wm)) and abs(std - ws) <= 1e-6 * max(1.0, abs(ws))
+
+
+def test_ppo_act_graph_equals_the_eager_act_path(monkeypatch):
+    """The rollout's ``batch_act`` as one captured graph (agents/ppo.py::_ActGraph) against the
+    eager launches it replaces, on the bench agent: entropy and value bit for bit, actions inside
+    the action set, drawn anew on every replay (the generator advances) and distributed like the
+    policy's probabilities; the rollout built from graph steps trains (an update runs)."""
+    import bench
+    from pfrl_amd.agents.ppo import _ActGraph
+    from pfrl_amd.utils.contexts import evaluating
+
+    dev = torch.device("cuda:0")
+    N = 512
+    args = _bench_args(algo="ppo", num_envs=N)
+    agent, env, _ = bench.build_agent(args, dev, 0)
+    obss = env.reset()
+    for _ in range(3):
+        obss = bench.one_step(agent, env, obss, N)
+    assert agent._act_graph is not None and agent._act_graph.entries, "the graph path was not taken"
+    refs_dev = torch.as_tensor(obss.refs, device=dev)
+    with torch.no_grad(), evaluating(agent.model):
+        distrib, value = agent.model(agent._features(refs_dev))
+        want_entropy, want_value = distrib.entropy().float(), value.reshape(-1).float()
+        probs = distrib.probs.double().mean(dim=0).cpu().numpy()
+    counts = np.zeros(probs.shape[0])
+    prev = None
+    for i in range(40):
+        action, stats = agent._act_graph.run(refs_dev)
+        a = action.clone()
+        assert torch.equal(stats[0], want_entropy) and torch.equal(stats[1], want_value)
+        assert int(a.min()) >= 0 and int(a.max()) < probs.shape[0]
+        if prev is not None:
+            assert not torch.equal(a, prev)
+        prev = a
+        counts += np.bincount(a.cpu().numpy(), minlength=probs.shape[0])
+    freq = counts / counts.sum()
+    assert np.abs(freq - probs).max() < 0.02, (freq, probs)     # 20 480 draws
+    # a subclass / instance that overrides the sampling hook keeps the eager path
+    monkeypatch.setattr(agent, "_sample_action", lambda d: d.sample(), raising=False)
+    assert not _ActGraph(agent).applicable()

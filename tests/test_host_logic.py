@@ -271,3 +271,20 @@ def test_sample_n_k_equals_the_reference_walk_including_the_stream_position():
             got = sample_n_k(n, k)
             pos = np.random.randint(1 << 30)
             assert np.array_equal(got, want) and pos == pos_ref, (n, k, seed)
+
+
+def test_ppo_minibatch_positions_drawn_up_front_consume_the_same_random_stream():
+    """PPO's minibatch order comes from Python's ``random`` (reference ppo.py:247-257).  The device
+    path draws every minibatch of an update before its loop (under the value pass) and keeps them
+    as arrays: same positions, same stream position afterwards."""
+    import random
+
+    from pfrl_amd.agents.ppo import _all_minibatch_positions, _yield_minibatch_positions
+
+    for n, mb, ep in [(100, 32, 3), (64, 64, 2), (65, 16, 4), (10, 3, 5), (2048, 512, 4)]:
+        random.seed(5)
+        a = [list(x) for x in _yield_minibatch_positions(n, mb, ep)]
+        sa = random.getstate()
+        random.seed(5)
+        b = [[int(v) for v in x] for x in _all_minibatch_positions(n, mb, ep)]
+        assert a == b and sa == random.getstate(), (n, mb, ep)
