@@ -516,7 +516,14 @@ struct DgradArgs {
     FastDiv q_ahw, q_aw, q_st, q_permP;   // by AH * AW, AW, ST, permP
 };
 
-template <int BM, int BN, int WM, int WN, int WK, int G>
+// MERGE: the ST x ST stride-parity classes of a strided convolution side by side in the tile's
+// columns (column n = class * C + ci, BN a multiple of C) instead of one class per grid.z slice.
+// Every class of an input cell (a, a2) reads the SAME dy taps -- only the weight slice differs --
+// so the dy tile (the operand that streams from memory; the weights are cache resident) is loaded
+// and parked once for 2 or 4 classes: the second convolution's input gradient (C = 32, four
+// classes) becomes a 64- or 128-column problem instead of four 32-column ones.  Same terms in the
+// same order per element: bit-identical to the per-class launch.
+template <int BM, int BN, int WM, int WN, int WK, int G, bool MERGE = false>
 __device__ __forceinline__ void dgrad_body(const DgradArgs &p, const int bx, const int by,
                                            const int bz, float *smem) {
     static_assert(WM * WN * WK == 4 && WK <= 2, "four waves");
@@ -534,7 +541,7 @@ __device__ __forceinline__ void dgrad_body(const DgradArgs &p, const int bx, con
     const int wk = wave % WK, wn = (wave / WK) % WN, wm = wave / (WK * WN);
     const int m0 = bx * BM, n0 = by * BN;
     const ConvGeom g = p.g;
-    const int ph = fdiv(bz, p.q_st), pw = bz - ph * g.ST;
+    const int ph = fdiv(bz, p.q_st), pw = bz - ph * g.ST;     // (per workgroup; MERGE: per column)
     const int ahw = p.AH * p.AW;
 
     // per-thread part of the dy address (tap (0, 0), first output channel) and of the weight address;
@@ -562,7 +569,16 @@ __device__ __forceinline__ void dgrad_body(const DgradArgs &p, const int bx, con
         const int f = tid + 256 * pp;
         bkk[pp] = f / QPR;
         bq4[pp] = 4 * (f - bkk[pp] * QPR);
-        bbase[pp] = (size_t)bkk[pp] * g.R * g.S * g.C + n0 + bq4[pp];
+        if (MERGE) {
+            // column -> (class, input channel): the class's (ph, pw) shift of the kernel position
+            // is a per-thread constant of the weight address
+            const int col = n0 + bq4[pp];
+            const int cls = col / g.C, ci = col - cls * g.C;
+            const int cph = cls / g.ST, cpw = cls - cph * g.ST;
+            bbase[pp] = (size_t)bkk[pp] * g.R * g.S * g.C + (size_t)(cph * g.S + cpw) * g.C + ci;
+        } else {
+            bbase[pp] = (size_t)bkk[pp] * g.R * g.S * g.C + n0 + bq4[pp];
+        }
     }
     struct Slot {
         float4 a[NPA], h[NPA], b[NPB];
@@ -599,7 +615,7 @@ __device__ __forceinline__ void dgrad_body(const DgradArgs &p, const int bx, con
             if (has_mask) sl.h[pp] = ldg4(p.dymask + off);
             sl.ok[pp] = ok;
         }
-        const int r = f_tb * g.ST + ph, s = f_tb2 * g.ST + pw;
+        const int r = f_tb * g.ST + (MERGE ? 0 : ph), s = f_tb2 * g.ST + (MERGE ? 0 : pw);
         const size_t bdelta = ((size_t)(f_co0 * g.R + r) * g.S + s) * g.C;
 #pragma unroll
         for (int pp = 0; pp < NPB; ++pp)
@@ -637,13 +653,13 @@ __device__ __forceinline__ void dgrad_body(const DgradArgs &p, const int bx, con
     };
     run_pipeline<Slot, G>(0, p.K / KC, fetch, stash, compute);
     fold_acc<AM, AN, P, WK, WM * WN>(acc, red, wm * WN + wn, wk, lane);
-    if (p.permP == 0 && n0 + BN <= g.C && (g.C & 3) == 0) {
+    if (p.permP == 0 && (MERGE || n0 + BN <= g.C) && (g.C & 3) == 0) {
         // NHWC rows of a tile inside the channel range: through LDS (the A chunk buffers are free),
         // so that a thread masks and stores a float4 of one row and the row -> (image, ih, iw) split
         // runs once per 16 bytes instead of once per element
         constexpr int LDT = BN + 4;
-        static_assert(BM * LDT <= G * BM * LDR, "the tile fits in the A chunk buffers");
-        float *tile = &As[0][0];
+        static_assert(BM * LDT <= G * BM * LDR + G * 32 * LDB, "the tile fits in the chunk buffers");
+        float *tile = &As[0][0];      // (A buffers, running on into the B buffers behind them)
         __syncthreads();
         if (wk == 0) {
 #pragma unroll
@@ -664,8 +680,15 @@ __device__ __forceinline__ void dgrad_body(const DgradArgs &p, const int bx, con
             if (m >= p.Mc) continue;
             const int n = fdiv(m, p.q_ahw), rem = m - n * ahw;
             const int a = fdiv(rem, p.q_aw), a2 = rem - a * p.AW;
-            const int ih = a * g.ST + ph, iw = a2 * g.ST + pw;
-            const size_t o = ((size_t)(n * g.H + ih) * g.W + iw) * g.C + n0 + c4;
+            int eph = ph, epw = pw, ec = n0 + c4;
+            if (MERGE) {
+                const int cls = ec / g.C;
+                ec -= cls * g.C;
+                eph = cls / g.ST;
+                epw = cls - eph * g.ST;
+            }
+            const int ih = a * g.ST + eph, iw = a2 * g.ST + epw;
+            const size_t o = ((size_t)(n * g.H + ih) * g.W + iw) * g.C + ec;
             float4 v = *reinterpret_cast<const float4 *>(&tile[row * LDT + c4]);
             if (p.aprev != nullptr) v = relu_mask(v, *reinterpret_cast<const float4 *>(p.aprev + o));
             *reinterpret_cast<float4 *>(p.dx + o) = v;
@@ -711,10 +734,10 @@ constexpr int wgrad_smem(int BI, int BJ, int WM, int WN, int WK, int G) {
 }
 constexpr int cmax(int a, int b) { return a > b ? a : b; }
 
-template <int BM, int BN, int WM, int WN, int WK, int G>
+template <int BM, int BN, int WM, int WN, int WK, int G, bool MERGE = false>
 __global__ __launch_bounds__(256) void k_conv_dgrad(DgradArgs p) {
     __shared__ __attribute__((aligned(16))) float smem[dgrad_smem(BM, BN, WM, WN, WK, G)];
-    dgrad_body<BM, BN, WM, WN, WK, G>(p, blockIdx.x, blockIdx.y, blockIdx.z, smem);
+    dgrad_body<BM, BN, WM, WN, WK, G, MERGE>(p, blockIdx.x, blockIdx.y, blockIdx.z, smem);
 }
 
 template <int BM, int BN, int WM, int WN, int WK, int G>
@@ -1393,7 +1416,13 @@ static int dgrad_program(const DgradArgs &a, int z) {
     // (128-row programs measured SLOWER here at every size -- 188 VGPRs, two waves per SIMD -- and
     // were dropped: conv2 1580 vs 1343 us, conv3 1036 vs 960 us at B = 16384)
     const int force = prog_override("PFRL_QNET_DGRAD");
+    const int st = a.g.ST, ncol = st * st * C;
+    // 6 = <64,64,MERGE>, 7 = <64,128,MERGE>: the parity classes of a strided layer in one tile
+    const bool merge64 = st > 1 && 64 % C == 0 && ncol % 64 == 0;
+    const bool merge128 = st > 1 && 128 % C == 0 && ncol % 128 == 0;
     if (force >= 0 && force <= 4 && (C % 64 == 0 || force != 0)) return force;
+    if ((force == 6 && merge64) || (force == 7 && merge128)) return force;
+    if (force < 0 && merge64 && (long long)((a.Mc + 63) / 64) * (ncol / 64) >= 2048) return merge128 ? 7 : 6;
     if (C % 64 == 0 && blocks(64, 64) >= 1024) return 0;
     if (blocks(64, 32) >= 1024) return 1;
     if (blocks(32, 32) >= 384) return 2;
@@ -1415,7 +1444,12 @@ extern "C" int pfrl_conv2d_nhwc_bwd_data(const float *dy, const float *dy_mask, 
 #define DG(BM, BN, WM, WN, WK, G)                                                                    \
     hipLaunchKernelGGL((k_conv_dgrad<BM, BN, WM, WN, WK, G>), dim3((a.Mc + BM - 1) / BM, C / BN, z), \
                        dim3(256), 0, st, a)
+#define DGM(BM, BN, WM, WN, WK, G)                                                                   \
+    hipLaunchKernelGGL((k_conv_dgrad<BM, BN, WM, WN, WK, G, true>),                                  \
+                       dim3((a.Mc + BM - 1) / BM, (z * C) / BN, 1), dim3(256), 0, st, a)
     switch (dgrad_program(a, (int)z)) {
+        case 6: DGM(64, 64, 2, 2, 1, 2); break;
+        case 7: DGM(64, 128, 2, 2, 1, 2); break;
         case 0: DG(64, 64, 2, 2, 1, 2); break;
         case 1: DG(64, 32, 2, 2, 1, 2); break;
         case 2: DG(32, 32, 2, 2, 1, 4); break;
@@ -1423,6 +1457,7 @@ extern "C" int pfrl_conv2d_nhwc_bwd_data(const float *dy, const float *dy_mask, 
         case 4: DG(16, 32, 1, 2, 2, 4); break;
         default: DG(32, 16, 2, 1, 2, 4); break;
     }
+#undef DGM
 #undef DG
     PFRL_LAUNCH_CHECK();
 }
