@@ -588,8 +588,22 @@ class PPO(agent.AttributeSavingMixin, agent.BatchAgent):
         self._last_dataset = dict(order=order, adv=adv, v_teacher=v_teacher, v_pred=v_pred,
                                   log_prob=log_probs, mean_std=mean_std)
 
+        captured = self._captured_update_ok(n, actions_i64)
+        if captured:
+            cols = self._static_columns(adv, mean_std, log_probs, v_pred, v_teacher, actions_i64,
+                                        s_refs)
         for flat in minibatches:
             (idx,) = self._stage.upload([flat])
+            if captured:
+                # one graph replay per minibatch: gather, forward, loss, backward, clip, Adam --
+                # the ~100 small launches of the heads and the loss no longer wait for the
+                # dispatcher (1.8 ms -> 0.45 ms of a 12 ms update, profiles/r04_ppo_update_timeline.txt)
+                cols["idx"].copy_(idx)
+                out = self._update_graph.run({"idx": cols["idx"]})
+                self.value_loss_record.extend(out["value_loss"].clone())
+                self.policy_loss_record.extend(out["policy_loss"].clone())
+                self.n_updates += 1
+                continue
             if actions_i64 is not None:
                 mb = ops.ppo_minibatch(idx, adv, mean_std, self.standardize_advantages, log_probs,
                                        v_pred, v_teacher, actions_i64, s_refs)
@@ -618,13 +632,70 @@ class PPO(agent.AttributeSavingMixin, agent.BatchAgent):
             ev = 1 - torch.var(v_teacher - v_pred, unbiased=False) / vart
             self.explained_variance = float("nan") if float(vart) == 0 else float(ev)
 
+    # -- one minibatch update as one captured graph -------------------------------------------
+    _update_graph = None
+    _static_cols = None
+
+    def _captured_update_ok(self, n, actions_i64):
+        """Discrete actions, one process, a stock ``_lossfun``: the minibatch update is a fixed
+        launch sequence on fixed-size tensors and can be replayed from a HIP graph."""
+        from pfrl_amd import distributed
+
+        return (os.environ.get("PFRL_PPO_UPDATE_GRAPH", "1") != "0" and self.device.type == "cuda"
+                and actions_i64 is not None and distributed.world_size() == 1
+                and n % self.minibatch_size == 0
+                and type(self)._lossfun is PPO._lossfun and "_lossfun" not in self.__dict__)
+
+    def _static_columns(self, adv, mean_std, log_probs, v_pred, v_teacher, actions_i64, s_refs):
+        """The rollout's columns in buffers that keep their addresses from rollout to rollout
+        (what the captured update reads), refreshed with one copy each per rollout."""
+        src = dict(adv=adv, mean_std=mean_std, log_prob=log_probs, v_pred=v_pred,
+                   v_teacher=v_teacher, action=actions_i64, s_refs=s_refs)
+        cols = self._static_cols
+        if cols is None or any(cols[k].shape != v.shape or cols[k].dtype != v.dtype
+                               for k, v in src.items()):
+            cols = self._static_cols = {k: torch.empty_like(v) for k, v in src.items()}
+            cols["idx"] = torch.empty(self.minibatch_size, dtype=torch.int64, device=self.device)
+            self._update_graph = None
+        for k, v in src.items():
+            cols[k].copy_(v)
+        if self._update_graph is None:
+            from pfrl_amd.agents.graphed_update import CapturedStep
+
+            self._update_graph = CapturedStep(self._minibatch_step, [self.model], [self.optimizer],
+                                              self.device)
+        return cols
+
+    def _minibatch_step(self, batch):
+        """reference ppo.py:480-532 for one minibatch, on the static columns."""
+        c = self._static_cols
+        with ops.profile_paused():
+            mb = ops.ppo_minibatch(batch["idx"], c["adv"], c["mean_std"], self.standardize_advantages,
+                                   c["log_prob"], c["v_pred"], c["v_teacher"], c["action"],
+                                   c["s_refs"])
+            states = self._features(mb["refs"])
+        distribs, vs_pred = self.model(states)
+        self.optimizer.zero_grad(set_to_none=True)
+        records = {}
+        loss = self._lossfun(
+            distribs.entropy(), vs_pred, distribs.log_prob(mb["action"]),
+            vs_pred_old=mb["v_pred"][..., None], log_probs_old=mb["log_prob"],
+            advs=mb["adv"], vs_teacher=mb["v_teacher"][..., None], records=records)
+        loss.backward()
+        if self.max_grad_norm is not None:
+            torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.max_grad_norm)
+        self.optimizer.step()
+        return {"loss": loss.detach(), "value_loss": records["value_loss"].detach(),
+                "policy_loss": records["policy_loss"].detach()}
+
     @staticmethod
     def _cut_with_rollout_end(ro, T):
         cut = ro.h_cut[:T].copy()
         cut[T - 1] = 1   # unfinished fragments end with the rollout (reference :450-458)
         return cut
 
-    def _lossfun(self, entropy, vs_pred, log_probs, vs_pred_old, log_probs_old, advs, vs_teacher):
+    def _lossfun(self, entropy, vs_pred, log_probs, vs_pred_old, log_probs_old, advs, vs_teacher,
+                 records=None):
         prob_ratio = torch.exp(log_probs - log_probs_old)
         loss_policy = -torch.mean(torch.min(
             prob_ratio * advs,
@@ -638,8 +709,12 @@ class PPO(agent.AttributeSavingMixin, agent.BatchAgent):
                 F.mse_loss(vs_pred, vs_teacher, reduction="none"),
                 F.mse_loss(clipped_vs_pred, vs_teacher, reduction="none")))
         loss_entropy = -torch.mean(entropy)
-        self.value_loss_record.extend(loss_value_func)
-        self.policy_loss_record.extend(loss_policy)
+        if records is None:
+            self.value_loss_record.extend(loss_value_func)
+            self.policy_loss_record.extend(loss_policy)
+        else:
+            # (a captured update: the tensors belong to the graph, the caller records copies)
+            records["value_loss"], records["policy_loss"] = loss_value_func, loss_policy
         return (loss_policy + self.value_func_coef * loss_value_func
                 + self.entropy_coef * loss_entropy)
 

@@ -1483,7 +1483,7 @@ extern "C" int pfrl_conv2d_nhwc_bwd_weight(const float *dy, const float *dy_mask
     // 0 = <32,32,G4>, 1 = <16,32,G4>, 2 = <64,64>, 3 = <64,128>, 4 = <32,128>, 5 = <32,256>
     int prog = Cout % 32 == 0 ? 0 : 1;
     if (a.M >= 16384 && Cout % 32 == 0) {
-        if (Cout % 64 == 0 && a.K % 128 == 0 && a.cps >= 64) prog = 3;
+        if (Cout % 64 == 0 && a.K % 128 == 0 && a.M >= 262144) prog = 3;
         else if (Cout % 64 == 0 && a.K % 64 == 0) prog = 2;
         else if (a.K % 256 == 0) prog = 5;
         else if (a.K % 128 == 0) prog = 4;

@@ -128,8 +128,31 @@ def _fwd_splits(M, F, K):
     return _ceil_div(nch, cps)
 
 
+def _wgrad_tile(M, Cout, K):
+    """(rows, columns) of the weight-gradient tile program pfrl_conv2d_nhwc_bwd_weight picks
+    (csrc/qnet.hip; keep in step)."""
+    if M >= 16384 and Cout % 32 == 0:
+        if Cout % 64 == 0 and K % 128 == 0 and M >= 262144:
+            return 64, 128
+        if Cout % 64 == 0 and K % 64 == 0:
+            return 64, 64
+        if K % 256 == 0:
+            return 32, 256
+        if K % 128 == 0:
+            return 32, 128
+    return (32, 32) if Cout % 32 == 0 else (16, 32)
+
+
 def _wgrad_splits(M, Cout, K):
     nch = _ceil_div(M, 32)
+    bi, bj = _wgrad_tile(M, Cout, K)
+    if bi * bj > 32 * 32:
+        # rollout- / update-sized batches on the large tile programs: ~3 workgroups per CU and
+        # walks of up to 256 chunks (a slab per split is written and folded: fewer, longer walks)
+        tiles = _ceil_div(Cout, bi) * _ceil_div(K, bj)
+        want = min(max(768 // tiles, _ceil_div(nch, 256), 1), nch, 1024)
+        cps = _ceil_div(nch, want)
+        return _ceil_div(nch, cps)
     tiles = _ceil_div(Cout, 32) * (K // 32)
     # enough workgroups to fill the chip, and at most 16 chunks walked per workgroup
     want = min(max(448 // tiles, _ceil_div(nch, 16), 1), nch, 1024)
@@ -268,20 +291,24 @@ def flush_fwd_folds(sink):
 # and the permuted input-gradient stores are 4-byte accesses 196 B / 256 B apart: 51 M of them per
 # launch at B = 16384 (PPO's minibatch), where they -- not the MFMAs -- set the launch time.  The
 # re-ordered weight is 6.4 MB, cached per weight version (the parameters change 16 times per rollout,
-# the trunk runs ~170 times), the weight gradient is re-ordered back by one copy.  Never inside a
-# stream capture (a cached copy would be baked into the graph) and not for the replay agents'
-# minibatches, whose bit-identity tests pin the planar route.
+# the trunk runs ~170 times; inside a stream capture the copy is made in the graph instead), the
+# weight gradient is re-ordered back by one copy.  Not for the replay agents' minibatches, whose
+# bit-identity tests pin the planar route.
 _NHWC_FC_MIN_BATCH = int(os.environ.get("PFRL_TRUNK_NHWC_FC_MIN_BATCH", "1024"))
 _WP_CACHE = {}
 
 
 def _reordered_weight(wf, C, P):
     """wf [F, C * P] with columns (c, p) -> [F, P * C] with columns (p, c)."""
+    F = wf.shape[0]
+    if torch.cuda.is_current_stream_capturing():
+        # inside a captured update the copy is part of the graph (10 us), never a cached tensor:
+        # a replay must read the weights of ITS update
+        return wf.detach().view(F, C, P).transpose(1, 2).contiguous().view(F, P * C)
     key = wf.data_ptr()
     hit = _WP_CACHE.get(key)
     if hit is not None and hit[0] == wf._version and hit[1].shape == wf.shape:
         return hit[1]
-    F = wf.shape[0]
     wp = wf.detach().view(F, C, P).transpose(1, 2).contiguous().view(F, P * C)
     if len(_WP_CACHE) > 8:
         _WP_CACHE.clear()
@@ -300,8 +327,7 @@ class _Trunk(torch.autograd.Function):
         L = len(specs)
         acts = []
         h = x
-        nhwc_fc = (len(params) > 2 * L and 0 < _NHWC_FC_MIN_BATCH <= N
-                   and not torch.cuda.is_current_stream_capturing())
+        nhwc_fc = len(params) > 2 * L and 0 < _NHWC_FC_MIN_BATCH <= N
         for i, sp in enumerate(specs):
             h = conv_fwd(h, params[2 * i], params[2 * i + 1], sp, N, relu=True,
                          planar=(i == L - 1 and not nhwc_fc))
@@ -355,13 +381,28 @@ class _Trunk(torch.autograd.Function):
             # everything in (p, c) column order: plain NHWC rows in, NHWC rows out, the mask of the
             # convolution below read where the gradient is written; the weight gradient goes back
             # to the parameter's (c, p) order with one copy
-            check(lib.pfrl_conv2d_nhwc_bwd_data(_p(dh), _p(out), _p(wp), _p(acts[-1]), _p(dy), N, 1, 1,
+            # (the ReLU mask of the hidden layer applied once, by one elementwise launch, instead of
+            # being loaded beside dh by both gradient kernels: at this size the second operand
+            # stream costs each of them more than the extra launch)
+            dhm = torch.ops.aten.threshold_backward(dh, out, 0.0)
+            check(lib.pfrl_conv2d_nhwc_bwd_data(_p(dhm), None, _p(wp), _p(acts[-1]), _p(dy), N, 1, 1,
                                                 Kf, F, 1, 1, 1, 0, 0, _stream()), "linear_bwd_data")
             dwp = torch.empty_like(wp)
             dbf = torch.empty(F, dtype=torch.float32, device=dev)
-            check(lib.pfrl_conv2d_nhwc_bwd_weight(_p(dh), _p(out), _p(acts[-1]), _p(dwp), _p(dbf), 0, 0,
-                                                  N, 1, 1, Kf, F, 1, 1, 1, 1, _stream()),
-                  "linear_bwd_weight")
+            fsplits = _wgrad_splits(N, F, Kf)
+            if fsplits == 1:
+                check(lib.pfrl_conv2d_nhwc_bwd_weight(_p(dhm), None, _p(acts[-1]), _p(dwp), _p(dbf), 0,
+                                                      0, N, 1, 1, Kf, F, 1, 1, 1, 1, _stream()),
+                      "linear_bwd_weight")
+            else:
+                fstride = F * Kf + F
+                fpart = torch.empty(fsplits * fstride, dtype=torch.float32, device=dev)
+                check(lib.pfrl_conv2d_nhwc_bwd_weight(_p(dhm), None, _p(acts[-1]), _p(fpart),
+                                                      _p(fpart[F * Kf:]), fstride, fstride, N, 1, 1, Kf,
+                                                      F, 1, 1, 1, fsplits, _stream()),
+                      "linear_bwd_weight")
+                _reduce([(fpart, dwp, None, fstride, F * Kf, fsplits, 4, 0),
+                         (fpart[F * Kf:], dbf, None, fstride, F, fsplits, 4, 0)])
             dwf = dwp.view(F, P, last.Cout).transpose(1, 2).contiguous().view(F, Kf)
             if _dist_initialized():
                 from pfrl_amd.distributed import announce_grad

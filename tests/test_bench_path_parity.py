@@ -362,3 +362,62 @@ def test_ppo_act_graph_equals_the_eager_act_path(monkeypatch):
     # a subclass / instance that overrides the sampling hook keeps the eager path
     monkeypatch.setattr(agent, "_sample_action", lambda d: d.sample(), raising=False)
     assert not _ActGraph(agent).applicable()
+
+
+def test_ppo_captured_minibatch_update_equals_the_eager_update(monkeypatch):
+    """One minibatch update of PPO (gather, forward, loss, backward, clipping, Adam) replayed from
+    a HIP graph (agents/ppo.py::_minibatch_step, default) against the eager launch sequence
+    (PFRL_PPO_UPDATE_GRAPH=0) on identical rollouts (the sampled actions are replayed from a
+    table): same parameters and loss statistics after three rollouts of 2 epochs x 4 minibatches.
+    Tolerance 2e-6: torch's capturable Adam keeps its step count on the device and forms the bias
+    corrections there in f32."""
+    import pfrl_amd as pfrl
+    from pfrl_amd import agents
+    from pfrl_amd.device_store import DeviceFrameStore
+    from pfrl_amd.envs import SyntheticAtariVectorEnv
+    from pfrl_amd.nn import Branched
+    from pfrl_amd.policies import SoftmaxCategoricalHead
+
+    dev = torch.device("cuda:0")
+    N, T, rollouts = 32, 16, 3
+    table = np.random.RandomState(7).randint(0, 6, size=(T * rollouts + 1, N))
+
+    def run(graph):
+        monkeypatch.setenv("PFRL_PPO_UPDATE_GRAPH", "1" if graph else "0")
+        pfrl.utils.set_random_seed(0)
+        torch.manual_seed(99)
+        model = torch.nn.Sequential(
+            torch.nn.Flatten(), torch.nn.Linear(4 * 144, 64), torch.nn.ReLU(),
+            Branched(torch.nn.Sequential(torch.nn.Linear(64, 6), SoftmaxCategoricalHead()),
+                     torch.nn.Linear(64, 1)))
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3, eps=1e-5, fused=True)
+        store = DeviceFrameStore((T + 8) * N + 512, (12, 12), torch.uint8, dev, stack=4)
+        env = SyntheticAtariVectorEnv(N, store=store, seed=3, frame_shape=(12, 12), p_done=0.05)
+        ag = agents.PPO(model, opt, gpu=0, phi=lambda x: np.asarray(x, dtype=np.float32) / 255,
+                        update_interval=N * T, minibatch_size=N * T // 4, epochs=2, clip_eps=0.1,
+                        standardize_advantages=True, entropy_coef=1e-2, max_grad_norm=0.5)
+        step = [0]
+
+        def replay_action(distrib):
+            a = torch.as_tensor(table[step[0]], device=dev)
+            step[0] += 1
+            return a
+
+        ag._sample_action = replay_action
+        obss = env.reset()
+        for _ in range(T * rollouts):
+            a = ag.batch_act(obss)
+            obss, r, d, _ = env.step(a)
+            ag.batch_observe(obss, r, d, np.zeros(N, dtype=bool))
+            obss = env.reset(~d)
+        torch.cuda.synchronize()
+        assert ag.n_updates == rollouts * 8
+        assert (ag._update_graph is not None) == graph
+        return (np.concatenate([p.detach().cpu().numpy().ravel() for p in model.parameters()]),
+                ag.value_loss_record.values(), ag.policy_loss_record.values())
+
+    pa, va, la = run(True)
+    pb, vb, lb = run(False)
+    np.testing.assert_allclose(pa, pb, rtol=2e-6, atol=2e-7)
+    np.testing.assert_allclose(va, vb, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(la, lb, rtol=1e-5, atol=1e-6)

@@ -62,7 +62,8 @@ def test_split_heuristics_cover_the_reduction():
         s = mt._fwd_splits(M, F_, K)
         cps = -(-(K // 32) // s)
         assert 1 <= s <= K // 32 and cps * s >= K // 32 and cps * (s - 1) < K // 32
-    for M, Co, K in [(12800, 32, 256), (2592, 64, 512), (1568, 64, 576), (102400, 32, 256), (7, 64, 576)]:
+    for M, Co, K in [(12800, 32, 256), (2592, 64, 512), (1568, 64, 576), (102400, 32, 256), (7, 64, 576),
+                     (6553600, 32, 256), (1327104, 64, 512), (802816, 64, 576), (16384, 512, 3136)]:
         s = mt._wgrad_splits(M, Co, K)
         nch = -(-M // 32)
         cps = -(-nch // s)
