@@ -678,6 +678,12 @@ typedef struct {
 /* sample_n_k(n, k), sparse regime 3 k < n (pfrl/utils/random.py:13-28): k distinct indices. */
 int pfrl_plan_sample_n_k(void *bitgen, int64_t n, int32_t k, int64_t *host_out);
 
+/* random.sample(range(n), k=n) of Python's `random` module (the minibatch order of
+ * pfrl/agents/ppo.py:247-257, Lib/random.py sample() + _randbelow_with_getrandbits) on the module's
+ * own MT19937 state: state625 = the 624 words + index of random.getstate()[1], advanced in place
+ * (write it back with random.setstate).  host_out = int64[n]. */
+int pfrl_pyrandom_permutation(uint32_t *state625, int64_t n, int64_t *host_out);
+
 /* n_envs x select_action_epsilon_greedily with random_action_func = np.random.randint(n_actions):
  * host_choice[i] = the random action, or -1 where the draw chose the greedy action. */
 int pfrl_plan_eps_greedy(void *bitgen, int64_t n_envs, double epsilon, int64_t n_actions,

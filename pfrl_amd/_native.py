@@ -155,6 +155,7 @@ EXPORTS = {
     "pfrl_synth_reward_done": (ctypes.c_int, "Qqqqdpp"),
     "pfrl_select_actions": (ctypes.c_int, "pippqp"),
     "pfrl_plan_sample_n_k": (ctypes.c_int, "pqip"),
+    "pfrl_pyrandom_permutation": (ctypes.c_int, "pqp"),
     "pfrl_plan_eps_greedy": (ctypes.c_int, "pqdqp"),
     "pfrl_plan_dqn_range": (ctypes.c_int64, "HpqpppppPqqqiiqppqp"),
     "pfrl_batch_states_u8": (ctypes.c_int, "pqpqfpp"),

@@ -5,6 +5,7 @@
 #include <stdint.h>
 
 #include "common.h"
+#include <vector>
 #include "powf_glibc.h"
 
 // One pinned-host -> device transfer on `stream` (hipMemcpyAsync): the staging rings' control
@@ -289,6 +290,63 @@ static inline double u01_of(uint64_t seed, uint64_t env, uint64_t t, uint64_t st
     const uint64_t key = mix64(seed ^ mix64(env * 0x9E3779B97F4A7C15ull + t));
     const uint64_t r = mix64(key + stream * 0xD1342543DE82EF95ull);
     return (double)(r >> 11) * (1.0 / 9007199254740992.0);
+}
+
+// ---------------------------------------------------------------------------------------
+// PPO's minibatch order: random.sample(range(n), k=n) on Python's `random` module
+// (pfrl/agents/ppo.py:247-257 -> _yield_minibatches).  CPython (Lib/random.py, 3.9 - 3.12):
+//   pool = list(range(n)); for i in range(n): j = _randbelow(n - i); result[i] = pool[j];
+//   pool[j] = pool[n - i - 1]                      (k == n always takes the pool branch)
+//   _randbelow(m): k = m.bit_length(); r = getrandbits(k); while r >= m: r = getrandbits(k)
+//   getrandbits(k <= 32) = genrand_uint32() >> (32 - k)           (Modules/_randommodule.c)
+// `random` publishes no function table, so the generator itself is restated (MT19937, the
+// reference implementation CPython embeds) and runs on the module's state: 624 words + index as
+// random.getstate() hands them out; the caller writes the advanced state back with setstate().
+// At n = 65 536 the interpreter spends 10 - 20 ms per permutation, four per PPO update.
+// ---------------------------------------------------------------------------------------
+static inline uint32_t mt_next(uint32_t *mt, uint32_t &idx) {
+    constexpr int N = 624, M = 397;
+    constexpr uint32_t UPPER = 0x80000000u, LOWER = 0x7fffffffu, MATRIX_A = 0x9908b0dfu;
+    if (idx >= N) {
+        int kk;
+        uint32_t y;
+        for (kk = 0; kk < N - M; ++kk) {
+            y = (mt[kk] & UPPER) | (mt[kk + 1] & LOWER);
+            mt[kk] = mt[kk + M] ^ (y >> 1) ^ ((y & 1u) ? MATRIX_A : 0u);
+        }
+        for (; kk < N - 1; ++kk) {
+            y = (mt[kk] & UPPER) | (mt[kk + 1] & LOWER);
+            mt[kk] = mt[kk + (M - N)] ^ (y >> 1) ^ ((y & 1u) ? MATRIX_A : 0u);
+        }
+        y = (mt[N - 1] & UPPER) | (mt[0] & LOWER);
+        mt[N - 1] = mt[M - 1] ^ (y >> 1) ^ ((y & 1u) ? MATRIX_A : 0u);
+        idx = 0;
+    }
+    uint32_t y = mt[idx++];
+    y ^= y >> 11;
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= y >> 18;
+    return y;
+}
+
+extern "C" int pfrl_pyrandom_permutation(uint32_t *state625, int64_t n, int64_t *host_out) {
+    PFRL_CHECK_ARG(state625 && host_out && n >= 1 && n <= 0x7fffffffll,
+                   "pfrl_pyrandom_permutation: 1 <= n < 2^31");
+    PFRL_CHECK_ARG(state625[624] <= 624, "pfrl_pyrandom_permutation: bad generator index");
+    uint32_t idx = state625[624];
+    std::vector<int64_t> pool((size_t)n);
+    for (int64_t i = 0; i < n; ++i) pool[(size_t)i] = i;
+    for (int64_t i = 0; i < n; ++i) {
+        const uint32_t m = (uint32_t)(n - i);
+        const int bits = 32 - __builtin_clz(m);          // m.bit_length(), m >= 1
+        uint32_t r;
+        do r = mt_next(state625, idx) >> (32 - bits); while (r >= m);
+        host_out[i] = pool[r];
+        pool[r] = pool[(size_t)(n - i - 1)];
+    }
+    state625[624] = idx;
+    return 0;
 }
 
 extern "C" int pfrl_synth_reward_done(uint64_t seed, int64_t env_id0, int64_t n, int64_t t,

@@ -128,36 +128,21 @@ def _fwd_splits(M, F, K):
     return _ceil_div(nch, cps)
 
 
-def _wgrad_tile(M, Cout, K):
-    """(rows, columns) of the weight-gradient tile program pfrl_conv2d_nhwc_bwd_weight picks
-    (csrc/qnet.hip; keep in step)."""
-    if M >= 16384 and Cout % 32 == 0:
-        if Cout % 64 == 0 and K % 128 == 0 and M >= 262144:
-            return 64, 128
-        if Cout % 64 == 0 and K % 64 == 0:
-            return 64, 64
-        if K % 256 == 0:
-            return 32, 256
-        if K % 128 == 0:
-            return 32, 128
-    return (32, 32) if Cout % 32 == 0 else (16, 32)
-
-
 def _wgrad_splits(M, Cout, K):
     nch = _ceil_div(M, 32)
-    bi, bj = _wgrad_tile(M, Cout, K)
-    if bi * bj > 32 * 32:
-        # rollout- / update-sized batches on the large tile programs: ~3 workgroups per CU and
-        # walks of up to 256 chunks (a slab per split is written and folded: fewer, longer walks)
-        tiles = _ceil_div(Cout, bi) * _ceil_div(K, bj)
-        want = min(max(768 // tiles, _ceil_div(nch, 256), 1), nch, 1024)
-        cps = _ceil_div(nch, want)
-        return _ceil_div(nch, cps)
     tiles = _ceil_div(Cout, 32) * (K // 32)
-    # enough workgroups to fill the chip, and at most 16 chunks walked per workgroup
-    want = min(max(448 // tiles, _ceil_div(nch, 16), 1), nch, 1024)
+    # enough workgroups to fill the chip, and at most 16 chunks walked per workgroup (up to 1024
+    # splits).  The same rule for the large tile programs of update-sized batches: fewer, longer
+    # walks (~3 workgroups per CU, 256 chunks each) measured 15 - 35 % SLOWER there
+    # (profiles/r04_layer_sweep.txt: conv1 1290 -> 1756 us, linear layer 552 -> 725 us at B = 16384)
+    want = min(max(448 // tiles, _ceil_div(nch, _WGRAD_CPS), 1), nch, _WGRAD_MAX_SPLITS)
     cps = _ceil_div(nch, want)
     return _ceil_div(nch, cps)
+
+
+# (measurement hooks of tools/layer_bench.py)
+_WGRAD_CPS = int(os.environ.get("PFRL_WGRAD_CPS", "16"))
+_WGRAD_MAX_SPLITS = int(os.environ.get("PFRL_WGRAD_MAX_SPLITS", "1024"))
 
 
 _FUSE_BWD = os.environ.get("PFRL_FUSE_BWD", "1") != "0"

@@ -275,16 +275,34 @@ def test_sample_n_k_equals_the_reference_walk_including_the_stream_position():
 
 def test_ppo_minibatch_positions_drawn_up_front_consume_the_same_random_stream():
     """PPO's minibatch order comes from Python's ``random`` (reference ppo.py:247-257).  The device
-    path draws every minibatch of an update before its loop (under the value pass) and keeps them
-    as arrays: same positions, same stream position afterwards."""
+    path keeps minibatches as arrays and, from 1 024 elements up, draws the permutations natively
+    on the module's own MT19937 state (pfrl_pyrandom_permutation, CPython's pool algorithm): same
+    positions, same stream position afterwards -- also right after a generator block boundary and
+    with a Gaussian draw pending (``gauss_next`` is carried through setstate)."""
     import random
 
     from pfrl_amd.agents.ppo import _all_minibatch_positions, _yield_minibatch_positions
 
-    for n, mb, ep in [(100, 32, 3), (64, 64, 2), (65, 16, 4), (10, 3, 5), (2048, 512, 4)]:
+    for n, mb, ep in [(100, 32, 3), (64, 64, 2), (65, 16, 4), (10, 3, 5), (2048, 512, 4),
+                      (65536, 16384, 2), (5000, 1250, 3), (1025, 41, 2)]:
         random.seed(5)
         a = [list(x) for x in _yield_minibatch_positions(n, mb, ep)]
         sa = random.getstate()
         random.seed(5)
         b = [[int(v) for v in x] for x in _all_minibatch_positions(n, mb, ep)]
         assert a == b and sa == random.getstate(), (n, mb, ep)
+    from pfrl_amd.agents.ppo import _random_permutation
+
+    for warm in (0, 1, 623, 624, 625, 1000):
+        random.seed(11)
+        random.gauss(0.0, 1.0)                      # leaves gauss_next set
+        for _ in range(warm):
+            random.getrandbits(32)
+        a = random.sample(range(4099), k=4099)
+        sa = random.getstate()
+        random.seed(11)
+        random.gauss(0.0, 1.0)
+        for _ in range(warm):
+            random.getrandbits(32)
+        b = _random_permutation(4099)
+        assert a == [int(v) for v in b] and sa == random.getstate(), warm

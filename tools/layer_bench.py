@@ -51,10 +51,16 @@ def time_us(fn, iters):
     return e0.elapsed_time(e1) * 1e3 / iters
 
 
-def wgrad_splits(M, Cout, K):
-    from pfrl_amd.nn.mfma_trunk import _wgrad_splits
+def wgrad_splits(M, Cout, K, cps=None, cap=None):
+    from pfrl_amd.nn import mfma_trunk as mt
 
-    return _wgrad_splits(M, Cout, K)
+    old = mt._WGRAD_CPS, mt._WGRAD_MAX_SPLITS
+    if cps is not None:
+        mt._WGRAD_CPS, mt._WGRAD_MAX_SPLITS = cps, cap
+    try:
+        return mt._wgrad_splits(M, Cout, K)
+    finally:
+        mt._WGRAD_CPS, mt._WGRAD_MAX_SPLITS = old
 
 
 def main():
@@ -63,6 +69,9 @@ def main():
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--only", default="fwd,dgrad,wgrad")
     ap.add_argument("--layers", default="conv1,conv2,conv3,fc")
+    ap.add_argument("--splits", default="",
+                    help="comma list of (chunks per split):(max splits) pairs for the weight-gradient "
+                         "split rule, e.g. 16:1024,8:2048,32:1024 -- timed with the default programs")
     ap.add_argument("--sweep", action="store_true",
                     help="every tile program that fits the layer (PFRL_QNET_FWD / _DGRAD / _WGRAD), each "
                          "checked bit for bit against the round-3 program of the same layer")
@@ -137,6 +146,20 @@ def main():
                             tag += " ==" if torch.equal(got, ref) else " d=%.1e" % diff
                     rows.append((tag, t, flop, nbytes))
                 os.environ.pop(env, None)
+            if args.splits and "wgrad" in only:
+                for pair in args.splits.split(","):
+                    cps, cap = [int(v) for v in pair.split(":")]
+                    sp = wgrad_splits(M, Co, K, cps, cap)
+                    part2 = torch.empty(sp * stride, device=dev)
+
+                    def run_w2():
+                        check(lib.pfrl_conv2d_nhwc_bwd_weight(
+                            _p(dy), None, _p(x), _p(part2), _p(part2[w.numel():]), stride, stride, B, H,
+                            H, C, Co, R, R, ST, sp, _stream()), "wgrad")
+
+                    rows.append(("wgrad/%d(%s)" % (sp, pair), time_us(run_w2, args.iters), flop,
+                                 bx + by + sp * stride * 4))
+                    del part2
             for d, t, f, nbytes in rows:
                 tf = f / t * 1e-6
                 print("%-6s %-16s %6d %10.1f %9.2f %8.1f %6.3f %9.1f" % (
