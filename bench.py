@@ -358,6 +358,8 @@ def workload_description(args, N, rbuf):
                 "on device prefilled to %d, B=%d, update_interval=1 (one update per env-step), "
                 "256-256 MLPs, Adam" % (N, args.capacity, len(rbuf), args.minibatch))
     return ("BASELINE.json configs[3]: PPO, %d synthetic Atari-shaped envs/GPU x 128-step rollouts, "
+            "reuse_next_values=True (V(next_state) from the next step's V(state): SURVEY 8(d)'s "
+            "0.854 MB/env-step variant), "
             "update_interval=%d, minibatch=%d, 4 epochs, GAE + advantage standardisation kernels, "
             "Adam" % (N, N * 128, 32 * N))
 
@@ -560,6 +562,16 @@ def step_flops_dqn(N, minibatch, update_interval):
     return N * NATURE_FWD_FLOPS + updates * per_update
 
 
+def step_flops_ppo(N, n_actions=6):
+    """Arithmetic of one batched PPO step (512 envs), the rollout's passes amortised per env step:
+    acting forward, the value pass over the rollout's states (reuse_next_values: once), and 4
+    epochs of forward + backward (backward = 2 x forward minus conv1's input gradient); the two
+    narrow heads (512 -> A, 512 -> 1) counted with the trunk."""
+    heads = 2 * 512 * (n_actions + 1)
+    fwd = NATURE_FWD_FLOPS + heads
+    return N * (fwd + fwd + 4 * (3 * fwd - NATURE_CONV1_FLOPS))
+
+
 def launches_per_update():
     """Kernel launches of one update, from the committed rocprofv3 timeline of this build
     (profiles/rNN_dqn_update_timeline.txt, tools/update_timeline.py), newest round first."""
@@ -581,7 +593,11 @@ def algorithmic_bytes_per_step(algo, N, minibatch, update_interval):
         rho = minibatch / update_interval
         return N * (fb + (k * fb + 4 * k * fb) + rho * 2 * (k * fb + 4 * k * fb))
     if algo == "ppo":
-        return N * 994932
+        # act 141,120 + ring 7,056 + value pass + 4 epochs x 141,120 + GAE 24 +
+        # adv-norm 12.  The reference evaluates V on states AND next_states (2 x 141,120: 994,932 B);
+        # this build runs reuse_next_values=True -- V(next_state) read from the next step's V(state),
+        # only episode ends re-evaluated -- which is the 0.854 MB variant SURVEY says to flag.
+        return N * (141120 + 7056 + 141120 + 4 * 141120 + 24 + 12)
     return N * (2 * minibatch * 3084 + 3084)   # sac
 
 
@@ -602,6 +618,21 @@ def assemble_result(args, world, N, elapsed, n_updates, t_fill, workload, roofli
             roofline["mfma"] = {"step_flops": int(fl), "achieved": round(tf, 2),
                                 "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                                 "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 4)}
+        if args.algo == "ppo":
+            # PPO is bound by the f32 MFMA trunk at update size (B = 16384), not by the gather the
+            # HBM block above describes (3 % of the device time): rollout FLOPs / time / peak
+            fl = step_flops_ppo(N)
+            tf = fl / (ms * 1e-3) / 1e12
+            roofline["mfma"] = {"step_flops": int(fl), "achieved": round(tf, 2),
+                                "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 4),
+                                "what": "acting + value pass + 4 epochs x (forward + backward) of the "
+                                        "rollout, per env step; per-layer fractions at B = 16384: "
+                                        "profiles/r04_layer_final.txt (tools/layer_bench.py)"}
+            roofline["captured_launches_not_timed"] = (
+                "the 65536-frame minibatch gathers run inside the captured update graph "
+                "(agents/ppo.py::_minibatch_step) and carry no event pair; the timed launches are the "
+                "value pass's gathers of the same kernel")
     per = "per GPU" if args.scaling == "weak" else "sharded over the GPUs"
     return {
         "metric": "env-steps/sec whole node (%s %d envs %s)" % (args.algo.upper(), N if args.scaling == "weak" else N * world, per),
@@ -748,6 +779,41 @@ def reference_baseline(args):
                   % (d["num_envs"], d["replay_len_at_start"],
                      d["end_to_end"]["env_steps_per_sample"][0], args.cpu_baseline_seconds,
                      d["cores"], d["data_path_only"]["env_steps_per_sample"][0]),
+    }
+
+
+def reference_baseline_ppo(args, num_envs=512, steps=16):
+    """The reference's PPO (pfrl/agents/ppo.py:465-532, gpu=-1, the model and hyperparameters of
+    examples/atari/train_ppo_ale.py:247-264) on this box's host cores, by the same tool and the same
+    oracle/_ref/ copy as :func:`reference_baseline`.  Bounded: rollouts of ``steps`` steps instead of
+    128 (update_interval and minibatch scaled with them: every transition still gets one acting
+    forward, one value pass and 4 epochs), one untimed + one timed rollout INCLUDING its update.
+    The full-size figure (128-step rollouts) is profiles/r04_reference_cpu_baseline_ppo_gpubox.json."""
+    import subprocess
+
+    ref_dir = os.path.join(ROOT, "oracle", "_ref")
+    if not os.path.isdir(os.path.join(ref_dir, "pfrl")):
+        return None
+    env = dict(os.environ, PFRL_REFERENCE=ref_dir, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "reference_cpu_baseline.py"), "--algo", "ppo",
+           "--num-envs", str(num_envs), "--ppo-steps", str(steps), "--ppo-rollouts", "1",
+           "--threads", str(args.cpu_baseline_threads)]
+    try:
+        out = subprocess.run(cmd, env=env, cwd="/tmp", capture_output=True, text=True, timeout=600)
+        d = json.loads(out.stdout.strip().splitlines()[-1])
+    except Exception as e:     # the baseline must never cost the line its GPU numbers
+        sys.stderr.write("reference PPO cpu baseline failed: %r\n" % (e,))
+        return None
+    return {
+        "value": d["end_to_end"]["value"], "unit": "env-steps/s", "cores": d["cores"],
+        "kind": "reference", "host_cores": d["host_cores"],
+        "sample": "pfnet/pfrl itself (oracle/_ref), gpu=-1, pfrl/agents/ppo.py on %d in-process "
+                  "synthetic Atari-shaped envs: one %d-step rollout INCLUDING its update "
+                  "(update_interval=%d, minibatch=%d, 4 epochs; BASELINE's rollout is 128 steps, the "
+                  "per-transition work is the same): %d env-steps in %.0f s with %d torch threads; "
+                  "full size: profiles/r04_reference_cpu_baseline_ppo_gpubox.json"
+                  % (d["num_envs"], d["rollout_steps"], d["update_interval"], d["minibatch"],
+                     d["end_to_end"]["env_steps"], d["end_to_end"]["seconds"], d["cores"]),
     }
 
 
@@ -914,6 +980,15 @@ def main():
                 out["cpu_baseline"] = ref
             else:
                 out["cpu_baseline"] = port
+            if "also" in out and "ppo" in out["also"]:
+                # the PPO half of the metric gets its own reference baseline
+                pref = reference_baseline_ppo(args)
+                if pref is not None:
+                    out["also"]["ppo"]["cpu_baseline"] = pref
+        if not args.no_cpu_baseline and world == 1 and args.algo == "ppo":
+            pref = reference_baseline_ppo(args, num_envs=args.num_envs)
+            if pref is not None:
+                out["cpu_baseline"] = pref
     if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
     sys.stdout.flush()

@@ -44,6 +44,12 @@ def main():
     ap.add_argument("--capacity", type=int, default=10 ** 5)
     ap.add_argument("--prefill", type=int, default=20000)
     ap.add_argument("--out", default=None)
+    ap.add_argument("--algo", choices=["dqn", "ppo"], default="dqn",
+                    help="ppo = BASELINE configs[3]: the reference's PPO (examples/atari/train_ppo_ale.py "
+                         "model and hyperparameters), --num-envs envs x --ppo-steps steps per rollout, "
+                         "minibatch = rollout / 4, 4 epochs; timed: whole rollouts including their update")
+    ap.add_argument("--ppo-steps", type=int, default=128, help="rollout length T (128 = BASELINE's)")
+    ap.add_argument("--ppo-rollouts", type=int, default=1, help="timed rollouts (after one untimed)")
     args = ap.parse_args()
 
     sys.path.insert(0, os.path.join(ROOT, "tests", "_gymshim"))   # test-only `gym` stand-in
@@ -99,6 +105,9 @@ def main():
 
     def phi(x):   # examples/atari/train_dqn_batch_ale.py:229-231
         return np.asarray(x, dtype=np.float32) / 255
+
+    if args.algo == "ppo":
+        return ppo_baseline(args, pfrl, torch, SyntheticAtari, phi, N, n_actions, cores, thread_counts)
 
     class ZeroFlopQ(torch.nn.Module):
         """Q-values that do not depend on the observation: one learnable row."""
@@ -189,6 +198,71 @@ def main():
                            "note": "zero-FLOP q_function: batch_states, append, sample, "
                                    "batch_experiences, loss on a [32, 6] constant"},
         "runs": runs,
+        "torch": torch.__version__, "numpy": np.__version__,
+    }
+    print(json.dumps(out))
+    if args.out:
+        with open(args.out, "w") as f:
+            json.dump(out, f, indent=1)
+
+
+def ppo_baseline(args, pfrl, torch, SyntheticAtari, phi, N, n_actions, cores, thread_counts):
+    """The reference's PPO (pfrl/agents/ppo.py, gpu=-1) as examples/atari/train_ppo_ale.py:247-264
+    builds it, on N in-process synthetic envs: whole rollouts of T steps INCLUDING the update each
+    one ends with (value pass, GAE, 4 epochs of minibatches); env-steps/s = N * T / wall."""
+    from pfrl import agents
+    from pfrl.policies import SoftmaxCategoricalHead
+
+    def lecun_init(layer, gain=1):
+        pfrl.initializers.init_lecun_normal(layer.weight, gain)
+        torch.nn.init.zeros_(layer.bias)
+        return layer
+
+    nn = torch.nn
+    T = args.ppo_steps
+    th = thread_counts[0]
+    torch.set_num_threads(th)
+    pfrl.utils.set_random_seed(int(args.seeds.split(",")[0]))
+    model = nn.Sequential(
+        lecun_init(nn.Conv2d(4, 32, 8, stride=4)), nn.ReLU(),
+        lecun_init(nn.Conv2d(32, 64, 4, stride=2)), nn.ReLU(),
+        lecun_init(nn.Conv2d(64, 64, 3, stride=1)), nn.ReLU(), nn.Flatten(),
+        lecun_init(nn.Linear(3136, 512)), nn.ReLU(),
+        pfrl.nn.Branched(
+            nn.Sequential(lecun_init(nn.Linear(512, n_actions), 1e-2), SoftmaxCategoricalHead()),
+            lecun_init(nn.Linear(512, 1))))
+    opt = torch.optim.Adam(model.parameters(), lr=2.5e-4, eps=1e-5)
+    agent = agents.PPO(model, opt, gpu=-1, phi=phi, update_interval=N * T, minibatch_size=N * T // 4,
+                       epochs=4, clip_eps=0.1, clip_eps_vf=None, standardize_advantages=True,
+                       entropy_coef=1e-2, max_grad_norm=0.5)
+    env = SyntheticAtari()
+    obss = env.reset()
+
+    def rollout(obss):
+        n0 = agent.n_updates
+        for _ in range(T):
+            actions = agent.batch_act(obss)
+            obss, rs, dones, infos = env.step(actions)
+            agent.batch_observe(obss, rs, dones, [False] * N)
+            obss = env.reset([not d for d in dones])
+        assert agent.n_updates > n0, "the rollout did not end with an update"
+        return obss
+
+    t0 = time.perf_counter()
+    obss = rollout(obss)                       # untimed: allocator / thread pool warm-up
+    t_warm = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    for _ in range(args.ppo_rollouts):
+        obss = rollout(obss)
+    el = time.perf_counter() - t0
+    out = {
+        "what": "reference pfnet/pfrl PPO (gpu=-1) on the synthetic configs[3] workload",
+        "reference_from": REFERENCE, "host_cores": cores, "torch_threads": th, "cores": th,
+        "num_envs": N, "rollout_steps": T, "update_interval": N * T, "minibatch": N * T // 4,
+        "epochs": 4, "rollouts_timed": args.ppo_rollouts, "warmup_rollout_s": round(t_warm, 1),
+        "end_to_end": {"value": round(args.ppo_rollouts * N * T / el, 2), "unit": "env-steps/s",
+                       "seconds": round(el, 1), "env_steps": args.ppo_rollouts * N * T,
+                       "updates": agent.n_updates},
         "torch": torch.__version__, "numpy": np.__version__,
     }
     print(json.dumps(out))
