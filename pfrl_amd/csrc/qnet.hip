@@ -36,7 +36,10 @@ namespace {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int KC = 32;
-constexpr int LDR = KC + 4;
+#ifndef PFRL_LDR
+#define PFRL_LDR (KC + 4)
+#endif
+constexpr int LDR = PFRL_LDR;
 
 // Exact unsigned division by a launch constant (Granlund-Montgomery round-up form, any 32-bit
 // numerator): the per-thread row -> (image, oh, ow) split of the weight-gradient loader runs once per

@@ -142,7 +142,7 @@ def _wgrad_splits(M, Cout, K):
 
 # (measurement hooks of tools/layer_bench.py)
 _WGRAD_CPS = int(os.environ.get("PFRL_WGRAD_CPS", "16"))
-_WGRAD_MAX_SPLITS = int(os.environ.get("PFRL_WGRAD_MAX_SPLITS", "1024"))
+_WGRAD_MAX_SPLITS = int(os.environ.get("PFRL_WGRAD_MAX_SPLITS", "4096"))
 
 
 _FUSE_BWD = os.environ.get("PFRL_FUSE_BWD", "1") != "0"

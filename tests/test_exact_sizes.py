@@ -321,3 +321,89 @@ def test_sac_configs4_bench_shape_matches_oracle():
             checked += 1
         obss = env.reset(~np.asarray(dones))
     assert checked >= 5 and shapes == {2048, 14336}
+
+
+def test_sac_configs4_at_capacity_1e6_matches_oracle():
+    """configs[4] at its STATED size: ReplayBuffer(10**6) of fp32 rows (obs f32[376], action f32[17]),
+    filled to capacity through the agent's own act / observe path (64 host envs), then updating
+    steps with the buffer wrapping: every sampled minibatch row -- checked through per-transition
+    signatures (a fixed random projection of the observation rows, the action row, reward, terminal)
+    kept for all 10**6 + transitions -- is the transition the reference's index draw
+    (pfrl/replay_buffer.py:329-356 -> sample_n_k) names, and the NumPy stream ends where the
+    reference's loop ends."""
+    import bench
+    from test_bench_path_parity import _bench_args
+
+    dev = torch.device("cuda:0")
+    N, B, CAP = 64, 256, 10 ** 6
+    args = _bench_args(algo="sac", num_envs=N, minibatch=B, capacity=CAP, blas="default")
+    agent, env, rbuf = bench.build_agent(args, dev, 0)
+    proj_s = np.random.RandomState(1).randn(376)
+    proj_a = np.random.RandomState(2).randn(17)
+    sig = dict(s=[], a=[], r=[], ns=[], d=[])
+    orig_observe = agent.batch_observe
+    last = {}
+
+    def note(obss2, rs, dones):
+        sig["s"].append((np.stack([np.asarray(o, dtype=np.float32) for o in last["obs"]]).astype(np.float64) * proj_s).sum(axis=1))
+        sig["a"].append((np.stack([np.asarray(a, dtype=np.float32) for a in last["act"]]).astype(np.float64) * proj_a).sum(axis=1))
+        sig["ns"].append((np.stack([np.asarray(o, dtype=np.float32) for o in obss2]).astype(np.float64) * proj_s).sum(axis=1))
+        sig["r"].append(np.asarray(rs, dtype=np.float64))
+        sig["d"].append(np.asarray(dones, dtype=bool))
+
+    # fill to capacity with updates off (bench.prefill's own switch), recording signatures
+    saved = agent.replay_updater.replay_start_size
+    agent.replay_updater.replay_start_size = 1 << 62
+    obss = env.reset()
+    while len(rbuf) < CAP:
+        acts = agent.batch_act(obss)
+        last["obs"], last["act"] = obss, acts
+        obss2, rs, dones, _ = env.step(acts)
+        note(obss2, rs, dones)
+        orig_observe(obss2, rs, dones, np.zeros(N, dtype=bool))
+        obss = env.reset(~np.asarray(dones))
+    agent.replay_updater.replay_start_size = saved
+    assert len(rbuf) == CAP
+    fetched = []
+    orig_fetch = rbuf.fetch_many
+
+    def spy_fetch(seq_sets, phi, g):
+        big = orig_fetch(seq_sets, phi, g)
+        fetched.append(({k: v.detach().cpu().numpy() for k, v in big.items()
+                         if isinstance(v, torch.Tensor)}, len(seq_sets)))
+        return big
+
+    rbuf.fetch_many = spy_fetch
+    checked = 0
+    for step in range(4):
+        acts = agent.batch_act(obss)
+        last["obs"], last["act"] = obss, acts
+        obss2, rs, dones, _ = env.step(acts)
+        t_before = sum(len(x) for x in sig["r"])
+        note(obss2, rs, dones)
+        del fetched[:]
+        s0 = np.random.get_state()
+        orig_observe(obss2, rs, dones, np.zeros(N, dtype=bool))
+        s1 = np.random.get_state()
+        torch.cuda.synchronize()
+        np.random.set_state(s0)
+        expected = []
+        for i in range(N):
+            total = t_before + i + 1
+            ln = min(total, CAP)
+            idx = _ref_sample_n_k(ln, B)
+            expected.append(total - ln + np.asarray(idx, dtype=np.int64))
+        assert _same_rng_state(np.random.get_state(), s1), "NumPy stream position differs"
+        assert sum(f[1] for f in fetched) == N and [f[1] for f in fetched] == [8, 56]
+        got = {k: np.concatenate([f[0][k] for f in fetched]) for k in fetched[0][0]}
+        S_, A_, NS_ = (np.concatenate(sig[k]) for k in ("s", "a", "ns"))
+        R_, D_ = np.concatenate(sig["r"]), np.concatenate(sig["d"])
+        for u, gids in enumerate(expected):
+            assert np.array_equal((got["state"][u].astype(np.float64) * proj_s).sum(axis=1), S_[gids]), (step, u)
+            assert np.array_equal((got["next_state"][u].astype(np.float64) * proj_s).sum(axis=1), NS_[gids]), (step, u)
+            assert np.array_equal((got["action"][u].astype(np.float64) * proj_a).sum(axis=1), A_[gids]), (step, u)
+            assert np.array_equal(got["reward"][u], R_[gids].astype(np.float32))
+            assert np.array_equal(got["is_state_terminal"][u], D_[gids].astype(np.float32))
+        checked += 1
+        obss = env.reset(~np.asarray(dones))
+    assert checked == 4 and sum(len(x) for x in sig["r"]) > CAP      # the ring wrapped
