@@ -450,7 +450,13 @@ class DQN(agent.AttributeSavingMixin, agent.BatchAgent):
     def _compute_loss_fused(self, exp_batch, errors_out, record):
         from pfrl_amd import distributed, ops
 
-        split = self._head_split() if distributed.world_size() == 1 else None
+        # (data parallel: only inside a captured update whose optimizer takes the head's slabs --
+        # they are then folded into the flat bucket; the eager path keeps autograd's head, whose
+        # gradient hooks the early all-reduce hangs on)
+        split = self._head_split() if (
+            distributed.world_size() == 1
+            or (self._defer_head_fold and getattr(self, "_graphed", None) is not None
+                and self._graphed._optimizer_finishes_gradients())) else None
         qout = None
         h_fold = None
         if split is not None:

@@ -139,12 +139,15 @@ class GraphedUpdate:
         # can hand the TD errors to the replay stream (priority update, next
         # sample, next gather) while backward + optimizer step still run here
         self.pipeline = False
-        # RCCL all-reduces are capturable: with PFRL_GRAPH_COLLECTIVE=1 and the nccl
-        # backend the collective goes INTO the graph (one replay per update, no eager
-        # launches in between: +8 % measured with a single-rank communicator).  Off by
-        # default until it has run on a real multi-GPU node -- this build could only
-        # be exercised on one device; default = graph -> eager all-reduce -> graph.
-        self.graph_collective = os.environ.get("PFRL_GRAPH_COLLECTIVE", "0") == "1"
+        # RCCL collectives are capturable: with the nccl backend they go INTO the graph (one
+        # replay per update -- or per env range -- and no eager launches in between; the early
+        # all-reduce / low-rank all-gather of the large layer run on RCCL's stream beside the
+        # convolution backward).  Default for a real process group, but only after
+        # distributed.captured_collectives_work() has captured, replayed and checked a small
+        # all-reduce on this group under a timeout and every rank has agreed; otherwise, and on
+        # any capture error, the split plan: graph -> eager collective -> graph.
+        # PFRL_GRAPH_COLLECTIVE=0 forces the split plan, =1 skips the probe.
+        self.graph_collective = os.environ.get("PFRL_GRAPH_COLLECTIVE", "auto")
 
     def _key(self, exp_batch):
         return (tuple(sorted((k, v.data_ptr(), tuple(v.shape)) for k, v in exp_batch.items()
@@ -172,10 +175,13 @@ class GraphedUpdate:
         nothing else reads the gradients: no clipping, no collective, one parameter group."""
         ag = self.agent
         opt = ag.optimizer
+        # (data parallel: the slabs are folded into the flat bucket instead -- pack_sources)
         return (os.environ.get("PFRL_FUSED_OPT", "1") != "0" and ag.max_grad_norm is None
-                and not self.split_for_allreduce and not self.pipeline
+                and not self.pipeline
                 and hasattr(opt, "step_from_sources") and opt.accepts_sources()
-                and self._optimizer_owns_every_parameter())
+                and self._optimizer_owns_every_parameter()
+                and (not self.split_for_allreduce
+                     or os.environ.get("PFRL_DP_SOURCES", "1") != "0"))
 
     def _optimizer_owns_every_parameter(self):
         """Sources are keyed by parameter: a trainable parameter outside the optimizer's groups
@@ -233,11 +239,41 @@ class GraphedUpdate:
 
     _sources, _folds = None, ()
 
+    def _sources_by_param(self):
+        ag = self.agent
+        by_ptr = {p.data_ptr(): p for g in ag.optimizer.param_groups for p in g["params"]}
+        return {by_ptr[ptr]: src for ptr, src in self._sources.items()}
+
+    def _reduce(self, part):
+        """The data-parallel exchange of one update, in the three parts the plans place inside or
+        between their graphs: "pack" (gradients / slabs -> flat bucket), "collective" (the flat
+        all-reduce), "finish" (join the early exchanges; flat -> gradients unless they alias)."""
+        red = self.agent.grad_reducer
+        if not red.active():
+            return
+        if self._sources is not None:
+            if part == "pack":
+                self._sources = {p.data_ptr(): s for p, s in self._pack_sources(red).items()}
+            elif part == "collective":
+                red.reduce_flat()
+            else:
+                red.finish_sources()
+        elif part == "pack":
+            red.pack()
+        elif part == "collective":
+            red.reduce_flat()
+        else:
+            red.unpack()
+
+    def _pack_sources(self, red):
+        sources = self._sources_by_param()
+        red.pack_sources(sources)
+        return sources
+
     def _step(self):
         ag = self.agent
-        if self._sources:
-            by_ptr = {p.data_ptr(): p for g in ag.optimizer.param_groups for p in g["params"]}
-            sources = {by_ptr[ptr]: src for ptr, src in self._sources.items()}
+        if self._sources is not None:
+            sources = self._sources_by_param()
             self._sources = None
             ag.optimizer.step_from_sources(sources, self._folds)
             self._folds = ()
@@ -245,6 +281,12 @@ class GraphedUpdate:
         if ag.max_grad_norm is not None:
             torch.nn.utils.clip_grad_norm_(ag.model.parameters(), float(ag.max_grad_norm))
         ag.optimizer.step()
+
+    def _reduce_and_step(self):
+        self._reduce("pack")
+        self._reduce("collective")
+        self._reduce("finish")
+        self._step()
 
     def _snapshot(self):
         ag = self.agent
@@ -274,8 +316,13 @@ class GraphedUpdate:
 
     def _collective_capturable(self):
         d = torch.distributed
-        return (self.graph_collective and d.is_available() and d.is_initialized()
-                and d.get_backend() == "nccl")
+        if not (d.is_available() and d.is_initialized() and d.get_backend() == "nccl"):
+            return False
+        if self.graph_collective == "auto":
+            # decided once, by a probe every rank takes part in (never from inside a capture)
+            self.graph_collective = "1" if distributed.captured_collectives_work(
+                self.agent.device) else "0"
+        return self.graph_collective not in ("0", False)
 
     def _capture(self, exp_batch, want_errors):
         if self.split_for_allreduce and self._collective_capturable():
@@ -284,7 +331,7 @@ class GraphedUpdate:
             except Exception as e:
                 self.logger.warning("capturing the RCCL all-reduce inside the update graph "
                                     "failed (%s); keeping it eager between two graphs", e)
-                self.graph_collective = False
+                self.graph_collective = "0"
         return self._capture_plan(exp_batch, want_errors, collective_in_graph=False)
 
     def _capture_plan(self, exp_batch, want_errors, collective_in_graph):
@@ -307,12 +354,15 @@ class GraphedUpdate:
                 for _ in range(2):
                     ag.optimizer.zero_grad(set_to_none=True)
                     self._forward_backward(exp_batch, want_errors)
-                    ag.grad_reducer.all_reduce()
-                    self._step()
+                    self._reduce_and_step()
             cur.wait_stream(side)
             _make_capturable(ag.optimizer, dev)  # state created by the warm-up
             ag.optimizer.zero_grad(set_to_none=True)
-            entry = self._capture_graphs(exp_batch, want_errors, collective_in_graph)
+            distributed._CAPTURE_COLLECTIVES[0] = bool(collective_in_graph)
+            try:
+                entry = self._capture_graphs(exp_batch, want_errors, collective_in_graph)
+            finally:
+                distributed._CAPTURE_COLLECTIVES[0] = False
         finally:
             cur.wait_stream(side)
             self._restore(snap)
@@ -330,15 +380,11 @@ class GraphedUpdate:
                 self.pool = g.pool()
             return g, r
 
-        red = ag.grad_reducer   # pack / unpack (multi-tensor copies) live inside the graphs
         # plan: graphs interleaved with the two things that cannot be captured --
         # the caller's hand-over after the forward pass ("after_forward", pipeline
-        # mode) and the eager RCCL all-reduce (data parallel)
-        def reduce_and_step():
-            red.pack()
-            red.reduce_flat()
-            red.unpack()
-            self._step()
+        # mode) and the eager RCCL all-reduce (data parallel); pack / finish (the fold into
+        # the flat bucket, the low-rank product) live inside the graphs
+        reduce_and_step = self._reduce_and_step
 
         plan = []
         if self.pipeline:
@@ -347,8 +393,9 @@ class GraphedUpdate:
             if collective_in_graph:
                 plan += [graph_of(lambda: (self._backward(loss), reduce_and_step()))[0]]
             elif self.split_for_allreduce:
-                plan += [graph_of(lambda: (self._backward(loss), red.pack()))[0], "all_reduce",
-                         graph_of(lambda: (red.unpack(), self._step()))[0]]
+                plan += [graph_of(lambda: (self._backward(loss), self._reduce("pack")))[0],
+                         "all_reduce",
+                         graph_of(lambda: (self._reduce("finish"), self._step()))[0]]
             else:
                 plan += [graph_of(lambda: (self._backward(loss), self._step()))[0]]
         elif collective_in_graph:
@@ -363,11 +410,12 @@ class GraphedUpdate:
             # data parallel: graph(fwd+bwd) -> eager RCCL all-reduce -> graph(step)
             def fwd_bwd_pack():
                 r = self._forward_backward(exp_batch, want_errors)
-                red.pack()
+                self._reduce("pack")
                 return r
 
             g, (loss, delta) = graph_of(fwd_bwd_pack)
-            plan += [g, "all_reduce", graph_of(lambda: (red.unpack(), self._step()))[0]]
+            plan += [g, "all_reduce",
+                     graph_of(lambda: (self._reduce("finish"), self._step()))[0]]
         else:
             def whole():
                 r = self._forward_backward(exp_batch, want_errors)
@@ -377,6 +425,7 @@ class GraphedUpdate:
             g, (loss, delta) = graph_of(whole)
             plan += [g]
         entry["plan"] = plan
+        entry["bucket"] = ag.grad_reducer.current_bucket()   # what the eager collective reduces
         entry["loss"] = loss
         entry["delta"] = delta
         entry["y"] = ag._last_y
@@ -389,7 +438,7 @@ class GraphedUpdate:
     def range_capturable(self):
         """Several consecutive updates can share one graph when nothing has to happen
         between them on the host: no eager collective, no hand-over to a replay stream."""
-        return not (self.split_for_allreduce or self.pipeline)
+        return not self.pipeline and (not self.split_for_allreduce or self._collective_capturable())
 
     def run_range(self, big):
         """``big``: dict of tensors with a leading update axis U (the step-fused gather's
@@ -428,7 +477,7 @@ class GraphedUpdate:
             for p in range(U):
                 ag.optimizer.zero_grad(set_to_none=True)
                 loss, _ = self._forward_backward({k: v[p] for k, v in big.items()}, False)
-                self._step()
+                self._reduce_and_step()
                 losses.append(loss.reshape(()))
                 ys.append(ag._last_y.reshape(-1))
             return torch.stack(losses), torch.cat(ys)
@@ -447,13 +496,17 @@ class GraphedUpdate:
                 for _ in range(2):
                     ag.optimizer.zero_grad(set_to_none=True)
                     self._forward_backward({k: v[0] for k, v in big.items()}, False)
-                    self._step()
+                    self._reduce_and_step()
             cur.wait_stream(side)
             _make_capturable(ag.optimizer, dev)
             ag.optimizer.zero_grad(set_to_none=True)
             g = torch.cuda.CUDAGraph()
-            with _capturing(g, self.pool):
-                losses, ys = body()
+            distributed._CAPTURE_COLLECTIVES[0] = self.split_for_allreduce
+            try:
+                with _capturing(g, self.pool):
+                    losses, ys = body()
+            finally:
+                distributed._CAPTURE_COLLECTIVES[0] = False
             if self.pool is None:
                 self.pool = g.pool()
         finally:
@@ -473,7 +526,7 @@ class GraphedUpdate:
         called = False
         for item in entry["plan"]:
             if item == "all_reduce":
-                self.agent.grad_reducer.reduce_flat()
+                self.agent.grad_reducer.reduce_flat(entry["bucket"])
             elif item == "after_forward":
                 if after_forward is not None:
                     after_forward(entry["delta"])

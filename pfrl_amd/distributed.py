@@ -3,11 +3,17 @@
 The reference has no multi-GPU path at all.  Here every
 rank owns its slice of the environments, its own frame ring / replay store /
 priority tree (per-GPU-local replay: no sample ever crosses GPUs) and the same
-network replica; the only collective on the hot path is ONE all-reduce of the
-flattened gradient per optimizer step (6.75 MB fp32 for the Nature DQN).  A
-single flat bucket is used on purpose: xGMI is point-to-point, a ring over it
-is per-link bound, and at this size the collective is latency dominated -- one
-call is better than per-parameter buckets.
+network replica.  Per optimizer step the ranks exchange
+
+* ONE all-reduce of a flat bucket holding every small gradient (the three convolutions and the
+  head of the Nature DQN: 0.32 MB fp32) -- a single call on purpose: xGMI is point-to-point, a
+  ring over it is per-link bound, and at this size the collective is latency dominated;
+* for a large ``Linear`` layer at minibatch size (the 3136 x 512 layer: 6.4 of the network's
+  6.75 MB) NOT its gradient but the two batch matrices the gradient is the product of: an
+  all-gather of ``dy [M, F]`` and ``x [M, K]`` (0.46 MB per rank at M = 32) and a local
+  ``dW = sum_g dy_g^T x_g / G`` -- 3.5 x fewer bytes on the links at G = 8 than all-reducing dW, and
+  it can leave as soon as the layer's backward has run, under the convolution backward
+  (``lowrank_pays``); a large gradient that is not such a product is all-reduced early instead.
 """
 import os
 import weakref
@@ -62,6 +68,37 @@ _EARLY_REDUCERS = weakref.WeakSet()
 _CAPTURE_COLLECTIVES = [False]
 
 
+def lowrank_pays(M, F, K, world=None):
+    """All-gathering the batch matrices of a Linear layer's weight gradient (every rank receives
+    (G - 1) M (F + K) floats) instead of all-reducing the gradient itself (a ring moves
+    2 (G - 1) / G F K floats per rank): only for minibatch-sized M."""
+    world = world_size() if world is None else world
+    if os.environ.get("PFRL_DP_LOWRANK") == "force":
+        # (a one-GPU box exercising the exchange with a single-rank communicator)
+        return M <= 256
+    return world > 1 and M <= 256 and world * M * (F + K) <= F * K
+
+
+def announce_lowrank(weight, bias, dy, x):
+    """Called by the producer of a large Linear layer's gradient INSTEAD of forming it: ``dy``
+    [M, F] (activation mask applied) and ``x`` [M, K] are the layer's batch matrices,
+    dW = dy^T x, db = sum_m dy.  Returns True when a data-parallel reducer took them (it then
+    owns ``weight.grad`` / ``bias.grad`` of this step); False = the caller forms the gradient."""
+    for r in list(_EARLY_REDUCERS):
+        if r.lowrank_ready(weight, bias, dy, x):
+            return True
+    return False
+
+
+def lowrank_wanted(weight, M):
+    """Would :func:`announce_lowrank` be taken for this weight at batch ``M``?  (asked by the MFMA
+    trunk's backward before it decides which launches to make)"""
+    for r in list(_EARLY_REDUCERS):
+        if r.wants_lowrank(weight, M):
+            return True
+    return False
+
+
 def announce_grad(param, grad):
     """Called by a gradient producer (pfrl_amd/nn/mfma_trunk.py backward) right after the
     launch that completes ``grad`` of ``param``: any data-parallel reducer that wants this
@@ -76,6 +113,57 @@ def announce_grad(param, grad):
         if r.grad_ready(target, grad):
             return True
     return False
+
+
+def _lowrank_product(dy_all, x_all, weight):
+    """dW [F, K] = dy_all^T x_all in the layout of ``weight``: the f32 MFMA weight-gradient program
+    on the GPU (csrc/qnet.hip, the same kernel that forms the layer's local gradient), a matmul
+    elsewhere."""
+    F, K = weight.shape
+    M = dy_all.shape[0]
+    if dy_all.is_cuda and K % 32 == 0 and F % 16 == 0 and weight.is_contiguous():
+        import ctypes
+
+        from pfrl_amd import _native
+        from pfrl_amd.nn import mfma_trunk as mt
+
+        if _native.available():
+            splits = mt._wgrad_splits(M, F, K)
+            dw = torch.empty((F, K), dtype=torch.float32, device=dy_all.device)
+            if splits == 1:
+                _native.check(_native.lib().pfrl_conv2d_nhwc_bwd_weight(
+                    mt._p(dy_all), None, mt._p(x_all), mt._p(dw), None, 0, 0, M, 1, 1, K, F, 1, 1, 1, 1,
+                    mt._stream()), "lowrank_bwd_weight")
+                return dw
+            stride = F * K
+            part = torch.empty(splits * stride, dtype=torch.float32, device=dy_all.device)
+            _native.check(_native.lib().pfrl_conv2d_nhwc_bwd_weight(
+                mt._p(dy_all), None, mt._p(x_all), mt._p(part), None, stride, 0, M, 1, 1, K, F, 1, 1, 1,
+                splits, mt._stream()), "lowrank_bwd_weight")
+            mt._reduce([(part, dw, None, stride, stride, splits, 4, 0)])
+            return dw
+    return (dy_all.t() @ x_all).to(weight.dtype).reshape(weight.shape)
+
+
+def _remember_input(module, args, output):
+    if torch.is_grad_enabled() and args and args[0].dim() == 2:
+        module._pfrl_dp_input = args[0].detach()
+
+
+class _LowRankHook:
+    """full-backward hook of an nn.Linear whose weight gradient is exchanged as (dy, x)."""
+
+    def __init__(self, reducer_ref, module):
+        self.ref, self.module = reducer_ref, module
+
+    def __call__(self, module, grad_input, grad_output):
+        r = self.ref()
+        x = getattr(module, "_pfrl_dp_input", None)
+        if r is None or x is None or grad_output[0] is None or grad_output[0].dim() != 2:
+            return None
+        module._pfrl_dp_input = None
+        r.lowrank_ready(module.weight, module.bias, grad_output[0].detach(), x)
+        return None
 
 
 class GradientAllReducer:
@@ -102,6 +190,11 @@ class GradientAllReducer:
         self._early = {id(p): p for p in self.params
                        if early_bytes > 0 and p.numel() * p.element_size() >= early_bytes}
         self._pending = {}      # id(param) -> (work handle or None, gradient tensor)
+        self._flat_sources = None   # the bucket of pack_sources (padded segments, aliases .grad)
+        self._bucket = None         # whichever bucket was packed last: what reduce_flat() reduces
+        self._lowrank = []      # (weight, bias, dy_all, x_all, work handles, kept inputs)
+        self._lowrank_modules = {}   # id(weight) -> nn.Linear whose hooks hand over (dy, x)
+        self._deferred = {}
         self._hooks = []
         if self._early and self.active():
             # weak registration: a reducer lives as long as its agent does (evaluation copies,
@@ -118,6 +211,13 @@ class GradientAllReducer:
             for p in self._early.values():
                 if hasattr(p, "register_post_accumulate_grad_hook"):
                     self._hooks.append(p.register_post_accumulate_grad_hook(on_accumulated))
+            # plain nn.Linear layers with an early-sized weight hand over their batch matrices
+            # when that is the cheaper exchange (autograd still forms dW; it is then not used)
+            for m in module.modules():
+                if type(m) is torch.nn.Linear and id(m.weight) in self._early:
+                    self._lowrank_modules[id(m.weight)] = m
+                    self._hooks.append(m.register_forward_hook(_remember_input))
+                    self._hooks.append(m.register_full_backward_hook(_LowRankHook(ref, m)))
 
     def close(self):
         """Detach from the early-announcement registry and remove the gradient hooks."""
@@ -139,8 +239,22 @@ class GradientAllReducer:
 
     # -- early (per-tensor) collectives ------------------------------------------------
     def _on_accumulated(self, p):
-        if id(p) not in self._pending and p.grad is not None:
-            self.grad_ready(p, p.grad)
+        if id(p) in self._pending or p.grad is None:
+            return
+        m = self._lowrank_modules.get(id(p))
+        x = getattr(m, "_pfrl_dp_input", None) if m is not None else None
+        if x is not None and self.wants_lowrank(p, x.shape[0]):
+            # the layer's backward hook (which has dy) may fire after this one: the choice between
+            # the two exchanges is made there, or by pack() if it never fires
+            self._deferred[id(p)] = p
+            return
+        self.grad_ready(p, p.grad)
+
+    def _start_deferred(self):
+        for p in self._deferred.values():
+            if id(p) not in self._pending and p.grad is not None:
+                self.grad_ready(p, p.grad)
+        self._deferred = {}
 
     def grad_ready(self, param, grad):
         """``grad`` (the tensor that is, or is about to become, ``param.grad``) is complete:
@@ -156,6 +270,55 @@ class GradientAllReducer:
         self._pending[id(param)] = (self._start(grad), grad)
         return True
 
+    # -- low-rank exchange of a large Linear layer's gradient ---------------------------------
+    def _find_early(self, param):
+        if id(param) in self._early:
+            return self._early[id(param)]
+        return next((q for q in self._early.values() if q.data_ptr() == param.data_ptr()), None)
+
+    def wants_lowrank(self, weight, M):
+        if not self.active() or os.environ.get("PFRL_DP_LOWRANK", "1") == "0" or weight.dim() != 2:
+            return False
+        target = self._find_early(weight)
+        return (target is not None and id(target) not in self._pending
+                and lowrank_pays(M, weight.shape[0], weight.shape[1]))
+
+    def lowrank_ready(self, weight, bias, dy, x):
+        """Start the all-gathers of ``dy`` and ``x`` now (RCCL's own stream / gloo's worker); the
+        products are formed in :meth:`_finish_early`.  Same capture rule as :meth:`grad_ready`."""
+        if not self.wants_lowrank(weight, dy.shape[0]):
+            return False
+        if dy.is_cuda and torch.cuda.is_current_stream_capturing() and not _CAPTURE_COLLECTIVES[0]:
+            return False
+        target = self._find_early(weight)
+        if bias is not None:
+            # (a producer may hold another Python object for the same storage)
+            bias = next((q for q in self.params if q.data_ptr() == bias.data_ptr()), None)
+        G = world_size()
+        dy = (dy * (1.0 / G)).contiguous()         # the average: dW = sum_g (dy_g / G)^T x_g
+        x = x.contiguous()
+        dy_all = torch.empty((G * dy.shape[0], dy.shape[1]), dtype=dy.dtype, device=dy.device)
+        x_all = torch.empty((G * x.shape[0], x.shape[1]), dtype=x.dtype, device=x.device)
+        if dist.get_backend() == "nccl":
+            w1 = dist.all_gather_into_tensor(dy_all, dy, async_op=True)
+            w2 = dist.all_gather_into_tensor(x_all, x, async_op=True)
+        else:
+            w1 = dist.all_gather(list(dy_all.chunk(G)), dy, async_op=True)
+            w2 = dist.all_gather(list(x_all.chunk(G)), x, async_op=True)
+        self._pending[id(target)] = (None, None)     # (claims the parameter: no early all-reduce)
+        self._deferred.pop(id(target), None)
+        self._lowrank.append((target, bias, dy_all, x_all, (w1, w2), (dy, x)))
+        return True
+
+    def _finish_lowrank(self):
+        for weight, bias, dy_all, x_all, works, _keep in self._lowrank:
+            for w in works:
+                w.wait()
+            weight.grad = _lowrank_product(dy_all, x_all, weight)
+            if bias is not None:
+                bias.grad = dy_all.sum(dim=0)
+        self._lowrank = []
+
     def _start(self, t):
         if dist.get_backend() == "nccl":
             return dist.all_reduce(t, op=dist.ReduceOp.AVG, async_op=True)
@@ -165,9 +328,10 @@ class GradientAllReducer:
         for work, t in self._pending.values():
             if work is not None:
                 work.wait()
-            if dist.get_backend() != "nccl":
+            if t is not None and dist.get_backend() != "nccl":
                 t.div_(world_size())
         self._pending = {}
+        self._finish_lowrank()
 
     # -- the flat bucket ---------------------------------------------------------------
     def _views(self):
@@ -191,19 +355,82 @@ class GradientAllReducer:
         """gradients -> flat bucket (one multi-tensor copy)."""
         if not self.active():
             return
+        self._start_deferred()
         grads, views = self._views()
         if grads:
             torch._foreach_copy_(views, grads)
+        self._bucket = self._flat
 
-    def reduce_flat(self):
-        """The collective itself: average the flat bucket over all ranks."""
-        if not self.active() or self._flat is None:
+    def current_bucket(self):
+        return self._bucket
+
+    def reduce_flat(self, bucket=None):
+        """The collective itself: average the flat bucket over all ranks (``bucket``: the one a
+        captured plan packed into; default = the one packed last)."""
+        bucket = self._bucket if bucket is None else bucket
+        if not self.active() or bucket is None:
             return
         if dist.get_backend() == "nccl":
-            dist.all_reduce(self._flat, op=dist.ReduceOp.AVG)   # RCCL averages in the collective
+            dist.all_reduce(bucket, op=dist.ReduceOp.AVG)   # RCCL averages in the collective
         else:
-            dist.all_reduce(self._flat, op=dist.ReduceOp.SUM)
-            self._flat.div_(world_size())
+            dist.all_reduce(bucket, op=dist.ReduceOp.SUM)
+            bucket.div_(world_size())
+
+    # -- gradients that are still split-K slabs (the fused optimizer path) ----------------------
+    def pack_sources(self, sources):
+        """The data-parallel form of "the optimizer finishes the gradients" (GraphedUpdate): the
+        backward pass left most small gradients as split-K slabs (``GradSource.slabs``) and never
+        materialised them.  ONE multi-tensor fold launch sums every parameter's slabs straight
+        into its segment of the flat bucket (the fold that would otherwise run inside the optimizer
+        launch, writing where the collective reads: no pack copy), plain gradients are copied in
+        beside them, and every such parameter's ``.grad`` becomes its (reduced-in-place) segment --
+        so there is no unpack copy either.  Handled sources are removed from ``sources``."""
+        if not self.active():
+            return
+        from pfrl_amd.nn import mfma_trunk as mt
+        from pfrl_amd.optimizers import OPT_SLABS
+
+        self._start_deferred()
+        plan, n = [], 0
+        for p in self.params:
+            if id(p) in self._pending:
+                continue
+            src = sources.get(p)
+            if src is not None and src.mode != OPT_SLABS:
+                continue                    # (stepped already / not a gradient that crosses ranks)
+            if src is None and p.grad is None:
+                continue
+            plan.append((p, src, n))
+            n += (p.numel() + 3) & ~3       # 16-byte aligned segments (float4 stores of the fold)
+        if not plan:
+            self._bucket = None
+            return
+        dev = plan[0][0].device
+        flat = self._flat_sources
+        if flat is None or flat.numel() != n or flat.device != dev:
+            flat = self._flat_sources = torch.zeros(n, dtype=torch.float32, device=dev)
+        self._bucket = flat
+        tasks, dst, srcs = [], [], []
+        for p, src, off in plan:
+            seg = flat[off:off + p.numel()]
+            view = seg.as_strided(p.size(), p.stride())     # the parameter's own (dense) layout
+            if src is not None:
+                tasks.append((src.src, seg, None, src.stride, p.numel(), src.n_slabs, 4, 0))
+                del sources[p]
+            else:
+                dst.append(view)
+                srcs.append(p.grad)
+            p.grad = view
+        for i in range(0, len(tasks), 12):
+            mt._reduce(tasks[i:i + 12])
+        if dst:
+            torch._foreach_copy_(dst, srcs)
+
+    def finish_sources(self):
+        """After :meth:`reduce_flat`: join the early all-reduces and low-rank exchanges (the flat
+        segments ARE the gradients already)."""
+        if self.active():
+            self._finish_early()
 
     def unpack(self):
         """flat bucket -> gradients; joins the early all-reduces."""
@@ -226,6 +453,59 @@ class GradientAllReducer:
             return
         for t in list(module.parameters()) + list(module.buffers()):
             dist.broadcast(t.data, src=src)
+
+
+_CAPTURE_PROBE = {}
+
+
+def captured_collectives_work(device, timeout_s=20.0):
+    """Can an RCCL collective be captured in a HIP graph and replayed on THIS process group?
+    Decided once per group by a probe instead of by hoping: a 1 024-element all-reduce is captured,
+    replayed twice, its completion awaited by polling an event for at most ``timeout_s`` and its
+    result checked; the verdict is then agreed between the ranks (MIN over an eager all-reduce), so
+    that every rank builds the same plan.  A probe that hangs leaves that tiny graph behind and the
+    caller on the split plan (graph -> eager collective -> graph), which needs no capture support."""
+    import time
+
+    if not (dist.is_available() and dist.is_initialized() and dist.get_backend() == "nccl"):
+        return False
+    key = (id(dist.group.WORLD), str(device))
+    if key in _CAPTURE_PROBE:
+        return _CAPTURE_PROBE[key]
+    ok = 0.0
+    try:
+        world = dist.get_world_size()
+        buf = torch.ones(1024, dtype=torch.float32, device=device)
+        side = torch.cuda.Stream(device)
+        side.wait_stream(torch.cuda.current_stream(device))
+        with torch.cuda.stream(side):
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM)       # communicator warm-up, eager
+            buf.fill_(1.0)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
+                dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+            done = torch.cuda.Event()
+            g.replay()
+            g.replay()
+            done.record(side)
+        t0 = time.time()
+        while not done.query() and time.time() - t0 < timeout_s:
+            time.sleep(0.002)
+        if done.query():
+            want = float(world) ** 2
+            ok = 1.0 if bool((buf == want).all().item()) else 0.0
+            torch.cuda.current_stream(device).wait_stream(side)
+        # (timed out: the side stream is left alone -- waiting on it would hang this stream too)
+    except Exception:            # capture refused, communicator error: the split plan it is
+        ok = 0.0
+    try:
+        verdict = torch.tensor([ok], dtype=torch.float32, device=device)
+        dist.all_reduce(verdict, op=dist.ReduceOp.MIN)
+        ok = float(verdict.item())
+    except Exception:
+        ok = 0.0
+    _CAPTURE_PROBE[key] = ok > 0.5
+    return _CAPTURE_PROBE[key]
 
 
 def broadcast_agent(agent, src=0):

@@ -407,6 +407,23 @@ class _Trunk(torch.autograd.Function):
             OPT_SOURCES[params[2 * L + 1].data_ptr()] = GradSource.lowrank_bias(dh, out)
             grads = [None] * (2 * L + 2)
             return _Trunk._conv_backward(ctx, specs, params, acts, x, dy, N, dev, grads)
+        if _dist_initialized():
+            from pfrl_amd.distributed import announce_lowrank, lowrank_wanted
+
+            if lowrank_wanted(wf, N):
+                # data parallel at minibatch size: the layer's weight gradient is not formed here
+                # at all.  Its batch matrices (dh with the ReLU mask applied, and the layer's input)
+                # leave NOW for an all-gather under the convolution backward below; every rank
+                # then forms dW = sum_g dh_g^T x_g / G itself (distributed.py: 0.46 MB per rank on
+                # the links instead of a 6.4 MB all-reduce)
+                dhm = torch.ops.aten.threshold_backward(dh, out, 0.0)
+                check(lib.pfrl_conv2d_nhwc_bwd_data(_p(dhm), None, _p(wf), _p(acts[-1]), _p(dy), N, 1,
+                                                    1, Kf, F, 1, 1, 1, P, last.Cout, _stream()),
+                      "linear_bwd_data")
+                if announce_lowrank(wf, params[2 * L + 1], dhm, acts[-1].view(N, Kf)):
+                    grads = [None] * (2 * L + 2)
+                    return _Trunk._conv_backward(ctx, specs, params, acts, x, dy, N, dev, grads)
+                # (not taken after all, e.g. a capture without collectives: the gradient below)
         dwf = torch.empty_like(wf)
         dbf = torch.empty(F, dtype=torch.float32, device=dev)
         if _fused_bwd_ok(N, 1, 1, Kf, 1):

@@ -140,6 +140,72 @@ def test_early_all_reduce_of_the_large_gradient_equals_single_bucket(tmp_path):
     assert np.array_equal(g0, g1) and np.abs(g0).sum() > 0
 
 
+def _lowrank_worker(rank, world, port, out_dir):
+    """Low-rank exchange of a large Linear layer's gradient (all-gather of dy and x, local
+    dW = sum_g dy_g^T x_g / G) against the flat all-reduce plan and against ONE process on the
+    concatenated batch: 20 RMSprop updates, parameters compared after each plan."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import copy
+
+    import torch.distributed as dist
+
+    from pfrl_amd import distributed
+
+    distributed.init_process_group_from_env(backend="gloo")
+    torch.manual_seed(5)
+    base = torch.nn.Sequential(torch.nn.Linear(16, 256), torch.nn.ReLU(), torch.nn.Linear(256, 512),
+                               torch.nn.ReLU(), torch.nn.Linear(512, 3))
+    M = 4
+    assert distributed.lowrank_pays(M, 512, 256, world) and not distributed.lowrank_pays(4096, 512, 256, world)
+    nets = {k: copy.deepcopy(base) for k in ("lowrank", "flat", "one")}
+    red = {"lowrank": distributed.GradientAllReducer(nets["lowrank"], early_bytes=100_000),
+           "flat": distributed.GradientAllReducer(nets["flat"], early_bytes=0)}
+    assert len(red["lowrank"]._early) == 1 and len(red["lowrank"]._lowrank_modules) == 1
+    opts = {k: torch.optim.RMSprop(n.parameters(), lr=1e-3, alpha=0.95, eps=1e-2, centered=True)
+            for k, n in nets.items()}
+    taken = []
+    orig = red["lowrank"].lowrank_ready
+    red["lowrank"].lowrank_ready = lambda *a: (taken.append(orig(*a)), taken[-1])[1]
+    started = []
+    orig_start = red["lowrank"]._start
+    red["lowrank"]._start = lambda t: (started.append(tuple(t.shape)), orig_start(t))[1]
+    for step in range(20):
+        gen = torch.Generator().manual_seed(1000 + step)
+        xs = torch.randn(world * M, 16, generator=gen)
+        ys = torch.randn(world * M, 3, generator=gen)
+        mine = slice(rank * M, (rank + 1) * M)
+        for k in ("lowrank", "flat"):
+            opts[k].zero_grad(set_to_none=True)
+            # (sum over the shard, averaged over ranks by the reducer = mean over ranks of shard sums)
+            torch.nn.functional.mse_loss(nets[k](xs[mine]), ys[mine], reduction="sum").backward()
+            red[k].all_reduce()
+            assert not red[k]._pending and not red[k]._lowrank
+            opts[k].step()
+        opts["one"].zero_grad(set_to_none=True)
+        (torch.nn.functional.mse_loss(nets["one"](xs), ys, reduction="sum") / world).backward()
+        opts["one"].step()
+    assert taken == [True] * 20 and started == []     # never the all-reduce of the 512 x 256 gradient
+    flat = {k: torch.cat([p.detach().reshape(-1) for p in n.parameters()]) for k, n in nets.items()}
+    scale = float(flat["one"].abs().max())
+    assert float((flat["lowrank"] - flat["flat"]).abs().max()) <= 1e-6 * scale
+    assert float((flat["lowrank"] - flat["one"]).abs().max()) <= 1e-6 * scale
+    np.save(os.path.join(out_dir, "lowrank%d.npy" % rank), flat["lowrank"].numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_lowrank_all_gather_of_a_large_linear_gradient_equals_the_flat_all_reduce(tmp_path):
+    """parameters after 20 updates are those of the flat all-reduce plan and
+    of a single process on the concatenated batch (<= 1e-6), identical on both ranks, and the
+    large gradient itself never crosses the link."""
+    port = _free_port()
+    mp.spawn(_lowrank_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    g0, g1 = (np.load(os.path.join(str(tmp_path), "lowrank%d.npy" % r)) for r in (0, 1))
+    assert np.array_equal(g0, g1) and np.abs(g0).sum() > 0
+
+
 def test_gradient_all_reduce_two_ranks_gloo(tmp_path):
     world = 2
     port = _free_port()
