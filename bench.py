@@ -13,8 +13,10 @@ fused batch_experiences gather, Huber loss, backward, centered RMSprop) ->
 env.reset(not_end).  BASELINE.json config[1]: DQN, Nature CNN,
 ReplayBuffer(10**6) prefilled to capacity, B=32, update_interval=4,
 batch_accumulator='sum', fp32 network.  Nothing is skipped inside the timed
-region.  N GPUs = N ranks with 256 envs each (weak scaling), per-GPU-local
-replay, one flat RCCL all-reduce of the gradient per update.
+region.  N GPUs = N ranks, the metric's 256 envs sharded 256 / N per rank (strong
+scaling, the default; --scaling weak keeps 256 per rank), per-GPU-local replay,
+per update one flat RCCL all-reduce of the small gradients + an all-gather of the
+hidden layer's batch matrices (pfrl_amd/distributed.py).
 
 Prints ONE JSON line on rank 0 (see DESIGN.md section "Measurement").
 """

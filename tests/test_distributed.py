@@ -265,12 +265,16 @@ def test_data_parallel_graph_plans_match_reference(prioritized, backend, tmp_pat
             got = T._run("dqn", False, 1, False, gpu=0)
         ag = got["agent"]
         assert ag._graphed is not None and ag._graphed.split_for_allreduce
-        plans = [e["plan"] for e in ag._graphed.graphs.values()]
-        assert plans
+        entries = list(ag._graphed.graphs.values())
+        plans = [e["plan"] for e in entries if "plan" in e]
+        assert entries
         if backend == "nccl":
-            assert ag._graphed.graph_collective
+            assert ag._graphed.graph_collective not in ("0", False)
             assert all("all_reduce" not in p for p in plans)
             assert all(len(p) == (3 if prioritized else 1) for p in plans)
+            if not prioritized:
+                # with the collective inside the graph a whole env range replays as one graph
+                assert any("graph" in e for e in entries)
         else:
             assert all("all_reduce" in p for p in plans)
         assert ag.grad_reducer._flat is not None
