@@ -840,6 +840,9 @@ def run_workload(args, device, rank, world, result_extras=True):
     t_fill = time.perf_counter() - t_fill
 
     def barrier():
+        # (the process group is the control plane -- gloo by default, pfrl_amd/distributed.py -- so the
+        # barrier is a host rendezvous: the device is drained before AND after it)
+        torch.cuda.synchronize()
         if torch.distributed.is_initialized():
             torch.distributed.barrier()
 
@@ -877,7 +880,9 @@ def run_workload(args, device, rank, world, result_extras=True):
     n_updates = updates_done() - optim_before
 
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        tmax = torch.tensor([elapsed], dtype=torch.float64)
+        if torch.distributed.get_backend() == "nccl":
+            tmax = tmax.to(device)
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
@@ -994,6 +999,10 @@ def main():
             if pref is not None:
                 out["cpu_baseline"] = pref
     if torch.distributed.is_initialized():
+        from pfrl_amd import rccl
+
+        torch.cuda.synchronize()
+        rccl.destroy_all()
         torch.distributed.destroy_process_group()
     sys.stdout.flush()
     if rank == 0:

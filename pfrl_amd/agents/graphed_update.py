@@ -316,8 +316,10 @@ class GraphedUpdate:
 
     def _collective_capturable(self):
         d = torch.distributed
-        if not (d.is_available() and d.is_initialized() and d.get_backend() == "nccl"):
+        if not (d.is_available() and d.is_initialized()):
             return False
+        if self.agent.grad_reducer._comm is None and d.get_backend() != "nccl":
+            return False            # (gloo on host buffers: nothing a HIP graph could hold)
         if self.graph_collective == "auto":
             # decided once, by a probe every rank takes part in (never from inside a capture)
             self.graph_collective = "1" if distributed.captured_collectives_work(

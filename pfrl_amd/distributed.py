@@ -33,8 +33,12 @@ def init_process_group_from_env(backend=None):
     always = os.environ.get("PFRL_DIST_ALWAYS") == "1"
     if (world > 1 or always) and not dist.is_initialized():
         if backend is None:
+            # the per-update collectives are driven directly on RCCL (pfrl_amd/rccl.py); the
+            # process group is the control plane only, and on gloo there is no NCCL watchdog
+            # thread in the process (its event polls abort HIP-graph captures on this stack)
+            direct = os.environ.get("PFRL_RCCL_DIRECT", "1") != "0"
             backend = os.environ.get("PFRL_DIST_BACKEND") or (
-                "nccl" if torch.cuda.is_available() else "gloo")
+                "nccl" if torch.cuda.is_available() and not direct else "gloo")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         kw = {}
@@ -166,6 +170,17 @@ class _LowRankHook:
         return None
 
 
+class _SideJoin:
+    """wait() = the current stream waits for everything enqueued on the communicator's side
+    stream so far (a stream wait: no host synchronisation, capturable)."""
+
+    def __init__(self, side, device):
+        self.side, self.device = side, device
+
+    def wait(self):
+        torch.cuda.current_stream(self.device).wait_stream(self.side)
+
+
 class GradientAllReducer:
     """Average gradients across ranks: one flat all-reduce per step for the small tensors, and
     -- ``early_bytes`` -- separate, EARLY all-reduces for the few large ones.
@@ -190,6 +205,11 @@ class GradientAllReducer:
         self._early = {id(p): p for p in self.params
                        if early_bytes > 0 and p.numel() * p.element_size() >= early_bytes}
         self._pending = {}      # id(param) -> (work handle or None, gradient tensor)
+        self._comm = None           # pfrl_amd.rccl.Communicator for CUDA parameters (data plane)
+        if self.params and self.params[0].is_cuda and dist.is_available() and dist.is_initialized():
+            from pfrl_amd import rccl
+
+            self._comm = rccl.default_comm(self.params[0].device)      # (collective on first use)
         self._flat_sources = None   # the bucket of pack_sources (padded segments, aliases .grad)
         self._bucket = None         # whichever bucket was packed last: what reduce_flat() reduces
         self._lowrank = []      # (weight, bias, dy_all, x_all, work handles, kept inputs)
@@ -299,7 +319,14 @@ class GradientAllReducer:
         x = x.contiguous()
         dy_all = torch.empty((G * dy.shape[0], dy.shape[1]), dtype=dy.dtype, device=dy.device)
         x_all = torch.empty((G * x.shape[0], x.shape[1]), dtype=x.dtype, device=x.device)
-        if dist.get_backend() == "nccl":
+        if self._comm is not None and dy.is_cuda:
+            cur = torch.cuda.current_stream(dy.device)
+            self._comm.side.wait_stream(cur)
+            with self._comm.group():
+                self._comm.all_gather(dy_all, dy, stream=self._comm.side)
+                self._comm.all_gather(x_all, x, stream=self._comm.side)
+            w1 = w2 = _SideJoin(self._comm.side, dy.device)
+        elif dist.get_backend() == "nccl":
             w1 = dist.all_gather_into_tensor(dy_all, dy, async_op=True)
             w2 = dist.all_gather_into_tensor(x_all, x, async_op=True)
         else:
@@ -319,7 +346,17 @@ class GradientAllReducer:
                 bias.grad = dy_all.sum(dim=0)
         self._lowrank = []
 
+    def _averages(self, t):
+        """Does the backend that will reduce ``t`` average by itself?"""
+        return (self._comm is not None and t.is_cuda) or dist.get_backend() == "nccl"
+
     def _start(self, t):
+        if self._comm is not None and t.is_cuda:
+            # beside the compute stream: fork, enqueue, and let wait() join
+            cur = torch.cuda.current_stream(t.device)
+            self._comm.side.wait_stream(cur)
+            self._comm.all_reduce(t, average=True, stream=self._comm.side)
+            return _SideJoin(self._comm.side, t.device)
         if dist.get_backend() == "nccl":
             return dist.all_reduce(t, op=dist.ReduceOp.AVG, async_op=True)
         return dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True)
@@ -328,7 +365,7 @@ class GradientAllReducer:
         for work, t in self._pending.values():
             if work is not None:
                 work.wait()
-            if t is not None and dist.get_backend() != "nccl":
+            if t is not None and not self._averages(t):
                 t.div_(world_size())
         self._pending = {}
         self._finish_lowrank()
@@ -370,7 +407,9 @@ class GradientAllReducer:
         bucket = self._bucket if bucket is None else bucket
         if not self.active() or bucket is None:
             return
-        if dist.get_backend() == "nccl":
+        if self._comm is not None and bucket.is_cuda:
+            self._comm.all_reduce(bucket, average=True)     # stream-ordered on the current stream
+        elif dist.get_backend() == "nccl":
             dist.all_reduce(bucket, op=dist.ReduceOp.AVG)   # RCCL averages in the collective
         else:
             dist.all_reduce(bucket, op=dist.ReduceOp.SUM)
@@ -467,11 +506,23 @@ def captured_collectives_work(device, timeout_s=20.0):
     caller on the split plan (graph -> eager collective -> graph), which needs no capture support."""
     import time
 
-    if not (dist.is_available() and dist.is_initialized() and dist.get_backend() == "nccl"):
+    from pfrl_amd import rccl
+
+    if not (dist.is_available() and dist.is_initialized()):
         return False
-    key = (id(dist.group.WORLD), str(device))
+    comm = rccl.default_comm(device)
+    if comm is None and dist.get_backend() != "nccl":
+        return False
+    key = (dist.distributed_c10d._world.group_count, str(device), comm is not None)
     if key in _CAPTURE_PROBE:
         return _CAPTURE_PROBE[key]
+
+    def all_reduce_sum(t):
+        if comm is not None:
+            comm.all_reduce(t, average=False)
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+
     ok = 0.0
     try:
         world = dist.get_world_size()
@@ -479,11 +530,11 @@ def captured_collectives_work(device, timeout_s=20.0):
         side = torch.cuda.Stream(device)
         side.wait_stream(torch.cuda.current_stream(device))
         with torch.cuda.stream(side):
-            dist.all_reduce(buf, op=dist.ReduceOp.SUM)       # communicator warm-up, eager
+            all_reduce_sum(buf)                              # communicator warm-up, eager
             buf.fill_(1.0)
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
-                dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+                all_reduce_sum(buf)
             done = torch.cuda.Event()
             g.replay()
             g.replay()
@@ -499,7 +550,9 @@ def captured_collectives_work(device, timeout_s=20.0):
     except Exception:            # capture refused, communicator error: the split plan it is
         ok = 0.0
     try:
-        verdict = torch.tensor([ok], dtype=torch.float32, device=device)
+        verdict = torch.tensor([ok], dtype=torch.float32)       # (control plane: a host tensor)
+        if dist.get_backend() == "nccl":
+            verdict = verdict.to(device)
         dist.all_reduce(verdict, op=dist.ReduceOp.MIN)
         ok = float(verdict.item())
     except Exception:

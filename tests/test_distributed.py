@@ -256,6 +256,9 @@ def test_data_parallel_graph_plans_match_reference(prioritized, backend, tmp_pat
                             world_size=1, **kw)
     os.environ["PFRL_FORCE_SPLIT_GRAPH"] = "1"
     os.environ["PFRL_GRAPH_COLLECTIVE"] = "1"    # captured collective where the backend allows
+    # gloo: the process group itself carries the gradients (host round trip, eager, between two
+    # graphs); nccl: the data plane is the directly driven RCCL communicator, inside the graph
+    os.environ["PFRL_RCCL_DIRECT"] = "0" if backend == "gloo" else "1"
     try:
         if prioritized:
             g = np.load(os.path.join(T.GOLDEN, "agent_trace_ddqn_per_n3.npz"))
@@ -282,6 +285,7 @@ def test_data_parallel_graph_plans_match_reference(prioritized, backend, tmp_pat
     finally:
         os.environ.pop("PFRL_FORCE_SPLIT_GRAPH", None)
         os.environ.pop("PFRL_GRAPH_COLLECTIVE", None)
+        os.environ.pop("PFRL_RCCL_DIRECT", None)
         dist.destroy_process_group()
 
 

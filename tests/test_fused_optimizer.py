@@ -218,6 +218,8 @@ def test_data_parallel_update_keeps_the_fused_forms(backend, tmp_path, monkeypat
                             world_size=1, **kw)
     monkeypatch.setenv("PFRL_FORCE_SPLIT_GRAPH", "1")
     monkeypatch.setenv("PFRL_DP_LOWRANK", "force")
+    # nccl: the directly driven RCCL communicator (pfrl_amd/rccl.py); gloo: the process group itself
+    monkeypatch.setenv("PFRL_RCCL_DIRECT", "1" if backend == "nccl" else "0")
     taken = []
     orig = distributed.GradientAllReducer.lowrank_ready
 
