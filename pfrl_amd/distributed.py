@@ -83,13 +83,14 @@ def lowrank_pays(M, F, K, world=None):
     return world > 1 and M <= 256 and world * M * (F + K) <= F * K
 
 
-def announce_lowrank(weight, bias, dy, x):
+def announce_lowrank(weight, bias, dy, x, mask=None):
     """Called by the producer of a large Linear layer's gradient INSTEAD of forming it: ``dy``
-    [M, F] (activation mask applied) and ``x`` [M, K] are the layer's batch matrices,
-    dW = dy^T x, db = sum_m dy.  Returns True when a data-parallel reducer took them (it then
-    owns ``weight.grad`` / ``bias.grad`` of this step); False = the caller forms the gradient."""
+    [M, F] and ``x`` [M, K] are the layer's batch matrices (``mask``: the layer's output when its
+    ReLU mask has not been applied to ``dy`` yet), dW = dy^T x, db = sum_m dy.  Returns True when a
+    data-parallel reducer took them (it then owns ``weight.grad`` / ``bias.grad`` of this step);
+    False = the caller forms the gradient."""
     for r in list(_EARLY_REDUCERS):
-        if r.lowrank_ready(weight, bias, dy, x):
+        if r.lowrank_ready(weight, bias, dy, x, mask):
             return True
     return False
 
@@ -119,34 +120,44 @@ def announce_grad(param, grad):
     return False
 
 
-def _lowrank_product(dy_all, x_all, weight):
-    """dW [F, K] = dy_all^T x_all in the layout of ``weight``: the f32 MFMA weight-gradient program
-    on the GPU (csrc/qnet.hip, the same kernel that forms the layer's local gradient), a matmul
-    elsewhere."""
+def _lowrank_product(dy_all, x_all, weight, dw=None, db=None):
+    """dW [F, K] = dy_all^T x_all in the layout of ``weight`` and db [F] = column sums of dy_all:
+    the f32 MFMA weight-gradient program on the GPU (csrc/qnet.hip, the same kernel that forms the
+    layer's local gradient; it writes the bias gradient beside it), a matmul elsewhere.  ``dw`` /
+    ``db``: preallocated outputs (the caller's stream owns them)."""
     F, K = weight.shape
     M = dy_all.shape[0]
     if dy_all.is_cuda and K % 32 == 0 and F % 16 == 0 and weight.is_contiguous():
-        import ctypes
-
         from pfrl_amd import _native
         from pfrl_amd.nn import mfma_trunk as mt
 
         if _native.available():
             splits = mt._wgrad_splits(M, F, K)
-            dw = torch.empty((F, K), dtype=torch.float32, device=dy_all.device)
+            dev = dy_all.device
+            dw = torch.empty((F, K), dtype=torch.float32, device=dev) if dw is None else dw
+            db = torch.empty(F, dtype=torch.float32, device=dev) if db is None else db
             if splits == 1:
                 _native.check(_native.lib().pfrl_conv2d_nhwc_bwd_weight(
-                    mt._p(dy_all), None, mt._p(x_all), mt._p(dw), None, 0, 0, M, 1, 1, K, F, 1, 1, 1, 1,
-                    mt._stream()), "lowrank_bwd_weight")
-                return dw
-            stride = F * K
-            part = torch.empty(splits * stride, dtype=torch.float32, device=dy_all.device)
+                    mt._p(dy_all), None, mt._p(x_all), mt._p(dw), mt._p(db), 0, 0, M, 1, 1, K, F, 1, 1, 1,
+                    1, mt._stream()), "lowrank_bwd_weight")
+                return dw, db
+            stride = F * K + F
+            part = torch.empty(splits * stride, dtype=torch.float32, device=dev)
             _native.check(_native.lib().pfrl_conv2d_nhwc_bwd_weight(
-                mt._p(dy_all), None, mt._p(x_all), mt._p(part), None, stride, 0, M, 1, 1, K, F, 1, 1, 1,
-                splits, mt._stream()), "lowrank_bwd_weight")
-            mt._reduce([(part, dw, None, stride, stride, splits, 4, 0)])
-            return dw
-    return (dy_all.t() @ x_all).to(weight.dtype).reshape(weight.shape)
+                mt._p(dy_all), None, mt._p(x_all), mt._p(part), mt._p(part[F * K:]), stride, stride, M, 1,
+                1, K, F, 1, 1, 1, splits, mt._stream()), "lowrank_bwd_weight")
+            mt._reduce([(part, dw, None, stride, F * K, splits, 4, 0),
+                        (part[F * K:], db, None, stride, F, splits, 4, 0)])
+            return dw, db
+    g = (dy_all.t() @ x_all).to(weight.dtype).reshape(weight.shape)
+    s = dy_all.sum(dim=0)
+    if dw is not None:
+        dw.copy_(g)
+        g = dw
+    if db is not None:
+        db.copy_(s)
+        s = db
+    return g, s
 
 
 def _remember_input(module, args, output):
@@ -303,9 +314,13 @@ class GradientAllReducer:
         return (target is not None and id(target) not in self._pending
                 and lowrank_pays(M, weight.shape[0], weight.shape[1]))
 
-    def lowrank_ready(self, weight, bias, dy, x):
-        """Start the all-gathers of ``dy`` and ``x`` now (RCCL's own stream / gloo's worker); the
-        products are formed in :meth:`_finish_early`.  Same capture rule as :meth:`grad_ready`."""
+    def lowrank_ready(self, weight, bias, dy, x, mask=None):
+        """Exchange this layer's gradient as its batch matrices, starting now: ``dy`` [M, F] (with
+        ``mask``: the layer's output, its ReLU mask still to be applied), ``x`` [M, K].  On the GPU
+        with the directly driven communicator EVERYTHING happens on its side stream, beside the
+        backward launches that follow on the caller's: mask and 1/G scale, the two all-gathers,
+        the product dW = sum_g dy_g^T x_g and the bias sums; :meth:`_finish_early` only joins the
+        stream and hands the finished tensors over.  Same capture rule as :meth:`grad_ready`."""
         if not self.wants_lowrank(weight, dy.shape[0]):
             return False
         if dy.is_cuda and torch.cuda.is_current_stream_capturing() and not _CAPTURE_COLLECTIVES[0]:
@@ -315,35 +330,51 @@ class GradientAllReducer:
             # (a producer may hold another Python object for the same storage)
             bias = next((q for q in self.params if q.data_ptr() == bias.data_ptr()), None)
         G = world_size()
-        dy = (dy * (1.0 / G)).contiguous()         # the average: dW = sum_g (dy_g / G)^T x_g
-        x = x.contiguous()
-        dy_all = torch.empty((G * dy.shape[0], dy.shape[1]), dtype=dy.dtype, device=dy.device)
-        x_all = torch.empty((G * x.shape[0], x.shape[1]), dtype=x.dtype, device=x.device)
-        if self._comm is not None and dy.is_cuda:
-            cur = torch.cuda.current_stream(dy.device)
-            self._comm.side.wait_stream(cur)
-            with self._comm.group():
-                self._comm.all_gather(dy_all, dy, stream=self._comm.side)
-                self._comm.all_gather(x_all, x, stream=self._comm.side)
-            w1 = w2 = _SideJoin(self._comm.side, dy.device)
-        elif dist.get_backend() == "nccl":
-            w1 = dist.all_gather_into_tensor(dy_all, dy, async_op=True)
-            w2 = dist.all_gather_into_tensor(x_all, x, async_op=True)
-        else:
-            w1 = dist.all_gather(list(dy_all.chunk(G)), dy, async_op=True)
-            w2 = dist.all_gather(list(x_all.chunk(G)), x, async_op=True)
+
+        def prepared():
+            d = dy if mask is None else torch.ops.aten.threshold_backward(dy, mask, 0.0)
+            if G > 1:
+                d = d * (1.0 / G)                  # the average: dW = sum_g (dy_g / G)^T x_g
+            d, xx = d.contiguous(), x.contiguous()
+            return (d, xx, torch.empty((G * d.shape[0], d.shape[1]), dtype=d.dtype, device=d.device),
+                    torch.empty((G * xx.shape[0], xx.shape[1]), dtype=xx.dtype, device=xx.device))
+
         self._pending[id(target)] = (None, None)     # (claims the parameter: no early all-reduce)
         self._deferred.pop(id(target), None)
-        self._lowrank.append((target, bias, dy_all, x_all, (w1, w2), (dy, x)))
+        if self._comm is not None and dy.is_cuda:
+            side = self._comm.side
+            # outputs belong to the caller's stream (allocated before the fork), temporaries to the
+            # side stream: no block changes streams while a kernel of the other may still use it
+            dw = torch.empty(tuple(target.shape), dtype=torch.float32, device=dy.device)
+            db = torch.empty(target.shape[0], dtype=torch.float32, device=dy.device)
+            side.wait_stream(torch.cuda.current_stream(dy.device))
+            with torch.cuda.stream(side):
+                d, xx, dy_all, x_all = prepared()
+                with self._comm.group():
+                    self._comm.all_gather(dy_all, d, stream=side)
+                    self._comm.all_gather(x_all, xx, stream=side)
+                _lowrank_product(dy_all, x_all, target, dw, db)
+            self._lowrank.append((target, bias, (_SideJoin(side, dy.device),), (dw, db),
+                                  (d, xx, dy_all, x_all, dy, x, mask)))
+            return True
+        d, xx, dy_all, x_all = prepared()
+        if dist.get_backend() == "nccl":
+            works = (dist.all_gather_into_tensor(dy_all, d, async_op=True),
+                     dist.all_gather_into_tensor(x_all, xx, async_op=True))
+        else:
+            works = (dist.all_gather(list(dy_all.chunk(G)), d, async_op=True),
+                     dist.all_gather(list(x_all.chunk(G)), xx, async_op=True))
+        self._lowrank.append((target, bias, works, None, (d, xx, dy_all, x_all)))
         return True
 
     def _finish_lowrank(self):
-        for weight, bias, dy_all, x_all, works, _keep in self._lowrank:
+        for weight, bias, works, done, keep in self._lowrank:
             for w in works:
                 w.wait()
-            weight.grad = _lowrank_product(dy_all, x_all, weight)
+            dw, db = done if done is not None else _lowrank_product(keep[2], keep[3], weight)
+            weight.grad = dw
             if bias is not None:
-                bias.grad = dy_all.sum(dim=0)
+                bias.grad = db
         self._lowrank = []
 
     def _averages(self, t):

@@ -416,11 +416,12 @@ class _Trunk(torch.autograd.Function):
                 # leave NOW for an all-gather under the convolution backward below; every rank
                 # then forms dW = sum_g dh_g^T x_g / G itself (distributed.py: 0.46 MB per rank on
                 # the links instead of a 6.4 MB all-reduce)
-                dhm = torch.ops.aten.threshold_backward(dh, out, 0.0)
-                check(lib.pfrl_conv2d_nhwc_bwd_data(_p(dhm), None, _p(wf), _p(acts[-1]), _p(dy), N, 1,
-                                                    1, Kf, F, 1, 1, 1, P, last.Cout, _stream()),
-                      "linear_bwd_data")
-                if announce_lowrank(wf, params[2 * L + 1], dhm, acts[-1].view(N, Kf)):
+                # (mask, scale, all-gathers, product: all on the communicator's side stream; this
+                # stream goes straight on with the input gradient, mask applied in the kernel)
+                if announce_lowrank(wf, params[2 * L + 1], dh, acts[-1].view(N, Kf), mask=out):
+                    check(lib.pfrl_conv2d_nhwc_bwd_data(_p(dh), _p(out), _p(wf), _p(acts[-1]), _p(dy), N,
+                                                        1, 1, Kf, F, 1, 1, 1, P, last.Cout, _stream()),
+                          "linear_bwd_data")
                     grads = [None] * (2 * L + 2)
                     return _Trunk._conv_backward(ctx, specs, params, acts, x, dy, N, dev, grads)
                 # (not taken after all, e.g. a capture without collectives: the gradient below)
