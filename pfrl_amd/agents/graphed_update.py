@@ -201,9 +201,13 @@ class GraphedUpdate:
             head = ab[2] if len(ab) > 2 else ()
             defer = bool(head) and bool(mfma_trunk._DEFERRED_FOLDS) and \
                 self._optimizer_finishes_gradients()
+            red = self.agent.grad_reducer
             if defer:
                 mfma_trunk.OPT_SOURCES = {}
                 mfma_trunk.RIDE_ALONG = self.agent.optimizer
+                # data parallel: a layer whose gradient is exchanged as its batch matrices is
+                # stepped where the product is formed, on the communicator's side stream
+                red.lowrank_step = self._step_on_side_stream
             try:
                 if ab[0].requires_grad:
                     torch.autograd.backward([ab[0]], [ab[1]])
@@ -211,6 +215,7 @@ class GraphedUpdate:
             finally:
                 mfma_trunk.OPT_SOURCES = None
                 mfma_trunk.RIDE_ALONG = None
+                red.lowrank_step = None
             if defer and sources:
                 # the head's per-row partials (queued by the loss launch for "the fold that ends
                 # the trunk's backward") become sources / folds of the optimizer launch too
@@ -231,6 +236,19 @@ class GraphedUpdate:
                     p.grad = g if p.grad is None else p.grad + g
         else:
             loss.backward()
+
+    def _step_on_side_stream(self, weight, bias, dw, db):
+        from pfrl_amd.nn import mfma_trunk
+        from pfrl_amd.optimizers import GradSource
+
+        if os.environ.get("PFRL_DP_SIDE_STEP", "1") == "0" or mfma_trunk.OPT_SOURCES is None:
+            return False
+        pairs = [(weight, dw)] + ([(bias, db)] if bias is not None else [])
+        if not self.agent.optimizer.step_pairs(pairs):
+            return False
+        for p, _ in pairs:
+            mfma_trunk.OPT_SOURCES[p.data_ptr()] = GradSource.done()
+        return True
 
     def _forward_backward(self, exp_batch, want_errors):
         loss, delta = self._forward(exp_batch, want_errors)

@@ -225,6 +225,9 @@ class GradientAllReducer:
         self._bucket = None         # whichever bucket was packed last: what reduce_flat() reduces
         self._lowrank = []      # (weight, bias, dy_all, x_all, work handles, kept inputs)
         self._lowrank_modules = {}   # id(weight) -> nn.Linear whose hooks hand over (dy, x)
+        # set by a caller whose optimizer can step single parameters (GraphedUpdate): called ON the
+        # side stream with (weight, bias, dW, db) once the product exists; True = stepped there
+        self.lowrank_step = None
         self._deferred = {}
         self._hooks = []
         if self._early and self.active():
@@ -354,8 +357,11 @@ class GradientAllReducer:
                     self._comm.all_gather(dy_all, d, stream=side)
                     self._comm.all_gather(x_all, xx, stream=side)
                 _lowrank_product(dy_all, x_all, target, dw, db)
-            self._lowrank.append((target, bias, (_SideJoin(side, dy.device),), (dw, db),
-                                  (d, xx, dy_all, x_all, dy, x, mask)))
+                stepped = bool(self.lowrank_step is not None
+                               and self.lowrank_step(target, bias, dw, db))
+            self._lowrank.append((target, bias, (_SideJoin(side, dy.device),),
+                                  (None, None) if stepped else (dw, db),
+                                  (d, xx, dy_all, x_all, dy, x, mask, dw, db)))
             return True
         d, xx, dy_all, x_all = prepared()
         if dist.get_backend() == "nccl":
@@ -372,7 +378,7 @@ class GradientAllReducer:
             for w in works:
                 w.wait()
             dw, db = done if done is not None else _lowrank_product(keep[2], keep[3], weight)
-            weight.grad = dw
+            weight.grad = dw              # (None: already stepped on the side stream)
             if bias is not None:
                 bias.grad = db
         self._lowrank = []

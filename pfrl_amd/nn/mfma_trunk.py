@@ -408,7 +408,7 @@ class _Trunk(torch.autograd.Function):
             grads = [None] * (2 * L + 2)
             return _Trunk._conv_backward(ctx, specs, params, acts, x, dy, N, dev, grads)
         if _dist_initialized():
-            from pfrl_amd.distributed import announce_lowrank, lowrank_wanted
+            from pfrl_amd.distributed import announce_grad, announce_lowrank, lowrank_wanted
 
             if lowrank_wanted(wf, N):
                 # data parallel at minibatch size: the layer's weight gradient is not formed here
@@ -418,13 +418,22 @@ class _Trunk(torch.autograd.Function):
                 # the links instead of a 6.4 MB all-reduce)
                 # (mask, scale, all-gathers, product: all on the communicator's side stream; this
                 # stream goes straight on with the input gradient, mask applied in the kernel)
-                if announce_lowrank(wf, params[2 * L + 1], dh, acts[-1].view(N, Kf), mask=out):
-                    check(lib.pfrl_conv2d_nhwc_bwd_data(_p(dh), _p(out), _p(wf), _p(acts[-1]), _p(dy), N,
-                                                        1, 1, Kf, F, 1, 1, 1, P, last.Cout, _stream()),
-                          "linear_bwd_data")
-                    grads = [None] * (2 * L + 2)
-                    return _Trunk._conv_backward(ctx, specs, params, acts, x, dy, N, dev, grads)
-                # (not taken after all, e.g. a capture without collectives: the gradient below)
+                # The input gradient goes first: it is the last reader of this layer's weight in the
+                # update, and the side stream -- forked behind it -- may step the weight.
+                check(lib.pfrl_conv2d_nhwc_bwd_data(_p(dh), _p(out), _p(wf), _p(acts[-1]), _p(dy), N, 1,
+                                                    1, Kf, F, 1, 1, 1, P, last.Cout, _stream()),
+                      "linear_bwd_data")
+                grads = [None] * (2 * L + 2)
+                if not announce_lowrank(wf, params[2 * L + 1], dh, acts[-1].view(N, Kf), mask=out):
+                    # (not taken after all, e.g. a capture without collectives: the local gradient)
+                    dwf = torch.empty_like(wf)
+                    dbf = torch.empty(F, dtype=torch.float32, device=dev)
+                    check(lib.pfrl_conv2d_nhwc_bwd_weight(_p(dh), _p(out), _p(acts[-1].view(N, Kf)),
+                                                          _p(dwf), _p(dbf), 0, 0, N, 1, 1, Kf, F, 1, 1, 1,
+                                                          1, _stream()), "linear_bwd_weight")
+                    announce_grad(wf, dwf)
+                    grads[2 * L], grads[2 * L + 1] = dwf, dbf
+                return _Trunk._conv_backward(ctx, specs, params, acts, x, dy, N, dev, grads)
         dwf = torch.empty_like(wf)
         dbf = torch.empty(F, dtype=torch.float32, device=dev)
         if _fused_bwd_ok(N, 1, 1, Kf, 1):

@@ -159,6 +159,42 @@ class FusedRMSprop(torch.optim.RMSprop):
             float(group["eps"]), float(group["weight_decay"]), int(centered), stream),
             "rmsprop_fused_step")
 
+    def step_pairs(self, pairs):
+        """The RMSprop step of the given ``(parameter, finished gradient)`` pairs only, as one
+        launch on the CURRENT stream (pfrl_rmsprop_step: the arithmetic of ``step()``, element by
+        element).  For a caller that has some gradients early and a stream to spare -- the
+        data-parallel update steps the hidden layer on the communicator's side stream, beside the
+        convolution backward (GraphedUpdate) -- and marks them ``GradSource.done()`` for the
+        optimizer's own launch.  False = outside what the kernel covers, nothing was done."""
+        if not self.accepts_sources() or not pairs:
+            return False
+        group = self.param_groups[0]
+        centered = bool(group["centered"])
+        for p, g in pairs:
+            if not (p.is_cuda and p.dtype == torch.float32 and _dense(p) and g.dtype == torch.float32
+                    and g.stride() == p.stride()):
+                return False
+        for p, _ in pairs:
+            st = self.state[p]
+            if len(st) == 0:
+                st["step"] = (torch.zeros((), dtype=torch.float32, device=p.device)
+                              if group.get("capturable", False) else torch.tensor(0.0))
+                st["square_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                if centered:
+                    st["grad_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+        n = len(pairs)
+        P = (ctypes.c_void_p * n)(*[p.data_ptr() for p, _ in pairs])
+        G = (ctypes.c_void_p * n)(*[g.data_ptr() for _, g in pairs])
+        S = (ctypes.c_void_p * n)(*[self.state[p]["square_avg"].data_ptr() for p, _ in pairs])
+        A = (ctypes.c_void_p * n)(*[self.state[p]["grad_avg"].data_ptr() if centered else 0
+                                    for p, _ in pairs])
+        L = (ctypes.c_int64 * n)(*[p.numel() for p, _ in pairs])
+        stream = ctypes.c_void_p(torch.cuda.current_stream(pairs[0][0].device).cuda_stream)
+        _native.check(_native.lib().pfrl_rmsprop_step(
+            n, P, G, S, A, L, float(group["lr"]), float(group["alpha"]), float(group["eps"]),
+            float(group["weight_decay"]), int(centered), stream), "rmsprop_step")
+        return True
+
     @torch.no_grad()
     def step(self, closure=None):
         loss = None
