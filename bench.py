@@ -534,18 +534,41 @@ def compute_roofline(algo, all_us, all_units, all_kinds):
     prof_dir = os.path.join(ROOT, "profiles")
     names = sorted((n for n in os.listdir(prof_dir) if n.endswith(("_pmc_gather.json", "_pmc_ppo.json"))),
                    reverse=True)      # newest round first
+    # A PMC pass describes the build it was taken on: it carries the hash of the gather kernels'
+    # sources (tools/pmc_gather.py: "kernel_sources_sha16") and is attached only while those files
+    # are unchanged; otherwise traffic stays null and the line says which pass went stale.
+    current = gather_sources_sha16()
     for name in names:
         try:
             pmc = json.load(open(os.path.join(prof_dir, name)))
             kk = pmc["kernels"].get("%s (%d %s)" % (kname, main_units, unit_name))
             if kk and "traffic_bytes_per_launch" in kk:
+                taken_on = pmc.get("kernel_sources_sha16")
+                if taken_on != current:
+                    roofline["traffic_source"] = (
+                        "none: profiles/%s was taken on gather sources %s, this build is %s"
+                        % (name, taken_on or "of an untagged earlier round", current))
+                    break
                 roofline["traffic"] = kk["traffic_bytes_per_launch"]
                 roofline["traffic_source"] = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / " \
-                                             "WRITE_SIZE, separate passes, corrected)" % name
+                                             "WRITE_SIZE, separate passes, corrected; taken on " \
+                                             "gather sources %s = this build)" % (name, taken_on)
                 break
         except Exception:
             pass
     return roofline
+
+
+def gather_sources_sha16():
+    """sha256 (first 16 hex digits) over the sources of the gather kernels the roofline object
+    describes: what a PMC pass is valid for."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for rel in ("pfrl_amd/csrc/replay.hip", "pfrl_amd/csrc/nhwc.h", "pfrl_amd/csrc/common.h"):
+        with open(os.path.join(ROOT, rel), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
 
 
 NATURE_FWD_FLOPS = 2 * (20 * 20 * 32 * 8 * 8 * 4 + 9 * 9 * 64 * 4 * 4 * 32 + 7 * 7 * 64 * 3 * 3 * 64

@@ -184,6 +184,11 @@ class _Rollout:
         self.min_seq = None
 
 
+def model_tail(model, h):
+    """The last child of a Sequential applied to what its other children produced."""
+    return list(model._modules.values())[-1](h)
+
+
 class _ActGraph:
     """The device side of ``batch_act`` during a rollout -- observation gather, network, sampling,
     entropy -- as ONE captured HIP graph per batch shape (reference ppo.py:759-778).
@@ -207,11 +212,56 @@ class _ActGraph:
                 and type(ag)._sample_action is PPO._sample_action
                 and "_sample_action" not in ag.__dict__)
 
+    def _split(self):
+        """(body, policy layer, value layer) when the model is ``Sequential(..., Branched(Sequential(
+        Linear(K, A), SoftmaxCategoricalHead()), Linear(K, 1)))`` -- the example network
+        (examples/atari/train_ppo_ale.py:247-264): its two narrow heads, the sampling and the
+        entropy then run as ONE launch (pfrl_ppo_act_head).  ``body`` is a view of the model without
+        its last child (same class, same children and parameters, so a fused trunk stays fused)."""
+        model = self.agent.model
+        hit = self.__dict__.get("_split_cache")
+        if hit is not None and hit[0] is model:
+            return hit[1]
+        import collections
+
+        from pfrl_amd.nn import Branched
+        from pfrl_amd.policies import SoftmaxCategoricalHead
+
+        out = None
+        nn = torch.nn
+        if (os.environ.get("PFRL_PPO_ACT_HEAD", "1") != "0" and isinstance(model, nn.Sequential)
+                and len(model) >= 2 and type(model[len(model) - 1]) is Branched):
+            kids = list(model[len(model) - 1].child_modules)
+            if len(kids) == 2 and type(kids[0]) is nn.Sequential and len(kids[0]) == 2:
+                pol, head, val = kids[0][0], kids[0][1], kids[1]
+                if (isinstance(pol, nn.Linear) and type(head) is SoftmaxCategoricalHead
+                        and isinstance(val, nn.Linear) and val.out_features == 1
+                        and pol.in_features == val.in_features and 1 <= pol.out_features <= 31
+                        and pol.bias is not None and val.bias is not None
+                        and pol.weight.dtype == torch.float32):
+                    body = object.__new__(type(model))
+                    body.__dict__ = dict(model.__dict__)
+                    body._modules = collections.OrderedDict(list(model._modules.items())[:-1])
+                    out = (body, pol, val)
+        self._split_cache = (model, out)
+        return out
+
     def _body(self, refs):
         ag = self.agent
         b_state = ag._features(refs)
+        split = self._split()
         with torch.no_grad(), evaluating(ag.model):
-            distrib, value = ag.model(b_state)
+            if split is not None:
+                body, pol, val = split
+                h = body(b_state)
+                if h.dim() == 2 and h.dtype == torch.float32 and h.is_contiguous():
+                    u = torch.rand(h.shape[0], dtype=torch.float32, device=h.device)
+                    action, entropy, value = ops.ppo_act_head(h, pol.weight, pol.bias, val.weight,
+                                                              val.bias, u)
+                    return action, torch.stack([entropy, value])
+                distrib, value = model_tail(ag.model, h)
+            else:
+                distrib, value = ag.model(b_state)
             action = distrib.sample()
             stats = torch.stack([distrib.entropy().reshape(-1).float(),
                                  value.reshape(-1).float()])

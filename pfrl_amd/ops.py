@@ -291,6 +291,23 @@ def gae_scan(reward, v_pred, next_v_pred, nonterminal, cut, gamma, lambd, mode=0
     return adv, vt
 
 
+def ppo_act_head(h, w_policy, b_policy, w_value, b_value, u01, want_log_prob=False):
+    """The two narrow heads of the PPO example network + Categorical sample / entropy in one launch
+    (pfrl_ppo_act_head).  h [N, K] f32; returns (action i64 [N], entropy [N], value [N][, log_prob])."""
+    N, K = h.shape
+    A = w_policy.shape[0]
+    dev = h.device
+    action = torch.empty(N, dtype=torch.int64, device=dev)
+    entropy = torch.empty(N, dtype=torch.float32, device=dev)
+    value = torch.empty(N, dtype=torch.float32, device=dev)
+    logp = torch.empty(N, dtype=torch.float32, device=dev) if want_log_prob else None
+    check(_native.lib().pfrl_ppo_act_head(_ptr(h), _ptr(w_policy), _ptr(b_policy), _ptr(w_value),
+                                          _ptr(b_value), _ptr(u01), _ptr(action), _ptr(entropy),
+                                          _ptr(value), _ptr(logp) if logp is not None else None,
+                                          N, K, A, _stream()), "ppo_act_head")
+    return (action, entropy, value, logp) if want_log_prob else (action, entropy, value)
+
+
 def a2c_returns(rewards, masks, value_preds, returns, gamma, tau, use_gae):
     T, N = rewards.shape
     check(_native.lib().pfrl_a2c_returns(T, N, _ptr(rewards), _ptr(masks), _ptr(value_preds),

@@ -326,7 +326,7 @@ def test_ppo_bench_path_gae_and_advantage_statistics_match_oracle(monkeypatch):
 
 def test_ppo_act_graph_equals_the_eager_act_path(monkeypatch):
     """The rollout's ``batch_act`` as one captured graph (agents/ppo.py::_ActGraph) against the
-    eager launches it replaces, on the bench agent: entropy and value bit for bit, actions inside
+    eager launches it replaces, on the bench agent: entropy and value to f32 rounding, actions inside
     the action set, drawn anew on every replay (the generator advances) and distributed like the
     policy's probabilities; the rollout built from graph steps trains (an update runs)."""
     import bench
@@ -351,7 +351,10 @@ def test_ppo_act_graph_equals_the_eager_act_path(monkeypatch):
     for i in range(40):
         action, stats = agent._act_graph.run(refs_dev)
         a = action.clone()
-        assert torch.equal(stats[0], want_entropy) and torch.equal(stats[1], want_value)
+        # (one launch for heads + sampling + entropy: same numbers to f32 rounding of another
+        # summation order, 512-term dot products by wave reduction)
+        assert torch.allclose(stats[0], want_entropy, rtol=1e-5, atol=2e-6)
+        assert torch.allclose(stats[1], want_value, rtol=1e-5, atol=2e-6)
         assert int(a.min()) >= 0 and int(a.max()) < probs.shape[0]
         if prev is not None:
             assert not torch.equal(a, prev)

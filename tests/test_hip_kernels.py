@@ -1261,3 +1261,39 @@ def test_select_actions(dev, dtype):
                              torch.from_numpy(choice).to(dev))
     assert out.dtype == torch.int64
     np.testing.assert_array_equal(out.cpu().numpy(), np.where(choice >= 0, choice, greedy))
+
+
+def test_ppo_act_head_matches_torch_categorical(dev):
+    """pfrl_ppo_act_head against the torch expressions it replaces on the acting path
+    (Linear + Categorical(logits): value, entropy, log pi(a)) and its inverse-CDF sampling: the
+    action is the interval of the row's cumulative probabilities that u01 falls into, and the
+    empirical action frequencies follow the probabilities."""
+    torch.manual_seed(3)
+    for N, K, A in [(512, 512, 6), (37, 512, 18), (5, 96, 1), (64, 256, 31)]:
+        h = torch.randn(N, K, device=dev)
+        wp, bp = torch.randn(A, K, device=dev) * 0.05, torch.randn(A, device=dev)
+        wv, bv = torch.randn(1, K, device=dev) * 0.05, torch.randn(1, device=dev)
+        u = torch.rand(N, device=dev)
+        a, ent, val, lp = ops.ppo_act_head(h, wp, bp, wv, bv, u, want_log_prob=True)
+        logits = (h.double() @ wp.double().t() + bp.double())
+        d = torch.distributions.Categorical(logits=logits)
+        assert torch.allclose(val.double(), (h.double() @ wv.double().t() + bv.double()).reshape(-1),
+                              rtol=1e-5, atol=1e-5)
+        assert torch.allclose(ent.double(), d.entropy(), rtol=1e-5, atol=1e-5)
+        assert torch.allclose(lp.double(), d.log_prob(a), rtol=1e-5, atol=1e-5)
+        assert int(a.min()) >= 0 and int(a.max()) < A
+        cdf = torch.cumsum(d.probs, dim=1)
+        lo = torch.where(a > 0, cdf.gather(1, (a - 1).clamp(min=0)[:, None])[:, 0], torch.zeros_like(cdf[:, 0]))
+        hi = cdf.gather(1, a[:, None])[:, 0]
+        assert bool(((u.double() >= lo - 1e-6) & (u.double() <= hi + 1e-6)).all())
+    # frequencies
+    N, K, A = 4096, 64, 5
+    h = torch.zeros(N, K, device=dev)
+    wp, bp = torch.zeros(A, K, device=dev), torch.tensor([0.0, 1.0, -1.0, 0.5, 2.0], device=dev)
+    wv, bv = torch.zeros(1, K, device=dev), torch.zeros(1, device=dev)
+    counts = torch.zeros(A, device=dev)
+    for _ in range(8):
+        a, _, _ = ops.ppo_act_head(h, wp, bp, wv, bv, torch.rand(N, device=dev))
+        counts += torch.bincount(a, minlength=A).float()
+    probs = torch.softmax(bp, dim=0)
+    assert float((counts / counts.sum() - probs).abs().max()) < 0.01
