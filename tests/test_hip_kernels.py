@@ -1268,6 +1268,7 @@ def test_ppo_act_head_matches_torch_categorical(dev):
     (Linear + Categorical(logits): value, entropy, log pi(a)) and its inverse-CDF sampling: the
     action is the interval of the row's cumulative probabilities that u01 falls into, and the
     empirical action frequencies follow the probabilities."""
+    ops = _ops()
     torch.manual_seed(3)
     for N, K, A in [(512, 512, 6), (37, 512, 18), (5, 96, 1), (64, 256, 31)]:
         h = torch.randn(N, K, device=dev)
