@@ -743,6 +743,157 @@ __global__ __launch_bounds__(256) void k_conv_dgrad(DgradArgs p) {
     dgrad_body<BM, BN, WM, WN, WK, G, MERGE>(p, blockIdx.x, blockIdx.y, blockIdx.z, smem);
 }
 
+// POS: the input gradient of a stride-1 convolution at rollout / update batch sizes, tiled by INPUT
+// POSITION: the BM rows of a tile are BM consecutive images at ONE input pixel (a, a2).  Which taps
+// (r, s) of that pixel fall inside the output is then a property of the whole tile -- a rectangle
+// [tb_lo, tb_hi] x [t2_lo, t2_hi] -- and the others are simply not walked: for the 3 x 3 layer on a
+// 9 x 9 input (7 x 7 output) 40 % of the taps of the row-major tiling are padding that costs MFMAs
+// and loads for nothing (a corner pixel has 1 valid tap of 9, an interior one 9).  The BM dy rows of a
+// tap are one 4 * Cout-byte piece per image (12.5 KB apart): every piece is needed by up to R * S
+// positions, so the workgroups of one image block are kept on ONE XCD (blockIdx.x % 8 is the XCD a
+// workgroup lands on: the image block is chosen by it, the position by blockIdx.x / 8) and the block's
+// dy (BM x OH x OW x Cout floats, 0.8 MB) is read from HBM once and from that XCD's L2 afterwards.
+// Same terms in the same order per element as the row-major program, minus exact zeros.
+template <int BM, int BN, int WM, int WN, int WK, int G>
+__device__ __forceinline__ void dgrad_pos_body(const DgradArgs &p, const int img_blk, const int pos,
+                                               const int by, float *smem) {
+    static_assert(WM * WN * WK == 4 && WK <= 2, "four waves");
+    constexpr int AM = BM / (16 * WM), AN = BN / (16 * WN);
+    constexpr int P = (AM * AN == 1) ? 2 : 1;
+    constexpr int NPA = (BM * 8 + 255) / 256;
+    constexpr int QPR = BN / 4, NPB = (32 * QPR + 255) / 256, LDB = BN + 4;
+    float(*As)[BM * LDR] = reinterpret_cast<float(*)[BM * LDR]>(smem);
+    float(*Bs)[32 * LDB] = reinterpret_cast<float(*)[32 * LDB]>(smem + G * BM * LDR);
+    f32x4 *red = reinterpret_cast<f32x4 *>(smem + G * BM * LDR + G * 32 * LDB);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wk = wave % WK, wn = (wave / WK) % WN, wm = wave / (WK * WN);
+    const int n0 = by * BN;
+    const ConvGeom g = p.g;
+    const int a = fdiv(pos, p.q_aw), a2 = pos - a * p.AW;
+    // taps whose output pixel (a - tb, a2 - t2) exists
+    const int tb_lo = max(0, a - (g.OH - 1)), tb_hi = min(p.TH - 1, a);
+    const int t2_lo = max(0, a2 - (g.OW - 1)), t2_hi = min(p.TW - 1, a2);
+    const int cpt = g.Cout / KC;
+    const int nchunks = (tb_hi - tb_lo + 1) * (t2_hi - t2_lo + 1) * cpt;
+
+    size_t abase[NPA];
+    bool aok[NPA];
+#pragma unroll
+    for (int pp = 0; pp < NPA; ++pp) {
+        const int f = tid + 256 * pp, row = f >> 3, q = f & 7;
+        const int n = img_blk * BM + row;
+        aok[pp] = row < BM && n < g.N;
+        abase[pp] = ((size_t)((aok[pp] ? n : 0) * g.OH + a) * g.OW + a2) * g.Cout + 4 * q;
+    }
+    int bkk[NPB], bq4[NPB];
+    size_t bbase[NPB];
+#pragma unroll
+    for (int pp = 0; pp < NPB; ++pp) {
+        const int f = tid + 256 * pp;
+        bkk[pp] = f / QPR;
+        bq4[pp] = 4 * (f - bkk[pp] * QPR);
+        bbase[pp] = (size_t)bkk[pp] * g.R * g.S * g.C + n0 + bq4[pp];
+    }
+    struct Slot {
+        float4 a[NPA], h[NPA], b[NPB];
+    };
+    const bool has_mask = p.dymask != nullptr;
+    auto a_on = [&](int pp) { return BM * 8 >= 256 * (pp + 1) || wave * 64 + 256 * pp < BM * 8; };
+    auto b_on = [&](int pp) { return 32 * QPR >= 256 * (pp + 1) || wave * 64 + 256 * pp < 32 * QPR; };
+    int f_c = 0, f_co0 = 0, f_tb = tb_lo, f_t2 = t2_lo;
+    auto fetch = [&](int c, Slot &sl) {
+        if (c > f_c) {
+            f_c = c;
+            f_co0 += KC;
+            if (f_co0 >= g.Cout) {
+                f_co0 = 0;
+                if (++f_t2 > t2_hi) {
+                    f_t2 = t2_lo;
+                    ++f_tb;
+                }
+            }
+        }
+        const size_t adelta = (size_t)f_co0 - (size_t)(f_tb * g.OW + f_t2) * g.Cout;
+#pragma unroll
+        for (int pp = 0; pp < NPA; ++pp) {
+            if (!a_on(pp)) continue;
+            const size_t off = abase[pp] + adelta;     // (rows past N read image 0: zeroed when parked)
+            sl.a[pp] = ldg4(p.dy + off);
+            if (has_mask) sl.h[pp] = ldg4(p.dymask + off);
+        }
+        const size_t bdelta = ((size_t)(f_co0 * g.R + f_tb) * g.S + f_t2) * g.C;
+#pragma unroll
+        for (int pp = 0; pp < NPB; ++pp)
+            if (b_on(pp)) sl.b[pp] = ldg4(p.w + bbase[pp] + bdelta);
+    };
+    auto stash = [&](int buf, int c, const Slot &sl) {
+#pragma unroll
+        for (int pp = 0; pp < NPA; ++pp) {
+            if (!a_on(pp)) continue;
+            const int f = tid + 256 * pp, row = f >> 3, q = f & 7;
+            float4 v = zero_unless(sl.a[pp], aok[pp]);
+            if (has_mask) v = relu_mask(v, sl.h[pp]);
+            *reinterpret_cast<float4 *>(&As[buf][row * LDR + 4 * q]) = v;
+        }
+#pragma unroll
+        for (int pp = 0; pp < NPB; ++pp)
+            if (b_on(pp)) *reinterpret_cast<float4 *>(&Bs[buf][bkk[pp] * LDB + bq4[pp]]) = sl.b[pp];
+    };
+    f32x4 acc[AM][AN][P];
+#pragma unroll
+    for (int am = 0; am < AM; ++am)
+#pragma unroll
+        for (int an = 0; an < AN; ++an)
+#pragma unroll
+            for (int pp = 0; pp < P; ++pp) acc[am][an][pp] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    auto compute = [&](int buf) {
+#pragma unroll
+        for (int s = 0; s < 2 / WK; ++s)
+            mma_sub<AM, AN, P, true, false, LDR, LDB>(As[buf], Bs[buf], wm * 16 * AM, wn * 16 * AN,
+                                                           WK == 2 ? wk : s, lane, acc);
+    };
+    run_pipeline<Slot, G>(0, nchunks, fetch, stash, compute);
+    fold_acc<AM, AN, P, WK, WM * WN>(acc, red, wm * WN + wn, wk, lane);
+    // NHWC rows through LDS: a thread masks and stores a float4 of one image's pixel (a, a2)
+    constexpr int LDT = BN + 4;
+    static_assert(BM * LDT <= G * BM * LDR + G * 32 * LDB, "the tile fits in the chunk buffers");
+    float *tile = &As[0][0];
+    __syncthreads();
+    if (wk == 0) {
+#pragma unroll
+        for (int am = 0; am < AM; ++am)
+#pragma unroll
+            for (int an = 0; an < AN; ++an)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg)
+                    tile[(wm * 16 * AM + 16 * am + 4 * (lane >> 4) + reg) * LDT + wn * 16 * AN + 16 * an +
+                         (lane & 15)] = acc[am][an][0][reg];
+    }
+    __syncthreads();
+    constexpr int Q = BN / 4;
+#pragma unroll
+    for (int f = tid; f < BM * Q; f += 256) {
+        const int row = f / Q, c4 = 4 * (f - row * Q);
+        const int n = img_blk * BM + row;
+        if (n >= g.N) continue;
+        const size_t o = ((size_t)(n * g.H + a) * g.W + a2) * g.C + n0 + c4;
+        float4 v = *reinterpret_cast<const float4 *>(&tile[row * LDT + c4]);
+        if (p.aprev != nullptr) v = relu_mask(v, *reinterpret_cast<const float4 *>(p.aprev + o));
+        *reinterpret_cast<float4 *>(p.dx + o) = v;
+    }
+}
+
+template <int BM, int BN, int WM, int WN, int WK, int G>
+__global__ __launch_bounds__(256) void k_conv_dgrad_pos(DgradArgs p, int nblk, int npos) {
+    __shared__ __attribute__((aligned(16))) float smem[dgrad_smem(BM, BN, WM, WN, WK, G)];
+    // workgroup -> (image block, position): all positions of an image block on one XCD
+    const int b = blockIdx.x, xcd = b & 7, slot = b >> 3;
+    const int sup = slot / npos, pos = slot - sup * npos;
+    const int img_blk = sup * 8 + xcd;
+    if (img_blk >= nblk) return;
+    dgrad_pos_body<BM, BN, WM, WN, WK, G>(p, img_blk, pos, blockIdx.y, smem);
+}
+
 template <int BM, int BN, int WM, int WN, int WK, int G>
 __global__ __launch_bounds__(256) void k_conv_dgrad2(DgradArgs p0, DgradArgs p1) {
     __shared__ __attribute__((aligned(16))) float smem[dgrad_smem(BM, BN, WM, WN, WK, G)];
@@ -1425,6 +1576,10 @@ static int dgrad_program(const DgradArgs &a, int z) {
     const bool merge128 = st > 1 && 128 % C == 0 && ncol % 128 == 0;
     if (force >= 0 && force <= 4 && (C % 64 == 0 || force != 0)) return force;
     if ((force == 6 && merge64) || (force == 7 && merge128)) return force;
+    // 8 = <64,64,POS>: stride-1 layers with more than one tap, tiled by input position
+    const bool pos_ok = st == 1 && a.TH * a.TW > 1 && C % 64 == 0 && a.permP == 0;
+    if (force == 8 && pos_ok) return 8;
+    if (force < 0 && pos_ok && a.g.N >= 1024) return 8;
     // (64 x 64 measured ahead of 64 x 128: 1219 vs 1262 us against 1345 per class, conv2 at B = 16384)
     if (force < 0 && merge64 && (long long)((a.Mc + 63) / 64) * (ncol / 64) >= 2048) return 6;
     if (C % 64 == 0 && blocks(64, 64) >= 1024) return 0;
@@ -1452,6 +1607,13 @@ extern "C" int pfrl_conv2d_nhwc_bwd_data(const float *dy, const float *dy_mask, 
     hipLaunchKernelGGL((k_conv_dgrad<BM, BN, WM, WN, WK, G, true>),                                  \
                        dim3((a.Mc + BM - 1) / BM, (z * C) / BN, 1), dim3(256), 0, st, a)
     switch (dgrad_program(a, (int)z)) {
+        case 8: {
+            const int nblk = (N + 63) / 64, npos = a.AH * a.AW;
+            hipLaunchKernelGGL((k_conv_dgrad_pos<64, 64, 2, 2, 1, 2>),
+                               dim3((unsigned)(((nblk + 7) / 8) * 8 * npos), C / 64, 1), dim3(256), 0, st,
+                               a, nblk, npos);
+            break;
+        }
         case 6: DGM(64, 64, 2, 2, 1, 2); break;
         case 7: DGM(64, 128, 2, 2, 1, 2); break;
         case 0: DG(64, 64, 2, 2, 1, 2); break;
