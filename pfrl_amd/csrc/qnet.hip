@@ -754,7 +754,9 @@ __global__ __launch_bounds__(256) void k_conv_dgrad(DgradArgs p) {
 // workgroup lands on: the image block is chosen by it, the position by blockIdx.x / 8) and the block's
 // dy (BM x OH x OW x Cout floats, 0.8 MB) is read from HBM once and from that XCD's L2 afterwards.
 // Same terms in the same order per element as the row-major program, minus exact zeros.
-template <int BM, int BN, int WM, int WN, int WK, int G>
+// CLS: a strided layer -- the tile's columns are (parity class, input channel) as in MERGE, the
+// position is a cell (a, a2) of the AH x AW grid every class shares, taps step by ST kernel positions.
+template <int BM, int BN, int WM, int WN, int WK, int G, bool CLS = false>
 __device__ __forceinline__ void dgrad_pos_body(const DgradArgs &p, const int img_blk, const int pos,
                                                const int by, float *smem) {
     static_assert(WM * WN * WK == 4 && WK <= 2, "four waves");
@@ -792,7 +794,14 @@ __device__ __forceinline__ void dgrad_pos_body(const DgradArgs &p, const int img
         const int f = tid + 256 * pp;
         bkk[pp] = f / QPR;
         bq4[pp] = 4 * (f - bkk[pp] * QPR);
-        bbase[pp] = (size_t)bkk[pp] * g.R * g.S * g.C + n0 + bq4[pp];
+        if (CLS) {
+            const int col = n0 + bq4[pp];
+            const int cls = col / g.C, ci = col - cls * g.C;
+            const int cph = cls / g.ST, cpw = cls - cph * g.ST;
+            bbase[pp] = (size_t)bkk[pp] * g.R * g.S * g.C + (size_t)(cph * g.S + cpw) * g.C + ci;
+        } else {
+            bbase[pp] = (size_t)bkk[pp] * g.R * g.S * g.C + n0 + bq4[pp];
+        }
     }
     struct Slot {
         float4 a[NPA], h[NPA], b[NPB];
@@ -821,7 +830,8 @@ __device__ __forceinline__ void dgrad_pos_body(const DgradArgs &p, const int img
             sl.a[pp] = ldg4(p.dy + off);
             if (has_mask) sl.h[pp] = ldg4(p.dymask + off);
         }
-        const size_t bdelta = ((size_t)(f_co0 * g.R + f_tb) * g.S + f_t2) * g.C;
+        const size_t bdelta = ((size_t)(f_co0 * g.R + f_tb * (CLS ? g.ST : 1)) * g.S +
+                               f_t2 * (CLS ? g.ST : 1)) * g.C;
 #pragma unroll
         for (int pp = 0; pp < NPB; ++pp)
             if (b_on(pp)) sl.b[pp] = ldg4(p.w + bbase[pp] + bdelta);
@@ -876,14 +886,22 @@ __device__ __forceinline__ void dgrad_pos_body(const DgradArgs &p, const int img
         const int row = f / Q, c4 = 4 * (f - row * Q);
         const int n = img_blk * BM + row;
         if (n >= g.N) continue;
-        const size_t o = ((size_t)(n * g.H + a) * g.W + a2) * g.C + n0 + c4;
+        int ih = a, iw = a2, ec = n0 + c4;
+        if (CLS) {
+            const int cls = ec / g.C;
+            ec -= cls * g.C;
+            const int eph = cls / g.ST;
+            ih = a * g.ST + eph;
+            iw = a2 * g.ST + (cls - eph * g.ST);
+        }
+        const size_t o = ((size_t)(n * g.H + ih) * g.W + iw) * g.C + ec;
         float4 v = *reinterpret_cast<const float4 *>(&tile[row * LDT + c4]);
         if (p.aprev != nullptr) v = relu_mask(v, *reinterpret_cast<const float4 *>(p.aprev + o));
         *reinterpret_cast<float4 *>(p.dx + o) = v;
     }
 }
 
-template <int BM, int BN, int WM, int WN, int WK, int G>
+template <int BM, int BN, int WM, int WN, int WK, int G, bool CLS = false>
 __global__ __launch_bounds__(256) void k_conv_dgrad_pos(DgradArgs p, int nblk, int npos) {
     __shared__ __attribute__((aligned(16))) float smem[dgrad_smem(BM, BN, WM, WN, WK, G)];
     // workgroup -> (image block, position): all positions of an image block on one XCD
@@ -891,7 +909,7 @@ __global__ __launch_bounds__(256) void k_conv_dgrad_pos(DgradArgs p, int nblk, i
     const int sup = slot / npos, pos = slot - sup * npos;
     const int img_blk = sup * 8 + xcd;
     if (img_blk >= nblk) return;
-    dgrad_pos_body<BM, BN, WM, WN, WK, G>(p, img_blk, pos, blockIdx.y, smem);
+    dgrad_pos_body<BM, BN, WM, WN, WK, G, CLS>(p, img_blk, pos, blockIdx.y, smem);
 }
 
 template <int BM, int BN, int WM, int WN, int WK, int G>
@@ -1580,6 +1598,10 @@ static int dgrad_program(const DgradArgs &a, int z) {
     const bool pos_ok = st == 1 && a.TH * a.TW > 1 && C % 64 == 0 && a.permP == 0;
     if (force == 8 && pos_ok) return 8;
     if (force < 0 && pos_ok && a.g.N >= 1024) return 8;
+    // 9 = <64,64,POS,CLS>: strided layers by cell of the class grid, classes side by side
+    const bool poscls_ok = merge64 && a.permP == 0;
+    if (force == 9 && poscls_ok) return 9;
+    if (force < 0 && poscls_ok && a.g.N >= 1024) return 9;
     // (64 x 64 measured ahead of 64 x 128: 1219 vs 1262 us against 1345 per class, conv2 at B = 16384)
     if (force < 0 && merge64 && (long long)((a.Mc + 63) / 64) * (ncol / 64) >= 2048) return 6;
     if (C % 64 == 0 && blocks(64, 64) >= 1024) return 0;
@@ -1612,6 +1634,13 @@ extern "C" int pfrl_conv2d_nhwc_bwd_data(const float *dy, const float *dy_mask, 
             hipLaunchKernelGGL((k_conv_dgrad_pos<64, 64, 2, 2, 1, 2>),
                                dim3((unsigned)(((nblk + 7) / 8) * 8 * npos), C / 64, 1), dim3(256), 0, st,
                                a, nblk, npos);
+            break;
+        }
+        case 9: {
+            const int nblk = (N + 63) / 64, npos = a.AH * a.AW;
+            hipLaunchKernelGGL((k_conv_dgrad_pos<64, 64, 2, 2, 1, 2, true>),
+                               dim3((unsigned)(((nblk + 7) / 8) * 8 * npos), (z * C) / 64, 1), dim3(256), 0,
+                               st, a, nblk, npos);
             break;
         }
         case 6: DGM(64, 64, 2, 2, 1, 2); break;

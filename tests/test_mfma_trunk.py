@@ -165,7 +165,7 @@ def test_large_tile_programs_equal_the_minibatch_ones_bit_for_bit(geom, monkeypa
     if C % 32 == 0:
         # (6, 7: the stride-parity classes side by side in one tile, strided layers only)
         cases.append(("PFRL_QNET_DGRAD", dgrad, [1] + ([0] if C % 64 == 0 else [])
-                      + ([6, 7] if ST > 1 and 64 % C == 0 else [])
+                      + ([6, 7, 9] if ST > 1 and 64 % C == 0 else [])
                       + ([8] if ST == 1 and R > 1 and C % 64 == 0 else []), True))     # 8: by input position
     # weight gradient: the 32 x 32 program interleaves two accumulators per tile (one MFMA tile per
     # wave), the large ones keep one: same terms, another order -> tolerance against it, and the

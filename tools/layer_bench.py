@@ -120,7 +120,7 @@ def main():
             plans = [("fwd", "PFRL_QNET_FWD", run_fwd, lambda: y, bx + by + bw,
                       ([2, 7] if wide else []) + [3, 8] if args.sweep else [None]),
                      ("dgrad", "PFRL_QNET_DGRAD", run_dgrad, lambda: dx, 2 * bx + by + bw,
-                      ([0] if C % 64 == 0 else []) + [1] + ([6, 7] if ST > 1 and 64 % C == 0 else []) + ([8] if ST == 1 and R > 1 and C % 64 == 0 else []) if args.sweep else [None]),
+                      ([0] if C % 64 == 0 else []) + [1] + ([6, 7, 9] if ST > 1 and 64 % C == 0 else []) + ([8] if ST == 1 and R > 1 and C % 64 == 0 else []) if args.sweep else [None]),
                      ("wgrad/%d" % splits, "PFRL_QNET_WGRAD", run_wgrad, lambda: part,
                       bx + by + splits * stride * 4,
                       [0] + ([2] if wide and K % 64 == 0 else []) + ([3] if wide and K % 128 == 0 else [])
