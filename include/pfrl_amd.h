@@ -292,11 +292,14 @@ int pfrl_ppo_minibatch(int64_t M, const int64_t *idx, const float *adv, const fl
  * with them (examples/atari/train_ppo_ale.py:257-263, pfrl/agents/ppo.py:759-778,
  * pfrl/policies/softmax_policy.py: Categorical(logits)): logits = h w_policy^T + b_policy,
  * value = h w_value^T + b_value, action ~ Categorical(logits) by inverse CDF on u01[row] in [0, 1),
- * entropy of the distribution, optionally log pi(action).  h [N][K], w_policy [A][K], A <= 31. */
+ * entropy of the distribution, optionally log pi(action).  given_action != NULL: no draw -- the
+ * value pass of an update (ppo.py:110-142): log pi(given_action | s) and V(s) (out_action /
+ * out_entropy / u01 may be NULL).  h [N][K], w_policy [A][K], A <= 31. */
 int pfrl_ppo_act_head(const float *h, const float *w_policy, const float *b_policy,
                       const float *w_value, const float *b_value, const float *u01,
-                      int64_t *out_action, float *out_entropy, float *out_value, float *out_log_prob,
-                      int32_t N, int32_t K, int32_t A, void *stream);
+                      const int64_t *given_action, int64_t *out_action, float *out_entropy,
+                      float *out_value, float *out_log_prob, int32_t N, int32_t K, int32_t A,
+                      void *stream);
 
 /* ------------------------------------------------------------------------
  * Optimizer step of the DQN update (pfrl/agents/dqn.py:360-365 calls

@@ -313,7 +313,7 @@ class PPO(agent.AttributeSavingMixin, agent.BatchAgent):
                  standardize_advantages=True, batch_states=batch_states, recurrent=False,
                  max_recurrent_sequence_len=None, act_deterministically=False, max_grad_norm=None,
                  value_stats_window=1000, entropy_stats_window=1000, value_loss_stats_window=100,
-                 policy_loss_stats_window=100, value_pass_chunk=8192,
+                 policy_loss_stats_window=100, value_pass_chunk=16384,
                  reuse_next_values=True):
         self.model = model
         self.optimizer = optimizer
@@ -575,10 +575,27 @@ class PPO(agent.AttributeSavingMixin, agent.BatchAgent):
         M = refs_dev.shape[0]
         log_probs = torch.empty(M, dtype=torch.float32, device=self.device)
         values = torch.empty(M, dtype=torch.float32, device=self.device)
+        split = None
+        if self._act_graph is not None and self._act_graph.applicable() and (
+                actions_dev is None or actions_dev.dtype == torch.int64):
+            split = self._act_graph._split()
         with torch.no_grad(), evaluating(self.model):
             for lo in range(0, M, self.value_pass_chunk):
                 hi = min(M, lo + self.value_pass_chunk)
-                distribs, vs = self.model(self._features(refs_dev[lo:hi]))
+                x = self._features(refs_dev[lo:hi])
+                if split is not None:
+                    # heads + log pi(a | s) + V(s) in one launch behind the trunk (the acting path's
+                    # kernel without the draw), written straight into the columns
+                    body, pol, val = split
+                    h = body(x)
+                    if h.dim() == 2 and h.dtype == torch.float32 and h.is_contiguous():
+                        ops.ppo_value_head(h, pol.weight, pol.bias, val.weight, val.bias,
+                                           actions_dev[lo:hi] if actions_dev is not None else None,
+                                           log_probs[lo:hi], values[lo:hi])
+                        continue
+                    distribs, vs = model_tail(self.model, h)
+                else:
+                    distribs, vs = self.model(x)
                 values[lo:hi] = vs.reshape(-1)
                 if actions_dev is not None:
                     log_probs[lo:hi] = distribs.log_prob(actions_dev[lo:hi])

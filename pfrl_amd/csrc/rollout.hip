@@ -187,8 +187,8 @@ constexpr int ACT_MAX_OUT = 32;
 __global__ __launch_bounds__(256) void k_ppo_act_head(
     const float *__restrict__ h, const float *__restrict__ wp, const float *__restrict__ bp,
     const float *__restrict__ wv, const float *__restrict__ bv, const float *__restrict__ u,
-    int64_t *__restrict__ action, float *__restrict__ entropy, float *__restrict__ value,
-    float *__restrict__ log_prob, int N, int K, int A) {
+    const int64_t *__restrict__ given, int64_t *__restrict__ action, float *__restrict__ entropy,
+    float *__restrict__ value, float *__restrict__ log_prob, int N, int K, int A) {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int row = blockIdx.x * 4 + wave;
     if (row >= N) return;
@@ -232,8 +232,10 @@ __global__ __launch_bounds__(256) void k_ppo_act_head(
     const float lse = m + logf(sum);
     // Categorical.entropy(): -sum p log p with log p = logits - logsumexp (probabilities of exactly
     // zero contribute nothing); the action: first j with u * sum < e_0 + .. + e_j
+    // (given != NULL: the value pass of an update -- log pi(a | s) of the RECORDED action, no draw)
     float ent = 0.f, cum = 0.f, lp_a = 0.f;
-    const float ur = u[row] * sum;
+    const float ur = given == nullptr ? u[row] * sum : 0.f;
+    const int ga = given != nullptr ? (int)given[row] : -1;
     int a = -1;
 #pragma unroll
     for (int j = 0; j < ACT_MAX_OUT; ++j) {
@@ -242,14 +244,15 @@ __global__ __launch_bounds__(256) void k_ppo_act_head(
             const float p = e[j] / sum;
             ent -= p > 0.f ? p * lp : 0.f;
             cum += e[j];
-            if (a < 0 && (ur < cum || j == A - 1)) {
+            const bool take = given != nullptr ? j == ga : (a < 0 && (ur < cum || j == A - 1));
+            if (take) {
                 a = j;
                 lp_a = lp;
             }
         }
     }
-    action[row] = a;
-    entropy[row] = ent;
+    if (action != nullptr) action[row] = a;
+    if (entropy != nullptr) entropy[row] = ent;
     value[row] = acc[A];
     if (log_prob != nullptr) log_prob[row] = lp_a;
 }
@@ -313,14 +316,17 @@ extern "C" int pfrl_ppo_minibatch(int64_t M, const int64_t *idx, const float *ad
 
 extern "C" int pfrl_ppo_act_head(const float *h, const float *w_policy, const float *b_policy,
                                  const float *w_value, const float *b_value, const float *u01,
-                                 int64_t *out_action, float *out_entropy, float *out_value,
-                                 float *out_log_prob, int32_t N, int32_t K, int32_t A, void *stream) {
+                                 const int64_t *given_action, int64_t *out_action, float *out_entropy,
+                                 float *out_value, float *out_log_prob, int32_t N, int32_t K, int32_t A,
+                                 void *stream) {
     PFRL_CHECK_ARG(N >= 0 && K >= 1 && A >= 1 && A < ACT_MAX_OUT, "pfrl_ppo_act_head: 1 <= A <= 31");
-    PFRL_CHECK_ARG(h && w_policy && b_policy && w_value && b_value && u01 && out_action && out_entropy
-                       && out_value, "pfrl_ppo_act_head: null pointer");
+    PFRL_CHECK_ARG(h && w_policy && b_policy && w_value && b_value && out_value,
+                   "pfrl_ppo_act_head: null pointer");
+    PFRL_CHECK_ARG(given_action != nullptr || (u01 != nullptr && out_action != nullptr),
+                   "pfrl_ppo_act_head: sampling needs u01 and out_action");
     if (N == 0) return 0;
     hipLaunchKernelGGL(k_ppo_act_head, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
-                       h, w_policy, b_policy, w_value, b_value, u01, out_action, out_entropy,
-                       out_value, out_log_prob, N, K, A);
+                       h, w_policy, b_policy, w_value, b_value, u01, given_action, out_action,
+                       out_entropy, out_value, out_log_prob, N, K, A);
     PFRL_LAUNCH_CHECK();
 }

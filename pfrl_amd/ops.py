@@ -302,10 +302,31 @@ def ppo_act_head(h, w_policy, b_policy, w_value, b_value, u01, want_log_prob=Fal
     value = torch.empty(N, dtype=torch.float32, device=dev)
     logp = torch.empty(N, dtype=torch.float32, device=dev) if want_log_prob else None
     check(_native.lib().pfrl_ppo_act_head(_ptr(h), _ptr(w_policy), _ptr(b_policy), _ptr(w_value),
-                                          _ptr(b_value), _ptr(u01), _ptr(action), _ptr(entropy),
+                                          _ptr(b_value), _ptr(u01), None, _ptr(action), _ptr(entropy),
                                           _ptr(value), _ptr(logp) if logp is not None else None,
                                           N, K, A, _stream()), "ppo_act_head")
     return (action, entropy, value, logp) if want_log_prob else (action, entropy, value)
+
+
+def ppo_value_head(h, w_policy, b_policy, w_value, b_value, actions, out_log_prob, out_value):
+    """The same launch without a draw: log pi(actions | s) (actions = None: values only) and V(s)
+    written into ``out_log_prob`` / ``out_value`` [N] (the value pass of a PPO update)."""
+    N, K = h.shape
+    check(_native.lib().pfrl_ppo_act_head(
+        _ptr(h), _ptr(w_policy), _ptr(b_policy), _ptr(w_value), _ptr(b_value), None,
+        _ptr(actions) if actions is not None else _ptr(_zeros_i64(N, h.device)), None, None,
+        _ptr(out_value), _ptr(out_log_prob) if actions is not None else None, N, K,
+        w_policy.shape[0], _stream()), "ppo_value_head")
+
+
+_ZI64 = {}
+
+
+def _zeros_i64(n, device):
+    t = _ZI64.get(device)
+    if t is None or t.numel() < n:
+        t = _ZI64[device] = torch.zeros(max(n, 1 << 16), dtype=torch.int64, device=device)
+    return t
 
 
 def a2c_returns(rewards, masks, value_preds, returns, gamma, tau, use_gae):

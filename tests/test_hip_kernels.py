@@ -1287,6 +1287,15 @@ def test_ppo_act_head_matches_torch_categorical(dev):
         lo = torch.where(a > 0, cdf.gather(1, (a - 1).clamp(min=0)[:, None])[:, 0], torch.zeros_like(cdf[:, 0]))
         hi = cdf.gather(1, a[:, None])[:, 0]
         assert bool(((u.double() >= lo - 1e-6) & (u.double() <= hi + 1e-6)).all())
+        # the value-pass form: log pi of GIVEN actions and V(s), no draw
+        given = torch.randint(0, A, (N,), device=dev)
+        lp2, v2 = torch.full((N,), float("nan"), device=dev), torch.full((N,), float("nan"), device=dev)
+        ops.ppo_value_head(h, wp, bp, wv, bv, given, lp2, v2)
+        assert torch.equal(v2, val)
+        assert torch.allclose(lp2.double(), d.log_prob(given), rtol=1e-5, atol=1e-5)
+        v3 = torch.full((N,), float("nan"), device=dev)
+        ops.ppo_value_head(h, wp, bp, wv, bv, None, lp2, v3)
+        assert torch.equal(v3, val)
     # frequencies
     N, K, A = 4096, 64, 5
     h = torch.zeros(N, K, device=dev)
