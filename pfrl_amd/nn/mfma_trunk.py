@@ -128,14 +128,39 @@ def _fwd_splits(M, F, K):
     return _ceil_div(nch, cps)
 
 
+def _wgrad_tile(M, Cout, K):
+    """(rows, columns) of the weight-gradient tile program pfrl_conv2d_nhwc_bwd_weight picks
+    (csrc/qnet.hip; keep in step)."""
+    if M >= 16384 and Cout % 32 == 0:
+        if Cout % 64 == 0 and K % 128 == 0 and M >= 262144:
+            return 64, 128
+        if Cout % 64 == 0 and K % 64 == 0:
+            return 64, 64
+        if K % 256 == 0:
+            return 32, 256
+        if K % 128 == 0:
+            return 32, 128
+    return (32, 32) if Cout % 32 == 0 else (16, 32)
+
+
 def _wgrad_splits(M, Cout, K):
     nch = _ceil_div(M, 32)
+    bi, bj = _wgrad_tile(M, Cout, K)
+    if bi * bj > 32 * 32:
+        # large tile programs (rollout / update size): what the kernel wants is ~4 000 workgroups
+        # (16 per CU) of at least 16 chunks each -- measured (profiles/r04_wgrad_splits.txt): more,
+        # shorter walks beat fewer, longer ones by 15-35 %, and beyond that nothing moves -- while
+        # every split is a slab of the whole output that the fold launch reads back: 4 096 splits
+        # for the first convolution (one tile, 33 KB slabs), ~10 for the linear layer (392 tiles,
+        # 6.4 MB slabs: 32 splits cost 50 us of fold for 14 us of kernel)
+        tiles = _ceil_div(Cout, bi) * _ceil_div(K, bj)
+        want = min(max(_ceil_div(4096, tiles), 1), max(nch // 16, 1), _WGRAD_MAX_SPLITS)
+        cps = _ceil_div(nch, want)
+        return _ceil_div(nch, cps)
     tiles = _ceil_div(Cout, 32) * (K // 32)
-    # enough workgroups to fill the chip, and at most 16 chunks walked per workgroup (up to 1024
-    # splits).  The same rule for the large tile programs of update-sized batches: fewer, longer
-    # walks (~3 workgroups per CU, 256 chunks each) measured 15 - 35 % SLOWER there
-    # (profiles/r04_layer_sweep.txt: conv1 1290 -> 1756 us, linear layer 552 -> 725 us at B = 16384)
-    want = min(max(448 // tiles, _ceil_div(nch, _WGRAD_CPS), 1), nch, _WGRAD_MAX_SPLITS)
+    # minibatch-sized launches: enough workgroups to fill the chip, and at most 16 chunks walked per
+    # workgroup
+    want = min(max(448 // tiles, _ceil_div(nch, _WGRAD_CPS), 1), nch, 1024)
     cps = _ceil_div(nch, want)
     return _ceil_div(nch, cps)
 
