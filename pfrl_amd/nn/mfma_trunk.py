@@ -300,30 +300,18 @@ def flush_fwd_folds(sink):
 # the planar (NCHW) output / planar -> NHWC input gradient of the minibatch route.  Planar stores
 # and the permuted input-gradient stores are 4-byte accesses 196 B / 256 B apart: 51 M of them per
 # launch at B = 16384 (PPO's minibatch), where they -- not the MFMAs -- set the launch time.  The
-# re-ordered weight is 6.4 MB, cached per weight version (the parameters change 16 times per rollout,
-# the trunk runs ~170 times; inside a stream capture the copy is made in the graph instead), the
-# weight gradient is re-ordered back by one copy.  Not for the replay agents' minibatches, whose
-# bit-identity tests pin the planar route.
+# re-ordered weight is a 6.4 MB copy per forward pass, the weight gradient is re-ordered back by
+# another.  Not for the replay agents' minibatches, whose bit-identity tests pin the planar route.
 _NHWC_FC_MIN_BATCH = int(os.environ.get("PFRL_TRUNK_NHWC_FC_MIN_BATCH", "1024"))
-_WP_CACHE = {}
 
 
 def _reordered_weight(wf, C, P):
-    """wf [F, C * P] with columns (c, p) -> [F, P * C] with columns (p, c)."""
+    """wf [F, C * P] with columns (c, p) -> [F, P * C] with columns (p, c): one 6.4 MB copy (~10 us)
+    per forward pass, against >= 200 us of trunk at the batch sizes that take this route.  Not
+    cached: the optimizers and the target-network sync of this package write parameters through raw
+    pointers, which a tensor's version counter never sees."""
     F = wf.shape[0]
-    if torch.cuda.is_current_stream_capturing():
-        # inside a captured update the copy is part of the graph (10 us), never a cached tensor:
-        # a replay must read the weights of ITS update
-        return wf.detach().view(F, C, P).transpose(1, 2).contiguous().view(F, P * C)
-    key = wf.data_ptr()
-    hit = _WP_CACHE.get(key)
-    if hit is not None and hit[0] == wf._version and hit[1].shape == wf.shape:
-        return hit[1]
-    wp = wf.detach().view(F, C, P).transpose(1, 2).contiguous().view(F, P * C)
-    if len(_WP_CACHE) > 8:
-        _WP_CACHE.clear()
-    _WP_CACHE[key] = (wf._version, wp)
-    return wp
+    return wf.detach().view(F, C, P).transpose(1, 2).contiguous().view(F, P * C)
 
 
 class _Trunk(torch.autograd.Function):
