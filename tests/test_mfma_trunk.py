@@ -118,6 +118,44 @@ def test_conv_kernels_match_torch(geom, B):
 
 
 @gpu
+def test_nhwc_route_of_the_hidden_layer_matches_torch_and_sees_raw_pointer_updates():
+    """From 1 024 observations up the trunk's last convolution writes NHWC rows and the hidden layer
+    reads a column-re-ordered copy of its weight (csrc-free: one torch copy per forward pass).
+    Forward, every gradient, and -- the hazard a cached copy would have -- a forward pass AFTER the
+    parameters were stepped by this package's own optimizer, which writes through raw pointers that
+    a tensor's version counter never sees, against stock PyTorch on the same (updated) weights."""
+    from pfrl_amd.optimizers import FusedRMSprop
+
+    dev = torch.device("cuda:0")
+    B = 1056                       # > 1 024 and ragged against every tile height
+    ref = _nature_q()
+    dut = copy.deepcopy(ref).to(dev).to(memory_format=torch.channels_last)
+    mt.accelerate_heads(dut)
+    torch.manual_seed(3)
+    x = torch.rand(B, 4, 84, 84)
+    xg = x.to(dev).contiguous(memory_format=torch.channels_last)
+    assert B >= mt._NHWC_FC_MIN_BATCH and mt.plan_for(dut[0].layers, dut[0].output, xg) is not None
+    q_ref, q = ref(x), dut(xg)
+    _close(q, q_ref, 5e-6)
+    g = torch.randn_like(q_ref)
+    q_ref.backward(g)
+    q.backward(g.to(dev))
+    for (name, p), (_, pr) in zip(dut.named_parameters(), ref.named_parameters()):
+        assert p.grad.stride() == p.stride(), name
+        _close(p.grad, pr.grad, 2e-3)       # (B x 400 terms per conv1 weight, f32 on both sides)
+    opt = FusedRMSprop(dut.parameters(), lr=1e-2, alpha=0.95, eps=1e-2, centered=True)
+    opt_ref = torch.optim.RMSprop(ref.parameters(), lr=1e-2, alpha=0.95, eps=1e-2, centered=True)
+    v0 = dut[0].output.weight._version
+    opt.step()
+    opt_ref.step()
+    assert dut[0].output.weight._version == v0      # (the premise: the write is invisible to autograd)
+    with torch.no_grad():
+        moved = float((dut(xg) - q).abs().max())
+        assert moved > 1e-3                          # the step really changed the function
+        _close(dut(xg), ref(x), 2e-4)                # and the trunk computes with the NEW weights
+
+
+@gpu
 @pytest.mark.parametrize("geom", [(4, 32, 8, 4, 84), (32, 64, 4, 2, 20), (64, 64, 3, 1, 9), (3136, 512, 1, 1, 1)])
 def test_large_tile_programs_equal_the_minibatch_ones_bit_for_bit(geom, monkeypatch):
     """The 128-row forward programs and the 64 x 64 ... 32 x 256 weight-gradient programs that
