@@ -251,6 +251,9 @@ class DQN(agent.AttributeSavingMixin, agent.BatchAgent):
     def sync_target_network(self):
         synchronize_parameters(src=self.model, dst=self.target_model,
                                method=self.target_update_method, tau=self.soft_update_tau)
+        self._side_needs_main = True     # (a side stream reading the target network: see _range_side)
+
+    _side_needs_main = True
 
     # -- learning -------------------------------------------------------------
     def update(self, experiences, errors_out=None):
@@ -746,16 +749,60 @@ class DQN(agent.AttributeSavingMixin, agent.BatchAgent):
         # preparation.  Order of appends, RNG draws, target syncs and updates is the
         # reference's in every case.
         chunks = self.step_fused_chunks
+        side = None
         if self.__dict__.get("_obs_cols") is not None and not self._chunks_set_by_caller:
             # native step: the host's share of a step is ~0.3 ms and nothing waits for the GPU, so
             # there is no preparation to hide -- one range, one gather, one graph per step
             # (measured 33.4 k vs 33.0 k env-steps/s with the (0.1, 0.4) cuts)
             chunks = ()
+            if self._range_overlap_ok():
+                # ... unless the NEXT range's replay side -- appends, the fused gather, the target
+                # network's pass over its next-states: 0.5 ms of a 6.1 ms step -- runs on a second
+                # stream UNDER the current range's update graph (64 latency-bound B = 32 updates
+                # that leave most of the chip idle).  Two ranges: a short one whose replay side is
+                # exposed, and the rest of the step hidden behind its updates.
+                chunks = self._RANGE_OVERLAP_CUT
+                side = self._range_side_stream()
         cuts = sorted({0, n_env} | {int(n_env * f) for f in chunks})
         for lo, hi in zip(cuts[:-1], cuts[1:]):
-            self._observe_range_fused(lo, hi, batch_obs, batch_reward, batch_done, batch_reset)
+            self._observe_range_fused(lo, hi, batch_obs, batch_reward, batch_done, batch_reset,
+                                      side=side)
 
-    def _observe_range_fused(self, lo, hi, batch_obs, batch_reward, batch_done, batch_reset):
+    _RANGE_OVERLAP_CUT = (float(os.environ.get("PFRL_DQN_RANGE_CUT", "0.25")),)
+
+    def _range_overlap_ok(self):
+        return (os.environ.get("PFRL_DQN_RANGE_OVERLAP", "1") != "0" and self.device.type == "cuda"
+                and self.use_graphs and self.range_graphs and self._replay_stream is None
+                and self.batch_target_pass and not self.recurrent)
+
+    def _range_side_stream(self):
+        s = self.__dict__.get("_range_side")
+        if s is None:
+            s = self._range_side = torch.cuda.Stream(self.device)
+        return s
+
+    def _observe_range_fused(self, lo, hi, batch_obs, batch_reward, batch_done, batch_reset,
+                             side=None):
+        """``side``: a second stream for this range's replay side (appends, gather, target pass).
+        It waits for the main stream at the first range of a step (this step's frames, actions and
+        everything before them) and after a target sync; the main stream waits for it before the
+        range's updates.  Nothing the side stream writes is read by the update graph of the
+        PREVIOUS range still running on the main stream (minibatch and target buffers alternate
+        between sets, the table rows it appends are read by gathers only), nothing it reads is
+        written there (the target network, the frame ring)."""
+        import contextlib
+
+        main = torch.cuda.current_stream(self.device) if side is not None else None
+        if side is not None and (lo == 0 or self._side_needs_main):
+            side.wait_stream(main)
+            self._side_needs_main = False
+        with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
+            plan = self._plan_and_fetch_range(lo, hi, batch_obs, batch_reward, batch_done, batch_reset)
+        if side is not None:
+            main.wait_stream(side)
+        self._run_range_updates(lo, hi, plan)
+
+    def _plan_and_fetch_range(self, lo, hi, batch_obs, batch_reward, batch_done, batch_reset):
         rbuf = self.replay_buffer
         up = self.replay_updater
         t0 = self.t
@@ -820,6 +867,10 @@ class DQN(agent.AttributeSavingMixin, agent.BatchAgent):
                         (U, B) + tuple(raw.shape[1:]), dtype=raw.dtype, device=raw.device)
                 buf.view(raw.shape).copy_(raw)
                 big["target_next_raw"] = buf
+        return plan_env, big, t0
+
+    def _run_range_updates(self, lo, hi, plan):
+        plan_env, big, t0 = plan
         if big is not None and self._range_as_one_graph(t0, hi - lo):
             # nothing happens on the host between this range's updates (no target sync
             # inside it): the whole range replays as ONE captured graph
