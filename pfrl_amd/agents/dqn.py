@@ -756,11 +756,13 @@ class DQN(agent.AttributeSavingMixin, agent.BatchAgent):
             # (measured 33.4 k vs 33.0 k env-steps/s with the (0.1, 0.4) cuts)
             chunks = ()
             if self._range_overlap_ok():
-                # ... unless the NEXT range's replay side -- appends, the fused gather, the target
-                # network's pass over its next-states: 0.5 ms of a 6.1 ms step -- runs on a second
-                # stream UNDER the current range's update graph (64 latency-bound B = 32 updates
-                # that leave most of the chip idle).  Two ranges: a short one whose replay side is
-                # exposed, and the rest of the step hidden behind its updates.
+                # (opt-in, PFRL_DQN_RANGE_OVERLAP=1: the NEXT range's replay side -- appends, the
+                # fused gather, the target network's pass over its next-states: 0.5 ms of a 6.1 ms
+                # step -- on a second stream UNDER the current range's update graph.  Measured on
+                # MI355X and NOT faster: 37.9 k vs 41.3 k env-steps/s at cuts of 12.5 / 25 / 50 %.
+                # The 64 B = 32 updates are latency-bound launch chains, and a 38-GFLOP target pass
+                # beside them stretches every launch (update 84.5 -> 92.4 us) by more than the
+                # 0.4 ms it hides.)
                 chunks = self._RANGE_OVERLAP_CUT
                 side = self._range_side_stream()
         cuts = sorted({0, n_env} | {int(n_env * f) for f in chunks})
@@ -771,7 +773,7 @@ class DQN(agent.AttributeSavingMixin, agent.BatchAgent):
     _RANGE_OVERLAP_CUT = (float(os.environ.get("PFRL_DQN_RANGE_CUT", "0.25")),)
 
     def _range_overlap_ok(self):
-        return (os.environ.get("PFRL_DQN_RANGE_OVERLAP", "1") != "0" and self.device.type == "cuda"
+        return (os.environ.get("PFRL_DQN_RANGE_OVERLAP", "0") == "1" and self.device.type == "cuda"
                 and self.use_graphs and self.range_graphs and self._replay_stream is None
                 and self.batch_target_pass and not self.recurrent)
 
