@@ -55,6 +55,31 @@ def world_size():
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
 
+def control_all_reduce_sum(t):
+    """Control-plane SUM all-reduce of a small tensor, in place, on ANY backend: with gloo (the
+    default control plane beside the direct RCCL data plane) a device tensor is staged through the
+    host -- gloo's device support is a build option this code does not rely on."""
+    if t.is_cuda and dist.get_backend() != "nccl":
+        h = t.detach().cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.SUM)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t
+
+
+def control_broadcast(t, src=0):
+    """Control-plane broadcast of one tensor, in place, on any backend (see above)."""
+    if t.is_cuda and dist.get_backend() != "nccl":
+        h = t.detach().cpu()
+        dist.broadcast(h, src=src)
+        if dist.get_rank() != src:
+            t.copy_(h)
+    else:
+        dist.broadcast(t, src=src)
+    return t
+
+
 def shard_envs(num_envs, rank=None, world=None):
     """Contiguous env slice [lo, hi) owned by ``rank``."""
     if world is None:
@@ -528,7 +553,7 @@ class GradientAllReducer:
         if not (dist.is_available() and dist.is_initialized()):
             return
         for t in list(module.parameters()) + list(module.buffers()):
-            dist.broadcast(t.data, src=src)
+            control_broadcast(t.data, src=src)
 
 
 _CAPTURE_PROBE = {}
@@ -611,7 +636,7 @@ def broadcast_agent(agent, src=0):
         if isinstance(module, torch.nn.Module) and id(module) not in seen:
             seen.add(id(module))
             for t in list(module.parameters()) + list(module.buffers()):
-                dist.broadcast(t.data, src=src)
+                control_broadcast(t.data, src=src)
 
 
 def global_mean_std(mean_std, n):
@@ -625,7 +650,7 @@ def global_mean_std(mean_std, n):
     m, s = mean_std[0].double(), mean_std[1].double()
     acc = torch.stack([torch.as_tensor(float(n), dtype=torch.float64, device=mean_std.device),
                        m * n, (s * s + m * m) * n])
-    dist.all_reduce(acc, op=dist.ReduceOp.SUM)
+    control_all_reduce_sum(acc)
     gm = acc[1] / acc[0]
     gv = torch.clamp(acc[2] / acc[0] - gm * gm, min=0.0)
     return torch.stack([gm, torch.sqrt(gv)]).to(mean_std.dtype)

@@ -72,14 +72,14 @@ class EmpiricalNormalization(nn.Module):
 
     def _union_batch_stats(self, x, n):
         """(count, mean, biased variance) of all ranks' batches together, as tensors."""
-        import torch.distributed as dist
-
         x64 = x.double()
         s1 = x64.sum(dim=self.batch_axis, keepdim=True)
         s2 = (x64 * x64).sum(dim=self.batch_axis, keepdim=True)
         acc = torch.cat([s1.reshape(-1), s2.reshape(-1),
                          torch.full((1,), float(n), dtype=torch.float64, device=x.device)])
-        dist.all_reduce(acc, op=dist.ReduceOp.SUM)
+        from pfrl_amd import distributed
+
+        distributed.control_all_reduce_sum(acc)
         d = s1.numel()
         total = acc[-1].clamp(min=1.0)
         mean = (acc[:d] / total).view_as(s1)
