@@ -763,6 +763,7 @@ def data_path_only(args, device, agent, env, rbuf, obss, steps):
             "what": "the replay side alone: env frames, acting gather + action select, native "
                     "planner + one transfer, appends, the fused gather of all 64 minibatches of the "
                     "step; no per-update launch"}
+        data_path_only.last_stub = stub          # (tools/data_path_phases.py times its phases)
     except Exception as e:      # an extra figure must never cost the line its numbers
         sys.stderr.write("data_path_only.without_update_launches failed: %r\n" % (e,))
     return out, obss

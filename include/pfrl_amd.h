@@ -585,6 +585,10 @@ int pfrl_twin_input_grad(const float *const *dy, const float *const *dy_mask, co
  *   receives -logp, the entropy estimate recorded at :299-306.
  * pfrl_squashed_gaussian_bwd: gradients w.r.t. loc and scale ([B][A] each) from
  *   dL/daction (may be NULL) and dL/dlogp (may be NULL).
+ * pfrl_squashed_head_fwd / _bwd: the same two launches with the example's head function folded
+ *   in (train_soft_actor_critic.py:128-141: mean, log_scale = chunk(x, 2); scale =
+ *   sqrt(exp(2 clamp(log_scale, lo, hi))), mode 0 -- or exp(clamp(..)), mode 1): x [B][2A] (row
+ *   stride ldx) is the last Linear's output, g_x [B][2A] its gradient, clamp mask included.
  * pfrl_soft_update: dst <- (1 - tau) dst + tau src for n tensors in one launch
  *   (pfrl/utils/copy_param.py:10-28; host arrays of device pointers, by value).
  * pfrl_adam_step: torch.optim.Adam's update (no amsgrad; _single_tensor_adam
@@ -597,6 +601,12 @@ int pfrl_squashed_gaussian_fwd(const float *loc, int64_t ld_loc, const float *sc
 int pfrl_squashed_gaussian_bwd(const float *g_action, const float *g_logp, const float *action,
                                const float *eps, const float *scale, int64_t ld_scale, float *g_loc,
                                float *g_scale, int32_t B, int32_t A, void *stream);
+int pfrl_squashed_head_fwd(const float *x, int64_t ldx, float clamp_lo, float clamp_hi, int32_t mode,
+                           const float *eps, float *action, float *logp, float *neg_logp, int32_t B,
+                           int32_t A, void *stream);
+int pfrl_squashed_head_bwd(const float *g_action, const float *g_logp, const float *action,
+                           const float *eps, const float *x, int64_t ldx, float clamp_lo, float clamp_hi,
+                           int32_t mode, float *g_x, int32_t B, int32_t A, void *stream);
 int pfrl_soft_update(int32_t n_tensors, float *const *dst, const float *const *src,
                      const int64_t *numel, double tau, void *stream);
 int pfrl_adam_step(int32_t n_tensors, float *const *params, const float *const *grads,

@@ -202,6 +202,8 @@ EXPORTS = {
     "pfrl_linear_small_bwd": (ctypes.c_int, "ppppppiiip"),
     "pfrl_squashed_gaussian_fwd": (ctypes.c_int, "pqpqppppiip"),
     "pfrl_squashed_gaussian_bwd": (ctypes.c_int, "pppppqppiip"),
+    "pfrl_squashed_head_fwd": (ctypes.c_int, "pqffippppiip"),
+    "pfrl_squashed_head_bwd": (ctypes.c_int, "pppppqffipiip"),
     "pfrl_soft_update": (ctypes.c_int, "ipppdp"),
     "pfrl_adam_step": (ctypes.c_int, "ippppppdddddpp"),
     "pfrl_sac_temperature_loss": (ctypes.c_int, "ppfpip"),

@@ -83,6 +83,81 @@ __global__ __launch_bounds__(kThreads) void k_squashed_gaussian_bwd(
     g_scale[i] = t * e + gl * (y2 * e - 1.f / s);
 }
 
+// The example policy head folded into the same two launches: x [B, 2A] is the last Linear's output,
+// (mean | log_scale) side by side; scale = sqrt(exp(2 clamp(log_scale, lo, hi))) (MODE 0, the
+// arithmetic of train_soft_actor_critic.py:128-141, one rounded f32 operation per torch op) or
+// exp(clamp(log_scale, lo, hi)) (MODE 1).  Replaces chunk / clamp / mul / exp / sqrt forward and
+// their ten backward launches (sqrt, exp, mul, two compares, and, where, fill x2, cat).
+template <int MODE>
+__device__ __forceinline__ float head_scale(float ls, float lo, float hi, float &v) {
+    float c = ls < lo ? lo : ls;          // torch.clamp: min(max(x, lo), hi), NaN passes through
+    c = c > hi ? hi : c;
+    if (MODE == 0) {
+        v = expf(c * 2.f);
+        return sqrtf(v);
+    }
+    v = expf(c);
+    return v;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(kThreads) void k_squashed_head_fwd(
+    const float *__restrict__ x, int64_t ldx, float lo, float hi, const float *__restrict__ eps,
+    float *__restrict__ action, float *__restrict__ logp, float *__restrict__ neg_logp, int B, int A) {
+    const int row = blockIdx.x * (kThreads / 64) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= B) return;
+    float s_ladj = 0.f, s_nlp = 0.f;
+    for (int a = lane; a < A; a += 64) {
+        float v;
+        const float l = x[(int64_t)row * ldx + a];
+        const float s = head_scale<MODE>(x[(int64_t)row * ldx + A + a], lo, hi, v);
+        const float e = eps[(int64_t)row * A + a];
+        const float u = l + e * s;
+        action[(int64_t)row * A + a] = tanhf(u);
+        const float d = u - l;
+        const float nlp = -(d * d) / (2.f * (s * s)) - logf(s) - 0.9189385332046727f;
+        const float z = -2.f * u;
+        const float sp = z > 20.f ? z : log1pf(expf(z));
+        s_ladj += 2.f * (0.6931471805599453f - u - sp);
+        s_nlp += nlp;
+    }
+    s_ladj = wave_sum(s_ladj);
+    s_nlp = wave_sum(s_nlp);
+    if (lane == 0) {
+        const float lp = (0.f - s_ladj) + s_nlp;
+        logp[row] = lp;
+        if (neg_logp != nullptr) neg_logp[row] = -lp;
+    }
+}
+
+// d/dx of the above: the mean half takes g_loc as is; the log-scale half takes g_scale through
+// sqrt (g / (2 s)), exp (g v), the doubling and the clamp mask (lo <= log_scale <= hi), each the
+// rounded operation of the autograd formula it replaces.
+template <int MODE>
+__global__ __launch_bounds__(kThreads) void k_squashed_head_bwd(
+    const float *__restrict__ g_action, const float *__restrict__ g_logp,
+    const float *__restrict__ action, const float *__restrict__ eps, const float *__restrict__ x,
+    int64_t ldx, float lo, float hi, float *__restrict__ g_x, int B, int A) {
+    const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (i >= (int64_t)B * A) return;
+    const int row = (int)(i / A), a = (int)(i - (int64_t)row * A);
+    const float ls = x[(int64_t)row * ldx + A + a];
+    float v;
+    const float s = head_scale<MODE>(ls, lo, hi, v);
+    const float y = action[i], e = eps[i];
+    const float ga = g_action != nullptr ? g_action[i] : 0.f;
+    const float gl = g_logp != nullptr ? g_logp[row] : 0.f;
+    const float t = ga * (1.f - y * y);
+    const float y2 = 2.f * y;
+    const float g_scale = t * e + gl * (y2 * e - 1.f / s);
+    float g_c;
+    if (MODE == 0) g_c = ((g_scale / (2.f * s)) * v) * 2.f;
+    else g_c = g_scale * v;
+    const bool inside = ls >= lo && ls <= hi;
+    g_x[(int64_t)row * 2 * A + a] = t + gl * y2;
+    g_x[(int64_t)row * 2 * A + A + a] = inside ? g_c : 0.f;
+}
+
 // ---------------------------------------------------------------------------------
 // multi-tensor elementwise launches
 // ---------------------------------------------------------------------------------
@@ -341,6 +416,39 @@ extern "C" int pfrl_squashed_gaussian_bwd(const float *g_action, const float *g_
     hipLaunchKernelGGL(k_squashed_gaussian_bwd, dim3((unsigned)((n + kThreads - 1) / kThreads)),
                        dim3(kThreads), 0, (hipStream_t)stream, g_action, g_logp, action, eps, scale,
                        ld_scale, g_loc, g_scale, B, A);
+    PFRL_LAUNCH_CHECK();
+}
+
+extern "C" int pfrl_squashed_head_fwd(const float *x, int64_t ldx, float clamp_lo, float clamp_hi,
+                                      int32_t mode, const float *eps, float *action, float *logp,
+                                      float *neg_logp, int32_t B, int32_t A, void *stream) {
+    PFRL_CHECK_ARG(B >= 0 && A >= 1 && ldx >= 2 * (int64_t)A && (mode == 0 || mode == 1) && clamp_lo <= clamp_hi,
+                   "pfrl_squashed_head_fwd: bad shape");
+    if (B == 0) return 0;
+    if (mode == 0)
+        hipLaunchKernelGGL(k_squashed_head_fwd<0>, dim3((B + 3) / 4), dim3(kThreads), 0, (hipStream_t)stream,
+                           x, ldx, clamp_lo, clamp_hi, eps, action, logp, neg_logp, B, A);
+    else
+        hipLaunchKernelGGL(k_squashed_head_fwd<1>, dim3((B + 3) / 4), dim3(kThreads), 0, (hipStream_t)stream,
+                           x, ldx, clamp_lo, clamp_hi, eps, action, logp, neg_logp, B, A);
+    PFRL_LAUNCH_CHECK();
+}
+
+extern "C" int pfrl_squashed_head_bwd(const float *g_action, const float *g_logp, const float *action,
+                                      const float *eps, const float *x, int64_t ldx, float clamp_lo,
+                                      float clamp_hi, int32_t mode, float *g_x, int32_t B, int32_t A,
+                                      void *stream) {
+    PFRL_CHECK_ARG(B >= 0 && A >= 1 && ldx >= 2 * (int64_t)A && (mode == 0 || mode == 1),
+                   "pfrl_squashed_head_bwd: bad shape");
+    if (B == 0) return 0;
+    const int64_t n = (int64_t)B * A;
+    const dim3 grid((unsigned)((n + kThreads - 1) / kThreads));
+    if (mode == 0)
+        hipLaunchKernelGGL(k_squashed_head_bwd<0>, grid, dim3(kThreads), 0, (hipStream_t)stream, g_action,
+                           g_logp, action, eps, x, ldx, clamp_lo, clamp_hi, g_x, B, A);
+    else
+        hipLaunchKernelGGL(k_squashed_head_bwd<1>, grid, dim3(kThreads), 0, (hipStream_t)stream, g_action,
+                           g_logp, action, eps, x, ldx, clamp_lo, clamp_hi, g_x, B, A);
     PFRL_LAUNCH_CHECK();
 }
 

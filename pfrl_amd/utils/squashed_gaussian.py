@@ -99,3 +99,154 @@ def sample_with_log_prob(distrib, reparameterize, with_negation=False):
         with torch.no_grad():
             a, lp, neg = _SquashedGaussian.apply(loc, scale, eps)
     return (a, lp, neg) if with_negation else (a, lp)
+
+
+# -------------------------------------------------------------------------------------------------
+# the example's head function folded into the same two launches
+# -------------------------------------------------------------------------------------------------
+class HeadSpec:
+    """What :func:`recognise_head` found: the clamp bounds of the log-scale, the scale formula
+    (0: ``sqrt(exp(2 c))``, 1: ``exp(c)``) and the action width."""
+
+    __slots__ = ("lo", "hi", "mode", "A", "bit_exact")
+
+    def __init__(self, lo, hi, mode, A, bit_exact):
+        self.lo, self.hi, self.mode, self.A, self.bit_exact = lo, hi, mode, A, bit_exact
+
+    def __repr__(self):
+        return "HeadSpec(clamp=[%g, %g], scale=%s, A=%d, bit_exact=%s)" % (
+            self.lo, self.hi, ("sqrt(exp(2c))", "exp(c)")[self.mode], self.A, self.bit_exact)
+
+
+class _SquashedHead(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, eps, spec):
+        B, A = x.shape[0], spec.A
+        action = torch.empty((B, A), dtype=torch.float32, device=x.device)
+        both = torch.empty((2, B), dtype=torch.float32, device=x.device)
+        logp, neg = both[0], both[1]
+        check(_native.lib().pfrl_squashed_head_fwd(_p(x), x.stride(0), spec.lo, spec.hi, spec.mode,
+                                                   _p(eps), _p(action), _p(logp), _p(neg), B, A,
+                                                   _stream()), "squashed_head_fwd")
+        ctx.save_for_backward(action, eps, x)
+        ctx.spec = spec
+        ctx.mark_non_differentiable(neg)
+        return action, logp, neg
+
+    @staticmethod
+    def backward(ctx, g_action, g_logp, _g_neg):
+        action, eps, x = ctx.saved_tensors
+        spec = ctx.spec
+        B, A = action.shape
+        g_x = torch.empty((B, 2 * A), dtype=torch.float32, device=x.device)
+        ga = g_action.contiguous() if g_action is not None else None
+        gl = g_logp.contiguous() if g_logp is not None else None
+        check(_native.lib().pfrl_squashed_head_bwd(_p(ga), _p(gl), _p(action), _p(eps), _p(x),
+                                                   x.stride(0), spec.lo, spec.hi, spec.mode, _p(g_x),
+                                                   B, A, _stream()), "squashed_head_bwd")
+        return g_x, None, None
+
+
+def head_sample_with_log_prob(x, spec, reparameterize):
+    """(action, log_prob, -log_prob) of the recognised head applied to ``x`` [B, 2A]: what
+    ``sample_with_log_prob(head(x), reparameterize, with_negation=True)`` returns, the same draw
+    from the device generator included."""
+    assert x.is_cuda and x.dim() == 2 and x.shape[1] == 2 * spec.A and x.dtype == torch.float32
+    if x.stride(1) != 1:
+        x = x.contiguous()
+    eps = _standard_normal((x.shape[0], spec.A), dtype=x.dtype, device=x.device)
+    if reparameterize:
+        return _SquashedHead.apply(x, eps, spec)
+    with torch.no_grad():
+        return _SquashedHead.apply(x, eps, spec)
+
+
+def _scale_formula(ls, lo, hi, mode):
+    c = torch.clamp(ls, lo, hi)
+    return torch.sqrt(torch.exp(c * 2)) if mode == 0 else torch.exp(c)
+
+
+def recognise_head(fn, width, device):
+    """Is ``fn`` (the function inside the policy's last ``Lambda``) the example's head --
+    ``mean, log_scale = chunk(x, 2, dim=1)``; a tanh-squashed diagonal Gaussian with ``loc = mean``
+    and ``scale = sqrt(exp(2 clamp(log_scale, lo, hi)))`` or ``exp(clamp(log_scale, lo, hi))`` --
+    and if so with which bounds?  Decided by probing it on the device, the way
+    ``recognise_phi`` decides about observation scalers: the returned distribution must have that
+    structure, its ``loc`` must BE the first half of the input, its ``scale`` must equal one of
+    the two formulas bit for bit on 4 099 log-scales (a sweep of [-30, 10], far outliers, NaN-free
+    random rows), and sample, log-probability and input gradient of the fused launches must agree
+    with ``fn`` + the distribution kernels on those rows.  Anything else: None, and the caller
+    keeps calling ``fn``.  Consumes nothing from the global generators."""
+    device = torch.device(device)
+    if device.type != "cuda" or width < 2 or width % 2 or not _native.available():
+        return None
+    A = width // 2
+    try:
+        gen = torch.Generator(device=device)
+        gen.manual_seed(20240924)
+        sweep = torch.linspace(-30.0, 10.0, 2048, device=device)
+        rnd = torch.randn(2048, generator=gen, device=device) * 4.0
+        far = torch.tensor([-1e4, 1e4, 0.0], device=device)
+        ls_col = torch.cat([far, sweep, rnd])
+        R = ls_col.numel()
+        # every action column sees every probe value (rolled, so that columns are not copies)
+        ls = torch.stack([torch.roll(ls_col[3:], 7 * j) for j in range(A)], dim=1)
+        ls = torch.cat([ls_col[:3, None].expand(3, A), ls], dim=0).contiguous()
+        mean = torch.randn((R, A), generator=gen, device=device) * 2.0
+        x = torch.cat([mean, ls], dim=1).contiguous()
+        with torch.no_grad():
+            d = fn(x)
+        params = squashed_gaussian_params(d)
+        if params is None:
+            return None
+        loc, scale = params
+        if loc.shape != (R, A) or not torch.equal(loc, mean):
+            return None
+        s_lo, s_hi = scale[0], scale[1]
+        if not (bool((s_lo == s_lo[0]).all()) and bool((s_hi == s_hi[0]).all())):
+            return None
+        found = None
+        for mode in (0, 1):
+            bounds = []
+            for s_edge in (float(s_lo[0]), float(s_hi[0])):
+                if not (s_edge > 0.0) or s_edge == float("inf"):
+                    break
+                import math
+
+                guess = math.log(s_edge)
+                hit = None
+                for digits in range(0, 7):
+                    c = round(guess, digits)
+                    t = torch.full((1,), c, dtype=torch.float32, device=device)
+                    if float(_scale_formula(t, c, c, mode)) == s_edge:
+                        hit = c
+                        break
+                if hit is None:
+                    break
+                bounds.append(hit)
+            if len(bounds) == 2 and bounds[0] <= bounds[1] and torch.equal(
+                    _scale_formula(ls, bounds[0], bounds[1], mode), scale):
+                found = (bounds[0], bounds[1], mode)
+                break
+        if found is None:
+            return None
+        spec = HeadSpec(found[0], found[1], found[2], A, False)
+        # the fused launches against fn + the distribution launches, same eps, same upstream grads
+        eps = torch.randn((R, A), generator=gen, device=device)
+        g_a = torch.randn((R, A), generator=gen, device=device)
+        g_l = torch.randn((R,), generator=gen, device=device)
+        xa = x.clone().requires_grad_(True)
+        a1, lp1, _ = _SquashedHead.apply(xa, eps, spec)
+        (gx1,) = torch.autograd.grad([a1, lp1], [xa], [g_a, g_l])
+        xb = x.clone().requires_grad_(True)
+        loc2, scale2 = squashed_gaussian_params(fn(xb))
+        a2, lp2, _ = _SquashedGaussian.apply(loc2, scale2, eps)
+        (gx2,) = torch.autograd.grad([a2, lp2], [xb], [g_a, g_l])
+        if not (torch.allclose(a1, a2, rtol=1e-6, atol=1e-7)
+                and torch.allclose(lp1, lp2, rtol=1e-6, atol=1e-5)
+                and torch.allclose(gx1, gx2, rtol=1e-5, atol=1e-6 * float(gx2.abs().max()))):
+            return None
+        spec.bit_exact = bool(torch.equal(a1, a2) and torch.equal(lp1, lp2) and torch.equal(gx1, gx2))
+        return spec
+    except Exception:      # fn does not take such an input, returns something else, ...: not the head
+        return None

@@ -126,6 +126,90 @@ def test_squashed_gaussian_matches_torch_distributions(B, A):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("B,A", [(256, 17), (32, 6), (1, 1), (100, 70)])
+def test_fused_policy_head_equals_the_head_function_plus_the_distribution_launches(B, A):
+    """pfrl_squashed_head_fwd/_bwd (the example's head folded in) against the user's function +
+    pfrl_squashed_gaussian_fwd/_bwd + autograd through chunk / clamp / exp / sqrt: same draw,
+    same sample, same log-probability, same input gradient -- log-scales on both sides of both
+    clamp bounds included (the mask of clamp's backward)."""
+    from pfrl_amd.utils.squashed_gaussian import head_sample_with_log_prob, recognise_head
+
+    dev = torch.device("cuda:0")
+    spec = recognise_head(_head, 2 * A, dev)
+    assert spec is not None and (spec.lo, spec.hi, spec.mode, spec.A) == (-20.0, 2.0, 0, A)
+    g = torch.Generator().manual_seed(B * 100 + A)
+    raw = torch.randn(B, 2 * A, generator=g) * 1.5
+    raw[:, A:] = raw[:, A:] * 8.0 - 6.0            # log-scales from about -30 to 18
+    raw = raw.to(dev)
+    g_a = torch.randn(B, A, generator=g).to(dev)
+    g_lp = torch.randn(B, generator=g).to(dev)
+    outs = []
+    for fused in (True, False):
+        x = raw.clone().requires_grad_(True)
+        torch.manual_seed(5)
+        if fused:
+            a, lp, neg = head_sample_with_log_prob(x, spec, True)
+            assert torch.equal(neg, -lp.detach())
+        else:
+            a, lp = sample_with_log_prob(_head(x), True)
+        (gx,) = torch.autograd.grad([a, lp], [x], [g_a, g_lp])
+        outs.append((a.detach(), lp.detach(), gx))
+    (a1, lp1, gx1), (a0, lp0, gx0) = outs
+    assert torch.allclose(a1, a0, rtol=1e-6, atol=1e-7)
+    assert torch.allclose(lp1, lp0, rtol=1e-6, atol=1e-5)
+    assert torch.equal(gx1[:, A:] == 0, gx0[:, A:] == 0)       # the clamp mask, element for element
+    scale = max(gx0.abs().max().item(), 1.0)
+    assert (gx1 - gx0).abs().max().item() <= 1e-6 * scale
+    if spec.bit_exact:
+        assert torch.equal(a1, a0) and torch.equal(lp1, lp0) and torch.equal(gx1, gx0)
+    torch.manual_seed(5)
+    a2, lp2, _ = head_sample_with_log_prob(raw, spec, False)
+    assert torch.equal(a2, a1) and torch.equal(lp2, lp1) and not a2.requires_grad
+
+
+@pytest.mark.gpu
+def test_policy_head_recognition_takes_only_what_it_proved():
+    from pfrl_amd.utils.squashed_gaussian import recognise_head
+
+    dev = torch.device("cuda:0")
+
+    def squashed(loc, scale):
+        return D.TransformedDistribution(D.Independent(D.Normal(loc=loc, scale=scale), 1),
+                                         [D.transforms.TanhTransform(cache_size=1)])
+
+    def exp_head(x):
+        mean, ls = torch.chunk(x, 2, dim=1)
+        return squashed(mean, torch.exp(torch.clamp(ls, -5.0, 1.5)))
+
+    spec = recognise_head(exp_head, 12, dev)
+    assert spec is not None and (spec.lo, spec.hi, spec.mode, spec.A) == (-5.0, 1.5, 1, 6)
+
+    def softplus_head(x):
+        mean, ls = torch.chunk(x, 2, dim=1)
+        return squashed(mean, torch.nn.functional.softplus(ls) + 1e-3)
+
+    def swapped_head(x):
+        ls, mean = torch.chunk(x, 2, dim=1)
+        return squashed(mean, torch.exp(torch.clamp(ls, -20.0, 2.0)))
+
+    def scaled_mean_head(x):
+        mean, ls = torch.chunk(x, 2, dim=1)
+        return squashed(mean * 0.5, torch.exp(torch.clamp(ls, -20.0, 2.0)))
+
+    def tanh_bounded_head(x):      # (log-scale squashed into the range instead of clamped)
+        mean, ls = torch.chunk(x, 2, dim=1)
+        return squashed(mean, torch.exp(-20.0 + 11.0 * (torch.tanh(ls) + 1.0)))
+
+    for fn in (softplus_head, swapped_head, scaled_mean_head, tanh_bounded_head,
+               lambda x: _head(x, cache_size=0), lambda x: x):
+        assert recognise_head(fn, 12, dev) is None
+    assert recognise_head(_head, 13, dev) is None          # odd width: no (mean | log_scale) halves
+    state = torch.cuda.get_rng_state(dev)
+    recognise_head(_head, 12, dev)
+    assert torch.equal(torch.cuda.get_rng_state(dev), state)   # the probe draws from its own generator
+
+
+@pytest.mark.gpu
 def test_other_distributions_are_left_alone():
     dev = torch.device("cuda:0")
     raw = torch.randn(4, 6, device=dev)

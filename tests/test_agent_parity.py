@@ -546,6 +546,9 @@ def test_sac_graph_captured_update_matches_reference():
     ag = got["agent"]
     assert ag.use_graphs and ag._captured is not None and len(ag._captured.graphs) >= 1
     assert ag.n_policy_updates == len(got["q_losses"])
+    # ... with the example's head function recognised and folded into the sample launches
+    assert ag._policy_head is not None and ag._policy_head.mode == 0
+    assert (ag._policy_head.lo, ag._policy_head.hi) == (-20.0, 2.0)
     _compare_sac(got, np.load(os.path.join(GOLDEN, "agent_trace_sac.npz")))
 
 
