@@ -481,7 +481,10 @@ int pfrl_noisy_weights_bwd(const float *g_w, const float *g_b, const float *r, f
  *   to 12 tensors in one launch (host arrays of device pointers, passed by value).
  * pfrl_linear_small_fwd / _bwd: a narrow head, y = x w^T + b with out_features <= 16
  *   (Linear(512, n_actions), pfrl/q_functions/state_q_functions.py) and its backward
- *   (dx may be NULL; dw and db may both be NULL for frozen weights).
+ *   (dx may be NULL; dw and db may both be NULL for frozen weights).  _bwd alone goes up to
+ *   out_features 64, M * out_features <= 10 240: the 2 x action_size policy head of SAC
+ *   (Linear(256, 34), train_soft_actor_critic.py:128-141), whose width the tile engine's
+ *   32-column gradient tiles do not divide.
  * pfrl_linear_fwd: y = act(x w^T + b), x [M][K], w [N][K], any K and N, no alignment
  *   requirement -- the `nn.Linear` layers of the MLP agents (obs 376 -> 256,
  *   obs + action 393 -> 256: examples/mujoco/reproduction/soft_actor_critic/
@@ -613,6 +616,16 @@ int pfrl_adam_step(int32_t n_tensors, float *const *params, const float *const *
                    float *const *exp_avg, float *const *exp_avg_sq, float *const *steps,
                    const int64_t *numel, double lr, double beta1, double beta2, double eps,
                    double weight_decay, void *ticket, void *stream);
+/* pfrl_adam_step with two riders: grads[t] may still be n_slabs[t] split-K partial slabs
+ * slab_stride[t] elements apart (summed slab 0 first, as pfrl_splitk_reduce sums them -- that launch
+ * then never runs; n_slabs == NULL: all plain), and soft_dst[t] (entry or array may be NULL) takes
+ * the soft target update dst <- (1 - tau) dst + tau p from the parameter value just written
+ * (pfrl_soft_update's arithmetic; pfrl/agents/soft_actor_critic.py:262-263 then :308). */
+int pfrl_adam_step_ex(int32_t n_tensors, float *const *params, const float *const *grads,
+                      const int64_t *slab_stride, const int32_t *n_slabs, float *const *exp_avg,
+                      float *const *exp_avg_sq, float *const *steps, float *const *soft_dst, double tau,
+                      const int64_t *numel, double lr, double beta1, double beta2, double eps,
+                      double weight_decay, void *ticket, void *stream);
 /* SAC losses on [B] vectors, pfrl/agents/soft_actor_critic.py.  The temperature is
  * exp(*log_temperature) when that device pointer is given (TemperatureHolder, :60-76),
  * else the float argument.
@@ -621,11 +634,20 @@ int pfrl_adam_step(int32_t n_tensors, float *const *params, const float *const *
  * pfrl_half_mse_fwd/_bwd (:247-248): loss[0] = 0.5 * mean((target - pred)^2) and its
  *   gradient w.r.t. pred given g_loss[0].
  * pfrl_sac_policy_loss_fwd/_bwd (:284-291): loss[0] = mean(T * log_prob - min(q1, q2)) and
- *   its gradients w.r.t. log_prob, q1, q2 (a tie in the minimum is split evenly). */
+ *   its gradients w.r.t. log_prob, q1, q2 (a tie in the minimum is split evenly).
+ * unit_g_* (pfrl_half_mse_twin_fwd, pfrl_sac_policy_loss_fwd; may be NULL): the forward launch
+ *   also writes the gradients for an upstream gradient of exactly 1 -- what loss.backward()
+ *   passes -- with the _bwd kernels' arithmetic, so that backward needs no launch of its own. */
 /* pfrl_sac_temperature_loss (:264-271): loss[0] = -mean(exp(*log_temperature) * (log_prob +
  *   entropy_target)); its derivative w.r.t. log_temperature is the loss itself. */
 int pfrl_sac_temperature_loss(const float *log_temperature, const float *log_prob,
                               float entropy_target, float *loss, int32_t B, void *stream);
+/* ... and torch.optim.Adam's step on *log_temperature with that loss as its gradient, in the same
+ * launch (the optimizer's exp_avg / exp_avg_sq / device-side step counter of that parameter). */
+int pfrl_sac_temperature_step(float *log_temperature, const float *log_prob, float entropy_target,
+                              float *loss, float *exp_avg, float *exp_avg_sq, float *step, double lr,
+                              double beta1, double beta2, double eps, double weight_decay, int32_t B,
+                              void *stream);
 int pfrl_sac_target_q(const float *reward, const float *discount, const float *terminal,
                       const float *next_q1, const float *next_q2, const float *next_log_prob,
                       const float *log_temperature, float temperature, float *target_q, int32_t B,
@@ -633,12 +655,13 @@ int pfrl_sac_target_q(const float *reward, const float *discount, const float *t
 int pfrl_half_mse_fwd(const float *target, const float *pred, float *loss, int32_t B, void *stream);
 int pfrl_half_mse_bwd(const float *g_loss, const float *target, const float *pred, float *g_pred,
                       int32_t B, void *stream);
-int pfrl_half_mse_twin_fwd(const float *target, const float *const *pred, float *const *loss, int32_t B,
-                           void *stream);
+int pfrl_half_mse_twin_fwd(const float *target, const float *const *pred, float *const *loss,
+                           float *const *unit_g_pred, int32_t B, void *stream);
 int pfrl_half_mse_twin_bwd(const float *const *g_loss, const float *target, const float *const *pred,
                            float *const *g_pred, int32_t B, void *stream);
 int pfrl_sac_policy_loss_fwd(const float *log_prob, const float *q1, const float *q2,
-                             const float *log_temperature, float temperature, float *loss, int32_t B,
+                             const float *log_temperature, float temperature, float *loss,
+                             float *unit_g_log_prob, float *unit_g_q1, float *unit_g_q2, int32_t B,
                              void *stream);
 int pfrl_sac_policy_loss_bwd(const float *g_loss, const float *q1, const float *q2,
                              const float *log_temperature, float temperature, float *g_log_prob,

@@ -206,18 +206,20 @@ EXPORTS = {
     "pfrl_squashed_head_bwd": (ctypes.c_int, "pppppqffipiip"),
     "pfrl_soft_update": (ctypes.c_int, "ipppdp"),
     "pfrl_adam_step": (ctypes.c_int, "ippppppdddddpp"),
+    "pfrl_adam_step_ex": (ctypes.c_int, "ippppppppdpdddddpp"),
     "pfrl_sac_temperature_loss": (ctypes.c_int, "ppfpip"),
+    "pfrl_sac_temperature_step": (ctypes.c_int, "ppfppppdddddip"),
     "pfrl_sac_target_q": (ctypes.c_int, "pppppppfpip"),
     "pfrl_half_mse_fwd": (ctypes.c_int, "pppip"),
     "pfrl_half_mse_bwd": (ctypes.c_int, "ppppip"),
-    "pfrl_half_mse_twin_fwd": (ctypes.c_int, "pppip"),
+    "pfrl_half_mse_twin_fwd": (ctypes.c_int, "ppppip"),
     "pfrl_half_mse_twin_bwd": (ctypes.c_int, "ppppip"),
     "pfrl_linear_fwd_twin": (ctypes.c_int, "ppipppiiiip"),
     "pfrl_linear_bwd_twin": (ctypes.c_int, "pppppipppqqiiiip"),
     "pfrl_linear_small_fwd_twin": (ctypes.c_int, "ppppiiip"),
     "pfrl_linear_small_bwd_twin": (ctypes.c_int, "ppppppiiip"),
     "pfrl_twin_input_grad": (ctypes.c_int, "pppiiipiip"),
-    "pfrl_sac_policy_loss_fwd": (ctypes.c_int, "ppppfpip"),
+    "pfrl_sac_policy_loss_fwd": (ctypes.c_int, "ppppfppppip"),
     "pfrl_sac_policy_loss_bwd": (ctypes.c_int, "ppppfpppip"),
     "pfrl_profile_enable": (ctypes.c_int, "i"),
     "pfrl_profile_collect": (ctypes.c_int64, "pppq"),

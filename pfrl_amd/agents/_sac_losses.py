@@ -41,6 +41,25 @@ def _temperature_value(temperature):
     return torch.exp(temperature.detach()) if torch.is_tensor(temperature) else temperature
 
 
+_UNIT = {}
+
+
+def unit_grad(device):
+    """THE scalar 1 that ``loss.backward(unit_grad(device))`` passes as dL/dloss.  The loss
+    nodes below recognise it by address: their forward launch has then already written the
+    gradients (``unit_g_*`` of the C ABI) and backward launches nothing."""
+    device = torch.device(device)
+    one = _UNIT.get(device)
+    if one is None:
+        one = _UNIT[device] = torch.ones((), dtype=torch.float32, device=device)
+    return one
+
+
+def _is_unit(g):
+    one = _UNIT.get(g.device) if g is not None else None
+    return one is not None and g.data_ptr() == one.data_ptr()
+
+
 def soft_target_q(reward, discount, terminal, next_q1, next_q2, next_log_prob, temperature):
     """reward + discount * (1 - terminal) * (min(next_q1, next_q2) - T * next_log_prob), no
     gradient.  ``temperature``: float, or the scalar log-temperature tensor (T = exp of it)."""
@@ -89,16 +108,20 @@ class _HalfMsePair(torch.autograd.Function):
     @staticmethod
     def forward(ctx, target, pred1, pred2):
         loss = torch.empty((2,), dtype=torch.float32, device=target.device)
+        unit = torch.empty((2, target.numel()), dtype=torch.float32, device=target.device)
         P = (ctypes.c_void_p * 2)(pred1.data_ptr(), pred2.data_ptr())
         Lp = (ctypes.c_void_p * 2)(loss[0].data_ptr(), loss[1].data_ptr())
-        check(_native.lib().pfrl_half_mse_twin_fwd(_p(target), P, Lp, target.numel(), _stream()),
+        U = (ctypes.c_void_p * 2)(unit[0].data_ptr(), unit[1].data_ptr())
+        check(_native.lib().pfrl_half_mse_twin_fwd(_p(target), P, Lp, U, target.numel(), _stream()),
               "half_mse_twin_fwd")
-        ctx.save_for_backward(target, pred1, pred2)
+        ctx.save_for_backward(target, pred1, pred2, unit)
         return loss[0], loss[1]
 
     @staticmethod
     def backward(ctx, g1, g2):
-        target, pred1, pred2 = ctx.saved_tensors
+        target, pred1, pred2, unit = ctx.saved_tensors
+        if _is_unit(g1) and _is_unit(g2):       # written by the forward launch
+            return None, unit[0].view(pred1.shape), unit[1].view(pred2.shape)
         gp = torch.empty((2, target.numel()), dtype=torch.float32, device=target.device)
         g1 = g1.contiguous() if g1 is not None else None
         g2 = g2.contiguous() if g2 is not None else None
@@ -123,15 +146,21 @@ class _PolicyLoss(torch.autograd.Function):
     def forward(ctx, log_prob, q1, q2, temperature):
         loss = torch.empty((), dtype=torch.float32, device=q1.device)
         lt, tv = _temperature_args(temperature)
+        B = q1.numel()
+        unit = torch.empty((3, B), dtype=torch.float32, device=q1.device)
         check(_native.lib().pfrl_sac_policy_loss_fwd(_p(log_prob), _p(q1), _p(q2), lt, tv, _p(loss),
-                                                     q1.numel(), _stream()), "sac_policy_loss_fwd")
-        ctx.save_for_backward(q1, q2, temperature if torch.is_tensor(temperature) else None)
+                                                     _p(unit[0]), _p(unit[1]), _p(unit[2]), B,
+                                                     _stream()), "sac_policy_loss_fwd")
+        ctx.save_for_backward(q1, q2, temperature if torch.is_tensor(temperature) else None, unit)
         ctx.t_val = tv
+        ctx.lp_shape = log_prob.shape
         return loss
 
     @staticmethod
     def backward(ctx, g):
-        q1, q2, log_t = ctx.saved_tensors
+        q1, q2, log_t, unit = ctx.saved_tensors
+        if _is_unit(g):                          # written by the forward launch
+            return unit[0].view(ctx.lp_shape), unit[1].view(q1.shape), unit[2].view(q2.shape), None
         g_lp = torch.empty(q1.numel(), dtype=torch.float32, device=q1.device)
         g1, g2 = torch.empty_like(q1), torch.empty_like(q2)
         check(_native.lib().pfrl_sac_policy_loss_bwd(_p(g.contiguous()), _p(q1), _p(q2), _p(log_t),
@@ -177,3 +206,32 @@ def temperature_loss(temperature_holder, log_prob, entropy_target):
             and log_t.numel() == 1 and not log_prob.requires_grad):
         return _TemperatureLoss.apply(log_t, log_prob, entropy_target)
     return -torch.mean(temperature_holder() * (log_prob + entropy_target))
+
+
+def temperature_step(temperature_holder, log_prob, entropy_target, optimizer):
+    """The temperature loss AND its optimizer step as one launch (pfrl_sac_temperature_step) when
+    the optimizer is a FusedAdam over exactly the log-temperature: d loss / d log T is the loss
+    itself, so no autograd pass is needed.  Returns the loss, or None when not applicable (the
+    caller then computes the loss and steps as usual)."""
+    from pfrl_amd.optimizers import FusedAdam
+
+    log_t = getattr(temperature_holder, "log_temperature", None)
+    if not (type(optimizer) is FusedAdam and log_t is not None and _vec_ok(log_prob) and log_t.is_cuda
+            and log_t.dtype == torch.float32 and log_t.numel() == 1 and not log_prob.requires_grad
+            and len(optimizer.param_groups) == 1):
+        return None
+    group = optimizer.param_groups[0]
+    if (len(group["params"]) != 1 or group["params"][0] is not log_t or group["amsgrad"]
+            or group.get("maximize", False) or isinstance(group["lr"], torch.Tensor)
+            or not optimizer._prepare_state(group, [log_t])):
+        return None
+    st = optimizer.state[log_t]
+    loss = torch.empty((), dtype=torch.float32, device=log_prob.device)
+    b1, b2 = group["betas"]
+    with torch.no_grad():
+        check(_native.lib().pfrl_sac_temperature_step(
+            _p(log_t), _p(log_prob), float(entropy_target), _p(loss), _p(st["exp_avg"]),
+            _p(st["exp_avg_sq"]), _p(st["step"]), float(group["lr"]), float(b1), float(b2),
+            float(group["eps"]), float(group["weight_decay"]), log_prob.numel(), _stream()),
+            "sac_temperature_step")
+    return loss

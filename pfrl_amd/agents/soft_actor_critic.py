@@ -14,6 +14,7 @@ one HIP graph.  Acting / observing plumbing is shared with TD3 and DDPG
 """
 import contextlib
 import copy
+import os
 from logging import getLogger
 
 import numpy as np
@@ -199,30 +200,77 @@ class SoftActorCritic(ReplayActorCritic):
                          self.soft_update_tau)
 
     # -- learning ----------------------------------------------------------------------------
+    def _defer_slabs(self, pairs):
+        """May the backward pass of these (module, optimizer) pairs leave split-K gradient slabs
+        unfolded for the optimizer launch to sum (nn.mfma_linear.slab_sink)?  Only when nothing
+        reads ``.grad`` in between: no gradient all-reduce, no clipping, and the optimizer is
+        exactly FusedAdam (whose step takes the slabs)."""
+        from pfrl_amd.optimizers import FusedAdam
+
+        if (self.device.type != "cuda" or self.max_grad_norm is not None
+                or os.environ.get("PFRL_SAC_RIDERS", "1") == "0"):
+            return False
+        for module, optimizer in pairs:
+            red = self._reducers.get(module)
+            if type(optimizer) is not FusedAdam or (red is not None and red.active()):
+                return False
+        return True
+
+    def _backward(self, losses, defer):
+        """backward of scalar losses with dL/dL = 1 from a tensor kept around (backward() would
+        fill a new one per loss; the loss nodes of _sac_losses recognise this one and skip their
+        own backward launch).  Returns the slab sink's contents (or None)."""
+        import contextlib
+
+        from pfrl_amd.nn.mfma_linear import slab_sink
+
+        with (slab_sink() if defer else contextlib.nullcontext()) as slabs:
+            if all(l.dim() == 0 and l.dtype == torch.float32 for l in losses):
+                one = self._unit_grad(losses[0])
+                torch.autograd.backward(list(losses), [one] * len(losses))
+            else:
+                torch.autograd.backward(list(losses))
+        return slabs
+
     def _step(self, loss, module, optimizer):
         optimizer.zero_grad()
-        if loss.dim() == 0 and loss.dtype == torch.float32:
-            # dL/dL = 1 from a tensor kept around (backward() would fill a new one per loss)
-            loss.backward(self._unit_grad(loss))
-        else:
-            loss.backward()
+        defer = self._defer_slabs([(module, optimizer)])
+        slabs = self._backward([loss], defer)
         if module in self._reducers:
             self._reducers[module].all_reduce()
         if self.max_grad_norm is not None:
             clip_l2_grad_norm_(module.parameters(), self.max_grad_norm)
-        optimizer.step()
+        if defer:
+            optimizer.step(slabs=slabs)
+        else:
+            optimizer.step()
 
     def _unit_grad(self, loss):
-        one = self.__dict__.get("_one")
-        if one is None or one.device != loss.device:
-            one = self._one = torch.ones((), dtype=torch.float32, device=loss.device)
-        return one
+        return _sac_losses.unit_grad(loss.device)
+
+    def _soft_update_rides(self):
+        """{critic parameter data_ptr: target tensor} when the soft target update may ride in the
+        critics' optimizer launch: the stock ``sync_target_network`` (nobody overrode it), networks
+        without buffers, parameter for parameter the same shapes.  None: sync_target_network()."""
+        if (self.device.type != "cuda" or os.environ.get("PFRL_SAC_RIDERS", "1") == "0"
+                or type(self).sync_target_network is not SoftActorCritic.sync_target_network):
+            return None
+        soft = {}
+        for q, tq in ((self.q_func1, self.target_q_func1), (self.q_func2, self.target_q_func2)):
+            ps, ts = list(q.parameters()), list(tq.parameters())
+            if (next(q.buffers(), None) is not None or next(tq.buffers(), None) is not None
+                    or len(ps) != len(ts) or any(a.shape != b.shape for a, b in zip(ps, ts))):
+                return None
+            for a, b in zip(ps, ts):
+                soft[a.data_ptr()] = b.data
+        return soft
 
     def _step_pair(self, loss1, loss2):
         self.q_func1_optimizer.zero_grad()
         self.q_func2_optimizer.zero_grad()
-        one = self._unit_grad(loss1)
-        torch.autograd.backward([loss1, loss2], [one, one])
+        pairs = [(self.q_func1, self.q_func1_optimizer), (self.q_func2, self.q_func2_optimizer)]
+        defer = self._defer_slabs(pairs)
+        slabs = self._backward([loss1, loss2], defer)
         for module in (self.q_func1, self.q_func2):
             if module in self._reducers:
                 self._reducers[module].all_reduce()
@@ -230,8 +278,12 @@ class SoftActorCritic(ReplayActorCritic):
                 clip_l2_grad_norm_(module.parameters(), self.max_grad_norm)
         from pfrl_amd.optimizers import FusedAdam
 
-        # (one launch for both when they are FusedAdam with equal hyperparameters)
-        FusedAdam.step_together([self.q_func1_optimizer, self.q_func2_optimizer])
+        # (one launch for both when they are FusedAdam with equal hyperparameters; the gradient
+        # slabs are summed and the target networks soft-updated in the same launch)
+        soft = self._soft_update_rides()
+        self._soft_done = bool(FusedAdam.step_together(
+            [self.q_func1_optimizer, self.q_func2_optimizer], slabs=slabs, soft=soft,
+            tau=self.soft_update_tau))
 
     @staticmethod
     def _q_pair(q1, q2, inputs):
@@ -276,6 +328,11 @@ class SoftActorCritic(ReplayActorCritic):
         assert not log_prob.requires_grad
         from pfrl_amd import distributed
 
+        if (distributed.world_size() == 1 and self.max_grad_norm is None
+                and os.environ.get("PFRL_SAC_RIDERS", "1") != "0"
+                and _sac_losses.temperature_step(self.temperature_holder, log_prob, self.entropy_target,
+                                                 self.temperature_optimizer) is not None):
+            return      # (loss and Adam step of the scalar in one launch)
         loss = _sac_losses.temperature_loss(self.temperature_holder, log_prob, self.entropy_target)
         if (isinstance(loss.grad_fn, _sac_losses._TemperatureLoss._backward_cls)
                 and distributed.world_size() == 1 and self.max_grad_norm is None):
@@ -312,9 +369,11 @@ class SoftActorCritic(ReplayActorCritic):
         self._stat(entropy=ent, policy_loss=loss)
 
     def _update_impl(self, batch, variant=None):
+        self._soft_done = False
         self.update_q_func(batch)
         self.update_policy_and_temperature(batch)
-        self.sync_target_network()
+        if not self._soft_done:     # (else it rode in the critics' optimizer launch, _step_pair)
+            self.sync_target_network()
 
     def _after_update(self, variant=None):
         self.n_policy_updates += 1

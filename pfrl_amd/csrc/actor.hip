@@ -200,6 +200,9 @@ struct AdamArgs {
     float *m[PFRL_OPT_MAX_TENSORS];
     float *v[PFRL_OPT_MAX_TENSORS];
     float *step[PFRL_OPT_MAX_TENSORS];
+    float *soft[PFRL_OPT_MAX_TENSORS];            // target-network tensor soft-updated from p (or NULL)
+    int64_t slab_stride[PFRL_OPT_MAX_TENSORS];    // n_slabs > 1: g = sum_s g[s * slab_stride + i]
+    int32_t n_slabs[PFRL_OPT_MAX_TENSORS];
     int64_t numel[PFRL_OPT_MAX_TENSORS];
     int32_t chunk_end[PFRL_OPT_MAX_TENSORS];
     int32_t n;
@@ -210,9 +213,14 @@ struct AdamArgs {
 //   denom = sqrt(v) / sqrt(1 - b2^t) + eps;  p.addcdiv_(m, denom, value = -lr / (1 - b1^t))
 // with t = step + 1 read from the tensor's device-side step counter.  The counters are
 // advanced by whichever workgroup finishes last (ticket), after every workgroup has read them.
+// Two things may ride along (pfrl_adam_step_ex): a gradient still in split-K slabs is summed here,
+// slab 0 first, exactly as pfrl_splitk_reduce sums it (that launch then never runs), and a target
+// network's tensor takes its soft update from the parameter value just written (pfrl_soft_update's
+// arithmetic: dst * (1 - tau) + tau * src).
 __global__ __launch_bounds__(kThreads) void k_adam(AdamArgs a, double lr, double b1d, double b2d,
                                                    float eps, float weight_decay,
-                                                   unsigned int *ticket, int reps) {
+                                                   unsigned int *ticket, int reps, float one_minus_tau,
+                                                   float tau) {
     __shared__ float s_step_size, s_bc2_sqrt;
     __shared__ bool s_last;
     int t = 0;
@@ -233,7 +241,10 @@ __global__ __launch_bounds__(kThreads) void k_adam(AdamArgs a, double lr, double
     const float *__restrict__ g = a.g[t];
     float *__restrict__ m = a.m[t];
     float *__restrict__ v = a.v[t];
+    float *__restrict__ soft = a.soft[t];
     const int64_t n = a.numel[t];
+    const int S = a.n_slabs[t];
+    const int64_t sstride = a.slab_stride[t];
     __syncthreads();
     const float step_size = s_step_size, bc2_sqrt = s_bc2_sqrt;
     // the scalars as PyTorch hands them to f32 kernels: computed in double, then rounded
@@ -241,12 +252,34 @@ __global__ __launch_bounds__(kThreads) void k_adam(AdamArgs a, double lr, double
     for (int r = 0; r < reps; ++r) {
         const int64_t base = base0 + (int64_t)r * kChunk;
         if (base >= n) break;   // (uniform)
-        float pv[4], gv[4], mv[4], vv[4];
+        float pv[4], gv[4], mv[4], vv[4], sv[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int64_t i = base + u * kThreads + threadIdx.x;
             const int64_t ii = i < n ? i : n - 1;
             pv[u] = p[ii]; gv[u] = g[ii]; mv[u] = m[ii]; vv[u] = v[ii];
+            sv[u] = soft != nullptr ? soft[ii] : 0.f;
+        }
+        if (S > 1) {   // (uniform) the slabs beyond the first, eight loads per element in flight
+#pragma unroll
+            for (int u = 0; u < 4; ++u) gv[u] = __fadd_rn(0.f, gv[u]);
+            for (int k = 1; k < S; k += 8) {
+                float w8[4][8];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int64_t i = base + u * kThreads + threadIdx.x;
+                    const int64_t ii = i < n ? i : n - 1;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q)
+                        w8[u][q] = g[(int64_t)(k + q < S ? k + q : S - 1) * sstride + ii];
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    if (k + q < S) {
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) gv[u] = __fadd_rn(gv[u], w8[u][q]);
+                    }
+            }
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -262,7 +295,9 @@ __global__ __launch_bounds__(kThreads) void k_adam(AdamArgs a, double lr, double
             const float denom = __fadd_rn(__fdiv_rn(__fsqrt_rn(vi), bc2_sqrt), eps);
             m[i] = mi;
             v[i] = vi;
-            p[i] = __fadd_rn(pv[u], __fdiv_rn(__fmul_rn(step_size, mi), denom));
+            const float pn = __fadd_rn(pv[u], __fdiv_rn(__fmul_rn(step_size, mi), denom));
+            p[i] = pn;
+            if (soft != nullptr) soft[i] = __fadd_rn(__fmul_rn(sv[u], one_minus_tau), __fmul_rn(tau, pn));
         }
     }
     // Every workgroup has read (and used) its step counter before it takes a ticket; nothing
@@ -322,9 +357,13 @@ __global__ __launch_bounds__(kThreads) void k_half_mse_fwd(const float *__restri
     __shared__ float sh[4];
     const float *__restrict__ pred = a.pred[blockIdx.y];
     float s = 0.f;
+    // (g_pred given: also the gradient for dL/dloss = 1, the arithmetic of k_half_mse_bwd)
+    float *__restrict__ unit = a.g_pred[blockIdx.y];
+    const float gB = 0.5f / (float)B;
     for (int i = threadIdx.x; i < B; i += kThreads) {
         const float d = target[i] - pred[i];
         s += d * d;
+        if (unit != nullptr) unit[i] = -((2.0f * d) * gB);
     }
     s = block_sum(s, sh);
     if (threadIdx.x == 0) a.loss[blockIdx.y][0] = 0.5f * (s / (float)B);
@@ -342,11 +381,21 @@ __global__ __launch_bounds__(kThreads) void k_half_mse_bwd(const float *__restri
 // loss = mean(T * log_prob - min(q1, q2))
 __global__ __launch_bounds__(kThreads) void k_sac_policy_loss_fwd(
     const float *__restrict__ logp, const float *__restrict__ q1, const float *__restrict__ q2,
-    const float *__restrict__ log_t, float t_val, float *__restrict__ loss, int B) {
+    const float *__restrict__ log_t, float t_val, float *__restrict__ loss, float *__restrict__ u_logp,
+    float *__restrict__ u_q1, float *__restrict__ u_q2, int B) {
     __shared__ float sh[4];
     const float T = temperature_of(log_t, t_val);
+    const float g = 1.0f / (float)B;      // (u_*: the gradients for dL/dloss = 1, as k_sac_policy_loss_bwd)
     float s = 0.f;
-    for (int i = threadIdx.x; i < B; i += kThreads) s += T * logp[i] - torch_min(q1[i], q2[i]);
+    for (int i = threadIdx.x; i < B; i += kThreads) {
+        const float a = q1[i], b = q2[i];
+        s += T * logp[i] - torch_min(a, b);
+        if (u_logp != nullptr) {
+            u_logp[i] = g * T;
+            u_q1[i] = -(g * (a < b ? 1.f : (a == b ? 0.5f : 0.f)));
+            u_q2[i] = -(g * (b < a ? 1.f : (a == b ? 0.5f : 0.f)));
+        }
+    }
     s = block_sum(s, sh);
     if (threadIdx.x == 0) loss[0] = s / (float)B;
 }
@@ -380,6 +429,41 @@ __global__ __launch_bounds__(kThreads) void k_sac_temperature_loss(const float *
     for (int i = threadIdx.x; i < B; i += kThreads) s += T * (logp[i] + entropy_target);
     s = block_sum(s, sh);
     if (threadIdx.x == 0) loss[0] = -(s / (float)B);
+}
+
+// ... and torch.optim.Adam's step on log_t with that loss as the gradient (k_adam's arithmetic for
+// one element, the step counter read as t - 1 and advanced), in the same single workgroup: the
+// temperature update of soft_actor_critic.py:264-271 as ONE launch instead of loss + optimizer.
+__global__ __launch_bounds__(kThreads) void k_sac_temperature_step(
+    float *__restrict__ log_t, const float *__restrict__ logp, float entropy_target,
+    float *__restrict__ loss, float *__restrict__ m, float *__restrict__ v, float *__restrict__ step,
+    double lr, double b1d, double b2d, float eps, float weight_decay, int B) {
+    __shared__ float sh[4];
+    const float p0 = *log_t;
+    const float T = expf(p0);
+    float s = 0.f;
+    for (int i = threadIdx.x; i < B; i += kThreads) s += T * (logp[i] + entropy_target);
+    s = block_sum(s, sh);
+    if (threadIdx.x == 0) {
+        const float l = -(s / (float)B);
+        loss[0] = l;
+        const double t = (double)(*step) + 1.0;
+        const double bc1 = 1.0 - pow(b1d, t), bc2 = 1.0 - pow(b2d, t);
+        const float step_size = (float)(-(lr / bc1)), bc2_sqrt = (float)sqrt(bc2);
+        const float w1 = (float)(1.0 - b1d), b2 = (float)b2d, omb2 = (float)(1.0 - b2d);
+        float gi = l;
+        if (weight_decay != 0.0f) gi = __fadd_rn(gi, __fmul_rn(weight_decay, p0));
+        const float m0 = *m, v0 = *v;
+        const float dm = __fsub_rn(gi, m0);
+        const float mi = w1 < 0.5f ? __fadd_rn(m0, __fmul_rn(w1, dm))
+                                   : __fsub_rn(gi, __fmul_rn(dm, __fsub_rn(1.0f, w1)));
+        const float vi = __fadd_rn(__fmul_rn(v0, b2), __fmul_rn(__fmul_rn(omb2, gi), gi));
+        const float denom = __fadd_rn(__fdiv_rn(__fsqrt_rn(vi), bc2_sqrt), eps);
+        *m = mi;
+        *v = vi;
+        *log_t = __fadd_rn(p0, __fdiv_rn(__fmul_rn(step_size, mi), denom));
+        *step = *step + 1.0f;
+    }
 }
 
 template <typename Args>
@@ -471,11 +555,17 @@ extern "C" int pfrl_soft_update(int32_t n_tensors, float *const *dst, const floa
     PFRL_LAUNCH_CHECK();
 }
 
-extern "C" int pfrl_adam_step(int32_t n_tensors, float *const *params, const float *const *grads,
-                              float *const *exp_avg, float *const *exp_avg_sq, float *const *steps,
-                              const int64_t *numel, double lr, double beta1, double beta2, double eps,
-                              double weight_decay, void *ticket, void *stream) {
+extern "C" int pfrl_adam_step_ex(int32_t n_tensors, float *const *params, const float *const *grads,
+                                 const int64_t *slab_stride, const int32_t *n_slabs,
+                                 float *const *exp_avg, float *const *exp_avg_sq, float *const *steps,
+                                 float *const *soft_dst, double tau, const int64_t *numel, double lr,
+                                 double beta1, double beta2, double eps, double weight_decay,
+                                 void *ticket, void *stream) {
     PFRL_CHECK_ARG(n_tensors >= 0 && ticket != nullptr, "pfrl_adam_step: bad arguments");
+    if (n_slabs != nullptr)
+        for (int t = 0; t < n_tensors; ++t)
+            PFRL_CHECK_ARG(n_slabs[t] >= 1 && (n_slabs[t] == 1 || (slab_stride != nullptr && slab_stride[t] >= numel[t])),
+                           "pfrl_adam_step_ex: slabs need a stride >= numel");
     for (int lo = 0; lo < n_tensors; lo += PFRL_OPT_MAX_TENSORS) {
         const int n = (n_tensors - lo) < PFRL_OPT_MAX_TENSORS ? (n_tensors - lo) : PFRL_OPT_MAX_TENSORS;
         AdamArgs a;
@@ -485,6 +575,9 @@ extern "C" int pfrl_adam_step(int32_t n_tensors, float *const *params, const flo
             a.m[t] = exp_avg[lo + t];
             a.v[t] = exp_avg_sq[lo + t];
             a.step[t] = steps[lo + t];
+            a.soft[t] = soft_dst != nullptr ? soft_dst[lo + t] : nullptr;
+            a.n_slabs[t] = n_slabs != nullptr ? n_slabs[lo + t] : 1;
+            a.slab_stride[t] = slab_stride != nullptr ? slab_stride[lo + t] : 0;
         }
         int64_t total = 0;
         for (int t = 0; t < n; ++t) total += numel[lo + t];
@@ -494,9 +587,18 @@ extern "C" int pfrl_adam_step(int32_t n_tensors, float *const *params, const flo
         const int chunks = fill_chunks(a, n, numel, lo, (int64_t)kChunk * reps);
         PFRL_CHECK_ARG(chunks > 0, "pfrl_adam_step: empty parameters");
         hipLaunchKernelGGL(k_adam, dim3(chunks), dim3(kThreads), 0, (hipStream_t)stream, a, lr, beta1,
-                           beta2, (float)eps, (float)weight_decay, (unsigned int *)ticket, reps);
+                           beta2, (float)eps, (float)weight_decay, (unsigned int *)ticket, reps,
+                           (float)(1.0 - tau), (float)tau);
     }
     PFRL_LAUNCH_CHECK();
+}
+
+extern "C" int pfrl_adam_step(int32_t n_tensors, float *const *params, const float *const *grads,
+                              float *const *exp_avg, float *const *exp_avg_sq, float *const *steps,
+                              const int64_t *numel, double lr, double beta1, double beta2, double eps,
+                              double weight_decay, void *ticket, void *stream) {
+    return pfrl_adam_step_ex(n_tensors, params, grads, nullptr, nullptr, exp_avg, exp_avg_sq, steps, nullptr,
+                             0.0, numel, lr, beta1, beta2, eps, weight_decay, ticket, stream);
 }
 
 extern "C" int pfrl_sac_target_q(const float *reward, const float *discount, const float *terminal,
@@ -531,9 +633,10 @@ extern "C" int pfrl_half_mse_bwd(const float *g_loss, const float *target, const
 // The two losses of twin predictions of one target, and both gradients, in one launch each
 // (host arrays of two device pointers; a NULL g_loss entry is a zero upstream gradient).
 extern "C" int pfrl_half_mse_twin_fwd(const float *target, const float *const *pred, float *const *loss,
-                                      int32_t B, void *stream) {
+                                      float *const *unit_g_pred, int32_t B, void *stream) {
     PFRL_CHECK_ARG(B >= 1, "pfrl_half_mse_twin_fwd: empty batch");
     HalfMseArgs a{{pred[0], pred[1]}, {nullptr, nullptr}, {loss[0], loss[1]}, {nullptr, nullptr}};
+    if (unit_g_pred != nullptr) { a.g_pred[0] = unit_g_pred[0]; a.g_pred[1] = unit_g_pred[1]; }
     hipLaunchKernelGGL(k_half_mse_fwd, dim3(1, 2), dim3(kThreads), 0, (hipStream_t)stream, target, a, B);
     PFRL_LAUNCH_CHECK();
 }
@@ -550,10 +653,14 @@ extern "C" int pfrl_half_mse_twin_bwd(const float *const *g_loss, const float *t
 
 extern "C" int pfrl_sac_policy_loss_fwd(const float *log_prob, const float *q1, const float *q2,
                                         const float *log_temperature, float temperature, float *loss,
+                                        float *unit_g_log_prob, float *unit_g_q1, float *unit_g_q2,
                                         int32_t B, void *stream) {
     PFRL_CHECK_ARG(B >= 1, "pfrl_sac_policy_loss_fwd: empty batch");
+    PFRL_CHECK_ARG((unit_g_log_prob == nullptr) == (unit_g_q1 == nullptr) &&
+                   (unit_g_q1 == nullptr) == (unit_g_q2 == nullptr),
+                   "pfrl_sac_policy_loss_fwd: the three unit gradients or none");
     hipLaunchKernelGGL(k_sac_policy_loss_fwd, dim3(1), dim3(kThreads), 0, (hipStream_t)stream, log_prob,
-                       q1, q2, log_temperature, temperature, loss, B);
+                       q1, q2, log_temperature, temperature, loss, unit_g_log_prob, unit_g_q1, unit_g_q2, B);
     PFRL_LAUNCH_CHECK();
 }
 
@@ -572,5 +679,18 @@ extern "C" int pfrl_sac_temperature_loss(const float *log_temperature, const flo
     PFRL_CHECK_ARG(B >= 1 && log_temperature != nullptr, "pfrl_sac_temperature_loss: bad arguments");
     hipLaunchKernelGGL(k_sac_temperature_loss, dim3(1), dim3(kThreads), 0, (hipStream_t)stream,
                        log_temperature, log_prob, entropy_target, loss, B);
+    PFRL_LAUNCH_CHECK();
+}
+
+extern "C" int pfrl_sac_temperature_step(float *log_temperature, const float *log_prob, float entropy_target,
+                                         float *loss, float *exp_avg, float *exp_avg_sq, float *step,
+                                         double lr, double beta1, double beta2, double eps,
+                                         double weight_decay, int32_t B, void *stream) {
+    PFRL_CHECK_ARG(B >= 1 && log_temperature != nullptr && loss != nullptr && exp_avg != nullptr &&
+                       exp_avg_sq != nullptr && step != nullptr,
+                   "pfrl_sac_temperature_step: bad arguments");
+    hipLaunchKernelGGL(k_sac_temperature_step, dim3(1), dim3(kThreads), 0, (hipStream_t)stream,
+                       log_temperature, log_prob, entropy_target, loss, exp_avg, exp_avg_sq, step, lr, beta1,
+                       beta2, (float)eps, (float)weight_decay, B);
     PFRL_LAUNCH_CHECK();
 }

@@ -1303,6 +1303,7 @@ __global__ __launch_bounds__(256) void k_splitk_reduce(RedArgs a) {
 // narrow linear head (out_features <= 16), e.g. Linear(512, n_actions)
 // ---------------------------------------------------------------------------------
 constexpr int SMALL_N = 16;
+constexpr int SMALL_BWD_N = 64;   // (the backward kernel also covers the 2 x action_size policy heads)
 
 // y[m][n] = sum_k x[m][k] w[n][k] + b[n]; one workgroup per row, every load of a pass
 // (4 k per thread: 4 of x, 4 N of w) issued before the first use
@@ -1366,9 +1367,13 @@ struct SmallBwdArgs {
     float *dx[2], *dw[2], *db[2];
 };
 
+// N = compile-time bound of the width (registers, unrolling, the LDS row stride), NR <= N the width
+// itself: widths up to 16 are instantiated exactly, 17..64 (the 2 x action_size policy heads) in
+// steps of 8 with the LDS copy of dy zero-padded to N columns -- so that no loop over n or over rows
+// carries a branch (a guard per FMA made every LDS read wait for itself: 50 us for 256 x 34).
 template <int N>
-__global__ __launch_bounds__(256) void k_linear_small_bwd(SmallBwdArgs a, int M, int K, int n_dw) {
-    extern __shared__ float sdy[];   // [M][N]
+__global__ __launch_bounds__(256) void k_linear_small_bwd(SmallBwdArgs a, int M, int K, int n_dw, int NR) {
+    extern __shared__ float sdy[];   // [M][N], columns >= NR zero
     const float *__restrict__ dy = a.dy[blockIdx.y];
     const float *__restrict__ x = a.x[blockIdx.y];
     const float *__restrict__ w = a.w[blockIdx.y];
@@ -1377,36 +1382,100 @@ __global__ __launch_bounds__(256) void k_linear_small_bwd(SmallBwdArgs a, int M,
     float *__restrict__ db = a.db[blockIdx.y];
     __shared__ float red[8][32][N + 1];
     const int tid = threadIdx.x;
-    for (int e = tid; e < M * N; e += 256) sdy[e] = dy[e];
+    // Everything a workgroup needs from memory -- its share of dy for the LDS copy AND its own x rows
+    // / w rows -- is requested before anything is waited for: after a kernel boundary a global load is
+    // a ~2 us round trip here (the producer ran on other XCDs).
+    const bool dw_role = (int)blockIdx.x < n_dw;
+    constexpr int DYL = 40;            // M * NR <= M * N <= 10 240 = 256 threads x 40
+    constexpr int XPRE = 4;            // x rows preloaded: 4 trips of 8 (M <= 256), the rest in the loop
+    float dv[DYL];
+    const int ndl = (M * NR + 255) / 256;   // (uniform)
+#pragma unroll
+    for (int u = 0; u < DYL; ++u)
+        if (u < ndl) dv[u] = dy[min(tid + 256 * u, M * NR - 1)];
+    const int kc = tid & 31, slice = tid >> 5;
+    const int kx = (K + 255) / 256;
+    const int r = dw_role ? 0 : blockIdx.x - n_dw;
+    const int k = dw_role ? blockIdx.x * 32 + kc : (r % kx) * 256 + tid;
+    const bool valid = k < K;
+    const int kk = valid ? k : K - 1;
+    float xv[XPRE][8], wk[N];
+    if (dw_role) {
+#pragma unroll
+        for (int q = 0; q < XPRE; ++q)
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int m = slice + 64 * q + 8 * u;
+                xv[q][u] = x[(size_t)min(m, M - 1) * K + kk];
+            }
+    } else {
+#pragma unroll
+        for (int n = 0; n < N; ++n) wk[n] = w[(size_t)min(n, NR - 1) * K + kk];
+#pragma unroll
+        for (int n = 0; n < N; ++n) wk[n] = n < NR ? wk[n] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < DYL; ++u)
+        if (u < ndl) {
+            const int e = tid + 256 * u;
+            if (e < M * NR) {
+                const int row = N == 1 ? e : e / NR;
+                sdy[row * N + (e - row * NR)] = dv[u];
+            }
+        }
+    if (NR < N) {      // (uniform) the pad columns
+        const int pad = N - NR;
+        for (int e = tid; e < M * pad; e += 256) {
+            const int row = e / pad;
+            sdy[row * N + NR + (e - row * pad)] = 0.f;
+        }
+    }
     __syncthreads();
-    if ((int)blockIdx.x < n_dw) {
-        if (blockIdx.x == 0 && tid < N && db != nullptr) {
+    if (dw_role) {
+        if (blockIdx.x == 0 && tid < NR && db != nullptr) {
             float s = 0.f;
-            for (int m = 0; m < M; ++m) s += sdy[m * N + tid];
+            for (int m0 = 0; m0 < M; m0 += 8) {   // (loads first, then the adds in row order)
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = sdy[min(m0 + u, M - 1) * N + tid];
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (m0 + u < M) s += v[u];
+            }
             db[tid] = s;
         }
-        const int kc = tid & 31, slice = tid >> 5;
-        const int k = blockIdx.x * 32 + kc;
-        const int kk = k < K ? k : K - 1;
         float gw[N];
 #pragma unroll
         for (int n = 0; n < N; ++n) gw[n] = 0.f;
-        for (int m0 = slice; m0 < M; m0 += 64) {
-            float xv[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) xv[u] = x[(size_t)min(m0 + 8 * u, M - 1) * K + kk];
+        for (int q = 0; q < XPRE; ++q) {
 #pragma unroll
-            for (int u = 0; u < 8; ++u)
-                if (m0 + 8 * u < M) {
+            for (int u = 0; u < 8; ++u) {
+                const int m = slice + 64 * q + 8 * u;
+                const float xm = m < M ? xv[q][u] : 0.f;          // (rows past M add 0)
+                const float *__restrict__ row = sdy + min(m, M - 1) * N;
 #pragma unroll
-                    for (int n = 0; n < N; ++n) gw[n] = fmaf(sdy[(m0 + 8 * u) * N + n], xv[u], gw[n]);
-                }
+                for (int n = 0; n < N; ++n) gw[n] = fmaf(row[n], xm, gw[n]);
+            }
+        }
+        for (int m0 = slice + 64 * XPRE; m0 < M; m0 += 64) {
+            float xl[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) xl[u] = x[(size_t)min(m0 + 8 * u, M - 1) * K + kk];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int m = m0 + 8 * u;
+                const float xm = m < M ? xl[u] : 0.f;
+                const float *__restrict__ row = sdy + min(m, M - 1) * N;
+#pragma unroll
+                for (int n = 0; n < N; ++n) gw[n] = fmaf(row[n], xm, gw[n]);
+            }
         }
 #pragma unroll
         for (int n = 0; n < N; ++n) red[slice][kc][n] = gw[n];
         __syncthreads();
-        // 32 columns x N outputs folded by the first 32 * N threads (N <= 16: two passes at most)
-        for (int e = tid; e < 32 * N; e += 256) {
+        // 32 columns x NR outputs folded by the threads, 256 at a time
+        for (int e = tid; e < 32 * NR; e += 256) {
             const int c = e & 31, n = e >> 5;
             float s = red[0][c][n];
 #pragma unroll
@@ -1415,24 +1484,15 @@ __global__ __launch_bounds__(256) void k_linear_small_bwd(SmallBwdArgs a, int M,
             if (ko < K) dw[(size_t)n * K + ko] = s;
         }
     } else {
-        const int kx = (K + 255) / 256;
-        const int r = blockIdx.x - n_dw;
-        const int k = (r % kx) * 256 + tid;
-        const bool valid = k < K;
-        const int kk = valid ? k : K - 1;
-        float wk[N];
-#pragma unroll
-        for (int n = 0; n < N; ++n) wk[n] = w[(size_t)n * K + kk];
         const int m0 = (r / kx) * 8;
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int m = m0 + u;
-            if (m < M && valid) {
-                float g = 0.f;
+            const float *__restrict__ row = sdy + min(m, M - 1) * N;
+            float g = 0.f;
 #pragma unroll
-                for (int n = 0; n < N; ++n) g = fmaf(sdy[m * N + n], wk[n], g);
-                dx[(size_t)m * K + k] = g;
-            }
+            for (int n = 0; n < N; ++n) g = fmaf(row[n], wk[n], g);
+            if (m < M && valid) dx[(size_t)m * K + k] = g;
         }
     }
 }
@@ -1902,22 +1962,194 @@ extern "C" int pfrl_linear_small_fwd(const float *x, const float *w, const float
 
 static int small_bwd_launch(const SmallBwdArgs &a, int twins, bool want_dx, bool want_dw, int32_t M,
                             int32_t K, int32_t N, void *stream) {
-    PFRL_CHECK_ARG(N >= 1 && N <= SMALL_N && M >= 1 && K >= 1 && (size_t)M * N * 4 <= 40 * 1024,
-                   "pfrl_linear_small_bwd: N <= 16, M * N <= 10240");
+    const int NP = N <= SMALL_N ? N : (N + 7) / 8 * 8;   // the instantiated width (LDS row stride)
+    PFRL_CHECK_ARG(N >= 1 && N <= SMALL_BWD_N && M >= 1 && K >= 1 && (size_t)M * NP * 4 <= 40 * 1024,
+                   "pfrl_linear_small_bwd: N <= 64, M * (N rounded up to 8 above 16) <= 10240");
     PFRL_CHECK_ARG(want_dw || want_dx, "pfrl_linear_small_bwd: nothing to compute");
     const int n_dw = want_dw ? (K + 31) / 32 : 0;   // dw == NULL: input gradient only
     const dim3 grid(n_dw + (want_dx ? ((K + 255) / 256) * ((M + 7) / 8) : 0), twins);
 #define CALL_BWD(NN)                                                                              \
-    hipLaunchKernelGGL(k_linear_small_bwd<NN>, grid, dim3(256), (size_t)M * N * sizeof(float),   \
-                       (hipStream_t)stream, a, M, K, n_dw)
-    SMALL_DISPATCH(N, CALL_BWD)
+    hipLaunchKernelGGL(k_linear_small_bwd<NN>, grid, dim3(256), (size_t)M * NP * sizeof(float),  \
+                       (hipStream_t)stream, a, M, K, n_dw, N)
+    if (N <= SMALL_N) {
+        SMALL_DISPATCH(N, CALL_BWD)
+    } else if (N <= 24) CALL_BWD(24);
+    else if (N <= 32) CALL_BWD(32);
+    else if (N <= 40) CALL_BWD(40);
+    else if (N <= 48) CALL_BWD(48);
+    else if (N <= 56) CALL_BWD(56);
+    else CALL_BWD(64);
 #undef CALL_BWD
     PFRL_LAUNCH_CHECK();
 }
 
+namespace {
+
+// Widths 17..64 (the 2 x action_size policy head of SAC, Linear(256, 34)): both gradients on the
+// matrix cores.  dy is staged ONCE into LDS, zero-padded to [M16][16 NT] (row stride + 1 against
+// bank conflicts), and serves as an MFMA operand of both products:
+//   dw[n][k] = sum_m dy[m][n] x[m][k]   A = dy^T (row n = lane & 15, m = 4 step + lane >> 4, from LDS)
+//                                       B = x    (one global load per step, straight into the operand)
+//              a wave = one 16-column tile of k x all n x one half of the batch; the halves meet in
+//              LDS; one more "tile" whose B is all ones yields db = sum_m dy[m][n]
+//   dx[m][k] = sum_n dy[m][n] w[n][k]   A = dy (row m), B = w: a wave = one k tile x half the m tiles
+// Every global load of a wave is issued before the LDS copy is waited for: the launch costs one memory
+// round trip.  18.4 us for the scalar narrow-head kernel at 256 x 34 (LDS-read bound), 15.6 for the
+// library's three launches.
+template <int NT>
+__global__ __launch_bounds__(256) void k_linear_narrow_bwd(
+    const float *__restrict__ dy, const float *__restrict__ x, const float *__restrict__ w,
+    float *__restrict__ dx, float *__restrict__ dw, float *__restrict__ db, int M, int K, int NR, int n_dw) {
+    constexpr int NP = 16 * NT, LD = NP + 1;
+    extern __shared__ float sdy[];               // [M16][LD]
+    __shared__ float comb[2][NT][64][4];
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int r16 = lane & 15, q = lane >> 4;
+    const int M16 = (M + 15) / 16 * 16, KT = (K + 15) / 16;
+    constexpr int DYL = 64;                      // M * NR <= 256 threads x 64
+    float dv[DYL];
+    const int ndl = (M * NR + 255) / 256;        // (uniform)
+#pragma unroll
+    for (int u = 0; u < DYL; ++u)
+        if (u < ndl) dv[u] = dy[min(tid + 256 * u, M * NR - 1)];
+    const bool dw_role = (int)blockIdx.x < n_dw;
+    // ---- this wave's own operand loads, before anything is waited for
+    constexpr int BMAX = 32;                     // B operand registers: 32 steps of the batch half / 4 NT steps of n
+    float b[BMAX];
+    int tile, mh = 0, Mh = 0, mt_lo = 0, mt_hi = 0;
+    bool ones = false, idle = false;
+    if (dw_role) {
+        tile = blockIdx.x * 2 + (wave >> 1);
+        mh = wave & 1;
+        Mh = M16 / 2;
+        ones = tile == KT;
+        idle = tile > KT;
+        const int k = min(tile * 16 + r16, K - 1);
+        const bool kin = tile * 16 + r16 < K;
+#pragma unroll
+        for (int u = 0; u < BMAX; ++u) {
+            const int m = mh * Mh + 4 * u + q;
+            const bool in = 4 * u < Mh && m < M && !idle;
+            b[u] = ones ? (in ? 1.f : 0.f) : ((in && kin) ? x[(size_t)min(m, M - 1) * K + k] : 0.f);
+        }
+    } else {
+        const int KG = (KT + 3) / 4, MT = M16 / 16, MS = MT >= 2 ? 2 : 1;
+        const int idx = blockIdx.x - n_dw;
+        tile = (idx % KG) * 4 + wave;
+        idle = tile >= KT;
+        const int ms = idx / KG, MTh = (MT + MS - 1) / MS;
+        mt_lo = ms * MTh;
+        mt_hi = min(MT, mt_lo + MTh);
+        const int k = min(tile * 16 + r16, K - 1);
+        const bool kin = tile * 16 + r16 < K && !idle;
+#pragma unroll
+        for (int u = 0; u < 4 * NT; ++u) {
+            const int n = 4 * u + q;
+            b[u] = (kin && n < NR) ? w[(size_t)min(n, NR - 1) * K + k] : 0.f;
+        }
+    }
+    // ---- the LDS copy of dy: zero, then scatter
+    for (int e = tid; e < M16 * LD; e += 256) sdy[e] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < DYL; ++u)
+        if (u < ndl) {
+            const int e = tid + 256 * u;
+            if (e < M * NR) {
+                const int row = e / NR;
+                sdy[row * LD + (e - row * NR)] = dv[u];
+            }
+        }
+    __syncthreads();
+    if (dw_role) {
+        f32x4 acc[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // (batches beyond the first 32 steps -- M16 > 256 -- load as they go)
+        for (int s0 = 0; 4 * s0 < Mh; s0 += BMAX) {
+            if (s0 > 0) {
+                const int k = min(tile * 16 + r16, K - 1);
+                const bool kin = tile * 16 + r16 < K;
+#pragma unroll
+                for (int u = 0; u < BMAX; ++u) {
+                    const int m = mh * Mh + 4 * (s0 + u) + q;
+                    const bool in = 4 * (s0 + u) < Mh && m < M && !idle;
+                    b[u] = ones ? (in ? 1.f : 0.f) : ((in && kin) ? x[(size_t)min(m, M - 1) * K + k] : 0.f);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < BMAX; ++u) {
+                if (4 * (s0 + u) >= Mh) continue;        // (uniform)
+                const int m = mh * Mh + 4 * (s0 + u) + q;
+                const float *__restrict__ row = sdy + m * LD + r16;
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(row[16 * t], b[u], acc[t], 0, 0, 0);
+            }
+        }
+        if (mh == 1) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) comb[wave >> 1][t][lane][i] = acc[t][i];
+        }
+        __syncthreads();
+        if (mh == 0 && !idle) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float v = acc[t][i] + comb[wave >> 1][t][lane][i];
+                    const int n = 16 * t + 4 * q + i, k = tile * 16 + r16;   // accumulator: row = 4 q + i, column = r16
+                    if (n < NR) {
+                        if (ones) {
+                            if (r16 == 0 && db != nullptr) db[n] = v;
+                        } else if (k < K) {
+                            dw[(size_t)n * K + k] = v;
+                        }
+                    }
+                }
+        }
+    } else if (!idle) {
+        for (int mt = mt_lo; mt < mt_hi; ++mt) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            const float *__restrict__ row = sdy + (mt * 16 + r16) * LD + q;
+#pragma unroll
+            for (int u = 0; u < 4 * NT; ++u)
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(row[4 * u], b[u], acc, 0, 0, 0);
+            const int k = tile * 16 + r16;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int m = mt * 16 + 4 * q + i;
+                if (m < M && k < K) dx[(size_t)m * K + k] = acc[i];
+            }
+        }
+    }
+}
+
+}  // namespace
+
 extern "C" int pfrl_linear_small_bwd(const float *dy, const float *x, const float *w, float *dx,
                                      float *dw, float *db, int32_t M, int32_t K, int32_t N,
                                      void *stream) {
+    if (N > SMALL_N && dw != nullptr && getenv("PFRL_NARROW_BWD_SCALAR") == nullptr) {
+        // widths 17..64 with weight gradients wanted: the MFMA kernel
+        const int NT = (N + 15) / 16, M16 = (M + 15) / 16 * 16;
+        const size_t lds = (size_t)M16 * (16 * NT + 1) * sizeof(float);
+        PFRL_CHECK_ARG(N <= SMALL_BWD_N && M >= 1 && K >= 1 && lds <= 64 * 1024 && (size_t)M * N <= 256 * 64,
+                       "pfrl_linear_small_bwd: N <= 64, M16 * (16 ceil(N / 16) + 1) floats of LDS <= 64 KB");
+        const int KT = (K + 15) / 16, n_dw = (KT + 1 + 1) / 2;
+        const int n_dx = dx != nullptr ? ((KT + 3) / 4) * (M16 / 16 >= 2 ? 2 : 1) : 0;
+        const dim3 grid(n_dw + n_dx);
+#define CALL_NARROW(NTT)                                                                                  \
+    hipLaunchKernelGGL(k_linear_narrow_bwd<NTT>, grid, dim3(256), lds, (hipStream_t)stream, dy, x, w, dx, dw, db, \
+                       M, K, N, n_dw)
+        if (NT == 2) CALL_NARROW(2);
+        else if (NT == 3) CALL_NARROW(3);
+        else CALL_NARROW(4);
+#undef CALL_NARROW
+        PFRL_LAUNCH_CHECK();
+    }
     SmallBwdArgs a{{dy, nullptr}, {x, nullptr}, {w, nullptr}, {dx, nullptr}, {dw, nullptr}, {db, nullptr}};
     return small_bwd_launch(a, 1, dx != nullptr, dw != nullptr, M, K, N, stream);
 }
@@ -2006,6 +2238,77 @@ __global__ __launch_bounds__(256) void k_twin_input_grad(TwinDxArgs a, int ldw, 
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
             if (lane == 0 && m < M) dx[(size_t)m * ncol + j] = v;
+        }
+    }
+}
+
+// The same product on the matrix cores, for N % 8 == 0: [16 rows] x [2N] (the masked dy of both
+// networks side by side) times [2N] x [32] (the weight columns, zero beyond ncol).  A workgroup
+// per 16 rows, its NW waves an equal share of the 2N reduction each: every operand element is ONE
+// global load straight into the MFMA operand layout (A: row = lane & 15, k = lane >> 4; B: k =
+// lane >> 4, column = lane & 15) -- no LDS staging of the weights, no index divisions, all loads
+// independent -- and the partial tiles are summed through LDS in wave order.  NW = waves per
+// workgroup: after a kernel boundary a global load is a ~2 us round trip on this part (the producer
+// ran on other XCDs), so what a launch this small costs is its number of DEPENDENT load batches:
+// with 16 waves (N % 32 == 0) a wave's 32 loads per lane are one batch for N = 256.
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void k_twin_input_grad_mfma(TwinDxArgs a, int ldw, int col0, int ncol,
+                                                                  float *__restrict__ dx, int M, int N) {
+    __shared__ float part[NW][16][33];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int r16 = lane & 15, kq = lane >> 4;
+    const int m0 = blockIdx.x * 16;
+    const int mrow = min(m0 + r16, M - 1);
+    const int KW = (2 * N) / NW;                // this wave's share of the reduction (a multiple of 16)
+    const bool two = ncol > 16;                 // (uniform)
+    const bool c0 = r16 < ncol, c1 = 16 + r16 < ncol;
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    // k order inside a block of 16: MFMA step i of the block takes k = 16 j + 4 kq + i from lane
+    // (r16, kq) for BOTH operands (any bijection serves a reduction), so that a lane's four A
+    // elements of a block are ONE 16-byte load along its row (a 4-byte load per step dragged 16
+    // cache lines through the L1 per instruction: 12.8 us; this: see profiles/r04_sac_update_timeline.txt).
+    for (int s0 = 0; s0 < KW; s0 += 32) {       // two blocks of 16 k per trip, loads first
+        float4 g[2], h[2];
+        float b0[2][4], b1[2][4];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int kb = wave * KW + min(s0 + 16 * j, KW - 16) + 4 * kq;   // (clamped: the tail repeats, masked below)
+            const int t = kb >= N, n = kb - t * N;
+            g[j] = *reinterpret_cast<const float4 *>(a.dy[t] + (size_t)mrow * N + n);
+            h[j] = a.mask[t] != nullptr ? *reinterpret_cast<const float4 *>(a.mask[t] + (size_t)mrow * N + n)
+                                        : make_float4(1.f, 1.f, 1.f, 1.f);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float *__restrict__ wr = a.w[t] + (size_t)(n + i) * ldw + col0;
+                b0[j][i] = c0 ? wr[r16] : 0.f;
+                b1[j][i] = (two && c1) ? wr[16 + r16] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            if (s0 + 16 * j >= KW) continue;    // (uniform)
+            const float gv[4] = {g[j].x, g[j].y, g[j].z, g[j].w}, hv[4] = {h[j].x, h[j].y, h[j].z, h[j].w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float av = hv[i] > 0.f ? gv[i] : 0.f;
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b0[j][i], acc0, 0, 0, 0);
+                if (two) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b1[j][i], acc1, 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {               // accumulator layout: row = 4 (lane >> 4) + i, column = lane & 15
+        part[wave][kq * 4 + i][r16] = acc0[i];
+        part[wave][kq * 4 + i][16 + r16] = acc1[i];
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < 16 * 32; e += NW * 64) {
+        const int row = e >> 5, j = e & 31;
+        if (j < ncol && m0 + row < M) {
+            float v = part[0][row][j];
+#pragma unroll
+            for (int q = 1; q < NW; ++q) v += part[q][row][j];
+            dx[(size_t)(m0 + row) * ncol + j] = v;
         }
     }
 }
@@ -2123,6 +2426,17 @@ extern "C" int pfrl_twin_input_grad(const float *const *dy, const float *const *
     TwinDxArgs a{{dy[0], dy[1]},
                  {dy_mask ? dy_mask[0] : nullptr, dy_mask ? dy_mask[1] : nullptr},
                  {w[0], w[1]}};
+    // (a wave's share is whole blocks of 16 k that do not straddle the two networks)
+    if (N % 128 == 0 && getenv("PFRL_TWIN_DX_STAGED") == nullptr) {
+        hipLaunchKernelGGL(k_twin_input_grad_mfma<16>, dim3((M + 15) / 16), dim3(1024), 0, (hipStream_t)stream,
+                           a, ldw, col0, ncol, dx, M, N);
+        PFRL_LAUNCH_CHECK();
+    }
+    if (N % 32 == 0 && getenv("PFRL_TWIN_DX_STAGED") == nullptr) {
+        hipLaunchKernelGGL(k_twin_input_grad_mfma<4>, dim3((M + 15) / 16), dim3(256), 0, (hipStream_t)stream, a,
+                           ldw, col0, ncol, dx, M, N);
+        PFRL_LAUNCH_CHECK();
+    }
     hipLaunchKernelGGL(k_twin_input_grad, dim3((M + 3) / 4), dim3(256),
                        (size_t)2 * N * ncol * sizeof(float), (hipStream_t)stream, a, ldw, col0, ncol, dx, M,
                        N);

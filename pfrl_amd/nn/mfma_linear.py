@@ -36,6 +36,39 @@ _DIRECT_TILES = int(os.environ.get("PFRL_MFMA_LINEAR_DIRECT_TILES", "96"))
 MIN_OUT = 17   # narrower layers are the narrow-head kernels' (mfma_trunk._SmallLinear)
 
 
+# While a ``slab_sink()`` is open, weight / bias gradients that the backward kernels leave as
+# split-K slabs are NOT folded (pfrl_splitk_reduce) and NOT returned: the slabs are recorded as
+# {parameter data_ptr: (slabs, stride, n)} for an optimizer that sums them inside its own launch
+# (FusedAdam.step(slabs=...), pfrl_adam_step_ex).  The caller owns the contract: ``.grad`` of those
+# parameters stays None, so nothing between backward and the step may read it.
+_SLAB_SINK = None
+
+
+class slab_sink:
+    def __enter__(self):
+        global _SLAB_SINK
+        self._prev = _SLAB_SINK
+        _SLAB_SINK = self.slabs = {}
+        return self.slabs
+
+    def __exit__(self, *exc):
+        global _SLAB_SINK
+        _SLAB_SINK = self._prev
+        return False
+
+
+def _fold_or_sink(part, stride, splits, w_ptr, b_ptr, dw, db, nW, Fo):
+    """Returns (dw, db) after folding the slabs -- or (None, None) with the slabs in the sink."""
+    sink = _SLAB_SINK
+    if sink is not None and b_ptr is not None:
+        sink[w_ptr] = (part, stride, splits)
+        sink[b_ptr] = (part[nW:], stride, splits)
+        return None, None
+    _t._reduce([(part, dw, None, stride, nW, splits, 4, 0),
+                (part[nW:], db, None, stride, Fo, splits, 4, 0)])
+    return dw, db
+
+
 def _fwd_splits(M, Fo, K):
     nch = _ceil_div(K, 32)
     tiles16 = _ceil_div(M, 16) * _ceil_div(Fo, 32)
@@ -71,6 +104,7 @@ class _Linear(torch.autograd.Function):
                   "linear_fwd_splitk")
             _t._reduce([(part, y, b, M * Fo, M * Fo, splits, Fo, int(relu))])
         ctx.relu = bool(relu)
+        ctx.b_ptr = b.data_ptr() if b is not None else None
         ctx.save_for_backward(x, w, y if relu else None)
         return y
 
@@ -81,6 +115,18 @@ class _Linear(torch.autograd.Function):
         Fo = w.shape[0]
         need_dx = ctx.needs_input_grad[0]
         dev = x.device
+        if (not _bwd_kernels_cover(M, K, Fo) and not ctx.relu and Fo <= 64 and Fo % 16 != 0
+                and _ceil_div(M, 16) * 16 * (_ceil_div(Fo, 16) * 16 + 1) * 4 <= 65536
+                and ctx.needs_input_grad[1]):
+            # the 2 * action_size policy head (Linear(256, 34) of SAC): dx, dw and db from the
+            # narrow-head launch (library route below: two products and a column sum)
+            dyc = dy.contiguous()
+            dx = torch.empty_like(x) if need_dx else None
+            dw = torch.empty_like(w)
+            db = torch.empty(Fo, dtype=torch.float32, device=dev)
+            check(_native.lib().pfrl_linear_small_bwd(_p(dyc), _p(x), _p(w), _p(dx), _p(dw), _p(db), M, K,
+                                                      Fo, _stream()), "linear_small_bwd")
+            return dx, dw, db, None
         if not _bwd_kernels_cover(M, K, Fo):
             # ragged layers (first layer of an MLP, 2 * action_size heads)
             need_w = ctx.needs_input_grad[1]
@@ -109,8 +155,7 @@ class _Linear(torch.autograd.Function):
                                                            M, K, Fo, splits, _stream()),
                       "linear_bwd_weight")
                 if splits > 1:
-                    _t._reduce([(part, dw, None, stride, nW, splits, 4, 0),
-                                (pb, db, None, stride, Fo, splits, 4, 0)])
+                    dw, db = _fold_or_sink(part, stride, splits, w.data_ptr(), ctx.b_ptr, dw, db, nW, Fo)
             elif need_w:
                 dw = g.t() @ x
                 db = g.sum(0) if ctx.needs_input_grad[2] else None
@@ -153,8 +198,7 @@ class _Linear(torch.autograd.Function):
                                                   K, Fo, 1, 1, 1, splits, _stream()),
                   "linear_bwd_weight")
         if splits > 1:
-            _t._reduce([(part, dw, None, stride, nW, splits, 4, 0),
-                        (pb, db, None, stride, Fo, splits, 4, 0)])
+            dw, db = _fold_or_sink(part, stride, splits, w.data_ptr(), ctx.b_ptr, dw, db, nW, Fo)
         return dx, dw, db, None
 
 

@@ -107,6 +107,7 @@ class _TwinQ(torch.autograd.Function):
         check(lib.pfrl_linear_small_fwd_twin(_pair(h2[0], h2[1]), _pair(w3a, w3b), _pair(b3a, b3b),
                                              _pair(q[0], q[1]), M, H2, No, st), "linear_small_fwd_twin")
         ctx.save_for_backward(obs, action, h1, h2, w1a, w2a, w3a, w1b, w2b, w3b)
+        ctx.ptrs = [[t.data_ptr() for t in (w1a, b1a, w2a, b2a)], [t.data_ptr() for t in (w1b, b1b, w2b, b2b)]]
         return q[0], q[1]
 
     @staticmethod
@@ -153,17 +154,28 @@ class _TwinQ(torch.autograd.Function):
                                            _pair(p1[0], p1[1]), _pair(p1[0][n1:], p1[1][n1:]), st1, st1, M,
                                            K, H1, s1, st),
                   "linear_bwd_twin")
-            dw2 = torch.empty((2, H2, H1), **f32)
-            db2 = torch.empty((2, H2), **f32)
-            dw1 = torch.empty((2, H1, K), **f32)
-            db1 = torch.empty((2, H1), **f32)
-            tasks = []
-            for t in range(2):
-                tasks += [(p2[t], dw2[t], None, st2, n2, s2, 4, 0), (p2[t][n2:], db2[t], None, st2, H2, s2, 4, 0),
-                          (p1[t], dw1[t], None, st1, n1, s1, 4, 0), (p1[t][n1:], db1[t], None, st1, H1, s1, 4, 0)]
-            _t._reduce(tasks)
-            for t in range(2):
-                grads[6 * t:6 * t + 6] = [dw1[t], db1[t], dw2[t], db2[t], dw3[t], db3[t]]
+            from pfrl_amd.nn import mfma_linear as _ml
+
+            sink = _ml._SLAB_SINK
+            if sink is not None and s1 > 1 and s2 > 1:
+                # the optimizer sums the slabs inside its own launch (mfma_linear.slab_sink)
+                for t in range(2):
+                    pw1, pb1, pw2, pb2 = ctx.ptrs[t]
+                    sink[pw1], sink[pb1] = (p1[t], st1, s1), (p1[t][n1:], st1, s1)
+                    sink[pw2], sink[pb2] = (p2[t], st2, s2), (p2[t][n2:], st2, s2)
+                    grads[6 * t:6 * t + 6] = [None, None, None, None, dw3[t], db3[t]]
+            else:
+                dw2 = torch.empty((2, H2, H1), **f32)
+                db2 = torch.empty((2, H2), **f32)
+                dw1 = torch.empty((2, H1, K), **f32)
+                db1 = torch.empty((2, H1), **f32)
+                tasks = []
+                for t in range(2):
+                    tasks += [(p2[t], dw2[t], None, st2, n2, s2, 4, 0), (p2[t][n2:], db2[t], None, st2, H2, s2, 4, 0),
+                              (p1[t], dw1[t], None, st1, n1, s1, 4, 0), (p1[t][n1:], db1[t], None, st1, H1, s1, 4, 0)]
+                _t._reduce(tasks)
+                for t in range(2):
+                    grads[6 * t:6 * t + 6] = [dw1[t], db1[t], dw2[t], db2[t], dw3[t], db3[t]]
         else:
             check(lib.pfrl_linear_small_bwd_twin(_pair(ga, gb), _pair(h2[0], h2[1]), _pair(w3a, w3b),
                                                  _pair(dh2[0], dh2[1]), None, None, M, H2, No, st),

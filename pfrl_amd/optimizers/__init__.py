@@ -262,21 +262,29 @@ class FusedAdam(torch.optim.Adam):
         kw.pop("foreach", None)
         super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay,
                          amsgrad=amsgrad, **kw)
-    def _fusable(self, group, params):
+    def _fusable(self, group, params, slabs=None):
+        def grad_ok(p):
+            if slabs and p.data_ptr() in slabs:
+                return p.is_contiguous()       # (slabs hold the row-major gradient)
+            return (not p.grad.is_sparse and p.grad.dtype == torch.float32
+                    and p.grad.stride() == p.stride())
+
         return (not group["amsgrad"] and not group.get("maximize", False)
                 and not group.get("differentiable", False)
                 and not isinstance(group["lr"], torch.Tensor)
-                and all(p.is_cuda and p.dtype == torch.float32 and _dense(p)
-                        and not p.grad.is_sparse and p.grad.dtype == torch.float32
-                        and p.grad.stride() == p.stride() for p in params))
+                and all(p.is_cuda and p.dtype == torch.float32 and _dense(p) and grad_ok(p)
+                        for p in params))
 
     @staticmethod
     @torch.no_grad()
-    def step_together(optimizers):
+    def step_together(optimizers, slabs=None, soft=None, tau=0.0):
         """``step()`` of several optimizers; one launch for all of them when they are FusedAdam
         instances with one parameter group each and equal hyperparameters (the two critics of
-        SAC / TD3), else one after the other."""
+        SAC / TD3), else one after the other.  ``slabs`` / ``soft`` / ``tau``: see ``_launch``;
+        returns True when the soft updates rode in the launch (else the caller still owes them)."""
         opts = list(optimizers)
+        if slabs or soft:
+            return FusedAdam._step_together_ex(opts, slabs or {}, soft or {}, tau)
         same = (len(opts) > 1 and all(type(o) is FusedAdam and len(o.param_groups) == 1 for o in opts))
         if same:
             keys = ("lr", "betas", "eps", "weight_decay", "amsgrad", "maximize")
@@ -301,6 +309,35 @@ class FusedAdam(torch.optim.Adam):
         flat = [(o, p) for o, ps in zip(opts, params) for p in ps]
         opts[0]._launch(ref, [p for _, p in flat], [o.state[p] for o, p in flat])
 
+    @staticmethod
+    def _step_together_ex(opts, slabs, soft, tau):
+        def has_grad(p):
+            return p.grad is not None or p.data_ptr() in slabs
+
+        ok = all(type(o) is FusedAdam and len(o.param_groups) == 1 for o in opts)
+        if ok and len(opts) > 1:
+            keys = ("lr", "betas", "eps", "weight_decay", "amsgrad", "maximize")
+            ref = opts[0].param_groups[0]
+            ok = all(all(o.param_groups[0].get(k) == ref.get(k) for k in keys) for o in opts)
+        groups = [o.param_groups[0] for o in opts] if ok else []
+        params = [[p for p in g["params"] if has_grad(p)] for g in groups]
+        ok = (ok and all(params) and len({ps[0].device for ps in params}) == 1
+              and all(o._fusable(g, ps, slabs) for o, g, ps in zip(opts, groups, params))
+              and all(o._prepare_state(g, ps) for o, g, ps in zip(opts, groups, params)))
+        if not ok:
+            for o in opts:
+                FusedAdam.materialize_slabs([p for g in o.param_groups for p in g["params"]], slabs)
+                o.step()
+            return False
+        flat = [(o, p) for o, ps in zip(opts, params) for p in ps]
+        stepped = {p.data_ptr(): p for _, p in flat}
+        soft_ok = bool(soft) and set(soft) <= set(stepped) and all(
+            t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
+            and stepped[k].is_contiguous() and t.shape == stepped[k].shape for k, t in soft.items())
+        opts[0]._launch(groups[0], [p for _, p in flat], [o.state[p] for o, p in flat], slabs,
+                        soft if soft_ok else None, tau)
+        return soft_ok
+
     def _prepare_state(self, group, params):
         """Device-side step counters (as torch's capturable path keeps them, which is also what
         its own step() needs should a later call fall outside the kernel) and moment buffers;
@@ -319,27 +356,53 @@ class FusedAdam(torch.optim.Adam):
                 return False
         return True
 
-    def _launch(self, group, params, states):
+    def _launch(self, group, params, states, slabs=None, soft=None, tau=0.0):
+        """``slabs``: {parameter data_ptr: (partial slabs, stride, n)} -- gradients the backward
+        pass left as split-K slabs (``nn.mfma_linear.slab_sink``), summed inside the launch;
+        ``soft``: {parameter data_ptr: target tensor} soft-updated with ``tau`` from the new values."""
         dev = params[0].device
         tickets = self.__dict__.setdefault("_ticket", {})
         if dev not in tickets:
             tickets[dev] = torch.zeros(1, dtype=torch.int32, device=dev)
         n = len(params)
         V = ctypes.c_void_p
+        slabs = slabs or {}
+        soft = soft or {}
+        src = [slabs.get(p.data_ptr()) for p in params]
         P = (V * n)(*[p.data_ptr() for p in params])
-        G = (V * n)(*[p.grad.data_ptr() for p in params])
+        G = (V * n)(*[(s[0].data_ptr() if s is not None else p.grad.data_ptr())
+                      for p, s in zip(params, src)])
         M = (V * n)(*[st["exp_avg"].data_ptr() for st in states])
         S = (V * n)(*[st["exp_avg_sq"].data_ptr() for st in states])
         T = (V * n)(*[st["step"].data_ptr() for st in states])
         L = (ctypes.c_int64 * n)(*[p.numel() for p in params])
         b1, b2 = group["betas"]
         stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-        _native.check(_native.lib().pfrl_adam_step(
-            n, P, G, M, S, T, L, float(group["lr"]), float(b1), float(b2), float(group["eps"]),
-            float(group["weight_decay"]), V(tickets[dev].data_ptr()), stream), "adam_step")
+        if not slabs and not soft:
+            _native.check(_native.lib().pfrl_adam_step(
+                n, P, G, M, S, T, L, float(group["lr"]), float(b1), float(b2), float(group["eps"]),
+                float(group["weight_decay"]), V(tickets[dev].data_ptr()), stream), "adam_step")
+            return
+        SS = (ctypes.c_int64 * n)(*[(int(s[1]) if s is not None else 0) for s in src])
+        NS = (ctypes.c_int32 * n)(*[(int(s[2]) if s is not None else 1) for s in src])
+        D = (V * n)(*[(soft[p.data_ptr()].data_ptr() if p.data_ptr() in soft else 0) for p in params])
+        _native.check(_native.lib().pfrl_adam_step_ex(
+            n, P, G, SS, NS, M, S, T, D, float(tau), L, float(group["lr"]), float(b1), float(b2),
+            float(group["eps"]), float(group["weight_decay"]), V(tickets[dev].data_ptr()), stream),
+            "adam_step_ex")
+
+    @staticmethod
+    def materialize_slabs(params, slabs):
+        """Fallback for a step the kernel does not cover: sum the slabs into ``.grad``."""
+        for p in params:
+            s = slabs.get(p.data_ptr()) if slabs else None
+            if s is not None and p.grad is None:
+                part, stride, n = s
+                flat = torch.as_strided(part, (int(n), p.numel()), (int(stride), 1))
+                p.grad = flat.sum(0).view_as(p)
 
     @torch.no_grad()
-    def step(self, closure=None):
+    def step(self, closure=None, slabs=None):
         loss = None
         if closure is not None:
             with torch.enable_grad():
@@ -349,15 +412,17 @@ class FusedAdam(torch.optim.Adam):
         # super().step() would step those groups twice)
         work = []
         for group in self.param_groups:
-            params = [p for p in group["params"] if p.grad is not None]
+            params = [p for p in group["params"]
+                      if p.grad is not None or (slabs and p.data_ptr() in slabs)]
             if not params:
                 continue
-            if not self._fusable(group, params) or not self._prepare_state(group, params):
+            if not self._fusable(group, params, slabs) or not self._prepare_state(group, params):
+                self.materialize_slabs([p for g in self.param_groups for p in g["params"]], slabs)
                 super().step(closure=None)
                 return loss
             work.append((group, params))
         for group, params in work:
-            self._launch(group, params, [self.state[p] for p in params])
+            self._launch(group, params, [self.state[p] for p in params], slabs)
         return loss
 
 

@@ -66,6 +66,7 @@ class _SquashedGaussian(torch.autograd.Function):
                                                        _stream()), "squashed_gaussian_fwd")
         ctx.save_for_backward(action, eps, scale)
         ctx.mark_non_differentiable(neg)
+        ctx.set_materialize_grads(False)    # (else a zero-fill launch per absent gradient)
         return action, logp, neg
 
     @staticmethod
@@ -131,6 +132,7 @@ class _SquashedHead(torch.autograd.Function):
         ctx.save_for_backward(action, eps, x)
         ctx.spec = spec
         ctx.mark_non_differentiable(neg)
+        ctx.set_materialize_grads(False)
         return action, logp, neg
 
     @staticmethod

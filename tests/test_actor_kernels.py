@@ -386,6 +386,38 @@ def test_sac_loss_kernels_match_the_torch_formulas(B):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("B", [256, 100, 1])
+def test_loss_gradients_written_by_the_forward_launch_equal_the_backward_kernels(B):
+    """``loss.backward(unit_grad(device))`` (what the SAC agent passes): the gradients the forward
+    launch wrote for dL/dloss = 1 (unit_g_* of pfrl_half_mse_twin_fwd / pfrl_sac_policy_loss_fwd)
+    are bit for bit what the _bwd kernels compute from any other tensor holding 1."""
+    from pfrl_amd.agents import _sac_losses as L
+
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(B + 11)
+    rnd = lambda *s: torch.randn(*s, generator=g).to(dev)
+    target, lp, q1, q2 = rnd(B), rnd(B), rnd(B, 1), rnd(B, 1)
+    q2[::5] = q1[::5]
+    log_t = torch.nn.Parameter(torch.tensor(-0.3, device=dev))
+    unit, other = L.unit_grad(dev), torch.ones((), device=dev)
+    grads = []
+    for one in (unit, other):
+        a, b, c = (x.clone().requires_grad_(True) for x in (lp, q1, q2))
+        gl = torch.autograd.grad(L.policy_loss(a, b, c, log_t), [a, b, c], [one])
+        p1, p2 = (x.clone().requires_grad_(True) for x in (q1.flatten(), q2.flatten()))
+        l1, l2 = L.half_mse_pair(target, p1, p2)
+        gm = torch.autograd.grad([l1, l2], [p1, p2], [one, one])
+        grads.append(list(gl) + list(gm))
+    for x, y in zip(*grads):
+        assert x.shape == y.shape and torch.equal(x, y)
+    # one unit and one foreign upstream gradient: the backward kernels
+    p1, p2 = (x.clone().requires_grad_(True) for x in (q1.flatten(), q2.flatten()))
+    l1, l2 = L.half_mse_pair(target, p1, p2)
+    gm = torch.autograd.grad([l1, l2], [p1, p2], [unit, other * 2.0])
+    assert torch.equal(gm[0], grads[0][3]) and torch.allclose(gm[1], grads[0][4] * 2.0, rtol=1e-6)
+
+
+@pytest.mark.gpu
 def test_fused_adam_step_together_equals_separate_steps():
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
@@ -446,3 +478,105 @@ def test_cpu_routes_of_the_round_two_helpers():
                                              nn.Linear(32, 32), nn.ReLU(), nn.Linear(32, 1)))
     q1, q2 = q(), q()
     assert twin_forward(q1, q2, (torch.randn(4, 8), torch.randn(4, 3))) is None
+
+
+@pytest.mark.gpu
+def test_fused_adam_sums_gradient_slabs_and_soft_updates_the_targets_in_its_launch():
+    """pfrl_adam_step_ex against the three launches it replaces -- pfrl_splitk_reduce (fold the
+    split-K slabs), pfrl_adam_step, pfrl_soft_update -- on the layers of the SAC critics: same
+    parameters, moments and targets, bit for bit, over several steps."""
+    from pfrl_amd.nn import mfma_trunk as _t
+
+    dev = torch.device("cuda:0")
+    torch.manual_seed(3)
+    nets = [nn.Linear(393, 256).to(dev), nn.Linear(256, 256).to(dev)]
+    refs = copy.deepcopy(nets)
+    tgt, tgt_ref = copy.deepcopy(nets), copy.deepcopy(nets)
+    opts = [FusedAdam(n.parameters(), lr=3e-4) for n in nets]
+    opts_ref = [FusedAdam(n.parameters(), lr=3e-4) for n in refs]
+    tau = 5e-3
+    for it in range(4):
+        slabs, soft = {}, {}
+        for net, ref, t_net, splits in zip(nets, refs, tgt, (5 + it, 11)):
+            nW, Fo = net.weight.numel(), net.bias.numel()
+            stride = nW + Fo
+            part = torch.randn(splits * stride, device=dev)
+            slabs[net.weight.data_ptr()] = (part, stride, splits)
+            slabs[net.bias.data_ptr()] = (part[nW:], stride, splits)
+            soft[net.weight.data_ptr()], soft[net.bias.data_ptr()] = t_net.weight.data, t_net.bias.data
+            dw, db = torch.empty_like(ref.weight), torch.empty_like(ref.bias)
+            _t._reduce([(part, dw, None, stride, nW, splits, 4, 0), (part[nW:], db, None, stride, Fo, splits, 4, 0)])
+            ref.weight.grad, ref.bias.grad = dw, db
+            net.weight.grad = net.bias.grad = None
+        assert FusedAdam.step_together(opts, slabs=slabs, soft=soft, tau=tau) is True
+        FusedAdam.step_together(opts_ref)
+        soft_copy_params(list(zip(tgt_ref, refs)), tau)
+        for a, b in zip(nets + tgt, refs + tgt_ref):
+            assert torch.equal(a.weight, b.weight) and torch.equal(a.bias, b.bias)
+        for o, orf, n, r in zip(opts, opts_ref, nets, refs):
+            for p, q in zip(n.parameters(), r.parameters()):
+                assert torch.equal(o.state[p]["exp_avg"], orf.state[q]["exp_avg"])
+                assert torch.equal(o.state[p]["exp_avg_sq"], orf.state[q]["exp_avg_sq"])
+                assert float(o.state[p]["step"]) == float(orf.state[q]["step"]) == it + 1
+    # a single optimizer's step() with slabs only
+    net, ref = nn.Linear(64, 32).to(dev), None
+    ref = copy.deepcopy(net)
+    o, orf = FusedAdam(net.parameters(), lr=1e-3), FusedAdam(ref.parameters(), lr=1e-3)
+    part = torch.randn(3 * (64 * 32 + 32), device=dev)
+    view = part.view(3, -1)
+    ref.weight.grad = (view[0, :2048] + view[1, :2048] + view[2, :2048]).view(32, 64)
+    ref.bias.grad = view[0, 2048:] + view[1, 2048:] + view[2, 2048:]
+    o.step(slabs={net.weight.data_ptr(): (part, 2080, 3), net.bias.data_ptr(): (part[2048:], 2080, 3)})
+    orf.step()
+    assert torch.equal(net.weight, ref.weight) and torch.equal(net.bias, ref.bias)
+
+
+@pytest.mark.gpu
+def test_sac_update_with_riders_equals_the_separate_launches(monkeypatch):
+    """The SAC update of the bench model (FusedAdam, 256-256 networks, B = 256) with the gradient
+    slabs summed in the optimizer launches and the soft target update riding in the critics' step
+    (PFRL_SAC_RIDERS, default on) against the same update with the fold, step and soft-update
+    launches separate: every network and target network bit for bit after 12 updates."""
+    import pfrl_amd as pfrl
+    from pfrl_amd import agents, replay_buffers
+    from pfrl_amd.envs.synthetic import HostSyntheticVectorObsEnv
+    from pfrl_amd.nn import ConcatObsAndAction, Lambda
+
+    def run(riders):
+        monkeypatch.setenv("PFRL_SAC_RIDERS", riders)
+        obs_dim, act_dim, N = 376, 17, 4
+        pfrl.utils.set_random_seed(0)
+        torch.manual_seed(11)
+        env = HostSyntheticVectorObsEnv(N, obs_dim=obs_dim, act_dim=act_dim, seed=2, p_done=0.02)
+        policy = nn.Sequential(nn.Linear(obs_dim, 256), nn.ReLU(), nn.Linear(256, 256), nn.ReLU(),
+                               nn.Linear(256, act_dim * 2), Lambda(_head))
+
+        def q():
+            return nn.Sequential(ConcatObsAndAction(), nn.Linear(obs_dim + act_dim, 256), nn.ReLU(),
+                                 nn.Linear(256, 256), nn.ReLU(), nn.Linear(256, 1))
+
+        q1, q2 = q(), q()
+        opts = [FusedAdam(m.parameters(), lr=3e-4) for m in (policy, q1, q2)]
+        ag = agents.SoftActorCritic(
+            policy, q1, q2, opts[0], opts[1], opts[2], replay_buffers.ReplayBuffer(2000), gamma=0.99,
+            gpu=0, replay_start_size=300, minibatch_size=256, update_interval=4,
+            burnin_action_func=lambda: np.random.uniform(-1, 1, size=act_dim).astype(np.float32),
+            entropy_target=-act_dim, temperature_optimizer_lr=3e-4)
+        obs = env.reset()
+        for _ in range(88):
+            acts = ag.batch_act(obs)
+            obs, r, done, _ = env.step(acts)
+            ag.batch_observe(obs, r, done, np.zeros(N, dtype=bool))
+            obs = env.reset(np.logical_not(done))
+        assert ag.n_policy_updates >= 12
+        mods = (ag.policy, ag.q_func1, ag.q_func2, ag.target_q_func1, ag.target_q_func2,
+                ag.temperature_holder)
+        return [p.detach().clone() for m in mods for p in m.parameters()], ag
+
+    on, ag = run("1")
+    assert ag._soft_done is True
+    off, ag0 = run("0")
+    assert ag0._soft_done is False
+    assert len(on) == len(off)
+    for a, b in zip(on, off):
+        assert torch.equal(a, b)

@@ -55,6 +55,7 @@ def test_split_rule():
     (256, 376, 256, True), (256, 393, 256, True), (256, 256, 256, True), (256, 256, 34, False),
     (100, 400, 300, True), (100, 300, 300, True), (7, 33, 40, True), (1, 376, 256, True),
     (64, 376, 256, True), (32, 256, 256, False), (1000, 64, 64, True), (5, 3, 17, False),
+    (100, 64, 62, False), (33, 100, 50, False), (256, 256, 12 + 17, False),
 ])
 def test_linear_matches_torch(M, K, N, relu):
     dev = torch.device("cuda:0")
@@ -139,7 +140,8 @@ def test_frozen_weights_give_the_input_gradient_only(K, N):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("M,obs,act,hid", [(256, 376, 17, 256), (100, 24, 3, 64), (7, 11, 33, 32)])
+@pytest.mark.parametrize("M,obs,act,hid", [(256, 376, 17, 256), (100, 24, 3, 64), (7, 11, 33, 32),
+                                           (33, 20, 6, 32), (48, 40, 32, 96)])
 def test_twin_q_networks_match_the_two_modules(M, obs, act, hid):
     """twin_forward(q1, q2, (s, a)) against q1((s, a)), q2((s, a)) evaluated one by one by
     stock PyTorch: values, all parameter gradients, the action gradient; then with frozen
