@@ -1390,9 +1390,14 @@ __global__ __launch_bounds__(256) void k_linear_small_bwd(SmallBwdArgs a, int M,
     constexpr int XPRE = 4;            // x rows preloaded: 4 trips of 8 (M <= 256), the rest in the loop
     float dv[DYL];
     const int ndl = (M * NR + 255) / 256;   // (uniform)
+    // (unconditional loads on clamped addresses, eight per uniform block: a load inside its own
+    // branch gets its own s_waitcnt and the batch serialises)
 #pragma unroll
-    for (int u = 0; u < DYL; ++u)
-        if (u < ndl) dv[u] = dy[min(tid + 256 * u, M * NR - 1)];
+    for (int g8 = 0; g8 < DYL / 8; ++g8)
+        if (8 * g8 < ndl) {
+#pragma unroll
+            for (int u = 8 * g8; u < 8 * g8 + 8; ++u) dv[u] = dy[min(tid + 256 * u, M * NR - 1)];
+        }
     const int kc = tid & 31, slice = tid >> 5;
     const int kx = (K + 255) / 256;
     const int r = dw_role ? 0 : blockIdx.x - n_dw;
@@ -1415,12 +1420,15 @@ __global__ __launch_bounds__(256) void k_linear_small_bwd(SmallBwdArgs a, int M,
         for (int n = 0; n < N; ++n) wk[n] = n < NR ? wk[n] : 0.f;
     }
 #pragma unroll
-    for (int u = 0; u < DYL; ++u)
-        if (u < ndl) {
-            const int e = tid + 256 * u;
-            if (e < M * NR) {
-                const int row = N == 1 ? e : e / NR;
-                sdy[row * N + (e - row * NR)] = dv[u];
+    for (int g8 = 0; g8 < DYL / 8; ++g8)
+        if (8 * g8 < ndl) {
+#pragma unroll
+            for (int u = 8 * g8; u < 8 * g8 + 8; ++u) {
+                const int e = tid + 256 * u;
+                if (e < M * NR) {
+                    const int row = N == 1 ? e : e / NR;
+                    sdy[row * N + (e - row * NR)] = dv[u];
+                }
             }
         }
     if (NR < N) {      // (uniform) the pad columns
@@ -2009,9 +2017,14 @@ __global__ __launch_bounds__(256) void k_linear_narrow_bwd(
     constexpr int DYL = 64;                      // M * NR <= 256 threads x 64
     float dv[DYL];
     const int ndl = (M * NR + 255) / 256;        // (uniform)
+    // (loads are UNCONDITIONAL on clamped addresses and masked by value afterwards: a load inside
+    // a branch gets its own s_waitcnt, which serialises the whole batch -- 15 us instead of 7)
 #pragma unroll
-    for (int u = 0; u < DYL; ++u)
-        if (u < ndl) dv[u] = dy[min(tid + 256 * u, M * NR - 1)];
+    for (int g8 = 0; g8 < DYL / 8; ++g8)
+        if (8 * g8 < ndl) {                      // (uniform, eight loads per block)
+#pragma unroll
+            for (int u = 8 * g8; u < 8 * g8 + 8; ++u) dv[u] = dy[min(tid + 256 * u, M * NR - 1)];
+        }
     const bool dw_role = (int)blockIdx.x < n_dw;
     // ---- this wave's own operand loads, before anything is waited for
     constexpr int BMAX = 32;                     // B operand registers: 32 steps of the batch half / 4 NT steps of n
@@ -2026,11 +2039,14 @@ __global__ __launch_bounds__(256) void k_linear_narrow_bwd(
         idle = tile > KT;
         const int k = min(tile * 16 + r16, K - 1);
         const bool kin = tile * 16 + r16 < K;
+        float xl[BMAX];
+#pragma unroll
+        for (int u = 0; u < BMAX; ++u) xl[u] = x[(size_t)min(mh * Mh + 4 * u + q, M - 1) * K + k];
 #pragma unroll
         for (int u = 0; u < BMAX; ++u) {
             const int m = mh * Mh + 4 * u + q;
             const bool in = 4 * u < Mh && m < M && !idle;
-            b[u] = ones ? (in ? 1.f : 0.f) : ((in && kin) ? x[(size_t)min(m, M - 1) * K + k] : 0.f);
+            b[u] = ones ? (in ? 1.f : 0.f) : ((in && kin) ? xl[u] : 0.f);
         }
     } else {
         const int KG = (KT + 3) / 4, MT = M16 / 16, MS = MT >= 2 ? 2 : 1;
@@ -2042,22 +2058,25 @@ __global__ __launch_bounds__(256) void k_linear_narrow_bwd(
         mt_hi = min(MT, mt_lo + MTh);
         const int k = min(tile * 16 + r16, K - 1);
         const bool kin = tile * 16 + r16 < K && !idle;
+        float wl[4 * NT];
 #pragma unroll
-        for (int u = 0; u < 4 * NT; ++u) {
-            const int n = 4 * u + q;
-            b[u] = (kin && n < NR) ? w[(size_t)min(n, NR - 1) * K + k] : 0.f;
-        }
+        for (int u = 0; u < 4 * NT; ++u) wl[u] = w[(size_t)min(4 * u + q, NR - 1) * K + k];
+#pragma unroll
+        for (int u = 0; u < 4 * NT; ++u) b[u] = (kin && 4 * u + q < NR) ? wl[u] : 0.f;
     }
     // ---- the LDS copy of dy: zero, then scatter
     for (int e = tid; e < M16 * LD; e += 256) sdy[e] = 0.f;
     __syncthreads();
 #pragma unroll
-    for (int u = 0; u < DYL; ++u)
-        if (u < ndl) {
-            const int e = tid + 256 * u;
-            if (e < M * NR) {
-                const int row = e / NR;
-                sdy[row * LD + (e - row * NR)] = dv[u];
+    for (int g8 = 0; g8 < DYL / 8; ++g8)
+        if (8 * g8 < ndl) {
+#pragma unroll
+            for (int u = 8 * g8; u < 8 * g8 + 8; ++u) {
+                const int e = tid + 256 * u;
+                if (e < M * NR) {
+                    const int row = e / NR;
+                    sdy[row * LD + (e - row * NR)] = dv[u];
+                }
             }
         }
     __syncthreads();
@@ -2070,11 +2089,14 @@ __global__ __launch_bounds__(256) void k_linear_narrow_bwd(
             if (s0 > 0) {
                 const int k = min(tile * 16 + r16, K - 1);
                 const bool kin = tile * 16 + r16 < K;
+                float xl[BMAX];
+#pragma unroll
+                for (int u = 0; u < BMAX; ++u) xl[u] = x[(size_t)min(mh * Mh + 4 * (s0 + u) + q, M - 1) * K + k];
 #pragma unroll
                 for (int u = 0; u < BMAX; ++u) {
                     const int m = mh * Mh + 4 * (s0 + u) + q;
                     const bool in = 4 * (s0 + u) < Mh && m < M && !idle;
-                    b[u] = ones ? (in ? 1.f : 0.f) : ((in && kin) ? x[(size_t)min(m, M - 1) * K + k] : 0.f);
+                    b[u] = ones ? (in ? 1.f : 0.f) : ((in && kin) ? xl[u] : 0.f);
                 }
             }
 #pragma unroll
@@ -2280,8 +2302,8 @@ __global__ __launch_bounds__(NW * 64) void k_twin_input_grad_mfma(TwinDxArgs a, 
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const float *__restrict__ wr = a.w[t] + (size_t)(n + i) * ldw + col0;
-                b0[j][i] = c0 ? wr[r16] : 0.f;
-                b1[j][i] = (two && c1) ? wr[16 + r16] : 0.f;
+                b0[j][i] = wr[min(r16, ncol - 1)];          // (unconditional, masked below)
+                b1[j][i] = wr[min(16 + r16, ncol - 1)];
             }
         }
 #pragma unroll
@@ -2291,8 +2313,8 @@ __global__ __launch_bounds__(NW * 64) void k_twin_input_grad_mfma(TwinDxArgs a, 
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const float av = hv[i] > 0.f ? gv[i] : 0.f;
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b0[j][i], acc0, 0, 0, 0);
-                if (two) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b1[j][i], acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, c0 ? b0[j][i] : 0.f, acc0, 0, 0, 0);
+                if (two) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, c1 ? b1[j][i] : 0.f, acc1, 0, 0, 0);
             }
         }
     }

@@ -16,7 +16,7 @@ try:
 except Exception as e: print('$name FAILED', e); print(open('$O/$name.err').read()[-800:])
 "; }
 run sac_new X=1
-run sac_scalar_narrow PFRL_NARROW_BWD_SCALAR=1
+run sac_x X=2
 run sac_new2 X=1
 rocprofv3 --kernel-trace --output-format csv -d /tmp/p3 -- python $R/bench.py --algo sac --no-cpu-baseline --steps 6 --warmup 2 --capacity 200000 > /dev/null 2>&1
 python $R/tools/update_timeline.py /tmp/p3/*/*_kernel_trace.csv --marker k_adam --every 3 > $O/sac_update_timeline.txt 2>&1
