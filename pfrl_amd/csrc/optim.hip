@@ -195,22 +195,12 @@ __global__ __launch_bounds__(kThreads) void k_rmsprop_fused(FusedArgs a, float l
         return;
     }
     // elementwise tasks: a thread owns four ADJACENT elements (one float4 per array), so that
-    // the slab sums keep many 16-byte loads in flight instead of walking slab after slab
+    // the slab sums keep eight 16-byte loads in flight instead of walking slab after slab
     const int64_t i0 = (int64_t)lb * kChunk + (int64_t)tid * 4;
     if (i0 >= t.numel) return;
     const int cnt = (int)min((int64_t)4, t.numel - i0);
     const bool vec = cnt == 4 && ((reinterpret_cast<uintptr_t>(t.src) | (uintptr_t)(t.slab_stride * 4)) & 15) == 0;
     float g[4] = {0.f, 0.f, 0.f, 0.f};
-    // parameter and state are requested BEFORE the gradient is formed (one trip fewer at the end)
-    const bool pvec = t.mode != PFRL_OPT_FOLD && cnt == 4 &&
-                      ((reinterpret_cast<uintptr_t>(t.p) | reinterpret_cast<uintptr_t>(t.sq) |
-                        reinterpret_cast<uintptr_t>(t.ga)) & 15) == 0;
-    float4 pv = make_float4(0.f, 0.f, 0.f, 0.f), sv = pv, mv = pv;
-    if (pvec) {   // (uniform per task in practice: whole tensors are aligned or not)
-        pv = *reinterpret_cast<const float4 *>(t.p + i0);
-        sv = *reinterpret_cast<const float4 *>(t.sq + i0);
-        if (CENTERED) mv = *reinterpret_cast<const float4 *>(t.ga + i0);
-    }
     if (t.mode == PFRL_OPT_PLAIN) {
         if (vec) {
             const float4 v = *reinterpret_cast<const float4 *>(t.src + i0);
@@ -226,20 +216,28 @@ __global__ __launch_bounds__(kThreads) void k_rmsprop_fused(FusedArgs a, float l
                 g[c] = __fadd_rn(g[c], (t.mask == nullptr || t.mask[(int64_t)m * t.F + i0 + c] > 0.f) ? v : 0.f);
             }
     } else if (vec) {
-        // the order of k_splitk_reduce (csrc/qnet.hip): 0 + slab 0 + slab 1 + ...  The slabs were
-        // written by the launch before this one, on every XCD: each dependent batch of loads is a
-        // trip to memory, and this launch is nothing but those trips -- 32 slabs in flight per
-        // thread (the 50 slabs of the first convolution: 2 trips instead of 7 at eight in flight)
+        // the order of k_splitk_reduce (csrc/qnet.hip): 0 + slab 0 + slab 1 + ...
         const float *base = t.src + i0;
         const int S = t.n_slabs;
-        constexpr int NF = 32;
-        for (int k = 0; k < S; k += NF) {
-            float4 v[NF];
+        int k = 0;
+        for (; k + 8 <= S; k += 8) {
+            float4 v[8];
 #pragma unroll
-            for (int u = 0; u < NF; ++u)
+            for (int u = 0; u < 8; ++u)
+                v[u] = *reinterpret_cast<const float4 *>(base + (int64_t)(k + u) * t.slab_stride);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                g[0] = __fadd_rn(g[0], v[u].x); g[1] = __fadd_rn(g[1], v[u].y);
+                g[2] = __fadd_rn(g[2], v[u].z); g[3] = __fadd_rn(g[3], v[u].w);
+            }
+        }
+        if (k < S) {
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
                 v[u] = *reinterpret_cast<const float4 *>(base + (int64_t)min(k + u, S - 1) * t.slab_stride);
 #pragma unroll
-            for (int u = 0; u < NF; ++u)
+            for (int u = 0; u < 8; ++u)
                 if (k + u < S) {
                     g[0] = __fadd_rn(g[0], v[u].x); g[1] = __fadd_rn(g[1], v[u].y);
                     g[2] = __fadd_rn(g[2], v[u].z); g[3] = __fadd_rn(g[3], v[u].w);
@@ -252,7 +250,12 @@ __global__ __launch_bounds__(kThreads) void k_rmsprop_fused(FusedArgs a, float l
         for (int c = 0; c < cnt; ++c) t.out[i0 + c] = g[c];
         return;
     }
+    const bool pvec = cnt == 4 && ((reinterpret_cast<uintptr_t>(t.p) | reinterpret_cast<uintptr_t>(t.sq) |
+                                   reinterpret_cast<uintptr_t>(t.ga)) & 15) == 0;
     if (pvec) {
+        float4 pv = *reinterpret_cast<float4 *>(t.p + i0);
+        float4 sv = *reinterpret_cast<float4 *>(t.sq + i0);
+        float4 mv = CENTERED ? *reinterpret_cast<float4 *>(t.ga + i0) : make_float4(0.f, 0.f, 0.f, 0.f);
         rms_update<CENTERED>(pv.x, g[0], sv.x, mv.x, lr, alpha, oma, eps, weight_decay);
         rms_update<CENTERED>(pv.y, g[1], sv.y, mv.y, lr, alpha, oma, eps, weight_decay);
         rms_update<CENTERED>(pv.z, g[2], sv.z, mv.z, lr, alpha, oma, eps, weight_decay);

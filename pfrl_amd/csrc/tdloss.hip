@@ -125,19 +125,6 @@ __device__ __forceinline__ void head_td_row(
     const float *__restrict__ sel_q = next_q_online ? next_q_online : target_q;
     const float *__restrict__ wt_src = weights ? weights : reward;
     float hv[KJ], wv[A][KJ], tqv[A], nqv[A], bv[A];
-    // everything that does not depend on h first: with the hidden layer's fold below, these loads
-    // would otherwise be a SECOND dependent round trip after the slabs (~1 us of this launch)
-#pragma unroll
-    for (int a = 0; a < A; ++a) {
-#pragma unroll
-        for (int j = 0; j < KJ; ++j) wv[a][j] = W[a * K + lane + 64 * j];
-        tqv[a] = target_q[(size_t)m * A + a];
-        nqv[a] = sel_q[(size_t)m * A + a];
-        bv[a] = bias[a];
-    }
-    const int act = (int)action[m];
-    const float rew = reward[m], disc = discount[m], term = terminal[m];
-    const float wt_raw = wt_src[m];
     if (h_part == nullptr) {
 #pragma unroll
         for (int j = 0; j < KJ; ++j) hv[j] = h[(size_t)m * K + lane + 64 * j];
@@ -170,6 +157,17 @@ __device__ __forceinline__ void head_td_row(
             h_out[(size_t)m * K + lane + 64 * j] = hv[j];
         }
     }
+#pragma unroll
+    for (int a = 0; a < A; ++a) {
+#pragma unroll
+        for (int j = 0; j < KJ; ++j) wv[a][j] = W[a * K + lane + 64 * j];
+        tqv[a] = target_q[(size_t)m * A + a];
+        nqv[a] = sel_q[(size_t)m * A + a];
+        bv[a] = bias[a];
+    }
+    const int act = (int)action[m];
+    const float rew = reward[m], disc = discount[m], term = terminal[m];
+    const float wt_raw = wt_src[m];
     const float wt = weights ? wt_raw : 1.0f;
     const float scale = mean ? 1.0f / (float)B : 1.0f;
     // y = q[act] = h[m] . W[act] + b[act]
