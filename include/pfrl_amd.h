@@ -235,6 +235,18 @@ int pfrl_tree_update_errors_f32(const pfrl_tree_t *tree, int64_t B, const int64_
                                 int has_max, float error_max, double pri_at_max, double eps,
                                 double alpha, int dedupe, int pow_mode, void *stream);
 
+/* The same followed by the leaf writes of pfrl_tree_write (n entries: the appends and pops that
+ * PrioritizedBuffer.append / popleft, pfrl/collections/prioritized.py:39-54, recorded after this
+ * minibatch was sampled) as one launch with one path repair: sequential semantics -- priorities
+ * and max_priority first, then the writes (which win on a shared leaf).  Both sets must belong
+ * to the frame in `tree`; B + n <= 1024. */
+int pfrl_tree_update_errors_write_f32(const pfrl_tree_t *tree, int64_t B, const int64_t *x,
+                                      const float *err, int has_min, float error_min,
+                                      double pri_at_min, int has_max, float error_max,
+                                      double pri_at_max, double eps, double alpha, int dedupe,
+                                      int pow_mode, int64_t n, const int64_t *wx, const double *wval,
+                                      const uint8_t *wtag, const uint8_t *wuse_maxp, void *stream);
+
 /* HOST helpers of the priority transform (no device work).  pfrl_powf_host evaluates the
  * restated glibc powf (pow_mode PFRL_POW_GLIBC / _FMA) on host arrays; pfrl_powf_host_variant
  * compares both restatements with THIS host's libm powf on n_probe pseudo-random inputs in

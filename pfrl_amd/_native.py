@@ -169,6 +169,7 @@ EXPORTS = {
     "pfrl_tree_write": (ctypes.c_int, "Rqppppp"),
     "pfrl_tree_sample": (ctypes.c_int, "Rqpppppppppidqpp"),
     "pfrl_tree_update_errors_f32": (ctypes.c_int, "Rqppifdifdddiip"),
+    "pfrl_tree_update_errors_write_f32": (ctypes.c_int, "Rqppifdifdddiiqppppp"),
     "pfrl_h2d_async": (ctypes.c_int, "ppqp"),
     "pfrl_powf_host": (ctypes.c_int, "ipfpq"),
     "pfrl_powf_host_variant": (ctypes.c_int, "fq"),

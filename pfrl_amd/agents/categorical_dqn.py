@@ -9,6 +9,9 @@ the path of subclasses that override the target computation.  Both plug into
 the same device replay path as DQN (fused gather, HIP-graph update, PER
 priorities handed over as a device tensor).
 """
+import os
+from contextlib import nullcontext as _nullcontext
+
 import torch
 
 from pfrl_amd.agents import dqn
@@ -58,6 +61,16 @@ class CategoricalDQN(dqn.DQN):
 
     _fused_td_double = None   # cross-entropy on distributions: not the scalar TD loss
     _c51_double = False       # greedy next action: target net (False) / online net (True)
+    _side_passes = None
+
+    def _pass_streams(self):
+        """Two side streams for the no-grad passes of the Double update (None: switched off
+        with PFRL_C51_FORK=0, or a precomputed target pass is in the minibatch)."""
+        if os.environ.get("PFRL_C51_FORK", "1") == "0" or self.device.type != "cuda":
+            return None
+        if self._side_passes is None:
+            self._side_passes = (torch.cuda.Stream(self.device), torch.cuda.Stream(self.device))
+        return self._side_passes
 
     def _project(self, exp_batch, next_dist, z_values):
         Tz = (exp_batch["reward"][..., None]
@@ -92,14 +105,36 @@ class CategoricalDQN(dqn.DQN):
         (pfrl_c51_loss): projection, cross entropy, its gradient, Q(s, a), KL."""
         from pfrl_amd import ops
 
+        # The three network passes of the Double update (online on s; target and online on s')
+        # read nothing of each other: the two no-grad passes are issued on side streams forked
+        # from the current one and joined in front of the loss launch.  In a captured update they
+        # become parallel branches of the graph; the host order of the calls -- hence the order in
+        # which the NoisyNet layers consume the device generator -- is that of the reference
+        # (pfrl/agents/categorical_double_dqn.py:17-39 after categorical_dqn.py:165-170).
+        cur = torch.cuda.current_stream(self.device)
+        side = self._pass_streams() if type(self)._c51_double else None
+        if side is not None:
+            for st in side:
+                st.wait_stream(cur)
         qout = self.model(exp_batch["state"])
         if not ops.c51_loss_supported(qout.q_dist):
+            if side is not None:
+                for st in side:
+                    cur.wait_stream(st)
             return None
         with torch.no_grad():
             if type(self)._c51_double:
                 with evaluating(self.target_model), evaluating(self.model):
-                    target_next = self._target_next_action_value(exp_batch)
-                    select = self.model(exp_batch["next_state"]).q_dist
+                    with torch.cuda.stream(side[0]) if side is not None else _nullcontext():
+                        target_next = self._target_next_action_value(exp_batch)
+                    with torch.cuda.stream(side[1]) if side is not None else _nullcontext():
+                        select = self.model(exp_batch["next_state"]).q_dist
+                if side is not None:
+                    for st in side:
+                        cur.wait_stream(st)
+                    # allocated on the side streams, read by the loss launch on this one
+                    target_next.q_dist.record_stream(cur)
+                    select.record_stream(cur)
             else:
                 target_next = self._target_next_action_value(exp_batch)
                 select = None

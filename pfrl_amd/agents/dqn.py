@@ -249,6 +249,7 @@ class DQN(agent.AttributeSavingMixin, agent.BatchAgent):
         return self._cumulative_steps
 
     def sync_target_network(self):
+        self._flush_backward()           # (the parameters of the last update, not the one before)
         synchronize_parameters(src=self.model, dst=self.target_model,
                                method=self.target_update_method, tau=self.soft_update_tau)
         self._side_needs_main = True     # (a side stream reading the target network: see _range_side)
@@ -287,9 +288,13 @@ class DQN(agent.AttributeSavingMixin, agent.BatchAgent):
         of the step and are recorded with one concatenation."""
         want_errors = has_weight or errors_out is not None
         handed_over = []
+        self._flush_backward()
         if self.use_graphs:
             hand_over = None
+            late = None
             if has_weight and errors_out is None and self._replay_stream is not None:
+                if self._late_backward_ok():
+                    late = self._late
                 def hand_over(delta):
                     # TD errors exist as soon as the forward graph has run: the replay
                     # stream takes them (priority update, then the next sample and
@@ -298,7 +303,7 @@ class DQN(agent.AttributeSavingMixin, agent.BatchAgent):
                     self._replay_stream.wait_event(self._fwd_event)
                     self.replay_buffer.update_errors(delta)
                     handed_over.append(True)
-            loss, delta = self._graphed_step(exp_batch, want_errors, deferred, hand_over)
+            loss, delta = self._graphed_step(exp_batch, want_errors, deferred, hand_over, late)
         else:
             loss, delta = self._compute_loss(exp_batch, want_errors=want_errors)
         if errors_out is not None:
@@ -318,7 +323,37 @@ class DQN(agent.AttributeSavingMixin, agent.BatchAgent):
             self.optimizer.step()
         self.optim_t += 1
 
-    def _graphed_step(self, exp_batch, want_errors, deferred=None, after_forward=None):
+    # -- backward + step of update k launched after the replay side of update k + 1 -----------
+    # With a replay stream the next forward pass waits for: priorities of this minibatch ->
+    # pending appends -> the B dependent draws -> the gather.  That chain starts as soon as the
+    # forward graph has produced the TD errors; the backward / optimizer graph only has to be
+    # done by the time the gather is.  The host, however, launches in program order, and a
+    # graph launch costs it ~90 us: launched first, the backward graph kept the chain waiting
+    # for the host (measured with events, tools/pipeline_events.py: 60 us from the end of the
+    # forward graph to the first replay-side kernel, 40 us of appends behind it).  So the
+    # launch is held back: update() of the NEXT minibatch (whose sample() has just enqueued
+    # the chain) replays it first thing, and so does everything else that touches the model.
+    _late = None
+    _in_train_step = False
+
+    def _late_backward_ok(self):
+        if self.__dict__.get("_late") is None:
+            self._late = []
+            self._late_enabled = os.environ.get("PFRL_LATE_BACKWARD", "1") != "0"
+        # (only inside batch_observe, which flushes on its way out: a caller of update() itself
+        # expects the parameters to be stepped when it returns)
+        return (self._late_enabled and self._in_train_step
+                and not getattr(self._graphed, "split_for_allreduce", False))
+
+    def _flush_backward(self):
+        late = self.__dict__.get("_late")
+        if late:
+            pending = list(late)
+            del late[:]
+            for replay_rest in pending:
+                replay_rest()
+
+    def _graphed_step(self, exp_batch, want_errors, deferred=None, after_forward=None, late=None):
         """loss -> backward -> step replayed from a captured HIP graph."""
         if self._graphed is None:
             from pfrl_amd.agents.graphed_update import GraphedUpdate
@@ -326,7 +361,7 @@ class DQN(agent.AttributeSavingMixin, agent.BatchAgent):
             self._graphed = GraphedUpdate(self)
             self._graphed.pipeline = self._replay_stream is not None
         try:
-            loss, delta, y = self._graphed.run(exp_batch, want_errors, after_forward)
+            loss, delta, y = self._graphed.run(exp_batch, want_errors, after_forward, late)
         except Exception as e:  # capture not possible -> stay eager on the GPU
             if self._graphed.graphs:
                 raise
@@ -973,7 +1008,12 @@ class DQN(agent.AttributeSavingMixin, agent.BatchAgent):
 
     def batch_observe(self, batch_obs, batch_reward, batch_done, batch_reset):
         if self.training:
-            return self._batch_observe_train(batch_obs, batch_reward, batch_done, batch_reset)
+            self._in_train_step = True
+            try:
+                return self._batch_observe_train(batch_obs, batch_reward, batch_done, batch_reset)
+            finally:
+                self._in_train_step = False
+                self._flush_backward()   # nothing of a step's updates is pending outside of it
         return self._batch_observe_eval(batch_obs, batch_reward, batch_done, batch_reset)
 
     def _can_start_replay(self):

@@ -534,27 +534,40 @@ class GraphedUpdate:
             self._restore(snap)
         return {"graph": g, "losses": losses, "ys": ys}
 
-    def run(self, exp_batch, want_errors, after_forward=None):
+    def _replay_items(self, items, bucket):
+        for item in items:
+            if item == "all_reduce":
+                self.agent.grad_reducer.reduce_flat(bucket)
+            elif item != "after_forward":
+                item.replay()
+
+    def run(self, exp_batch, want_errors, after_forward=None, late=None):
         """Returns (loss, delta, y) tensors owned by the graph (static).  In
         pipeline mode ``after_forward(delta)`` is called between the forward
-        graph and the backward/step graph."""
+        graph and the backward/step graph.  ``late``: a list that receives a
+        callable replaying everything after the hand-over, instead of it being
+        replayed here -- the caller launches the next minibatch's replay-side work
+        first (that chain, not backward + step, is what the next forward pass waits
+        for) and must call it before anything else touches the model."""
         key = (self._key(exp_batch), bool(want_errors))
         entry = self.graphs.lookup(key)
         if entry is None:
             entry = self._capture(exp_batch, want_errors)
             self.graphs.admit(key, entry)
-        called = False
-        for item in entry["plan"]:
-            if item == "all_reduce":
-                self.agent.grad_reducer.reduce_flat(entry["bucket"])
-            elif item == "after_forward":
-                if after_forward is not None:
-                    after_forward(entry["delta"])
-                    called = True
-            else:
-                item.replay()
-        if after_forward is not None and not called:
+        plan = entry["plan"]
+        if after_forward is not None and "after_forward" in plan:
+            cut = plan.index("after_forward")
+            self._replay_items(plan[:cut], entry["bucket"])
             after_forward(entry["delta"])
+            rest, bucket = plan[cut + 1:], entry["bucket"]
+            if late is not None:
+                late.append(lambda: self._replay_items(rest, bucket))
+            else:
+                self._replay_items(rest, bucket)
+        else:
+            self._replay_items(plan, entry["bucket"])
+            if after_forward is not None:
+                after_forward(entry["delta"])
         return entry["loss"], entry["delta"], entry["y"]
 
 

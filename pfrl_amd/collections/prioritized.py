@@ -8,6 +8,7 @@ driven by the kernels in pfrl_amd/csrc/sumtree.hip.  The host keeps only the
 integer bookkeeping (TreeFrame) and the Python payload deque.
 """
 import collections
+import os
 
 import numpy as np
 import torch
@@ -77,6 +78,10 @@ class PrioritizedBuffer:
         self.side_stream = None
         self._sample_parity = 0
         self._n_sampled = 0
+        # update_errors_device of the last minibatch, held back until the next leaf writes go
+        # to the device (one launch and one path repair for both; see _launch_deferred)
+        self._deferred = None
+        self.defer_errors = os.environ.get("PFRL_TREE_FUSE_ERRORS", "1") != "0"
         self._desc = TreeDesc()
         d = self._desc
         d.sum_val, d.sum_tag = self.sum_val.data_ptr(), self.sum_tag.data_ptr()
@@ -112,10 +117,27 @@ class PrioritizedBuffer:
         self._pend_t.append(tag)
         self._pend_m.append(use_maxp)
 
+    def _launch_deferred(self, desc, writes=None):
+        """The held-back update_errors_device -- alone, or together with the leaf writes
+        ``writes`` = (x, val, tag, use_maxp) when both fit one launch (returns True then).
+        Both belong to the current frame: every frame change flushes first."""
+        d, self._deferred = self._deferred, None
+        if d is None:
+            return False
+        x, err, args, kw = d
+        if writes is not None and x.numel() + writes[0].numel() <= 1024:
+            ops.tree_update_errors_write_f32(desc, x, err, *args, writes=writes, **kw)
+            return True
+        ops.tree_update_errors_f32(desc, x, err, *args, **kw)
+        return False
+
     def flush(self):
         """Launch the recorded leaf writes under the frame they belong to."""
         n = len(self._pend_x)
         if n == 0:
+            if self._deferred is not None:
+                with on_stream(self.side_stream):
+                    self._launch_deferred(self._sync_desc())
             return
         desc = self._sync_desc()
         with on_stream(self.side_stream):
@@ -127,7 +149,8 @@ class PrioritizedBuffer:
                     np.asarray(self._pend_t[lo:hi], dtype=np.uint8),
                     np.asarray(self._pend_m[lo:hi], dtype=np.uint8),
                 ])
-                ops.tree_write(desc, x, v, t, m)
+                if not self._launch_deferred(desc, (x, v, t, m)):
+                    ops.tree_write(desc, x, v, t, m)
         self._pend_x, self._pend_v, self._pend_t, self._pend_m = [], [], [], []
         self._pend_at = {}
 
@@ -146,7 +169,8 @@ class PrioritizedBuffer:
         self._pend_at = {}
 
         def launch(x, v, t, m):
-            ops.tree_write(desc, x, v, t, m)
+            if not self._launch_deferred(desc, (x, v, t, m)):
+                ops.tree_write(desc, x, v, t, m)
 
         return arrays, launch
 
@@ -305,10 +329,16 @@ class PrioritizedBuffer:
         """set_last_priority for f32 errors already on the device (DQN path)."""
         assert not self.wait_priority_after_sampling or self.flag_wait_priority
         assert self._n_sampled == err.numel()
-        with on_stream(self.side_stream):
-            ops.tree_update_errors_f32(self._sync_desc(), self._sampled_x, err, error_min,
-                                       pri_at_min, error_max, pri_at_max, eps, alpha, dedupe=True,
-                                       pow_mode=pow_mode)
+        assert self._deferred is None
+        args = (error_min, pri_at_min, error_max, pri_at_max, eps, alpha)
+        kw = dict(dedupe=True, pow_mode=pow_mode)
+        if self.defer_errors:
+            # nothing reads the tree before the next flush / sample; the launch then carries
+            # the appends recorded in between as well (err stays referenced until then)
+            self._deferred = (self._sampled_x, err, args, kw)
+        else:
+            with on_stream(self.side_stream):
+                ops.tree_update_errors_f32(self._sync_desc(), self._sampled_x, err, *args, **kw)
         self.flag_wait_priority = False
         self.sampled_indices = []
         self._n_sampled = 0
@@ -320,6 +350,8 @@ class PrioritizedBuffer:
 
     @property
     def max_priority(self):
+        if self._deferred is not None:
+            self.flush()
         self._join()
         v = float(self._maxp_val.item())
         t = int(self._maxp_tag.item())

@@ -95,13 +95,15 @@ __global__ __launch_bounds__(kMaxBatch) void k_tree_write(pfrl_tree_t T, int64_t
     repair_paths(T, active, xi);
 }
 
-// Shared tail of set_last_priority: typed max_priority scan, last-occurrence
-// de-duplication, leaf writes into both trees, path repair.
-__device__ void set_priorities_tail(const pfrl_tree_t &T, int64_t B, const int64_t *x, TV p,
-                                    int dedupe, double *s_v, uint8_t *s_t, int64_t *s_x) {
+// Shared body of set_last_priority: typed max_priority scan, last-occurrence
+// de-duplication, leaf writes into both trees.  Returns whether this thread's leaf
+// takes part in the path repair that has to follow.
+__device__ bool set_priorities_leaves(const pfrl_tree_t &T, int64_t B, const int64_t *x, TV p,
+                                      int dedupe, double *s_v, uint8_t *s_t, int64_t *s_x,
+                                      int64_t &xi) {
     const int i = threadIdx.x;
     const bool in = i < B;
-    int64_t xi = 0;
+    xi = 0;
     if (in) {
         xi = x[i];
         s_v[i] = p.v;
@@ -134,6 +136,13 @@ __device__ void set_priorities_tail(const pfrl_tree_t &T, int64_t B, const int64
         T.min_val[il] = p.v;
         T.min_tag[il] = (uint8_t)p.t;
     }
+    return active;
+}
+
+__device__ void set_priorities_tail(const pfrl_tree_t &T, int64_t B, const int64_t *x, TV p,
+                                    int dedupe, double *s_v, uint8_t *s_t, int64_t *s_x) {
+    int64_t xi;
+    const bool active = set_priorities_leaves(T, B, x, p, dedupe, s_v, s_t, s_x, xi);
     repair_paths(T, active, xi);
 }
 
@@ -158,6 +167,24 @@ struct ErrCfg {
     int pow_mode;   // PFRL_POW_*
 };
 
+// pfrl/replay_buffers/prioritized.py:47-55 with np.float32 errors
+__device__ __forceinline__ TV priority_of_error(const ErrCfg &c, float e) {
+    if (c.has_min && !(e > c.error_min)) return mk_tv(c.pri_at_min, PFRL_TAG_PY);
+    if (c.has_max && !(e < c.error_max)) return mk_tv(c.pri_at_max, PFRL_TAG_PY);
+    const float s = __fadd_rn(e, (float)c.eps);
+    // np.float32 ** float -> powf(s, (float)alpha) of the host's libm: glibc's powf is
+    // not correctly rounded (1 ulp off in ~0.05 % of inputs), so it is restated
+    // operation by operation (powf_glibc.h) -- the leaves are the numbers NumPy gives.
+    float r;
+    if (c.pow_mode == PFRL_POW_GLIBC_FMA)
+        r = pfrl_powf::powf_glibc<true>(s, (float)c.alpha);
+    else if (c.pow_mode == PFRL_POW_GLIBC)
+        r = pfrl_powf::powf_glibc<false>(s, (float)c.alpha);
+    else   // PFRL_POW_CORRECTLY_ROUNDED (rounds 1 and 2)
+        r = (float)pow((double)s, (double)(float)c.alpha);
+    return mk_tv((double)r, PFRL_TAG_F32);
+}
+
 __global__ __launch_bounds__(kMaxBatch) void k_tree_update_errors(pfrl_tree_t T, int64_t B,
                                                                   const int64_t *__restrict__ x,
                                                                   const float *__restrict__ err,
@@ -167,29 +194,48 @@ __global__ __launch_bounds__(kMaxBatch) void k_tree_update_errors(pfrl_tree_t T,
     __shared__ int64_t s_x[kMaxBatch];
     const int i = threadIdx.x;
     TV p = mk_tv(0.0, PFRL_TAG_PY);
-    if (i < B) {
-        // pfrl/replay_buffers/prioritized.py:47-55 with np.float32 errors
-        const float e = err[i];
-        if (c.has_min && !(e > c.error_min)) {
-            p = mk_tv(c.pri_at_min, PFRL_TAG_PY);
-        } else if (c.has_max && !(e < c.error_max)) {
-            p = mk_tv(c.pri_at_max, PFRL_TAG_PY);
-        } else {
-            const float s = __fadd_rn(e, (float)c.eps);
-            // np.float32 ** float -> powf(s, (float)alpha) of the host's libm: glibc's powf is
-            // not correctly rounded (1 ulp off in ~0.05 % of inputs), so it is restated
-            // operation by operation (powf_glibc.h) -- the leaves are the numbers NumPy gives.
-            float r;
-            if (c.pow_mode == PFRL_POW_GLIBC_FMA)
-                r = pfrl_powf::powf_glibc<true>(s, (float)c.alpha);
-            else if (c.pow_mode == PFRL_POW_GLIBC)
-                r = pfrl_powf::powf_glibc<false>(s, (float)c.alpha);
-            else   // PFRL_POW_CORRECTLY_ROUNDED (rounds 1 and 2)
-                r = (float)pow((double)s, (double)(float)c.alpha);
-            p = mk_tv((double)r, PFRL_TAG_F32);
-        }
-    }
+    if (i < B) p = priority_of_error(c, err[i]);
     set_priorities_tail(T, B, x, p, dedupe, s_v, s_t, s_x);
+}
+
+// update_errors of one minibatch followed by the leaf writes recorded since (appends at
+// max_priority, pops) as ONE launch and ONE bottom-up repair over the union of the touched
+// paths.  Sequentially (prioritized.py:107-116, then :39-54) the priorities are set first --
+// max_priority included, which the appended leaves then take -- and a later write to the same
+// leaf wins; the node values are pure functions of the leaves, so one repair after both sets
+// of leaf stores gives the state the two launches gave.  Threads [0, B) carry the errors,
+// [B, B + n) the writes; both under the same frame (the host launches separately otherwise).
+__global__ __launch_bounds__(kMaxBatch) void k_tree_update_errors_write(
+    pfrl_tree_t T, int64_t B, const int64_t *__restrict__ x, const float *__restrict__ err,
+    ErrCfg c, int dedupe, int64_t n, const int64_t *__restrict__ wx,
+    const double *__restrict__ wval, const uint8_t *__restrict__ wtag,
+    const uint8_t *__restrict__ wuse_maxp) {
+    __shared__ double s_v[kMaxBatch];
+    __shared__ uint8_t s_t[kMaxBatch];
+    __shared__ int64_t s_x[kMaxBatch];
+    const int i = threadIdx.x;
+    TV p = mk_tv(0.0, PFRL_TAG_PY);
+    if (i < B) p = priority_of_error(c, err[i]);
+    int64_t xi;
+    bool active = set_priorities_leaves(T, B, x, p, dedupe, s_v, s_t, s_x, xi);
+    __threadfence_block();
+    __syncthreads();             // max_priority and the minibatch's leaves are in place
+    const int64_t k = (int64_t)i - B;
+    if (k >= 0 && k < n) {
+        xi = wx[k];
+        TV q;
+        if (wuse_maxp && wuse_maxp[k])
+            q = mk_tv(*T.maxp_val, *T.maxp_tag);
+        else
+            q = mk_tv(wval[k], wtag[k]);
+        const int64_t il = node_idx(T, 0, xi);
+        T.sum_val[il] = q.v;
+        T.sum_tag[il] = (uint8_t)q.t;
+        T.min_val[il] = q.v;
+        T.min_tag[il] = (uint8_t)q.t;
+        active = true;
+    }
+    repair_paths(T, active, xi);
 }
 
 // One wave; lane 0 performs the B sequentially dependent draws
@@ -613,6 +659,341 @@ __global__ __launch_bounds__(64) void k_tree_sample_lds(
     }
 }
 
+
+// ---------------------------------------------------------------------------
+// Lean sampler (round 4).  Same arithmetic, same visiting order, same results as
+// k_tree_sample; what changes is the number of instructions on the chain.  The
+// kernel is ONE wave, and a wave issues at most one instruction -- of any kind --
+// every four clocks: k_tree_sample_lds spends ~70 instructions per level on
+// branch-free typed arithmetic (both candidate types evaluated, selects) and
+// ~50 per level of the repair, i.e. it is bound by instruction issue, not by
+// LDS latency (in-kernel clocks: 157 ns per level).
+//
+//   * descent: almost every level is an np.float32 operation -- the position is
+//     np.float32 after its first subtraction, and NEP 50 makes f32 (op) python
+//     float a float32 operation on the float32-rounded values; an absent left child
+//     is the Python float 0.0.  A level whose operands do not fit that (np.float64
+//     anywhere, Python float against Python float) takes the general typed step.
+//     The position is carried as (p32 = float32 of its value, p64 = its value
+//     while it is not np.float32); only the left child of a node is read, two
+//     levels per LDS round trip (the left children of both children requested
+//     with it).
+//   * siblings: once the path is known, lane l reads the sibling of level l from
+//     the heaps -- one parallel round trip instead of selects at every level.
+//   * repair (prioritized.py:304-308: _write(ix, 0.0)): a chain of L typed additions
+//     cur = cur + sibling, bottom-up.  Result types only ever widen along it
+//     (PY -> F32 -> F64), so the chain is at most three runs of plain adds (f64,
+//     f32, f64) whose boundaries two ballots over the sibling tags give; the running
+//     sum reads lane l's sibling with v_readlane.  Lane l keeps the node of level l
+//     and stores it to the LDS top heap and to HBM itself.
+//   * the draws' uniforms are loaded 64 at a time, one per lane (a scalar load per
+//     draw was a memory round trip on the chain); level constants come out of the
+//     owning lane's registers.
+// Tried first and dropped (profiles/r04_per_sampler_phases.txt): six levels per round
+// with lane j speculating the path whose decisions are the bits of j -- bit-exact, and
+// slower (2.6 us for the 12 top levels against 1.9): the per-round bookkeeping (64
+// paths' loads, sibling selects, the winner's stores, broadcasts) is ~500 instructions.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ double readlane_f64(double v, int l) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ int64_t readlane_i64(int64_t v, int l) {
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(v & 0xffffffff), l);
+    const int hi = __builtin_amdgcn_readlane((int)(v >> 32), l);
+    return ((int64_t)hi << 32) | (int64_t)lo;
+}
+
+__device__ __forceinline__ float readlane_f32(float v, int l) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+}
+
+// One level of _find (prioritized.py:262-276) given the left child (lv, lt) of the current node.
+// Position: value p64 / type pt while pt != F32, value p32 when pt == F32; p32 == (float)value
+// always.  Returns true when the reference goes right.
+__device__ __forceinline__ bool find_level(double lv, int lt, double &p64, float &p32, int &pt) {
+    const bool absent = lt == PFRL_TAG_ABSENT;
+    const bool lean = (pt == PFRL_TAG_F32 && lt != PFRL_TAG_F64) ||
+                      (pt == PFRL_TAG_PY && lt == PFRL_TAG_F32);
+    bool go_left;
+    if (lean) {
+        const float l32 = absent ? 0.0f : (float)lv;
+        go_left = p32 < l32;
+        const float sub = __fsub_rn(p32, l32);
+        p32 = go_left ? p32 : sub;
+        pt = (go_left || absent) ? pt : PFRL_TAG_F32;
+    } else {
+        const TV pos = mk_tv(pt == PFRL_TAG_F32 ? (double)p32 : p64, pt);
+        const TV left = mk_tv(absent ? 0.0 : lv, absent ? PFRL_TAG_PY : lt);
+        go_left = tv_lt(pos, left);
+        const TV sub = tv_sub(pos, left);
+        p64 = go_left ? p64 : sub.v;
+        pt = go_left ? pt : sub.t;
+        p32 = go_left ? p32 : (float)sub.v;
+    }
+    return !go_left;
+}
+
+// n levels down an LDS heap from node h (children of node i: 2i, 2i + 1); returns the node reached.
+__device__ __forceinline__ int find_down(const double *hv, const uint8_t *ht, int h, int n,
+                                         double &p64, float &p32, int &pt) {
+    int d = 0;
+    for (; d + 1 < n; d += 2) {
+        const double lv0 = hv[2 * h], lva = hv[4 * h], lvb = hv[4 * h + 2];
+        const int lt0 = ht[2 * h], lta = ht[4 * h], ltb = ht[4 * h + 2];
+        const bool r0 = find_level(lv0, lt0, p64, p32, pt);
+        const double lv1 = r0 ? lvb : lva;
+        const int lt1 = r0 ? ltb : lta;
+        const bool r1 = find_level(lv1, lt1, p64, p32, pt);
+        h = 4 * h + (r0 ? 2 : 0) + (r1 ? 1 : 0);
+    }
+    if (d < n) {
+        const bool r0 = find_level(hv[2 * h], ht[2 * h], p64, p32, pt);
+        h = 2 * h + (r0 ? 1 : 0);
+    }
+    return h;
+}
+
+__global__ __launch_bounds__(64) void k_tree_sample_lean(
+    pfrl_tree_t T, int64_t B, const double *__restrict__ u01, int64_t *__restrict__ out_x,
+    double *__restrict__ out_pri, uint8_t *__restrict__ out_pri_tag, double *__restrict__ out_prob,
+    float *__restrict__ out_weight, double *__restrict__ out_total,
+    uint8_t *__restrict__ out_total_tag, double *__restrict__ out_min_prob, int normalize,
+    double beta, int64_t slot_mod, int32_t *__restrict__ out_slot) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int L = T.log2_size;
+    const int r = L < kBotLevels ? L : kBotLevels;
+    const int top_levels = L - r + 1;           // levels L..r  -> depths 0..top_levels-1
+    const int top_n = 1 << top_levels;          // heap indices 1..top_n-1
+    const int bot_n = 1 << (r + 1);             // heap indices 1..bot_n-1 (levels r..0)
+    double *top_v = reinterpret_cast<double *>(smem);
+    double *bot_v = top_v + top_n;
+    uint8_t *top_t = reinterpret_cast<uint8_t *>(bot_v + bot_n);
+    uint8_t *bot_t = top_t + top_n;
+    __shared__ double s_total_v, s_min_v;
+    __shared__ int s_total_t, s_min_t;
+    __shared__ int64_t lv_off[PFRL_MAX_LEVELS], lv_org[PFRL_MAX_LEVELS], lv_mask[PFRL_MAX_LEVELS];
+    const int lane = threadIdx.x;
+    if (lane <= L) {
+        const int sh = T.log2_smax - lane;
+        lv_off[lane] = T.level_off[lane];
+        lv_org[lane] = T.origin[lane];
+        lv_mask[lane] = (sh > 0 ? ((int64_t)1 << sh) : 1) - 1;
+    }
+    if (lane == 0) {
+        // heap index 0 is never a node; the pair (0, 1) is never requested either, but keep it defined
+        top_v[0] = 0.0;
+        top_t[0] = 0;
+        bot_v[0] = 0.0;
+        bot_t[0] = 0;
+    }
+    __syncthreads();
+#define NODE_AT(l, x) (lv_off[l] + ((((x) - lv_org[l]) >> (l)) & lv_mask[l]))
+    // my own level's addressing constants (lane l owns level l in the repair / write-back)
+    const int myl = lane <= L ? lane : 0;
+    const int64_t my_off = lv_off[myl], my_org = lv_org[myl], my_mask = lv_mask[myl];
+
+    // stage the top of the sum tree (loads batched 16 deep per lane)
+    for (int h0 = 1; h0 < top_n; h0 += 64 * 16) {
+        double v[16];
+        uint8_t tg[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int h = h0 + k * 64 + lane;
+            if (h < top_n) {
+                const int d = 31 - __clz(h);
+                const int l = L - d;
+                const int64_t gi = NODE_AT(l, T.base + ((int64_t)(h - (1 << d)) << l));
+                v[k] = T.sum_val[gi];
+                tg[k] = T.sum_tag[gi];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int h = h0 + k * 64 + lane;
+            if (h < top_n) {
+                top_v[h] = v[k];
+                top_t[h] = tg[k];
+            }
+        }
+    }
+    if (lane == 0) {
+        const int64_t iroot = NODE_AT(L, T.base);
+        s_total_v = T.sum_val[iroot];
+        s_total_t = T.sum_tag[iroot];
+        s_min_v = T.min_val[iroot];
+        s_min_t = T.min_tag[iroot];
+    }
+    __syncthreads();
+
+#ifdef PFRL_TREE_DEBUG
+    unsigned long long t_prev = wall_clock64();
+    if (lane == 0) for (int k = 0; k < 8; ++k) g_dbg[k] = 0;
+#endif
+    double my_u = 0.0;
+    for (int64_t i = 0; i < B; ++i) {
+        // the draws of this launch, 64 at a time, one per lane (a scalar load per draw would be
+        // a memory round trip on the chain)
+        if ((i & 63) == 0) my_u = i + lane < B ? u01[i + lane] : 0.0;
+        const double u = readlane_f64(my_u, (int)(i & 63));
+        // ---- top heap: L - r levels ----
+        const TV root = mk_tv(top_v[1], top_t[1]);
+        // np.random.uniform(0.0, root) = 0.0 + (root - 0.0) * u
+        double p64 = __dadd_rn(0.0, __dmul_rn(root.v, u));
+        float p32 = (float)p64;
+        int pt = PFRL_TAG_PY;
+        const int h = find_down(top_v, top_t, 1, L - r, p64, p32, pt);
+        const int64_t x0 = T.base + ((int64_t)(h - (top_n >> 1)) << r);
+        DBG_T(0);
+        // ---- fan-out: the whole subtree below in one parallel round trip ----
+        {
+            double v[8 + 4 + 2 + kBotLevels - 2];
+            uint8_t tg[8 + 4 + 2 + kBotLevels - 2];
+            int n_ld = 0;
+#pragma unroll
+            for (int l = 0; l <= kBotLevels; ++l) {
+                const int lr = l <= r ? l : r;               // clamp (uniform)
+                const int cnt = l <= r ? (1 << (r - l)) : 0;
+                // level constants from the lane that owns the level: scalar registers, and the
+                // slot of the subtree's first node of the level is scalar arithmetic
+                const int64_t org = readlane_i64(my_org, lr);
+                const int64_t off = readlane_i64(my_off, lr), mask = readlane_i64(my_mask, lr);
+                const int64_t q0 = (x0 - org) >> lr;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    if (k * 64 < (1 << (kBotLevels - l))) {
+                        const int j = k * 64 + lane;
+                        const int64_t gi = off + ((q0 + (j < cnt ? j : 0)) & mask);
+                        v[n_ld] = T.sum_val[gi];
+                        tg[n_ld] = T.sum_tag[gi];
+                        ++n_ld;
+                    }
+                }
+            }
+            n_ld = 0;
+#pragma unroll
+            for (int l = 0; l <= kBotLevels; ++l) {
+                const int cnt = l <= r ? (1 << (r - l)) : 0;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    if (k * 64 < (1 << (kBotLevels - l))) {
+                        const int j = k * 64 + lane;
+                        if (j < cnt) {
+                            bot_v[cnt + j] = v[n_ld];   // heap index of (level l, j)
+                            bot_t[cnt + j] = tg[n_ld];
+                        }
+                        ++n_ld;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        DBG_T(1);
+        // ---- bottom heap: r levels ----
+        const int g = find_down(bot_v, bot_t, 1, r, p64, p32, pt);
+        const int64_t x = x0 + (g - (bot_n >> 1));
+        const double leaf_v = bot_v[g];
+        const uint8_t leaf_t = bot_t[g];
+        // ---- the siblings of the path: lane l reads the one of level l ----
+        int st = PFRL_TAG_ABSENT;
+        double sv = 0.0;
+        if (lane < L) {
+            const bool below = lane < r;
+            const int node = below ? (g >> lane) : (h >> (lane - r));     // path node of level `lane`
+            const double *sib_v = below ? bot_v : top_v;
+            const uint8_t *sib_t = below ? bot_t : top_t;
+            st = sib_t[node ^ 1];
+            sv = sib_v[node ^ 1];
+        }
+        if (st == PFRL_TAG_ABSENT) sv = 0.0;      // (an absent child adds nothing; its slot may hold anything)
+        DBG_T(2);
+        if (lane == 0) {
+            out_x[i] = x;
+            out_pri[i] = leaf_v;
+            out_pri_tag[i] = leaf_t;
+        }
+        // ---- zero the leaf, re-reduce the path: lane l holds the sibling of level l ----
+        const float sv32 = (float)sv;
+        const unsigned long long m2 = __ballot(st >= PFRL_TAG_F32);
+        const unsigned long long m3 = __ballot(st == PFRL_TAG_F64);
+        const int l2 = m2 ? __builtin_ctzll(m2) : L;    // first sibling that makes the sum f32 (or f64)
+        const int l3 = m3 ? __builtin_ctzll(m3) : L;    // first sibling that makes it f64
+        double c64 = 0.0, mine64 = 0.0;
+        float c32 = 0.0f, mine32 = 0.0f;
+        int j = 0;
+        for (; j < l2; ++j) {                 // Python floats: f64 adds
+            c64 = __dadd_rn(c64, readlane_f64(sv, j));
+            if (lane == j + 1) mine64 = c64;
+        }
+        if (l2 < l3) {
+            c32 = (float)c64;
+            for (; j < l3; ++j) {             // np.float32 result type: f32 adds of the f32 operands
+                c32 = __fadd_rn(c32, readlane_f32(sv32, j));
+                if (lane == j + 1) mine32 = c32;
+            }
+            c64 = (double)c32;
+        }
+        for (; j < L; ++j) {                  // np.float64 result type
+            c64 = __dadd_rn(c64, readlane_f64(sv, j));
+            if (lane == j + 1) mine64 = c64;
+        }
+        DBG_T(3);
+        // ---- lane l owns the node of level l: top heap + HBM ----
+        if (lane <= L) {
+            const int l = lane;
+            double v;
+            int tg;
+            if (l == 0) {
+                v = 0.0;
+                tg = PFRL_TAG_PY;
+            } else {
+                tg = l > l3 ? PFRL_TAG_F64 : (l > l2 ? PFRL_TAG_F32 : PFRL_TAG_PY);
+                v = tg == PFRL_TAG_F32 ? (double)mine32 : mine64;
+            }
+            if (l >= r) {
+                const int hh = h >> (l - r);
+                top_v[hh] = v;
+                top_t[hh] = (uint8_t)tg;
+            }
+            const int64_t gi = my_off + (((x - my_org) >> l) & my_mask);
+            T.sum_val[gi] = v;
+            T.sum_tag[gi] = (uint8_t)tg;
+        }
+        __syncthreads();          // stores visible to the next draw's fan-out, heaps settled
+        DBG_T(4);
+    }
+#undef NODE_AT
+    if (lane == 0) {
+        *out_total = s_total_v;
+        *out_total_tag = (uint8_t)s_total_t;
+    }
+    __threadfence_block();
+    __syncthreads();
+    const TV total = mk_tv(s_total_v, s_total_t);
+    double local_min = __builtin_huge_val();
+    for (int64_t i = lane; i < B; i += 64) {
+        TV pr = tv_add(mk_tv(0.0, PFRL_TAG_PY), tv_div(mk_tv(out_pri[i], out_pri_tag[i]), total));
+        out_prob[i] = pr.v;
+        local_min = fmin(local_min, pr.v);
+    }
+    for (int off = 32; off > 0; off >>= 1) local_min = fmin(local_min, __shfl_xor(local_min, off));
+    double min_prob = tv_div(mk_tv(s_min_v, s_min_t), total).v;
+    if (lane == 0) *out_min_prob = min_prob;
+    if (normalize == 1) min_prob = local_min;
+    for (int64_t i = lane; i < B; i += 64) {
+        const double p = out_prob[i];
+        double w;
+        if (normalize)
+            w = pow(p / min_prob, -beta);
+        else
+            w = pow((double)T.length * p, -beta);
+        out_weight[i] = (float)w;
+        if (out_slot) out_slot[i] = (int32_t)(out_x[i] % slot_mod);
+    }
+}
+
 }  // namespace
 
 #ifdef PFRL_TREE_DEBUG
@@ -642,24 +1023,36 @@ extern "C" int pfrl_tree_sample(const pfrl_tree_t *tree, int64_t B, const double
     if (B == 0) return 0;
     const int L = tree->log2_size;
     const int r = L < kBotLevels ? L : kBotLevels;
-    static int use_lds = -1;
-    if (use_lds < 0) {
-        const char *e = getenv("PFRL_TREE_SAMPLE_LDS");
-        use_lds = (e && e[0] == '0') ? 0 : 1;
+    // 2 = path-parallel rounds (default), 1 = the round-2 LDS sampler, 0 = global-memory descent
+    static int mode = -1;
+    if (mode < 0) {
+        const char *e = getenv("PFRL_TREE_SAMPLE");
+        const char *old = getenv("PFRL_TREE_SAMPLE_LDS");
+        mode = 2;
+        if (e && e[0] == 'l') mode = 1;
+        if ((e && e[0] == 'g') || (old && old[0] == '0')) mode = 0;
     }
-    if (use_lds && L - r + 1 <= kMaxTopLog2) {
+    if (mode && L - r + 1 <= kMaxTopLog2) {
         const size_t top_n = (size_t)1 << (L - r + 1), bot_n = (size_t)1 << (r + 1);
         const size_t lds = (top_n + bot_n) * (sizeof(double) + 1);
         static bool attr_set = false;
         if (!attr_set) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_tree_sample_lds),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_tree_sample_lean),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
             attr_set = true;
         }
-        hipLaunchKernelGGL(k_tree_sample_lds, dim3(1), dim3(64), lds, (hipStream_t)stream, *tree, B,
-                           u01, out_x, out_pri, out_pri_tag, out_prob, out_weight, out_total,
-                           out_total_tag, out_min_prob, normalize, beta,
-                           slot_mod > 0 ? slot_mod : 1, out_slot);
+        if (mode == 2)
+            hipLaunchKernelGGL(k_tree_sample_lean, dim3(1), dim3(64), lds, (hipStream_t)stream,
+                               *tree, B, u01, out_x, out_pri, out_pri_tag, out_prob, out_weight,
+                               out_total, out_total_tag, out_min_prob, normalize, beta,
+                               slot_mod > 0 ? slot_mod : 1, out_slot);
+        else
+            hipLaunchKernelGGL(k_tree_sample_lds, dim3(1), dim3(64), lds, (hipStream_t)stream, *tree,
+                               B, u01, out_x, out_pri, out_pri_tag, out_prob, out_weight, out_total,
+                               out_total_tag, out_min_prob, normalize, beta,
+                               slot_mod > 0 ? slot_mod : 1, out_slot);
     } else {
         hipLaunchKernelGGL(k_tree_sample, dim3(1), dim3(64), 0, (hipStream_t)stream, *tree, B, u01,
                            out_x, out_pri, out_pri_tag, out_prob, out_weight, out_total,
@@ -690,6 +1083,32 @@ extern "C" int pfrl_tree_update_errors_f32(const pfrl_tree_t *tree, int64_t B, c
     int threads = (int)((B + 63) / 64 * 64);
     hipLaunchKernelGGL(k_tree_update_errors, dim3(1), dim3(threads), 0, (hipStream_t)stream, *tree,
                        B, x, err, c, dedupe);
+    PFRL_LAUNCH_CHECK();
+}
+
+extern "C" int pfrl_tree_update_errors_write_f32(
+    const pfrl_tree_t *tree, int64_t B, const int64_t *x, const float *err, int has_min,
+    float error_min, double pri_at_min, int has_max, float error_max, double pri_at_max, double eps,
+    double alpha, int dedupe, int pow_mode, int64_t n, const int64_t *wx, const double *wval,
+    const uint8_t *wtag, const uint8_t *wuse_maxp, void *stream) {
+    PFRL_CHECK_ARG(tree && B >= 0 && n >= 0 && B + n <= kMaxBatch,
+                   "pfrl_tree_update_errors_write_f32: B + n must be <= 1024");
+    PFRL_CHECK_ARG(pow_mode >= 0 && pow_mode <= 2, "pfrl_tree_update_errors_write_f32: bad pow_mode");
+    PFRL_CHECK_ARG(n == 0 || (wx && wval && wtag), "pfrl_tree_update_errors_write_f32: null write list");
+    if (B + n <= 0) return 0;
+    ErrCfg c;
+    c.has_min = has_min;
+    c.has_max = has_max;
+    c.error_min = error_min;
+    c.error_max = error_max;
+    c.pri_at_min = pri_at_min;
+    c.pri_at_max = pri_at_max;
+    c.eps = eps;
+    c.alpha = alpha;
+    c.pow_mode = pow_mode;
+    int threads = (int)((B + n + 63) / 64 * 64);
+    hipLaunchKernelGGL(k_tree_update_errors_write, dim3(1), dim3(threads), 0, (hipStream_t)stream,
+                       *tree, B, x, err, c, dedupe, n, wx, wval, wtag, wuse_maxp);
     PFRL_LAUNCH_CHECK();
 }
 

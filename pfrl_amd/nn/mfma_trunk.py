@@ -34,7 +34,15 @@ _MAX_BATCH = int(os.environ.get("PFRL_MFMA_TRUNK_MAX_BATCH", "0"))
 SMALL_LINEAR_MAX_OUT = 16
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream():
+    # (torch.cuda.current_stream() builds a Stream object through several Python layers, ~7 us a
+    # call and a dozen calls per update; the raw handle of the current device's current stream
+    # is one C call)
+    if _raw_stream is not None:
+        return ctypes.c_void_p(_raw_stream(torch.cuda.current_device()))
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 

@@ -52,8 +52,10 @@ class StagingRing:
 
             self._copy = _native.lib().pfrl_h2d_async
             self._vp = ctypes.c_void_p
-        rc = self._copy(self._dev_ptr[i], self._host_ptr[i], total,
-                        self._vp(torch.cuda.current_stream(self.device).cuda_stream))
+        raw = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+        st = raw(self.device.index if self.device.index is not None else torch.cuda.current_device()) \
+            if raw is not None else torch.cuda.current_stream(self.device).cuda_stream
+        rc = self._copy(self._dev_ptr[i], self._host_ptr[i], total, self._vp(st))
         if rc != 0:
             raise RuntimeError("pfrl_h2d_async failed (%d)" % rc)
         self._events[i].record()

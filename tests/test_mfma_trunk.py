@@ -152,7 +152,10 @@ def test_nhwc_route_of_the_hidden_layer_matches_torch_and_sees_raw_pointer_updat
     with torch.no_grad():
         moved = float((dut(xg) - q).abs().max())
         assert moved > 1e-3                          # the step really changed the function
-        _close(dut(xg), ref(x), 2e-4)                # and the trunk computes with the NEW weights
+        # and the trunk computes with the NEW weights.  (Tolerance: the two sides step on gradients
+        # that agree to 2e-3 above, and a centred RMSprop step is lr * g / sqrt(var): the gradient
+        # difference reaches the outputs undamped -- 2.1e-4 measured, 1e-3 if the copy were stale.)
+        _close(dut(xg), ref(x), 5e-4)
 
 
 @gpu
