@@ -92,13 +92,22 @@ class DistributionalDiscreteActionValue(ActionValue):
         assert z_values.ndim == 1
         assert q_dist.shape[2] == int(z_values.shape[0])
         self.z_values = z_values
-        self.q_values = torch.matmul(q_dist, self.z_values)
         self.q_dist = q_dist
+        self._q_values = None
         self.n_actions = q_dist.shape[1]
         self.q_values_formatter = q_values_formatter
         self.device = q_dist.device
         self._greedy = None
         self._max = None
+
+    @property
+    def q_values(self):
+        """E[Z] per action (reference :113: computed in the constructor; here on first use -- the
+        fused C51 loss reads the distributions only, and three matrix-vector launches per update
+        were spent on expectations nobody looked at)."""
+        if self._q_values is None:
+            self._q_values = torch.matmul(self.q_dist, self.z_values)
+        return self._q_values
 
     @property
     def greedy_actions(self):

@@ -257,14 +257,19 @@ class DQN(agent.AttributeSavingMixin, agent.BatchAgent):
     _side_needs_main = True
 
     # -- learning -------------------------------------------------------------
-    def update(self, experiences, errors_out=None):
-        """One minibatch update (reference :316-365)."""
+    def update(self, experiences, errors_out=None, _gathered=None):
+        """One minibatch update (reference :316-365).  ``_gathered``: the result of
+        ``batch_experiences`` when the caller has launched the gather already."""
+        # (a held-back backward + step of the previous minibatch goes first: ahead of the wait
+        # for this minibatch's gather, which it does not depend on)
+        self._flush_backward()
         if isinstance(experiences, DeviceExperienceBatch):
             has_weight = experiences.has_weight
         else:
             has_weight = "weight" in experiences[0][0]
-        exp_batch = batch_experiences(experiences, device=self.device, phi=self.phi,
-                                      gamma=self.gamma, batch_states=self.batch_states)
+        exp_batch = _gathered if _gathered is not None else batch_experiences(
+            experiences, device=self.device, phi=self.phi, gamma=self.gamma,
+            batch_states=self.batch_states)
         if self._replay_stream is not None and isinstance(experiences, DeviceExperienceBatch):
             # the minibatch was sampled and gathered on the replay stream
             torch.cuda.current_stream(self.device).wait_event(experiences.store.ready_event)
@@ -750,6 +755,8 @@ class DQN(agent.AttributeSavingMixin, agent.BatchAgent):
         if self.step_fused_gather and getattr(rbuf, "supports_lookahead", False):
             return self._batch_observe_train_fused(batch_obs, batch_reward, batch_done,
                                                    batch_reset)
+        if self._per_lookahead_ok():
+            return self._batch_observe_train_per(batch_obs, batch_reward, batch_done, batch_reset)
         updater = self.replay_updater
         for i in range(len(batch_obs)):
             self.t += 1
@@ -762,6 +769,68 @@ class DQN(agent.AttributeSavingMixin, agent.BatchAgent):
             self.train_prev_recurrent_states = None
             self.train_recurrent_states = self._restart_ended(
                 self.train_recurrent_states, batch_done, batch_reset)
+
+    def _per_lookahead_ok(self):
+        rbuf, up = self.replay_buffer, self.replay_updater
+        return (os.environ.get("PFRL_PER_LOOKAHEAD", "1") != "0" and self._replay_stream is not None
+                and self.use_graphs and not self.recurrent and hasattr(rbuf, "sample_prepare")
+                and getattr(rbuf, "store", None) is not None and not up.episodic_update
+                and up.n_times_update == 1 and up.update_func == self.update)
+
+    def _batch_observe_train_per(self, batch_obs, batch_reward, batch_done, batch_reset):
+        """The loop of _batch_observe_train (reference :516-549) for a prioritized device buffer,
+        with the host one update point ahead of the device.  What the next forward pass waits for
+        is a chain on the replay stream -- priorities of minibatch k, pending appends, B dependent
+        draws, gather -- and only its first link needs minibatch k's TD errors.  Launched in
+        program order, that chain started 80 us after the forward graph had ended: the host was
+        still walking through the appends and the sample's preparation (tools/pipeline_events.py).
+        Here, once sample k is launched, the host first appends the transitions up to update
+        point k + 1 and prepares that sample (NumPy draws, staging transfer, table rows: nothing
+        the update changes), THEN launches update k; what is left for afterwards is two launches.
+        Appends, draws from the NumPy stream, target syncs and updates keep the reference's order;
+        the look-ahead stops where that could not be guaranteed (a target sync or a tree frame
+        change ahead: both must see update k done)."""
+        rbuf, up = self.replay_buffer, self.replay_updater
+        tree = rbuf.memory.tree
+        n = len(batch_obs)
+        B = up.batchsize
+        ahead = int(getattr(rbuf, "num_steps", 1)) + 1      # entries one transition can append
+
+        def due():      # ReplayUpdater.update_if_necessary
+            return len(rbuf) >= up.replay_start_size and self.t % up.update_interval == 0
+
+        def advance(i):
+            self.t += 1
+            self._cumulative_steps += 1
+            if self.t % self.target_update_interval == 0:
+                self.sync_target_network()
+            self._append_transition(i, batch_obs, batch_reward, batch_done, batch_reset)
+
+        i = 0
+        finish_next = None          # the prepared sample of the update point the loop stands on
+        while True:
+            if finish_next is None:
+                if i >= n:
+                    break
+                advance(i)
+                i += 1
+                if not due():
+                    continue
+                finish_next = rbuf.sample_prepare(B)
+            experiences = finish_next()
+            finish_next = None
+            # the gather goes onto the replay stream right behind the draws, ahead of the rows
+            # the look-ahead is about to ship
+            gathered = batch_experiences(experiences, device=self.device, phi=self.phi,
+                                         gamma=self.gamma, batch_states=self.batch_states)
+            while (i < n and (self.t + 1) % self.target_update_interval != 0
+                   and tree.next_appends_keep_frame(ahead)):
+                advance(i)
+                i += 1
+                if due():
+                    finish_next = rbuf.sample_prepare(B)
+                    break
+            self.update(experiences, _gathered=gathered)
 
     def _batch_observe_train_fused(self, batch_obs, batch_reward, batch_done, batch_reset):
         """Same schedule as the loop above (reference :516-549), reorganised

@@ -230,21 +230,42 @@ class PrioritizedBuffer:
         self.frame.popleft()
         return self.data.popleft()
 
-    def sample_device(self, n, u01=None, normalize=1, beta=0.0, slot_mod=0, co_stage=None):
+    def next_appends_keep_frame(self, m=1):
+        """True when the next ``m`` calls of ``append`` (each with the ``popleft`` a full buffer
+        does first) leave the tree frame as it is, i.e. none of them flushes."""
+        f = self.frame
+        if f.length <= m + 1:
+            return False
+        if f.next_x + m > f.base + f.size:              # (prioritized.py:207-223: doubling)
+            return False
+        if self.capacity is not None and len(self) + m > self.capacity:
+            if f.head + m >= f.base + f.size // 2:      # (:225-242: halving / re-rooting)
+                return False
+        return True
+
+    def sample_device(self, n, u01=None, normalize=1, beta=0.0, slot_mod=0, co_stage=None,
+                      split=False):
         """Device-side ``sample``: returns a dict of device tensors (x, pri,
         pri_tag, prob, weight, total, total_tag, min_prob[, slot]).  ``u01``
         defaults to the draws np.random.uniform would consume (same stream).
         ``co_stage`` = (arrays, launch) of another object (the replay store's new rows) whose
         control traffic rides in the same host->device copy, or a callable returning that pair
-        (or None), called after the preconditions hold."""
-        assert not self.wait_priority_after_sampling or not self.flag_wait_priority
+        (or None), called after the preconditions hold.
+
+        ``split=True``: only what does not depend on the PREVIOUS sample's priorities is done
+        now -- the host side, the one staging transfer, the other object's launches -- and
+        ``(out, finish)`` is returned; ``finish()`` launches the held-back priority update fused
+        with the pending leaf writes and the draws.  A caller that knows the next sample point
+        ahead of time (DQN._batch_observe_train_per) prepares it before it launches the update
+        that produces those priorities, so that only two launches are left for afterwards."""
+        assert split or not self.wait_priority_after_sampling or not self.flag_wait_priority
         assert len(self) >= n
         if callable(co_stage):
             # taken only now: take_pending() clears the other object's pending rows, which must
             # not be lost to a failed assert above
             co_stage = co_stage()
         pending = self.take_pending()
-        if pending is None:
+        if pending is None and (self._pend_x or not split):
             self.flush()            # (nothing pending, or more than one launch's worth)
         if u01 is None:
             u01 = np.random.random_sample(n)
@@ -288,13 +309,23 @@ class PrioritizedBuffer:
             views = self._stage.upload(arrays)
             if co_stage is not None:
                 co_stage[1](*views[1 + n_t:1 + n_t + n_c])
-            if pending is not None:
-                pending[1](*views[1:1 + n_t])
-            ops.tree_sample(self._sync_desc(), views[0], out, normalize, beta, slot_mod)
-        self._sampled_x = out["x"]
-        self._n_sampled = n
-        self.flag_wait_priority = True
-        return out
+
+        def finish():
+            assert not self.wait_priority_after_sampling or not self.flag_wait_priority
+            with on_stream(self.side_stream):
+                if pending is not None:
+                    pending[1](*views[1:1 + n_t])
+                elif self._deferred is not None:
+                    self._launch_deferred(self._sync_desc())
+                ops.tree_sample(self._sync_desc(), views[0], out, normalize, beta, slot_mod)
+            self._sampled_x = out["x"]
+            self._n_sampled = n
+            self.flag_wait_priority = True
+            return out
+
+        if split:
+            return out, finish
+        return finish()
 
     def sample(self, n, uniform_ratio=0):
         """prioritized.py:86-105 (host-visible results; one D2H sync)."""

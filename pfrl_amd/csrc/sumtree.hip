@@ -994,6 +994,286 @@ __global__ __launch_bounds__(64) void k_tree_sample_lean(
     }
 }
 
+
+// ---------------------------------------------------------------------------
+// Lean sampler with a prefetching second wave.  What is left on the chain of
+// k_tree_sample_lean is the fetch of the 1023-node subtree under the level-9
+// node a draw reaches (1.7 us of 5.5, almost all of it memory latency), and it
+// cannot start before the draw's own top descent has finished.  It can be
+// PREDICTED, though: draw i + 1 starts from root_i * u, and root_i differs from
+// the root before draw i by one leaf out of a million, so a descent of the top
+// heap as it stands while draw i is still in flight ends in the right level-9
+// node almost always.  Wave 1 does that -- predicts draw i + 1 while wave 0 works
+// on draw i, and loads that subtree into the other of two LDS buffers.  Wave 0
+// descends the top heap exactly, as before; if it arrives where wave 1 predicted
+// AND no earlier draw of this launch went through that subtree (its zeroed leaf
+// would be missing from a fetch issued before or beside the write-back), the
+// subtree is already in LDS; otherwise it fetches it itself, exactly as
+// k_tree_sample_lean does.  The prediction decides where bytes are fetched from
+// early, never what is computed: results are those of k_tree_sample bit for bit.
+// One workgroup barrier per draw (both waves, top of the loop).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void wave_lds_fence() {
+    // LDS traffic of ONE wave executes in program order; this only keeps the compiler from
+    // moving accesses across (no workgroup barrier: the other wave is elsewhere)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// the 2^(r+1) - 1 nodes under the level-r node whose first leaf is x0 -> an LDS heap (bv, bt);
+// lane l of the calling wave holds the addressing constants of level l
+__device__ __forceinline__ void fetch_subtree(const pfrl_tree_t &T, int64_t x0, int r, int lane,
+                                              int64_t my_off, int64_t my_org, int64_t my_mask,
+                                              double *bv, uint8_t *bt) {
+    double v[8 + 4 + 2 + kBotLevels - 2];
+    uint8_t tg[8 + 4 + 2 + kBotLevels - 2];
+    int n_ld = 0;
+#pragma unroll
+    for (int l = 0; l <= kBotLevels; ++l) {
+        const int lr = l <= r ? l : r;               // clamp (uniform)
+        const int cnt = l <= r ? (1 << (r - l)) : 0;
+        const int64_t org = readlane_i64(my_org, lr);
+        const int64_t off = readlane_i64(my_off, lr), mask = readlane_i64(my_mask, lr);
+        const int64_t q0 = (x0 - org) >> lr;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            if (k * 64 < (1 << (kBotLevels - l))) {
+                const int j = k * 64 + lane;
+                const int64_t gi = off + ((q0 + (j < cnt ? j : 0)) & mask);
+                v[n_ld] = T.sum_val[gi];
+                tg[n_ld] = T.sum_tag[gi];
+                ++n_ld;
+            }
+        }
+    }
+    n_ld = 0;
+#pragma unroll
+    for (int l = 0; l <= kBotLevels; ++l) {
+        const int cnt = l <= r ? (1 << (r - l)) : 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            if (k * 64 < (1 << (kBotLevels - l))) {
+                const int j = k * 64 + lane;
+                if (j < cnt) {
+                    bv[cnt + j] = v[n_ld];   // heap index of (level l, j)
+                    bt[cnt + j] = tg[n_ld];
+                }
+                ++n_ld;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(128) void k_tree_sample_lean2(
+    pfrl_tree_t T, int64_t B, const double *__restrict__ u01, int64_t *__restrict__ out_x,
+    double *__restrict__ out_pri, uint8_t *__restrict__ out_pri_tag, double *__restrict__ out_prob,
+    float *__restrict__ out_weight, double *__restrict__ out_total,
+    uint8_t *__restrict__ out_total_tag, double *__restrict__ out_min_prob, int normalize,
+    double beta, int64_t slot_mod, int32_t *__restrict__ out_slot) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int L = T.log2_size;
+    const int r = L < kBotLevels ? L : kBotLevels;
+    const int top_levels = L - r + 1;           // levels L..r  -> depths 0..top_levels-1
+    const int top_n = 1 << top_levels;          // heap indices 1..top_n-1
+    const int bot_n = 1 << (r + 1);             // heap indices 1..bot_n-1 (levels r..0)
+    double *top_v = reinterpret_cast<double *>(smem);
+    double *bot_v2 = top_v + top_n;             // two subtree buffers
+    uint8_t *top_t = reinterpret_cast<uint8_t *>(bot_v2 + 2 * bot_n);
+    uint8_t *bot_t2 = top_t + top_n;
+    __shared__ double s_total_v, s_min_v;
+    __shared__ int s_total_t, s_min_t;
+    __shared__ int s_pred_h[2];
+    __shared__ int64_t lv_off[PFRL_MAX_LEVELS], lv_org[PFRL_MAX_LEVELS], lv_mask[PFRL_MAX_LEVELS];
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    if (tid <= L) {
+        const int sh = T.log2_smax - tid;
+        lv_off[tid] = T.level_off[tid];
+        lv_org[tid] = T.origin[tid];
+        lv_mask[tid] = (sh > 0 ? ((int64_t)1 << sh) : 1) - 1;
+    }
+    if (tid < 2) s_pred_h[tid] = -1;
+    __syncthreads();
+#define NODE_AT(l, x) (lv_off[l] + ((((x) - lv_org[l]) >> (l)) & lv_mask[l]))
+    const int myl = lane <= L ? lane : 0;
+    const int64_t my_off = lv_off[myl], my_org = lv_org[myl], my_mask = lv_mask[myl];
+    // stage the top of the sum tree, both waves (loads batched 16 deep per thread)
+    for (int h0 = 1; h0 < top_n; h0 += 128 * 16) {
+        double v[16];
+        uint8_t tg[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int h = h0 + k * 128 + tid;
+            if (h < top_n) {
+                const int d = 31 - __clz(h);
+                const int l = L - d;
+                const int64_t gi = NODE_AT(l, T.base + ((int64_t)(h - (1 << d)) << l));
+                v[k] = T.sum_val[gi];
+                tg[k] = T.sum_tag[gi];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int h = h0 + k * 128 + tid;
+            if (h < top_n) {
+                top_v[h] = v[k];
+                top_t[h] = tg[k];
+            }
+        }
+    }
+    if (tid == 0) {
+        const int64_t iroot = NODE_AT(L, T.base);
+        s_total_v = T.sum_val[iroot];
+        s_total_t = T.sum_tag[iroot];
+        s_min_v = T.min_val[iroot];
+        s_min_t = T.min_tag[iroot];
+    }
+#undef NODE_AT
+    double my_u = 0.0;
+    int myh = -1;       // wave 0, lane j: the level-r node draw j went through (first 64 draws)
+    if (wave == 1) my_u = lane < B ? u01[lane] : 0.0;      // the prefetcher looks at draws 1..63 only
+    for (int64_t i = 0; i < B; ++i) {
+        __syncthreads();        // draw i - 1 is complete, its prefetch too: the only workgroup barrier
+        if (wave == 0) {
+            if ((i & 63) == 0) my_u = i + lane < B ? u01[i + lane] : 0.0;
+            const double u = readlane_f64(my_u, (int)(i & 63));
+            // ---- top heap: L - r levels ----
+            const double rootv = top_v[1];
+            // np.random.uniform(0.0, root) = 0.0 + (root - 0.0) * u
+            double p64 = __dadd_rn(0.0, __dmul_rn(rootv, u));
+            float p32 = (float)p64;
+            int pt = PFRL_TAG_PY;
+            const int h = find_down(top_v, top_t, 1, L - r, p64, p32, pt);
+            const int64_t x0 = T.base + ((int64_t)(h - (top_n >> 1)) << r);
+            double *bot_v = bot_v2 + (i & 1) * bot_n;
+            uint8_t *bot_t = bot_t2 + (i & 1) * bot_n;
+            bool prefetched = false;
+            if (i > 0 && i < 64) {
+                const bool seen = __ballot(lane < (int)i && myh == h) != 0;
+                prefetched = !seen && s_pred_h[i & 1] == h;
+            }
+            if (lane == (int)(i & 63)) myh = h;
+            if (!prefetched) {
+                fetch_subtree(T, x0, r, lane, my_off, my_org, my_mask, bot_v, bot_t);
+                wave_lds_fence();
+            }
+            // ---- bottom heap: r levels ----
+            const int g = find_down(bot_v, bot_t, 1, r, p64, p32, pt);
+            const int64_t x = x0 + (g - (bot_n >> 1));
+            const double leaf_v = bot_v[g];
+            const uint8_t leaf_t = bot_t[g];
+            // ---- the siblings of the path: lane l reads the one of level l ----
+            int st = PFRL_TAG_ABSENT;
+            double sv = 0.0;
+            if (lane < L) {
+                const bool below = lane < r;
+                const int node = below ? (g >> lane) : (h >> (lane - r));
+                const double *sib_v = below ? bot_v : top_v;
+                const uint8_t *sib_t = below ? bot_t : top_t;
+                st = sib_t[node ^ 1];
+                sv = sib_v[node ^ 1];
+            }
+            if (st == PFRL_TAG_ABSENT) sv = 0.0;
+            if (lane == 0) {
+                out_x[i] = x;
+                out_pri[i] = leaf_v;
+                out_pri_tag[i] = leaf_t;
+            }
+            // ---- zero the leaf, re-reduce the path ----
+            const float sv32 = (float)sv;
+            const unsigned long long m2 = __ballot(st >= PFRL_TAG_F32);
+            const unsigned long long m3 = __ballot(st == PFRL_TAG_F64);
+            const int l2 = m2 ? __builtin_ctzll(m2) : L;
+            const int l3 = m3 ? __builtin_ctzll(m3) : L;
+            double c64 = 0.0, mine64 = 0.0;
+            float c32 = 0.0f, mine32 = 0.0f;
+            int j = 0;
+            for (; j < l2; ++j) {
+                c64 = __dadd_rn(c64, readlane_f64(sv, j));
+                if (lane == j + 1) mine64 = c64;
+            }
+            if (l2 < l3) {
+                c32 = (float)c64;
+                for (; j < l3; ++j) {
+                    c32 = __fadd_rn(c32, readlane_f32(sv32, j));
+                    if (lane == j + 1) mine32 = c32;
+                }
+                c64 = (double)c32;
+            }
+            for (; j < L; ++j) {
+                c64 = __dadd_rn(c64, readlane_f64(sv, j));
+                if (lane == j + 1) mine64 = c64;
+            }
+            wave_lds_fence();           // (sibling reads of the top heap before its nodes are rewritten)
+            // ---- lane l owns the node of level l: top heap + HBM ----
+            if (lane <= L) {
+                const int l = lane;
+                double v;
+                int tg;
+                if (l == 0) {
+                    v = 0.0;
+                    tg = PFRL_TAG_PY;
+                } else {
+                    tg = l > l3 ? PFRL_TAG_F64 : (l > l2 ? PFRL_TAG_F32 : PFRL_TAG_PY);
+                    v = tg == PFRL_TAG_F32 ? (double)mine32 : mine64;
+                }
+                if (l >= r) {
+                    const int hh = h >> (l - r);
+                    top_v[hh] = v;
+                    top_t[hh] = (uint8_t)tg;
+                }
+                const int64_t gi = my_off + (((x - my_org) >> l) & my_mask);
+                T.sum_val[gi] = v;
+                T.sum_tag[gi] = (uint8_t)tg;
+            }
+        } else if (i + 1 < B && i + 1 < 64) {
+            // ---- wave 1: where will draw i + 1 go?  (the top heap may change under this descent:
+            // any outcome is a valid level-r node, and wave 0 checks it) ----
+            const double u = readlane_f64(my_u, (int)(i + 1));
+            const double rootv = top_v[1];
+            double p64 = __dadd_rn(0.0, __dmul_rn(rootv, u));
+            float p32 = (float)p64;
+            int pt = PFRL_TAG_PY;
+            const int hp = find_down(top_v, top_t, 1, L - r, p64, p32, pt);
+            const int64_t x0 = T.base + ((int64_t)(hp - (top_n >> 1)) << r);
+            fetch_subtree(T, x0, r, lane, my_off, my_org, my_mask, bot_v2 + ((i + 1) & 1) * bot_n,
+                          bot_t2 + ((i + 1) & 1) * bot_n);
+            if (lane == 0) s_pred_h[(i + 1) & 1] = hp;
+        }
+    }
+    __threadfence_block();
+    __syncthreads();
+    if (wave == 0) {
+        if (lane == 0) {
+            *out_total = s_total_v;
+            *out_total_tag = (uint8_t)s_total_t;
+        }
+        const TV total = mk_tv(s_total_v, s_total_t);
+        double local_min = __builtin_huge_val();
+        for (int64_t i = lane; i < B; i += 64) {
+            TV pr = tv_add(mk_tv(0.0, PFRL_TAG_PY), tv_div(mk_tv(out_pri[i], out_pri_tag[i]), total));
+            out_prob[i] = pr.v;
+            local_min = fmin(local_min, pr.v);
+        }
+        for (int off = 32; off > 0; off >>= 1) local_min = fmin(local_min, __shfl_xor(local_min, off));
+        double min_prob = tv_div(mk_tv(s_min_v, s_min_t), total).v;
+        if (lane == 0) *out_min_prob = min_prob;
+        if (normalize == 1) min_prob = local_min;
+        for (int64_t i = lane; i < B; i += 64) {
+            const double p = out_prob[i];
+            double w;
+            if (normalize)
+                w = pow(p / min_prob, -beta);
+            else
+                w = pow((double)T.length * p, -beta);
+            out_weight[i] = (float)w;
+            if (out_slot) out_slot[i] = (int32_t)(out_x[i] % slot_mod);
+        }
+    }
+}
+
 }  // namespace
 
 #ifdef PFRL_TREE_DEBUG
@@ -1023,27 +1303,37 @@ extern "C" int pfrl_tree_sample(const pfrl_tree_t *tree, int64_t B, const double
     if (B == 0) return 0;
     const int L = tree->log2_size;
     const int r = L < kBotLevels ? L : kBotLevels;
-    // 2 = path-parallel rounds (default), 1 = the round-2 LDS sampler, 0 = global-memory descent
+    // PFRL_TREE_SAMPLE: "prefetch" (default) = lean sampler + prefetching wave, "lean" = without it,
+    // "lds" = the round-2 sampler, "global" = global-memory descent
     static int mode = -1;
     if (mode < 0) {
         const char *e = getenv("PFRL_TREE_SAMPLE");
         const char *old = getenv("PFRL_TREE_SAMPLE_LDS");
-        mode = 2;
-        if (e && e[0] == 'l') mode = 1;
+        mode = 3;
+        if (e && e[0] == 'l' && e[1] == 'e') mode = 2;
+        if (e && e[0] == 'l' && e[1] == 'd') mode = 1;
         if ((e && e[0] == 'g') || (old && old[0] == '0')) mode = 0;
     }
     if (mode && L - r + 1 <= kMaxTopLog2) {
         const size_t top_n = (size_t)1 << (L - r + 1), bot_n = (size_t)1 << (r + 1);
         const size_t lds = (top_n + bot_n) * (sizeof(double) + 1);
+        const size_t lds2 = (top_n + 2 * bot_n) * (sizeof(double) + 1);
         static bool attr_set = false;
         if (!attr_set) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_tree_sample_lds),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_tree_sample_lean),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_tree_sample_lean2),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024);
             attr_set = true;
         }
-        if (mode == 2)
+        if (mode == 3)
+            hipLaunchKernelGGL(k_tree_sample_lean2, dim3(1), dim3(128), lds2, (hipStream_t)stream,
+                               *tree, B, u01, out_x, out_pri, out_pri_tag, out_prob, out_weight,
+                               out_total, out_total_tag, out_min_prob, normalize, beta,
+                               slot_mod > 0 ? slot_mod : 1, out_slot);
+        else if (mode == 2)
             hipLaunchKernelGGL(k_tree_sample_lean, dim3(1), dim3(64), lds, (hipStream_t)stream,
                                *tree, B, u01, out_x, out_pri, out_pri_tag, out_prob, out_weight,
                                out_total, out_total_tag, out_min_prob, normalize, beta,

@@ -182,6 +182,28 @@ class PrioritizedReplayBuffer(ReplayBuffer, PriorityWeightError):
         return DeviceExperienceBatch(self.store, out["slot"], _LazySeqs(out["x"], n),
                                      weights_dev=out["weight"])
 
+    def sample_prepare(self, n):
+        """``sample(n)`` in two parts for a caller that reaches the sample point before the
+        previous minibatch's priorities exist (DQN._batch_observe_train_per): everything that
+        does not depend on them happens now (host side, NumPy draws, the staging transfer, the
+        store's new rows); the returned callable launches the rest and returns the batch."""
+        self._ensure_bound()
+        assert len(self.memory) >= n
+        assert self.store is not None
+        tree = self.memory.tree
+        out, finish = tree.sample_device(n, normalize=_NORMALIZE_CODE[self.normalize_by_max],
+                                         beta=self.beta, slot_mod=self.store.E,
+                                         co_stage=self.store.take_pending, split=True)
+        self.beta = min(1.0, self.beta + self.beta_add)
+
+        def finish_sample():
+            finish()
+            self._last_sample = out
+            return DeviceExperienceBatch(self.store, out["slot"], _LazySeqs(out["x"], n),
+                                         weights_dev=out["weight"])
+
+        return finish_sample
+
     def _native_state(self):
         tree = self.memory.tree
         tree.flush()

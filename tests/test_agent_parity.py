@@ -89,6 +89,22 @@ def _run(name, prioritized, num_steps, double, gpu, priority_pow="device", steps
         return exps
 
     rbuf.sample = spy_sample
+    if hasattr(rbuf, "sample_prepare"):
+        # prioritized device buffers: the agent prepares the next sample ahead of the update
+        # (DQN._batch_observe_train_per); the minibatch exists once the prepared sample is finished
+        orig_prepare = rbuf.sample_prepare
+
+        def spy_prepare(n):
+            finish = orig_prepare(n)
+
+            def finish_noted():
+                exps = finish()
+                note_sample(exps)
+                return exps
+
+            return finish_noted
+
+        rbuf.sample_prepare = spy_prepare
     if hasattr(rbuf, "lookahead_sample"):
         orig_look = rbuf.lookahead_sample
 

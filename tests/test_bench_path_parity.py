@@ -222,17 +222,23 @@ def test_rainbow_bench_path_tree_matches_oracle(priority_pow):
     orig_append = dev_pri.PrioritizedBuffer.append
     orig_sample = dev_pri.PrioritizedBuffer.sample_device
 
+    # The agent keeps the host one update point ahead of the device (DQN._batch_observe_train_per):
+    # the appends up to the next sample point and that sample's preparation are CALLED before the
+    # update that sets the previous minibatch's priorities is launched.  The oracle is fed in the
+    # reference's logical order: appends made while a sample is waiting for its priorities are
+    # replayed right after them, and a prepared sample is drawn when it is finished.
+    late_appends = []
+
     def spy_append(self, value, priority=None):
         assert priority is None
-        orc.append(value)
+        if self.flag_wait_priority:
+            late_appends.append(value)
+        else:
+            orc.append(value)
         counts["appends"] += 1
         return orig_append(self, value, priority)
 
-    def spy_sample(self, n, u01=None, normalize=1, beta=0.0, slot_mod=0, **kw):
-        assert u01 is None
-        u = np.random.random_sample(n)          # the draws np.random.uniform would consume
-        want = orc.sample(u)
-        out = orig_sample(self, n, u01=u, normalize=normalize, beta=beta, slot_mod=slot_mod, **kw)
+    def check_sample(self, out, want, beta):
         self._join()
         x = out["x"].cpu().numpy()
         np.testing.assert_array_equal(x - self.frame.head, want["indices"])
@@ -242,6 +248,25 @@ def test_rainbow_bench_path_tree_matches_oracle(priority_pow):
         np.testing.assert_allclose(out["weight"].cpu().numpy(), w, rtol=1e-5)
         counts["samples"] += 1
         pending["x"] = x
+
+    def spy_sample(self, n, u01=None, normalize=1, beta=0.0, slot_mod=0, **kw):
+        assert u01 is None
+        u = np.random.random_sample(n)          # the draws np.random.uniform would consume
+        if kw.get("split"):
+            out, finish = orig_sample(self, n, u01=u, normalize=normalize, beta=beta,
+                                      slot_mod=slot_mod, **kw)
+            counts["split"] = counts.get("split", 0) + 1
+
+            def finish_checked():
+                want = orc.sample(u)
+                r = finish()
+                check_sample(self, out, want, beta)
+                return r
+
+            return out, finish_checked
+        want = orc.sample(u)
+        out = orig_sample(self, n, u01=u, normalize=normalize, beta=beta, slot_mod=slot_mod, **kw)
+        check_sample(self, out, want, beta)
         return out
 
     dev_pri.PrioritizedBuffer.append = spy_append
@@ -254,9 +279,16 @@ def test_rainbow_bench_path_tree_matches_oracle(priority_pow):
                                                rbuf.alpha)
         orc.set_last_priority(v, t)
         orig_update(errors)
-        got, so = rbuf.memory.tree.root_stats(), orc.stats()
-        assert got[0] == so["sum"] and got[1] == so["min"] and got[2] == so["max_priority"], \
-            (counts, got, so)
+        tree = rbuf.memory.tree
+        if not late_appends:
+            # (with appends already recorded on the device side the root is not a state the
+            # reference ever shows; the next sample's indices and priorities check it instead)
+            got, so = tree.root_stats(), orc.stats()
+            assert got[0] == so["sum"] and got[1] == so["min"] and got[2] == so["max_priority"], \
+                (counts, got, so)
+        for value in late_appends:
+            orc.append(value)
+        del late_appends[:]
         counts["updates"] += 1
 
     rbuf.update_errors = spy_update

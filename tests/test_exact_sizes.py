@@ -186,16 +186,20 @@ def test_rainbow_configs2_at_capacity_1e6_tree_matches_oracle():
     orig_append = dev_pri.PrioritizedBuffer.append
     orig_sample = dev_pri.PrioritizedBuffer.sample_device
 
+    # (the host runs one update point ahead of the device, DQN._batch_observe_train_per: the oracle
+    # gets the calls in the reference's logical order -- see test_rainbow_bench_path_tree_matches_oracle)
+    late_appends = []
+
     def spy_append(self, value, priority=None):
-        orc.append(value)
+        if self.flag_wait_priority:
+            late_appends.append(value)
+        else:
+            orc.append(value)
         r = orig_append(self, value, priority)
         log2_seen.add(self.frame.log2_size)
         return r
 
-    def spy_sample(self, n, u01=None, normalize=1, beta=0.0, slot_mod=0, **kw):
-        u = np.random.random_sample(n)
-        want = orc.sample(u)
-        out = orig_sample(self, n, u01=u, normalize=normalize, beta=beta, slot_mod=slot_mod, **kw)
+    def check_sample(self, out, want, beta):
         if checking[0]:
             self._join()
             x = out["x"].cpu().numpy()
@@ -204,6 +208,23 @@ def test_rainbow_configs2_at_capacity_1e6_tree_matches_oracle():
             w = (want["probabilities"] / want["min_prob"]) ** (-beta)
             np.testing.assert_allclose(out["weight"].cpu().numpy(), w, rtol=1e-5)
             counts["samples"] += 1
+
+    def spy_sample(self, n, u01=None, normalize=1, beta=0.0, slot_mod=0, **kw):
+        u = np.random.random_sample(n)
+        if kw.get("split"):
+            out, finish = orig_sample(self, n, u01=u, normalize=normalize, beta=beta,
+                                      slot_mod=slot_mod, **kw)
+
+            def finish_checked():
+                want = orc.sample(u)
+                r = finish()
+                check_sample(self, out, want, beta)
+                return r
+
+            return out, finish_checked
+        want = orc.sample(u)
+        out = orig_sample(self, n, u01=u, normalize=normalize, beta=beta, slot_mod=slot_mod, **kw)
+        check_sample(self, out, want, beta)
         return out
 
     dev_pri.PrioritizedBuffer.append = spy_append
@@ -217,10 +238,14 @@ def test_rainbow_configs2_at_capacity_1e6_tree_matches_oracle():
         orc.set_last_priority(v, t)
         orig_update(errors)
         if checking[0]:
-            got, so = rbuf.memory.tree.root_stats(), orc.stats()
-            assert got[0] == so["sum"] and got[1] == so["min"] and got[2] == so["max_priority"], \
-                (counts, got, so)
+            if not late_appends:
+                got, so = rbuf.memory.tree.root_stats(), orc.stats()
+                assert got[0] == so["sum"] and got[1] == so["min"] and got[2] == so["max_priority"], \
+                    (counts, got, so)
             counts["updates"] += 1
+        for value in late_appends:
+            orc.append(value)
+        del late_appends[:]
 
     rbuf.update_errors = spy_update
     try:

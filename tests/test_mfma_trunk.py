@@ -154,7 +154,8 @@ def test_nhwc_route_of_the_hidden_layer_matches_torch_and_sees_raw_pointer_updat
         assert moved > 1e-3                          # the step really changed the function
         # and the trunk computes with the NEW weights.  (Tolerance: the two sides step on gradients
         # that agree to 2e-3 above, and a centred RMSprop step is lr * g / sqrt(var): the gradient
-        # difference reaches the outputs undamped -- 2.1e-4 measured, 1e-3 if the copy were stale.)
+        # difference reaches the outputs undamped -- 2.1e-4 measured; a stale copy would be off by the
+        # whole step, `moved` above.)
         _close(dut(xg), ref(x), 5e-4)
 
 
