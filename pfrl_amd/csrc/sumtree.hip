@@ -737,16 +737,32 @@ __device__ __forceinline__ bool find_level(double lv, int lt, double &p64, float
 }
 
 // n levels down an LDS heap from node h (children of node i: 2i, 2i + 1); returns the node reached.
+// Two levels per LDS round trip: the left child of h and the left children of both its children
+// are requested together.  While the position is np.float32 and none of the three is np.float64
+// (one test for the pair of levels) both levels are plain float compare / subtract / select;
+// anything else goes through find_level.
 __device__ __forceinline__ int find_down(const double *hv, const uint8_t *ht, int h, int n,
                                          double &p64, float &p32, int &pt) {
     int d = 0;
     for (; d + 1 < n; d += 2) {
         const double lv0 = hv[2 * h], lva = hv[4 * h], lvb = hv[4 * h + 2];
         const int lt0 = ht[2 * h], lta = ht[4 * h], ltb = ht[4 * h + 2];
-        const bool r0 = find_level(lv0, lt0, p64, p32, pt);
-        const double lv1 = r0 ? lvb : lva;
-        const int lt1 = r0 ? ltb : lta;
-        const bool r1 = find_level(lv1, lt1, p64, p32, pt);
+        bool r0, r1;
+        if (pt == PFRL_TAG_F32 && lt0 != PFRL_TAG_F64 && lta != PFRL_TAG_F64 && ltb != PFRL_TAG_F64) {
+            const float l0 = lt0 == PFRL_TAG_ABSENT ? 0.0f : (float)lv0;
+            r0 = !(p32 < l0);
+            const float s0 = __fsub_rn(p32, l0);
+            p32 = r0 ? s0 : p32;
+            const double lv1 = r0 ? lvb : lva;
+            const int lt1 = r0 ? ltb : lta;
+            const float l1 = lt1 == PFRL_TAG_ABSENT ? 0.0f : (float)lv1;
+            r1 = !(p32 < l1);
+            const float s1 = __fsub_rn(p32, l1);
+            p32 = r1 ? s1 : p32;
+        } else {
+            r0 = find_level(lv0, lt0, p64, p32, pt);
+            r1 = find_level(r0 ? lvb : lva, r0 ? ltb : lta, p64, p32, pt);
+        }
         h = 4 * h + (r0 ? 2 : 0) + (r1 ? 1 : 0);
     }
     if (d < n) {
