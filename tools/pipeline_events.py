@@ -11,13 +11,16 @@ import bench  # noqa: E402
 n_upd = 64
 if "--updates" in sys.argv:
     i = sys.argv.index("--updates"); n_upd = int(sys.argv[i + 1]); del sys.argv[i:i + 2]
-sys.argv = ["bench.py", "--no-cpu-baseline", "--capacity", "200000"] + sys.argv[1:]
+cap = 200000
+if "--capacity" in sys.argv:
+    i = sys.argv.index("--capacity"); cap = int(sys.argv[i + 1]); del sys.argv[i:i + 2]
+sys.argv = ["bench.py", "--no-cpu-baseline", "--capacity", str(cap)] + sys.argv[1:]
 args = bench.parse_args()
 dev = torch.device("cuda:0")
 agent, env, rbuf = bench.build_agent(args, dev, 0)
 N = args.num_envs
 obss = env.reset()
-obss = bench.prefill(agent, env, obss, N, 60000 if args.algo != "sac" else 20000)
+obss = bench.prefill(agent, env, obss, N, (cap if cap > 200000 else 60000) if args.algo != "sac" else 20000)
 for _ in range(6):
     obss = bench.one_step(agent, env, obss, N)
 torch.cuda.synchronize()
