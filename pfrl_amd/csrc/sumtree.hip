@@ -1037,13 +1037,14 @@ __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// the 2^(r+1) - 1 nodes under the level-r node whose first leaf is x0 -> an LDS heap (bv, bt);
-// lane l of the calling wave holds the addressing constants of level l
-__device__ __forceinline__ void fetch_subtree(const pfrl_tree_t &T, int64_t x0, int r, int lane,
+// the 2^(r+1) - 1 nodes under the level-r node whose first leaf is x0, in two halves: the loads
+// (kSubLoads values + tags per lane, all requested before anything waits) and the stores into an
+// LDS heap (bv, bt).  Lane l of the calling wave holds the addressing constants of level l.
+constexpr int kSubLoads = 8 + 4 + 2 + kBotLevels - 2;
+
+__device__ __forceinline__ void subtree_loads(const pfrl_tree_t &T, int64_t x0, int r, int lane,
                                               int64_t my_off, int64_t my_org, int64_t my_mask,
-                                              double *bv, uint8_t *bt) {
-    double v[8 + 4 + 2 + kBotLevels - 2];
-    uint8_t tg[8 + 4 + 2 + kBotLevels - 2];
+                                              double (&v)[kSubLoads], uint8_t (&tg)[kSubLoads]) {
     int n_ld = 0;
 #pragma unroll
     for (int l = 0; l <= kBotLevels; ++l) {
@@ -1063,7 +1064,11 @@ __device__ __forceinline__ void fetch_subtree(const pfrl_tree_t &T, int64_t x0, 
             }
         }
     }
-    n_ld = 0;
+}
+
+__device__ __forceinline__ void subtree_stores(int r, int lane, const double (&v)[kSubLoads],
+                                               const uint8_t (&tg)[kSubLoads], double *bv, uint8_t *bt) {
+    int n_ld = 0;
 #pragma unroll
     for (int l = 0; l <= kBotLevels; ++l) {
         const int cnt = l <= r ? (1 << (r - l)) : 0;
@@ -1079,6 +1084,23 @@ __device__ __forceinline__ void fetch_subtree(const pfrl_tree_t &T, int64_t x0, 
             }
         }
     }
+}
+
+__device__ __forceinline__ void fetch_subtree(const pfrl_tree_t &T, int64_t x0, int r, int lane,
+                                              int64_t my_off, int64_t my_org, int64_t my_mask,
+                                              double *bv, uint8_t *bt) {
+    double v[kSubLoads];
+    uint8_t tg[kSubLoads];
+    subtree_loads(T, x0, r, lane, my_off, my_org, my_mask, v, tg);
+    subtree_stores(r, lane, v, tg, bv, bt);
+}
+
+// the level-r node a draw with uniform u would reach on the top heap as it stands
+__device__ __forceinline__ int predict_level_r(const double *top_v, const uint8_t *top_t, int n, double u) {
+    double p64 = __dadd_rn(0.0, __dmul_rn(top_v[1], u));
+    float p32 = (float)p64;
+    int pt = PFRL_TAG_PY;
+    return find_down(top_v, top_t, 1, n, p64, p32, pt);
 }
 
 __global__ __launch_bounds__(128) void k_tree_sample_lean2(
@@ -1104,6 +1126,13 @@ __global__ __launch_bounds__(128) void k_tree_sample_lean2(
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
+#ifdef PFRL_TREE_PRIO
+    __builtin_amdgcn_s_setprio(3);
+#endif
+#ifdef PFRL_TREE_DEBUG
+    // phase clocks of wave 0 (tools/per_dbg2.py): [0] prologue, [1] the draws, [2] epilogue
+    unsigned long long t_dbg0 = wall_clock64(), t_dbg1 = 0, t_dbg2 = 0;
+#endif
     if (tid <= L) {
         const int sh = T.log2_smax - tid;
         lv_off[tid] = T.level_off[tid];
@@ -1121,14 +1150,15 @@ __global__ __launch_bounds__(128) void k_tree_sample_lean2(
         uint8_t tg[16];
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
-            const int h = h0 + k * 128 + tid;
-            if (h < top_n) {
-                const int d = 31 - __clz(h);
-                const int l = L - d;
-                const int64_t gi = NODE_AT(l, T.base + ((int64_t)(h - (1 << d)) << l));
-                v[k] = T.sum_val[gi];
-                tg[k] = T.sum_tag[gi];
-            }
+            // (unconditional loads from a clamped, always valid node: a load inside a branch is
+            // waited for before the next one is issued -- 32 round trips per batch instead of one)
+            const int hh = h0 + k * 128 + tid;
+            const int h = hh < top_n ? hh : top_n - 1;
+            const int d = 31 - __clz(h);
+            const int l = L - d;
+            const int64_t gi = NODE_AT(l, T.base + ((int64_t)(h - (1 << d)) << l));
+            v[k] = T.sum_val[gi];
+            tg[k] = T.sum_tag[gi];
         }
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
@@ -1149,12 +1179,26 @@ __global__ __launch_bounds__(128) void k_tree_sample_lean2(
 #undef NODE_AT
     double my_u = 0.0;
     int myh = -1;       // wave 0, lane j: the level-r node draw j went through (first 64 draws)
+#ifdef PFRL_TREE_DEBUG
+    __syncthreads();
+    t_dbg1 = wall_clock64();
+#endif
     if (wave == 1) my_u = lane < B ? u01[lane] : 0.0;      // the prefetcher looks at draws 1..63 only
-    for (int64_t i = 0; i < B; ++i) {
-        __syncthreads();        // draw i - 1 is complete, its prefetch too: the only workgroup barrier
-        if (wave == 0) {
-            if ((i & 63) == 0) my_u = i + lane < B ? u01[i + lane] : 0.0;
-            const double u = readlane_f64(my_u, (int)(i & 63));
+    // Both waves pass B workgroup barriers, one per draw (wave 0 at the top of its loop, wave 1 at
+    // the top of its own): draw i - 1 is complete and the subtree predicted for draw i is in LDS.
+    if (wave == 0) {
+        // (the uniforms are loaded 64 draws at a time OUTSIDE the loop over those draws: a load
+        // anywhere inside makes every iteration wait for the wave's vector-memory counter, i.e.
+        // for the previous draw's write-back stores to reach memory -- 1-3 us beside a busy GPU)
+        for (int64_t i0 = 0; i0 < B; i0 += 64) {
+          my_u = i0 + lane < B ? u01[i0 + lane] : 0.0;
+          const int64_t i_end = i0 + 64 < B ? i0 + 64 : B;
+          // (first use of the loaded register here, so that the wait for it is here too)
+          double u_next = readlane_f64(my_u, 0);
+          for (int64_t i = i0; i < i_end; ++i) {
+            __syncthreads();
+            const double u = u_next;
+            u_next = readlane_f64(my_u, (int)((i + 1 - i0) & 63));
             // ---- top heap: L - r levels ----
             const double rootv = top_v[1];
             // np.random.uniform(0.0, root) = 0.0 + (root - 0.0) * u
@@ -1173,6 +1217,11 @@ __global__ __launch_bounds__(128) void k_tree_sample_lean2(
             if (lane == (int)(i & 63)) myh = h;
             if (!prefetched) {
                 fetch_subtree(T, x0, r, lane, my_off, my_org, my_mask, bot_v, bot_t);
+                // vmcnt(0) HERE, on the rare path: the last stores of the fetch sit behind a lane
+                // mask, so without it the compiler waits for "possibly pending" loads after the
+                // join -- on every draw, and the counter it waits for also holds the previous
+                // draw's write-back stores (1-3 us to reach memory beside a busy GPU)
+                __builtin_amdgcn_s_waitcnt(0x0F70);
                 wave_lds_fence();
             }
             // ---- bottom heap: r levels ----
@@ -1244,23 +1293,55 @@ __global__ __launch_bounds__(128) void k_tree_sample_lean2(
                 T.sum_val[gi] = v;
                 T.sum_tag[gi] = (uint8_t)tg;
             }
-        } else if (i + 1 < B && i + 1 < 64) {
-            // ---- wave 1: where will draw i + 1 go?  (the top heap may change under this descent:
-            // any outcome is a valid level-r node, and wave 0 checks it) ----
-            const double u = readlane_f64(my_u, (int)(i + 1));
-            const double rootv = top_v[1];
-            double p64 = __dadd_rn(0.0, __dmul_rn(rootv, u));
-            float p32 = (float)p64;
-            int pt = PFRL_TAG_PY;
-            const int hp = find_down(top_v, top_t, 1, L - r, p64, p32, pt);
-            const int64_t x0 = T.base + ((int64_t)(hp - (top_n >> 1)) << r);
-            fetch_subtree(T, x0, r, lane, my_off, my_org, my_mask, bot_v2 + ((i + 1) & 1) * bot_n,
-                          bot_t2 + ((i + 1) & 1) * bot_n);
-            if (lane == 0) s_pred_h[(i + 1) & 1] = hp;
+          }
+        }
+    } else {
+        // ---- wave 1: where will the next draws go?  (the top heap may change under these
+        // descents: any outcome is a valid level-r node, and wave 0 checks it.)  The subtree of
+        // draw i + 1 must be in LDS when iteration i ends; beside the backward / optimizer launches
+        // of the other stream a fetch takes longer than a draw, so its loads are requested one
+        // iteration earlier and stay in flight across the barrier (the registers that receive
+        // them are written in ONE place per iteration: a merge of two definitions made the
+        // compiler copy them, i.e. wait for them, at the top of the loop).
+        const int last = (int)((B < 64 ? B : 64) - 1);       // draws beyond are wave 0's own business
+        double pf_v[kSubLoads];
+        uint8_t pf_t[kSubLoads];
+        int pend_h;
+        __syncthreads();                                     // (iteration 0: the top heap is staged)
+        {
+            const int k1 = 1 < last ? 1 : last;
+            pend_h = predict_level_r(top_v, top_t, L - r, readlane_f64(my_u, k1));
+            subtree_loads(T, T.base + ((int64_t)(pend_h - (top_n >> 1)) << r), r, lane, my_off, my_org,
+                          my_mask, pf_v, pf_t);
+            if (1 <= last) {
+                subtree_stores(r, lane, pf_v, pf_t, bot_v2 + bot_n, bot_t2 + bot_n);
+                if (lane == 0) s_pred_h[1] = pend_h;
+            }
+            const int k2 = 2 < last ? 2 : last;
+            pend_h = predict_level_r(top_v, top_t, L - r, readlane_f64(my_u, k2));
+            subtree_loads(T, T.base + ((int64_t)(pend_h - (top_n >> 1)) << r), r, lane, my_off, my_org,
+                          my_mask, pf_v, pf_t);
+        }
+        for (int64_t i = 1; i < B; ++i) {
+            __syncthreads();
+            if (i + 1 <= last) {
+                subtree_stores(r, lane, pf_v, pf_t, bot_v2 + ((i + 1) & 1) * bot_n,
+                               bot_t2 + ((i + 1) & 1) * bot_n);
+                if (lane == 0) s_pred_h[(i + 1) & 1] = pend_h;
+            }
+            // (always: past the last prefetched draw the same subtree is requested again and
+            // nobody reads it)
+            const int k2 = i + 2 < last ? (int)(i + 2) : last;
+            pend_h = predict_level_r(top_v, top_t, L - r, readlane_f64(my_u, k2));
+            subtree_loads(T, T.base + ((int64_t)(pend_h - (top_n >> 1)) << r), r, lane, my_off, my_org,
+                          my_mask, pf_v, pf_t);
         }
     }
     __threadfence_block();
     __syncthreads();
+#ifdef PFRL_TREE_DEBUG
+    t_dbg2 = wall_clock64();
+#endif
     if (wave == 0) {
         if (lane == 0) {
             *out_total = s_total_v;
@@ -1288,6 +1369,15 @@ __global__ __launch_bounds__(128) void k_tree_sample_lean2(
             if (out_slot) out_slot[i] = (int32_t)(out_x[i] % slot_mod);
         }
     }
+#ifdef PFRL_TREE_DEBUG
+    if (tid == 0) {
+        const unsigned long long t3 = wall_clock64();
+        g_dbg[0] = (t_dbg1 - t_dbg0) * (unsigned long long)B;     // (per_dbg2 divides by B)
+        g_dbg[1] = (t_dbg2 - t_dbg1) * (unsigned long long)B;
+        g_dbg[2] = (t3 - t_dbg2) * (unsigned long long)B;
+        g_dbg[3] = g_dbg[4] = 0;
+    }
+#endif
 }
 
 }  // namespace
