@@ -233,15 +233,10 @@ class PrioritizedBuffer:
     def next_appends_keep_frame(self, m=1):
         """True when the next ``m`` calls of ``append`` (each with the ``popleft`` a full buffer
         does first) leave the tree frame as it is, i.e. none of them flushes."""
-        f = self.frame
-        if f.length <= m + 1:
-            return False
-        if f.next_x + m > f.base + f.size:              # (prioritized.py:207-223: doubling)
-            return False
-        if self.capacity is not None and len(self) + m > self.capacity:
-            if f.head + m >= f.base + f.size // 2:      # (:225-242: halving / re-rooting)
-                return False
-        return True
+        from pfrl_amd.collections.tree_frame import appends_keep_frame
+
+        pops = self.capacity is not None and len(self) + m > self.capacity
+        return appends_keep_frame(self.frame, m, pops)
 
     def sample_device(self, n, u01=None, normalize=1, beta=0.0, slot_mod=0, co_stage=None,
                       split=False):

@@ -79,6 +79,20 @@ class TreeFrame:
         return x
 
 
+def appends_keep_frame(frame, m, pops):
+    """True when the next ``m`` appends -- each preceded by a ``popleft`` if ``pops`` (a buffer
+    at capacity) -- leave ``frame`` (a :class:`TreeFrame`) as it is: no doubling
+    (prioritized.py:207-223), no halving / re-rooting (:225-242), i.e. ``epoch`` stays.
+    Conservative: may say False for a sequence that would in fact keep the frame."""
+    if frame.length <= m + 1:
+        return False
+    if frame.next_x + m > frame.base + frame.size:
+        return False
+    if pops and frame.head + m >= frame.base + frame.size // 2:
+        return False
+    return True
+
+
 def smax_log2_for_capacity(capacity):
     """Largest frame the reference can reach with this capacity: doubling needs
     more than size/2 live items, so size <= 2 * next_pow2(capacity)."""

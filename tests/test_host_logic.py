@@ -306,3 +306,32 @@ def test_ppo_minibatch_positions_drawn_up_front_consume_the_same_random_stream()
             random.getrandbits(32)
         b = _random_permutation(4099)
         assert a == [int(v) for v in b] and sa == random.getstate(), warm
+
+
+def test_appends_keep_frame_never_misses_a_frame_change():
+    """``appends_keep_frame`` (what lets DQN._batch_observe_train_per look one update point ahead)
+    against the frame bookkeeping itself: whenever it says the next m appends -- with the popleft a
+    full buffer does first -- keep the frame, performing them must not move ``epoch``."""
+    import random
+
+    from pfrl_amd.collections.tree_frame import TreeFrame, appends_keep_frame
+
+    rnd = random.Random(7)
+    said_yes = said_no = 0
+    for capacity in (5, 8, 33, 64, 100, 257):
+        f = TreeFrame()
+        for step in range(6 * capacity):
+            m = rnd.randint(1, 4)
+            pops = f.length + m > capacity
+            ok = appends_keep_frame(f, m, pops)
+            before = f.epoch
+            for _ in range(m):
+                if f.length == capacity:
+                    f.popleft()
+                f.append()
+            if ok:
+                assert f.epoch == before, (capacity, step, m)
+                said_yes += 1
+            else:
+                said_no += 1
+    assert said_yes > 10 * said_no > 0      # (and it is not vacuous: mostly yes, sometimes no)
