@@ -597,6 +597,47 @@ def step_flops_ppo(N, n_actions=6):
     return N * (fwd + fwd + 4 * (3 * fwd - NATURE_CONV1_FLOPS))
 
 
+def mfma_per_launch(B=32, n_actions=6):
+    """Per launch of ONE DQN update: device time from the committed rocprofv3 timeline of this
+    build (profiles/rNN_dqn_update_timeline.txt) and the arithmetic that launch performs (the
+    Nature CNN of pfrl/nn/atari_cnn.py:17-47 at minibatch B: forward per layer; a backward launch
+    = input gradient + weight gradient of its layer = 2 x forward, conv1 has no input gradient;
+    the hidden layer's RMSprop step rides in the last backward launch), as a fraction of the
+    f32 MFMA peak.  The launches of the chain are matched by position: the update is ten
+    dependent launches in network order."""
+    import re
+
+    conv1 = 2 * 20 * 20 * 32 * 8 * 8 * 4
+    conv2 = 2 * 9 * 9 * 64 * 4 * 4 * 32
+    conv3 = 2 * 7 * 7 * 64 * 3 * 3 * 64
+    hidden = 2 * 3136 * 512
+    head = 2 * 512 * n_actions
+    flops = [conv1, conv2, conv3, hidden,           # forward
+             3 * head,                              # head forward + TD loss + head backward
+             2 * hidden, 2 * conv3, 2 * conv2,      # backward: input + weight gradients
+             conv1,                                 # conv1: weight gradient only
+             0]                                     # optimizer step (no MFMA work)
+    what = ["conv1 fwd", "conv2 fwd", "conv3 fwd", "hidden fwd", "head + TD loss + head bwd",
+            "hidden bwd", "conv3 bwd", "conv2 bwd", "conv1 wgrad (+ the hidden layer's RMSprop step riding)",
+            "RMSprop (slab folds + step)"]
+    prof_dir = os.path.join(ROOT, "profiles")
+    for name in sorted(os.listdir(prof_dir), reverse=True):
+        if not name.endswith("_dqn_update_timeline.txt"):
+            continue
+        rows = re.findall(r"dur\s+([0-9.]+)\s+grid\s+\d+\s+(\S+)", open(os.path.join(prof_dir, name)).read())
+        if len(rows) != len(flops):
+            return {"source": "profiles/" + name,
+                    "note": "%d launches in the timeline, %d expected: not matched" % (len(rows), len(flops))}
+        out = []
+        for (us, kern), f, w in zip(rows, flops, what):
+            us = float(us)
+            gf = f * B / 1e9
+            out.append({"kernel": kern.split("<")[0], "what": w, "us": us, "gflop": round(gf, 4),
+                        "frac": round(gf / 1e3 / (us * 1e-6) / MFMA_F32_PEAK_TFLOPS, 4) if us > 0 else None})
+        return {"source": "profiles/" + name, "launches": out}
+    return None
+
+
 def launches_per_update():
     """Kernel launches of one update, from the committed rocprofv3 timeline of this build
     (profiles/rNN_dqn_update_timeline.txt, tools/update_timeline.py), newest round first."""
@@ -924,6 +965,7 @@ def run_workload(args, device, rank, world, result_extras=True):
                 "device time of ONE optimizer update (forward, TD loss, backward, optimizer step) "
                 "inside the captured %d-update range graph, hipEvents around the replay" % big_u)
             roofline["mfma"]["launches_per_update"] = launches_per_update()
+            roofline["mfma"]["per_launch"] = mfma_per_launch(args.minibatch)
     out["config"]["ranks_seen"] = world
     if args.algo == "rainbow":
         out["config"]["priority_pow"] = rbuf.priority_pow
