@@ -965,7 +965,10 @@ def run_workload(args, device, rank, world, result_extras=True):
                 "device time of ONE optimizer update (forward, TD loss, backward, optimizer step) "
                 "inside the captured %d-update range graph, hipEvents around the replay" % big_u)
             roofline["mfma"]["launches_per_update"] = launches_per_update()
-            roofline["mfma"]["per_launch"] = mfma_per_launch(args.minibatch)
+            try:
+                roofline["mfma"]["per_launch"] = mfma_per_launch(args.minibatch)
+            except Exception as e:      # (a profile file in another format must not cost the line)
+                roofline["mfma"]["per_launch"] = {"note": "not available: %s" % e}
     out["config"]["ranks_seen"] = world
     if args.algo == "rainbow":
         out["config"]["priority_pow"] = rbuf.priority_pow

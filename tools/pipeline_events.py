@@ -46,10 +46,14 @@ def wrap(obj, attr, name):
 
 _replay = torch.cuda.CUDAGraph.replay
 _count = [0]
+_names = {}
 def replay(self):
-    mark("graph%d:begin" % (_count[0] & 1))
+    # graphs named in the order they are first replayed inside the measured region (an update
+    # replays two or three: [noise,] forward, backward + step)
+    name = _names.setdefault(id(self), "graph%d" % len(_names)) if on[0] else "graph?"
+    mark(name + ":begin")
     r = _replay(self)
-    mark("graph%d:end" % (_count[0] & 1))
+    mark(name + ":end")
     _count[0] += 1
     return r
 torch.cuda.CUDAGraph.replay = replay
