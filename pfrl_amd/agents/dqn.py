@@ -774,6 +774,8 @@ class DQN(agent.AttributeSavingMixin, agent.BatchAgent):
         rbuf, up = self.replay_buffer, self.replay_updater
         return (os.environ.get("PFRL_PER_LOOKAHEAD", "1") != "0" and self._replay_stream is not None
                 and self.use_graphs and not self.recurrent and hasattr(rbuf, "sample_prepare")
+                # (somebody who wrapped sample() to see the minibatches must keep seeing them)
+                and "sample" not in vars(rbuf)
                 and getattr(rbuf, "store", None) is not None and not up.episodic_update
                 and up.n_times_update == 1 and up.update_func == self.update)
 
