@@ -102,7 +102,14 @@ class DistributionalDuelingDQN(nn.Module):
         h = _conv_trunk(self.conv_layers, x, self.activation)
         batch_size = x.shape[0]
         h = linear_activation(self.main_stream, h.reshape(batch_size, -1), self.activation)
-        h_a, h_v = torch.chunk(h, 2, dim=1)
+        if h.is_cuda and h.shape[1] % 2 == 0:
+            # both halves contiguous out of ONE copy (the linear kernels want dense rows; chunk()
+            # gives two strided views and each stream would copy its own: one launch fewer forwards
+            # and one backwards, same values)
+            halves = h.view(batch_size, 2, h.shape[1] // 2).transpose(0, 1).contiguous()
+            h_a, h_v = halves[0], halves[1]
+        else:
+            h_a, h_v = torch.chunk(h, 2, dim=1)
         ya_flat = self.a_stream(h_a)
         if h.is_cuda:
             from pfrl_amd import ops
