@@ -381,6 +381,7 @@ def prefill(agent, env, obss, num_envs, target):
     saved = agent.replay_updater.replay_start_size
     agent.replay_updater.replay_start_size = 1 << 62
     while len(agent.replay_buffer) < target:
+        _tick("prefill")
         obss = one_step(agent, env, obss, num_envs)
     agent.replay_updater.replay_start_size = saved
     return obss
@@ -884,13 +885,101 @@ def reference_baseline_ppo(args, num_envs=512, steps=16):
     }
 
 
+def collective_microbench(agent, device, iters=50):
+    """Per-update exchange of the data-parallel update, timed on its own (hipEvents around ``iters``
+    back-to-back calls, every rank takes part): the flat bucket's all-reduce and the grouped
+    all-gather of the large Linear layer's batch matrices at this agent's sizes.  The in-graph cost
+    is part of ``update_us``; these are the collectives' stand-alone latencies."""
+    red = getattr(agent, "grad_reducer", None)
+    comm = getattr(red, "_comm", None)
+    if red is None or not red.active():
+        return None
+    out = {}
+    bucket = red.current_bucket() if red.current_bucket() is not None else red._flat
+    try:
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        if bucket is not None:
+            buf = torch.zeros_like(bucket)
+            for _ in range(3):
+                red.reduce_flat(buf)
+            ev[0].record()
+            for _ in range(iters):
+                red.reduce_flat(buf)
+            ev[1].record()
+            torch.cuda.synchronize()
+            out["flat_all_reduce"] = round(ev[0].elapsed_time(ev[1]) * 1e3 / iters, 2)
+            out["flat_bytes"] = int(buf.numel() * 4)
+        if comm is not None:
+            B = getattr(agent, "minibatch_size", 32)
+            G = comm.world
+            dy, x = torch.zeros(B * 512, device=device), torch.zeros(B * 3136, device=device)
+            dya, xa = torch.zeros(G * B * 512, device=device), torch.zeros(G * B * 3136, device=device)
+            for i in range(iters + 3):
+                if i == 3:
+                    ev[2].record()
+                with comm.group():
+                    comm.all_gather(dya, dy)
+                    comm.all_gather(xa, x)
+            ev[3].record()
+            torch.cuda.synchronize()
+            out["lowrank_all_gather_pair"] = round(ev[2].elapsed_time(ev[3]) * 1e3 / iters, 2)
+            out["lowrank_bytes_per_rank"] = int((dy.numel() + x.numel()) * 4)
+    except Exception as e:      # (evidence only: never costs the line)
+        out["note"] = "not measured: %s" % (str(e)[:120],)
+    return out
+
+
+class _StallWatchdog:
+    """N > 1 only: if the ranks stop making progress (a peer died, a collective hangs), rank 0
+    still prints a line -- ``value`` null, ``config.dp_plan`` = "fallback:stalled ..." -- and the
+    process leaves with status 0 instead of sitting in the driver's timeout."""
+
+    def __init__(self, args, rank, world, result_fd, limit_s):
+        import threading
+
+        self.t = time.time()
+        self.what = "start"
+        self.done = False
+        self.printed = False
+        self.args, self.rank, self.world, self.fd, self.limit = args, rank, world, result_fd, limit_s
+        threading.Thread(target=self._run, name="pfrl-bench-watchdog", daemon=True).start()
+
+    def tick(self, what):
+        self.t, self.what = time.time(), what
+
+    def _run(self):
+        while not self.done:
+            time.sleep(1.0)
+            if time.time() - self.t > self.limit:
+                a = self.args
+                line = {"metric": "env-steps/sec whole node (%s)" % a.algo.upper(), "value": None,
+                        "unit": "env-steps/s", "n_gpus": self.world, "steps": a.steps,
+                        "warmup": a.warmup, "ms_per_step": None, "higher_is_better": True,
+                        "scaling": a.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                        "config": {"workload": "not completed", "ranks_seen": self.world,
+                                   "dp_plan": "fallback:stalled for %.0f s in %s" % (self.limit, self.what)}}
+                if self.rank == 0 and not self.printed:
+                    os.write(self.fd, (json.dumps(line) + "\n").encode())
+                os._exit(0)
+
+
+_WATCHDOG = [None]
+
+
+def _tick(what):
+    if _WATCHDOG[0] is not None:
+        _WATCHDOG[0].tick(what)
+
+
 def run_workload(args, device, rank, world, result_extras=True):
     """Build, prefill, warm up and time one workload; returns the result dict (rank 0) or None."""
     from pfrl_amd import ops
 
+    _tick("build %s" % args.algo)
     agent, env, rbuf = build_agent(args, device, rank)
     N = args.num_envs
     obss = env.reset()
+    _tick("prefill %s" % args.algo)
     t_fill = time.perf_counter()
     if rbuf is not None:
         # every replay workload runs at its stated size: the buffer is FULL when the timed region
@@ -917,8 +1006,10 @@ def run_workload(args, device, rank, world, result_extras=True):
     # holds for the first rollout + update.
     need = (128 if args.algo == "ppo" else 3) - args.warmup
     for _ in range(max(0, need)):
+        _tick("warm-up %s" % args.algo)
         obss = one_step(agent, env, obss, N)
     for _ in range(args.warmup):
+        _tick("warm-up %s" % args.algo)
         obss = one_step(agent, env, obss, N)
 
     def updates_done():
@@ -937,10 +1028,12 @@ def run_workload(args, device, rank, world, result_extras=True):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
+        _tick("timed steps %s" % args.algo)
         obss = one_step(agent, env, obss, N)
     barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    _tick("after timed steps %s" % args.algo)
     ops.profile_enable(False)
     n_updates = updates_done() - optim_before
 
@@ -970,6 +1063,11 @@ def run_workload(args, device, rank, world, result_extras=True):
             except Exception as e:      # (a profile file in another format must not cost the line)
                 roofline["mfma"]["per_launch"] = {"note": "not available: %s" % e}
     out["config"]["ranks_seen"] = world
+    if torch.distributed.is_initialized():
+        from pfrl_amd import rccl
+
+        out["config"].update(rccl.status())
+        out["config"]["collective_us"] = collective_microbench(agent, device)
     if args.algo == "rainbow":
         out["config"]["priority_pow"] = rbuf.priority_pow
     if result_extras and args.algo == "dqn" and not args.host_env and not args.no_data_path_only:
@@ -1017,7 +1115,29 @@ def main():
         torch.cuda.tunable.set_max_tuning_duration(10)
         torch.cuda.tunable.set_filename("/tmp/pfrl_tunableop_rank%d.csv" % rank)
 
-    out = run_workload(args, device, rank, world)
+    if world > 1:
+        _WATCHDOG[0] = _StallWatchdog(args, rank, world, result_fd,
+                                      float(os.environ.get("PFRL_BENCH_STALL_S", "600")))
+    run_guarded = run_workload
+    if torch.distributed.is_initialized():
+        from pfrl_amd import rccl
+
+        def run_guarded(*a, **kw):
+            """The data plane must not cost the line: an RCCL error code raised on this rank (the
+            same call fails on its peers) retires the direct data plane -- the ranks confirm it to
+            each other over the control plane -- and the workload is built and run again with the
+            gradients carried by the process group (config.dp_plan = "fallback:...")."""
+            try:
+                return run_workload(*a, **kw)
+            except rccl.DataPlaneError as e:
+                sys.stderr.write("bench.py: %s -- retrying on the process-group path\n" % (e,))
+                why = str(e)[:160]
+            torch.distributed.monitored_barrier(timeout=__import__("datetime").timedelta(seconds=120)) \
+                if torch.distributed.get_backend() == "gloo" else torch.distributed.barrier()
+            rccl.retire(why)
+            return run_workload(*a, **kw)
+
+    out = run_guarded(args, device, rank, world)
     if args.algo == "dqn" and not args.host_env and not args.no_also:
         # the other half of BASELINE.json's metric ("DQN 256 envs, PPO 512 envs"): the PPO
         # configs[3] workload, timed by the same process right after
@@ -1028,7 +1148,7 @@ def main():
         pargs.num_envs = 512 if args.scaling == "weak" else 512 // world
         pargs.cudnn_benchmark = False
         torch.backends.cudnn.benchmark = False
-        also = run_workload(pargs, device, rank, world, result_extras=False)
+        also = run_guarded(pargs, device, rank, world, result_extras=False)
         keys = ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "scaling", "config",
                 "roofline")
         if rank == 0:
@@ -1067,15 +1187,21 @@ def main():
             pref = reference_baseline_ppo(args, num_envs=args.num_envs)
             if pref is not None:
                 out["cpu_baseline"] = pref
+    # the line first: teardown of a communicator must not be able to cost it
+    sys.stdout.flush()
+    if rank == 0:
+        os.write(result_fd, (json.dumps(out) + "\n").encode())
+    if _WATCHDOG[0] is not None:
+        _WATCHDOG[0].printed = True
+    _tick("teardown")
     if torch.distributed.is_initialized():
         from pfrl_amd import rccl
 
         torch.cuda.synchronize()
         rccl.destroy_all()
         torch.distributed.destroy_process_group()
-    sys.stdout.flush()
-    if rank == 0:
-        os.write(result_fd, (json.dumps(out) + "\n").encode())
+    if _WATCHDOG[0] is not None:
+        _WATCHDOG[0].done = True
     os.close(result_fd)
 
 

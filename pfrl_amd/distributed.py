@@ -392,6 +392,13 @@ class GradientAllReducer:
         if dist.get_backend() == "nccl":
             works = (dist.all_gather_into_tensor(dy_all, d, async_op=True),
                      dist.all_gather_into_tensor(x_all, xx, async_op=True))
+        elif d.is_cuda:
+            # device batch matrices on gloo (direct data plane off or retired): via the host
+            for full, part in ((dy_all, d), (x_all, xx)):
+                h = torch.empty(full.shape, dtype=full.dtype)
+                dist.all_gather(list(h.chunk(G)), part.detach().cpu())
+                full.copy_(h)
+            works = ()
         else:
             works = (dist.all_gather(list(dy_all.chunk(G)), d, async_op=True),
                      dist.all_gather(list(x_all.chunk(G)), xx, async_op=True))
@@ -421,6 +428,11 @@ class GradientAllReducer:
             return _SideJoin(self._comm.side, t.device)
         if dist.get_backend() == "nccl":
             return dist.all_reduce(t, op=dist.ReduceOp.AVG, async_op=True)
+        if t.is_cuda:
+            # the process group carries a device gradient (direct data plane off or retired,
+            # pfrl_amd/rccl.py): through the host, synchronously -- _finish_early divides
+            control_all_reduce_sum(t)
+            return None
         return dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True)
 
     def _finish_early(self):
@@ -474,7 +486,7 @@ class GradientAllReducer:
         elif dist.get_backend() == "nccl":
             dist.all_reduce(bucket, op=dist.ReduceOp.AVG)   # RCCL averages in the collective
         else:
-            dist.all_reduce(bucket, op=dist.ReduceOp.SUM)
+            control_all_reduce_sum(bucket)                  # (a device bucket on gloo: via the host)
             bucket.div_(world_size())
 
     # -- gradients that are still split-K slabs (the fused optimizer path) ----------------------

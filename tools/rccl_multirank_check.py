@@ -1,9 +1,10 @@
 """Functional check of the data plane with MORE THAN ONE rank (pfrl_amd/rccl.py + distributed.py).
 
 Run on a box that shows >= 2 HIP devices (an 8-GPU node, or ONE MI355X put into CPX compute
-partitioning -- 8 XCD partitions, each its own device):
+partitioning -- 8 XCD partitions, each its own device), or with --shared-device on a one-GPU box
+(the lease of round 5 refused CPX: profiles/r05_cpx_refused.txt):
 
-    python tools/rccl_multirank_check.py --world 2 --out gpurun_out/r05/rccl_multirank.json
+    python tools/rccl_multirank_check.py --world 2 [--shared-device] --out gpurun_out/r05/rccl_multirank.json
 
 Every rank: unique-id broadcast over the gloo control plane, ncclCommInitRank(nranks = world),
 eager all-reduce / all-gather / grouped all-gather, the capture probe, ONE captured graph holding
@@ -36,11 +37,13 @@ def _free_port():
     return port
 
 
-def worker(rank, world, port, out_dir):
+def worker(rank, world, port, out_dir, shared=False):
     sys.path.insert(0, ROOT)
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if shared:
+        os.environ["PFRL_RCCL_SHARED_DEVICE"] = "1"     # (rccl.py: one NCCL_HOSTID per rank)
     import torch.distributed as dist
 
     from pfrl_amd import distributed, rccl
@@ -180,18 +183,23 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--world", type=int, default=2)
     ap.add_argument("--out", default=None)
+    ap.add_argument("--shared-device", action="store_true",
+                    help="all ranks on ONE device: every rank poses as its own host (NCCL_HOSTID), so "
+                         "RCCL's duplicate-GPU check passes and the ranks talk over its socket "
+                         "transport on loopback -- real multi-rank communicators, graphs and "
+                         "exchanges on a one-GPU box")
     args = ap.parse_args()
     import tempfile
 
     n_dev = torch.cuda.device_count()
-    summary = {"devices_visible": n_dev, "world": args.world}
-    if n_dev < args.world:
+    summary = {"devices_visible": n_dev, "world": args.world, "shared_device": args.shared_device}
+    if n_dev < args.world and not args.shared_device:
         summary["ok"] = False
         summary["reason"] = "only %d HIP device(s) visible" % n_dev
     else:
         d = tempfile.mkdtemp()
         try:
-            mp.spawn(worker, args=(args.world, _free_port(), d), nprocs=args.world, join=True)
+            mp.spawn(worker, args=(args.world, _free_port(), d, args.shared_device), nprocs=args.world, join=True)
             ranks = [json.load(open(os.path.join(d, "rank%d.json" % r))) for r in range(args.world)]
             p = [np.load(os.path.join(d, "lowrank%d.npy" % r)) for r in range(args.world)]
             summary["replicas_identical"] = bool(all(np.array_equal(p[0], q) for q in p[1:]))
