@@ -64,6 +64,8 @@ def parse_args():
     p.add_argument("--prefill", type=int, default=None,
                    help="transitions to prefill (default: capacity, i.e. full buffer)")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--allow-lib-override", action="store_true",
+                   help="accept PFRL_AMD_LIB (an A/B build of the native library); recorded on the line")
     p.add_argument("--no-data-path-only", action="store_true",
                    help="dqn: skip the second measurement with a zero-FLOP q_function")
     p.add_argument("--no-also", action="store_true",
@@ -1079,8 +1081,113 @@ def run_workload(args, device, rank, world, result_extras=True):
     return out if rank == 0 else None
 
 
+def _die_with_parent():
+    import ctypes
+    import signal
+
+    ctypes.CDLL("libc.so.6").prctl(1, signal.SIGKILL)       # PR_SET_PDEATHSIG
+
+
+# what the ranks try, in order, when a data-parallel plan takes a worker down
+DP_PLANS = [
+    ("captured collectives (RCCL inside the update graph)", {}),
+    ("eager RCCL collective between two graphs", {"PFRL_GRAPH_COLLECTIVE": "0"}),
+    ("process group, host-staged", {"PFRL_RCCL_DIRECT": "0", "PFRL_GRAPH_COLLECTIVE": "0"}),
+]
+
+
+def supervise(args):
+    """N > 1: every rank launched by torchrun is a SUPERVISOR that never touches the GPU; the
+    workload runs in a child process (this same file, PFRL_BENCH_CHILD=1, its own rendezvous
+    port).  A child that dies (a SIGSEGV inside hipStreamEndCapture with RCCL nodes in the graph is
+    not an exception anyone can catch -- round 5 met exactly that with a live peer), stalls or
+    prints no value costs ONE attempt: the supervisors tell each other through the rendezvous store,
+    stop their children, and start the next, more conservative plan of DP_PLANS.  Rank 0 prints the
+    first line that every rank completed, with ``config.dp_attempts`` listing what failed before;
+    if nothing completes it prints a line with ``value`` null.  Exit status 0 either way: the data
+    plane never costs the driver its JSON line."""
+    import subprocess
+
+    import torch.distributed as dist
+
+    # (gloo's connection banner goes to fd 1 through C stdio: park fd 1 on stderr, as main() does)
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    base_port = int(os.environ.setdefault("MASTER_PORT", "29500"))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    store = dist.distributed_c10d._get_default_store()
+    limit = float(os.environ.get("PFRL_BENCH_ATTEMPT_S", "1500"))
+    attempts, line = [], None
+    first = int(os.environ.get("PFRL_BENCH_FIRST_PLAN", "0"))
+    for k, (name, extra) in list(enumerate(DP_PLANS))[first:]:
+        env = dict(os.environ)
+        env.update(extra)
+        env.update(PFRL_BENCH_CHILD="1", MASTER_PORT=str(base_port + 101 + k))
+        for v in ("TORCHELASTIC_USE_AGENT_STORE", "TORCHELASTIC_RUN_ID"):
+            env.pop(v, None)       # (the children rendezvous on a store of their own)
+        argv = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
+        if os.environ.get("PFRL_BENCH_CHILD_ARGV"):        # (tests/test_bench_supervisor.py: a stub worker)
+            argv = json.loads(os.environ["PFRL_BENCH_CHILD_ARGV"])
+        child = subprocess.Popen(argv, env=env, stdout=subprocess.PIPE, preexec_fn=_die_with_parent)
+        key = "pfrl_bench_attempt_%d_failed" % k
+        t0, why, out = time.time(), None, b""
+        while True:
+            try:
+                out, _ = child.communicate(timeout=1.0)
+                break
+            except subprocess.TimeoutExpired:
+                if store.add(key, 0) > 0:
+                    why = "stopped: a peer's worker failed"
+                elif time.time() - t0 > limit:
+                    why = "no result within %.0f s" % limit
+                if why is not None:
+                    child.kill()
+                    out, _ = child.communicate()
+                    break
+        parsed = None
+        if why is None and child.returncode != 0:
+            why = "worker exited with status %d" % child.returncode
+        if why is None and rank == 0:
+            try:
+                parsed = json.loads(out.decode().strip().splitlines()[-1])
+                if parsed.get("value") is None:
+                    why = "worker printed no value (%s)" % parsed.get("config", {}).get("dp_plan")
+            except Exception as e:      # noqa: BLE001
+                why = "worker printed no JSON line (%s)" % (e,)
+        if why is not None:
+            store.add(key, 1)
+        ok = torch.tensor([0.0 if why is not None else 1.0])
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if float(ok.item()) > 0.5:
+            line = parsed
+            break
+        reasons = [None] * world
+        dist.all_gather_object(reasons, why)
+        attempts.append({"plan": name, "failed": {str(r): w for r, w in enumerate(reasons) if w}})
+        sys.stderr.write("bench.py supervisor: plan '%s' failed (%s)\n" % (name, attempts[-1]["failed"]))
+    if rank == 0:
+        if line is None:
+            line = {"metric": "env-steps/sec whole node (%s)" % args.algo.upper(), "value": None,
+                    "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                    "ms_per_step": None, "higher_is_better": True, "scaling": args.scaling,
+                    "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                    "config": {"workload": "not completed", "ranks_seen": world,
+                               "dp_plan": "fallback:every data-parallel plan failed"}}
+        line.setdefault("config", {})["dp_attempts_failed"] = attempts
+        os.write(result_fd, (json.dumps(line) + "\n").encode())
+    os.close(result_fd)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def main():
     args = parse_args()
+    if (int(os.environ.get("WORLD_SIZE", "1")) > 1 and os.environ.get("PFRL_BENCH_CHILD") != "1"
+            and os.environ.get("PFRL_BENCH_SUPERVISE", "1") != "0"):
+        return supervise(args)
     # stdout carries exactly ONE line, the JSON result.  Native libraries (RCCL's
     # version banner, MIOpen notes) write to fd 1 through C stdio at times of their
     # own choosing: park fd 1 on stderr for the whole run and keep the real stdout
@@ -1097,6 +1204,10 @@ def main():
         assert world == 1 and args.gpus == 1, "--gpus must equal WORLD_SIZE (use torchrun for N>1)"
     device = torch.device("cuda", local % torch.cuda.device_count())
     torch.cuda.set_device(device)
+    # the line is about the library the parity tests validated: the in-tree build, nothing else
+    assert args.allow_lib_override or not os.environ.get("PFRL_AMD_LIB"), (
+        "PFRL_AMD_LIB is set: bench.py measures pfrl_amd/lib/libpfrl_amd.so only (A/B builds of "
+        "tools/build_variant.sh: --allow-lib-override, and the line says so)")
     _native.lib()
     if world > 1:
         # one process per GPU: keep each rank's host-side torch ops on its share of cores
@@ -1187,6 +1298,15 @@ def main():
             pref = reference_baseline_ppo(args, num_envs=args.num_envs)
             if pref is not None:
                 out["cpu_baseline"] = pref
+    if rank == 0 and out is not None:
+        import hashlib
+
+        lib_path = os.environ.get("PFRL_AMD_LIB") or _native.LIB_PATH
+        with open(lib_path, "rb") as f:
+            out["config"]["native_lib"] = {
+                "path": os.path.relpath(lib_path, os.path.dirname(os.path.abspath(__file__))),
+                "sha256_16": hashlib.sha256(f.read()).hexdigest()[:16],
+                "override": bool(os.environ.get("PFRL_AMD_LIB"))}
     # the line first: teardown of a communicator must not be able to cost it
     sys.stdout.flush()
     if rank == 0:

@@ -714,11 +714,13 @@ class CapturedStep:
         entry[0].replay()
         return entry[1]
 
-    def run(self, batch, variant=None):
+    def run(self, batch, variant=None, baked=None):
         """``variant`` (hashable) selects between differently shaped steps over the
         same buffers (TD3: with / without the delayed policy update); it is passed
-        to ``fn`` as a second argument when not None."""
-        key = (self._key(batch), variant, _hyper_signature(self.optimizers))
+        to ``fn`` as a second argument when not None.  ``baked`` (hashable): every Python-side
+        number ``fn`` reads while it is captured (loss coefficients, clip ranges, ...) -- they
+        become kernel arguments of the graph, so a changed value must capture anew."""
+        key = (self._key(batch), variant, _hyper_signature(self.optimizers), baked)
         entry = self.graphs.lookup(key)
         if entry is None:
             entry = self._capture(batch, variant)

@@ -199,7 +199,15 @@ class _ActGraph:
     330 ms rollout).  Replayed, the step costs the host one small copy and one hipGraphLaunch.
     The graph reads the frame ring, the parameters and the normaliser statistics in place, so
     optimizer steps and new frames need no re-capture; sampling draws from the default generator
-    through PyTorch's graph-safe Philox offsets (each replay advances the stream)."""
+    through PyTorch's graph-safe Philox offsets (each replay advances the stream).
+
+    Seed streams: with the example network the action is drawn by inverse CDF from ONE
+    ``torch.rand`` per env (``pfrl_ppo_act_head``), not by ``Categorical.sample`` /
+    ``torch.multinomial``, so for a given torch seed the action stream on a device env differs
+    from the eager path's (same distribution: tests/test_hip_kernels.py::
+    test_ppo_act_head_matches_torch_categorical; ``PFRL_PPO_ACT_GRAPH=0`` or
+    ``PFRL_PPO_ACT_HEAD=0`` restore the eager draws).  The reference's trajectory parity fixtures
+    (tests/golden/agent_trace_ppo.npz) are recorded with host envs and take the eager path."""
 
     def __init__(self, agent):
         self.agent = agent
@@ -291,8 +299,9 @@ class _ActGraph:
     def run(self, refs_dev):
         """(actions [N], stats [2, N] = entropy, value): tensors OWNED BY THE GRAPH, overwritten by
         the next replay -- callers copy what they keep."""
-        key = (tuple(refs_dev.shape), id(self.agent.model), self.agent.frames.emit_channels_last
-               if self.agent.frames is not None else None)
+        # (the graph bakes in the module tree it walked: a replaced child captures anew)
+        key = (tuple(refs_dev.shape), tuple(id(m) for m in self.agent.model.modules()),
+               self.agent.frames.emit_channels_last if self.agent.frames is not None else None)
         e = self.entries.get(key)
         if e is None:
             e = self.entries[key] = self._capture(refs_dev)
@@ -693,7 +702,7 @@ class PPO(agent.AttributeSavingMixin, agent.BatchAgent):
                 # the ~100 small launches of the heads and the loss no longer wait for the
                 # dispatcher (1.8 ms -> 0.45 ms of a 12 ms update, profiles/r04_ppo_update_timeline.txt)
                 cols["idx"].copy_(idx)
-                out = self._update_graph.run({"idx": cols["idx"]})
+                out = self._update_graph.run({"idx": cols["idx"]}, baked=self._baked_hyperparameters())
                 self.value_loss_record.extend(out["value_loss"].clone())
                 self.policy_loss_record.extend(out["policy_loss"].clone())
                 self.n_updates += 1
@@ -739,6 +748,18 @@ class PPO(agent.AttributeSavingMixin, agent.BatchAgent):
                 and actions_i64 is not None and distributed.world_size() == 1
                 and n % self.minibatch_size == 0
                 and type(self)._lossfun is PPO._lossfun and "_lossfun" not in self.__dict__)
+
+    def _baked_hyperparameters(self):
+        """What ``_minibatch_step`` / ``_lossfun`` read as Python numbers, i.e. what a captured
+        update holds as kernel arguments: part of the graph key, so that a hook that moves one of
+        them (the reference's ``LinearInterpolationHook`` on ``clip_eps``,
+        examples/atari/train_ppo_ale.py:301-306) is not replayed away."""
+        def num(v):
+            return None if v is None else float(v)
+
+        return (num(self.clip_eps), num(self.clip_eps_vf), num(self.entropy_coef),
+                num(self.value_func_coef), num(self.max_grad_norm), bool(self.standardize_advantages),
+                id(self.model), tuple(id(m) for m in self.model.children()))
 
     def _static_columns(self, adv, mean_std, log_probs, v_pred, v_teacher, actions_i64, s_refs):
         """The rollout's columns in buffers that keep their addresses from rollout to rollout

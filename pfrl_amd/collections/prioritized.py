@@ -260,8 +260,12 @@ class PrioritizedBuffer:
             # not be lost to a failed assert above
             co_stage = co_stage()
         pending = self.take_pending()
-        if pending is None and (self._pend_x or not split):
+        if pending is None and not split:
             self.flush()            # (nothing pending, or more than one launch's worth)
+        # (split with more than one launch's worth of writes: they stay recorded until finish(),
+        # which launches them BEHIND the previous sample's priority update -- flushing here would
+        # put the pops of the look-ahead appends in front of it, and the update would then write a
+        # live priority onto a leaf that is already absent)
         if u01 is None:
             u01 = np.random.random_sample(n)
         key = n
@@ -310,8 +314,8 @@ class PrioritizedBuffer:
             with on_stream(self.side_stream):
                 if pending is not None:
                     pending[1](*views[1:1 + n_t])
-                elif self._deferred is not None:
-                    self._launch_deferred(self._sync_desc())
+                elif self._pend_x or self._deferred is not None:
+                    self.flush()        # (priority update first, fused with the first 1 024 writes)
                 ops.tree_sample(self._sync_desc(), views[0], out, normalize, beta, slot_mod)
             self._sampled_x = out["x"]
             self._n_sampled = n

@@ -266,6 +266,12 @@ def default_comm(device):
             os.environ["NCCL_HOSTID"] = "pfrl-shared-device-rank-%d" % rank
             os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
             os.environ.setdefault("NCCL_IB_DISABLE", "1")
+        # the HIP context of this process exists before RCCL is entered (on a helper thread, below):
+        # a rank whose first GPU call was ncclCommInitRank died with SIGSEGV inside RCCL's
+        # topology discovery (round 5, tools/rccl_multirank_check.py on a fresh process)
+        with torch.cuda.device(device):
+            torch.zeros(1, device=device)
+            torch.cuda.synchronize(device)
         t0 = time.time()
         box, comm, why = [None], None, None
         if rank == 0:

@@ -313,6 +313,58 @@ def test_update_errors_f32_priority_transform(dev, alpha):
         np.testing.assert_array_equal(lv[x], wv)      # 0 ulp, f32 and Python-float branches
 
 
+def test_split_sample_keeps_the_priority_update_in_front_of_more_than_one_launch_of_writes(dev):
+    """sample_device(split=True) with more than 1 024 recorded leaf writes (a large
+    update_interval at capacity: every look-ahead append pops first) used to flush at prepare
+    time, i.e. BEFORE the previous minibatch's priorities -- which then landed on leaves that were
+    already absent.  The reference's order is priorities, then pops / appends, then the draws."""
+    from pfrl_amd import ops
+    from pfrl_amd.collections.prioritized import PrioritizedBuffer
+
+    alpha, eps = 0.5, 0.01
+    mode = ops.powf_host_variant(alpha)
+    assert mode is not None
+    rs = np.random.RandomState(11)
+    cap, B, extra = 1500, 32, 700          # 700 appends at capacity = 1 400 recorded writes
+    buf = PrioritizedBuffer(cap, device=dev)
+    orc = oracle.OraclePrioritizedBuffer(cap)
+    for i in range(cap):
+        buf.append(i)
+        orc.append(i)
+    # first draws from the OLDEST leaves on purpose: the ones the look-ahead appends pop
+    u = np.sort(rs.random_sample(B)) * (B / cap)
+    out = buf.sample_device(B, u01=u)
+    np.testing.assert_array_equal(out["x"].cpu().numpy() - buf.frame.head, orc.sample(u)["indices"])
+    nxt = cap
+    for r in range(4):
+        err = (rs.rand(B) * 1.5).astype(np.float32)
+        # the caller is one sample point ahead: the appends are recorded and the next draw is
+        # prepared BEFORE this minibatch's errors exist
+        for i in range(extra):
+            buf.append(nxt + i)
+        assert len(buf._pend_x) > 1024
+        u = rs.random_sample(B)
+        out, finish = buf.sample_device(B, u01=u, split=True)
+        buf.update_errors_device(torch.from_numpy(err).to(dev), 0, (0 + eps) ** alpha, 1,
+                                 (1 + eps) ** alpha, eps, alpha, pow_mode=mode)
+        finish()
+        # the reference's order
+        wv, wt = oracle.priority_from_errors_f32(err, 0, 1, eps, alpha)
+        orc.set_last_priority(wv, wt)
+        for i in range(extra):
+            orc.append(nxt + i)
+        nxt += extra
+        want = orc.sample(u)
+        np.testing.assert_array_equal(out["x"].cpu().numpy() - buf.frame.head, want["indices"])
+        np.testing.assert_array_equal(out["pri"].cpu().numpy(), want["priorities"])
+    err = (rs.rand(B) * 1.5).astype(np.float32)
+    buf.update_errors_device(torch.from_numpy(err).to(dev), 0, (0 + eps) ** alpha, 1,
+                             (1 + eps) ** alpha, eps, alpha, pow_mode=mode)
+    orc.set_last_priority(*oracle.priority_from_errors_f32(err, 0, 1, eps, alpha))
+    st, so = buf.root_stats(), orc.stats()
+    assert st[0] == so["sum"] and st[1] == so["min"] and st[2] == so["max_priority"]
+
+
 def test_update_errors_f32_correctly_rounded_mode_is_within_one_ulp(dev):
     """pow_mode 0 (rounds 1-2): the correctly rounded power, <= 1 ulp from libm's."""
     from pfrl_amd.collections.prioritized import PrioritizedBuffer

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Another build of the HIP library for A/B measurements on the GPU box:
 #   bash tools/build_variant.sh NAME [extra hipcc flags...]   ->  tools/variants/libpfrl_amd_NAME.so
-#   PFRL_AMD_LIB=tools/variants/libpfrl_amd_NAME.so python bench.py ...
+#   PFRL_AMD_LIB=tools/variants/libpfrl_amd_NAME.so python bench.py --allow-lib-override ...
 set -e
 cd "$(dirname "$0")/.."
 NAME=$1; shift

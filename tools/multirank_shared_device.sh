@@ -8,7 +8,7 @@ R=$(pwd)
 O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-export HSA_ENABLE_IPC_MODE_LEGACY=0 NCCL_DEBUG=WARN
+export HSA_ENABLE_IPC_MODE_LEGACY=0
 for W in 2 4; do
   timeout 240 python $R/tools/rccl_multirank_check.py --world $W --shared-device --out $O/rccl_multirank_w$W.json > $O/rccl_multirank_w$W.log 2>&1
   echo "rccl_multirank_check world=$W rc=$?"; tail -4 $O/rccl_multirank_w$W.log
@@ -27,11 +27,11 @@ except Exception as e:
     print('  no line:', e); print(open('$O/$name.err').read()[-1500:])
 PY
 }
-ARGS="--steps 6 --warmup 3 --num-envs 64 --capacity 20000 --no-cpu-baseline --no-also --no-data-path-only"
+ARGS="--steps 6 --warmup 3 --num-envs 64 --capacity 100000 --no-cpu-baseline --no-also --no-data-path-only"
 PORT=29521 run bench_dqn_w2 X=1
 PORT=29522 run bench_dqn_w2_refused PFRL_RCCL_SHARED_DEVICE=0
 PORT=29523 run bench_dqn_w2_split PFRL_FORCE_SPLIT_GRAPH=1 PFRL_GRAPH_COLLECTIVE=0
-ARGS="--algo ppo --steps 16 --warmup 16 --num-envs 32 --no-cpu-baseline"
+ARGS="--algo ppo --steps 128 --warmup 128 --num-envs 64 --no-cpu-baseline"
 PORT=29524 run bench_ppo_w2 X=1
 ARGS="--algo sac --steps 20 --warmup 10 --num-envs 16 --capacity 20000 --no-cpu-baseline"
 PORT=29525 run bench_sac_w2 X=1

@@ -37,22 +37,27 @@ def _free_port():
     return port
 
 
-def worker(rank, world, port, out_dir, shared=False):
+def worker(rank, world, port, out_dir, shared=False, pattern="D"):
     sys.path.insert(0, ROOT)
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if shared:
         os.environ["PFRL_RCCL_SHARED_DEVICE"] = "1"     # (rccl.py: one NCCL_HOSTID per rank)
+    import faulthandler
+
     import torch.distributed as dist
 
     from pfrl_amd import distributed, rccl
 
+    faulthandler.enable()
     res = {"rank": rank, "world": world, "steps": []}
 
     def step(name, t0):
         torch.cuda.synchronize()
         res["steps"].append({"name": name, "s": round(time.time() - t0, 3)})
+        sys.stderr.write("[rank %d] %s ok (%.2f s)\n" % (rank, name, time.time() - t0))
+        sys.stderr.flush()
 
     distributed.init_process_group_from_env()            # gloo control plane (default)
     assert dist.get_backend() == "gloo"
@@ -91,8 +96,14 @@ def worker(rank, world, port, out_dir, shared=False):
     res["captured_collectives_work"] = bool(distributed.captured_collectives_work(dev))
     step("capture_probe", t0)
 
-    # one graph: all-reduce on the capture stream + grouped all-gathers forked to the side stream
-    if res["captured_collectives_work"]:
+    # one graph holding collectives, in the shape `pattern` names:
+    #   A  all-reduce on the capture stream
+    #   B  A + a grouped pair of all-gathers, all on the capture stream
+    #   C  fork: two separate all-gathers on the side stream, all-reduce on the capture stream, join
+    #   D  fork: GROUPED all-gathers on the side stream, all-reduce on the capture stream, join
+    #   E  fork: grouped all-gathers on the side stream only, join
+    #   F  fork: grouped all-gathers AND the all-reduce on the side stream, join
+    if res["captured_collectives_work"] and pattern != "none":
         t0 = time.time()
         x = torch.zeros(4096, device=dev)
         red = torch.zeros(4096, device=dev)
@@ -100,27 +111,48 @@ def worker(rank, world, port, out_dir, shared=False):
         go1, go2 = torch.zeros(world * 512, device=dev), torch.zeros(world * 512, device=dev)
         s = torch.cuda.Stream(dev)
         s.wait_stream(torch.cuda.current_stream(dev))
+
+        def gathers(stream, grouped):
+            if grouped:
+                with comm.group():
+                    comm.all_gather(go1, gi, stream=stream)
+                    comm.all_gather(go2, gi, stream=stream)
+            else:
+                comm.all_gather(go1, gi, stream=stream)
+                comm.all_gather(go2, gi, stream=stream)
+
         with torch.cuda.stream(s):
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, stream=s, capture_error_mode="thread_local"):
                 x.add_(float(rank + 1))
                 gi.copy_(x[:512])
-                comm.side.wait_stream(torch.cuda.current_stream(dev))
-                with torch.cuda.stream(comm.side):
-                    with comm.group():
-                        comm.all_gather(go1, gi, stream=comm.side)
-                        comm.all_gather(go2, gi, stream=comm.side)
                 red.copy_(x)
-                comm.all_reduce(red, average=False)
-                torch.cuda.current_stream(dev).wait_stream(comm.side)
+                if pattern == "A":
+                    comm.all_reduce(red, average=False)
+                elif pattern == "B":
+                    comm.all_reduce(red, average=False)
+                    gathers(None, True)
+                else:
+                    comm.side.wait_stream(torch.cuda.current_stream(dev))
+                    with torch.cuda.stream(comm.side):
+                        gathers(comm.side, pattern in ("D", "E", "F"))
+                        if pattern == "F":
+                            comm.all_reduce(red, average=False, stream=comm.side)
+                    if pattern in ("C", "D"):
+                        comm.all_reduce(red, average=False)
+                    torch.cuda.current_stream(dev).wait_stream(comm.side)
+            sys.stderr.write("[rank %d] pattern %s captured\n" % (rank, pattern))
+            sys.stderr.flush()
             for _ in range(100):
                 g.replay()
         torch.cuda.current_stream(dev).wait_stream(s)
         torch.cuda.synchronize()
-        assert bool((red == 100.0 * world * (world + 1) / 2).all()), "captured all_reduce"
-        want = (torch.arange(world, dtype=torch.float32) + 1) * 100.0
-        assert torch.equal(go1.view(world, 512)[:, 0].cpu(), want), "captured all_gather"
-        assert torch.equal(go1, go2)
+        if pattern != "E":
+            assert bool((red == 100.0 * world * (world + 1) / 2).all()), "captured all_reduce"
+        if pattern != "A":
+            want = (torch.arange(world, dtype=torch.float32) + 1) * 100.0
+            assert torch.equal(go1.view(world, 512)[:, 0].cpu(), want), "captured all_gather"
+            assert torch.equal(go1, go2)
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         with torch.cuda.stream(s):
             ev0.record(s)
@@ -128,8 +160,9 @@ def worker(rank, world, port, out_dir, shared=False):
                 g.replay()
             ev1.record(s)
         torch.cuda.synchronize()
+        res["captured_graph_pattern"] = pattern
         res["captured_graph_us_per_replay"] = round(ev0.elapsed_time(ev1) * 1e3 / 200, 2)
-        step("captured_graph_100_replays", t0)
+        step("captured_graph_%s_100_replays" % pattern, t0)
 
     # low-rank exchange == flat all-reduce == one process on the concatenated batch
     t0 = time.time()
@@ -183,6 +216,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--world", type=int, default=2)
     ap.add_argument("--out", default=None)
+    ap.add_argument("--graph-pattern", default="D", choices=["A", "B", "C", "D", "E", "F", "none"],
+                    help="shape of the captured graph (see worker()); D = the data-parallel update's")
     ap.add_argument("--shared-device", action="store_true",
                     help="all ranks on ONE device: every rank poses as its own host (NCCL_HOSTID), so "
                          "RCCL's duplicate-GPU check passes and the ranks talk over its socket "
@@ -192,14 +227,15 @@ def main():
     import tempfile
 
     n_dev = torch.cuda.device_count()
-    summary = {"devices_visible": n_dev, "world": args.world, "shared_device": args.shared_device}
+    summary = {"devices_visible": n_dev, "world": args.world, "shared_device": args.shared_device,
+               "graph_pattern": args.graph_pattern}
     if n_dev < args.world and not args.shared_device:
         summary["ok"] = False
         summary["reason"] = "only %d HIP device(s) visible" % n_dev
     else:
         d = tempfile.mkdtemp()
         try:
-            mp.spawn(worker, args=(args.world, _free_port(), d, args.shared_device), nprocs=args.world, join=True)
+            mp.spawn(worker, args=(args.world, _free_port(), d, args.shared_device, args.graph_pattern), nprocs=args.world, join=True)
             ranks = [json.load(open(os.path.join(d, "rank%d.json" % r))) for r in range(args.world)]
             p = [np.load(os.path.join(d, "lowrank%d.npy" % r)) for r in range(args.world)]
             summary["replicas_identical"] = bool(all(np.array_equal(p[0], q) for q in p[1:]))
