@@ -687,6 +687,21 @@ def assemble_result(args, world, N, elapsed, n_updates, t_fill, workload, roofli
             roofline["mfma"] = {"step_flops": int(fl), "achieved": round(tf, 2),
                                 "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                                 "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 4)}
+            # what fp32 arithmetic + the reference's schedule allow at all: the N / update_interval
+            # updates of a batched step are DEPENDENT (each reads the parameters the previous one
+            # wrote, pfrl/agents/dqn.py:516-549, pfrl/replay_buffer.py:329-356), so even with
+            # every launch at the f32 MFMA peak a step takes step_flops / peak
+            per_update = (fl - N * NATURE_FWD_FLOPS) / max(1, N // args.update_interval)
+            floor_us = per_update / (MFMA_F32_PEAK_TFLOPS * 1e12) * 1e6
+            ceiling = N / (fl / (MFMA_F32_PEAK_TFLOPS * 1e12))
+            roofline["mfma"].update({
+                "flop_per_update": int(per_update), "floor_us_per_update": round(floor_us, 2),
+                "parity_ceiling_env_steps_s": int(ceiling),
+                "frac_of_parity_ceiling": round(N / (ms * 1e-3) / ceiling, 4),
+                "ceiling_what": "env-steps/s if every launch of the step ran at the f32 MFMA peak under "
+                                "the reference's schedule (B = %d, %d dependent updates per %d-env step, "
+                                "fp32 as the parity contract demands); the north star's 1 M env-steps/s "
+                                "is above it" % (args.minibatch, N // args.update_interval, N)})
         if args.algo == "ppo":
             # PPO is bound by the f32 MFMA trunk at update size (B = 16384), not by the gather the
             # HBM block above describes (3 % of the device time): rollout FLOPs / time / peak
@@ -884,6 +899,37 @@ def reference_baseline_ppo(args, num_envs=512, steps=16):
                   "full size: profiles/r04_reference_cpu_baseline_ppo_gpubox.json"
                   % (d["num_envs"], d["rollout_steps"], d["update_interval"], d["minibatch"],
                      d["end_to_end"]["env_steps"], d["end_to_end"]["seconds"], d["cores"]),
+    }
+
+
+def reference_baseline_other(args, algo, num_envs, seconds=8.0):
+    """The reference's Rainbow / SAC (gpu=-1; tools/reference_cpu_baseline.py --algo rainbow|sac, the
+    constructions of train_rainbow.py:110-159 / train_soft_actor_critic.py:172-243) on this box's host
+    cores from the same oracle/_ref/ copy: a bounded sample of whole env steps with their updates."""
+    import subprocess
+
+    ref_dir = os.path.join(ROOT, "oracle", "_ref")
+    if not os.path.isdir(os.path.join(ref_dir, "pfrl")):
+        return None
+    env = dict(os.environ, PFRL_REFERENCE=ref_dir, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "reference_cpu_baseline.py"), "--algo", algo,
+           "--num-envs", str(num_envs), "--seconds", str(seconds), "--prefill", "5120",
+           "--threads", str(args.cpu_baseline_threads)]
+    try:
+        out = subprocess.run(cmd, env=env, cwd="/tmp", capture_output=True, text=True, timeout=600)
+        d = json.loads(out.stdout.strip().splitlines()[-1])
+    except Exception as e:     # the baseline must never cost the line its GPU numbers
+        sys.stderr.write("reference %s cpu baseline failed: %r\n" % (algo, e))
+        return None
+    return {
+        "value": d["end_to_end"]["value"], "unit": "env-steps/s", "cores": d["cores"],
+        "kind": "reference", "host_cores": d["host_cores"],
+        "sample": "pfnet/pfrl itself (oracle/_ref), gpu=-1, %s on %d in-process synthetic envs, replay "
+                  "capacity 1e5 holding %d transitions at the start: %d env-steps (%d updates) in %.0f s "
+                  "with %d torch threads"
+                  % (d["what"].split("pfrl ")[1].split(" (")[0], d["num_envs"], d["replay_len_at_start"],
+                     d["end_to_end"]["env_steps"], d["end_to_end"]["updates"],
+                     d["end_to_end"]["seconds"], d["cores"]),
     }
 
 
@@ -1294,6 +1340,15 @@ def main():
                 pref = reference_baseline_ppo(args)
                 if pref is not None:
                     out["also"]["ppo"]["cpu_baseline"] = pref
+            for algo, n_envs in (("rainbow", 256), ("sac", 64)):
+                if algo in out.get("also", {}):
+                    oref = reference_baseline_other(args, algo, n_envs)
+                    if oref is not None:
+                        out["also"][algo]["cpu_baseline"] = oref
+        if not args.no_cpu_baseline and world == 1 and args.algo in ("rainbow", "sac"):
+            oref = reference_baseline_other(args, args.algo, args.num_envs)
+            if oref is not None:
+                out["cpu_baseline"] = oref
         if not args.no_cpu_baseline and world == 1 and args.algo == "ppo":
             pref = reference_baseline_ppo(args, num_envs=args.num_envs)
             if pref is not None:
@@ -1315,11 +1370,19 @@ def main():
         _WATCHDOG[0].printed = True
     _tick("teardown")
     if torch.distributed.is_initialized():
-        from pfrl_amd import rccl
-
+        # The communicator is NOT destroyed: ncclCommDestroy waits for every captured graph that
+        # holds one of its collectives to be released first (round 5, two live ranks: the check
+        # tool sat in it until its timeout with a graph still referenced), and nothing here needs
+        # an orderly RCCL shutdown -- the device is drained, the ranks meet at a barrier, and the
+        # process leaves without running finalizers.
         torch.cuda.synchronize()
-        rccl.destroy_all()
-        torch.distributed.destroy_process_group()
+        try:
+            torch.distributed.barrier()
+        except Exception:       # noqa: BLE001 -- a peer that already left must not cost the status
+            pass
+        os.close(result_fd)
+        sys.stderr.flush()
+        os._exit(0)
     if _WATCHDOG[0] is not None:
         _WATCHDOG[0].done = True
     os.close(result_fd)

@@ -214,7 +214,9 @@ class _SideJoin:
         self.side, self.device = side, device
 
     def wait(self):
-        torch.cuda.current_stream(self.device).wait_stream(self.side)
+        cur = torch.cuda.current_stream(self.device)
+        if cur != self.side:
+            cur.wait_stream(self.side)
 
 
 class GradientAllReducer:
@@ -370,12 +372,13 @@ class GradientAllReducer:
         self._pending[id(target)] = (None, None)     # (claims the parameter: no early all-reduce)
         self._deferred.pop(id(target), None)
         if self._comm is not None and dy.is_cuda:
-            side = self._comm.side
+            side = self._exchange_stream(dy.device)
             # outputs belong to the caller's stream (allocated before the fork), temporaries to the
             # side stream: no block changes streams while a kernel of the other may still use it
             dw = torch.empty(tuple(target.shape), dtype=torch.float32, device=dy.device)
             db = torch.empty(target.shape[0], dtype=torch.float32, device=dy.device)
-            side.wait_stream(torch.cuda.current_stream(dy.device))
+            if side != torch.cuda.current_stream(dy.device):
+                side.wait_stream(torch.cuda.current_stream(dy.device))
             with torch.cuda.stream(side):
                 d, xx, dy_all, x_all = prepared()
                 with self._comm.group():
@@ -405,6 +408,23 @@ class GradientAllReducer:
         self._lowrank.append((target, bias, works, None, (d, xx, dy_all, x_all)))
         return True
 
+    def _exchange_stream(self, device):
+        """Where an early exchange is enqueued: the communicator's side stream (beside the
+        backward launches that follow on the caller's) -- except inside a graph capture, where it
+        stays ON the capturing stream.  Measured in round 5 with a live peer (two ranks, RCCL's
+        socket transport; tools/rccl_multirank_check.py --graph-pattern A..F,
+        profiles/r05_rccl_multirank.txt): collectives captured on the capture's origin stream
+        replay correctly (one, several, grouped), while ANY collective on a stream that joined the
+        capture through an event wait takes the process down with SIGSEGV inside
+        hipStreamEndCapture -- grouped or not, with or without other collectives on the origin
+        stream.  A captured update therefore gives up the overlap (PFRL_DP_FORK_IN_CAPTURE=1
+        restores the fork for a stack where it works)."""
+        cur = torch.cuda.current_stream(device)
+        if (torch.cuda.is_current_stream_capturing()
+                and os.environ.get("PFRL_DP_FORK_IN_CAPTURE", "0") != "1"):
+            return cur
+        return self._comm.side
+
     def _finish_lowrank(self):
         for weight, bias, works, done, keep in self._lowrank:
             for w in works:
@@ -423,9 +443,11 @@ class GradientAllReducer:
         if self._comm is not None and t.is_cuda:
             # beside the compute stream: fork, enqueue, and let wait() join
             cur = torch.cuda.current_stream(t.device)
-            self._comm.side.wait_stream(cur)
-            self._comm.all_reduce(t, average=True, stream=self._comm.side)
-            return _SideJoin(self._comm.side, t.device)
+            side = self._exchange_stream(t.device)
+            if side != cur:
+                side.wait_stream(cur)
+            self._comm.all_reduce(t, average=True, stream=side)
+            return _SideJoin(side, t.device)
         if dist.get_backend() == "nccl":
             return dist.all_reduce(t, op=dist.ReduceOp.AVG, async_op=True)
         if t.is_cuda:

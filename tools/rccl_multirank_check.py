@@ -208,8 +208,10 @@ def worker(rank, world, port, out_dir, shared=False, pattern="D"):
         json.dump(res, f)
     dist.barrier()
     torch.cuda.synchronize()
-    rccl.destroy_all()
-    dist.destroy_process_group()
+    # (no ncclCommDestroy: it waits for every captured graph holding a collective of the
+    # communicator to be released; the process simply leaves)
+    sys.stderr.flush()
+    os._exit(0)
 
 
 def main():

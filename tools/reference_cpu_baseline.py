@@ -44,7 +44,7 @@ def main():
     ap.add_argument("--capacity", type=int, default=10 ** 5)
     ap.add_argument("--prefill", type=int, default=20000)
     ap.add_argument("--out", default=None)
-    ap.add_argument("--algo", choices=["dqn", "ppo"], default="dqn",
+    ap.add_argument("--algo", choices=["dqn", "ppo", "rainbow", "sac"], default="dqn",
                     help="ppo = BASELINE configs[3]: the reference's PPO (examples/atari/train_ppo_ale.py "
                          "model and hyperparameters), --num-envs envs x --ppo-steps steps per rollout, "
                          "minibatch = rollout / 4, 4 epochs; timed: whole rollouts including their update")
@@ -108,6 +108,10 @@ def main():
 
     if args.algo == "ppo":
         return ppo_baseline(args, pfrl, torch, SyntheticAtari, phi, N, n_actions, cores, thread_counts)
+    if args.algo == "rainbow":
+        return rainbow_baseline(args, pfrl, torch, SyntheticAtari, phi, N, n_actions, cores, thread_counts)
+    if args.algo == "sac":
+        return sac_baseline(args, pfrl, torch, N, cores, thread_counts)
 
     class ZeroFlopQ(torch.nn.Module):
         """Q-values that do not depend on the observation: one learnable row."""
@@ -263,6 +267,169 @@ def ppo_baseline(args, pfrl, torch, SyntheticAtari, phi, N, n_actions, cores, th
         "end_to_end": {"value": round(args.ppo_rollouts * N * T / el, 2), "unit": "env-steps/s",
                        "seconds": round(el, 1), "env_steps": args.ppo_rollouts * N * T,
                        "updates": agent.n_updates},
+        "torch": torch.__version__, "numpy": np.__version__,
+    }
+    print(json.dumps(out))
+    if args.out:
+        with open(args.out, "w") as f:
+            json.dump(out, f, indent=1)
+
+
+def _timed_steps(one_step, obss, seconds, N):
+    steps, t0 = 0, time.perf_counter()
+    while True:
+        obss = one_step(obss)
+        steps += 1
+        el = time.perf_counter() - t0
+        if el >= seconds:
+            return steps, el, obss
+
+
+def rainbow_baseline(args, pfrl, torch, SyntheticAtari, phi, N, n_actions, cores, thread_counts):
+    """The reference's Rainbow (examples/atari/reproduction/rainbow/train_rainbow.py:110-159, gpu=-1):
+    CategoricalDoubleDQN on DistributionalDuelingDQN(51 atoms) with factorised NoisyNet,
+    PrioritizedReplayBuffer(alpha 0.5, beta0 0.4, num_steps 3, normalize_by_max='memory'),
+    Adam(6.25e-5, eps 1.5e-4), B = 32, update_interval 4 -- BASELINE configs[2] on N in-process
+    synthetic envs, capacity cut to --capacity for host memory."""
+    from pfrl import agents, explorers, replay_buffers
+    from pfrl.q_functions import DistributionalDuelingDQN
+
+    th = thread_counts[0]
+    torch.set_num_threads(th)
+    pfrl.utils.set_random_seed(int(args.seeds.split(",")[0]))
+    q_func = DistributionalDuelingDQN(n_actions, 51, -10, 10)
+    pfrl.nn.to_factorized_noisy(q_func, sigma_scale=0.5)
+    opt = torch.optim.Adam(q_func.parameters(), 6.25e-5, eps=1.5 * 10 ** -4)
+    rbuf = replay_buffers.PrioritizedReplayBuffer(args.capacity, alpha=0.5, beta0=0.4,
+                                                  betasteps=2 * 10 ** 6, num_steps=3,
+                                                  normalize_by_max="memory")
+    agent = agents.CategoricalDoubleDQN(
+        q_func, opt, rbuf, gpu=-1, gamma=0.99, explorer=explorers.Greedy(), minibatch_size=32,
+        replay_start_size=args.capacity, target_update_interval=32000, update_interval=4,
+        batch_accumulator="mean", phi=phi)
+    env = SyntheticAtari()
+    obss = env.reset()
+
+    def one_step(obss):
+        actions = agent.batch_act(obss)
+        obss, rs, dones, infos = env.step(actions)
+        agent.batch_observe(obss, rs, dones, [False] * N)
+        return env.reset([not d for d in dones])
+
+    t0 = time.perf_counter()
+    while len(rbuf) < args.prefill:
+        obss = one_step(obss)
+    t_fill = time.perf_counter() - t0
+    agent.replay_updater.replay_start_size = args.prefill
+    obss = one_step(obss)                       # untimed: first updates
+    u0 = agent.optim_t
+    steps, el, obss = _timed_steps(one_step, obss, args.seconds, N)
+    out = {
+        "what": "reference pfnet/pfrl Rainbow (gpu=-1) on the synthetic configs[2] workload",
+        "reference_from": REFERENCE, "host_cores": cores, "torch_threads": th, "cores": th,
+        "num_envs": N, "capacity": args.capacity, "replay_len_at_start": args.prefill,
+        "prefill_s": round(t_fill, 1),
+        "end_to_end": {"value": round(steps * N / el, 2), "unit": "env-steps/s",
+                       "seconds": round(el, 1), "env_steps": steps * N,
+                       "updates": agent.optim_t - u0},
+        "torch": torch.__version__, "numpy": np.__version__,
+    }
+    print(json.dumps(out))
+    if args.out:
+        with open(args.out, "w") as f:
+            json.dump(out, f, indent=1)
+
+
+def sac_baseline(args, pfrl, torch, N, cores, thread_counts):
+    """The reference's SAC (examples/mujoco/reproduction/soft_actor_critic/
+    train_soft_actor_critic.py:172-243, gpu=-1): 256-256 MLP squashed-Gaussian policy and twin Q,
+    Adam(3e-4), B = 256, update_interval 1, learned temperature -- BASELINE configs[4] on N
+    in-process Humanoid-shaped synthetic envs (obs f32[376] ~ N(0,1), action f32[17], reward
+    ~ N(0,1), done w.p. 1/1000), capacity cut to --capacity for host memory."""
+    from pfrl import agents, replay_buffers
+    from torch import distributions as D
+    from torch import nn
+
+    obs_size, action_size = 376, 17
+    th = thread_counts[0]
+    torch.set_num_threads(th)
+    pfrl.utils.set_random_seed(int(args.seeds.split(",")[0]))
+
+    class SyntheticVectorObs(pfrl.env.VectorEnv):
+        def __init__(self):
+            self.num_envs = N
+            self.rs = np.random.RandomState(1000)
+
+        def _obs(self):
+            return list(self.rs.randn(N, obs_size).astype(np.float32))
+
+        def reset(self, mask=None):
+            return self._obs()
+
+        def step(self, actions):
+            rews = [float(r) for r in self.rs.randn(N)]
+            dones = [bool(d) for d in self.rs.rand(N) < 1.0 / 1000]
+            return self._obs(), rews, dones, [{} for _ in range(N)]
+
+        def seed(self, seeds=None):
+            pass
+
+        def close(self):
+            pass
+
+    def squashed_diagonal_gaussian_head(x):
+        mean, log_scale = torch.chunk(x, 2, dim=1)
+        var = torch.exp(torch.clamp(log_scale, -20.0, 2.0) * 2)
+        base = D.Independent(D.Normal(loc=mean, scale=torch.sqrt(var)), 1)
+        return D.transformed_distribution.TransformedDistribution(
+            base, [D.transforms.TanhTransform(cache_size=1)])
+
+    policy = nn.Sequential(nn.Linear(obs_size, 256), nn.ReLU(), nn.Linear(256, 256), nn.ReLU(),
+                           nn.Linear(256, action_size * 2), pfrl.nn.lmbda.Lambda(squashed_diagonal_gaussian_head))
+    for i in (0, 2, 4):
+        nn.init.xavier_uniform_(policy[i].weight)
+
+    def make_q():
+        q = nn.Sequential(pfrl.nn.ConcatObsAndAction(), nn.Linear(obs_size + action_size, 256),
+                          nn.ReLU(), nn.Linear(256, 256), nn.ReLU(), nn.Linear(256, 1))
+        for i in (1, 3, 5):
+            nn.init.xavier_uniform_(q[i].weight)
+        return q, torch.optim.Adam(q.parameters(), lr=3e-4)
+
+    q1, q1opt = make_q()
+    q2, q2opt = make_q()
+    rbuf = replay_buffers.ReplayBuffer(args.capacity)
+    agent = agents.SoftActorCritic(
+        policy, q1, q2, torch.optim.Adam(policy.parameters(), lr=3e-4), q1opt, q2opt, rbuf,
+        gamma=0.99, gpu=-1, replay_start_size=1 << 62, minibatch_size=256, update_interval=1,
+        burnin_action_func=lambda: np.random.uniform(-1, 1, size=action_size).astype(np.float32),
+        entropy_target=-action_size, temperature_optimizer_lr=3e-4)
+    env = SyntheticVectorObs()
+    obss = env.reset()
+
+    def one_step(obss):
+        actions = agent.batch_act(obss)
+        obss, rs, dones, infos = env.step(actions)
+        agent.batch_observe(obss, rs, dones, [False] * N)
+        return obss
+
+    t0 = time.perf_counter()
+    while len(rbuf) < args.prefill:
+        obss = one_step(obss)
+    t_fill = time.perf_counter() - t0
+    agent.replay_start_size = args.prefill
+    agent.replay_updater.replay_start_size = args.prefill
+    obss = one_step(obss)
+    u0 = agent.n_policy_updates
+    steps, el, obss = _timed_steps(one_step, obss, args.seconds, N)
+    out = {
+        "what": "reference pfnet/pfrl SoftActorCritic (gpu=-1) on the synthetic configs[4] workload",
+        "reference_from": REFERENCE, "host_cores": cores, "torch_threads": th, "cores": th,
+        "num_envs": N, "capacity": args.capacity, "replay_len_at_start": args.prefill,
+        "prefill_s": round(t_fill, 1),
+        "end_to_end": {"value": round(steps * N / el, 2), "unit": "env-steps/s",
+                       "seconds": round(el, 1), "env_steps": steps * N,
+                       "updates": agent.n_policy_updates - u0},
         "torch": torch.__version__, "numpy": np.__version__,
     }
     print(json.dumps(out))
