@@ -957,8 +957,10 @@ def collective_microbench(agent, device, iters=50):
             torch.cuda.synchronize()
             out["flat_all_reduce"] = round(ev[0].elapsed_time(ev[1]) * 1e3 / iters, 2)
             out["flat_bytes"] = int(buf.numel() * 4)
-        if comm is not None:
-            B = getattr(agent, "minibatch_size", 32)
+        from pfrl_amd import distributed
+
+        B = getattr(agent, "minibatch_size", 32)
+        if comm is not None and distributed.lowrank_pays(B, 512, 3136, comm.world):
             G = comm.world
             dy, x = torch.zeros(B * 512, device=device), torch.zeros(B * 3136, device=device)
             dya, xa = torch.zeros(G * B * 512, device=device), torch.zeros(G * B * 3136, device=device)

@@ -16,7 +16,8 @@ int64_t pfrl_nt_min_bytes();
 // bench.py roofline support (defined in replay.hip): when profiling is enabled,
 // returns a start/stop event pair to attach to ONE dispatch with
 // hipExtLaunchKernelGGL; both are nullptr otherwise.
-enum { PFRL_PROFILE_BATCH_EXPERIENCES = 0, PFRL_PROFILE_BATCH_STATES_U8 = 1 };
+enum { PFRL_PROFILE_BATCH_EXPERIENCES = 0, PFRL_PROFILE_BATCH_STATES_U8 = 1, PFRL_PROFILE_GAE_SCAN = 2,
+       PFRL_PROFILE_ADV_STATS = 3 };
 void pfrl_profile_events(int kind, int64_t units, hipEvent_t *start, hipEvent_t *stop);
 
 #define PFRL_CHECK_ARG(cond, msg)      \

@@ -3,7 +3,13 @@
 // Layout [T][N] with the env index minor, so the 64 lanes of a wave read 64
 // consecutive envs of one time step (coalesced) and each lane owns one env's
 // sequential scan (pfrl/agents/ppo.py:36-47 is inherently sequential in t).
+#include <hip/hip_ext.h>
+
 #include "common.h"
+
+#include <stdlib.h>
+
+#include <type_traits>
 
 namespace {
 
@@ -49,6 +55,100 @@ __global__ __launch_bounds__(kThreads) void k_gae_scan(int64_t T, int64_t N,
             adv = __dadd_rn(td, ga);
             adv_out[i] = (float)adv;
             vt_out[i] = (float)__dadd_rn(adv, (double)v_pred[i]);
+        }
+    }
+}
+
+// The same scan with the rollout staged through LDS (the form pfrl_gae_scan launches).  The scan
+// of pfrl/agents/ppo.py:36-47 is sequential in t and its rounding is part of the parity contract
+// (adv = fl(td + fl(gl * adv))), so it cannot become an associative prefix scan; what CAN leave
+// the dependent chain is everything else.  A workgroup owns E = 16 envs:
+//   1. all 256 threads load the five input columns of the E envs for every t (independent,
+//      coalesced in 64..128-byte runs) and compute td[t][e] -- the part with the memory latency --
+//      into LDS, together with v_pred and the cut flag;
+//   2. one lane per env runs the recurrence out of LDS, 16 steps at a time through registers: the
+//      chain is one multiply and one add per step, no load in it;
+//   3. all threads write adv and v_teacher back, coalesced.
+// One lane per env in global memory (k_gae_scan above) was 8 waves on the chip at N = 512 walking
+// 128 dependent iterations of 5 global loads each; here N / 16 workgroups issue all loads at once.
+constexpr int kGaeE = 16, kGaeChunk = 16;
+
+template <int MODE>
+__global__ __launch_bounds__(kThreads) void k_gae_scan_lds(
+    int T, int64_t N, const double *__restrict__ reward, const float *__restrict__ v_pred,
+    const float *__restrict__ next_v_pred, const uint8_t *__restrict__ nonterminal,
+    const uint8_t *__restrict__ cut, double gamma, double lambd, float *__restrict__ adv_out,
+    float *__restrict__ vt_out) {
+    using acc_t = typename std::conditional<MODE == 0, float, double>::type;
+    extern __shared__ unsigned char lds_raw[];
+    acc_t *s_td = reinterpret_cast<acc_t *>(lds_raw);                 // [T][E], becomes adv
+    float *s_v = reinterpret_cast<float *>(s_td + (size_t)T * kGaeE);   // [T][E]
+    uint8_t *s_cut = reinterpret_cast<uint8_t *>(s_v + (size_t)T * kGaeE);
+    const int64_t e0 = (int64_t)blockIdx.x * kGaeE;
+    const int total = T * kGaeE;
+    const double gl = __dmul_rn(gamma, lambd);
+    for (int q = threadIdx.x; q < total; q += kThreads) {
+        const int t = q / kGaeE, j = q % kGaeE;
+        const int64_t e = e0 + j;
+        if (e >= N) continue;
+        const int64_t i = (int64_t)t * N + e;
+        const double gn = nonterminal[i] ? gamma : __dmul_rn(gamma, 0.0);
+        const float v = v_pred[i];
+        const float prod = __fmul_rn((float)gn, next_v_pred[i]);
+        if (MODE == 0) {
+            const float s1 = __fadd_rn((float)reward[i], prod);
+            s_td[q] = (acc_t)__fsub_rn(s1, v);
+        } else {
+            const double s1 = __dadd_rn(reward[i], (double)prod);
+            s_td[q] = (acc_t)__dsub_rn(s1, (double)v);
+        }
+        s_v[q] = v;
+        s_cut[q] = cut[i];
+    }
+    __syncthreads();
+    if (threadIdx.x < kGaeE && e0 + threadIdx.x < N) {
+        const int j = threadIdx.x;
+        const acc_t glx = (acc_t)gl;
+        acc_t adv = (acc_t)0;
+        for (int t1 = T; t1 > 0; t1 -= kGaeChunk) {
+            acc_t td[kGaeChunk];
+            uint8_t c[kGaeChunk];
+#pragma unroll
+            for (int u = 0; u < kGaeChunk; ++u) {
+                const int t = t1 - 1 - u;
+                const int q = (t >= 0 ? t : 0) * kGaeE + j;
+                td[u] = s_td[q];
+                c[u] = s_cut[q];
+            }
+#pragma unroll
+            for (int u = 0; u < kGaeChunk; ++u) {
+                if (t1 - 1 - u < 0) break;
+                if (c[u]) adv = (acc_t)0;
+                if (MODE == 0) adv = (acc_t)__fadd_rn((float)td[u], __fmul_rn((float)glx, (float)adv));
+                else adv = (acc_t)__dadd_rn((double)td[u], __dmul_rn((double)glx, (double)adv));
+                td[u] = adv;
+            }
+#pragma unroll
+            for (int u = 0; u < kGaeChunk; ++u) {
+                const int t = t1 - 1 - u;
+                if (t >= 0) s_td[t * kGaeE + j] = td[u];
+            }
+        }
+    }
+    __syncthreads();
+    for (int q = threadIdx.x; q < total; q += kThreads) {
+        const int t = q / kGaeE, j = q % kGaeE;
+        const int64_t e = e0 + j;
+        if (e >= N) continue;
+        const int64_t i = (int64_t)t * N + e;
+        if (MODE == 0) {
+            const float a = (float)s_td[q];
+            adv_out[i] = a;
+            vt_out[i] = __fadd_rn(a, s_v[q]);
+        } else {
+            const double a = (double)s_td[q];
+            adv_out[i] = (float)a;
+            vt_out[i] = (float)__dadd_rn(a, (double)s_v[q]);
         }
     }
 }
@@ -271,15 +371,36 @@ extern "C" int pfrl_gae_scan(int64_t T, int64_t N, const double *reward, const f
                              float *v_teacher, void *stream) {
     PFRL_CHECK_ARG(T >= 0 && N >= 0, "pfrl_gae_scan: bad shape");
     if (T == 0 || N == 0) return 0;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    pfrl_profile_events(PFRL_PROFILE_GAE_SCAN, T * N, &e0, &e1);
+    // rollouts that fit a workgroup's LDS (T * 16 envs * 9 or 13 bytes <= 64 KB: T <= 455 / 315)
+    // take the LDS-staged form; PFRL_GAE_LDS=0 keeps the lane-per-env loop for A/B runs
+    static const bool use_lds = [] {
+        const char *e = getenv("PFRL_GAE_LDS");
+        return !(e != nullptr && e[0] == '0');
+    }();
+    const size_t lds = (size_t)T * kGaeE * ((mode == 0 ? 4 : 8) + 4 + 1);
+    if (use_lds && lds <= 64 * 1024 && T < (1 << 20)) {
+        const unsigned blocks = (unsigned)((N + kGaeE - 1) / kGaeE);
+        if (mode == 0)
+            hipExtLaunchKernelGGL(k_gae_scan_lds<0>, dim3(blocks), dim3(kThreads), lds, (hipStream_t)stream,
+                                  e0, e1, 0, (int)T, N, reward, v_pred, next_v_pred, nonterminal, cut,
+                                  gamma, lambd, adv, v_teacher);
+        else
+            hipExtLaunchKernelGGL(k_gae_scan_lds<1>, dim3(blocks), dim3(kThreads), lds, (hipStream_t)stream,
+                                  e0, e1, 0, (int)T, N, reward, v_pred, next_v_pred, nonterminal, cut,
+                                  gamma, lambd, adv, v_teacher);
+        PFRL_LAUNCH_CHECK();
+    }
     const unsigned blocks = (unsigned)((N + kThreads - 1) / kThreads);
     if (mode == 0)
-        hipLaunchKernelGGL(k_gae_scan<0>, dim3(blocks), dim3(kThreads), 0, (hipStream_t)stream, T,
-                           N, reward, v_pred, next_v_pred, nonterminal, cut, gamma, lambd, adv,
-                           v_teacher);
+        hipExtLaunchKernelGGL(k_gae_scan<0>, dim3(blocks), dim3(kThreads), 0, (hipStream_t)stream, e0, e1,
+                              0, T, N, reward, v_pred, next_v_pred, nonterminal, cut, gamma, lambd, adv,
+                              v_teacher);
     else
-        hipLaunchKernelGGL(k_gae_scan<1>, dim3(blocks), dim3(kThreads), 0, (hipStream_t)stream, T,
-                           N, reward, v_pred, next_v_pred, nonterminal, cut, gamma, lambd, adv,
-                           v_teacher);
+        hipExtLaunchKernelGGL(k_gae_scan<1>, dim3(blocks), dim3(kThreads), 0, (hipStream_t)stream, e0, e1,
+                              0, T, N, reward, v_pred, next_v_pred, nonterminal, cut, gamma, lambd, adv,
+                              v_teacher);
     PFRL_LAUNCH_CHECK();
 }
 
@@ -299,8 +420,10 @@ extern "C" int pfrl_adv_stats(const float *adv, int64_t n, float *out_mean_std, 
     PFRL_CHECK_ARG(n > 0 && partial_ws, "pfrl_adv_stats: need n > 0 and a workspace of 2*1024 f64");
     int blocks = (int)((n + kThreads * 8 - 1) / (kThreads * 8));
     if (blocks > 1024) blocks = 1024;
-    hipLaunchKernelGGL(k_adv_partial, dim3(blocks), dim3(kThreads), 0, (hipStream_t)stream, adv, n,
-                       (double *)partial_ws);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    pfrl_profile_events(PFRL_PROFILE_ADV_STATS, n, &e0, &e1);
+    hipExtLaunchKernelGGL(k_adv_partial, dim3(blocks), dim3(kThreads), 0, (hipStream_t)stream, e0, e1, 0,
+                          adv, n, (double *)partial_ws);
     hipLaunchKernelGGL(k_adv_final, dim3(1), dim3(64), 0, (hipStream_t)stream,
                        (const double *)partial_ws, blocks, n, out_mean_std);
     PFRL_LAUNCH_CHECK();
