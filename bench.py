@@ -475,7 +475,7 @@ def _cpu_baseline_run(args, seconds, N, B, cores):
     }
 
 
-PROFILE_BATCH_EXPERIENCES, PROFILE_BATCH_STATES_U8 = 0, 1   # pfrl_amd.ops constants
+PROFILE_BATCH_EXPERIENCES, PROFILE_BATCH_STATES_U8, PROFILE_GAE_SCAN, PROFILE_ADV_STATS = 0, 1, 2, 3   # pfrl_amd.ops constants
 
 
 def compute_roofline(algo, all_us, all_units, all_kinds):
@@ -501,6 +501,21 @@ def compute_roofline(algo, all_us, all_units, all_kinds):
     k_units = [n for n, kd in zip(all_units, all_kinds) if kd == kind]
     if not k_us:
         return None
+    scan = {}
+    for skind, sname, sbytes, swhat in (
+            (PROFILE_GAE_SCAN, "k_gae_scan_lds", 8 + 4 + 4 + 1 + 1 + 4 + 4,
+             "per (t, env): reward f64 + v + next_v f32 + nonterminal + cut u8 read, adv + v_teacher "
+             "f32 written"),
+            (PROFILE_ADV_STATS, "k_adv_partial", 4, "per advantage: one f32 read")):
+        s_us = [u for u, kd in zip(all_us, all_kinds) if kd == skind]
+        s_units = [n for n, kd in zip(all_units, all_kinds) if kd == skind]
+        if s_us:
+            gbs = sbytes * sum(s_units) / (sum(s_us) * 1e-6) / 1e9
+            scan[sname] = {"achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": round(gbs / HBM_PEAK_GBS, 5), "launches_timed": len(s_us),
+                           "avg_launch_us": round(sum(s_us) / len(s_us), 2),
+                           "elements_per_launch": int(s_units[0]), "bytes_per_element": sbytes,
+                           "what": swhat}
     # The kernel is launched in a few shapes (DQN: a small and a large env range per
     # step; PPO: acting, value pass and minibatch gathers).  The roofline object
     # describes the shape that moves the most bytes; the aggregate over every timed
@@ -531,6 +546,10 @@ def compute_roofline(algo, all_us, all_units, all_kinds):
         "timing": "hipEvent pair attached to each dispatch (hipExtLaunchKernelGGL) on the "
                   "launch stream, inside the timed region",
     }
+    if scan:
+        # the north star's named scan / reduction kernels: one launch each per rollout, a few MB --
+        # latency-bound (the launch, not the bytes), reported against the same HBM roofline
+        roofline["scan_kernels"] = scan
     # HBM traffic cannot be sampled from inside the process: it is taken from the
     # committed rocprofv3 --pmc passes of this same command
     # (profiles/rNN_pmc_gather.json, tools/pmc_gather.py), per launch shape.

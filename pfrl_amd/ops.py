@@ -169,6 +169,8 @@ class profile_paused:
 
 PROFILE_BATCH_EXPERIENCES = 0
 PROFILE_BATCH_STATES_U8 = 1
+PROFILE_GAE_SCAN = 2
+PROFILE_ADV_STATS = 3
 
 
 def profile_collect(kind=PROFILE_BATCH_EXPERIENCES, cap=1 << 16):

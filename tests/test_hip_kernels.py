@@ -438,7 +438,7 @@ def test_prioritized_golden_weights_and_tree(dev, path):
 # rollout kernels
 # ---------------------------------------------------------------------------
 @pytest.mark.parametrize("mode", [0, 1])
-@pytest.mark.parametrize("T,N", [(128, 512), (5, 3), (1, 70), (37, 257)])
+@pytest.mark.parametrize("T,N", [(128, 512), (5, 3), (1, 70), (37, 257), (300, 40), (500, 33)])
 def test_gae_scan_bit_exact(dev, mode, T, N):
     rs = np.random.RandomState(T * 7 + N + mode)
     gamma, lambd = 0.99, 0.95
