@@ -201,6 +201,15 @@ typedef struct {
 int pfrl_tree_write(const pfrl_tree_t *tree, int64_t n, const int64_t *x, const double *val,
                     const uint8_t *tag, const uint8_t *use_maxp, void *stream);
 
+/* TreeQueue._write on the SUM tree only, for n <= 1024 distinct leaves
+ * (pfrl/collections/prioritized.py:278-292 SumTreeQueue.uniform_sample: the leaves sample_n_k
+ * picked are zeroed and their previous priorities returned; :289-291 / :308-310: with
+ * remove=False the samplers write the priorities back).  val / tag NULL = write Python-float 0.0;
+ * old_val / old_tag (NULL or both) receive the leaves' previous contents.  The min tree is
+ * untouched, as in the reference. */
+int pfrl_tree_write_sum(const pfrl_tree_t *tree, int64_t n, const int64_t *x, const double *val,
+                        const uint8_t *tag, double *old_val, uint8_t *old_tag, void *stream);
+
 /* SumTreeQueue.prioritized_sample(n, remove=True) + the probability / weight
  * math of PrioritizedBuffer._sample_indices_and_probabilities (:56-84) and
  * PriorityWeightError.weights_from_probabilities

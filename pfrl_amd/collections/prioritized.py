@@ -44,8 +44,6 @@ class PrioritizedBuffer:
             raise RuntimeError("pfrl_amd PrioritizedBuffer is device-resident (needs a GPU)")
         self.capacity = capacity
         self.wait_priority_after_sampling = wait_priority_after_sampling
-        if not wait_priority_after_sampling:
-            raise NotImplementedError("remove=False sampling is not used by any replay buffer")
         self.flag_wait_priority = False
         self.data = collections.deque()
         self.frame = TreeFrame()
@@ -327,17 +325,85 @@ class PrioritizedBuffer:
         return finish()
 
     def sample(self, n, uniform_ratio=0):
-        """prioritized.py:86-105 (host-visible results; one D2H sync)."""
-        if uniform_ratio != 0:
-            raise NotImplementedError("uniform_ratio > 0 is not used by the replay buffers")
-        out = self.sample_device(n)
+        """prioritized.py:56-105 (host-visible results; one D2H sync).  ``uniform_ratio > 0``
+        mixes in leaves picked uniformly (SumTreeQueue.uniform_sample, :278-292) and
+        ``wait_priority_after_sampling=False`` puts every sampled priority back afterwards
+        (remove=False, :289-291 / :308-310): both on the device trees, the probabilities of the
+        mixed form evaluated on the host from the typed priorities (the reference's own
+        expression on NumPy scalars: NEP-50 decides its precision)."""
+        assert not self.wait_priority_after_sampling or not self.flag_wait_priority
+        if uniform_ratio == 0 and self.wait_priority_after_sampling:
+            out = self.sample_device(n)
+            self._join()
+            x = out["x"].cpu().numpy()
+            idx = x - self.frame.head
+            self.sampled_indices = [int(i) for i in idx]
+            sampled = [self.data[i] for i in self.sampled_indices]
+            probs = out["prob"].cpu().numpy().tolist()
+            return sampled, probs, float(out["min_prob"].item())
+        return self._sample_mixed(n, uniform_ratio)
+
+    @staticmethod
+    def _typed(v, t):
+        """The NumPy / Python scalar a tagged tree value stands for."""
+        return np.float32(v) if t == TAG_F32 else (np.float64(v) if t == TAG_F64 else float(v))
+
+    def _sample_mixed(self, n, uniform_ratio):
+        """_sample_indices_and_probabilities (prioritized.py:56-84) in the reference's order:
+        total and minimum first, then the binomial split, sample_n_k and the uniform removals,
+        then the prioritized draws -- all three consuming the global NumPy stream as there."""
+        from pfrl_amd.utils.random import sample_n_k
+
+        assert len(self) >= n
+        stats = self.root_stats()                       # (flushes; the trees as sampling finds them)
+        total = self._typed(*stats[0])
+        min_prob = self._typed(*stats[1]) / total
+        dev = self.device
+        xs, pris = [], []
+        n_pr = n
+        if uniform_ratio > 0:
+            n_uniform = np.random.binomial(n, uniform_ratio)
+            un = np.asarray(list(sample_n_k(len(self), n_uniform)), dtype=np.int64)
+            if n_uniform > 0:
+                assert n_uniform <= 1024, "at most 1 024 uniform samples per call"
+                with on_stream(self.side_stream):
+                    (ux,) = self._stage.upload([un + self.frame.head])
+                    ux = ux.clone()
+                    ov = torch.empty(n_uniform, dtype=torch.float64, device=dev)
+                    ot = torch.empty(n_uniform, dtype=torch.uint8, device=dev)
+                    ops.tree_write_sum(self._sync_desc(), ux, None, None, ov, ot)
+                    if not self.wait_priority_after_sampling:
+                        # remove=False: uniform_sample itself puts them back (:289-291), i.e.
+                        # BEFORE the prioritized draws, which may pick the same leaves again
+                        ops.tree_write_sum(self._sync_desc(), ux, ov, ot)
+                xs.append(ux)
+                pris.append((ov, ot))
+            n_pr = n - n_uniform
+            min_prob = uniform_ratio / len(self) + (1 - uniform_ratio) * min_prob
+        if n_pr > 0:
+            self.flag_wait_priority = False             # (sample_device checks and sets it)
+            out = self.sample_device(n_pr)
+            xs.append(out["x"].clone())
+            pris.append((out["pri"].clone(), out["pri_tag"].clone()))
         self._join()
-        x = out["x"].cpu().numpy()
-        idx = x - self.frame.head
-        self.sampled_indices = [int(i) for i in idx]
-        sampled = [self.data[i] for i in self.sampled_indices]
-        probs = out["prob"].cpu().numpy().tolist()
-        return sampled, probs, float(out["min_prob"].item())
+        x_all = torch.cat(xs) if xs else torch.empty(0, dtype=torch.int64, device=dev)
+        pv = torch.cat([p[0] for p in pris]).cpu().numpy() if pris else np.empty(0)
+        pt = torch.cat([p[1] for p in pris]).cpu().numpy() if pris else np.empty(0, dtype=np.uint8)
+        priorities = [self._typed(v, t) for v, t in zip(pv, pt)]
+        probs = [uniform_ratio / len(self) + (1 - uniform_ratio) * pri / total for pri in priorities]
+        if not self.wait_priority_after_sampling and n_pr > 0:
+            # remove=False: prioritized_sample writes its leaves back after its draws (:308-310)
+            with on_stream(self.side_stream):
+                px, (ppv, ppt) = xs[-1], pris[-1]
+                for lo in range(0, n_pr, 1024):
+                    hi = min(n_pr, lo + 1024)
+                    ops.tree_write_sum(self._sync_desc(), px[lo:hi].contiguous(),
+                                       ppv[lo:hi].contiguous(), ppt[lo:hi].contiguous())
+        self._sampled_x = x_all
+        self._n_sampled = int(x_all.numel())
+        self.sampled_indices = [int(i) for i in (x_all.cpu().numpy() - self.frame.head)]
+        self.flag_wait_priority = True
+        return [self.data[i] for i in self.sampled_indices], probs, min_prob
 
     def set_last_priority(self, priority):
         """prioritized.py:107-116 with host-side typed priorities."""

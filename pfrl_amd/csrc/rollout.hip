@@ -62,7 +62,7 @@ __global__ __launch_bounds__(kThreads) void k_gae_scan(int64_t T, int64_t N,
 // The same scan with the rollout staged through LDS (the form pfrl_gae_scan launches).  The scan
 // of pfrl/agents/ppo.py:36-47 is sequential in t and its rounding is part of the parity contract
 // (adv = fl(td + fl(gl * adv))), so it cannot become an associative prefix scan; what CAN leave
-// the dependent chain is everything else.  A workgroup owns E = 16 envs:
+// the dependent chain is everything else.  A workgroup owns E envs (8, or 16 from 4 096 envs on):
 //   1. all 256 threads load the five input columns of the E envs for every t (independent,
 //      coalesced in 64..128-byte runs) and compute td[t][e] -- the part with the memory latency --
 //      into LDS, together with v_pred and the cut flag;
@@ -71,9 +71,9 @@ __global__ __launch_bounds__(kThreads) void k_gae_scan(int64_t T, int64_t N,
 //   3. all threads write adv and v_teacher back, coalesced.
 // One lane per env in global memory (k_gae_scan above) was 8 waves on the chip at N = 512 walking
 // 128 dependent iterations of 5 global loads each; here N / 16 workgroups issue all loads at once.
-constexpr int kGaeE = 16, kGaeChunk = 16;
+constexpr int kGaeChunk = 16;
 
-template <int MODE>
+template <int MODE, int E>
 __global__ __launch_bounds__(kThreads) void k_gae_scan_lds(
     int T, int64_t N, const double *__restrict__ reward, const float *__restrict__ v_pred,
     const float *__restrict__ next_v_pred, const uint8_t *__restrict__ nonterminal,
@@ -82,31 +82,36 @@ __global__ __launch_bounds__(kThreads) void k_gae_scan_lds(
     using acc_t = typename std::conditional<MODE == 0, float, double>::type;
     extern __shared__ unsigned char lds_raw[];
     acc_t *s_td = reinterpret_cast<acc_t *>(lds_raw);                 // [T][E], becomes adv
-    float *s_v = reinterpret_cast<float *>(s_td + (size_t)T * kGaeE);   // [T][E]
-    uint8_t *s_cut = reinterpret_cast<uint8_t *>(s_v + (size_t)T * kGaeE);
-    const int64_t e0 = (int64_t)blockIdx.x * kGaeE;
-    const int total = T * kGaeE;
+    float *s_v = reinterpret_cast<float *>(s_td + (size_t)T * E);     // [T][E]
+    uint8_t *s_cut = reinterpret_cast<uint8_t *>(s_v + (size_t)T * E);
+    const int64_t e0 = (int64_t)blockIdx.x * E;
+    const int total = T * E;
     const double gl = __dmul_rn(gamma, lambd);
-    for (int q = threadIdx.x; q < total; q += kThreads) {
-        const int t = q / kGaeE, j = q % kGaeE;
-        const int64_t e = e0 + j;
-        if (e >= N) continue;
+    const double g0 = __dmul_rn(gamma, 0.0);
+    // (no branch around the loads: an env past N reads env N - 1 and is never looked at again --
+    // behind a branch every load is waited for on the spot, five round trips per element)
+    for (int q0 = 0; q0 < total; q0 += kThreads) {
+        const int q = min(q0 + (int)threadIdx.x, total - 1);
+        const int t = q / E, j = q % E;
+        const int64_t e = min(e0 + j, N - 1);
         const int64_t i = (int64_t)t * N + e;
-        const double gn = nonterminal[i] ? gamma : __dmul_rn(gamma, 0.0);
-        const float v = v_pred[i];
-        const float prod = __fmul_rn((float)gn, next_v_pred[i]);
+        const double r = reward[i];
+        const float v = v_pred[i], nv = next_v_pred[i];
+        const uint8_t nt = nonterminal[i], c = cut[i];
+        const double gn = nt ? gamma : g0;
+        const float prod = __fmul_rn((float)gn, nv);
         if (MODE == 0) {
-            const float s1 = __fadd_rn((float)reward[i], prod);
+            const float s1 = __fadd_rn((float)r, prod);
             s_td[q] = (acc_t)__fsub_rn(s1, v);
         } else {
-            const double s1 = __dadd_rn(reward[i], (double)prod);
+            const double s1 = __dadd_rn(r, (double)prod);
             s_td[q] = (acc_t)__dsub_rn(s1, (double)v);
         }
         s_v[q] = v;
-        s_cut[q] = cut[i];
+        s_cut[q] = c;
     }
     __syncthreads();
-    if (threadIdx.x < kGaeE && e0 + threadIdx.x < N) {
+    if (threadIdx.x < E && e0 + threadIdx.x < N) {
         const int j = threadIdx.x;
         const acc_t glx = (acc_t)gl;
         acc_t adv = (acc_t)0;
@@ -116,7 +121,7 @@ __global__ __launch_bounds__(kThreads) void k_gae_scan_lds(
 #pragma unroll
             for (int u = 0; u < kGaeChunk; ++u) {
                 const int t = t1 - 1 - u;
-                const int q = (t >= 0 ? t : 0) * kGaeE + j;
+                const int q = (t >= 0 ? t : 0) * E + j;
                 td[u] = s_td[q];
                 c[u] = s_cut[q];
             }
@@ -131,13 +136,13 @@ __global__ __launch_bounds__(kThreads) void k_gae_scan_lds(
 #pragma unroll
             for (int u = 0; u < kGaeChunk; ++u) {
                 const int t = t1 - 1 - u;
-                if (t >= 0) s_td[t * kGaeE + j] = td[u];
+                if (t >= 0) s_td[t * E + j] = td[u];
             }
         }
     }
     __syncthreads();
     for (int q = threadIdx.x; q < total; q += kThreads) {
-        const int t = q / kGaeE, j = q % kGaeE;
+        const int t = q / E, j = q % E;
         const int64_t e = e0 + j;
         if (e >= N) continue;
         const int64_t i = (int64_t)t * N + e;
@@ -373,23 +378,25 @@ extern "C" int pfrl_gae_scan(int64_t T, int64_t N, const double *reward, const f
     if (T == 0 || N == 0) return 0;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     pfrl_profile_events(PFRL_PROFILE_GAE_SCAN, T * N, &e0, &e1);
-    // rollouts that fit a workgroup's LDS (T * 16 envs * 9 or 13 bytes <= 64 KB: T <= 455 / 315)
+    // rollouts that fit a workgroup's LDS (T * E envs * 9 or 13 bytes <= 64 KB)
     // take the LDS-staged form; PFRL_GAE_LDS=0 keeps the lane-per-env loop for A/B runs
     static const bool use_lds = [] {
         const char *e = getenv("PFRL_GAE_LDS");
         return !(e != nullptr && e[0] == '0');
     }();
-    const size_t lds = (size_t)T * kGaeE * ((mode == 0 ? 4 : 8) + 4 + 1);
+    const int E = N >= 4096 ? 16 : 8;
+    const size_t lds = (size_t)T * E * ((mode == 0 ? 4 : 8) + 4 + 1);
     if (use_lds && lds <= 64 * 1024 && T < (1 << 20)) {
-        const unsigned blocks = (unsigned)((N + kGaeE - 1) / kGaeE);
-        if (mode == 0)
-            hipExtLaunchKernelGGL(k_gae_scan_lds<0>, dim3(blocks), dim3(kThreads), lds, (hipStream_t)stream,
-                                  e0, e1, 0, (int)T, N, reward, v_pred, next_v_pred, nonterminal, cut,
-                                  gamma, lambd, adv, v_teacher);
-        else
-            hipExtLaunchKernelGGL(k_gae_scan_lds<1>, dim3(blocks), dim3(kThreads), lds, (hipStream_t)stream,
-                                  e0, e1, 0, (int)T, N, reward, v_pred, next_v_pred, nonterminal, cut,
-                                  gamma, lambd, adv, v_teacher);
+        const unsigned blocks = (unsigned)((N + E - 1) / E);
+#define PFRL_GAE_LAUNCH(MODE_, E_)                                                                   \
+    hipExtLaunchKernelGGL((k_gae_scan_lds<MODE_, E_>), dim3(blocks), dim3(kThreads), lds,            \
+                          (hipStream_t)stream, e0, e1, 0, (int)T, N, reward, v_pred, next_v_pred,    \
+                          nonterminal, cut, gamma, lambd, adv, v_teacher)
+        if (mode == 0 && E == 8) PFRL_GAE_LAUNCH(0, 8);
+        else if (mode == 0) PFRL_GAE_LAUNCH(0, 16);
+        else if (E == 8) PFRL_GAE_LAUNCH(1, 8);
+        else PFRL_GAE_LAUNCH(1, 16);
+#undef PFRL_GAE_LAUNCH
         PFRL_LAUNCH_CHECK();
     }
     const unsigned blocks = (unsigned)((N + kThreads - 1) / kThreads);

@@ -95,6 +95,52 @@ __global__ __launch_bounds__(kMaxBatch) void k_tree_write(pfrl_tree_t T, int64_t
     repair_paths(T, active, xi);
 }
 
+// TreeQueue._write on the SUM tree only, for a batch of distinct leaves: what
+// SumTreeQueue.uniform_sample does to the leaves sample_n_k picked (prioritized.py:278-292:
+// _write(ix, 0.0) one after the other, the previous values returned) and what both samplers do
+// afterwards with remove=False (:289-291, :308-310: _write(ix, val) puts them back).  The min
+// tree is never touched by a sampler.  Node values are pure functions of the leaves, so the
+// leaf stores followed by one bottom-up re-reduction of the touched paths give the state the
+// sequential writes give; old_val / old_tag (may be NULL) receive what the leaves held.
+__global__ __launch_bounds__(kMaxBatch) void k_tree_write_sum(pfrl_tree_t T, int64_t n,
+                                                              const int64_t *__restrict__ x,
+                                                              const double *__restrict__ val,
+                                                              const uint8_t *__restrict__ tag,
+                                                              double *__restrict__ old_val,
+                                                              uint8_t *__restrict__ old_tag) {
+    const int i = threadIdx.x;
+    bool active = i < n;
+    int64_t xi = 0;
+    if (active) {
+        xi = x[i];
+        const int64_t il = node_idx(T, 0, xi);
+        if (old_val != nullptr) {
+            old_val[i] = T.sum_val[il];
+            old_tag[i] = T.sum_tag[il];
+        }
+        T.sum_val[il] = val != nullptr ? val[i] : 0.0;
+        T.sum_tag[il] = tag != nullptr ? tag[i] : (uint8_t)PFRL_TAG_PY;
+    }
+    const int L = T.log2_size;
+    if (active && (xi < T.base || xi >= T.base + ((int64_t)1 << L))) active = false;
+    for (int l = 1; l <= L; ++l) {
+        __threadfence_block();
+        __syncthreads();
+        if (active) {
+            const int64_t half = (int64_t)1 << (l - 1);
+            const int64_t xl = xi - ((xi - T.origin[l]) & (((int64_t)1 << l) - 1));
+            const int64_t il = node_idx(T, l - 1, xl);
+            const int64_t ir = node_idx(T, l - 1, xl + half);
+            const int64_t ip = node_idx(T, l, xi);
+            const TV a = mk_tv(T.sum_val[il], T.sum_tag[il]);
+            const TV b = mk_tv(T.sum_val[ir], T.sum_tag[ir]);
+            const TV sum = reduce_sum(a, b);
+            T.sum_val[ip] = sum.v;
+            T.sum_tag[ip] = (uint8_t)sum.t;
+        }
+    }
+}
+
 // Shared body of set_last_priority: typed max_priority scan, last-occurrence
 // de-duplication, leaf writes into both trees.  Returns whether this thread's leaf
 // takes part in the path repair that has to follow.
@@ -1396,6 +1442,19 @@ extern "C" int pfrl_tree_write(const pfrl_tree_t *tree, int64_t n, const int64_t
     int threads = (int)((n + 63) / 64 * 64);
     hipLaunchKernelGGL(k_tree_write, dim3(1), dim3(threads), 0, (hipStream_t)stream, *tree, n, x,
                        val, tag, use_maxp);
+    PFRL_LAUNCH_CHECK();
+}
+
+extern "C" int pfrl_tree_write_sum(const pfrl_tree_t *tree, int64_t n, const int64_t *x,
+                                   const double *val, const uint8_t *tag, double *old_val,
+                                   uint8_t *old_tag, void *stream) {
+    PFRL_CHECK_ARG(tree && n <= kMaxBatch, "pfrl_tree_write_sum: n must be <= 1024");
+    PFRL_CHECK_ARG((val == nullptr) == (tag == nullptr) && (old_val == nullptr) == (old_tag == nullptr),
+                   "pfrl_tree_write_sum: value / tag arrays come in pairs");
+    if (n <= 0) return 0;
+    int threads = (int)((n + 63) / 64 * 64);
+    hipLaunchKernelGGL(k_tree_write_sum, dim3(1), dim3(threads), 0, (hipStream_t)stream, *tree, n, x,
+                       val, tag, old_val, old_tag);
     PFRL_LAUNCH_CHECK();
 }
 

@@ -232,6 +232,15 @@ def tree_write(desc, x, val, tag, use_maxp):
                                         _ptr(tag), _ptr(use_maxp), _stream()), "tree_write")
 
 
+def tree_write_sum(desc, x, val=None, tag=None, old_val=None, old_tag=None):
+    """TreeQueue._write on the sum tree only (pfrl_tree_write_sum): ``val`` / ``tag`` None writes
+    Python-float zeros; ``old_val`` / ``old_tag`` receive the leaves' previous contents."""
+    check(_native.lib().pfrl_tree_write_sum(
+        ctypes.byref(desc), x.numel(), _ptr(x), _ptr(val) if val is not None else None,
+        _ptr(tag) if tag is not None else None, _ptr(old_val) if old_val is not None else None,
+        _ptr(old_tag) if old_tag is not None else None, _stream()), "tree_write_sum")
+
+
 def tree_sample(desc, u01, out, normalize, beta, slot_mod=0):
     B = u01.numel()
     check(_native.lib().pfrl_tree_sample(

@@ -312,6 +312,80 @@ def pbuf_trace(name, seed, capacity, n_ops, batch):
 
 
 # --------------------------------------------------------------------------
+# A''. PrioritizedBuffer with uniform_ratio > 0 and / or wait_priority_after_sampling=False
+#      (prioritized.py:56-84, 278-312): the replay re-seeds the GLOBAL NumPy stream and performs
+#      the same calls; binomial, sample_n_k and the prioritized draws consume it in that order
+# --------------------------------------------------------------------------
+def pbuf_uniform_trace(name, seed, capacity, n_ops, batch, uniform_ratio, wait):
+    np.random.seed(seed)
+    rs = np.random.RandomState(seed + 177)
+    buf = PrioritizedBuffer(capacity=capacity, wait_priority_after_sampling=wait)
+    rec = dict(op_kind=[], idx=[], prob_v=[], prob_t=[], min_prob_v=[], min_prob_t=[], set_v=[], set_t=[],
+               app_v=[], app_t=[], sum_v=[], sum_t=[], min_v=[], min_t=[], maxp_v=[], maxp_t=[],
+               length=[], n_sampled=[])
+    payload = 0
+    for k in range(n_ops):
+        r = rs.rand()
+        if len(buf) >= batch and r < 0.3:
+            sampled, probs, min_prob = buf.sample(batch, uniform_ratio=uniform_ratio)
+            rec["op_kind"].append(2)
+            rec["n_sampled"].append(len(sampled))
+            rec["idx"].extend(int(i) for i in buf.sampled_indices)
+            rec["prob_v"].extend(val(p) for p in probs); rec["prob_t"].extend(tag(p) for p in probs)
+            rec["min_prob_v"].append(val(min_prob)); rec["min_prob_t"].append(tag(min_prob))
+            # with wait=False the priorities may, but need not, be set afterwards
+            if wait or rs.rand() < 0.5:
+                newp = []
+                for _ in range(batch):
+                    c = rs.rand()
+                    x = rs.rand() * 3 + 1e-3
+                    newp.append(np.float32(x) if c < 0.5 else (float(x) if c < 0.9 else np.float64(x)))
+                buf.set_last_priority(newp)
+                rec["op_kind"].append(3)
+                rec["set_v"].extend(val(p) for p in newp); rec["set_t"].extend(tag(p) for p in newp)
+        elif len(buf) > 0 and r < 0.36:
+            buf.popleft()
+            rec["op_kind"].append(4)
+        else:
+            c = rs.rand()
+            p = None if c < 0.6 else (float(rs.rand() * 2 + 0.01) if c < 0.8 else np.float32(rs.rand() * 2 + 0.01))
+            buf.append(payload, priority=p)
+            payload += 1
+            rec["op_kind"].append(0 if p is None else 1)
+            rec["app_v"].append(val(p)); rec["app_t"].append(tag(p))
+        s = buf.priority_sums.sum() if len(buf) else 0.0
+        m = buf.priority_mins.min() if len(buf) else float("inf")
+        rec["sum_v"].append(val(s)); rec["sum_t"].append(tag(s))
+        rec["min_v"].append(val(m)); rec["min_t"].append(1 if not len(buf) else tag(m))
+        rec["maxp_v"].append(val(buf.max_priority)); rec["maxp_t"].append(tag(buf.max_priority))
+        rec["length"].append(len(buf))
+    out = {k2: np.asarray(v) for k2, v in rec.items()}
+    sv, st_ = flat_dump(buf.priority_sums)
+    mv, mt = flat_dump(buf.priority_mins)
+    out.update(final_sum_v=sv, final_sum_t=st_, final_min_v=mv, final_min_t=mt)
+    out["meta"] = np.array([seed, -1 if capacity is None else capacity, batch, int(wait)])
+    out["uniform_ratio"] = np.array(uniform_ratio, dtype=np.float64)
+    np.savez_compressed(os.path.join(HERE, "pbufmix_trace_%s.npz" % name), **out)
+    print("pbuf_uniform_trace", name, "final len", len(buf), "samples", len(rec["n_sampled"]))
+
+
+def prioritized_episodic_uniform_traces():
+    # (a glob of their own: the CPU test of the plain traces runs on the C oracle's tree)
+    prioritized_episodic_trace("cap30_r03", 43, 30, 500, 3, uniform_ratio=0.3,
+                               prefix="prioritized_episodic_uniform_trace")
+    prioritized_episodic_trace("unbounded_r06_memory", 44, None, 300, 2, normalize_by_max="memory",
+                               uniform_ratio=0.6, prefix="prioritized_episodic_uniform_trace")
+
+
+def pbuf_uniform_traces():
+    pbuf_uniform_trace("r03_cap64", 21, 64, 900, 8, 0.3, True)
+    pbuf_uniform_trace("r05_cap1000", 22, 1000, 1400, 32, 0.5, True)
+    pbuf_uniform_trace("r10_unbounded", 23, None, 600, 6, 1.0, True)
+    pbuf_uniform_trace("r00_nowait_cap100", 24, 100, 900, 8, 0.0, False)
+    pbuf_uniform_trace("r04_nowait_cap300", 25, 300, 1500, 16, 0.4, False)
+
+
+# --------------------------------------------------------------------------
 # B. uniform ReplayBuffer n-step traces + batch_experiences
 # --------------------------------------------------------------------------
 def replay_trace(name, seed, capacity, num_steps, n_ops, n_envs, gamma=0.99, batch=8):
@@ -1301,7 +1375,7 @@ def episodic_trace(name, seed, capacity, n_ops, n_envs, batch=4, max_len=5):
 
 
 def prioritized_episodic_trace(name, seed, capacity, n_ops, n_envs, batch=3, max_len=4,
-                               normalize_by_max=True):
+                               normalize_by_max=True, uniform_ratio=0, prefix="prioritized_episodic_trace"):
     """The reference's PrioritizedEpisodicReplayBuffer under random traffic: sizes and
     capacity_left after every op; sampled (sub-)episodes, importance weights and the errors fed
     back, at random points."""
@@ -1310,7 +1384,7 @@ def prioritized_episodic_trace(name, seed, capacity, n_ops, n_envs, batch=3, max
     np.random.seed(seed)
     rs = np.random.RandomState(seed + 5)
     rbuf = PrioritizedEpisodicReplayBuffer(capacity=capacity, normalize_by_max=normalize_by_max,
-                                           betasteps=50, error_max=2.0)
+                                           betasteps=50, error_max=2.0, uniform_ratio=uniform_ratio)
     rec = dict(op_kind=[], op_env=[], op_term=[], length=[], n_episodes=[], cap_left=[])
     smp = dict(at_op=[], ep_len=[], first_tid=[], weights=[], errors=[], beta=[])
     tid = 0
@@ -1343,8 +1417,9 @@ def prioritized_episodic_trace(name, seed, capacity, n_ops, n_envs, batch=3, max
                                     else np.int64)
     out["meta"] = np.array([seed, -1 if capacity is None else capacity, n_envs, batch, max_len])
     out["normalize"] = np.asarray({True: 1, "batch": 1, "memory": 2, False: 0}[normalize_by_max])
-    np.savez_compressed(os.path.join(HERE, "prioritized_episodic_trace_%s.npz" % name), **out)
-    print("prioritized_episodic_trace", name, "len", len(rbuf), "episodes", rbuf.n_episodes,
+    out["uniform_ratio"] = np.asarray(float(uniform_ratio))
+    np.savez_compressed(os.path.join(HERE, "%s_%s.npz" % (prefix, name)), **out)
+    print(prefix, name, "len", len(rbuf), "episodes", rbuf.n_episodes,
           "samples", len(smp["at_op"]))
 
 
@@ -1516,6 +1591,7 @@ def episodic_golden():
     episodic_trace("cap40", 31, 40, 600, 4)
     episodic_trace("cap7", 32, 7, 400, 2, batch=2, max_len=2)
     prioritized_episodic_trace("cap30", 40, 30, 500, 3)
+    prioritized_episodic_uniform_traces()
     prioritized_episodic_trace("unbounded_memory", 41, None, 300, 2, normalize_by_max="memory")
     prioritized_episodic_trace("cap12_nonorm", 42, 12, 300, 2, batch=2, normalize_by_max=False)
 
@@ -1678,6 +1754,7 @@ if __name__ == "__main__":
     pbuf_trace("cap64", 3, 64, 1500, 16)
     pbuf_trace("cap1000", 4, 1000, 3000, 32)
     pbuf_trace("unbounded", 5, None, 700, 8)
+    pbuf_uniform_traces()
     per_trace("f32_cap100_n1", 10, 100, 1, 600, 8, "f32", True)
     per_trace("f32_cap50_n3", 11, 50, 3, 600, 8, "f32", "memory", alpha=0.5)
     per_trace("py_cap20_n1", 12, 20, 1, 300, 4, "py", False)

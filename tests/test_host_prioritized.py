@@ -100,6 +100,29 @@ def test_host_prioritized_buffer_follows_reference_trace(path):
     _check_levels(buf.priority_mins, g["final_min_v"], g["final_min_t"])
 
 
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "pbufmix_trace_*.npz"))),
+                         ids=os.path.basename)
+def test_host_prioritized_buffer_uniform_ratio_and_no_wait_follow_reference_trace(path):
+    """uniform_ratio > 0 (binomial split + SumTreeQueue.uniform_sample) and
+    wait_priority_after_sampling=False (priorities written back after the draws): indices on
+    the reference's NumPy stream, probabilities and min_prob with their NEP-50 types, root
+    statistics after every operation, the final trees."""
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from _pbuf_uniform_replay import replay
+
+    def stats(buf):
+        if len(buf) == 0:
+            return None
+        return (_typed(buf.priority_sums.sum()), _typed(buf.priority_mins.min()), _typed(buf.max_priority))
+
+    g = np.load(path)
+    buf = replay(g, lambda cap, wait: HostPrioritizedBuffer(cap, wait_priority_after_sampling=wait), stats)
+    _check_levels(buf.priority_sums, g["final_sum_v"], g["final_sum_t"])
+    _check_levels(buf.priority_mins, g["final_min_v"], g["final_min_t"])
+
+
 def test_host_prioritized_buffer_uniform_mixture_and_misuse():
     np.random.seed(3)
     buf = HostPrioritizedBuffer(capacity=8)

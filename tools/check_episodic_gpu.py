@@ -29,8 +29,9 @@ def check_prioritized_episodic(path, payload_on_device=False):
     seed, cap, _, batch, max_len = (int(v) for v in g["meta"])
     norm = {0: False, 1: True, 2: "memory"}[int(g["normalize"])]
     np.random.seed(seed)
+    ur = float(g["uniform_ratio"]) if "uniform_ratio" in g.files else 0
     rbuf = PrioritizedEpisodicReplayBuffer(capacity=None if cap < 0 else cap, betasteps=50,
-                                           normalize_by_max=norm, error_max=2.0,
+                                           normalize_by_max=norm, error_max=2.0, uniform_ratio=ur,
                                            device="cuda:0", max_episodes=4096)   # HBM trees
     if payload_on_device:
         rbuf._device_opts = dict(max_size=4096, slack=None, frame_slots=None)
