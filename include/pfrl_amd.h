@@ -783,6 +783,19 @@ int pfrl_profile_enable(int on);
 int64_t pfrl_profile_collect(double *host_out_us, int64_t *host_out_units, int32_t *host_out_kind,
                              int64_t cap);
 
+/* torch.randn on the device generator, restated (pfrl/nn/noisy_linear.py:52-60 draws one
+ * torch.normal(0, 1, size = in + out) per NoisyNet layer and forward pass: nine launches per Rainbow
+ * update).  n_calls <= 16 draws in ONE launch: call i writes numel[i] floats at out + out_offsets[i],
+ * bit for bit what torch.randn(numel[i]) writes when the CUDA generator holds (seed, base_offset +
+ * offsets[i]) -- offsets[] relative to the first call, so that a caller prepares the arrays once;
+ * grids[i] = the blocks of 256 threads torch launches for that size (min(CUs * (max threads per CU /
+ * 256), ceil(numel / 256))).  variant: 0 / 1 = Box-Muller without / with a * b + c contracted to an
+ * fma (what torch's own build does is pinned by tests/test_philox.py).  The caller advances the
+ * generator's offset exactly as the torch calls would. */
+int pfrl_philox_normal(uint64_t seed, uint64_t base_offset, int32_t n_calls, const uint64_t *offsets,
+                       const int64_t *numel, const int64_t *out_offsets, const int32_t *grids, float *out,
+                       int32_t variant, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(LIB_DIR, "libpfrl_amd.so")
 # measurement hook (tools/build_variant.sh): another build of the same sources, e.g. other compiler
 # flags, loaded instead of the in-tree library.  Never set by the package, the tests or bench.py.
 _LIB_OVERRIDE = os.environ.get("PFRL_AMD_LIB")
-SOURCES = ["frames.hip", "replay.hip", "sumtree.hip", "rollout.hip", "optim.hip", "tdloss.hip", "bias_act.hip", "noisy.hip", "c51.hip", "dueling.hip", "qnet.hip", "actor.hip", "hostplan.hip"]
+SOURCES = ["frames.hip", "replay.hip", "sumtree.hip", "rollout.hip", "optim.hip", "tdloss.hip", "bias_act.hip", "noisy.hip", "c51.hip", "dueling.hip", "qnet.hip", "actor.hip", "hostplan.hip", "philox.hip"]
 HIPCC_FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
     # the parity contract is one correctly rounded IEEE op per source op
@@ -223,6 +223,7 @@ EXPORTS = {
     "pfrl_twin_input_grad": (ctypes.c_int, "pppiiipiip"),
     "pfrl_sac_policy_loss_fwd": (ctypes.c_int, "ppppfppppip"),
     "pfrl_sac_policy_loss_bwd": (ctypes.c_int, "ppppfpppip"),
+    "pfrl_philox_normal": (ctypes.c_int, "QQipppppip"),
     "pfrl_profile_enable": (ctypes.c_int, "i"),
     "pfrl_profile_collect": (ctypes.c_int64, "pppq"),
 }

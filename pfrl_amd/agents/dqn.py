@@ -271,6 +271,9 @@ class DQN(agent.AttributeSavingMixin, agent.BatchAgent):
             experiences, device=self.device, phi=self.phi, gamma=self.gamma,
             batch_states=self.batch_states)
         if self._replay_stream is not None and isinstance(experiences, DeviceExperienceBatch):
+            if self._graphed is not None and self.use_graphs and has_weight:
+                # NoisyNet draws of this update (one launch): ahead of the wait, not behind it
+                self._graphed.prefill(exp_batch, True)
             # the minibatch was sampled and gathered on the replay stream
             torch.cuda.current_stream(self.device).wait_event(experiences.store.ready_event)
         if has_weight and "weights" not in exp_batch:

@@ -332,6 +332,50 @@ class GraphedUpdate:
                     v.zero_()
         torch.cuda.set_rng_state(rng, ag.device)
 
+    # -- the NoisyNet draws of an update as ONE launch in front of its graph ---------------------
+    def _noise_feed_ok(self):
+        """The update's networks hold factorised-noise layers on the GPU and csrc/philox.hip
+        reproduces this PyTorch build's torch.randn bit for bit (probed): the draws then leave the
+        captured graph -- one eager launch per replay writes all of them, in the layers' call
+        order, from the device generator (PFRL_NOISE_FEED=0: torch.randn calls inside the graph)."""
+        if os.environ.get("PFRL_NOISE_FEED", "1") == "0" or self.agent.device.type != "cuda":
+            return False
+        from pfrl_amd import ops
+        from pfrl_amd.nn.noisy_linear import FactorizedNoisyLinear
+
+        if not any(isinstance(m, FactorizedNoisyLinear) for m in self.agent.model.modules()):
+            return False
+        return ops.philox_variant(self.agent.device) is not None
+
+    def _noise_buffers(self, sizes, repeat=1):
+        sizes = list(sizes) * repeat
+        offs, pos = [], 0
+        for n in sizes:
+            offs.append(pos)
+            pos += (n + 3) & ~3
+        from pfrl_amd import ops
+
+        buf = torch.zeros(pos, dtype=torch.float32, device=self.agent.device)
+        plan = ops.RandnPlan(sizes, self.agent.device, out=buf)      # (argument arrays built once)
+        return {"sizes": sizes, "buf": buf, "views": plan.views, "plan": plan}
+
+    def _fill_noise(self, entry):
+        noise = entry.get("noise")
+        if noise is not None:
+            if noise.pop("filled", False):
+                return              # (prefill() has drawn this replay's noise already)
+            noise["plan"].run()
+
+    def prefill(self, exp_batch, want_errors):
+        """Draw the noise of the NEXT ``run(exp_batch, want_errors)`` now: a caller that is about
+        to make its stream wait for the minibatch (the replay stream's gather) enqueues the draws
+        in front of that wait -- they depend on nothing but the generator.  The host order of
+        generator consumers is unchanged (nothing may draw between this call and that run)."""
+        entry = self.graphs.lookup((self._key(exp_batch), bool(want_errors)))
+        if entry is not None and entry.get("noise") is not None and not entry["noise"].get("filled"):
+            entry["noise"]["plan"].run()
+            entry["noise"]["filled"] = True
+
     def _collective_capturable(self):
         d = torch.distributed
         if not (d.is_available() and d.is_initialized()):
@@ -369,18 +413,32 @@ class GraphedUpdate:
         cur = torch.cuda.current_stream(dev)
         side = torch.cuda.Stream(dev)
         side.wait_stream(cur)
+        from pfrl_amd.nn.noisy_linear import NoiseFeed, noise_feed
+
+        noise = None
+        rec = NoiseFeed() if self._noise_feed_ok() else None
         try:
             with torch.cuda.stream(side):
-                for _ in range(2):
-                    ag.optimizer.zero_grad(set_to_none=True)
-                    self._forward_backward(exp_batch, want_errors)
-                    self._reduce_and_step()
+                for it in range(2):
+                    if it == 1 and rec is not None and rec.sizes:
+                        # the first warm-up drew through torch.randn and noted the sizes: from here
+                        # on the layers read views of one static buffer (filled once for the rest of
+                        # the warm-up; the RNG state is restored below either way)
+                        noise = self._noise_buffers(rec.sizes)
+                        self._fill_noise({"noise": noise})
+                    feed = rec if it == 0 else (NoiseFeed(noise["views"]) if noise else None)
+                    with noise_feed(feed):
+                        ag.optimizer.zero_grad(set_to_none=True)
+                        self._forward_backward(exp_batch, want_errors)
+                        self._reduce_and_step()
             cur.wait_stream(side)
             _make_capturable(ag.optimizer, dev)  # state created by the warm-up
             ag.optimizer.zero_grad(set_to_none=True)
             distributed._CAPTURE_COLLECTIVES[0] = bool(collective_in_graph)
             try:
-                entry = self._capture_graphs(exp_batch, want_errors, collective_in_graph)
+                with noise_feed(NoiseFeed(noise["views"]) if noise else None):
+                    entry = self._capture_graphs(exp_batch, want_errors, collective_in_graph)
+                entry["noise"] = noise
             finally:
                 distributed._CAPTURE_COLLECTIVES[0] = False
         finally:
@@ -471,6 +529,7 @@ class GraphedUpdate:
         if entry is None:
             entry = self._capture_range(big)
             self.graphs.admit(key, entry)
+        self._fill_noise(entry)
         timing = self.time_ranges
         if timing is not None:
             # bench.py: device time of a whole range graph (events on the launch stream)
@@ -510,20 +569,29 @@ class GraphedUpdate:
         cur = torch.cuda.current_stream(dev)
         side = torch.cuda.Stream(dev)
         side.wait_stream(cur)
+        from pfrl_amd.nn.noisy_linear import NoiseFeed, noise_feed
+
+        noise = None
+        rec = NoiseFeed() if self._noise_feed_ok() else None
         try:
             with torch.cuda.stream(side):
                 # warm-up on the first update of the range only (same kernels for all U)
-                for _ in range(2):
-                    ag.optimizer.zero_grad(set_to_none=True)
-                    self._forward_backward({k: v[0] for k, v in big.items()}, False)
-                    self._reduce_and_step()
+                for it in range(2):
+                    if it == 1 and rec is not None and rec.sizes:
+                        noise = self._noise_buffers(rec.sizes, repeat=U)    # (every update draws anew)
+                        self._fill_noise({"noise": noise})
+                    feed = rec if it == 0 else (NoiseFeed(noise["views"]) if noise else None)
+                    with noise_feed(feed):
+                        ag.optimizer.zero_grad(set_to_none=True)
+                        self._forward_backward({k: v[0] for k, v in big.items()}, False)
+                        self._reduce_and_step()
             cur.wait_stream(side)
             _make_capturable(ag.optimizer, dev)
             ag.optimizer.zero_grad(set_to_none=True)
             g = torch.cuda.CUDAGraph()
             distributed._CAPTURE_COLLECTIVES[0] = self.split_for_allreduce
             try:
-                with _capturing(g, self.pool):
+                with _capturing(g, self.pool), noise_feed(NoiseFeed(noise["views"]) if noise else None):
                     losses, ys = body()
             finally:
                 distributed._CAPTURE_COLLECTIVES[0] = False
@@ -532,7 +600,7 @@ class GraphedUpdate:
         finally:
             cur.wait_stream(side)
             self._restore(snap)
-        return {"graph": g, "losses": losses, "ys": ys}
+        return {"graph": g, "losses": losses, "ys": ys, "noise": noise}
 
     def _replay_items(self, items, bucket):
         for item in items:
@@ -555,6 +623,7 @@ class GraphedUpdate:
             entry = self._capture(exp_batch, want_errors)
             self.graphs.admit(key, entry)
         plan = entry["plan"]
+        self._fill_noise(entry)
         if after_forward is not None and "after_forward" in plan:
             cut = plan.index("after_forward")
             self._replay_items(plan[:cut], entry["bucket"])

@@ -33,8 +33,55 @@ def init_variance_scaling_constant(tensor, scale=1.0):
     return tensor.fill_(scale / math.sqrt(_fan_in(tensor)))
 
 
+# Where the layers' Gaussian draws come from.  None: every forward calls torch.randn (the
+# reference's torch.normal, same kernel, same stream).  A captured update installs a feed
+# (agents/graphed_update.py): first a RECORDING one -- the layers draw as usual and the sizes of
+# their draws are noted in call order -- then a SERVING one whose take() hands out views of one
+# static buffer in the same order; that buffer is filled before every replay by ONE launch that
+# reproduces those torch.randn calls bit for bit and advances the generator as they would
+# (ops.randn_calls, csrc/philox.hip).
+_FEED = [None]
+
+
+class NoiseFeed:
+    def __init__(self, views=None):
+        self.sizes = []          # recording: the draws seen so far
+        self.views = views       # serving: one tensor per draw, in call order
+        self.at = 0
+
+    def take(self, n, like):
+        if self.views is None:
+            self.sizes.append(int(n))
+            return torch.randn(n, dtype=like.dtype, device=like.device)
+        v = self.views[self.at % len(self.views)]
+        self.at += 1
+        assert v.numel() == n and v.device == like.device, "noise feed out of step with the layers"
+        return v
+
+
+class noise_feed:
+    """``with noise_feed(feed):`` -- the layers draw through ``feed`` (None: torch.randn)."""
+
+    def __init__(self, feed):
+        self.feed = feed
+
+    def __enter__(self):
+        self.saved, _FEED[0] = _FEED[0], self.feed
+        return self.feed
+
+    def __exit__(self, *exc):
+        _FEED[0] = self.saved
+
+
+def _draw(n, like):
+    feed = _FEED[0]
+    if feed is not None and like.is_cuda and like.dtype == torch.float32:
+        return feed.take(n, like)
+    return torch.randn(n, dtype=like.dtype, device=like.device)
+
+
 def _shaped_noise(n, like):
-    r = torch.randn(n, dtype=like.dtype, device=like.device)
+    r = _draw(n, like)
     return r.sign() * r.abs().sqrt()
 
 
@@ -67,7 +114,7 @@ class FactorizedNoisyLinear(nn.Module):
             if ops.noisy_weights_supported(sw) and self.mu.weight.is_contiguous():
                 # same draw as below (one normal_ of in + out values); shaping, outer
                 # product and both addcmul fused into one launch (and one for backward)
-                r = torch.randn(in_features + out_features, dtype=sw.dtype, device=sw.device)
+                r = _draw(in_features + out_features, sw)
                 weight, bias = ops.noisy_weights(
                     self.mu.weight, sw, self.mu.bias if self.hasbias else None,
                     self.sigma.bias if self.hasbias else None, r)

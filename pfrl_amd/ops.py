@@ -743,3 +743,115 @@ def dueling_softmax_supported(ya, n_atoms):
 def dueling_softmax(ya, ys, n_actions, n_atoms):
     """ya [B, A*Z] (or [B, A, Z]), ys [B, Z] -> q [B, A, Z]."""
     return _DuelingSoftmax.apply(ya, ys, n_actions, n_atoms)
+
+
+# ---------------------------------------------------------------------------------------------
+# torch.randn on the device generator as ONE launch for several draws (csrc/philox.hip)
+# ---------------------------------------------------------------------------------------------
+_PHILOX_VARIANT = {}
+
+
+def _default_generator(device):
+    torch.cuda.init()          # (the tuple of default generators is filled by the lazy init)
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    return torch.cuda.default_generators[idx]
+
+
+def _randn_grid(numel, device):
+    """Blocks of 256 threads torch launches for a float normal_ of ``numel`` elements
+    (ATen/native/cuda/DistributionTemplates.h calc_execution_policy)."""
+    prop = torch.cuda.get_device_properties(device)
+    cap = prop.multi_processor_count * (prop.max_threads_per_multi_processor // 256)
+    return max(1, min(cap, (numel + 255) // 256))
+
+
+def _randn_increment(numel, grid):
+    """By how much that call advances the generator's Philox offset."""
+    inc = ((numel - 1) // (256 * grid * 4) + 1) * 4
+    return (inc + 3) // 4 * 4
+
+
+class RandnPlan:
+    """``[torch.randn(n, device=device) for n in sizes]`` on the device's default generator as a
+    prepared launch sequence: the argument arrays are built once, ``run()`` reads the generator's
+    (seed, offset) on the host, launches (one launch per 16 draws) and advances the offset as the
+    torch calls would.  ``views[i]`` is draw i inside ``out`` (16-byte aligned offsets)."""
+
+    def __init__(self, sizes, device, out=None, variant=None):
+        device = torch.device(device)
+        if variant is None:
+            variant = philox_variant(device)
+            assert variant is not None, "pfrl_philox_normal does not reproduce torch.randn on this stack"
+        self.variant, self.device = int(variant), device
+        self.gen = _default_generator(device)
+        self.sizes = [int(n) for n in sizes]
+        rel, grids, outs = [], [], []
+        pos = off = 0
+        for numel in self.sizes:
+            g = _randn_grid(numel, device)
+            rel.append(off)
+            grids.append(g)
+            outs.append(pos)
+            off += _randn_increment(numel, g)
+            pos += (numel + 3) & ~3
+        self.total_increment = off
+        if out is None:
+            out = torch.empty(pos, dtype=torch.float32, device=device)
+        assert out.numel() >= pos and out.dtype == torch.float32 and out.is_contiguous()
+        self.out = out
+        self.views = [out[o:o + k] for o, k in zip(outs, self.sizes)]
+        self.launches = []
+        for lo in range(0, len(self.sizes), 16):
+            hi = min(len(self.sizes), lo + 16)
+            m = hi - lo
+            self.launches.append((m, (ctypes.c_uint64 * m)(*rel[lo:hi]), (ctypes.c_int64 * m)(*self.sizes[lo:hi]),
+                                  (ctypes.c_int64 * m)(*outs[lo:hi]), (ctypes.c_int32 * m)(*grids[lo:hi])))
+        self._out_ptr = _ptr(out)
+        self._fn = _native.lib().pfrl_philox_normal
+
+    def run(self):
+        gen = self.gen
+        seed, base = gen.initial_seed(), gen.get_offset()
+        stream = _stream()
+        for m, rel, numel, outs, grids in self.launches:
+            check(self._fn(seed, base, m, rel, numel, outs, grids, self._out_ptr, self.variant, stream),
+                  "philox_normal")
+        gen.set_offset(base + self.total_increment)
+        return self.views
+
+
+def randn_calls(sizes, device, out=None, variant=None):
+    """One-shot form of :class:`RandnPlan`: returns the list of views into ``out``.  Eager only:
+    the generator's (seed, offset) are read and advanced on the host."""
+    return RandnPlan(sizes, device, out=out, variant=variant).run()
+
+
+def philox_variant(device):
+    """Which restatement of rocRAND's Box-Muller arithmetic (0: separate multiply and add, 1:
+    contracted to an fma) reproduces ``torch.randn`` of THIS PyTorch build on this device bit for
+    bit, generator offsets included -- or None if neither does (callers then keep their
+    torch.randn calls).  Probed once per device; the generator is left as it was found."""
+    device = torch.device(device)
+    key = (device.index, torch.__version__)
+    if key in _PHILOX_VARIANT:
+        return _PHILOX_VARIANT[key]
+    gen = _default_generator(device)
+    state = gen.get_state()
+    found = None
+    sizes = [4160, 51, 563, 1, 70001]
+    try:
+        gen.manual_seed(0x5EED5)
+        gen.set_offset(8)
+        want = [torch.randn(k, device=device) for k in sizes]
+        end = gen.get_offset()
+        for v in (1, 0):
+            gen.manual_seed(0x5EED5)
+            gen.set_offset(8)
+            got = randn_calls(sizes, device, variant=v)
+            if gen.get_offset() == end and all(torch.equal(a, b) for a, b in zip(got, want)):
+                found = v
+                break
+    finally:
+        gen.set_state(state)
+    _PHILOX_VARIANT[key] = found
+    return found

@@ -456,3 +456,45 @@ def test_ppo_captured_minibatch_update_equals_the_eager_update(monkeypatch):
     np.testing.assert_allclose(pa, pb, rtol=2e-6, atol=2e-7)
     np.testing.assert_allclose(va, vb, rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(la, lb, rtol=1e-5, atol=1e-6)
+
+
+def _rainbow_run(monkeypatch, feed, steps=10):
+    import bench
+
+    monkeypatch.setenv("PFRL_NOISE_FEED", "1" if feed else "0")
+    dev = torch.device("cuda:0")
+    N, CAP, START = 256, 3000, 1024
+    args = _bench_args(algo="rainbow", capacity=CAP, frame_slots=3000 + 24 * N + 512, slack=1024,
+                       replay_start=START)
+    agent, env, rbuf = bench.build_agent(args, dev, 0)
+    obss = env.reset()
+    actions = []
+    for _ in range(steps):
+        a = agent.batch_act(obss)
+        actions.append(torch.as_tensor(a.tensor if hasattr(a, "tensor") else np.asarray(a)).cpu().numpy().copy())
+        obss, rs, dones, infos = env.step(a)
+        agent.batch_observe(obss, rs, dones, np.zeros(N, dtype=bool))
+        obss = env.reset(np.logical_not(dones))
+    torch.cuda.synchronize()
+    params = torch.cat([p.detach().reshape(-1) for p in agent.model.parameters()]).cpu()
+    tparams = torch.cat([p.detach().reshape(-1) for p in agent.target_model.parameters()]).cpu()
+    fed = [e.get("noise") for e in agent._graphed.graphs.values() if isinstance(e, dict)]
+    return dict(actions=np.asarray(actions), params=params, tparams=tparams, optim_t=agent.optim_t,
+                rng=torch.cuda.get_rng_state(dev).clone(), fed=fed)
+
+
+def test_rainbow_noise_draws_as_one_launch_equal_the_torch_randn_calls(monkeypatch):
+    """the nine factorised-noise draws of a Rainbow update (three NoisyNet
+    layers x three passes; the reference draws each with torch.normal on the device generator in
+    call order, pfrl/nn/noisy_linear.py:52-60) come from ONE launch in front of the update's graph
+    (csrc/philox.hip, graphed_update._fill_noise).  Gate: the run is the run with the torch.randn
+    calls inside the graph -- every acting draw in between sees the same generator state, so
+    actions, online and target parameters and the final generator state are BIT-IDENTICAL."""
+    a = _rainbow_run(monkeypatch, feed=False)
+    b = _rainbow_run(monkeypatch, feed=True)
+    assert a["optim_t"] == b["optim_t"] >= 100
+    assert not any(a["fed"]) and all(n is not None and len(n["sizes"]) == 9 for n in b["fed"]) and b["fed"]
+    assert b["fed"][0]["sizes"] == [3136 + 1024, 512 + 6 * 51, 512 + 51] * 3
+    assert torch.equal(a["rng"], b["rng"])
+    np.testing.assert_array_equal(a["actions"], b["actions"])
+    assert torch.equal(a["params"], b["params"]) and torch.equal(a["tparams"], b["tparams"])
