@@ -783,6 +783,25 @@ int pfrl_profile_enable(int on);
 int64_t pfrl_profile_collect(double *host_out_us, int64_t *host_out_units, int32_t *host_out_kind,
                              int64_t cap);
 
+/* y = act(x W^T + b) of a factorised NoisyNet layer (pfrl/nn/noisy_linear.py:56-70: W = mu.W +
+ * sigma.W * outer(f(r_out), f(r_in)), b = mu.b + sigma.b * f(r_out), f(r) = sign(r) sqrt|r|, r = the
+ * layer's in + out unit Gaussians, inputs first) without the perturbed weights ever being written:
+ * the weight operand is formed chunk by chunk inside the forward kernel.  Bit-identical to
+ * pfrl_noisy_weights_fwd followed by pfrl_linear_fwd (same roundings in W, same tile program).
+ * Minibatch-sized problems, in_features % 32 == 0, 16-byte aligned operands.  splits > 1: partials
+ * [splits][M][N] for pfrl_splitk_reduce_noisy (mu_b / sigma_b may then be NULL). */
+int pfrl_linear_noisy_fwd(const float *x, const float *mu_w, const float *sigma_w, const float *mu_b,
+                          const float *sigma_b, const float *r, float *y, int32_t M, int32_t K, int32_t N,
+                          int32_t relu, int32_t splits, void *stream);
+
+/* pfrl_splitk_reduce whose bias may be a NoisyNet layer's: bias[t] + bias_sigma[t] * f(bias_noise[t])
+ * (bias_noise[t] = the out_features Gaussians of the layer's draw, i.e. r + in_features).
+ * bias_sigma / bias_noise NULL (or NULL entries) = plain biases. */
+int pfrl_splitk_reduce_noisy(int32_t n_tasks, const float *const *part, float *const *out,
+                             const float *const *bias, const float *const *bias_sigma,
+                             const float *const *bias_noise, const int64_t *stride, const int32_t *n,
+                             const int32_t *splits, const int32_t *ncol, const int32_t *relu, void *stream);
+
 /* torch.randn on the device generator, restated (pfrl/nn/noisy_linear.py:52-60 draws one
  * torch.normal(0, 1, size = in + out) per NoisyNet layer and forward pass: nine launches per Rainbow
  * update).  n_calls <= 16 draws in ONE launch: call i writes numel[i] floats at out + out_offsets[i],

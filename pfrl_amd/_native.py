@@ -198,6 +198,8 @@ EXPORTS = {
     "pfrl_conv2d_nhwc_bwd_weight_ride": (ctypes.c_int, "pppppqqiiiiiiiiiipppppffffip"),
     "pfrl_conv2d_nhwc_bwd": (ctypes.c_int, "ppppppppqqiiiiiiiiiiip"),
     "pfrl_splitk_reduce": (ctypes.c_int, "ippppppppp"),
+    "pfrl_splitk_reduce_noisy": (ctypes.c_int, "ippppppppppp"),
+    "pfrl_linear_noisy_fwd": (ctypes.c_int, "pppppppiiiiip"),
     "pfrl_linear_fwd": (ctypes.c_int, "ppppiiiiip"),
     "pfrl_linear_bwd_weight": (ctypes.c_int, "pppppqqiiiip"),
     "pfrl_linear_small_fwd": (ctypes.c_int, "ppppiiip"),

@@ -258,14 +258,26 @@ struct FwdArgs {
     // [K1, K) from x2 (row stride K - K1) -- cat((obs, action)) without the copy
     const float *x2 = nullptr;
     int K1 = 0;
+    // (NOISY only) factorised NoisyNet (pfrl/nn/noisy_linear.py:56-70): w is mu.W, w_sigma is
+    // sigma.W, noise the layer's K + Cout unit Gaussians (inputs first), bias_sigma sigma.b.  The
+    // B-operand loader forms W = mu + sigma * (f(r_out) f(r_in)) chunk by chunk -- the same three
+    // roundings as pfrl_noisy_weights_fwd, so the product is the one on the materialised weights.
+    const float *w_sigma = nullptr, *noise = nullptr, *bias_sigma = nullptr;
 };
+
+__device__ __forceinline__ float noisy_shaped(float r) {
+    // |sqrt(|r|)| * sign(r), sign(0) = 0 (csrc/noisy.hip)
+    const float s = sqrtf(fabsf(r));
+    return r > 0.0f ? s : (r < 0.0f ? -s : r * 0.0f);
+}
 
 // TAIL: linear layers (1x1) whose in_features are not a multiple of 32 or whose rows are
 // not 16-byte aligned (MLP inputs such as 376 observations, 376 + 17 with the action
 // appended): scalar loads, addresses clamped to the row, the overhang zeroed when parked.
-template <int BM, int BN, int WM, int WN, int WK, int G, bool TAIL = false>
+template <int BM, int BN, int WM, int WN, int WK, int G, bool TAIL = false, bool NOISY = false>
 __device__ __forceinline__ void fwd_body(const FwdArgs &p, const int bx, const int by, const int bz) {
     static_assert(WM * WN * WK == 4 && WK <= 2, "four waves");
+    static_assert(!(TAIL && NOISY), "noisy weights: aligned rows only");
     constexpr int AM = BM / (16 * WM), AN = BN / (16 * WN);
     constexpr int P = (AM * AN == 1) ? 2 : 1;
     constexpr int NPA = (BM * 8 + 255) / 256, NPB = (BN * 8 + 255) / 256;
@@ -285,8 +297,10 @@ __device__ __forceinline__ void fwd_body(const FwdArgs &p, const int bx, const i
 
     struct Slot {
         float4 a[NPA], b[NPB];
+        float4 s[NOISY ? NPB : 1], e;    // (NOISY) sigma pieces, this lane's four input-noise values
     };
-    const float *ap[NPA], *ap2[NPA], *bp[NPB];
+    const float *ap[NPA], *ap2[NPA], *bp[NPB], *sp[NPB];
+    float fo[NPB];                       // (NOISY) f(r_out) of the piece's weight row
     bool aok[NPA], bok[NPB];
     const int K1 = (TAIL && p.x2 != nullptr) ? p.K1 : p.K;
 #pragma unroll
@@ -313,6 +327,10 @@ __device__ __forceinline__ void fwd_body(const FwdArgs &p, const int bx, const i
         const bool ok = row < BN && co < g.Cout;
         bp[pp] = p.w + (size_t)(ok ? co : 0) * p.K + (TAIL ? 0 : 4 * q);
         bok[pp] = ok;
+        if (NOISY) {
+            sp[pp] = p.w_sigma + (size_t)(ok ? co : 0) * p.K + 4 * q;
+            fo[pp] = noisy_shaped(p.noise[p.K + (ok ? co : 0)]);
+        }
     }
     const int SC = g.S * g.C, WC = g.W * g.C;
     const int kq4 = 4 * (tid & 7);
@@ -360,7 +378,11 @@ __device__ __forceinline__ void fwd_body(const FwdArgs &p, const int bx, const i
             if (a_on(pp)) sl.a[pp] = ldg4(ap[pp] + f_ad);
 #pragma unroll
         for (int pp = 0; pp < NPB; ++pp)
-            if (b_on(pp)) sl.b[pp] = ldg4(bp[pp] + k0);
+            if (b_on(pp)) {
+                sl.b[pp] = ldg4(bp[pp] + k0);
+                if (NOISY) sl.s[pp] = ldg4(sp[pp] + k0);
+            }
+        if (NOISY) sl.e = ldg4(p.noise + k0 + kq4);
     };
     auto stash = [&](int buf, int c, const Slot &sl) {
         // (TAIL) elements of this lane that lie inside the row; the overhang is zeroed
@@ -384,6 +406,15 @@ __device__ __forceinline__ void fwd_body(const FwdArgs &p, const int bx, const i
             if (TAIL) {
                 v.x = left > 0 ? v.x : 0.f; v.y = left > 1 ? v.y : 0.f;
                 v.z = left > 2 ? v.z : 0.f; v.w = left > 3 ? v.w : 0.f;
+            }
+            if (NOISY) {
+                // mu + sigma * (f_out * f_in): multiply, multiply, add -- the roundings of k_noisy_fwd
+                const float4 sg = sl.s[pp];
+                const float f = fo[pp];
+                v.x = __fadd_rn(v.x, __fmul_rn(sg.x, __fmul_rn(f, noisy_shaped(sl.e.x))));
+                v.y = __fadd_rn(v.y, __fmul_rn(sg.y, __fmul_rn(f, noisy_shaped(sl.e.y))));
+                v.z = __fadd_rn(v.z, __fmul_rn(sg.z, __fmul_rn(f, noisy_shaped(sl.e.z))));
+                v.w = __fadd_rn(v.w, __fmul_rn(sg.w, __fmul_rn(f, noisy_shaped(sl.e.w))));
             }
             if (b_on(pp)) *reinterpret_cast<float4 *>(&Bs[buf][row * LDR + 4 * q]) = v;
         }
@@ -426,7 +457,10 @@ __device__ __forceinline__ void fwd_body(const FwdArgs &p, const int bx, const i
 #pragma unroll
                 for (int an = 0; an < AN; ++an) {
                     const int col = wn * 16 * AN + 16 * an + (lane & 15);
-                    const float bias = p.partial ? 0.f : p.bias[n0 + col];
+                    float bias = p.partial ? 0.f : p.bias[n0 + col];
+                    if (NOISY && !p.partial)
+                        bias = __fadd_rn(bias, __fmul_rn(p.bias_sigma[n0 + col],
+                                                         noisy_shaped(p.noise[p.K + n0 + col])));
 #pragma unroll
                     for (int reg = 0; reg < 4; ++reg) {
                         float v = acc[am][an][0][reg];
@@ -458,7 +492,9 @@ __device__ __forceinline__ void fwd_body(const FwdArgs &p, const int bx, const i
         for (int an = 0; an < AN; ++an) {
             const int n = n0 + wn * 16 * AN + 16 * an + (lane & 15);
             if (n >= g.Cout) continue;
-            const float bias = p.partial ? 0.f : p.bias[n];
+            float bias = p.partial ? 0.f : p.bias[n];
+            if (NOISY && !p.partial)
+                bias = __fadd_rn(bias, __fmul_rn(p.bias_sigma[n], noisy_shaped(p.noise[p.K + n])));
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
                 const int m = m0 + wm * 16 * AM + 16 * am + 4 * (lane >> 4) + reg;
@@ -480,7 +516,7 @@ __device__ __forceinline__ void fwd_body(const FwdArgs &p, const int bx, const i
         }
 }
 
-template <int BM, int BN, int WM, int WN, int WK, int G, bool TAIL = false>
+template <int BM, int BN, int WM, int WN, int WK, int G, bool TAIL = false, bool NOISY = false>
 __global__ __launch_bounds__(256) void k_conv_fwd(FwdArgs p) {
 #ifdef PFRL_QNET_DEBUG
     // g_qreps = 2: the body runs twice and the stamps of the SECOND pass stay -- the same work with
@@ -488,12 +524,12 @@ __global__ __launch_bounds__(256) void k_conv_fwd(FwdArgs p) {
     const int q_wg = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
     for (int rep = g_qreps; rep > 0; --rep) {
         QSTAMP(0);
-        fwd_body<BM, BN, WM, WN, WK, G, TAIL>(p, blockIdx.x, blockIdx.y, blockIdx.z);
+        fwd_body<BM, BN, WM, WN, WK, G, TAIL, NOISY>(p, blockIdx.x, blockIdx.y, blockIdx.z);
         __syncthreads();
         QSTAMP(5);
     }
 #else
-    fwd_body<BM, BN, WM, WN, WK, G, TAIL>(p, blockIdx.x, blockIdx.y, blockIdx.z);
+    fwd_body<BM, BN, WM, WN, WK, G, TAIL, NOISY>(p, blockIdx.x, blockIdx.y, blockIdx.z);
 #endif
 }
 
@@ -1236,6 +1272,9 @@ struct RedArgs {
     const float *part[RED_MAX];
     float *out[RED_MAX];
     const float *bias[RED_MAX];
+    // (NoisyNet layers) bias = bias + bias_sigma * f(bias_noise): the layer's sigma.b and the
+    // out_features Gaussians of its draw, combined as pfrl_noisy_weights_fwd combines them
+    const float *bias_sigma[RED_MAX], *bias_noise[RED_MAX];
     long long stride[RED_MAX];
     int n[RED_MAX], splits[RED_MAX], ncol[RED_MAX], relu[RED_MAX];
     int block_end[RED_MAX];
@@ -1281,7 +1320,15 @@ __global__ __launch_bounds__(256) void k_splitk_reduce(RedArgs a) {
         }
         if (a.bias[t] != nullptr) {
             const int col = e % a.ncol[t];   // ncol % 4 == 0: the four lanes stay in one row
-            const float4 bb = *reinterpret_cast<const float4 *>(a.bias[t] + col);
+            float4 bb = *reinterpret_cast<const float4 *>(a.bias[t] + col);
+            if (a.bias_sigma[t] != nullptr) {
+                const float4 bs = *reinterpret_cast<const float4 *>(a.bias_sigma[t] + col);
+                const float *rn = a.bias_noise[t] + col;
+                bb.x = __fadd_rn(bb.x, __fmul_rn(bs.x, noisy_shaped(rn[0])));
+                bb.y = __fadd_rn(bb.y, __fmul_rn(bs.y, noisy_shaped(rn[1])));
+                bb.z = __fadd_rn(bb.z, __fmul_rn(bs.z, noisy_shaped(rn[2])));
+                bb.w = __fadd_rn(bb.w, __fmul_rn(bs.w, noisy_shaped(rn[3])));
+            }
             s.x += bb.x; s.y += bb.y; s.z += bb.z; s.w += bb.w;
         }
         if (a.relu[t]) {
@@ -1292,7 +1339,13 @@ __global__ __launch_bounds__(256) void k_splitk_reduce(RedArgs a) {
         for (int u = e; u < n; ++u) {
             float s = part[u];
             for (int k = 1; k < S; ++k) s += part[k * stride + u];
-            if (a.bias[t] != nullptr) s += a.bias[t][u % a.ncol[t]];
+            if (a.bias[t] != nullptr) {
+                const int col = u % a.ncol[t];
+                float bb = a.bias[t][col];
+                if (a.bias_sigma[t] != nullptr)
+                    bb = __fadd_rn(bb, __fmul_rn(a.bias_sigma[t][col], noisy_shaped(a.bias_noise[t][col])));
+                s += bb;
+            }
             if (a.relu[t]) s = fmaxf(s, 0.f);
             a.out[t][u] = s;
         }
@@ -1524,6 +1577,70 @@ bool geom_ok(const ConvGeom &g) {
 // C ABI
 // ===================================================================================
 
+// tile program of the forward kernel for a problem (see the switch in pfrl_conv2d_nhwc_fwd)
+static int fwd_program(const FwdArgs &a, int Cout, unsigned z) {
+    auto blocks = [&](int bm, int bn) { return (long long)((a.M + bm - 1) / bm) * ((Cout + bn - 1) / bn) * z; };
+    const int force = prog_override("PFRL_QNET_FWD");
+    int prog;
+    if (Cout % 32 != 0) prog = blocks(64, 16) >= 512 ? 0 : 1;        // narrow outputs (16 channels)
+    else if (Cout % 64 == 0 && a.K >= 2048 && blocks(128, 64) >= 1024) prog = 7;
+    else if (Cout % 64 != 0 && blocks(128, 32) >= 16384) prog = 8;
+    else if (Cout % 64 == 0 && blocks(64, 64) >= 1024) prog = 2;
+    else if (blocks(64, 32) >= 1024) prog = 3;
+    else if (blocks(32, 32) >= 384) prog = 4;
+    else prog = a.cps >= 12 ? 5 : 6;   // few workgroups, long reduction: stages of 8 chunks
+    if (force >= 0 && force <= 8) {
+        const bool narrow = Cout % 32 != 0, wide = force == 2 || force == 7;
+        if (narrow ? force <= 1 : (force >= 2 && (!wide || Cout % 64 == 0))) prog = force;
+    }
+    return prog;
+}
+
+// y = act(x W^T + b) of a factorised NoisyNet layer (pfrl/nn/noisy_linear.py:56-70) WITHOUT its
+// perturbed weights ever existing: W = mu_w + sigma_w * (f(r_out) f(r_in)^T), b = mu_b + sigma_b *
+// f(r_out), r = the layer's K + N unit Gaussians (inputs first), formed by the B-operand loader of
+// the forward kernel / the bias of its epilogue.  Same tile programs, same summation order and the
+// same roundings in W as pfrl_noisy_weights_fwd followed by pfrl_linear_fwd: bit-identical
+// output.  Minibatch-sized problems (the programs of up to 32 x 32 tiles); K % 32 == 0.
+// splits > 1 writes partials [splits][M][N] for pfrl_splitk_reduce_noisy.
+extern "C" int pfrl_linear_noisy_fwd(const float *x, const float *mu_w, const float *sigma_w,
+                                     const float *mu_b, const float *sigma_b, const float *r, float *y,
+                                     int32_t M, int32_t K, int32_t N, int32_t relu, int32_t splits,
+                                     void *stream) {
+    PFRL_CHECK_ARG(M >= 1 && N >= 1 && K >= KC && K % KC == 0 && splits >= 1,
+                   "pfrl_linear_noisy_fwd: in_features must be a multiple of 32");
+    PFRL_CHECK_ARG(x && mu_w && sigma_w && r && y, "pfrl_linear_noisy_fwd: null pointer");
+    const uintptr_t bits = (uintptr_t)x | (uintptr_t)mu_w | (uintptr_t)sigma_w | (uintptr_t)r;
+    PFRL_CHECK_ARG((bits & 15) == 0, "pfrl_linear_noisy_fwd: 16-byte aligned operands");
+    FwdArgs a;
+    a.x = x; a.w = mu_w; a.bias = mu_b; a.y = y;
+    a.w_sigma = sigma_w; a.noise = r; a.bias_sigma = sigma_b;
+    a.g = make_geom(M, 1, 1, K, N, 1, 1, 1);
+    a.M = M;
+    a.K = K;
+    const int nch = K / KC;
+    a.cps = (nch + splits - 1) / splits;
+    a.relu = relu; a.planar = 0; a.partial = splits > 1;
+    PFRL_CHECK_ARG(a.partial || (mu_b != nullptr && sigma_b != nullptr),
+                   "pfrl_linear_noisy_fwd: both biases required");
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned z = (unsigned)splits;
+#define FWDN(BM, BN, WM, WN, WK, G)                                                                  \
+    hipLaunchKernelGGL((k_conv_fwd<BM, BN, WM, WN, WK, G, false, true>),                             \
+                       dim3((M + BM - 1) / BM, (N + BN - 1) / BN, z), dim3(256), 0, st, a)
+    switch (fwd_program(a, N, z)) {
+        case 1: FWDN(32, 16, 2, 1, 2, 4); break;
+        case 4: FWDN(32, 32, 2, 2, 1, 4); break;
+        case 5: FWDN(16, 32, 1, 2, 2, 8); break;
+        case 6: FWDN(16, 32, 1, 2, 2, 4); break;
+        default:
+            pfrl_set_error("pfrl_linear_noisy_fwd: problem outside the minibatch-sized tile programs");
+            return PFRL_ERR_ARG;
+    }
+#undef FWDN
+    PFRL_LAUNCH_CHECK();
+}
+
 extern "C" int pfrl_conv2d_nhwc_fwd(const float *x, const float *w, const float *bias, float *y,
                                     int32_t N, int32_t H, int32_t W, int32_t C, int32_t Cout, int32_t R,
                                     int32_t S, int32_t stride, int32_t relu, int32_t planar_out,
@@ -1541,7 +1658,6 @@ extern "C" int pfrl_conv2d_nhwc_fwd(const float *x, const float *w, const float 
     PFRL_CHECK_ARG(a.partial || bias != nullptr, "pfrl_conv2d_nhwc_fwd: bias required");
     hipStream_t st = (hipStream_t)stream;
     const unsigned z = (unsigned)splits;
-    auto blocks = [&](int bm, int bn) { return (long long)((a.M + bm - 1) / bm) * ((Cout + bn - 1) / bn) * z; };
 #define FWD(BM, BN, WM, WN, WK, G)                                                                   \
     hipLaunchKernelGGL((k_conv_fwd<BM, BN, WM, WN, WK, G>),                                          \
                        dim3((a.M + BM - 1) / BM, (Cout + BN - 1) / BN, z), dim3(256), 0, st, a)
@@ -1551,20 +1667,7 @@ extern "C" int pfrl_conv2d_nhwc_fwd(const float *x, const float *w, const float 
     // MFMA for 64 x 64, 3.1 for 64 x 32 by SQ_INSTS_*), not bytes: 128 x 32 beats 64 x 32 for the first
     // convolution (1241 vs 1436 us), 128 x 64 beats 64 x 64 only for the long reduction of the linear
     // layer (485 vs 535 us) and loses below ~1000 workgroups.
-    const int force = prog_override("PFRL_QNET_FWD");
-    int prog;
-    if (Cout % 32 != 0) prog = blocks(64, 16) >= 512 ? 0 : 1;        // narrow outputs (16 channels)
-    else if (Cout % 64 == 0 && a.K >= 2048 && blocks(128, 64) >= 1024) prog = 7;
-    else if (Cout % 64 != 0 && blocks(128, 32) >= 16384) prog = 8;
-    else if (Cout % 64 == 0 && blocks(64, 64) >= 1024) prog = 2;
-    else if (blocks(64, 32) >= 1024) prog = 3;
-    else if (blocks(32, 32) >= 384) prog = 4;
-    else prog = a.cps >= 12 ? 5 : 6;   // few workgroups, long reduction: stages of 8 chunks
-    if (force >= 0 && force <= 8) {
-        const bool narrow = Cout % 32 != 0, wide = force == 2 || force == 7;
-        if (narrow ? force <= 1 : (force >= 2 && (!wide || Cout % 64 == 0))) prog = force;
-    }
-    switch (prog) {
+    switch (fwd_program(a, Cout, z)) {
         case 0: FWD(64, 16, 4, 1, 1, 2); break;
         case 1: FWD(32, 16, 2, 1, 2, 4); break;
         case 2: FWD(64, 64, 2, 2, 1, 2); break;
@@ -1918,6 +2021,16 @@ extern "C" int pfrl_splitk_reduce(int32_t n_tasks, const float *const *host_part
                                   const float *const *host_bias, const int64_t *host_stride,
                                   const int32_t *host_n, const int32_t *host_splits,
                                   const int32_t *host_ncol, const int32_t *host_relu, void *stream) {
+    return pfrl_splitk_reduce_noisy(n_tasks, host_part, host_out, host_bias, nullptr, nullptr, host_stride,
+                                    host_n, host_splits, host_ncol, host_relu, stream);
+}
+
+extern "C" int pfrl_splitk_reduce_noisy(int32_t n_tasks, const float *const *host_part,
+                                        float *const *host_out, const float *const *host_bias,
+                                        const float *const *host_bias_sigma,
+                                        const float *const *host_bias_noise, const int64_t *host_stride,
+                                        const int32_t *host_n, const int32_t *host_splits,
+                                        const int32_t *host_ncol, const int32_t *host_relu, void *stream) {
     PFRL_CHECK_ARG(n_tasks >= 0 && n_tasks <= RED_MAX, "pfrl_splitk_reduce: too many tensors");
     if (n_tasks == 0) return 0;
     RedArgs a;
@@ -1926,6 +2039,10 @@ extern "C" int pfrl_splitk_reduce(int32_t n_tasks, const float *const *host_part
         a.part[t] = host_part[t];
         a.out[t] = host_out[t];
         a.bias[t] = host_bias ? host_bias[t] : nullptr;
+        a.bias_sigma[t] = host_bias_sigma ? host_bias_sigma[t] : nullptr;
+        a.bias_noise[t] = host_bias_noise ? host_bias_noise[t] : nullptr;
+        PFRL_CHECK_ARG(a.bias_sigma[t] == nullptr || (a.bias[t] != nullptr && a.bias_noise[t] != nullptr),
+                       "pfrl_splitk_reduce_noisy: sigma bias needs the mu bias and the noise");
         a.stride[t] = host_stride[t];
         a.n[t] = host_n[t];
         a.splits[t] = host_splits[t];

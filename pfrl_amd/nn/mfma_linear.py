@@ -202,6 +202,82 @@ class _Linear(torch.autograd.Function):
         return dx, dw, db, None
 
 
+def _reduce_noisy(part, y, mu_b, sigma_b, r_out, n, splits, ncol, relu):
+    import ctypes
+
+    V = ctypes.c_void_p
+    one = lambda t: (V * 1)(t.data_ptr())    # noqa: E731
+    check(_native.lib().pfrl_splitk_reduce_noisy(
+        1, one(part), one(y), one(mu_b), one(sigma_b), one(r_out), (ctypes.c_int64 * 1)(n),
+        (ctypes.c_int32 * 1)(n), (ctypes.c_int32 * 1)(splits), (ctypes.c_int32 * 1)(ncol),
+        (ctypes.c_int32 * 1)(int(relu)), _stream()), "splitk_reduce_noisy")
+
+
+class _Ctx:
+    """What ``_Linear.backward`` reads from its context."""
+
+    def __init__(self, saved, needs, relu):
+        self.saved_tensors, self.needs_input_grad, self.relu, self.b_ptr = saved, needs, relu, None
+
+
+class _NoisyLinear(torch.autograd.Function):
+    """``act(x W^T + b)`` of a factorised NoisyNet layer as one node that never writes W in its
+    forward pass (pfrl_linear_noisy_fwd: the perturbed weights are formed inside the kernel's
+    operand loader; bit-identical to noisy_weights + _Linear).  The no-grad passes of an update
+    (target network, Double-DQN action selection, acting) need nothing else; a pass that is
+    differentiated builds W once in its BACKWARD (where the launch is off the path the next
+    minibatch waits for) and continues as _Linear.backward / pfrl_noisy_weights_bwd do."""
+
+    @staticmethod
+    def forward(ctx, x, mu_w, sigma_w, mu_b, sigma_b, r, relu):
+        M, K = x.shape
+        Fo = mu_w.shape[0]
+        x = x.contiguous()
+        lib = _native.lib()
+        y = torch.empty((M, Fo), dtype=torch.float32, device=x.device)
+        splits = _fwd_splits(M, Fo, K)
+        if splits == 1:
+            check(lib.pfrl_linear_noisy_fwd(_p(x), _p(mu_w), _p(sigma_w), _p(mu_b), _p(sigma_b), _p(r),
+                                            _p(y), M, K, Fo, int(relu), 1, _stream()), "linear_noisy_fwd")
+        else:
+            part = torch.empty((splits, M, Fo), dtype=torch.float32, device=x.device)
+            check(lib.pfrl_linear_noisy_fwd(_p(x), _p(mu_w), _p(sigma_w), None, None, _p(r), _p(part), M,
+                                            K, Fo, 0, splits, _stream()), "linear_noisy_fwd_splitk")
+            _reduce_noisy(part, y, mu_b, sigma_b, r[K:], M * Fo, splits, Fo, relu)
+        ctx.relu = bool(relu)
+        ctx.save_for_backward(x, mu_w, sigma_w, r, y if relu else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, mu_w, sigma_w, r, y = ctx.saved_tensors
+        Fo, K = mu_w.shape
+        lib = _native.lib()
+        w = torch.empty_like(mu_w)
+        check(lib.pfrl_noisy_weights_fwd(_p(mu_w), _p(sigma_w), None, None, _p(r), _p(w), None, Fo, K,
+                                         _stream()), "noisy_weights_fwd")
+        need_w = any(ctx.needs_input_grad[1:5])
+        dx, dw, db, _ = _Linear.backward(
+            _Ctx((x, w, y), (ctx.needs_input_grad[0], need_w, need_w, False), ctx.relu), dy)
+        if not need_w:
+            return dx, None, None, None, None, None, None
+        dw, db = dw.contiguous(), db.contiguous()
+        g_sw, g_sb = torch.empty_like(dw), torch.empty_like(db)
+        check(lib.pfrl_noisy_weights_bwd(_p(dw), _p(db), _p(r), _p(g_sw), _p(g_sb), Fo, K, _stream()),
+              "noisy_weights_bwd")
+        return dx, dw, g_sw, db, g_sb, None, None
+
+
+def noisy_supported(x, mu_w, sigma_w, mu_b, sigma_b):
+    """The in-kernel NoisyNet forward covers minibatch- and acting-sized batches of layers whose
+    in_features are a multiple of 32 (PFRL_NOISY_IN_LOADER=0: materialised weights as before)."""
+    return (_ENABLED and os.environ.get("PFRL_NOISY_IN_LOADER", "1") != "0" and x.is_cuda
+            and x.dim() == 2 and x.dtype == torch.float32 and 0 < x.shape[0] <= _MAX_BATCH
+            and mu_b is not None and sigma_b is not None and mu_w.shape[0] >= MIN_OUT
+            and mu_w.shape[1] % 32 == 0 and mu_w.is_contiguous() and sigma_w.is_contiguous()
+            and mu_w.dtype == torch.float32 and _native.available())
+
+
 def supported(layer, x):
     return (_ENABLED and x.is_cuda and x.dim() == 2 and x.dtype == torch.float32
             and layer.bias is not None and layer.out_features >= MIN_OUT

@@ -115,6 +115,13 @@ class FactorizedNoisyLinear(nn.Module):
                 # same draw as below (one normal_ of in + out values); shaping, outer
                 # product and both addcmul fused into one launch (and one for backward)
                 r = _draw(in_features + out_features, sw)
+                from pfrl_amd.nn import mfma_linear
+
+                if self.hasbias and mfma_linear.noisy_supported(x, self.mu.weight, sw, self.mu.bias,
+                                                                self.sigma.bias):
+                    # the perturbed weights never exist: formed in the GEMM's operand loader
+                    return mfma_linear._NoisyLinear.apply(x, self.mu.weight, sw, self.mu.bias,
+                                                          self.sigma.bias, r, bool(relu))
                 weight, bias = ops.noisy_weights(
                     self.mu.weight, sw, self.mu.bias if self.hasbias else None,
                     self.sigma.bias if self.hasbias else None, r)

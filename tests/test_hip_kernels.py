@@ -918,6 +918,44 @@ def test_noisy_linear_module_uses_fused_path(dev):
         np.testing.assert_allclose(a.cpu().numpy(), p.grad.cpu().numpy(), rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("M,K,N,relu", [(32, 3136, 1024, True), (32, 512, 306, False), (32, 512, 51, False),
+                                        (256, 3136, 1024, True), (256, 512, 306, False), (1, 64, 32, True),
+                                        (1024, 512, 64, True), (7, 96, 20, False)])
+def test_noisy_linear_in_the_operand_loader_is_bit_identical_to_materialised_weights(dev, monkeypatch,
+                                                                                   M, K, N, relu):
+    """pfrl_linear_noisy_fwd (W = mu + sigma * outer(f(r_out), f(r_in)) formed inside the forward
+    kernel's weight loader, the noisy bias in its epilogue / in the split-K fold) against the
+    round-4 path (pfrl_noisy_weights_fwd writes W and b, pfrl_linear_fwd multiplies): outputs and
+    all five gradients BIT-IDENTICAL on the same draw, at the Rainbow head's shapes (minibatch and
+    acting batch) and a few ragged ones."""
+    from pfrl_amd.nn import mfma_linear
+    from pfrl_amd.nn import noisy_linear as nl
+
+    torch.manual_seed(M + K + N)
+    layer = nl.FactorizedNoisyLinear(torch.nn.Linear(K, N), sigma_scale=0.5).to(dev)
+    with torch.no_grad():
+        layer.sigma.weight.mul_(1 + torch.rand_like(layer.sigma.weight))
+        layer.sigma.bias.mul_(1 + torch.rand_like(layer.sigma.bias))
+    x0 = torch.randn(M, K, device=dev)
+    r = torch.randn(K + N, device=dev)
+    dy = torch.randn(M, N, device=dev)
+    outs = []
+    for in_loader in (False, True):
+        monkeypatch.setenv("PFRL_NOISY_IN_LOADER", "1" if in_loader else "0")
+        assert mfma_linear.noisy_supported(x0, layer.mu.weight, layer.sigma.weight, layer.mu.bias,
+                                           layer.sigma.bias) == in_loader
+        x = x0.clone().requires_grad_(True)
+        layer.zero_grad()
+        with nl.noise_feed(nl.NoiseFeed([r])):
+            y = layer(x, relu=relu)
+        y.backward(dy)
+        outs.append([y.detach().clone(), x.grad.clone()] + [p.grad.clone() for p in layer.parameters()])
+        with torch.no_grad(), nl.noise_feed(nl.NoiseFeed([r])):
+            assert torch.equal(layer(x0, relu=relu), y)        # the no-grad pass: same kernel, same bits
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+
+
 # ---------------------------------------------------------------------------
 # fused C51 loss
 # ---------------------------------------------------------------------------
