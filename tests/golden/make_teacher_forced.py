@@ -12,7 +12,7 @@ on -- the online and target parameters BEFORE the update and the minibatch ``exp
 computed.  A test can then load exactly that state into the device path and compare that one
 number at the north-star tolerance (1e-5), wherever in the trajectory it sits.
 
-Output: tests/golden/teacher_forced_{dqn_uniform_n1,ddqn_per_n3,c51_per_n3}.npz
+Output: tests/golden/teacher_forced_{dqn_uniform_n1,ddqn_per_n3,c51_per_n3,ppo}.npz
 """
 import os
 import sys
@@ -146,7 +146,155 @@ def finish(name, out, losses):
     print("teacher_forced", name, {k: float(out["u%d_loss" % k]) for k in UPDATES})
 
 
+PPO_UPDATES = (1, 9, 20, 32)        # minibatch updates of agent_trace_ppo (8 per rollout)
+
+
+def ppo(steps=280, N=4):
+    """The reference's PPO run of agent_trace_ppo.npz again (asserted: same losses), recording for
+    minibatch updates PPO_UPDATES what ONE evaluation of pfrl/agents/ppo.py:480-532 depends on:
+    the model's parameters before the step, the minibatch's states (after phi), actions and the
+    four columns _lossfun reads (standardised advantages, old log-probabilities, old values, value
+    targets) -- and the three numbers it produced (loss, value loss, policy loss)."""
+    import tempfile
+
+    import pfrl
+    from pfrl import agents, experiments
+    from pfrl.policies import SoftmaxCategoricalHead
+
+    sys.path.insert(0, os.path.join(HERE, "..", ".."))
+    from pfrl_amd.envs.synthetic import HostSyntheticAtariVectorEnv
+
+    pfrl.utils.set_random_seed(0)
+    env = HostSyntheticAtariVectorEnv(N, seed=5, frame_shape=(12, 12), p_done=0.06)
+
+    def phi(x):
+        return np.asarray(x, dtype=np.float32) / 255
+
+    model = mg.make_ppo_model(4 * 144, 6, SoftmaxCategoricalHead, pfrl.nn.Branched)
+    opt = torch.optim.SGD(model.parameters(), lr=1e-2)
+    ag = agents.PPO(model, opt, gpu=-1, gamma=0.99, lambd=0.95, phi=phi, update_interval=64,
+                    minibatch_size=16, epochs=2, clip_eps=0.1, clip_eps_vf=None,
+                    standardize_advantages=True, max_grad_norm=0.5)
+    out, losses = {}, []
+    count = [0]
+    last_states = [None]
+    orig_forward = model.forward
+
+    def spy_forward(x):
+        last_states[0] = x
+        return orig_forward(x)
+
+    model.forward = spy_forward
+    orig_loss = ag._lossfun
+
+    def spy_loss(entropy, vs_pred, log_probs, vs_pred_old, log_probs_old, advs, vs_teacher):
+        count[0] += 1
+        k = count[0]
+        loss = orig_loss(entropy, vs_pred, log_probs, vs_pred_old=vs_pred_old,
+                         log_probs_old=log_probs_old, advs=advs, vs_teacher=vs_teacher)
+        losses.append([float(loss), ag.value_loss_record[-1], ag.policy_loss_record[-1]])
+        if k in PPO_UPDATES:
+            states = last_states[0]
+            distribs, _ = orig_forward(states)
+            # the actions of the minibatch: the ones whose log-probability _lossfun was given
+            lp_all = distribs.logits - distribs.logits.logsumexp(-1, keepdim=True)
+            actions = (lp_all - log_probs[:, None]).abs().argmin(-1)
+            assert torch.equal(distribs.log_prob(actions), log_probs)
+            out["u%d_params" % k] = np.concatenate([p.detach().numpy().ravel() for p in model.parameters()])
+            out["u%d_states" % k] = states.detach().numpy().copy()
+            out["u%d_actions" % k] = actions.numpy().copy()
+            for name, t in (("advs", advs), ("log_probs_old", log_probs_old),
+                            ("vs_pred_old", vs_pred_old), ("vs_teacher", vs_teacher)):
+                out["u%d_%s" % (k, name)] = t.detach().numpy().copy()
+            out["u%d_losses" % k] = np.asarray(losses[-1])
+        return loss
+
+    ag._lossfun = spy_loss
+    experiments.train_agent_batch(ag, env, steps, tempfile.mkdtemp())
+    g = np.load(os.path.join(HERE, "agent_trace_ppo.npz"))
+    assert np.array_equal(np.asarray(losses), g["losses"]), "not the run of agent_trace_ppo"
+    out["updates"] = np.asarray(PPO_UPDATES)
+    out["hyper"] = np.asarray([0.1, 1.0, 0.01])     # clip_eps, value_func_coef, entropy_coef
+    np.savez_compressed(os.path.join(HERE, "teacher_forced_ppo.npz"), **out)
+    print("teacher_forced ppo", {k: out["u%d_losses" % k].tolist() for k in PPO_UPDATES})
+
+
+SAC_UPDATES = (1, 90, 180)
+
+
+def sac(steps=240, N=2, obs_dim=24, act_dim=3):
+    """The reference's SoftActorCritic run of agent_trace_sac.npz again (asserted: same Q losses),
+    recording for updates SAC_UPDATES what one ``update`` (pfrl/agents/soft_actor_critic.py:
+    214-300) depends on -- the five networks' parameters before it and the minibatch -- and its
+    three losses: the two critic losses and the policy loss (evaluated, as the reference does,
+    after the critics' steps).  Sampling noise is off on both sides (sample = mean), as in the
+    trace: the CPU and GPU generators differ."""
+    import tempfile
+
+    import pfrl
+    from pfrl import agents, experiments, replay_buffers
+
+    sys.path.insert(0, os.path.join(HERE, "..", ".."))
+    from pfrl_amd.envs.synthetic import HostSyntheticVectorObsEnv
+
+    pfrl.utils.set_random_seed(0)
+    env = HostSyntheticVectorObsEnv(N, obs_dim=obs_dim, act_dim=act_dim, seed=2, p_done=0.03)
+    policy, q1, q2 = mg.make_sac_nets(obs_dim, act_dim, pfrl.nn.ConcatObsAndAction, pfrl.nn.Lambda)
+    opts = [torch.optim.SGD(m.parameters(), lr=1e-2) for m in (policy, q1, q2)]
+    rbuf = replay_buffers.ReplayBuffer(500)
+    ag = agents.SoftActorCritic(
+        policy, q1, q2, opts[0], opts[1], opts[2], rbuf, gamma=0.99, gpu=-1,
+        replay_start_size=40, minibatch_size=16, update_interval=1,
+        burnin_action_func=lambda: np.random.uniform(-1, 1, size=act_dim).astype(np.float32),
+        entropy_target=None, initial_temperature=0.2, soft_update_tau=5e-3)
+    flat = lambda m: np.concatenate([p.detach().numpy().ravel() for p in m.parameters()])  # noqa: E731
+    out, q_losses = {}, []
+    count = [0]
+    orig_q, orig_p = ag.update_q_func, ag.update_policy_and_temperature
+
+    def spy_q(batch):
+        count[0] += 1
+        k = count[0]
+        if k in SAC_UPDATES:
+            for name, m in (("policy", policy), ("q1", q1), ("q2", q2), ("tq1", ag.target_q_func1),
+                            ("tq2", ag.target_q_func2)):
+                out["u%d_%s_params" % (k, name)] = flat(m)
+            for key in ("state", "action", "reward", "next_state", "is_state_terminal", "discount"):
+                out["u%d_%s" % (k, key)] = batch[key].detach().numpy().copy()
+        orig_q(batch)
+        q_losses.append([ag.q_func1_loss_record[-1], ag.q_func2_loss_record[-1]])
+        if k in SAC_UPDATES:
+            out["u%d_q_losses" % k] = np.asarray(q_losses[-1])
+
+    def spy_p(batch):
+        k = count[0]
+        if k in SAC_UPDATES:
+            with torch.no_grad():       # :273-286 on the parameters as they are now
+                s0 = batch["state"]
+                d = policy(s0)
+                a = d.rsample()
+                q = torch.min(q1((s0, a)), q2((s0, a)))
+                out["u%d_policy_loss" % k] = np.asarray(float(torch.mean(ag.temperature * d.log_prob(a)[..., None] - q)))
+        orig_p(batch)
+
+    ag.update_q_func, ag.update_policy_and_temperature = spy_q, spy_p
+    with mg._NoNoise():
+        experiments.train_agent_batch(ag, env, steps, tempfile.mkdtemp())
+    g = np.load(os.path.join(HERE, "agent_trace_sac.npz"))
+    assert np.array_equal(np.asarray(q_losses), g["q_losses"]), "not the run of agent_trace_sac"
+    out["updates"] = np.asarray(SAC_UPDATES)
+    np.savez_compressed(os.path.join(HERE, "teacher_forced_sac.npz"), **out)
+    print("teacher_forced sac", {k: (out["u%d_q_losses" % k].tolist(), float(out["u%d_policy_loss" % k]))
+                                 for k in SAC_UPDATES})
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1:
+        for fn in sys.argv[1:]:
+            globals()[fn]()
+        sys.exit(0)
+    ppo()
+    sac()
     dqn_like("dqn_uniform_n1", False, 1, False)
     dqn_like("ddqn_per_n3", True, 3, True)
     c51()

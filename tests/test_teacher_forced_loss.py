@@ -92,3 +92,120 @@ def test_teacher_forced_losses_on_the_device_path(kind):
     """The fused TD-loss / C51-loss launches (csrc/tdloss.hip, csrc/c51.hip) on the reference's
     parameters and minibatch of updates 1, 50 and 140: each loss within 1e-5."""
     _check(kind, 0)
+
+
+# ---------------------------------------------------------------------------------------------
+# PPO: one evaluation of pfrl/agents/ppo.py:480-532 on the reference's parameters and minibatch
+# ---------------------------------------------------------------------------------------------
+def _check_ppo(gpu):
+    import pfrl_amd as pfrl
+    from pfrl_amd import agents
+    from pfrl_amd.policies import SoftmaxCategoricalHead
+
+    g = np.load(os.path.join(GOLDEN, "teacher_forced_ppo.npz"))
+    clip_eps, vcoef, ecoef = (float(x) for x in g["hyper"])
+    torch.manual_seed(4321)
+    model = torch.nn.Sequential(
+        torch.nn.Flatten(), torch.nn.Linear(4 * 144, 32), torch.nn.ReLU(),
+        pfrl.nn.Branched(torch.nn.Sequential(torch.nn.Linear(32, 6), SoftmaxCategoricalHead()),
+                         torch.nn.Linear(32, 1)))
+    opt = torch.optim.SGD(model.parameters(), lr=1e-2)
+    ag = agents.PPO(model, opt, gpu=gpu, gamma=0.99, lambd=0.95,
+                    phi=lambda x: np.asarray(x, dtype=np.float32) / 255, update_interval=64,
+                    minibatch_size=16, epochs=2, clip_eps=clip_eps, clip_eps_vf=None,
+                    standardize_advantages=True, max_grad_norm=0.5, value_func_coef=vcoef,
+                    entropy_coef=ecoef)
+    dev = ag.device
+    for k in g["updates"]:
+        _load_flat(ag.model, g["u%d_params" % k])
+        T = lambda name: torch.as_tensor(g["u%d_%s" % (k, name)]).to(dev)   # noqa: E731
+        distribs, vs_pred = ag.model(T("states"))
+        records = {}
+        loss = ag._lossfun(distribs.entropy(), vs_pred, distribs.log_prob(T("actions")),
+                           vs_pred_old=T("vs_pred_old"), log_probs_old=T("log_probs_old"),
+                           advs=T("advs"), vs_teacher=T("vs_teacher"), records=records)
+        want = g["u%d_losses" % k]
+        got = [float(loss.detach().cpu()), float(records["value_loss"].detach().cpu()),
+               float(records["policy_loss"].detach().cpu())]
+        for a, b, what in zip(got, want, ("loss", "value loss", "policy loss")):
+            assert abs(a - b) <= TOL * max(1.0, abs(b)), (int(k), what, a, float(b))
+
+
+def test_teacher_forced_ppo_losses_on_the_host_path():
+    """the trajectory trace holds PPO's losses to 1e-5 only for the
+    first rollout; here minibatch updates 1, 9, 20 and 32 of that same reference run are each held
+    to 1e-5 on the reference's own parameters, states, actions and dataset columns."""
+    _check_ppo(-1)
+
+
+@pytest.mark.gpu
+def test_teacher_forced_ppo_losses_on_the_device_path():
+    _check_ppo(0)
+
+
+# ---------------------------------------------------------------------------------------------
+# SAC: one update (pfrl/agents/soft_actor_critic.py:214-300) on the reference's five networks and
+# minibatch; sampling noise off on both sides, as in the trajectory trace
+# ---------------------------------------------------------------------------------------------
+def _check_sac(gpu, **agent_kw):
+    from test_agent_parity import _NoNoise, _squashed_head
+
+    from pfrl_amd import agents, replay_buffers
+    from pfrl_amd.nn import ConcatObsAndAction, Lambda
+
+    g = np.load(os.path.join(GOLDEN, "teacher_forced_sac.npz"))
+    obs_dim, act_dim = 24, 3
+    torch.manual_seed(1357)
+    policy = torch.nn.Sequential(torch.nn.Linear(obs_dim, 32), torch.nn.ReLU(),
+                                 torch.nn.Linear(32, act_dim * 2), Lambda(_squashed_head))
+
+    def q():
+        return torch.nn.Sequential(ConcatObsAndAction(), torch.nn.Linear(obs_dim + act_dim, 32),
+                                   torch.nn.ReLU(), torch.nn.Linear(32, 1))
+
+    q1, q2 = q(), q()
+    opts = [torch.optim.SGD(m.parameters(), lr=1e-2) for m in (policy, q1, q2)]
+    ag = agents.SoftActorCritic(
+        policy, q1, q2, opts[0], opts[1], opts[2], replay_buffers.ReplayBuffer(500), gamma=0.99,
+        gpu=gpu, replay_start_size=40, minibatch_size=16, update_interval=1,
+        burnin_action_func=lambda: np.random.uniform(-1, 1, size=act_dim).astype(np.float32),
+        entropy_target=None, initial_temperature=0.2, soft_update_tau=5e-3, **agent_kw)
+    dev = ag.device
+    seen = {}
+    orig_record = ag._record_stats
+
+    def spy_record(st):
+        orig_record(st)
+        for name in ("loss1", "loss2", "policy_loss"):
+            if name in st:
+                seen[name] = float(st[name].detach().reshape(-1)[0].cpu())
+
+    ag._record_stats = spy_record
+    for k in g["updates"]:
+        for name, m in (("policy", ag.policy), ("q1", ag.q_func1), ("q2", ag.q_func2),
+                        ("tq1", ag.target_q_func1), ("tq2", ag.target_q_func2)):
+            _load_flat(m, g["u%d_%s_params" % (k, name)])
+        batch = {key: torch.as_tensor(g["u%d_%s" % (k, key)]).to(dev)
+                 for key in ("state", "action", "reward", "next_state", "is_state_terminal", "discount")}
+        seen.clear()
+        with _NoNoise():
+            ag._update_impl(batch)
+        want = list(g["u%d_q_losses" % k]) + [float(g["u%d_policy_loss" % k])]
+        got = [seen["loss1"], seen["loss2"], seen["policy_loss"]]
+        for a, b, what in zip(got, want, ("Q1 loss", "Q2 loss", "policy loss")):
+            assert abs(a - b) <= TOL * max(1.0, abs(b)), (int(k), what, a, float(b))
+
+
+def test_teacher_forced_sac_losses_on_the_host_path():
+    """updates 1, 90 and 180 of the reference's SAC run, each on the reference's
+    own parameters (policy, twin Q, twin target Q) and minibatch: both critic losses and the policy
+    loss within 1e-5 (the trajectory trace holds the critic losses to 1e-4 and never looked at the
+    policy loss)."""
+    _check_sac(-1)
+
+
+@pytest.mark.gpu
+def test_teacher_forced_sac_losses_on_the_device_path():
+    """... through the twin-Q MFMA launches, the fused squashed-Gaussian head and the loss kernels
+    of csrc/actor.hip."""
+    _check_sac(0)

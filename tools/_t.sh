@@ -1,7 +1,13 @@
-timeout 900 python -m pytest -x -q -m gpu tests/test_hip_kernels.py -k "noisy" 2>&1 | tail -30
-timeout 900 python -m pytest -x -q -m gpu tests/test_bench_path_parity.py -k "noise_draws or rainbow" 2>&1 | tail -8
+cd /root/repo
+timeout 1500 python -m pytest -x -q -m gpu tests 2>&1 | tail -12
 cd /tmp
-for L in 0 1; do
-PFRL_NOISY_IN_LOADER=$L timeout 600 python /root/repo/bench.py --algo rainbow --no-cpu-baseline --capacity 200000 --steps 100 2>/dev/null | python -c "
-import json,sys; d=json.loads(sys.stdin.read()); print('in_loader=$L', d['value'], d['ms_per_step'])"
-done
+timeout 900 python /root/repo/bench.py > /root/repo/gpurun_out/r05_bench_default_a.json 2> /root/repo/gpurun_out/r05_bench_default_a.err
+python - <<'PY'
+import json
+d = json.load(open('/root/repo/gpurun_out/r05_bench_default_a.json'))
+print('dqn', d['value'], d['ms_per_step'], d['roofline']['frac'], d['roofline']['mfma'].get('update_us'), d['roofline']['mfma'].get('parity_ceiling_env_steps_s'))
+for k, v in d.get('also', {}).items():
+    print(k, v['value'], v['ms_per_step'], (v.get('cpu_baseline') or {}).get('value'))
+print('cpu', d['cpu_baseline']['value'], d['config'].get('native_lib'))
+print('dpo', d.get('data_path_only', {}).get('value'), d.get('data_path_only', {}).get('without_update_launches'))
+PY
