@@ -554,7 +554,7 @@ def compute_roofline(algo, all_us, all_units, all_kinds):
     # committed rocprofv3 --pmc passes of this same command
     # (profiles/rNN_pmc_gather.json, tools/pmc_gather.py), per launch shape.
     prof_dir = os.path.join(ROOT, "profiles")
-    names = sorted((n for n in os.listdir(prof_dir) if n.endswith(("_pmc_gather.json", "_pmc_ppo.json", "_pmc_rainbow.json"))),
+    names = sorted((n for n in os.listdir(prof_dir) if n.endswith(("_pmc_gather.json", "_pmc_ppo.json", "_pmc_rainbow.json", "_pmc_sac.json"))),
                    reverse=True)      # newest round first
     # A PMC pass describes the build it was taken on: it carries the hash of the gather kernels'
     # sources (tools/pmc_gather.py: "kernel_sources_sha16") and is attached only while those files

@@ -48,7 +48,48 @@ def load(d, counter):
     return out
 
 
+def main_sac(fetch_dir, write_dir, entries, cal):
+    """configs[4] (vector observations: the fused gather is plain f32 row copies, no u8 frames to
+    calibrate FETCH_SIZE on): the dominant k_batch_experiences launch shape of the run, ``entries``
+    sampled transitions per launch (bench.py's roofline.entries_per_launch), FETCH_SIZE corrected
+    by the factor ``cal`` calibrated on the same box by the DQN passes (rNN_pmc_gather.json)."""
+    import hashlib
+
+    def dominant(d, counter):
+        by = defaultdict(list)
+        for path in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+            with open(path) as f:
+                for r in csv.DictReader(f):
+                    if r.get("Counter_Name") == counter and "k_batch_experiences" in r["Kernel_Name"]:
+                        by[int(r["Grid_Size"])].append(float(r["Counter_Value"]))
+        grid = max(by, key=lambda g: len(by[g]) * g)
+        return grid, by[grid]
+
+    gf, f = dominant(fetch_dir, "FETCH_SIZE")
+    gw, w = dominant(write_dir, "WRITE_SIZE")
+    assert gf == gw, (gf, gw)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    h = hashlib.sha256()
+    for rel in ("pfrl_amd/csrc/replay.hip", "pfrl_amd/csrc/nhwc.h", "pfrl_amd/csrc/common.h"):
+        with open(os.path.join(root, rel), "rb") as fh:
+            h.update(fh.read())
+    per = 2 * (2 * 376 * 4) + 2 * 17 * 4 + 2 * 12          # bench.py compute_roofline, sac
+    fk, wk = sum(f) / len(f), sum(w) / len(w)
+    rb, wb = fk * 1024 * cal, wk * 1024
+    item = {"launches": len(f), "grid_threads": gf, "algorithmic_read_B": entries * per // 2,
+            "algorithmic_write_B": entries * per // 2, "FETCH_SIZE_KiB": round(fk, 2),
+            "WRITE_SIZE_KiB": round(wk, 2), "fetch_bytes_corrected": int(rb), "write_bytes": int(wb),
+            "traffic_bytes_per_launch": int(rb + wb), "algorithmic_bytes_per_launch": entries * per,
+            "traffic_over_algorithmic": round((rb + wb) / (entries * per), 4)}
+    json.dump({"unit_note": "FETCH_SIZE / WRITE_SIZE in KiB; FETCH_SIZE corrected by the factor calibrated on "
+                            "the u8 acting gather of the DQN passes of the same collection",
+               "kernel_sources_sha16": h.hexdigest()[:16], "fetch_calibration_factor": cal,
+               "kernels": {"k_batch_experiences (%d entries)" % entries: item}}, sys.stdout, indent=1)
+
+
 def main():
+    if len(sys.argv) > 3 and sys.argv[3] == "--sac":
+        return main_sac(sys.argv[1], sys.argv[2], int(sys.argv[4]), float(sys.argv[5]))
     fetch = load(sys.argv[1], "FETCH_SIZE")
     write = load(sys.argv[2], "WRITE_SIZE")
     import hashlib
