@@ -794,6 +794,16 @@ int pfrl_linear_noisy_fwd(const float *x, const float *mu_w, const float *sigma_
                           const float *sigma_b, const float *r, float *y, int32_t M, int32_t K, int32_t N,
                           int32_t relu, int32_t splits, void *stream);
 
+/* Two NoisyNet layers in one launch: the advantage and value streams of the distributional dueling
+ * head (pfrl/q_functions/dueling_dqn.py:93-118).  Problem t = 0, 1: y[t] [M, N[t]] = act(rows of x[t]
+ * (K floats at a stride of x_row_stride floats: the halves of the hidden activations in place)
+ * times the perturbed weights of layer t).  Arrays of two pointers / sizes.  Both layers must be
+ * narrow-output minibatch problems (N % 32 != 0); bit-identical to two pfrl_linear_noisy_fwd calls. */
+int pfrl_linear_noisy_fwd_pair(const float *const *x, int32_t x_row_stride, const float *const *mu_w,
+                               const float *const *sigma_w, const float *const *mu_b,
+                               const float *const *sigma_b, const float *const *r, float *const *y,
+                               int32_t M, int32_t K, const int32_t *N, int32_t relu, void *stream);
+
 /* pfrl_splitk_reduce whose bias may be a NoisyNet layer's: bias[t] + bias_sigma[t] * f(bias_noise[t])
  * (bias_noise[t] = the out_features Gaussians of the layer's draw, i.e. r + in_features).
  * bias_sigma / bias_noise NULL (or NULL entries) = plain biases. */

@@ -200,6 +200,7 @@ EXPORTS = {
     "pfrl_splitk_reduce": (ctypes.c_int, "ippppppppp"),
     "pfrl_splitk_reduce_noisy": (ctypes.c_int, "ippppppppppp"),
     "pfrl_linear_noisy_fwd": (ctypes.c_int, "pppppppiiiiip"),
+    "pfrl_linear_noisy_fwd_pair": (ctypes.c_int, "pippppppiipip"),
     "pfrl_linear_fwd": (ctypes.c_int, "ppppiiiiip"),
     "pfrl_linear_bwd_weight": (ctypes.c_int, "pppppqqiiiip"),
     "pfrl_linear_small_fwd": (ctypes.c_int, "ppppiiip"),

@@ -537,9 +537,12 @@ __global__ __launch_bounds__(256) void k_conv_fwd(FwdArgs p) {
 // pfrl/agents/soft_actor_critic.py:97-110) side by side in one grid, blockIdx.z picks the
 // problem.  Inside a captured graph a launch costs ~4 us whatever it computes, and the twins
 // are always evaluated on the same inputs one after the other.  No split-K here.
-template <int BM, int BN, int WM, int WN, int WK, int G, bool TAIL>
+template <int BM, int BN, int WM, int WN, int WK, int G, bool TAIL, bool NOISY = false>
 __global__ __launch_bounds__(256) void k_conv_fwd2(FwdArgs p0, FwdArgs p1) {
-    fwd_body<BM, BN, WM, WN, WK, G, TAIL>(blockIdx.z == 0 ? p0 : p1, blockIdx.x, blockIdx.y, 0);
+    const FwdArgs &p = blockIdx.z == 0 ? p0 : p1;
+    // (the two problems may differ in out_features: the grid is sized for the wider one)
+    if ((int)blockIdx.y * BN >= p.g.Cout) return;
+    fwd_body<BM, BN, WM, WN, WK, G, TAIL, NOISY>(p, blockIdx.x, blockIdx.y, 0);
 }
 
 // ---------------------------------------------------------------------------------
@@ -1638,6 +1641,46 @@ extern "C" int pfrl_linear_noisy_fwd(const float *x, const float *mu_w, const fl
             return PFRL_ERR_ARG;
     }
 #undef FWDN
+    PFRL_LAUNCH_CHECK();
+}
+
+// Two NoisyNet layers of one network side by side in ONE launch: the advantage and value streams of
+// the distributional dueling head (pfrl/q_functions/dueling_dqn.py:93-118: a_stream on the first
+// half of the hidden activations, v_stream on the second).  Problem t reads rows of x[t] with row
+// stride x_row_stride (a multiple of K: the halves of h are addressed in place, no copy) and
+// writes y[t] [M, N[t]].  Both problems must fall into the narrow-output tile program (N % 32 != 0,
+// few workgroups), which is also what the single-layer entry picks for them: bit-identical to two
+// pfrl_linear_noisy_fwd calls on contiguous copies of the halves.
+extern "C" int pfrl_linear_noisy_fwd_pair(const float *const *x, int32_t x_row_stride,
+                                          const float *const *mu_w, const float *const *sigma_w,
+                                          const float *const *mu_b, const float *const *sigma_b,
+                                          const float *const *r, float *const *y, int32_t M, int32_t K,
+                                          const int32_t *N, int32_t relu, void *stream) {
+    PFRL_CHECK_ARG(M >= 1 && K >= KC && K % KC == 0 && x_row_stride >= K && x_row_stride % K == 0,
+                   "pfrl_linear_noisy_fwd_pair: in_features % 32, row stride a multiple of in_features");
+    FwdArgs a[2];
+    int ny = 0;
+    for (int t = 0; t < 2; ++t) {
+        PFRL_CHECK_ARG(x[t] && mu_w[t] && sigma_w[t] && mu_b[t] && sigma_b[t] && r[t] && y[t] && N[t] >= 1,
+                       "pfrl_linear_noisy_fwd_pair: null pointer");
+        const uintptr_t bits = (uintptr_t)x[t] | (uintptr_t)mu_w[t] | (uintptr_t)sigma_w[t] | (uintptr_t)r[t];
+        PFRL_CHECK_ARG((bits & 15) == 0, "pfrl_linear_noisy_fwd_pair: 16-byte aligned operands");
+        a[t].x = x[t]; a[t].w = mu_w[t]; a[t].bias = mu_b[t]; a[t].y = y[t];
+        a[t].w_sigma = sigma_w[t]; a[t].noise = r[t]; a[t].bias_sigma = sigma_b[t];
+        // rows of K floats at a stride of x_row_stride: a 1 x 1 convolution over [M, 1, W, K] that
+        // steps over the W - 1 other pieces of each row
+        const int Wd = x_row_stride / K;
+        a[t].g = make_geom(M, 1, Wd, K, N[t], 1, 1, Wd);
+        a[t].M = M;
+        a[t].K = K;
+        a[t].cps = K / KC;
+        a[t].relu = relu; a[t].planar = 0; a[t].partial = 0;
+        PFRL_CHECK_ARG(fwd_program(a[t], N[t], 1) == 1,
+                       "pfrl_linear_noisy_fwd_pair: both layers must be narrow-output minibatch problems");
+        ny = ny > (N[t] + 15) / 16 ? ny : (N[t] + 15) / 16;
+    }
+    hipLaunchKernelGGL((k_conv_fwd2<32, 16, 2, 1, 2, 4, false, true>), dim3((M + 31) / 32, ny, 2), dim3(256),
+                       0, (hipStream_t)stream, a[0], a[1]);
     PFRL_LAUNCH_CHECK();
 }
 

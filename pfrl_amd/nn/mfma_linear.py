@@ -268,6 +268,70 @@ class _NoisyLinear(torch.autograd.Function):
         return dx, dw, g_sw, db, g_sb, None, None
 
 
+class _NoisyLinearPair(torch.autograd.Function):
+    """Two NoisyNet layers on the two halves of one activation tensor -- the advantage and value
+    streams of the distributional dueling head -- as ONE forward launch reading the halves in place
+    (pfrl_linear_noisy_fwd_pair).  Backward: what the two single-layer nodes and the split of ``h``
+    do (contiguous halves, _NoisyLinear.backward each, the two input gradients side by side)."""
+
+    @staticmethod
+    def forward(ctx, h, mu_w0, sigma_w0, mu_b0, sigma_b0, r0, mu_w1, sigma_w1, mu_b1, sigma_b1, r1):
+        import ctypes
+
+        M, K2 = h.shape
+        K = K2 // 2
+        h = h.contiguous()
+        N0, N1 = mu_w0.shape[0], mu_w1.shape[0]
+        y0 = torch.empty((M, N0), dtype=torch.float32, device=h.device)
+        y1 = torch.empty((M, N1), dtype=torch.float32, device=h.device)
+        V = ctypes.c_void_p
+        two = lambda a, b: (V * 2)(a, b)                                  # noqa: E731
+        check(_native.lib().pfrl_linear_noisy_fwd_pair(
+            two(h.data_ptr(), h.data_ptr() + 4 * K), K2, two(_p(mu_w0), _p(mu_w1)),
+            two(_p(sigma_w0), _p(sigma_w1)), two(_p(mu_b0), _p(mu_b1)), two(_p(sigma_b0), _p(sigma_b1)),
+            two(_p(r0), _p(r1)), two(_p(y0), _p(y1)), M, K, (ctypes.c_int32 * 2)(N0, N1), 0, _stream()),
+            "linear_noisy_fwd_pair")
+        ctx.save_for_backward(h, mu_w0, sigma_w0, r0, mu_w1, sigma_w1, r1)
+        return y0, y1
+
+    @staticmethod
+    def backward(ctx, dy0, dy1):
+        h, mu_w0, sigma_w0, r0, mu_w1, sigma_w1, r1 = ctx.saved_tensors
+        M, K2 = h.shape
+        K = K2 // 2
+        halves = h.view(M, 2, K).transpose(0, 1).contiguous()
+        need = ctx.needs_input_grad
+        outs, dxs = [], []
+        for x, mu_w, sigma_w, r, dy, ni in ((halves[0], mu_w0, sigma_w0, r0, dy0, 1),
+                                            (halves[1], mu_w1, sigma_w1, r1, dy1, 6)):
+            if dy is None:
+                dy = torch.zeros((M, mu_w.shape[0]), dtype=torch.float32, device=h.device)
+            sub = _Ctx((x, mu_w, sigma_w, r, None), (need[0],) + tuple(need[ni:ni + 4]) + (False, False),
+                       False)
+            g = _NoisyLinear.backward(sub, dy)
+            dxs.append(g[0])
+            outs.append(g[1:5])
+        dh = torch.cat(dxs, dim=1) if need[0] else None
+        return (dh,) + tuple(outs[0]) + (None,) + tuple(outs[1]) + (None,)
+
+
+def noisy_pair_supported(h, a, v):
+    """Both streams are factorised-noise layers on the halves of ``h`` and fall into the
+    narrow-output tile program of the forward kernel (what pfrl_linear_noisy_fwd_pair covers)."""
+    if not (h.is_cuda and h.dim() == 2 and h.shape[1] % 2 == 0 and a.hasbias and v.hasbias):
+        return False
+    K = h.shape[1] // 2
+    ma, mv = a.mu.weight, v.mu.weight
+    if ma.shape[1] != K or mv.shape[1] != K or K % 32 != 0:
+        return False
+    M = h.shape[0]
+    narrow = all(w.shape[0] % 32 != 0 and _ceil_div(M, 64) * _ceil_div(w.shape[0], 16) < 512
+                 and _fwd_splits(M, w.shape[0], K) == 1 for w in (ma, mv))
+    return (narrow and os.environ.get("PFRL_NOISY_PAIR", "1") != "0"
+            and noisy_supported(h[:, :K], ma, a.sigma.weight, a.mu.bias, a.sigma.bias)
+            and noisy_supported(h[:, :K], mv, v.sigma.weight, v.mu.bias, v.sigma.bias))
+
+
 def noisy_supported(x, mu_w, sigma_w, mu_b, sigma_b):
     """The in-kernel NoisyNet forward covers minibatch- and acting-sized batches of layers whose
     in_features are a multiple of 32 (PFRL_NOISY_IN_LOADER=0: materialised weights as before)."""

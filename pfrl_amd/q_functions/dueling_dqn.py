@@ -98,11 +98,40 @@ class DistributionalDuelingDQN(nn.Module):
         self.apply(init_chainer_default)
         self.conv_layers.apply(constant_bias_initializer(bias=bias))
 
+    def _noisy_pair(self, h):
+        """(a_stream(h[:, :half]), v_stream(h[:, half:])) of two factorised NoisyNet streams as ONE
+        launch that reads the halves of ``h`` in place (nn/mfma_linear.py::_NoisyLinearPair), or
+        None.  The streams draw their noise in the order of the separate calls: a, then v."""
+        from pfrl_amd.nn.noisy_linear import FactorizedNoisyLinear, _draw
+
+        a, v = self.a_stream, self.v_stream
+        if not (type(a) is FactorizedNoisyLinear and type(v) is FactorizedNoisyLinear and h.is_cuda):
+            return None
+        from pfrl_amd.nn import mfma_linear
+
+        if not mfma_linear.noisy_pair_supported(h, a, v):
+            return None
+        ra = _draw(a.mu.weight.shape[1] + a.mu.weight.shape[0], a.sigma.weight)
+        rv = _draw(v.mu.weight.shape[1] + v.mu.weight.shape[0], v.sigma.weight)
+        return mfma_linear._NoisyLinearPair.apply(
+            h, a.mu.weight, a.sigma.weight, a.mu.bias, a.sigma.bias, ra,
+            v.mu.weight, v.sigma.weight, v.mu.bias, v.sigma.bias, rv)
+
     def forward(self, x):
         h = _conv_trunk(self.conv_layers, x, self.activation)
         batch_size = x.shape[0]
         h = linear_activation(self.main_stream, h.reshape(batch_size, -1), self.activation)
-        if h.is_cuda and h.shape[1] % 2 == 0:
+        pair = self._noisy_pair(h)
+        ys = None
+        if pair is not None:
+            ya_flat, ys = pair
+            from pfrl_amd import ops
+
+            if ops.dueling_softmax_supported(ya_flat, self.n_atoms):
+                q = ops.dueling_softmax(ya_flat, ys, self.n_actions, self.n_atoms)
+                return action_value.DistributionalDiscreteActionValue(q, self.z_values)
+            h_a = h_v = None
+        elif h.is_cuda and h.shape[1] % 2 == 0:
             # both halves contiguous out of ONE copy (the linear kernels want dense rows; chunk()
             # gives two strided views and each stream would copy its own: one launch fewer forwards
             # and one backwards, same values)
@@ -110,17 +139,18 @@ class DistributionalDuelingDQN(nn.Module):
             h_a, h_v = halves[0], halves[1]
         else:
             h_a, h_v = torch.chunk(h, 2, dim=1)
-        ya_flat = self.a_stream(h_a)
-        if h.is_cuda:
-            from pfrl_amd import ops
+        if pair is None:
+            ya_flat = self.a_stream(h_a)
+            if h.is_cuda:
+                from pfrl_amd import ops
 
-            if ops.dueling_softmax_supported(ya_flat, self.n_atoms):
-                # centring, value add and softmax over atoms in one launch
-                q = ops.dueling_softmax(ya_flat, self.v_stream(h_v), self.n_actions, self.n_atoms)
-                return action_value.DistributionalDiscreteActionValue(q, self.z_values)
+                if ops.dueling_softmax_supported(ya_flat, self.n_atoms):
+                    # centring, value add and softmax over atoms in one launch
+                    q = ops.dueling_softmax(ya_flat, self.v_stream(h_v), self.n_actions, self.n_atoms)
+                    return action_value.DistributionalDiscreteActionValue(q, self.z_values)
         ya = ya_flat.reshape((batch_size, self.n_actions, self.n_atoms))
         mean = ya.sum(dim=1, keepdim=True) / self.n_actions
         ya = ya - mean
-        ys = self.v_stream(h_v).reshape((batch_size, 1, self.n_atoms))
+        ys = (ys if ys is not None else self.v_stream(h_v)).reshape((batch_size, 1, self.n_atoms))
         q = F.softmax(ya + ys, dim=2)
         return action_value.DistributionalDiscreteActionValue(q, self.z_values)

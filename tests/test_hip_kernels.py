@@ -956,6 +956,43 @@ def test_noisy_linear_in_the_operand_loader_is_bit_identical_to_materialised_wei
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("B", [32, 256, 5])
+def test_dueling_head_streams_as_one_launch_are_bit_identical_to_separate_layers(dev, monkeypatch, B):
+    """The advantage and value streams of the distributional dueling head (factorised NoisyNet) as
+    ONE launch on the halves of the hidden activations in place (pfrl_linear_noisy_fwd_pair) against
+    the two separate layers on a contiguous copy of the halves: distribution, and the gradients of
+    the input and of all 14 parameters, BIT-IDENTICAL on the same draws; the generator is consumed
+    identically."""
+    import pfrl_amd as pfrl
+    from pfrl_amd.q_functions import DistributionalDuelingDQN
+
+    torch.manual_seed(B)
+    q = DistributionalDuelingDQN(6, 51, -10, 10)
+    pfrl.nn.to_factorized_noisy(q, sigma_scale=0.5)
+    q = q.to(dev).to(memory_format=torch.channels_last)
+    x0 = torch.rand(B, 4, 84, 84, device=dev).contiguous(memory_format=torch.channels_last)
+    g = torch.randn(B, 6, 51, device=dev)
+    outs, rng = [], []
+    for pair in (False, True):
+        monkeypatch.setenv("PFRL_NOISY_PAIR", "1" if pair else "0")
+        torch.manual_seed(99)
+        q.zero_grad()
+        x = x0.clone().requires_grad_(True)
+        dist = q(x).q_dist
+        dist.backward(g)
+        outs.append([dist.detach().clone(), x.grad.clone()] + [p.grad.clone() for p in q.parameters()])
+        rng.append(torch.cuda.get_rng_state(dev).clone())
+    assert torch.equal(rng[0], rng[1])
+    names = ["dist", "x.grad"] + [n for n, _ in q.named_parameters()]
+    for n, a, b in zip(names, *outs):
+        if n.startswith("conv_layers") and n.endswith("weight"):
+            # (with a differentiable input this eager pass takes the library's convolution weight
+            # gradients, which are not reproducible run to run; everything the head touches is)
+            assert torch.allclose(a, b, rtol=1e-5, atol=1e-6), n
+        else:
+            assert torch.equal(a, b), n
+
+
 # ---------------------------------------------------------------------------
 # fused C51 loss
 # ---------------------------------------------------------------------------
