@@ -1186,7 +1186,7 @@ def supervise(args):
     base_port = int(os.environ.setdefault("MASTER_PORT", "29500"))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     store = dist.distributed_c10d._get_default_store()
-    limit = float(os.environ.get("PFRL_BENCH_ATTEMPT_S", "1500"))
+    limit = float(os.environ.get("PFRL_BENCH_ATTEMPT_S", "600"))
     attempts, line = [], None
     first = int(os.environ.get("PFRL_BENCH_FIRST_PLAN", "0"))
     for k, (name, extra) in list(enumerate(DP_PLANS))[first:]:
@@ -1295,7 +1295,7 @@ def main():
 
     if world > 1:
         _WATCHDOG[0] = _StallWatchdog(args, rank, world, result_fd,
-                                      float(os.environ.get("PFRL_BENCH_STALL_S", "600")))
+                                      float(os.environ.get("PFRL_BENCH_STALL_S", "300")))
     run_guarded = run_workload
     if torch.distributed.is_initialized():
         from pfrl_amd import rccl
