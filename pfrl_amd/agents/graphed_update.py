@@ -706,7 +706,7 @@ class CapturedStep:
             out.extend(b for b in m.buffers())
         return out
 
-    def _capture(self, batch, variant=None, step=None, warm=None):
+    def _capture(self, batch, variant=None, step=None, warm=None, repeat=1):
         dev = self.device
         if step is None:
             step = (lambda: self.fn(batch)) if variant is None else (lambda: self.fn(batch, variant))
@@ -739,26 +739,54 @@ class CapturedStep:
                             v.zero_()
             torch.cuda.set_rng_state(rng, dev)
 
+        from pfrl_amd.nn.noisy_linear import NoiseFeed, noise_feed
+
         cur = torch.cuda.current_stream(dev)
         side = torch.cuda.Stream(dev)
         side.wait_stream(cur)
+        noise = None
+        rec = NoiseFeed() if self._noise_feed_ok() else None
         try:
             with torch.cuda.stream(side), _no_distribution_validation():
-                for _ in range(2):
+                # first warm-up: the step draws its normals as usual and their sizes are noted;
+                # from then on they are views of one buffer that ONE launch fills per replay
+                with noise_feed(rec):
+                    warm()
+                if rec is not None and rec.sizes:
+                    noise = self._noise_buffers(rec.sizes, repeat)
+                    noise["plan"].run()
+                with noise_feed(NoiseFeed(noise["views"]) if noise else None):
                     warm()
             cur.wait_stream(side)
             for opt in self.optimizers:
                 _make_capturable(opt, dev)  # state created by the warm-up
                 opt.zero_grad(set_to_none=True)
             g = torch.cuda.CUDAGraph()
-            with _capturing(g, self.pool), _no_distribution_validation():
+            with _capturing(g, self.pool), _no_distribution_validation(), \
+                    noise_feed(NoiseFeed(noise["views"]) if noise else None):
                 out = step()
             if self.pool is None:
                 self.pool = g.pool()
         finally:
             cur.wait_stream(side)
             restore()
-        return g, out
+        return g, out, noise
+
+    def _noise_feed_ok(self):
+        if os.environ.get("PFRL_NOISE_FEED", "1") == "0" or torch.device(self.device).type != "cuda":
+            return False
+        from pfrl_amd import ops
+
+        return ops.philox_variant(self.device) is not None
+
+    def _noise_buffers(self, sizes, repeat):
+        from pfrl_amd import ops
+
+        sizes = list(sizes) * repeat
+        pos = sum((n + 3) & ~3 for n in sizes)
+        buf = torch.zeros(pos, dtype=torch.float32, device=self.device)
+        plan = ops.RandnPlan(sizes, self.device, out=buf)
+        return {"sizes": sizes, "buf": buf, "views": plan.views, "plan": plan}
 
     def run_range(self, big, variants):
         """``big``: dict of tensors with a leading update axis U (one fused gather for all
@@ -778,8 +806,10 @@ class CapturedStep:
                 return self.fn(slice_of(p)) if v is None else self.fn(slice_of(p), v)
 
             entry = self._capture(None, None, step=lambda: [call(p) for p in range(U)],
-                                  warm=lambda: call(0))
+                                  warm=lambda: call(0), repeat=U)
             self.graphs.admit(key, entry)
+        if entry[2] is not None:
+            entry[2]["plan"].run()          # every normal of the U steps: one launch per 16 draws
         entry[0].replay()
         return entry[1]
 
@@ -794,5 +824,7 @@ class CapturedStep:
         if entry is None:
             entry = self._capture(batch, variant)
             self.graphs.admit(key, entry)
+        if entry[2] is not None:
+            entry[2]["plan"].run()
         entry[0].replay()
         return entry[1]

@@ -58,6 +58,17 @@ class NoiseFeed:
         assert v.numel() == n and v.device == like.device, "noise feed out of step with the layers"
         return v
 
+    def take_shaped(self, n, shape, dtype, device):
+        """The same for a draw of another shape (``torch.empty(shape).normal_()`` of
+        ``Normal.rsample``: the kernel torch.randn(n) launches)."""
+        if self.views is None:
+            self.sizes.append(int(n))
+            return torch.empty(shape, dtype=dtype, device=device).normal_()
+        v = self.views[self.at % len(self.views)]
+        self.at += 1
+        assert v.numel() == n, "noise feed out of step with the samplers"
+        return v.view(shape)
+
 
 class noise_feed:
     """``with noise_feed(feed):`` -- the layers draw through ``feed`` (None: torch.randn)."""

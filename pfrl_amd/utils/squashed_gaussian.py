@@ -23,6 +23,26 @@ from pfrl_amd import _native
 from pfrl_amd._native import check
 
 
+_TORCH_STANDARD_NORMAL = _standard_normal
+
+
+def _eps(shape, dtype, device):
+    """The standard-normal draw of ``Normal.rsample``: through the noise feed of a captured update
+    when one is installed (nn/noisy_linear.py: one launch draws every normal of the update, bit for
+    bit and with the generator advanced as the separate calls would) -- unless somebody replaced
+    this module's ``_standard_normal`` (tests that switch the sampling noise off)."""
+    from pfrl_amd.nn import noisy_linear as nl
+
+    feed = nl._FEED[0]
+    if (feed is not None and _standard_normal is _TORCH_STANDARD_NORMAL and dtype == torch.float32
+            and torch.device(device).type == "cuda"):
+        n = 1
+        for d in shape:
+            n *= int(d)
+        return feed.take_shaped(n, tuple(shape), dtype, device)
+    return _standard_normal(shape, dtype=dtype, device=device)
+
+
 def _p(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else None
 
@@ -93,7 +113,7 @@ def sample_with_log_prob(distrib, reparameterize, with_negation=False):
         lp = distrib.log_prob(a)
         return (a, lp, None) if with_negation else (a, lp)
     loc, scale = params
-    eps = _standard_normal(loc.shape, dtype=loc.dtype, device=loc.device)
+    eps = _eps(loc.shape, loc.dtype, loc.device)
     if reparameterize:
         a, lp, neg = _SquashedGaussian.apply(loc, scale, eps)
     else:
@@ -156,7 +176,7 @@ def head_sample_with_log_prob(x, spec, reparameterize):
     assert x.is_cuda and x.dim() == 2 and x.shape[1] == 2 * spec.A and x.dtype == torch.float32
     if x.stride(1) != 1:
         x = x.contiguous()
-    eps = _standard_normal((x.shape[0], spec.A), dtype=x.dtype, device=x.device)
+    eps = _eps((x.shape[0], spec.A), x.dtype, x.device)
     if reparameterize:
         return _SquashedHead.apply(x, eps, spec)
     with torch.no_grad():

