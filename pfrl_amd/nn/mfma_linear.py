@@ -88,13 +88,13 @@ class _Linear(torch.autograd.Function):
     """y = act(x w^T + b), act = ReLU or identity, as one autograd node."""
 
     @staticmethod
-    def forward(ctx, x, w, b, relu):
+    def forward(ctx, x, w, b, relu, splits=None):
         M, K = x.shape
         Fo = w.shape[0]
         x = x.contiguous()
         lib = _native.lib()
         y = torch.empty((M, Fo), dtype=torch.float32, device=x.device)
-        splits = _fwd_splits(M, Fo, K)
+        splits = _fwd_splits(M, Fo, K) if splits is None else int(splits)
         if splits == 1:
             check(lib.pfrl_linear_fwd(_p(x), _p(w), _p(b), _p(y), M, K, Fo, int(relu), 1, _stream()),
                   "linear_fwd")
@@ -126,7 +126,7 @@ class _Linear(torch.autograd.Function):
             db = torch.empty(Fo, dtype=torch.float32, device=dev)
             check(_native.lib().pfrl_linear_small_bwd(_p(dyc), _p(x), _p(w), _p(dx), _p(dw), _p(db), M, K,
                                                       Fo, _stream()), "linear_small_bwd")
-            return dx, dw, db, None
+            return dx, dw, db, None, None
         if not _bwd_kernels_cover(M, K, Fo):
             # ragged layers (first layer of an MLP, 2 * action_size heads)
             need_w = ctx.needs_input_grad[1]
@@ -159,7 +159,7 @@ class _Linear(torch.autograd.Function):
             elif need_w:
                 dw = g.t() @ x
                 db = g.sum(0) if ctx.needs_input_grad[2] else None
-            return dx, dw, db, None
+            return dx, dw, db, None, None
         dy = dy.contiguous()
         lib = _native.lib()
         if not ctx.needs_input_grad[1]:
@@ -169,7 +169,7 @@ class _Linear(torch.autograd.Function):
                 dx = torch.empty_like(x)
                 check(lib.pfrl_conv2d_nhwc_bwd_data(_p(dy), _p(y), _p(w), None, _p(dx), M, 1, 1, K, Fo,
                                                     1, 1, 1, 0, 0, _stream()), "linear_bwd_data")
-            return dx, None, None, None
+            return dx, None, None, None, None
         dw = torch.empty_like(w)
         db = torch.empty(Fo, dtype=torch.float32, device=dev)
         splits = _t._wgrad_splits(M, Fo, K)
@@ -199,7 +199,7 @@ class _Linear(torch.autograd.Function):
                   "linear_bwd_weight")
         if splits > 1:
             dw, db = _fold_or_sink(part, stride, splits, w.data_ptr(), ctx.b_ptr, dw, db, nW, Fo)
-        return dx, dw, db, None
+        return dx, dw, db, None, None
 
 
 def _reduce_noisy(part, y, mu_b, sigma_b, r_out, n, splits, ncol, relu):
@@ -235,7 +235,7 @@ class _NoisyLinear(torch.autograd.Function):
         x = x.contiguous()
         lib = _native.lib()
         y = torch.empty((M, Fo), dtype=torch.float32, device=x.device)
-        splits = _fwd_splits(M, Fo, K)
+        splits = noisy_fwd_splits(M, Fo, K)
         if splits == 1:
             check(lib.pfrl_linear_noisy_fwd(_p(x), _p(mu_w), _p(sigma_w), _p(mu_b), _p(sigma_b), _p(r),
                                             _p(y), M, K, Fo, int(relu), 1, _stream()), "linear_noisy_fwd")
@@ -257,7 +257,7 @@ class _NoisyLinear(torch.autograd.Function):
         check(lib.pfrl_noisy_weights_fwd(_p(mu_w), _p(sigma_w), None, None, _p(r), _p(w), None, Fo, K,
                                          _stream()), "noisy_weights_fwd")
         need_w = any(ctx.needs_input_grad[1:5])
-        dx, dw, db, _ = _Linear.backward(
+        dx, dw, db, _, _ = _Linear.backward(
             _Ctx((x, w, y), (ctx.needs_input_grad[0], need_w, need_w, False), ctx.relu), dy)
         if not need_w:
             return dx, None, None, None, None, None, None
@@ -330,6 +330,21 @@ def noisy_pair_supported(h, a, v):
     return (narrow and os.environ.get("PFRL_NOISY_PAIR", "1") != "0"
             and noisy_supported(h[:, :K], ma, a.sigma.weight, a.mu.bias, a.sigma.bias)
             and noisy_supported(h[:, :K], mv, v.sigma.weight, v.mu.bias, v.sigma.bias))
+
+
+def noisy_fwd_splits(M, Fo, K):
+    """Split-K of a NoisyNet layer's forward: twice the plain layer's (the loader streams mu AND
+    sigma: 25.7 MB for the 3136 x 1024 layer of the Rainbow head, and the launch is bound by how
+    many workgroups have loads in flight -- 7 -> 14 splits: Rainbow +4 %, 28: +0.6 % more).  Used by
+    both noisy paths (in-loader and materialised), so that they stay bit-identical."""
+    s = _fwd_splits(M, Fo, K)
+    if s == 1:
+        return 1
+    if os.environ.get("PFRL_NOISY_SPLITS"):      # (A/B experiments)
+        return max(1, min(_ceil_div(K, 32), int(os.environ["PFRL_NOISY_SPLITS"])))
+    nch = _ceil_div(K, 32)
+    cps = _ceil_div(nch, min(nch, 2 * s))
+    return _ceil_div(nch, cps)
 
 
 def noisy_supported(x, mu_w, sigma_w, mu_b, sigma_b):

@@ -142,7 +142,9 @@ class FactorizedNoisyLinear(nn.Module):
                         and mfma_linear.supported_tensors(x, weight, bias)):
                     # the noisy weights are a dense [out, in] matrix: the GEMM (and its
                     # backward towards mu / sigma) on the MFMA linear kernels
-                    return mfma_linear._Linear.apply(x, weight, bias, bool(relu))
+                    return mfma_linear._Linear.apply(
+                        x, weight, bias, bool(relu),
+                        mfma_linear.noisy_fwd_splits(x.shape[0], weight.shape[0], weight.shape[1]))
                 y = F.linear(x, weight, bias)
                 return F.relu(y) if relu else y
         noise = _shaped_noise(in_features + out_features, self.sigma.weight)
