@@ -105,7 +105,47 @@ class _GraphCache(collections.OrderedDict):
         self[key] = entry
 
 
-def _hyper_signature(optimizers):
+class _DeviceLR:
+    """Learning rates of stock ``torch.optim.Adam`` optimizers held in DEVICE scalars while a step
+    is captured, so that the graph reads them from memory instead of baking them in: a schedule
+    that moves ``param_group["lr"]`` every step (the reference's ``LinearInterpolationHook`` on the
+    learning rate, examples/atari/train_ppo_ale.py:307-311) then costs one scalar fill per change
+    instead of a new capture per rollout.  Users keep seeing Python floats in
+    ``param_groups``: the tensors are installed around warm-up / capture only."""
+
+    def __init__(self, optimizers, device):
+        self.slots = []
+        self.ok = bool(optimizers)
+        for opt in optimizers:
+            if type(opt) is not torch.optim.Adam:
+                self.ok = False
+                return
+            for g in opt.param_groups:
+                if isinstance(g["lr"], torch.Tensor) or g.get("amsgrad") or not g.get("fused"):
+                    self.ok = False
+                    return
+                self.slots.append([g, torch.tensor(float(g["lr"]), dtype=torch.float32, device=device),
+                                   float(g["lr"])])
+
+    def install(self):
+        for g, t, last in self.slots:
+            g["lr"] = t
+
+    def restore(self):
+        for g, t, last in self.slots:
+            g["lr"] = last
+
+    def sync(self):
+        """Before a replay: whatever a hook wrote into the groups since goes to the device."""
+        for slot in self.slots:
+            g, t, last = slot
+            v = float(g["lr"])
+            if v != last:
+                t.fill_(v)
+                slot[2] = v
+
+
+def _hyper_signature(optimizers, skip=()):
     """What a captured optimizer launch bakes in as kernel arguments: the Python-number
     hyperparameters of every parameter group.  Part of the graph key, so that a changed
     learning rate (a schedule hook) captures anew instead of replaying the old value."""
@@ -117,7 +157,7 @@ def _hyper_signature(optimizers):
             # (flags such as `capturable` are switched by the capture itself: numbers only)
             sig.append(tuple((k, v if isinstance(v, (int, float, tuple)) else id(v))
                              for k, v in sorted(g.items())
-                             if k != "params" and not isinstance(v, bool)
+                             if k != "params" and k not in skip and not isinstance(v, bool)
                              and isinstance(v, (int, float, tuple, torch.Tensor))))
     return tuple(sig)
 
@@ -685,7 +725,7 @@ class CapturedStep:
     capturable code path.  The returned tensors are owned by the graph.
     """
 
-    def __init__(self, fn, modules, optimizers, device, max_graphs=64):
+    def __init__(self, fn, modules, optimizers, device, max_graphs=64, lr_on_device=False):
         self.fn = fn
         self.modules = [m for m in modules if m is not None]
         self.optimizers = [o for o in optimizers if o is not None]
@@ -693,6 +733,10 @@ class CapturedStep:
         self.graphs = _GraphCache(max_graphs)
         self.pool = None
         self.max_graphs = max_graphs
+        self.device_lr = None
+        if lr_on_device and os.environ.get("PFRL_LR_ON_DEVICE", "1") != "0":
+            d = _DeviceLR(self.optimizers, device)
+            self.device_lr = d if d.ok else None
 
     @staticmethod
     def _key(batch):
@@ -746,6 +790,9 @@ class CapturedStep:
         side.wait_stream(cur)
         noise = None
         rec = NoiseFeed() if self._noise_feed_ok() else None
+        if self.device_lr is not None:
+            self.device_lr.sync()
+            self.device_lr.install()
         try:
             with torch.cuda.stream(side), _no_distribution_validation():
                 # first warm-up: the step draws its normals as usual and their sizes are noted;
@@ -770,6 +817,8 @@ class CapturedStep:
         finally:
             cur.wait_stream(side)
             restore()
+            if self.device_lr is not None:
+                self.device_lr.restore()
         return g, out, noise
 
     def _noise_feed_ok(self):
@@ -819,11 +868,14 @@ class CapturedStep:
         to ``fn`` as a second argument when not None.  ``baked`` (hashable): every Python-side
         number ``fn`` reads while it is captured (loss coefficients, clip ranges, ...) -- they
         become kernel arguments of the graph, so a changed value must capture anew."""
-        key = (self._key(batch), variant, _hyper_signature(self.optimizers), baked)
+        skip = ("lr",) if self.device_lr is not None else ()
+        key = (self._key(batch), variant, _hyper_signature(self.optimizers, skip), baked)
         entry = self.graphs.lookup(key)
         if entry is None:
             entry = self._capture(batch, variant)
             self.graphs.admit(key, entry)
+        if self.device_lr is not None:
+            self.device_lr.sync()
         if entry[2] is not None:
             entry[2]["plan"].run()
         entry[0].replay()

@@ -777,8 +777,9 @@ class PPO(agent.AttributeSavingMixin, agent.BatchAgent):
         if self._update_graph is None:
             from pfrl_amd.agents.graphed_update import CapturedStep
 
+            # (the learning rate in a device scalar: an lr schedule does not re-capture)
             self._update_graph = CapturedStep(self._minibatch_step, [self.model], [self.optimizer],
-                                              self.device)
+                                              self.device, lr_on_device=True)
         return cols
 
     def _minibatch_step(self, batch):

@@ -458,6 +458,70 @@ def test_ppo_captured_minibatch_update_equals_the_eager_update(monkeypatch):
     np.testing.assert_allclose(la, lb, rtol=1e-5, atol=1e-6)
 
 
+def test_ppo_schedules_on_lr_and_clip_eps_reach_the_captured_update(monkeypatch):
+    """the captured minibatch update used to bake ``clip_eps`` in and to
+    re-capture every rollout under an lr schedule.  Now the graph is keyed by the Python-side
+    numbers it bakes (a changed ``clip_eps`` captures anew) and reads the learning rate from a
+    device scalar (a changed lr does NOT): a run with both schedules equals the eager run, with one
+    graph per distinct clip_eps."""
+    import pfrl_amd as pfrl
+    from pfrl_amd import agents
+    from pfrl_amd.device_store import DeviceFrameStore
+    from pfrl_amd.envs import SyntheticAtariVectorEnv
+    from pfrl_amd.nn import Branched
+    from pfrl_amd.policies import SoftmaxCategoricalHead
+
+    dev = torch.device("cuda:0")
+    N, T, rollouts = 32, 16, 4
+    table = np.random.RandomState(7).randint(0, 6, size=(T * rollouts + 1, N))
+
+    def run(graph):
+        monkeypatch.setenv("PFRL_PPO_UPDATE_GRAPH", "1" if graph else "0")
+        pfrl.utils.set_random_seed(0)
+        torch.manual_seed(99)
+        model = torch.nn.Sequential(
+            torch.nn.Flatten(), torch.nn.Linear(4 * 144, 64), torch.nn.ReLU(),
+            Branched(torch.nn.Sequential(torch.nn.Linear(64, 6), SoftmaxCategoricalHead()),
+                     torch.nn.Linear(64, 1)))
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3, eps=1e-5, fused=True)
+        store = DeviceFrameStore((T + 8) * N + 512, (12, 12), torch.uint8, dev, stack=4)
+        env = SyntheticAtariVectorEnv(N, store=store, seed=3, frame_shape=(12, 12), p_done=0.05)
+        ag = agents.PPO(model, opt, gpu=0, phi=lambda x: np.asarray(x, dtype=np.float32) / 255,
+                        update_interval=N * T, minibatch_size=N * T // 4, epochs=2, clip_eps=0.2,
+                        standardize_advantages=True, entropy_coef=1e-2, max_grad_norm=0.5)
+        step = [0]
+
+        def replay_action(distrib):
+            a = torch.as_tensor(table[step[0]], device=dev)
+            step[0] += 1
+            return a
+
+        ag._sample_action = replay_action
+        obss = env.reset()
+        for t in range(T * rollouts):
+            # what LinearInterpolationHook does before every step (train_ppo_ale.py:301-311)
+            for g in opt.param_groups:
+                g["lr"] = 1e-3 * (1.0 - 0.5 * t / (T * rollouts))
+            ag.clip_eps = 0.2 if t < 2 * T else 0.1
+            a = ag.batch_act(obss)
+            obss, r, d, _ = env.step(a)
+            ag.batch_observe(obss, r, d, np.zeros(N, dtype=bool))
+            obss = env.reset(~d)
+        torch.cuda.synchronize()
+        assert ag.n_updates == rollouts * 8
+        n_graphs = len(ag._update_graph.graphs) if graph else 0
+        assert all(isinstance(g["lr"], float) for g in opt.param_groups)
+        return (np.concatenate([p.detach().cpu().numpy().ravel() for p in model.parameters()]),
+                ag.value_loss_record.values(), ag.policy_loss_record.values(), n_graphs)
+
+    pa, va, la, n_graphs = run(True)
+    pb, vb, lb, _ = run(False)
+    assert n_graphs == 2            # one per clip_eps value; four different learning rates
+    np.testing.assert_allclose(pa, pb, rtol=2e-6, atol=2e-7)
+    np.testing.assert_allclose(va, vb, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(la, lb, rtol=1e-5, atol=1e-6)
+
+
 def _rainbow_run(monkeypatch, feed, steps=10):
     import bench
 
