@@ -71,6 +71,133 @@ __device__ void repair_paths(const pfrl_tree_t &T, bool active, int64_t x) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// repair_paths without a memory round trip per level (round 5).  repair_paths() walks the levels
+// between barriers and every level READS the two children from memory that the level below has
+// just STORED: 21 levels x (barrier + store -> fence -> load through L2) = 28 us for a minibatch's
+// priorities plus the pending appends, on the chain the next minibatch's draws wait for.  Here a
+// thread carries its path node in registers.  What it needs per level is the SIBLING: either
+// untouched by this launch -- then its value is in memory already, and the siblings of ALL levels
+// are requested up front, one round trip for the whole walk -- or on another thread's path, and
+// then that thread publishes its node per level in a small LDS hash table keyed by the node's
+// index (three tables in rotation: insert, barrier, look up; the table of two levels ago is
+// cleared meanwhile).  Same typed reductions on the same operands as repair_paths: the nodes come
+// out bit-identical; threads whose paths merge compute (and store) identical parents.
+// Launches of up to 256 leaves on frames of up to 2^24 leaves; anything else takes repair_paths.
+// ---------------------------------------------------------------------------------------------
+constexpr int kFastThreads = 128;
+constexpr int kFastLevels = 22;
+constexpr int kHashSlots = 256;
+
+struct PathTab {
+    int key[kHashSlots];
+    double sv[kHashSlots], mv[kHashSlots];
+    int tags[kHashSlots];      // sum tag | min tag << 8
+};
+
+// LDS of the fast kernels (dynamic: 80 KB): the three tables, the prefetched siblings [level][thread]
+// and the scratch arrays of set_priorities_leaves
+struct FastLds {
+    PathTab tab[3];
+    double sib_sv[kFastLevels][kFastThreads], sib_mv[kFastLevels][kFastThreads];
+    int sib_tg[kFastLevels][kFastThreads];
+    double s_v[kFastThreads];
+    int64_t s_x[kFastThreads];
+    uint8_t s_t[kFastThreads];
+};
+
+__device__ __forceinline__ int path_hash(int key) { return (int)(((unsigned)key * 2654435761u) >> 24); }
+
+__device__ void repair_paths_hashed(const pfrl_tree_t &T, bool active, int64_t x, FastLds &S) {
+    const int L = T.log2_size;
+    const int tid = threadIdx.x;
+    if (active && (x < T.base || x >= T.base + ((int64_t)1 << L))) active = false;
+    if (!active) x = T.base;
+    for (int i = tid; i < 3 * kHashSlots; i += blockDim.x) S.tab[i / kHashSlots].key[i % kHashSlots] = -1;
+    __threadfence_block();
+    __syncthreads();            // every leaf of this launch is stored; tables empty
+    // my leaf as it stands now (a later write of the launch may have replaced what I stored) and
+    // the sibling of my path node at every level: all requested before anything is waited for,
+    // then parked in LDS (the level loop below is rolled: its 22 typed bodies unrolled are 12 700
+    // instructions of once-executed straight-line code, and a cold launch pays an instruction
+    // fetch stall per line -- DESIGN_LOG 2a -- while register arrays indexed by a run-time level
+    // end up in scratch memory)
+    const int64_t ileaf = node_idx(T, 0, x);
+    const double leaf_sv = T.sum_val[ileaf], leaf_mv = T.min_val[ileaf];
+    const int leaf_st = T.sum_tag[ileaf], leaf_mt = T.min_tag[ileaf];
+    {
+        double sv[kFastLevels], mv[kFastLevels];
+        int tg[kFastLevels];
+#pragma unroll
+        for (int l = 0; l < kFastLevels; ++l) {
+            const int ll = l < L ? l : 0;               // (levels past the root: a valid dummy address)
+            const int64_t half = (int64_t)1 << ll;
+            const int64_t xp = x - ((x - T.origin[ll + 1]) & (2 * half - 1));   // parent's span start
+            const int64_t xme = x - ((x - T.origin[ll]) & (half - 1));           // my node's span start
+            const int64_t is = node_idx(T, ll, xme == xp ? xp + half : xp);
+            sv[l] = T.sum_val[is];
+            mv[l] = T.min_val[is];
+            tg[l] = (int)T.sum_tag[is] | ((int)T.min_tag[is] << 8);
+        }
+#pragma unroll
+        for (int l = 0; l < kFastLevels; ++l) {
+            S.sib_sv[l][tid] = sv[l];
+            S.sib_mv[l][tid] = mv[l];
+            S.sib_tg[l][tid] = tg[l];
+        }
+    }
+    TV cs = mk_tv(leaf_sv, leaf_st), cm = mk_tv(leaf_mv, leaf_mt);
+#pragma unroll 1
+    for (int l = 0; l < L; ++l) {                    // (L is uniform: the barriers are taken by all)
+        PathTab &h = S.tab[l % 3];
+        const int64_t half = (int64_t)1 << l;
+        const int64_t xp = x - ((x - T.origin[l + 1]) & (2 * half - 1));
+        const int64_t xme = x - ((x - T.origin[l]) & (half - 1));
+        const bool left = xme == xp;
+        if (active) {
+            const int key = (int)node_idx(T, l, xme);
+            int s_ = path_hash(key) & (kHashSlots - 1);
+            while (true) {
+                const int old = atomicCAS(&h.key[s_], -1, key);
+                if (old == -1 || old == key) break;      // (same key: a merged path, same values)
+                s_ = (s_ + 1) & (kHashSlots - 1);
+            }
+            h.sv[s_] = cs.v;
+            h.mv[s_] = cm.v;
+            h.tags[s_] = cs.t | (cm.t << 8);
+        }
+        __threadfence_block();
+        __syncthreads();
+        if (active) {
+            const int tg = S.sib_tg[l][tid];
+            TV ss = mk_tv(S.sib_sv[l][tid], tg & 255), sm = mk_tv(S.sib_mv[l][tid], tg >> 8);
+            const int skey = (int)node_idx(T, l, left ? xp + half : xp);
+            int s_ = path_hash(skey) & (kHashSlots - 1);
+            while (true) {
+                const int k_ = h.key[s_];
+                if (k_ == -1) break;
+                if (k_ == skey) {                        // the sibling is on another thread's path
+                    ss = mk_tv(h.sv[s_], h.tags[s_] & 255);
+                    sm = mk_tv(h.mv[s_], h.tags[s_] >> 8);
+                    break;
+                }
+                s_ = (s_ + 1) & (kHashSlots - 1);
+            }
+            cs = left ? reduce_sum(cs, ss) : reduce_sum(ss, cs);
+            cm = left ? reduce_min(cm, sm) : reduce_min(sm, cm);
+            const int64_t ip = node_idx(T, l + 1, x);
+            T.sum_val[ip] = cs.v;
+            T.sum_tag[ip] = (uint8_t)cs.t;
+            T.min_val[ip] = cm.v;
+            T.min_tag[ip] = (uint8_t)cm.t;
+        }
+        // the table of level l - 1 (read for the last time before the barrier above) is the one
+        // level l + 2 inserts into, a barrier from now
+        PathTab &old_tab = S.tab[(l + 2) % 3];
+        for (int i = tid; i < kHashSlots; i += blockDim.x) old_tab.key[i] = -1;
+    }
+}
+
 __global__ __launch_bounds__(kMaxBatch) void k_tree_write(pfrl_tree_t T, int64_t n,
                                                           const int64_t *__restrict__ x,
                                                           const double *__restrict__ val,
@@ -1445,6 +1572,40 @@ extern "C" int pfrl_tree_write(const pfrl_tree_t *tree, int64_t n, const int64_t
     PFRL_LAUNCH_CHECK();
 }
 
+// k_tree_update_errors_write for launches of up to 256 leaves: the same leaf stores, then
+// repair_paths_hashed instead of repair_paths.
+__global__ __launch_bounds__(kFastThreads) void k_tree_update_errors_write_fast(
+    pfrl_tree_t T, int64_t B, const int64_t *__restrict__ x, const float *__restrict__ err,
+    ErrCfg c, int dedupe, int64_t n, const int64_t *__restrict__ wx,
+    const double *__restrict__ wval, const uint8_t *__restrict__ wtag,
+    const uint8_t *__restrict__ wuse_maxp) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char fast_lds_raw[];
+    FastLds &S = *reinterpret_cast<FastLds *>(fast_lds_raw);
+    const int i = threadIdx.x;
+    TV p = mk_tv(0.0, PFRL_TAG_PY);
+    if (i < B) p = priority_of_error(c, err[i]);
+    int64_t xi;
+    bool active = set_priorities_leaves(T, B, x, p, dedupe, S.s_v, S.s_t, S.s_x, xi);
+    __threadfence_block();
+    __syncthreads();             // max_priority and the minibatch's leaves are in place
+    const int64_t k = (int64_t)i - B;
+    if (k >= 0 && k < n) {
+        xi = wx[k];
+        TV q;
+        if (wuse_maxp && wuse_maxp[k])
+            q = mk_tv(*T.maxp_val, *T.maxp_tag);
+        else
+            q = mk_tv(wval[k], wtag[k]);
+        const int64_t il = node_idx(T, 0, xi);
+        T.sum_val[il] = q.v;
+        T.sum_tag[il] = (uint8_t)q.t;
+        T.min_val[il] = q.v;
+        T.min_tag[il] = (uint8_t)q.t;
+        active = true;
+    }
+    repair_paths_hashed(T, active, xi, S);
+}
+
 extern "C" int pfrl_tree_write_sum(const pfrl_tree_t *tree, int64_t n, const int64_t *x,
                                    const double *val, const uint8_t *tag, double *old_val,
                                    uint8_t *old_tag, void *stream) {
@@ -1562,8 +1723,22 @@ extern "C" int pfrl_tree_update_errors_write_f32(
     c.alpha = alpha;
     c.pow_mode = pow_mode;
     int threads = (int)((B + n + 63) / 64 * 64);
-    hipLaunchKernelGGL(k_tree_update_errors_write, dim3(1), dim3(threads), 0, (hipStream_t)stream,
-                       *tree, B, x, err, c, dedupe, n, wx, wval, wtag, wuse_maxp);
+    // PFRL_TREE_REPAIR=levels: the level-by-level repair for every launch (A/B, tests)
+    const char *repair_env = getenv("PFRL_TREE_REPAIR");     // (read per call: tests switch it)
+    const bool hashed = !(repair_env != nullptr && repair_env[0] == 'l');
+    if (hashed && B + n <= kFastThreads && tree->log2_size <= kFastLevels && tree->log2_size >= 1) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_tree_update_errors_write_fast),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(FastLds));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(k_tree_update_errors_write_fast, dim3(1), dim3(threads), sizeof(FastLds),
+                           (hipStream_t)stream, *tree, B, x, err, c, dedupe, n, wx, wval, wtag, wuse_maxp);
+    }
+    else
+        hipLaunchKernelGGL(k_tree_update_errors_write, dim3(1), dim3(threads), 0, (hipStream_t)stream,
+                           *tree, B, x, err, c, dedupe, n, wx, wval, wtag, wuse_maxp);
     PFRL_LAUNCH_CHECK();
 }
 

@@ -313,6 +313,63 @@ def test_update_errors_f32_priority_transform(dev, alpha):
         np.testing.assert_array_equal(lv[x], wv)      # 0 ulp, f32 and Python-float branches
 
 
+@pytest.mark.parametrize("cap,B,max_new", [(5, 2, 3), (64, 8, 20), (1000, 32, 24), (100000, 32, 90),
+                                          (300, 32, 96)])
+@pytest.mark.parametrize("repair", ["hashed", "levels"])
+def test_priority_update_with_pending_writes_in_one_launch_matches_the_oracle(dev, monkeypatch, cap, B,
+                                                                             max_new, repair):
+    """update_errors of a minibatch followed by the appends / pops recorded since, as ONE launch
+    (pfrl_tree_update_errors_write_f32): with the round-5 path repair (every thread carries its path
+    node in registers, siblings of all levels requested up front, merged paths meet in an LDS hash
+    table per level: k_tree_update_errors_write_fast) and with the level-by-level repair it
+    replaces on the chain -- sampled indices, priorities, root statistics every round and EVERY
+    node of both trees, type tags included, against the pointer-tree oracle."""
+    from pfrl_amd import ops
+    from pfrl_amd.collections.prioritized import PrioritizedBuffer
+
+    monkeypatch.setenv("PFRL_TREE_REPAIR", repair)
+    alpha, eps = 0.5, 0.01
+    mode = ops.powf_host_variant(alpha)
+    assert mode is not None
+    rs = np.random.RandomState(cap + B)
+    buf = PrioritizedBuffer(cap, device=dev)
+    orc = oracle.OraclePrioritizedBuffer(cap)
+    nxt = 0
+    for _ in range(min(cap, 3 * B + 7)):
+        buf.append(nxt)
+        orc.append(nxt)
+        nxt += 1
+    assert buf.defer_errors
+    for r in range(40):
+        n = min(B, len(buf))
+        u = rs.random_sample(n)
+        out = buf.sample_device(n, u01=u)              # (launches the previous round's errors + writes)
+        want = orc.sample(u)
+        np.testing.assert_array_equal(out["x"].cpu().numpy() - buf.frame.head, want["indices"])
+        np.testing.assert_array_equal(out["pri"].cpu().numpy(), want["priorities"])
+        np.testing.assert_array_equal(out["pri_tag"].cpu().numpy(), want["priority_tags"])
+        err = (rs.rand(n) * 1.5).astype(np.float32)
+        if r % 3 == 0:
+            err[: n // 2] = err[0]                     # (equal priorities, and duplicates when n > len)
+        buf.update_errors_device(torch.from_numpy(err).to(dev), 0, (0 + eps) ** alpha, 1,
+                                 (1 + eps) ** alpha, eps, alpha, pow_mode=mode)
+        orc.set_last_priority(*oracle.priority_from_errors_f32(err, 0, 1, eps, alpha))
+        for _ in range(int(rs.randint(0, max_new + 1))):
+            pr = None if rs.rand() < 0.7 else float(rs.rand() * 2 + 0.01)
+            buf.append(nxt, priority=pr)
+            orc.append(nxt, pr)
+            nxt += 1
+        if r % 8 == 7:
+            st, so = buf.root_stats(), orc.stats()
+            assert st[0] == so["sum"] and st[1] == so["min"] and st[2] == so["max_priority"], r
+            for l in range(buf.frame.log2_size + 1):
+                for which in (0, 1):
+                    gv, gt = buf.dump_level(which, l)
+                    ov, ot = orc.dump_level(which, 1 << l)
+                    np.testing.assert_array_equal(gt, ot)
+                    np.testing.assert_array_equal(gv, ov)
+
+
 def test_split_sample_keeps_the_priority_update_in_front_of_more_than_one_launch_of_writes(dev):
     """sample_device(split=True) with more than 1 024 recorded leaf writes (a large
     update_interval at capacity: every look-ahead append pops first) used to flush at prepare
