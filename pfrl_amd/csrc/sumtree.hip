@@ -85,30 +85,37 @@ __device__ void repair_paths(const pfrl_tree_t &T, bool active, int64_t x) {
 // out bit-identical; threads whose paths merge compute (and store) identical parents.
 // Launches of up to 256 leaves on frames of up to 2^24 leaves; anything else takes repair_paths.
 // ---------------------------------------------------------------------------------------------
-constexpr int kFastThreads = 128;
+constexpr int kFastThreads = 128;     // largest launch of the fast kernels
 constexpr int kFastLevels = 22;
-constexpr int kHashSlots = 256;
 
+template <int SLOTS>
 struct PathTab {
-    int key[kHashSlots];
-    double sv[kHashSlots], mv[kHashSlots];
-    int tags[kHashSlots];      // sum tag | min tag << 8
+    int key[SLOTS];
+    double sv[SLOTS], mv[SLOTS];
+    int tags[SLOTS];      // sum tag | min tag << 8
 };
 
-// LDS of the fast kernels (dynamic: 80 KB): the three tables, the prefetched siblings [level][thread]
-// and the scratch arrays of set_priorities_leaves
+// LDS of the fast kernels (dynamic; 38 KB for launches of up to 64 leaves, 76 KB up to 128 -- the
+// smaller the better: the workgroup has to find a CU with that much LDS free beside the backward
+// pass running on the other stream): the three tables (2 slots per thread), the prefetched
+// siblings [level][thread] and the scratch arrays of set_priorities_leaves
+template <int THREADS>
 struct FastLds {
-    PathTab tab[3];
-    double sib_sv[kFastLevels][kFastThreads], sib_mv[kFastLevels][kFastThreads];
-    int sib_tg[kFastLevels][kFastThreads];
-    double s_v[kFastThreads];
-    int64_t s_x[kFastThreads];
-    uint8_t s_t[kFastThreads];
+    static constexpr int kHashSlots = 2 * THREADS;
+    PathTab<2 * THREADS> tab[3];
+    double sib_sv[kFastLevels][THREADS], sib_mv[kFastLevels][THREADS];
+    int sib_tg[kFastLevels][THREADS];
+    double s_v[THREADS];
+    int64_t s_x[THREADS];
+    uint8_t s_t[THREADS];
 };
 
-__device__ __forceinline__ int path_hash(int key) { return (int)(((unsigned)key * 2654435761u) >> 24); }
+__device__ __forceinline__ int path_hash(int key) { return (int)(((unsigned)key * 2654435761u) >> 20); }
 
-__device__ void repair_paths_hashed(const pfrl_tree_t &T, bool active, int64_t x, FastLds &S) {
+template <int THREADS>
+__device__ void repair_paths_hashed(const pfrl_tree_t &T, bool active, int64_t x, FastLds<THREADS> &S) {
+    constexpr int kHashSlots = 2 * THREADS;
+    using PathTab = PathTab<2 * THREADS>;
     const int L = T.log2_size;
     const int tid = threadIdx.x;
     if (active && (x < T.base || x >= T.base + ((int64_t)1 << L))) active = false;
@@ -1574,13 +1581,14 @@ extern "C" int pfrl_tree_write(const pfrl_tree_t *tree, int64_t n, const int64_t
 
 // k_tree_update_errors_write for launches of up to 256 leaves: the same leaf stores, then
 // repair_paths_hashed instead of repair_paths.
-__global__ __launch_bounds__(kFastThreads) void k_tree_update_errors_write_fast(
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void k_tree_update_errors_write_fast(
     pfrl_tree_t T, int64_t B, const int64_t *__restrict__ x, const float *__restrict__ err,
     ErrCfg c, int dedupe, int64_t n, const int64_t *__restrict__ wx,
     const double *__restrict__ wval, const uint8_t *__restrict__ wtag,
     const uint8_t *__restrict__ wuse_maxp) {
     extern __shared__ __attribute__((aligned(16))) unsigned char fast_lds_raw[];
-    FastLds &S = *reinterpret_cast<FastLds *>(fast_lds_raw);
+    FastLds<THREADS> &S = *reinterpret_cast<FastLds<THREADS> *>(fast_lds_raw);
     const int i = threadIdx.x;
     TV p = mk_tv(0.0, PFRL_TAG_PY);
     if (i < B) p = priority_of_error(c, err[i]);
@@ -1729,12 +1737,16 @@ extern "C" int pfrl_tree_update_errors_write_f32(
     if (hashed && B + n <= kFastThreads && tree->log2_size <= kFastLevels && tree->log2_size >= 1) {
         static bool attr_set = false;
         if (!attr_set) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_tree_update_errors_write_fast),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(FastLds));
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_tree_update_errors_write_fast<128>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(FastLds<128>));
             attr_set = true;
         }
-        hipLaunchKernelGGL(k_tree_update_errors_write_fast, dim3(1), dim3(threads), sizeof(FastLds),
-                           (hipStream_t)stream, *tree, B, x, err, c, dedupe, n, wx, wval, wtag, wuse_maxp);
+        if (B + n <= 64)
+            hipLaunchKernelGGL(k_tree_update_errors_write_fast<64>, dim3(1), dim3(64), sizeof(FastLds<64>),
+                               (hipStream_t)stream, *tree, B, x, err, c, dedupe, n, wx, wval, wtag, wuse_maxp);
+        else
+            hipLaunchKernelGGL(k_tree_update_errors_write_fast<128>, dim3(1), dim3(128), sizeof(FastLds<128>),
+                               (hipStream_t)stream, *tree, B, x, err, c, dedupe, n, wx, wval, wtag, wuse_maxp);
     }
     else
         hipLaunchKernelGGL(k_tree_update_errors_write, dim3(1), dim3(threads), 0, (hipStream_t)stream,
