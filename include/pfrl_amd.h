@@ -201,6 +201,20 @@ typedef struct {
 int pfrl_tree_write(const pfrl_tree_t *tree, int64_t n, const int64_t *x, const double *val,
                     const uint8_t *tag, const uint8_t *use_maxp, void *stream);
 
+/* pfrl_tree_update_errors_write_f32 and pfrl_tree_sample as ONE launch: the priorities of minibatch k
+ * (pfrl/replay_buffers/prioritized.py:117-126 -> collections/prioritized.py:107-116), the appends /
+ * pops recorded since (:39-54) and the B dependent draws of minibatch k + 1 (:56-84, 294-312) -- the
+ * chain the next forward pass waits for, without the launch boundary and the second dispatch in
+ * the middle.  Be + n <= 64; same outputs, bit for bit, as the two calls. */
+int pfrl_tree_update_errors_write_sample(
+    const pfrl_tree_t *tree, int64_t Be, const int64_t *x, const float *err, int has_min,
+    float error_min, double pri_at_min, int has_max, float error_max, double pri_at_max, double eps,
+    double alpha, int dedupe, int pow_mode, int64_t n, const int64_t *wx, const double *wval,
+    const uint8_t *wtag, const uint8_t *wuse_maxp, int64_t B, const double *u01, int64_t *out_x,
+    double *out_pri, uint8_t *out_pri_tag, double *out_prob, float *out_weight, double *out_total,
+    uint8_t *out_total_tag, double *out_min_prob, int normalize, double beta, int64_t slot_mod,
+    int32_t *out_slot, void *stream);
+
 /* TreeQueue._write on the SUM tree only, for n <= 1024 distinct leaves
  * (pfrl/collections/prioritized.py:278-292 SumTreeQueue.uniform_sample: the leaves sample_n_k
  * picked are zeroed and their previous priorities returned; :289-291 / :308-310: with

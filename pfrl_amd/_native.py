@@ -168,6 +168,7 @@ EXPORTS = {
     "pfrl_batch_episodes": (ctypes.c_int, "Tpqifpppiiqqfppppppp"),
     "pfrl_tree_write": (ctypes.c_int, "Rqppppp"),
     "pfrl_tree_write_sum": (ctypes.c_int, "Rqpppppp"),
+    "pfrl_tree_update_errors_write_sample": (ctypes.c_int, "Rqppifdifdddiiqppppqpppppppppidqpp"),
     "pfrl_tree_sample": (ctypes.c_int, "Rqpppppppppidqpp"),
     "pfrl_tree_update_errors_f32": (ctypes.c_int, "Rqppifdifdddiip"),
     "pfrl_tree_update_errors_write_f32": (ctypes.c_int, "Rqppifdifdddiiqppppp"),

@@ -310,11 +310,20 @@ class PrioritizedBuffer:
         def finish():
             assert not self.wait_priority_after_sampling or not self.flag_wait_priority
             with on_stream(self.side_stream):
-                if pending is not None:
-                    pending[1](*views[1:1 + n_t])
-                elif self._pend_x or self._deferred is not None:
-                    self.flush()        # (priority update first, fused with the first 1 024 writes)
-                ops.tree_sample(self._sync_desc(), views[0], out, normalize, beta, slot_mod)
+                if self._fuse_into_sampler(n, n_t and views[1].numel(), bool(self._pend_x)):
+                    # priorities of the last minibatch + the writes recorded since + these draws:
+                    # ONE launch (nothing between the TD errors and the next minibatch but it)
+                    d, self._deferred = self._deferred, None
+                    dx, derr, dargs, dkw = d
+                    ops.tree_update_errors_write_sample(
+                        self._sync_desc(), dx, derr, *dargs, tuple(views[1:1 + n_t]) if n_t else None,
+                        views[0], out, normalize, beta, slot_mod, **dkw)
+                else:
+                    if pending is not None:
+                        pending[1](*views[1:1 + n_t])
+                    elif self._pend_x or self._deferred is not None:
+                        self.flush()        # (priority update first, fused with the first 1 024 writes)
+                    ops.tree_sample(self._sync_desc(), views[0], out, normalize, beta, slot_mod)
             self._sampled_x = out["x"]
             self._n_sampled = n
             self.flag_wait_priority = True
@@ -323,6 +332,19 @@ class PrioritizedBuffer:
         if split:
             return out, finish
         return finish()
+
+    def _fuse_into_sampler(self, n_draws, n_writes, more_pending):
+        """Can the held-back priority update (+ the staged writes) ride in the sampler's launch?
+        (pfrl_tree_update_errors_write_sample: at most 64 leaves, the lean sampler's tree sizes;
+        PFRL_TREE_FUSE_SAMPLE=0: separate launches)"""
+        d = self._deferred
+        if d is None or more_pending or os.environ.get("PFRL_TREE_FUSE_SAMPLE", "1") == "0":
+            return False
+        if os.environ.get("PFRL_TREE_SAMPLE") not in (None, "", "prefetch"):
+            return False
+        L = self.frame.log2_size
+        return (n_draws >= 1 and d[0].numel() + int(n_writes or 0) <= 64 and 1 <= L <= 22
+                and L - min(L, 9) + 1 <= 13)
 
     def sample(self, n, uniform_ratio=0):
         """prioritized.py:56-105 (host-visible results; one D2H sync).  ``uniform_ratio > 0``

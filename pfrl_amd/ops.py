@@ -305,6 +305,30 @@ def tree_update_errors_write_f32(desc, x, err, error_min, pri_at_min, error_max,
         _ptr(wt), _ptr(wm), _stream()), "tree_update_errors_write_f32")
 
 
+def tree_update_errors_write_sample(desc, x, err, error_min, pri_at_min, error_max, pri_at_max, eps,
+                                    alpha, writes, u01, out, normalize, beta, slot_mod=0, dedupe=True,
+                                    pow_mode=POW_CORRECTLY_ROUNDED):
+    """``tree_update_errors_write_f32`` (``writes`` = (x, val, tag, use_maxp) or None) followed by
+    ``tree_sample`` as one launch (pfrl_tree_update_errors_write_sample)."""
+    if writes is not None:
+        wx, wv, wt, wm = writes
+        n = wx.numel()
+    else:
+        wx = wv = wt = wm = None
+        n = 0
+    check(_native.lib().pfrl_tree_update_errors_write_sample(
+        ctypes.byref(desc), x.numel(), _ptr(x), _ptr(err),
+        int(error_min is not None), float(error_min or 0.0), float(pri_at_min or 0.0),
+        int(error_max is not None), float(error_max or 0.0), float(pri_at_max or 0.0),
+        float(eps), float(alpha), int(dedupe), int(pow_mode), n,
+        _ptr(wx) if n else None, _ptr(wv) if n else None, _ptr(wt) if n else None,
+        _ptr(wm) if n else None, u01.numel(), _ptr(u01), _ptr(out["x"]), _ptr(out["pri"]),
+        _ptr(out["pri_tag"]), _ptr(out["prob"]), _ptr(out["weight"]), _ptr(out["total"]),
+        _ptr(out["total_tag"]), _ptr(out["min_prob"]), int(normalize), float(beta), int(slot_mod),
+        _ptr(out.get("slot")), _stream()), "tree_update_errors_write_sample")
+    return out
+
+
 def tree_set_priorities(desc, x, val, tag, dedupe=True):
     check(_native.lib().pfrl_tree_set_priorities(ctypes.byref(desc), x.numel(), _ptr(x), _ptr(val),
                                                  _ptr(tag), int(dedupe), _stream()),

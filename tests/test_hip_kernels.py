@@ -315,7 +315,7 @@ def test_update_errors_f32_priority_transform(dev, alpha):
 
 @pytest.mark.parametrize("cap,B,max_new", [(5, 2, 3), (64, 8, 20), (1000, 32, 24), (100000, 32, 90),
                                           (300, 32, 96)])
-@pytest.mark.parametrize("repair", ["hashed", "levels"])
+@pytest.mark.parametrize("repair", ["fused", "hashed", "levels"])
 def test_priority_update_with_pending_writes_in_one_launch_matches_the_oracle(dev, monkeypatch, cap, B,
                                                                              max_new, repair):
     """update_errors of a minibatch followed by the appends / pops recorded since, as ONE launch
@@ -327,7 +327,18 @@ def test_priority_update_with_pending_writes_in_one_launch_matches_the_oracle(de
     from pfrl_amd import ops
     from pfrl_amd.collections.prioritized import PrioritizedBuffer
 
-    monkeypatch.setenv("PFRL_TREE_REPAIR", repair)
+    real_fused = ops.tree_update_errors_write_sample
+    n_fused = [0]
+
+    def counting(*a, **k):
+        n_fused[0] += 1
+        return real_fused(*a, **k)
+
+    monkeypatch.setattr(ops, "tree_update_errors_write_sample", counting)
+    # "fused": priorities + writes + the NEXT minibatch's draws as one launch
+    # (pfrl_tree_update_errors_write_sample) wherever they fit, else as "hashed"
+    monkeypatch.setenv("PFRL_TREE_REPAIR", "levels" if repair == "levels" else "hashed")
+    monkeypatch.setenv("PFRL_TREE_FUSE_SAMPLE", "1" if repair == "fused" else "0")
     alpha, eps = 0.5, 0.01
     mode = ops.powf_host_variant(alpha)
     assert mode is not None
@@ -368,6 +379,10 @@ def test_priority_update_with_pending_writes_in_one_launch_matches_the_oracle(de
                     ov, ot = orc.dump_level(which, 1 << l)
                     np.testing.assert_array_equal(gt, ot)
                     np.testing.assert_array_equal(gv, ov)
+    if repair == "fused" and max_new <= 24:
+        assert n_fused[0] >= 10          # (most rounds fit one launch)
+    if repair != "fused":
+        assert n_fused[0] == 0
 
 
 def test_split_sample_keeps_the_priority_update_in_front_of_more_than_one_launch_of_writes(dev):
