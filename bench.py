@@ -68,6 +68,10 @@ def parse_args():
                    help="accept PFRL_AMD_LIB (an A/B build of the native library); recorded on the line")
     p.add_argument("--no-data-path-only", action="store_true",
                    help="dqn: skip the second measurement with a zero-FLOP q_function")
+    p.add_argument("--ppo-reuse-next-values", type=int, default=1, choices=[0, 1],
+                   help="ppo: 1 = this package's default (V(next_state) read from the next step's "
+                        "V(state)); 0 = the reference's value pass over states AND next_states "
+                        "(pfrl/agents/ppo.py:110-142), reported as also.ppo_reference_semantics")
     p.add_argument("--no-also", action="store_true",
                    help="dqn: do not append the PPO configs[3] measurement ('also') to the line")
     p.add_argument("--scaling", choices=["weak", "strong"], default=None,
@@ -214,7 +218,8 @@ def build_ppo(args, device, rank):
 
     agent = agents.PPO(model, opt, gpu=device.index, phi=phi, update_interval=N * T,
                        minibatch_size=32 * N, epochs=4, clip_eps=0.1, clip_eps_vf=None,
-                       standardize_advantages=True, entropy_coef=1e-2, max_grad_norm=0.5)
+                       standardize_advantages=True, entropy_coef=1e-2, max_grad_norm=0.5,
+                       reuse_next_values=bool(getattr(args, "ppo_reuse_next_values", 1)))
     agent.grad_reducer.broadcast_parameters(agent.model)
     return agent, env, None
 
@@ -362,10 +367,14 @@ def workload_description(args, N, rbuf):
                 "on device prefilled to %d, B=%d, update_interval=1 (one update per env-step), "
                 "256-256 MLPs, Adam" % (N, args.capacity, len(rbuf), args.minibatch))
     return ("BASELINE.json configs[3]: PPO, %d synthetic Atari-shaped envs/GPU x 128-step rollouts, "
-            "reuse_next_values=True (V(next_state) from the next step's V(state): SURVEY 8(d)'s "
-            "0.854 MB/env-step variant), "
+            "%s, "
             "update_interval=%d, minibatch=%d, 4 epochs, GAE + advantage standardisation kernels, "
-            "Adam" % (N, N * 128, 32 * N))
+            "Adam" % (N, "reuse_next_values=True (V(next_state) from the next step's V(state): "
+                      "SURVEY 8(d)'s 0.854 MB/env-step variant)"
+                      if getattr(args, "ppo_reuse_next_values", 1) else
+                      "reuse_next_values=False (the reference's value pass: V over states AND "
+                      "next_states, pfrl/agents/ppo.py:110-142; SURVEY 8(d)'s 0.995 MB/env-step)",
+                      N * 128, 32 * N))
 
 
 def one_step(agent, env, obss, num_envs):
@@ -609,14 +618,15 @@ def step_flops_dqn(N, minibatch, update_interval):
     return N * NATURE_FWD_FLOPS + updates * per_update
 
 
-def step_flops_ppo(N, n_actions=6):
+def step_flops_ppo(N, n_actions=6, reuse_next_values=True):
     """Arithmetic of one batched PPO step (512 envs), the rollout's passes amortised per env step:
     acting forward, the value pass over the rollout's states (reuse_next_values: once), and 4
     epochs of forward + backward (backward = 2 x forward minus conv1's input gradient); the two
     narrow heads (512 -> A, 512 -> 1) counted with the trunk."""
     heads = 2 * 512 * (n_actions + 1)
     fwd = NATURE_FWD_FLOPS + heads
-    return N * (fwd + fwd + 4 * (3 * fwd - NATURE_CONV1_FLOPS))
+    value_passes = 1 if reuse_next_values else 2       # the reference: states AND next_states
+    return N * (fwd + value_passes * fwd + 4 * (3 * fwd - NATURE_CONV1_FLOPS))
 
 
 def mfma_per_launch(B=32, n_actions=6):
@@ -674,7 +684,7 @@ def launches_per_update():
     return None
 
 
-def algorithmic_bytes_per_step(algo, N, minibatch, update_interval):
+def algorithmic_bytes_per_step(algo, N, minibatch, update_interval, reuse_next_values=True):
     """SURVEY.md 8(d) per env-step figures x envs per batched step."""
     fb, k = 84 * 84, 4
     if algo in ("dqn", "rainbow"):
@@ -685,7 +695,7 @@ def algorithmic_bytes_per_step(algo, N, minibatch, update_interval):
         # adv-norm 12.  The reference evaluates V on states AND next_states (2 x 141,120: 994,932 B);
         # this build runs reuse_next_values=True -- V(next_state) read from the next step's V(state),
         # only episode ends re-evaluated -- which is the 0.854 MB variant SURVEY says to flag.
-        return N * (141120 + 7056 + 141120 + 4 * 141120 + 24 + 12)
+        return N * (141120 + 7056 + (1 if reuse_next_values else 2) * 141120 + 4 * 141120 + 24 + 12)
     return N * (2 * minibatch * 3084 + 3084)   # sac
 
 
@@ -695,7 +705,9 @@ def assemble_result(args, world, N, elapsed, n_updates, t_fill, workload, roofli
     if roofline is not None:
         # the step as a whole against the same roofline: the kernel fraction above is for
         # the dominant gather alone and must not be read as the end-to-end figure
-        step_bytes = algorithmic_bytes_per_step(args.algo, N, args.minibatch, args.update_interval)
+        reuse = bool(getattr(args, "ppo_reuse_next_values", 1))
+        step_bytes = algorithmic_bytes_per_step(args.algo, N, args.minibatch, args.update_interval,
+                                                reuse)
         roofline["step_algorithmic_bytes"] = int(step_bytes)
         roofline["step_frac"] = round(step_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
         if args.algo == "dqn":
@@ -724,7 +736,7 @@ def assemble_result(args, world, N, elapsed, n_updates, t_fill, workload, roofli
         if args.algo == "ppo":
             # PPO is bound by the f32 MFMA trunk at update size (B = 16384), not by the gather the
             # HBM block above describes (3 % of the device time): rollout FLOPs / time / peak
-            fl = step_flops_ppo(N)
+            fl = step_flops_ppo(N, reuse_next_values=reuse)
             tf = fl / (ms * 1e-3) / 1e12
             roofline["mfma"] = {"step_flops": int(fl), "achieved": round(tf, 2),
                                 "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -1332,6 +1344,16 @@ def main():
         if rank == 0:
             out["also"] = {"ppo": {k: also[k] for k in keys}}
         if world == 1:
+            # the same workload with the reference's own value pass (V over states AND
+            # next_states, pfrl/agents/ppo.py:110-142; this package's default reads V(next_state)
+            # from the next step's V(state)): SURVEY 8(d) says to flag the variant -- the line
+            # carries both
+            rargs = copy.copy(pargs)
+            rargs.ppo_reuse_next_values = 0
+            ref_sem = run_workload(rargs, device, rank, world, result_extras=False)
+            if rank == 0:
+                out["also"]["ppo_reference_semantics"] = {k: ref_sem[k] for k in keys}
+            del ref_sem
             # configs[2] and configs[4], short: every GPU config of BASELINE.json on one line
             for algo, n_envs, mb, blas in (("rainbow", 256, 32, "default"), ("sac", 64, 256, "tunable")):
                 a2 = copy.copy(args)
