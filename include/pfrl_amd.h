@@ -770,8 +770,10 @@ int pfrl_pyrandom_permutation(uint32_t *state625, int64_t n, int64_t *host_out);
 int pfrl_plan_eps_greedy(void *bitgen, int64_t n_envs, double epsilon, int64_t n_actions,
                          int32_t *host_choice);
 
-/* The per-env loop of DQN._batch_observe_train (pfrl/agents/dqn.py:516-549) for m envs of one
- * batched step with a uniform one-step ReplayBuffer: m appends (transition + entry rows, host
+/* The per-env loop of DQN._batch_observe_train (pfrl/agents/dqn.py:516-549) -- and the same loop
+ * of the vector-observation agents (pfrl/agents/soft_actor_critic.py:354-374, td3.py:283-303,
+ * ddpg.py:207-227; k = 1 frame per observation, the float action rows travel behind the planner's
+ * part of the block) -- for m envs of one batched step with a uniform one-step ReplayBuffer: m appends (transition + entry rows, host
  * mirrors updated, RandomAccessQueue head advanced) and every index set the loop draws between
  * them.  counters = {n_trans, n_entries, head} in / out; t0 = agent.t before the first env.
  * Everything the device needs goes into ONE pinned block (host_block; offs[0..8] = byte

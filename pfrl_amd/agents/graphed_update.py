@@ -750,7 +750,7 @@ class CapturedStep:
             out.extend(b for b in m.buffers())
         return out
 
-    def _capture(self, batch, variant=None, step=None, warm=None, repeat=1):
+    def _capture(self, batch, variant=None, step=None, warm=None, repeat=1, prewarm=None):
         dev = self.device
         if step is None:
             step = (lambda: self.fn(batch)) if variant is None else (lambda: self.fn(batch, variant))
@@ -795,6 +795,8 @@ class CapturedStep:
             self.device_lr.install()
         try:
             with torch.cuda.stream(side), _no_distribution_validation():
+                if prewarm is not None:
+                    prewarm()
                 # first warm-up: the step draws its normals as usual and their sizes are noted;
                 # from then on they are views of one buffer that ONE launch fills per replay
                 with noise_feed(rec):
@@ -854,8 +856,14 @@ class CapturedStep:
                 v = variants[p]
                 return self.fn(slice_of(p)) if v is None else self.fn(slice_of(p), v)
 
+            # warm-up: the first update of EACH variant in the range (TD3's delayed policy
+            # update only runs in every second one; lazily created state of the modules it
+            # alone reaches -- e.g. BoundByTanh's bounds on the device -- must exist before
+            # the capture begins, where a host->device copy is not permitted)
+            others = [variants.index(v) for v in dict.fromkeys(variants)][1:]
             entry = self._capture(None, None, step=lambda: [call(p) for p in range(U)],
-                                  warm=lambda: call(0), repeat=U)
+                                  warm=lambda: call(0), repeat=U,
+                                  prewarm=(lambda: [call(p) for p in others]) if others else None)
             self.graphs.admit(key, entry)
         if entry[2] is not None:
             entry[2]["plan"].run()          # every normal of the U steps: one launch per 16 draws

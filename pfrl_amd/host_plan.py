@@ -99,11 +99,17 @@ def recognise_randint(func, probes=48, max_actions=1 << 16):
 
 class DQNRangePlanner:
     """Binds the planner to one uniform, one-step device ReplayBuffer (store mirrors, queue
-    head) and plans env ranges of ``DQN._batch_observe_train`` into a pinned staging block."""
+    head) and plans env ranges of ``DQN._batch_observe_train`` -- and of the same per-env loop
+    of the vector-observation agents (pfrl/agents/soft_actor_critic.py:354-374, td3.py:283-303,
+    ddpg.py:207-227: append, then ``sample_n_k`` when an update is due) -- into a pinned staging
+    block."""
 
-    def __init__(self, rbuf):
+    def __init__(self, rbuf, float_actions=False):
         st = rbuf.store
-        assert st.n == 1 and st.desc is not None and st.act_dim == 0
+        # the planner never touches the action column: DQN's comes from the device tensor of
+        # selected actions, the vector-observation agents' (float_actions) rides in the same
+        # pinned block behind the planner's part (agents/_vector_device_step.py)
+        assert st.n == 1 and st.desc is not None and (st.act_dim == 0 or float_actions)
         self.rbuf = rbuf
         self.store = st
         d = _native.HostStoreDesc()

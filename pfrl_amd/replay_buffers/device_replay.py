@@ -297,6 +297,60 @@ class DeviceReplayStore:
             ocache.popitem(last=False)
         return refs, min_seq
 
+    def ingest_vectors(self, obs_list):
+        """:meth:`ingest` for a list of plain array observations (one frame each: the f32[376]
+        MuJoCo-shaped vectors of SAC / TD3 / DDPG) in ONE pass -> (refs int32 [n, 1], min_seq
+        int64 [n]): identity resolved through the same cache, every observation not seen before
+        gets its ring slot from one allocation, and the new ones go up in one stacked transfer.
+        None (nothing touched) when the list is not of that form or the store is not this
+        buffer's own one-frame store yet -- callers fall back to per-observation ``ingest``."""
+        fr = self.frames
+        if (fr is None or not self._own_frames or fr.stack != 1 or self._phi_at_ingest
+                or (self._phi is not None and self._divisor is None)):
+            return None
+        want = np.uint8 if fr.dtype == torch.uint8 else np.float32
+        shape = fr.frame_shape
+        size = int(np.prod(shape))
+        n = len(obs_list)
+        refs = np.empty((n, 1), dtype=np.int32)
+        seqs = np.empty(n, dtype=np.int64)
+        ocache = self._obs_cache
+        new, pos, first = [], [], {}
+        for i, obs in enumerate(obs_list):
+            hit = ocache.get(id(obs))
+            if hit is not None and hit[0] is obs:
+                refs[i, 0] = hit[1][0]
+                seqs[i] = hit[2]
+                continue
+            if not (type(obs) is np.ndarray and obs.size == size
+                    and (obs.dtype == want or (want is np.float32 and obs.dtype.kind in "fiub"))):
+                return None
+            t = first.get(id(obs))
+            if t is None:
+                t = first[id(obs)] = len(new)
+                new.append(obs)
+            pos.append((i, t))
+        if new:
+            self._flush_frames()
+            aseq, aslot = fr.alloc(len(new))
+            block = np.empty((len(new),) + tuple(shape), dtype=want)
+            for t, obs in enumerate(new):
+                block[t] = obs.reshape(shape)          # (the f32 cast of ingest(), where needed)
+            rows = self._frame_stage_rows
+            with on_stream(self.side_stream):
+                for a in range(0, len(new), rows):
+                    src, sl = self._frame_stage.upload([block[a:a + rows],
+                                                        np.asarray(aslot[a:a + rows], dtype=np.int32)])
+                    fr.write(src.view(fr.dtype).view((-1,) + tuple(shape)), sl)
+            for i, t in pos:
+                refs[i, 0] = aslot[t]
+                seqs[i] = aseq[t]
+            for t, obs in enumerate(new):
+                ocache[id(obs)] = (obs, np.array([aslot[t]], dtype=np.int32), int(aseq[t]))
+            while len(ocache) > 4096:
+                ocache.popitem(last=False)
+        return refs, seqs
+
     def _ingest_foreign(self, obs):
         """A device observation whose frames live in ANOTHER frame store (a device env that
         keeps feeding a buffer which already owns a store, e.g. after ``load()`` of a
@@ -638,10 +692,20 @@ class DeviceReplayStore:
                                   gp, flat)
         return {k: v.view((U, B) + tuple(v.shape[1:])) for k, v in flat.items()}
 
-    def fetch_many_slots(self, slots_dev, U, B, phi, gamma):
+    def fetch_many_slots(self, slots_dev, U, B, phi, gamma, alternate=True):
         """``fetch_many`` for entry slots that are already on the device (planned natively,
-        liveness checked by the planner): the one fused gather, [U, B, ...] views."""
+        liveness checked by the planner): the one fused gather, [U, B, ...] views.
+        ``alternate=False``: always the buffers of :meth:`fetch_many` (callers whose host
+        cannot run a step ahead anyway -- a host env waits for the actions -- keep one graph
+        per range instead of MANY_SETS)."""
         self.flush()
+        if not alternate:
+            flat = self._out_buffers(U * B, "many")
+            gp = [gamma ** i for i in range(self.n + 1)]
+            with on_stream(self.side_stream):
+                ops.batch_experiences(self.desc, self.frames.frames, self.divisor_for(phi),
+                                      slots_dev, gp, flat)
+            return {k: v.view((U, B) + tuple(v.shape[1:])) for k, v in flat.items()}
         # Alternate between MANY_SETS sets of minibatch buffers: every set has its own captured
         # range graph, and launching a graph while ITS previous replay is still running makes
         # hipGraphLaunch wait on the host -- with one set the host could never be more than one

@@ -229,6 +229,19 @@ class ReplayBuffer(replay_buffer.AbstractReplayBuffer):
                 and st.desc is not None and st.act_dim == 0 and st.frames is not None
                 and getattr(obs_batch, "store", None) is st.frames and not st._phi_at_ingest)
 
+    def vector_range_append_supported(self):
+        """The native append + draw walk of the vector-observation agents applies
+        (agents/_vector_device_step.py): uniform device replay with one-step entries whose
+        tables exist, float action rows, this buffer's own one-frame store, no per-transition
+        extras."""
+        st = self.store
+        return (st is not None and type(self.memory) is _DeviceQueue and self.num_steps == 1
+                and st.desc is not None and st.act_dim is not None and st.act_dim > 0
+                and st.k == 1 and st.frames is not None and st._own_frames
+                and not st._phi_at_ingest and not st.h_extra
+                and type(self).append is ReplayBuffer.append
+                and type(self).stop_current_episode is ReplayBuffer.stop_current_episode)
+
     def append_batch_n1(self, s_refs, s_min_seq, actions, rewards, n_refs, n_min_seq, terminals):
         """``append(...)`` for m envs in env order, num_steps == 1 (each append emits its own
         one-transition entry at once; reference replay_buffer.py:33-62), as array writes.

@@ -270,6 +270,22 @@ def test_rainbow_configs2_at_capacity_1e6_tree_matches_oracle():
     assert tree.frame.log2_size in (20, 21)
 
 
+def _spy_planned_gather(rbuf, fetched, keep):
+    """The same record as the ``fetch_many`` spies below for ranges planned natively
+    (agents/_vector_device_step.py): their gather goes through ``store.fetch_many_slots``."""
+    st = rbuf.store
+    orig = st.fetch_many_slots
+
+    def spy(slots_dev, U, B, phi, g, **kw):
+        big = orig(slots_dev, U, B, phi, g, **kw)
+        if keep[0]:
+            fetched.append(({k: v.detach().cpu().numpy() for k, v in big.items()
+                             if isinstance(v, torch.Tensor)}, U))
+        return big
+
+    st.fetch_many_slots = spy
+
+
 def test_sac_configs4_bench_shape_matches_oracle():
     """configs[4] as bench.py builds it (obs f32[376], action f32[17], B = 256, 64 host envs,
     update_interval 1, two env ranges -> 2 048- and 14 336-entry gathers): appends and index
@@ -296,6 +312,7 @@ def test_sac_configs4_bench_shape_matches_oracle():
         return big
 
     rbuf.fetch_many = spy_fetch
+    _spy_planned_gather(rbuf, fetched, keep)
     obss = env.reset()
     start = agent.replay_updater.replay_start_size
     n_steps = start // N + 6
@@ -399,6 +416,7 @@ def test_sac_configs4_at_capacity_1e6_matches_oracle():
         return big
 
     rbuf.fetch_many = spy_fetch
+    _spy_planned_gather(rbuf, fetched, [True])
     checked = 0
     for step in range(4):
         acts = agent.batch_act(obss)
