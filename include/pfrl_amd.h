@@ -99,6 +99,14 @@ int pfrl_batch_states_u8(const void *frames, int64_t frame_bytes, const int32_t 
 int pfrl_batch_states_u8_nhwc4(const void *frames, int64_t frame_bytes, const int32_t *refs,
                                int64_t n_obs, float divisor, float *out, void *stream);
 
+/* The same stacks of four u8 frames as u8 NHWC4 pixels, phi NOT applied: out = u8
+ * [n_obs][frame_bytes][4] (16-byte aligned), byte c of pixel p = frame refs[obs][c] at p.  For
+ * consumers that evaluate phi(x) = float32(x) / divisor in their own operand loader
+ * (pfrl_conv2d_u8nhwc4_fwd / _bwd_weight): the minibatch of pfrl/agents/ppo.py:480-487 costs
+ * 2 bytes per frame byte here instead of 5. */
+int pfrl_batch_states_u8_raw_nhwc4(const void *frames, int64_t frame_bytes, const int32_t *refs,
+                                   int64_t n_obs, void *out, void *stream);
+
 /* batch_states with the identity phi on float32 observations
  * (examples/gym/train_dqn_gym.py, mujoco examples): plain gather. */
 int pfrl_batch_states_f32(const void *frames, int64_t frame_bytes, const int32_t *refs,
@@ -536,6 +544,21 @@ int pfrl_conv2d_nhwc_bwd_weight(const float *dy, const float *dy_mask, const flo
                                 float *db_part, int64_t dw_stride, int64_t db_stride, int32_t N,
                                 int32_t H, int32_t W, int32_t C, int32_t Cout, int32_t R, int32_t S,
                                 int32_t stride, int32_t splits, void *stream);
+/* pfrl_conv2d_nhwc_fwd / pfrl_conv2d_nhwc_bwd_weight for a FIRST layer whose input is the u8
+ * NHWC4 minibatch of pfrl_batch_states_u8_raw_nhwc4 (C = 4): the feature extractor
+ * phi(x) = float32(x) / divisor (pfrl/utils/batch_states.py:18-36 with the example scripts' phi,
+ * examples/atari/train_ppo_ale.py:229-231) is evaluated where the operand enters LDS, with the
+ * rounding of IEEE division for every byte value (the caller checks the divisor:
+ * pfrl_amd.ops.u8_division_exact).  Same tile programs, operands and summation order as the fp32
+ * entries on the gathered fp32 minibatch: bit-identical y / dw / db.  Cout % 32 == 0 and
+ * Cout % 64 != 0; forward: at least 384 tiles of 32 x 32, no split-K. */
+int pfrl_conv2d_u8nhwc4_fwd(const uint8_t *x, float divisor, const float *w, const float *bias,
+                            float *y, int32_t N, int32_t H, int32_t W, int32_t Cout, int32_t R,
+                            int32_t S, int32_t stride, int32_t relu, int32_t planar_out, void *stream);
+int pfrl_conv2d_u8nhwc4_bwd_weight(const float *dy, const float *dy_mask, const uint8_t *x,
+                                   float divisor, float *dw_part, float *db_part, int64_t dw_stride,
+                                   int64_t db_stride, int32_t N, int32_t H, int32_t W, int32_t Cout,
+                                   int32_t R, int32_t S, int32_t stride, int32_t splits, void *stream);
 /* pfrl_conv2d_nhwc_bwd_weight with the RMSprop steps of OTHER parameter tensors riding in the
  * same launch (pfrl/agents/dqn.py:360-365 `loss.backward(); optimizer.step()` at minibatch size):
  * the first layer's weight gradient is the last launch of the backward pass, a few hundred

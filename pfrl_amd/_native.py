@@ -160,6 +160,9 @@ EXPORTS = {
     "pfrl_plan_dqn_range": (ctypes.c_int64, "HpqpppppPqqqiiqppqp"),
     "pfrl_batch_states_u8": (ctypes.c_int, "pqpqfpp"),
     "pfrl_batch_states_u8_nhwc4": (ctypes.c_int, "pqpqfpp"),
+    "pfrl_batch_states_u8_raw_nhwc4": (ctypes.c_int, "pqpqpp"),
+    "pfrl_conv2d_u8nhwc4_fwd": (ctypes.c_int, "pfpppiiiiiiiiip"),
+    "pfrl_conv2d_u8nhwc4_bwd_weight": (ctypes.c_int, "pppfppqqiiiiiiiip"),
     "pfrl_batch_states_f32": (ctypes.c_int, "pqpqpp"),
     "pfrl_table_append": (ctypes.c_int, "Tqppppppp"),
     "pfrl_entries_append": (ctypes.c_int, "Tqpppp"),

@@ -99,6 +99,31 @@ __global__ __launch_bounds__(kThreads) void k_batch_states_u8_nhwc4(
     pfrl_nhwc::convert_tile<DIV, NT>(f0, f1, f2, f3, dst, tile, (int)frame_bytes, d);
 }
 
+// Stacks of four u8 frames as u8 NHWC4 pixels: out[obs][pixel] = one dword holding the pixel's
+// byte in each of the four frames (frame 0 in the low byte) -- the observation in channels-last
+// order WITHOUT the fp32 conversion, for consumers that evaluate phi in their own operand loader
+// (pfrl_conv2d_u8nhwc4_fwd / _bwd_weight, csrc/qnet.hip).  A lane takes four consecutive pixels:
+// one dword from each frame in, one 16-byte store out; grid = n_obs * tiles.
+__global__ __launch_bounds__(kThreads) void k_batch_states_u8_raw_nhwc4(
+    const uint8_t *__restrict__ frames, int64_t frame_bytes, const int32_t *__restrict__ refs,
+    uint4 *__restrict__ out, int tiles, int ndw) {
+    const int64_t obs = blockIdx.x / tiles;
+    const int tile = (int)(blockIdx.x - obs * tiles);
+    const int i = tile * kThreads + threadIdx.x;
+    if (i >= ndw) return;
+    const int32_t *r = refs + obs * 4;
+    const uint32_t w0 = reinterpret_cast<const uint32_t *>(frames + (int64_t)r[0] * frame_bytes)[i];
+    const uint32_t w1 = reinterpret_cast<const uint32_t *>(frames + (int64_t)r[1] * frame_bytes)[i];
+    const uint32_t w2 = reinterpret_cast<const uint32_t *>(frames + (int64_t)r[2] * frame_bytes)[i];
+    const uint32_t w3 = reinterpret_cast<const uint32_t *>(frames + (int64_t)r[3] * frame_bytes)[i];
+    uint4 o;
+    o.x = (w0 & 0xffu) | ((w1 & 0xffu) << 8) | ((w2 & 0xffu) << 16) | (w3 << 24);
+    o.y = ((w0 >> 8) & 0xffu) | (w1 & 0xff00u) | ((w2 & 0xff00u) << 8) | ((w3 & 0xff00u) << 16);
+    o.z = ((w0 >> 16) & 0xffu) | ((w1 >> 8) & 0xff00u) | (w2 & 0xff0000u) | ((w3 & 0xff0000u) << 8);
+    o.w = (w0 >> 24) | ((w1 >> 16) & 0xff00u) | ((w2 >> 8) & 0xff0000u) | (w3 & 0xff000000u);
+    out[obs * ndw + i] = o;
+}
+
 // f32 frames: plain gather, 16 B per lane when the frame size allows.
 template <typename VecT>
 __global__ __launch_bounds__(kThreads) void k_batch_states_f32(const uint8_t *__restrict__ frames,
@@ -274,6 +299,22 @@ extern "C" int pfrl_batch_states_u8_nhwc4(const void *frames, int64_t frame_byte
             hipExtLaunchKernelGGL((k_batch_states_u8_nhwc4<true, false>), grid, block, 0, st, e0,
                                   e1, 0, fr, frame_bytes, refs, divisor, out, tiles);
     }
+    PFRL_LAUNCH_CHECK();
+}
+
+extern "C" int pfrl_batch_states_u8_raw_nhwc4(const void *frames, int64_t frame_bytes,
+                                              const int32_t *refs, int64_t n_obs, void *out,
+                                              void *stream) {
+    PFRL_CHECK_ARG(frame_bytes > 0 && (frame_bytes & 3) == 0, "frame_bytes must be a multiple of 4");
+    PFRL_CHECK_ARG(((uintptr_t)out & 15) == 0, "pfrl_batch_states_u8_raw_nhwc4: out must be 16-byte aligned");
+    if (n_obs <= 0) return 0;
+    const int ndw = (int)(frame_bytes >> 2);
+    const int tiles = (ndw + kThreads - 1) / kThreads;
+    // (no profile events: the roofline entry of kind BATCH_STATES_U8 prices 5 bytes per frame byte,
+    // the fp32 form; this launch moves 2)
+    hipLaunchKernelGGL(k_batch_states_u8_raw_nhwc4, dim3((unsigned)(n_obs * tiles)), dim3(kThreads), 0,
+                       (hipStream_t)stream, (const uint8_t *)frames, frame_bytes, refs, (uint4 *)out,
+                       tiles, ndw);
     PFRL_LAUNCH_CHECK();
 }
 

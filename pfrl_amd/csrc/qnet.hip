@@ -90,6 +90,22 @@ __device__ __forceinline__ float4 relu_mask(float4 v, float4 h) {
     return v;
 }
 
+// U8 operand loaders (the first convolution reading a minibatch of u8 NHWC4 pixels, one dword =
+// the four stacked frames of a pixel, instead of the fp32 copy the gather would write): the
+// feature extractor phi(x) = float32(x) / d (pfrl/utils/batch_states.py:18-36 with the example
+// scripts' phi) evaluated where the operand is parked in LDS.  x / d as q = x r, then ONE residual
+// step q + (x - q d) r with r = fl(1 / d): correctly rounded for EVERY x in 0..255 when the host has
+// checked exactly that for this d (ops.u8_division_exact: all 256 values against IEEE division;
+// d = 255 and d = 1 pass) -- the same fp32 numbers k_batch_states_u8* writes with __fdiv_rn.
+__device__ __forceinline__ float u8_over(float x, float r, float d) {
+    const float q = __fmul_rn(x, r);
+    return __fmaf_rn(__fmaf_rn(-q, d, x), r, q);
+}
+__device__ __forceinline__ float4 u8x4_over(uint32_t w, float r, float d) {
+    return make_float4(u8_over((float)(w & 0xffu), r, d), u8_over((float)((w >> 8) & 0xffu), r, d),
+                       u8_over((float)((w >> 16) & 0xffu), r, d), u8_over((float)(w >> 24), r, d));
+}
+
 // One 16-wide sub-chunk (4 MFMA steps) of the current LDS chunk.
 template <int AM, int AN, int P, bool A_R, bool B_R, int LDA, int LDB>
 __device__ __forceinline__ void mma_sub(const float *As, const float *Bs, int wm0, int wn0, int sc,
@@ -263,6 +279,9 @@ struct FwdArgs {
     // B-operand loader forms W = mu + sigma * (f(r_out) f(r_in)) chunk by chunk -- the same three
     // roundings as pfrl_noisy_weights_fwd, so the product is the one on the materialised weights.
     const float *w_sigma = nullptr, *noise = nullptr, *bias_sigma = nullptr;
+    // (U8 only) the input as u8 NHWC4 pixels (x is unused), r = fl(1 / d), d: see u8_over
+    const uint8_t *xu8 = nullptr;
+    float u8_r = 1.f, u8_d = 1.f;
 };
 
 __device__ __forceinline__ float noisy_shaped(float r) {
@@ -274,10 +293,12 @@ __device__ __forceinline__ float noisy_shaped(float r) {
 // TAIL: linear layers (1x1) whose in_features are not a multiple of 32 or whose rows are
 // not 16-byte aligned (MLP inputs such as 376 observations, 376 + 17 with the action
 // appended): scalar loads, addresses clamped to the row, the overhang zeroed when parked.
-template <int BM, int BN, int WM, int WN, int WK, int G, bool TAIL = false, bool NOISY = false>
+template <int BM, int BN, int WM, int WN, int WK, int G, bool TAIL = false, bool NOISY = false,
+          bool U8 = false>
 __device__ __forceinline__ void fwd_body(const FwdArgs &p, const int bx, const int by, const int bz) {
     static_assert(WM * WN * WK == 4 && WK <= 2, "four waves");
     static_assert(!(TAIL && NOISY), "noisy weights: aligned rows only");
+    static_assert(!(U8 && (TAIL || NOISY)), "u8 pixels: convolutions over four stacked frames only");
     constexpr int AM = BM / (16 * WM), AN = BN / (16 * WN);
     constexpr int P = (AM * AN == 1) ? 2 : 1;
     constexpr int NPA = (BM * 8 + 255) / 256, NPB = (BN * 8 + 255) / 256;
@@ -300,6 +321,7 @@ __device__ __forceinline__ void fwd_body(const FwdArgs &p, const int bx, const i
         float4 s[NOISY ? NPB : 1], e;    // (NOISY) sigma pieces, this lane's four input-noise values
     };
     const float *ap[NPA], *ap2[NPA], *bp[NPB], *sp[NPB];
+    const uint8_t *au[NPA];              // (U8) the piece's pixel in the u8 input
     float fo[NPB];                       // (NOISY) f(r_out) of the piece's weight row
     bool aok[NPA], bok[NPB];
     const int K1 = (TAIL && p.x2 != nullptr) ? p.K1 : p.K;
@@ -315,8 +337,10 @@ __device__ __forceinline__ void fwd_body(const FwdArgs &p, const int bx, const i
             ap[pp] = p.x + (size_t)mm * K1;
             ap2[pp] = p.x2 != nullptr ? p.x2 + (size_t)mm * (p.K - K1) : ap[pp];
         } else {
-            ap[pp] = p.x + ((size_t)(n * g.H + oh * g.ST) * g.W + ow * g.ST) * g.C + 4 * q;
+            const size_t at = ((size_t)(n * g.H + oh * g.ST) * g.W + ow * g.ST) * g.C + 4 * q;
+            ap[pp] = p.x + at;
             ap2[pp] = ap[pp];
+            au[pp] = p.xu8 + at;          // (one byte per element: the same element offset)
         }
         aok[pp] = ok;
     }
@@ -375,7 +399,12 @@ __device__ __forceinline__ void fwd_body(const FwdArgs &p, const int bx, const i
         }
 #pragma unroll
         for (int pp = 0; pp < NPA; ++pp)
-            if (a_on(pp)) sl.a[pp] = ldg4(ap[pp] + f_ad);
+            if (a_on(pp)) {
+                if (U8)   // (C = 4: the float4 piece of the fp32 form is ONE dword here; parked in .x)
+                    sl.a[pp].x = __uint_as_float(*reinterpret_cast<const uint32_t *>(au[pp] + f_ad));
+                else
+                    sl.a[pp] = ldg4(ap[pp] + f_ad);
+            }
 #pragma unroll
         for (int pp = 0; pp < NPB; ++pp)
             if (b_on(pp)) {
@@ -393,6 +422,7 @@ __device__ __forceinline__ void fwd_body(const FwdArgs &p, const int bx, const i
             // (rows past M / Cout are never zeroed: a row of A or B only reaches its own row / column
             // of the product, and those are not stored)
             float4 v = sl.a[pp];
+            if (U8) v = u8x4_over(__float_as_uint(sl.a[pp].x), p.u8_r, p.u8_d);
             if (TAIL) {
                 v.x = left > 0 ? v.x : 0.f; v.y = left > 1 ? v.y : 0.f;
                 v.z = left > 2 ? v.z : 0.f; v.w = left > 3 ? v.w : 0.f;
@@ -516,7 +546,8 @@ __device__ __forceinline__ void fwd_body(const FwdArgs &p, const int bx, const i
         }
 }
 
-template <int BM, int BN, int WM, int WN, int WK, int G, bool TAIL = false, bool NOISY = false>
+template <int BM, int BN, int WM, int WN, int WK, int G, bool TAIL = false, bool NOISY = false,
+          bool U8 = false>
 __global__ __launch_bounds__(256) void k_conv_fwd(FwdArgs p) {
 #ifdef PFRL_QNET_DEBUG
     // g_qreps = 2: the body runs twice and the stamps of the SECOND pass stay -- the same work with
@@ -524,12 +555,12 @@ __global__ __launch_bounds__(256) void k_conv_fwd(FwdArgs p) {
     const int q_wg = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
     for (int rep = g_qreps; rep > 0; --rep) {
         QSTAMP(0);
-        fwd_body<BM, BN, WM, WN, WK, G, TAIL, NOISY>(p, blockIdx.x, blockIdx.y, blockIdx.z);
+        fwd_body<BM, BN, WM, WN, WK, G, TAIL, NOISY, U8>(p, blockIdx.x, blockIdx.y, blockIdx.z);
         __syncthreads();
         QSTAMP(5);
     }
 #else
-    fwd_body<BM, BN, WM, WN, WK, G, TAIL, NOISY>(p, blockIdx.x, blockIdx.y, blockIdx.z);
+    fwd_body<BM, BN, WM, WN, WK, G, TAIL, NOISY, U8>(p, blockIdx.x, blockIdx.y, blockIdx.z);
 #endif
 }
 
@@ -968,11 +999,15 @@ struct WgradArgs {
     int M, K, cps;
     const float *x2 = nullptr;   // (TAIL only) second input tensor, as in FwdArgs
     int K1 = 0;
+    // (U8 only) the layer input as u8 NHWC4 pixels (x is unused), as in FwdArgs
+    const uint8_t *xu8 = nullptr;
+    float u8_r = 1.f, u8_d = 1.f;
 };
 
 // TAIL: linear layers (1x1) whose in_features are not a multiple of 32 / whose rows are not
 // 16-byte aligned: the x loads are scalar, clamped to the row, the overhang zeroed.
-template <int BI, int BJ, int WM, int WN, int WK, int G, bool TAIL = false>
+// U8: the layer input is u8 NHWC4 pixels (see u8_over); C = 4, so a float4 piece is one dword.
+template <int BI, int BJ, int WM, int WN, int WK, int G, bool TAIL = false, bool U8 = false>
 __device__ __forceinline__ void wgrad_body(const WgradArgs &p, const int bx, const int by,
                                            const int bz, float *smem) {
     static_assert(WM * WN * WK == 4 && WK <= 2, "four waves");
@@ -1053,7 +1088,11 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs &p, const int bx, con
             }
             const int n = fdiv(mm, g.q_ohow), rem = mm - n * ohow;
             const int oh = fdiv(rem, g.q_ow), ow = rem - oh * g.OW;
-            sl.b[pp] = ldg4(p.x + ((size_t)(n * g.H + oh * g.ST) * g.W + ow * g.ST) * g.C + bcol[pp]);
+            const size_t at = ((size_t)(n * g.H + oh * g.ST) * g.W + ow * g.ST) * g.C + bcol[pp];
+            if (U8)
+                sl.b[pp].x = __uint_as_float(*reinterpret_cast<const uint32_t *>(p.xu8 + at));
+            else
+                sl.b[pp] = ldg4(p.x + at);
         }
     };
     auto stash = [&](int buf, int c, const Slot &sl) {
@@ -1070,6 +1109,7 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs &p, const int bx, con
         for (int pp = 0; pp < NPB; ++pp) {
             if (!b_on(pp)) continue;
             float4 v = sl.b[pp];
+            if (U8) v = u8x4_over(__float_as_uint(sl.b[pp].x), p.u8_r, p.u8_d);
             if (TAIL) {
                 const int left = p.K - (j0 + 4 * bq[pp]);
                 v.x = left > 0 ? v.x : 0.f; v.y = left > 1 ? v.y : 0.f;
@@ -1120,10 +1160,10 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs &p, const int bx, con
         }
 }
 
-template <int BI, int BJ, int WM, int WN, int WK, int G, bool TAIL = false>
+template <int BI, int BJ, int WM, int WN, int WK, int G, bool TAIL = false, bool U8 = false>
 __global__ __launch_bounds__(256) void k_conv_wgrad(WgradArgs p) {
     __shared__ __attribute__((aligned(16))) float smem[wgrad_smem(BI, BJ, WM, WN, WK, G)];
-    wgrad_body<BI, BJ, WM, WN, WK, G, TAIL>(p, blockIdx.x, blockIdx.y, blockIdx.z, smem);
+    wgrad_body<BI, BJ, WM, WN, WK, G, TAIL, U8>(p, blockIdx.x, blockIdx.y, blockIdx.z, smem);
 }
 
 template <int BI, int BJ, int WM, int WN, int WK, int G, bool TAIL>
@@ -1725,6 +1765,46 @@ extern "C" int pfrl_conv2d_nhwc_fwd(const float *x, const float *w, const float 
     PFRL_LAUNCH_CHECK();
 }
 
+// pfrl_conv2d_nhwc_fwd for an input of u8 NHWC4 pixels (C = 4: one dword per pixel, e.g. the four
+// stacked 84 x 84 frames of an Atari observation as pfrl_batch_states_u8_raw_nhwc4 gathers them):
+// y = act(conv(float32(x) / divisor, w) + b) with the division done where the operand enters LDS
+// (u8_over) -- the same tile program, the same fp32 operands and the same summation order as the
+// fp32 entry on the gathered fp32 minibatch, so the output is bit-identical, while the minibatch
+// costs a quarter of the bytes to write and to read.  Rollout- / update-sized batches of layers
+// with Cout % 32 == 0 and Cout % 64 != 0 (the 64 x 32, 32 x 32 and 128 x 32 programs); the caller
+// has checked the divisor (ops.u8_division_exact).  No split-K.
+extern "C" int pfrl_conv2d_u8nhwc4_fwd(const uint8_t *x, float divisor, const float *w,
+                                       const float *bias, float *y, int32_t N, int32_t H, int32_t W,
+                                       int32_t Cout, int32_t R, int32_t S, int32_t stride,
+                                       int32_t relu, int32_t planar_out, void *stream) {
+    const ConvGeom g = make_geom(N, H, W, 4, Cout, R, S, stride);
+    PFRL_CHECK_ARG(geom_ok(g), "pfrl_conv2d_u8nhwc4_fwd: unsupported geometry (need S*4 % 32 == 0)");
+    PFRL_CHECK_ARG(x != nullptr && bias != nullptr && divisor > 0.f,
+                   "pfrl_conv2d_u8nhwc4_fwd: null input / bias, or divisor <= 0");
+    FwdArgs a;
+    a.x = nullptr; a.xu8 = x; a.u8_d = divisor; a.u8_r = 1.0f / divisor;
+    a.w = w; a.bias = bias; a.y = y; a.g = g;
+    a.M = N * g.OH * g.OW;
+    a.K = R * S * 4;
+    a.cps = a.K / KC;
+    a.relu = relu; a.planar = planar_out; a.partial = 0;
+    hipStream_t st = (hipStream_t)stream;
+#define FWDU(BM, BN, WM, WN, WK, G)                                                                  \
+    hipLaunchKernelGGL((k_conv_fwd<BM, BN, WM, WN, WK, G, false, false, true>),                      \
+                       dim3((a.M + BM - 1) / BM, (Cout + BN - 1) / BN, 1), dim3(256), 0, st, a)
+    switch (fwd_program(a, Cout, 1)) {
+        case 3: FWDU(64, 32, 2, 2, 1, 2); break;
+        case 4: FWDU(32, 32, 2, 2, 1, 4); break;
+        case 8: FWDU(128, 32, 4, 1, 1, 2); break;
+        default:
+            pfrl_set_error("pfrl_conv2d_u8nhwc4_fwd: problem outside the u8 tile programs "
+                           "(Cout % 32 == 0, Cout % 64 != 0, >= 384 tiles of 32 x 32)");
+            return PFRL_ERR_ARG;
+    }
+#undef FWDU
+    PFRL_LAUNCH_CHECK();
+}
+
 // y = act(x w^T + b) for any in_features: the 1x1 case of the forward kernel, with the TAIL
 // loaders when K is not a multiple of 32 (rows need no alignment then).  splits > 1 writes
 // partials [splits][M][N] for pfrl_splitk_reduce, as pfrl_conv2d_nhwc_fwd does.
@@ -1915,6 +1995,38 @@ extern "C" int pfrl_conv2d_nhwc_bwd_weight(const float *dy, const float *dy_mask
         default: WG(32, 256, 1, 4, 1, 2); break;
     }
 #undef WG
+    PFRL_LAUNCH_CHECK();
+}
+
+// pfrl_conv2d_nhwc_bwd_weight for a layer whose input is u8 NHWC4 pixels (see
+// pfrl_conv2d_u8nhwc4_fwd): dw = dy^T (float32(x) / divisor), the same tile program and summation
+// order as the fp32 entry -- bit-identical partials.  Cout % 32 == 0 and Cout % 64 != 0.
+extern "C" int pfrl_conv2d_u8nhwc4_bwd_weight(const float *dy, const float *dy_mask, const uint8_t *x,
+                                              float divisor, float *dw_part, float *db_part,
+                                              int64_t dw_stride, int64_t db_stride, int32_t N,
+                                              int32_t H, int32_t W, int32_t Cout, int32_t R, int32_t S,
+                                              int32_t stride, int32_t splits, void *stream) {
+    WgradArgs a;
+    if (int rc = make_wgrad_args(a, dy, dy_mask, nullptr, dw_part, db_part, dw_stride, db_stride, N, H,
+                                 W, 4, Cout, R, S, stride, splits))
+        return rc;
+    PFRL_CHECK_ARG(x != nullptr && divisor > 0.f && Cout % 32 == 0 && Cout % 64 != 0,
+                   "pfrl_conv2d_u8nhwc4_bwd_weight: null input, divisor <= 0, or Cout outside the "
+                   "u8 tile programs (Cout % 32 == 0, Cout % 64 != 0)");
+    a.xu8 = x; a.u8_d = divisor; a.u8_r = 1.0f / divisor;
+    hipStream_t st = (hipStream_t)stream;
+    // (the rule of pfrl_conv2d_nhwc_bwd_weight for these Cout: keep in step)
+    int prog = 0;
+    if (a.M >= 16384) prog = a.K % 256 == 0 ? 5 : (a.K % 128 == 0 ? 4 : 0);
+#define WGU(BI, BJ, WM, WN, WK, G)                                                                   \
+    hipLaunchKernelGGL((k_conv_wgrad<BI, BJ, WM, WN, WK, G, false, true>),                           \
+                       dim3(Cout / BI, a.K / BJ, splits), dim3(256), 0, st, a)
+    switch (prog) {
+        case 0: WGU(32, 32, 2, 2, 1, 4); break;
+        case 4: WGU(32, 128, 1, 4, 1, 2); break;
+        default: WGU(32, 256, 1, 4, 1, 2); break;
+    }
+#undef WGU
     PFRL_LAUNCH_CHECK();
 }
 

@@ -84,11 +84,43 @@ def _conv_ok(conv):
             and conv.out_channels % 16 == 0)
 
 
+def u8_first_layer_shape_ok(conv, M, H, W, divisor):
+    """The u8 tile programs of pfrl_conv2d_u8nhwc4_fwd / _bwd_weight (csrc/qnet.hip) cover
+    ``conv`` on M images of H x W u8 NHWC4 pixels, and ``divisor`` divides every byte value with
+    IEEE rounding in the loader's three operations."""
+    from pfrl_amd import ops
+
+    if not (_U8_FIRST and _conv_ok(conv) and conv.in_channels == 4
+            and conv.out_channels % 32 == 0 and conv.out_channels % 64 != 0
+            and H >= conv.kernel_size[0] and W >= conv.kernel_size[1]):
+        return False
+    st = conv.stride[0]
+    rows = M * ((H - conv.kernel_size[0]) // st + 1) * ((W - conv.kernel_size[1]) // st + 1)
+    return (_ceil_div(rows, 32) * (conv.out_channels // 32) >= 384
+            and ops.u8_division_exact(divisor))
+
+
+def u8_first_layer_ok(conv, px):
+    """The first convolution can read ``px`` (ops.U8Pixels) itself."""
+    d = px.data
+    return (d.is_cuda and d.dtype == torch.uint8 and d.dim() == 4 and d.shape[3] == 4
+            and d.is_contiguous() and d.data_ptr() % 16 == 0
+            and u8_first_layer_shape_ok(conv, d.shape[0], d.shape[1], d.shape[2], px.divisor))
+
+
+_U8_FIRST = os.environ.get("PFRL_U8_CONV1", "1") != "0"
+
+
 def plan_for(convs, linear, x):
-    """ConvSpec list if (convs..., flatten, linear) on input ``x`` [N, C, H, W] is inside what
-    the kernels cover, else None."""
-    if not (_ENABLED and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4
-            and not x.requires_grad and _native.available()):
+    """ConvSpec list if (convs..., flatten, linear) on input ``x`` [N, C, H, W] (or the
+    ops.U8Pixels standing for one) is inside what the kernels cover, else None."""
+    from pfrl_amd.ops import U8Pixels
+
+    if isinstance(x, U8Pixels):
+        if not (_ENABLED and _native.available() and convs and u8_first_layer_ok(convs[0], x)):
+            return None
+    elif not (_ENABLED and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4
+              and not x.requires_grad and _native.available()):
         return None
     if _MAX_BATCH and x.shape[0] > _MAX_BATCH:
         return None
@@ -269,6 +301,17 @@ def conv_fwd(x, w, b, sp, N, relu=True, planar=False):
     return y
 
 
+def conv_fwd_u8(px, w, b, sp, N, relu=True, planar=False):
+    """:func:`conv_fwd` for the first layer reading u8 NHWC4 pixels (ops.U8Pixels): phi(x) =
+    float32(x) / divisor in the operand loader; bit-identical to conv_fwd on the fp32 minibatch."""
+    shape = (N, sp.Cout, sp.OH * sp.OW) if planar else (N, sp.OH, sp.OW, sp.Cout)
+    y = torch.empty(shape, dtype=torch.float32, device=px.data.device)
+    check(_native.lib().pfrl_conv2d_u8nhwc4_fwd(_p(px.data), px.divisor, _p(w), _p(b), _p(y), N, sp.H,
+                                                sp.W, sp.Cout, sp.R, sp.S, sp.ST, int(relu),
+                                                int(planar), _stream()), "conv2d_u8nhwc4_fwd")
+    return y
+
+
 def linear_fwd(x, w, b, relu=True):
     """x: [M, K] contiguous -> relu(x w^T + b) [M, F]; split-K + fold for small M."""
     M, K = x.shape
@@ -327,16 +370,20 @@ class _Trunk(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, specs, *params):
+        from pfrl_amd.ops import U8Pixels
+
         N = x.shape[0]
-        if not x.is_contiguous(memory_format=torch.channels_last):
+        u8 = isinstance(x, U8Pixels)      # (the first layer evaluates phi itself: plan_for agreed)
+        if not u8 and not x.is_contiguous(memory_format=torch.channels_last):
             x = x.contiguous(memory_format=torch.channels_last)
         L = len(specs)
         acts = []
         h = x
         nhwc_fc = len(params) > 2 * L and 0 < _NHWC_FC_MIN_BATCH <= N
         for i, sp in enumerate(specs):
-            h = conv_fwd(h, params[2 * i], params[2 * i + 1], sp, N, relu=True,
-                         planar=(i == L - 1 and not nhwc_fc))
+            fwd = conv_fwd_u8 if (u8 and i == 0) else conv_fwd
+            h = fwd(h, params[2 * i], params[2 * i + 1], sp, N, relu=True,
+                    planar=(i == L - 1 and not nhwc_fc))
             acts.append(h)
         wp = None
         if len(params) == 2 * L:
@@ -352,7 +399,9 @@ class _Trunk(torch.autograd.Function):
         if any(ctx.needs_input_grad[2:]):
             ctx.specs = specs
             ctx.nhwc_fc = nhwc_fc
-            ctx.save_for_backward(x, out, *acts, *params, *([wp] if nhwc_fc else []))
+            ctx.u8_divisor = x.divisor if u8 else None
+            ctx.save_for_backward(x.data if u8 else x, out, *acts, *params,
+                                  *([wp] if nhwc_fc else []))
         return out
 
     @staticmethod
@@ -477,7 +526,7 @@ class _Trunk(torch.autograd.Function):
         grads = [None] * (2 * L) + [dwf, dbf]
         ride = None
         if (RIDE_ALONG is not None and OPT_SOURCES is not None and _RIDE and L >= 1
-                and not _dist_initialized()):
+                and not _dist_initialized() and getattr(ctx, "u8_divisor", None) is None):
             ride = [(wf, dwf, 2 * L), (params[2 * L + 1], dbf, 2 * L + 1)]
         return _Trunk._conv_backward(ctx, specs, params, acts, x, dy, N, dev, grads, ride)
 
@@ -532,6 +581,14 @@ class _Trunk(torch.autograd.Function):
                 for p_, g_, slot in ride:
                     OPT_SOURCES[p_.data_ptr()] = GradSource.done()
                     grads[slot] = None
+                continue
+            u8d = getattr(ctx, "u8_divisor", None)
+            if i == 0 and u8d is not None:
+                # the layer input is the u8 minibatch itself (saved as such: a quarter of the bytes)
+                check(lib.pfrl_conv2d_u8nhwc4_bwd_weight(_p(dy), None, _p(below), u8d, _p(pw), _p(pb),
+                                                         st, st, N, sp.H, sp.W, sp.Cout, sp.R, sp.S,
+                                                         sp.ST, splits, _stream()),
+                      "conv2d_u8nhwc4_bwd_weight")
                 continue
             check(lib.pfrl_conv2d_nhwc_bwd_weight(_p(dy), None, _p(below), _p(pw), _p(pb), st, st, N,
                                                   sp.H, sp.W, sp.C, sp.Cout, sp.R, sp.S, sp.ST, splits,
@@ -632,8 +689,13 @@ class _TrunkSequential(nn.Sequential):
     the input is inside what the kernels cover, and child by child otherwise."""
 
     def forward(self, x):
+        from pfrl_amd.ops import U8Pixels
+
         start, end, conv_idx, lin_idx = self._trunk_run
         mods = list(self._modules.values())
+        if isinstance(x, U8Pixels) and (start != 0 or plan_for([mods[k] for k in conv_idx],
+                                                                mods[lin_idx], x) is None):
+            x = x.float()       # nobody here reads u8 pixels: the fp32 input they stand for
         i = 0
         while i < len(mods):
             if i == start:

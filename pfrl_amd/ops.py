@@ -100,6 +100,87 @@ def batch_states_nhwc4(frames, refs, divisor=255.0, out=None):
     return out
 
 
+class U8Pixels:
+    """A minibatch of observations as u8 NHWC4 pixels -- ``data``: uint8 [M, H, W, 4], byte c of
+    a pixel = stacked frame c -- together with the divisor of the feature extractor
+    ``phi(x) = float32(x) / divisor`` that has NOT been applied yet.  What
+    :func:`batch_states_raw_nhwc4` returns and the MFMA trunk's first convolution consumes
+    (nn/mfma_trunk.py): phi is evaluated in that kernel's operand loader, so the fp32 copy of the
+    minibatch (4 x the bytes, written by the gather and read twice by the layer) never exists."""
+
+    __slots__ = ("data", "divisor")
+
+    def __init__(self, data, divisor):
+        self.data, self.divisor = data, float(divisor)
+
+    @property
+    def shape(self):            # (as the fp32 network input would have it: [M, 4, H, W])
+        M, H, W, C = self.data.shape
+        return torch.Size((M, C, H, W))
+
+    @property
+    def device(self):
+        return self.data.device
+
+    def float(self):
+        """The fp32 channels_last tensor this stands for (any consumer without a u8 loader):
+        the 256 values of phi from NumPy's float32 division (IEEE; torch's device division is
+        not correctly rounded on this stack), looked up per byte."""
+        lut = torch.from_numpy(np.arange(256, dtype=np.float32) / np.float32(self.divisor))
+        return lut.to(self.data.device)[self.data.long()].permute(0, 3, 1, 2)
+
+
+_U8_DIV_OK = {}
+
+
+def u8_division_exact(divisor):
+    """True when ``q = x * r; q + fma(-q, d, x) * r`` with ``r = fl(1 / d)`` (the u8 operand
+    loaders of csrc/qnet.hip: ``u8_over``) equals IEEE ``float32(x) / float32(d)`` for EVERY byte
+    value x -- checked here in exact rational arithmetic, once per divisor (255 and 1 pass)."""
+    d32 = np.float32(divisor)
+    key = float(d32)
+    hit = _U8_DIV_OK.get(key)
+    if hit is not None:
+        return hit
+    from fractions import Fraction as Fr
+
+    def rn(fr):          # round-to-nearest-even of an exact value to float32
+        f = np.float32(float(fr))       # (a double-rounded guess; the neighbours decide)
+        best = None
+        for c in (np.nextafter(f, np.float32(-np.inf)), f, np.nextafter(f, np.float32(np.inf))):
+            err = abs(Fr(float(c)) - fr)
+            tie = int(np.float32(c).view(np.uint32)) & 1
+            if best is None or (err, tie) < best[:2]:
+                best = (err, tie, c)
+        return np.float32(best[2])
+
+    ok = bool(np.isfinite(d32) and d32 > 0)
+    if ok:
+        d = Fr(float(d32))
+        r = Fr(float(rn(1 / d)))
+        for x in range(256):
+            q = Fr(float(rn(x * r)))
+            e = Fr(float(rn(x - q * d)))
+            if float(rn(q + e * r)) != float(np.float32(x) / d32):
+                ok = False
+                break
+    _U8_DIV_OK[key] = ok
+    return ok
+
+
+def batch_states_raw_nhwc4(frames, refs, divisor=255.0, out=None):
+    """refs: int32 [M, 4] into u8 frames -> :class:`U8Pixels` ([M, H, W, 4] bytes, phi pending)."""
+    M, k = refs.shape
+    assert channels_last_supported(frames, k) and frames.dtype == torch.uint8
+    hw = _spatial_hw(tuple(frames.shape[1:]))
+    if out is None:
+        out = torch.empty((M, hw[0], hw[1], 4), dtype=torch.uint8, device=frames.device)
+    check(_native.lib().pfrl_batch_states_u8_raw_nhwc4(
+        _ptr(frames), frame_bytes_of(frames), _ptr(refs), M, ctypes.c_void_p(out.data_ptr()),
+        _stream()), "batch_states_u8_raw_nhwc4")
+    return U8Pixels(out, divisor)
+
+
 def batch_states(frames, refs, divisor=255.0, out=None):
     """refs: int32 [M, k] -> f32 [M, k, *frame_shape]."""
     M, k = refs.shape

@@ -562,3 +562,42 @@ def test_rainbow_noise_draws_as_one_launch_equal_the_torch_randn_calls(monkeypat
     assert torch.equal(a["rng"], b["rng"])
     np.testing.assert_array_equal(a["actions"], b["actions"])
     assert torch.equal(a["params"], b["params"]) and torch.equal(a["tparams"], b["tparams"])
+
+
+@pytest.mark.gpu
+def test_ppo_update_on_u8_minibatches_equals_the_fp32_minibatches(monkeypatch):
+    """configs[3]'s model and update as bench.py builds them (64 envs x 128 steps: minibatches of
+    2 048 observations): the captured update with the first convolution reading u8 NHWC4
+    minibatches (agents/ppo.py ``_minibatch_states``, default) leaves the SAME parameters, bit for
+    bit, as with the fp32 minibatch gathered first (PFRL_U8_CONV1=0)."""
+    import bench
+    from pfrl_amd.nn import mfma_trunk
+    from pfrl_amd import ops
+
+    dev = torch.device("cuda:0")
+    N, T = 64, 128
+
+    def run(u8):
+        monkeypatch.setattr(mfma_trunk, "_U8_FIRST", u8)
+        args = _bench_args(algo="ppo", num_envs=N)
+        agent, env, _ = bench.build_agent(args, dev, 0)
+        seen = []
+        orig = ops.batch_states_raw_nhwc4
+
+        def spy(*a, **kw):
+            seen.append(1)
+            return orig(*a, **kw)
+
+        monkeypatch.setattr(ops, "batch_states_raw_nhwc4", spy)
+        obss = env.reset()
+        for _ in range(2 * T):
+            obss = bench.one_step(agent, env, obss, N)
+        torch.cuda.synchronize()
+        monkeypatch.setattr(ops, "batch_states_raw_nhwc4", orig)
+        assert agent.n_updates == 2 * 4 * 4       # two rollouts x 4 epochs x 4 minibatches
+        assert bool(seen) == u8
+        return np.concatenate([p.detach().cpu().numpy().ravel() for p in agent.model.parameters()])
+
+    a = run(True)
+    b = run(False)
+    assert np.array_equal(a, b)
