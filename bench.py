@@ -1383,6 +1383,10 @@ def main():
                 pref = reference_baseline_ppo(args)
                 if pref is not None:
                     out["also"]["ppo"]["cpu_baseline"] = pref
+                    if "ppo_reference_semantics" in out["also"]:
+                        # (the reference itself evaluates V on states and next_states: the same run
+                        # is the baseline of both lines)
+                        out["also"]["ppo_reference_semantics"]["cpu_baseline"] = pref
             for algo, n_envs in (("rainbow", 256), ("sac", 64)):
                 if algo in out.get("also", {}):
                     oref = reference_baseline_other(args, algo, n_envs)
