@@ -452,34 +452,37 @@ class PPO(agent.AttributeSavingMixin, agent.BatchAgent):
             return x.view((x.shape[0], refs_dev.shape[1]) + fs[1:])
         return x
 
-    def _minibatch_states(self, refs_dev):
-        """Network input of one minibatch of the update (reference ppo.py:480-487:
-        ``batch_states(states, device, phi)``).  Where the model's first stage is the MFMA trunk
-        and the first convolution can evaluate ``phi(x) = float32(x) / d`` in its own operand
-        loader (nn/mfma_trunk.py ``u8_first_layer_ok``), the minibatch is gathered as u8 NHWC4
-        pixels -- 2 bytes moved per frame byte instead of 5, and the layer's forward and
+    def _u8_pixels(self, refs_dev):
+        """The observations as u8 NHWC4 pixels (ops.U8Pixels) where the model's first stage is the
+        MFMA trunk and its first convolution can evaluate ``phi(x) = float32(x) / d`` in its own
+        operand loader (nn/mfma_trunk.py ``u8_first_layer_shape_ok``), else None.  The batch is
+        then gathered with 2 bytes moved per frame byte instead of 5, and the layer's forward and
         weight-gradient launches read a quarter of the bytes -- with bit-identical activations
-        and gradients (tests/test_mfma_trunk.py).  ``PFRL_U8_CONV1=0`` keeps the fp32 minibatch."""
+        and gradients (tests/test_mfma_trunk.py).  ``PFRL_U8_CONV1=0`` keeps the fp32 batch."""
         from pfrl_amd.nn import mfma_trunk
         from pfrl_amd.nn.atari_cnn import wants_channels_last
 
         fr = self.frames
-        if (self.obs_normalizer is None and isinstance(self.model, mfma_trunk._TrunkSequential)
-                and self.model._trunk_run[0] == 0 and refs_dev.shape[1] == 4
-                and fr.frames.dtype == torch.uint8 and wants_channels_last(self.model)
-                and ops.channels_last_supported(fr.frames, 4)):
-            first = list(self.model._modules.values())[self.model._trunk_run[2][0]]
-            hw = fr.frames.shape[-2:]
-            if mfma_trunk.u8_first_layer_shape_ok(first, refs_dev.shape[0], hw[0], hw[1],
+        if not (self.obs_normalizer is None and isinstance(self.model, mfma_trunk._TrunkSequential)
+                and self.model._trunk_run[0] == 0 and refs_dev.dim() == 2 and refs_dev.shape[1] == 4
+                and refs_dev.is_contiguous() and fr.frames.dtype == torch.uint8
+                and wants_channels_last(self.model) and ops.channels_last_supported(fr.frames, 4)):
+            return None
+        first = list(self.model._modules.values())[self.model._trunk_run[2][0]]
+        hw = fr.frames.shape[-2:]
+        if not mfma_trunk.u8_first_layer_shape_ok(first, refs_dev.shape[0], hw[0], hw[1],
                                                   self._divisor()):
-                return ops.batch_states_raw_nhwc4(fr.frames, refs_dev, self._divisor())
-        return self._features(refs_dev)
+            return None
+        return ops.batch_states_raw_nhwc4(fr.frames, refs_dev, self._divisor())
 
     def _features(self, refs_dev):
         """Network input for a batch of observation refs: the gathered fp32 batch,
         normalised with the CURRENT statistics of ``obs_normalizer`` if there is one
         (reference ppo.py:75-77,124-126,486-487,689-690: always ``update=False``; the
         statistics only learn in :meth:`_update`, once per rollout)."""
+        px = self._u8_pixels(refs_dev)
+        if px is not None:
+            return px       # (the trunk's first convolution applies phi itself)
         x = self._gather(refs_dev)
         if self.obs_normalizer is not None:
             x = self.obs_normalizer(x, update=False)
@@ -812,7 +815,7 @@ class PPO(agent.AttributeSavingMixin, agent.BatchAgent):
             mb = ops.ppo_minibatch(batch["idx"], c["adv"], c["mean_std"], self.standardize_advantages,
                                    c["log_prob"], c["v_pred"], c["v_teacher"], c["action"],
                                    c["s_refs"])
-            states = self._minibatch_states(mb["refs"])
+            states = self._features(mb["refs"])
         distribs, vs_pred = self.model(states)
         self.optimizer.zero_grad(set_to_none=True)
         records = {}

@@ -568,7 +568,7 @@ def test_rainbow_noise_draws_as_one_launch_equal_the_torch_randn_calls(monkeypat
 def test_ppo_update_on_u8_minibatches_equals_the_fp32_minibatches(monkeypatch):
     """configs[3]'s model and update as bench.py builds them (64 envs x 128 steps: minibatches of
     2 048 observations): the captured update with the first convolution reading u8 NHWC4
-    minibatches (agents/ppo.py ``_minibatch_states``, default) leaves the SAME parameters, bit for
+    minibatches (agents/ppo.py ``_u8_pixels``: acting, value pass and update; default) leaves the SAME parameters, bit for
     bit, as with the fp32 minibatch gathered first (PFRL_U8_CONV1=0)."""
     import bench
     from pfrl_amd.nn import mfma_trunk
