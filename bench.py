@@ -485,6 +485,7 @@ def _cpu_baseline_run(args, seconds, N, B, cores):
 
 
 PROFILE_BATCH_EXPERIENCES, PROFILE_BATCH_STATES_U8, PROFILE_GAE_SCAN, PROFILE_ADV_STATS = 0, 1, 2, 3   # pfrl_amd.ops constants
+PROFILE_BATCH_STATES_U8_RAW = 4
 
 
 def compute_roofline(algo, all_us, all_units, all_kinds):
@@ -497,6 +498,12 @@ def compute_roofline(algo, all_us, all_units, all_kinds):
         kind, kname, unit_name = PROFILE_BATCH_STATES_U8, "k_batch_states_u8", "frames"
         # per gathered frame: fb bytes read as u8, 4*fb written as f32
         per_unit = fb + 4 * fb
+        if PROFILE_BATCH_STATES_U8_RAW in all_kinds:
+            # round 5: the network reads u8 NHWC4 pixels (phi in the first convolution's operand
+            # loader, agents/ppo.py _u8_pixels), so the gather writes one byte per frame byte: the
+            # path's gather IS this kernel, priced at what it has to move (2 bytes per frame byte;
+            # SURVEY 8d's 5 bytes assume the fp32 copy that no longer exists)
+            kind, kname, per_unit = PROFILE_BATCH_STATES_U8_RAW, "k_batch_states_u8_raw", fb + fb
     elif algo == "sac":
         kind, kname, unit_name = PROFILE_BATCH_EXPERIENCES, "k_batch_experiences", "entries"
         # per sampled entry: state + next_state f32[376] read and written, action f32[17]
@@ -1262,6 +1269,39 @@ def supervise(args):
     dist.destroy_process_group()
 
 
+def also_in_own_process(args, argv, limit_s=900):
+    """One ``also`` workload as ``bench.py --algo X`` would measure it ALONE: a process of its own,
+    so that nothing an earlier workload of this process left behind (allocator state, captured
+    graphs and their pools, module-level hooks of another agent) is part of the number.  (Round 5:
+    Rainbow measured 5.8 k env-steps/s as the fifth workload of one process against 9.3-9.9 k alone
+    or straight after PPO; the line is about each workload, not about their order.)  Returns the
+    child's result dict, or None (the caller then runs the workload in this process)."""
+    import subprocess
+
+    cmd = [sys.executable, os.path.abspath(__file__)] + argv + [
+        "--no-also", "--no-cpu-baseline", "--no-data-path-only", "--seed", str(args.seed)]
+    if args.allow_lib_override:
+        cmd.append("--allow-lib-override")
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "PFRL_BENCH_CHILD"):
+        env.pop(k, None)
+    try:
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, env=env,
+                           timeout=limit_s)
+        lines = [ln for ln in r.stdout.decode(errors="replace").splitlines() if ln.startswith("{")]
+        if r.returncode != 0 or not lines:
+            sys.stderr.write("bench.py: %s exited with %d; running it in this process\n"
+                             % (" ".join(argv), r.returncode))
+            return None
+        d = json.loads(lines[-1])
+        d["config"]["process"] = "its own: bench.py " + " ".join(argv)
+        return d
+    except Exception as e:      # (timeout, unparsable line: the workload still gets measured)
+        sys.stderr.write("bench.py: %s in its own process failed (%s); running it in this process\n"
+                         % (" ".join(argv), e))
+        return None
+
+
 def main():
     args = parse_args()
     if (int(os.environ.get("WORLD_SIZE", "1")) > 1 and os.environ.get("PFRL_BENCH_CHILD") != "1"
@@ -1338,9 +1378,14 @@ def main():
         pargs.num_envs = 512 if args.scaling == "weak" else 512 // world
         pargs.cudnn_benchmark = False
         torch.backends.cudnn.benchmark = False
-        also = run_guarded(pargs, device, rank, world, result_extras=False)
         keys = ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "scaling", "config",
                 "roofline")
+        own = world == 1 and os.environ.get("PFRL_BENCH_ALSO_IN_PROCESS") != "1"
+        torch.cuda.empty_cache()
+        also = also_in_own_process(args, ["--algo", "ppo", "--steps", "128", "--warmup", "128",
+                                          "--num-envs", "512"]) if own else None
+        if also is None:
+            also = run_guarded(pargs, device, rank, world, result_extras=False)
         if rank == 0:
             out["also"] = {"ppo": {k: also[k] for k in keys}}
         if world == 1:
@@ -1348,25 +1393,34 @@ def main():
             # next_states, pfrl/agents/ppo.py:110-142; this package's default reads V(next_state)
             # from the next step's V(state)): SURVEY 8(d) says to flag the variant -- the line
             # carries both
-            rargs = copy.copy(pargs)
-            rargs.ppo_reuse_next_values = 0
-            ref_sem = run_workload(rargs, device, rank, world, result_extras=False)
+            ref_sem = also_in_own_process(args, ["--algo", "ppo", "--steps", "128", "--warmup", "128",
+                                                 "--num-envs", "512", "--ppo-reuse-next-values", "0"]) \
+                if own else None
+            if ref_sem is None:
+                rargs = copy.copy(pargs)
+                rargs.ppo_reuse_next_values = 0
+                ref_sem = run_workload(rargs, device, rank, world, result_extras=False)
             if rank == 0:
                 out["also"]["ppo_reference_semantics"] = {k: ref_sem[k] for k in keys}
             del ref_sem
             # configs[2] and configs[4], short: every GPU config of BASELINE.json on one line
             for algo, n_envs, mb, blas in (("rainbow", 256, 32, "default"), ("sac", 64, 256, "tunable")):
-                a2 = copy.copy(args)
-                a2.algo, a2.steps, a2.warmup = algo, 50, 20   # (warm-up: every double-buffered minibatch set captures its graphs)
-                a2.num_envs, a2.minibatch, a2.blas = n_envs, mb, blas
-                a2.cudnn_benchmark = True
-                torch.backends.cudnn.benchmark = True
-                if blas == "tunable":
-                    torch.cuda.tunable.enable(True)
-                    torch.cuda.tunable.tuning_enable(True)
-                else:
-                    torch.cuda.tunable.enable(False)
-                r2 = run_workload(a2, device, rank, world, result_extras=False)
+                # (warm-up: every double-buffered minibatch set captures its graphs)
+                r2 = also_in_own_process(args, ["--algo", algo, "--steps", "50", "--warmup", "20",
+                                                "--num-envs", str(n_envs), "--minibatch", str(mb),
+                                                "--blas", blas]) if own else None
+                if r2 is None:
+                    a2 = copy.copy(args)
+                    a2.algo, a2.steps, a2.warmup = algo, 50, 20
+                    a2.num_envs, a2.minibatch, a2.blas = n_envs, mb, blas
+                    a2.cudnn_benchmark = True
+                    torch.backends.cudnn.benchmark = True
+                    if blas == "tunable":
+                        torch.cuda.tunable.enable(True)
+                        torch.cuda.tunable.tuning_enable(True)
+                    else:
+                        torch.cuda.tunable.enable(False)
+                    r2 = run_workload(a2, device, rank, world, result_extras=False)
                 if rank == 0:
                     out["also"][algo] = {k: r2[k] for k in keys}
     if rank == 0:

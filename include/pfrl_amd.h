@@ -814,9 +814,10 @@ int64_t pfrl_plan_dqn_range(const pfrl_host_store_t *st, void *bitgen, int64_t m
 
 /* ------------------------------------------------------------------------
  * Measurement support (bench.py roofline): time every pfrl_batch_experiences
- * (kind 0, units = sampled entries) and pfrl_batch_states_u8 (kind 1, units =
- * frame refs) launch with a hipEvent pair attached to the dispatch, on its own
- * stream.  pfrl_profile_collect synchronises, returns durations in
+ * (kind 0, units = sampled entries), pfrl_batch_states_u8[_nhwc4] (kind 1, units =
+ * frame refs), pfrl_gae_scan (kind 2, units = T * N), pfrl_adv_stats (kind 3) and
+ * pfrl_batch_states_u8_raw_nhwc4 (kind 4, units = frame refs) launch with a hipEvent
+ * pair attached to the dispatch, on its own stream.  pfrl_profile_collect synchronises, returns durations in
  * microseconds, the unit count and the kind of each timed launch. */
 int pfrl_profile_enable(int on);
 int64_t pfrl_profile_collect(double *host_out_us, int64_t *host_out_units, int32_t *host_out_kind,

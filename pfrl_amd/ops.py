@@ -252,6 +252,7 @@ PROFILE_BATCH_EXPERIENCES = 0
 PROFILE_BATCH_STATES_U8 = 1
 PROFILE_GAE_SCAN = 2
 PROFILE_ADV_STATS = 3
+PROFILE_BATCH_STATES_U8_RAW = 4     # (pfrl_batch_states_u8_raw_nhwc4: 2 bytes per frame byte)
 
 
 def profile_collect(kind=PROFILE_BATCH_EXPERIENCES, cap=1 << 16):

@@ -24,19 +24,29 @@ if has pmc; then
     for C in FETCH_SIZE WRITE_SIZE; do
       rocprofv3 --pmc $C --kernel-trace --output-format csv -d /tmp/prof_$C -- $B "$@" > /dev/null 2>&1
     done; }
-  pmc gather --steps 4 --warmup 2 --capacity 100000 --no-also --no-data-path-only
-  python $R/tools/pmc_gather.py /tmp/prof_FETCH_SIZE /tmp/prof_WRITE_SIZE > $O/pmc_gather.json 2> $O/pmc_gather.err
-  rm -rf /tmp/prof_FETCH_SIZE /tmp/prof_WRITE_SIZE
-  pmc ppo --algo ppo --steps 128 --warmup 128
-  python $R/tools/pmc_gather.py /tmp/prof_FETCH_SIZE /tmp/prof_WRITE_SIZE > $O/pmc_ppo.json 2> $O/pmc_ppo.err
-  rm -rf /tmp/prof_FETCH_SIZE /tmp/prof_WRITE_SIZE
-  pmc rainbow --algo rainbow --steps 6 --warmup 3 --capacity 100000
-  python $R/tools/pmc_gather.py /tmp/prof_FETCH_SIZE /tmp/prof_WRITE_SIZE > $O/pmc_rainbow.json 2> $O/pmc_rainbow.err
-  rm -rf /tmp/prof_FETCH_SIZE /tmp/prof_WRITE_SIZE
-  pmc sac --algo sac --steps 20 --warmup 10 --capacity 100000
-  CAL=$(python -c "import json; print(json.load(open('$O/pmc_gather.json'))['fetch_calibration_factor'])")
-  python $R/tools/pmc_gather.py /tmp/prof_FETCH_SIZE /tmp/prof_WRITE_SIZE --sac 14336 $CAL > $O/pmc_sac.json 2> $O/pmc_sac.err
-  rm -rf /tmp/prof_FETCH_SIZE /tmp/prof_WRITE_SIZE
+  # PMC_ONLY="ppo" (any of gather ppo rainbow sac) restricts the passes; default: all four
+  want() { [ -z "${PMC_ONLY:-}" ] || [[ " $PMC_ONLY " == *" $1 "* ]]; }
+  if want gather; then
+    pmc gather --steps 4 --warmup 2 --capacity 100000 --no-also --no-data-path-only
+    python $R/tools/pmc_gather.py /tmp/prof_FETCH_SIZE /tmp/prof_WRITE_SIZE > $O/pmc_gather.json 2> $O/pmc_gather.err
+    rm -rf /tmp/prof_FETCH_SIZE /tmp/prof_WRITE_SIZE
+  fi
+  if want ppo; then
+    pmc ppo --algo ppo --steps 128 --warmup 128
+    python $R/tools/pmc_gather.py /tmp/prof_FETCH_SIZE /tmp/prof_WRITE_SIZE > $O/pmc_ppo.json 2> $O/pmc_ppo.err
+    rm -rf /tmp/prof_FETCH_SIZE /tmp/prof_WRITE_SIZE
+  fi
+  if want rainbow; then
+    pmc rainbow --algo rainbow --steps 6 --warmup 3 --capacity 100000
+    python $R/tools/pmc_gather.py /tmp/prof_FETCH_SIZE /tmp/prof_WRITE_SIZE > $O/pmc_rainbow.json 2> $O/pmc_rainbow.err
+    rm -rf /tmp/prof_FETCH_SIZE /tmp/prof_WRITE_SIZE
+  fi
+  if want sac; then
+    pmc sac --algo sac --steps 20 --warmup 10 --capacity 100000
+    CAL=$(python -c "import json; print(json.load(open('$R/profiles/r05_pmc_gather.json'))['fetch_calibration_factor'])")
+    python $R/tools/pmc_gather.py /tmp/prof_FETCH_SIZE /tmp/prof_WRITE_SIZE --sac 14336 $CAL > $O/pmc_sac.json 2> $O/pmc_sac.err
+    rm -rf /tmp/prof_FETCH_SIZE /tmp/prof_WRITE_SIZE
+  fi
 fi
 if has ppo; then
   rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p2 -- $B --algo ppo > $O/bench_ppo_under_rocprof.json 2>/dev/null

@@ -32,6 +32,8 @@ def load(d, counter):
                 name = r["Kernel_Name"]
                 if "k_batch_experiences" in name:
                     kind = "k_batch_experiences"
+                elif "k_batch_states_u8_raw" in name:
+                    kind = "k_batch_states_u8_raw"      # (u8 NHWC4 out: one byte per frame byte)
                 elif "k_batch_states_u8" in name:
                     kind = "k_batch_states_u8"
                 else:
@@ -39,7 +41,9 @@ def load(d, counter):
                 blocks = int(r["Grid_Size"]) // int(r["Workgroup_Size"])
                 # normalise the grid to "frame workgroups": the channels-last kernels
                 # launch TILES (ceil(7056 / 1024) = 7) workgroups per 4-frame observation
-                if "nhwc4" in name:
+                if kind == "k_batch_states_u8_raw":
+                    blocks = (blocks // TILES) * 4     # (7 tiles of 256 dwords per observation)
+                elif "nhwc4" in name:
                     if kind == "k_batch_experiences":
                         blocks = (blocks // (2 * TILES)) * 8 + 1
                     else:
@@ -106,12 +110,14 @@ def main():
     # calibration: the smallest acting gather (N observations = 4N frame workgroups, all
     # frames distinct within one launch): known bytes / reported bytes
     cal = None
-    acts = sorted(b for (kind, b) in fetch if kind == "k_batch_states_u8")
-    if acts:
-        key = ("k_batch_states_u8", acts[0])
-        kib = sum(fetch[key]) / len(fetch[key])
-        cal = acts[0] * FRAME / (kib * 1024)
-        res["fetch_calibrated_on"] = "k_batch_states_u8 (%d frames)" % acts[0]
+    for ckind in ("k_batch_states_u8", "k_batch_states_u8_raw"):
+        acts = sorted(b for (kind, b) in fetch if kind == ckind)
+        if acts:
+            key = (ckind, acts[0])
+            kib = sum(fetch[key]) / len(fetch[key])
+            cal = acts[0] * FRAME / (kib * 1024)
+            res["fetch_calibrated_on"] = "%s (%d frames)" % (ckind, acts[0])
+            break
     res["fetch_calibration_factor"] = cal
     for (kind, blocks) in sorted(set(fetch) | set(write)):
         f = fetch.get((kind, blocks), [])
@@ -122,7 +128,7 @@ def main():
             label = "%s (%d entries)" % (kind, entries)
         else:
             frames = blocks
-            alg_r, alg_w = frames * FRAME, frames * FRAME * 4
+            alg_r, alg_w = frames * FRAME, frames * FRAME * (1 if kind.endswith("_raw") else 4)
             label = "%s (%d frames)" % (kind, frames)
         item = {"launches": max(len(f), len(w)), "algorithmic_read_B": alg_r,
                 "algorithmic_write_B": alg_w}
