@@ -85,3 +85,46 @@ def test_when_every_plan_fails_the_line_is_still_printed_with_status_zero(tmp_pa
     assert line["value"] is None and line["n_gpus"] == 2
     assert len(line["config"]["dp_attempts_failed"]) == 3
     assert line["config"]["dp_plan"].startswith("fallback:")
+
+
+def test_also_workload_in_its_own_process_falls_back_when_the_child_fails(monkeypatch):
+    """bench.py measures every ``also`` workload as ``bench.py --algo X`` in a process of its own;
+    a child that dies, times out or prints no line costs nothing: None comes back and the caller
+    runs the workload in-process.  A child that prints its line is taken at its word, and the
+    line says which process measured it."""
+    import argparse
+    import subprocess
+
+    import bench
+
+    args = argparse.Namespace(seed=3, allow_lib_override=False)
+    calls = []
+
+    class Done:
+        def __init__(self, rc, out):
+            self.returncode, self.stdout = rc, out
+
+    def fake_run(cmd, **kw):
+        calls.append(cmd)
+        assert "--no-also" in cmd and "--no-cpu-baseline" in cmd and cmd[cmd.index("--seed") + 1] == "3"
+        assert not any(k in kw["env"] for k in ("RANK", "WORLD_SIZE", "PFRL_BENCH_CHILD"))
+        return fake_run.result
+
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.setenv("WORLD_SIZE", "1")
+    fake_run.result = Done(1, b"")
+    assert bench.also_in_own_process(args, ["--algo", "rainbow"]) is None
+    fake_run.result = Done(0, b"RCCL banner\nnot json\n")
+    assert bench.also_in_own_process(args, ["--algo", "rainbow"]) is None
+    line = json.dumps({"metric": "m", "value": 9900.0, "config": {"workload": "w"}}).encode()
+    fake_run.result = Done(0, b"noise\n" + line + b"\n")
+    got = bench.also_in_own_process(args, ["--algo", "rainbow", "--steps", "50"])
+    assert got["value"] == 9900.0
+    assert got["config"]["process"] == "its own: bench.py --algo rainbow --steps 50"
+
+    def raising(cmd, **kw):
+        raise subprocess.TimeoutExpired(cmd, 1)
+
+    monkeypatch.setattr(subprocess, "run", raising)
+    assert bench.also_in_own_process(args, ["--algo", "sac"]) is None
+    assert len(calls) == 3
