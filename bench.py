@@ -68,10 +68,11 @@ def parse_args():
                    help="accept PFRL_AMD_LIB (an A/B build of the native library); recorded on the line")
     p.add_argument("--no-data-path-only", action="store_true",
                    help="dqn: skip the second measurement with a zero-FLOP q_function")
-    p.add_argument("--ppo-reuse-next-values", type=int, default=1, choices=[0, 1],
-                   help="ppo: 1 = this package's default (V(next_state) read from the next step's "
-                        "V(state)); 0 = the reference's value pass over states AND next_states "
-                        "(pfrl/agents/ppo.py:110-142), reported as also.ppo_reference_semantics")
+    p.add_argument("--ppo-reuse-next-values", type=int, default=0, choices=[0, 1],
+                   help="ppo: 0 (default, the package's default) = the reference's value pass over "
+                        "states AND next_states (pfrl/agents/ppo.py:110-142; rows the two passes "
+                        "share are evaluated once where that is bit-identical); 1 = the opt-in "
+                        "shortcut without that guarantee (PPO(reuse_next_values=True))")
     p.add_argument("--no-also", action="store_true",
                    help="dqn: do not append the PPO configs[3] measurement ('also') to the line")
     p.add_argument("--scaling", choices=["weak", "strong"], default=None,
@@ -219,7 +220,7 @@ def build_ppo(args, device, rank):
     agent = agents.PPO(model, opt, gpu=device.index, phi=phi, update_interval=N * T,
                        minibatch_size=32 * N, epochs=4, clip_eps=0.1, clip_eps_vf=None,
                        standardize_advantages=True, entropy_coef=1e-2, max_grad_norm=0.5,
-                       reuse_next_values=bool(getattr(args, "ppo_reuse_next_values", 1)))
+                       reuse_next_values=bool(getattr(args, "ppo_reuse_next_values", 0)))
     agent.grad_reducer.broadcast_parameters(agent.model)
     return agent, env, None
 
@@ -369,11 +370,14 @@ def workload_description(args, N, rbuf):
     return ("BASELINE.json configs[3]: PPO, %d synthetic Atari-shaped envs/GPU x 128-step rollouts, "
             "%s, "
             "update_interval=%d, minibatch=%d, 4 epochs, GAE + advantage standardisation kernels, "
-            "Adam" % (N, "reuse_next_values=True (V(next_state) from the next step's V(state): "
-                      "SURVEY 8(d)'s 0.854 MB/env-step variant)"
-                      if getattr(args, "ppo_reuse_next_values", 1) else
-                      "reuse_next_values=False (the reference's value pass: V over states AND "
-                      "next_states, pfrl/agents/ppo.py:110-142; SURVEY 8(d)'s 0.995 MB/env-step)",
+            "Adam" % (N, "reuse_next_values=True (opt-in: V(next_state) from the next step's V(state), "
+                      "equal to f32 rounding only; SURVEY 8(d)'s 0.854 MB/env-step variant)"
+                      if getattr(args, "ppo_reuse_next_values", 0) else
+                      "reuse_next_values=False = the reference's value pass, V over states AND "
+                      "next_states (pfrl/agents/ppo.py:110-142); rows the two passes share (a "
+                      "next_state that IS the next step's state) are evaluated once, bit-identical "
+                      "to the brute-force second pass (tests/test_bench_path_parity.py), so the "
+                      "bytes MOVED are SURVEY 8(d)'s 0.854 MB/env-step and that is what is priced",
                       N * 128, 32 * N))
 
 
@@ -625,14 +629,14 @@ def step_flops_dqn(N, minibatch, update_interval):
     return N * NATURE_FWD_FLOPS + updates * per_update
 
 
-def step_flops_ppo(N, n_actions=6, reuse_next_values=True):
-    """Arithmetic of one batched PPO step (512 envs), the rollout's passes amortised per env step:
-    acting forward, the value pass over the rollout's states (reuse_next_values: once), and 4
-    epochs of forward + backward (backward = 2 x forward minus conv1's input gradient); the two
-    narrow heads (512 -> A, 512 -> 1) counted with the trunk."""
+def step_flops_ppo(N, n_actions=6, value_passes=2.0):
+    """Arithmetic EXECUTED by one batched PPO step (512 envs), the rollout's passes amortised per
+    env step: acting forward, the value pass(es) over the rollout (``value_passes``: 2 = states and
+    all next_states; 1 + the fraction of next_states actually evaluated when shared rows are taken
+    from the first pass), and 4 epochs of forward + backward (backward = 2 x forward minus conv1's
+    input gradient); the two narrow heads (512 -> A, 512 -> 1) counted with the trunk."""
     heads = 2 * 512 * (n_actions + 1)
     fwd = NATURE_FWD_FLOPS + heads
-    value_passes = 1 if reuse_next_values else 2       # the reference: states AND next_states
     return N * (fwd + value_passes * fwd + 4 * (3 * fwd - NATURE_CONV1_FLOPS))
 
 
@@ -691,7 +695,7 @@ def launches_per_update():
     return None
 
 
-def algorithmic_bytes_per_step(algo, N, minibatch, update_interval, reuse_next_values=True):
+def algorithmic_bytes_per_step(algo, N, minibatch, update_interval, value_passes=2.0):
     """SURVEY.md 8(d) per env-step figures x envs per batched step."""
     fb, k = 84 * 84, 4
     if algo in ("dqn", "rainbow"):
@@ -700,9 +704,10 @@ def algorithmic_bytes_per_step(algo, N, minibatch, update_interval, reuse_next_v
     if algo == "ppo":
         # act 141,120 + ring 7,056 + value pass + 4 epochs x 141,120 + GAE 24 +
         # adv-norm 12.  The reference evaluates V on states AND next_states (2 x 141,120: 994,932 B);
-        # this build runs reuse_next_values=True -- V(next_state) read from the next step's V(state),
-        # only episode ends re-evaluated -- which is the 0.854 MB variant SURVEY says to flag.
-        return N * (141120 + 7056 + (1 if reuse_next_values else 2) * 141120 + 4 * 141120 + 24 + 12)
+        # priced here are the bytes the build MOVES: next_states that are the next step's state are
+        # not gathered again (value_passes = 1 + evaluated fraction: the 0.854 MB variant SURVEY
+        # says to flag -- flagged in config.workload; the VALUES are the full second pass's).
+        return N * (141120 + 7056 + value_passes * 141120 + 4 * 141120 + 24 + 12)
     return N * (2 * minibatch * 3084 + 3084)   # sac
 
 
@@ -712,9 +717,10 @@ def assemble_result(args, world, N, elapsed, n_updates, t_fill, workload, roofli
     if roofline is not None:
         # the step as a whole against the same roofline: the kernel fraction above is for
         # the dominant gather alone and must not be read as the end-to-end figure
-        reuse = bool(getattr(args, "ppo_reuse_next_values", 1))
+        nvp = getattr(args, "_ppo_next_value_pass", None) or {}
+        vp = 1.0 + (nvp.get("evaluated", nvp.get("of", 1)) / max(1, nvp.get("of", 1)))
         step_bytes = algorithmic_bytes_per_step(args.algo, N, args.minibatch, args.update_interval,
-                                                reuse)
+                                                vp)
         roofline["step_algorithmic_bytes"] = int(step_bytes)
         roofline["step_frac"] = round(step_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
         if args.algo == "dqn":
@@ -743,13 +749,14 @@ def assemble_result(args, world, N, elapsed, n_updates, t_fill, workload, roofli
         if args.algo == "ppo":
             # PPO is bound by the f32 MFMA trunk at update size (B = 16384), not by the gather the
             # HBM block above describes (3 % of the device time): rollout FLOPs / time / peak
-            fl = step_flops_ppo(N, reuse_next_values=reuse)
+            fl = step_flops_ppo(N, value_passes=vp)
             tf = fl / (ms * 1e-3) / 1e12
             roofline["mfma"] = {"step_flops": int(fl), "achieved": round(tf, 2),
                                 "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                                 "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 4),
-                                "what": "acting + value pass + 4 epochs x (forward + backward) of the "
-                                        "rollout, per env step; per-layer fractions at B = 16384: "
+                                "value_passes": round(vp, 4), "next_value_pass": nvp or None,
+                                "what": "acting + value pass(es) + 4 epochs x (forward + backward) of the "
+                                        "rollout, per env step (FLOPs executed); per-layer fractions at B = 16384: "
                                         "profiles/r04_layer_final.txt (tools/layer_bench.py)"}
             roofline["captured_launches_not_timed"] = (
                 "the 65536-frame minibatch gathers run inside the captured update graph "
@@ -1134,6 +1141,7 @@ def run_workload(args, device, rank, world, result_extras=True):
 
     all_us, all_units, all_kinds = ops.profile_collect(kind=None)
     roofline = compute_roofline(args.algo, all_us, all_units, all_kinds)
+    args._ppo_next_value_pass = getattr(agent, "next_value_pass", None)
     out = assemble_result(args, world, N, elapsed, n_updates, t_fill,
                           workload_description(args, N, rbuf), roofline)
     if graphed is not None and getattr(graphed, "time_ranges", None):
@@ -1389,20 +1397,8 @@ def main():
         if rank == 0:
             out["also"] = {"ppo": {k: also[k] for k in keys}}
         if world == 1:
-            # the same workload with the reference's own value pass (V over states AND
-            # next_states, pfrl/agents/ppo.py:110-142; this package's default reads V(next_state)
-            # from the next step's V(state)): SURVEY 8(d) says to flag the variant -- the line
-            # carries both
-            ref_sem = also_in_own_process(args, ["--algo", "ppo", "--steps", "128", "--warmup", "128",
-                                                 "--num-envs", "512", "--ppo-reuse-next-values", "0"]) \
-                if own else None
-            if ref_sem is None:
-                rargs = copy.copy(pargs)
-                rargs.ppo_reuse_next_values = 0
-                ref_sem = run_workload(rargs, device, rank, world, result_extras=False)
-            if rank == 0:
-                out["also"]["ppo_reference_semantics"] = {k: ref_sem[k] for k in keys}
-            del ref_sem
+            # (also.ppo IS the reference's value pass since round 6 -- PPO(reuse_next_values=False)
+            # is the package default; round 5's separate also.ppo_reference_semantics leg is gone)
             # configs[2] and configs[4], short: every GPU config of BASELINE.json on one line
             for algo, n_envs, mb, blas in (("rainbow", 256, 32, "default"), ("sac", 64, 256, "tunable")):
                 # (warm-up: every double-buffered minibatch set captures its graphs)

@@ -595,6 +595,24 @@ int pfrl_linear_bwd_weight(const float *dy, const float *dy_mask, const float *x
                            int32_t N, int32_t splits, void *stream);
 int pfrl_linear_small_fwd(const float *x, const float *w, const float *bias, float *y, int32_t M,
                           int32_t K, int32_t N, void *stream);
+/* The narrow Q head on the ACTING path with what DQN.batch_act does with its output, in one
+ * launch (pfrl/agents/dqn.py:490-507: `batch_av.greedy_actions` = argmax over the action values,
+ * pfrl/action_value.py:59-61; then per env `select_action_epsilon_greedily`,
+ * pfrl/explorers/epsilon_greedy.py:8-12): q = h w^T + b with the arithmetic of
+ * pfrl_linear_small_fwd (bit-identical action values; written to `q` unless NULL), greedy = the
+ * FIRST maximum, action[m] = choice[m] >= 0 ? choice[m] : greedy[m] (`choice`: the host's
+ * epsilon-greedy draws, pfrl_plan_eps_greedy; NULL = greedy).  `greedy` may be NULL.
+ * Replaces pfrl_linear_small_fwd + an argmax reduction + a cast + pfrl_select_actions. */
+int pfrl_dqn_act_head(const float *h, const float *w, const float *bias, const int32_t *choice,
+                      float *q, int64_t *greedy, int64_t *action, int32_t M, int32_t K, int32_t N,
+                      void *stream);
+/* Forward tile programs (pfrl_conv2d_nhwc_fwd, pfrl_conv2d_u8nhwc4_fwd) planned for a batch of
+ * `images` images when a call brings fewer (0: off; per host thread).  No tile program mixes rows,
+ * so a row evaluated in a small batch under this plan has bit for bit the value it has inside the
+ * large batch: PPO evaluates V(next_state) only for the rows that are not also a state of the
+ * rollout and still returns what the reference's second pass over ALL next states
+ * (pfrl/agents/ppo.py:119-133) would, pfrl_amd/agents/ppo.py::_next_values_exact. */
+int pfrl_qnet_plan_images(int32_t images);
 int pfrl_linear_small_bwd(const float *dy, const float *x, const float *w, float *dx, float *dw,
                           float *db, int32_t M, int32_t K, int32_t N, void *stream);
 

@@ -26,6 +26,7 @@ hold (another explorer, a host env, prioritized or n-step replay, recurrent mode
 import collections
 import ctypes
 import logging
+import os
 
 import numpy as np
 import torch
@@ -74,6 +75,129 @@ def _align16(x):
     return (x + 15) & ~15
 
 
+def act_split(agent):
+    """(body, head layer) when the model is ``Sequential(..., Linear(K, A <= 16),
+    DiscreteActionValueHead())`` -- the example Q-network (examples/atari/train_dqn_batch_ale.py:35-41):
+    its narrow head, the argmax and the epsilon-greedy decision then run as ONE launch
+    (pfrl_dqn_act_head) instead of head + torch argmax + cast + select.  ``body`` is a view of the model
+    without its last two children (same class, children and parameters: a fused trunk stays fused)."""
+    model = agent.model
+    hit = agent.__dict__.get("_act_split_cache")
+    if hit is not None and hit[0] is model and hit[2] == tuple(id(m) for m in model.children()):
+        return hit[1]
+    from pfrl_amd.q_functions import DiscreteActionValueHead
+
+    out = None
+    nn = torch.nn
+    if (os.environ.get("PFRL_DQN_ACT_HEAD", "1") != "0" and isinstance(model, nn.Sequential)
+            and len(model) >= 3 and type(model[len(model) - 1]) is DiscreteActionValueHead):
+        lin = model[len(model) - 2]
+        if (isinstance(lin, nn.Linear) and 1 <= lin.out_features <= 16
+                and lin.weight.dtype == torch.float32 and lin.weight.is_contiguous()):
+            body = object.__new__(type(model))
+            body.__dict__ = dict(model.__dict__)
+            body._modules = collections.OrderedDict(list(model._modules.items())[:-2])
+            out = (body, lin)
+    agent._act_split_cache = (model, out, tuple(id(m) for m in model.children()))
+    return out
+
+
+class ActGraph:
+    """The device side of ``DQN.batch_act`` on the device-step path -- observation gather, trunk,
+    Q head + argmax + epsilon-greedy decision -- as ONE captured HIP graph per batch shape, fed by
+    the step's single staging transfer (frame slots + the host's draws) landing in the graph's own
+    input block (reference pfrl/agents/dqn.py:490-507).  Two instances alternate, so the actions
+    of a step stay valid while the next step's are computed.  The graph reads the frame ring and
+    the parameters in place: optimizer steps, target syncs and new frames need no re-capture."""
+
+    def __init__(self, agent):
+        self.agent = agent
+        self.entries = {}
+        self.pool = None
+
+    @staticmethod
+    def applicable(agent):
+        return (os.environ.get("PFRL_DQN_ACT_GRAPH", "1") != "0" and agent.use_graphs
+                and act_split(agent) is not None)
+
+    def _body(self, agent, batch_obs, inp, N, k, off_choice, out):
+        refs_bytes = 4 * N * k
+        batch_obs._refs_dev = inp[:refs_bytes].view(torch.int32).view(N, k)
+        choice = inp[off_choice:off_choice + 4 * N].view(torch.int32)
+        return _act_launches(agent, batch_obs, choice, out)
+
+    def _capture(self, agent, batch_obs, N, k, off_choice, need):
+        from pfrl_amd.agents.graphed_update import _capturing
+
+        dev = agent.device
+        pair = []
+        for _ in range(2):
+            inp = torch.zeros(_align16(need), dtype=torch.uint8, device=dev)
+            inp[:4 * N * k].view(torch.int32).copy_(
+                torch.from_numpy(np.ascontiguousarray(batch_obs.refs.reshape(-1))).to(dev))
+            inp[off_choice:off_choice + 4 * N].view(torch.int32).fill_(-1)
+            out = torch.empty(N, dtype=torch.int64, device=dev)
+            cur = torch.cuda.current_stream(dev)
+            side = torch.cuda.Stream(dev)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                for _ in range(2):
+                    if self._body(agent, batch_obs, inp, N, k, off_choice, out) is None:
+                        cur.wait_stream(side)
+                        return None
+            cur.wait_stream(side)
+            g = torch.cuda.CUDAGraph()
+            with ops.profile_paused(), _capturing(g, self.pool):
+                self._body(agent, batch_obs, inp, N, k, off_choice, out)
+            if self.pool is None:
+                self.pool = g.pool()
+            pair.append((g, inp, out))
+        return [pair, 0]
+
+    def run(self, agent, batch_obs, ring, tok, N, k, off_choice, need):
+        """Ships pinned slot ``tok`` into the graph's input block and replays; returns the
+        actions (int64 [N], owned by the graph instance) or None when the model cannot take the
+        fused head (the caller then commits the slot to the ring and launches eagerly)."""
+        model = agent.model
+        fr = batch_obs.store
+        key = (N, k, id(model), tuple(id(m) for m in model.modules()), id(fr),
+               getattr(fr, "emit_channels_last", None), id(agent.phi))
+        e = self.entries.get(key)
+        if e is None:
+            if len(self.entries) > 8:
+                self.entries.clear()
+            e = self.entries[key] = self._capture(agent, batch_obs, N, k, off_choice, need) or False
+        if e is False:
+            return None
+        pair, at = e
+        e[1] = at ^ 1
+        g, inp, out = pair[at]
+        ring.commit_to(tok, need, inp)
+        batch_obs._refs_dev = inp[:4 * N * k].view(torch.int32).view(N, k)
+        g.replay()
+        return out
+
+
+def _act_launches(agent, batch_obs, choice, out=None):
+    """gather -> trunk -> fused head: the actions (int64 [N]), or None when the hidden activations
+    are not what pfrl_dqn_act_head reads."""
+    split = act_split(agent)
+    with torch.no_grad(), evaluating(agent.model):
+        if split is None:
+            greedy = agent._evaluate_model(batch_obs).greedy_actions.detach()
+            return ops.select_actions(greedy, choice, out=out)
+        body, lin = split
+        agent._route_observation_layout(batch_obs)
+        h = body(agent.batch_states(batch_obs, agent.device, agent.phi))
+        if not (torch.is_tensor(h) and h.dim() == 2 and h.dtype == torch.float32 and h.is_contiguous()
+                and h.shape[1] == lin.in_features):
+            if out is not None:
+                return None
+            greedy = list(agent.model._modules.values())[-1](lin(h)).greedy_actions.detach()
+            return ops.select_actions(greedy, choice)
+        return ops.dqn_act_head(h, lin.weight, lin.bias, choice, out=out)[0]
+
+
 def act(agent, batch_obs):
     """``DQN.batch_act`` in training mode for a DeviceObsBatch; None = conditions not met."""
     if not (agent.training and isinstance(batch_obs, DeviceObsBatch) and not agent.recurrent
@@ -101,11 +225,16 @@ def act(agent, batch_obs):
     choice = host[off_choice:need].view(np.int32)
     ex.epsilon = eps = ex.compute_epsilon(agent.t)
     host_plan.eps_greedy(N, eps, n_act, out=choice)
-    dev = ring.commit(tok, need)
-    batch_obs._refs_dev = dev[:refs_bytes].view(torch.int32).view(N, k)
-    with torch.no_grad(), evaluating(agent.model):
-        greedy = agent._evaluate_model(batch_obs).greedy_actions.detach()
-    actions = ops.select_actions(greedy, dev[off_choice:need].view(torch.int32))
+    actions = None
+    if ActGraph.applicable(agent):
+        graph = agent.__dict__.get("_act_graph")
+        if graph is None:
+            graph = agent._act_graph = ActGraph(agent)
+        actions = graph.run(agent, batch_obs, ring, tok, N, k, off_choice, need)
+    if actions is None:
+        dev = ring.commit(tok, need)
+        batch_obs._refs_dev = dev[:refs_bytes].view(torch.int32).view(N, k)
+        actions = _act_launches(agent, batch_obs, dev[off_choice:need].view(torch.int32))
     ev = torch.cuda.Event()
     ev.record()
     evs.append(ev)

@@ -323,7 +323,7 @@ class PPO(agent.AttributeSavingMixin, agent.BatchAgent):
                  max_recurrent_sequence_len=None, act_deterministically=False, max_grad_norm=None,
                  value_stats_window=1000, entropy_stats_window=1000, value_loss_stats_window=100,
                  policy_loss_stats_window=100, value_pass_chunk=16384,
-                 reuse_next_values=True):
+                 reuse_next_values=False):
         self.model = model
         self.optimizer = optimizer
         self.obs_normalizer = obs_normalizer
@@ -357,10 +357,15 @@ class PPO(agent.AttributeSavingMixin, agent.BatchAgent):
         self.act_deterministically = act_deterministically
         self.max_grad_norm = max_grad_norm
         self.value_pass_chunk = value_pass_chunk
-        # V(next_state) of a non-final transition is V(state) of the next step: skip
-        # the second pass over the whole rollout (reference ppo.py:119-133 evaluates
-        # both; same values up to fp32 batch-position effects of the conv kernels)
+        # False (default): V over states AND next_states, as the reference (ppo.py:119-133).  On
+        # the device path rows of the second pass that ARE rows of the first -- the next
+        # observation of (t, env) is the observation of (t + 1, env) unless an episode ended --
+        # are not evaluated twice where that is provably the same bits (_next_value_plan); the
+        # result is the full second pass bit for bit (tests/test_bench_path_parity.py).
+        # True (opt-in): the same shortcut WITHOUT the guarantee -- the remaining rows run as a
+        # small batch of their own (other tile programs: values equal to f32 rounding only).
         self.reuse_next_values = bool(reuse_next_values)
+        self.next_value_pass = None    # what the last rollout's second pass did (for bench.py)
         self.logger = getLogger(__name__)
 
         self.rollout = None
@@ -636,6 +641,51 @@ class PPO(agent.AttributeSavingMixin, agent.BatchAgent):
                     log_probs[lo:hi] = distribs.log_prob(actions_dev[lo:hi])
         return log_probs, values
 
+    def _next_value_plan(self, M):
+        """Rows per chunk of the value pass if evaluating a FEW rows of it on their own can be made
+        to give bit for bit what the whole pass gives, else 0.  Holds when everything between the
+        frame ring and V(s) is this library's row-independent kernels (u8 / fp32 gather, MFMA
+        trunk, the fused value head: no launch mixes rows, and ``mfma_trunk.plan_batch`` pins the
+        tile programs, split-K and layout route to the ones a full chunk takes) and every chunk
+        of the pass has the same size.  Library GEMMs / convolutions (another model, an
+        ``obs_normalizer``) pick kernels by batch size: no guarantee, the full pass runs."""
+        from pfrl_amd.nn import mfma_trunk
+
+        if os.environ.get("PFRL_PPO_DEDUP_NEXT", "1") == "0" or self.obs_normalizer is not None:
+            return 0
+        chunk = int(self.value_pass_chunk)
+        if not (M <= chunk or M % chunk == 0):
+            return 0
+        if self._act_graph is None:
+            self._act_graph = _ActGraph(self)
+        split = self._act_graph._split() if self._act_graph.applicable() else None
+        if split is None:
+            return 0
+        body = split[0]
+        run = getattr(body, "_trunk_run", None)
+        if not (isinstance(body, mfma_trunk._TrunkSequential) and run is not None and run[0] == 0
+                and run[1] == len(body._modules)):
+            return 0
+        return min(M, chunk)
+
+    def _next_values(self, ro, T, N, v_pred, n_refs):
+        """V(next_state) for every rollout position (reference ppo.py:119-133)."""
+        M = T * N
+        if self.reuse_next_values:
+            self.next_value_pass = {"mode": "reuse_next_values (opt-in, f32-rounding equal)", "of": M}
+            return self._next_values_from_states(ro, T, N, v_pred, n_refs)
+        rows = self._next_value_plan(M)
+        if rows:
+            from pfrl_amd.nn import mfma_trunk
+
+            self.next_value_pass = {"mode": "rows shared with the state pass evaluated once "
+                                            "(bit-identical to the full pass)", "of": M}
+            with mfma_trunk.plan_batch(rows):
+                return self._next_values_from_states(ro, T, N, v_pred, n_refs)
+        self.next_value_pass = {"mode": "full pass", "of": M, "evaluated": M}
+        _, next_v = self._value_pass(n_refs, None)
+        return next_v
+
     def _next_values_from_states(self, ro, T, N, v_pred, n_refs):
         """V(next_state) without a second pass over the whole rollout: wherever the
         next observation of (t, env) IS the observation of (t+1, env) -- the same
@@ -652,6 +702,8 @@ class PPO(agent.AttributeSavingMixin, agent.BatchAgent):
         pad = (-len(need_idx)) % N
         if pad:
             need_idx = np.concatenate([need_idx, np.repeat(need_idx[-1:], pad)])
+        if self.next_value_pass is not None:
+            self.next_value_pass["evaluated"] = int(len(need_idx))
         (idx_dev,) = self._stage.upload([need_idx.astype(np.int64)])
         idx_dev = idx_dev.clone()
         _, vals = self._value_pass(n_refs[idx_dev], None)
@@ -693,10 +745,7 @@ class PPO(agent.AttributeSavingMixin, agent.BatchAgent):
         log_probs, v_pred = self._value_pass(s_refs, actions)
         minibatches = (order[pos] for pos in
                        _iter_minibatch_positions(n, self.minibatch_size, self.epochs))
-        if self.reuse_next_values:
-            next_v = self._next_values_from_states(ro, T, N, v_pred, n_refs)
-        else:
-            _, next_v = self._value_pass(n_refs, None)
+        next_v = self._next_values(ro, T, N, v_pred, n_refs)
         adv, v_teacher = ops.gae_scan(reward.view(T, N), v_pred.view(T, N), next_v.view(T, N),
                                       nonterm.view(T, N), cut.view(T, N), self.gamma, self.lambd,
                                       self._reward_mode)

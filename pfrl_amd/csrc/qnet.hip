@@ -1409,14 +1409,12 @@ struct SmallFwdArgs {
     float *y[2];
 };
 
+// (the row product shared by k_linear_small_fwd and k_dqn_act_head: thread n < N returns
+// sum_k x[m][k] w[n][k], other threads 0; `part` is the workgroup's [4][N] LDS scratch)
 template <int N>
-__global__ __launch_bounds__(256) void k_linear_small_fwd(SmallFwdArgs a, int K) {
-    __shared__ float part[4][N];
-    const float *__restrict__ x = a.x[blockIdx.y];
-    const float *__restrict__ w = a.w[blockIdx.y];
-    const float *__restrict__ bias = a.bias[blockIdx.y];
-    float *__restrict__ y = a.y[blockIdx.y];
-    const int m = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+__device__ __forceinline__ float small_fwd_row(const float *__restrict__ x, const float *__restrict__ w,
+                                               const int K, const int m, float (*part)[N]) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     float acc[N];
 #pragma unroll
     for (int n = 0; n < N; ++n) acc[n] = 0.f;
@@ -1445,10 +1443,58 @@ __global__ __launch_bounds__(256) void k_linear_small_fwd(SmallFwdArgs a, int K)
         if (lane == 0) part[wave][n] = v;
     }
     __syncthreads();
+    if (tid < N) return ((part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]));
+    return 0.f;
+}
+
+template <int N>
+__global__ __launch_bounds__(256) void k_linear_small_fwd(SmallFwdArgs a, int K) {
+    __shared__ float part[4][N];
+    const float *__restrict__ bias = a.bias[blockIdx.y];
+    float *__restrict__ y = a.y[blockIdx.y];
+    const int m = blockIdx.x, tid = threadIdx.x;
+    float v = small_fwd_row<N>(a.x[blockIdx.y], a.w[blockIdx.y], K, m, part);
     if (tid < N) {
-        float v = ((part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]));
         if (bias != nullptr) v += bias[tid];
         y[(size_t)m * N + tid] = v;
+    }
+}
+
+// The Q head on the acting path + greedy action + the host's epsilon-greedy decision, one launch
+// (see pfrl_dqn_act_head in include/pfrl_amd.h).  The action values are those of
+// k_linear_small_fwd bit for bit; the first maximum wins, as numpy / torch argmax on the host.
+template <int N>
+__global__ __launch_bounds__(256) void k_dqn_act_head(const float *__restrict__ h, const float *__restrict__ w,
+                                                      const float *__restrict__ bias,
+                                                      const int32_t *__restrict__ choice, float *__restrict__ q,
+                                                      int64_t *__restrict__ greedy, int64_t *__restrict__ action,
+                                                      int K) {
+    __shared__ float part[4][N];
+    __shared__ float qrow[N];
+    const int m = blockIdx.x, tid = threadIdx.x;
+    // (requested before the row product: nothing below waits for it until the very end)
+    const int ch = (tid == 0 && choice != nullptr) ? choice[m] : -1;
+    float v = small_fwd_row<N>(h, w, K, m, part);
+    if (tid < N) {
+        if (bias != nullptr) v += bias[tid];
+        qrow[tid] = v;
+        if (q != nullptr) q[(size_t)m * N + tid] = v;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int best = 0;
+        float bv = qrow[0];
+#pragma unroll
+        for (int n = 1; n < N; ++n) {
+            const float c = qrow[n];
+            // (a NaN compares as the maximum, as in torch / numpy argmax)
+            if (c > bv || (c != c && bv == bv)) {
+                bv = c;
+                best = n;
+            }
+        }
+        if (greedy != nullptr) greedy[m] = best;
+        if (action != nullptr) action[m] = ch >= 0 ? ch : best;
     }
 }
 
@@ -1620,9 +1666,29 @@ bool geom_ok(const ConvGeom &g) {
 // C ABI
 // ===================================================================================
 
+// Batch size the forward tile programs are PLANNED for (0: the batch of the call).  A caller that
+// evaluates a few rows of a large batch on their own -- PPO's V(next_state) for the rows that are
+// not also a state of the rollout, pfrl_amd/agents/ppo.py::_next_values_exact -- sets it to the
+// size of the large batch's chunks: every output row is then computed by the SAME tile program
+// (same K order, same wave split) as in the large batch, i.e. bit for bit the same value, because
+// no tile program mixes rows.  Per host thread; see pfrl_qnet_plan_images().
+static thread_local int g_plan_images = 0;
+
+extern "C" int pfrl_qnet_plan_images(int32_t images) {
+    g_plan_images = images > 0 ? images : 0;
+    return 0;
+}
+
+// rows the tile program is chosen for: the call's own, or the planned batch's if that is larger
+static long long plan_rows(long long M, int images) {
+    if (g_plan_images <= images || images <= 0) return M;
+    return M / images * g_plan_images;
+}
+
 // tile program of the forward kernel for a problem (see the switch in pfrl_conv2d_nhwc_fwd)
-static int fwd_program(const FwdArgs &a, int Cout, unsigned z) {
-    auto blocks = [&](int bm, int bn) { return (long long)((a.M + bm - 1) / bm) * ((Cout + bn - 1) / bn) * z; };
+static int fwd_program(const FwdArgs &a, int Cout, unsigned z, long long Mplan = 0) {
+    const long long Mp = Mplan > 0 ? Mplan : a.M;
+    auto blocks = [&](int bm, int bn) { return ((Mp + bm - 1) / bm) * ((Cout + bn - 1) / bn) * z; };
     const int force = prog_override("PFRL_QNET_FWD");
     int prog;
     if (Cout % 32 != 0) prog = blocks(64, 16) >= 512 ? 0 : 1;        // narrow outputs (16 channels)
@@ -1750,7 +1816,7 @@ extern "C" int pfrl_conv2d_nhwc_fwd(const float *x, const float *w, const float 
     // MFMA for 64 x 64, 3.1 for 64 x 32 by SQ_INSTS_*), not bytes: 128 x 32 beats 64 x 32 for the first
     // convolution (1241 vs 1436 us), 128 x 64 beats 64 x 64 only for the long reduction of the linear
     // layer (485 vs 535 us) and loses below ~1000 workgroups.
-    switch (fwd_program(a, Cout, z)) {
+    switch (fwd_program(a, Cout, z, plan_rows(a.M, N))) {
         case 0: FWD(64, 16, 4, 1, 1, 2); break;
         case 1: FWD(32, 16, 2, 1, 2, 4); break;
         case 2: FWD(64, 64, 2, 2, 1, 2); break;
@@ -1792,7 +1858,7 @@ extern "C" int pfrl_conv2d_u8nhwc4_fwd(const uint8_t *x, float divisor, const fl
 #define FWDU(BM, BN, WM, WN, WK, G)                                                                  \
     hipLaunchKernelGGL((k_conv_fwd<BM, BN, WM, WN, WK, G, false, false, true>),                      \
                        dim3((a.M + BM - 1) / BM, (Cout + BN - 1) / BN, 1), dim3(256), 0, st, a)
-    switch (fwd_program(a, Cout, 1)) {
+    switch (fwd_program(a, Cout, 1, plan_rows(a.M, N))) {
         case 3: FWDU(64, 32, 2, 2, 1, 2); break;
         case 4: FWDU(32, 32, 2, 2, 1, 4); break;
         case 8: FWDU(128, 32, 4, 1, 1, 2); break;
@@ -2238,6 +2304,19 @@ extern "C" int pfrl_linear_small_fwd(const float *x, const float *w, const float
                                      int32_t M, int32_t K, int32_t N, void *stream) {
     SmallFwdArgs a{{x, nullptr}, {w, nullptr}, {bias, nullptr}, {y, nullptr}};
     return small_fwd_launch(a, 1, M, K, N, stream);
+}
+
+extern "C" int pfrl_dqn_act_head(const float *h, const float *w, const float *bias, const int32_t *choice,
+                                 float *q, int64_t *greedy, int64_t *action, int32_t M, int32_t K,
+                                 int32_t N, void *stream) {
+    PFRL_CHECK_ARG(N >= 1 && N <= SMALL_N && M >= 1 && K >= 1, "pfrl_dqn_act_head: 1 <= N <= 16");
+    PFRL_CHECK_ARG(h && w && (q || greedy || action), "pfrl_dqn_act_head: null argument");
+#define CALL_ACT(NN)                                                                             \
+    hipLaunchKernelGGL(k_dqn_act_head<NN>, dim3(M), dim3(256), 0, (hipStream_t)stream, h, w, bias, \
+                       choice, q, greedy, action, K)
+    SMALL_DISPATCH(N, CALL_ACT)
+#undef CALL_ACT
+    PFRL_LAUNCH_CHECK();
 }
 
 static int small_bwd_launch(const SmallBwdArgs &a, int twins, bool want_dx, bool want_dw, int32_t M,

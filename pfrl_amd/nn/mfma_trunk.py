@@ -19,6 +19,7 @@ are in that order, and the linear layer's input gradient is written back as NHWC
 the convolution backward.  There is no fallback inside: ``supported()`` decides up
 front, and unsupported shapes take the stock PyTorch route.
 """
+import contextlib
 import ctypes
 import os
 
@@ -95,6 +96,7 @@ def u8_first_layer_shape_ok(conv, M, H, W, divisor):
             and H >= conv.kernel_size[0] and W >= conv.kernel_size[1]):
         return False
     st = conv.stride[0]
+    M = max(M, _PLAN_BATCH)
     rows = M * ((H - conv.kernel_size[0]) // st + 1) * ((W - conv.kernel_size[1]) // st + 1)
     return (_ceil_div(rows, 32) * (conv.out_channels // 32) >= 384
             and ops.u8_division_exact(divisor))
@@ -157,7 +159,29 @@ def plan_for(convs, linear, x):
     return specs
 
 
+# Batch size the FORWARD launches are planned for (0: the batch of the call): tile programs, the
+# split-K of the linear layer and the NHWC / planar route are then chosen as for a batch of that
+# many images, so that a few rows evaluated on their own come out bit for bit as they would inside
+# the large batch (no tile program mixes rows).  See csrc/qnet.hip::pfrl_qnet_plan_images and
+# PPO._next_values_exact.  Forward passes without gradients only.
+_PLAN_BATCH = 0
+
+
+@contextlib.contextmanager
+def plan_batch(images):
+    global _PLAN_BATCH
+    prev = _PLAN_BATCH
+    _PLAN_BATCH = int(images)
+    check(_native.lib().pfrl_qnet_plan_images(_PLAN_BATCH), "qnet_plan_images")
+    try:
+        yield
+    finally:
+        _PLAN_BATCH = prev
+        check(_native.lib().pfrl_qnet_plan_images(prev), "qnet_plan_images")
+
+
 def _fwd_splits(M, F, K):
+    M = max(M, _PLAN_BATCH)
     nch = K // 32
     tiles16 = _ceil_div(M, 16) * _ceil_div(F, 32)
     if tiles16 >= 1024:
@@ -379,7 +403,7 @@ class _Trunk(torch.autograd.Function):
         L = len(specs)
         acts = []
         h = x
-        nhwc_fc = len(params) > 2 * L and 0 < _NHWC_FC_MIN_BATCH <= N
+        nhwc_fc = len(params) > 2 * L and 0 < _NHWC_FC_MIN_BATCH <= max(N, _PLAN_BATCH)
         for i, sp in enumerate(specs):
             fwd = conv_fwd_u8 if (u8 and i == 0) else conv_fwd
             h = fwd(h, params[2 * i], params[2 * i + 1], sp, N, relu=True,

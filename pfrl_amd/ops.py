@@ -66,6 +66,25 @@ def select_actions(greedy, choice, out=None):
     return out
 
 
+def dqn_act_head(h, weight, bias, choice=None, want_q=False, out=None):
+    """The narrow Q head of the acting path with argmax and the epsilon-greedy decision in one
+    launch (pfrl_dqn_act_head; reference pfrl/agents/dqn.py:490-507): ``h`` [M, K] f32, ``weight``
+    [A, K], ``choice`` int32 [M] (the host's draws, < 0 = greedy) or None.  Returns (actions int64
+    [M], q [M, A] or None); the action values are those of ``pfrl_linear_small_fwd`` bit for bit."""
+    M, K = h.shape
+    A = weight.shape[0]
+    assert h.dtype == torch.float32 and h.is_contiguous() and weight.is_contiguous() and 1 <= A <= 16
+    assert choice is None or (choice.dtype == torch.int32 and choice.numel() == M)
+    if out is None:
+        out = torch.empty(M, dtype=torch.int64, device=h.device)
+    q = torch.empty((M, A), dtype=torch.float32, device=h.device) if want_q else None
+    check(_native.lib().pfrl_dqn_act_head(_ptr(h), _ptr(weight), _ptr(bias) if bias is not None else None,
+                                          _ptr(choice) if choice is not None else None,
+                                          _ptr(q) if q is not None else None, None, _ptr(out), M, K, A,
+                                          _stream()), "dqn_act_head")
+    return out, q
+
+
 def _spatial_hw(fshape):
     """(H, W) if the frame is one 2-D plane ((H, W) or (1, H, W)), else None."""
     dims = [d for d in fshape]

@@ -75,6 +75,17 @@ class StagingRing:
         self._ship(token, (int(nbytes) + 15) & ~15)
         return self._dev[token]
 
+    def commit_to(self, token, nbytes, dst):
+        """:meth:`commit` with the bytes shipped into ``dst`` (a device uint8 tensor that keeps its
+        address, e.g. the input block of a captured graph) instead of the ring's device slot."""
+        dev_ptr = self._dev_ptr[token]
+        self._dev_ptr[token] = dst.data_ptr()
+        try:
+            self._ship(token, (int(nbytes) + 15) & ~15)
+        finally:
+            self._dev_ptr[token] = dev_ptr
+        return dst
+
     @staticmethod
     def view(dev, offset, count, dtype, shape=None):
         """Typed view of ``count`` elements at byte ``offset`` of a staged device buffer."""

@@ -356,6 +356,92 @@ def test_ppo_bench_path_gae_and_advantage_statistics_match_oracle(monkeypatch):
     assert abs(mean - wm) <= 1e-6 * max(1.0, abs(wm)) and abs(std - ws) <= 1e-6 * max(1.0, abs(ws))
 
 
+@pytest.mark.parametrize("N,T,chunk", [(512, 128, 16384), (64, 24, 4096), (64, 24, 512), (64, 20, 512)])
+def test_ppo_next_state_values_evaluated_once_are_the_full_second_pass_bit_for_bit(monkeypatch, N, T,
+                                                                                    chunk):
+    """The reference evaluates the model on ALL states and ALL next_states of a rollout
+    (pfrl/agents/ppo.py:119-133).  The device path (default ``reuse_next_values=False``) takes the
+    value of a next_state that IS the next step's state from the first pass and evaluates only
+    the other rows (episode ends, the rollout's last step), planned as a full chunk
+    (``mfma_trunk.plan_batch``): V(next_state) must equal the brute-force second pass over every
+    next_state BIT FOR BIT -- at BASELINE configs[3]'s size, in one chunk, in several chunks --
+    and with ragged chunks (no guarantee) the full pass must be what runs."""
+    import bench
+
+    dev = torch.device("cuda:0")
+    args = _bench_args(algo="ppo", num_envs=N)
+    agent, env, _ = bench.build_agent(args, dev, 0)
+    assert agent.reuse_next_values is False, "the default must be the reference's semantics"
+    agent.update_interval = N * T
+    agent.minibatch_size = N * T // 4
+    agent.value_pass_chunk = chunk
+    seen = {}
+    orig = agent._next_values
+
+    def spy(ro, T_, N_, v_pred, n_refs):
+        got = orig(ro, T_, N_, v_pred, n_refs)
+        seen["pass"] = dict(agent.next_value_pass)
+        _, full = agent._value_pass(n_refs, None)
+        seen["equal"] = bool(torch.equal(got, full))
+        seen["max_abs"] = float((got - full).abs().max())
+        seen["cuts"] = int(ro.h_cut[:T_ - 1].sum())
+        return got
+
+    monkeypatch.setattr(agent, "_next_values", spy)
+    obss = env.reset()
+    for _ in range(T):
+        obss = bench.one_step(agent, env, obss, N)
+    assert agent.n_updates > 0 and "pass" in seen
+    assert seen["equal"], seen
+    M = N * T
+    if M <= chunk or M % chunk == 0:
+        assert seen["pass"]["mode"].startswith("rows shared"), seen
+        # one row per env for the last step + one per episode end, padded to a multiple of N
+        assert seen["pass"]["evaluated"] <= N + seen["cuts"] + N, seen
+    else:
+        assert seen["pass"]["mode"] == "full pass" and seen["pass"]["evaluated"] == M, seen
+
+
+def test_dqn_act_graph_and_fused_head_equal_the_eager_act_path(monkeypatch):
+    """``DQN.batch_act`` of the device step as one captured graph with the fused head
+    (agents/_dqn_device_step.py::ActGraph, pfrl_dqn_act_head) against the launches it replaces
+    (gather, trunk, narrow head, torch argmax, cast, pfrl_select_actions): on the bench agent,
+    with updates running, the actions of every step and the parameters after the run are
+    bit-identical, and the NumPy stream ends at the same position."""
+    import bench
+
+    dev = torch.device("cuda:0")
+    N = 256
+
+    def run(graph):
+        monkeypatch.setenv("PFRL_DQN_ACT_GRAPH", "1" if graph else "0")
+        monkeypatch.setenv("PFRL_DQN_ACT_HEAD", "1" if graph else "0")
+        args = _bench_args(capacity=3000, frame_slots=12288, slack=512, replay_start=1024)
+        agent, env, rbuf = bench.build_agent(args, dev, 0)
+        obss = env.reset()
+        acts = []
+        for _ in range(24):
+            a = agent.batch_act(obss)
+            acts.append(np.asarray(a).copy())
+            obss2, rs, dones, _ = env.step(a)
+            agent.batch_observe(obss2, rs, dones, np.zeros(N, dtype=bool))
+            obss = env.reset(~np.asarray(dones))
+        torch.cuda.synchronize()
+        params = [p.detach().cpu().clone() for p in agent.model.parameters()]
+        used = agent.__dict__.get("_act_graph")
+        return acts, params, np.random.get_state(), used, agent.optim_t
+
+    a0, p0, s0, g0, n0 = run(False)
+    a1, p1, s1, g1, n1 = run(True)
+    assert g0 is None and g1 is not None and g1.entries, "the graph path was not taken"
+    assert n0 == n1 and n0 > 10 * 64
+    for t, (x, y) in enumerate(zip(a0, a1)):
+        np.testing.assert_array_equal(x, y, err_msg="step %d" % t)
+    assert _same_rng_state(s0, s1)
+    for x, y in zip(p0, p1):
+        assert torch.equal(x, y)
+
+
 def test_ppo_act_graph_equals_the_eager_act_path(monkeypatch):
     """The rollout's ``batch_act`` as one captured graph (agents/ppo.py::_ActGraph) against the
     eager launches it replaces, on the bench agent: entropy and value to f32 rounding, actions inside

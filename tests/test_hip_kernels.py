@@ -1528,6 +1528,36 @@ def test_select_actions(dev, dtype):
     np.testing.assert_array_equal(out.cpu().numpy(), np.where(choice >= 0, choice, greedy))
 
 
+@pytest.mark.parametrize("M,K,A", [(256, 512, 6), (37, 512, 18 - 2), (5, 96, 1), (1, 256, 4)])
+def test_dqn_act_head_is_the_small_linear_head_plus_argmax_and_selection(dev, M, K, A):
+    """pfrl_dqn_act_head (reference pfrl/agents/dqn.py:490-507 on the acting path): action values
+    bit-identical to pfrl_linear_small_fwd, greedy = the FIRST maximum (numpy argmax on the host
+    copy), action = the host's epsilon-greedy draw where one fired."""
+    from pfrl_amd import ops
+    from pfrl_amd.nn import mfma_trunk
+
+    torch.manual_seed(5)
+    h = torch.relu(torch.randn(M, K, device=dev))
+    w, b = torch.randn(A, K, device=dev) * 0.05, torch.randn(A, device=dev)
+    if A > 1 and M > 2:
+        # exact ties: two identical weight rows -> the lower index must win
+        w[A - 1] = w[0]
+        b[A - 1] = b[0]
+    rs = np.random.RandomState(1)
+    choice = np.where(rs.rand(M) < 0.3, rs.randint(0, A, size=M), -1).astype(np.int32)
+    lin = torch.nn.Linear(K, A).to(dev)
+    with torch.no_grad():
+        lin.weight.copy_(w)
+        lin.bias.copy_(b)
+        want_q = mfma_trunk.small_linear(h, lin)
+    act, q = ops.dqn_act_head(h, w, b, torch.from_numpy(choice).to(dev), want_q=True)
+    assert torch.equal(q, want_q)
+    greedy = np.argmax(want_q.cpu().numpy(), axis=1)
+    np.testing.assert_array_equal(act.cpu().numpy(), np.where(choice >= 0, choice, greedy))
+    act2, _ = ops.dqn_act_head(h, w, b, None)
+    np.testing.assert_array_equal(act2.cpu().numpy(), greedy)
+
+
 def test_ppo_act_head_matches_torch_categorical(dev):
     """pfrl_ppo_act_head against the torch expressions it replaces on the acting path
     (Linear + Categorical(logits): value, entropy, log pi(a)) and its inverse-CDF sampling: the
