@@ -1121,13 +1121,19 @@ def run_workload(args, device, rank, world, result_extras=True):
         graphed.time_ranges = []
     barrier()
     torch.cuda.synchronize()
+    # (one event per step boundary: where the device time of the timed region goes, step by step)
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(min(args.steps, 1024) + 1)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    marks[0].record()
+    for i in range(args.steps):
         _tick("timed steps %s" % args.algo)
         obss = one_step(agent, env, obss, N)
+        if i + 1 < len(marks):
+            marks[i + 1].record()
     barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    step_ms = [a.elapsed_time(b) for a, b in zip(marks[:-1], marks[1:])]
     _tick("after timed steps %s" % args.algo)
     ops.profile_enable(False)
     n_updates = updates_done() - optim_before
@@ -1159,6 +1165,16 @@ def run_workload(args, device, rank, world, result_extras=True):
             except Exception as e:      # (a profile file in another format must not cost the line)
                 roofline["mfma"]["per_launch"] = {"note": "not available: %s" % e}
     out["config"]["ranks_seen"] = world
+    if step_ms:
+        srt = sorted(step_ms)
+        split = {"median_step_ms": round(srt[len(srt) // 2], 4), "max_step_ms": round(srt[-1], 4),
+                 "what": "device time between step boundaries (hipEvents), timed region"}
+        if args.algo == "ppo" and len(srt) >= 8:
+            # a rollout = (steps - 1) acting steps + the step that also runs the update
+            n_up = max(1, args.steps * N // (N * 128))
+            split["act_phase_ms"] = round(sum(srt[:-n_up]), 3)
+            split["update_phase_ms"] = round(sum(srt[-n_up:]) - n_up * srt[len(srt) // 2], 3)
+        out["config"]["phase_split"] = split
     if torch.distributed.is_initialized():
         from pfrl_amd import rccl
 
@@ -1277,7 +1293,7 @@ def supervise(args):
     dist.destroy_process_group()
 
 
-def also_in_own_process(args, argv, limit_s=900):
+def also_in_own_process(args, argv, limit_s=900, extra_env=None):
     """One ``also`` workload as ``bench.py --algo X`` would measure it ALONE: a process of its own,
     so that nothing an earlier workload of this process left behind (allocator state, captured
     graphs and their pools, module-level hooks of another agent) is part of the number.  (Round 5:
@@ -1293,6 +1309,7 @@ def also_in_own_process(args, argv, limit_s=900):
     env = dict(os.environ)
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "PFRL_BENCH_CHILD"):
         env.pop(k, None)
+    env.update(extra_env or {})
     try:
         r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, env=env,
                            timeout=limit_s)
@@ -1302,12 +1319,43 @@ def also_in_own_process(args, argv, limit_s=900):
                              % (" ".join(argv), r.returncode))
             return None
         d = json.loads(lines[-1])
-        d["config"]["process"] = "its own: bench.py " + " ".join(argv)
+        d["config"]["process"] = "its own: " + " ".join(
+            ["%s=%s" % kv for kv in sorted((extra_env or {}).items())] + ["bench.py"] + argv)
         return d
     except Exception as e:      # (timeout, unparsable line: the workload still gets measured)
         sys.stderr.write("bench.py: %s in its own process failed (%s); running it in this process\n"
                          % (" ".join(argv), e))
         return None
+
+
+def rank_shape_legs(args, out, keys):
+    """What ONE rank of the 8-GPU job runs, measured on this GPU under a single-rank process group
+    (PFRL_DIST_ALWAYS=1: RCCL communicator, data-parallel form of the update with its collectives
+    as single-rank launches, the control-plane exchanges): 256 / 8 = 32 envs for DQN, 512 / 8 = 64
+    envs x 128 steps with minibatch 2 048 for PPO.  ``projected_speedup_g8`` = 8 x the rank-shaped
+    value / the 1-GPU value of the same line: what env sharding gives BEFORE any byte crosses a
+    link (the collective's wire time is not in it; DESIGN.md section 6 prices that).  No hardware
+    scaling curve is claimed here: the driver measures that itself."""
+    dp_env = {"PFRL_DIST_ALWAYS": "1", "PFRL_FORCE_SPLIT_GRAPH": "1", "PFRL_DP_LOWRANK": "force",
+              "MASTER_ADDR": "127.0.0.1"}
+    legs = (("dqn_rank_shape_g8", out.get("value"),
+             ["--algo", "dqn", "--num-envs", "32", "--steps", "160", "--warmup", "40", "--scaling", "weak"]),
+            ("ppo_rank_shape_g8", (out["also"].get("ppo") or {}).get("value"),
+             ["--algo", "ppo", "--num-envs", "64", "--steps", "128", "--warmup", "128", "--scaling", "weak"]))
+    for k, (name, full, argv) in enumerate(legs):
+        env = dict(dp_env, MASTER_PORT=str(29731 + k))
+        r = also_in_own_process(args, argv, extra_env=env)
+        if r is None:
+            out["also"][name] = {"value": None, "note": "the rank-shaped run did not complete"}
+            continue
+        leg = {k_: r[k_] for k_ in keys if k_ in r}
+        leg["metric"] = "env-steps/sec of ONE rank of the 8-GPU job (its env shard, data-parallel update)"
+        if full:
+            leg["projected_speedup_g8"] = round(8.0 * r["value"] / full, 3)
+            leg["projection_what"] = ("8 x this value / the 1-GPU value of the full workload on this "
+                                      "line; collectives run as single-rank launches, wire time "
+                                      "excluded (DESIGN.md section 6)")
+        out["also"][name] = leg
 
 
 def main():
@@ -1419,6 +1467,8 @@ def main():
                     r2 = run_workload(a2, device, rank, world, result_extras=False)
                 if rank == 0:
                     out["also"][algo] = {k: r2[k] for k in keys}
+            if own and rank == 0:
+                rank_shape_legs(args, out, keys)
     if rank == 0:
         if not args.no_cpu_baseline and world == 1 and args.algo == "dqn":
             port = cpu_baseline(args, min(args.cpu_baseline_seconds, 8.0))
@@ -1433,10 +1483,6 @@ def main():
                 pref = reference_baseline_ppo(args)
                 if pref is not None:
                     out["also"]["ppo"]["cpu_baseline"] = pref
-                    if "ppo_reference_semantics" in out["also"]:
-                        # (the reference itself evaluates V on states and next_states: the same run
-                        # is the baseline of both lines)
-                        out["also"]["ppo_reference_semantics"]["cpu_baseline"] = pref
             for algo, n_envs in (("rainbow", 256), ("sac", 64)):
                 if algo in out.get("also", {}):
                     oref = reference_baseline_other(args, algo, n_envs)
@@ -1466,7 +1512,9 @@ def main():
     if _WATCHDOG[0] is not None:
         _WATCHDOG[0].printed = True
     _tick("teardown")
-    if torch.distributed.is_initialized():
+    if torch.distributed.is_initialized() and os.environ.get("PFRL_BENCH_SOFT_EXIT") != "1":
+        # (PFRL_BENCH_SOFT_EXIT=1: a profiler's exit handlers must run -- rocprofv3 writes its
+        # trace at exit -- single-rank groups only)
         # The communicator is NOT destroyed: ncclCommDestroy waits for every captured graph that
         # holds one of its collectives to be released first (round 5, two live ranks: the check
         # tool sat in it until its timeout with a graph still referenced), and nothing here needs

@@ -647,6 +647,8 @@ void orc_batch_states_f32(long M, int k, long frame_elems, const float *frames, 
  *         next_v_pred are np.float32 from .cpu().numpy(), ppo.py:133-142).
  * mode 1: reward is np.float64      -> td_err/adv in f64, but the product
  *         (gamma*nonterminal) * next_v_pred is still rounded to f32 first.
+ * mode 2: v_pred / next_v_pred are Python floats (the recurrent dataset stores
+ *         float(v), ppo.py:98-107)  -> every op in f64, the product included.
  * ------------------------------------------------------------------------ */
 void orc_gae_fragment(long T, const double *reward, const float *v_pred, const float *next_v_pred,
                       const double *nonterminal, double gamma, double lambd, int mode,
@@ -674,8 +676,9 @@ void orc_gae_fragment(long T, const double *reward, const float *v_pred, const f
         volatile double adv = 0.0;
         for (i = T - 1; i >= 0; i--) {
             double gn = gamma * nonterminal[i];
-            volatile float prod = (float)gn * next_v_pred[i];
-            volatile double s1 = reward[i] + (double)prod;
+            volatile float prodf = (float)gn * next_v_pred[i];
+            volatile double prod = mode == 2 ? gn * (double)next_v_pred[i] : (double)prodf;
+            volatile double s1 = reward[i] + prod;
             volatile double td = s1 - (double)v_pred[i];
             volatile double ga = gl * adv;
             adv = td + ga;

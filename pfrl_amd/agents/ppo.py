@@ -177,6 +177,17 @@ class _Rollout:
                 parts.append(np.arange(a, T, dtype=np.int64) * N + e)
         return np.concatenate(parts) if parts else np.zeros(0, dtype=np.int64)
 
+    def fragments(self):
+        """(env, t_start, t_end inclusive) of every fragment in the reference's ``memory`` order:
+        finished ones as they completed, then the open ones in env order (reference :448-456,
+        :786-789)."""
+        out = list(self.closed)
+        for e in range(self.N):
+            a = int(self.open_start[e])
+            if a < self.T:
+                out.append((e, a, self.T - 1))
+        return out
+
     def reset(self):
         self.T = 0
         self.closed = []
@@ -389,18 +400,24 @@ class PPO(agent.AttributeSavingMixin, agent.BatchAgent):
 
         self.grad_reducer = GradientAllReducer(self.model)
         self._host = None
-        if on_gpu and not recurrent:
+        self._rec = None
+        if on_gpu and not (recurrent and os.environ.get("PFRL_PPO_RECURRENT_HOST") == "1"):
             from pfrl_amd.staging import StagingRing
 
             self._stage = StagingRing(self.device,
                                       slot_bytes=max(1 << 22, 96 * int(update_interval)),
                                       n_slots=8)
+            if recurrent:
+                # the same HBM rollout columns + two columns of recurrent states; fragments and
+                # sequences are arrays of positions (agents/_ppo_recurrent_device.py; reference
+                # ppo.py:56-107,534-632)
+                from pfrl_amd.agents._ppo_recurrent_device import RecurrentDeviceRollouts
+
+                self._rec = RecurrentDeviceRollouts(self)
         else:
-            # gpu=None, and recurrent models on any device: the reference's fragments of
-            # transition dicts (reference ppo.py:56-107,534-632 cut them into sequences of
-            # varying length).  With a GPU the network, the packed sequences and every
-            # loss run on the device; the rollout bookkeeping stays on the host -- the HBM
-            # rollout store holds fixed-length (T, N) columns only.
+            # gpu=None (and PFRL_PPO_RECURRENT_HOST=1, the round-5 arrangement for recurrent
+            # models: network on the device, rollout bookkeeping on the host): the reference's
+            # fragments of transition dicts
             from pfrl_amd.agents.ppo_host import HostRollouts
 
             self._host = HostRollouts(self)
@@ -504,7 +521,9 @@ class PPO(agent.AttributeSavingMixin, agent.BatchAgent):
         (refs_dev,) = self._stage.upload([refs])
         if self._act_graph is None:
             self._act_graph = _ActGraph(self)
-        if (isinstance(batch_obs, DeviceObsBatch) and self.device_actions
+        if self._rec is not None:
+            action_dev = self._rec.act_train(refs_dev)
+        elif (isinstance(batch_obs, DeviceObsBatch) and self.device_actions
                 and self._act_graph.applicable()):
             # device env: nothing of this step is looked at on the host -- one graph replay
             action_dev, stats = self._act_graph.run(refs_dev)
@@ -552,7 +571,10 @@ class PPO(agent.AttributeSavingMixin, agent.BatchAgent):
             if self.obs_normalizer is not None:
                 b_state = self.obs_normalizer(b_state, update=False)
         with torch.no_grad(), evaluating(self.model):
-            action_distrib, _ = self.model(b_state)
+            if self._rec is not None:
+                action_distrib = self._rec.act_eval(b_state)
+            else:
+                action_distrib, _ = self.model(b_state)
             if self.act_deterministically:
                 action = mode_of_distribution(action_distrib).cpu().numpy()
             else:
@@ -589,6 +611,8 @@ class PPO(agent.AttributeSavingMixin, agent.BatchAgent):
         reset = np.asarray(batch_reset, dtype=bool)
         self.rollout.add_step(self._last_refs, next_refs, actions,
                               np.asarray(batch_reward, dtype=np.float64), done, reset)
+        if self._rec is not None:
+            self._rec.observe_train(self.rollout.T - 1, done, reset)
         self.rollout.note_frames(min(self._last_min_seq, int(np.min(next_batch.min_seq))))
         self.batch_last_state = [None] * n_env
         self.batch_last_action = [None] * n_env
@@ -602,6 +626,8 @@ class PPO(agent.AttributeSavingMixin, agent.BatchAgent):
             return observe(batch_obs, batch_reward, batch_done, batch_reset)
         if self.training:
             self._batch_observe_train(batch_obs, batch_reward, batch_done, batch_reset)
+        elif self._rec is not None:
+            self._rec.observe_eval(batch_done, batch_reset)
 
     # -- learning --------------------------------------------------------------------
     def _update_if_dataset_is_ready(self):
@@ -713,13 +739,7 @@ class PPO(agent.AttributeSavingMixin, agent.BatchAgent):
         next_v[idx_dev] = vals
         return next_v
 
-    def _update(self):
-        ro = self.rollout
-        T, N, k = ro.T, ro.N, ro.k
-        dev = self.device
-        order = ro.dataset_order()
-        n = len(order)
-        assert n == T * N
+    def _check_frames_alive(self, ro):
         if (ro.min_seq is not None and self.frames is not None
                 and ro.min_seq < self.frames.oldest_live_seq()):
             # same liveness rule as the replay store's slots_for(): a rollout whose oldest
@@ -728,6 +748,17 @@ class PPO(agent.AttributeSavingMixin, agent.BatchAgent):
                 "PPO rollout refers to frame %d but the frame ring (%d slots) has wrapped past "
                 "it (oldest live frame %d); give the frame store more slots than one rollout "
                 "writes" % (ro.min_seq, self.frames.n_slots, self.frames.oldest_live_seq()))
+
+    def _update(self):
+        if self._rec is not None:
+            return self._rec.update()
+        ro = self.rollout
+        T, N, k = ro.T, ro.N, ro.k
+        dev = self.device
+        order = ro.dataset_order()
+        n = len(order)
+        assert n == T * N
+        self._check_frames_alive(ro)
         # ship the rollout columns (one transfer)
         on_dev = ro.d_action is not None
         up = self._stage.upload([
@@ -820,9 +851,28 @@ class PPO(agent.AttributeSavingMixin, agent.BatchAgent):
         from pfrl_amd import distributed
 
         return (os.environ.get("PFRL_PPO_UPDATE_GRAPH", "1") != "0" and self.device.type == "cuda"
-                and actions_i64 is not None and distributed.world_size() == 1
+                and actions_i64 is not None and self._dp_update_capturable()
                 and n % self.minibatch_size == 0
                 and type(self)._lossfun is PPO._lossfun and "_lossfun" not in self.__dict__)
+
+    def _dp_update_capturable(self):
+        """Data parallel (env-sharded rollouts): the gradient all-reduce of a
+        minibatch sits between ``backward`` and ``clip`` + ``step``.  With the directly driven RCCL
+        communicator it is stream-ordered and -- issued on the capturing stream itself,
+        distributed.GradientAllReducer._exchange_stream -- a node of the captured update like any
+        kernel, where a probe every rank takes part in says captured collectives replay
+        (``captured_collectives_work``; ``PFRL_GRAPH_COLLECTIVE=0`` = bench.py's more conservative
+        plans: the eager update with the eager collective)."""
+        from pfrl_amd import distributed
+
+        red = self.grad_reducer
+        if not red.active():
+            return True
+        if os.environ.get("PFRL_GRAPH_COLLECTIVE", "auto") == "0":
+            return False
+        if red._comm is None and torch.distributed.get_backend() != "nccl":
+            return False
+        return distributed.captured_collectives_work(self.device)
 
     def _baked_hyperparameters(self):
         """What ``_minibatch_step`` / ``_lossfun`` read as Python numbers, i.e. what a captured
@@ -873,6 +923,9 @@ class PPO(agent.AttributeSavingMixin, agent.BatchAgent):
             vs_pred_old=mb["v_pred"][..., None], log_probs_old=mb["log_prob"],
             advs=mb["adv"], vs_teacher=mb["v_teacher"][..., None], records=records)
         loss.backward()
+        # (data parallel: one flat all-reduce per minibatch, a graph node when captured;
+        # nothing without a process group)
+        self.grad_reducer.all_reduce()
         if self.max_grad_norm is not None:
             torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.max_grad_norm)
         self.optimizer.step()

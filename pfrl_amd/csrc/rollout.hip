@@ -48,8 +48,11 @@ __global__ __launch_bounds__(kThreads) void k_gae_scan(int64_t T, int64_t N,
             const int64_t i = t * N + e;
             if (cut[i]) adv = 0.0;
             const double gn = nonterminal[i] ? gamma : __dmul_rn(gamma, 0.0);
-            const float prod = __fmul_rn((float)gn, next_v_pred[i]);
-            const double s1 = __dadd_rn(reward[i], (double)prod);
+            // MODE 1: np.float32 values under NEP 50 (the product rounds to f32);
+            // MODE 2: Python floats throughout (the recurrent dataset, ppo.py:98-107): f64
+            const double prod = MODE == 2 ? __dmul_rn(gn, (double)next_v_pred[i])
+                                          : (double)__fmul_rn((float)gn, next_v_pred[i]);
+            const double s1 = __dadd_rn(reward[i], prod);
             const double td = __dsub_rn(s1, (double)v_pred[i]);
             const double ga = __dmul_rn(gl, adv);
             adv = __dadd_rn(td, ga);
@@ -104,7 +107,9 @@ __global__ __launch_bounds__(kThreads) void k_gae_scan_lds(
             const float s1 = __fadd_rn((float)r, prod);
             s_td[q] = (acc_t)__fsub_rn(s1, v);
         } else {
-            const double s1 = __dadd_rn(r, (double)prod);
+            // (MODE 2: every operand a Python float -- the product stays in f64)
+            const double pd = MODE == 2 ? __dmul_rn(gn, (double)nv) : (double)prod;
+            const double s1 = __dadd_rn(r, pd);
             s_td[q] = (acc_t)__dsub_rn(s1, (double)v);
         }
         s_v[q] = v;
@@ -376,7 +381,7 @@ extern "C" int pfrl_gae_scan(int64_t T, int64_t N, const double *reward, const f
                              const float *next_v_pred, const uint8_t *nonterminal,
                              const uint8_t *cut, double gamma, double lambd, int mode, float *adv,
                              float *v_teacher, void *stream) {
-    PFRL_CHECK_ARG(T >= 0 && N >= 0, "pfrl_gae_scan: bad shape");
+    PFRL_CHECK_ARG(T >= 0 && N >= 0 && mode >= 0 && mode <= 2, "pfrl_gae_scan: bad shape / mode");
     if (T == 0 || N == 0) return 0;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     pfrl_profile_events(PFRL_PROFILE_GAE_SCAN, T * N, &e0, &e1);
@@ -396,8 +401,10 @@ extern "C" int pfrl_gae_scan(int64_t T, int64_t N, const double *reward, const f
                           nonterminal, cut, gamma, lambd, adv, v_teacher)
         if (mode == 0 && E == 8) PFRL_GAE_LAUNCH(0, 8);
         else if (mode == 0) PFRL_GAE_LAUNCH(0, 16);
-        else if (E == 8) PFRL_GAE_LAUNCH(1, 8);
-        else PFRL_GAE_LAUNCH(1, 16);
+        else if (mode == 1 && E == 8) PFRL_GAE_LAUNCH(1, 8);
+        else if (mode == 1) PFRL_GAE_LAUNCH(1, 16);
+        else if (E == 8) PFRL_GAE_LAUNCH(2, 8);
+        else PFRL_GAE_LAUNCH(2, 16);
 #undef PFRL_GAE_LAUNCH
         PFRL_LAUNCH_CHECK();
     }
@@ -406,8 +413,12 @@ extern "C" int pfrl_gae_scan(int64_t T, int64_t N, const double *reward, const f
         hipExtLaunchKernelGGL(k_gae_scan<0>, dim3(blocks), dim3(kThreads), 0, (hipStream_t)stream, e0, e1,
                               0, T, N, reward, v_pred, next_v_pred, nonterminal, cut, gamma, lambd, adv,
                               v_teacher);
-    else
+    else if (mode == 1)
         hipExtLaunchKernelGGL(k_gae_scan<1>, dim3(blocks), dim3(kThreads), 0, (hipStream_t)stream, e0, e1,
+                              0, T, N, reward, v_pred, next_v_pred, nonterminal, cut, gamma, lambd, adv,
+                              v_teacher);
+    else
+        hipExtLaunchKernelGGL(k_gae_scan<2>, dim3(blocks), dim3(kThreads), 0, (hipStream_t)stream, e0, e1,
                               0, T, N, reward, v_pred, next_v_pred, nonterminal, cut, gamma, lambd, adv,
                               v_teacher);
     PFRL_LAUNCH_CHECK();

@@ -679,8 +679,11 @@ def global_mean_std(mean_std, n):
     (count, sum, sum of squares).  PPO standardises advantages over the whole
     dataset (reference ppo.py:476-478); with env sharding the dataset is the
     union of the shards.  No-op for a single process."""
-    if world_size() == 1:
+    if world_size() == 1 and not (os.environ.get("PFRL_DIST_ALWAYS") == "1" and dist.is_available()
+                                  and dist.is_initialized()):
         return mean_std
+    # (PFRL_DIST_ALWAYS=1: a one-GPU box pays for the exchange under its single-rank group, so
+    # that a rank-shaped measurement -- bench.py also.*_rank_shape_g8 -- includes it)
     m, s = mean_std[0].double(), mean_std[1].double()
     acc = torch.stack([torch.as_tensor(float(n), dtype=torch.float64, device=mean_std.device),
                        m * n, (s * s + m * m) * n])

@@ -474,6 +474,43 @@ def batch_states_golden():
 
 
 # --------------------------------------------------------------------------
+# D2. GAE on the RECURRENT dataset: v_pred / next_v_pred stored as Python floats
+# (ppo.py:98-107 `float(v)`), so every operation of ppo.py:36-47 is f64
+# --------------------------------------------------------------------------
+def gae_recurrent_golden():
+    from pfrl.agents.ppo import _add_advantage_and_value_target_to_episode
+
+    rs = np.random.RandomState(12)
+    rec = dict(off=[0], reward=[], v=[], nv=[], nonterm=[], adv=[], vt=[], adv_t=[], gamma=[], lambd=[])
+    for case in range(16):
+        T = int(rs.randint(1, 140))
+        gamma = [0.99, 1.0, 0.8, 0.0][case % 4]
+        lambd = [0.95, 1.0, 0.0][case % 3]
+        v = rs.randn(T).astype(np.float32)
+        nv = rs.randn(T).astype(np.float32)
+        rew = rs.choice([-1.0, 0.0, 1.0], size=T) if case % 3 else rs.randn(T)
+        ep = []
+        for i in range(T):
+            done = (i == T - 1) and (case % 5 != 0)
+            ep.append(dict(reward=(np.float64(rew[i]) if case % 2 else float(rew[i])),
+                           nonterminal=0.0 if done else 1.0, v_pred=float(v[i]),
+                           next_v_pred=float(nv[i])))
+        _add_advantage_and_value_target_to_episode(ep, gamma, lambd)
+        rec["off"].append(rec["off"][-1] + T)
+        rec["reward"].extend(float(t["reward"]) for t in ep)
+        rec["v"].extend(v.tolist()); rec["nv"].extend(nv.tolist())
+        rec["nonterm"].extend(t["nonterminal"] for t in ep)
+        rec["adv"].extend(float(t["adv"]) for t in ep)
+        rec["vt"].extend(float(t["v_teacher"]) for t in ep)
+        rec["adv_t"].extend(tag(t["adv"]) for t in ep)
+        rec["gamma"].append(gamma); rec["lambd"].append(lambd)
+    out = {k: np.asarray(v) for k, v in rec.items()}
+    out["v"] = out["v"].astype(np.float32); out["nv"] = out["nv"].astype(np.float32)
+    np.savez_compressed(os.path.join(HERE, "gae_recurrent.npz"), **out)
+    print("gae recurrent cases", len(rec["gamma"]))
+
+
+# --------------------------------------------------------------------------
 # D. GAE (ppo.py:36-47), both reward dtypes
 # --------------------------------------------------------------------------
 def gae_golden():
@@ -1765,6 +1802,7 @@ if __name__ == "__main__":
     replay_trace("cap200_n3_env16", 23, 200, 3, 1200, 16, batch=32)
     batch_states_golden()
     gae_golden()
+    gae_recurrent_golden()
     a2c_golden()
     sample_n_k_golden()
     agent_trace("dqn_uniform_n1", False, 1, False)

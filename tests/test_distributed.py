@@ -289,6 +289,51 @@ def test_data_parallel_graph_plans_match_reference(prioritized, backend, tmp_pat
         dist.destroy_process_group()
 
 
+@pytest.mark.gpu
+def test_ppo_captured_update_with_the_gradient_all_reduce_inside_equals_one_process(tmp_path, monkeypatch):
+    """PPO's captured minibatch update (agents/ppo.py::_minibatch_step) under a real single-rank
+    process group with the directly driven RCCL communicator: the gradient all-reduce is a node
+    of the captured graph (no eager fallback), the 3-scalar advantage statistics go through the
+    control plane, and two rollouts leave the parameters of the run WITHOUT a process group, bit
+    for bit (an average over one rank is the identity)."""
+    import torch.distributed as dist
+
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import bench
+    from test_bench_path_parity import _bench_args
+
+    dev = torch.device("cuda:0")
+    N, T = 32, 16
+
+    def run():
+        args = _bench_args(algo="ppo", num_envs=N)
+        agent, env, _ = bench.build_agent(args, dev, 0)
+        agent.update_interval = N * T
+        agent.minibatch_size = N * T // 4
+        obss = env.reset()
+        for _ in range(2 * T):
+            obss = bench.one_step(agent, env, obss, N)
+        torch.cuda.synchronize()
+        assert agent.n_updates == 2 * 4 * 4
+        assert agent._update_graph is not None and len(agent._update_graph.graphs) >= 1, \
+            "the captured update was not taken"
+        return agent, [p.detach().cpu().clone() for p in agent.model.parameters()]
+
+    assert not dist.is_initialized()
+    _, want = run()
+    monkeypatch.setenv("PFRL_DIST_ALWAYS", "1")
+    monkeypatch.setenv("PFRL_RCCL_DIRECT", "1")
+    dist.init_process_group("gloo", init_method="file://%s" % (tmp_path / "pg"), rank=0, world_size=1)
+    try:
+        agent, got = run()
+        assert agent.grad_reducer.active() and agent.grad_reducer._comm is not None
+        assert agent.grad_reducer._flat is not None, "no gradient went through the all-reduce"
+        for a, b in zip(want, got):
+            assert torch.equal(a, b)
+    finally:
+        dist.destroy_process_group()
+
+
 def _agent_worker(rank, world, port, out_dir, kind):
     """Each rank trains on its own env shard (different env seeds, different replay
     contents); after the broadcast of rank 0's initial weights and with one averaged

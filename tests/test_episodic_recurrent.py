@@ -862,21 +862,58 @@ def _run_recurrent_ppo(gpu, replay_actions=None):
 
 
 @pytest.mark.gpu
-def test_recurrent_ppo_with_the_network_on_the_device_matches_the_host_run():
-    """PPO(recurrent=True, gpu=0) (reference ppo.py:56-107,534-632): the network, the packed
-    sequences and the losses on the GPU, rollout fragments on the host.  Same seeds and the
-    host run's sampled actions (CPU and GPU generators differ by construction): every loss
-    and the trained parameters agree with the gpu=None run, which the reference's own
-    test-suite pins (COVERAGE.md)."""
+def test_recurrent_ppo_on_the_device_rollout_matches_the_host_runs(monkeypatch):
+    """PPO(recurrent=True, gpu=0) (reference ppo.py:56-107,196-225,534-632) on the DEVICE rollout
+    (agents/_ppo_recurrent_device.py: HBM columns + recurrent-state columns, fragments and
+    sequences as position arrays, packed layouts built on the host, GAE mode 2).  Same seeds and
+    the host run's sampled actions (CPU and GPU generators differ by construction):
+    * against the round-5 arrangement on the same GPU (rollout fragments as lists of dicts on the
+      host, PFRL_PPO_RECURRENT_HOST=1 -- the reference's algorithm verbatim) every loss and the
+      trained parameters agree to 1e-5: same sequences in the same minibatches, same packed order,
+      same start states, same advantages;
+    * against the gpu=None run, which the reference's own test-suite pins (COVERAGE.md), to the
+      CPU / GPU LSTM rounding (2e-4)."""
     host = _run_recurrent_ppo(None)
+    monkeypatch.setenv("PFRL_PPO_RECURRENT_HOST", "1")
+    mixed = _run_recurrent_ppo(0, replay_actions=host["actions"])
+    assert mixed["agent"]._host is not None and mixed["agent"]._rec is None
+    monkeypatch.delenv("PFRL_PPO_RECURRENT_HOST")
     dev = _run_recurrent_ppo(0, replay_actions=host["actions"])
     ag = dev["agent"]
-    assert ag.device.type == "cuda" and ag.recurrent and ag._host is not None
+    assert ag.device.type == "cuda" and ag.recurrent and ag._host is None and ag._rec is not None
+    assert ag.rollout is not None and ag._rec.prev_cols.bufs is not None
     assert next(ag.model.parameters()).is_cuda
-    assert ag.n_updates == host["agent"].n_updates > 0
+    assert ag.n_updates == host["agent"].n_updates == mixed["agent"].n_updates > 0
     np.testing.assert_array_equal(dev["actions"], host["actions"])
+    np.testing.assert_allclose(dev["losses"], mixed["losses"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(dev["params"], mixed["params"], rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(dev["losses"], host["losses"], rtol=2e-4, atol=1e-5)
     np.testing.assert_allclose(dev["params"], host["params"], rtol=2e-4, atol=1e-5)
+
+
+def test_packed_layout_is_pack_sequence_on_length_sorted_sequences():
+    """``packed_layout`` (positions + batch_sizes built on the host) against what the reference
+    does with lists: ``sorted(key=len, reverse=True)`` -> ``pack_sequence`` /
+    ``flatten_sequences_time_first`` (pfrl/utils/recurrent.py:177-192, ppo.py:64-75)."""
+    from torch.nn.utils.rnn import pack_sequence
+
+    from pfrl_amd.agents._ppo_recurrent_device import packed_layout
+
+    rs = np.random.RandomState(0)
+    for trial in range(20):
+        n = int(rs.randint(1, 12))
+        seqs, base = [], 0
+        for _ in range(n):
+            L = int(rs.randint(1, 9))
+            seqs.append(np.arange(base, base + L, dtype=np.int64))
+            base += L + int(rs.randint(0, 3))
+        order, flat, batch_sizes = packed_layout(seqs)
+        ref_sorted = sorted(seqs, key=len, reverse=True)
+        assert [s.tolist() for s in ref_sorted] == [seqs[i].tolist() for i in order]
+        packed = pack_sequence([torch.from_numpy(s) for s in ref_sorted])
+        assert packed.data.tolist() == flat.tolist()
+        assert packed.batch_sizes.tolist() == batch_sizes.tolist()
+        assert R.flatten_sequences_time_first([s.tolist() for s in ref_sorted]) == flat.tolist()
 
 
 # ---------------------------------------------------------------------------------------------

@@ -549,7 +549,7 @@ def test_device_prioritized_buffer_uniform_ratio_and_no_wait_follow_reference_tr
 # ---------------------------------------------------------------------------
 # rollout kernels
 # ---------------------------------------------------------------------------
-@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("mode", [0, 1, 2])
 @pytest.mark.parametrize("T,N", [(128, 512), (5, 3), (1, 70), (37, 257), (300, 40), (500, 33), (1200, 9), (16, 4100)])
 def test_gae_scan_bit_exact(dev, mode, T, N):
     rs = np.random.RandomState(T * 7 + N + mode)
@@ -592,6 +592,23 @@ def test_gae_scan_golden(dev):
                                   T_(g["nv"][lo:hi]), T_((g["nonterm"][lo:hi] != 0).astype(np.uint8)),
                                   T_(cut), float(g["gamma"][c]), float(g["lambd"][c]),
                                   int(g["mode"][c]))
+        np.testing.assert_array_equal(adv.cpu().numpy().ravel(), g["adv"][lo:hi].astype(np.float32))
+        np.testing.assert_array_equal(vt.cpu().numpy().ravel(), g["vt"][lo:hi].astype(np.float32))
+
+
+def test_gae_scan_golden_recurrent_dataset(dev):
+    """mode 2: the recurrent dataset's Python-float values (reference ppo.py:98-107 then :36-47,
+    every operation f64), against the vectors recorded from the reference."""
+    g = np.load(os.path.join(GOLDEN, "gae_recurrent.npz"))
+    for c in range(len(g["gamma"])):
+        lo, hi = g["off"][c], g["off"][c + 1]
+        T = hi - lo
+        T_ = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev).reshape(T, 1)
+        cut = np.zeros(T, dtype=np.uint8)
+        cut[-1] = 1
+        adv, vt = _ops().gae_scan(T_(g["reward"][lo:hi].astype(np.float64)), T_(g["v"][lo:hi]),
+                                  T_(g["nv"][lo:hi]), T_((g["nonterm"][lo:hi] != 0).astype(np.uint8)),
+                                  T_(cut), float(g["gamma"][c]), float(g["lambd"][c]), 2)
         np.testing.assert_array_equal(adv.cpu().numpy().ravel(), g["adv"][lo:hi].astype(np.float32))
         np.testing.assert_array_equal(vt.cpu().numpy().ravel(), g["vt"][lo:hi].astype(np.float32))
 

@@ -225,6 +225,23 @@ def test_gae_fragments():
         assert set(g["adv_t"][lo:hi]) == {want_tag}
 
 
+def test_gae_fragments_of_the_recurrent_dataset():
+    """mode 2: v_pred / next_v_pred are Python floats (reference ppo.py:98-107), so ppo.py:36-47
+    runs in f64 throughout -- the product gamma * nonterminal * next_v included."""
+    g = np.load(os.path.join(GOLDEN, "gae_recurrent.npz"))
+    differs = 0
+    for c in range(len(g["gamma"])):
+        lo, hi = g["off"][c], g["off"][c + 1]
+        args = (g["reward"][lo:hi], g["v"][lo:hi], g["nv"][lo:hi], g["nonterm"][lo:hi],
+                g["gamma"][c], g["lambd"][c])
+        adv, vt = oracle.gae_fragment(*args, 2)
+        np.testing.assert_array_equal(adv, g["adv"][lo:hi])
+        np.testing.assert_array_equal(vt, g["vt"][lo:hi])
+        assert set(g["adv_t"][lo:hi]) <= {1, 3}      # Python float / np.float64: f64 either way
+        differs += int(not np.array_equal(oracle.gae_fragment(*args, 1)[0], adv))
+    assert differs > 0      # (the f32-rounded product of mode 1 is a different number)
+
+
 def test_a2c_returns():
     g = np.load(os.path.join(GOLDEN, "a2c_returns.npz"))
     for c in range(4):
