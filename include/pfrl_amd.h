@@ -343,6 +343,17 @@ int pfrl_ppo_act_head(const float *h, const float *w_policy, const float *b_poli
                       const int64_t *given_action, int64_t *out_action, float *out_entropy,
                       float *out_value, float *out_log_prob, int32_t N, int32_t K, int32_t A,
                       void *stream);
+/* PPO._lossfun (pfrl/agents/ppo.py:634-671) on the logits [M, A] and values [M] of a minibatch:
+ * clipped surrogate + (clipped, if clip_eps_vf >= 0) value MSE + entropy bonus, AND its gradient
+ * with respect to logits and values (d loss = 1), in one launch + a one-workgroup finish.
+ * `adv` is the (standardised) advantage column of the minibatch.  out4 = {loss, loss_policy,
+ * loss_value, mean entropy}; partial_ws: 3 * ceil(M / 256) doubles.  A <= 31.  Replaces ~90
+ * elementwise / reduction launches of torch.distributions + autograd per minibatch. */
+int pfrl_ppo_loss(const float *logits, const float *value, const int64_t *action, const float *adv,
+                  const float *log_prob_old, const float *v_pred_old, const float *v_teacher,
+                  int32_t M, int32_t A, float clip_eps, float clip_eps_vf, float value_func_coef,
+                  float entropy_coef, float *dlogits, float *dvalue, double *partial_ws, float *out4,
+                  void *stream);
 
 /* ------------------------------------------------------------------------
  * Optimizer step of the DQN update (pfrl/agents/dqn.py:360-365 calls

@@ -907,6 +907,17 @@ class PPO(agent.AttributeSavingMixin, agent.BatchAgent):
                                               self.device, lr_on_device=True)
         return cols
 
+    def _fused_loss_split(self):
+        """(body, policy layer, value layer) when the loss of a minibatch can run as the fused
+        launch: the example network's two narrow heads behind one body (``_ActGraph._split``),
+        the stock ``_lossfun``; ``PFRL_PPO_FUSED_LOSS=0`` keeps torch.distributions + autograd."""
+        if (os.environ.get("PFRL_PPO_FUSED_LOSS", "1") == "0" or self.device.type != "cuda"
+                or type(self)._lossfun is not PPO._lossfun or "_lossfun" in self.__dict__):
+            return None
+        if self._act_graph is None:
+            self._act_graph = _ActGraph(self)
+        return self._act_graph._split()
+
     def _minibatch_step(self, batch):
         """reference ppo.py:480-532 for one minibatch, on the static columns."""
         c = self._static_cols
@@ -915,14 +926,31 @@ class PPO(agent.AttributeSavingMixin, agent.BatchAgent):
                                    c["log_prob"], c["v_pred"], c["v_teacher"], c["action"],
                                    c["s_refs"])
             states = self._features(mb["refs"])
-        distribs, vs_pred = self.model(states)
-        self.optimizer.zero_grad(set_to_none=True)
-        records = {}
-        loss = self._lossfun(
-            distribs.entropy(), vs_pred, distribs.log_prob(mb["action"]),
-            vs_pred_old=mb["v_pred"][..., None], log_probs_old=mb["log_prob"],
-            advs=mb["adv"], vs_teacher=mb["v_teacher"][..., None], records=records)
-        loss.backward()
+        fused = self._fused_loss_split()
+        if fused is not None:
+            # heads as plain layers on the trunk's output, then loss + its gradient with respect to
+            # logits and values in ONE launch (pfrl_ppo_loss) instead of ~90 through
+            # torch.distributions + autograd; backward starts at the logits / values
+            body, pol, val = fused
+            h = body(states)
+            logits, vs_pred = pol(h), val(h)
+            self.optimizer.zero_grad(set_to_none=True)
+            out4, dlogits, dvalue = ops.ppo_loss(
+                logits, vs_pred, mb["action"], mb["adv"], mb["log_prob"], mb["v_pred"],
+                mb["v_teacher"], self.clip_eps, self.clip_eps_vf, self.value_func_coef,
+                self.entropy_coef)
+            torch.autograd.backward([logits, vs_pred], [dlogits, dvalue])
+            loss = out4[0]
+            records = {"value_loss": out4[2], "policy_loss": out4[1]}
+        else:
+            distribs, vs_pred = self.model(states)
+            self.optimizer.zero_grad(set_to_none=True)
+            records = {}
+            loss = self._lossfun(
+                distribs.entropy(), vs_pred, distribs.log_prob(mb["action"]),
+                vs_pred_old=mb["v_pred"][..., None], log_probs_old=mb["log_prob"],
+                advs=mb["adv"], vs_teacher=mb["v_teacher"][..., None], records=records)
+            loss.backward()
         # (data parallel: one flat all-reduce per minibatch, a graph node when captured;
         # nothing without a process group)
         self.grad_reducer.all_reduce()

@@ -375,6 +375,146 @@ __global__ __launch_bounds__(256) void k_ppo_act_head(
     if (log_prob != nullptr) log_prob[row] = lp_a;
 }
 
+// ---------------------------------------------------------------------------------------
+// PPO._lossfun (pfrl/agents/ppo.py:634-671) on the logits and values of a minibatch, forward AND
+// the gradient with respect to both, in one launch + a 1-workgroup finish:
+//   prob_ratio = exp(log pi(a|s) - log_prob_old)
+//   loss_policy = -mean(min(prob_ratio adv, clamp(prob_ratio, 1 - eps, 1 + eps) adv))
+//   loss_value  = mean((v - v_teacher)^2)                                   (clip_eps_vf < 0)
+//               = mean(max((v - vt)^2, (clip(v, v_old -+ eps_vf) - vt)^2))  (otherwise)
+//   loss_entropy = -mean(H(Categorical(logits)))
+//   loss = loss_policy + value_func_coef loss_value + entropy_coef loss_entropy
+// Through torch.distributions + autograd that is ~45 elementwise / reduction launches forward and
+// as many backward on [M, A] numbers: 0.5 ms of a 2 ms update at the 8-GPU rank's minibatch of
+// 2 048 (profiles/r06_ppo_rank_shape.txt), 4 % at 16 384.  One thread per row; torch's tie rules
+// are kept (min / max split the gradient of equal operands, clamp passes it at the bounds).
+// The sums over the batch are f64 per workgroup, folded in index order by the finish kernel.
+// ---------------------------------------------------------------------------------------
+template <int A>
+__global__ __launch_bounds__(kThreads) void k_ppo_loss(
+    const float *__restrict__ logits, const float *__restrict__ value,
+    const int64_t *__restrict__ action, const float *__restrict__ adv,
+    const float *__restrict__ logp_old, const float *__restrict__ v_old,
+    const float *__restrict__ v_teacher, int M, float clip_eps, float clip_eps_vf, float vf_coef,
+    float ent_coef, float *__restrict__ dlogits, float *__restrict__ dvalue,
+    double *__restrict__ partial) {
+    __shared__ double s_red[3][kThreads / 64];
+    const int m = blockIdx.x * kThreads + threadIdx.x;
+    const float inv_m = 1.0f / (float)M;
+    double pol = 0.0, val = 0.0, ent = 0.0;
+    if (m < M) {
+        float z[A];
+#pragma unroll
+        for (int j = 0; j < A; ++j) z[j] = logits[(size_t)m * A + j];
+        const int a = (int)action[m];
+        const float ad = adv[m], lpo = logp_old[m], v = value[m], vt = v_teacher[m];
+        float mx = z[0];
+#pragma unroll
+        for (int j = 1; j < A; ++j) mx = fmaxf(mx, z[j]);
+        float e[A], sum = 0.f;
+#pragma unroll
+        for (int j = 0; j < A; ++j) {
+            e[j] = expf(z[j] - mx);
+            sum += e[j];
+        }
+        const float lse = mx + logf(sum);
+        float H = 0.f, lpa = 0.f, p[A], lp[A];
+#pragma unroll
+        for (int j = 0; j < A; ++j) {
+            lp[j] = z[j] - lse;
+            p[j] = e[j] / sum;
+            H -= p[j] > 0.f ? p[j] * lp[j] : 0.f;
+            if (j == a) lpa = lp[j];
+        }
+        const float ratio = expf(lpa - lpo);
+        const float lo = 1.0f - clip_eps, hi = 1.0f + clip_eps;
+        const float rc = fminf(fmaxf(ratio, lo), hi);
+        const float s1 = ratio * ad, s2 = rc * ad;
+        const float surr = fminf(s1, s2);
+        // d surr / d ratio: both operands of min carry it inside the clip range (a tie: half
+        // each, summing to adv); outside only the unclipped product does, if it is the minimum
+        const bool inside = ratio >= lo && ratio <= hi;
+        float ds = 0.f;
+        if (inside) ds = ad;
+        else if (s1 < s2) ds = ad;
+        else if (s1 == s2) ds = 0.5f * ad;
+        const float g_lpa = -inv_m * ds * ratio;
+        const float ge = ent_coef * inv_m;
+#pragma unroll
+        for (int j = 0; j < A; ++j) {
+            const float onehot = j == a ? 1.f : 0.f;
+            float g = g_lpa * (onehot - p[j]);
+            g += p[j] > 0.f ? ge * p[j] * (lp[j] + H) : 0.f;
+            dlogits[(size_t)m * A + j] = g;
+        }
+        const float d1 = v - vt;
+        float lv = d1 * d1, gv = 2.f * d1;
+        if (clip_eps_vf >= 0.f) {
+            const float vo = v_old[m];
+            const float vlo = vo - clip_eps_vf, vhi = vo + clip_eps_vf;
+            const float vc = fminf(fmaxf(v, vlo), vhi);
+            const float d2 = vc - vt;
+            const float l2 = d2 * d2;
+            // d vc / d v: torch.min(torch.max(v, lo), hi) -- 1 strictly inside, 1/2 at a bound
+            // (max / min split ties), 0 outside
+            float dvc = (v > vlo && v < vhi) ? 1.f : ((v == vlo || v == vhi) ? 0.5f : 0.f);
+            if (l2 > lv) {
+                lv = l2;
+                gv = 2.f * d2 * dvc;
+            } else if (l2 == lv) {
+                gv = 0.5f * (2.f * d1) + 0.5f * (2.f * d2 * dvc);
+            }
+        }
+        dvalue[m] = vf_coef * inv_m * gv;
+        pol = -(double)surr;
+        val = (double)lv;
+        ent = (double)H;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        pol += __shfl_xor(pol, o, 64);
+        val += __shfl_xor(val, o, 64);
+        ent += __shfl_xor(ent, o, 64);
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) {
+        s_red[0][wave] = pol;
+        s_red[1][wave] = val;
+        s_red[2][wave] = ent;
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        double t = 0.0;
+#pragma unroll
+        for (int w = 0; w < kThreads / 64; ++w) t += s_red[threadIdx.x][w];
+        partial[(size_t)blockIdx.x * 3 + threadIdx.x] = t;
+    }
+}
+
+// out[0] = loss, out[1] = loss_policy, out[2] = loss_value, out[3] = mean entropy
+__global__ __launch_bounds__(64) void k_ppo_loss_finish(const double *__restrict__ partial, int nblk,
+                                                        int M, float vf_coef, float ent_coef,
+                                                        float *__restrict__ out) {
+    const int lane = threadIdx.x;
+    double s[3] = {0.0, 0.0, 0.0};
+    for (int b = lane; b < nblk; b += 64) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) s[k] += partial[(size_t)b * 3 + k];
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s[k] += __shfl_xor(s[k], o, 64);
+    }
+    if (lane == 0) {
+        const float pol = (float)(s[0] / M), val = (float)(s[1] / M), ent = (float)(s[2] / M);
+        out[1] = pol;
+        out[2] = val;
+        out[3] = ent;
+        out[0] = (pol + vf_coef * val) + ent_coef * (-ent);
+    }
+}
+
 }  // namespace
 
 extern "C" int pfrl_gae_scan(int64_t T, int64_t N, const double *reward, const float *v_pred,
@@ -488,5 +628,36 @@ extern "C" int pfrl_ppo_act_head(const float *h, const float *w_policy, const fl
         ACT_CALL(30) ACT_CALL(31)
     }
 #undef ACT_CALL
+    PFRL_LAUNCH_CHECK();
+}
+
+extern "C" int pfrl_ppo_loss(const float *logits, const float *value, const int64_t *action,
+                             const float *adv, const float *log_prob_old, const float *v_pred_old,
+                             const float *v_teacher, int32_t M, int32_t A, float clip_eps,
+                             float clip_eps_vf, float value_func_coef, float entropy_coef,
+                             float *dlogits, float *dvalue, double *partial_ws, float *out4,
+                             void *stream) {
+    PFRL_CHECK_ARG(M >= 1 && A >= 1 && A < ACT_MAX_OUT, "pfrl_ppo_loss: 1 <= A <= 31, M >= 1");
+    PFRL_CHECK_ARG(logits && value && action && adv && log_prob_old && v_teacher && dlogits && dvalue &&
+                       partial_ws && out4 && (clip_eps_vf < 0.f || v_pred_old),
+                   "pfrl_ppo_loss: null pointer");
+    const unsigned blocks = (unsigned)((M + kThreads - 1) / kThreads);
+#define LOSS_CALL(AA)                                                                              \
+    case AA:                                                                                       \
+        hipLaunchKernelGGL(k_ppo_loss<AA>, dim3(blocks), dim3(kThreads), 0, (hipStream_t)stream,   \
+                           logits, value, action, adv, log_prob_old, v_pred_old, v_teacher, M,     \
+                           clip_eps, clip_eps_vf, value_func_coef, entropy_coef, dlogits, dvalue,  \
+                           partial_ws);                                                            \
+        break;
+    switch (A) {
+        LOSS_CALL(1) LOSS_CALL(2) LOSS_CALL(3) LOSS_CALL(4) LOSS_CALL(5) LOSS_CALL(6) LOSS_CALL(7)
+        LOSS_CALL(8) LOSS_CALL(9) LOSS_CALL(10) LOSS_CALL(11) LOSS_CALL(12) LOSS_CALL(13) LOSS_CALL(14)
+        LOSS_CALL(15) LOSS_CALL(16) LOSS_CALL(17) LOSS_CALL(18) LOSS_CALL(19) LOSS_CALL(20)
+        LOSS_CALL(21) LOSS_CALL(22) LOSS_CALL(23) LOSS_CALL(24) LOSS_CALL(25) LOSS_CALL(26)
+        LOSS_CALL(27) LOSS_CALL(28) LOSS_CALL(29) LOSS_CALL(30) LOSS_CALL(31)
+    }
+#undef LOSS_CALL
+    hipLaunchKernelGGL(k_ppo_loss_finish, dim3(1), dim3(64), 0, (hipStream_t)stream, partial_ws,
+                       (int)blocks, M, value_func_coef, entropy_coef, out4);
     PFRL_LAUNCH_CHECK();
 }

@@ -447,6 +447,28 @@ def gae_scan(reward, v_pred, next_v_pred, nonterminal, cut, gamma, lambd, mode=0
     return adv, vt
 
 
+def ppo_loss(logits, value, action, adv, log_prob_old, v_pred_old, v_teacher, clip_eps, clip_eps_vf,
+             value_func_coef, entropy_coef):
+    """PPO._lossfun (reference pfrl/agents/ppo.py:634-671) and its gradient with respect to the
+    logits [M, A] and values [M(, 1)] of a minibatch in one launch (pfrl_ppo_loss).  Returns (out4 =
+    [loss, loss_policy, loss_value, mean entropy], dlogits [M, A], dvalue shaped like ``value``);
+    the caller starts backward at the logits / values with these gradients."""
+    M, A = logits.shape
+    logits, v = logits.detach().contiguous(), value.detach().reshape(-1).contiguous()
+    dev = logits.device
+    dlogits = torch.empty_like(logits)
+    dvalue = torch.empty(M, dtype=torch.float32, device=dev)
+    ws = torch.empty(3 * ((M + 255) // 256), dtype=torch.float64, device=dev)
+    out = torch.empty(4, dtype=torch.float32, device=dev)
+    check(_native.lib().pfrl_ppo_loss(
+        _ptr(logits), _ptr(v), _ptr(action), _ptr(adv.reshape(-1)), _ptr(log_prob_old.reshape(-1)),
+        _ptr(v_pred_old.reshape(-1)) if clip_eps_vf is not None else None, _ptr(v_teacher.reshape(-1)),
+        M, A, float(clip_eps), -1.0 if clip_eps_vf is None else float(clip_eps_vf),
+        float(value_func_coef), float(entropy_coef), _ptr(dlogits), _ptr(dvalue), _ptr(ws), _ptr(out),
+        _stream()), "ppo_loss")
+    return out, dlogits, dvalue.view(value.shape)
+
+
 def ppo_act_head(h, w_policy, b_policy, w_value, b_value, u01, want_log_prob=False):
     """The two narrow heads of the PPO example network + Categorical sample / entropy in one launch
     (pfrl_ppo_act_head).  h [N, K] f32; returns (action i64 [N], entropy [N], value [N][, log_prob])."""

@@ -1575,6 +1575,53 @@ def test_dqn_act_head_is_the_small_linear_head_plus_argmax_and_selection(dev, M,
     np.testing.assert_array_equal(act2.cpu().numpy(), greedy)
 
 
+@pytest.mark.parametrize("clip_eps_vf", [None, 0.2])
+@pytest.mark.parametrize("M,A", [(2048, 6), (37, 18), (1, 2), (16384, 6), (300, 31)])
+def test_fused_ppo_loss_matches_the_reference_expression_and_its_autograd(dev, M, A, clip_eps_vf):
+    """pfrl_ppo_loss against PPO._lossfun (the reference's expression, pfrl/agents/ppo.py:634-671)
+    on a ``Categorical(logits=...)`` with autograd: loss, its three parts, and the gradients with
+    respect to logits and values -- including rows whose ratio is clipped from either side, rows
+    with zero advantage and values outside / inside the value clip range."""
+    from pfrl_amd import ops
+    from pfrl_amd.agents.ppo import PPO
+
+    torch.manual_seed(M * 31 + A)
+    logits = (torch.randn(M, A, device=dev) * 1.5).requires_grad_(True)
+    value = torch.randn(M, 1, device=dev).requires_grad_(True)
+    action = torch.randint(0, A, (M,), device=dev)
+    with torch.no_grad():
+        lp_now = torch.distributions.Categorical(logits=logits).log_prob(action)
+    # old log-probs around the current ones: ratios from ~0.6 to ~1.6, a third exactly 1
+    shift = torch.randn(M, device=dev) * 0.25
+    shift[::3] = 0.0
+    logp_old = lp_now - shift
+    adv = torch.randn(M, device=dev)
+    adv[::7] = 0.0
+    v_old = value.detach().reshape(-1) + torch.randn(M, device=dev) * 0.3
+    v_teacher = torch.randn(M, device=dev)
+
+    class _A:
+        clip_eps, value_func_coef, entropy_coef = 0.1, 0.7, 0.02
+        value_loss_record = policy_loss_record = None
+
+    _A.clip_eps_vf = clip_eps_vf
+    rec = {}
+    d = torch.distributions.Categorical(logits=logits)
+    want = PPO._lossfun(_A, d.entropy(), value, d.log_prob(action), vs_pred_old=v_old[:, None],
+                        log_probs_old=logp_old, advs=adv, vs_teacher=v_teacher[:, None], records=rec)
+    want.backward()
+    out4, dlogits, dvalue = ops.ppo_loss(logits, value, action, adv, logp_old, v_old, v_teacher,
+                                         _A.clip_eps, clip_eps_vf, _A.value_func_coef, _A.entropy_coef)
+    tol = dict(rtol=2e-5, atol=2e-7)
+    assert torch.allclose(out4[0], want.detach(), rtol=1e-5, atol=1e-6)
+    assert torch.allclose(out4[1], rec["policy_loss"].detach(), rtol=1e-5, atol=1e-6)
+    assert torch.allclose(out4[2], rec["value_loss"].detach(), rtol=1e-5, atol=1e-6)
+    assert torch.allclose(out4[3], d.entropy().mean().detach(), rtol=1e-5, atol=1e-6)
+    assert dvalue.shape == value.shape
+    assert torch.allclose(dvalue, value.grad, **tol), float((dvalue - value.grad).abs().max())
+    assert torch.allclose(dlogits, logits.grad, **tol), float((dlogits - logits.grad).abs().max())
+
+
 def test_ppo_act_head_matches_torch_categorical(dev):
     """pfrl_ppo_act_head against the torch expressions it replaces on the acting path
     (Linear + Categorical(logits): value, entropy, log pi(a)) and its inverse-CDF sampling: the
