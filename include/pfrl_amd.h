@@ -428,13 +428,17 @@ int pfrl_dqn_td_loss(const float *q, const int64_t *action, const float *target_
  * [A*K, A*K + A), the loss of [A*K + 16].  A <= 16, K = 256 or 512.  * h_part != NULL: the hidden layer's forward (pfrl_conv2d_nhwc_fwd with splits > 1) left h as
  * h_splits split-K slabs of h_stride floats; each row folds them here (h = relu(sum + h_bias),
  * the order of pfrl_splitk_reduce), uses h and writes it to h_out for the backward pass -- the
- * fold launch between the two disappears.  h is then ignored. */
+ * fold launch between the two disappears.  h is then ignored.
+ * dh_masked != NULL (data parallel): also dh with the ReLU mask of h applied (h > 0) and
+ * multiplied by dh_scale (1 / world size) -- the hidden layer's batch matrix as the low-rank
+ * gradient exchange all-gathers it (pfrl_amd/distributed.py::lowrank_ready). */
 int pfrl_dqn_head_td_loss(const float *h, const float *w, const float *bias, const int64_t *action,
                           const float *target_q, const float *next_q_online, const float *reward,
                           const float *discount, const float *terminal, const float *weights,
                           int32_t B, int32_t K, int32_t A, int clip_delta, int mean, float *out_y,
                           float *out_abs_delta, float *dh, float *partials, const float *h_part, int32_t h_splits,
-                          int64_t h_stride, const float *h_bias, float *h_out, void *stream);
+                          int64_t h_stride, const float *h_bias, float *h_out, float *dh_masked,
+                          float dh_scale, void *stream);
 
 /* Fused bias + ReLU of the conv trunk (pfrl/nn/atari_cnn.py:40-47: activation(
  * layer(h)) with conv bias) on row-major [rows][C] activations, i.e.
@@ -597,6 +601,20 @@ int pfrl_splitk_reduce(int32_t n_tasks, const float *const *host_part, float *co
                        const float *const *host_bias, const int64_t *host_stride,
                        const int32_t *host_n, const int32_t *host_splits, const int32_t *host_ncol,
                        const int32_t *host_relu, void *stream);
+/* torch.nn.utils.clip_grad_norm_(parameters, max_norm, norm_type=2) as the reference's update
+ * calls it between backward and step (pfrl/agents/ppo.py:602-605, dqn.py:362-364): global L2 norm
+ * of up to 24 dense f32 gradient tensors, coef = min(max_norm / (norm + 1e-6), 1), every gradient
+ * scaled in place -- three launches.  partial_ws: sum over tensors of ceil(numel / 4096) doubles;
+ * out_norm_coef[0] = the norm, [1] = the coefficient. */
+int pfrl_clip_grad_norm(int32_t n_tensors, float *const *grads, const int64_t *numel, float max_norm,
+                        double *partial_ws, float *out_norm_coef, void *stream);
+/* First level of a two-level split-K fold: out[g * out_stride + e] = the sum, in slab order, of
+ * slabs [g * per, (g + 1) * per) of `part` (per = ceil(splits / groups)), e < n, all groups in one
+ * launch; pfrl_splitk_reduce then folds the `groups` partial slabs.  For tensors with thousands
+ * of short slabs (the first convolution's weight gradient at rollout size, autograd's
+ * `conv2d` backward in PPO._update_once, pfrl/agents/ppo.py:521-532). */
+int pfrl_splitk_group(const float *part, int64_t stride, int32_t n, int32_t splits, int32_t groups,
+                      float *out, int64_t out_stride, void *stream);
 int pfrl_linear_fwd(const float *x, const float *w, const float *bias, float *y, int32_t M, int32_t K,
                     int32_t N, int32_t relu, int32_t splits, void *stream);
 /* Weight and bias gradient of such a layer, any in_features (out_features % 16 == 0):

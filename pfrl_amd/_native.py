@@ -189,7 +189,7 @@ EXPORTS = {
     "pfrl_rmsprop_step": (ctypes.c_int, "ipppppffffip"),
     "pfrl_rmsprop_fused_step": (ctypes.c_int, "ipffffip"),
     "pfrl_dqn_td_loss": (ctypes.c_int, "ppppppppqiiippppp"),
-    "pfrl_dqn_head_td_loss": (ctypes.c_int, "ppppppppppiiiiipppppiqppp"),
+    "pfrl_dqn_head_td_loss": (ctypes.c_int, "ppppppppppiiiiipppppiqpppfp"),
     "pfrl_bias_relu_fwd": (ctypes.c_int, "pppqiqp"),
     "pfrl_bias_relu_bwd": (ctypes.c_int, "ppppppqiiqp"),
     "pfrl_c51_loss": (ctypes.c_int, "pppppppppiiiippppp"),
@@ -204,6 +204,8 @@ EXPORTS = {
     "pfrl_conv2d_nhwc_bwd": (ctypes.c_int, "ppppppppqqiiiiiiiiiiip"),
     "pfrl_splitk_reduce": (ctypes.c_int, "ippppppppp"),
     "pfrl_splitk_reduce_noisy": (ctypes.c_int, "ippppppppppp"),
+    "pfrl_splitk_group": (ctypes.c_int, "pqiiipqp"),
+    "pfrl_clip_grad_norm": (ctypes.c_int, "ippfppp"),
     "pfrl_linear_noisy_fwd": (ctypes.c_int, "pppppppiiiiip"),
     "pfrl_linear_noisy_fwd_pair": (ctypes.c_int, "pippppppiipip"),
     "pfrl_linear_fwd": (ctypes.c_int, "ppppiiiiip"),

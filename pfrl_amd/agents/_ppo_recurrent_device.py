@@ -30,6 +30,7 @@ from torch.nn.utils.rnn import PackedSequence
 from pfrl_amd import ops
 from pfrl_amd.agents.ppo_host import (_limit_sequence_length,
                                       _yield_subset_of_sequences_with_fixed_number_of_items)
+from pfrl_amd.utils.clip_l2_grad_norm import clip_grad_norm_device_
 from pfrl_amd.utils.contexts import evaluating
 from pfrl_amd.utils.recurrent import (_map_state, mask_recurrent_state_at, one_step_forward,
                                       unwrap_packed_sequences_recursive)
@@ -236,6 +237,6 @@ class RecurrentDeviceRollouts:
         loss.backward()
         a.grad_reducer.all_reduce()
         if a.max_grad_norm is not None:
-            torch.nn.utils.clip_grad_norm_(a.model.parameters(), a.max_grad_norm)
+            clip_grad_norm_device_(a.model.parameters(), a.max_grad_norm)
         a.optimizer.step()
         a.n_updates += 1

@@ -36,6 +36,7 @@ import torch.nn.functional as F
 
 from pfrl_amd import agent, ops
 from pfrl_amd.agents.dqn import _DeviceRecord, _mean_or_nan
+from pfrl_amd.utils.clip_l2_grad_norm import clip_grad_norm_device_
 from pfrl_amd.device_store import DeviceObs, DeviceObsBatch
 from pfrl_amd.utils.batch_states import batch_states
 from pfrl_amd.utils.contexts import evaluating
@@ -832,7 +833,7 @@ class PPO(agent.AttributeSavingMixin, agent.BatchAgent):
             loss.backward()
             self.grad_reducer.all_reduce()
             if self.max_grad_norm is not None:
-                torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.max_grad_norm)
+                clip_grad_norm_device_(self.model.parameters(), self.max_grad_norm)
             self.optimizer.step()
             self.n_updates += 1
         # explained variance (reference :181-193), one small reduction
@@ -955,7 +956,7 @@ class PPO(agent.AttributeSavingMixin, agent.BatchAgent):
         # nothing without a process group)
         self.grad_reducer.all_reduce()
         if self.max_grad_norm is not None:
-            torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.max_grad_norm)
+            clip_grad_norm_device_(self.model.parameters(), self.max_grad_norm)
         self.optimizer.step()
         return {"loss": loss.detach(), "value_loss": records["value_loss"].detach(),
                 "policy_loss": records["policy_loss"].detach()}

@@ -347,3 +347,108 @@ extern "C" int pfrl_rmsprop_fused_step(int32_t n_tasks, const pfrl_opt_task_t *h
     }
     PFRL_LAUNCH_CHECK();
 }
+
+// ---------------------------------------------------------------------------------------
+// torch.nn.utils.clip_grad_norm_(parameters, max_norm) (pfrl/agents/ppo.py:602-605: between
+// loss.backward() and optimizer.step() of every minibatch) in three launches instead of twelve
+// (_foreach_norm + lpnorm_cleanup, stack, vector_norm, add eps, reciprocal, mul, clamp,
+// _foreach_mul x 2 ...): 60 us of a 1.7 ms update at the 8-GPU rank's minibatch.
+//   1. per 4 096-element chunk of every gradient: sum of squares (f64) -> partial[chunk]
+//   2. one wavefront: total = sum of partials in index order, norm = sqrtf((float)total),
+//      coef = min(max_norm / (norm + 1e-6), 1)      (torch's clip_coef_clamped)
+//   3. every gradient *= coef  (also when coef == 1, as torch does)
+// ---------------------------------------------------------------------------------------
+namespace {
+
+constexpr int kClipChunk = 4096;
+
+struct ClipArgs {
+    float *g[PFRL_OPT_MAX_TENSORS];
+    int64_t numel[PFRL_OPT_MAX_TENSORS];
+    int32_t chunk_end[PFRL_OPT_MAX_TENSORS];
+    int32_t n;
+};
+
+__global__ __launch_bounds__(kThreads) void k_grad_sumsq(ClipArgs a, double *__restrict__ partial) {
+    __shared__ double s_w[kThreads / 64];
+    int t = 0;
+    const int b = blockIdx.x;
+    while (t < a.n - 1 && b >= a.chunk_end[t]) ++t;
+    const int64_t base = (int64_t)(b - (t == 0 ? 0 : a.chunk_end[t - 1])) * kClipChunk;
+    const float *__restrict__ g = a.g[t];
+    const int64_t n = a.numel[t];
+    float v[kClipChunk / kThreads];
+#pragma unroll
+    for (int u = 0; u < kClipChunk / kThreads; ++u) {
+        const int64_t i = base + u * kThreads + threadIdx.x;
+        v[u] = i < n ? g[i] : 0.f;
+    }
+    double acc = 0.0;
+#pragma unroll
+    for (int u = 0; u < kClipChunk / kThreads; ++u) acc += (double)v[u] * (double)v[u];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double s = 0.0;
+#pragma unroll
+        for (int w = 0; w < kThreads / 64; ++w) s += s_w[w];
+        partial[b] = s;
+    }
+}
+
+// out[0] = total norm, out[1] = clamped clip coefficient
+__global__ __launch_bounds__(64) void k_clip_coef(const double *__restrict__ partial, int nblk,
+                                                  float max_norm, float *__restrict__ out) {
+    double s = 0.0;
+    for (int b = threadIdx.x; b < nblk; b += 64) s += partial[b];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (threadIdx.x == 0) {
+        const float norm = sqrtf((float)s);
+        const float coef = max_norm / (norm + 1e-6f);
+        out[0] = norm;
+        out[1] = coef < 1.0f ? coef : 1.0f;
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void k_grad_scale(ClipArgs a, const float *__restrict__ coef_p) {
+    int t = 0;
+    const int b = blockIdx.x;
+    while (t < a.n - 1 && b >= a.chunk_end[t]) ++t;
+    const int64_t base = (int64_t)(b - (t == 0 ? 0 : a.chunk_end[t - 1])) * kClipChunk;
+    float *__restrict__ g = a.g[t];
+    const int64_t n = a.numel[t];
+    const float coef = coef_p[1];
+#pragma unroll
+    for (int u = 0; u < kClipChunk / kThreads; ++u) {
+        const int64_t i = base + u * kThreads + threadIdx.x;
+        if (i < n) g[i] = __fmul_rn(g[i], coef);
+    }
+}
+
+}  // namespace
+
+extern "C" int pfrl_clip_grad_norm(int32_t n_tensors, float *const *grads, const int64_t *numel,
+                                   float max_norm, double *partial_ws, float *out_norm_coef,
+                                   void *stream) {
+    PFRL_CHECK_ARG(n_tensors >= 1 && n_tensors <= PFRL_OPT_MAX_TENSORS && grads && numel && partial_ws &&
+                       out_norm_coef && max_norm > 0.f,
+                   "pfrl_clip_grad_norm: 1 <= tensors <= 24, max_norm > 0");
+    ClipArgs a;
+    int chunks = 0;
+    for (int t = 0; t < n_tensors; ++t) {
+        a.g[t] = grads[t];
+        a.numel[t] = numel[t];
+        chunks += (int)((numel[t] + kClipChunk - 1) / kClipChunk);
+        a.chunk_end[t] = chunks;
+    }
+    a.n = n_tensors;
+    if (chunks == 0) return 0;
+    hipLaunchKernelGGL(k_grad_sumsq, dim3(chunks), dim3(kThreads), 0, (hipStream_t)stream, a, partial_ws);
+    hipLaunchKernelGGL(k_clip_coef, dim3(1), dim3(64), 0, (hipStream_t)stream, partial_ws, chunks, max_norm,
+                       out_norm_coef);
+    hipLaunchKernelGGL(k_grad_scale, dim3(chunks), dim3(kThreads), 0, (hipStream_t)stream, a, out_norm_coef);
+    PFRL_LAUNCH_CHECK();
+}

@@ -118,7 +118,8 @@ __device__ __forceinline__ void head_td_row(
     const float *__restrict__ weights, int B, int clip_delta, int mean, float *__restrict__ out_y,
     float *__restrict__ out_abs_delta, float *__restrict__ dh, const int m, float (*s_c)[64 * KJ],
     float *s_g, float *s_l, int *s_act, const float *__restrict__ h_part, int h_splits,
-    int64_t h_stride, const float *__restrict__ h_bias, float *__restrict__ h_out) {
+    int64_t h_stride, const float *__restrict__ h_bias, float *__restrict__ h_out,
+    float *__restrict__ dh_masked, float dh_scale) {
     constexpr int K = 64 * KJ;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // (optional inputs are read through a pointer that is always valid: no branch at a load)
@@ -211,7 +212,14 @@ __device__ __forceinline__ void head_td_row(
         wsel[j] = wv[0][j];
 #pragma unroll
         for (int a = 1; a < A; ++a) wsel[j] = (a == act) ? wv[a][j] : wsel[j];
-        dh[(size_t)m * K + lane + 64 * j] = gq * wsel[j];
+        const float dv = gq * wsel[j];
+        dh[(size_t)m * K + lane + 64 * j] = dv;
+        // (data parallel: the hidden layer's batch matrix dy as its low-rank exchange wants it --
+        // ReLU mask of h applied, times 1 / world size -- written here instead of by two
+        // elementwise launches in front of the all-gather, distributed.lowrank_ready)
+        if (dh_masked != nullptr)
+            dh_masked[(size_t)m * K + lane + 64 * j] =
+                hv[j] > 0.f ? (dh_scale == 1.0f ? dv : __fmul_rn(dv, dh_scale)) : 0.f;
     }
     if (lane == 0) {
         out_y[m] = y;
@@ -238,7 +246,8 @@ __global__ __launch_bounds__(kThreads) void k_dqn_head_td_rows(
     const float *__restrict__ weights, int B, int clip_delta, int mean, float *__restrict__ out_y,
     float *__restrict__ out_abs_delta, float *__restrict__ dh, float *__restrict__ part,
     const float *__restrict__ h_part, int h_splits, int64_t h_stride,
-    const float *__restrict__ h_bias, float *__restrict__ h_out) {
+    const float *__restrict__ h_bias, float *__restrict__ h_out, float *__restrict__ dh_masked,
+    float dh_scale) {
     constexpr int K = 64 * KJ;
     constexpr int STRIDE = A * K + 32;
     __shared__ float s_c[4][K];
@@ -255,7 +264,7 @@ __global__ __launch_bounds__(kThreads) void k_dqn_head_td_rows(
     if (m < B)
         head_td_row<A, KJ>(h, W, bias, action, target_q, next_q_online, reward, discount, terminal,
                            weights, B, clip_delta, mean, out_y, out_abs_delta, dh, m, s_c, s_g, s_l,
-                           s_act, h_part, h_splits, h_stride, h_bias, h_out);
+                           s_act, h_part, h_splits, h_stride, h_bias, h_out, dh_masked, dh_scale);
     __syncthreads();
     float *pr = part + (size_t)blockIdx.x * STRIDE;
     for (int e = tid; e < A * K; e += kThreads) {
@@ -288,7 +297,8 @@ extern "C" int pfrl_dqn_head_td_loss(const float *h, const float *w, const float
                                      int32_t B, int32_t K, int32_t A, int clip_delta, int mean,
                                      float *out_y, float *out_abs_delta, float *dh, float *partials,
                                      const float *h_part, int32_t h_splits, int64_t h_stride,
-                                     const float *h_bias, float *h_out, void *stream) {
+                                     const float *h_bias, float *h_out, float *dh_masked,
+                                     float dh_scale, void *stream) {
     PFRL_CHECK_ARG(B >= 1 && A >= 1 && A <= 16 && (K == 512 || K == 256),
                    "pfrl_dqn_head_td_loss: A <= 16, K = 256 or 512");
     PFRL_CHECK_ARG(h_part == nullptr || (h_splits >= 1 && h_bias && h_out && h_stride >= (int64_t)B * K),
@@ -301,13 +311,13 @@ extern "C" int pfrl_dqn_head_td_loss(const float *h, const float *w, const float
                                (hipStream_t)stream, h, w, bias, action, target_q, next_q_online,   \
                                reward, discount, terminal, weights, B, clip_delta, mean, out_y,    \
                                out_abs_delta, dh, partials, h_part, h_splits, h_stride, h_bias,    \
-                               h_out);                                                             \
+                               h_out, dh_masked, dh_scale);                                        \
         else                                                                                       \
             hipLaunchKernelGGL((k_dqn_head_td_rows<AA, 4>), grid, dim3(kThreads), 0,               \
                                (hipStream_t)stream, h, w, bias, action, target_q, next_q_online,   \
                                reward, discount, terminal, weights, B, clip_delta, mean, out_y,    \
                                out_abs_delta, dh, partials, h_part, h_splits, h_stride, h_bias,    \
-                               h_out);                                                             \
+                               h_out, dh_masked, dh_scale);                                        \
     } while (0)
     switch (A) {
         case 1: CALL_HT(1); break;   case 2: CALL_HT(2); break;   case 3: CALL_HT(3); break;

@@ -51,6 +51,14 @@ def init_process_group_from_env(backend=None):
     return rank, world, local
 
 
+def _is_dense(t):
+    """Every element of the storage span exactly once (any permutation of a contiguous layout)."""
+    if t.is_contiguous():
+        return True
+    order = sorted(range(t.dim()), key=lambda d: -t.stride(d))
+    return t.permute(*order).is_contiguous()
+
+
 def world_size():
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
@@ -108,14 +116,14 @@ def lowrank_pays(M, F, K, world=None):
     return world > 1 and M <= 256 and world * M * (F + K) <= F * K
 
 
-def announce_lowrank(weight, bias, dy, x, mask=None):
+def announce_lowrank(weight, bias, dy, x, mask=None, premasked=None):
     """Called by the producer of a large Linear layer's gradient INSTEAD of forming it: ``dy``
     [M, F] and ``x`` [M, K] are the layer's batch matrices (``mask``: the layer's output when its
     ReLU mask has not been applied to ``dy`` yet), dW = dy^T x, db = sum_m dy.  Returns True when a
     data-parallel reducer took them (it then owns ``weight.grad`` / ``bias.grad`` of this step);
     False = the caller forms the gradient."""
     for r in list(_EARLY_REDUCERS):
-        if r.lowrank_ready(weight, bias, dy, x, mask):
+        if r.lowrank_ready(weight, bias, dy, x, mask, premasked=premasked):
             return True
     return False
 
@@ -344,7 +352,7 @@ class GradientAllReducer:
         return (target is not None and id(target) not in self._pending
                 and lowrank_pays(M, weight.shape[0], weight.shape[1]))
 
-    def lowrank_ready(self, weight, bias, dy, x, mask=None):
+    def lowrank_ready(self, weight, bias, dy, x, mask=None, premasked=None):
         """Exchange this layer's gradient as its batch matrices, starting now: ``dy`` [M, F] (with
         ``mask``: the layer's output, its ReLU mask still to be applied), ``x`` [M, K].  On the GPU
         with the directly driven communicator EVERYTHING happens on its side stream, beside the
@@ -362,9 +370,14 @@ class GradientAllReducer:
         G = world_size()
 
         def prepared():
-            d = dy if mask is None else torch.ops.aten.threshold_backward(dy, mask, 0.0)
-            if G > 1:
-                d = d * (1.0 / G)                  # the average: dW = sum_g (dy_g / G)^T x_g
+            if premasked is not None and premasked[1] == G:
+                # (``premasked``: (dy masked and scaled by 1 / G already, G) -- the producer's own
+                # launch wrote it, pfrl_dqn_head_td_loss)
+                d = premasked[0]
+            else:
+                d = dy if mask is None else torch.ops.aten.threshold_backward(dy, mask, 0.0)
+                if G > 1:
+                    d = d * (1.0 / G)              # the average: dW = sum_g (dy_g / G)^T x_g
             d, xx = d.contiguous(), x.contiguous()
             return (d, xx, torch.empty((G * d.shape[0], d.shape[1]), dtype=d.dtype, device=d.device),
                     torch.empty((G * xx.shape[0], xx.shape[1]), dtype=xx.dtype, device=xx.device))
@@ -579,9 +592,54 @@ class GradientAllReducer:
     def all_reduce(self):
         if not self.active():
             return
+        if self._all_reduce_in_bucket_views():
+            return
         self.pack()
         self.reduce_flat()
         self.unpack()
+
+    def _all_reduce_in_bucket_views(self):
+        """pack -> all-reduce -> unpack for dense f32 device gradients WITHOUT the per-tensor
+        copies: ONE multi-tensor launch moves every gradient into its 16-byte aligned segment of
+        the flat bucket (raw memory order: the segment view takes the gradient's own strides), the
+        collective reduces the bucket, and ``p.grad`` BECOMES the segment view -- no copy back.
+        (``torch._foreach_copy_`` is a launch per tensor on this stack: 24 launches, 110 us of a
+        1.7 ms PPO update at the 8-GPU rank's minibatch, profiles/r06_ppo_rank_shape.txt.)
+        False = some gradient is outside what this covers; the caller takes the copy path."""
+        params = [p for p in self.params if p.grad is not None and id(p) not in self._pending]
+        if not params or not all(
+                p.grad.is_cuda and p.grad.dtype == torch.float32 and p.grad.stride() == p.stride()
+                and p.grad.data_ptr() % 16 == 0 and p.grad.numel() > 0 and _is_dense(p)
+                for p in params):
+            return False
+        from pfrl_amd import _native
+
+        if not _native.available() or os.environ.get("PFRL_DP_BUCKET_VIEWS", "1") == "0":
+            return False
+        from pfrl_amd.nn import mfma_trunk as mt
+
+        self._start_deferred()
+        params = [p for p in params if id(p) not in self._pending]
+        n = sum((p.numel() + 3) & ~3 for p in params)
+        dev = params[0].device
+        flat = self._flat_sources
+        if flat is None or flat.numel() != n or flat.device != dev:
+            flat = self._flat_sources = torch.zeros(n, dtype=torch.float32, device=dev)
+        tasks, off = [], 0
+        for p in params:
+            seg = flat[off:off + p.numel()]
+            tasks.append((p.grad, seg, None, 0, p.numel(), 1, 4, 0))
+            off += (p.numel() + 3) & ~3
+        for i in range(0, len(tasks), 12):
+            mt._reduce(tasks[i:i + 12])
+        off = 0
+        for p in params:
+            p.grad = flat[off:off + p.numel()].as_strided(p.size(), p.stride())
+            off += (p.numel() + 3) & ~3
+        self._bucket = flat
+        self.reduce_flat()
+        self._finish_early()
+        return True
 
     def broadcast_parameters(self, module, src=0):
         if not (dist.is_available() and dist.is_initialized()):

@@ -269,8 +269,46 @@ def _dist_initialized():
     return d.is_available() and d.is_initialized()
 
 
+# A fold of this many slabs or more runs in two levels (pfrl_splitk_group): the weight gradient of
+# the first convolution at rollout size arrives as 1 600 - 4 096 slabs of 33 KB, which n / 1024 = 9
+# workgroups would otherwise walk eight at a time.  Minibatch-sized folds (<= 50 slabs) keep their
+# summation order (the bit-identity tests of the replay agents' update pin it).
+_TWO_LEVEL_FOLD_MIN = int(os.environ.get("PFRL_TWO_LEVEL_FOLD_MIN", "256"))
+
+
+def _pre_fold(tasks):
+    """Tasks that share one slab buffer with very many slabs: one grouped launch sums ~sqrt(S)
+    consecutive slabs each into a small buffer, and the tasks are re-pointed at that."""
+    out = list(tasks)
+    done = {}
+    for i, t in enumerate(out):
+        part, _, _, stride, n, splits = t[:6]
+        if splits < _TWO_LEVEL_FOLD_MIN or stride <= 0 or stride % 4:
+            continue
+        base = part.data_ptr()
+        # (weight and bias slabs of one layer live in the same buffer: fold whole slab rows once)
+        key = next((k for k in done if k[1] == stride and k[2] == splits
+                    and 0 <= base - k[0] < 4 * stride), None)
+        if key is None:
+            width = stride
+            groups = max(8, int(round(splits ** 0.5)))
+            per = _ceil_div(splits, groups)
+            groups = _ceil_div(splits, per)
+            tmp = torch.empty(groups * width, dtype=torch.float32, device=part.device)
+            check(_native.lib().pfrl_splitk_group(_p(part), stride, width, splits, groups, _p(tmp), width,
+                                                  _stream()), "splitk_group")
+            key = (base, stride, splits)
+            done[key] = (tmp, groups, width)
+        tmp, groups, width = done[key]
+        off = (base - key[0]) // 4
+        out[i] = (tmp[off:], t[1], t[2], width, n, groups) + tuple(t[6:])
+    return out
+
+
 def _reduce(tasks):
     """tasks: (part, out, bias or None, stride, n, splits, ncol, relu)"""
+    if any(t[5] >= _TWO_LEVEL_FOLD_MIN for t in tasks):
+        tasks = _pre_fold(tasks)
     n = len(tasks)
     L = _native.lib()
     P = (ctypes.c_void_p * n)(*[t[0].data_ptr() for t in tasks])
@@ -297,6 +335,11 @@ OPT_SOURCES = None
 # launch (pfrl_conv2d_nhwc_bwd_weight_ride) and marked GradSource.done() for the optimizer launch.
 RIDE_ALONG = None
 _RIDE = os.environ.get("PFRL_RIDE_ALONG", "1") != "0"
+
+# dh.data_ptr() -> (dh with the hidden layer's ReLU mask applied and scaled by 1 / world, world):
+# left by the fused head + TD-loss launch of a data-parallel update (ops._DQNHeadTDLoss) for the
+# low-rank exchange below, which then skips its own mask / scale launches.
+MASKED_DH = {}
 
 # Folds queued by other nodes of the same backward pass (the fused head + loss launch of
 # ops.dqn_head_td_loss) for the fold launch that ends the trunk's backward: one launch less.
@@ -518,7 +561,8 @@ class _Trunk(torch.autograd.Function):
                                                     1, Kf, F, 1, 1, 1, P, last.Cout, _stream()),
                       "linear_bwd_data")
                 grads = [None] * (2 * L + 2)
-                if not announce_lowrank(wf, params[2 * L + 1], dh, acts[-1].view(N, Kf), mask=out):
+                if not announce_lowrank(wf, params[2 * L + 1], dh, acts[-1].view(N, Kf), mask=out,
+                                        premasked=MASKED_DH.pop(dh.data_ptr(), None)):
                     # (not taken after all, e.g. a capture without collectives: the local gradient)
                     dwf = torch.empty_like(wf)
                     dbf = torch.empty(F, dtype=torch.float32, device=dev)

@@ -4,6 +4,7 @@ Tensors only supply device pointers and the current HIP stream; every
 computation happens in the hand-written gfx950 kernels of pfrl_amd/csrc.
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -621,13 +622,25 @@ class _DQNHeadTDLoss(torch.autograd.Function):
         stride = A * K + 32
         slabs = (B + 3) // 4          # one partial slab per workgroup of four rows
         part = torch.empty(slabs * stride, dtype=torch.float32, device=dev)
+        # data parallel: the masked, 1 / world-scaled copy of dh the hidden layer's low-rank exchange
+        # all-gathers comes out of this launch too (two elementwise launches less per update)
+        dh_masked, dh_scale = None, 1.0
+        mfma_trunk.MASKED_DH.clear()
+        d = torch.distributed
+        if (d.is_available() and d.is_initialized()
+                and os.environ.get("PFRL_DP_FUSED_MASK", "1") != "0"):
+            world = d.get_world_size()
+            dh_masked = torch.empty((B, K), dtype=torch.float32, device=dev)
+            dh_scale = 1.0 / world
+            mfma_trunk.MASKED_DH[dh.data_ptr()] = (dh_masked, world)
         check(_native.lib().pfrl_dqn_head_td_loss(
             _ptr(hc), _ptr(w.detach()), _ptr(b.detach()), _ptr(action.contiguous()),
             _ptr(target_q.contiguous()),
             _ptr(next_q_online.contiguous()) if next_q_online is not None else None,
             _ptr(reward), _ptr(discount), _ptr(terminal),
             _ptr(weights.contiguous()) if weights is not None else None, B, K, A, int(clip_delta),
-            int(mean), _ptr(y), _ptr(delta), _ptr(dh), _ptr(part), *fold_args, _stream()),
+            int(mean), _ptr(y), _ptr(delta), _ptr(dh), _ptr(part), *fold_args,
+            _ptr(dh_masked) if dh_masked is not None else None, float(dh_scale), _stream()),
             "dqn_head_td_loss")
         tasks = [(part, dw, None, stride, A * K, slabs, 4, 0),
                  (part[A * K:], db, None, stride, A, slabs, 4, 0),

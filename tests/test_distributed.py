@@ -327,7 +327,7 @@ def test_ppo_captured_update_with_the_gradient_all_reduce_inside_equals_one_proc
     try:
         agent, got = run()
         assert agent.grad_reducer.active() and agent.grad_reducer._comm is not None
-        assert agent.grad_reducer._flat is not None, "no gradient went through the all-reduce"
+        assert agent.grad_reducer.current_bucket() is not None, "no gradient went through the all-reduce"
         for a, b in zip(want, got):
             assert torch.equal(a, b)
     finally:

@@ -223,8 +223,8 @@ def test_data_parallel_update_keeps_the_fused_forms(backend, tmp_path, monkeypat
     taken = []
     orig = distributed.GradientAllReducer.lowrank_ready
 
-    def spy(self, *a):
-        r = orig(self, *a)
+    def spy(self, *a, **kw):
+        r = orig(self, *a, **kw)
         taken.append(r)
         return r
 

@@ -1622,6 +1622,60 @@ def test_fused_ppo_loss_matches_the_reference_expression_and_its_autograd(dev, M
     assert torch.allclose(dlogits, logits.grad, **tol), float((dlogits - logits.grad).abs().max())
 
 
+@pytest.mark.parametrize("max_norm", [0.5, 1e6])
+def test_clip_grad_norm_in_three_launches_matches_torch(dev, max_norm):
+    """pfrl_clip_grad_norm against torch.nn.utils.clip_grad_norm_ (reference ppo.py:602-605) on the
+    PPO example network's gradient shapes, a channels_last convolution weight included: the norm
+    to 1e-6, the scaled gradients to 1e-6 (clipping active) / untouched bits (coefficient 1)."""
+    from pfrl_amd.utils.clip_l2_grad_norm import clip_grad_norm_device_
+
+    torch.manual_seed(7)
+    shapes = [(32, 4, 8, 8), (32,), (64, 32, 4, 4), (64,), (64, 64, 3, 3), (64,), (512, 3136), (512,),
+              (6, 512), (6,), (1, 512), (1,)]
+    ps, qs = [], []
+    for sh in shapes:
+        w = torch.randn(*sh, device=dev)
+        if len(sh) == 4:
+            w = w.contiguous(memory_format=torch.channels_last)
+        g = torch.randn_like(w) * 0.01
+        a, b = torch.nn.Parameter(w.clone()), torch.nn.Parameter(w.clone())
+        a.grad, b.grad = g.clone(), g.clone()
+        ps.append(a)
+        qs.append(b)
+    want = torch.nn.utils.clip_grad_norm_(qs, max_norm)
+    got = clip_grad_norm_device_(ps, max_norm)
+    assert torch.allclose(got, want, rtol=1e-6)
+    for a, b in zip(ps, qs):
+        if max_norm > 1e5:
+            assert torch.equal(a.grad, b.grad)
+        else:
+            assert torch.allclose(a.grad, b.grad, rtol=2e-6, atol=0)
+
+
+def test_two_level_fold_of_thousands_of_slabs(dev):
+    """mfma_trunk._reduce with >= 256 slabs (pfrl_splitk_group then pfrl_splitk_reduce) against
+    an f64 sum, for a weight and a bias tensor living in the same slab rows; a 50-slab fold keeps
+    the single-level order bit for bit."""
+    from pfrl_amd.nn import mfma_trunk as mt
+
+    torch.manual_seed(3)
+    nW, nb, S = 8192, 32, 1600
+    stride = nW + nb
+    part = torch.randn(S * stride, device=dev)
+    dw, db = torch.empty(nW, device=dev), torch.empty(nb, device=dev)
+    mt._reduce([(part, dw, None, stride, nW, S, 4, 0), (part[nW:], db, None, stride, nb, S, 4, 0)])
+    ref = part.view(S, stride).double().sum(0)
+    assert torch.allclose(dw.double(), ref[:nW], rtol=1e-5, atol=1e-4)
+    assert torch.allclose(db.double(), ref[nW:], rtol=1e-5, atol=1e-4)
+    small = part[:50 * stride]
+    a, b = torch.empty(nW, device=dev), torch.empty(nW, device=dev)
+    mt._reduce([(small, a, None, stride, nW, 50, 4, 0)])
+    acc = torch.zeros(nW, device=dev)
+    for k in range(50):
+        acc = acc + small.view(50, stride)[k, :nW]
+    assert torch.equal(a, acc)
+
+
 def test_ppo_act_head_matches_torch_categorical(dev):
     """pfrl_ppo_act_head against the torch expressions it replaces on the acting path
     (Linear + Categorical(logits): value, entropy, log pi(a)) and its inverse-CDF sampling: the
