@@ -640,45 +640,49 @@ def step_flops_ppo(N, n_actions=6, value_passes=2.0):
     return N * (fwd + value_passes * fwd + 4 * (3 * fwd - NATURE_CONV1_FLOPS))
 
 
-def mfma_per_launch(B=32, n_actions=6):
-    """Per launch of ONE DQN update: device time from the committed rocprofv3 timeline of this
-    build (profiles/rNN_dqn_update_timeline.txt) and the arithmetic that launch performs (the
-    Nature CNN of pfrl/nn/atari_cnn.py:17-47 at minibatch B: forward per layer; a backward launch
-    = input gradient + weight gradient of its layer = 2 x forward, conv1 has no input gradient;
-    the hidden layer's RMSprop step rides in the last backward launch), as a fraction of the
-    f32 MFMA peak.  The launches of the chain are matched by position: the update is ten
-    dependent launches in network order."""
-    import re
-
+def mfma_per_launch(agent, rbuf, B=32, n_actions=6):
+    """Per launch of ONE DQN update, MEASURED in this run: the launches a captured update replays
+    (``GraphedUpdate.measure_launches``: the same Python run eagerly on a fresh minibatch, every
+    library entry point bracketed by a pair of timing events, median of 5) and the arithmetic each
+    performs (the Nature CNN of pfrl/nn/atari_cnn.py:17-47 at minibatch B: forward per layer; a
+    backward launch = input gradient + weight gradient of its layer = 2 x forward, conv1 has no
+    input gradient; the hidden layer's RMSprop step rides in the last backward launch), as a
+    fraction of the f32 MFMA peak.  Eager durations carry ~1 us of event bracketing each and no
+    graph-internal boundary: their sum is not ``update_us`` (that is the range graph's own clock)."""
     conv1 = 2 * 20 * 20 * 32 * 8 * 8 * 4
     conv2 = 2 * 9 * 9 * 64 * 4 * 4 * 32
     conv3 = 2 * 7 * 7 * 64 * 3 * 3 * 64
     hidden = 2 * 3136 * 512
     head = 2 * 512 * n_actions
-    flops = [conv1, conv2, conv3, hidden,           # forward
-             3 * head,                              # head forward + TD loss + head backward
-             2 * hidden, 2 * conv3, 2 * conv2,      # backward: input + weight gradients
-             conv1,                                 # conv1: weight gradient only
-             0]                                     # optimizer step (no MFMA work)
-    what = ["conv1 fwd", "conv2 fwd", "conv3 fwd", "hidden fwd", "head + TD loss + head bwd",
-            "hidden bwd", "conv3 bwd", "conv2 bwd", "conv1 wgrad (+ the hidden layer's RMSprop step riding)",
-            "RMSprop (slab folds + step)"]
-    prof_dir = os.path.join(ROOT, "profiles")
-    for name in sorted(os.listdir(prof_dir), reverse=True):
-        if not name.endswith("_dqn_update_timeline.txt"):
-            continue
-        rows = re.findall(r"dur\s+([0-9.]+)\s+grid\s+\d+\s+(\S+)", open(os.path.join(prof_dir, name)).read())
-        if len(rows) != len(flops):
-            return {"source": "profiles/" + name,
-                    "note": "%d launches in the timeline, %d expected: not matched" % (len(rows), len(flops))}
-        out = []
-        for (us, kern), f, w in zip(rows, flops, what):
-            us = float(us)
-            gf = f * B / 1e9
-            out.append({"kernel": kern.split("<")[0], "what": w, "us": us, "gflop": round(gf, 4),
-                        "frac": round(gf / 1e3 / (us * 1e-6) / MFMA_F32_PEAK_TFLOPS, 4) if us > 0 else None})
-        return {"source": "profiles/" + name, "launches": out}
-    return None
+    fwd = iter([(conv1, "conv1 fwd"), (conv2, "conv2 fwd"), (conv3, "conv3 fwd"), (hidden, "hidden fwd")])
+    bwd = iter([(2 * hidden, "hidden bwd (input + weight gradient)"), (2 * conv3, "conv3 bwd"),
+                (2 * conv2, "conv2 bwd")])
+    seqs = [rbuf.lookahead_sample(B)]
+    big = rbuf.fetch_many(seqs, agent.phi, agent.gamma)
+    ns = big["next_state"]
+    raw = agent._precompute_target_raw(ns.view((B,) + tuple(ns.shape[2:])))
+    big["target_next_raw"] = raw.view((1, B) + tuple(raw.shape[1:]))
+    calls = agent._graphed.measure_launches({k: v[0] for k, v in big.items()})
+    out = []
+    for name, us in calls:
+        if name == "pfrl_conv2d_nhwc_fwd":
+            f, w = next(fwd, (0, "forward"))
+        elif name == "pfrl_dqn_head_td_loss":
+            f, w = 3 * head, "hidden-layer fold + head + TD loss + head bwd"
+        elif name == "pfrl_conv2d_nhwc_bwd":
+            f, w = next(bwd, (0, "backward"))
+        elif name == "pfrl_conv2d_nhwc_bwd_weight_ride":
+            f, w = conv1, "conv1 wgrad (+ the hidden layer's RMSprop step riding)"
+        elif name == "pfrl_rmsprop_fused_step":
+            f, w = 0, "RMSprop (slab folds + step of the convolutions and the head)"
+        else:
+            f, w = 0, "-"
+        gf = f * B / 1e9
+        out.append({"entry": name, "what": w, "us": round(us, 2), "gflop": round(gf, 4),
+                    "frac": round(gf / 1e3 / (us * 1e-6) / MFMA_F32_PEAK_TFLOPS, 4) if us > 0 and f else None})
+    return {"source": "measured in this run (hipEvent pair around each launch of one eager update)",
+            "launches": out, "n_launches": len(out),
+            "sum_us": round(sum(o["us"] for o in out), 1)}
 
 
 def launches_per_update():
@@ -1159,11 +1163,15 @@ def run_workload(args, device, rank, world, result_extras=True):
             roofline["mfma"]["update_us_what"] = (
                 "device time of ONE optimizer update (forward, TD loss, backward, optimizer step) "
                 "inside the captured %d-update range graph, hipEvents around the replay" % big_u)
-            roofline["mfma"]["launches_per_update"] = launches_per_update()
             try:
-                roofline["mfma"]["per_launch"] = mfma_per_launch(args.minibatch)
-            except Exception as e:      # (a profile file in another format must not cost the line)
+                if args.algo != "dqn" or torch.distributed.is_initialized():
+                    raise RuntimeError("measured for the single-process DQN update only")
+                pl = mfma_per_launch(agent, rbuf, args.minibatch)
+                roofline["mfma"]["per_launch"] = pl
+                roofline["mfma"]["launches_per_update"] = {"value": pl["n_launches"], "source": pl["source"]}
+            except Exception as e:      # (the measurement must not cost the line)
                 roofline["mfma"]["per_launch"] = {"note": "not available: %s" % e}
+                roofline["mfma"]["launches_per_update"] = launches_per_update()
     out["config"]["ranks_seen"] = world
     if step_ms:
         srt = sorted(step_ms)

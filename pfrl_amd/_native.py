@@ -277,3 +277,51 @@ def check(rc, what=""):
     if rc != 0:
         msg = lib().pfrl_amd_last_error().decode()
         raise RuntimeError("pfrl_amd %s failed (code %d): %s" % (what, rc, msg))
+
+
+class timed_calls:
+    """``with timed_calls() as rec:`` -- every entry point of the library that launches on a stream
+    (last argument of its signature: the stream) is bracketed by a pair of timing events on the
+    current torch stream while the block runs; ``rec.results()`` -> [(entry point, microseconds)]
+    in call order.  A measurement hook (bench.py's per-launch table of one update run eagerly):
+    the launches are the ones a captured graph replays, their durations include ~1 us of event
+    bracketing each.  Not re-entrant; restores the plain entry points on exit."""
+
+    def __init__(self):
+        self.calls = []
+        self._saved = {}
+
+    def __enter__(self):
+        import torch
+
+        L = lib()
+        for name, (_, args) in EXPORTS.items():
+            if not (isinstance(args, str) and args.endswith("p")) or name.startswith("pfrl_plan_"):
+                continue
+            orig = getattr(L, name)
+            self._saved[name] = orig
+
+            def wrapped(*a, _orig=orig, _name=name):
+                e0 = torch.cuda.Event(enable_timing=True)
+                e1 = torch.cuda.Event(enable_timing=True)
+                e0.record()
+                rc = _orig(*a)
+                e1.record()
+                self.calls.append((_name, e0, e1))
+                return rc
+
+            setattr(L, name, wrapped)
+        return self
+
+    def __exit__(self, *exc):
+        L = lib()
+        for name, orig in self._saved.items():
+            setattr(L, name, orig)
+        self._saved = {}
+        return False
+
+    def results(self):
+        import torch
+
+        torch.cuda.synchronize()
+        return [(n, e0.elapsed_time(e1) * 1e3) for n, e0, e1 in self.calls]

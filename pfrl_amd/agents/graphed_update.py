@@ -558,6 +558,33 @@ class GraphedUpdate:
         between them on the host: no eager collective, no hand-over to a replay stream."""
         return not self.pipeline and (not self.split_for_allreduce or self._collective_capturable())
 
+    def measure_launches(self, exp_batch, repeats=5):
+        """The launches of ONE update -- exactly the Python a capture records (``_forward_backward``
+        + ``_reduce_and_step``) run eagerly on ``exp_batch`` -- each bracketed by timing events
+        (``_native.timed_calls``): [(entry point, median microseconds over ``repeats``)] in launch
+        order.  Parameters, optimizer state and generator are restored afterwards."""
+        from pfrl_amd import _native
+
+        ag = self.agent
+        snap = self._snapshot()
+        runs = []
+        try:
+            for _ in range(repeats + 1):
+                with _native.timed_calls() as rec:
+                    ag.optimizer.zero_grad(set_to_none=True)
+                    self._forward_backward(exp_batch, False)
+                    self._reduce_and_step()
+                runs.append(rec.results())
+        finally:
+            ag.optimizer.zero_grad(set_to_none=True)
+            self._restore(snap)
+        runs = [r for r in runs[1:] if [n for n, _ in r] == [n for n, _ in runs[-1]]]
+        out = []
+        for i, (name, _) in enumerate(runs[-1]):
+            us = sorted(r[i][1] for r in runs)
+            out.append((name, us[len(us) // 2]))
+        return out
+
     def run_range(self, big):
         """``big``: dict of tensors with a leading update axis U (the step-fused gather's
         buffers).  Replays ONE graph holding the U updates back to back (each: forward,
