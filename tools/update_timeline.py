@@ -15,11 +15,13 @@ ap = argparse.ArgumentParser()
 ap.add_argument("csv")
 ap.add_argument("--marker", default="FusedAdam")
 ap.add_argument("--every", type=int, default=3, help="marker launches per update")
+ap.add_argument("--skip", type=int, default=0, help="updates to skip at the end of the trace (e.g. bench.py's "
+                "eager, event-bracketed updates of mfma.per_launch: 6)")
 a = ap.parse_args()
 rows = [r for r in csv.DictReader(open(a.csv))]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 idx = [i for i, r in enumerate(rows) if a.marker in r["Kernel_Name"]]
-if len(idx) <= 2 * a.every:
+if len(idx) <= (2 + a.skip) * a.every:
     # (too few marker launches for this --every: say what the trace holds instead of a traceback)
     import collections
 
@@ -28,8 +30,8 @@ if len(idx) <= 2 * a.every:
     for n, c in names.most_common(25):
         print("%8d  %s" % (c, n))
     raise SystemExit(0)
-i1 = idx[-1 - a.every]
-i0 = idx[-1 - 2 * a.every]
+i1 = idx[-1 - a.every * (1 + a.skip)]
+i0 = idx[-1 - a.every * (2 + a.skip)]
 t0 = int(rows[i0]["End_Timestamp"])
 prev = t0
 busy = 0
