@@ -37,7 +37,9 @@ if ROOT not in sys.path:
 from benchkit.baselines import (cpu_baseline, data_path_only, reference_baseline,  # noqa: E402,F401
                                 reference_baseline_other, reference_baseline_ppo)
 from benchkit.roofline import (HBM_PEAK_GBS, MFMA_F32_PEAK_TFLOPS, NATURE_CONV1_FLOPS,  # noqa: E402,F401
-                               NATURE_FWD_FLOPS, algorithmic_bytes_per_step, compute_roofline,
+                               NATURE_FWD_FLOPS, PROFILE_ADV_STATS, PROFILE_BATCH_EXPERIENCES,
+                               PROFILE_BATCH_STATES_U8, PROFILE_BATCH_STATES_U8_RAW, PROFILE_GAE_SCAN,
+                               algorithmic_bytes_per_step, compute_roofline,
                                gather_sources_sha16, launches_per_update, mfma_per_launch,
                                step_flops_dqn, step_flops_ppo)
 from benchkit.supervisor import (_WATCHDOG, DP_PLANS, _StallWatchdog, _tick,  # noqa: E402,F401

@@ -81,6 +81,8 @@ def compute_roofline(algo, all_us, all_units, all_kinds):
         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
         "bytes_per_launch": int(bytes_main),
+        # (the pricing convention, explicit -- ADVICE r5: what one unit is charged, in bytes)
+        "priced_bytes_per_unit": int(per_unit), "unit_name": unit_name,
         "%s_per_launch" % unit_name: int(main_units),
         "avg_launch_us": round(us_main / n_main, 2), "launches_timed": n_main,
         "share_of_kernel_bytes": round(bytes_main * n_main / tot_bytes, 4),

@@ -580,7 +580,7 @@ int pfrl_conv2d_u8nhwc4_bwd_weight(const float *dy, const float *dy_mask, const 
  * latency-bound workgroups; by then the gradients of the layers above are final (ride_grad[i],
  * finished tensors) and their parameters are not read again in this update, so their
  * elementwise steps (the arithmetic of pfrl_rmsprop_step) run as extra workgroups of this launch.
- * 1 <= n_ride <= 4 HOST arrays of device pointers; 16-byte aligned, numel % 4 == 0;
+ * 1 <= n_ride <= 8 HOST arrays of device pointers (plus whatever pfrl_ride_set left pending); 16-byte aligned, numel % 4 == 0;
  * ride_grad_avg may be NULL when centered == 0.  The caller must not step these tensors again. */
 int pfrl_conv2d_nhwc_bwd_weight_ride(
     const float *dy, const float *dy_mask, const float *x, float *dw_part, float *db_part,
@@ -589,6 +589,20 @@ int pfrl_conv2d_nhwc_bwd_weight_ride(
     const float *const *ride_grad, float *const *ride_square_avg, float *const *ride_grad_avg,
     const int64_t *ride_numel, float lr, float alpha, float eps, float weight_decay, int centered,
     void *stream);
+/* Optimizer steps (the arithmetic of pfrl_rmsprop_step) handed to the NEXT backward launch of this
+ * host thread -- pfrl_conv2d_nhwc_bwd or pfrl_conv2d_nhwc_bwd_weight_ride -- which runs them as extra
+ * workgroups and clears the set (pfrl/agents/dqn.py:360-365 `loss.backward(); optimizer.step()` at
+ * minibatch size: by the time a layer's backward launch starts, the gradient of the layer above
+ * is complete and its parameters are not read again in the update).  Up to 8 tensors; the
+ * gradient of tensor i is grad_src[i] itself (n_slabs[i] == 0) or the sum, in slab order, of
+ * n_slabs[i] split-K slabs slab_stride[i] floats apart (what pfrl_conv2d_nhwc_bwd_weight /
+ * pfrl_dqn_head_td_loss leave).  n == 0 clears the set.  A pfrl_conv2d_nhwc_bwd whose tile
+ * program has no riding form returns an error WITHOUT launching (and clears the set): the caller
+ * launches again and steps those tensors elsewhere. */
+int pfrl_ride_set(int32_t n, float *const *param, const float *const *grad_src,
+                  float *const *square_avg, float *const *grad_avg, const int64_t *numel,
+                  const int32_t *n_slabs, const int64_t *slab_stride, float lr, float alpha, float eps,
+                  float weight_decay, int centered);
 /* Both gradients of one layer in ONE launch (same dy): arguments of _bwd_data and _bwd_weight
  * combined.  Minibatch-sized problems only; returns PFRL_ERR_ARG for larger ones (the caller
  * then issues the two launches). */

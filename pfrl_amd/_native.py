@@ -202,6 +202,7 @@ EXPORTS = {
     "pfrl_conv2d_nhwc_bwd_weight": (ctypes.c_int, "pppppqqiiiiiiiiip"),
     "pfrl_conv2d_nhwc_bwd_weight_ride": (ctypes.c_int, "pppppqqiiiiiiiiiipppppffffip"),
     "pfrl_conv2d_nhwc_bwd": (ctypes.c_int, "ppppppppqqiiiiiiiiiiip"),
+    "pfrl_ride_set": (ctypes.c_int, "ippppppp" + "ffffi"),
     "pfrl_splitk_reduce": (ctypes.c_int, "ippppppppp"),
     "pfrl_splitk_reduce_noisy": (ctypes.c_int, "ippppppppppp"),
     "pfrl_splitk_group": (ctypes.c_int, "pqiiipqp"),

@@ -657,11 +657,16 @@ class GraphedUpdate:
             ag.optimizer.zero_grad(set_to_none=True)
             g = torch.cuda.CUDAGraph()
             distributed._CAPTURE_COLLECTIVES[0] = self.split_for_allreduce
+            cap_feed = NoiseFeed(noise["views"]) if noise else None
             try:
-                with _capturing(g, self.pool), noise_feed(NoiseFeed(noise["views"]) if noise else None):
+                with _capturing(g, self.pool), noise_feed(cap_feed):
                     losses, ys = body()
             finally:
                 distributed._CAPTURE_COLLECTIVES[0] = False
+            # (the captured range must have consumed exactly the draws recorded x U)
+            assert cap_feed is None or cap_feed.at == len(noise["views"]), \
+                "the captured updates drew %d normals' tensors, %d were recorded" % (
+                    cap_feed.at, len(noise["views"]))
             if self.pool is None:
                 self.pool = g.pool()
         finally:

@@ -17,7 +17,10 @@ int64_t pfrl_nt_min_bytes();
 // returns a start/stop event pair to attach to ONE dispatch with
 // hipExtLaunchKernelGGL; both are nullptr otherwise.
 enum { PFRL_PROFILE_BATCH_EXPERIENCES = 0, PFRL_PROFILE_BATCH_STATES_U8 = 1, PFRL_PROFILE_GAE_SCAN = 2,
-       PFRL_PROFILE_ADV_STATS = 3 };
+       PFRL_PROFILE_ADV_STATS = 3,
+       // pfrl_batch_states_u8_raw_nhwc4: 2 bytes moved per frame byte (BATCH_STATES_U8 prices the
+       // fp32 form's 5); mirrored in pfrl_amd/ops.py and benchkit/roofline.py
+       PFRL_PROFILE_BATCH_STATES_U8_RAW = 4 };
 void pfrl_profile_events(int kind, int64_t units, hipEvent_t *start, hipEvent_t *stop);
 
 #define PFRL_CHECK_ARG(cond, msg)      \

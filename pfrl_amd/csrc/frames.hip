@@ -311,11 +311,9 @@ extern "C" int pfrl_batch_states_u8_raw_nhwc4(const void *frames, int64_t frame_
     const int ndw = (int)(frame_bytes >> 2);
     const int tiles = (ndw + kThreads - 1) / kThreads;
     // (a profile kind of its own: BATCH_STATES_U8 prices 5 bytes per frame byte, the fp32 form;
-    // this launch moves 2.  The number lives here and in pfrl_amd/ops.py, include/pfrl_amd.h:
-    // common.h is part of the hash that ties the committed PMC passes to the gather sources.)
-    constexpr int kProfileBatchStatesU8Raw = 4;
+    // this launch moves 2)
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    pfrl_profile_events(kProfileBatchStatesU8Raw, n_obs * 4, &e0, &e1);
+    pfrl_profile_events(PFRL_PROFILE_BATCH_STATES_U8_RAW, n_obs * 4, &e0, &e1);
     hipExtLaunchKernelGGL(k_batch_states_u8_raw_nhwc4, dim3((unsigned)(n_obs * tiles)), dim3(kThreads),
                           0, (hipStream_t)stream, e0, e1, 0, (const uint8_t *)frames, frame_bytes, refs,
                           (uint4 *)out, tiles, ndw);

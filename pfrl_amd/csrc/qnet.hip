@@ -1186,12 +1186,18 @@ __global__ __launch_bounds__(256) void k_conv_wgrad2(WgradArgs p0, WgradArgs p1,
 // gradient is never written or read.  The layer's own launch, left with the input gradient, got
 // 1.6 us shorter; this one 3 us longer: 32 x 32 tiles touch parameter and state in 128-byte pieces
 // 12.5 KB apart, against 1 KB contiguous per wave for the chunks below.)
-constexpr int RIDE_MAX = 4;
+constexpr int RIDE_MAX = 8;
 constexpr int RIDE_CHUNK = 1024;
+// A riding tensor's gradient is either a finished dense tensor (n_slabs == 0) or -- round 6 -- the
+// split-K slabs a backward launch left (n_slabs >= 1, slab s at g + s * slab_stride): summed here
+// in the order of k_rmsprop_fused / k_splitk_reduce (0 + slab 0 + slab 1 + ..., eight in flight),
+// so that a step that rides is the step the optimizer launch would have made, bit for bit.
 struct RideArgs {
     float *p[RIDE_MAX], *sq[RIDE_MAX], *ga[RIDE_MAX];
     const float *g[RIDE_MAX];
     long long numel[RIDE_MAX];
+    long long slab_stride[RIDE_MAX];
+    int n_slabs[RIDE_MAX];
     int block_end[RIDE_MAX];
     int n;
     float lr, alpha, eps, weight_decay;
@@ -1206,19 +1212,68 @@ __device__ __forceinline__ void ride_block(const RideArgs &r, const int b, const
     int t = 0;
     while (t < r.n - 1 && b >= r.block_end[t]) ++t;
     const long long i0 = (long long)(b - (t == 0 ? 0 : r.block_end[t - 1])) * RIDE_CHUNK + 4 * tid;
-    if (i0 >= r.numel[t]) return;       // (numel % 4 == 0: whole float4)
+    const long long n = r.numel[t];
+    if (i0 >= n) return;
     const float oma = __fsub_rn(1.0f, r.alpha);
-    const float4 gv = *reinterpret_cast<const float4 *>(r.g[t] + i0);
-    float4 pv = *reinterpret_cast<float4 *>(r.p[t] + i0);
-    float4 sv = *reinterpret_cast<float4 *>(r.sq[t] + i0);
-    float4 mv = CENTERED ? *reinterpret_cast<float4 *>(r.ga[t] + i0) : make_float4(0.f, 0.f, 0.f, 0.f);
-    rms_update<CENTERED>(pv.x, gv.x, sv.x, mv.x, r.lr, r.alpha, oma, r.eps, r.weight_decay);
-    rms_update<CENTERED>(pv.y, gv.y, sv.y, mv.y, r.lr, r.alpha, oma, r.eps, r.weight_decay);
-    rms_update<CENTERED>(pv.z, gv.z, sv.z, mv.z, r.lr, r.alpha, oma, r.eps, r.weight_decay);
-    rms_update<CENTERED>(pv.w, gv.w, sv.w, mv.w, r.lr, r.alpha, oma, r.eps, r.weight_decay);
-    *reinterpret_cast<float4 *>(r.p[t] + i0) = pv;
-    *reinterpret_cast<float4 *>(r.sq[t] + i0) = sv;
-    if (CENTERED) *reinterpret_cast<float4 *>(r.ga[t] + i0) = mv;
+    const int S = r.n_slabs[t];
+    const float *__restrict__ src = r.g[t] + i0;
+    if (i0 + 4 <= n) {
+        float4 gv;
+        if (S == 0) {
+            gv = *reinterpret_cast<const float4 *>(src);
+        } else {
+            const long long st = r.slab_stride[t];
+            gv = make_float4(0.f, 0.f, 0.f, 0.f);
+            int k = 0;
+            for (; k + 8 <= S; k += 8) {
+                float4 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4 *>(src + (long long)(k + u) * st);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    gv.x = __fadd_rn(gv.x, v[u].x); gv.y = __fadd_rn(gv.y, v[u].y);
+                    gv.z = __fadd_rn(gv.z, v[u].z); gv.w = __fadd_rn(gv.w, v[u].w);
+                }
+            }
+            if (k < S) {
+                float4 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    v[u] = *reinterpret_cast<const float4 *>(src + (long long)min(k + u, S - 1) * st);
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (k + u < S) {
+                        gv.x = __fadd_rn(gv.x, v[u].x); gv.y = __fadd_rn(gv.y, v[u].y);
+                        gv.z = __fadd_rn(gv.z, v[u].z); gv.w = __fadd_rn(gv.w, v[u].w);
+                    }
+            }
+        }
+        float4 pv = *reinterpret_cast<float4 *>(r.p[t] + i0);
+        float4 sv = *reinterpret_cast<float4 *>(r.sq[t] + i0);
+        float4 mv = CENTERED ? *reinterpret_cast<float4 *>(r.ga[t] + i0) : make_float4(0.f, 0.f, 0.f, 0.f);
+        rms_update<CENTERED>(pv.x, gv.x, sv.x, mv.x, r.lr, r.alpha, oma, r.eps, r.weight_decay);
+        rms_update<CENTERED>(pv.y, gv.y, sv.y, mv.y, r.lr, r.alpha, oma, r.eps, r.weight_decay);
+        rms_update<CENTERED>(pv.z, gv.z, sv.z, mv.z, r.lr, r.alpha, oma, r.eps, r.weight_decay);
+        rms_update<CENTERED>(pv.w, gv.w, sv.w, mv.w, r.lr, r.alpha, oma, r.eps, r.weight_decay);
+        *reinterpret_cast<float4 *>(r.p[t] + i0) = pv;
+        *reinterpret_cast<float4 *>(r.sq[t] + i0) = sv;
+        if (CENTERED) *reinterpret_cast<float4 *>(r.ga[t] + i0) = mv;
+        return;
+    }
+    // (tail of a tensor whose element count is not a multiple of four: a head's bias)
+    for (long long i = i0; i < n; ++i) {
+        float g = 0.f;
+        if (S == 0) {
+            g = r.g[t][i];
+        } else {
+            for (int k = 0; k < S; ++k) g = __fadd_rn(g, r.g[t][(long long)k * r.slab_stride[t] + i]);
+        }
+        float pi = r.p[t][i], si = r.sq[t][i], mi = CENTERED ? r.ga[t][i] : 0.f;
+        rms_update<CENTERED>(pi, g, si, mi, r.lr, r.alpha, oma, r.eps, r.weight_decay);
+        r.p[t][i] = pi;
+        r.sq[t][i] = si;
+        if (CENTERED) r.ga[t][i] = mi;
+    }
 }
 
 template <int BI, int BJ, int WM, int WN, int WK, int G, bool CENTERED>
@@ -1284,6 +1339,31 @@ __global__ __launch_bounds__(256) void k_conv_bwd(int nd, DgradArgs d, WgradArgs
     __syncthreads();
 #endif
     QSTAMP(5);
+}
+
+// k_conv_bwd with the optimizer steps of FINISHED tensors riding as a third kind of workgroup
+// (round 6): blocks [nd + nw, grid) run ride_block.  By the time a layer's backward launch starts,
+// the slabs of the layer ABOVE are complete and its parameters have been read for the last time in
+// this update (by that layer's own input-gradient workgroups, one launch earlier), so its RMSprop
+// step -- slab sums included -- needs no launch of its own.
+template <int DM, int DN, int DWM, int DWN, int DWK, int DG_, int WI, int WWM, int WWN, int WWK, bool CENTERED>
+__global__ __launch_bounds__(256) void k_conv_bwd_ride(int nd, int nw, DgradArgs d, WgradArgs w, BwdGrid bg,
+                                                       RideArgs r) {
+    __shared__ __attribute__((aligned(16))) float
+        smem[cmax(dgrad_smem(DM, DN, DWM, DWN, DWK, DG_), wgrad_smem(WI, 32, WWM, WWN, WWK, 4))];
+    const int b = blockIdx.x;
+    if (b < nd) {
+        const int q = fdiv(b, bg.q_dgx), bx = b - q * bg.dgx;
+        const int bz = fdiv(q, bg.q_dgy);
+        dgrad_body<DM, DN, DWM, DWN, DWK, DG_>(d, bx, q - bz * bg.dgy, bz, smem);
+    } else if (b < nd + nw) {
+        const int c = b - nd;
+        const int q = fdiv(c, bg.q_wgx), bx = c - q * bg.wgx;
+        const int bz = fdiv(q, bg.q_wgy);
+        wgrad_body<WI, 32, WWM, WWN, WWK, 4>(w, bx, q - bz * bg.wgy, bz, smem);
+    } else {
+        ride_block<CENTERED>(r, b - nd - nw, threadIdx.x);
+    }
 }
 
 template <int DM, int DN, int DWM, int DWN, int DWK, int DG_, int WI, int WWM, int WWN, int WWK>
@@ -2142,6 +2222,51 @@ extern "C" int pfrl_conv2d_u8nhwc4_bwd_weight(const float *dy, const float *dy_m
     PFRL_LAUNCH_CHECK();
 }
 
+// Optimizer steps waiting for the NEXT backward launch of this host thread to carry them
+// (pfrl_ride_set): consumed -- and cleared -- by pfrl_conv2d_nhwc_bwd / pfrl_conv2d_nhwc_bwd_weight_ride.
+struct PendingRide {
+    RideArgs r;
+    int n = 0, blocks = 0, centered = 0;
+};
+static thread_local PendingRide g_ride;
+
+extern "C" int pfrl_ride_set(int32_t n, float *const *param, const float *const *grad_src,
+                             float *const *square_avg, float *const *grad_avg, const int64_t *numel,
+                             const int32_t *n_slabs, const int64_t *slab_stride, float lr, float alpha,
+                             float eps, float weight_decay, int centered) {
+    g_ride.n = 0;
+    g_ride.blocks = 0;
+    if (n == 0) return 0;
+    PFRL_CHECK_ARG(n >= 1 && n <= RIDE_MAX && param && grad_src && square_avg && numel && n_slabs &&
+                       slab_stride && (!centered || grad_avg),
+                   "pfrl_ride_set: 1..8 riding tensors");
+    RideArgs &r = g_ride.r;
+    int blocks = 0;
+    for (int i = 0; i < RIDE_MAX; ++i) {
+        const int j = i < n ? i : 0;
+        r.p[i] = param[j]; r.g[i] = grad_src[j]; r.sq[i] = square_avg[j];
+        r.ga[i] = centered ? grad_avg[j] : nullptr;
+        r.numel[i] = i < n ? numel[j] : 0;
+        r.n_slabs[i] = n_slabs[j];
+        r.slab_stride[i] = slab_stride[j];
+        if (i < n) {
+            const uintptr_t bits = (uintptr_t)r.p[i] | (uintptr_t)r.g[i] | (uintptr_t)r.sq[i] |
+                                   (uintptr_t)r.ga[i] | (uintptr_t)(r.slab_stride[i] * 4);
+            PFRL_CHECK_ARG(r.p[i] && r.g[i] && r.sq[i] && (bits & 15) == 0 && r.numel[i] > 0 &&
+                               r.numel[i] < (1ll << 40) && r.n_slabs[i] >= 0,
+                           "pfrl_ride_set: riding tensors and slab strides must be 16-byte aligned");
+            blocks += (int)((r.numel[i] + RIDE_CHUNK - 1) / RIDE_CHUNK);
+        }
+        r.block_end[i] = blocks;
+    }
+    r.n = n;
+    r.lr = lr; r.alpha = alpha; r.eps = eps; r.weight_decay = weight_decay;
+    g_ride.n = n;
+    g_ride.blocks = blocks;
+    g_ride.centered = centered;
+    return 0;
+}
+
 // pfrl_conv2d_nhwc_bwd_weight with RMSprop steps of OTHER parameters riding in the launch
 // (k_conv_wgrad_ride): n_ride <= 4 tensors, each with its finished gradient tensor grad[i];
 // 16-byte aligned, numel % 4 == 0.  The caller guarantees that nothing later in the stream order
@@ -2159,14 +2284,32 @@ extern "C" int pfrl_conv2d_nhwc_bwd_weight_ride(
         return rc;
     PFRL_CHECK_ARG(n_ride >= 1 && n_ride <= RIDE_MAX && ride_param && ride_grad && ride_square_avg &&
                        ride_numel && (!centered || ride_grad_avg),
-                   "pfrl_conv2d_nhwc_bwd_weight_ride: 1..4 riding tensors");
+                   "pfrl_conv2d_nhwc_bwd_weight_ride: 1..8 riding tensors");
+    // (more steps may be waiting from pfrl_ride_set: they join this launch's own)
+    const PendingRide pend = g_ride;
+    g_ride.n = 0;
+    g_ride.blocks = 0;
+    PFRL_CHECK_ARG(n_ride + pend.n <= RIDE_MAX && (pend.n == 0 || pend.centered == centered),
+                   "pfrl_conv2d_nhwc_bwd_weight_ride: too many riding tensors with the pending set");
     RideArgs r;
     int blocks = 0;
+    const int n_all = n_ride + pend.n;
     for (int i = 0; i < RIDE_MAX; ++i) {
+        if (i >= n_ride && i < n_all) {
+            const int q = i - n_ride;
+            r.p[i] = pend.r.p[q]; r.g[i] = pend.r.g[q]; r.sq[i] = pend.r.sq[q]; r.ga[i] = pend.r.ga[q];
+            r.numel[i] = pend.r.numel[q]; r.n_slabs[i] = pend.r.n_slabs[q];
+            r.slab_stride[i] = pend.r.slab_stride[q];
+            blocks += (int)((r.numel[i] + RIDE_CHUNK - 1) / RIDE_CHUNK);
+            r.block_end[i] = blocks;
+            continue;
+        }
         const int j = i < n_ride ? i : 0;
         r.p[i] = ride_param[j]; r.g[i] = ride_grad[j]; r.sq[i] = ride_square_avg[j];
         r.ga[i] = centered ? ride_grad_avg[j] : nullptr;
         r.numel[i] = i < n_ride ? ride_numel[j] : 0;
+        r.n_slabs[i] = 0;
+        r.slab_stride[i] = 0;
         if (i < n_ride) {
             const uintptr_t bits = (uintptr_t)r.p[i] | (uintptr_t)r.g[i] | (uintptr_t)r.sq[i] |
                                    (uintptr_t)r.ga[i];
@@ -2178,7 +2321,7 @@ extern "C" int pfrl_conv2d_nhwc_bwd_weight_ride(
         }
         r.block_end[i] = blocks;
     }
-    r.n = n_ride;
+    r.n = n_all;
     r.lr = lr; r.alpha = alpha; r.eps = eps; r.weight_decay = weight_decay;
     const bool w32 = Cout % 32 == 0;
     WgradGrid wg;
@@ -2254,11 +2397,37 @@ extern "C" int pfrl_conv2d_nhwc_bwd(const float *dy, const float *dy_mask, const
         return rc;
     const int z = stride * stride;
     const int prog = dgrad_program(d, z);
+    const PendingRide pend = g_ride;      // (consumed here, whatever happens below)
+    g_ride.n = 0;
+    g_ride.blocks = 0;
     PFRL_CHECK_ARG(prog >= 2 && prog <= 5, "pfrl_conv2d_nhwc_bwd: problem too large for the fused launch");
     hipStream_t st = (hipStream_t)stream;
     const bool w32 = Cout % 32 == 0;
     const int wgx = w32 ? Cout / 32 : Cout / 16, wgy = wa.K / 32;
     const int nw = wgx * wgy * splits;
+    if (pend.n > 0) {
+        // optimizer steps of finished tensors ride in this launch (pfrl_ride_set)
+        PFRL_CHECK_ARG(w32 && prog >= 2 && prog <= 4,
+                       "pfrl_conv2d_nhwc_bwd: no riding form of this tile program (nothing was launched)");
+#define BWDR(DM, DN, DWM, DWN, DWK, DGG)                                                             \
+    do {                                                                                             \
+        const int dgx = (d.Mc + DM - 1) / DM, dgy = C / DN;                                          \
+        const int nd = dgx * dgy * z;                                                                \
+        const unsigned grid = (unsigned)(nd + nw + pend.blocks);                                     \
+        if (pend.centered)                                                                           \
+            hipLaunchKernelGGL((k_conv_bwd_ride<DM, DN, DWM, DWN, DWK, DGG, 32, 2, 2, 1, true>),     \
+                               dim3(grid), dim3(256), 0, st, nd, nw, d, wa,                          \
+                               make_bwd_grid(dgx, dgy, z, wgx, wgy), pend.r);                        \
+        else                                                                                         \
+            hipLaunchKernelGGL((k_conv_bwd_ride<DM, DN, DWM, DWN, DWK, DGG, 32, 2, 2, 1, false>),    \
+                               dim3(grid), dim3(256), 0, st, nd, nw, d, wa,                          \
+                               make_bwd_grid(dgx, dgy, z, wgx, wgy), pend.r);                        \
+    } while (0)
+        if (prog == 2) BWDR(32, 32, 2, 2, 1, 4);
+        else BWDR(16, 32, 1, 2, 2, 4);
+#undef BWDR
+        PFRL_LAUNCH_CHECK();
+    }
 #define BWD(DM, DN, DWM, DWN, DWK, DGG)                                                              \
     do {                                                                                             \
         const int dgx = (d.Mc + DM - 1) / DM, dgy = C / DN;                                          \

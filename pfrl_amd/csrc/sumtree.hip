@@ -83,7 +83,8 @@ __device__ void repair_paths(const pfrl_tree_t &T, bool active, int64_t x) {
 // index (three tables in rotation: insert, barrier, look up; the table of two levels ago is
 // cleared meanwhile).  Same typed reductions on the same operands as repair_paths: the nodes come
 // out bit-identical; threads whose paths merge compute (and store) identical parents.
-// Launches of up to 256 leaves on frames of up to 2^24 leaves; anything else takes repair_paths.
+// Launches of up to kFastThreads = 128 leaves on frames of up to 2^kFastLevels = 2^22 leaves;
+// anything else takes repair_paths.
 // ---------------------------------------------------------------------------------------------
 constexpr int kFastThreads = 128;     // largest launch of the fast kernels
 constexpr int kFastLevels = 22;
@@ -1589,7 +1590,7 @@ extern "C" int pfrl_tree_write(const pfrl_tree_t *tree, int64_t n, const int64_t
     PFRL_LAUNCH_CHECK();
 }
 
-// k_tree_update_errors_write for launches of up to 256 leaves: the same leaf stores, then
+// k_tree_update_errors_write for launches of up to kFastThreads (128) leaves: the same leaf stores, then
 // repair_paths_hashed instead of repair_paths.
 template <int THREADS>
 __global__ __launch_bounds__(THREADS) void k_tree_update_errors_write_fast(
@@ -1683,6 +1684,17 @@ extern "C" int pfrl_tree_write_sum(const pfrl_tree_t *tree, int64_t n, const int
     PFRL_LAUNCH_CHECK();
 }
 
+// hipFuncSetAttribute is per DEVICE: a process that drives trees on a second device must set the
+// dynamic-LDS limit there too.  One bit per device ordinal per call site.
+static bool attr_needed(unsigned long long *seen) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return true;
+    const unsigned long long bit = 1ull << dev;
+    if (*seen & bit) return false;
+    *seen |= bit;
+    return true;
+}
+
 extern "C" int pfrl_tree_sample(const pfrl_tree_t *tree, int64_t B, const double *u01,
                                 int64_t *out_x, double *out_pri, uint8_t *out_pri_tag,
                                 double *out_prob, float *out_weight, double *out_total,
@@ -1708,15 +1720,14 @@ extern "C" int pfrl_tree_sample(const pfrl_tree_t *tree, int64_t B, const double
         const size_t top_n = (size_t)1 << (L - r + 1), bot_n = (size_t)1 << (r + 1);
         const size_t lds = (top_n + bot_n) * (sizeof(double) + 1);
         const size_t lds2 = (top_n + 2 * bot_n) * (sizeof(double) + 1);
-        static bool attr_set = false;
-        if (!attr_set) {
+        static unsigned long long attr_seen = 0;
+        if (attr_needed(&attr_seen)) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_tree_sample_lds),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_tree_sample_lean),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_tree_sample_lean2),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024);
-            attr_set = true;
         }
         if (mode == 3)
             hipLaunchKernelGGL(k_tree_sample_lean2, dim3(1), dim3(128), lds2, (hipStream_t)stream,
@@ -1791,11 +1802,10 @@ extern "C" int pfrl_tree_update_errors_write_f32(
     const char *repair_env = getenv("PFRL_TREE_REPAIR");     // (read per call: tests switch it)
     const bool hashed = !(repair_env != nullptr && repair_env[0] == 'l');
     if (hashed && B + n <= kFastThreads && tree->log2_size <= kFastLevels && tree->log2_size >= 1) {
-        static bool attr_set = false;
-        if (!attr_set) {
+        static unsigned long long attr_seen = 0;
+        if (attr_needed(&attr_seen)) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_tree_update_errors_write_fast<128>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(FastLds<128>));
-            attr_set = true;
         }
         if (B + n <= 64)
             hipLaunchKernelGGL(k_tree_update_errors_write_fast<64>, dim3(1), dim3(64), sizeof(FastLds<64>),
@@ -1839,11 +1849,10 @@ extern "C" int pfrl_tree_update_errors_write_sample(
     const size_t top_n = (size_t)1 << (L - r + 1), bot_n = (size_t)1 << (r + 1);
     const size_t lds2 = ((top_n + 2 * bot_n) * (sizeof(double) + 1) + 15) & ~(size_t)15;
     const size_t total = lds2 + sizeof(FastLds<64>);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static unsigned long long attr_seen = 0;
+    if (attr_needed(&attr_seen)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_tree_update_errors_write_sample),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
-        attr_set = true;
     }
     PFRL_CHECK_ARG(total <= 156 * 1024, "pfrl_tree_update_errors_write_sample: LDS");
     hipLaunchKernelGGL(k_tree_update_errors_write_sample, dim3(1), dim3(128), total, (hipStream_t)stream,

@@ -53,7 +53,10 @@ class NoiseFeed:
         if self.views is None:
             self.sizes.append(int(n))
             return torch.randn(n, dtype=like.dtype, device=like.device)
-        v = self.views[self.at % len(self.views)]
+        # (no wrap-around: a step that draws MORE normals than the recording warm-up would be
+        # served the same noise twice, silently -- ADVICE r5)
+        assert self.at < len(self.views), "noise feed exhausted: the step draws more than was recorded"
+        v = self.views[self.at]
         self.at += 1
         assert v.numel() == n and v.device == like.device, "noise feed out of step with the layers"
         return v
@@ -64,7 +67,8 @@ class NoiseFeed:
         if self.views is None:
             self.sizes.append(int(n))
             return torch.empty(shape, dtype=dtype, device=device).normal_()
-        v = self.views[self.at % len(self.views)]
+        assert self.at < len(self.views), "noise feed exhausted: the step draws more than was recorded"
+        v = self.views[self.at]
         self.at += 1
         assert v.numel() == n, "noise feed out of step with the samplers"
         return v.view(shape)
