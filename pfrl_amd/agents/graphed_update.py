@@ -245,6 +245,9 @@ class GraphedUpdate:
             if defer:
                 mfma_trunk.OPT_SOURCES = {}
                 mfma_trunk.RIDE_ALONG = self.agent.optimizer
+                # (the head's per-row partials may ride in a backward launch too: which parameter
+                # each of the queued folds belongs to)
+                mfma_trunk.RIDE_HEAD = {g.data_ptr(): p for p, g in head if p.requires_grad}
                 # data parallel: a layer whose gradient is exchanged as its batch matrices is
                 # stepped where the product is formed, on the communicator's side stream
                 red.lowrank_step = self._step_on_side_stream
@@ -255,6 +258,7 @@ class GraphedUpdate:
             finally:
                 mfma_trunk.OPT_SOURCES = None
                 mfma_trunk.RIDE_ALONG = None
+                mfma_trunk.RIDE_HEAD = None
                 red.lowrank_step = None
             if defer and sources:
                 # the head's per-row partials (queued by the loss launch for "the fold that ends
@@ -265,7 +269,9 @@ class GraphedUpdate:
                 del mfma_trunk._DEFERRED_FOLDS[:]
                 by_out = {t[1].data_ptr(): t for t in queued}
                 for p, g in head:
-                    t = by_out.pop(g.data_ptr())
+                    t = by_out.pop(g.data_ptr(), None)
+                    if t is None:
+                        continue        # (its step rode in a backward launch: marked done there)
                     sources[p.data_ptr()] = GradSource.slabs(t[0], t[3], t[5])
                 self._folds = [(t[0], t[1], t[3], t[5]) for t in by_out.values()]
                 self._sources = sources

@@ -335,6 +335,19 @@ OPT_SOURCES = None
 # launch (pfrl_conv2d_nhwc_bwd_weight_ride) and marked GradSource.done() for the optimizer launch.
 RIDE_ALONG = None
 _RIDE = os.environ.get("PFRL_RIDE_ALONG", "1") != "0"
+# Round 6, measured and NOT the default (PFRL_RIDE_MORE=1 turns it on): EVERY finished layer's step
+# riding in the next backward launch (pfrl_ride_set) -- the head's in the last convolution's
+# backward launch, each convolution's in the launch of the layer below it, the optimizer's own
+# launch left with the first convolution and the loss fold.  Bit-identical
+# (tests/test_fused_optimizer.py), and slower: update 84.8 -> 87.8 us, 41.5 -> 40.4 k env-steps/s on
+# one box, twice (profiles/r06_ride_more.txt).  The residual launch does not get shorter -- it is
+# the 50-slab sum of the first convolution either way, 7 dependent round trips on 8 workgroups --
+# while three launches that are latency-bound at 1-3 workgroups per CU each gain slab-summing
+# workgroups and 0.5 KB of arguments.
+# RIDE_HEAD: {gradient tensor data_ptr: parameter} of the narrow head, set next to RIDE_ALONG by
+# GraphedUpdate (the head's per-row partials sit in _DEFERRED_FOLDS).
+RIDE_HEAD = None
+_RIDE_MORE = os.environ.get("PFRL_RIDE_MORE", "0") == "1"
 
 # dh.data_ptr() -> (dh with the hidden layer's ReLU mask applied and scaled by 1 / world, world):
 # left by the fused head + TD-loss launch of a data-parallel update (ops._DQNHeadTDLoss) for the
@@ -605,6 +618,17 @@ class _Trunk(torch.autograd.Function):
         lib = _native.lib()
         L = len(specs)
         tasks = []
+        # steps waiting for the next backward launch: [(parameter, dense gradient or GradSource)]
+        riding = (ride is not None and _RIDE_MORE and RIDE_ALONG is not None and OPT_SOURCES is not None
+                  and hasattr(RIDE_ALONG, "ride_set"))
+        carry = []
+        if riding and RIDE_HEAD and _DEFERRED_FOLDS:
+            from pfrl_amd.optimizers import GradSource
+
+            for t in list(_DEFERRED_FOLDS):
+                p_ = RIDE_HEAD.get(t[1].data_ptr())
+                if p_ is not None and len(carry) < 4:
+                    carry.append((p_, GradSource.slabs(t[0], t[3], t[5]), t))
         for i in range(L - 1, -1, -1):
             sp = specs[i]
             w = params[2 * i]
@@ -633,9 +657,19 @@ class _Trunk(torch.autograd.Function):
                 grads[2 * i], grads[2 * i + 1] = None, None
             if i > 0 and _fused_bwd_ok(N, sp.H, sp.W, sp.C, sp.ST):
                 dx = torch.empty((N, sp.H, sp.W, sp.C), dtype=torch.float32, device=dev)
-                check(lib.pfrl_conv2d_nhwc_bwd(_p(dy), None, _p(w), _p(below), _p(below), _p(dx), _p(pw),
-                                               _p(pb), st, st, N, sp.H, sp.W, sp.C, sp.Cout, sp.R, sp.S,
-                                               sp.ST, 0, 0, splits, _stream()), "conv2d_nhwc_bwd")
+                bwd_args = (_p(dy), None, _p(w), _p(below), _p(below), _p(dx), _p(pw), _p(pb), st, st, N,
+                            sp.H, sp.W, sp.C, sp.Cout, sp.R, sp.S, sp.ST, 0, 0, splits, _stream())
+                rode = False
+                if carry and RIDE_ALONG.ride_set([(p_, g_) for p_, g_, _ in carry]):
+                    # (a tile program without a riding form refuses BEFORE launching and drops the set)
+                    rode = lib.pfrl_conv2d_nhwc_bwd(*bwd_args) == 0
+                if not rode:
+                    check(lib.pfrl_conv2d_nhwc_bwd(*bwd_args), "conv2d_nhwc_bwd")
+                carry = _after_ride(carry, rode)
+                if riding and splits > 1 and OPT_SOURCES is not None:
+                    # this layer's own step: in the launch of the layer below
+                    carry += [(w, OPT_SOURCES[w.data_ptr()], None),
+                              (params[2 * i + 1], OPT_SOURCES[params[2 * i + 1].data_ptr()], None)]
                 dy = dx
                 continue
             ra = RIDE_ALONG.ride_arrays([(p_, g_) for p_, g_, _ in ride]) if (ride and i == 0) else None
@@ -643,9 +677,12 @@ class _Trunk(torch.autograd.Function):
                 # the last launch of the backward pass: the finished layers' optimizer steps ride in it
                 from pfrl_amd.optimizers import GradSource
 
+                more = bool(carry) and len(carry) + len(ride) <= 8 and \
+                    RIDE_ALONG.ride_set([(p_, g_) for p_, g_, _ in carry])
                 check(lib.pfrl_conv2d_nhwc_bwd_weight_ride(
                     _p(dy), None, _p(below), _p(pw), _p(pb), st, st, N, sp.H, sp.W, sp.C, sp.Cout, sp.R,
                     sp.S, sp.ST, splits, *ra, _stream()), "conv2d_nhwc_bwd_weight_ride")
+                carry = _after_ride(carry, more)
                 for p_, g_, slot in ride:
                     OPT_SOURCES[p_.data_ptr()] = GradSource.done()
                     grads[slot] = None
@@ -673,6 +710,21 @@ class _Trunk(torch.autograd.Function):
         if tasks:
             _reduce(tasks)
         return (None, None) + tuple(grads)
+
+
+def _after_ride(carry, rode):
+    """Bookkeeping behind a backward launch that carried (``rode``) or did not carry the steps of
+    ``carry``: carried parameters are marked done for the optimizer launch, and the head's
+    deferred folds they came from are withdrawn.  Returns the new (empty) carry list; what did not
+    ride stays with the optimizer launch, as before."""
+    if rode:
+        from pfrl_amd.optimizers import GradSource
+
+        for p_, _, task in carry:
+            OPT_SOURCES[p_.data_ptr()] = GradSource.done()
+            if task is not None and task in _DEFERRED_FOLDS:
+                _DEFERRED_FOLDS.remove(task)
+    return []
 
 
 def trunk_forward(x, specs, convs, linear):

@@ -105,6 +105,56 @@ class FusedRMSprop(torch.optim.RMSprop):
                 float(group["lr"]), float(group["alpha"]), float(group["eps"]),
                 float(group["weight_decay"]), int(centered))
 
+    def ride_set(self, entries):
+        """Hand the steps of ``entries`` = [(parameter, gradient)] -- gradient: a finished dense
+        tensor or a ``GradSource.slabs`` -- to the NEXT backward launch of this thread
+        (``pfrl_ride_set``: consumed by ``pfrl_conv2d_nhwc_bwd`` / ``..._bwd_weight_ride``, which run
+        them as extra workgroups).  True = set; the caller then marks the parameters
+        ``GradSource.done()``.  False = a tensor is outside what the kernel covers (nothing set)."""
+        if not self.accepts_sources() or not 1 <= len(entries) <= 8:
+            return False
+        group = self.param_groups[0]
+        centered = bool(group["centered"])
+        rows = []
+        for p, g in entries:
+            st = self.state[p]
+            if len(st) == 0:
+                st["step"] = (torch.zeros((), dtype=torch.float32, device=p.device)
+                              if group.get("capturable", False) else torch.tensor(0.0))
+                st["square_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                if centered:
+                    st["grad_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            sq = st["square_avg"]
+            ga = st["grad_avg"] if centered else None
+            if isinstance(g, GradSource):
+                if g.mode != OPT_SLABS or g.stride % 4 != 0:
+                    return False
+                src, n_slabs, stride = g.src, g.n_slabs, g.stride
+            else:
+                if g.stride() != p.stride() or g.dtype != torch.float32:
+                    return False
+                src, n_slabs, stride = g, 0, 0
+            ts = [p, sq] + ([ga] if centered else [])
+            if not all(t.is_cuda and t.dtype == torch.float32 and _dense(t) and t.stride() == p.stride()
+                       and t.data_ptr() % 16 == 0 for t in ts) or src.data_ptr() % 16 != 0:
+                return False
+            if p.numel() == 0:
+                return False
+            rows.append((p.data_ptr(), src.data_ptr(), sq.data_ptr(), ga.data_ptr() if centered else 0,
+                         p.numel(), n_slabs, stride))
+        n = len(rows)
+        V = ctypes.c_void_p * n
+        rc = _native.lib().pfrl_ride_set(
+            n, V(*[r[0] for r in rows]), V(*[r[1] for r in rows]), V(*[r[2] for r in rows]),
+            V(*[r[3] for r in rows]), (ctypes.c_int64 * n)(*[r[4] for r in rows]),
+            (ctypes.c_int32 * n)(*[r[5] for r in rows]), (ctypes.c_int64 * n)(*[r[6] for r in rows]),
+            float(group["lr"]), float(group["alpha"]), float(group["eps"]),
+            float(group["weight_decay"]), int(centered))
+        return rc == 0
+
+    def ride_clear(self):
+        _native.lib().pfrl_ride_set(0, None, None, None, None, None, None, None, 0.0, 0.0, 0.0, 0.0, 0)
+
     def step_from_sources(self, sources, folds=()):
         """``step()`` where the gradient of parameter ``p`` is ``sources[p]`` (a GradSource) if
         present and ``p.grad`` otherwise; ``folds`` = (part, out, stride, n_slabs) slab sums with

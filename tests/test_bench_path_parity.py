@@ -402,6 +402,42 @@ def test_ppo_next_state_values_evaluated_once_are_the_full_second_pass_bit_for_b
         assert seen["pass"]["mode"] == "full pass" and seen["pass"]["evaluated"] == M, seen
 
 
+def test_bench_per_launch_table_is_measured_and_leaves_the_agent_untouched():
+    """``roofline.mfma.per_launch`` of the bench line (measured in the run, not
+    read from a committed profile): the launches of ONE update -- the Python a capture records,
+    run eagerly with an event pair around every library launch -- are the ten of the chain,
+    carry 1.585 GFLOP at B = 32 in all, and parameters / optimizer state are what they were
+    before the measurement."""
+    import bench
+
+    dev = torch.device("cuda:0")
+    N = 256
+    args = _bench_args(capacity=3000, frame_slots=12288, slack=512, replay_start=1024)
+    agent, env, rbuf = bench.build_agent(args, dev, 0)
+    obss = env.reset()
+    for _ in range(8):
+        obss = bench.one_step(agent, env, obss, N)
+    assert agent._graphed is not None and agent.optim_t > 0
+    torch.cuda.synchronize()
+    before = [p.detach().clone() for p in agent.model.parameters()]
+    state = [v.detach().clone() for st in agent.optimizer.state.values() for v in st.values()
+             if torch.is_tensor(v)]
+    table = bench.mfma_per_launch(agent, rbuf, 32)
+    rows = table["launches"]
+    assert table["n_launches"] == len(rows) == 10, [r["entry"] for r in rows]
+    assert [r["entry"] for r in rows][:4] == ["pfrl_conv2d_nhwc_fwd"] * 4
+    assert rows[4]["entry"] == "pfrl_dqn_head_td_loss" and rows[-1]["entry"] == "pfrl_rmsprop_fused_step"
+    assert abs(sum(r["gflop"] for r in rows) - 1.585) < 0.01
+    assert all(r["us"] > 0 and (r["frac"] is None or 0.0 < r["frac"] < 1.0) for r in rows)
+    for a, b in zip(before, agent.model.parameters()):
+        assert torch.equal(a, b)
+    after = [v for st in agent.optimizer.state.values() for v in st.values() if torch.is_tensor(v)]
+    for a, b in zip(state, after):
+        assert torch.equal(a, b)
+    # ... and training goes on
+    obss = bench.one_step(agent, env, obss, N)
+
+
 def test_dqn_act_graph_and_fused_head_equal_the_eager_act_path(monkeypatch):
     """``DQN.batch_act`` of the device step as one captured graph with the fused head
     (agents/_dqn_device_step.py::ActGraph, pfrl_dqn_act_head) against the launches it replaces

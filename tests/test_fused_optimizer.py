@@ -158,44 +158,63 @@ def test_module_between_trunk_and_head_reads_the_folded_hidden_layer():
         np.testing.assert_array_equal(a, b)
 
 
-def test_optimizer_steps_riding_in_the_last_backward_launch_are_bit_identical():
-    """The hidden layer's RMSprop step as extra workgroups of the first convolution's
-    weight-gradient launch (default, pfrl_conv2d_nhwc_bwd_weight_ride) vs inside the optimizer
-    launch (PFRL_RIDE_ALONG=0): the same arithmetic on the same gradients, so the same bits --
-    losses and every parameter after 6 updates; and the ride is really taken."""
+def test_optimizer_steps_riding_in_the_backward_launches_are_bit_identical():
+    """RMSprop steps as extra workgroups of the backward launches against the optimizer's own
+    launch (same arithmetic on the same gradients / the same slab sums in the same order, so the
+    same bits -- losses and every parameter after 6 updates):
+      off    PFRL_RIDE_ALONG=0: every step in pfrl_rmsprop_fused_step
+      last   round 5: the hidden layer's step in the first convolution's weight-gradient launch
+      all    round 6 (PFRL_RIDE_MORE=1; measured slower, not the default): + the head's in conv3's
+             backward launch, conv3's in conv2's, conv2's in conv1's (pfrl_ride_set); the
+             optimizer launch keeps conv1 + the loss fold
+    and the rides are really taken."""
     from pfrl_amd import _native
     from pfrl_amd.nn import mfma_trunk
 
-    calls = []
+    calls = {"ride": 0, "set": 0}
     lib = _native.lib()
-    real = lib.pfrl_conv2d_nhwc_bwd_weight_ride
+    real_ride, real_set = lib.pfrl_conv2d_nhwc_bwd_weight_ride, lib.pfrl_ride_set
 
     class _Spy:
         def __getattr__(self, name):
             if name == "pfrl_conv2d_nhwc_bwd_weight_ride":
                 def f(*a):
-                    calls.append(1)
-                    return real(*a)
+                    calls["ride"] += 1
+                    return real_ride(*a)
+                return f
+            if name == "pfrl_ride_set":
+                def f(*a):
+                    calls["set"] += 1 if a[0] > 0 else 0
+                    return real_set(*a)
                 return f
             return getattr(lib, name)
 
-    old_lib, old_ride = _native.lib, mfma_trunk._RIDE
+    old_lib, old_ride, old_more = _native.lib, mfma_trunk._RIDE, mfma_trunk._RIDE_MORE
     _native.lib = lambda: _Spy()
     mfma_trunk._native.lib = _native.lib
+    from pfrl_amd import optimizers
+
+    optimizers._native.lib = _native.lib
+    out = {}
     try:
-        mfma_trunk._RIDE = True
-        pa, la, ua = _run_updates(True)
-        n_on = len(calls)
-        mfma_trunk._RIDE = False
-        pb, lb, ub = _run_updates(True)
-        n_off = len(calls) - n_on
+        for name, ride, more in (("all", True, True), ("last", True, False), ("off", False, False)):
+            mfma_trunk._RIDE, mfma_trunk._RIDE_MORE = ride, more
+            calls["ride"] = calls["set"] = 0
+            p, l, used = _run_updates(True)
+            out[name] = (p, l, used, dict(calls))
     finally:
         _native.lib = old_lib
-        mfma_trunk._RIDE = old_ride
-    assert ua and ub and n_on >= 1 and n_off == 0
-    np.testing.assert_array_equal(la, lb)
-    for a, b in zip(pa, pb):
-        np.testing.assert_array_equal(a, b)
+        mfma_trunk._native.lib = old_lib
+        optimizers._native.lib = old_lib
+        mfma_trunk._RIDE, mfma_trunk._RIDE_MORE = old_ride, old_more
+    assert all(o[2] for o in out.values())
+    assert out["all"][3]["ride"] >= 1 and out["all"][3]["set"] >= 3 * out["all"][3]["ride"]
+    assert out["last"][3]["ride"] >= 1 and out["last"][3]["set"] == 0
+    assert out["off"][3] == {"ride": 0, "set": 0}
+    for name in ("last", "off"):
+        np.testing.assert_array_equal(out["all"][1], out[name][1])
+        for a, b in zip(out["all"][0], out[name][0]):
+            np.testing.assert_array_equal(a, b)
 
 
 @pytest.mark.parametrize("backend", ["nccl", "gloo"])

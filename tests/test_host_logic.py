@@ -337,27 +337,3 @@ def test_appends_keep_frame_never_misses_a_frame_change():
     assert said_yes > 10 * said_no > 0      # (and it is not vacuous: mostly yes, sometimes no)
 
 
-def test_bench_per_launch_table_reads_the_committed_update_timeline():
-    """``roofline.mfma.per_launch`` of the bench line: ten launches matched by position with the
-    committed one-update timeline, 1.58 GFLOP of arithmetic per B = 32 update in all (forward
-    0.598, backward 2 x forward minus conv1's input gradient), every fraction below the peak."""
-    import importlib.util
-    import os
-    import sys
-
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    spec = importlib.util.spec_from_file_location("bench_for_test", os.path.join(root, "bench.py"))
-    bench = importlib.util.module_from_spec(spec)
-    saved = sys.argv
-    sys.argv = ["bench.py"]
-    try:
-        spec.loader.exec_module(bench)
-    finally:
-        sys.argv = saved
-    table = bench.mfma_per_launch(32)
-    assert table is not None and table["source"].endswith("_dqn_update_timeline.txt")
-    rows = table["launches"]
-    assert len(rows) == 10
-    assert abs(sum(r["gflop"] for r in rows) - 1.585) < 0.01
-    assert all(r["frac"] is None or 0.0 <= r["frac"] < 1.0 for r in rows)
-    assert rows[0]["kernel"] == "k_conv_fwd" and rows[-1]["kernel"].startswith("k_rmsprop")
