@@ -93,6 +93,12 @@ def compute_roofline(algo, all_us, all_units, all_kinds):
         "timing": "hipEvent pair attached to each dispatch (hipExtLaunchKernelGGL) on the "
                   "launch stream, inside the timed region",
     }
+    if roofline["frac"] > 1.0:
+        # (algorithmic bytes count every observation's k stacked frames as read; a launch whose
+        # frames AND output fit the 256 MiB Infinity Cache -- a 64-env rank's rollout -- is served
+        # from there and can exceed the HBM peak: say so instead of leaving a fraction above one)
+        roofline["note"] = ("above the HBM peak: the launch's working set is Infinity-Cache resident "
+                            "(consecutive observations share k - 1 frames); not an HBM-bound measurement")
     if scan:
         # the north star's named scan / reduction kernels: one launch each per rollout, a few MB --
         # latency-bound (the launch, not the bytes), reported against the same HBM roofline

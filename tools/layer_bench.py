@@ -160,6 +160,28 @@ def main():
                     rows.append(("wgrad/%d(%s)" % (sp, pair), time_us(run_w2, args.iters), flop,
                                  bx + by + sp * stride * 4))
                     del part2
+            if name == "conv1" and B >= 64:
+                # the forms PPO runs since round 5: the layer reads u8 NHWC4 pixels itself
+                px = torch.randint(0, 256, (B, H, H, 4), dtype=torch.uint8, device=dev)
+
+                def run_fwd_u8():
+                    check(lib.pfrl_conv2d_u8nhwc4_fwd(_p(px), 255.0, _p(w), _p(b), _p(y), B, H, H, Co, R, R,
+                                                      ST, 1, 0, _stream()), "fwd_u8")
+
+                def run_wgrad_u8():
+                    check(lib.pfrl_conv2d_u8nhwc4_bwd_weight(_p(dy), None, _p(px), 255.0, _p(part),
+                                                             _p(part[w.numel():]), stride, stride, B, H, H,
+                                                             Co, R, R, ST, splits, _stream()), "wgrad_u8")
+
+                try:
+                    if "fwd" in only:
+                        rows.append(("fwd (u8 input)", time_us(run_fwd_u8, args.iters), flop, bx // 4 + by + bw))
+                    if "wgrad" in only:
+                        rows.append(("wgrad/%d (u8)" % splits, time_us(run_wgrad_u8, args.iters), flop,
+                                     bx // 4 + by + splits * stride * 4))
+                except RuntimeError as e:
+                    print("# conv1 u8 forms at B = %d: %s" % (B, str(e)[:120]))
+                del px
             for d, t, f, nbytes in rows:
                 tf = f / t * 1e-6
                 print("%-6s %-16s %6d %10.1f %9.2f %8.1f %6.3f %9.1f" % (
