@@ -394,9 +394,14 @@ def rank_shape_legs(args, out, keys):
              ["--algo", "dqn", "--num-envs", "32", "--steps", "160", "--warmup", "40", "--scaling", "weak"]),
             ("ppo_rank_shape_g8", (out["also"].get("ppo") or {}).get("value"),
              ["--algo", "ppo", "--num-envs", "64", "--steps", "128", "--warmup", "128", "--scaling", "weak"]))
+    import socket
+
     for k, (name, full, argv) in enumerate(legs):
-        env = dict(dp_env, MASTER_PORT=str(29731 + k))
-        r = also_in_own_process(args, argv, extra_env=env)
+        with socket.socket() as sock:       # (a free rendezvous port for the leg's single-rank group)
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+        env = dict(dp_env, MASTER_PORT=str(port))
+        r = also_in_own_process(args, argv, limit_s=300, extra_env=env)
         if r is None:
             out["also"][name] = {"value": None, "note": "the rank-shaped run did not complete"}
             continue
