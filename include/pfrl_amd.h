@@ -337,12 +337,14 @@ int pfrl_ppo_minibatch(int64_t M, const int64_t *idx, const float *adv, const fl
  * value = h w_value^T + b_value, action ~ Categorical(logits) by inverse CDF on u01[row] in [0, 1),
  * entropy of the distribution, optionally log pi(action).  given_action != NULL: no draw -- the
  * value pass of an update (ppo.py:110-142): log pi(given_action | s) and V(s) (out_action /
- * out_entropy / u01 may be NULL).  h [N][K], w_policy [A][K], A <= 31. */
+ * out_entropy / u01 may be NULL).  h [N][K], w_policy [A][K], A <= 31.  * rows != NULL (device int32[2]): outputs are offset on the device -- out_action by rows[0] * N,
+ * out_entropy / out_value by rows[1] * 2 * N -- so that a captured rollout step writes into the
+ * rollout's columns with fixed kernel arguments. */
 int pfrl_ppo_act_head(const float *h, const float *w_policy, const float *b_policy,
                       const float *w_value, const float *b_value, const float *u01,
                       const int64_t *given_action, int64_t *out_action, float *out_entropy,
                       float *out_value, float *out_log_prob, int32_t N, int32_t K, int32_t A,
-                      void *stream);
+                      const int32_t *rows, void *stream);
 /* PPO._lossfun (pfrl/agents/ppo.py:634-671) on the logits [M, A] and values [M] of a minibatch:
  * clipped surrogate + (clipped, if clip_eps_vf >= 0) value MSE + entropy bonus, AND its gradient
  * with respect to logits and values (d loss = 1), in one launch + a one-workgroup finish.

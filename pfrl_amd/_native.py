@@ -184,7 +184,7 @@ EXPORTS = {
     "pfrl_a2c_returns": (ctypes.c_int, "qqppppddip"),
     "pfrl_adv_stats": (ctypes.c_int, "pqppp"),
     "pfrl_ppo_minibatch": (ctypes.c_int, "qpppipppppippppppp"),
-    "pfrl_ppo_act_head": (ctypes.c_int, "pppppppppppiiip"),
+    "pfrl_ppo_act_head": (ctypes.c_int, "pppppppppppiiipp"),
     "pfrl_ppo_loss": (ctypes.c_int, "pppppppiiffffppppp"),
     "pfrl_rmsprop_step": (ctypes.c_int, "ipppppffffip"),
     "pfrl_rmsprop_fused_step": (ctypes.c_int, "ipffffip"),

@@ -147,7 +147,8 @@ class _Rollout:
                                             device=action.device)
                 if t > 0:
                     self.d_action[:t].copy_(torch.from_numpy(self.h_action[:t]))
-            self.d_action[t].copy_(action)
+            if action.data_ptr() != self.d_action[t].data_ptr():    # (else: written there by the act graph)
+                self.d_action[t].copy_(action)
         else:
             self.h_action[t] = action
             if self.d_action is not None:
@@ -266,7 +267,7 @@ class _ActGraph:
         self._split_cache = (model, out)
         return out
 
-    def _body(self, refs):
+    def _body(self, refs, into=None):
         ag = self.agent
         b_state = ag._features(refs)
         split = self._split()
@@ -276,37 +277,63 @@ class _ActGraph:
                 h = body(b_state)
                 if h.dim() == 2 and h.dtype == torch.float32 and h.is_contiguous():
                     u = torch.rand(h.shape[0], dtype=torch.float32, device=h.device)
+                    if into is not None:
+                        # (action / entropy / value land in the rollout's own columns: no stack,
+                        # no clones, no copy into the action column afterwards)
+                        ops.ppo_act_head(h, pol.weight, pol.bias, val.weight, val.bias, u, into=into)
+                        return None, None
                     action, entropy, value = ops.ppo_act_head(h, pol.weight, pol.bias, val.weight,
                                                               val.bias, u)
                     return action, torch.stack([entropy, value])
                 distrib, value = model_tail(ag.model, h)
             else:
                 distrib, value = ag.model(b_state)
+            assert into is None
             action = distrib.sample()
             stats = torch.stack([distrib.entropy().reshape(-1).float(),
                                  value.reshape(-1).float()])
         return action, stats
 
-    def _capture(self, refs_dev):
+    def in_place_ok(self, n_env):
+        """The rollout-column form of a step: the fused head (``_split``), int64 actions [N]."""
+        return (os.environ.get("PFRL_PPO_ACT_IN_PLACE", "1") != "0" and self._split() is not None
+                and self.agent.obs_normalizer is None)
+
+    def _capture(self, refs_dev, into=None):
         from pfrl_amd.agents.graphed_update import _capturing, _no_distribution_validation
 
         dev = self.agent.device
-        refs = refs_dev.clone()
+        if into is None:
+            refs = refs_dev.clone()
+            block = None
+        else:
+            # ONE input block: the step's frame slots + the two row indices, shipped straight from
+            # the pinned staging slot (no device-side copy in front of the replay)
+            nb = refs_dev.numel() * 4
+            block = torch.zeros(((nb + 15) & ~15) + 16, dtype=torch.uint8, device=dev)
+            refs = block[:nb].view(torch.int32).view(refs_dev.shape)
+            refs.copy_(refs_dev)
+            rows = block[(nb + 15) & ~15:][:8].view(torch.int32)
+            # (warm-up and capture write somewhere nobody reads: the LAST row of the action column
+            # -- the rollout never gets that far -- and the ring's reserved last slot; a capture in
+            # the middle of a rollout must not touch rows that hold its data)
+            rows.copy_(torch.tensor([into[0].shape[0] - 1, into[1].shape[0] - 1], dtype=torch.int32))
+            into = (into[0], into[1], rows)
         rng = torch.cuda.get_rng_state(dev)
         cur = torch.cuda.current_stream(dev)
         side = torch.cuda.Stream(dev)
         side.wait_stream(cur)
         with torch.cuda.stream(side), _no_distribution_validation():
             for _ in range(2):
-                self._body(refs)
+                self._body(refs, into)
         cur.wait_stream(side)
         torch.cuda.set_rng_state(rng, dev)      # the warm-up draws are not part of the run
         g = torch.cuda.CUDAGraph()
         with ops.profile_paused(), _capturing(g, self.pool), _no_distribution_validation():
-            action, stats = self._body(refs)
+            action, stats = self._body(refs, into)
         if self.pool is None:
             self.pool = g.pool()
-        return g, refs, action, stats
+        return g, refs, action, stats, block
 
     def run(self, refs_dev):
         """(actions [N], stats [2, N] = entropy, value): tensors OWNED BY THE GRAPH, overwritten by
@@ -317,10 +344,33 @@ class _ActGraph:
         e = self.entries.get(key)
         if e is None:
             e = self.entries[key] = self._capture(refs_dev)
-        g, refs, action, stats = e
+        g, refs, action, stats, _ = e
         refs.copy_(refs_dev)
         g.replay()
         return action, stats
+
+    def run_in_place(self, refs_host, col, ring, row, slot, stage):
+        """One rollout step whose outputs land in the rollout's columns: ``col`` [T, N] i64 gets
+        the actions in row ``row``, ``ring`` [R, 2, N] f32 the (entropy, value) block in slot
+        ``slot``.  The step costs ONE staging transfer (frame slots + the two indices, into the
+        graph's own input block) and ONE replay.  Returns (col[row], ring[slot])."""
+        if self.agent.frames is not None:
+            from pfrl_amd.nn.atari_cnn import wants_channels_last
+
+            # (the layout switch _gather() would flip inside the capture: settle it first, so that
+            # the key of the second step is the key of the first)
+            self.agent.frames.emit_channels_last = wants_channels_last(self.agent.model)
+        key = (tuple(refs_host.shape), tuple(id(m) for m in self.agent.model.modules()),
+               self.agent.frames.emit_channels_last if self.agent.frames is not None else None,
+               col.data_ptr(), ring.data_ptr())
+        e = self.entries.get(key)
+        if e is None:
+            (refs_dev,) = stage.upload([refs_host])
+            e = self.entries[key] = self._capture(refs_dev, into=(col, ring))
+        g, _, _, _, block = e
+        stage.upload_to(block, [refs_host, np.array([row, slot], dtype=np.int32)])
+        g.replay()
+        return col[row], ring[slot]
 
 
 class PPO(agent.AttributeSavingMixin, agent.BatchAgent):
@@ -519,11 +569,27 @@ class PPO(agent.AttributeSavingMixin, agent.BatchAgent):
         assert self.training
         refs, dev_batch = self._refs_of(batch_obs)
         self._sample_obs = dev_batch[0]
-        (refs_dev,) = self._stage.upload([refs])
         if self._act_graph is None:
             self._act_graph = _ActGraph(self)
+        in_place = (self._rec is None and isinstance(batch_obs, DeviceObsBatch) and self.device_actions
+                    and self._act_graph.applicable() and self._act_graph.in_place_ok(len(batch_obs)))
+        refs_dev = None if in_place else self._stage.upload([refs])[0]
         if self._rec is not None:
             action_dev = self._rec.act_train(refs_dev)
+        elif (isinstance(batch_obs, DeviceObsBatch) and self.device_actions
+                and self._act_graph.applicable() and self._act_graph.in_place_ok(len(batch_obs))):
+            # device env, example network: ONE transfer + ONE replay per step; the actions land in
+            # the rollout's action column, entropy / value in a ring the statistics windows read
+            ro = self._ensure_rollout(len(batch_obs), refs.shape[1], (), np.dtype(np.int64))
+            if ro.d_action is None:
+                ro.d_action = torch.zeros((ro.cap, ro.N), dtype=torch.int64, device=self.device)
+            ring = self._stats_ring(len(batch_obs))
+            slot = self._stats_at % (ring.shape[0] - 1)      # (the last slot: the capture's scratch)
+            self._stats_at += 1
+            action_dev, stats = self._act_graph.run_in_place(refs, ro.d_action, ring, ro.T, slot,
+                                                             self._stage)
+            self.entropy_record.extend(stats[0])
+            self.value_record.extend(stats[1])
         elif (isinstance(batch_obs, DeviceObsBatch) and self.device_actions
                 and self._act_graph.applicable()):
             # device env: nothing of this step is looked at on the host -- one graph replay
@@ -582,6 +648,26 @@ class PPO(agent.AttributeSavingMixin, agent.BatchAgent):
                 action = action_distrib.sample().cpu().numpy()
         return action
 
+    _stats_at = 0
+    _stats_ring_buf = None
+
+    def _stats_ring(self, n_env):
+        """[R, 2, N] f32: (entropy, value) of the last R acting steps, R large enough that a slot
+        is reused only after both statistics windows have dropped it."""
+        window = max(self.value_record.maxlen, self.entropy_record.maxlen)
+        R = -(-window // n_env) + 4
+        ring = self._stats_ring_buf
+        if ring is None or tuple(ring.shape) != (R, 2, n_env):
+            ring = self._stats_ring_buf = torch.zeros((R, 2, n_env), dtype=torch.float32,
+                                                      device=self.device)
+        return ring
+
+    def _ensure_rollout(self, n_env, k, act_shape, act_dtype):
+        if self.rollout is None:
+            t_cap = -(-self.update_interval // n_env) + 2
+            self.rollout = _Rollout(self.device, n_env, k, t_cap, act_shape, act_dtype)
+        return self.rollout
+
     def batch_act(self, batch_obs):
         if self._host is not None:
             act = self._host.batch_act_train if self.training else self._host.batch_act_eval
@@ -598,11 +684,9 @@ class PPO(agent.AttributeSavingMixin, agent.BatchAgent):
         actions = self.__dict__.get("_last_action_dev")
         if actions is None:
             actions = np.asarray(self.batch_last_action)
-        if self.rollout is None:
-            t_cap = -(-self.update_interval // n_env) + 2
-            self.rollout = _Rollout(self.device, n_env, next_refs.shape[1], t_cap, actions.shape[1:],
-                                    actions.dtype if isinstance(actions, np.ndarray) else
-                                    np.dtype(str(actions.dtype).replace("torch.", "")))
+        self._ensure_rollout(n_env, next_refs.shape[1], actions.shape[1:],
+                             actions.dtype if isinstance(actions, np.ndarray) else
+                             np.dtype(str(actions.dtype).replace("torch.", "")))
         if self._reward_mode is None:
             r0 = batch_reward[0]
             # NEP 50: np.float64 rewards promote the GAE arithmetic to f64,

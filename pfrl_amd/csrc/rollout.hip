@@ -304,10 +304,21 @@ __global__ __launch_bounds__(256) void k_ppo_act_head(
     const float *__restrict__ h, const float *__restrict__ wp, const float *__restrict__ bp,
     const float *__restrict__ wv, const float *__restrict__ bv, const float *__restrict__ u,
     const int64_t *__restrict__ given, int64_t *__restrict__ action, float *__restrict__ entropy,
-    float *__restrict__ value, float *__restrict__ log_prob, int N, int K) {
+    float *__restrict__ value, float *__restrict__ log_prob, int N, int K,
+    const int32_t *__restrict__ rows) {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int row = blockIdx.x * 4 + wave;
     if (row >= N) return;
+    // (rows != NULL: a captured rollout step writes straight into the rollout's columns -- the
+    // action into row rows[0] of an [T][N] column, entropy / value into slot rows[1] of a ring of
+    // [2][N] blocks -- the indices arrive with the step's staging transfer, so the graph's
+    // addresses stay fixed and no copy launch follows it, agents/ppo.py::_ActGraph)
+    if (rows != nullptr) {
+        const int ra = rows[0], rs = rows[1];
+        if (action != nullptr) action += (size_t)ra * N;
+        if (entropy != nullptr) entropy += (size_t)rs * 2 * N;
+        value += (size_t)rs * 2 * N;
+    }
     float acc[A + 1];
 #pragma unroll
     for (int j = 0; j <= A; ++j) acc[j] = 0.f;
@@ -607,7 +618,7 @@ extern "C" int pfrl_ppo_act_head(const float *h, const float *w_policy, const fl
                                  const float *w_value, const float *b_value, const float *u01,
                                  const int64_t *given_action, int64_t *out_action, float *out_entropy,
                                  float *out_value, float *out_log_prob, int32_t N, int32_t K, int32_t A,
-                                 void *stream) {
+                                 const int32_t *rows, void *stream) {
     PFRL_CHECK_ARG(N >= 0 && K >= 1 && A >= 1 && A < ACT_MAX_OUT, "pfrl_ppo_act_head: 1 <= A <= 31");
     PFRL_CHECK_ARG(h && w_policy && b_policy && w_value && b_value && out_value,
                    "pfrl_ppo_act_head: null pointer");
@@ -618,7 +629,8 @@ extern "C" int pfrl_ppo_act_head(const float *h, const float *w_policy, const fl
     case AA:                                                                                      \
         hipLaunchKernelGGL(k_ppo_act_head<AA>, dim3((unsigned)((N + 3) / 4)), dim3(256), 0,       \
                            (hipStream_t)stream, h, w_policy, b_policy, w_value, b_value, u01,     \
-                           given_action, out_action, out_entropy, out_value, out_log_prob, N, K); \
+                           given_action, out_action, out_entropy, out_value, out_log_prob, N, K,  \
+                           rows);                                                                 \
         break;
     switch (A) {
         ACT_CALL(1) ACT_CALL(2) ACT_CALL(3) ACT_CALL(4) ACT_CALL(5) ACT_CALL(6) ACT_CALL(7) ACT_CALL(8)

@@ -470,20 +470,33 @@ def ppo_loss(logits, value, action, adv, log_prob_old, v_pred_old, v_teacher, cl
     return out, dlogits, dvalue.view(value.shape)
 
 
-def ppo_act_head(h, w_policy, b_policy, w_value, b_value, u01, want_log_prob=False):
+def ppo_act_head(h, w_policy, b_policy, w_value, b_value, u01, want_log_prob=False, into=None):
     """The two narrow heads of the PPO example network + Categorical sample / entropy in one launch
-    (pfrl_ppo_act_head).  h [N, K] f32; returns (action i64 [N], entropy [N], value [N][, log_prob])."""
+    (pfrl_ppo_act_head).  h [N, K] f32; returns (action i64 [N], entropy [N], value [N][, log_prob]).
+    ``into`` = (action column i64 [T, N], stats ring f32 [R, 2, N], rows int32[2] on the device):
+    the launch writes the action into row rows[0] of the column and (entropy, value) into slot
+    rows[1] of the ring -- the indices are read on the device, so a captured graph keeps fixed
+    arguments -- and the returned tensors are the BASES (index them with the host's copy of rows)."""
     N, K = h.shape
     A = w_policy.shape[0]
     dev = h.device
-    action = torch.empty(N, dtype=torch.int64, device=dev)
-    entropy = torch.empty(N, dtype=torch.float32, device=dev)
-    value = torch.empty(N, dtype=torch.float32, device=dev)
+    rows = None
+    if into is not None:
+        col, ring, rows = into
+        assert col.dtype == torch.int64 and col.is_contiguous() and col.shape[1] == N
+        assert ring.dtype == torch.float32 and ring.is_contiguous() and tuple(ring.shape[1:]) == (2, N)
+        assert rows.dtype == torch.int32 and rows.numel() == 2
+        action, entropy, value = col, ring, ring.view(-1)[N:]
+    else:
+        action = torch.empty(N, dtype=torch.int64, device=dev)
+        entropy = torch.empty(N, dtype=torch.float32, device=dev)
+        value = torch.empty(N, dtype=torch.float32, device=dev)
     logp = torch.empty(N, dtype=torch.float32, device=dev) if want_log_prob else None
     check(_native.lib().pfrl_ppo_act_head(_ptr(h), _ptr(w_policy), _ptr(b_policy), _ptr(w_value),
                                           _ptr(b_value), _ptr(u01), None, _ptr(action), _ptr(entropy),
-                                          _ptr(value), _ptr(logp) if logp is not None else None,
-                                          N, K, A, _stream()), "ppo_act_head")
+                                          _ptr_dense(value), _ptr(logp) if logp is not None else None,
+                                          N, K, A, _ptr(rows) if rows is not None else None, _stream()),
+          "ppo_act_head")
     return (action, entropy, value, logp) if want_log_prob else (action, entropy, value)
 
 
@@ -495,7 +508,7 @@ def ppo_value_head(h, w_policy, b_policy, w_value, b_value, actions, out_log_pro
         _ptr(h), _ptr(w_policy), _ptr(b_policy), _ptr(w_value), _ptr(b_value), None,
         _ptr(actions) if actions is not None else _ptr(_zeros_i64(N, h.device)), None, None,
         _ptr(out_value), _ptr(out_log_prob) if actions is not None else None, N, K,
-        w_policy.shape[0], _stream()), "ppo_value_head")
+        w_policy.shape[0], None, _stream()), "ppo_value_head")
 
 
 _ZI64 = {}

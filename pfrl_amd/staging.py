@@ -86,6 +86,25 @@ class StagingRing:
             self._dev_ptr[token] = dev_ptr
         return dst
 
+    def upload_to(self, dst, arrays):
+        """:meth:`upload` with the bytes shipped into ``dst`` (a device uint8 tensor that keeps its
+        address: the input block of a captured graph); arrays are laid out back to back at
+        16-byte aligned offsets, as :meth:`upload` lays them out."""
+        i = self._i
+        self._i = (i + 1) % self.n_slots
+        self._wait(i)
+        hb = self._host_np[i]
+        off = 0
+        for a in arrays:
+            a = np.ascontiguousarray(a)
+            off = (off + 15) & ~15
+            nb = a.nbytes
+            if off + nb > self.slot_bytes or off + nb > dst.numel():
+                raise ValueError("staging slot / destination too small: need %d bytes" % (off + nb))
+            hb[off:off + nb] = a.view(np.uint8).reshape(-1)
+            off += nb
+        return self.commit_to(i, off, dst)
+
     @staticmethod
     def view(dev, offset, count, dtype, shape=None):
         """Typed view of ``count`` elements at byte ``offset`` of a staged device buffer."""

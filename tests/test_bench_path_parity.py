@@ -521,6 +521,53 @@ def test_ppo_act_graph_equals_the_eager_act_path(monkeypatch):
     assert not _ActGraph(agent).applicable()
 
 
+def test_ppo_act_step_into_the_rollout_columns_equals_the_copying_step(monkeypatch):
+    """Round 6: a captured acting step that writes its outputs where they belong -- actions into the
+    rollout's action column, (entropy, value) into the ring the statistics windows read, frame slots
+    and the two row indices arriving in ONE staging transfer (``_ActGraph.run_in_place``) --
+    against the round-5 step (graph outputs cloned, the action copied into its column): same
+    generator use, so two rollouts + updates give the same actions at every step, the same
+    statistics and bit-identical parameters."""
+    import bench
+
+    dev = torch.device("cuda:0")
+    N, T = 64, 24
+
+    def run(in_place):
+        monkeypatch.setenv("PFRL_PPO_ACT_IN_PLACE", "1" if in_place else "0")
+        args = _bench_args(algo="ppo", num_envs=N)
+        agent, env, _ = bench.build_agent(args, dev, 0)
+        agent.update_interval = N * T
+        agent.minibatch_size = N * T // 4
+        torch.manual_seed(11)
+        obss = env.reset()
+        acts = []
+        for step in range(2 * T + 3):
+            if in_place and step == 7:
+                # a capture in the MIDDLE of a rollout (a changed module tree would cause one): its
+                # warm-up launches must not touch rows that already hold the rollout's data
+                agent._act_graph.entries.clear()
+            a = agent.batch_act(obss)
+            acts.append(np.asarray(a).copy())
+            obss, rs, dones, _ = env.step(a)
+            agent.batch_observe(obss, rs, dones, np.zeros(N, dtype=bool))
+            obss = env.reset(~np.asarray(dones))
+        torch.cuda.synchronize()
+        stats = dict(agent.get_statistics())
+        return acts, [p.detach().cpu().clone() for p in agent.model.parameters()], stats, agent
+
+    a0, p0, s0, ag0 = run(False)
+    a1, p1, s1, ag1 = run(True)
+    assert ag1._stats_ring_buf is not None and ag0._stats_ring_buf is None
+    assert ag0.n_updates == ag1.n_updates == 2 * 4 * 4
+    for t, (x, y) in enumerate(zip(a0, a1)):
+        np.testing.assert_array_equal(x, y, err_msg="step %d" % t)
+    for x, y in zip(p0, p1):
+        assert torch.equal(x, y)
+    for k in ("average_value", "average_entropy", "average_value_loss", "average_policy_loss"):
+        assert s0[k] == s1[k], (k, s0[k], s1[k])
+
+
 def test_ppo_captured_minibatch_update_equals_the_eager_update(monkeypatch):
     """One minibatch update of PPO (gather, forward, loss, backward, clipping, Adam) replayed from
     a HIP graph (agents/ppo.py::_minibatch_step, default) against the eager launch sequence
