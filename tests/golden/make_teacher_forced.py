@@ -288,6 +288,73 @@ def sac(steps=240, N=2, obs_dim=24, act_dim=3):
                                  for k in SAC_UPDATES})
 
 
+TD3_UPDATES = (1, 90, 180)
+
+
+def td3(steps=260, N=2, obs_dim=24, act_dim=3):
+    """The reference's TD3 run of agent_trace_td3.npz again (asserted: same critic losses),
+    recording for updates TD3_UPDATES what one ``update`` (pfrl/agents/td3.py:181-262) depends on --
+    the six networks' parameters before it (policy, twin Q and their three targets) and the
+    minibatch -- and its losses: both critic losses, and for updates that also step the policy
+    (every ``policy_update_delay`` = 2nd) the policy loss, evaluated as the reference does after
+    the critics' steps.  Exploration noise and target smoothing are the deterministic stand-ins of
+    the trace (the CPU and GPU generators differ by construction)."""
+    import tempfile
+
+    import pfrl
+    from pfrl import agents, experiments, explorers, replay_buffers
+
+    sys.path.insert(0, os.path.join(HERE, "..", ".."))
+    from pfrl_amd.envs.synthetic import HostSyntheticVectorObsEnv
+
+    pfrl.utils.set_random_seed(0)
+    env = HostSyntheticVectorObsEnv(N, obs_dim=obs_dim, act_dim=act_dim, seed=4, p_done=0.03)
+    torch.manual_seed(2468)
+    policy, q = mg._det_nets(obs_dim, act_dim, pfrl.nn, pfrl.policies)
+    q1, q2 = q(), q()
+    opts = [torch.optim.SGD(m.parameters(), lr=1e-2) for m in (policy, q1, q2)]
+    ag = agents.TD3(policy, q1, q2, opts[0], opts[1], opts[2], replay_buffers.ReplayBuffer(500),
+                    gamma=0.99, explorer=explorers.AdditiveGaussian(scale=0.1, low=-1.0, high=1.0),
+                    gpu=-1, replay_start_size=40, minibatch_size=16, update_interval=1,
+                    soft_update_tau=5e-3,
+                    burnin_action_func=lambda: np.random.uniform(-1, 1, size=act_dim).astype(np.float32),
+                    policy_update_delay=2, target_policy_smoothing_func=mg._shifted_smoothing)
+    flat = lambda m: np.concatenate([p.detach().numpy().ravel() for p in m.parameters()])  # noqa: E731
+    out, q_losses = {}, []
+    count = [0]
+    orig_q, orig_p = ag.update_q_func, ag.update_policy
+
+    def spy_q(batch):
+        count[0] += 1
+        k = count[0]
+        if k in TD3_UPDATES:
+            for name, m in (("policy", policy), ("q1", q1), ("q2", q2), ("tpolicy", ag.target_policy),
+                            ("tq1", ag.target_q_func1), ("tq2", ag.target_q_func2)):
+                out["u%d_%s_params" % (k, name)] = flat(m)
+            for key in ("state", "action", "reward", "next_state", "is_state_terminal", "discount"):
+                out["u%d_%s" % (k, key)] = batch[key].detach().numpy().copy()
+        orig_q(batch)
+        q_losses.append([ag.q_func1_loss_record[-1], ag.q_func2_loss_record[-1]])
+        if k in TD3_UPDATES:
+            out["u%d_q_losses" % k] = np.asarray(q_losses[-1])
+            out["u%d_with_policy" % k] = np.asarray(int(ag.q_func_n_updates % ag.policy_update_delay == 0))
+
+    def spy_p(batch):
+        k = count[0]
+        orig_p(batch)
+        if k in TD3_UPDATES:
+            out["u%d_policy_loss" % k] = np.asarray(float(ag.policy_loss_record[-1]))
+
+    ag.update_q_func, ag.update_policy = spy_q, spy_p
+    experiments.train_agent_batch(ag, env, steps, tempfile.mkdtemp())
+    g = np.load(os.path.join(HERE, "agent_trace_td3.npz"))
+    assert np.array_equal(np.asarray(q_losses), g["losses"]), "not the run of agent_trace_td3"
+    out["updates"] = np.asarray(TD3_UPDATES)
+    np.savez_compressed(os.path.join(HERE, "teacher_forced_td3.npz"), **out)
+    print("teacher_forced td3", {k: (out["u%d_q_losses" % k].tolist(), int(out["u%d_with_policy" % k]),
+                                     float(out.get("u%d_policy_loss" % k, np.nan))) for k in TD3_UPDATES})
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1:
         for fn in sys.argv[1:]:
@@ -295,6 +362,7 @@ if __name__ == "__main__":
         sys.exit(0)
     ppo()
     sac()
+    td3()
     dqn_like("dqn_uniform_n1", False, 1, False)
     dqn_like("ddqn_per_n3", True, 3, True)
     c51()

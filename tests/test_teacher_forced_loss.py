@@ -209,3 +209,82 @@ def test_teacher_forced_sac_losses_on_the_device_path():
     """... through the twin-Q MFMA launches, the fused squashed-Gaussian head and the loss kernels
     of csrc/actor.hip."""
     _check_sac(0)
+
+
+def _check_td3(gpu, **agent_kw):
+    from test_agent_parity import _shifted_smoothing
+
+    import pfrl_amd as pfrl
+    from pfrl_amd import agents, explorers, replay_buffers
+
+    g = np.load(os.path.join(GOLDEN, "teacher_forced_td3.npz"))
+    obs_dim, act_dim = 24, 3
+    torch.manual_seed(2468)
+    policy = torch.nn.Sequential(
+        torch.nn.Linear(obs_dim, 32), torch.nn.ReLU(), torch.nn.Linear(32, act_dim),
+        pfrl.nn.BoundByTanh(low=-np.ones(act_dim, dtype=np.float32),
+                            high=np.ones(act_dim, dtype=np.float32)),
+        pfrl.policies.DeterministicHead())
+
+    def q():
+        return torch.nn.Sequential(pfrl.nn.ConcatObsAndAction(),
+                                   torch.nn.Linear(obs_dim + act_dim, 32), torch.nn.ReLU(),
+                                   torch.nn.Linear(32, 1))
+
+    q1, q2 = q(), q()
+    opts = [torch.optim.SGD(m.parameters(), lr=1e-2) for m in (policy, q1, q2)]
+    ag = agents.TD3(policy, q1, q2, opts[0], opts[1], opts[2], replay_buffers.ReplayBuffer(500),
+                    gamma=0.99, explorer=explorers.AdditiveGaussian(scale=0.1, low=-1.0, high=1.0),
+                    gpu=gpu, replay_start_size=40, minibatch_size=16, update_interval=1,
+                    soft_update_tau=5e-3,
+                    burnin_action_func=lambda: np.random.uniform(-1, 1, size=act_dim).astype(np.float32),
+                    policy_update_delay=2, target_policy_smoothing_func=_shifted_smoothing, **agent_kw)
+    dev = ag.device
+    seen = {}
+    orig_record = ag._record_stats
+
+    def spy_record(st):
+        orig_record(st)
+        for name in ("loss1", "loss2", "policy_loss"):
+            if name in st:
+                seen[name] = float(st[name].detach().reshape(-1)[0].cpu())
+
+    ag._record_stats = spy_record
+    n_policy = 0
+    for k in g["updates"]:
+        for name, m in (("policy", ag.policy), ("q1", ag.q_func1), ("q2", ag.q_func2),
+                        ("tpolicy", ag.target_policy), ("tq1", ag.target_q_func1),
+                        ("tq2", ag.target_q_func2)):
+            _load_flat(m, g["u%d_%s_params" % (k, name)])
+        batch = {key: torch.as_tensor(g["u%d_%s" % (k, key)]).to(dev)
+                 for key in ("state", "action", "reward", "next_state", "is_state_terminal", "discount")}
+        with_policy = bool(int(g["u%d_with_policy" % k]))
+        seen.clear()
+        ag._update_impl(batch, with_policy)
+        want = list(g["u%d_q_losses" % k])
+        got = [seen["loss1"], seen["loss2"]]
+        names = ["Q1 loss", "Q2 loss"]
+        if with_policy:
+            n_policy += 1
+            want.append(float(g["u%d_policy_loss" % k]))
+            got.append(seen["policy_loss"])
+            names.append("policy loss")
+        else:
+            assert "policy_loss" not in seen
+        for a, b, what in zip(got, want, names):
+            assert abs(a - b) <= TOL * max(1.0, abs(b)), (int(k), what, a, float(b))
+    assert n_policy >= 2
+
+
+def test_teacher_forced_td3_losses_on_the_host_path():
+    """updates 1, 90 and 180 of the reference's TD3 run, each on the
+    reference's own six networks (policy, twin Q, their targets) and minibatch: both critic losses
+    and -- on the delayed policy updates -- the policy loss within 1e-5 (the trajectory trace holds
+    the critic losses to 1e-4 over the run and never looked at the policy loss)."""
+    _check_td3(-1)
+
+
+@pytest.mark.gpu
+def test_teacher_forced_td3_losses_on_the_device_path():
+    """... through the twin-Q launches and the MFMA linear kernels on the device."""
+    _check_td3(0)
