@@ -110,7 +110,9 @@ class ReplayActorCritic(AttributeSavingMixin, BatchAgent):
         finally:
             self._stat_sink = None
         names = sorted(sink)
-        return {"stats": torch.cat([sink[k].reshape(-1).float() for k in names]),
+        # (the statistics stay separate tensors inside the graph: packing them with a cat was one
+        # launch per update -- 64 per env step for SAC -- and the caller packs a whole range with ONE)
+        return {"parts": [sink[k].reshape(-1).float() for k in names],
                 "names": names, "sizes": [sink[k].numel() for k in names]}
 
     def update(self, experiences, errors_out=None):
@@ -131,7 +133,7 @@ class ReplayActorCritic(AttributeSavingMixin, BatchAgent):
                 self.use_graphs = False
                 self._captured = None
                 return self.update(experiences, errors_out)
-            flat = out["stats"].clone()   # the graph owns (and overwrites) its outputs
+            flat = torch.cat(out["parts"])   # (new memory: the graph owns and overwrites its outputs)
             self._record_stats(dict(zip(out["names"], torch.split(flat, out["sizes"]))))
         else:
             self._update_impl(batch, variant)
@@ -264,7 +266,7 @@ class ReplayActorCritic(AttributeSavingMixin, BatchAgent):
             while (j < len(outs) and outs[j]["names"] == outs[i]["names"]
                    and outs[j]["sizes"] == outs[i]["sizes"]):
                 j += 1
-            flat = torch.stack([o["stats"] for o in outs[i:j]])      # [updates, S], new memory
+            flat = torch.cat([p for o in outs[i:j] for p in o["parts"]]).view(j - i, -1)   # new memory
             off = 0
             st = {}
             for name, size in zip(outs[i]["names"], outs[i]["sizes"]):
