@@ -577,6 +577,116 @@ __global__ __launch_bounds__(256) void k_conv_fwd2(FwdArgs p0, FwdArgs p1) {
 }
 
 // ---------------------------------------------------------------------------------
+// The first Nature-DQN convolution (84 x 84 x 4 u8 pixels, 8 x 8 stride 4, 32 channels:
+// pfrl/q_functions + examples/atari NatureDQNHead conv1) in DIRECT form.  The implicit-GEMM
+// program above parks every input pixel in LDS four times (each pixel lies under 2 x 2 output
+// positions) and converts it from u8 four times; at Cout = 32 that operand traffic, not the MFMAs,
+// is what its workgroups spend their issue slots on (0.52-0.55 of the f32 MFMA peak).  Here a
+// workgroup stages a BAND -- the 20 input rows under 4 output rows of an image, converted once --
+// and the MFMA A fragments are read straight out of the staged pixels: unit (row, pixel) = the
+// pixel's four channels as one float4, stored as [row][pixel % 4][pixel / 4] so that the 16 lanes
+// of a fragment (16 consecutive output columns, one kernel column) read consecutive units, and
+// the (kernel row, kernel column) of a fragment is an immediate offset.  The weights never enter
+// LDS: a wave owns 16 output channels and keeps their 16 x 256 weights as MFMA B fragments in 64
+// VGPRs for its whole (persistent) life.  A workgroup takes two bands at a time -- the same band of
+// two consecutive images: 2 x 5 pixel tiles x 2 channel halves = 20 tiles, five per wave, all of
+// one channel half -- with the next unit's raw dwords in flight (registers) while it multiplies.
+// Per output element the terms enter the accumulator in the order of the tile programs with one
+// accumulator per tile (kernel row, half row, channel, column within the half): bit-identical to
+// k_conv_fwd<128, 32, ..., U8> / <64, 32, ..., U8>.
+// ---------------------------------------------------------------------------------
+constexpr int D1_HW = 84, D1_O = 20, D1_BAND_ROWS = 20, D1_AS = 21, D1_RS = 84;
+constexpr int D1_BAND_UNITS = D1_BAND_ROWS * D1_RS;       // float4 units of one staged band
+constexpr int D1_NQ = (D1_BAND_UNITS + 255) / 256;        // raw dwords per thread and band
+
+__global__ __launch_bounds__(256, 3) void k_conv1_u8_direct(
+    const uint32_t *__restrict__ x, const float *__restrict__ w, const float *__restrict__ bias,
+    float *__restrict__ y, int N, int relu, float u8_r, float u8_d, int units) {
+    __shared__ float4 band[2 * D1_BAND_UNITS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = wave & 1, ub = wave >> 1;            // channel half, which of the two bands
+    const int i = lane & 15, kq = lane >> 4;
+    // B fragments of this wave's 16 channels: [kernel row][half row] x float4 (channels of one pixel)
+    float4 bw[8][2];
+    {
+        const float *wr = w + (size_t)(16 * half + i) * 256 + 4 * kq;
+#pragma unroll
+        for (int kh = 0; kh < 8; ++kh)
+#pragma unroll
+            for (int sc = 0; sc < 2; ++sc) bw[kh][sc] = ldg4(wr + 32 * kh + 16 * sc);
+    }
+    const float bias_v = bias[16 * half + i];
+    // A fragment base (float4 units) of the wave's five pixel tiles: tile j = band pixels 16 j .. 16 j + 15
+    int abase[5];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        const int px = 16 * j + i, oh = px / D1_O, ow = px - D1_O * oh;
+        abase[j] = ub * D1_BAND_UNITS + 4 * oh * D1_RS + kq * D1_AS + ow;
+    }
+    // where this thread's raw dwords of a band go (dword d = row d / 84, pixel d % 84)
+    int sdst[D1_NQ], ssrc[D1_NQ];
+#pragma unroll
+    for (int q = 0; q < D1_NQ; ++q) {
+        const int d = min(tid + 256 * q, D1_BAND_UNITS - 1);
+        const int rr = d / D1_HW, px = d - D1_HW * rr;
+        ssrc[q] = d;
+        sdst[q] = rr * D1_RS + (px & 3) * D1_AS + (px >> 2);
+    }
+    uint32_t raw[2][D1_NQ];
+    auto fetch = [&](int unit) {
+        const int pair = unit / 5, bnd = unit - 5 * pair;
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int img = min(2 * pair + b, N - 1);
+            const uint32_t *src = x + (size_t)img * (D1_HW * D1_HW) + bnd * 16 * D1_HW;
+#pragma unroll
+            for (int q = 0; q < D1_NQ; ++q) raw[b][q] = src[ssrc[q]];
+        }
+    };
+    int unit = blockIdx.x;
+    if (unit < units) fetch(unit);
+    for (; unit < units; unit += gridDim.x) {
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int q = 0; q < D1_NQ; ++q)
+                if (tid + 256 * q < D1_BAND_UNITS)
+                    band[b * D1_BAND_UNITS + sdst[q]] = u8x4_over(raw[b][q], u8_r, u8_d);
+        __syncthreads();
+        const int next = unit + gridDim.x;
+        if (next < units) fetch(next);
+        const int pair = unit / 5, bnd = unit - 5 * pair;
+        const int img = 2 * pair + ub;
+        float *yo = y + ((size_t)img * (D1_O * D1_O) + bnd * 4 * D1_O + 4 * kq) * 32 + 16 * half + i;
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+            const float4 *ap = band + abase[j];
+#pragma unroll
+            for (int kh = 0; kh < 8; ++kh)
+#pragma unroll
+                for (int sc = 0; sc < 2; ++sc) {
+                    const float4 a = ap[kh * D1_RS + sc];
+                    const float4 b = bw[kh][sc];
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc, 0, 0, 0);
+                }
+            if (img < N) {
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    float v = acc[reg] + bias_v;
+                    if (relu) v = fmaxf(v, 0.f);
+                    yo[(size_t)(16 * j + reg) * 32] = v;
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------
 // dgrad: gradient w.r.t. the layer input, masked by the ReLU of the layer below
 // ---------------------------------------------------------------------------------
 struct DgradArgs {
@@ -1981,10 +2091,22 @@ extern "C" int pfrl_conv2d_u8nhwc4_fwd(const uint8_t *x, float divisor, const fl
     a.cps = a.K / KC;
     a.relu = relu; a.planar = planar_out; a.partial = 0;
     hipStream_t st = (hipStream_t)stream;
+    const int prog = fwd_program(a, Cout, 1, plan_rows(a.M, N));
+    // the Nature first layer wherever a one-accumulator tile program would run: the direct kernel
+    // (same bits; PFRL_CONV1_DIRECT=0 keeps the tile programs, for the comparison tests)
+    const int direct = prog_override("PFRL_CONV1_DIRECT");
+    if (direct != 0 && (prog == 3 || prog == 8) && H == D1_HW && W == D1_HW && Cout == 32 && R == 8 &&
+        S == 8 && stride == 4 && !planar_out && ((uintptr_t)x & 3) == 0 && ((uintptr_t)w & 15) == 0) {
+        const int units = (N + 1) / 2 * 5;
+        hipLaunchKernelGGL(k_conv1_u8_direct, dim3(units < 768 ? units : 768), dim3(256), 0, st,
+                           reinterpret_cast<const uint32_t *>(x), w, bias, y, N, relu, a.u8_r, a.u8_d,
+                           units);
+        PFRL_LAUNCH_CHECK();
+    }
 #define FWDU(BM, BN, WM, WN, WK, G)                                                                  \
     hipLaunchKernelGGL((k_conv_fwd<BM, BN, WM, WN, WK, G, false, false, true>),                      \
                        dim3((a.M + BM - 1) / BM, (Cout + BN - 1) / BN, 1), dim3(256), 0, st, a)
-    switch (fwd_program(a, Cout, 1, plan_rows(a.M, N))) {
+    switch (prog) {
         case 3: FWDU(64, 32, 2, 2, 1, 2); break;
         case 4: FWDU(32, 32, 2, 2, 1, 4); break;
         case 8: FWDU(128, 32, 4, 1, 1, 2); break;

@@ -176,6 +176,10 @@ def main():
                 try:
                     if "fwd" in only:
                         rows.append(("fwd (u8 input)", time_us(run_fwd_u8, args.iters), flop, bx // 4 + by + bw))
+                        # the implicit-GEMM tile program the direct kernel replaced (round 6)
+                        os.environ["PFRL_CONV1_DIRECT"] = "0"
+                        rows.append(("fwd (u8, tiles)", time_us(run_fwd_u8, args.iters), flop, bx // 4 + by + bw))
+                        os.environ.pop("PFRL_CONV1_DIRECT")
                     if "wgrad" in only:
                         rows.append(("wgrad/%d (u8)" % splits, time_us(run_wgrad_u8, args.iters), flop,
                                      bx // 4 + by + splits * stride * 4))
