@@ -28,6 +28,8 @@
 // MFMA issue is never the bound here (<= 2 us per layer even from one wave per
 // SIMD); grids are sized so that >= 256 workgroups exist at B = 32, with split-K
 // (partials + one multi-tensor reduce) where the output is small.
+#include <type_traits>
+
 #include "common.h"
 #include "rms_update.h"
 
@@ -615,7 +617,7 @@ __global__ __launch_bounds__(256, 3) void k_conv1_u8_direct(
 #pragma unroll
             for (int sc = 0; sc < 2; ++sc) bw[kh][sc] = ldg4(wr + 32 * kh + 16 * sc);
     }
-    const float bias_v = bias[16 * half + i];
+    const float4 bias_v = ldg4(bias + 16 * half + 4 * kq);
     // A fragment base (float4 units) of the wave's five pixel tiles: tile j = band pixels 16 j .. 16 j + 15
     int abase[5];
 #pragma unroll
@@ -643,9 +645,11 @@ __global__ __launch_bounds__(256, 3) void k_conv1_u8_direct(
             for (int q = 0; q < D1_NQ; ++q) raw[b][q] = src[ssrc[q]];
         }
     };
-    int unit = blockIdx.x;
-    if (unit < units) fetch(unit);
-    for (; unit < units; unit += gridDim.x) {
+    // One unit.  The loads of the NEXT unit and the stores of this one are unconditional (clamped),
+    // and the first unit is peeled below, so every path into the loop header carries the same
+    // [14 loads, 5 stores] in flight: the compiler's vmcnt for "this thread's pixels have landed" then
+    // does not also wait for the previous unit's stores to be acknowledged.
+    auto step = [&](const int unit) {
 #pragma unroll
         for (int b = 0; b < 2; ++b)
 #pragma unroll
@@ -653,37 +657,64 @@ __global__ __launch_bounds__(256, 3) void k_conv1_u8_direct(
                 if (tid + 256 * q < D1_BAND_UNITS)
                     band[b * D1_BAND_UNITS + sdst[q]] = u8x4_over(raw[b][q], u8_r, u8_d);
         __syncthreads();
-        const int next = unit + gridDim.x;
-        if (next < units) fetch(next);
+        fetch(min(unit + (int)gridDim.x, units - 1));
         const int pair = unit / 5, bnd = unit - 5 * pair;
-        const int img = 2 * pair + ub;
-        float *yo = y + ((size_t)img * (D1_O * D1_O) + bnd * 4 * D1_O + 4 * kq) * 32 + 16 * half + i;
+        // (an odd batch: the last unit's second band repeats the last image -- fetch() clamps the same
+        // way -- and both waves store the same values to the same rows; unconditional stores also let
+        // the compiler count them in vmcnt, so the wait for the next unit's pixels does not wait for
+        // this unit's stores to be acknowledged)
+        const int img = min(2 * pair + ub, N - 1);
+        // (the weights are the MFMA's A operand, the pixels its B operand: a lane then holds four
+        // consecutive channels of ONE pixel -- a float4 store -- and the products are the same)
+        float *yo = y + ((size_t)img * (D1_O * D1_O) + bnd * 4 * D1_O + i) * 32 + 16 * half + 4 * kq;
+        auto tiles = [&](auto nt, const int j0) {
+            constexpr int NT = decltype(nt)::value;
+            f32x4 acc[NT];
+            float4 a[2][NT];
 #pragma unroll
-        for (int j = 0; j < 5; ++j) {
-            f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-            const float4 *ap = band + abase[j];
-#pragma unroll
-            for (int kh = 0; kh < 8; ++kh)
-#pragma unroll
-                for (int sc = 0; sc < 2; ++sc) {
-                    const float4 a = ap[kh * D1_RS + sc];
-                    const float4 b = bw[kh][sc];
-                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc, 0, 0, 0);
-                }
-            if (img < N) {
-#pragma unroll
-                for (int reg = 0; reg < 4; ++reg) {
-                    float v = acc[reg] + bias_v;
-                    if (relu) v = fmaxf(v, 0.f);
-                    yo[(size_t)(16 * j + reg) * 32] = v;
-                }
+            for (int u = 0; u < NT; ++u) {
+                acc[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                a[0][u] = band[abase[j0 + u]];
             }
-        }
+#pragma unroll
+            for (int st = 0; st < 16; ++st) {
+                // fragments of the next (kernel row, half row) are read while this one multiplies
+                if (st + 1 < 16) {
+#pragma unroll
+                    for (int u = 0; u < NT; ++u)
+                        a[(st + 1) & 1][u] = band[abase[j0 + u] + ((st + 1) >> 1) * D1_RS + ((st + 1) & 1)];
+                }
+                const float4 b = bw[st >> 1][st & 1];
+                const float4 *ac = a[st & 1];
+#pragma unroll
+                for (int u = 0; u < NT; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(b.x, ac[u].x, acc[u], 0, 0, 0);
+#pragma unroll
+                for (int u = 0; u < NT; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(b.y, ac[u].y, acc[u], 0, 0, 0);
+#pragma unroll
+                for (int u = 0; u < NT; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(b.z, ac[u].z, acc[u], 0, 0, 0);
+#pragma unroll
+                for (int u = 0; u < NT; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(b.w, ac[u].w, acc[u], 0, 0, 0);
+                if (st + 1 < 16) __builtin_amdgcn_sched_group_barrier(0x100, NT, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 4 * NT, 0);
+            }
+#pragma unroll
+            for (int u = 0; u < NT; ++u) {
+                float4 v = make_float4(acc[u][0] + bias_v.x, acc[u][1] + bias_v.y, acc[u][2] + bias_v.z,
+                                       acc[u][3] + bias_v.w);
+                if (relu) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+                *reinterpret_cast<float4 *>(yo + (size_t)(16 * (j0 + u)) * 32) = v;
+            }
+        };
+        tiles(std::integral_constant<int, 2>{}, 0);
+        tiles(std::integral_constant<int, 2>{}, 2);
+        tiles(std::integral_constant<int, 1>{}, 4);
         __syncthreads();
-    }
+    };
+    int unit = blockIdx.x;
+    if (unit >= units) return;
+    fetch(unit);
+    step(unit);
+    for (unit += gridDim.x; unit < units; unit += gridDim.x) step(unit);
 }
 
 // ---------------------------------------------------------------------------------
@@ -2096,7 +2127,8 @@ extern "C" int pfrl_conv2d_u8nhwc4_fwd(const uint8_t *x, float divisor, const fl
     // (same bits; PFRL_CONV1_DIRECT=0 keeps the tile programs, for the comparison tests)
     const int direct = prog_override("PFRL_CONV1_DIRECT");
     if (direct != 0 && (prog == 3 || prog == 8) && H == D1_HW && W == D1_HW && Cout == 32 && R == 8 &&
-        S == 8 && stride == 4 && !planar_out && ((uintptr_t)x & 3) == 0 && ((uintptr_t)w & 15) == 0) {
+        S == 8 && stride == 4 && !planar_out && ((uintptr_t)x & 3) == 0 &&
+        (((uintptr_t)w | (uintptr_t)bias | (uintptr_t)y) & 15) == 0) {
         const int units = (N + 1) / 2 * 5;
         hipLaunchKernelGGL(k_conv1_u8_direct, dim3(units < 768 ? units : 768), dim3(256), 0, st,
                            reinterpret_cast<const uint32_t *>(x), w, bias, y, N, relu, a.u8_r, a.u8_d,
