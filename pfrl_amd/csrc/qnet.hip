@@ -1307,6 +1307,169 @@ __global__ __launch_bounds__(256) void k_conv_wgrad(WgradArgs p) {
     wgrad_body<BI, BJ, WM, WN, WK, G, TAIL, U8>(p, blockIdx.x, blockIdx.y, blockIdx.z, smem);
 }
 
+// ---------------------------------------------------------------------------------
+// Weight gradient of the first Nature convolution on u8 pixels, direct form (see k_conv1_u8_direct).
+// The tile program <32, 256, ..., U8> rebuilds the 32 x 256 patch matrix of every chunk of 32
+// output pixels in LDS: each input pixel is loaded, converted and parked four times.  Here a
+// workgroup (one split-K slab = a range of chunks, as before) keeps a RING of converted input
+// rows -- indexed by the global row number (image * 84 + row) mod 24, every row staged once as the
+// chunks walk down the images -- and the MFMA B fragments (16 consecutive patch elements of one
+// kernel row = 4 pixels x 4 channels, contiguous in the input row) are read straight from it;
+// rows 0..3 of the ring are mirrored behind row 23 so that the 8 kernel rows of a patch are
+// always consecutive (immediate offsets).  Within a row, bit 4 of the float offset is flipped by
+// bit 6: the lanes of a fragment whose pixels lie 4 output columns apart (64 floats) then hit
+// different banks.  dy chunks are parked as in the tile program.  Per element of dW the terms
+// enter the accumulator in the tile program's order (chunk, half chunk, t, and 4 k + t inside
+// the MFMA), the bias gradient in pixel order: bit-identical slabs.
+// ---------------------------------------------------------------------------------
+// (a row holds 84 pixels; the bit flip sends pixels 80..83 to 84..87: rows of 88 pixels)
+constexpr int W1_RING = 24, W1_ROWS = 28, W1_RSF = 352, W1_LDA = 36, W1_NQ = 4;
+
+__global__ __launch_bounds__(256, 3) void k_conv1_u8_wgrad_direct(
+    const float *__restrict__ dy, const float *__restrict__ dymask, const uint32_t *__restrict__ x,
+    float *__restrict__ dw, float *__restrict__ db, long long dw_stride, long long db_stride, int N,
+    int M, int cps, float u8_r, float u8_d) {
+    __shared__ __attribute__((aligned(16))) float ring[W1_ROWS * W1_RSF];
+    __shared__ __attribute__((aligned(16))) float As[2][32 * W1_LDA];
+    const int tid = threadIdx.x, lane = tid & 63, wn = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 15, kq = lane >> 4;
+    const int nch = (M + 31) / 32;
+    const int c0 = blockIdx.x * cps, c1 = min(c0 + cps, nch);
+    if (c0 >= c1) return;
+    const int last_row = N * D1_HW - 1;
+    const bool has_mask = dymask != nullptr;
+    // first input row (global numbering) of the patches of global output row G = pixel / 20
+    auto patch_row = [](int G) { return 4 * (G + G / D1_O); };
+    // rows [.., need(c)) must be staged before chunk c is multiplied
+    auto need = [&](int c) { return patch_row(min(32 * c + 31, M - 1) / D1_O) + 8; };
+
+    // this thread's dwords of a run of rows: dword d = tid + 256 q -> row d / 84, pixel d % 84
+    int rr[W1_NQ], rpx[W1_NQ], rdst[W1_NQ];
+#pragma unroll
+    for (int q = 0; q < W1_NQ; ++q) {
+        const int d = tid + 256 * q;
+        rr[q] = d / D1_HW;
+        rpx[q] = d - D1_HW * rr[q];
+        rdst[q] = 4 * (rpx[q] ^ (((rpx[q] >> 4) & 1) << 2));
+    }
+    uint32_t raw[W1_NQ];
+    auto fetch_rows = [&](int lo) {      // (rows past the run are loaded too, clamped: never parked)
+#pragma unroll
+        for (int q = 0; q < W1_NQ; ++q)
+            raw[q] = x[(size_t)min(lo + rr[q], last_row) * D1_HW + rpx[q]];
+    };
+    auto stash_rows = [&](int lo, int hi) {
+        const int lo24 = lo % W1_RING, nd = (hi - lo) * D1_HW;
+#pragma unroll
+        for (int q = 0; q < W1_NQ; ++q) {
+            if (tid + 256 * q >= nd) continue;
+            int idx = lo24 + rr[q];
+            idx -= idx >= W1_RING ? W1_RING : 0;
+            const float4 v = u8x4_over(raw[q], u8_r, u8_d);
+            *reinterpret_cast<float4 *>(&ring[idx * W1_RSF + rdst[q]]) = v;
+            if (idx < W1_ROWS - W1_RING)
+                *reinterpret_cast<float4 *>(&ring[(idx + W1_RING) * W1_RSF + rdst[q]]) = v;
+        }
+    };
+    // dy chunk: thread -> (pixel tid / 8, channels 4 (tid % 8) ..)
+    float4 dv, dh;
+    bool dok;
+    auto fetch_dy = [&](int c) {
+        const int m = 32 * c + (tid >> 3);
+        dok = m < M;
+        const size_t off = dok ? (size_t)m * 32 + 4 * (tid & 7) : (size_t)0;
+        dv = ldg4(dy + off);
+        if (has_mask) dh = ldg4(dymask + off);
+    };
+    auto stash_dy = [&](int buf) {
+        float4 v = zero_unless(dv, dok);
+        if (has_mask) v = relu_mask(v, dh);
+        *reinterpret_cast<float4 *>(&As[buf][(tid >> 3) * W1_LDA + 4 * (tid & 7)]) = v;
+    };
+
+    f32x4 acc[2][4];
+#pragma unroll
+    for (int am = 0; am < 2; ++am)
+#pragma unroll
+        for (int an = 0; an < 4; ++an) acc[am][an] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float bsum = 0.f;
+    const bool do_bias = db != nullptr;
+
+    auto compute = [&](int c) {
+        const float *Ab = As[c & 1];
+#pragma unroll
+        for (int sc = 0; sc < 2; ++sc) {
+            // the four pixels 4 kq .. 4 kq + 3 of this half chunk lie in ONE output row (20 % 4 == 0);
+            // pixels past M (a ragged last chunk) read the last pixel group: their dy is zero
+            const int px0 = min(32 * c + 16 * sc + 4 * kq, M - 4);
+            const int G = px0 / D1_O, ow0 = px0 - D1_O * G;
+            const float *rb = ring + (patch_row(G) % W1_RING + 2 * wn) * W1_RSF + i;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                // u = output column + kernel column / 4: patch floats 16 u .. 16 u + 15 of the row
+                const int u0 = ow0 + t, u1 = u0 + 1;
+                const float *b0 = rb + 16 * (u0 ^ ((u0 >> 2) & 1));
+                const float *b1 = rb + 16 * (u1 ^ ((u1 >> 2) & 1));
+                const float *ap = Ab + (16 * sc + 4 * kq + t) * W1_LDA + i;
+                const float a0 = ap[0], a1 = ap[16];
+                const float b[4] = {b0[0], b1[0], b0[W1_RSF], b1[W1_RSF]};
+#pragma unroll
+                for (int am = 0; am < 2; ++am)
+#pragma unroll
+                    for (int an = 0; an < 4; ++an)
+                        acc[am][an] = __builtin_amdgcn_mfma_f32_16x16x4f32(am ? a1 : a0, b[an],
+                                                                           acc[am][an], 0, 0, 0);
+            }
+        }
+        if (do_bias && tid < 32) {
+#pragma unroll 8
+            for (int kk = 0; kk < 32; ++kk) bsum += Ab[kk * W1_LDA + tid];
+        }
+    };
+
+    // prologue: the rows of the first chunk (up to 20: two runs), its dy, and the loads of the second
+    int staged = patch_row(32 * c0 / D1_O);
+    for (const int n0 = need(c0); staged < n0;) {
+        const int hi = min(staged + 12, n0);
+        fetch_rows(staged);
+        stash_rows(staged, hi);
+        staged = hi;
+    }
+    fetch_dy(c0);
+    stash_dy(c0 & 1);
+    int lo1 = staged, hi1 = staged;
+    if (c0 + 1 < c1) {
+        hi1 = max(staged, need(c0 + 1));
+        fetch_rows(lo1);
+        fetch_dy(c0 + 1);
+    }
+    __syncthreads();
+    for (int c = c0; c < c1; ++c) {
+        if (c + 1 < c1) {
+            stash_rows(lo1, hi1);
+            stash_dy((c + 1) & 1);
+            staged = hi1;
+        }
+        if (c + 2 < c1) {
+            lo1 = staged;
+            hi1 = max(staged, need(c + 2));
+            fetch_rows(lo1);
+            fetch_dy(c + 2);
+        }
+        compute(c);
+        __syncthreads();
+    }
+    float *dwp = dw + (size_t)blockIdx.x * dw_stride;
+#pragma unroll
+    for (int am = 0; am < 2; ++am)
+#pragma unroll
+        for (int an = 0; an < 4; ++an)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg)
+                dwp[(size_t)(16 * am + 4 * kq + reg) * 256 + 64 * wn + 16 * an + i] = acc[am][an][reg];
+    if (do_bias && tid < 32) db[(size_t)blockIdx.x * db_stride + tid] = bsum;
+}
+
 template <int BI, int BJ, int WM, int WN, int WK, int G, bool TAIL>
 __global__ __launch_bounds__(256) void k_conv_wgrad2(WgradArgs p0, WgradArgs p1, int nz) {
     __shared__ __attribute__((aligned(16))) float smem[wgrad_smem(BI, BJ, WM, WN, WK, G)];
@@ -2364,6 +2527,15 @@ extern "C" int pfrl_conv2d_u8nhwc4_bwd_weight(const float *dy, const float *dy_m
     // (the rule of pfrl_conv2d_nhwc_bwd_weight for these Cout: keep in step)
     int prog = 0;
     if (a.M >= 16384) prog = a.K % 256 == 0 ? 5 : (a.K % 128 == 0 ? 4 : 0);
+    // the Nature first layer where the 32 x 256 tile program would run: the direct kernel (same slabs)
+    if (prog == 5 && prog_override("PFRL_CONV1_DIRECT") != 0 && H == D1_HW && W == D1_HW && Cout == 32 &&
+        R == 8 && S == 8 && stride == 4 && ((uintptr_t)x & 3) == 0 &&
+        (((uintptr_t)dy | (uintptr_t)dy_mask) & 15) == 0) {
+        hipLaunchKernelGGL(k_conv1_u8_wgrad_direct, dim3(splits), dim3(256), 0, st, dy, dy_mask,
+                           reinterpret_cast<const uint32_t *>(x), dw_part, db_part, (long long)dw_stride,
+                           (long long)db_stride, N, a.M, a.cps, a.u8_r, a.u8_d);
+        PFRL_LAUNCH_CHECK();
+    }
 #define WGU(BI, BJ, WM, WN, WK, G)                                                                   \
     hipLaunchKernelGGL((k_conv_wgrad<BI, BJ, WM, WN, WK, G, false, true>),                           \
                        dim3(Cout / BI, a.K / BJ, splits), dim3(256), 0, st, a)

@@ -183,6 +183,10 @@ def main():
                     if "wgrad" in only:
                         rows.append(("wgrad/%d (u8)" % splits, time_us(run_wgrad_u8, args.iters), flop,
                                      bx // 4 + by + splits * stride * 4))
+                        os.environ["PFRL_CONV1_DIRECT"] = "0"
+                        rows.append(("wgrad (u8,tiles)", time_us(run_wgrad_u8, args.iters), flop,
+                                     bx // 4 + by + splits * stride * 4))
+                        os.environ.pop("PFRL_CONV1_DIRECT")
                 except RuntimeError as e:
                     print("# conv1 u8 forms at B = %d: %s" % (B, str(e)[:120]))
                 del px
