@@ -1322,8 +1322,9 @@ __global__ __launch_bounds__(256) void k_conv_wgrad(WgradArgs p) {
 // enter the accumulator in the tile program's order (chunk, half chunk, t, and 4 k + t inside
 // the MFMA), the bias gradient in pixel order: bit-identical slabs.
 // ---------------------------------------------------------------------------------
-// (a row holds 84 pixels; the bit flip sends pixels 80..83 to 84..87: rows of 88 pixels)
-constexpr int W1_RING = 24, W1_ROWS = 28, W1_RSF = 352, W1_LDA = 36, W1_NQ = 4;
+// (a row holds 84 pixels and the bit flip sends pixels 80..83 to 84..87; 96 pixels = 384 floats per row
+// keep bits 6..7 of a byte offset inside the row, which is what compute() flips)
+constexpr int W1_RING = 24, W1_ROWS = 28, W1_RSF = 384, W1_LDA = 36, W1_NQ = 4;
 
 __global__ __launch_bounds__(256, 3) void k_conv1_u8_wgrad_direct(
     const float *__restrict__ dy, const float *__restrict__ dymask, const uint32_t *__restrict__ x,
@@ -1331,6 +1332,9 @@ __global__ __launch_bounds__(256, 3) void k_conv1_u8_wgrad_direct(
     int M, int cps, float u8_r, float u8_d) {
     __shared__ __attribute__((aligned(16))) float ring[W1_ROWS * W1_RSF];
     __shared__ __attribute__((aligned(16))) float As[2][32 * W1_LDA];
+    // per chunk parity and pixel group (half chunk, kq): byte offset in the ring of the group's first
+    // patch column, see group_entry()
+    __shared__ int gtab[2][8];
     const int tid = threadIdx.x, lane = tid & 63, wn = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 15, kq = lane >> 4;
     const int nch = (M + 31) / 32;
@@ -1395,21 +1399,30 @@ __global__ __launch_bounds__(256, 3) void k_conv1_u8_wgrad_direct(
     float bsum = 0.f;
     const bool do_bias = db != nullptr;
 
+    // Group g = 4 sc + kq of chunk c: the four pixels 32 c + 4 g .. + 3 lie in ONE output row
+    // (20 % 4 == 0); pixels past M (a ragged last chunk) read the last pixel group: their dy is zero.
+    // The entry is the ring byte offset of patch column block u = ow0 of kernel row 0, with the
+    // block's flip bit f = (ow0 / 4) & 1 already applied: block ow0 + t is then the entry ^ 64 t for
+    // t < 4, and block ow0 + 4 (flip bit !f) is (entry ^ 64) + 256.  Eight threads of wave 1 fill the
+    // table of the NEXT chunk while the others park its operands: two divisions per chunk instead
+    // of two per lane (vector instructions are not hidden behind the MFMAs: they add to them).
+    auto group_entry = [&](int c, int g) {
+        const int px0 = min(32 * c + 4 * g, M - 4);
+        const int G = px0 / D1_O, ow0 = px0 - D1_O * G;
+        return 4 * ((patch_row(G) % W1_RING) * W1_RSF + 16 * ow0 + 16 * ((ow0 >> 2) & 1));
+    };
+    const int lane_off = 4 * i + 4 * 2 * wn * W1_RSF;       // this lane's column, this wave's kernel rows
+    const char *ringb = reinterpret_cast<const char *>(ring);
     auto compute = [&](int c) {
         const float *Ab = As[c & 1];
 #pragma unroll
         for (int sc = 0; sc < 2; ++sc) {
-            // the four pixels 4 kq .. 4 kq + 3 of this half chunk lie in ONE output row (20 % 4 == 0);
-            // pixels past M (a ragged last chunk) read the last pixel group: their dy is zero
-            const int px0 = min(32 * c + 16 * sc + 4 * kq, M - 4);
-            const int G = px0 / D1_O, ow0 = px0 - D1_O * G;
-            const float *rb = ring + (patch_row(G) % W1_RING + 2 * wn) * W1_RSF + i;
+            const int P = gtab[c & 1][4 * sc + kq] + lane_off;
+            const int blk[5] = {P, P ^ 64, P ^ 128, P ^ 192, (P ^ 64) + 256};
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                // u = output column + kernel column / 4: patch floats 16 u .. 16 u + 15 of the row
-                const int u0 = ow0 + t, u1 = u0 + 1;
-                const float *b0 = rb + 16 * (u0 ^ ((u0 >> 2) & 1));
-                const float *b1 = rb + 16 * (u1 ^ ((u1 >> 2) & 1));
+                const float *b0 = reinterpret_cast<const float *>(ringb + blk[t]);
+                const float *b1 = reinterpret_cast<const float *>(ringb + blk[t + 1]);
                 const float *ap = Ab + (16 * sc + 4 * kq + t) * W1_LDA + i;
                 const float a0 = ap[0], a1 = ap[16];
                 const float b[4] = {b0[0], b1[0], b0[W1_RSF], b1[W1_RSF]};
@@ -1437,6 +1450,7 @@ __global__ __launch_bounds__(256, 3) void k_conv1_u8_wgrad_direct(
     }
     fetch_dy(c0);
     stash_dy(c0 & 1);
+    if (tid >= 64 && tid < 72) gtab[c0 & 1][tid - 64] = group_entry(c0, tid - 64);
     int lo1 = staged, hi1 = staged;
     if (c0 + 1 < c1) {
         hi1 = max(staged, need(c0 + 1));
@@ -1448,6 +1462,7 @@ __global__ __launch_bounds__(256, 3) void k_conv1_u8_wgrad_direct(
         if (c + 1 < c1) {
             stash_rows(lo1, hi1);
             stash_dy((c + 1) & 1);
+            if (tid >= 64 && tid < 72) gtab[(c + 1) & 1][tid - 64] = group_entry(c + 1, tid - 64);
             staged = hi1;
         }
         if (c + 2 < c1) {
