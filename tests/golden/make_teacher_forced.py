@@ -12,7 +12,7 @@ on -- the online and target parameters BEFORE the update and the minibatch ``exp
 computed.  A test can then load exactly that state into the device path and compare that one
 number at the north-star tolerance (1e-5), wherever in the trajectory it sits.
 
-Output: tests/golden/teacher_forced_{dqn_uniform_n1,ddqn_per_n3,c51_per_n3,ppo}.npz
+Output: tests/golden/teacher_forced_{dqn_uniform_n1,ddqn_per_n3,c51_per_n3,ppo,sac,td3,iqn_per_n3,a2c}.npz
 """
 import os
 import sys
@@ -355,6 +355,161 @@ def td3(steps=260, N=2, obs_dim=24, act_dim=3):
                                      float(out.get("u%d_policy_loss" % k, np.nan))) for k in TD3_UPDATES})
 
 
+A2C_UPDATES = {True: (1, 12, 30), False: (1, 30)}
+
+
+def _as_u8(x):
+    """phi(x) = float32(x) / 255 of u8 frames, stored as the frames (a quarter of the bytes, and
+    they compress): float32(u8) / 255 gives every value back exactly (asserted)."""
+    u = np.rint(np.asarray(x, dtype=np.float64) * 255).astype(np.uint8)
+    assert np.array_equal(u.astype(np.float32) / 255, x)
+    return u
+
+
+def a2c(steps=600, N=4):
+    """The reference's A2C (the networks / environment of agent_trace_a2c_gae{0,1}, a longer run:
+    30 updates) recording, for the updates of A2C_UPDATES, what ONE ``update``
+    (pfrl/agents/a2c.py:169-213) depends on -- the parameters before it and the rollout storage
+    (states, actions, rewards, masks, value predictions) -- and what it produces: the three loss
+    terms (read through the moving averages with their decay set to 0 for that update, which makes
+    the average the term itself) and the parameters after the clipped SGD step."""
+    import tempfile
+
+    import pfrl
+    from pfrl import agents, experiments
+    from pfrl.policies import SoftmaxCategoricalHead
+
+    sys.path.insert(0, os.path.join(HERE, "..", ".."))
+    from pfrl_amd.envs.synthetic import HostSyntheticAtariVectorEnv
+
+    out = {}
+    for use_gae in (True, False):
+        pfrl.utils.set_random_seed(0)
+        env = HostSyntheticAtariVectorEnv(N, seed=7, frame_shape=(12, 12), p_done=0.08)
+
+        def phi(x):
+            return np.asarray(x, dtype=np.float32) / 255
+
+        model = mg.make_ppo_model(4 * 144, 6, SoftmaxCategoricalHead, pfrl.nn.Branched)
+        opt = torch.optim.SGD(model.parameters(), lr=1e-2)
+        ag = agents.A2C(model, opt, gamma=0.99, num_processes=N, gpu=-1, update_steps=5, phi=phi,
+                        use_gae=use_gae, tau=0.95, max_grad_norm=0.5)
+        flat = lambda: np.concatenate([p.detach().numpy().ravel() for p in model.parameters()])  # noqa: E731
+        count = [0]
+        orig = ag.update
+        tag = "gae%d" % int(use_gae)
+
+        def spy(_orig=orig, _ag=ag, _count=count, _tag=tag, _use_gae=use_gae, _flat=flat):
+            _count[0] += 1
+            k = _count[0]
+            if k not in A2C_UPDATES[_use_gae]:
+                return _orig()
+            pre = "%s_u%d_" % (_tag, k)
+            out[pre + "params"] = _flat()
+            for key in ("states", "actions", "rewards", "masks", "value_preds"):
+                out[pre + key] = getattr(_ag, key).detach().numpy().copy()
+            out[pre + "states"] = _as_u8(out[pre + "states"])
+            saved = (_ag.average_actor_loss, _ag.average_value, _ag.average_entropy,
+                     _ag.average_actor_loss_decay, _ag.average_value_decay, _ag.average_entropy_decay)
+            _ag.average_actor_loss_decay = _ag.average_value_decay = _ag.average_entropy_decay = 0.0
+            _ag.average_actor_loss = _ag.average_value = _ag.average_entropy = 0.0
+            _orig()
+            out[pre + "losses"] = np.asarray([_ag.average_value, _ag.average_actor_loss,
+                                              _ag.average_entropy])        # value, action, entropy
+            (_, _, _, _ag.average_actor_loss_decay, _ag.average_value_decay,
+             _ag.average_entropy_decay) = saved
+            # the moving averages as the unmodified run would hold them
+            _ag.average_actor_loss = saved[0] + (1 - saved[3]) * (out[pre + "losses"][1] - saved[0])
+            _ag.average_value = saved[1] + (1 - saved[4]) * (out[pre + "losses"][0] - saved[1])
+            _ag.average_entropy = saved[2] + (1 - saved[5]) * (out[pre + "losses"][2] - saved[2])
+            out[pre + "returns"] = _ag.returns.numpy().copy()
+            out[pre + "params_after"] = _flat()
+
+        ag.update = spy
+        experiments.train_agent_batch(ag, env, steps, tempfile.mkdtemp())
+        assert count[0] >= max(A2C_UPDATES[use_gae]), count
+        out[tag + "_updates"] = np.asarray(A2C_UPDATES[use_gae])
+    np.savez_compressed(os.path.join(HERE, "teacher_forced_a2c.npz"), **out)
+    print("teacher_forced a2c", {k: out[k].tolist() for k in out if k.endswith("losses")})
+
+
+def iqn(steps=640, N=4):
+    """The reference's IQN + PER (n = 3) run of agent_trace_iqn_per_n3.npz again (asserted: same
+    losses), recording for updates {1, 50, 140} what one ``_compute_loss``
+    (pfrl/agents/iqn.py:340-400 with :285-338) depends on: the online / target parameters, the
+    minibatch, and the three threshold draws it makes (taus, taus_tilde, taus_prime, in the order
+    the CPU generator served them) -- and the loss."""
+    import tempfile
+
+    import pfrl
+    from pfrl import agents, explorers, experiments, replay_buffers
+    from pfrl.agents import iqn as riqn
+
+    sys.path.insert(0, os.path.join(HERE, "..", ".."))
+    from pfrl_amd.envs.synthetic import HostSyntheticAtariVectorEnv
+
+    pfrl.utils.set_random_seed(0)
+    env = HostSyntheticAtariVectorEnv(N, seed=13, frame_shape=(12, 12), p_done=0.04)
+
+    def phi(x):
+        return np.asarray(x, dtype=np.float32) / 255
+
+    torch.manual_seed(9753)
+    q = riqn.ImplicitQuantileQFunction(
+        psi=torch.nn.Sequential(torch.nn.Flatten(), torch.nn.Linear(4 * 144, 32), torch.nn.ReLU()),
+        phi=torch.nn.Sequential(riqn.CosineBasisLinear(16, 32), torch.nn.ReLU()),
+        f=torch.nn.Linear(32, 6))
+    opt = torch.optim.SGD(q.parameters(), lr=1e-2)
+    rbuf = replay_buffers.PrioritizedReplayBuffer(200, alpha=0.5, beta0=0.4, betasteps=100,
+                                                  num_steps=3, normalize_by_max="memory")
+    ex = explorers.LinearDecayEpsilonGreedy(1.0, 0.1, 400, lambda: np.random.randint(6))
+    ag = agents.IQN(q, opt, rbuf, 0.99, ex, gpu=-1, replay_start_size=40, minibatch_size=8,
+                    update_interval=4, target_update_interval=60, phi=phi,
+                    batch_accumulator="mean", quantile_thresholds_N=8,
+                    quantile_thresholds_N_prime=8, quantile_thresholds_K=4)
+    out = {}
+    record(ag, out)
+    inner = ag._compute_loss
+    count = [0]
+
+    def spy(exp_batch, errors_out=None):
+        count[0] += 1
+        k = count[0]
+        if k not in UPDATES:
+            return inner(exp_batch, errors_out)
+        draws, real = [], torch.rand
+
+        def rec(*a, **kw):
+            t = real(*a, **kw)
+            draws.append(t.numpy().copy())
+            return t
+
+        torch.rand = rec
+        try:
+            loss = inner(exp_batch, errors_out)
+        finally:
+            torch.rand = real
+        assert len(draws) == 3, len(draws)
+        for j, d in enumerate(draws):
+            out["u%d_rand%d" % (k, j)] = d
+        return loss
+
+    ag._compute_loss = spy
+    losses = []
+    orig_update = ag.update
+
+    def spy_update(exps, errors_out=None):
+        orig_update(exps, errors_out)
+        losses.append(float(ag.loss_record[-1]))
+
+    ag.replay_updater.update_func = spy_update
+    experiments.train_agent_batch(ag, env, steps, tempfile.mkdtemp())
+    for k in UPDATES:
+        for key in ("state", "next_state"):
+            out["u%d_%s" % (k, key)] = _as_u8(out["u%d_%s" % (k, key)])
+    finish("iqn_per_n3", out, losses)
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1:
         for fn in sys.argv[1:]:
@@ -366,3 +521,5 @@ if __name__ == "__main__":
     dqn_like("dqn_uniform_n1", False, 1, False)
     dqn_like("ddqn_per_n3", True, 3, True)
     c51()
+    iqn()
+    a2c()

@@ -288,3 +288,127 @@ def test_teacher_forced_td3_losses_on_the_host_path():
 def test_teacher_forced_td3_losses_on_the_device_path():
     """... through the twin-Q launches and the MFMA linear kernels on the device."""
     _check_td3(0)
+
+
+# ---------------------------------------------------------------------------------------------
+# IQN: one evaluation of pfrl/agents/iqn.py:340-400 (with :285-338) on the reference's parameters,
+# minibatch AND threshold draws (the three torch.rand calls of one _compute_loss, in order)
+# ---------------------------------------------------------------------------------------------
+def _check_iqn(gpu, **agent_kw):
+    from pfrl_amd import agents, explorers, replay_buffers
+    from pfrl_amd.agents import iqn
+
+    g = np.load(os.path.join(GOLDEN, "teacher_forced_iqn_per_n3.npz"))
+
+    def phi(x):
+        return np.asarray(x, dtype=np.float32) / 255
+
+    q = iqn.ImplicitQuantileQFunction(
+        psi=torch.nn.Sequential(torch.nn.Flatten(), torch.nn.Linear(4 * 144, 32), torch.nn.ReLU()),
+        phi=torch.nn.Sequential(iqn.CosineBasisLinear(16, 32), torch.nn.ReLU()),
+        f=torch.nn.Linear(32, 6))
+    opt = torch.optim.SGD(q.parameters(), lr=1e-2)
+    rbuf = replay_buffers.PrioritizedReplayBuffer(200, alpha=0.5, beta0=0.4, betasteps=100,
+                                                  num_steps=3, normalize_by_max="memory")
+    ex = explorers.LinearDecayEpsilonGreedy(1.0, 0.1, 400, lambda: np.random.randint(6))
+    ag = agents.IQN(q, opt, rbuf, 0.99, ex, gpu=gpu, replay_start_size=40, minibatch_size=8,
+                    update_interval=4, target_update_interval=60, phi=phi,
+                    batch_accumulator="mean", quantile_thresholds_N=8,
+                    quantile_thresholds_N_prime=8, quantile_thresholds_K=4, **agent_kw)
+    dev = ag.device
+    for k in g["updates"]:
+        _load_flat(ag.model, g["u%d_params" % k])
+        _load_flat(ag.target_model, g["u%d_target_params" % k])
+        batch = {}
+        for key in ("state", "action", "reward", "next_state", "is_state_terminal", "discount",
+                    "weights"):
+            a = g["u%d_%s" % (k, key)]
+            if key in ("state", "next_state"):          # stored as the u8 frames: phi gives them back
+                a = a.astype(np.float32) / 255
+            batch[key] = torch.as_tensor(a).to(dev)
+        draws = [torch.as_tensor(g["u%d_rand%d" % (k, j)]).to(dev) for j in range(3)]
+
+        def replay(rows, cols, _d=draws):
+            t = _d.pop(0)
+            assert tuple(t.shape) == (rows, cols), (tuple(t.shape), rows, cols)
+            return t
+
+        ag._rand = replay
+        loss = ag._compute_loss(batch, errors_out=None)[0]
+        assert not draws
+        want, got = float(g["u%d_loss" % k]), float(loss.detach().cpu())
+        assert abs(got - want) <= TOL * max(1.0, abs(want)), (int(k), got, want)
+
+
+def test_teacher_forced_iqn_losses_on_the_host_path():
+    _check_iqn(-1)
+
+
+@pytest.mark.gpu
+def test_teacher_forced_iqn_losses_on_the_device_path():
+    """The quantile-regression loss on the device (thresholds replayed from the reference's CPU
+    generator) at updates 1, 50 and 140 of the recorded run: each within 1e-5."""
+    _check_iqn(0, use_graphs=False)
+
+
+# ---------------------------------------------------------------------------------------------
+# A2C: one whole update of pfrl/agents/a2c.py:169-213 on the reference's parameters and rollout
+# storage: the three loss terms, the returns, and the parameters after the clipped SGD step
+# ---------------------------------------------------------------------------------------------
+def _check_a2c(gpu):
+    import pfrl_amd as pfrl
+    from pfrl_amd import agents
+    from pfrl_amd.policies import SoftmaxCategoricalHead
+
+    g = np.load(os.path.join(GOLDEN, "teacher_forced_a2c.npz"))
+
+    def phi(x):
+        return np.asarray(x, dtype=np.float32) / 255
+
+    T, N = 5, 4
+    for use_gae in (True, False):
+        tag = "gae%d" % int(use_gae)
+        for k in g[tag + "_updates"]:
+            pre = "%s_u%d_" % (tag, k)
+            model = torch.nn.Sequential(
+                torch.nn.Flatten(), torch.nn.Linear(4 * 144, 32), torch.nn.ReLU(),
+                pfrl.nn.Branched(torch.nn.Sequential(torch.nn.Linear(32, 6), SoftmaxCategoricalHead()),
+                                 torch.nn.Linear(32, 1)))
+            opt = torch.optim.SGD(model.parameters(), lr=1e-2)
+            ag = agents.A2C(model, opt, gamma=0.99, num_processes=N, gpu=gpu, update_steps=T, phi=phi,
+                            use_gae=use_gae, tau=0.95, max_grad_norm=0.5)
+            dev = ag.device
+            _load_flat(ag.model, g[pre + "params"])
+            states = torch.as_tensor(g[pre + "states"].astype(np.float32) / 255).to(dev)
+            actions = torch.as_tensor(g[pre + "actions"]).to(dev)
+            if gpu >= 0:
+                # the device path stores frame-slot refs and gathers the network input from HBM
+                # (tested on its own); here the "slots" index the reference's recorded states
+                table = states.reshape((T + 1) * N, *states.shape[2:])
+                ag._flush_storage(N, 1, actions[0])
+                ag.refs = torch.arange((T + 1) * N, dtype=torch.int32, device=dev).view(T + 1, N, 1)
+                ag._gather = lambda refs, _t=table: _t[refs.reshape(-1).long()]
+            else:
+                ag._flush_storage(N, tuple(states.shape[2:]), actions[0])
+                ag.refs = states.clone()
+            ag.actions = actions.reshape(ag.actions.shape).float().clone()
+            ag.rewards = torch.as_tensor(g[pre + "rewards"]).to(dev).clone()
+            ag.masks = torch.as_tensor(g[pre + "masks"]).to(dev).clone()
+            ag.value_preds = torch.as_tensor(g[pre + "value_preds"]).to(dev).clone()
+            ag.update()
+            got = np.asarray([float(v.cpu()) for v in ag._last_losses])
+            np.testing.assert_allclose(got, g[pre + "losses"], rtol=TOL, atol=TOL, err_msg=pre)
+            np.testing.assert_allclose(ag.returns.cpu().numpy(), g[pre + "returns"], rtol=TOL, atol=TOL)
+            after = np.concatenate([p.detach().cpu().numpy().ravel() for p in ag.model.parameters()])
+            np.testing.assert_allclose(after, g[pre + "params_after"], rtol=TOL, atol=1e-6, err_msg=pre)
+
+
+def test_teacher_forced_a2c_update_on_the_host_path():
+    _check_a2c(-1)
+
+
+@pytest.mark.gpu
+def test_teacher_forced_a2c_update_on_the_device_path():
+    """Return scan (pfrl_a2c_returns), losses and the clipped step on the device, on the
+    reference's storage of updates 1, 12, 30 (GAE) and 1, 30 (n-step returns): 1e-5."""
+    _check_a2c(0)
