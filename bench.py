@@ -182,7 +182,7 @@ def assemble_result(args, world, N, elapsed, n_updates, t_fill, workload, roofli
                                 "value_passes": round(vp, 4), "next_value_pass": nvp or None,
                                 "what": "acting + value pass(es) + 4 epochs x (forward + backward) of the "
                                         "rollout, per env step (FLOPs executed); per-layer fractions at B = 16384: "
-                                        "profiles/r04_layer_final.txt (tools/layer_bench.py)"}
+                                        "profiles/r06_layer_final.txt (tools/layer_bench.py)"}
             roofline["captured_launches_not_timed"] = (
                 "the 65536-frame minibatch gathers run inside the captured update graph "
                 "(agents/ppo.py::_minibatch_step) and carry no event pair; the timed launches are the "
