@@ -728,6 +728,7 @@ struct DgradArgs {
     int TH, TW, K;       // taps per class and dimension; K = TH * TW * Cout
     int permP, permC;    // dx written as [n][p][c] for c*P + p (planar -> NHWC), 0 = off
     FastDiv q_ahw, q_aw, q_st, q_permP;   // by AH * AW, AW, ST, permP
+    FastDiv q_c;                          // by C (the class of a merged column)
 };
 
 // MERGE: the ST x ST stride-parity classes of a strided convolution side by side in the tile's
@@ -787,8 +788,10 @@ __device__ __forceinline__ void dgrad_body(const DgradArgs &p, const int bx, con
             // column -> (class, input channel): the class's (ph, pw) shift of the kernel position
             // is a per-thread constant of the weight address
             const int col = n0 + bq4[pp];
-            const int cls = col / g.C, ci = col - cls * g.C;
-            const int cph = cls / g.ST, cpw = cls - cph * g.ST;
+            // (FastDiv: a compiler-expanded division is ~20 vector instructions, and these
+            // workgroups only run 4-8 chunks)
+            const int cls = fdiv(col, p.q_c), ci = col - cls * g.C;
+            const int cph = fdiv(cls, p.q_st), cpw = cls - cph * g.ST;
             bbase[pp] = (size_t)bkk[pp] * g.R * g.S * g.C + (size_t)(cph * g.S + cpw) * g.C + ci;
         } else {
             bbase[pp] = (size_t)bkk[pp] * g.R * g.S * g.C + n0 + bq4[pp];
@@ -896,9 +899,9 @@ __device__ __forceinline__ void dgrad_body(const DgradArgs &p, const int bx, con
             const int a = fdiv(rem, p.q_aw), a2 = rem - a * p.AW;
             int eph = ph, epw = pw, ec = n0 + c4;
             if (MERGE) {
-                const int cls = ec / g.C;
+                const int cls = fdiv(ec, p.q_c);
                 ec -= cls * g.C;
-                eph = cls / g.ST;
+                eph = fdiv(cls, p.q_st);
                 epw = cls - eph * g.ST;
             }
             const int ih = a * g.ST + eph, iw = a2 * g.ST + epw;
@@ -1007,8 +1010,10 @@ __device__ __forceinline__ void dgrad_pos_body(const DgradArgs &p, const int img
         bq4[pp] = 4 * (f - bkk[pp] * QPR);
         if (CLS) {
             const int col = n0 + bq4[pp];
-            const int cls = col / g.C, ci = col - cls * g.C;
-            const int cph = cls / g.ST, cpw = cls - cph * g.ST;
+            // (FastDiv: a compiler-expanded division is ~20 vector instructions, and these
+            // workgroups only run 4-8 chunks)
+            const int cls = fdiv(col, p.q_c), ci = col - cls * g.C;
+            const int cph = fdiv(cls, p.q_st), cpw = cls - cph * g.ST;
             bbase[pp] = (size_t)bkk[pp] * g.R * g.S * g.C + (size_t)(cph * g.S + cpw) * g.C + ci;
         } else {
             bbase[pp] = (size_t)bkk[pp] * g.R * g.S * g.C + n0 + bq4[pp];
@@ -1099,9 +1104,9 @@ __device__ __forceinline__ void dgrad_pos_body(const DgradArgs &p, const int img
         if (n >= g.N) continue;
         int ih = a, iw = a2, ec = n0 + c4;
         if (CLS) {
-            const int cls = ec / g.C;
+            const int cls = fdiv(ec, p.q_c);
             ec -= cls * g.C;
-            const int eph = cls / g.ST;
+            const int eph = fdiv(cls, p.q_st);
             ih = a * g.ST + eph;
             iw = a2 * g.ST + (cls - eph * g.ST);
         }
@@ -2377,6 +2382,7 @@ static int make_dgrad_args(DgradArgs &a, const float *dy, const float *dy_mask, 
     a.q_ahw = fast_div((uint32_t)(a.AH * a.AW));
     a.q_aw = fast_div((uint32_t)a.AW);
     a.q_st = fast_div((uint32_t)stride);
+    a.q_c = fast_div((uint32_t)C);
     a.q_permP = fast_div((uint32_t)(perm_p > 0 ? perm_p : 1));
     return 0;
 }
