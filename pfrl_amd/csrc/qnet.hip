@@ -1148,6 +1148,9 @@ struct WgradArgs {
     // (U8 only) the layer input as u8 NHWC4 pixels (x is unused), as in FwdArgs
     const uint8_t *xu8 = nullptr;
     float u8_r = 1.f, u8_d = 1.f;
+    // how the large tile programs turn an output row m into its patch offset (see wgrad_body):
+    // 0 two divisions per piece and chunk, 1 linear layer (the row itself), 2 table + carried (image, pixel)
+    int pix_mode = 0;
 };
 
 // TAIL: linear layers (1x1) whose in_features are not a multiple of 32 / whose rows are not
@@ -1186,6 +1189,31 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs &p, const int bx, con
         const int r = fdiv(j, g.q_sc);
         bcol[pp] = r * WC + (j - r * SC);
     }
+    // Large tile programs (rollout / update sized): the row -> patch offset of the x loader without
+    // divisions in the chunk loop.  The SQ counters put these programs at 2.6 vector instructions per
+    // MFMA and, on gfx950, those ADD to the MFMA time; two FastDiv splits per piece and
+    // chunk were a third of them.  Mode 2: the offset of pixel (oh, ow) inside an image comes from a
+    // table in LDS (OH * OW <= 400 entries, filled once), and every piece carries (image, pixel) of its
+    // row from chunk to chunk -- a row advances by 32 per chunk, 32 <= OH * OW, so one conditional wrap.
+    // Mode 1 (linear layers): the offset is the row itself.  Same addresses, same values.
+    constexpr bool PIXCAP = !TAIL && BI * BJ > 32 * 32;
+    __shared__ int pixtab[PIXCAP ? 400 : 1];
+    const int pix_mode = PIXCAP ? p.pix_mode : 0;
+    const int HWC = g.H * g.W * g.C;
+    int pn[NPB], prem[NPB], p_c = c0;
+    if (PIXCAP && pix_mode == 2) {
+        for (int e = tid; e < ohow; e += 256) {
+            const int oh = fdiv(e, g.q_ow), ow = e - oh * g.OW;
+            pixtab[e] = (oh * g.ST * g.W + ow * g.ST) * g.C;
+        }
+#pragma unroll
+        for (int pp = 0; pp < NPB; ++pp) {
+            const int m = c0 * KC + bkk[pp];
+            pn[pp] = fdiv(m, g.q_ohow);
+            prem[pp] = m - pn[pp] * ohow;
+        }
+        __syncthreads();
+    }
     struct Slot {
         float4 a[NPA], h[NPA], b[NPB];
         bool ok[NPA];
@@ -1213,11 +1241,36 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs &p, const int bx, con
             if (has_mask) sl.h[pp] = ldg4(p.dymask + off);
             sl.ok[pp] = ok;
         }
+        if (PIXCAP && pix_mode == 2 && c > p_c) {
+            // (chunks are asked for in non-decreasing order, one step at a time: run_pipeline)
+            p_c = c;
+#pragma unroll
+            for (int pp = 0; pp < NPB; ++pp) {
+                prem[pp] += KC;
+                const bool wrap = prem[pp] >= ohow;
+                prem[pp] -= wrap ? ohow : 0;
+                pn[pp] += wrap ? 1 : 0;
+            }
+        }
 #pragma unroll
         for (int pp = 0; pp < NPB; ++pp) {
             if (!b_on(pp)) continue;
             const int m = mbase + bkk[pp];
             const int mm = m < p.M ? m : 0;
+            if (PIXCAP && pix_mode != 0) {
+                size_t at;
+                if (pix_mode == 1) {
+                    at = (size_t)mm * g.C + bcol[pp];
+                } else {
+                    const bool in = m < p.M;        // (rows past M read row 0, as below)
+                    at = (size_t)(in ? pn[pp] : 0) * HWC + pixtab[in ? prem[pp] : 0] + bcol[pp];
+                }
+                if (U8)
+                    sl.b[pp].x = __uint_as_float(*reinterpret_cast<const uint32_t *>(p.xu8 + at));
+                else
+                    sl.b[pp] = ldg4(p.x + at);
+                continue;
+            }
             if (TAIL) {
                 const int K1 = p.x2 != nullptr ? p.K1 : p.K;
                 const float *row = p.x + (size_t)mm * K1;
@@ -2400,6 +2453,10 @@ static int make_wgrad_args(WgradArgs &a, const float *dy, const float *dy_mask, 
     a.K = R * S * C;
     const int nch = (a.M + KC - 1) / KC;
     a.cps = (nch + splits - 1) / splits;
+    const int ohow = g.OH * g.OW;
+    a.pix_mode = prog_override("PFRL_WGRAD_PIX") == 0 ? 0
+                 : (H == 1 && W == 1 && R == 1 && S == 1 && stride == 1) ? 1
+                 : (ohow >= KC && ohow <= 400) ? 2 : 0;
     return 0;
 }
 
