@@ -356,6 +356,19 @@ int pfrl_ppo_loss(const float *logits, const float *value, const int64_t *action
                   int32_t M, int32_t A, float clip_eps, float clip_eps_vf, float value_func_coef,
                   float entropy_coef, float *dlogits, float *dvalue, double *partial_ws, float *out4,
                   void *stream);
+/* The same loss with the two narrow heads of the example network (examples/atari/train_ppo_ale.py:
+ * nn.Linear(512, n_actions) + SoftmaxCategoricalHead, nn.Linear(512, 1) behind one body) and their
+ * backward in ONE launch: logits = h Wp^T + bp, v = h Wv^T + bv, the loss of pfrl/agents/ppo.py:634-671
+ * and its gradient, dh = dlogits Wp + dv Wv (where backward of the body starts) and the heads'
+ * parameter gradients as `blocks` partial slabs dw_part[blocks][(A + 1) * K + pad4(A + 1)] (rows 0..A-1
+ * = dWp, row A = dWv, then dbp[A], dbv; the bias block padded to a multiple of 4) for pfrl_splitk_reduce.  h is read once and dh written once.
+ * K = 256 or 512, A <= 9; partial_ws: 3 * blocks doubles; out4 as pfrl_ppo_loss. */
+int pfrl_ppo_head_loss(const float *h, const float *w_policy, const float *b_policy,
+                       const float *w_value, const float *b_value, const int64_t *action,
+                       const float *adv, const float *log_prob_old, const float *v_pred_old,
+                       const float *v_teacher, int32_t M, int32_t K, int32_t A, float clip_eps,
+                       float clip_eps_vf, float value_func_coef, float entropy_coef, float *dh,
+                       float *dw_part, int32_t blocks, double *partial_ws, float *out4, void *stream);
 
 /* ------------------------------------------------------------------------
  * Optimizer step of the DQN update (pfrl/agents/dqn.py:360-365 calls

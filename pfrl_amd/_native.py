@@ -186,6 +186,7 @@ EXPORTS = {
     "pfrl_ppo_minibatch": (ctypes.c_int, "qpppipppppippppppp"),
     "pfrl_ppo_act_head": (ctypes.c_int, "pppppppppppiiipp"),
     "pfrl_ppo_loss": (ctypes.c_int, "pppppppiiffffppppp"),
+    "pfrl_ppo_head_loss": (ctypes.c_int, "ppppppppppiiiffffppippp"),
     "pfrl_rmsprop_step": (ctypes.c_int, "ipppppffffip"),
     "pfrl_rmsprop_fused_step": (ctypes.c_int, "ipffffip"),
     "pfrl_dqn_td_loss": (ctypes.c_int, "ppppppppqiiippppp"),

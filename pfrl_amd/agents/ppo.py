@@ -113,6 +113,8 @@ def _all_minibatch_positions(n, minibatch_size, num_epochs):
     return list(_iter_minibatch_positions(n, minibatch_size, num_epochs))
 
 
+_HEAD_LOSS = os.environ.get("PFRL_PPO_HEAD_LOSS", "1") != "0"
+
 class _Rollout:
     """T x N on-device rollout (env index minor)."""
 
@@ -1018,13 +1020,25 @@ class PPO(agent.AttributeSavingMixin, agent.BatchAgent):
             # torch.distributions + autograd; backward starts at the logits / values
             body, pol, val = fused
             h = body(states)
-            logits, vs_pred = pol(h), val(h)
-            self.optimizer.zero_grad(set_to_none=True)
-            out4, dlogits, dvalue = ops.ppo_loss(
-                logits, vs_pred, mb["action"], mb["adv"], mb["log_prob"], mb["v_pred"],
-                mb["v_teacher"], self.clip_eps, self.clip_eps_vf, self.value_func_coef,
-                self.entropy_coef)
-            torch.autograd.backward([logits, vs_pred], [dlogits, dvalue])
+            if _HEAD_LOSS and ops.ppo_head_loss_ok(h, pol.weight):
+                # ... and the heads themselves, forward and backward, in the same launch: h is read
+                # once and dh written once where the library route runs five narrow GEMMs and two
+                # adds over the 16 384 rows (pfrl_ppo_head_loss; PFRL_PPO_HEAD_LOSS=0 keeps them)
+                self.optimizer.zero_grad(set_to_none=True)
+                out4, dh, (dwp, dbp, dwv, dbv) = ops.ppo_head_loss(
+                    h, pol.weight, pol.bias, val.weight, val.bias, mb["action"], mb["adv"],
+                    mb["log_prob"], mb["v_pred"], mb["v_teacher"], self.clip_eps, self.clip_eps_vf,
+                    self.value_func_coef, self.entropy_coef)
+                pol.weight.grad, pol.bias.grad, val.weight.grad, val.bias.grad = dwp, dbp, dwv, dbv
+                h.backward(dh)
+            else:
+                logits, vs_pred = pol(h), val(h)
+                self.optimizer.zero_grad(set_to_none=True)
+                out4, dlogits, dvalue = ops.ppo_loss(
+                    logits, vs_pred, mb["action"], mb["adv"], mb["log_prob"], mb["v_pred"],
+                    mb["v_teacher"], self.clip_eps, self.clip_eps_vf, self.value_func_coef,
+                    self.entropy_coef)
+                torch.autograd.backward([logits, vs_pred], [dlogits, dvalue])
             loss = out4[0]
             records = {"value_loss": out4[2], "policy_loss": out4[1]}
         else:

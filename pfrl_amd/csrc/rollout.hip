@@ -401,6 +401,76 @@ __global__ __launch_bounds__(256) void k_ppo_act_head(
 // are kept (min / max split the gradient of equal operands, clamp passes it at the bounds).
 // The sums over the batch are f64 per workgroup, folded in index order by the finish kernel.
 // ---------------------------------------------------------------------------------------
+// one row of the loss: logits z, value v -> the gradient with respect to both (g, gv: 1 / M and the
+// coefficients included) and the row's three terms (-surrogate, value loss, entropy)
+template <int A>
+__device__ __forceinline__ void ppo_loss_row(const float (&z)[A], float v, int a, float ad, float lpo,
+                                             float vo, float vt, float inv_m, float clip_eps,
+                                             float clip_eps_vf, float vf_coef, float ent_coef,
+                                             float (&g)[A], float &gv_out, double &pol, double &val,
+                                             double &ent) {
+    float mx = z[0];
+#pragma unroll
+    for (int j = 1; j < A; ++j) mx = fmaxf(mx, z[j]);
+    float e[A], sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < A; ++j) {
+        e[j] = expf(z[j] - mx);
+        sum += e[j];
+    }
+    const float lse = mx + logf(sum);
+    float H = 0.f, lpa = 0.f, p[A], lp[A];
+#pragma unroll
+    for (int j = 0; j < A; ++j) {
+        lp[j] = z[j] - lse;
+        p[j] = e[j] / sum;
+        H -= p[j] > 0.f ? p[j] * lp[j] : 0.f;
+        if (j == a) lpa = lp[j];
+    }
+    const float ratio = expf(lpa - lpo);
+    const float lo = 1.0f - clip_eps, hi = 1.0f + clip_eps;
+    const float rc = fminf(fmaxf(ratio, lo), hi);
+    const float s1 = ratio * ad, s2 = rc * ad;
+    const float surr = fminf(s1, s2);
+    // d surr / d ratio: both operands of min carry it inside the clip range (a tie: half
+    // each, summing to adv); outside only the unclipped product does, if it is the minimum
+    const bool inside = ratio >= lo && ratio <= hi;
+    float ds = 0.f;
+    if (inside) ds = ad;
+    else if (s1 < s2) ds = ad;
+    else if (s1 == s2) ds = 0.5f * ad;
+    const float g_lpa = -inv_m * ds * ratio;
+    const float ge = ent_coef * inv_m;
+#pragma unroll
+    for (int j = 0; j < A; ++j) {
+        const float onehot = j == a ? 1.f : 0.f;
+        float gj = g_lpa * (onehot - p[j]);
+        gj += p[j] > 0.f ? ge * p[j] * (lp[j] + H) : 0.f;
+        g[j] = gj;
+    }
+    const float d1 = v - vt;
+    float lv = d1 * d1, gv = 2.f * d1;
+    if (clip_eps_vf >= 0.f) {
+        const float vlo = vo - clip_eps_vf, vhi = vo + clip_eps_vf;
+        const float vc = fminf(fmaxf(v, vlo), vhi);
+        const float d2 = vc - vt;
+        const float l2 = d2 * d2;
+        // d vc / d v: torch.min(torch.max(v, lo), hi) -- 1 strictly inside, 1/2 at a bound
+        // (max / min split ties), 0 outside
+        float dvc = (v > vlo && v < vhi) ? 1.f : ((v == vlo || v == vhi) ? 0.5f : 0.f);
+        if (l2 > lv) {
+            lv = l2;
+            gv = 2.f * d2 * dvc;
+        } else if (l2 == lv) {
+            gv = 0.5f * (2.f * d1) + 0.5f * (2.f * d2 * dvc);
+        }
+    }
+    gv_out = vf_coef * inv_m * gv;
+    pol = -(double)surr;
+    val = (double)lv;
+    ent = (double)H;
+}
+
 template <int A>
 __global__ __launch_bounds__(kThreads) void k_ppo_loss(
     const float *__restrict__ logits, const float *__restrict__ value,
@@ -414,72 +484,15 @@ __global__ __launch_bounds__(kThreads) void k_ppo_loss(
     const float inv_m = 1.0f / (float)M;
     double pol = 0.0, val = 0.0, ent = 0.0;
     if (m < M) {
-        float z[A];
+        float z[A], g[A], gv;
 #pragma unroll
         for (int j = 0; j < A; ++j) z[j] = logits[(size_t)m * A + j];
-        const int a = (int)action[m];
-        const float ad = adv[m], lpo = logp_old[m], v = value[m], vt = v_teacher[m];
-        float mx = z[0];
+        ppo_loss_row<A>(z, value[m], (int)action[m], adv[m], logp_old[m],
+                        clip_eps_vf >= 0.f ? v_old[m] : 0.f, v_teacher[m], inv_m, clip_eps, clip_eps_vf,
+                        vf_coef, ent_coef, g, gv, pol, val, ent);
 #pragma unroll
-        for (int j = 1; j < A; ++j) mx = fmaxf(mx, z[j]);
-        float e[A], sum = 0.f;
-#pragma unroll
-        for (int j = 0; j < A; ++j) {
-            e[j] = expf(z[j] - mx);
-            sum += e[j];
-        }
-        const float lse = mx + logf(sum);
-        float H = 0.f, lpa = 0.f, p[A], lp[A];
-#pragma unroll
-        for (int j = 0; j < A; ++j) {
-            lp[j] = z[j] - lse;
-            p[j] = e[j] / sum;
-            H -= p[j] > 0.f ? p[j] * lp[j] : 0.f;
-            if (j == a) lpa = lp[j];
-        }
-        const float ratio = expf(lpa - lpo);
-        const float lo = 1.0f - clip_eps, hi = 1.0f + clip_eps;
-        const float rc = fminf(fmaxf(ratio, lo), hi);
-        const float s1 = ratio * ad, s2 = rc * ad;
-        const float surr = fminf(s1, s2);
-        // d surr / d ratio: both operands of min carry it inside the clip range (a tie: half
-        // each, summing to adv); outside only the unclipped product does, if it is the minimum
-        const bool inside = ratio >= lo && ratio <= hi;
-        float ds = 0.f;
-        if (inside) ds = ad;
-        else if (s1 < s2) ds = ad;
-        else if (s1 == s2) ds = 0.5f * ad;
-        const float g_lpa = -inv_m * ds * ratio;
-        const float ge = ent_coef * inv_m;
-#pragma unroll
-        for (int j = 0; j < A; ++j) {
-            const float onehot = j == a ? 1.f : 0.f;
-            float g = g_lpa * (onehot - p[j]);
-            g += p[j] > 0.f ? ge * p[j] * (lp[j] + H) : 0.f;
-            dlogits[(size_t)m * A + j] = g;
-        }
-        const float d1 = v - vt;
-        float lv = d1 * d1, gv = 2.f * d1;
-        if (clip_eps_vf >= 0.f) {
-            const float vo = v_old[m];
-            const float vlo = vo - clip_eps_vf, vhi = vo + clip_eps_vf;
-            const float vc = fminf(fmaxf(v, vlo), vhi);
-            const float d2 = vc - vt;
-            const float l2 = d2 * d2;
-            // d vc / d v: torch.min(torch.max(v, lo), hi) -- 1 strictly inside, 1/2 at a bound
-            // (max / min split ties), 0 outside
-            float dvc = (v > vlo && v < vhi) ? 1.f : ((v == vlo || v == vhi) ? 0.5f : 0.f);
-            if (l2 > lv) {
-                lv = l2;
-                gv = 2.f * d2 * dvc;
-            } else if (l2 == lv) {
-                gv = 0.5f * (2.f * d1) + 0.5f * (2.f * d2 * dvc);
-            }
-        }
-        dvalue[m] = vf_coef * inv_m * gv;
-        pol = -(double)surr;
-        val = (double)lv;
-        ent = (double)H;
+        for (int j = 0; j < A; ++j) dlogits[(size_t)m * A + j] = g[j];
+        dvalue[m] = gv;
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -500,6 +513,142 @@ __global__ __launch_bounds__(kThreads) void k_ppo_loss(
         for (int w = 0; w < kThreads / 64; ++w) t += s_red[threadIdx.x][w];
         partial[(size_t)blockIdx.x * 3 + threadIdx.x] = t;
     }
+}
+
+// ---------------------------------------------------------------------------------------
+// The two narrow heads of the example network, the loss and the heads' backward in ONE launch:
+// logits = h Wp^T + bp, v = h Wv^T + bv, the row's loss gradient (ppo_loss_row), then
+//   dh = g Wp + gv Wv           (written: where backward of the body starts)
+//   dWp, dbp, dWv, dbv          (per-workgroup partial slabs [A + 1][K] + [A + 1], folded afterwards)
+// h is read once and dh written once (2 x 33.5 MB at 16 384 x 512) where the library route runs
+// five narrow GEMMs, two elementwise adds and the loss launch over the same rows (~180 us per
+// minibatch, profiles/r06_ppo_kernel_stats.csv).  A wave owns a row: lane l holds columns
+// 4 l .. 4 l + 3 of every 256-column block of h, of the A + 1 weight rows (registers, loaded once)
+// and of the A + 1 gradient rows it accumulates; the A + 1 dot products are folded across the wave
+// by butterflies.  K = 256 or 512, A <= 9.
+// ---------------------------------------------------------------------------------------
+template <int A, int KQ>
+__global__ __launch_bounds__(256) void k_ppo_head_loss(
+    const float *__restrict__ h, const float *__restrict__ wp, const float *__restrict__ bp,
+    const float *__restrict__ wv, const float *__restrict__ bv, const int64_t *__restrict__ action,
+    const float *__restrict__ adv, const float *__restrict__ logp_old, const float *__restrict__ v_old,
+    const float *__restrict__ v_teacher, int M, int rows_per_block, float clip_eps, float clip_eps_vf,
+    float vf_coef, float ent_coef, float *__restrict__ dh, float *__restrict__ dw_part,
+    double *__restrict__ partial) {
+    constexpr int K = 256 * KQ, NO = A + 1;
+    __shared__ float s_w[NO * K + NO];
+    __shared__ double s_red[3][4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float inv_m = 1.0f / (float)M;
+    float4 w[NO][KQ], dw[NO][KQ];
+    float db[NO];
+#pragma unroll
+    for (int j = 0; j < NO; ++j) {
+        const float *src = j < A ? wp + (size_t)j * K : wv;
+#pragma unroll
+        for (int q = 0; q < KQ; ++q) {
+            w[j][q] = *reinterpret_cast<const float4 *>(src + 256 * q + 4 * lane);
+            dw[j][q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        db[j] = 0.f;
+    }
+    float bias[NO];
+#pragma unroll
+    for (int j = 0; j < A; ++j) bias[j] = bp[j];
+    bias[A] = bv[0];
+    const int r0 = blockIdx.x * rows_per_block, r1 = min(r0 + rows_per_block, M);
+    double pol = 0.0, val = 0.0, ent = 0.0;
+    float4 hv[KQ], hn[KQ];
+    int r = r0 + wave;
+    if (r < r1) {
+#pragma unroll
+        for (int q = 0; q < KQ; ++q) hn[q] = *reinterpret_cast<const float4 *>(h + (size_t)r * K + 256 * q + 4 * lane);
+    }
+    for (; r < r1; r += 4) {
+#pragma unroll
+        for (int q = 0; q < KQ; ++q) hv[q] = hn[q];
+        if (r + 4 < r1) {       // the next row of this wave is in flight while this one is worked on
+#pragma unroll
+            for (int q = 0; q < KQ; ++q)
+                hn[q] = *reinterpret_cast<const float4 *>(h + (size_t)(r + 4) * K + 256 * q + 4 * lane);
+        }
+        float z[NO];
+#pragma unroll
+        for (int j = 0; j < NO; ++j) {
+            float s = 0.f;
+#pragma unroll
+            for (int q = 0; q < KQ; ++q) {
+                s = fmaf(hv[q].x, w[j][q].x, s);
+                s = fmaf(hv[q].y, w[j][q].y, s);
+                s = fmaf(hv[q].z, w[j][q].z, s);
+                s = fmaf(hv[q].w, w[j][q].w, s);
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+            z[j] = s + bias[j];
+        }
+        float zl[A], g[A], gv;
+#pragma unroll
+        for (int j = 0; j < A; ++j) zl[j] = z[j];
+        double rp, rv, re;
+        ppo_loss_row<A>(zl, z[A], (int)action[r], adv[r], logp_old[r],
+                        clip_eps_vf >= 0.f ? v_old[r] : 0.f, v_teacher[r], inv_m, clip_eps, clip_eps_vf,
+                        vf_coef, ent_coef, g, gv, rp, rv, re);
+        pol += rp;
+        val += rv;
+        ent += re;
+        float gg[NO];
+#pragma unroll
+        for (int j = 0; j < A; ++j) gg[j] = g[j];
+        gg[A] = gv;
+#pragma unroll
+        for (int q = 0; q < KQ; ++q) {
+            float4 d = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int j = 0; j < NO; ++j) {
+                d.x = fmaf(gg[j], w[j][q].x, d.x);
+                d.y = fmaf(gg[j], w[j][q].y, d.y);
+                d.z = fmaf(gg[j], w[j][q].z, d.z);
+                d.w = fmaf(gg[j], w[j][q].w, d.w);
+                dw[j][q].x = fmaf(gg[j], hv[q].x, dw[j][q].x);
+                dw[j][q].y = fmaf(gg[j], hv[q].y, dw[j][q].y);
+                dw[j][q].z = fmaf(gg[j], hv[q].z, dw[j][q].z);
+                dw[j][q].w = fmaf(gg[j], hv[q].w, dw[j][q].w);
+            }
+            *reinterpret_cast<float4 *>(dh + (size_t)r * K + 256 * q + 4 * lane) = d;
+        }
+#pragma unroll
+        for (int j = 0; j < NO; ++j) db[j] += gg[j];
+    }
+    // the four waves' gradient rows folded in wave order through LDS, then one slab per workgroup
+    for (int wv_i = 0; wv_i < 4; ++wv_i) {
+        if (wave == wv_i) {
+#pragma unroll
+            for (int j = 0; j < NO; ++j) {
+#pragma unroll
+                for (int q = 0; q < KQ; ++q) {
+                    float4 *dst = reinterpret_cast<float4 *>(&s_w[j * K + 256 * q + 4 * lane]);
+                    float4 v = dw[j][q];
+                    if (wv_i > 0) {
+                        const float4 o = *dst;
+                        v = make_float4(o.x + v.x, o.y + v.y, o.z + v.z, o.w + v.w);
+                    }
+                    *dst = v;
+                }
+                if (lane == 0) s_w[NO * K + j] = (wv_i > 0 ? s_w[NO * K + j] : 0.f) + db[j];
+            }
+            if (lane == 0) {
+                s_red[0][wave] = pol;
+                s_red[1][wave] = val;
+                s_red[2][wave] = ent;
+            }
+        }
+        __syncthreads();
+    }
+    // (slab stride: the bias block padded to a multiple of 4 floats, pfrl_splitk_reduce reads float4)
+    float *slab = dw_part + (size_t)blockIdx.x * (NO * K + (NO + 3) / 4 * 4);
+    for (int e = tid; e < NO * K + NO; e += 256) slab[e] = s_w[e];
+    if (tid < 3) partial[(size_t)blockIdx.x * 3 + tid] = ((s_red[tid][0] + s_red[tid][1]) + s_red[tid][2]) + s_red[tid][3];
 }
 
 // out[0] = loss, out[1] = loss_policy, out[2] = loss_value, out[3] = mean entropy
@@ -611,6 +760,41 @@ extern "C" int pfrl_ppo_minibatch(int64_t M, const int64_t *idx, const float *ad
     hipLaunchKernelGGL(k_ppo_minibatch, dim3(blocks), dim3(kThreads), 0, (hipStream_t)stream, M,
                        idx, adv, mean_std, standardize, log_prob, v_pred, v_teacher, action,
                        state_refs, k, out_adv, out_logp, out_v, out_vt, out_action, out_refs);
+    PFRL_LAUNCH_CHECK();
+}
+
+extern "C" int pfrl_ppo_head_loss(const float *h, const float *w_policy, const float *b_policy,
+                                  const float *w_value, const float *b_value, const int64_t *action,
+                                  const float *adv, const float *log_prob_old, const float *v_pred_old,
+                                  const float *v_teacher, int32_t M, int32_t K, int32_t A,
+                                  float clip_eps, float clip_eps_vf, float value_func_coef,
+                                  float entropy_coef, float *dh, float *dw_part, int32_t blocks,
+                                  double *partial_ws, float *out4, void *stream) {
+    PFRL_CHECK_ARG(M >= 1 && blocks >= 1 && A >= 1 && A <= 9 && (K == 256 || K == 512),
+                   "pfrl_ppo_head_loss: 1 <= A <= 9, K = 256 or 512");
+    PFRL_CHECK_ARG(h && w_policy && b_policy && w_value && b_value && action && adv && log_prob_old &&
+                       v_teacher && dh && dw_part && partial_ws && out4 && (clip_eps_vf < 0.f || v_pred_old),
+                   "pfrl_ppo_head_loss: null pointer");
+    PFRL_CHECK_ARG((((uintptr_t)h | (uintptr_t)w_policy | (uintptr_t)w_value | (uintptr_t)dh) & 15) == 0,
+                   "pfrl_ppo_head_loss: 16-byte aligned rows");
+    const int rpb = (M + blocks - 1) / blocks;
+#define HL_CALL(AA, KQ)                                                                             \
+    hipLaunchKernelGGL((k_ppo_head_loss<AA, KQ>), dim3((unsigned)blocks), dim3(256), 0,             \
+                       (hipStream_t)stream, h, w_policy, b_policy, w_value, b_value, action, adv,   \
+                       log_prob_old, v_pred_old, v_teacher, M, rpb, clip_eps, clip_eps_vf,          \
+                       value_func_coef, entropy_coef, dh, dw_part, partial_ws)
+#define HL_CASE(AA)                                                                                 \
+    case AA:                                                                                        \
+        if (K == 256) HL_CALL(AA, 1);                                                               \
+        else HL_CALL(AA, 2);                                                                        \
+        break;
+    switch (A) {
+        HL_CASE(1) HL_CASE(2) HL_CASE(3) HL_CASE(4) HL_CASE(5) HL_CASE(6) HL_CASE(7) HL_CASE(8) HL_CASE(9)
+    }
+#undef HL_CASE
+#undef HL_CALL
+    hipLaunchKernelGGL(k_ppo_loss_finish, dim3(1), dim3(64), 0, (hipStream_t)stream, partial_ws, blocks,
+                       M, value_func_coef, entropy_coef, out4);
     PFRL_LAUNCH_CHECK();
 }
 

@@ -470,6 +470,49 @@ def ppo_loss(logits, value, action, adv, log_prob_old, v_pred_old, v_teacher, cl
     return out, dlogits, dvalue.view(value.shape)
 
 
+def ppo_head_loss_ok(h, w_policy):
+    """Shapes the one-launch heads + loss + heads' backward covers (pfrl_ppo_head_loss)."""
+    return (h.is_cuda and h.dim() == 2 and h.dtype == torch.float32 and h.shape[1] in (256, 512)
+            and 1 <= w_policy.shape[0] <= 9)
+
+
+def ppo_head_loss(h, w_policy, b_policy, w_value, b_value, action, adv, log_prob_old, v_pred_old,
+                  v_teacher, clip_eps, clip_eps_vf, value_func_coef, entropy_coef):
+    """The two narrow heads on the body's output h [M, K], PPO._lossfun and the heads' backward in one
+    launch (pfrl_ppo_head_loss) + the fold of the per-workgroup gradient slabs.  Returns (out4 =
+    [loss, loss_policy, loss_value, mean entropy], dh [M, K], (dWp, dbp, dWv, dbv)): backward of the
+    body starts at h with dh; the four head gradients are final."""
+    from pfrl_amd.nn import mfma_trunk as _t
+
+    M, K = h.shape
+    A = w_policy.shape[0]
+    h = h.detach().contiguous()
+    dev = h.device
+    NO = A + 1
+    blocks = min(512, (M + 7) // 8)
+    stride = NO * K + (NO + 3) // 4 * 4
+    dh = torch.empty_like(h)
+    part = torch.empty(blocks * stride, dtype=torch.float32, device=dev)
+    ws = torch.empty(3 * blocks, dtype=torch.float64, device=dev)
+    out = torch.empty(4, dtype=torch.float32, device=dev)
+    check(_native.lib().pfrl_ppo_head_loss(
+        _ptr(h), _ptr(w_policy), _ptr(b_policy), _ptr(w_value), _ptr(b_value), _ptr(action),
+        _ptr(adv.reshape(-1)), _ptr(log_prob_old.reshape(-1)),
+        _ptr(v_pred_old.reshape(-1)) if clip_eps_vf is not None else None, _ptr(v_teacher.reshape(-1)),
+        M, K, A, float(clip_eps), -1.0 if clip_eps_vf is None else float(clip_eps_vf),
+        float(value_func_coef), float(entropy_coef), _ptr(dh), _ptr(part), blocks, _ptr(ws), _ptr(out),
+        _stream()), "ppo_head_loss")
+    dwp = torch.empty_like(w_policy)
+    dbp = torch.empty_like(b_policy)
+    dwv = torch.empty_like(w_value)
+    dbv = torch.empty_like(b_value)
+    _t._reduce([(part, dwp, None, stride, A * K, blocks, 4, 0),
+                (part[A * K:], dwv, None, stride, K, blocks, 4, 0),
+                (part[NO * K:], dbp, None, stride, A, blocks, 1, 0),
+                (part[NO * K + A:], dbv, None, stride, 1, blocks, 1, 0)])
+    return out, dh, (dwp, dbp, dwv, dbv)
+
+
 def ppo_act_head(h, w_policy, b_policy, w_value, b_value, u01, want_log_prob=False, into=None):
     """The two narrow heads of the PPO example network + Categorical sample / entropy in one launch
     (pfrl_ppo_act_head).  h [N, K] f32; returns (action i64 [N], entropy [N], value [N][, log_prob]).

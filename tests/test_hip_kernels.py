@@ -1622,6 +1622,64 @@ def test_fused_ppo_loss_matches_the_reference_expression_and_its_autograd(dev, M
     assert torch.allclose(dlogits, logits.grad, **tol), float((dlogits - logits.grad).abs().max())
 
 
+@pytest.mark.parametrize("clip_eps_vf", [None, 0.2])
+@pytest.mark.parametrize("M,K,A", [(2048, 512, 6), (37, 512, 9), (1, 256, 2), (16384, 512, 6), (4099, 256, 4)])
+def test_ppo_heads_loss_and_heads_backward_in_one_launch(dev, M, K, A, clip_eps_vf):
+    """pfrl_ppo_head_loss against the path it replaces: two nn.Linear heads on h, PPO._lossfun
+    (pfrl/agents/ppo.py:634-671) on ``Categorical(logits=...)`` and autograd down to h and the four
+    head parameters -- loss terms, dh, dWp, dbp, dWv, dbv; ragged row counts included."""
+    from pfrl_amd import ops
+    from pfrl_amd.agents.ppo import PPO
+
+    torch.manual_seed(M + 7 * K + A)
+    h = torch.relu(torch.randn(M, K, device=dev)).requires_grad_(True)
+    pol = torch.nn.Linear(K, A).to(dev)
+    val = torch.nn.Linear(K, 1).to(dev)
+    with torch.no_grad():
+        pol.weight.mul_(0.3)
+    action = torch.randint(0, A, (M,), device=dev)
+    logits, value = pol(h), val(h)
+    with torch.no_grad():
+        lp_now = torch.distributions.Categorical(logits=logits).log_prob(action)
+    shift = torch.randn(M, device=dev) * 0.25
+    shift[::3] = 0.0
+    logp_old = lp_now - shift
+    adv = torch.randn(M, device=dev)
+    adv[::7] = 0.0
+    v_old = value.detach().reshape(-1) + torch.randn(M, device=dev) * 0.3
+    v_teacher = torch.randn(M, device=dev)
+
+    class _A:
+        clip_eps, value_func_coef, entropy_coef = 0.1, 0.7, 0.02
+        value_loss_record = policy_loss_record = None
+
+    _A.clip_eps_vf = clip_eps_vf
+    rec = {}
+    d = torch.distributions.Categorical(logits=logits)
+    want = PPO._lossfun(_A, d.entropy(), value, d.log_prob(action), vs_pred_old=v_old[:, None],
+                        log_probs_old=logp_old, advs=adv, vs_teacher=v_teacher[:, None], records=rec)
+    want.backward()
+    assert ops.ppo_head_loss_ok(h, pol.weight)
+    out4, dh, (dwp, dbp, dwv, dbv) = ops.ppo_head_loss(
+        h, pol.weight, pol.bias, val.weight, val.bias, action, adv, logp_old, v_old, v_teacher,
+        _A.clip_eps, clip_eps_vf, _A.value_func_coef, _A.entropy_coef)
+    assert torch.allclose(out4[0], want.detach(), rtol=1e-5, atol=1e-6)
+    assert torch.allclose(out4[1], rec["policy_loss"].detach(), rtol=1e-5, atol=1e-6)
+    assert torch.allclose(out4[2], rec["value_loss"].detach(), rtol=1e-5, atol=1e-6)
+    assert torch.allclose(out4[3], d.entropy().mean().detach(), rtol=1e-5, atol=1e-6)
+
+    def close(got, ref, what):
+        scale = float(ref.abs().max()) + 1e-12
+        err = float((got - ref).abs().max())
+        assert err <= 2e-5 * scale + 1e-7, (what, err, scale)
+
+    close(dh, h.grad, "dh")
+    close(dwp, pol.weight.grad, "dWp")
+    close(dbp, pol.bias.grad, "dbp")
+    close(dwv, val.weight.grad, "dWv")
+    close(dbv, val.bias.grad, "dbv")
+
+
 @pytest.mark.parametrize("max_norm", [0.5, 1e6])
 def test_clip_grad_norm_in_three_launches_matches_torch(dev, max_norm):
     """pfrl_clip_grad_norm against torch.nn.utils.clip_grad_norm_ (reference ppo.py:602-605) on the
