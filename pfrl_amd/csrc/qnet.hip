@@ -2366,7 +2366,16 @@ extern "C" int pfrl_conv2d_u8nhwc4_fwd(const uint8_t *x, float divisor, const fl
         S == 8 && stride == 4 && !planar_out && ((uintptr_t)x & 3) == 0 &&
         (((uintptr_t)w | (uintptr_t)bias | (uintptr_t)y) & 15) == 0) {
         const int units = (N + 1) / 2 * 5;
-        hipLaunchKernelGGL(k_conv1_u8_direct, dim3(units < 768 ? units : 768), dim3(256), 0, st,
+        // persistent workgroups: three per CU (what their LDS allows) of the current device
+        static thread_local int slots_dev = -1, slots = 768;
+        int devid = 0;
+        if (hipGetDevice(&devid) == hipSuccess && devid != slots_dev) {
+            int cus = 0;
+            if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, devid) == hipSuccess && cus > 0)
+                slots = 3 * cus;
+            slots_dev = devid;
+        }
+        hipLaunchKernelGGL(k_conv1_u8_direct, dim3(units < slots ? units : slots), dim3(256), 0, st,
                            reinterpret_cast<const uint32_t *>(x), w, bias, y, N, relu, a.u8_r, a.u8_d,
                            units);
         PFRL_LAUNCH_CHECK();

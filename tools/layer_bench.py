@@ -104,8 +104,11 @@ def main():
                                                _stream()), "fwd")
 
             def run_dgrad():
-                check(lib.pfrl_conv2d_nhwc_bwd_data(_p(dy), None, _p(w), _p(x), _p(dx), B, H, H, C, Co, R, R,
-                                                    ST, 0, 0, _stream()), "dgrad")
+                # (LAYER_BENCH_NO_MASK=1: without the ReLU mask of the layer below -- what its 4 bytes per
+                # element of extra reads cost)
+                check(lib.pfrl_conv2d_nhwc_bwd_data(_p(dy), None, _p(w),
+                                                    None if os.environ.get("LAYER_BENCH_NO_MASK") else _p(x),
+                                                    _p(dx), B, H, H, C, Co, R, R, ST, 0, 0, _stream()), "dgrad")
 
             splits = wgrad_splits(M, Co, K)
             stride = w.numel() + Co
