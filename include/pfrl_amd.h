@@ -671,15 +671,6 @@ int pfrl_dqn_act_head(const float *h, const float *w, const float *bias, const i
  * rollout and still returns what the reference's second pass over ALL next states
  * (pfrl/agents/ppo.py:119-133) would, pfrl_amd/agents/ppo.py::_next_values_exact. */
 int pfrl_qnet_plan_images(int32_t images);
-/* The ReLU mask of an activation tensor as ONE BIT per element (the backward of
- * torch.nn.functional.relu reads its output only for the sign: pfrl/nn/atari_cnn.py:17-47 under
- * autograd).  `out_bits` (device, ceil(elements / 32) words, or NULL) is taken by the NEXT
- * pfrl_conv2d_nhwc_fwd / pfrl_conv2d_u8nhwc4_fwd launch of this host thread, which must be a
- * row-major ReLU output with Cout % 32 == 0 and then also writes bit e % 32 of word e / 32 =
- * (y[e] > 0); `in_bits` (or NULL) by the next pfrl_conv2d_nhwc_bwd_data launch, which reads the
- * bits where it would read a_prev.  Same mask, same gradients; at 16 384 images the second
- * convolution's input gradient no longer reads 839 MB of first-layer activations for their signs. */
-int pfrl_qnet_relu_bits(void *out_bits, const void *in_bits);
 int pfrl_linear_small_bwd(const float *dy, const float *x, const float *w, float *dx, float *dw,
                           float *db, int32_t M, int32_t K, int32_t N, void *stream);
 

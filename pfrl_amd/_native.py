@@ -216,7 +216,6 @@ EXPORTS = {
     "pfrl_linear_small_bwd": (ctypes.c_int, "ppppppiiip"),
     "pfrl_dqn_act_head": (ctypes.c_int, "pppppppiiip"),
     "pfrl_qnet_plan_images": (ctypes.c_int, "i"),
-    "pfrl_qnet_relu_bits": (ctypes.c_int, "pp"),
     "pfrl_squashed_gaussian_fwd": (ctypes.c_int, "pqpqppppiip"),
     "pfrl_squashed_gaussian_bwd": (ctypes.c_int, "pppppqppiip"),
     "pfrl_squashed_head_fwd": (ctypes.c_int, "pqffippppiip"),

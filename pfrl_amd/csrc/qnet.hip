@@ -92,14 +92,6 @@ __device__ __forceinline__ float4 relu_mask(float4 v, float4 h) {
     return v;
 }
 
-// the ReLU mask of four consecutive elements from the bit form (element o, o % 4 == 0)
-__device__ __forceinline__ float4 relu_mask_bits(float4 v, const uint32_t *bits, size_t o) {
-    const uint32_t nb = bits[o >> 5] >> (unsigned)(o & 31);
-    v.x = (nb & 1u) ? v.x : 0.f; v.y = (nb & 2u) ? v.y : 0.f;
-    v.z = (nb & 4u) ? v.z : 0.f; v.w = (nb & 8u) ? v.w : 0.f;
-    return v;
-}
-
 // U8 operand loaders (the first convolution reading a minibatch of u8 NHWC4 pixels, one dword =
 // the four stacked frames of a pixel, instead of the fp32 copy the gather would write): the
 // feature extractor phi(x) = float32(x) / d (pfrl/utils/batch_states.py:18-36 with the example
@@ -292,9 +284,6 @@ struct FwdArgs {
     // (U8 only) the input as u8 NHWC4 pixels (x is unused), r = fl(1 / d), d: see u8_over
     const uint8_t *xu8 = nullptr;
     float u8_r = 1.f, u8_d = 1.f;
-    // (row-major ReLU outputs) one bit per output element, y > 0, element e -> bit e % 32 of word e / 32:
-    // what the input-gradient kernel of the layer above needs of this tensor (pfrl_qnet_relu_bits)
-    uint32_t *relu_bits = nullptr;
 };
 
 __device__ __forceinline__ float noisy_shaped(float r) {
@@ -522,22 +511,9 @@ __device__ __forceinline__ void fwd_body(const FwdArgs &p, const int bx, const i
         for (int f = tid; f < BM * Q; f += 256) {
             const int row = f / Q, c4 = 4 * (f - row * Q);
             const int m = m0 + row;
-            if (m < p.M) {
-                const float4 v = *reinterpret_cast<const float4 *>(&tile[row * LDT + c4]);
-                *reinterpret_cast<float4 *>(yb + (size_t)m * g.Cout + c4) = v;
-                if (p.relu_bits != nullptr) {
-                    // eight consecutive lanes hold the 32 elements of one word (Cout % 32 == 0, BN % 32 == 0;
-                    // a row's lanes are all active or all not)
-                    const size_t e = (size_t)m * g.Cout + n0 + c4;
-                    uint32_t w = (uint32_t)(v.x > 0.f) | ((uint32_t)(v.y > 0.f) << 1) |
-                                 ((uint32_t)(v.z > 0.f) << 2) | ((uint32_t)(v.w > 0.f) << 3);
-                    w <<= (unsigned)(e & 31);
-                    w |= __shfl_xor(w, 1, 64);
-                    w |= __shfl_xor(w, 2, 64);
-                    w |= __shfl_xor(w, 4, 64);
-                    if ((e & 31) == 0) p.relu_bits[e >> 5] = w;
-                }
-            }
+            if (m < p.M)
+                *reinterpret_cast<float4 *>(yb + (size_t)m * g.Cout + c4) =
+                    *reinterpret_cast<const float4 *>(&tile[row * LDT + c4]);
         }
         return;
     }
@@ -627,8 +603,7 @@ constexpr int D1_NQ = (D1_BAND_UNITS + 255) / 256;        // raw dwords per thre
 
 __global__ __launch_bounds__(256, 3) void k_conv1_u8_direct(
     const uint32_t *__restrict__ x, const float *__restrict__ w, const float *__restrict__ bias,
-    float *__restrict__ y, int N, int relu, float u8_r, float u8_d, int units,
-    uint16_t *__restrict__ bits16) {
+    float *__restrict__ y, int N, int relu, float u8_r, float u8_d, int units) {
     __shared__ float4 band[2 * D1_BAND_UNITS];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = wave & 1, ub = wave >> 1;            // channel half, which of the two bands
@@ -728,18 +703,6 @@ __global__ __launch_bounds__(256, 3) void k_conv1_u8_direct(
                                        acc[u][3] + bias_v.w);
                 if (relu) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
                 *reinterpret_cast<float4 *>(yo + (size_t)(16 * (j0 + u)) * 32) = v;
-                if (bits16 != nullptr) {
-                    // (pfrl_qnet_relu_bits) a pixel is one word; this wave holds 16 of its channels: the four
-                    // kq lanes' nibbles folded into a half word
-                    uint32_t w = (uint32_t)(v.x > 0.f) | ((uint32_t)(v.y > 0.f) << 1) |
-                                 ((uint32_t)(v.z > 0.f) << 2) | ((uint32_t)(v.w > 0.f) << 3);
-                    w <<= 4 * kq;
-                    w |= __shfl_xor(w, 16, 64);
-                    w |= __shfl_xor(w, 32, 64);
-                    if (kq == 0)
-                        bits16[((size_t)img * (D1_O * D1_O) + bnd * 4 * D1_O + 16 * (j0 + u) + i) * 2 + half] =
-                            (uint16_t)w;
-                }
             }
         };
         tiles(std::integral_constant<int, 2>{}, 0);
@@ -766,8 +729,6 @@ struct DgradArgs {
     int permP, permC;    // dx written as [n][p][c] for c*P + p (planar -> NHWC), 0 = off
     FastDiv q_ahw, q_aw, q_st, q_permP;   // by AH * AW, AW, ST, permP
     FastDiv q_c;                          // by C (the class of a merged column)
-    // (optional) the ReLU mask of the layer below as one bit per element instead of the tensor itself
-    const uint32_t *aprev_bits = nullptr;
 };
 
 // MERGE: the ST x ST stride-parity classes of a strided convolution side by side in the tile's
@@ -946,8 +907,7 @@ __device__ __forceinline__ void dgrad_body(const DgradArgs &p, const int bx, con
             const int ih = a * g.ST + eph, iw = a2 * g.ST + epw;
             const size_t o = ((size_t)(n * g.H + ih) * g.W + iw) * g.C + ec;
             float4 v = *reinterpret_cast<const float4 *>(&tile[row * LDT + c4]);
-            if (p.aprev_bits != nullptr) v = relu_mask_bits(v, p.aprev_bits, o);
-            else if (p.aprev != nullptr) v = relu_mask(v, *reinterpret_cast<const float4 *>(p.aprev + o));
+            if (p.aprev != nullptr) v = relu_mask(v, *reinterpret_cast<const float4 *>(p.aprev + o));
             *reinterpret_cast<float4 *>(p.dx + o) = v;
         }
         return;
@@ -968,9 +928,7 @@ __device__ __forceinline__ void dgrad_body(const DgradArgs &p, const int bx, con
                 const int ci = n0 + wn * 16 * AN + 16 * an + (lane & 15);
                 if (ci >= g.C) continue;
                 float v = acc[am][an][0][reg];
-                if (p.aprev_bits != nullptr)
-                    v = ((p.aprev_bits[(base + ci) >> 5] >> (unsigned)((base + ci) & 31)) & 1u) ? v : 0.f;
-                else if (p.aprev != nullptr) v = p.aprev[base + ci] > 0.f ? v : 0.f;
+                if (p.aprev != nullptr) v = p.aprev[base + ci] > 0.f ? v : 0.f;
                 size_t o = base + ci;
                 if (p.permP > 0) {
                     const int c = fdiv(ci, p.q_permP), px = ci - c * p.permP;
@@ -1154,8 +1112,7 @@ __device__ __forceinline__ void dgrad_pos_body(const DgradArgs &p, const int img
         }
         const size_t o = ((size_t)(n * g.H + ih) * g.W + iw) * g.C + ec;
         float4 v = *reinterpret_cast<const float4 *>(&tile[row * LDT + c4]);
-        if (p.aprev_bits != nullptr) v = relu_mask_bits(v, p.aprev_bits, o);
-        else if (p.aprev != nullptr) v = relu_mask(v, *reinterpret_cast<const float4 *>(p.aprev + o));
+        if (p.aprev != nullptr) v = relu_mask(v, *reinterpret_cast<const float4 *>(p.aprev + o));
         *reinterpret_cast<float4 *>(p.dx + o) = v;
     }
 }
@@ -2225,27 +2182,6 @@ extern "C" int pfrl_qnet_plan_images(int32_t images) {
     return 0;
 }
 
-// The ReLU mask of an activation tensor as one bit per element (pfrl_qnet_relu_bits): `out` is
-// taken -- and cleared -- by the NEXT forward launch of this host thread (row-major ReLU output with
-// Cout % 32 == 0: it also writes bit e % 32 of word e / 32 = y[e] > 0), `in` by the next
-// pfrl_conv2d_nhwc_bwd_data launch, which then reads the bits where it would read a_prev (4 bytes per
-// element of dx: at 16 384 images the second convolution's input gradient reads 839 MB of first-layer
-// activations for their signs alone).  Same mask, same gradients.
-static thread_local uint32_t *g_relu_bits_out = nullptr;
-static thread_local const uint32_t *g_relu_bits_in = nullptr;
-
-extern "C" int pfrl_qnet_relu_bits(void *out_bits, const void *in_bits) {
-    PFRL_CHECK_ARG((((uintptr_t)out_bits | (uintptr_t)in_bits) & 3) == 0, "pfrl_qnet_relu_bits: 4-byte aligned");
-    g_relu_bits_out = static_cast<uint32_t *>(out_bits);
-    g_relu_bits_in = static_cast<const uint32_t *>(in_bits);
-    return 0;
-}
-static uint32_t *take_relu_bits_out() {
-    uint32_t *p = g_relu_bits_out;
-    g_relu_bits_out = nullptr;
-    return p;
-}
-
 // rows the tile program is chosen for: the call's own, or the planned batch's if that is larger
 static long long plan_rows(long long M, int images) {
     if (g_plan_images <= images || images <= 0) return M;
@@ -2372,9 +2308,6 @@ extern "C" int pfrl_conv2d_nhwc_fwd(const float *x, const float *w, const float 
     a.cps = (nch + splits - 1) / splits;
     a.relu = relu; a.planar = planar_out; a.partial = splits > 1;
     PFRL_CHECK_ARG(a.partial || bias != nullptr, "pfrl_conv2d_nhwc_fwd: bias required");
-    a.relu_bits = take_relu_bits_out();
-    PFRL_CHECK_ARG(a.relu_bits == nullptr || (relu && !planar_out && !a.partial && Cout % 32 == 0),
-                   "pfrl_conv2d_nhwc_fwd: ReLU bits need a row-major ReLU output with Cout % 32 == 0");
     hipStream_t st = (hipStream_t)stream;
     const unsigned z = (unsigned)splits;
 #define FWD(BM, BN, WM, WN, WK, G)                                                                   \
@@ -2424,9 +2357,6 @@ extern "C" int pfrl_conv2d_u8nhwc4_fwd(const uint8_t *x, float divisor, const fl
     a.K = R * S * 4;
     a.cps = a.K / KC;
     a.relu = relu; a.planar = planar_out; a.partial = 0;
-    a.relu_bits = take_relu_bits_out();
-    PFRL_CHECK_ARG(a.relu_bits == nullptr || (relu && !planar_out && Cout % 32 == 0),
-                   "pfrl_conv2d_u8nhwc4_fwd: ReLU bits need a row-major ReLU output with Cout % 32 == 0");
     hipStream_t st = (hipStream_t)stream;
     const int prog = fwd_program(a, Cout, 1, plan_rows(a.M, N));
     // the Nature first layer wherever a one-accumulator tile program would run: the direct kernel
@@ -2447,7 +2377,7 @@ extern "C" int pfrl_conv2d_u8nhwc4_fwd(const uint8_t *x, float divisor, const fl
         }
         hipLaunchKernelGGL(k_conv1_u8_direct, dim3(units < slots ? units : slots), dim3(256), 0, st,
                            reinterpret_cast<const uint32_t *>(x), w, bias, y, N, relu, a.u8_r, a.u8_d,
-                           units, reinterpret_cast<uint16_t *>(a.relu_bits));
+                           units);
         PFRL_LAUNCH_CHECK();
     }
 #define FWDU(BM, BN, WM, WN, WK, G)                                                                  \
@@ -2580,10 +2510,6 @@ extern "C" int pfrl_conv2d_nhwc_bwd_data(const float *dy, const float *dy_mask, 
     if (int rc = make_dgrad_args(a, dy, dy_mask, w, a_prev, dx, N, H, W, C, Cout, R, S, stride, perm_p,
                                  perm_c))
         return rc;
-    a.aprev_bits = g_relu_bits_in;      // (pfrl_qnet_relu_bits: the mask of a_prev in bit form)
-    g_relu_bits_in = nullptr;
-    PFRL_CHECK_ARG(a.aprev_bits == nullptr || a_prev != nullptr,
-                   "pfrl_conv2d_nhwc_bwd_data: ReLU bits without a layer below to mask by");
     hipStream_t st = (hipStream_t)stream;
     const unsigned z = (unsigned)(stride * stride);
 #define DG(BM, BN, WM, WN, WK, G)                                                                    \

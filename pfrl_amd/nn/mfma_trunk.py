@@ -235,13 +235,6 @@ _WGRAD_MAX_SPLITS = int(os.environ.get("PFRL_WGRAD_MAX_SPLITS", "4096"))
 
 
 _FUSE_BWD = os.environ.get("PFRL_FUSE_BWD", "1") != "0"
-# ReLU masks as bits between the forward and the input-gradient launches (see _Trunk.forward).
-# Measured and NOT the default (PFRL_TRUNK_RELU_BITS=1 turns it on): bit-identical, the input-gradient
-# launches alone get 6-11 % shorter at 16 384 images (conv2 1 077 -> 967 us: 839 MB of reads less), but
-# PPO's update as a whole does not move (five alternations on one box: 149.6 vs 151.7 ms) -- the
-# launches around them give the time back (profiles/r06_relu_bits.txt).
-_RELU_BITS = os.environ.get("PFRL_TRUNK_RELU_BITS", "0") == "1"
-_RELU_BITS_MIN_BATCH = int(os.environ.get("PFRL_TRUNK_RELU_BITS_MIN_BATCH", "1024"))
 
 
 def _fused_bwd_ok(N, H, W, C, ST):
@@ -467,22 +460,11 @@ class _Trunk(torch.autograd.Function):
         acts = []
         h = x
         nhwc_fc = len(params) > 2 * L and 0 < _NHWC_FC_MIN_BATCH <= max(N, _PLAN_BATCH)
-        # rollout- / update-sized batches under autograd: every convolution's ReLU mask also leaves its
-        # forward launch as one bit per element, and the input gradient of the layer above reads the
-        # bits instead of the activation tensor (pfrl_qnet_relu_bits: 4 bytes per element of dx less)
-        want_bits = _RELU_BITS and N >= _RELU_BITS_MIN_BATCH and any(ctx.needs_input_grad[2:])
-        bits = []
         for i, sp in enumerate(specs):
             fwd = conv_fwd_u8 if (u8 and i == 0) else conv_fwd
-            planar = i == L - 1 and not nhwc_fc
-            b_i = None
-            if want_bits and not planar and sp.Cout % 32 == 0 and (i < L - 1 or nhwc_fc):
-                b_i = torch.empty((N * sp.OH * sp.OW * sp.Cout + 31) // 32, dtype=torch.int32,
-                                  device=h.data.device if u8 and i == 0 else h.device)
-                check(_native.lib().pfrl_qnet_relu_bits(_p(b_i), None), "qnet_relu_bits")
-            h = fwd(h, params[2 * i], params[2 * i + 1], sp, N, relu=True, planar=planar)
+            h = fwd(h, params[2 * i], params[2 * i + 1], sp, N, relu=True,
+                    planar=(i == L - 1 and not nhwc_fc))
             acts.append(h)
-            bits.append(b_i)
         wp = None
         if len(params) == 2 * L:
             # convolutions only: the planar (NCHW) output of the last one, as [N, Cout, OH, OW]
@@ -498,7 +480,6 @@ class _Trunk(torch.autograd.Function):
             ctx.specs = specs
             ctx.nhwc_fc = nhwc_fc
             ctx.u8_divisor = x.divisor if u8 else None
-            ctx.relu_bits = bits
             ctx.save_for_backward(x.data if u8 else x, out, *acts, *params,
                                   *([wp] if nhwc_fc else []))
         return out
@@ -539,7 +520,6 @@ class _Trunk(torch.autograd.Function):
             # being loaded beside dh by both gradient kernels: at this size the second operand
             # stream costs each of them more than the extra launch)
             dhm = torch.ops.aten.threshold_backward(dh, out, 0.0)
-            _mask_bits(ctx, L - 1)
             check(lib.pfrl_conv2d_nhwc_bwd_data(_p(dhm), None, _p(wp), _p(acts[-1]), _p(dy), N, 1, 1,
                                                 Kf, F, 1, 1, 1, 0, 0, _stream()), "linear_bwd_data")
             dwp = torch.empty_like(wp)
@@ -720,7 +700,6 @@ class _Trunk(torch.autograd.Function):
                                                   _stream()), "conv2d_nhwc_bwd_weight")
             if i > 0:
                 dx = torch.empty((N, sp.H, sp.W, sp.C), dtype=torch.float32, device=dev)
-                _mask_bits(ctx, i - 1)
                 check(lib.pfrl_conv2d_nhwc_bwd_data(_p(dy), None, _p(w), _p(below), _p(dx), N, sp.H,
                                                     sp.W, sp.C, sp.Cout, sp.R, sp.S, sp.ST, 0, 0,
                                                     _stream()), "conv2d_nhwc_bwd_data")
@@ -731,14 +710,6 @@ class _Trunk(torch.autograd.Function):
         if tasks:
             _reduce(tasks)
         return (None, None) + tuple(grads)
-
-
-def _mask_bits(ctx, layer):
-    """Hand the bit form of layer ``layer``'s ReLU mask (written by its forward launch) to the next
-    input-gradient launch, if the forward pass kept one."""
-    bits = getattr(ctx, "relu_bits", None)
-    if bits and bits[layer] is not None:
-        check(_native.lib().pfrl_qnet_relu_bits(None, _p(bits[layer])), "qnet_relu_bits")
 
 
 def _after_ride(carry, rode):

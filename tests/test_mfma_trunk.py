@@ -658,35 +658,3 @@ def test_trunk_on_u8_pixels_equals_the_trunk_on_the_fp32_minibatch():
     # a plain (unfused) network takes the pixels as the fp32 tensor they stand for
     px = ops.batch_states_raw_nhwc4(frames, refs[:8], 255.0)
     assert torch.equal(px.float(), ops.batch_states_nhwc4(frames, refs[:8], 255.0))
-
-
-@gpu
-@pytest.mark.parametrize("N", [1024, 2051])
-def test_relu_masks_as_bits_give_the_same_gradients(N, monkeypatch):
-    """pfrl_qnet_relu_bits: the forward launches of a rollout-sized batch also write each
-    convolution's ReLU mask as one bit per element and the input-gradient launches read the bits
-    instead of the activation tensors -- output and EVERY parameter gradient bit for bit what the
-    tensor-reading route gives (u8 pixels -> direct first layer included; odd batch: ragged tiles)."""
-    from pfrl_amd import ops
-
-    dev = torch.device("cuda:0")
-    frames = _u8_frames(dev, seed=N)
-    refs = torch.randint(0, 300, (N, 4), dtype=torch.int32, device=dev)
-    px = ops.batch_states_raw_nhwc4(frames, refs, 255.0)
-    torch.manual_seed(5)
-    net = nn.Sequential(nn.Conv2d(4, 32, 8, stride=4), nn.ReLU(), nn.Conv2d(32, 64, 4, stride=2),
-                        nn.ReLU(), nn.Conv2d(64, 64, 3), nn.ReLU(), nn.Flatten(),
-                        nn.Linear(3136, 512), nn.ReLU())
-    net = net.to(dev).to(memory_format=torch.channels_last)
-    pfrl_amd.nn.fuse_sequential_trunk(net)
-    g = torch.randn(N, 512, device=dev)
-    grads = {}
-    for on in (True, False):
-        monkeypatch.setattr(mt, "_RELU_BITS", on)
-        net.zero_grad(set_to_none=True)
-        out = net(px)
-        out.backward(g)
-        grads[on] = [out.detach().clone()] + [p.grad.detach().clone() for p in net.parameters()]
-    for a, b in zip(grads[True], grads[False]):
-        assert torch.equal(a, b)
-    assert float(grads[True][1].abs().max()) > 0
