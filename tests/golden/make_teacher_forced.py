@@ -12,7 +12,7 @@ on -- the online and target parameters BEFORE the update and the minibatch ``exp
 computed.  A test can then load exactly that state into the device path and compare that one
 number at the north-star tolerance (1e-5), wherever in the trajectory it sits.
 
-Output: tests/golden/teacher_forced_{dqn_uniform_n1,ddqn_per_n3,c51_per_n3,ppo,sac,td3,iqn_per_n3,a2c}.npz
+Output: tests/golden/teacher_forced_{dqn_uniform_n1,ddqn_per_n3,c51_per_n3,ppo,sac,td3,ddpg,iqn_per_n3,a2c}.npz
 """
 import os
 import sys
@@ -355,6 +355,67 @@ def td3(steps=260, N=2, obs_dim=24, act_dim=3):
                                      float(out.get("u%d_policy_loss" % k, np.nan))) for k in TD3_UPDATES})
 
 
+def ddpg(steps=260, N=2, obs_dim=24, act_dim=3):
+    """The reference's DDPG run of agent_trace_ddpg.npz again (asserted: same losses), recording
+    for updates TD3_UPDATES what one ``update`` (pfrl/agents/ddpg.py:150-200) depends on -- policy,
+    Q-function and their two targets before it, and the minibatch -- and both losses: the critic's,
+    and the actor's evaluated as the reference does, AFTER the critic's step."""
+    import tempfile
+
+    import pfrl
+    from pfrl import agents, experiments, explorers, replay_buffers
+
+    sys.path.insert(0, os.path.join(HERE, "..", ".."))
+    from pfrl_amd.envs.synthetic import HostSyntheticVectorObsEnv
+
+    pfrl.utils.set_random_seed(0)
+    env = HostSyntheticVectorObsEnv(N, obs_dim=obs_dim, act_dim=act_dim, seed=4, p_done=0.03)
+    torch.manual_seed(2468)
+    policy, q = mg._det_nets(obs_dim, act_dim, pfrl.nn, pfrl.policies)
+    q1 = q()
+    opts = [torch.optim.SGD(m.parameters(), lr=1e-2) for m in (policy, q1)]
+    ag = agents.DDPG(policy, q1, opts[0], opts[1], replay_buffers.ReplayBuffer(500), gamma=0.99,
+                     explorer=explorers.AdditiveGaussian(scale=0.1, low=-1.0, high=1.0), gpu=-1,
+                     replay_start_size=40, minibatch_size=16, update_interval=1,
+                     target_update_interval=7, target_update_method="soft", soft_update_tau=5e-2,
+                     burnin_action_func=lambda: np.random.uniform(-1, 1, size=act_dim).astype(np.float32))
+    flat = lambda m: np.concatenate([p.detach().numpy().ravel() for p in m.parameters()])  # noqa: E731
+    out, losses = {}, []
+    count = [0]
+    orig_c, orig_a = ag.compute_critic_loss, ag.compute_actor_loss
+
+    def spy_c(batch):
+        count[0] += 1
+        k = count[0]
+        if k in TD3_UPDATES:
+            for name, m in (("policy", policy), ("q", q1), ("tpolicy", ag.target_policy),
+                            ("tq", ag.target_q_function)):
+                out["u%d_%s_params" % (k, name)] = flat(m)
+            for key in ("state", "action", "reward", "next_state", "is_state_terminal", "discount"):
+                out["u%d_%s" % (k, key)] = batch[key].detach().numpy().copy()
+        loss = orig_c(batch)
+        if k in TD3_UPDATES:
+            out["u%d_critic_loss" % k] = np.asarray(float(loss))
+        return loss
+
+    def spy_a(batch):
+        k = count[0]
+        loss = orig_a(batch)
+        if k in TD3_UPDATES:
+            out["u%d_actor_loss" % k] = np.asarray(float(loss))
+        losses.append([ag.critic_loss_record[-1], ag.actor_loss_record[-1]])
+        return loss
+
+    ag.compute_critic_loss, ag.compute_actor_loss = spy_c, spy_a
+    experiments.train_agent_batch(ag, env, steps, tempfile.mkdtemp())
+    g = np.load(os.path.join(HERE, "agent_trace_ddpg.npz"))
+    assert np.array_equal(np.asarray(losses), g["losses"]), "not the run of agent_trace_ddpg"
+    out["updates"] = np.asarray(TD3_UPDATES)
+    np.savez_compressed(os.path.join(HERE, "teacher_forced_ddpg.npz"), **out)
+    print("teacher_forced ddpg", {k: (float(out["u%d_critic_loss" % k]), float(out["u%d_actor_loss" % k]))
+                                  for k in TD3_UPDATES})
+
+
 A2C_UPDATES = {True: (1, 12, 30), False: (1, 30)}
 
 
@@ -523,3 +584,4 @@ if __name__ == "__main__":
     c51()
     iqn()
     a2c()
+    ddpg()
