@@ -601,9 +601,16 @@ constexpr int D1_HW = 84, D1_O = 20, D1_BAND_ROWS = 20, D1_AS = 21, D1_RS = 84;
 constexpr int D1_BAND_UNITS = D1_BAND_ROWS * D1_RS;       // float4 units of one staged band
 constexpr int D1_NQ = (D1_BAND_UNITS + 255) / 256;        // raw dwords per thread and band
 
+// U8 = false: the same kernel on the fp32 NHWC4 minibatch (a pixel = one float4; DQN's acting and target
+// passes, pfrl_conv2d_nhwc_fwd): nothing to convert, and the pixels of a unit are loaded at the top of
+// its own step instead of a step ahead (14 float4 per thread would not fit beside the fragments at
+// three waves per SIMD; the other workgroups of the CU cover the load).
+template <bool U8>
 __global__ __launch_bounds__(256, 3) void k_conv1_u8_direct(
-    const uint32_t *__restrict__ x, const float *__restrict__ w, const float *__restrict__ bias,
+    const void *__restrict__ xin, const float *__restrict__ w, const float *__restrict__ bias,
     float *__restrict__ y, int N, int relu, float u8_r, float u8_d, int units) {
+    using Raw = typename std::conditional<U8, uint32_t, float4>::type;
+    const Raw *__restrict__ x = static_cast<const Raw *>(xin);
     __shared__ float4 band[2 * D1_BAND_UNITS];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = wave & 1, ub = wave >> 1;            // channel half, which of the two bands
@@ -634,13 +641,13 @@ __global__ __launch_bounds__(256, 3) void k_conv1_u8_direct(
         ssrc[q] = d;
         sdst[q] = rr * D1_RS + (px & 3) * D1_AS + (px >> 2);
     }
-    uint32_t raw[2][D1_NQ];
+    Raw raw[2][D1_NQ];
     auto fetch = [&](int unit) {
         const int pair = unit / 5, bnd = unit - 5 * pair;
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
             const int img = min(2 * pair + b, N - 1);
-            const uint32_t *src = x + (size_t)img * (D1_HW * D1_HW) + bnd * 16 * D1_HW;
+            const Raw *src = x + (size_t)img * (D1_HW * D1_HW) + bnd * 16 * D1_HW;
 #pragma unroll
             for (int q = 0; q < D1_NQ; ++q) raw[b][q] = src[ssrc[q]];
         }
@@ -650,14 +657,30 @@ __global__ __launch_bounds__(256, 3) void k_conv1_u8_direct(
     // [14 loads, 5 stores] in flight: the compiler's vmcnt for "this thread's pixels have landed" then
     // does not also wait for the previous unit's stores to be acknowledged.
     auto step = [&](const int unit) {
+        if constexpr (U8) {
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+            for (int b = 0; b < 2; ++b)
 #pragma unroll
-            for (int q = 0; q < D1_NQ; ++q)
-                if (tid + 256 * q < D1_BAND_UNITS)
-                    band[b * D1_BAND_UNITS + sdst[q]] = u8x4_over(raw[b][q], u8_r, u8_d);
+                for (int q = 0; q < D1_NQ; ++q)
+                    if (tid + 256 * q < D1_BAND_UNITS)
+                        band[b * D1_BAND_UNITS + sdst[q]] = u8x4_over(raw[b][q], u8_r, u8_d);
+        } else {
+            // (band by band: seven float4 in flight per thread, not fourteen)
+            const int pair = unit / 5, bnd = unit - 5 * pair;
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const int img = min(2 * pair + b, N - 1);
+                const Raw *src = x + (size_t)img * (D1_HW * D1_HW) + bnd * 16 * D1_HW;
+                Raw r[D1_NQ];
+#pragma unroll
+                for (int q = 0; q < D1_NQ; ++q) r[q] = src[ssrc[q]];
+#pragma unroll
+                for (int q = 0; q < D1_NQ; ++q)
+                    if (tid + 256 * q < D1_BAND_UNITS) band[b * D1_BAND_UNITS + sdst[q]] = r[q];
+            }
+        }
         __syncthreads();
-        fetch(min(unit + (int)gridDim.x, units - 1));
+        if constexpr (U8) fetch(min(unit + (int)gridDim.x, units - 1));
         const int pair = unit / 5, bnd = unit - 5 * pair;
         // (an odd batch: the last unit's second band repeats the last image -- fetch() clamps the same
         // way -- and both waves store the same values to the same rows; unconditional stores also let
@@ -712,9 +735,22 @@ __global__ __launch_bounds__(256, 3) void k_conv1_u8_direct(
     };
     int unit = blockIdx.x;
     if (unit >= units) return;
-    fetch(unit);
+    if constexpr (U8) fetch(unit);
     step(unit);
     for (unit += gridDim.x; unit < units; unit += gridDim.x) step(unit);
+}
+
+// persistent workgroups of the direct forward kernel: three per CU (what their LDS allows)
+static int conv1_direct_slots() {
+    static thread_local int slots_dev = -1, slots = 768;
+    int devid = 0;
+    if (hipGetDevice(&devid) == hipSuccess && devid != slots_dev) {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, devid) == hipSuccess && cus > 0)
+            slots = 3 * cus;
+        slots_dev = devid;
+    }
+    return slots;
 }
 
 // ---------------------------------------------------------------------------------
@@ -2310,6 +2346,19 @@ extern "C" int pfrl_conv2d_nhwc_fwd(const float *x, const float *w, const float 
     PFRL_CHECK_ARG(a.partial || bias != nullptr, "pfrl_conv2d_nhwc_fwd: bias required");
     hipStream_t st = (hipStream_t)stream;
     const unsigned z = (unsigned)splits;
+    {
+        // the Nature first layer on the fp32 NHWC4 minibatch wherever a one-accumulator tile program
+        // would run (the acting and target passes of the replay agents): the direct kernel, same bits
+        const int prog = fwd_program(a, Cout, z, plan_rows(a.M, N));
+        if ((prog == 3 || prog == 8) && splits == 1 && C == 4 && H == D1_HW && W == D1_HW && Cout == 32 &&
+            R == 8 && S == 8 && stride == 4 && !planar_out && prog_override("PFRL_CONV1_DIRECT") != 0 &&
+            (((uintptr_t)x | (uintptr_t)w | (uintptr_t)bias | (uintptr_t)y) & 15) == 0) {
+            const int units = (N + 1) / 2 * 5, slots = conv1_direct_slots();
+            hipLaunchKernelGGL(k_conv1_u8_direct<false>, dim3(units < slots ? units : slots), dim3(256), 0,
+                               st, static_cast<const void *>(x), w, bias, y, N, relu, 1.f, 1.f, units);
+            PFRL_LAUNCH_CHECK();
+        }
+    }
 #define FWD(BM, BN, WM, WN, WK, G)                                                                   \
     hipLaunchKernelGGL((k_conv_fwd<BM, BN, WM, WN, WK, G>),                                          \
                        dim3((a.M + BM - 1) / BM, (Cout + BN - 1) / BN, z), dim3(256), 0, st, a)
@@ -2365,19 +2414,9 @@ extern "C" int pfrl_conv2d_u8nhwc4_fwd(const uint8_t *x, float divisor, const fl
     if (direct != 0 && (prog == 3 || prog == 8) && H == D1_HW && W == D1_HW && Cout == 32 && R == 8 &&
         S == 8 && stride == 4 && !planar_out && ((uintptr_t)x & 3) == 0 &&
         (((uintptr_t)w | (uintptr_t)bias | (uintptr_t)y) & 15) == 0) {
-        const int units = (N + 1) / 2 * 5;
-        // persistent workgroups: three per CU (what their LDS allows) of the current device
-        static thread_local int slots_dev = -1, slots = 768;
-        int devid = 0;
-        if (hipGetDevice(&devid) == hipSuccess && devid != slots_dev) {
-            int cus = 0;
-            if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, devid) == hipSuccess && cus > 0)
-                slots = 3 * cus;
-            slots_dev = devid;
-        }
-        hipLaunchKernelGGL(k_conv1_u8_direct, dim3(units < slots ? units : slots), dim3(256), 0, st,
-                           reinterpret_cast<const uint32_t *>(x), w, bias, y, N, relu, a.u8_r, a.u8_d,
-                           units);
+        const int units = (N + 1) / 2 * 5, slots = conv1_direct_slots();
+        hipLaunchKernelGGL(k_conv1_u8_direct<true>, dim3(units < slots ? units : slots), dim3(256), 0, st,
+                           static_cast<const void *>(x), w, bias, y, N, relu, a.u8_r, a.u8_d, units);
         PFRL_LAUNCH_CHECK();
     }
 #define FWDU(BM, BN, WM, WN, WK, G)                                                                  \

@@ -587,7 +587,7 @@ def test_raw_nhwc4_gather_holds_the_four_frames_of_each_pixel():
 
 @gpu
 @pytest.mark.parametrize("N", [16, 32, 64, 333, 512, 1001, 5300])
-def test_first_convolution_on_u8_pixels_is_bit_identical_to_the_fp32_minibatch(N):
+def test_first_convolution_on_u8_pixels_is_bit_identical_to_the_fp32_minibatch(N, monkeypatch):
     """VERDICT r4 next #4's gate: conv1 forward and weight gradient reading the u8 NHWC4
     minibatch (phi in the operand loader) == the same entries on the gathered fp32 minibatch,
     bit for bit, in every tile program the u8 entries have (forward 32 x 32 / 64 x 32 / 128 x 32,
@@ -609,6 +609,16 @@ def test_first_convolution_on_u8_pixels_is_bit_identical_to_the_fp32_minibatch(N
             want = mt.conv_fwd(x32, conv.weight, conv.bias, sp, N, relu=True, planar=planar)
             got = mt.conv_fwd_u8(px, conv.weight, conv.bias, sp, N, relu=True, planar=planar)
             assert torch.equal(got, want), planar
+        # from ~164 images both entries run the direct-form kernels (csrc/qnet.hip k_conv1_u8_direct<U8>):
+        # against the tile programs they replace (PFRL_CONV1_DIRECT=0, read per call), with and without ReLU
+        for relu in (True, False):
+            monkeypatch.setenv("PFRL_CONV1_DIRECT", "0")
+            tiles = mt.conv_fwd(x32, conv.weight, conv.bias, sp, N, relu=relu)
+            tiles_u8 = mt.conv_fwd_u8(px, conv.weight, conv.bias, sp, N, relu=relu)
+            monkeypatch.delenv("PFRL_CONV1_DIRECT")
+            assert torch.equal(mt.conv_fwd(x32, conv.weight, conv.bias, sp, N, relu=relu), tiles)
+            assert torch.equal(mt.conv_fwd_u8(px, conv.weight, conv.bias, sp, N, relu=relu), tiles_u8)
+            assert torch.equal(tiles, tiles_u8)
     else:
         assert not mt.u8_first_layer_ok(conv, px)        # (under 384 tiles: the fp32 path)
     # weight gradient: partial slabs, as _Trunk._conv_backward asks for them

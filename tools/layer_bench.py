@@ -163,6 +163,14 @@ def main():
                     rows.append(("wgrad/%d(%s)" % (sp, pair), time_us(run_w2, args.iters), flop,
                                  bx + by + sp * stride * 4))
                     del part2
+            if name == "conv1" and B >= 256 and "fwd" in only:
+                # the fp32 form of the direct kernel (DQN's acting / target passes) beside its tile program
+                os.environ["PFRL_CONV1_DIRECT"] = "0"
+                t_tiles = time_us(run_fwd, args.iters)
+                os.environ.pop("PFRL_CONV1_DIRECT")
+                tf = flop / t_tiles * 1e-6
+                print("%-6s %-16s %6d %10.1f %9.2f %8.1f %6.3f %9.1f" % (
+                    name, "fwd (f32, tiles)", B, t_tiles, flop * 1e-9, tf, tf / PEAK_TF, (bx + by + bw) / HBM_TBS * 1e-6))
             if name == "conv1" and B >= 64:
                 # the forms PPO runs since round 5: the layer reads u8 NHWC4 pixels itself
                 px = torch.randint(0, 256, (B, H, H, 4), dtype=torch.uint8, device=dev)
