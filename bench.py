@@ -291,6 +291,13 @@ def run_workload(args, device, rank, world, result_extras=True):
     for _ in range(args.warmup):
         _tick("warm-up %s" % args.algo)
         obss = one_step(agent, env, obss, N)
+    # (everything allocated so far -- networks, graphs, staging rings -- moved out of the collector's
+    # generations: a full collection over them landing in the timed region is a ~10 ms host pause,
+    # seen once as a 34 ms instead of a 22.5 ms acting phase of the PPO leg.  The collector stays on.)
+    import gc
+
+    gc.collect()
+    gc.freeze()
 
     def updates_done():
         for name in ("optim_t", "n_updates", "n_policy_updates"):
